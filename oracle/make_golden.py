@@ -1,0 +1,160 @@
+"""Generate golden fixtures under tests/golden/ by running the REFERENCE itself (build container only).
+
+    python oracle/make_golden.py            # needs /root/reference; never runs on the GPU box
+
+The reference (`/root/reference/model/VSLNet_t7.py`, `layers_t7.py`, `util/*_t7.py`) is imported read-only
+with one caller-side shim (`transformers.AdamW` no longer exists in transformers 5.x, VSLNet_t7.py:5).
+What is written is DATA only: inputs, per-key checksums of the `state_dict` (weights are re-derived from a seed), the outputs of every sub-module on the
+forward path (forward hooks), h_score / logits, both losses, every parameter gradient of
+`loc + 5.0 * highlight`, and `extract_index`.  No reference source or bytecode is copied.
+"""
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+REF = '/root/reference'
+
+from oracle import vslnet_oracle as O  # noqa: E402
+
+
+def load_reference():
+    import transformers
+    if not hasattr(transformers, 'AdamW'):
+        transformers.AdamW = torch.optim.AdamW          # VSLNet_t7.py:5 import shim (reference untouched)
+    sys.path.insert(0, REF)
+    from model.VSLNet_t7 import VSLNet                   # noqa
+    from util import runner_utils_t7, data_loader_t7    # noqa
+    return VSLNet, runner_utils_t7, data_loader_t7
+
+
+CASES = {
+    # name: (cfg overrides, B, T, Lq, Lc, ragged)
+    'tiny_tf':  (dict(video_feature_dim=64, max_pos_len=32, word_size=52), 3, 24, 7, 6, True),
+    'tiny_rnn': (dict(video_feature_dim=64, max_pos_len=32, word_size=52, predictor='rnn'), 3, 24, 7, 6, True),
+    'real_tf':  (dict(video_feature_dim=1024, max_pos_len=128, word_size=52), 2, 128, 20, 10, True),
+    'long_tf':  (dict(video_feature_dim=64, max_pos_len=256, word_size=52), 2, 200, 12, 5, True),
+}
+
+
+PARAM_SEED = 12345
+
+
+def run_case(VSLNet, name, spec):
+    over, B, T, Lq, Lc, ragged = spec
+    cfg = O.make_cfg(**over)
+    torch.manual_seed(12345)
+    glove = np.zeros((cfg.word_size - 2, cfg.word_dim), np.float32)     # overwritten by load_state_dict
+    model = VSLNet(configs=cfg, word_vectors=glove)
+    # weights come from the build's own seeded factory and are loaded into the reference model with
+    # strict=True -- this both keeps the fixture small (no weights stored, only checksums) and pins the
+    # state_dict schema (names + shapes) against the reference.
+    P = O.random_params(cfg, seed=PARAM_SEED)
+    model.load_state_dict(P, strict=True)
+    model.eval()
+    batch = O.synthetic_batch(cfg, B, T, Lq, Lc, seed=3, ragged=ragged)
+
+    taps = {}
+
+    def tap(key):
+        def hook(_m, _inp, out):
+            taps.setdefault(key, []).append(out.detach().clone() if torch.is_tensor(out) else
+                                            [o.detach().clone() for o in out])
+        return hook
+
+    hooks = []
+    for key, mod in [('video_affine', model.video_affine), ('embedding_net', model.embedding_net),
+                     ('word_emb', model.embedding_net.word_emb), ('char_emb', model.embedding_net.char_emb),
+                     ('feature_encoder', model.feature_encoder),
+                     ('fe_conv_block', model.feature_encoder.conv_block),
+                     ('cq_attention', model.cq_attention), ('cq_concat', model.cq_concat),
+                     ('highlight_layer', model.highlight_layer)]:
+        hooks.append(mod.register_forward_hook(tap(key)))
+    if cfg.predictor != 'rnn':
+        hooks.append(model.predictor.encoder.register_forward_hook(tap('pred_encoder')))
+    else:
+        hooks.append(model.predictor.start_encoder.register_forward_hook(tap('pred_start_rnn')))
+        hooks.append(model.predictor.end_encoder.register_forward_hook(tap('pred_end_rnn')))
+
+    h, sl, el = model(batch['word_ids'], batch['char_ids'], batch['vfeats'], batch['v_mask'], batch['q_mask'])
+    hl = model.compute_highlight_loss(h, batch['h_labels'], batch['v_mask'])
+    loc = model.compute_loss(sl, el, batch['s_labels'], batch['e_labels'])
+    total = loc + 5.0 * hl
+    model.zero_grad()
+    total.backward()
+    si, ei = model.extract_index(sl, el)
+    for hk in hooks:
+        hk.remove()
+
+    out = {}
+    for k, v in batch.items():
+        out['in.' + k] = v.numpy()
+    out['param_seed'] = np.array(PARAM_SEED)
+    for k, v in model.state_dict().items():
+        v64 = v.detach().double()
+        out['sdsum.' + k] = np.array([float(v64.sum()), float(v64.abs().sum()), float(v64.flatten()[-1])])
+    for n, p in model.named_parameters():
+        if p.requires_grad:
+            out['grad.' + n] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy()
+    out['out.h_score'] = h.detach().numpy()
+    out['out.start_logits'] = sl.detach().numpy()
+    out['out.end_logits'] = el.detach().numpy()
+    out['out.highlight_loss'] = hl.detach().numpy()
+    out['out.loc_loss'] = loc.detach().numpy()
+    out['out.start_index'] = si.numpy()
+    out['out.end_index'] = ei.numpy()
+    for k, lst in taps.items():
+        for i, t in enumerate(lst):
+            out['tap.%s.%d' % (k, i)] = t.numpy()
+    out['cfg'] = np.array(repr(vars(cfg)))
+    path = os.path.join(ROOT, 'tests', 'golden', name + '.npz')
+    np.savez_compressed(path, **out)
+    print(name, 'written', os.path.getsize(path) // 1024, 'KiB', 'loss', float(total))
+
+
+def run_host_helpers(ru, dl):
+    """Pins for the host-side helpers the callers own (SURVEY 8c last row)."""
+    rs = np.random.RandomState(5)
+    lens = torch.tensor(rs.randint(5, 40, size=9), dtype=torch.int64)
+    mask = ru.convert_length_to_mask(lens)
+    # collate labels: run the reference's train_collate_fn on synthetic records
+    data = []
+    for i in range(9):
+        L = int(lens[i])
+        s = int(rs.randint(0, L // 2 + 1))
+        e = min(L - 1, s + int(rs.randint(0, L // 2 + 1)))
+        feat = rs.randn(L, 16).astype(np.float32)
+        nw = int(rs.randint(2, 7))
+        w_ids = [int(x) for x in rs.randint(1, 50, size=nw)]
+        c_ids = [[int(x) for x in rs.randint(1, 30, size=int(rs.randint(1, 6)))] for _ in range(nw)]
+        data.append(({'vid': str(i)}, feat, w_ids, c_ids, s, e))
+    _, vfeats, vlens, word_ids, char_ids, s_l, e_l, h_l = dl.train_collate_fn(data)
+    out = dict(lens=lens.numpy(), mask=mask.numpy(), vlens=vlens.numpy(), s_labels=s_l.numpy(),
+               e_labels=e_l.numpy(), h_labels=h_l.numpy(), word_ids=word_ids.numpy(), char_ids=char_ids.numpy(),
+               vfeats=vfeats.numpy())
+    # IoU helper pins
+    pairs = rs.rand(20, 4).astype(np.float64) * 30
+    ious = [ru.calculate_iou(sorted(p[:2]), sorted(p[2:])) for p in pairs]
+    out['iou_pairs'] = pairs
+    out['ious'] = np.array(ious)
+    path = os.path.join(ROOT, 'tests', 'golden', 'host_helpers.npz')
+    np.savez_compressed(path, **out)
+    print('host_helpers written')
+
+
+def main():
+    VSLNet, ru, dl = load_reference()
+    os.makedirs(os.path.join(ROOT, 'tests', 'golden'), exist_ok=True)
+    torch.set_num_threads(8)
+    for name, spec in CASES.items():
+        run_case(VSLNet, name, spec)
+    run_host_helpers(ru, dl)
+
+
+if __name__ == '__main__':
+    main()
