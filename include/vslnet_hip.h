@@ -1,0 +1,119 @@
+/* libvslnet_hip.so -- C ABI of the MI355X-native VSLNet forward/backward path.
+ *
+ * The reference (26hzhang/VSLNet) has no FFI / plugin interface: the hot path sits behind an ordinary Python class
+ * (`model/VSLNet_t7.py:20-72`).  This ABI is therefore NEW; it is shaped so that the reference-side binding is one
+ * thin `nn.Module` (vslnet_amd/model/VSLNet.py, loaded with ctypes -- see INTEGRATION.md).  Each entry point names the
+ * reference interface it replaces.
+ *
+ * Conventions
+ *   - plain C: opaque handle, plain pointers and sizes, no torch / C++ types in any signature;
+ *   - every pointer inside `vsl_io` is a DEVICE pointer into caller-owned memory (PyTorch-ROCm tensors are used for
+ *     storage only); the library owns nothing but the handle and its small per-shape plans;
+ *   - all work is enqueued asynchronously on the caller's `hipStream_t` (passed as void*);
+ *   - return value 0 = ok, non-zero = error; `vsl_last_error()` returns a thread-local message; nothing throws
+ *     across the ABI;  one handle per device, not thread-safe per handle.
+ *   - fp32 everywhere (the reference is IEEE fp32 end to end), ids/labels int64, masks fp32 0/1.
+ */
+#ifndef VSLNET_HIP_H
+#define VSLNET_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vsl_handle_s* vsl_handle;
+
+/* fields of the `configs` namespace read by VSLNet.__init__ (VSLNet_t7.py:24-38) */
+typedef struct {
+    int32_t dim;               /* configs.dim              (kernels are specialised for 128)              */
+    int32_t num_heads;         /* configs.num_heads        (head size must be 16 -> 8 heads)              */
+    int32_t max_pos_len;       /* configs.max_pos_len      (rows of the positional table; T, Lq <= it)    */
+    int32_t video_feature_dim; /* configs.video_feature_dim (multiple of 8)                               */
+    int32_t word_dim;          /* configs.word_dim = 300   (word_dim + 100 must be a multiple of 8)       */
+    int32_t char_dim;          /* configs.char_dim = 50    (<= 64)                                        */
+    int32_t word_size;         /* configs.word_size  = rows of [pad; unk; glove]                          */
+    int32_t char_size;         /* configs.char_size  = rows of the character table                        */
+    int32_t predictor;         /* 0 = 'rnn' (not implemented in HIP yet -> error), 1 = 'transformer'      */
+    float drop_rate;           /* configs.drop_rate                                                        */
+} vsl_config;
+
+/* One forward / backward problem instance.  Replaces the argument list of VSLNet.forward (VSLNet_t7.py:52) plus
+ * the tensors autograd keeps alive between forward and `total_loss.backward()` (main_t7.py:103-110). */
+typedef struct {
+    int32_t B, T, Lq, Lc;          /* batch, padded clips, padded query words, padded chars per word              */
+    /* parameters */
+    const float* params;           /* flat trainable parameter bucket, layout = vsl_param_info()                   */
+    const float* pad_vec;          /* embedding_net.word_emb.pad_vec   (1, word_dim)  frozen                       */
+    const float* glove_vec;        /* embedding_net.word_emb.glove_vec (word_size-2, word_dim) frozen              */
+    /* batch (VSLNet_t7.py:52) */
+    const int64_t* word_ids;       /* (B, Lq)                                                                      */
+    const int64_t* char_ids;       /* (B, Lq, Lc)                                                                  */
+    const float* video_features;   /* (B, T, video_feature_dim)                                                    */
+    const float* v_mask;           /* (B, T)                                                                       */
+    const float* q_mask;           /* (B, Lq)                                                                      */
+    /* outputs (VSLNet_t7.py:62) */
+    float* h_score;                /* (B, T)  exactly 0 at padded clips                                            */
+    float* start_logits;           /* (B, T)  exactly -1e30 at padded clips                                        */
+    float* end_logits;             /* (B, T)                                                                       */
+    /* saved activations + backward temporaries; vsl_workspace_floats() floats, caller-owned                       */
+    float* workspace;
+    /* dropout (nn.Dropout sites of layers_t7.py): counter-based masks, keyed by (seed, site, element)             */
+    int32_t training;              /* 0: eval (no dropout)                                                         */
+    uint64_t seed;                 /* change every step; the backward must see the forward's value                 */
+    /* backward inputs / outputs */
+    const float* d_h_score;        /* (B, T) dLoss/dh_score      (nullable = zeros)                                */
+    const float* d_start_logits;   /* (B, T)                                                                        */
+    const float* d_end_logits;     /* (B, T)                                                                        */
+    float* grads;                  /* flat gradient bucket, same layout as `params` (overwritten, not accumulated) */
+} vsl_io;
+
+/* labels + weights for the fused loss (replaces compute_loss / compute_highlight_loss, VSLNet_t7.py:67-72, and the
+ * combination `loc + highlight_lambda * hl` of main_t7.py:107).  Data-parallel callers pass the GLOBAL normalisers. */
+typedef struct {
+    const int64_t* start_labels;   /* (B)    */
+    const int64_t* end_labels;     /* (B)    */
+    const int64_t* h_labels;       /* (B, T) */
+    float w_loc;                   /* weight of CE(start)+CE(end)      (main_t7.py: 1.0)                           */
+    float w_highlight;             /* weight of the highlight loss     (main_t7.py: highlight_lambda = 5.0)        */
+    float inv_batch;               /* 1 / global batch size (CrossEntropyLoss(mean), layers_t7.py:367-368)         */
+    float mask_sum;                /* global sum(v_mask) (layers_t7.py:298); <= 0: use this batch's own sum        */
+    float* losses;                 /* out, device, 4 floats: loc, highlight, w_loc*loc + w_hl*hl, mask_sum used     */
+    float* d_h_score;              /* out (B, T), nullable: seeds for vsl_backward                                  */
+    float* d_start_logits;         /* out (B, T)                                                                    */
+    float* d_end_logits;           /* out (B, T)                                                                    */
+} vsl_loss_io;
+
+const char* vsl_last_error(void);
+
+/* VSLNet.__init__ (VSLNet_t7.py:21-40): validates the config, fixes the flat parameter layout. */
+int vsl_create(const vsl_config* cfg, vsl_handle* out);
+int vsl_destroy(vsl_handle h);
+
+/* flat parameter bucket layout; names and shapes are the reference's state_dict entries, trainable only
+ * (pad_vec / glove_vec are passed separately in vsl_io). */
+int vsl_param_count(vsl_handle h);
+int vsl_param_info(vsl_handle h, int index, char* name, int name_cap, int64_t* offset, int64_t* numel, int32_t* ndim,
+                   int64_t dims[4]);
+int64_t vsl_param_floats(vsl_handle h);
+
+/* number of floats the caller must provide in vsl_io.workspace for this shape */
+int vsl_workspace_floats(vsl_handle h, int B, int T, int Lq, int Lc, int64_t* out);
+
+/* VSLNet.forward (VSLNet_t7.py:52-62) */
+int vsl_forward(vsl_handle h, const vsl_io* io, void* hip_stream);
+/* compute_loss + compute_highlight_loss (VSLNet_t7.py:67-72) and their gradient seeds */
+int vsl_loss(vsl_handle h, const vsl_io* io, const vsl_loss_io* l, void* hip_stream);
+/* autograd backward of everything in vsl_forward (main_t7.py:110); needs the same io (workspace, seed) */
+int vsl_backward(vsl_handle h, const vsl_io* io, void* hip_stream);
+/* ConditionedPredictor.extract_index (layers_t7.py:355-363) */
+int vsl_extract_index(vsl_handle h, const float* start_logits, const float* end_logits, int B, int T,
+                      int64_t* start_index, int64_t* end_index, void* hip_stream);
+
+/* workspace introspection for the parity tests: float offset of a named saved activation, -1 if unknown.
+ * names: "video_affine", "embedding_net", "venc", "qenc", "cq_attention", "cq_concat", "gated", "pred_s", "pred_e" */
+int64_t vsl_workspace_offset(vsl_handle h, int B, int T, int Lq, int Lc, const char* name);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

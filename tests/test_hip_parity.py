@@ -1,0 +1,167 @@
+"""GPU parity tests: the HIP path (through the C ABI, vslnet_amd.engine) vs the pinned CPU oracle and the golden
+vectors generated from the reference.  Tolerances (SURVEY 8c / north_star): activations + logits 1e-4 abs (scaled by
+the tensor's magnitude when > 1), gradients 1e-4 * ||g||inf + 1e-6 per tensor.  Run with `-m gpu` on an MI355X."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vslnet_oracle as O
+from tests.helpers import load_golden, grad_tol
+
+pytestmark = pytest.mark.gpu
+
+CASES = ['tiny_tf', 'real_tf', 'long_tf']
+ATOL = 1e-4
+
+
+def _dev(t):
+    return t.cuda().contiguous()
+
+
+def _setup(name):
+    from vslnet_amd.engine import Engine, flat_from_state_dict
+    cfg, P, b, z = load_golden(name)
+    eng = Engine(cfg)
+    flat = flat_from_state_dict(eng, P)
+    return cfg, P, b, z, eng, flat
+
+
+def _run_forward(eng, flat, P, b, training=False, seed=0):
+    return eng.forward(flat, _dev(P['embedding_net.word_emb.pad_vec']), _dev(P['embedding_net.word_emb.glove_vec']),
+                       _dev(b['word_ids']), _dev(b['char_ids']), _dev(b['vfeats']), _dev(b['v_mask']), _dev(b['q_mask']),
+                       training=training, seed=seed)
+
+
+class Report:
+    def __init__(self):
+        self.rows, self.bad = [], []
+
+    def check(self, what, got, ref, atol=ATOL):
+        got = got.detach().float().cpu().numpy() if torch.is_tensor(got) else np.asarray(got)
+        ref = ref.detach().float().cpu().numpy() if torch.is_tensor(ref) else np.asarray(ref)
+        assert got.shape == ref.shape, (what, got.shape, ref.shape)
+        big = np.abs(ref) > 1e29
+        ok_mask = np.array_equal(got[big], ref[big])
+        fin = ~big
+        err = float(np.abs(got[fin] - ref[fin]).max()) if fin.any() else 0.0
+        if not np.isfinite(err):
+            err = float('inf')
+        tol = atol * max(1.0, float(np.abs(ref[fin]).max()) if fin.any() else 1.0)
+        self.rows.append('%-28s err %.3e tol %.1e %s' % (what, err, tol, '' if (err <= tol and ok_mask) else '<-- FAIL'))
+        if not (err <= tol and ok_mask):
+            self.bad.append(what)
+
+    def finish(self):
+        print('\n' + '\n'.join(self.rows))
+        assert not self.bad, 'mismatches: ' + ', '.join(self.bad)
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_forward_every_stage(name):
+    cfg, P, b, z, eng, flat = _setup(name)
+    h, sl, el = _run_forward(eng, flat, P, b)
+    torch.cuda.synchronize()
+    want = {}
+    with torch.no_grad():
+        oh, osl, oel = O.forward(P, cfg, b['word_ids'], b['char_ids'], b['vfeats'], b['v_mask'], b['q_mask'], want=want)
+    B, T = b['v_mask'].shape
+    Lq = b['q_mask'].shape[1]
+    rep = Report()
+    V, Q, Cq = want['venc_parts'], want['qenc_parts'], want['cq_parts']
+    rep.check('video_affine', eng.ws_view('video_affine', (B, T, 128)), want['video_affine'])
+    with torch.no_grad():
+        econ = torch.cat([O.word_embedding(P, b['word_ids'], 0, False), O.char_embedding(P, b['char_ids'], 0, False)], -1)
+    rep.check('emb_concat', eng.ws_view('emb_concat', (B, Lq, cfg.word_dim + 100)), econ)
+    rep.check('embedding_net', eng.ws_view('embedding_net', (B, Lq, 128)), want['embedding_net'])
+    rep.check('venc_x0', eng.ws_view('venc_x0', (B, T, 128)), V['x0'])
+    rep.check('venc_conv0', eng.ws_view('venc_conv0', (B, T, 128)), V['conv_outs'][0])
+    rep.check('venc_conv3', eng.ws_view('venc_conv3', (B, T, 128)), V['conv_outs'][3])
+    rep.check('venc_q', eng.ws_view('venc_q', (B, T, 128)), V['q'])
+    rep.check('venc_k', eng.ws_view('venc_k', (B, T, 128)), V['k'])
+    rep.check('venc_v', eng.ws_view('venc_v', (B, T, 128)), V['v'])
+    rep.check('venc_att', eng.ws_view('venc_att', (B, T, 128)), V['att'])
+    rep.check('venc_r', eng.ws_view('venc_r', (B, T, 128)), V['r'])
+    rep.check('venc', eng.ws_view('venc', (B, T, 128)), want['venc'])
+    rep.check('qenc_conv3', eng.ws_view('qenc_conv3', (B, Lq, 128)), Q['conv_outs'][3])
+    rep.check('qenc_att', eng.ws_view('qenc_att', (B, Lq, 128)), Q['att'])
+    rep.check('qenc', eng.ws_view('qenc', (B, Lq, 128)), want['qenc'])
+    rep.check('cq_score', eng.ws_view('cq_score', (B, T, Lq)), Cq['score'])
+    rep.check('cq_srow', eng.ws_view('cq_srow', (B, T, Lq)), Cq['s_row'])
+    rep.check('cq_scol', eng.ws_view('cq_scol', (B, T, Lq)), Cq['s_col'])
+    rep.check('cq_M', eng.ws_view('cq_M', (B, Lq, 128)), torch.matmul(Cq['s_col'].transpose(1, 2), want['venc']))
+    rep.check('cq_attention', eng.ws_view('cq_attention', (B, T, 128)), want['cq_attention'])
+    rep.check('cq_concat', eng.ws_view('cq_concat', (B, T, 128)), want['cq_concat'])
+    rep.check('gated', eng.ws_view('gated', (B, T, 128)), want['gated'])
+    rep.check('pred_s', eng.ws_view('pred_s', (B, T, 128)), want['pred_parts']['pred_s'])
+    rep.check('pred_e', eng.ws_view('pred_e', (B, T, 128)), want['pred_parts']['pred_e'])
+    rep.check('h_score(oracle)', h, oh, atol=2e-5)
+    rep.check('start_logits(oracle)', sl, osl)
+    rep.check('end_logits(oracle)', el, oel)
+    # and against the reference's own outputs (golden)
+    rep.check('h_score(golden)', h, z['out.h_score'], atol=2e-5)
+    rep.check('start_logits(golden)', sl, z['out.start_logits'])
+    rep.check('end_logits(golden)', el, z['out.end_logits'])
+    pad = b['v_mask'].numpy() == 0
+    assert np.all(sl.cpu().numpy()[pad] == np.float32(-1e30)) and np.all(h.cpu().numpy()[pad] == 0.0)
+    si, ei = eng.extract_index(sl, el)
+    assert np.array_equal(si.cpu().numpy(), z['out.start_index']) and np.array_equal(ei.cpu().numpy(), z['out.end_index'])
+    rep.finish()
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_losses_and_every_gradient(name):
+    cfg, P, b, z, eng, flat = _setup(name)
+    _run_forward(eng, flat, P, b)
+    losses, d_h, d_sl, d_el = eng.loss(_dev(b['s_labels']), _dev(b['e_labels']), _dev(b['h_labels']), 1.0, 5.0)
+    grads = torch.full((eng.param_floats,), float('nan'), device=eng.device)
+    eng.backward(d_h, d_sl, d_el, grads)
+    torch.cuda.synchronize()
+    B, T = b['v_mask'].shape
+    Lq = b['q_mask'].shape[1]
+    # oracle with autograd, keeping the gradients of the intermediate activations
+    Pg = {k: v.clone().requires_grad_(k not in O.FROZEN) for k, v in P.items()}
+    want = {}
+    oh, osl, oel = O.forward(Pg, cfg, b['word_ids'], b['char_ids'], b['vfeats'], b['v_mask'], b['q_mask'], want=want)
+    keep = {'d_gated': want['gated'], 'd_venc': want['venc'], 'd_qenc': want['qenc'], 'd_video_affine': want['video_affine'],
+            'd_embedding_net': want['embedding_net'], 'd_pred_s': want['pred_parts']['pred_s'],
+            'd_cq_concat': want['cq_concat'], 'd_cq_attention': want['cq_attention']}
+    for t in list(keep.values()) + [oh, osl, oel]:
+        t.retain_grad()
+    hl = O.highlight_loss(oh, b['h_labels'], b['v_mask'])
+    loc = O.span_loss(osl, oel, b['s_labels'], b['e_labels'])
+    (loc + 5.0 * hl).backward()
+    rep = Report()
+    lo = losses.cpu().numpy()
+    rep.check('loc_loss', lo[0], z['out.loc_loss'], atol=2e-5)
+    rep.check('highlight_loss', lo[1], z['out.highlight_loss'], atol=2e-5)
+    sc = lambda g: 1e-4 * float(g.abs().max()) + 1e-6      # noqa: E731  (gradient gate as an absolute tolerance)
+    for nm, t, g in [('d_start_logits', d_sl, osl.grad), ('d_end_logits', d_el, oel.grad), ('d_h_score', d_h, oh.grad)]:
+        rep.check(nm, t, g, atol=sc(g))
+    shapes = {'d_gated': (B, T, 128), 'd_venc': (B, T, 128), 'd_qenc': (B, Lq, 128), 'd_video_affine': (B, T, 128),
+              'd_embedding_net': (B, Lq, 128), 'd_pred_s': (B, T, 128), 'd_cq_concat': (B, T, 128),
+              'd_cq_attention': (B, T, 128)}
+    for nm in ['d_pred_s', 'd_gated', 'd_cq_concat', 'd_cq_attention', 'd_venc', 'd_qenc', 'd_video_affine', 'd_embedding_net']:
+        g = keep[nm].grad
+        got = eng.ws_view(nm, shapes[nm])
+        err = float((got.cpu() - g).abs().max())
+        tol = sc(g)
+        rep.rows.append('%-28s err %.3e tol %.1e %s' % (nm, err, tol, '' if err <= tol else '<-- FAIL'))
+        if not err <= tol:
+            rep.bad.append(nm)
+    gv = eng.views(grads)
+    n = 0
+    for k in z.files:
+        if not k.startswith('grad.'):
+            continue
+        g_ref = z[k]
+        got = gv[k[5:]].cpu().numpy()
+        err = float(np.abs(got - g_ref).max())
+        if not np.isfinite(err):
+            err = float('inf')
+        tol = grad_tol(g_ref)
+        rep.rows.append('%-60s err %.3e tol %.1e %s' % (k, err, tol, '' if err <= tol else '<-- FAIL'))
+        if not err <= tol:
+            rep.bad.append(k)
+        n += 1
+    assert n == len(eng.layout)
+    rep.finish()

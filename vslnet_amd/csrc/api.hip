@@ -1,0 +1,768 @@
+// C ABI of libvslnet_hip.so (declared in include/vslnet_hip.h): parameter layout, per-shape plan (workspace
+// layout, weight-pack jobs, partial-slab table for the gradient reduction) and the forward / loss / backward
+// launch sequences.  Host code only -- no device code lives here.
+#include "../../include/vslnet_hip.h"
+#include "launch.hpp"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+
+using namespace vsl;
+
+static thread_local std::string g_err;
+static int fail(const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return 1;
+}
+#define HIP_OK(x)                                                                         \
+    do {                                                                                  \
+        hipError_t e_ = (x);                                                              \
+        if (e_ != hipSuccess) return fail("%s failed: %s", #x, hipGetErrorString(e_));    \
+    } while (0)
+
+namespace {
+
+struct ParamInfo { std::string name; int64_t off, numel; int ndim; int64_t dims[4]; };
+
+struct EncP { int pos, dw[4], pw[4], pwb[4], lng[4], lnb[4], qw, qb, kw, kb, vw, vb, ln1g, ln1b, ln2g, ln2b, ow, ob; };
+struct EncPk { int pw_f[4], pw_t[4], qkv_f, qkv_t, o_f, o_t; };
+struct ModelP {
+    int unk, char_tab, ccw[4], ccb[4], emb_w, emb_b, va_w, va_b;
+    EncP fe;
+    int w4C, w4Q, w4mlu, cqa_w, cqa_b, pool_w, cat_w, cat_b, hl_w, hl_b;
+    EncP pe;
+    int sln_g, sln_b, eln_g, eln_b, s0w, s0b, s1w, s1b, e0w, e0b, e1w, e1b;
+};
+struct ModelPk { int va_f, emb_f, emb_t; EncPk fe, pe; int cqa_f, cqa_t, cat1_f, cat1_t, s0_f, s0_t, e0_f, e0_t; };
+
+struct EncWs { int64_t x0, y[4], u[4], mask[4], h1, q, k, v, lse, att, r, h2, out; int R, L; };
+
+struct SlabRec { int dst, n, nslabs, ss, rl, ds; int64_t src; };
+
+struct Plan {
+    int B, T, Lq, Lc;
+    int64_t pack, vf, E, argpos, qf;
+    EncWs ve, qe, p1, p2;
+    int64_t S, Srow, Scol, M, alpha, pooled, pb, cat, f1, f2, gated, hid_s, hid_e, lnf_s, lnf_e;
+    // backward temporaries
+    int64_t loss_scratch, gz_s, gz_e, dfeat_s, dfeat_e, dxh_s, dxh_e, g_s1, g_gated;
+    int64_t t_dr, t_dq, t_dk, t_dv, t_Dq, t_go, t_du, t_gz[4], t_ga, t_gb;
+    int64_t df2, df1, dC, dc2q, dq2c, dSr, dSs, dQtot, dvf, dqf, dE;
+    int64_t partial, partial_floats, total;
+    std::vector<int64_t> part_offs;     // sequence of partial-arena allocations made by the backward
+    ReduceSeg* segs_dev = nullptr;
+    int* blk2seg_dev = nullptr;
+    int nblocks = 0;
+};
+
+}  // namespace
+
+struct vsl_handle_s {
+    vsl_config cfg;
+    std::vector<ParamInfo> params;
+    int64_t param_floats = 0;
+    ModelP P;
+    ModelPk K;
+    int64_t pack_floats = 0;
+    std::vector<PackJob> jobs;
+    PackJob* jobs_dev = nullptr;
+    std::map<std::tuple<int, int, int, int>, Plan*> plans;
+};
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ parameters
+struct ParamBuilder {
+    vsl_handle_s* h;
+    int add(const std::string& name, std::initializer_list<int64_t> dims) {
+        ParamInfo p;
+        p.name = name;
+        p.ndim = (int)dims.size();
+        p.numel = 1;
+        int i = 0;
+        for (auto d : dims) { p.dims[i++] = d; p.numel *= d; }
+        p.off = h->param_floats;
+        h->param_floats += (p.numel + 3) & ~int64_t(3);          // keep every tensor 16-byte aligned
+        h->params.push_back(p);
+        return (int)p.off;
+    }
+};
+
+void build_encoder_params(ParamBuilder& pb, const std::string& pre, EncP& e, int max_pos) {
+    const int64_t d = D;
+    e.pos = pb.add(pre + "pos_embedding.position_embeddings.weight", {max_pos, d});
+    for (int i = 0; i < 4; ++i) {
+        const std::string b = pre + "conv_block.depthwise_separable_conv." + std::to_string(i);
+        e.dw[i] = pb.add(b + ".0.weight", {d, 1, 7});
+        e.pw[i] = pb.add(b + ".1.weight", {d, d, 1});
+        e.pwb[i] = pb.add(b + ".1.bias", {d});
+    }
+    for (int i = 0; i < 4; ++i) {
+        const std::string b = pre + "conv_block.layer_norms." + std::to_string(i);
+        e.lng[i] = pb.add(b + ".weight", {d});
+        e.lnb[i] = pb.add(b + ".bias", {d});
+    }
+    const std::string a = pre + "attention_block.";
+    e.qw = pb.add(a + "query.conv1d.weight", {d, d, 1});
+    e.qb = pb.add(a + "query.conv1d.bias", {d});
+    e.kw = pb.add(a + "key.conv1d.weight", {d, d, 1});
+    e.kb = pb.add(a + "key.conv1d.bias", {d});
+    e.vw = pb.add(a + "value.conv1d.weight", {d, d, 1});
+    e.vb = pb.add(a + "value.conv1d.bias", {d});
+    e.ln1g = pb.add(a + "layer_norm1.weight", {d});
+    e.ln1b = pb.add(a + "layer_norm1.bias", {d});
+    e.ln2g = pb.add(a + "layer_norm2.weight", {d});
+    e.ln2b = pb.add(a + "layer_norm2.bias", {d});
+    e.ow = pb.add(a + "out_layer.conv1d.weight", {d, d, 1});
+    e.ob = pb.add(a + "out_layer.conv1d.bias", {d});
+}
+
+void build_params(vsl_handle_s* h) {
+    // order == the reference's state_dict order restricted to trainable tensors
+    const vsl_config& c = h->cfg;
+    ParamBuilder pb{h};
+    ModelP& P = h->P;
+    const int64_t d = D;
+    P.unk = pb.add("embedding_net.word_emb.unk_vec", {1, c.word_dim});
+    P.char_tab = pb.add("embedding_net.char_emb.char_emb.weight", {c.char_size, c.char_dim});
+    const int ch[4] = {10, 20, 30, 40};
+    for (int i = 0; i < 4; ++i) {
+        const std::string b = "embedding_net.char_emb.char_convs." + std::to_string(i) + ".0";
+        P.ccw[i] = pb.add(b + ".weight", {ch[i], c.char_dim, 1, i + 1});
+        P.ccb[i] = pb.add(b + ".bias", {ch[i]});
+    }
+    P.emb_w = pb.add("embedding_net.linear.conv1d.weight", {d, c.word_dim + 100, 1});
+    P.emb_b = pb.add("embedding_net.linear.conv1d.bias", {d});
+    P.va_w = pb.add("video_affine.linear.conv1d.weight", {d, c.video_feature_dim, 1});
+    P.va_b = pb.add("video_affine.linear.conv1d.bias", {d});
+    build_encoder_params(pb, "feature_encoder.", P.fe, c.max_pos_len);
+    P.w4C = pb.add("cq_attention.w4C", {d, 1});
+    P.w4Q = pb.add("cq_attention.w4Q", {d, 1});
+    P.w4mlu = pb.add("cq_attention.w4mlu", {1, 1, d});
+    P.cqa_w = pb.add("cq_attention.cqa_linear.conv1d.weight", {d, 4 * d, 1});
+    P.cqa_b = pb.add("cq_attention.cqa_linear.conv1d.bias", {d});
+    P.pool_w = pb.add("cq_concat.weighted_pool.weight", {d, 1});
+    P.cat_w = pb.add("cq_concat.conv1d.conv1d.weight", {d, 2 * d, 1});
+    P.cat_b = pb.add("cq_concat.conv1d.conv1d.bias", {d});
+    P.hl_w = pb.add("highlight_layer.conv1d.conv1d.weight", {1, d, 1});
+    P.hl_b = pb.add("highlight_layer.conv1d.conv1d.bias", {1});
+    build_encoder_params(pb, "predictor.encoder.", P.pe, c.max_pos_len);
+    P.sln_g = pb.add("predictor.start_layer_norm.weight", {d});
+    P.sln_b = pb.add("predictor.start_layer_norm.bias", {d});
+    P.eln_g = pb.add("predictor.end_layer_norm.weight", {d});
+    P.eln_b = pb.add("predictor.end_layer_norm.bias", {d});
+    P.s0w = pb.add("predictor.start_block.0.conv1d.weight", {d, 2 * d, 1});
+    P.s0b = pb.add("predictor.start_block.0.conv1d.bias", {d});
+    P.s1w = pb.add("predictor.start_block.2.conv1d.weight", {1, d, 1});
+    P.s1b = pb.add("predictor.start_block.2.conv1d.bias", {1});
+    P.e0w = pb.add("predictor.end_block.0.conv1d.weight", {d, 2 * d, 1});
+    P.e0b = pb.add("predictor.end_block.0.conv1d.bias", {d});
+    P.e1w = pb.add("predictor.end_block.2.conv1d.weight", {1, d, 1});
+    P.e1b = pb.add("predictor.end_block.2.conv1d.bias", {1});
+}
+
+// ------------------------------------------------------------------------------------------------ weight packs
+struct PackBuilder {
+    vsl_handle_s* h;
+    // forward pack of W (N x K, leading dim ld): Bm[k][c] = W[c][k]
+    int fwd(int src, int N, int Kd, int ld) {
+        const int dst = (int)h->pack_floats;
+        h->pack_floats += (int64_t)pack_size(Kd, N);
+        h->jobs.push_back(PackJob{src, dst, Kd, N, ld, 0, N, 0, 0});
+        return dst;
+    }
+    // transpose pack of W (N x K): Bm[k = n][c] = W[n][c], ncols = K
+    int tr(int src, int N, int Kd, int ld) {
+        const int dst = (int)h->pack_floats;
+        h->pack_floats += (int64_t)pack_size(N, Kd);
+        h->jobs.push_back(PackJob{src, dst, N, Kd, ld, 1, Kd, 0, 0});
+        return dst;
+    }
+};
+void build_encoder_packs(PackBuilder& pk, vsl_handle_s* h, const EncP& e, EncPk& k) {
+    for (int i = 0; i < 4; ++i) { k.pw_f[i] = pk.fwd(e.pw[i], D, D, D); k.pw_t[i] = pk.tr(e.pw[i], D, D, D); }
+    // fused QKV operand: forward pack has 384 columns [q | k | v]; transpose pack has 384 contraction rows
+    k.qkv_f = (int)h->pack_floats;
+    h->pack_floats += (int64_t)pack_size(D, 3 * D);
+    const int qkv[3] = {e.qw, e.kw, e.vw};
+    for (int i = 0; i < 3; ++i) h->jobs.push_back(PackJob{qkv[i], k.qkv_f, D, D, D, 0, 3 * D, 0, i * D});
+    k.qkv_t = (int)h->pack_floats;
+    h->pack_floats += (int64_t)pack_size(3 * D, D);
+    for (int i = 0; i < 3; ++i) h->jobs.push_back(PackJob{qkv[i], k.qkv_t, D, D, D, 1, D, i * D, 0});
+    k.o_f = pk.fwd(e.ow, D, D, D);
+    k.o_t = pk.tr(e.ow, D, D, D);
+}
+void build_packs(vsl_handle_s* h) {
+    const vsl_config& c = h->cfg;
+    PackBuilder pk{h};
+    ModelPk& K = h->K;
+    const ModelP& P = h->P;
+    K.va_f = pk.fwd(P.va_w, D, c.video_feature_dim, c.video_feature_dim);
+    K.emb_f = pk.fwd(P.emb_w, D, c.word_dim + 100, c.word_dim + 100);
+    K.emb_t = pk.tr(P.emb_w, D, c.word_dim + 100, c.word_dim + 100);
+    build_encoder_packs(pk, h, P.fe, K.fe);
+    build_encoder_packs(pk, h, P.pe, K.pe);
+    K.cqa_f = pk.fwd(P.cqa_w, D, 4 * D, 4 * D);
+    K.cqa_t = pk.tr(P.cqa_w, D, 4 * D, 4 * D);
+    K.cat1_f = pk.fwd(P.cat_w, D, D, 2 * D);          // first half of the (128, 256) CQConcatenate weight
+    K.cat1_t = pk.tr(P.cat_w, D, D, 2 * D);
+    K.s0_f = pk.fwd(P.s0w, D, 2 * D, 2 * D);
+    K.s0_t = pk.tr(P.s0w, D, 2 * D, 2 * D);
+    K.e0_f = pk.fwd(P.e0w, D, 2 * D, 2 * D);
+    K.e0_t = pk.tr(P.e0w, D, 2 * D, 2 * D);
+}
+
+// ------------------------------------------------------------------------------------------------ plan
+struct Bump {
+    int64_t cur = 0;
+    int64_t operator()(int64_t n) { const int64_t o = cur; cur += (n + 3) & ~int64_t(3); return o; }
+};
+void plan_encoder(Bump& al, EncWs& w, int Bn, int L, int H) {
+    const int64_t R = (int64_t)Bn * L;
+    w.R = (int)R; w.L = L;
+    w.x0 = al(R * D);
+    for (int i = 0; i < 4; ++i) { w.y[i] = al(R * D); w.u[i] = al(R * D); w.mask[i] = al(R * 4); }
+    w.h1 = al(R * D); w.q = al(R * D); w.k = al(R * D); w.v = al(R * D);
+    w.lse = al((int64_t)Bn * H * L);
+    w.att = al(R * D); w.r = al(R * D); w.h2 = al(R * D); w.out = al(R * D);
+}
+
+struct Ctx {
+    vsl_handle_s* h;
+    Plan* p;
+    const vsl_io* io;
+    hipStream_t s;
+    bool dry;                           // plan-building pass: record partial-slab allocations, launch nothing
+    float* ws;
+    size_t part_idx = 0;
+    int64_t part_cur = 0;
+    std::vector<SlabRec>* recs = nullptr;
+    const float* P(int off) const { return io->params + off; }
+    const float* PK(int off) const { return ws + p->pack + off; }
+    float* W(int64_t off) const { return ws + off; }
+    // raw allocation in the partial arena
+    int64_t part_alloc(int64_t n) {
+        n = (n + 3) & ~int64_t(3);
+        if (dry) { p->part_offs.push_back(part_cur); part_cur += n; return p->part_offs.back(); }
+        return p->part_offs[part_idx++];
+    }
+    void reg(int dst, int n, int64_t src, int nslabs, int ss, int rl = 0, int ds = 0) {
+        if (dry) recs->push_back(SlabRec{dst, n, nslabs, ss, rl ? rl : n, ds, src});
+    }
+    // the common case: `nslabs` contiguous slabs of n floats for the parameter at dst
+    float* slab(int dst, int n, int nslabs) {
+        const int64_t o = part_alloc((int64_t)n * nslabs);
+        reg(dst, n, o, nslabs, n);
+        return dry ? nullptr : ws + p->partial + o;
+    }
+    float* part_ptr(int64_t o) const { return dry ? nullptr : ws + p->partial + o; }
+    Drop drop(int site) const {
+        Drop d{0u, 0u, 1.0f};
+        const float pr = h->cfg.drop_rate;
+        if (io && io->training && pr > 0.f) {
+            uint32_t x = (uint32_t)io->seed ^ ((uint32_t)(io->seed >> 32) * 0x9E3779B1u) ^ ((uint32_t)site * 0x85EBCA77u + 0x165667B1u);
+            x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+            d.seed = x;
+            d.thresh = (uint32_t)std::min(4294967295.0, (double)pr * 4294967296.0);
+            d.scale = 1.0f / (1.0f - pr);
+        }
+        return d;
+    }
+};
+#define LAUNCH(stmt) do { if (!c.dry) { stmt; } } while (0)
+
+// dropout site ids: encoder application `app` (0 video, 1 query, 2 predictor pass 1, 3 predictor pass 2) uses
+// app * 16 + {0..3 conv layers, 4 LN1 out, 5 attention probs, 6 attention out, 7 LN2 out, 8 out_layer}
+enum { SITE_VIS = 64, SITE_WORD = 65, SITE_CHAR = 66, SITE_CQ_C = 67, SITE_CQ_Q = 68 };
+
+// ------------------------------------------------------------------------------------------------ forward
+void enc_fwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float* xin, const float* mask, int Bn, int app) {
+    const int R = w.R, L = w.L, H = c.h->cfg.num_heads;
+    for (int i = 0; i < 4; ++i)
+        launch_conv_layer_fwd(i == 0 ? xin : c.W(w.y[i - 1]), i == 0 ? c.P(P.pos) : nullptr, i == 0 ? c.W(w.x0) : nullptr,
+                              c.P(P.lng[i]), c.P(P.lnb[i]), c.P(P.dw[i]), c.PK(K.pw_f[i]), c.P(P.pwb[i]), c.W(w.y[i]),
+                              c.W(w.u[i]), reinterpret_cast<uint32_t*>(c.W(w.mask[i])), R, L, c.drop(app * 16 + i), c.s);
+    launch_ln_qkv_fwd(c.W(w.y[3]), c.P(P.ln1g), c.P(P.ln1b), c.PK(K.qkv_f), c.P(P.qb), c.P(P.kb), c.P(P.vb), c.W(w.h1),
+                      c.W(w.q), c.W(w.k), c.W(w.v), R, c.drop(app * 16 + 4), c.s);
+    launch_attn_fwd(c.W(w.q), c.W(w.k), c.W(w.v), mask, c.W(w.att), c.W(w.lse), Bn, L, H, 0, c.drop(app * 16 + 5), c.s);
+    launch_attn_out_fwd(c.W(w.att), c.W(w.y[3]), c.P(P.ln2g), c.P(P.ln2b), c.PK(K.o_f), c.P(P.ob), c.W(w.r), c.W(w.h2),
+                        c.W(w.out), R, c.drop(app * 16 + 6), c.drop(app * 16 + 7), c.drop(app * 16 + 8), c.s);
+}
+
+CharConvPtrs char_ptrs(const Ctx& c) {
+    CharConvPtrs cc;
+    for (int i = 0; i < 4; ++i) { cc.w[i] = c.P(c.h->P.ccw[i]); cc.b[i] = c.P(c.h->P.ccb[i]); }
+    return cc;
+}
+
+void run_forward(Ctx& c) {
+    const vsl_config& cf = c.h->cfg;
+    const ModelP& P = c.h->P;
+    const ModelPk& K = c.h->K;
+    const Plan& p = *c.p;
+    const vsl_io& io = *c.io;
+    const int B = p.B, T = p.T, Lq = p.Lq, R = B * T, Rq = B * Lq;
+    launch_pack(io.params, c.W(p.pack), c.h->jobs_dev, (int)c.h->jobs.size(), c.s);
+    launch_vproj_fwd(io.video_features, c.PK(K.va_f), c.P(P.va_b), c.W(p.vf), R, cf.video_feature_dim, c.drop(SITE_VIS), c.s);
+    launch_embed_fwd(io.word_ids, io.char_ids, io.pad_vec, c.P(P.unk), io.glove_vec, c.P(P.char_tab), char_ptrs(c), c.W(p.E),
+                     reinterpret_cast<int8_t*>(c.W(p.argpos)), Rq, p.Lc, cf.word_dim, cf.char_dim, c.drop(SITE_WORD),
+                     c.drop(SITE_CHAR), c.s);
+    launch_linear_fwd(c.W(p.E), c.PK(K.emb_f), c.P(P.emb_b), c.W(p.qf), Rq, cf.word_dim + 100, c.s);
+    enc_fwd(c, P.fe, K.fe, p.ve, c.W(p.vf), io.v_mask, B, 0);
+    enc_fwd(c, P.fe, K.fe, p.qe, c.W(p.qf), io.q_mask, B, 1);
+    launch_cq_score(c.W(p.ve.out), c.W(p.qe.out), io.q_mask, c.P(P.w4C), c.P(P.w4Q), c.P(P.w4mlu), c.W(p.S), c.W(p.Srow), B, T,
+                    Lq, 0, c.drop(SITE_CQ_C), c.drop(SITE_CQ_Q), c.s);
+    launch_cq_col(c.W(p.ve.out), c.W(p.qe.out), c.W(p.S), io.v_mask, io.q_mask, c.P(P.pool_w), c.P(P.cat_w), c.P(P.cat_b),
+                  c.W(p.Scol), c.W(p.M), c.W(p.alpha), c.W(p.pooled), c.W(p.pb), B, T, Lq, c.s);
+    launch_cq_out(c.W(p.ve.out), c.W(p.qe.out), c.W(p.Srow), c.W(p.M), c.PK(K.cqa_f), c.P(P.cqa_b), c.W(p.cat), c.W(p.f1), B, T,
+                  Lq, c.s);
+    launch_cqcat_fwd(c.W(p.f1), c.PK(K.cat1_f), c.W(p.pb), c.P(P.hl_w), c.P(P.hl_b), io.v_mask, c.W(p.f2), io.h_score,
+                     c.W(p.gated), R, T, c.s);
+    enc_fwd(c, P.pe, K.pe, p.p1, c.W(p.gated), io.v_mask, B, 2);
+    enc_fwd(c, P.pe, K.pe, p.p2, c.W(p.p1.out), io.v_mask, B, 3);
+    HeadArgs hs{c.W(p.p1.out), c.P(P.sln_g), c.P(P.sln_b), c.PK(K.s0_f), c.P(P.s0b), c.P(P.s1w), c.P(P.s1b), c.W(p.hid_s),
+                c.W(p.lnf_s), io.start_logits};
+    HeadArgs he{c.W(p.p2.out), c.P(P.eln_g), c.P(P.eln_b), c.PK(K.e0_f), c.P(P.e0b), c.P(P.e1w), c.P(P.e1b), c.W(p.hid_e),
+                c.W(p.lnf_e), io.end_logits};
+    launch_head_fwd(hs, he, c.W(p.gated), io.v_mask, R, c.s);
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+WgradJob wjob() { WgradJob j; memset(&j, 0, sizeof j); return j; }
+
+// backward of one FeatureEncoder application: dy = grad wrt its output; writes grad wrt its input (dx0_out)
+void enc_bwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float* dy, const float* extra, float* dx0_out,
+             const float* mask, int Bn, int app) {
+    const Plan& p = *c.p;
+    const int R = w.R, L = w.L, H = c.h->cfg.num_heads;
+    const int ntiles = (R + TILE_M - 1) / TILE_M, nchunk = (R + WG_ROWS - 1) / WG_ROWS;
+    const bool dropping = c.io && c.io->training && c.h->cfg.drop_rate > 0.f;
+    float* p_ln2g = c.slab(P.ln2g, D, ntiles);
+    float* p_ln2b = c.slab(P.ln2b, D, ntiles);
+    float* g_o = dropping ? c.W(p.t_go) : nullptr;
+    LAUNCH(launch_attn_out_bwd(dy, c.W(w.r), c.P(P.ln2g), c.PK(K.o_t), g_o, c.W(p.t_dr), p_ln2g, p_ln2b, R,
+                               c.drop(app * 16 + 7), c.drop(app * 16 + 8), c.s));
+    LAUNCH(launch_attn_bwd(c.W(w.q), c.W(w.k), c.W(w.v), c.W(w.att), c.W(p.t_dr), c.W(w.lse), mask, c.W(p.t_dq), c.W(p.t_dk),
+                           c.W(p.t_dv), c.W(p.t_Dq), Bn, L, H, 0, c.drop(app * 16 + 5), c.drop(app * 16 + 6), c.s));
+    float* p_ln1g = c.slab(P.ln1g, D, ntiles);
+    float* p_ln1b = c.slab(P.ln1b, D, ntiles);
+    LAUNCH(launch_qkv_bwd(c.W(p.t_dq), c.W(p.t_dk), c.W(p.t_dv), c.W(w.y[3]), c.W(p.t_dr), c.P(P.ln1g), c.PK(K.qkv_t),
+                          c.W(p.t_ga), p_ln1g, p_ln1b, R, c.drop(app * 16 + 4), c.s));
+    float* g = c.dry ? nullptr : c.W(p.t_ga);
+    float* other = c.dry ? nullptr : c.W(p.t_gb);
+    for (int i = 3; i >= 0; --i) {
+        LAUNCH(launch_conv_bwd_gemm(g, reinterpret_cast<const uint32_t*>(c.W(w.mask[i])), c.PK(K.pw_t[i]), c.W(p.t_gz[i]),
+                                    c.W(p.t_du), R, c.drop(app * 16 + i), c.s));
+        float* p_g = c.slab(P.lng[i], D, ntiles);
+        float* p_b = c.slab(P.lnb[i], D, ntiles);
+        float* p_dw = c.slab(P.dw[i], D * DWK, ntiles);
+        float* out = i > 0 ? other : dx0_out;
+        LAUNCH(launch_conv_bwd_dwln(c.W(p.t_du), i > 0 ? c.W(w.y[i - 1]) : c.W(w.x0), g, c.P(P.lng[i]), c.P(P.lnb[i]),
+                                    c.P(P.dw[i]), i == 0 ? extra : nullptr, out, p_g, p_b, p_dw, R, L, c.s));
+        other = g;
+        g = out;
+    }
+    // weight gradients of this application: out_layer, fused q/k/v, 4 pointwise convs
+    WgradBatch wb;
+    memset(&wb, 0, sizeof wb);
+    {
+        WgradJob j = wjob();
+        j.G[0] = dropping ? g_o : dy; j.nG = 1; j.A[0] = c.dry ? nullptr : c.W(w.h2); j.nA = 1; j.K = D; j.R = R;
+        j.out = c.slab(P.ow, D * D, nchunk);
+        j.out_bias[0] = c.slab(P.ob, D, nchunk);
+        wb.j[wb.n++] = j;
+    }
+    {
+        WgradJob j = wjob();
+        if (!c.dry) { j.G[0] = c.W(p.t_dq); j.G[1] = c.W(p.t_dk); j.G[2] = c.W(p.t_dv); j.A[0] = c.W(w.h1); }
+        j.nG = 3; j.nA = 1; j.K = D; j.R = R;
+        const int64_t o = c.part_alloc((int64_t)nchunk * 3 * D * D);
+        c.reg(P.qw, D * D, o, nchunk, 3 * D * D);
+        c.reg(P.kw, D * D, o + D * D, nchunk, 3 * D * D);
+        c.reg(P.vw, D * D, o + 2 * D * D, nchunk, 3 * D * D);
+        j.out = c.part_ptr(o);
+        j.out_bias[0] = c.slab(P.qb, D, nchunk);
+        j.out_bias[1] = c.slab(P.kb, D, nchunk);
+        j.out_bias[2] = c.slab(P.vb, D, nchunk);
+        wb.j[wb.n++] = j;
+    }
+    for (int i = 0; i < 4; ++i) {
+        WgradJob j = wjob();
+        if (!c.dry) { j.G[0] = c.W(p.t_gz[i]); j.A[0] = c.W(w.u[i]); }
+        j.nG = 1; j.nA = 1; j.K = D; j.R = R;
+        j.out = c.slab(P.pw[i], D * D, nchunk);
+        j.out_bias[0] = c.slab(P.pwb[i], D, nchunk);
+        wb.j[wb.n++] = j;
+    }
+    LAUNCH(launch_wgrad(wb, c.s));
+    float* p_pos = c.slab(P.pos, c.h->cfg.max_pos_len * D, 1);
+    LAUNCH(launch_pos_grad(dx0_out, p_pos, Bn, L, c.h->cfg.max_pos_len, c.s));
+}
+
+void run_backward(Ctx& c) {
+    const vsl_config& cf = c.h->cfg;
+    const ModelP& P = c.h->P;
+    const ModelPk& K = c.h->K;
+    const Plan& p = *c.p;
+    const int B = p.B, T = p.T, Lq = p.Lq, R = B * T, Rq = B * Lq;
+    const int ntiles = (R + TILE_M - 1) / TILE_M, nchunk = (R + WG_ROWS - 1) / WG_ROWS, nchunk_q = (Rq + WG_ROWS - 1) / WG_ROWS;
+    const vsl_io* io = c.io;
+    // ---- span heads
+    HeadBwdArgs hs, he;
+    memset(&hs, 0, sizeof hs);
+    memset(&he, 0, sizeof he);
+    if (!c.dry) {
+        hs = HeadBwdArgs{io->d_start_logits, c.W(p.hid_s), c.W(p.p1.out), c.P(P.sln_g), c.PK(K.s0_t), c.P(P.s1w), c.W(p.gz_s),
+                         c.W(p.dfeat_s), c.W(p.dxh_s), nullptr, nullptr, nullptr, nullptr, nullptr};
+        he = HeadBwdArgs{io->d_end_logits, c.W(p.hid_e), c.W(p.p2.out), c.P(P.eln_g), c.PK(K.e0_t), c.P(P.e1w), c.W(p.gz_e),
+                         c.W(p.dfeat_e), c.W(p.dxh_e), nullptr, nullptr, nullptr, nullptr, nullptr};
+    }
+    hs.p_b0 = c.slab(P.s0b, D, ntiles); hs.p_w1 = c.slab(P.s1w, D, ntiles); hs.p_b1 = c.slab(P.s1b, 1, ntiles);
+    hs.p_lng = c.slab(P.sln_g, D, ntiles); hs.p_lnb = c.slab(P.sln_b, D, ntiles);
+    he.p_b0 = c.slab(P.e0b, D, ntiles); he.p_w1 = c.slab(P.e1w, D, ntiles); he.p_b1 = c.slab(P.e1b, 1, ntiles);
+    he.p_lng = c.slab(P.eln_g, D, ntiles); he.p_lnb = c.slab(P.eln_b, D, ntiles);
+    LAUNCH(launch_head_bwd(hs, he, R, c.s));
+    {
+        WgradBatch wb;
+        memset(&wb, 0, sizeof wb);
+        for (int e = 0; e < 2; ++e) {
+            WgradJob j = wjob();
+            if (!c.dry) { j.G[0] = c.W(e ? p.gz_e : p.gz_s); j.A[0] = c.W(e ? p.lnf_e : p.lnf_s); j.A[1] = c.W(p.gated); }
+            j.nG = 1; j.nA = 2; j.K = 2 * D; j.R = R;
+            j.out = c.slab(e ? P.e0w : P.s0w, D * 2 * D, nchunk);
+            wb.j[wb.n++] = j;
+        }
+        LAUNCH(launch_wgrad(wb, c.s));
+    }
+    // ---- predictor encoder, second pass (input = output of the first pass), then first pass
+    enc_bwd(c, P.pe, K.pe, p.p2, c.dry ? nullptr : c.W(p.dfeat_e), c.dry ? nullptr : c.W(p.dfeat_s),
+            c.dry ? nullptr : c.W(p.g_s1), c.dry ? nullptr : io->v_mask, B, 3);
+    enc_bwd(c, P.pe, K.pe, p.p1, c.dry ? nullptr : c.W(p.g_s1), nullptr, c.dry ? nullptr : c.W(p.g_gated),
+            c.dry ? nullptr : io->v_mask, B, 2);
+    // ---- gating + highlight + CQConcatenate
+    float* p_hlw = c.slab(P.hl_w, D, ntiles);
+    float* p_hlb = c.slab(P.hl_b, 1, ntiles);
+    LAUNCH(launch_cqcat_bwd(c.W(p.g_gated), c.W(p.dxh_s), c.W(p.dxh_e), io->d_h_score, c.W(p.f2), io->h_score, c.P(P.hl_w),
+                            c.PK(K.cat1_t), c.W(p.df2), c.W(p.df1), p_hlw, p_hlb, R, c.s));
+    {
+        WgradBatch wb;
+        memset(&wb, 0, sizeof wb);
+        {   // first half of the (128, 256) CQConcatenate weight: destination rows are strided by 256
+            WgradJob j = wjob();
+            if (!c.dry) { j.G[0] = c.W(p.df2); j.A[0] = c.W(p.f1); }
+            j.nG = 1; j.nA = 1; j.K = D; j.R = R;
+            const int64_t o = c.part_alloc((int64_t)nchunk * D * D);
+            c.reg(P.cat_w, D * D, o, nchunk, D * D, D, 2 * D);
+            j.out = c.part_ptr(o);
+            wb.j[wb.n++] = j;
+        }
+        {   // cqa_linear (128, 512)
+            WgradJob j = wjob();
+            if (!c.dry) { j.G[0] = c.W(p.df1); j.Afull = c.W(p.cat); }
+            j.nG = 1; j.nA = 0; j.K = 4 * D; j.R = R;
+            j.out = c.slab(P.cqa_w, D * 4 * D, nchunk);
+            j.out_bias[0] = c.slab(P.cqa_b, D, nchunk);
+            wb.j[wb.n++] = j;
+        }
+        LAUNCH(launch_wgrad(wb, c.s));
+    }
+    // ---- CQAttention
+    LAUNCH(launch_cq_out_bwd(c.W(p.df1), c.W(p.ve.out), c.W(p.qe.out), c.W(p.Srow), c.W(p.M), c.PK(K.cqa_t), c.W(p.dC),
+                             c.W(p.dc2q), c.W(p.dq2c), c.W(p.dSr), B, T, Lq, c.s));
+    {
+        CqColBwdArgs a;
+        memset(&a, 0, sizeof a);
+        if (!c.dry) {
+            a.C = c.W(p.ve.out); a.Qf = c.W(p.qe.out); a.Srow = c.W(p.Srow); a.Scol = c.W(p.Scol); a.cmask = io->v_mask;
+            a.qmask = io->q_mask; a.alpha = c.W(p.alpha); a.pooled = c.W(p.pooled); a.w4C = c.P(P.w4C); a.w4Q = c.P(P.w4Q);
+            a.w4mlu = c.P(P.w4mlu); a.pool_w = c.P(P.pool_w); a.Wcat = c.P(P.cat_w); a.dc2q = c.W(p.dc2q); a.dq2c = c.W(p.dq2c);
+            a.dSr = c.W(p.dSr); a.df2 = c.W(p.df2); a.dC = c.W(p.dC); a.dQ = c.W(p.dQtot); a.scratch = c.W(p.dSs);
+        }
+        a.T = T; a.Lq = Lq; a.b_off = 0; a.dc = c.drop(SITE_CQ_C); a.dq = c.drop(SITE_CQ_Q);
+        a.p_w4C = c.slab(P.w4C, D, B); a.p_w4Q = c.slab(P.w4Q, D, B); a.p_w4mlu = c.slab(P.w4mlu, D, B);
+        a.p_pool = c.slab(P.pool_w, D, B); a.p_bcat = c.slab(P.cat_b, D, B);
+        const int64_t o = c.part_alloc((int64_t)B * D * D);
+        c.reg(P.cat_w + D, D * D, o, B, D * D, D, 2 * D);          // second half of the (128, 256) weight
+        a.p_W2 = c.part_ptr(o);
+        LAUNCH(launch_cq_col_bwd(a, B, c.s));
+    }
+    // ---- shared feature encoder: video pass, then VisualProjection weight gradient
+    enc_bwd(c, P.fe, K.fe, p.ve, c.dry ? nullptr : c.W(p.dC), nullptr, c.dry ? nullptr : c.W(p.dvf),
+            c.dry ? nullptr : io->v_mask, B, 0);
+    {
+        WgradBatch wb;
+        memset(&wb, 0, sizeof wb);
+        WgradJob j = wjob();
+        if (!c.dry) { j.G[0] = c.W(p.dvf); j.Afull = io->video_features; }
+        j.nG = 1; j.nA = 0; j.K = cf.video_feature_dim; j.R = R; j.drop_on_A = 1; j.dp = c.drop(SITE_VIS);
+        j.out = c.slab(P.va_w, D * cf.video_feature_dim, nchunk);
+        j.out_bias[0] = c.slab(P.va_b, D, nchunk);
+        wb.j[wb.n++] = j;
+        LAUNCH(launch_wgrad(wb, c.s));
+    }
+    // ---- query pass, then the embedding stack
+    enc_bwd(c, P.fe, K.fe, p.qe, c.dry ? nullptr : c.W(p.dQtot), nullptr, c.dry ? nullptr : c.W(p.dqf),
+            c.dry ? nullptr : io->q_mask, B, 1);
+    const int EW = cf.word_dim + 100;
+    LAUNCH(launch_linear_bwd_data(c.W(p.dqf), c.PK(K.emb_t), c.W(p.dE), Rq, EW, c.s));
+    {
+        WgradBatch wb;
+        memset(&wb, 0, sizeof wb);
+        WgradJob j = wjob();
+        if (!c.dry) { j.G[0] = c.W(p.dqf); j.Afull = c.W(p.E); }
+        j.nG = 1; j.nA = 0; j.K = EW; j.R = Rq;
+        j.out = c.slab(P.emb_w, D * EW, nchunk_q);
+        j.out_bias[0] = c.slab(P.emb_b, D, nchunk_q);
+        wb.j[wb.n++] = j;
+        LAUNCH(launch_wgrad(wb, c.s));
+    }
+    {
+        const int nce = (Rq + EMB_CHUNK - 1) / EMB_CHUNK;
+        const int wtot = cf.char_dim * 300;
+        const int64_t ow = c.part_alloc((int64_t)nce * wtot), ob = c.part_alloc((int64_t)nce * 100);
+        const int ch[4] = {10, 20, 30, 40};
+        int wo = 0, bo = 0;
+        for (int i = 0; i < 4; ++i) {
+            const int wn = ch[i] * cf.char_dim * (i + 1);
+            c.reg(P.ccw[i], wn, ow + wo, nce, wtot);
+            c.reg(P.ccb[i], ch[i], ob + bo, nce, 100);
+            wo += wn; bo += ch[i];
+        }
+        float* p_tab = c.slab(P.char_tab, cf.char_size * cf.char_dim, nce);
+        LAUNCH(launch_embed_bwd(c.W(p.dE), io->word_ids, io->char_ids, c.W(p.E), reinterpret_cast<const int8_t*>(c.W(p.argpos)),
+                                c.P(P.char_tab), char_ptrs(c), c.part_ptr(ow), c.part_ptr(ob), p_tab, io->grads + P.unk, Rq,
+                                p.Lc, cf.word_dim, cf.char_dim, cf.char_size, c.drop(SITE_WORD), c.drop(SITE_CHAR), c.s));
+    }
+    LAUNCH(launch_reduce(c.W(p.partial), io->grads, p.segs_dev, p.blk2seg_dev, p.nblocks, c.s));
+}
+
+int build_plan(vsl_handle_s* h, int B, int T, int Lq, int Lc, Plan** out) {
+    const vsl_config& cf = h->cfg;
+    if (B <= 0 || T <= 0 || Lq <= 0) return fail("empty batch (B=%d T=%d Lq=%d)", B, T, Lq);
+    if (T > cf.max_pos_len || Lq > cf.max_pos_len)
+        return fail("sequence length (T=%d, Lq=%d) exceeds max_pos_len=%d: the positional table has no such row "
+                    "(layers_t7.py:196 -- IndexError in the reference)", T, Lq, cf.max_pos_len);
+    if (T > MAX_L) return fail("T=%d > %d clips not supported by the LDS-resident attention kernels", T, MAX_L);
+    if (Lq > MAX_LQ) return fail("Lq=%d > %d query words not supported yet", Lq, MAX_LQ);
+    if (Lc < 4 || Lc > MAX_LC) return fail("Lc=%d must be in [4, %d] (the widest char conv has kernel 4, layers_t7.py:52)", Lc, MAX_LC);
+    Plan* p = new Plan();
+    p->B = B; p->T = T; p->Lq = Lq; p->Lc = Lc;
+    const int64_t R = (int64_t)B * T, Rq = (int64_t)B * Lq;
+    const int H = cf.num_heads, EW = cf.word_dim + 100;
+    Bump al;
+    p->pack = al(h->pack_floats);
+    p->vf = al(R * D); p->E = al(Rq * EW); p->argpos = al((Rq * 100 + 3) / 4); p->qf = al(Rq * D);
+    plan_encoder(al, p->ve, B, T, H); plan_encoder(al, p->qe, B, Lq, H);
+    plan_encoder(al, p->p1, B, T, H); plan_encoder(al, p->p2, B, T, H);
+    p->S = al(R * Lq); p->Srow = al(R * Lq); p->Scol = al(R * Lq); p->M = al(Rq * D); p->alpha = al(Rq);
+    p->pooled = al((int64_t)B * D); p->pb = al((int64_t)B * D); p->cat = al(R * 4 * D);
+    p->f1 = al(R * D); p->f2 = al(R * D); p->gated = al(R * D);
+    p->hid_s = al(R * D); p->hid_e = al(R * D); p->lnf_s = al(R * D); p->lnf_e = al(R * D);
+    p->loss_scratch = al(5 * (int64_t)B + 8);
+    p->gz_s = al(R * D); p->gz_e = al(R * D); p->dfeat_s = al(R * D); p->dfeat_e = al(R * D);
+    p->dxh_s = al(R * D); p->dxh_e = al(R * D); p->g_s1 = al(R * D); p->g_gated = al(R * D);
+    p->t_dr = al(R * D); p->t_dq = al(R * D); p->t_dk = al(R * D); p->t_dv = al(R * D); p->t_Dq = al((int64_t)B * H * T);
+    p->t_go = al(R * D); p->t_du = al(R * D);
+    for (int i = 0; i < 4; ++i) p->t_gz[i] = al(R * D);
+    p->t_ga = al(R * D); p->t_gb = al(R * D);
+    p->df2 = al(R * D); p->df1 = al(R * D); p->dC = al(R * D); p->dc2q = al(R * D); p->dq2c = al(R * D);
+    p->dSr = al(R * Lq); p->dSs = al(R * Lq); p->dQtot = al(Rq * D); p->dvf = al(R * D); p->dqf = al(Rq * D); p->dE = al(Rq * EW);
+    p->partial = al(0);
+    // dry-run the backward to lay out the partial arena and collect the reduction table
+    std::vector<SlabRec> recs;
+    Ctx c{h, p, nullptr, nullptr, true, nullptr};
+    c.recs = &recs;
+    run_backward(c);
+    p->partial_floats = c.part_cur;
+    al(p->partial_floats);
+    p->total = al.cur;
+    // group the records by destination (shared weights are written by up to 4 encoder applications)
+    std::vector<ReduceSeg> segs;
+    std::map<int, int> by_dst;
+    for (const SlabRec& r : recs) {
+        auto it = by_dst.find(r.dst);
+        if (it == by_dst.end()) {
+            ReduceSeg s;
+            memset(&s, 0, sizeof s);
+            s.dst = r.dst; s.n = r.n; s.rl = r.rl; s.ds = r.ds;
+            by_dst[r.dst] = (int)segs.size();
+            segs.push_back(s);
+            it = by_dst.find(r.dst);
+        }
+        ReduceSeg& s = segs[it->second];
+        if (s.n != r.n || s.nsrc >= 4) { delete p; return fail("internal: inconsistent partial slabs for param offset %d", r.dst); }
+        s.src[s.nsrc] = (int)r.src; s.nslabs[s.nsrc] = r.nslabs; s.ss[s.nsrc] = r.ss;
+        ++s.nsrc;
+    }
+    std::vector<int> blk;
+    for (size_t i = 0; i < segs.size(); ++i)
+        for (int o = 0; o < segs[i].n; o += 256) { blk.push_back((int)i); blk.push_back(o); }
+    p->nblocks = (int)blk.size() / 2;
+    HIP_OK(hipMalloc(&p->segs_dev, segs.size() * sizeof(ReduceSeg)));
+    HIP_OK(hipMalloc(&p->blk2seg_dev, blk.size() * sizeof(int)));
+    HIP_OK(hipMemcpy(p->segs_dev, segs.data(), segs.size() * sizeof(ReduceSeg), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(p->blk2seg_dev, blk.data(), blk.size() * sizeof(int), hipMemcpyHostToDevice));
+    *out = p;
+    return 0;
+}
+
+int get_plan(vsl_handle_s* h, int B, int T, int Lq, int Lc, Plan** out) {
+    auto key = std::make_tuple(B, T, Lq, Lc);
+    auto it = h->plans.find(key);
+    if (it != h->plans.end()) { *out = it->second; return 0; }
+    Plan* p = nullptr;
+    if (int rc = build_plan(h, B, T, Lq, Lc, &p)) return rc;
+    h->plans[key] = p;
+    *out = p;
+    return 0;
+}
+
+int check_io(vsl_handle_s* h, const vsl_io* io) {
+    if (!h || !io) return fail("null handle / io");
+    if (!io->params || !io->pad_vec || !io->glove_vec || !io->word_ids || !io->char_ids || !io->video_features ||
+        !io->v_mask || !io->q_mask || !io->h_score || !io->start_logits || !io->end_logits || !io->workspace)
+        return fail("vsl_io has a null device pointer");
+    return 0;
+}
+
+}  // namespace
+
+// =================================================================================================== C ABI
+extern "C" {
+
+const char* vsl_last_error(void) { return g_err.c_str(); }
+
+int vsl_create(const vsl_config* cfg, vsl_handle* out) {
+    if (!cfg || !out) return fail("null argument");
+    if (cfg->dim != D) return fail("configs.dim=%d: the HIP kernels are specialised for dim=128", cfg->dim);
+    if (cfg->num_heads <= 0 || cfg->dim % cfg->num_heads != 0)
+        return fail("The channels (%d) is not a multiple of attention heads (%d)", cfg->dim, cfg->num_heads);   // layers_t7.py:146
+    if (cfg->dim / cfg->num_heads != HD) return fail("num_heads=%d: the attention kernels are specialised for head size 16 (8 heads)", cfg->num_heads);
+    if (cfg->predictor != 1) return fail("predictor='rnn' (DynamicRNN, layers_t7.py:302-313) is not implemented in HIP yet; use 'transformer'");
+    if (cfg->video_feature_dim <= 0 || cfg->video_feature_dim % 8) return fail("video_feature_dim=%d must be a positive multiple of 8", cfg->video_feature_dim);
+    if ((cfg->word_dim + 100) % 8) return fail("word_dim + 100 = %d must be a multiple of 8", cfg->word_dim + 100);
+    if (cfg->char_dim <= 0 || cfg->char_dim > 64) return fail("char_dim=%d must be in [1, 64]", cfg->char_dim);
+    if (cfg->char_size <= 0 || cfg->char_size * cfg->char_dim > 16384) return fail("char table too large for the LDS accumulator");
+    if (cfg->max_pos_len <= 0 || cfg->word_size < 2) return fail("bad max_pos_len / word_size");
+    if (cfg->drop_rate < 0.f || cfg->drop_rate >= 1.f) return fail("drop_rate must be in [0, 1)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("no HIP device available: libvslnet_hip needs an MI355X (gfx950)");
+    vsl_handle_s* h = new vsl_handle_s();
+    h->cfg = *cfg;
+    build_params(h);
+    build_packs(h);
+    if (hipMalloc(&h->jobs_dev, h->jobs.size() * sizeof(PackJob)) != hipSuccess ||
+        hipMemcpy(h->jobs_dev, h->jobs.data(), h->jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice) != hipSuccess) {
+        delete h;
+        return fail("hipMalloc/hipMemcpy of the pack table failed");
+    }
+    *out = h;
+    return 0;
+}
+
+int vsl_destroy(vsl_handle h) {
+    if (!h) return 0;
+    for (auto& kv : h->plans) {
+        if (kv.second->segs_dev) (void)hipFree(kv.second->segs_dev);
+        if (kv.second->blk2seg_dev) (void)hipFree(kv.second->blk2seg_dev);
+        delete kv.second;
+    }
+    if (h->jobs_dev) (void)hipFree(h->jobs_dev);
+    delete h;
+    return 0;
+}
+
+int vsl_param_count(vsl_handle h) { return h ? (int)h->params.size() : 0; }
+int64_t vsl_param_floats(vsl_handle h) { return h ? h->param_floats : 0; }
+int vsl_param_info(vsl_handle h, int index, char* name, int name_cap, int64_t* offset, int64_t* numel, int32_t* ndim,
+                   int64_t dims[4]) {
+    if (!h || index < 0 || index >= (int)h->params.size()) return fail("bad parameter index");
+    const ParamInfo& p = h->params[index];
+    if (name && name_cap > 0) { strncpy(name, p.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+    if (offset) *offset = p.off;
+    if (numel) *numel = p.numel;
+    if (ndim) *ndim = p.ndim;
+    if (dims) for (int i = 0; i < 4; ++i) dims[i] = i < p.ndim ? p.dims[i] : 1;
+    return 0;
+}
+
+int vsl_workspace_floats(vsl_handle h, int B, int T, int Lq, int Lc, int64_t* out) {
+    if (!h || !out) return fail("null argument");
+    Plan* p = nullptr;
+    if (int rc = get_plan(h, B, T, Lq, Lc, &p)) return rc;
+    *out = p->total;
+    return 0;
+}
+
+int64_t vsl_workspace_offset(vsl_handle h, int B, int T, int Lq, int Lc, const char* name) {
+    Plan* p = nullptr;
+    if (!h || !name || get_plan(h, B, T, Lq, Lc, &p)) return -1;
+    const std::string n = name;
+    const std::pair<const char*, int64_t> tab[] = {
+        {"video_affine", p->vf}, {"embedding_net", p->qf}, {"emb_concat", p->E}, {"venc", p->ve.out}, {"qenc", p->qe.out},
+        {"venc_x0", p->ve.x0}, {"venc_conv0", p->ve.y[0]}, {"venc_conv3", p->ve.y[3]}, {"venc_q", p->ve.q}, {"venc_k", p->ve.k},
+        {"venc_v", p->ve.v}, {"venc_att", p->ve.att}, {"venc_r", p->ve.r}, {"qenc_conv3", p->qe.y[3]}, {"qenc_att", p->qe.att},
+        {"cq_score", p->S}, {"cq_srow", p->Srow}, {"cq_scol", p->Scol}, {"cq_M", p->M}, {"cq_attention", p->f1},
+        {"cq_concat", p->f2}, {"gated", p->gated}, {"pred_s", p->p1.out}, {"pred_e", p->p2.out},
+        {"d_gated", p->g_gated}, {"d_venc", p->dC}, {"d_qenc", p->dQtot}, {"d_video_affine", p->dvf}, {"d_embedding_net", p->dqf},
+        {"d_pred_s", p->g_s1}, {"d_cq_concat", p->df2}, {"d_cq_attention", p->df1}, {"d_emb_concat", p->dE}};
+    for (auto& kv : tab) if (n == kv.first) return kv.second;
+    return -1;
+}
+
+int vsl_forward(vsl_handle h, const vsl_io* io, void* hip_stream) {
+    if (int rc = check_io(h, io)) return rc;
+    Plan* p = nullptr;
+    if (int rc = get_plan(h, io->B, io->T, io->Lq, io->Lc, &p)) return rc;
+    Ctx c{h, p, io, (hipStream_t)hip_stream, false, io->workspace};
+    run_forward(c);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int vsl_loss(vsl_handle h, const vsl_io* io, const vsl_loss_io* l, void* hip_stream) {
+    if (!h || !io || !l) return fail("null argument");
+    if (!l->start_labels || !l->end_labels || !l->h_labels || !l->losses) return fail("vsl_loss_io has a null pointer");
+    if ((l->d_h_score == nullptr) != (l->d_start_logits == nullptr) || (l->d_h_score == nullptr) != (l->d_end_logits == nullptr))
+        return fail("gradient seed outputs must be all set or all null");
+    Plan* p = nullptr;
+    if (int rc = get_plan(h, io->B, io->T, io->Lq, io->Lc, &p)) return rc;
+    launch_loss(io->start_logits, io->end_logits, io->h_score, l->start_labels, l->end_labels, l->h_labels, io->v_mask, io->B,
+                io->T, l->inv_batch, l->mask_sum, l->w_loc, l->w_highlight, io->workspace + p->loss_scratch, l->losses,
+                l->d_start_logits, l->d_end_logits, l->d_h_score, (hipStream_t)hip_stream);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int vsl_backward(vsl_handle h, const vsl_io* io, void* hip_stream) {
+    if (int rc = check_io(h, io)) return rc;
+    if (!io->d_start_logits || !io->d_end_logits || !io->grads) return fail("vsl_backward needs d_start_logits, d_end_logits and grads");
+    Plan* p = nullptr;
+    if (int rc = get_plan(h, io->B, io->T, io->Lq, io->Lc, &p)) return rc;
+    Ctx c{h, p, io, (hipStream_t)hip_stream, false, io->workspace};
+    run_backward(c);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int vsl_extract_index(vsl_handle h, const float* start_logits, const float* end_logits, int B, int T, int64_t* start_index,
+                      int64_t* end_index, void* hip_stream) {
+    if (!h || !start_logits || !end_logits || !start_index || !end_index) return fail("null argument");
+    if (T > 8192) return fail("T too large");
+    launch_extract_index(start_logits, end_logits, start_index, end_index, B, T, (hipStream_t)hip_stream);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

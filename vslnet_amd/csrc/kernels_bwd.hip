@@ -1,0 +1,1260 @@
+// Loss / eval / backward kernels of the VSLNet hot path (gfx950).  The reference has no hand-written backward: it is
+// whatever autograd derives from /root/reference/model/layers_t7.py; each kernel names the forward lines it
+// differentiates.  Parameter gradients are produced as per-tile / per-row-chunk PARTIAL SLABS and summed by
+// k_reduce into the flat gradient bucket (deterministic, no float atomics on global memory).
+#include "common.hpp"
+#include "launch.hpp"
+
+namespace vsl {
+
+// =========================================================================================================
+// a13 + a16 losses (layers_t7.py:291-299, 365-369) and their seeds d(total)/d(logits), d(total)/d(h_score)
+//   total = w_loc * (CE(start) + CE(end)) + w_hl * highlight      (main_t7.py:105-107 uses 1, 5)
+//   scratch layout (floats): [0,B) lse_s | [B,2B) lse_e | [2B,3B) ce | [3B,4B) hl numerator | [4B,5B) mask sum
+// =========================================================================================================
+__device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) {
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    v = is_max ? wave_max(v) : wave_sum(v);
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    const int nw = blockDim.x >> 6;
+    float r = red[0];
+    for (int i = 1; i < nw; ++i) r = is_max ? fmaxf(r, red[i]) : r + red[i];
+    return r;
+}
+__global__ __launch_bounds__(256) void k_loss_a(const float* __restrict__ sl, const float* __restrict__ el,
+                                                const float* __restrict__ h, const int64_t* __restrict__ s_lab,
+                                                const int64_t* __restrict__ e_lab, const int64_t* __restrict__ h_lab,
+                                                const float* __restrict__ vmask, int B, int T, float* __restrict__ scratch) {
+    __shared__ float red[8];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* s = sl + (size_t)b * T;
+    const float* e = el + (size_t)b * T;
+    float ms = -3.0e38f, me = -3.0e38f;
+    for (int t = tid; t < T; t += 256) { ms = fmaxf(ms, s[t]); me = fmaxf(me, e[t]); }
+    ms = block_reduce(ms, red, true);
+    me = block_reduce(me, red, true);
+    float ss = 0.f, se = 0.f, num = 0.f, den = 0.f;
+    for (int t = tid; t < T; t += 256) {
+        ss += expf(s[t] - ms);
+        se += expf(e[t] - me);
+        const float m = vmask[(size_t)b * T + t];
+        const float y = (float)h_lab[(size_t)b * T + t];
+        const float p = h[(size_t)b * T + t];
+        const float wgt = y == 0.f ? 1.f : 2.f * y;                         // (:293)
+        const float lp = fmaxf(logf(p), -100.f), lq = fmaxf(logf(1.f - p), -100.f);   // BCELoss log clamp
+        num += -(y * lp + (1.f - y) * lq) * wgt * m;
+        den += m;
+    }
+    ss = block_reduce(ss, red, false);
+    se = block_reduce(se, red, false);
+    num = block_reduce(num, red, false);
+    den = block_reduce(den, red, false);
+    if (tid == 0) {
+        const float lses = ms + logf(ss), lsee = me + logf(se);
+        scratch[b] = lses;
+        scratch[B + b] = lsee;
+        scratch[2 * B + b] = (lses - s[s_lab[b]]) + (lsee - e[e_lab[b]]);
+        scratch[3 * B + b] = num;
+        scratch[4 * B + b] = den;
+    }
+}
+__global__ __launch_bounds__(256) void k_loss_b(int B, float inv_batch, float mask_sum_override, float w_loc, float w_hl,
+                                                const float* __restrict__ scratch, float* __restrict__ losses) {
+    __shared__ float red[8];
+    float ce = 0.f, num = 0.f, den = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) { ce += scratch[2 * B + b]; num += scratch[3 * B + b]; den += scratch[4 * B + b]; }
+    ce = block_reduce(ce, red, false);
+    num = block_reduce(num, red, false);
+    den = block_reduce(den, red, false);
+    if (threadIdx.x == 0) {
+        const float d = mask_sum_override > 0.f ? mask_sum_override : den;
+        const float loc = ce * inv_batch;                                   // CrossEntropyLoss(mean) twice (:367-368)
+        const float hl = num / (d + 1e-12f);                                // (:298)
+        losses[0] = loc; losses[1] = hl; losses[2] = w_loc * loc + w_hl * hl; losses[3] = d;
+    }
+}
+__global__ __launch_bounds__(256) void k_loss_c(const float* __restrict__ sl, const float* __restrict__ el,
+                                                const float* __restrict__ h, const int64_t* __restrict__ s_lab,
+                                                const int64_t* __restrict__ e_lab, const int64_t* __restrict__ h_lab,
+                                                const float* __restrict__ vmask, int B, int T, float inv_batch, float w_loc,
+                                                float w_hl, const float* __restrict__ scratch,
+                                                const float* __restrict__ losses, float* __restrict__ d_sl,
+                                                float* __restrict__ d_el, float* __restrict__ d_h) {
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    const size_t i = (size_t)b * T + t;
+    const float cs = w_loc * inv_batch;
+    d_sl[i] = cs * (expf(sl[i] - scratch[b]) - (t == (int)s_lab[b] ? 1.f : 0.f));
+    d_el[i] = cs * (expf(el[i] - scratch[B + b]) - (t == (int)e_lab[b] ? 1.f : 0.f));
+    const float y = (float)h_lab[i], p = h[i], m = vmask[i];
+    const float wgt = y == 0.f ? 1.f : 2.f * y;
+    // d BCE / dp = (p - y) / max(p (1 - p), 1e-12)   (torch's binary_cross_entropy_backward)
+    d_h[i] = w_hl * wgt * m / (losses[3] + 1e-12f) * (p - y) / fmaxf(p * (1.f - p), 1e-12f);
+}
+void launch_loss(const float* sl, const float* el, const float* h, const int64_t* s_lab, const int64_t* e_lab,
+                 const int64_t* h_lab, const float* vmask, int B, int T, float inv_batch, float mask_sum_override,
+                 float w_loc, float w_hl, float* scratch, float* losses, float* d_sl, float* d_el, float* d_h,
+                 hipStream_t s) {
+    hipLaunchKernelGGL(k_loss_a, dim3(B), dim3(256), 0, s, sl, el, h, s_lab, e_lab, h_lab, vmask, B, T, scratch);
+    hipLaunchKernelGGL(k_loss_b, dim3(1), dim3(256), 0, s, B, inv_batch, mask_sum_override, w_loc, w_hl, scratch, losses);
+    if (d_sl)
+        hipLaunchKernelGGL(k_loss_c, dim3((T + 255) / 256, B), dim3(256), 0, s, sl, el, h, s_lab, e_lab, h_lab, vmask, B, T,
+                           inv_batch, w_loc, w_hl, scratch, losses, d_sl, d_el, d_h);
+}
+
+// a17 extract_index (:355-363): argmax over the upper-triangular outer product of the two softmaxes, computed as
+//   start = argmax_i ps[i] * max_{j>=i} pe[j],  end = argmax_j pe[j] * max_{i<=j} ps[i]   (no (B,T,T) tensor)
+__global__ __launch_bounds__(256) void k_extract_index(const float* __restrict__ sl, const float* __restrict__ el,
+                                                       int64_t* __restrict__ si, int64_t* __restrict__ ei, int T) {
+    extern __shared__ float sm[];
+    float* ps = sm;
+    float* pe = sm + T;
+    float* red = pe + T;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* s = sl + (size_t)b * T;
+    const float* e = el + (size_t)b * T;
+    float ms = -3.0e38f, me = -3.0e38f;
+    for (int t = tid; t < T; t += 256) { ms = fmaxf(ms, s[t]); me = fmaxf(me, e[t]); }
+    ms = block_reduce(ms, red, true);
+    me = block_reduce(me, red, true);
+    float ss = 0.f, se = 0.f;
+    for (int t = tid; t < T; t += 256) {
+        const float a = expf(s[t] - ms), c = expf(e[t] - me);
+        ps[t] = a; pe[t] = c; ss += a; se += c;
+    }
+    ss = block_reduce(ss, red, false);
+    se = block_reduce(se, red, false);
+    for (int t = tid; t < T; t += 256) { ps[t] = ps[t] / ss; pe[t] = pe[t] / se; }
+    __syncthreads();
+    if (tid == 0) {          // start: scan from the right keeping the suffix max of pe
+        float suf = 0.f, best = -1.f;
+        int bi = 0;
+        for (int i = T - 1; i >= 0; --i) {
+            suf = fmaxf(suf, pe[i]);
+            const float v = ps[i] * suf;
+            if (v >= best) { best = v; bi = i; }       // >= while scanning right-to-left keeps the FIRST maximal index
+        }
+        si[b] = bi;
+    } else if (tid == 64) {  // end: scan from the left keeping the prefix max of ps
+        float pre = 0.f, best = -1.f;
+        int bi = 0;
+        for (int j = 0; j < T; ++j) {
+            pre = fmaxf(pre, ps[j]);
+            const float v = pe[j] * pre;
+            if (v > best) { best = v; bi = j; }
+        }
+        ei[b] = bi;
+    }
+}
+void launch_extract_index(const float* sl, const float* el, int64_t* si, int64_t* ei, int B, int T, hipStream_t s) {
+    hipLaunchKernelGGL(k_extract_index, dim3(B), dim3(256), (size_t)(2 * T + 8) * sizeof(float), s, sl, el, si, ei, T);
+}
+
+// =========================================================================================================
+// shared epilogue:  Ts (32 x 128 LDS tile, grad wrt a LayerNorm OUTPUT, dropout already applied)
+//   -> LayerNorm backward against the raw input rows `xin` -> (+ residual grad) -> out ; gamma/beta partial slabs.
+//   red: LDS scratch of 4 * 256 floats.
+// =========================================================================================================
+__device__ __forceinline__ void ln_bwd_rows(const float* Ts, const float* __restrict__ xin, const float* __restrict__ resid,
+                                            const float* __restrict__ extra, const float* __restrict__ ln_g,
+                                            float* __restrict__ out,
+                                            float* __restrict__ p_lng, float* __restrict__ p_lnb, float* red, int r0, int R) {
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    float ag0 = 0.f, ag1 = 0.f, ab0 = 0.f, ab1 = 0.f;
+    for (int rr = w; rr < TILE_M; rr += 4) {
+        const int r = r0 + rr;
+        if (r >= R) continue;                                    // wave-uniform
+        const float x0 = xin[(size_t)r * D + lane], x1 = xin[(size_t)r * D + lane + 64];
+        const float dy0 = Ts[rr * LDP + lane], dy1 = Ts[rr * LDP + lane + 64];
+        float dx0, dx1, xh0, xh1;
+        ln_row_bwd(x0, x1, dy0, dy1, ln_g, dx0, dx1, xh0, xh1);
+        ag0 += dy0 * xh0; ag1 += dy1 * xh1; ab0 += dy0; ab1 += dy1;
+        if (resid) { dx0 += resid[(size_t)r * D + lane]; dx1 += resid[(size_t)r * D + lane + 64]; }
+        if (extra) { dx0 += extra[(size_t)r * D + lane]; dx1 += extra[(size_t)r * D + lane + 64]; }
+        out[(size_t)r * D + lane] = dx0;
+        out[(size_t)r * D + lane + 64] = dx1;
+    }
+    __syncthreads();
+    red[w * 256 + lane] = ag0; red[w * 256 + 64 + lane] = ag1;
+    red[w * 256 + 128 + lane] = ab0; red[w * 256 + 192 + lane] = ab1;
+    __syncthreads();
+    {
+        const float v = red[tid] + red[256 + tid] + red[512 + tid] + red[768 + tid];
+        if (tid < 128) p_lng[(size_t)blockIdx.x * D + tid] = v;
+        else p_lnb[(size_t)blockIdx.x * D + tid - 128] = v;
+    }
+}
+
+// =========================================================================================================
+// heads backward (a14, :349-352): dlogit -> dz = dlogit * w1 * (hid > 0) -> [dLN(feat) | dx] = dz W0 ;
+//   LN backward -> dfeat.  blockIdx.y selects start / end.
+// =========================================================================================================
+__global__ __launch_bounds__(256) void k_head_bwd(HeadBwdArgs a0, HeadBwdArgs a1, int R) {
+    __shared__ __attribute__((aligned(16))) float Gs[TILE_M * LDP];
+    __shared__ __attribute__((aligned(16))) float Hs[TILE_M * LDP];
+    __shared__ float red[1024];
+    __shared__ float dl[TILE_M];
+    const HeadBwdArgs a = blockIdx.y == 0 ? a0 : a1;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int r0 = blockIdx.x * TILE_M;
+    if (tid < TILE_M) dl[tid] = r0 + tid < R ? a.dlogit[r0 + tid] : 0.f;
+    load_tile128(Hs, a.hid, r0, TILE_M, R);
+    __syncthreads();
+    for (int e = tid; e < TILE_M * D; e += 256) {
+        const int rr = e >> 7, c = e & 127;
+        const float hv = Hs[rr * LDP + c];
+        const float dz = hv > 0.f ? dl[rr] * a.w1[c] : 0.f;
+        Gs[rr * LDP + c] = dz;
+        if (r0 + rr < R) a.gz[(size_t)(r0 + rr) * D + c] = dz;
+    }
+    __syncthreads();
+    {   // bias / w1 partials: threads 0..127 -> db0[c], 128..255 -> dw1[c]
+        const int c = tid & 127;
+        float acc = 0.f;
+        if (tid < 128) { for (int rr = 0; rr < TILE_M; ++rr) acc += Gs[rr * LDP + c]; a.p_b0[(size_t)blockIdx.x * D + c] = acc; }
+        else { for (int rr = 0; rr < TILE_M; ++rr) acc += dl[rr] * Hs[rr * LDP + c]; a.p_w1[(size_t)blockIdx.x * D + c] = acc; }
+        if (tid == 0) { float sdl = 0.f; for (int rr = 0; rr < TILE_M; ++rr) sdl += dl[rr]; a.p_b1[blockIdx.x] = sdl; }
+    }
+    f32x16 acc[2];
+    zero_acc(acc);
+    gemm32<2>(Gs, LDP, D, a.W0Tpack, 2 * D, 32 * w, D, acc);
+    __syncthreads();                       // everyone is done reading Hs/Gs
+    const int col = 32 * w + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r, lane);
+        Hs[row * LDP + col] = acc[0][r];                           // grad wrt LN(feat)
+        if (r0 + row < R) a.dx[(size_t)(r0 + row) * D + col] = acc[1][r];
+    }
+    __syncthreads();
+    if (a.ln_g) {
+        ln_bwd_rows(Hs, a.feat, nullptr, nullptr, a.ln_g, a.dfeat, a.p_lng, a.p_lnb, red, r0, R);
+    } else {
+        for (int e = tid; e < TILE_M * D; e += 256) {
+            const int rr = e >> 7, c = e & 127;
+            if (r0 + rr < R) a.dfeat[(size_t)(r0 + rr) * D + c] = Hs[rr * LDP + c];
+        }
+    }
+}
+void launch_head_bwd(const HeadBwdArgs& a0, const HeadBwdArgs& a1, int R, hipStream_t s) {
+    hipLaunchKernelGGL(k_head_bwd, dim3((R + TILE_M - 1) / TILE_M, 2), dim3(256), 0, s, a0, a1, R);
+}
+
+// =========================================================================================================
+// generic weight gradient  dW[n][k] = sum_r G[r][n] A[r][k]   (+ bias = column sums of G)
+//   grid = (k tiles of 128, row chunks of WG_ROWS, job * 3 + G block); each workgroup writes one partial slab tile.
+// =========================================================================================================
+__global__ __launch_bounds__(256) void k_wgrad(WgradBatch wb) {
+    __shared__ __attribute__((aligned(16))) float Gs[TILE_M * LDP];
+    __shared__ __attribute__((aligned(16))) float As[TILE_M * LDP];
+    const int ji = blockIdx.z / 3, gb = blockIdx.z % 3;
+    const WgradJob& j = wb.j[ji];
+    const int kt = blockIdx.x, ch = blockIdx.y;
+    const int K = j.K, R = j.R;
+    if (gb >= j.nG || kt * 128 >= K || ch * WG_ROWS >= R) return;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const float* G = j.G[gb];
+    f32x16 acc[4];
+    zero_acc(acc);
+    float bsum = 0.f;
+    const int rbeg = ch * WG_ROWS, rend = min(R, rbeg + WG_ROWS);
+    for (int rs = rbeg; rs < rend; rs += TILE_M) {
+        for (int e = tid; e < TILE_M * 32; e += 256) {
+            const int rr = e >> 5, c = (e & 31) * 4;
+            const int r = rs + rr;
+            float4 gv = make_float4(0.f, 0.f, 0.f, 0.f), av = gv;
+            if (r < rend) {
+                gv = *reinterpret_cast<const float4*>(G + (size_t)r * D + c);
+                if (j.nA > 0) {
+                    av = *reinterpret_cast<const float4*>(j.A[kt] + (size_t)r * D + c);
+                } else if (kt * 128 + c < K) {
+                    const size_t off = (size_t)r * K + kt * 128 + c;
+                    av = *reinterpret_cast<const float4*>(j.Afull + off);
+                    if (j.drop_on_A && j.dp.thresh) {
+                        const uint32_t base = (uint32_t)off;
+                        av.x *= drop_mul(j.dp, base); av.y *= drop_mul(j.dp, base + 1);
+                        av.z *= drop_mul(j.dp, base + 2); av.w *= drop_mul(j.dp, base + 3);
+                    }
+                }
+            }
+            *reinterpret_cast<float4*>(&Gs[rr * LDP + c]) = gv;
+            *reinterpret_cast<float4*>(&As[rr * LDP + c]) = av;
+        }
+        __syncthreads();
+        gemm_tn<4>(Gs, LDP, 32 * w, As, LDP, 0, TILE_M, acc);
+        if (kt == 0 && tid < 128) {
+#pragma unroll 8
+            for (int rr = 0; rr < TILE_M; ++rr) bsum += Gs[rr * LDP + tid];
+        }
+        __syncthreads();
+    }
+    const int N = 128 * j.nG;
+    float* out = j.out + ((size_t)ch * N + gb * 128) * K;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int k = kt * 128 + 32 * t + (lane & 31);
+        if (k < K) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = 32 * w + acc_row(r, lane);
+                out[(size_t)n * K + k] = acc[t][r];
+            }
+        }
+    }
+    if (kt == 0 && tid < 128 && j.out_bias[gb]) j.out_bias[gb][(size_t)ch * D + tid] = bsum;
+}
+void launch_wgrad(const WgradBatch& wb, hipStream_t s) {
+    int kt = 1, ch = 1;
+    for (int i = 0; i < wb.n; ++i) {
+        kt = max(kt, (wb.j[i].K + 127) / 128);
+        ch = max(ch, (wb.j[i].R + WG_ROWS - 1) / WG_ROWS);
+    }
+    hipLaunchKernelGGL(k_wgrad, dim3(kt, ch, wb.n * 3), dim3(256), 0, s, wb);
+}
+
+// =========================================================================================================
+// conv block backward (a7, :133-139), two kernels per layer:
+//  (1) k_conv_bwd_gemm : dz = dy * dropmask * relu-bit  (saved to gz for the weight gradient) ; du = dz Wp
+//  (2) k_conv_bwd_dwln : dv = depthwise^T(du) ; dx = dy + LN^T(dv) ; partials for gamma, beta and the depthwise taps
+// =========================================================================================================
+__global__ __launch_bounds__(256) void k_conv_bwd_gemm(const float* __restrict__ dy, const uint32_t* __restrict__ relu_mask,
+                                                       const float* __restrict__ WTpack, float* __restrict__ gz,
+                                                       float* __restrict__ du, int R, Drop dp) {
+    __shared__ __attribute__((aligned(16))) float Gs[TILE_M * LDP];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int r0 = blockIdx.x * TILE_M;
+    for (int e = tid; e < TILE_M * 32; e += 256) {
+        const int rr = e >> 5, c = (e & 31) * 4;
+        const int r = r0 + rr;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < R) {
+            v = *reinterpret_cast<const float4*>(dy + (size_t)r * D + c);
+            const uint32_t bits = relu_mask[(size_t)r * 4 + (c >> 5)] >> (c & 31);
+            const uint32_t base = (uint32_t)(r * D + c);
+            v.x = (bits & 1u) ? v.x * drop_mul(dp, base) : 0.f;
+            v.y = (bits & 2u) ? v.y * drop_mul(dp, base + 1) : 0.f;
+            v.z = (bits & 4u) ? v.z * drop_mul(dp, base + 2) : 0.f;
+            v.w = (bits & 8u) ? v.w * drop_mul(dp, base + 3) : 0.f;
+            *reinterpret_cast<float4*>(gz + (size_t)r * D + c) = v;
+        }
+        *reinterpret_cast<float4*>(&Gs[rr * LDP + c]) = v;
+    }
+    __syncthreads();
+    f32x16 acc[1];
+    zero_acc(acc);
+    gemm32<1>(Gs, LDP, D, WTpack, D, 32 * w, 0, acc);
+    const int col = 32 * w + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int gr = r0 + acc_row(r, lane);
+        if (gr < R) du[(size_t)gr * D + col] = acc[0][r];
+    }
+}
+void launch_conv_bwd_gemm(const float* dy, const uint32_t* relu_mask, const float* WTpack, float* gz, float* du, int R,
+                          Drop dp, hipStream_t s) {
+    hipLaunchKernelGGL(k_conv_bwd_gemm, dim3((R + TILE_M - 1) / TILE_M), dim3(256), 0, s, dy, relu_mask, WTpack, gz, du, R, dp);
+}
+
+__global__ __launch_bounds__(256) void k_conv_bwd_dwln(const float* __restrict__ du, const float* __restrict__ xin,
+                                                       const float* __restrict__ dy, const float* __restrict__ ln_g,
+                                                       const float* __restrict__ ln_b, const float* __restrict__ dw_w,
+                                                       const float* __restrict__ extra, float* __restrict__ dx,
+                                                       float* __restrict__ p_lng,
+                                                       float* __restrict__ p_lnb, float* __restrict__ p_dw, int R, int L) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NH = TILE_M + 2 * HALO;
+    float* DUs = smem;                       // [38][LDP] du with halo
+    float* Vs = DUs + NH * LDP;              // [38][LDP] LN(x') with halo (forward recompute)
+    float* Ts = Vs + NH * LDP;               // [32][LDP] dv = grad wrt LN output
+    float* red = Ts + TILE_M * LDP;          // [1024]
+    const int tid = threadIdx.x, w = tid >> 6;
+    const int r0 = blockIdx.x * TILE_M;
+    load_tile128(DUs, du, r0 - HALO, NH, R);
+    load_tile128(Vs, xin, r0 - HALO, NH, R);
+    __syncthreads();
+    for (int rr = w; rr < NH; rr += 4) {
+        float mu, rs;
+        ln_row_inplace(Vs + rr * LDP, ln_g, ln_b, mu, rs);
+    }
+    __syncthreads();
+    {
+        const int c = tid & 127, hb = (tid >> 7) * 16;
+        float wk[DWK], gw[DWK];
+#pragma unroll
+        for (int k = 0; k < DWK; ++k) { wk[k] = dw_w[c * DWK + k]; gw[k] = 0.f; }
+        for (int rr = hb; rr < hb + 16; ++rr) {
+            const int r = r0 + rr;
+            const int t = r % L;
+            float dv = 0.f;
+            const float duc = r < R ? DUs[(rr + HALO) * LDP + c] : 0.f;
+#pragma unroll
+            for (int k = 0; k < DWK; ++k) {
+                // forward: u[t] += w[k] v[t + k - 3]  =>  dv[t] += w[k] du[t - k + 3] ; dw[k] += du[t] v[t + k - 3]
+                const int ts = t - k + HALO;
+                if (ts >= 0 && ts < L) dv += wk[k] * DUs[(rr + 2 * HALO - k) * LDP + c];
+                const int tv = t + k - HALO;
+                if (tv >= 0 && tv < L) gw[k] += duc * Vs[(rr + k) * LDP + c];
+            }
+            Ts[rr * LDP + c] = dv;
+        }
+        // combine the two row halves of each channel, then write the depthwise-tap partial slab [tile][128*7]
+#pragma unroll
+        for (int k = 0; k < DWK; ++k) red[(tid >> 7) * 896 + c * DWK + k] = gw[k];
+    }
+    __syncthreads();
+    for (int e = tid; e < D * DWK; e += 256) p_dw[(size_t)blockIdx.x * D * DWK + e] = red[e] + red[896 + e];
+    __syncthreads();
+    ln_bwd_rows(Ts, xin, dy, extra, ln_g, dx, p_lng, p_lnb, red, r0, R);
+}
+void launch_conv_bwd_dwln(const float* du, const float* xin, const float* dy, const float* ln_g, const float* ln_b,
+                          const float* dw_w, const float* extra, float* dx, float* p_lng, float* p_lnb, float* p_dw,
+                          int R, int L, hipStream_t s) {
+    const size_t shm = (size_t)((2 * (TILE_M + 2 * HALO) + TILE_M) * LDP + 1792) * sizeof(float);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)k_conv_bwd_dwln, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr = true; }
+    hipLaunchKernelGGL(k_conv_bwd_dwln, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm, s, du, xin, dy, ln_g, ln_b, dw_w, extra,
+                       dx, p_lng, p_lnb, p_dw, R, L);
+}
+
+// =========================================================================================================
+// MHA block backward (a8, :167-190)
+//  k_attn_out_bwd : do = dy * m5 ; dh2 = do Wo ; dr = dy + LN2^T(dh2 * m4)
+//  k_attn_bwd_dq / k_attn_bwd_dkv : attention core (recompute P from Q, K and the saved LSE)
+//  k_qkv_bwd      : dh1 = [dQ|dK|dV] [Wq;Wk;Wv] ; dx = dr + LN1^T(dh1 * m1)
+// =========================================================================================================
+__global__ __launch_bounds__(256) void k_attn_out_bwd(const float* __restrict__ dy, const float* __restrict__ r_in,
+                                                      const float* __restrict__ ln_g, const float* __restrict__ WTpack,
+                                                      float* __restrict__ g_o, float* __restrict__ dr,
+                                                      float* __restrict__ p_lng, float* __restrict__ p_lnb, int R, Drop d4,
+                                                      Drop d5) {
+    __shared__ __attribute__((aligned(16))) float Gs[TILE_M * LDP];
+    __shared__ float red[1024];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int r0 = blockIdx.x * TILE_M;
+    for (int e = tid; e < TILE_M * 32; e += 256) {
+        const int rr = e >> 5, c = (e & 31) * 4;
+        const int r = r0 + rr;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < R) {
+            v = *reinterpret_cast<const float4*>(dy + (size_t)r * D + c);
+            if (d5.thresh) {
+                const uint32_t base = (uint32_t)(r * D + c);
+                v.x *= drop_mul(d5, base); v.y *= drop_mul(d5, base + 1);
+                v.z *= drop_mul(d5, base + 2); v.w *= drop_mul(d5, base + 3);
+            }
+            if (g_o) *reinterpret_cast<float4*>(g_o + (size_t)r * D + c) = v;
+        }
+        *reinterpret_cast<float4*>(&Gs[rr * LDP + c]) = v;
+    }
+    __syncthreads();
+    f32x16 acc[1];
+    zero_acc(acc);
+    gemm32<1>(Gs, LDP, D, WTpack, D, 32 * w, 0, acc);
+    __syncthreads();
+    const int col = 32 * w + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r, lane);
+        Gs[row * LDP + col] = acc[0][r] * drop_mul(d4, (uint32_t)((r0 + row) * D + col));
+    }
+    __syncthreads();
+    ln_bwd_rows(Gs, r_in, dy, nullptr, ln_g, dr, p_lng, p_lnb, red, r0, R);
+}
+void launch_attn_out_bwd(const float* dy, const float* r, const float* ln_g, const float* WTpack, float* g_o, float* dr,
+                         float* p_lng, float* p_lnb, int R, Drop d4, Drop d5, hipStream_t s) {
+    hipLaunchKernelGGL(k_attn_out_bwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), 0, s, dy, r, ln_g, WTpack, g_o, dr, p_lng,
+                       p_lnb, R, d4, d5);
+}
+
+// dQ: wave owns 16 queries (lane: query qi = lane & 15, key group g = lane >> 4), K/V head slices in LDS.
+__global__ __launch_bounds__(256) void k_attn_bwd_dq(const float* __restrict__ Q, const float* __restrict__ K,
+                                                     const float* __restrict__ V, const float* __restrict__ att,
+                                                     const float* __restrict__ dr, const float* __restrict__ lse,
+                                                     const float* __restrict__ mask, float* __restrict__ dQ,
+                                                     float* __restrict__ Dq, int L, int H, int b_off, Drop d2, Drop d3) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int Lp = (L + 15) & ~15;
+    const int kst = head_slice_stride(Lp);
+    float* Ks = smem;
+    float* Vs = Ks + Lp * kst;
+    float* Mb = Vs + Lp * kst;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const size_t rowbase = (size_t)b * L;
+    for (int e = tid; e < Lp * 4; e += 256) {
+        const int key = e >> 2, c4 = (e & 3) * 4;
+        float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+        if (key < L) {
+            kv = *reinterpret_cast<const float4*>(K + (rowbase + key) * D + h * HD + c4);
+            vv = *reinterpret_cast<const float4*>(V + (rowbase + key) * D + h * HD + c4);
+        }
+        *reinterpret_cast<float4*>(&Ks[key * kst + c4]) = kv;
+        *reinterpret_cast<float4*>(&Vs[key * kst + c4]) = vv;
+    }
+    for (int key = tid; key < Lp; key += 256) Mb[key] = key < L ? (1.0f - mask[rowbase + key]) * MASK_VALUE : MASK_VALUE;
+    __syncthreads();
+    const int qi = lane & 15, g = lane >> 4;
+    const int q = blockIdx.x * 64 + w * 16 + qi;
+    const bool qok = q < L;
+    float4 qf = make_float4(0.f, 0.f, 0.f, 0.f), da = qf, of = qf;
+    float lq = 0.f;
+    if (qok) {
+        const size_t off = (rowbase + q) * D + h * HD + 4 * g;
+        qf = *reinterpret_cast<const float4*>(Q + off);
+        da = *reinterpret_cast<const float4*>(dr + off);
+        of = *reinterpret_cast<const float4*>(att + off);
+        if (d3.thresh) {                    // r = drop3(att) + x  (:183-184)
+            const uint32_t base = (uint32_t)off;
+            da.x *= drop_mul(d3, base); da.y *= drop_mul(d3, base + 1);
+            da.z *= drop_mul(d3, base + 2); da.w *= drop_mul(d3, base + 3);
+        }
+        lq = lse[((size_t)b * H + h) * L + q];
+    }
+    float dsum = da.x * of.x + da.y * of.y + da.z * of.z + da.w * of.w;     // D_q = dA . O  (= sum_k dP_k P_k)
+    dsum += __shfl_xor(dsum, 16);
+    dsum += __shfl_xor(dsum, 32);
+    if (qok && g == 0) Dq[((size_t)b * H + h) * L + q] = dsum;
+    const float scale = 0.25f;
+    const uint32_t pbase = (uint32_t)(((size_t)(b + b_off) * H + h) * L + q) * (uint32_t)L;
+    f32x4 dq = {0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < Lp; kt += 16) {
+        const float4 kf = *reinterpret_cast<const float4*>(&Ks[(kt + qi) * kst + 4 * g]);
+        const float4 vf = *reinterpret_cast<const float4*>(&Vs[(kt + qi) * kst + 4 * g]);
+        f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf.x, s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf.y, s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf.z, s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf.w, s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.x, da.x, dp, 0, 0, 0);   // dPd^T[key][q] = V[key] . dA[q]
+        dp = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.y, da.y, dp, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.z, da.z, dp, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.w, da.w, dp, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = kt + 4 * g + r;
+            const float p = __expf(s[r] * scale + Mb[key] - lq);
+            const float ds = p * (dp[r] * drop_mul(d2, pbase + key) - dsum) * scale;
+            // dQ^T[dd][q] += K[key][dd] * dS[q][key]
+            dq = __builtin_amdgcn_mfma_f32_16x16x4f32(Ks[key * kst + qi], ds, dq, 0, 0, 0);
+        }
+    }
+    if (qok) *reinterpret_cast<float4*>(dQ + (rowbase + q) * D + h * HD + 4 * g) = make_float4(dq[0], dq[1], dq[2], dq[3]);
+}
+// dK, dV: wave owns 16 keys (lane: key ki = lane & 15, query group g = lane >> 4), Q / dA head slices in LDS.
+__global__ __launch_bounds__(256) void k_attn_bwd_dkv(const float* __restrict__ Q, const float* __restrict__ K,
+                                                      const float* __restrict__ V, const float* __restrict__ dr,
+                                                      const float* __restrict__ lse, const float* __restrict__ Dq,
+                                                      const float* __restrict__ mask, float* __restrict__ dK,
+                                                      float* __restrict__ dV, int L, int H, int b_off, Drop d2, Drop d3) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int Lp = (L + 15) & ~15;
+    const int kst = head_slice_stride(Lp);
+    float* Qs = smem;
+    float* As = Qs + Lp * kst;          // dA = dr * m3
+    float* Ls = As + Lp * kst;          // LSE per query
+    float* Ds = Ls + Lp;                // D per query
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const size_t rowbase = (size_t)b * L;
+    for (int e = tid; e < Lp * 4; e += 256) {
+        const int qq = e >> 2, c4 = (e & 3) * 4;
+        float4 qv = make_float4(0.f, 0.f, 0.f, 0.f), av = qv;
+        if (qq < L) {
+            const size_t off = (rowbase + qq) * D + h * HD + c4;
+            qv = *reinterpret_cast<const float4*>(Q + off);
+            av = *reinterpret_cast<const float4*>(dr + off);
+            if (d3.thresh) {
+                const uint32_t base = (uint32_t)off;
+                av.x *= drop_mul(d3, base); av.y *= drop_mul(d3, base + 1);
+                av.z *= drop_mul(d3, base + 2); av.w *= drop_mul(d3, base + 3);
+            }
+        }
+        *reinterpret_cast<float4*>(&Qs[qq * kst + c4]) = qv;
+        *reinterpret_cast<float4*>(&As[qq * kst + c4]) = av;
+    }
+    for (int qq = tid; qq < Lp; qq += 256) {
+        Ls[qq] = qq < L ? lse[((size_t)b * H + h) * L + qq] : 0.f;
+        Ds[qq] = qq < L ? Dq[((size_t)b * H + h) * L + qq] : 0.f;
+    }
+    __syncthreads();
+    const int ki = lane & 15, g = lane >> 4;
+    const int key = blockIdx.x * 64 + w * 16 + ki;
+    const bool kok = key < L;
+    float4 kf = make_float4(0.f, 0.f, 0.f, 0.f), vf = kf;
+    float mb = MASK_VALUE;
+    if (kok) {
+        kf = *reinterpret_cast<const float4*>(K + (rowbase + key) * D + h * HD + 4 * g);
+        vf = *reinterpret_cast<const float4*>(V + (rowbase + key) * D + h * HD + 4 * g);
+        mb = (1.0f - mask[rowbase + key]) * MASK_VALUE;
+    }
+    const float scale = 0.25f;
+    const uint32_t hb = (uint32_t)(((size_t)(b + b_off) * H + h) * L);
+    f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
+    for (int qt = 0; qt < Lp; qt += 16) {
+        // S tile (rows = queries qt + 4g + reg, col = key ki) and dPd tile, same shape
+        const float4 qa = *reinterpret_cast<const float4*>(&Qs[(qt + ki) * kst + 4 * g]);
+        const float4 aa = *reinterpret_cast<const float4*>(&As[(qt + ki) * kst + 4 * g]);
+        f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        s = __builtin_amdgcn_mfma_f32_16x16x4f32(qa.x, kf.x, s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_16x16x4f32(qa.y, kf.y, s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_16x16x4f32(qa.z, kf.z, s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_16x16x4f32(qa.w, kf.w, s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x4f32(aa.x, vf.x, dp, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x4f32(aa.y, vf.y, dp, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x4f32(aa.z, vf.z, dp, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x4f32(aa.w, vf.w, dp, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int qq = qt + 4 * g + r;
+            const float p = __expf(s[r] * scale + mb - Ls[qq]);
+            const float m2 = drop_mul(d2, (hb + (uint32_t)qq) * (uint32_t)L + (uint32_t)key);
+            const float pd = p * m2;
+            const float ds = p * (dp[r] * m2 - Ds[qq]) * scale;
+            // dV^T[dd][key] += dA[q][dd] * Pd[q][key] ; dK^T[dd][key] += Q[q][dd] * dS[q][key]
+            dv = __builtin_amdgcn_mfma_f32_16x16x4f32(As[qq * kst + ki], pd, dv, 0, 0, 0);
+            dk = __builtin_amdgcn_mfma_f32_16x16x4f32(Qs[qq * kst + ki], ds, dk, 0, 0, 0);
+        }
+    }
+    if (kok) {
+        *reinterpret_cast<float4*>(dK + (rowbase + key) * D + h * HD + 4 * g) = make_float4(dk[0], dk[1], dk[2], dk[3]);
+        *reinterpret_cast<float4*>(dV + (rowbase + key) * D + h * HD + 4 * g) = make_float4(dv[0], dv[1], dv[2], dv[3]);
+    }
+}
+void launch_attn_bwd(const float* Q, const float* K, const float* V, const float* att, const float* dr, const float* lse,
+                     const float* mask, float* dQ, float* dK, float* dV, float* Dq, int B, int L, int H, int b_off, Drop d2,
+                     Drop d3, hipStream_t s) {
+    const int Lp = (L + 15) & ~15;
+    const int kst = head_slice_stride(Lp);
+    const size_t shm1 = (size_t)(2 * Lp * kst + Lp) * sizeof(float), shm2 = (size_t)(2 * Lp * kst + 2 * Lp) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)k_attn_bwd_dq, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_attn_bwd_dkv, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL(k_attn_bwd_dq, dim3((L + 63) / 64, H, B), dim3(256), shm1, s, Q, K, V, att, dr, lse, mask, dQ, Dq, L, H,
+                       b_off, d2, d3);
+    hipLaunchKernelGGL(k_attn_bwd_dkv, dim3((L + 63) / 64, H, B), dim3(256), shm2, s, Q, K, V, dr, lse, Dq, mask, dK, dV, L, H,
+                       b_off, d2, d3);
+}
+
+constexpr int QKVP = 3 * D + 4;
+__global__ __launch_bounds__(256) void k_qkv_bwd(const float* __restrict__ dQ, const float* __restrict__ dK,
+                                                 const float* __restrict__ dV, const float* __restrict__ x,
+                                                 const float* __restrict__ dr, const float* __restrict__ ln_g,
+                                                 const float* __restrict__ WTpack, float* __restrict__ dx,
+                                                 float* __restrict__ p_lng, float* __restrict__ p_lnb, int R, Drop d1) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                         // [32][QKVP] = [dQ | dK | dV]
+    float* Ts = As + TILE_M * QKVP;           // [32][LDP]
+    float* red = Ts + TILE_M * LDP;           // [1024]
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int r0 = blockIdx.x * TILE_M;
+    for (int e = tid; e < TILE_M * 32; e += 256) {
+        const int rr = e >> 5, c = (e & 31) * 4;
+        const int r = r0 + rr;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), bq = a, cv = a;
+        if (r < R) {
+            a = *reinterpret_cast<const float4*>(dQ + (size_t)r * D + c);
+            bq = *reinterpret_cast<const float4*>(dK + (size_t)r * D + c);
+            cv = *reinterpret_cast<const float4*>(dV + (size_t)r * D + c);
+        }
+        *reinterpret_cast<float4*>(&As[rr * QKVP + c]) = a;
+        *reinterpret_cast<float4*>(&As[rr * QKVP + D + c]) = bq;
+        *reinterpret_cast<float4*>(&As[rr * QKVP + 2 * D + c]) = cv;
+    }
+    __syncthreads();
+    f32x16 acc[1];
+    zero_acc(acc);
+    gemm32<1>(As, QKVP, 3 * D, WTpack, D, 32 * w, 0, acc);
+    const int col = 32 * w + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r, lane);
+        Ts[row * LDP + col] = acc[0][r] * drop_mul(d1, (uint32_t)((r0 + row) * D + col));
+    }
+    __syncthreads();
+    ln_bwd_rows(Ts, x, dr, nullptr, ln_g, dx, p_lng, p_lnb, red, r0, R);
+}
+void launch_qkv_bwd(const float* dQ, const float* dK, const float* dV, const float* x, const float* dr,
+                    const float* ln_g, const float* WTpack, float* dx, float* p_lng, float* p_lnb, int R, Drop d1,
+                    hipStream_t s) {
+    const size_t shm = (size_t)(TILE_M * QKVP + TILE_M * LDP + 1024) * sizeof(float);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)k_qkv_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr = true; }
+    hipLaunchKernelGGL(k_qkv_bwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm, s, dQ, dK, dV, x, dr, ln_g, WTpack, dx, p_lng,
+                       p_lnb, R, d1);
+}
+
+// positional-embedding gradient (a6, :202): dpos[t] = sum_b dx0[b, t] ; rows >= L of the table get zero
+__global__ __launch_bounds__(256) void k_pos_grad(const float* __restrict__ dx0, float* __restrict__ out, int B, int L,
+                                                  int max_pos) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= max_pos * D) return;
+    const int t = e >> 7, c = e & 127;
+    float acc = 0.f;
+    if (t < L)
+        for (int b = 0; b < B; ++b) acc += dx0[((size_t)b * L + t) * D + c];
+    out[e] = acc;
+}
+void launch_pos_grad(const float* dx0, float* out, int B, int L, int max_pos, hipStream_t s) {
+    hipLaunchKernelGGL(k_pos_grad, dim3((max_pos * D + 255) / 256), dim3(256), 0, s, dx0, out, B, L, max_pos);
+}
+
+// =========================================================================================================
+// a11 + a12 backward: gated = f2 * h ; h = sigmoid(mask_logits(f2 . wh + bh)) ; f2 = f1 W1^T + pb[b]
+//   dgated = dg0 + dg1 + dg2 (two heads + predictor encoder input) ; dh_loss from the highlight loss.
+// =========================================================================================================
+__global__ __launch_bounds__(256) void k_cqcat_bwd(const float* __restrict__ dg0, const float* __restrict__ dg1,
+                                                   const float* __restrict__ dg2, const float* __restrict__ dh_loss,
+                                                   const float* __restrict__ f2, const float* __restrict__ hscore,
+                                                   const float* __restrict__ wh, const float* __restrict__ W1Tpack,
+                                                   float* __restrict__ df2, float* __restrict__ df1,
+                                                   float* __restrict__ p_wh, float* __restrict__ p_bh, int R) {
+    __shared__ __attribute__((aligned(16))) float Gs[TILE_M * LDP];     // dgated -> df2
+    __shared__ __attribute__((aligned(16))) float Fs[TILE_M * LDP];     // f2
+    __shared__ float dlg[TILE_M];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int r0 = blockIdx.x * TILE_M;
+    for (int e = tid; e < TILE_M * 32; e += 256) {
+        const int rr = e >> 5, c = (e & 31) * 4;
+        const int r = r0 + rr;
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f), f = g;
+        if (r < R) {
+            g = *reinterpret_cast<const float4*>(dg0 + (size_t)r * D + c);
+            if (dg1) { const float4 t = *reinterpret_cast<const float4*>(dg1 + (size_t)r * D + c); g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w; }
+            if (dg2) { const float4 t = *reinterpret_cast<const float4*>(dg2 + (size_t)r * D + c); g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w; }
+            f = *reinterpret_cast<const float4*>(f2 + (size_t)r * D + c);
+        }
+        *reinterpret_cast<float4*>(&Gs[rr * LDP + c]) = g;
+        *reinterpret_cast<float4*>(&Fs[rr * LDP + c]) = f;
+    }
+    __syncthreads();
+    for (int rr = w; rr < TILE_M; rr += 4) {
+        const int r = r0 + rr;
+        const float d = wave_sum(Gs[rr * LDP + lane] * Fs[rr * LDP + lane] + Gs[rr * LDP + lane + 64] * Fs[rr * LDP + lane + 64]);
+        float hv = 0.f, dl = 0.f;
+        if (r < R) {
+            hv = hscore[r];
+            dl = (d + (dh_loss ? dh_loss[r] : 0.f)) * hv * (1.f - hv);      // sigmoid backward; mask_logits is additive
+        }
+        // df2 = dgated * h + dlogit * wh
+        Gs[rr * LDP + lane] = Gs[rr * LDP + lane] * hv + dl * wh[lane];
+        Gs[rr * LDP + lane + 64] = Gs[rr * LDP + lane + 64] * hv + dl * wh[lane + 64];
+        if (lane == 0) dlg[rr] = dl;
+    }
+    __syncthreads();
+    if (tid < 128) {
+        float acc = 0.f;
+        for (int rr = 0; rr < TILE_M; ++rr) acc += dlg[rr] * Fs[rr * LDP + tid];
+        p_wh[(size_t)blockIdx.x * D + tid] = acc;
+    } else if (tid == 128) {
+        float acc = 0.f;
+        for (int rr = 0; rr < TILE_M; ++rr) acc += dlg[rr];
+        p_bh[blockIdx.x] = acc;
+    }
+    for (int e = tid; e < TILE_M * 32; e += 256) {
+        const int rr = e >> 5, c = (e & 31) * 4;
+        if (r0 + rr < R) *reinterpret_cast<float4*>(df2 + (size_t)(r0 + rr) * D + c) = *reinterpret_cast<const float4*>(&Gs[rr * LDP + c]);
+    }
+    f32x16 acc[1];
+    zero_acc(acc);
+    gemm32<1>(Gs, LDP, D, W1Tpack, D, 32 * w, 0, acc);
+    const int col = 32 * w + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int gr = r0 + acc_row(r, lane);
+        if (gr < R) df1[(size_t)gr * D + col] = acc[0][r];
+    }
+}
+void launch_cqcat_bwd(const float* dg0, const float* dg1, const float* dg2, const float* dh_loss, const float* f2,
+                      const float* hscore, const float* wh, const float* W1Tpack, float* df2, float* df1, float* p_wh,
+                      float* p_bh, int R, hipStream_t s) {
+    hipLaunchKernelGGL(k_cqcat_bwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), 0, s, dg0, dg1, dg2, dh_loss, f2, hscore, wh,
+                       W1Tpack, df2, df1, p_wh, p_bh, R);
+}
+
+// =========================================================================================================
+// a10 backward, row-tile part:  dcat = df1 Wcqa ; split into dC(direct), dc2q, dq2c ;
+//   dS_row = dc2q Q^T + dq2c M^T ; row-softmax backward -> dSr.
+// =========================================================================================================
+__global__ __launch_bounds__(256) void k_cq_out_bwd(const float* __restrict__ df1, const float* __restrict__ C,
+                                                    const float* __restrict__ Qf, const float* __restrict__ Srow,
+                                                    const float* __restrict__ M, const float* __restrict__ WTpack,
+                                                    float* __restrict__ dC, float* __restrict__ dc2q,
+                                                    float* __restrict__ dq2c, float* __restrict__ dSr, int T, int Lq) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Dc = smem;                          // [32][CATP] grad wrt the concat tile
+    float* Gs = Dc + TILE_M * CATP;            // [32][LDP]  df1 tile, later C tile
+    float* Ss = Gs + TILE_M * LDP;             // [32][Lq]   S_row
+    float* Sd = Ss + TILE_M * Lq;              // [32][Lq+1] dS_row
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int b = blockIdx.y, t0 = blockIdx.x * TILE_M;
+    const size_t crow = (size_t)b * T, qrow = (size_t)b * Lq;
+    load_tile128(Gs, df1 + crow * D, t0, TILE_M, T);
+    for (int e = tid; e < TILE_M * Lq; e += 256) Ss[e] = (t0 + e / Lq < T) ? Srow[(crow + t0) * Lq + e] : 0.f;
+    __syncthreads();
+    f32x16 acc[4];
+    zero_acc(acc);
+    gemm32<4>(Gs, LDP, D, WTpack, 4 * D, 32 * w, D, acc);
+    const int col = 32 * w + (lane & 31);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Dc[acc_row(r, lane) * CATP + t * D + col] = acc[t][r];
+    __syncthreads();
+    load_tile128(Gs, C + crow * D, t0, TILE_M, T);      // Gs now holds the C tile
+    __syncthreads();
+    {
+        // thread = (channel c, 16 rows): recompute c2q / q2c (:229-230), then the product-rule split of :231
+        const int c = tid & 127, hb = (tid >> 7) * 16;
+        float a1[16], a2[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { a1[q] = 0.f; a2[q] = 0.f; }
+        for (int j = 0; j < Lq; ++j) {
+            const float qv = Qf[(qrow + j) * D + c], mv = M[(qrow + j) * D + c];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const float sv = Ss[(hb + q) * Lq + j];
+                a1[q] += sv * qv;
+                a2[q] += sv * mv;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int rr = hb + q;
+            float* d = Dc + rr * CATP;
+            const float cv = Gs[rr * LDP + c];
+            const float d0 = d[c], d1 = d[D + c], d2 = d[2 * D + c], d3 = d[3 * D + c];
+            const float g_c = d0 + d2 * a1[q] + d3 * a2[q];
+            const float g_c2q = d1 + d2 * cv;
+            const float g_q2c = d3 * cv;
+            d[D + c] = g_c2q;                  // keep in LDS for the dS dots below
+            d[3 * D + c] = g_q2c;
+            if (t0 + rr < T) {
+                const size_t o = (crow + t0 + rr) * D + c;
+                dC[o] = g_c; dc2q[o] = g_c2q; dq2c[o] = g_q2c;
+            }
+        }
+    }
+    __syncthreads();
+    {   // dS_row[i][j] = dc2q[i] . Q[j] + dq2c[i] . M[j]
+        const int i = tid >> 3;
+        const float4* r1 = reinterpret_cast<const float4*>(Dc + i * CATP + D);
+        const float4* r3 = reinterpret_cast<const float4*>(Dc + i * CATP + 3 * D);
+        for (int j = tid & 7; j < Lq; j += 8) {
+            const float4* qr = reinterpret_cast<const float4*>(Qf + (qrow + j) * D);
+            const float4* mr = reinterpret_cast<const float4*>(M + (qrow + j) * D);
+            float a = 0.f;
+#pragma unroll 8
+            for (int c = 0; c < 32; ++c) {
+                const float4 x1 = r1[c], q4 = qr[c], x3 = r3[c], m4 = mr[c];
+                a += x1.x * q4.x + x1.y * q4.y + x1.z * q4.z + x1.w * q4.w + x3.x * m4.x + x3.y * m4.y + x3.z * m4.z + x3.w * m4.w;
+            }
+            Sd[i * (Lq + 1) + j] = a;
+        }
+    }
+    __syncthreads();
+    for (int rr = w; rr < TILE_M; rr += 4) {     // softmax backward over the query words (dim=2, :225)
+        const int t = t0 + rr;
+        if (t >= T) continue;
+        const float s0 = lane < Lq ? Ss[rr * Lq + lane] : 0.f, s1 = lane + 64 < Lq ? Ss[rr * Lq + lane + 64] : 0.f;
+        const float g0 = lane < Lq ? Sd[rr * (Lq + 1) + lane] : 0.f, g1 = lane + 64 < Lq ? Sd[rr * (Lq + 1) + lane + 64] : 0.f;
+        const float dot = wave_sum(s0 * g0 + s1 * g1);
+        if (lane < Lq) dSr[(crow + t) * Lq + lane] = s0 * (g0 - dot);
+        if (lane + 64 < Lq) dSr[(crow + t) * Lq + lane + 64] = s1 * (g1 - dot);
+    }
+}
+void launch_cq_out_bwd(const float* df1, const float* C, const float* Qf, const float* Srow, const float* M,
+                       const float* WTpack, float* dC, float* dc2q, float* dq2c, float* dSr, int B, int T, int Lq,
+                       hipStream_t s) {
+    const size_t shm = (size_t)(TILE_M * CATP + TILE_M * LDP + TILE_M * Lq + TILE_M * (Lq + 1)) * sizeof(float);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)k_cq_out_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    hipLaunchKernelGGL(k_cq_out_bwd, dim3((T + TILE_M - 1) / TILE_M, B), dim3(256), shm, s, df1, C, Qf, Srow, M, WTpack, dC, dc2q,
+                       dq2c, dSr, T, Lq);
+}
+
+// =========================================================================================================
+// a10 / a11 backward, per-sample part (one workgroup per sample; everything that reduces over the clips):
+//   dM, dQ(c2q) ; column-softmax backward ; trilinear-score backward (w4C, w4Q, w4mlu, dC, dQ) ;
+//   WeightedPool + pooled-query bias backward.
+// =========================================================================================================
+__global__ __launch_bounds__(256) void k_cq_col_bwd(CqColBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int T = a.T, Lq = a.Lq;
+    const int LQ1 = Lq + 1;
+    float* dMs = smem;                         // [Lq][LDP]  dM
+    float* dQs = dMs + Lq * LDP;               // [Lq][LDP]  dQ accumulator (un-dropped query grad)
+    float* Qds = dQs + Lq * LDP;               // [Lq][LDP]  dropped-out Q (as used by the trilinear score)
+    float* Cs = Qds + Lq * LDP;                // [32][LDP]  C tile
+    float* Cd = Cs + TILE_M * LDP;             // [32][LDP]  dropped C tile
+    float* St = Cd + TILE_M * LDP;             // [32][LQ1]  S_col tile
+    float* Sg = St + TILE_M * LQ1;             // [32][LQ1]  dS tile
+    float* csum = Sg + TILE_M * LQ1;           // [Lq] column dot for the softmax backward
+    float* cs2 = csum + Lq;                    // [Lq] column sums of dS
+    float* rsum = cs2 + Lq;                    // [32] row sums of dS
+    float* v128 = rsum + TILE_M;               // [4][128] small vectors: dpb, dpooled, (w4C acc), (w4mlu acc)
+    float* sv = v128 + 4 * D;                  // [Lq] small per-word scalars
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int b = blockIdx.x;
+    const size_t crow = (size_t)b * T, qrow = (size_t)b * Lq;
+    const int c = tid & 127, hf = tid >> 7;
+    const int jn = (Lq + 1) / 2, j0 = hf * jn, j1 = min(Lq, j0 + jn);
+    const int ntile = (T + TILE_M - 1) / TILE_M;
+
+    // ---- (1) dM[j][c] = sum_i Srow[i][j] dq2c[i][c] ; dQ(c2q)[j][c] = sum_i Srow[i][j] dc2q[i][c]
+    for (int jb = j0; jb < j1; jb += 8) {
+        float am[8], aq[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { am[q] = 0.f; aq[q] = 0.f; }
+        for (int t = 0; t < T; ++t) {
+            const float x3 = a.dq2c[(crow + t) * D + c], x1 = a.dc2q[(crow + t) * D + c];
+            const float* sr = a.Srow + (crow + t) * Lq + jb;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (jb + q < j1) { am[q] += sr[q] * x3; aq[q] += sr[q] * x1; }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (jb + q < j1) { dMs[(jb + q) * LDP + c] = am[q]; dQs[(jb + q) * LDP + c] = aq[q]; }
+    }
+    for (int e = tid; e < Lq * D; e += 256) {
+        const int j = e >> 7, cc = e & 127;
+        Qds[j * LDP + cc] = a.Qf[(qrow + j) * D + cc] * drop_mul(a.dq, (uint32_t)(((b + a.b_off) * Lq + j) * D + cc));
+    }
+    if (tid < Lq) { csum[tid] = 0.f; cs2[tid] = 0.f; }
+    __syncthreads();
+
+    // ---- (2) sweep 1: dSt[i][j] = dM[j] . C[i] -> scratch ; csum[j] = sum_i dSt[i][j] * Scol[i][j]
+    float* dS = a.scratch + crow * Lq;
+    for (int tl = 0; tl < ntile; ++tl) {
+        const int t0 = tl * TILE_M;
+        load_tile128(Cs, a.C + crow * D, t0, TILE_M, T);
+        __syncthreads();
+        {
+            const int i = tid >> 3;
+            const float4* cr = reinterpret_cast<const float4*>(Cs + i * LDP);
+            for (int j = tid & 7; j < Lq; j += 8) {
+                const float4* mr = reinterpret_cast<const float4*>(dMs + j * LDP);
+                float acc = 0.f;
+#pragma unroll 8
+                for (int k = 0; k < 32; ++k) { const float4 x = cr[k], y = mr[k]; acc += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w; }
+                Sg[i * LQ1 + j] = acc;
+                if (t0 + i < T) dS[(size_t)(t0 + i) * Lq + j] = acc;
+            }
+        }
+        __syncthreads();
+        if (tid < Lq) {
+            float acc = 0.f;
+            for (int i = 0; i < TILE_M && t0 + i < T; ++i) acc += Sg[i * LQ1 + tid] * a.Scol[(crow + t0 + i) * Lq + tid];
+            csum[tid] += acc;
+        }
+        __syncthreads();
+    }
+
+    // ---- (3) sweep 2: full dS tile, then the trilinear backward
+    float acc_w4C = 0.f, acc_mlu = 0.f;       // per-thread partials for channel c over this thread's rows
+    for (int tl = 0; tl < ntile; ++tl) {
+        const int t0 = tl * TILE_M;
+        load_tile128(Cs, a.C + crow * D, t0, TILE_M, T);
+        for (int e = tid; e < TILE_M * LQ1; e += 256) {
+            const int i = e / LQ1, j = e - i * LQ1;
+            float g = 0.f, st = 0.f;
+            if (j < Lq && t0 + i < T) {
+                st = a.Scol[(crow + t0 + i) * Lq + j];
+                g = a.dSr[(crow + t0 + i) * Lq + j] + st * (dS[(size_t)(t0 + i) * Lq + j] - csum[j]);
+            }
+            St[e] = st;
+            Sg[e] = g;
+        }
+        __syncthreads();
+        for (int e = tid; e < TILE_M * D; e += 256) {
+            const int rr = e >> 7, cc = e & 127;
+            const int t = t0 + rr;
+            Cd[rr * LDP + cc] = t < T ? Cs[rr * LDP + cc] * drop_mul(a.dc, (uint32_t)(((b + a.b_off) * T + t) * D + cc)) : 0.f;
+        }
+        if (tid < TILE_M) { float s = 0.f; for (int j = 0; j < Lq; ++j) s += Sg[tid * LQ1 + j]; rsum[tid] = s; }
+        if (tid >= 64 && tid < 64 + Lq) { const int j = tid - 64; float s = 0.f; for (int i = 0; i < TILE_M; ++i) s += Sg[i * LQ1 + j]; cs2[j] += s; }
+        __syncthreads();
+        {
+            // rows of this thread: hf * 16 .. + 15 ; channel c
+            const float wC = a.w4C[c], wM = a.w4mlu[c];
+            for (int rr = hf * 16; rr < hf * 16 + 16; ++rr) {
+                const int t = t0 + rr;
+                if (t >= T) break;
+                float tq = 0.f, tm = 0.f;
+                for (int j = 0; j < Lq; ++j) {
+                    tq += Sg[rr * LQ1 + j] * Qds[j * LDP + c];        // sum_j dS[i][j] Qd[j][c]
+                    tm += St[rr * LQ1 + j] * dMs[j * LDP + c];        // sum_j Scol[i][j] dM[j][c]   (M = Scol^T C)
+                }
+                const float cdv = Cd[rr * LDP + c];
+                const float dcd = rsum[rr] * wC + wM * tq;            // grad wrt dropped-out C
+                acc_w4C += rsum[rr] * cdv;
+                acc_mlu += tq * cdv;
+                const size_t o = (crow + t) * D + c;
+                a.dC[o] = a.dC[o] + tm + dcd * drop_mul(a.dc, (uint32_t)(((b + a.b_off) * T + t) * D + c));
+            }
+        }
+        // dQ[j][c] += mask_q[j][c] * w4mlu[c] * sum_i dS[i][j] Cd[i][c]      (thread owns (c, its half of the words))
+        {
+            const float wM = a.w4mlu[c];
+            for (int jb = j0; jb < j1; jb += 8) {
+                float acc[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+                for (int i = 0; i < TILE_M; ++i) {
+                    const float cv = Cd[i * LDP + c] * wM;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        if (jb + q < j1) acc[q] += Sg[i * LQ1 + jb + q] * cv;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (jb + q < j1)
+                        dQs[(jb + q) * LDP + c] += acc[q] * drop_mul(a.dq, (uint32_t)(((b + a.b_off) * Lq + jb + q) * D + c));
+            }
+        }
+        __syncthreads();
+    }
+    // combine the two row-halves of the per-channel accumulators
+    v128[hf * D + c] = acc_w4C;
+    v128[2 * D + hf * D + c] = acc_mlu;
+    __syncthreads();
+    if (tid < D) {
+        a.p_w4C[(size_t)b * D + tid] = v128[tid] + v128[D + tid];
+        a.p_w4mlu[(size_t)b * D + tid] = v128[2 * D + tid] + v128[3 * D + tid];
+        // dw4Q[c] = sum_j cs2[j] Qd[j][c]
+        float s = 0.f;
+        for (int j = 0; j < Lq; ++j) s += cs2[j] * Qds[j * LDP + tid];
+        a.p_w4Q[(size_t)b * D + tid] = s;
+    }
+    __syncthreads();
+    // dQ += cs2[j] * w4Q * dropmask_q      (the s1 = Qd . w4Q term of the trilinear score)
+    for (int e = tid; e < Lq * D; e += 256) {
+        const int j = e >> 7, cc = e & 127;
+        dQs[j * LDP + cc] += cs2[j] * a.w4Q[cc] * drop_mul(a.dq, (uint32_t)(((b + a.b_off) * Lq + j) * D + cc));
+    }
+    // ---- (4) pooled-query path: pb = W2 pooled + bcat ; pooled = sum_j alpha_j Q[j] ; alpha = softmax(Q w + mask)
+    if (tid < D) {
+        float s = 0.f;
+        for (int t = 0; t < T; ++t) s += a.df2[(crow + t) * D + tid];
+        v128[tid] = s;                                   // dpb[o]
+        a.p_bcat[(size_t)b * D + tid] = s;
+    }
+    __syncthreads();
+    for (int e = tid; e < D * D; e += 256)                // dW2[o][c] = dpb[o] * pooled[c]
+        a.p_W2[(size_t)b * D * D + e] = v128[e >> 7] * a.pooled[(size_t)b * D + (e & 127)];
+    if (tid < D) {
+        float s = 0.f;
+        for (int o = 0; o < D; ++o) s += a.Wcat[(size_t)o * 2 * D + D + tid] * v128[o];
+        v128[D + tid] = s;                               // dpooled[c]
+    }
+    __syncthreads();
+    for (int j = w; j < Lq; j += 4) {                     // dalpha_j = dpooled . Q[j]
+        const float* qr = a.Qf + (qrow + j) * D;
+        const float d = wave_sum(qr[lane] * v128[D + lane] + qr[lane + 64] * v128[D + lane + 64]);
+        if (lane == 0) sv[j] = d;
+    }
+    __syncthreads();
+    if (w == 0) {
+        const float a0 = lane < Lq ? a.alpha[qrow + lane] : 0.f, a1 = lane + 64 < Lq ? a.alpha[qrow + lane + 64] : 0.f;
+        const float g0 = lane < Lq ? sv[lane] : 0.f, g1 = lane + 64 < Lq ? sv[lane + 64] : 0.f;
+        const float dot = wave_sum(a0 * g0 + a1 * g1);
+        if (lane < Lq) sv[lane] = a0 * (g0 - dot);        // dlogit_j
+        if (lane + 64 < Lq) sv[lane + 64] = a1 * (g1 - dot);
+    }
+    __syncthreads();
+    if (tid < D) {
+        float s = 0.f;
+        for (int j = 0; j < Lq; ++j) s += sv[j] * a.Qf[(qrow + j) * D + tid];
+        a.p_pool[(size_t)b * D + tid] = s;
+    }
+    for (int e = tid; e < Lq * D; e += 256) {
+        const int j = e >> 7, cc = e & 127;
+        a.dQ[(qrow + j) * D + cc] = dQs[j * LDP + cc] + a.alpha[qrow + j] * v128[D + cc] + sv[j] * a.pool_w[cc];
+    }
+}
+void launch_cq_col_bwd(const CqColBwdArgs& a, int B, hipStream_t s) {
+    const int Lq = a.Lq;
+    const size_t shm = (size_t)(3 * Lq * LDP + 2 * TILE_M * LDP + 2 * TILE_M * (Lq + 1) + 2 * Lq + TILE_M + 4 * D + Lq) * sizeof(float);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)k_cq_col_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    hipLaunchKernelGGL(k_cq_col_bwd, dim3(B), dim3(256), shm, s, a);
+}
+
+// =========================================================================================================
+// generic data gradient  dA (R, K) = G (R, 128) W   (transpose pack, ncols = K) ; used for a5 (K = 400)
+// =========================================================================================================
+__global__ __launch_bounds__(256) void k_linear_bwd_data(const float* __restrict__ G, const float* __restrict__ WTpack,
+                                                         float* __restrict__ dA, int R, int K) {
+    __shared__ __attribute__((aligned(16))) float Gs[TILE_M * LDP];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int r0 = blockIdx.x * TILE_M;
+    load_tile128(Gs, G, r0, TILE_M, R);
+    __syncthreads();
+    for (int cb = 0; cb < K; cb += 512) {
+        f32x16 acc[4];
+        zero_acc(acc);
+        gemm32<4>(Gs, LDP, D, WTpack, K, cb + 32 * w, D, acc);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int col = cb + 32 * w + t * D + (lane & 31);
+            if (col < K) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int gr = r0 + acc_row(r, lane);
+                    if (gr < R) dA[(size_t)gr * K + col] = acc[t][r];
+                }
+            }
+        }
+    }
+}
+void launch_linear_bwd_data(const float* G, const float* WTpack, float* dA, int R, int K, hipStream_t s) {
+    hipLaunchKernelGGL(k_linear_bwd_data, dim3((R + TILE_M - 1) / TILE_M), dim3(256), 0, s, G, WTpack, dA, R, K);
+}
+
+// =========================================================================================================
+// a3 / a4 backward: unk_vec gradient, char-CNN weights / biases, char table (padding_idx = 0 gets none).
+//   one workgroup per EMB_CHUNK query words; partial slabs per workgroup.
+// =========================================================================================================
+__global__ __launch_bounds__(256) void k_embed_bwd(const float* __restrict__ dE, const int64_t* __restrict__ char_ids,
+                                                   const float* __restrict__ E, const int8_t* __restrict__ argpos,
+                                                   const float* __restrict__ char_tab, CharConvPtrs cc,
+                                                   float* __restrict__ p_cw, float* __restrict__ p_cb,
+                                                   float* __restrict__ p_tab, int Rq, int Lc, int word_dim, int char_dim,
+                                                   int char_size, Drop dc) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ce = smem;                         // [MAX_LC][64] dropped char embeddings of the current word
+    float* dCe = Ce + MAX_LC * 64;            // [MAX_LC][64] grad wrt them
+    float* gch = dCe + MAX_LC * 64;           // [100] grad of the 100 char features (0 where relu/max inactive)
+    float* tab = gch + 128;                   // [char_size][char_dim] table-gradient accumulator
+    __shared__ int pos[128];
+    __shared__ int cids[MAX_LC];
+    const int tid = threadIdx.x;
+    const int EW = word_dim + 100;
+    const int wtot = char_dim * 300;          // 10*1 + 20*2 + 30*3 + 40*4 = 300 taps per input channel
+    // this thread's slice of the flattened conv weights: element e -> (conv, ch, ci, kk)
+    constexpr int MAXE = 64;                  // ceil(15000 / 256) = 59
+    float wacc[MAXE];
+    int wcode[MAXE];                          // (oc << 16) | (ci << 8) | kk of this thread's q-th weight element
+#pragma unroll
+    for (int q = 0; q < MAXE; ++q) {
+        wacc[q] = 0.f;
+        const int e = tid + q * 256;
+        int oc = 0, ci = 0, kk = 0;
+        if (e < wtot) {
+            // flattened order: conv0 (10, cd, 1), conv1 (20, cd, 2), conv2 (30, cd, 3), conv3 (40, cd, 4)
+            int rem = e;
+            const int s0 = 10 * char_dim, s1 = 20 * char_dim * 2, s2 = 30 * char_dim * 3;
+            if (rem < s0) { oc = rem / char_dim; ci = rem % char_dim; kk = 0; }
+            else if ((rem -= s0) < s1) { const int ch = rem / (char_dim * 2); rem -= ch * char_dim * 2; ci = rem / 2; kk = rem % 2; oc = 10 + ch; }
+            else if ((rem -= s1) < s2) { const int ch = rem / (char_dim * 3); rem -= ch * char_dim * 3; ci = rem / 3; kk = rem % 3; oc = 30 + ch; }
+            else { rem -= s2; const int ch = rem / (char_dim * 4); rem -= ch * char_dim * 4; ci = rem / 4; kk = rem % 4; oc = 60 + ch; }
+        }
+        wcode[q] = (oc << 16) | (ci << 8) | kk;
+    }
+    float bacc = 0.f;
+    for (int e = tid; e < char_size * char_dim; e += 256) tab[e] = 0.f;
+    const int rbeg = blockIdx.x * EMB_CHUNK, rend = min(Rq, rbeg + EMB_CHUNK);
+    for (int r = rbeg; r < rend; ++r) {
+        __syncthreads();
+        if (tid < Lc) cids[tid] = (int)char_ids[(size_t)r * Lc + tid];
+        if (tid < 100) {
+            const float v = E[(size_t)r * EW + word_dim + tid];
+            gch[tid] = v > 0.f ? dE[(size_t)r * EW + word_dim + tid] : 0.f;     // relu + max: grad only to an active arg-max
+            pos[tid] = argpos[(size_t)r * 100 + tid];
+        }
+        __syncthreads();
+        for (int e = tid; e < Lc * char_dim; e += 256) {
+            const int p = e / char_dim, ci = e - p * char_dim;
+            Ce[p * 64 + ci] = char_tab[(size_t)cids[p] * char_dim + ci] * drop_mul(dc, (uint32_t)((r * Lc + p) * char_dim + ci));
+            dCe[p * 64 + ci] = 0.f;
+        }
+        __syncthreads();
+        if (tid < 100) bacc += gch[tid];
+        // weight grads: dW[oc][ci][kk] += g[oc] * Ce[pos[oc] + kk][ci]
+#pragma unroll
+        for (int q = 0; q < MAXE; ++q) {
+            const int e = tid + q * 256;
+            if (e < wtot) {
+                const int oc = wcode[q] >> 16, ci = (wcode[q] >> 8) & 255, kk = wcode[q] & 255;
+                wacc[q] += gch[oc] * Ce[(pos[oc] + kk) * 64 + ci];
+            }
+        }
+        // dCe[p][ci] = sum_{oc, kk : pos[oc] + kk == p} g[oc] W[oc][ci][kk]   (thread = (p, ci))
+        for (int e = tid; e < Lc * char_dim; e += 256) {
+            const int p = e / char_dim, ci = e - p * char_dim;
+            float acc = 0.f;
+            for (int oc = 0; oc < 100; ++oc) {
+                const float g = gch[oc];
+                if (g == 0.f) continue;
+                int conv, ch, k;
+                if (oc < 10) { conv = 0; ch = oc; k = 1; } else if (oc < 30) { conv = 1; ch = oc - 10; k = 2; }
+                else if (oc < 60) { conv = 2; ch = oc - 30; k = 3; } else { conv = 3; ch = oc - 60; k = 4; }
+                const int kk = p - pos[oc];
+                if (kk >= 0 && kk < k) acc += g * cc.w[conv][((size_t)ch * char_dim + ci) * k + kk];
+            }
+            dCe[p * 64 + ci] = acc * drop_mul(dc, (uint32_t)((r * Lc + p) * char_dim + ci));
+        }
+        __syncthreads();
+        // scatter into the table accumulator; thread owns channel ci for all positions -> no intra-word races
+        if (tid < char_dim)
+            for (int p = 0; p < Lc; ++p)
+                if (cids[p] != 0) tab[cids[p] * char_dim + tid] += dCe[p * 64 + tid];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < MAXE; ++q) {
+        const int e = tid + q * 256;
+        if (e < wtot) p_cw[(size_t)blockIdx.x * wtot + e] = wacc[q];
+    }
+    if (tid < 100) p_cb[(size_t)blockIdx.x * 100 + tid] = bacc;
+    for (int e = tid; e < char_size * char_dim; e += 256) p_tab[(size_t)blockIdx.x * char_size * char_dim + e] = tab[e];
+}
+// unk_vec gradient (:31-33, 41): sum over the words whose id == 1 of the (dropped-out) word-embedding gradient
+__global__ __launch_bounds__(256) void k_unk_grad(const float* __restrict__ dE, const int64_t* __restrict__ word_ids,
+                                                  float* __restrict__ g_unk, int Rq, int word_dim, Drop dw) {
+    const int EW = word_dim + 100;
+    for (int c = threadIdx.x; c < word_dim; c += 256) {
+        float acc = 0.f;
+        for (int r = 0; r < Rq; ++r)
+            if (word_ids[r] == 1) acc += dE[(size_t)r * EW + c] * drop_mul(dw, (uint32_t)(r * word_dim + c));
+        g_unk[c] = acc;
+    }
+}
+void launch_embed_bwd(const float* dE, const int64_t* word_ids, const int64_t* char_ids, const float* E,
+                      const int8_t* argpos, const float* char_tab, CharConvPtrs cc, float* p_cw, float* p_cb, float* p_tab,
+                      float* g_unk, int Rq, int Lc, int word_dim, int char_dim, int char_size, Drop dw, Drop dc,
+                      hipStream_t s) {
+    const size_t shm = (size_t)(2 * MAX_LC * 64 + 128 + char_size * char_dim) * sizeof(float);
+    hipLaunchKernelGGL(k_embed_bwd, dim3((Rq + EMB_CHUNK - 1) / EMB_CHUNK), dim3(256), shm, s, dE, char_ids, E, argpos, char_tab,
+                       cc, p_cw, p_cb, p_tab, Rq, Lc, word_dim, char_dim, char_size, dc);
+    hipLaunchKernelGGL(k_unk_grad, dim3(1), dim3(256), 0, s, dE, word_ids, g_unk, Rq, word_dim, dw);
+}
+
+// =========================================================================================================
+// final reduction of all partial slabs into the flat gradient bucket
+// =========================================================================================================
+__global__ __launch_bounds__(256) void k_reduce(const float* __restrict__ partial, float* __restrict__ grads,
+                                                const ReduceSeg* __restrict__ segs, const int* __restrict__ blk2seg) {
+    const int si = blk2seg[2 * blockIdx.x], off = blk2seg[2 * blockIdx.x + 1];
+    const ReduceSeg sg = segs[si];
+    const int i = off + threadIdx.x;
+    if (i >= sg.n) return;
+    float acc = 0.f;
+    for (int q = 0; q < sg.nsrc; ++q) {
+        const float* p = partial + sg.src[q] + i;
+        for (int s = 0; s < sg.nslabs[q]; ++s) acc += p[(size_t)s * sg.ss[q]];
+    }
+    grads[sg.dst + (i / sg.rl) * sg.ds + (i % sg.rl)] = acc;
+}
+void launch_reduce(const float* partial, float* grads, const ReduceSeg* segs_dev, const int* blk2seg_dev, int nblocks,
+                   hipStream_t s) {
+    hipLaunchKernelGGL(k_reduce, dim3(nblocks), dim3(256), 0, s, partial, grads, segs_dev, blk2seg_dev);
+}
+
+}  // namespace vsl

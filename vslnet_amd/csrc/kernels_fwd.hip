@@ -1,0 +1,877 @@
+// Forward kernels of the VSLNet hot path (gfx950).  Every kernel cites the reference lines it reproduces
+// (/root/reference/model/layers_t7.py unless noted).  Layout: activations are row-major (B*L, 128) fp32.
+#include "common.hpp"
+#include "launch.hpp"
+
+namespace vsl {
+
+// =========================================================================================================
+// weight packing (one launch per forward; jobs table lives in the plan)
+// =========================================================================================================
+__global__ __launch_bounds__(256) void k_pack(const float* __restrict__ params, float* __restrict__ pack,
+                                              const PackJob* __restrict__ jobs) {
+    const PackJob j = jobs[blockIdx.y];
+    const int n = j.kn * j.cn;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+        int k, c;
+        float v;
+        if (j.transpose) {          // Bm[k][c] = W[k][c]  (W row = contraction index): c is the fast source index
+            k = e / j.cn; c = e - k * j.cn;
+            v = params[j.src + (size_t)k * j.ld + c];
+        } else {                    // Bm[k][c] = W[c][k]: k is the fast source index
+            c = e / j.kn; k = e - c * j.kn;
+            v = params[j.src + (size_t)c * j.ld + k];
+        }
+        pack[j.dst + pack_index(j.k_off + k, j.col_off + c, j.ncols)] = v;
+    }
+}
+void launch_pack(const float* params, float* pack, const PackJob* jobs_dev, int njobs, hipStream_t s) {
+    if (njobs == 0) return;
+    hipLaunchKernelGGL(k_pack, dim3(64, njobs), dim3(256), 0, s, params, pack, jobs_dev);
+}
+
+// =========================================================================================================
+// a2  VisualProjection (:105-115):  Y = drop(X) W^T + b,  X (R, Dv) streamed from HBM once.
+//     32-row tile per workgroup, K streamed in 128-wide chunks through a double-buffered LDS tile
+//     (global -> regs -> LDS so the dropout mask is applied on the fly), B operand from the packed weight.
+// =========================================================================================================
+constexpr int VP_KC = 128;
+__global__ __launch_bounds__(256) void k_vproj_fwd(const float* __restrict__ X, const float* __restrict__ Wpack,
+                                                   const float* __restrict__ bias, float* __restrict__ Y, int R, int Dv,
+                                                   Drop dp) {
+    __shared__ __attribute__((aligned(16))) float As[2][TILE_M * LDP];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int r0 = blockIdx.x * TILE_M;
+    f32x16 acc[1];
+    zero_acc(acc);
+    const int nchunk = (Dv + VP_KC - 1) / VP_KC;
+    float4 stage[4];
+    auto gload = [&](int ch) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + q * 256;                 // 1024 float4 per chunk: row = e >> 5, c4 = e & 31
+            const int rr = e >> 5, c = (e & 31) * 4 + ch * VP_KC;
+            const int r = r0 + rr;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < R && c < Dv) {
+                v = *reinterpret_cast<const float4*>(X + (size_t)r * Dv + c);
+                if (dp.thresh) {
+                    const uint32_t base = (uint32_t)((size_t)r * Dv + c);
+                    v.x *= drop_mul(dp, base); v.y *= drop_mul(dp, base + 1);
+                    v.z *= drop_mul(dp, base + 2); v.w *= drop_mul(dp, base + 3);
+                }
+            }
+            stage[q] = v;
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + q * 256;
+            *reinterpret_cast<float4*>(&As[buf][(e >> 5) * LDP + (e & 31) * 4]) = stage[q];
+        }
+    };
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int buf = ch & 1;
+        if (ch + 1 < nchunk) gload(ch + 1);             // next chunk in flight while the MFMAs run
+        const int kc = min(VP_KC, Dv - ch * VP_KC);
+        gemm32<1>(As[buf], LDP, kc, Wpack + (size_t)ch * (VP_KC / 8) * D * 8, D, 32 * w, 0, acc);
+        if (ch + 1 < nchunk) sstore(buf ^ 1);
+        __syncthreads();
+    }
+    const int col = 32 * w + (lane & 31);
+    const float bv = bias[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int gr = r0 + acc_row(r, lane);
+        if (gr < R) Y[(size_t)gr * D + col] = acc[0][r] + bv;
+    }
+}
+void launch_vproj_fwd(const float* X, const float* Wpack, const float* bias, float* Y, int R, int Dv, Drop dp,
+                      hipStream_t s) {
+    hipLaunchKernelGGL(k_vproj_fwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), 0, s, X, Wpack, bias, Y, R, Dv, dp);
+}
+
+// =========================================================================================================
+// a3/a4  word + character embedding (:25-72) -> concatenated (Rq, 300 + 100) row, ready for the a5 linear.
+//   one workgroup (128 threads) per query word.
+//   char CNN: 4 x [Conv2d(50 -> c, (1,k)) + bias + ReLU -> max over char positions]; the arg-max position is
+//   saved (int8) for the backward.  Requires k <= Lc <= MAX_LC.
+// =========================================================================================================
+__device__ __forceinline__ void char_channel(int oc, int& conv, int& ch, int& k, int& woff, int& boff) {
+    // channel oc in [0,100): convs have 10/20/30/40 channels with kernel widths 1/2/3/4
+    if (oc < 10) { conv = 0; ch = oc; k = 1; }
+    else if (oc < 30) { conv = 1; ch = oc - 10; k = 2; }
+    else if (oc < 60) { conv = 2; ch = oc - 30; k = 3; }
+    else { conv = 3; ch = oc - 60; k = 4; }
+    woff = 0; boff = 0;
+}
+__global__ __launch_bounds__(128) void k_embed_fwd(const int64_t* __restrict__ word_ids, const int64_t* __restrict__ char_ids,
+                                                   const float* __restrict__ pad_vec, const float* __restrict__ unk_vec,
+                                                   const float* __restrict__ glove, const float* __restrict__ char_tab,
+                                                   CharConvPtrs cc, float* __restrict__ E, int8_t* __restrict__ argpos,
+                                                   int Rq, int Lc, int word_dim, int char_dim, Drop dw, Drop dc) {
+    __shared__ float Ce[MAX_LC * 64];                    // dropped-out char embeddings [Lc][char_dim <= 64]
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const int EW = word_dim + 100;
+    // ---- word vector (F.embedding over [pad; unk; glove], :41) + dropout
+    const int64_t wid = word_ids[r];
+    const float* src = wid == 0 ? pad_vec : (wid == 1 ? unk_vec : glove + (size_t)(wid - 2) * word_dim);
+    for (int c = tid; c < word_dim; c += 128)
+        E[(size_t)r * EW + c] = src[c] * drop_mul(dw, (uint32_t)(r * word_dim + c));
+    // ---- char embeddings + dropout -> LDS
+    for (int e = tid; e < Lc * char_dim; e += 128) {
+        const int p = e / char_dim, ci = e - p * char_dim;
+        const int64_t cid = char_ids[(size_t)r * Lc + p];
+        Ce[p * 64 + ci] = char_tab[(size_t)cid * char_dim + ci] * drop_mul(dc, (uint32_t)((r * Lc + p) * char_dim + ci));
+    }
+    __syncthreads();
+    if (tid < 100) {
+        int conv, ch, k, wo, bo;
+        char_channel(tid, conv, ch, k, wo, bo);
+        const float* W = cc.w[conv] + (size_t)ch * char_dim * k;    // (c, char_dim, 1, k): [ch][ci][kk]
+        const float bias = cc.b[conv][ch];
+        const int npos = Lc - k + 1;
+        float best = -1.f;
+        int bestp = 0;
+        for (int p0 = 0; p0 < npos; p0 += 8) {
+            float acc[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[q] = bias;
+            for (int ci = 0; ci < char_dim; ++ci)
+                for (int kk = 0; kk < k; ++kk) {
+                    const float wv = W[ci * k + kk];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int p = p0 + q + kk;
+                        acc[q] += wv * (p < Lc ? Ce[p * 64 + ci] : 0.f);
+                    }
+                }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float v = fmaxf(acc[q], 0.f);                 // ReLU before the max (:58,69-70)
+                if (p0 + q < npos && v > best) { best = v; bestp = p0 + q; }
+            }
+        }
+        E[(size_t)r * EW + word_dim + tid] = best;
+        argpos[(size_t)r * 100 + tid] = (int8_t)bestp;
+    }
+}
+void launch_embed_fwd(const int64_t* word_ids, const int64_t* char_ids, const float* pad_vec, const float* unk_vec,
+                      const float* glove, const float* char_tab, CharConvPtrs cc, float* E, int8_t* argpos, int Rq,
+                      int Lc, int word_dim, int char_dim, Drop dw, Drop dc, hipStream_t s) {
+    hipLaunchKernelGGL(k_embed_fwd, dim3(Rq), dim3(128), 0, s, word_ids, char_ids, pad_vec, unk_vec, glove, char_tab, cc,
+                       E, argpos, Rq, Lc, word_dim, char_dim, dw, dc);
+}
+
+// =========================================================================================================
+// generic row-tile linear  Y = A W^T + b  (Conv1D k=1, :12-22) for an (R, K) row-major A, K % 8 == 0.
+// Used for a5 (Embedding.linear, K = 400).  A is staged through LDS in 128-wide chunks.
+// =========================================================================================================
+__global__ __launch_bounds__(256) void k_linear_fwd(const float* __restrict__ A, const float* __restrict__ Wpack,
+                                                    const float* __restrict__ bias, float* __restrict__ Y, int R, int K) {
+    __shared__ __attribute__((aligned(16))) float As[TILE_M * LDP];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int r0 = blockIdx.x * TILE_M;
+    f32x16 acc[1];
+    zero_acc(acc);
+    for (int k0 = 0; k0 < K; k0 += 128) {
+        const int kc = min(128, K - k0);
+        for (int e = tid; e < TILE_M * 32; e += 256) {
+            const int rr = e >> 5, c = (e & 31) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r0 + rr < R && c < kc) v = *reinterpret_cast<const float4*>(A + (size_t)(r0 + rr) * K + k0 + c);
+            *reinterpret_cast<float4*>(&As[rr * LDP + c]) = v;
+        }
+        __syncthreads();
+        gemm32<1>(As, LDP, kc, Wpack + (size_t)(k0 / 8) * D * 8, D, 32 * w, 0, acc);
+        __syncthreads();
+    }
+    const int col = 32 * w + (lane & 31);
+    const float bv = bias[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int gr = r0 + acc_row(r, lane);
+        if (gr < R) Y[(size_t)gr * D + col] = acc[0][r] + bv;
+    }
+}
+void launch_linear_fwd(const float* A, const float* Wpack, const float* bias, float* Y, int R, int K, hipStream_t s) {
+    hipLaunchKernelGGL(k_linear_fwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), 0, s, A, Wpack, bias, Y, R, K);
+}
+
+// =========================================================================================================
+// a6/a7  one DepthwiseSeparableConvBlock layer (:131-140), fused:
+//   x' = x (+ pos[t])  ->  v = LN(x')  ->  u = depthwise7(v) (zero outside the sample, padded rows NOT masked)
+//   -> z = u Wp^T + b  ->  y = x' + drop(relu(z)).      Saves the relu bit-mask (R x 4 uint32) for the backward.
+// Tile = 32 rows + 3 halo rows each side (LayerNorm of the halo rows is recomputed).
+// =========================================================================================================
+__global__ __launch_bounds__(256) void k_conv_layer_fwd(const float* __restrict__ xin, const float* __restrict__ pos,
+                                                        float* __restrict__ x0_out, const float* __restrict__ ln_g,
+                                                        const float* __restrict__ ln_b, const float* __restrict__ dw_w,
+                                                        const float* __restrict__ Wpack, const float* __restrict__ pw_b,
+                                                        float* __restrict__ y_out, float* __restrict__ u_out,
+                                                        uint32_t* __restrict__ relu_mask, int R, int L, Drop dp) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NH = TILE_M + 2 * HALO;               // 38 rows
+    float* Xs = smem;                                   // [38][LDP] raw x' (residual source)
+    float* Vs = Xs + NH * LDP;                          // [38][LDP] LN(x')
+    float* Us = Vs + NH * LDP;                          // [32][LDP] depthwise output = GEMM A operand
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int r0 = blockIdx.x * TILE_M;
+    // ---- load rows r0-3 .. r0+34 (+ positional rows, :202)
+    for (int e = tid; e < NH * 32; e += 256) {
+        const int rr = e >> 5, c = (e & 31) * 4;
+        const int r = r0 - HALO + rr;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r >= 0 && r < R) {
+            v = *reinterpret_cast<const float4*>(xin + (size_t)r * D + c);
+            if (pos) {
+                const float4 pv = *reinterpret_cast<const float4*>(pos + (size_t)(r % L) * D + c);
+                v.x += pv.x; v.y += pv.y; v.z += pv.z; v.w += pv.w;
+                if (x0_out && rr >= HALO && rr < HALO + TILE_M) *reinterpret_cast<float4*>(x0_out + (size_t)r * D + c) = v;
+            }
+        }
+        *reinterpret_cast<float4*>(&Xs[rr * LDP + c]) = v;
+        *reinterpret_cast<float4*>(&Vs[rr * LDP + c]) = v;
+    }
+    __syncthreads();
+    // ---- LayerNorm of all 38 rows (one wave per row)
+    for (int rr = w; rr < NH; rr += 4) {
+        float mu, rs;
+        ln_row_inplace(Vs + rr * LDP, ln_g, ln_b, mu, rs);
+    }
+    __syncthreads();
+    // ---- depthwise conv k=7 along the sequence: thread = (channel c, half of the tile)
+    {
+        const int c = tid & 127, hb = (tid >> 7) * 16;
+        float wk[DWK];
+#pragma unroll
+        for (int k = 0; k < DWK; ++k) wk[k] = dw_w[c * DWK + k];
+        for (int rr = hb; rr < hb + 16; ++rr) {
+            const int t = (r0 + rr) % L;
+            float u = 0.f;
+#pragma unroll
+            for (int k = 0; k < DWK; ++k) {
+                const int tt = t + k - HALO;
+                if (tt >= 0 && tt < L) u += wk[k] * Vs[(rr + k) * LDP + c];
+            }
+            Us[rr * LDP + c] = u;
+            if (u_out && r0 + rr < R) u_out[(size_t)(r0 + rr) * D + c] = u;     // saved: A operand of the weight gradient
+        }
+    }
+    __syncthreads();
+    // ---- pointwise GEMM + bias + ReLU (+ dropout) + residual
+    f32x16 acc[1];
+    zero_acc(acc);
+    gemm32<1>(Us, LDP, D, Wpack, D, 32 * w, 0, acc);
+    const int col = 32 * w + (lane & 31);
+    const float bv = pw_b[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r, lane);
+        const int gr = r0 + row;
+        const float z = acc[0][r] + bv;
+        const unsigned long long bal = __ballot(z > 0.f);
+        if (lane == 0) {
+            const int glo = r0 + (r & 3) + 8 * (r >> 2);
+            if (glo < R) relu_mask[(size_t)glo * 4 + w] = (uint32_t)bal;
+            if (glo + 4 < R) relu_mask[(size_t)(glo + 4) * 4 + w] = (uint32_t)(bal >> 32);
+        }
+        if (gr < R) {
+            const float a = fmaxf(z, 0.f) * drop_mul(dp, (uint32_t)(gr * D + col));
+            y_out[(size_t)gr * D + col] = Xs[(row + HALO) * LDP + col] + a;
+        }
+    }
+}
+void launch_conv_layer_fwd(const float* xin, const float* pos, float* x0_out, const float* ln_g, const float* ln_b,
+                           const float* dw_w, const float* Wpack, const float* pw_b, float* y_out, float* u_out,
+                           uint32_t* relu_mask, int R, int L, Drop dp, hipStream_t s) {
+    const size_t shm = (size_t)(2 * (TILE_M + 2 * HALO) + TILE_M) * LDP * sizeof(float);
+    hipLaunchKernelGGL(k_conv_layer_fwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm, s, xin, pos, x0_out, ln_g, ln_b,
+                       dw_w, Wpack, pw_b, y_out, u_out, relu_mask, R, L, dp);
+}
+
+// =========================================================================================================
+// a8 (first half)  h1 = drop(LN1(x));  Q,K,V = h1 W{q,k,v}^T + b   (:168-173).  One GEMM with N = 384.
+// =========================================================================================================
+__global__ __launch_bounds__(256) void k_ln_qkv_fwd(const float* __restrict__ x, const float* __restrict__ ln_g,
+                                                    const float* __restrict__ ln_b, const float* __restrict__ Wpack,
+                                                    const float* __restrict__ bq, const float* __restrict__ bk,
+                                                    const float* __restrict__ bv, float* __restrict__ h1,
+                                                    float* __restrict__ q, float* __restrict__ k, float* __restrict__ v,
+                                                    int R, Drop d1) {
+    __shared__ __attribute__((aligned(16))) float Hs[TILE_M * LDP];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int r0 = blockIdx.x * TILE_M;
+    load_tile128(Hs, x, r0, TILE_M, R);
+    __syncthreads();
+    for (int rr = w; rr < TILE_M; rr += 4) {
+        float mu, rs;
+        float* row = Hs + rr * LDP;
+        ln_row_inplace(row, ln_g, ln_b, mu, rs);
+        if (d1.thresh) {
+            const uint32_t base = (uint32_t)((r0 + rr) * D);
+            row[lane] *= drop_mul(d1, base + lane);
+            row[lane + 64] *= drop_mul(d1, base + lane + 64);
+        }
+        if (h1 && r0 + rr < R) {
+            h1[(size_t)(r0 + rr) * D + lane] = row[lane];
+            h1[(size_t)(r0 + rr) * D + lane + 64] = row[lane + 64];
+        }
+    }
+    __syncthreads();
+    f32x16 acc[3];
+    zero_acc(acc);
+    gemm32<3>(Hs, LDP, D, Wpack, 3 * D, 32 * w, D, acc);
+    const int col = 32 * w + (lane & 31);
+    const float b0 = bq[col], b1 = bk[col], b2 = bv[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int gr = r0 + acc_row(r, lane);
+        if (gr < R) {
+            q[(size_t)gr * D + col] = acc[0][r] + b0;
+            k[(size_t)gr * D + col] = acc[1][r] + b1;
+            v[(size_t)gr * D + col] = acc[2][r] + b2;
+        }
+    }
+}
+void launch_ln_qkv_fwd(const float* x, const float* ln_g, const float* ln_b, const float* Wpack, const float* bq,
+                       const float* bk, const float* bv, float* h1, float* q, float* k, float* v, int R, Drop d1,
+                       hipStream_t s) {
+    hipLaunchKernelGGL(k_ln_qkv_fwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), 0, s, x, ln_g, ln_b, Wpack, bq, bk, bv, h1, q,
+                       k, v, R, d1);
+}
+
+// =========================================================================================================
+// a8 (attention core)  S = Q K^T / sqrt(hd) + (1 - mask[key]) * -1e30 ; P = softmax ; O = drop(P) V   (:174-182)
+//   head size 16, fp32 MFMA 16x16x4.  Workgroup = (64 queries, head, sample); wave = 16 queries.
+//   K/V head slices live in LDS; scores are computed transposed (S^T = K Q^T) so every lane owns one query column:
+//   online softmax is lane-local (+2 shuffles across the 4 key groups) and P feeds the PV MFMA from registers.
+//   Saves LSE = m + log(l) per (b, h, q) for the backward.
+// =========================================================================================================
+__global__ __launch_bounds__(256) void k_attn_fwd(const float* __restrict__ Q, const float* __restrict__ K,
+                                                  const float* __restrict__ V, const float* __restrict__ mask,
+                                                  float* __restrict__ att, float* __restrict__ lse, int L, int H,
+                                                  int b_off, Drop d2) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int Lp = (L + 15) & ~15;
+    const int kst = head_slice_stride(Lp);
+    float* Ks = smem;                 // [Lp][kst]
+    float* Vs = Ks + Lp * kst;        // [Lp][kst]
+    float* Mb = Vs + Lp * kst;        // [Lp] additive key bias
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const size_t rowbase = (size_t)b * L;
+    for (int e = tid; e < Lp * 4; e += 256) {
+        const int key = e >> 2, c4 = (e & 3) * 4;
+        float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+        if (key < L) {
+            kv = *reinterpret_cast<const float4*>(K + (rowbase + key) * D + h * HD + c4);
+            vv = *reinterpret_cast<const float4*>(V + (rowbase + key) * D + h * HD + c4);
+        }
+        *reinterpret_cast<float4*>(&Ks[key * kst + c4]) = kv;
+        *reinterpret_cast<float4*>(&Vs[key * kst + c4]) = vv;
+    }
+    for (int key = tid; key < Lp; key += 256)
+        Mb[key] = key < L ? (1.0f - mask[rowbase + key]) * MASK_VALUE : MASK_VALUE;
+    __syncthreads();
+    const int qi = lane & 15, g = lane >> 4;
+    const int q = blockIdx.x * 64 + w * 16 + qi;
+    const bool qok = q < L;
+    float4 qf = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (qok) qf = *reinterpret_cast<const float4*>(Q + (rowbase + q) * D + h * HD + 4 * g);
+    const float scale = 0.25f;                     // 1 / sqrt(16), applied AFTER QK^T like the reference (:175)
+    float m = -3.0e38f, l = 0.f;
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    const uint32_t pbase = (uint32_t)(((size_t)(b + b_off) * H + h) * L + q) * (uint32_t)L;
+    for (int kt = 0; kt < Lp; kt += 16) {
+        // S^T tile: rows = keys kt + 4g + reg, col = query qi
+        const float4 kf = *reinterpret_cast<const float4*>(&Ks[(kt + qi) * kst + 4 * g]);
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf.x, s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf.y, s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf.z, s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf.w, s, 0, 0, 0);
+        float p[4];
+        float tmax = -3.0e38f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            p[r] = s[r] * scale + Mb[kt + 4 * g + r];
+            tmax = fmaxf(tmax, p[r]);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        const float mn = fmaxf(m, tmax);
+        const float alpha = __expf(m - mn);
+        m = mn;
+        l *= alpha;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            p[r] = __expf(p[r] - mn);
+            l += p[r];
+            o[r] *= alpha;
+        }
+        // O^T += V^T P^T : A[i = dd][k = key] = V[key][dd], B[k = key][j = q] = P (in registers)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = kt + 4 * g + r;
+            const float pd = p[r] * drop_mul(d2, pbase + key);
+            const float vv = Vs[key * kst + qi];
+            o = __builtin_amdgcn_mfma_f32_16x16x4f32(vv, pd, o, 0, 0, 0);
+        }
+    }
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    if (qok) {
+        const float inv = 1.0f / l;
+        // lane (qi, g) holds O[q][dd = 4g + reg]
+        *reinterpret_cast<float4*>(att + (rowbase + q) * D + h * HD + 4 * g) =
+            make_float4(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
+        if (g == 0) lse[((size_t)b * H + h) * L + q] = m + __logf(l);
+    }
+}
+void launch_attn_fwd(const float* Q, const float* K, const float* V, const float* mask, float* att, float* lse, int B,
+                     int L, int H, int b_off, Drop d2, hipStream_t s) {
+    const int Lp = (L + 15) & ~15;
+    const int kst = head_slice_stride(Lp);
+    const size_t shm = (size_t)(2 * Lp * kst + Lp) * sizeof(float);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)k_attn_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    hipLaunchKernelGGL(k_attn_fwd, dim3((L + 63) / 64, H, B), dim3(256), shm, s, Q, K, V, mask, att, lse, L, H, b_off, d2);
+}
+
+// =========================================================================================================
+// a8 (second half)  r = drop(att) + x ; y = drop( drop(LN2(r)) Wo^T + bo ) + r      (:183-190)
+// =========================================================================================================
+__global__ __launch_bounds__(256) void k_attn_out_fwd(const float* __restrict__ att, const float* __restrict__ x,
+                                                      const float* __restrict__ ln_g, const float* __restrict__ ln_b,
+                                                      const float* __restrict__ Wpack, const float* __restrict__ bo,
+                                                      float* __restrict__ r_out, float* __restrict__ h2_out,
+                                                      float* __restrict__ y_out, int R, Drop d3, Drop d4, Drop d5) {
+    __shared__ __attribute__((aligned(16))) float Rs[TILE_M * LDP];
+    __shared__ __attribute__((aligned(16))) float Hs[TILE_M * LDP];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int r0 = blockIdx.x * TILE_M;
+    for (int e = tid; e < TILE_M * 32; e += 256) {
+        const int rr = e >> 5, c = (e & 31) * 4;
+        const int r = r0 + rr;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < R) {
+            const float4 a = *reinterpret_cast<const float4*>(att + (size_t)r * D + c);
+            const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)r * D + c);
+            const uint32_t base = (uint32_t)(r * D + c);
+            v.x = a.x * drop_mul(d3, base) + xv.x;
+            v.y = a.y * drop_mul(d3, base + 1) + xv.y;
+            v.z = a.z * drop_mul(d3, base + 2) + xv.z;
+            v.w = a.w * drop_mul(d3, base + 3) + xv.w;
+            *reinterpret_cast<float4*>(r_out + (size_t)r * D + c) = v;
+        }
+        *reinterpret_cast<float4*>(&Rs[rr * LDP + c]) = v;
+        *reinterpret_cast<float4*>(&Hs[rr * LDP + c]) = v;
+    }
+    __syncthreads();
+    for (int rr = w; rr < TILE_M; rr += 4) {
+        float mu, rs;
+        float* row = Hs + rr * LDP;
+        ln_row_inplace(row, ln_g, ln_b, mu, rs);
+        if (d4.thresh) {
+            const uint32_t base = (uint32_t)((r0 + rr) * D);
+            row[lane] *= drop_mul(d4, base + lane);
+            row[lane + 64] *= drop_mul(d4, base + lane + 64);
+        }
+        if (h2_out && r0 + rr < R) {
+            h2_out[(size_t)(r0 + rr) * D + lane] = row[lane];
+            h2_out[(size_t)(r0 + rr) * D + lane + 64] = row[lane + 64];
+        }
+    }
+    __syncthreads();
+    f32x16 acc[1];
+    zero_acc(acc);
+    gemm32<1>(Hs, LDP, D, Wpack, D, 32 * w, 0, acc);
+    const int col = 32 * w + (lane & 31);
+    const float bvv = bo[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r, lane);
+        const int gr = r0 + row;
+        if (gr < R)
+            y_out[(size_t)gr * D + col] = (acc[0][r] + bvv) * drop_mul(d5, (uint32_t)(gr * D + col)) + Rs[row * LDP + col];
+    }
+}
+void launch_attn_out_fwd(const float* att, const float* x, const float* ln_g, const float* ln_b, const float* Wpack,
+                         const float* bo, float* r_out, float* h2_out, float* y_out, int R, Drop d3, Drop d4, Drop d5,
+                         hipStream_t s) {
+    hipLaunchKernelGGL(k_attn_out_fwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), 0, s, att, x, ln_g, ln_b, Wpack, bo, r_out,
+                       h2_out, y_out, R, d3, d4, d5);
+}
+
+// =========================================================================================================
+// a10  CQAttention (:208-243), three kernels.
+//  (1) k_cq_score: trilinear score on dropped-out C, Q (:237-242) for a 32-row tile + row softmax over the
+//      query words (:225).  Writes raw score S (B,T,Lq) and S_row (B,T,Lq).
+//  (2) k_cq_col  : per sample: column softmax over clips (:226) -> S_col (B,T,Lq);  M = S_col^T C (Lq,128)
+//      (re-association of (S_row S_col^T) C = S_row (S_col^T C): O(T Lq d) instead of O(T^2 d), fp32 rounding only);
+//      plus a11's WeightedPool (:253-259) and the per-sample bias  pb = W2 pooled + b  of CQConcatenate (:268-274).
+//  (3) k_cq_out  : c2q = S_row Q, q2c = S_row M, concat [C, c2q, C*c2q, C*q2c] (:231) -> Conv1D 4d->d (:232).
+// =========================================================================================================
+__global__ __launch_bounds__(256) void k_cq_score(const float* __restrict__ C, const float* __restrict__ Qf,
+                                                  const float* __restrict__ qmask, const float* __restrict__ w4C,
+                                                  const float* __restrict__ w4Q, const float* __restrict__ w4mlu,
+                                                  float* __restrict__ S, float* __restrict__ Srow, int T, int Lq, int b_off,
+                                                  Drop dc, Drop dq) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Cs = smem;                         // [32][LDP]  dropped C * w4mlu
+    float* Qs = Cs + TILE_M * LDP;            // [Lq][LDP]  dropped Q
+    float* s0 = Qs + Lq * LDP;                // [32]
+    float* s1 = s0 + TILE_M;                  // [Lq]
+    float* Sc = s1 + ((Lq + 3) & ~3);         // [32][Lq+1]
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int b = blockIdx.y, t0 = blockIdx.x * TILE_M;
+    const size_t crow = (size_t)b * T, qrow = (size_t)b * Lq;
+    for (int e = tid; e < TILE_M * D; e += 256) {
+        const int rr = e >> 7, c = e & 127;
+        const int t = t0 + rr;
+        float v = 0.f;
+        if (t < T) v = C[(crow + t) * D + c] * drop_mul(dc, (uint32_t)(((b + b_off) * T + t) * D + c));
+        Cs[rr * LDP + c] = v;
+    }
+    for (int e = tid; e < Lq * D; e += 256) {
+        const int j = e >> 7, c = e & 127;
+        Qs[j * LDP + c] = Qf[(qrow + j) * D + c] * drop_mul(dq, (uint32_t)(((b + b_off) * Lq + j) * D + c));
+    }
+    __syncthreads();
+    // s0[i] = Cd[i] . w4C ; s1[j] = Qd[j] . w4Q   (one wave per row)
+    for (int rr = w; rr < TILE_M + Lq; rr += 4) {
+        const float* row = rr < TILE_M ? Cs + rr * LDP : Qs + (rr - TILE_M) * LDP;
+        const float* wv = rr < TILE_M ? w4C : w4Q;
+        const float d = wave_sum(row[lane] * wv[lane] + row[lane + 64] * wv[lane + 64]);
+        if (lane == 0) { if (rr < TILE_M) s0[rr] = d; else s1[rr - TILE_M] = d; }
+    }
+    __syncthreads();
+    // scale C by w4mlu in place (after s0 used the unscaled values)
+    for (int e = tid; e < TILE_M * D; e += 256) Cs[(e >> 7) * LDP + (e & 127)] *= w4mlu[e & 127];
+    __syncthreads();
+    // S[i][j]: thread (i = tid >> 3, j = tid & 7, +8, ...)
+    {
+        const int i = tid >> 3;
+        const float4* cr = reinterpret_cast<const float4*>(Cs + i * LDP);
+        for (int j = tid & 7; j < Lq; j += 8) {
+            const float4* qr = reinterpret_cast<const float4*>(Qs + j * LDP);
+            float acc = 0.f;
+#pragma unroll 8
+            for (int c = 0; c < 32; ++c) {
+                const float4 a = cr[c], q4 = qr[c];
+                acc += a.x * q4.x + a.y * q4.y + a.z * q4.z + a.w * q4.w;
+            }
+            Sc[i * (Lq + 1) + j] = acc + s0[i] + s1[j];
+        }
+    }
+    __syncthreads();
+    // row softmax over j with the query mask; one wave per row (Lq <= 128: lane handles j = lane, lane + 64)
+    for (int rr = w; rr < TILE_M; rr += 4) {
+        const int t = t0 + rr;
+        if (t >= T) continue;
+        float v0 = -3.0e38f, v1 = -3.0e38f, r0 = 0.f, r1 = 0.f;
+        if (lane < Lq) { r0 = Sc[rr * (Lq + 1) + lane]; v0 = r0 + (1.f - qmask[qrow + lane]) * MASK_VALUE; }
+        if (lane + 64 < Lq) { r1 = Sc[rr * (Lq + 1) + lane + 64]; v1 = r1 + (1.f - qmask[qrow + lane + 64]) * MASK_VALUE; }
+        const float mx = wave_max(fmaxf(v0, v1));
+        const float e0 = lane < Lq ? __expf(v0 - mx) : 0.f, e1 = lane + 64 < Lq ? __expf(v1 - mx) : 0.f;
+        const float inv = 1.0f / wave_sum(e0 + e1);
+        if (lane < Lq) { S[(crow + t) * Lq + lane] = r0; Srow[(crow + t) * Lq + lane] = e0 * inv; }
+        if (lane + 64 < Lq) { S[(crow + t) * Lq + lane + 64] = r1; Srow[(crow + t) * Lq + lane + 64] = e1 * inv; }
+    }
+}
+void launch_cq_score(const float* C, const float* Qf, const float* qmask, const float* w4C, const float* w4Q,
+                     const float* w4mlu, float* S, float* Srow, int B, int T, int Lq, int b_off, Drop dc, Drop dq,
+                     hipStream_t s) {
+    const size_t shm = (size_t)((TILE_M + Lq) * LDP + TILE_M + ((Lq + 3) & ~3) + TILE_M * (Lq + 1)) * sizeof(float);
+    hipLaunchKernelGGL(k_cq_score, dim3((T + TILE_M - 1) / TILE_M, B), dim3(256), shm, s, C, Qf, qmask, w4C, w4Q, w4mlu, S,
+                       Srow, T, Lq, b_off, dc, dq);
+}
+
+__global__ __launch_bounds__(256) void k_cq_col(const float* __restrict__ C, const float* __restrict__ Qf,
+                                                const float* __restrict__ S, const float* __restrict__ cmask,
+                                                const float* __restrict__ qmask, const float* __restrict__ pool_w,
+                                                const float* __restrict__ Wcat, const float* __restrict__ bcat,
+                                                float* __restrict__ Scol, float* __restrict__ M, float* __restrict__ alpha,
+                                                float* __restrict__ pooled, float* __restrict__ pb, int T, int Lq) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* cmax = smem;              // [Lq]
+    float* cinv = cmax + Lq;         // [Lq]
+    float* red = cinv + Lq;          // [256]
+    float* al = red + 256;           // [Lq]
+    float* pl = al + Lq;             // [128]
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int b = blockIdx.x;
+    const size_t crow = (size_t)b * T, qrow = (size_t)b * Lq;
+    // ---- column statistics over the clips: one wave per column j
+    for (int j = w; j < Lq; j += 4) {
+        float mx = -3.0e38f;
+        for (int t = lane; t < T; t += 64) mx = fmaxf(mx, S[(crow + t) * Lq + j] + (1.f - cmask[crow + t]) * MASK_VALUE);
+        mx = wave_max(mx);
+        float sm = 0.f;
+        for (int t = lane; t < T; t += 64) sm += __expf(S[(crow + t) * Lq + j] + (1.f - cmask[crow + t]) * MASK_VALUE - mx);
+        sm = wave_sum(sm);
+        if (lane == 0) { cmax[j] = mx; cinv[j] = 1.0f / sm; }
+    }
+    __syncthreads();
+    for (int e = tid; e < T * Lq; e += 256) {
+        const int t = e / Lq, j = e - t * Lq;
+        Scol[crow * Lq + e] = __expf(S[crow * Lq + e] + (1.f - cmask[crow + t]) * MASK_VALUE - cmax[j]) * cinv[j];
+    }
+    __syncthreads();    // Scol of this sample is re-read below by other threads of this workgroup (same CU: L1-coherent)
+    // ---- M[j][c] = sum_t Scol[t][j] * C[t][c] : thread = (c, half of the j range)
+    {
+        const int c = tid & 127, jh = tid >> 7;
+        const int jn = (Lq + 1) / 2, j0 = jh * jn, j1 = min(Lq, j0 + jn);
+        for (int jb = j0; jb < j1; jb += 8) {
+            float acc[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+            for (int t = 0; t < T; ++t) {
+                const float cv = C[(crow + t) * D + c];
+                const float* sr = Scol + (crow + t) * Lq + jb;
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (jb + q < j1) acc[q] += sr[q] * cv;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (jb + q < j1) M[(qrow + jb + q) * D + c] = acc[q];
+        }
+    }
+    // ---- WeightedPool: alpha = softmax_j(Q[j].w + mask) ; pooled = sum_j alpha_j Q[j]
+    for (int j = w; j < Lq; j += 4) {
+        const float* row = Qf + (qrow + j) * D;
+        const float d = wave_sum(row[lane] * pool_w[lane] + row[lane + 64] * pool_w[lane + 64]);
+        if (lane == 0) al[j] = d + (1.f - qmask[qrow + j]) * MASK_VALUE;
+    }
+    __syncthreads();
+    if (w == 0) {
+        const float v0 = lane < Lq ? al[lane] : -3.0e38f, v1 = lane + 64 < Lq ? al[lane + 64] : -3.0e38f;
+        const float mx = wave_max(fmaxf(v0, v1));
+        const float e0 = lane < Lq ? __expf(v0 - mx) : 0.f, e1 = lane + 64 < Lq ? __expf(v1 - mx) : 0.f;
+        const float inv = 1.0f / wave_sum(e0 + e1);
+        if (lane < Lq) { al[lane] = e0 * inv; alpha[qrow + lane] = e0 * inv; }
+        if (lane + 64 < Lq) { al[lane + 64] = e1 * inv; alpha[qrow + lane + 64] = e1 * inv; }
+    }
+    __syncthreads();
+    if (tid < D) {
+        float acc = 0.f;
+        for (int j = 0; j < Lq; ++j) acc += al[j] * Qf[(qrow + j) * D + tid];
+        pl[tid] = acc;
+        pooled[(size_t)b * D + tid] = acc;
+    }
+    __syncthreads();
+    // ---- pb[o] = sum_c Wcat[o][128 + c] * pooled[c] + bcat[o]     (second half of the 2d -> d Conv1D)
+    for (int o = w; o < D; o += 4) {
+        const float* wr = Wcat + (size_t)o * 2 * D + D;
+        const float d = wave_sum(wr[lane] * pl[lane] + wr[lane + 64] * pl[lane + 64]);
+        if (lane == 0) pb[(size_t)b * D + o] = d + bcat[o];
+    }
+}
+void launch_cq_col(const float* C, const float* Qf, const float* S, const float* cmask, const float* qmask,
+                   const float* pool_w, const float* Wcat, const float* bcat, float* Scol, float* M, float* alpha,
+                   float* pooled, float* pb, int B, int T, int Lq, hipStream_t s) {
+    const size_t shm = (size_t)(3 * Lq + 256 + D) * sizeof(float);
+    hipLaunchKernelGGL(k_cq_col, dim3(B), dim3(256), shm, s, C, Qf, S, cmask, qmask, pool_w, Wcat, bcat, Scol, M, alpha,
+                       pooled, pb, T, Lq);
+}
+
+// builds the [32][4*128] concat tile (:231) in LDS from C, S_row, Q, M  (shared by forward and backward)
+__device__ __forceinline__ void cq_build_concat(float* Cat /*[32][CATP]*/, const float* Cs /*[32][LDP]*/,
+                                                const float* Ss /*[32][Lq]*/, const float* __restrict__ Qg,
+                                                const float* __restrict__ Mg, int Lq, int catp) {
+    const int c = threadIdx.x & 127, hb = (threadIdx.x >> 7) * 16;
+    float a1[16], a2[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { a1[q] = 0.f; a2[q] = 0.f; }
+    for (int j = 0; j < Lq; ++j) {
+        const float qv = Qg[(size_t)j * D + c], mv = Mg[(size_t)j * D + c];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float sv = Ss[(hb + q) * Lq + j];
+            a1[q] += sv * qv;
+            a2[q] += sv * mv;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int rr = hb + q;
+        const float cv = Cs[rr * LDP + c];
+        float* o = Cat + rr * catp;
+        o[c] = cv;
+        o[D + c] = a1[q];
+        o[2 * D + c] = cv * a1[q];
+        o[3 * D + c] = cv * a2[q];
+    }
+}
+__global__ __launch_bounds__(256) void k_cq_out(const float* __restrict__ C, const float* __restrict__ Qf,
+                                                const float* __restrict__ Srow, const float* __restrict__ M,
+                                                const float* __restrict__ Wpack, const float* __restrict__ bias,
+                                                float* __restrict__ cat_out, float* __restrict__ out, int T, int Lq) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Cat = smem;                        // [32][CATP]
+    float* Cs = Cat + TILE_M * CATP;          // [32][LDP]
+    float* Ss = Cs + TILE_M * LDP;            // [32][Lq]
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int b = blockIdx.y, t0 = blockIdx.x * TILE_M;
+    const size_t crow = (size_t)b * T, qrow = (size_t)b * Lq;
+    load_tile128(Cs, C + crow * D, t0, TILE_M, T);
+    for (int e = tid; e < TILE_M * Lq; e += 256) {
+        const int rr = e / Lq;
+        Ss[e] = (t0 + rr < T) ? Srow[(crow + t0) * Lq + e] : 0.f;
+    }
+    __syncthreads();
+    cq_build_concat(Cat, Cs, Ss, Qf + qrow * D, M + qrow * D, Lq, CATP);
+    __syncthreads();
+    if (cat_out)                                   // saved: A operand (R, 512) of the cqa_linear weight gradient
+        for (int e = tid; e < TILE_M * D; e += 256) {
+            const int rr = e >> 7, c4 = (e & 127) * 4;
+            if (t0 + rr < T)
+                *reinterpret_cast<float4*>(cat_out + (crow + t0 + rr) * 4 * D + c4) = *reinterpret_cast<const float4*>(&Cat[rr * CATP + c4]);
+        }
+    f32x16 acc[1];
+    zero_acc(acc);
+    gemm32<1>(Cat, CATP, 4 * D, Wpack, D, 32 * w, 0, acc);
+    const int col = 32 * w + (lane & 31);
+    const float bv = bias[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int t = t0 + acc_row(r, lane);
+        if (t < T) out[(crow + t) * D + col] = acc[0][r] + bv;
+    }
+}
+void launch_cq_out(const float* C, const float* Qf, const float* Srow, const float* M, const float* Wpack,
+                   const float* bias, float* cat_out, float* out, int B, int T, int Lq, hipStream_t s) {
+    const size_t shm = (size_t)(TILE_M * CATP + TILE_M * LDP + TILE_M * Lq) * sizeof(float);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)k_cq_out, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    hipLaunchKernelGGL(k_cq_out, dim3((T + TILE_M - 1) / TILE_M, B), dim3(256), shm, s, C, Qf, Srow, M, Wpack, bias, cat_out, out, T, Lq);
+}
+
+// =========================================================================================================
+// a11 + a12  CQConcatenate conv (first half of the 2d -> d Conv1D on the context + per-sample pooled-query bias pb)
+//            fused with HighLightLayer (:282-289) and the gating  features * h  (VSLNet_t7.py:60).
+// =========================================================================================================
+__global__ __launch_bounds__(256) void k_cqcat_fwd(const float* __restrict__ f1, const float* __restrict__ Wpack,
+                                                   const float* __restrict__ pb, const float* __restrict__ wh,
+                                                   const float* __restrict__ bh, const float* __restrict__ vmask,
+                                                   float* __restrict__ f2, float* __restrict__ hscore,
+                                                   float* __restrict__ gated, int R, int T) {
+    __shared__ __attribute__((aligned(16))) float As[TILE_M * LDP];
+    __shared__ __attribute__((aligned(16))) float Fs[TILE_M * LDP];
+    __shared__ float hs[TILE_M];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int r0 = blockIdx.x * TILE_M;
+    load_tile128(As, f1, r0, TILE_M, R);
+    __syncthreads();
+    f32x16 acc[1];
+    zero_acc(acc);
+    gemm32<1>(As, LDP, D, Wpack, D, 32 * w, 0, acc);
+    const int col = 32 * w + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r, lane);
+        const int gr = min(r0 + row, R - 1);
+        Fs[row * LDP + col] = acc[0][r] + pb[(size_t)(gr / T) * D + col];
+    }
+    __syncthreads();
+    for (int rr = w; rr < TILE_M; rr += 4) {
+        const float* row = Fs + rr * LDP;
+        const float d = wave_sum(row[lane] * wh[lane] + row[lane + 64] * wh[lane + 64]);
+        if (lane == 0) {
+            const int gr = r0 + rr;
+            float hv = 0.f;
+            if (gr < R) {
+                const float lg = d + bh[0] + (1.f - vmask[gr]) * MASK_VALUE;      // mask_logits (:286)
+                hv = 1.0f / (1.0f + __expf(-lg));
+                hscore[gr] = hv;
+            }
+            hs[rr] = hv;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < TILE_M * 32; e += 256) {
+        const int rr = e >> 5, c = (e & 31) * 4;
+        const int gr = r0 + rr;
+        if (gr < R) {
+            const float4 v = *reinterpret_cast<const float4*>(&Fs[rr * LDP + c]);
+            const float hv = hs[rr];
+            *reinterpret_cast<float4*>(f2 + (size_t)gr * D + c) = v;
+            *reinterpret_cast<float4*>(gated + (size_t)gr * D + c) = make_float4(v.x * hv, v.y * hv, v.z * hv, v.w * hv);
+        }
+    }
+}
+void launch_cqcat_fwd(const float* f1, const float* Wpack, const float* pb, const float* wh, const float* bh,
+                      const float* vmask, float* f2, float* hscore, float* gated, int R, int T, hipStream_t s) {
+    hipLaunchKernelGGL(k_cqcat_fwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), 0, s, f1, Wpack, pb, wh, bh, vmask, f2, hscore,
+                       gated, R, T);
+}
+
+// =========================================================================================================
+// a14 heads (:328-337, 347-352): logits = mask_logits( Conv1D(d->1)( relu( Conv1D(2d->d)([LN(feat), x]) ) ) )
+//   blockIdx.y selects start / end.  `hid` (relu output) is saved for the backward.
+// =========================================================================================================
+constexpr int HDP = 2 * D + 4;
+__global__ __launch_bounds__(256) void k_head_fwd(HeadArgs a0, HeadArgs a1, const float* __restrict__ x,
+                                                  const float* __restrict__ vmask, int R) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                     // [32][HDP] = [LN(feat) | x]
+    float* Hd = As + TILE_M * HDP;        // [32][LDP] relu(z)
+    const HeadArgs a = blockIdx.y == 0 ? a0 : a1;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int r0 = blockIdx.x * TILE_M;
+    for (int e = tid; e < TILE_M * 32; e += 256) {
+        const int rr = e >> 5, c = (e & 31) * 4;
+        const int r = r0 + rr;
+        float4 fv = make_float4(0.f, 0.f, 0.f, 0.f), xv = fv;
+        if (r < R) {
+            fv = *reinterpret_cast<const float4*>(a.feat + (size_t)r * D + c);
+            xv = *reinterpret_cast<const float4*>(x + (size_t)r * D + c);
+        }
+        *reinterpret_cast<float4*>(&As[rr * HDP + c]) = fv;
+        *reinterpret_cast<float4*>(&As[rr * HDP + D + c]) = xv;
+    }
+    __syncthreads();
+    if (a.ln_g) {                          // transformer head: LayerNorm on the encoder features (:347-348); rnn: none
+        for (int rr = w; rr < TILE_M; rr += 4) {
+            float mu, rs;
+            ln_row_inplace(As + rr * HDP, a.ln_g, a.ln_b, mu, rs);
+            if (a.lnfeat && r0 + rr < R) {
+                a.lnfeat[(size_t)(r0 + rr) * D + lane] = As[rr * HDP + lane];
+                a.lnfeat[(size_t)(r0 + rr) * D + lane + 64] = As[rr * HDP + lane + 64];
+            }
+        }
+        __syncthreads();
+    }
+    f32x16 acc[1];
+    zero_acc(acc);
+    gemm32<1>(As, HDP, 2 * D, a.W0pack, D, 32 * w, 0, acc);
+    const int col = 32 * w + (lane & 31);
+    const float bv = a.b0[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r, lane);
+        const int gr = r0 + row;
+        const float hv = fmaxf(acc[0][r] + bv, 0.f);
+        Hd[row * LDP + col] = hv;
+        if (gr < R) a.hid[(size_t)gr * D + col] = hv;
+    }
+    __syncthreads();
+    for (int rr = w; rr < TILE_M; rr += 4) {
+        const float* row = Hd + rr * LDP;
+        const float d = wave_sum(row[lane] * a.w1[lane] + row[lane + 64] * a.w1[lane + 64]);
+        const int gr = r0 + rr;
+        if (lane == 0 && gr < R) a.logits[gr] = d + a.b1[0] + (1.f - vmask[gr]) * MASK_VALUE;
+    }
+}
+void launch_head_fwd(const HeadArgs& a0, const HeadArgs& a1, const float* x, const float* vmask, int R, hipStream_t s) {
+    const size_t shm = (size_t)(TILE_M * HDP + TILE_M * LDP) * sizeof(float);
+    hipLaunchKernelGGL(k_head_fwd, dim3((R + TILE_M - 1) / TILE_M, 2), dim3(256), shm, s, a0, a1, x, vmask, R);
+}
+
+}  // namespace vsl

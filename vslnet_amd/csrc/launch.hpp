@@ -1,0 +1,158 @@
+// Host-side launcher prototypes + small POD argument structs shared by kernels_fwd.hip, kernels_bwd.hip, api.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "common.hpp"
+
+namespace vsl {
+
+struct PackJob {          // one weight -> packed B-operand copy (see common.hpp pack_index)
+    int src;              // float offset into the flat parameter buffer
+    int dst;              // float offset into the pack buffer
+    int kn, cn;           // extent of the contraction index / of the output-column index covered by this job
+    int ld;               // leading dimension of the source matrix
+    int transpose;        // 0: Bm[k][c] = W[c][k] (forward pack)   1: Bm[k][c] = W[k][c] (data-gradient pack)
+    int ncols;            // total columns of the packed operand
+    int k_off, col_off;   // placement inside the packed operand
+};
+
+struct CharConvPtrs { const float* w[4]; const float* b[4]; };
+struct CharConvGrads { float* w[4]; float* b[4]; };
+
+struct HeadArgs {
+    const float* feat;    // (R,128) encoder / rnn features
+    const float* ln_g;    // nullptr for the rnn predictor
+    const float* ln_b;
+    const float* W0pack;  // forward pack of (128, 256)
+    const float* b0;
+    const float* w1;      // (128)
+    const float* b1;      // (1)
+    float* hid;           // (R,128) relu output, saved
+    float* lnfeat;        // (R,128) LN(feat), saved for the weight gradient
+    float* logits;        // (R)
+};
+
+struct HeadBwdArgs {
+    const float* dlogit;  // (R)
+    const float* hid;     // (R,128)
+    const float* feat;    // (R,128)
+    const float* ln_g;
+    const float* W0Tpack; // transpose pack, ncols = 256
+    const float* w1;
+    float* gz;            // (R,128) grad wrt the pre-relu activation (G operand of the weight gradient)
+    float* dfeat;         // (R,128)
+    float* dx;            // (R,128) grad wrt the gated features through this head
+    float* p_b0;          // partial slabs [ntiles][128]
+    float* p_w1;          // [ntiles][128]
+    float* p_b1;          // [ntiles]
+    float* p_lng;         // [ntiles][128]
+    float* p_lnb;         // [ntiles][128]
+};
+
+// generic weight-gradient job: dW[n][k] = sum_r G[r][n] * A[r][k]  over row chunks -> partial slabs
+struct WgradJob {
+    const float* G[3];    // N = 128 * nG ; each (R,128)
+    const float* A[4];    // column blocks of 128 (ldA == 128 each) when nA > 0
+    const float* Afull;   // or one (R, K) matrix with leading dimension K (nA == 0)
+    int nG, nA, K;
+    int R;
+    int drop_on_A;        // apply dropout to Afull on load (VisualProjection input)
+    Drop dp;
+    float* out;           // partial slabs [nchunk][N][K]
+    float* out_bias[3];   // partial slabs [nchunk][128] per G block (nullable)
+};
+constexpr int WG_ROWS = 256;
+constexpr int MAX_WJOBS = 8;
+struct WgradBatch { WgradJob j[MAX_WJOBS]; int n; };
+
+struct ReduceSeg {        // grads[dst + (i / rl) * ds + i % rl] = sum over sources q, slabs s of partial[src[q] + s * ss[q] + i],  i < n
+    int dst, n;
+    int rl, ds;           // destination row length / row stride (rl == n, ds == 0 for a contiguous destination)
+    int nsrc;
+    int src[4], nslabs[4], ss[4];
+};
+
+// ---------------------------------------------------------------- forward
+void launch_pack(const float* params, float* pack, const PackJob* jobs_dev, int njobs, hipStream_t s);
+void launch_vproj_fwd(const float* X, const float* Wpack, const float* bias, float* Y, int R, int Dv, Drop dp, hipStream_t s);
+void launch_embed_fwd(const int64_t* word_ids, const int64_t* char_ids, const float* pad_vec, const float* unk_vec,
+                      const float* glove, const float* char_tab, CharConvPtrs cc, float* E, int8_t* argpos, int Rq,
+                      int Lc, int word_dim, int char_dim, Drop dw, Drop dc, hipStream_t s);
+void launch_linear_fwd(const float* A, const float* Wpack, const float* bias, float* Y, int R, int K, hipStream_t s);
+void launch_conv_layer_fwd(const float* xin, const float* pos, float* x0_out, const float* ln_g, const float* ln_b,
+                           const float* dw_w, const float* Wpack, const float* pw_b, float* y_out, float* u_out,
+                           uint32_t* relu_mask, int R, int L, Drop dp, hipStream_t s);
+void launch_ln_qkv_fwd(const float* x, const float* ln_g, const float* ln_b, const float* Wpack, const float* bq,
+                       const float* bk, const float* bv, float* h1, float* q, float* k, float* v, int R, Drop d1,
+                       hipStream_t s);
+void launch_attn_fwd(const float* Q, const float* K, const float* V, const float* mask, float* att, float* lse, int B,
+                     int L, int H, int b_off, Drop d2, hipStream_t s);
+void launch_attn_out_fwd(const float* att, const float* x, const float* ln_g, const float* ln_b, const float* Wpack,
+                         const float* bo, float* r_out, float* h2_out, float* y_out, int R, Drop d3, Drop d4, Drop d5,
+                         hipStream_t s);
+void launch_cq_score(const float* C, const float* Qf, const float* qmask, const float* w4C, const float* w4Q,
+                     const float* w4mlu, float* S, float* Srow, int B, int T, int Lq, int b_off, Drop dc, Drop dq,
+                     hipStream_t s);
+void launch_cq_col(const float* C, const float* Qf, const float* S, const float* cmask, const float* qmask,
+                   const float* pool_w, const float* Wcat, const float* bcat, float* Scol, float* M, float* alpha,
+                   float* pooled, float* pb, int B, int T, int Lq, hipStream_t s);
+void launch_cq_out(const float* C, const float* Qf, const float* Srow, const float* M, const float* Wpack,
+                   const float* bias, float* cat_out, float* out, int B, int T, int Lq, hipStream_t s);
+void launch_cqcat_fwd(const float* f1, const float* Wpack, const float* pb, const float* wh, const float* bh,
+                      const float* vmask, float* f2, float* hscore, float* gated, int R, int T, hipStream_t s);
+void launch_head_fwd(const HeadArgs& a0, const HeadArgs& a1, const float* x, const float* vmask, int R, hipStream_t s);
+
+// ---------------------------------------------------------------- losses / eval
+void launch_loss(const float* sl, const float* el, const float* h, const int64_t* s_lab, const int64_t* e_lab,
+                 const int64_t* h_lab, const float* vmask, int B, int T, float inv_batch, float mask_sum_override,
+                 float w_loc, float w_hl, float* scratch, float* losses /*[4]: loc, hl, total, mask_sum*/, float* d_sl,
+                 float* d_el, float* d_h, hipStream_t s);
+void launch_extract_index(const float* sl, const float* el, int64_t* si, int64_t* ei, int B, int T, hipStream_t s);
+
+// ---------------------------------------------------------------- backward
+void launch_head_bwd(const HeadBwdArgs& a0, const HeadBwdArgs& a1, int R, hipStream_t s);
+void launch_wgrad(const WgradBatch& wb, hipStream_t s);
+void launch_conv_bwd_gemm(const float* dy, const uint32_t* relu_mask, const float* WTpack, float* gz, float* du, int R,
+                          Drop dp, hipStream_t s);
+void launch_conv_bwd_dwln(const float* du, const float* xin, const float* dy, const float* ln_g, const float* ln_b,
+                          const float* dw_w, const float* extra, float* dx, float* p_lng, float* p_lnb, float* p_dw, int R, int L,
+                          hipStream_t s);
+void launch_attn_out_bwd(const float* dy, const float* r, const float* ln_g, const float* WTpack, float* g_o, float* dr,
+                         float* p_lng, float* p_lnb, int R, Drop d4, Drop d5, hipStream_t s);
+void launch_attn_bwd(const float* Q, const float* K, const float* V, const float* att, const float* dr, const float* lse,
+                     const float* mask, float* dQ, float* dK, float* dV, float* Dq, int B, int L, int H, int b_off, Drop d2,
+                     Drop d3, hipStream_t s);
+void launch_qkv_bwd(const float* dQ, const float* dK, const float* dV, const float* x, const float* dr,
+                    const float* ln_g, const float* WTpack, float* dx, float* p_lng, float* p_lnb, int R, Drop d1,
+                    hipStream_t s);
+void launch_pos_grad(const float* dx0, float* out, int B, int L, int max_pos, hipStream_t s);
+void launch_cqcat_bwd(const float* dg0, const float* dg1, const float* dg2, const float* dh_loss, const float* f2,
+                      const float* hscore, const float* wh, const float* W1Tpack, float* df2, float* df1, float* p_wh,
+                      float* p_bh, int R, hipStream_t s);
+void launch_cq_out_bwd(const float* df1, const float* C, const float* Qf, const float* Srow, const float* M,
+                       const float* WTpack, float* dC, float* dc2q, float* dq2c, float* dSr, int B, int T, int Lq,
+                       hipStream_t s);
+struct CqColBwdArgs {
+    const float *C, *Qf, *Srow, *Scol, *cmask, *qmask, *alpha, *pooled;
+    const float *w4C, *w4Q, *w4mlu, *pool_w, *Wcat;
+    const float *dc2q, *dq2c, *dSr, *df2;
+    float *dC;            // (B,T,128): in = direct part from cq_out_bwd, out = total grad wrt the video encoder output
+    float *dQ;            // (B,Lq,128) total grad wrt the query encoder output
+    float *p_w4C, *p_w4Q, *p_w4mlu, *p_pool, *p_bcat;   // per-sample partial slabs [B][128]
+    float *p_W2;          // per-sample partial slabs [B][128][128] for Wcat[:, 128:]
+    float *scratch;       // (B, T*Lq) workspace for dS
+    int T, Lq, b_off;
+    Drop dc, dq;
+};
+void launch_cq_col_bwd(const CqColBwdArgs& a, int B, hipStream_t s);
+void launch_linear_bwd_data(const float* G, const float* WTpack, float* dA, int R, int K, hipStream_t s);
+void launch_embed_bwd(const float* dE, const int64_t* word_ids, const int64_t* char_ids, const float* E,
+                      const int8_t* argpos, const float* char_tab, CharConvPtrs cc, float* p_cw /*[nchunk][15000]*/,
+                      float* p_cb /*[nchunk][100]*/, float* p_tab /*[nchunk][char_size*char_dim]*/, float* g_unk, int Rq,
+                      int Lc, int word_dim, int char_dim, int char_size, Drop dw, Drop dc, hipStream_t s);
+void launch_reduce(const float* partial, float* grads, const ReduceSeg* segs_dev, const int* blk2seg_dev, int nblocks,
+                   hipStream_t s);
+constexpr int EMB_CHUNK = 32;     // query words per workgroup in the embedding backward
+constexpr int CHARW_TOTAL = 15000;
+
+}  // namespace vsl

@@ -1,0 +1,247 @@
+"""ctypes binding of libvslnet_hip.so (include/vslnet_hip.h) + a thin engine object.
+
+PyTorch-ROCm tensors are used for STORAGE ONLY: every pointer handed to the library is `tensor.data_ptr()` of a
+caller-owned CUDA(HIP) tensor, and all kernels are enqueued on torch's current stream.  There is no CPU fallback:
+if the shared library is missing or no MI355X is visible, construction raises.
+"""
+import ctypes as C
+import os
+from types import SimpleNamespace
+
+import torch
+
+from . import build as _build
+
+_LIB = None
+
+
+class vsl_config(C.Structure):
+    _fields_ = [('dim', C.c_int32), ('num_heads', C.c_int32), ('max_pos_len', C.c_int32),
+                ('video_feature_dim', C.c_int32), ('word_dim', C.c_int32), ('char_dim', C.c_int32),
+                ('word_size', C.c_int32), ('char_size', C.c_int32), ('predictor', C.c_int32), ('drop_rate', C.c_float)]
+
+
+class vsl_io(C.Structure):
+    _fields_ = [('B', C.c_int32), ('T', C.c_int32), ('Lq', C.c_int32), ('Lc', C.c_int32),
+                ('params', C.c_void_p), ('pad_vec', C.c_void_p), ('glove_vec', C.c_void_p),
+                ('word_ids', C.c_void_p), ('char_ids', C.c_void_p), ('video_features', C.c_void_p),
+                ('v_mask', C.c_void_p), ('q_mask', C.c_void_p),
+                ('h_score', C.c_void_p), ('start_logits', C.c_void_p), ('end_logits', C.c_void_p),
+                ('workspace', C.c_void_p), ('training', C.c_int32), ('seed', C.c_uint64),
+                ('d_h_score', C.c_void_p), ('d_start_logits', C.c_void_p), ('d_end_logits', C.c_void_p),
+                ('grads', C.c_void_p)]
+
+
+class vsl_loss_io(C.Structure):
+    _fields_ = [('start_labels', C.c_void_p), ('end_labels', C.c_void_p), ('h_labels', C.c_void_p),
+                ('w_loc', C.c_float), ('w_highlight', C.c_float), ('inv_batch', C.c_float), ('mask_sum', C.c_float),
+                ('losses', C.c_void_p), ('d_h_score', C.c_void_p), ('d_start_logits', C.c_void_p),
+                ('d_end_logits', C.c_void_p)]
+
+
+ABI_SYMBOLS = ['vsl_last_error', 'vsl_create', 'vsl_destroy', 'vsl_param_count', 'vsl_param_info', 'vsl_param_floats',
+               'vsl_workspace_floats', 'vsl_forward', 'vsl_loss', 'vsl_backward', 'vsl_extract_index',
+               'vsl_workspace_offset']
+
+
+def load_library():
+    """dlopen libvslnet_hip.so (building it in-tree with hipcc when stale/missing).  Raises if that fails."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = _build.LIB
+    if not os.path.exists(path) or _build._stale():
+        path = _build.build()
+    lib = C.CDLL(path)
+    lib.vsl_last_error.restype = C.c_char_p
+    lib.vsl_create.argtypes = [C.POINTER(vsl_config), C.POINTER(C.c_void_p)]
+    lib.vsl_destroy.argtypes = [C.c_void_p]
+    lib.vsl_param_count.argtypes = [C.c_void_p]
+    lib.vsl_param_floats.argtypes = [C.c_void_p]
+    lib.vsl_param_floats.restype = C.c_int64
+    lib.vsl_param_info.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                   C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
+    lib.vsl_workspace_floats.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]
+    lib.vsl_forward.argtypes = [C.c_void_p, C.POINTER(vsl_io), C.c_void_p]
+    lib.vsl_loss.argtypes = [C.c_void_p, C.POINTER(vsl_io), C.POINTER(vsl_loss_io), C.c_void_p]
+    lib.vsl_backward.argtypes = [C.c_void_p, C.POINTER(vsl_io), C.c_void_p]
+    lib.vsl_extract_index.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.vsl_workspace_offset.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p]
+    lib.vsl_workspace_offset.restype = C.c_int64
+    _LIB = lib
+    return lib
+
+
+class VslError(RuntimeError):
+    pass
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _chk(t, dtype, shape, name):
+    if t.dtype != dtype or tuple(t.shape) != tuple(shape) or not t.is_cuda or not t.is_contiguous():
+        raise ValueError('%s: expected contiguous cuda %s %s, got %s %s on %s' %
+                         (name, dtype, tuple(shape), t.dtype, tuple(t.shape), t.device))
+
+
+class Engine:
+    """One `vsl_handle` + caller-owned buffers.  Mirrors what VSLNet.__init__ / forward / backward need."""
+
+    def __init__(self, configs, device=None):
+        if not torch.cuda.is_available():
+            raise VslError('vslnet_amd needs an MI355X (gfx950) visible to PyTorch-ROCm; there is no CPU fallback')
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self.lib = load_library()
+        pred = {'rnn': 0, 'transformer': 1}.get(configs.predictor)
+        if pred is None:
+            raise ValueError('unknown predictor %r' % (configs.predictor,))
+        self.cfg = vsl_config(int(configs.dim), int(configs.num_heads), int(configs.max_pos_len),
+                              int(configs.video_feature_dim), int(configs.word_dim), int(configs.char_dim),
+                              int(configs.word_size), int(configs.char_size), pred, float(configs.drop_rate))
+        self.configs = configs
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            if self.lib.vsl_create(C.byref(self.cfg), C.byref(h)):
+                msg = self.lib.vsl_last_error().decode()
+                if 'not implemented' in msg:
+                    raise NotImplementedError(msg)
+                if 'not a multiple of attention heads' in msg:
+                    raise AssertionError(msg)               # same condition the reference asserts (layers_t7.py:146)
+                raise VslError(msg)
+        self.h = h
+        self.param_floats = int(self.lib.vsl_param_floats(h))
+        self.layout = []                                    # (name, offset, numel, shape)
+        name = C.create_string_buffer(256)
+        off, num, nd = C.c_int64(), C.c_int64(), C.c_int32()
+        dims = (C.c_int64 * 4)()
+        for i in range(self.lib.vsl_param_count(h)):
+            self._call(self.lib.vsl_param_info(h, i, name, 256, C.byref(off), C.byref(num), C.byref(nd), dims))
+            self.layout.append((name.value.decode(), off.value, num.value, tuple(dims[j] for j in range(nd.value))))
+        self._ws = {}
+        self._last = None
+
+    def __del__(self):
+        try:
+            if getattr(self, 'h', None):
+                self.lib.vsl_destroy(self.h)
+        except Exception:
+            pass
+
+    def _call(self, rc):
+        if rc:
+            msg = self.lib.vsl_last_error().decode()
+            if 'exceeds max_pos_len' in msg:
+                raise IndexError(msg)                       # the reference raises IndexError from nn.Embedding here
+            raise VslError(msg)
+
+    # ---- flat parameter bucket helpers -------------------------------------------------------------------
+    def new_flat(self):
+        return torch.zeros(self.param_floats, dtype=torch.float32, device=self.device)
+
+    def views(self, flat):
+        return {n: flat[o:o + k].view(shp) for n, o, k, shp in self.layout}
+
+    def workspace(self, B, T, Lq, Lc):
+        key = (B, T, Lq, Lc)
+        if key not in self._ws:
+            n = C.c_int64()
+            with torch.cuda.device(self.device):
+                self._call(self.lib.vsl_workspace_floats(self.h, B, T, Lq, Lc, C.byref(n)))
+            self._ws[key] = torch.empty(n.value, dtype=torch.float32, device=self.device)
+        return self._ws[key]
+
+    def ws_view(self, name, shape):
+        """Saved activation `name` of the LAST forward as a tensor view (parity tests)."""
+        io = self._last
+        off = self.lib.vsl_workspace_offset(self.h, io.B, io.T, io.Lq, io.Lc, name.encode())
+        if off < 0:
+            raise KeyError(name)
+        n = 1
+        for s in shape:
+            n *= s
+        return self._last_ws[off:off + n].view(shape)
+
+    # ---- the three calls ------------------------------------------------------------------------------------
+    def forward(self, flat, pad_vec, glove_vec, word_ids, char_ids, vfeats, v_mask, q_mask, training=False, seed=0):
+        B, T, Dv = vfeats.shape
+        Lq, Lc = char_ids.shape[1], char_ids.shape[2]
+        _chk(flat, torch.float32, (self.param_floats,), 'params')
+        _chk(word_ids, torch.int64, (B, Lq), 'word_ids')
+        _chk(char_ids, torch.int64, (B, Lq, Lc), 'char_ids')
+        _chk(vfeats, torch.float32, (B, T, self.cfg.video_feature_dim), 'video_features')
+        _chk(v_mask, torch.float32, (B, T), 'v_mask')
+        _chk(q_mask, torch.float32, (B, Lq), 'q_mask')
+        _chk(pad_vec, torch.float32, (1, self.cfg.word_dim), 'pad_vec')
+        _chk(glove_vec, torch.float32, (self.cfg.word_size - 2, self.cfg.word_dim), 'glove_vec')
+        ws = self.workspace(B, T, Lq, Lc)
+        out = torch.empty(3, B, T, dtype=torch.float32, device=self.device)
+        io = vsl_io()
+        io.B, io.T, io.Lq, io.Lc = B, T, Lq, Lc
+        io.params, io.pad_vec, io.glove_vec = _ptr(flat), _ptr(pad_vec), _ptr(glove_vec)
+        io.word_ids, io.char_ids, io.video_features = _ptr(word_ids), _ptr(char_ids), _ptr(vfeats)
+        io.v_mask, io.q_mask = _ptr(v_mask), _ptr(q_mask)
+        io.h_score, io.start_logits, io.end_logits = _ptr(out[0]), _ptr(out[1]), _ptr(out[2])
+        io.workspace = _ptr(ws)
+        io.training, io.seed = int(bool(training)), int(seed) & 0xFFFFFFFFFFFFFFFF
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        self._call(self.lib.vsl_forward(self.h, C.byref(io), stream))
+        self._last, self._last_ws = io, ws
+        # keep every tensor the io struct points to alive until the backward
+        self._keep = (flat, pad_vec, glove_vec, word_ids, char_ids, vfeats, v_mask, q_mask, out, ws)
+        return out[0], out[1], out[2]
+
+    def loss(self, start_labels, end_labels, h_labels, w_loc=1.0, w_highlight=5.0, inv_batch=None, mask_sum=0.0,
+             want_grads=True):
+        """Fused compute_loss + compute_highlight_loss on the LAST forward.  Returns (losses[4], d_h, d_sl, d_el)."""
+        io = self._last
+        B, T = io.B, io.T
+        _chk(start_labels, torch.int64, (B,), 'start_labels')
+        _chk(end_labels, torch.int64, (B,), 'end_labels')
+        _chk(h_labels, torch.int64, (B, T), 'h_labels')
+        losses = torch.empty(4, dtype=torch.float32, device=self.device)
+        d = torch.empty(3, B, T, dtype=torch.float32, device=self.device) if want_grads else None
+        l = vsl_loss_io()
+        l.start_labels, l.end_labels, l.h_labels = _ptr(start_labels), _ptr(end_labels), _ptr(h_labels)
+        l.w_loc, l.w_highlight = float(w_loc), float(w_highlight)
+        l.inv_batch = float(1.0 / B if inv_batch is None else inv_batch)
+        l.mask_sum = float(mask_sum)
+        l.losses = _ptr(losses)
+        if want_grads:
+            l.d_h_score, l.d_start_logits, l.d_end_logits = _ptr(d[0]), _ptr(d[1]), _ptr(d[2])
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        self._call(self.lib.vsl_loss(self.h, C.byref(io), C.byref(l), stream))
+        return (losses,) + ((d[0], d[1], d[2]) if want_grads else (None, None, None))
+
+    def backward(self, d_h, d_sl, d_el, grads):
+        """Backward of the LAST forward; writes the flat gradient bucket `grads` (same layout as the params)."""
+        io = self._last
+        B, T = io.B, io.T
+        if d_h is not None:
+            _chk(d_h, torch.float32, (B, T), 'd_h_score')
+        _chk(d_sl, torch.float32, (B, T), 'd_start_logits')
+        _chk(d_el, torch.float32, (B, T), 'd_end_logits')
+        _chk(grads, torch.float32, (self.param_floats,), 'grads')
+        io.d_h_score, io.d_start_logits, io.d_end_logits, io.grads = _ptr(d_h), _ptr(d_sl), _ptr(d_el), _ptr(grads)
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        self._call(self.lib.vsl_backward(self.h, C.byref(io), stream))
+        return grads
+
+    def extract_index(self, start_logits, end_logits):
+        B, T = start_logits.shape
+        _chk(start_logits, torch.float32, (B, T), 'start_logits')
+        _chk(end_logits, torch.float32, (B, T), 'end_logits')
+        idx = torch.empty(2, B, dtype=torch.int64, device=self.device)
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        self._call(self.lib.vsl_extract_index(self.h, _ptr(start_logits), _ptr(end_logits), B, T, _ptr(idx[0]),
+                                              _ptr(idx[1]), stream))
+        return idx[0], idx[1]
+
+
+def flat_from_state_dict(engine, sd):
+    """Pack a reference-style state_dict (name -> tensor) into the engine's flat parameter bucket."""
+    flat = engine.new_flat()
+    for n, o, k, shp in engine.layout:
+        flat[o:o + k] = sd[n].reshape(-1).to(device=engine.device, dtype=torch.float32)
+    return flat
