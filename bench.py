@@ -1,0 +1,216 @@
+"""Headline benchmark (BASELINE.json): (video, query) pairs/s, forward + both losses + backward, on
+Charades-STA-shaped synthetic batches (configs[1]: --predictor transformer, B=64 per GPU, T=128, Dv=1024, Lq=20, Lc=10,
+drop_rate 0.2, training mode, fp32 -- the precision in which the 1e-4 logit parity holds).
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W
+
+One process per GPU.  A step = vsl_forward + vsl_loss + vsl_backward (the region of main_t7.py:103-110) on a batch
+already resident in HBM, plus -- for N > 1 -- ONE RCCL all-reduce of the flat fp32 gradient bucket (weak scaling: the
+per-GPU batch is fixed, losses use the global normalisers).  Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_MFMA_F32 = 157.3e12       # MI355X_MICROARCH.md: fp32-in MFMA = fp32 vector peak
+PEAK_HBM = 8.0e12              # HBM3E spec
+
+
+def alg_flops_per_pair(T, Dv, Lq, Lc, d=128, NL=4, k=7):
+    """matmul/conv FLOPs (2*MAC) per (video, query) pair, forward and forward+backward."""
+    def enc(L):
+        return NL * (2 * L * d * k + 2 * L * d * d) + 8 * L * d * d + 4 * L * L * d
+    charcnn = sum(2 * Lq * (Lc - kk + 1) * 50 * kk * c for kk, c in zip((1, 2, 3, 4), (10, 20, 30, 40)))
+    fwd = (2 * T * Dv * d + charcnn + 2 * Lq * 400 * d + enc(T) + enc(Lq)
+           + (2 * T * d + 2 * Lq * d + 4 * T * Lq * d + 2 * T * T * Lq + 2 * T * T * d + 8 * T * d * d)
+           + (4 * Lq * d + 4 * T * d * d) + 2 * T * d + 2 * (4 * T * d * d + 2 * T * d) + 2 * enc(T))
+    return fwd, 3 * fwd - 2 * T * Dv * d          # bwd = 2*fwd - (no dX for the input features)
+
+
+def kernel_work(name, B, T, Dv, Lq, d=128, H=8):
+    """Algorithmic (flops, HBM bytes) of ONE step's launches of a kernel group, for the roofline line (DESIGN.md 'kernels')."""
+    R, Rq = B * T, B * Lq
+    enc_rows = 3 * R + Rq                       # rows seen by the four encoder applications
+    att = lambda L: B * H * L * L * 16          # noqa: E731  one (L x L x 16) product per head
+    tbl = {
+        'vproj_fwd': (2 * R * Dv * d, 4 * (R * Dv + R * d)),
+        'conv_layer_fwd': (4 * enc_rows * (2 * d * d + 2 * d * 7), 4 * 4 * enc_rows * 3 * d),
+        'ln_qkv_fwd': (enc_rows * 2 * d * 3 * d, 4 * enc_rows * 5 * d),
+        'attn_fwd': (4 * (3 * att(T) + att(Lq)), 4 * enc_rows * 4 * d),
+        'attn_out_fwd': (enc_rows * 2 * d * d, 4 * enc_rows * 5 * d),
+        'attn_bwd': (14 * (3 * att(T) + att(Lq)), 4 * enc_rows * 8 * d),
+        'attn_out_bwd': (enc_rows * 2 * d * d, 4 * enc_rows * 3 * d),
+        'qkv_bwd': (enc_rows * 2 * d * 3 * d, 4 * enc_rows * 6 * d),
+        'conv_bwd_gemm': (4 * enc_rows * 2 * d * d, 4 * 4 * enc_rows * 3 * d),
+        'conv_bwd_dwln': (4 * enc_rows * 4 * d * 7, 4 * 4 * enc_rows * 4 * d),
+        # every weight gradient of the step: 8 (128x128) per encoder application, heads, cqa, cat, embedding, visual
+        'wgrad': (2 * d * (enc_rows * 8 * d + 2 * R * 2 * d + R * 4 * d + R * d + Rq * 400 + R * Dv),
+                  4 * (enc_rows * 16 * d + R * (4 * d + 4 * d + 2 * d) + Rq * 528 + R * (Dv + d))),
+        'cq_out': (2 * R * 4 * d * d + 4 * R * Lq * d, 4 * R * 6 * d),
+        'cq_out_bwd': (2 * R * 4 * d * d + 8 * R * Lq * d, 4 * R * 6 * d),
+        'cq_col_bwd': (16 * R * Lq * d, 4 * R * 6 * d),
+        'head_fwd': (2 * 2 * R * 2 * d * d, 4 * 2 * R * 4 * d),
+        'head_bwd': (2 * 2 * R * 2 * d * d, 4 * 2 * R * 5 * d),
+        'cqcat_fwd': (2 * R * d * d, 4 * R * 3 * d),
+        'cqcat_bwd': (2 * R * d * d, 4 * R * 6 * d),
+    }
+    return tbl.get(name)
+
+
+def cpu_baseline(configs, T, Lq, Lc, sample_B=16, iters=3):
+    """The pinned CPU oracle (restatement of the reference's PyTorch CPU path) timed on this box's host cores on a
+    bounded sample of the same workload.  kind = 'port'."""
+    from oracle import vslnet_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    cfg = O.make_cfg(video_feature_dim=configs.video_feature_dim, max_pos_len=configs.max_pos_len,
+                     word_size=configs.word_size, drop_rate=configs.drop_rate)
+    P = {k: v.clone().requires_grad_(k not in O.FROZEN) for k, v in O.random_params(cfg, seed=1).items()}
+    b = O.synthetic_batch(cfg, sample_B, T, Lq, Lc, seed=0)
+
+    def step():
+        for p in P.values():
+            p.grad = None
+        total, _ = O.total_loss(P, cfg, b, training=True)
+        total.backward()
+    step()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        step()
+    dt = (time.perf_counter() - t0) / iters
+    return {'value': round(sample_B / dt, 2), 'unit': 'pairs/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': 'B=%d of the T=%d Dv=%d Lq=%d workload, drop_rate %.1f, 1 warm-up + %d timed fwd+loss+bwd steps '
+                      'of oracle/vslnet_oracle.py (torch CPU fp32), %.0f ms/step' % (sample_B, T, configs.video_feature_dim,
+                                                                                   Lq, configs.drop_rate, iters, dt * 1e3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--batch', type=int, default=64, help='per-GPU batch (weak scaling)')
+    ap.add_argument('--T', type=int, default=128)
+    ap.add_argument('--dv', type=int, default=1024)
+    ap.add_argument('--lq', type=int, default=20)
+    ap.add_argument('--lc', type=int, default=10)
+    ap.add_argument('--drop-rate', type=float, default=0.2)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--profile-all', action='store_true', help='also print the per-kernel HIP-event table to stderr')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d' % (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))     # RCCL over xGMI
+
+    from vslnet_amd.model.VSLNet import VSLNet
+    from vslnet_amd.synthetic import make_configs, synthetic_batch
+    B, T, Dv, Lq, Lc = args.batch, args.T, args.dv, args.lq, args.lc
+    configs = make_configs(video_feature_dim=Dv, max_pos_len=max(T, Lq), drop_rate=args.drop_rate)
+    torch.manual_seed(configs.seed)                         # identical random-init weights on every rank
+    glove = torch.randn(configs.word_size - 2, configs.word_dim).numpy()
+    model = VSLNet(configs, glove).cuda().train()
+    flat, grads = model.flat_parameters
+    eng = model._engine
+    pad_vec, glove_vec = model.embedding_net.word_emb.pad_vec.data, model.embedding_net.word_emb.glove_vec.data
+    batch = synthetic_batch(configs, B, T, Lq, Lc, seed=100 + rank)
+    inv_batch = 1.0 / (B * world)
+    mask_sum = float(batch['v_mask'].sum().item()) * world   # full-length synthetic clips: same on every rank
+
+    def step(i):
+        eng.forward(flat, pad_vec, glove_vec, batch['word_ids'], batch['char_ids'], batch['vfeats'], batch['v_mask'],
+                    batch['q_mask'], training=True, seed=(rank << 32) + i)
+        losses, d_h, d_sl, d_el = eng.loss(batch['s_labels'], batch['e_labels'], batch['h_labels'], 1.0,
+                                           configs.highlight_lambda, inv_batch=inv_batch, mask_sum=mask_sum)
+        eng.backward(d_h, d_sl, d_el, grads)
+        if dist is not None:
+            dist.all_reduce(grads)                           # one flat fp32 bucket, summed (losses carry 1/B_global)
+        return losses
+
+    for i in range(args.warmup):
+        step(i)
+    # find the dominant kernel group (untimed pass with every launch bracketed by HIP events)
+    eng.profile_select('*')
+    step(args.warmup)
+    torch.cuda.synchronize()
+    table = eng.profile_read()
+    dominant = max(table, key=lambda k: table[k][0])
+    if args.profile_all and rank == 0:
+        tot = sum(v[0] for v in table.values())
+        for k, (ms, n) in sorted(table.items(), key=lambda kv: -kv[1][0]):
+            print('%-18s %8.1f us  %3d launches  %5.1f%%' % (k, ms * 1e3, n, 100 * ms / tot), file=sys.stderr)
+    eng.profile_select(dominant)                             # timed region: events around the dominant kernel only
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        losses = step(args.warmup + 1 + i)
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], device='cuda', dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    kt = eng.profile_read()[dominant]
+    eng.profile_select(None)
+    loss_val = float(losses[2].item())
+    if not (loss_val == loss_val) or abs(loss_val) > 1e6:
+        raise SystemExit('non-finite loss in the timed region: %r' % loss_val)
+
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        value = B * world * args.steps / dt
+        fwd, fb = alg_flops_per_pair(T, Dv, Lq, Lc)
+        work = kernel_work(dominant, B, T, Dv, Lq)
+        k_s = kt[0] * 1e-3 / args.steps                      # seconds of this kernel group per step
+        roof = {'kernel': dominant, 'launches_per_step': kt[1] // args.steps, 'ms_per_step': round(k_s * 1e3, 4)}
+        if work:
+            t_m, t_h = work[0] / PEAK_MFMA_F32, work[1] / PEAK_HBM
+            if t_m >= t_h:
+                roof.update(bound='mfma', achieved=round(work[0] / k_s / 1e12, 3), peak=PEAK_MFMA_F32 / 1e12, unit='TFLOP/s')
+            else:
+                roof.update(bound='hbm', achieved=round(work[1] / k_s / 1e9, 1), peak=PEAK_HBM / 1e9, unit='GB/s')
+            roof['frac'] = round(roof['achieved'] / roof['peak'], 4)
+        roof['traffic'] = None                               # PMC pass: profiles/ 
+        roof['step_mfma_frac'] = round(fb * value / world / PEAK_MFMA_F32, 4)   # whole step vs the fp32 MFMA roof, per GPU
+        out = {'metric': '(video,query) pairs/sec fwd+bwd, Charades I3D T=128 D=1024', 'value': round(value, 1),
+               'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+               'ms_per_step': round(ms_step, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+               'dtype': 'f32', 'data': 'synthetic',
+               'config': {'workload': 'configs[1]: Charades-STA I3D shape, --predictor transformer, B=%d/GPU T=%d Dv=%d Lq=%d '
+                                      'Lc=%d drop_rate=%.1f train mode; step = forward + CE(start)+CE(end)+5*highlight + '
+                                      'backward%s' % (B, T, Dv, Lq, Lc, args.drop_rate,
+                                                      ' + RCCL all-reduce of the flat grad bucket' if world > 1 else ''),
+                          'global_batch': B * world, 'parallelism': 'dp%d' % world,
+                          'alg_mflop_per_pair': round(fb / 1e6, 1), 'loss': round(loss_val, 5)},
+               'roofline': roof}
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(configs, T, Lq, Lc)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

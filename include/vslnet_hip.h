@@ -113,6 +113,12 @@ int vsl_extract_index(vsl_handle h, const float* start_logits, const float* end_
  * names: "video_affine", "embedding_net", "venc", "qenc", "cq_attention", "cq_concat", "gated", "pred_s", "pred_e" */
 int64_t vsl_workspace_offset(vsl_handle h, int B, int T, int Lq, int Lc, const char* name);
 
+/* per-kernel timing with HIP events recorded on the launch stream (no reference counterpart; feeds bench.py's roofline
+ * object).  select: kernel launcher name ("wgrad", "vproj_fwd", ... or "*" for all, NULL/"" = off) and resets the
+ * records; read: index-th aggregated record, returns 2 past the end. */
+int vsl_profile_select(vsl_handle h, const char* kernel);
+int vsl_profile_read(vsl_handle h, int index, char* name, int name_cap, double* total_ms, int32_t* count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,1 @@
+from vslnet_amd.model.VSLNet import VSLNet, build_optimizer_and_scheduler  # noqa: F401

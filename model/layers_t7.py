@@ -1,0 +1,1 @@
+from vslnet_amd.model.layers import *  # noqa: F401,F403

@@ -142,7 +142,10 @@ def test_losses_and_every_gradient(name):
               'd_cq_attention': (B, T, 128)}
     for nm in ['d_pred_s', 'd_gated', 'd_cq_concat', 'd_cq_attention', 'd_venc', 'd_qenc', 'd_video_affine', 'd_embedding_net']:
         g = keep[nm].grad
-        got = eng.ws_view(nm, shapes[nm])
+        if nm == 'd_gated':      # three consumers: predictor encoder input + both span heads (VSLNet_t7.py:61, layers_t7.py:349-350)
+            got = sum(eng.ws_view(k, shapes[nm]) for k in ('d_gated_enc', 'd_gated_hs', 'd_gated_he'))
+        else:
+            got = eng.ws_view(nm, shapes[nm])
         err = float((got.cpu() - g).abs().max())
         tol = sc(g)
         rep.rows.append('%-28s err %.3e tol %.1e %s' % (nm, err, tol, '' if err <= tol else '<-- FAIL'))

@@ -78,6 +78,13 @@ struct vsl_handle_s {
     std::vector<PackJob> jobs;
     PackJob* jobs_dev = nullptr;
     std::map<std::tuple<int, int, int, int>, Plan*> plans;
+    // optional per-kernel timing with HIP events on the launch stream (vsl_profile_*), used by bench.py's roofline line
+    bool prof_on = false;
+    std::string prof_sel;
+    std::vector<hipEvent_t> prof_pool;
+    size_t prof_used = 0;
+    struct ProfRec { const char* name; size_t e0, e1; };
+    std::vector<ProfRec> prof_recs;
 };
 
 namespace {
@@ -267,6 +274,19 @@ struct Ctx {
         return dry ? nullptr : ws + p->partial + o;
     }
     float* part_ptr(int64_t o) const { return dry ? nullptr : ws + p->partial + o; }
+    size_t prof_e0 = 0;
+    bool prof_live = false;
+    hipEvent_t prof_event() {
+        if (h->prof_used == h->prof_pool.size()) { hipEvent_t e; (void)hipEventCreate(&e); h->prof_pool.push_back(e); }
+        return h->prof_pool[h->prof_used++];
+    }
+    void pb(const char* name) {
+        prof_live = h->prof_on && (h->prof_sel == "*" || h->prof_sel == name);
+        if (prof_live) { prof_e0 = h->prof_used; (void)hipEventRecord(prof_event(), s); }
+    }
+    void pe(const char* name) {
+        if (prof_live) { const size_t e1 = h->prof_used; (void)hipEventRecord(prof_event(), s); h->prof_recs.push_back({name, prof_e0, e1}); }
+    }
     Drop drop(int site) const {
         Drop d{0u, 0u, 1.0f};
         const float pr = h->cfg.drop_rate;
@@ -280,7 +300,7 @@ struct Ctx {
         return d;
     }
 };
-#define LAUNCH(stmt) do { if (!c.dry) { stmt; } } while (0)
+#define LAUNCH(name, stmt) do { if (!c.dry) { c.pb(name); stmt; c.pe(name); } } while (0)
 
 // dropout site ids: encoder application `app` (0 video, 1 query, 2 predictor pass 1, 3 predictor pass 2) uses
 // app * 16 + {0..3 conv layers, 4 LN1 out, 5 attention probs, 6 attention out, 7 LN2 out, 8 out_layer}
@@ -290,14 +310,14 @@ enum { SITE_VIS = 64, SITE_WORD = 65, SITE_CHAR = 66, SITE_CQ_C = 67, SITE_CQ_Q 
 void enc_fwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float* xin, const float* mask, int Bn, int app) {
     const int R = w.R, L = w.L, H = c.h->cfg.num_heads;
     for (int i = 0; i < 4; ++i)
-        launch_conv_layer_fwd(i == 0 ? xin : c.W(w.y[i - 1]), i == 0 ? c.P(P.pos) : nullptr, i == 0 ? c.W(w.x0) : nullptr,
+        LAUNCH("conv_layer_fwd", launch_conv_layer_fwd(i == 0 ? xin : c.W(w.y[i - 1]), i == 0 ? c.P(P.pos) : nullptr, i == 0 ? c.W(w.x0) : nullptr,
                               c.P(P.lng[i]), c.P(P.lnb[i]), c.P(P.dw[i]), c.PK(K.pw_f[i]), c.P(P.pwb[i]), c.W(w.y[i]),
-                              c.W(w.u[i]), reinterpret_cast<uint32_t*>(c.W(w.mask[i])), R, L, c.drop(app * 16 + i), c.s);
-    launch_ln_qkv_fwd(c.W(w.y[3]), c.P(P.ln1g), c.P(P.ln1b), c.PK(K.qkv_f), c.P(P.qb), c.P(P.kb), c.P(P.vb), c.W(w.h1),
-                      c.W(w.q), c.W(w.k), c.W(w.v), R, c.drop(app * 16 + 4), c.s);
-    launch_attn_fwd(c.W(w.q), c.W(w.k), c.W(w.v), mask, c.W(w.att), c.W(w.lse), Bn, L, H, 0, c.drop(app * 16 + 5), c.s);
-    launch_attn_out_fwd(c.W(w.att), c.W(w.y[3]), c.P(P.ln2g), c.P(P.ln2b), c.PK(K.o_f), c.P(P.ob), c.W(w.r), c.W(w.h2),
-                        c.W(w.out), R, c.drop(app * 16 + 6), c.drop(app * 16 + 7), c.drop(app * 16 + 8), c.s);
+                              c.W(w.u[i]), reinterpret_cast<uint32_t*>(c.W(w.mask[i])), R, L, c.drop(app * 16 + i), c.s));
+    LAUNCH("ln_qkv_fwd", launch_ln_qkv_fwd(c.W(w.y[3]), c.P(P.ln1g), c.P(P.ln1b), c.PK(K.qkv_f), c.P(P.qb), c.P(P.kb), c.P(P.vb), c.W(w.h1),
+                      c.W(w.q), c.W(w.k), c.W(w.v), R, c.drop(app * 16 + 4), c.s));
+    LAUNCH("attn_fwd", launch_attn_fwd(c.W(w.q), c.W(w.k), c.W(w.v), mask, c.W(w.att), c.W(w.lse), Bn, L, H, 0, c.drop(app * 16 + 5), c.s));
+    LAUNCH("attn_out_fwd", launch_attn_out_fwd(c.W(w.att), c.W(w.y[3]), c.P(P.ln2g), c.P(P.ln2b), c.PK(K.o_f), c.P(P.ob), c.W(w.r), c.W(w.h2),
+                        c.W(w.out), R, c.drop(app * 16 + 6), c.drop(app * 16 + 7), c.drop(app * 16 + 8), c.s));
 }
 
 CharConvPtrs char_ptrs(const Ctx& c) {
@@ -313,29 +333,29 @@ void run_forward(Ctx& c) {
     const Plan& p = *c.p;
     const vsl_io& io = *c.io;
     const int B = p.B, T = p.T, Lq = p.Lq, R = B * T, Rq = B * Lq;
-    launch_pack(io.params, c.W(p.pack), c.h->jobs_dev, (int)c.h->jobs.size(), c.s);
-    launch_vproj_fwd(io.video_features, c.PK(K.va_f), c.P(P.va_b), c.W(p.vf), R, cf.video_feature_dim, c.drop(SITE_VIS), c.s);
-    launch_embed_fwd(io.word_ids, io.char_ids, io.pad_vec, c.P(P.unk), io.glove_vec, c.P(P.char_tab), char_ptrs(c), c.W(p.E),
+    LAUNCH("pack", launch_pack(io.params, c.W(p.pack), c.h->jobs_dev, (int)c.h->jobs.size(), c.s));
+    LAUNCH("vproj_fwd", launch_vproj_fwd(io.video_features, c.PK(K.va_f), c.P(P.va_b), c.W(p.vf), R, cf.video_feature_dim, c.drop(SITE_VIS), c.s));
+    LAUNCH("embed_fwd", launch_embed_fwd(io.word_ids, io.char_ids, io.pad_vec, c.P(P.unk), io.glove_vec, c.P(P.char_tab), char_ptrs(c), c.W(p.E),
                      reinterpret_cast<int8_t*>(c.W(p.argpos)), Rq, p.Lc, cf.word_dim, cf.char_dim, c.drop(SITE_WORD),
-                     c.drop(SITE_CHAR), c.s);
-    launch_linear_fwd(c.W(p.E), c.PK(K.emb_f), c.P(P.emb_b), c.W(p.qf), Rq, cf.word_dim + 100, c.s);
+                     c.drop(SITE_CHAR), c.s));
+    LAUNCH("linear_fwd", launch_linear_fwd(c.W(p.E), c.PK(K.emb_f), c.P(P.emb_b), c.W(p.qf), Rq, cf.word_dim + 100, c.s));
     enc_fwd(c, P.fe, K.fe, p.ve, c.W(p.vf), io.v_mask, B, 0);
     enc_fwd(c, P.fe, K.fe, p.qe, c.W(p.qf), io.q_mask, B, 1);
-    launch_cq_score(c.W(p.ve.out), c.W(p.qe.out), io.q_mask, c.P(P.w4C), c.P(P.w4Q), c.P(P.w4mlu), c.W(p.S), c.W(p.Srow), B, T,
-                    Lq, 0, c.drop(SITE_CQ_C), c.drop(SITE_CQ_Q), c.s);
-    launch_cq_col(c.W(p.ve.out), c.W(p.qe.out), c.W(p.S), io.v_mask, io.q_mask, c.P(P.pool_w), c.P(P.cat_w), c.P(P.cat_b),
-                  c.W(p.Scol), c.W(p.M), c.W(p.alpha), c.W(p.pooled), c.W(p.pb), B, T, Lq, c.s);
-    launch_cq_out(c.W(p.ve.out), c.W(p.qe.out), c.W(p.Srow), c.W(p.M), c.PK(K.cqa_f), c.P(P.cqa_b), c.W(p.cat), c.W(p.f1), B, T,
-                  Lq, c.s);
-    launch_cqcat_fwd(c.W(p.f1), c.PK(K.cat1_f), c.W(p.pb), c.P(P.hl_w), c.P(P.hl_b), io.v_mask, c.W(p.f2), io.h_score,
-                     c.W(p.gated), R, T, c.s);
+    LAUNCH("cq_score", launch_cq_score(c.W(p.ve.out), c.W(p.qe.out), io.q_mask, c.P(P.w4C), c.P(P.w4Q), c.P(P.w4mlu), c.W(p.S), c.W(p.Srow), B, T,
+                    Lq, 0, c.drop(SITE_CQ_C), c.drop(SITE_CQ_Q), c.s));
+    LAUNCH("cq_col", launch_cq_col(c.W(p.ve.out), c.W(p.qe.out), c.W(p.S), io.v_mask, io.q_mask, c.P(P.pool_w), c.P(P.cat_w), c.P(P.cat_b),
+                  c.W(p.Scol), c.W(p.M), c.W(p.alpha), c.W(p.pooled), c.W(p.pb), B, T, Lq, c.s));
+    LAUNCH("cq_out", launch_cq_out(c.W(p.ve.out), c.W(p.qe.out), c.W(p.Srow), c.W(p.M), c.PK(K.cqa_f), c.P(P.cqa_b), c.W(p.cat), c.W(p.f1), B, T,
+                  Lq, c.s));
+    LAUNCH("cqcat_fwd", launch_cqcat_fwd(c.W(p.f1), c.PK(K.cat1_f), c.W(p.pb), c.P(P.hl_w), c.P(P.hl_b), io.v_mask, c.W(p.f2), io.h_score,
+                     c.W(p.gated), R, T, c.s));
     enc_fwd(c, P.pe, K.pe, p.p1, c.W(p.gated), io.v_mask, B, 2);
     enc_fwd(c, P.pe, K.pe, p.p2, c.W(p.p1.out), io.v_mask, B, 3);
     HeadArgs hs{c.W(p.p1.out), c.P(P.sln_g), c.P(P.sln_b), c.PK(K.s0_f), c.P(P.s0b), c.P(P.s1w), c.P(P.s1b), c.W(p.hid_s),
                 c.W(p.lnf_s), io.start_logits};
     HeadArgs he{c.W(p.p2.out), c.P(P.eln_g), c.P(P.eln_b), c.PK(K.e0_f), c.P(P.e0b), c.P(P.e1w), c.P(P.e1b), c.W(p.hid_e),
                 c.W(p.lnf_e), io.end_logits};
-    launch_head_fwd(hs, he, c.W(p.gated), io.v_mask, R, c.s);
+    LAUNCH("head_fwd", launch_head_fwd(hs, he, c.W(p.gated), io.v_mask, R, c.s));
 }
 
 // ------------------------------------------------------------------------------------------------ backward
@@ -351,24 +371,24 @@ void enc_bwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float*
     float* p_ln2g = c.slab(P.ln2g, D, ntiles);
     float* p_ln2b = c.slab(P.ln2b, D, ntiles);
     float* g_o = dropping ? c.W(p.t_go) : nullptr;
-    LAUNCH(launch_attn_out_bwd(dy, c.W(w.r), c.P(P.ln2g), c.PK(K.o_t), g_o, c.W(p.t_dr), p_ln2g, p_ln2b, R,
+    LAUNCH("attn_out_bwd", launch_attn_out_bwd(dy, c.W(w.r), c.P(P.ln2g), c.PK(K.o_t), g_o, c.W(p.t_dr), p_ln2g, p_ln2b, R,
                                c.drop(app * 16 + 7), c.drop(app * 16 + 8), c.s));
-    LAUNCH(launch_attn_bwd(c.W(w.q), c.W(w.k), c.W(w.v), c.W(w.att), c.W(p.t_dr), c.W(w.lse), mask, c.W(p.t_dq), c.W(p.t_dk),
+    LAUNCH("attn_bwd", launch_attn_bwd(c.W(w.q), c.W(w.k), c.W(w.v), c.W(w.att), c.W(p.t_dr), c.W(w.lse), mask, c.W(p.t_dq), c.W(p.t_dk),
                            c.W(p.t_dv), c.W(p.t_Dq), Bn, L, H, 0, c.drop(app * 16 + 5), c.drop(app * 16 + 6), c.s));
     float* p_ln1g = c.slab(P.ln1g, D, ntiles);
     float* p_ln1b = c.slab(P.ln1b, D, ntiles);
-    LAUNCH(launch_qkv_bwd(c.W(p.t_dq), c.W(p.t_dk), c.W(p.t_dv), c.W(w.y[3]), c.W(p.t_dr), c.P(P.ln1g), c.PK(K.qkv_t),
+    LAUNCH("qkv_bwd", launch_qkv_bwd(c.W(p.t_dq), c.W(p.t_dk), c.W(p.t_dv), c.W(w.y[3]), c.W(p.t_dr), c.P(P.ln1g), c.PK(K.qkv_t),
                           c.W(p.t_ga), p_ln1g, p_ln1b, R, c.drop(app * 16 + 4), c.s));
     float* g = c.dry ? nullptr : c.W(p.t_ga);
     float* other = c.dry ? nullptr : c.W(p.t_gb);
     for (int i = 3; i >= 0; --i) {
-        LAUNCH(launch_conv_bwd_gemm(g, reinterpret_cast<const uint32_t*>(c.W(w.mask[i])), c.PK(K.pw_t[i]), c.W(p.t_gz[i]),
+        LAUNCH("conv_bwd_gemm", launch_conv_bwd_gemm(g, reinterpret_cast<const uint32_t*>(c.W(w.mask[i])), c.PK(K.pw_t[i]), c.W(p.t_gz[i]),
                                     c.W(p.t_du), R, c.drop(app * 16 + i), c.s));
         float* p_g = c.slab(P.lng[i], D, ntiles);
         float* p_b = c.slab(P.lnb[i], D, ntiles);
         float* p_dw = c.slab(P.dw[i], D * DWK, ntiles);
         float* out = i > 0 ? other : dx0_out;
-        LAUNCH(launch_conv_bwd_dwln(c.W(p.t_du), i > 0 ? c.W(w.y[i - 1]) : c.W(w.x0), g, c.P(P.lng[i]), c.P(P.lnb[i]),
+        LAUNCH("conv_bwd_dwln", launch_conv_bwd_dwln(c.W(p.t_du), i > 0 ? c.W(w.y[i - 1]) : c.W(w.x0), g, c.P(P.lng[i]), c.P(P.lnb[i]),
                                     c.P(P.dw[i]), i == 0 ? extra : nullptr, out, p_g, p_b, p_dw, R, L, c.s));
         other = g;
         g = out;
@@ -405,9 +425,9 @@ void enc_bwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float*
         j.out_bias[0] = c.slab(P.pwb[i], D, nchunk);
         wb.j[wb.n++] = j;
     }
-    LAUNCH(launch_wgrad(wb, c.s));
+    LAUNCH("wgrad", launch_wgrad(wb, c.s));
     float* p_pos = c.slab(P.pos, c.h->cfg.max_pos_len * D, 1);
-    LAUNCH(launch_pos_grad(dx0_out, p_pos, Bn, L, c.h->cfg.max_pos_len, c.s));
+    LAUNCH("pos_grad", launch_pos_grad(dx0_out, extra, p_pos, Bn, L, c.h->cfg.max_pos_len, c.s));
 }
 
 void run_backward(Ctx& c) {
@@ -432,7 +452,7 @@ void run_backward(Ctx& c) {
     hs.p_lng = c.slab(P.sln_g, D, ntiles); hs.p_lnb = c.slab(P.sln_b, D, ntiles);
     he.p_b0 = c.slab(P.e0b, D, ntiles); he.p_w1 = c.slab(P.e1w, D, ntiles); he.p_b1 = c.slab(P.e1b, 1, ntiles);
     he.p_lng = c.slab(P.eln_g, D, ntiles); he.p_lnb = c.slab(P.eln_b, D, ntiles);
-    LAUNCH(launch_head_bwd(hs, he, R, c.s));
+    LAUNCH("head_bwd", launch_head_bwd(hs, he, R, c.s));
     {
         WgradBatch wb;
         memset(&wb, 0, sizeof wb);
@@ -443,7 +463,7 @@ void run_backward(Ctx& c) {
             j.out = c.slab(e ? P.e0w : P.s0w, D * 2 * D, nchunk);
             wb.j[wb.n++] = j;
         }
-        LAUNCH(launch_wgrad(wb, c.s));
+        LAUNCH("wgrad", launch_wgrad(wb, c.s));
     }
     // ---- predictor encoder, second pass (input = output of the first pass), then first pass
     enc_bwd(c, P.pe, K.pe, p.p2, c.dry ? nullptr : c.W(p.dfeat_e), c.dry ? nullptr : c.W(p.dfeat_s),
@@ -453,7 +473,7 @@ void run_backward(Ctx& c) {
     // ---- gating + highlight + CQConcatenate
     float* p_hlw = c.slab(P.hl_w, D, ntiles);
     float* p_hlb = c.slab(P.hl_b, 1, ntiles);
-    LAUNCH(launch_cqcat_bwd(c.W(p.g_gated), c.W(p.dxh_s), c.W(p.dxh_e), io->d_h_score, c.W(p.f2), io->h_score, c.P(P.hl_w),
+    LAUNCH("cqcat_bwd", launch_cqcat_bwd(c.W(p.g_gated), c.W(p.dxh_s), c.W(p.dxh_e), io->d_h_score, c.W(p.f2), io->h_score, c.P(P.hl_w),
                             c.PK(K.cat1_t), c.W(p.df2), c.W(p.df1), p_hlw, p_hlb, R, c.s));
     {
         WgradBatch wb;
@@ -475,10 +495,10 @@ void run_backward(Ctx& c) {
             j.out_bias[0] = c.slab(P.cqa_b, D, nchunk);
             wb.j[wb.n++] = j;
         }
-        LAUNCH(launch_wgrad(wb, c.s));
+        LAUNCH("wgrad", launch_wgrad(wb, c.s));
     }
     // ---- CQAttention
-    LAUNCH(launch_cq_out_bwd(c.W(p.df1), c.W(p.ve.out), c.W(p.qe.out), c.W(p.Srow), c.W(p.M), c.PK(K.cqa_t), c.W(p.dC),
+    LAUNCH("cq_out_bwd", launch_cq_out_bwd(c.W(p.df1), c.W(p.ve.out), c.W(p.qe.out), c.W(p.Srow), c.W(p.M), c.PK(K.cqa_t), c.W(p.dC),
                              c.W(p.dc2q), c.W(p.dq2c), c.W(p.dSr), B, T, Lq, c.s));
     {
         CqColBwdArgs a;
@@ -495,7 +515,7 @@ void run_backward(Ctx& c) {
         const int64_t o = c.part_alloc((int64_t)B * D * D);
         c.reg(P.cat_w + D, D * D, o, B, D * D, D, 2 * D);          // second half of the (128, 256) weight
         a.p_W2 = c.part_ptr(o);
-        LAUNCH(launch_cq_col_bwd(a, B, c.s));
+        LAUNCH("cq_col_bwd", launch_cq_col_bwd(a, B, c.s));
     }
     // ---- shared feature encoder: video pass, then VisualProjection weight gradient
     enc_bwd(c, P.fe, K.fe, p.ve, c.dry ? nullptr : c.W(p.dC), nullptr, c.dry ? nullptr : c.W(p.dvf),
@@ -509,13 +529,13 @@ void run_backward(Ctx& c) {
         j.out = c.slab(P.va_w, D * cf.video_feature_dim, nchunk);
         j.out_bias[0] = c.slab(P.va_b, D, nchunk);
         wb.j[wb.n++] = j;
-        LAUNCH(launch_wgrad(wb, c.s));
+        LAUNCH("wgrad", launch_wgrad(wb, c.s));
     }
     // ---- query pass, then the embedding stack
     enc_bwd(c, P.fe, K.fe, p.qe, c.dry ? nullptr : c.W(p.dQtot), nullptr, c.dry ? nullptr : c.W(p.dqf),
             c.dry ? nullptr : io->q_mask, B, 1);
     const int EW = cf.word_dim + 100;
-    LAUNCH(launch_linear_bwd_data(c.W(p.dqf), c.PK(K.emb_t), c.W(p.dE), Rq, EW, c.s));
+    LAUNCH("linear_bwd_data", launch_linear_bwd_data(c.W(p.dqf), c.PK(K.emb_t), c.W(p.dE), Rq, EW, c.s));
     {
         WgradBatch wb;
         memset(&wb, 0, sizeof wb);
@@ -525,7 +545,7 @@ void run_backward(Ctx& c) {
         j.out = c.slab(P.emb_w, D * EW, nchunk_q);
         j.out_bias[0] = c.slab(P.emb_b, D, nchunk_q);
         wb.j[wb.n++] = j;
-        LAUNCH(launch_wgrad(wb, c.s));
+        LAUNCH("wgrad", launch_wgrad(wb, c.s));
     }
     {
         const int nce = (Rq + EMB_CHUNK - 1) / EMB_CHUNK;
@@ -540,11 +560,11 @@ void run_backward(Ctx& c) {
             wo += wn; bo += ch[i];
         }
         float* p_tab = c.slab(P.char_tab, cf.char_size * cf.char_dim, nce);
-        LAUNCH(launch_embed_bwd(c.W(p.dE), io->word_ids, io->char_ids, c.W(p.E), reinterpret_cast<const int8_t*>(c.W(p.argpos)),
+        LAUNCH("embed_bwd", launch_embed_bwd(c.W(p.dE), io->word_ids, io->char_ids, c.W(p.E), reinterpret_cast<const int8_t*>(c.W(p.argpos)),
                                 c.P(P.char_tab), char_ptrs(c), c.part_ptr(ow), c.part_ptr(ob), p_tab, io->grads + P.unk, Rq,
                                 p.Lc, cf.word_dim, cf.char_dim, cf.char_size, c.drop(SITE_WORD), c.drop(SITE_CHAR), c.s));
     }
-    LAUNCH(launch_reduce(c.W(p.partial), io->grads, p.segs_dev, p.blk2seg_dev, p.nblocks, c.s));
+    LAUNCH("reduce", launch_reduce(c.W(p.partial), io->grads, p.segs_dev, p.blk2seg_dev, p.nblocks, c.s));
 }
 
 int build_plan(vsl_handle_s* h, int B, int T, int Lq, int Lc, Plan** out) {
@@ -715,7 +735,7 @@ int64_t vsl_workspace_offset(vsl_handle h, int B, int T, int Lq, int Lc, const c
         {"venc_v", p->ve.v}, {"venc_att", p->ve.att}, {"venc_r", p->ve.r}, {"qenc_conv3", p->qe.y[3]}, {"qenc_att", p->qe.att},
         {"cq_score", p->S}, {"cq_srow", p->Srow}, {"cq_scol", p->Scol}, {"cq_M", p->M}, {"cq_attention", p->f1},
         {"cq_concat", p->f2}, {"gated", p->gated}, {"pred_s", p->p1.out}, {"pred_e", p->p2.out},
-        {"d_gated", p->g_gated}, {"d_venc", p->dC}, {"d_qenc", p->dQtot}, {"d_video_affine", p->dvf}, {"d_embedding_net", p->dqf},
+        {"d_gated_enc", p->g_gated}, {"d_gated_hs", p->dxh_s}, {"d_gated_he", p->dxh_e}, {"d_venc", p->dC}, {"d_qenc", p->dQtot}, {"d_video_affine", p->dvf}, {"d_embedding_net", p->dqf},
         {"d_pred_s", p->g_s1}, {"d_cq_concat", p->df2}, {"d_cq_attention", p->df1}, {"d_emb_concat", p->dE}};
     for (auto& kv : tab) if (n == kv.first) return kv.second;
     return -1;
@@ -762,6 +782,34 @@ int vsl_extract_index(vsl_handle h, const float* start_logits, const float* end_
     if (T > 8192) return fail("T too large");
     launch_extract_index(start_logits, end_logits, start_index, end_index, B, T, (hipStream_t)hip_stream);
     HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int vsl_profile_select(vsl_handle h, const char* kernel) {
+    if (!h) return fail("null handle");
+    h->prof_on = kernel != nullptr && kernel[0] != 0;
+    h->prof_sel = kernel ? kernel : "";
+    h->prof_recs.clear();
+    h->prof_used = 0;
+    return 0;
+}
+
+int vsl_profile_read(vsl_handle h, int index, char* name, int name_cap, double* total_ms, int32_t* count) {
+    if (!h) return fail("null handle");
+    // aggregate by kernel name (synchronises on the recorded events)
+    std::vector<std::pair<std::string, std::pair<double, int>>> agg;
+    for (auto& r : h->prof_recs) {
+        float ms = 0.f;
+        if (hipEventSynchronize(h->prof_pool[r.e1]) != hipSuccess || hipEventElapsedTime(&ms, h->prof_pool[r.e0], h->prof_pool[r.e1]) != hipSuccess)
+            return fail("hipEventElapsedTime failed");
+        bool found = false;
+        for (auto& a : agg) if (a.first == r.name) { a.second.first += ms; a.second.second++; found = true; break; }
+        if (!found) agg.push_back({r.name, {ms, 1}});
+    }
+    if (index < 0 || index >= (int)agg.size()) return 2;       // end of list
+    if (name && name_cap > 0) { strncpy(name, agg[index].first.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+    if (total_ms) *total_ms = agg[index].second.first;
+    if (count) *count = agg[index].second.second;
     return 0;
 }
 

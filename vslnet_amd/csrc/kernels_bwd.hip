@@ -690,18 +690,21 @@ void launch_qkv_bwd(const float* dQ, const float* dK, const float* dV, const flo
 }
 
 // positional-embedding gradient (a6, :202): dpos[t] = sum_b dx0[b, t] ; rows >= L of the table get zero
-__global__ __launch_bounds__(256) void k_pos_grad(const float* __restrict__ dx0, float* __restrict__ out, int B, int L,
-                                                  int max_pos) {
+__global__ __launch_bounds__(256) void k_pos_grad(const float* __restrict__ dx0, const float* __restrict__ extra,
+                                                  float* __restrict__ out, int B, int L, int max_pos) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= max_pos * D) return;
     const int t = e >> 7, c = e & 127;
     float acc = 0.f;
     if (t < L)
-        for (int b = 0; b < B; ++b) acc += dx0[((size_t)b * L + t) * D + c];
+        for (int b = 0; b < B; ++b) {
+            const size_t o = ((size_t)b * L + t) * D + c;
+            acc += extra ? dx0[o] - extra[o] : dx0[o];     // `extra` was folded into dx0 but is not a grad of x + pos
+        }
     out[e] = acc;
 }
-void launch_pos_grad(const float* dx0, float* out, int B, int L, int max_pos, hipStream_t s) {
-    hipLaunchKernelGGL(k_pos_grad, dim3((max_pos * D + 255) / 256), dim3(256), 0, s, dx0, out, B, L, max_pos);
+void launch_pos_grad(const float* dx0, const float* extra, float* out, int B, int L, int max_pos, hipStream_t s) {
+    hipLaunchKernelGGL(k_pos_grad, dim3((max_pos * D + 255) / 256), dim3(256), 0, s, dx0, extra, out, B, L, max_pos);
 }
 
 // =========================================================================================================

@@ -125,7 +125,7 @@ void launch_attn_bwd(const float* Q, const float* K, const float* V, const float
 void launch_qkv_bwd(const float* dQ, const float* dK, const float* dV, const float* x, const float* dr,
                     const float* ln_g, const float* WTpack, float* dx, float* p_lng, float* p_lnb, int R, Drop d1,
                     hipStream_t s);
-void launch_pos_grad(const float* dx0, float* out, int B, int L, int max_pos, hipStream_t s);
+void launch_pos_grad(const float* dx0, const float* extra, float* out, int B, int L, int max_pos, hipStream_t s);
 void launch_cqcat_bwd(const float* dg0, const float* dg1, const float* dg2, const float* dh_loss, const float* f2,
                       const float* hscore, const float* wh, const float* W1Tpack, float* df2, float* df1, float* p_wh,
                       float* p_bh, int R, hipStream_t s);

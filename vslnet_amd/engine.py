@@ -41,7 +41,7 @@ class vsl_loss_io(C.Structure):
 
 ABI_SYMBOLS = ['vsl_last_error', 'vsl_create', 'vsl_destroy', 'vsl_param_count', 'vsl_param_info', 'vsl_param_floats',
                'vsl_workspace_floats', 'vsl_forward', 'vsl_loss', 'vsl_backward', 'vsl_extract_index',
-               'vsl_workspace_offset']
+               'vsl_workspace_offset', 'vsl_profile_select', 'vsl_profile_read']
 
 
 def load_library():
@@ -68,6 +68,8 @@ def load_library():
     lib.vsl_extract_index.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.vsl_workspace_offset.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p]
     lib.vsl_workspace_offset.restype = C.c_int64
+    lib.vsl_profile_select.argtypes = [C.c_void_p, C.c_char_p]
+    lib.vsl_profile_read.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
     _LIB = lib
     return lib
 
@@ -193,9 +195,20 @@ class Engine:
         return out[0], out[1], out[2]
 
     def loss(self, start_labels, end_labels, h_labels, w_loc=1.0, w_highlight=5.0, inv_batch=None, mask_sum=0.0,
-             want_grads=True):
-        """Fused compute_loss + compute_highlight_loss on the LAST forward.  Returns (losses[4], d_h, d_sl, d_el)."""
+             want_grads=True, scores=None, start_logits=None, end_logits=None, v_mask=None):
+        """Fused compute_loss + compute_highlight_loss.  By default on the outputs of the LAST forward; explicit
+        (B, T) tensors may be passed instead.  Returns (losses[4], d_h, d_sl, d_el)."""
         io = self._last
+        if scores is not None:
+            B, T = scores.shape
+            for t, nm in ((scores, 'scores'), (start_logits, 'start_logits'), (end_logits, 'end_logits'), (v_mask, 'mask')):
+                _chk(t, torch.float32, (B, T), nm)
+            io2 = vsl_io()
+            C.memmove(C.byref(io2), C.byref(io), C.sizeof(vsl_io))
+            if (B, T) != (io.B, io.T):
+                raise ValueError('loss inputs (%d, %d) do not match the last forward (%d, %d)' % (B, T, io.B, io.T))
+            io2.h_score, io2.start_logits, io2.end_logits, io2.v_mask = _ptr(scores), _ptr(start_logits), _ptr(end_logits), _ptr(v_mask)
+            io = io2
         B, T = io.B, io.T
         _chk(start_labels, torch.int64, (B,), 'start_labels')
         _chk(end_labels, torch.int64, (B,), 'end_labels')
@@ -227,6 +240,23 @@ class Engine:
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         self._call(self.lib.vsl_backward(self.h, C.byref(io), stream))
         return grads
+
+    def profile_select(self, kernel):
+        """Time launches of `kernel` ('*' = all, None = off) with HIP events on the launch stream."""
+        self._call(self.lib.vsl_profile_select(self.h, None if kernel is None else kernel.encode()))
+
+    def profile_read(self):
+        """-> {kernel: (total_ms, launches)} since the last profile_select."""
+        out, name, ms, n = {}, C.create_string_buffer(64), C.c_double(), C.c_int32()
+        i = 0
+        while True:
+            rc = self.lib.vsl_profile_read(self.h, i, name, 64, C.byref(ms), C.byref(n))
+            if rc == 2:
+                break
+            self._call(rc)
+            out[name.value.decode()] = (ms.value, n.value)
+            i += 1
+        return out
 
     def extract_index(self, start_logits, end_logits):
         B, T = start_logits.shape
