@@ -66,11 +66,13 @@ def kernel_work(name, B, T, Dv, Lq, d=128, H=8):
     return tbl.get(name)
 
 
-def cpu_baseline(configs, T, Lq, Lc, sample_B=16, iters=3):
+def cpu_baseline(configs, T, Lq, Lc, sample_B=16, iters=3, threads=32, budget_s=30.0):
     """The pinned CPU oracle (restatement of the reference's PyTorch CPU path) timed on this box's host cores on a
     bounded sample of the same workload.  kind = 'port'."""
     from oracle import vslnet_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
+    # intra-op threads: the reference's CPU path saturates well before this box's 100+ hardware threads (and gets
+    # pathologically slow when oversubscribed), so a bounded thread count is used and reported as `cores`
+    torch.set_num_threads(max(1, min(threads, os.cpu_count() or 1)))
     cfg = O.make_cfg(video_feature_dim=configs.video_feature_dim, max_pos_len=configs.max_pos_len,
                      word_size=configs.word_size, drop_rate=configs.drop_rate)
     P = {k: v.clone().requires_grad_(k not in O.FROZEN) for k, v in O.random_params(cfg, seed=1).items()}
@@ -81,7 +83,10 @@ def cpu_baseline(configs, T, Lq, Lc, sample_B=16, iters=3):
             p.grad = None
         total, _ = O.total_loss(P, cfg, b, training=True)
         total.backward()
+    t0 = time.perf_counter()
     step()
+    warm = time.perf_counter() - t0
+    iters = max(1, min(iters, int(budget_s / max(warm, 1e-3))))          # keep the whole leg within ~budget_s
     t0 = time.perf_counter()
     for _ in range(iters):
         step()

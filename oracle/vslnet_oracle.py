@@ -81,9 +81,8 @@ def char_embedding(P, char_ids, p, training):
     for i, k in enumerate(CHAR_KERNELS):
         w = P['embedding_net.char_emb.char_convs.%d.0.weight' % i]       # (c, 50, 1, k)
         b = P['embedding_net.char_emb.char_convs.%d.0.bias' % i]
-        win = emb.unfold(2, k, 1)                                         # (B, Lq, Lc-k+1, 50, k)
-        y = torch.einsum('bwpik,oik->bwpo', win, w[:, :, 0, :]) + b
-        outs.append(torch.relu(y).max(dim=2).values)                      # (B, Lq, c)
+        y = F.conv2d(emb.permute(0, 3, 1, 2), w, b)                       # (B, c, Lq, Lc-k+1)
+        outs.append(torch.relu(y).max(dim=3).values.permute(0, 2, 1))     # (B, Lq, c)
     return torch.cat(outs, dim=-1)                                        # (B, Lq, 100)
 
 
@@ -101,9 +100,7 @@ def depthwise7(x, w):
 
     u[b,t,c] = sum_k w[c,0,k] * x[b,t+k-3,c], zero outside [0, L) -- padded rows are NOT masked."""
     k = w.shape[-1]
-    xp = F.pad(x, (0, 0, k // 2, k // 2))
-    win = xp.unfold(1, k, 1)                                              # (B, L, C, k)
-    return (win * w[:, 0, :]).sum(dim=-1)
+    return F.conv1d(x.transpose(1, 2), w, padding=k // 2, groups=w.shape[0]).transpose(1, 2)
 
 
 def conv_layer(x, ln_g, ln_b, dw_w, pw_w, pw_b, p, training):
