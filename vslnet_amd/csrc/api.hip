@@ -48,7 +48,7 @@ struct ModelPk { int va_f, emb_f, emb_t; EncPk fe, pe; int cqa_f, cqa_t, cat1_f,
 
 struct EncWs { int64_t x0, y[4], u[4], mask[4], h1, q, k, v, lse, att, r, h2, out; int R, L; };
 
-struct SlabRec { int dst, n, nslabs, ss, rl, ds; int64_t src; };
+struct SlabRec { int dst, n, nslabs, ss, rl, ds, vn; int64_t src; };
 
 struct Plan {
     int B, T, Lq, Lc;
@@ -264,13 +264,14 @@ struct Ctx {
         if (dry) { p->part_offs.push_back(part_cur); part_cur += n; return p->part_offs.back(); }
         return p->part_offs[part_idx++];
     }
-    void reg(int dst, int n, int64_t src, int nslabs, int ss, int rl = 0, int ds = 0) {
-        if (dry) recs->push_back(SlabRec{dst, n, nslabs, ss, rl ? rl : n, ds, src});
+    // register a reduction source: `src` is an ABSOLUTE workspace offset (partial arena or any saved buffer)
+    void reg(int dst, int n, int64_t src, int nslabs, int ss, int rl = 0, int ds = 0, int vn = 0) {
+        if (dry) recs->push_back(SlabRec{dst, n, nslabs, ss, rl ? rl : n, ds, vn ? vn : n, src});
     }
     // the common case: `nslabs` contiguous slabs of n floats for the parameter at dst
     float* slab(int dst, int n, int nslabs) {
         const int64_t o = part_alloc((int64_t)n * nslabs);
-        reg(dst, n, o, nslabs, n);
+        reg(dst, n, p->partial + o, nslabs, n);
         return dry ? nullptr : ws + p->partial + o;
     }
     float* part_ptr(int64_t o) const { return dry ? nullptr : ws + p->partial + o; }
@@ -362,16 +363,15 @@ void run_forward(Ctx& c) {
 WgradJob wjob() { WgradJob j; memset(&j, 0, sizeof j); return j; }
 
 // backward of one FeatureEncoder application: dy = grad wrt its output; writes grad wrt its input (dx0_out)
-void enc_bwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float* dy, const float* extra, float* dx0_out,
+void enc_bwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float* dy, const float* dy2, int64_t dx0_off,
              const float* mask, int Bn, int app) {
+    float* dx0_out = c.dry ? nullptr : c.W(dx0_off);
     const Plan& p = *c.p;
     const int R = w.R, L = w.L, H = c.h->cfg.num_heads;
     const int ntiles = (R + TILE_M - 1) / TILE_M, nchunk = (R + WG_ROWS - 1) / WG_ROWS;
-    const bool dropping = c.io && c.io->training && c.h->cfg.drop_rate > 0.f;
     float* p_ln2g = c.slab(P.ln2g, D, ntiles);
     float* p_ln2b = c.slab(P.ln2b, D, ntiles);
-    float* g_o = dropping ? c.W(p.t_go) : nullptr;
-    LAUNCH("attn_out_bwd", launch_attn_out_bwd(dy, c.W(w.r), c.P(P.ln2g), c.PK(K.o_t), g_o, c.W(p.t_dr), p_ln2g, p_ln2b, R,
+    LAUNCH("attn_out_bwd", launch_attn_out_bwd(dy, dy2, c.W(w.r), c.P(P.ln2g), c.PK(K.o_t), c.W(p.t_go), c.W(p.t_dr), p_ln2g, p_ln2b, R,
                                c.drop(app * 16 + 7), c.drop(app * 16 + 8), c.s));
     LAUNCH("attn_bwd", launch_attn_bwd(c.W(w.q), c.W(w.k), c.W(w.v), c.W(w.att), c.W(p.t_dr), c.W(w.lse), mask, c.W(p.t_dq), c.W(p.t_dk),
                            c.W(p.t_dv), c.W(p.t_Dq), Bn, L, H, 0, c.drop(app * 16 + 5), c.drop(app * 16 + 6), c.s));
@@ -389,7 +389,7 @@ void enc_bwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float*
         float* p_dw = c.slab(P.dw[i], D * DWK, ntiles);
         float* out = i > 0 ? other : dx0_out;
         LAUNCH("conv_bwd_dwln", launch_conv_bwd_dwln(c.W(p.t_du), i > 0 ? c.W(w.y[i - 1]) : c.W(w.x0), g, c.P(P.lng[i]), c.P(P.lnb[i]),
-                                    c.P(P.dw[i]), i == 0 ? extra : nullptr, out, p_g, p_b, p_dw, R, L, c.s));
+                                    c.P(P.dw[i]), nullptr, out, p_g, p_b, p_dw, R, L, c.s));
         other = g;
         g = out;
     }
@@ -398,7 +398,7 @@ void enc_bwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float*
     memset(&wb, 0, sizeof wb);
     {
         WgradJob j = wjob();
-        j.G[0] = dropping ? g_o : dy; j.nG = 1; j.A[0] = c.dry ? nullptr : c.W(w.h2); j.nA = 1; j.K = D; j.R = R;
+        j.G[0] = c.dry ? nullptr : c.W(p.t_go); j.nG = 1; j.A[0] = c.dry ? nullptr : c.W(w.h2); j.nA = 1; j.K = D; j.R = R;
         j.out = c.slab(P.ow, D * D, nchunk);
         j.out_bias[0] = c.slab(P.ob, D, nchunk);
         wb.j[wb.n++] = j;
@@ -408,9 +408,9 @@ void enc_bwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float*
         if (!c.dry) { j.G[0] = c.W(p.t_dq); j.G[1] = c.W(p.t_dk); j.G[2] = c.W(p.t_dv); j.A[0] = c.W(w.h1); }
         j.nG = 3; j.nA = 1; j.K = D; j.R = R;
         const int64_t o = c.part_alloc((int64_t)nchunk * 3 * D * D);
-        c.reg(P.qw, D * D, o, nchunk, 3 * D * D);
-        c.reg(P.kw, D * D, o + D * D, nchunk, 3 * D * D);
-        c.reg(P.vw, D * D, o + 2 * D * D, nchunk, 3 * D * D);
+        c.reg(P.qw, D * D, p.partial + o, nchunk, 3 * D * D);
+        c.reg(P.kw, D * D, p.partial + o + D * D, nchunk, 3 * D * D);
+        c.reg(P.vw, D * D, p.partial + o + 2 * D * D, nchunk, 3 * D * D);
         j.out = c.part_ptr(o);
         j.out_bias[0] = c.slab(P.qb, D, nchunk);
         j.out_bias[1] = c.slab(P.kb, D, nchunk);
@@ -426,8 +426,8 @@ void enc_bwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float*
         wb.j[wb.n++] = j;
     }
     LAUNCH("wgrad", launch_wgrad(wb, c.s));
-    float* p_pos = c.slab(P.pos, c.h->cfg.max_pos_len * D, 1);
-    LAUNCH("pos_grad", launch_pos_grad(dx0_out, extra, p_pos, Bn, L, c.h->cfg.max_pos_len, c.s));
+    // positional table (:202): dpos[t] = sum_b dx0[b, t] -- the per-sample rows of dx0 ARE the partial slabs
+    c.reg(P.pos, c.h->cfg.max_pos_len * D, dx0_off, Bn, L * D, 0, 0, L * D);
 }
 
 void run_backward(Ctx& c) {
@@ -466,9 +466,9 @@ void run_backward(Ctx& c) {
         LAUNCH("wgrad", launch_wgrad(wb, c.s));
     }
     // ---- predictor encoder, second pass (input = output of the first pass), then first pass
-    enc_bwd(c, P.pe, K.pe, p.p2, c.dry ? nullptr : c.W(p.dfeat_e), c.dry ? nullptr : c.W(p.dfeat_s),
-            c.dry ? nullptr : c.W(p.g_s1), c.dry ? nullptr : io->v_mask, B, 3);
-    enc_bwd(c, P.pe, K.pe, p.p1, c.dry ? nullptr : c.W(p.g_s1), nullptr, c.dry ? nullptr : c.W(p.g_gated),
+    enc_bwd(c, P.pe, K.pe, p.p2, c.dry ? nullptr : c.W(p.dfeat_e), nullptr, p.g_s1, c.dry ? nullptr : io->v_mask, B, 3);
+    // grad wrt the first pass' output = (input grad of the second pass) + (LayerNorm path of the start head)
+    enc_bwd(c, P.pe, K.pe, p.p1, c.dry ? nullptr : c.W(p.g_s1), c.dry ? nullptr : c.W(p.dfeat_s), p.g_gated,
             c.dry ? nullptr : io->v_mask, B, 2);
     // ---- gating + highlight + CQConcatenate
     float* p_hlw = c.slab(P.hl_w, D, ntiles);
@@ -483,7 +483,7 @@ void run_backward(Ctx& c) {
             if (!c.dry) { j.G[0] = c.W(p.df2); j.A[0] = c.W(p.f1); }
             j.nG = 1; j.nA = 1; j.K = D; j.R = R;
             const int64_t o = c.part_alloc((int64_t)nchunk * D * D);
-            c.reg(P.cat_w, D * D, o, nchunk, D * D, D, 2 * D);
+            c.reg(P.cat_w, D * D, p.partial + o, nchunk, D * D, D, 2 * D);
             j.out = c.part_ptr(o);
             wb.j[wb.n++] = j;
         }
@@ -513,13 +513,12 @@ void run_backward(Ctx& c) {
         a.p_w4C = c.slab(P.w4C, D, B); a.p_w4Q = c.slab(P.w4Q, D, B); a.p_w4mlu = c.slab(P.w4mlu, D, B);
         a.p_pool = c.slab(P.pool_w, D, B); a.p_bcat = c.slab(P.cat_b, D, B);
         const int64_t o = c.part_alloc((int64_t)B * D * D);
-        c.reg(P.cat_w + D, D * D, o, B, D * D, D, 2 * D);          // second half of the (128, 256) weight
+        c.reg(P.cat_w + D, D * D, p.partial + o, B, D * D, D, 2 * D);          // second half of the (128, 256) weight
         a.p_W2 = c.part_ptr(o);
         LAUNCH("cq_col_bwd", launch_cq_col_bwd(a, B, c.s));
     }
     // ---- shared feature encoder: video pass, then VisualProjection weight gradient
-    enc_bwd(c, P.fe, K.fe, p.ve, c.dry ? nullptr : c.W(p.dC), nullptr, c.dry ? nullptr : c.W(p.dvf),
-            c.dry ? nullptr : io->v_mask, B, 0);
+    enc_bwd(c, P.fe, K.fe, p.ve, c.dry ? nullptr : c.W(p.dC), nullptr, p.dvf, c.dry ? nullptr : io->v_mask, B, 0);
     {
         WgradBatch wb;
         memset(&wb, 0, sizeof wb);
@@ -532,8 +531,7 @@ void run_backward(Ctx& c) {
         LAUNCH("wgrad", launch_wgrad(wb, c.s));
     }
     // ---- query pass, then the embedding stack
-    enc_bwd(c, P.fe, K.fe, p.qe, c.dry ? nullptr : c.W(p.dQtot), nullptr, c.dry ? nullptr : c.W(p.dqf),
-            c.dry ? nullptr : io->q_mask, B, 1);
+    enc_bwd(c, P.fe, K.fe, p.qe, c.dry ? nullptr : c.W(p.dQtot), nullptr, p.dqf, c.dry ? nullptr : io->q_mask, B, 1);
     const int EW = cf.word_dim + 100;
     LAUNCH("linear_bwd_data", launch_linear_bwd_data(c.W(p.dqf), c.PK(K.emb_t), c.W(p.dE), Rq, EW, c.s));
     {
@@ -555,16 +553,17 @@ void run_backward(Ctx& c) {
         int wo = 0, bo = 0;
         for (int i = 0; i < 4; ++i) {
             const int wn = ch[i] * cf.char_dim * (i + 1);
-            c.reg(P.ccw[i], wn, ow + wo, nce, wtot);
-            c.reg(P.ccb[i], ch[i], ob + bo, nce, 100);
+            c.reg(P.ccw[i], wn, p.partial + ow + wo, nce, wtot);
+            c.reg(P.ccb[i], ch[i], p.partial + ob + bo, nce, 100);
             wo += wn; bo += ch[i];
         }
         float* p_tab = c.slab(P.char_tab, cf.char_size * cf.char_dim, nce);
+        float* p_unk = c.slab(P.unk, cf.word_dim, nce);
         LAUNCH("embed_bwd", launch_embed_bwd(c.W(p.dE), io->word_ids, io->char_ids, c.W(p.E), reinterpret_cast<const int8_t*>(c.W(p.argpos)),
-                                c.P(P.char_tab), char_ptrs(c), c.part_ptr(ow), c.part_ptr(ob), p_tab, io->grads + P.unk, Rq,
+                                c.P(P.char_tab), char_ptrs(c), c.part_ptr(ow), c.part_ptr(ob), p_tab, p_unk, Rq,
                                 p.Lc, cf.word_dim, cf.char_dim, cf.char_size, c.drop(SITE_WORD), c.drop(SITE_CHAR), c.s));
     }
-    LAUNCH("reduce", launch_reduce(c.W(p.partial), io->grads, p.segs_dev, p.blk2seg_dev, p.nblocks, c.s));
+    LAUNCH("reduce", launch_reduce(c.ws, io->grads, p.segs_dev, p.blk2seg_dev, p.nblocks, c.s));
 }
 
 int build_plan(vsl_handle_s* h, int B, int T, int Lq, int Lc, Plan** out) {
@@ -607,6 +606,7 @@ int build_plan(vsl_handle_s* h, int B, int T, int Lq, int Lc, Plan** out) {
     p->partial_floats = c.part_cur;
     al(p->partial_floats);
     p->total = al.cur;
+    if (p->total >= (int64_t(1) << 31)) { delete p; return fail("workspace of %lld floats exceeds the 2^31 offset range of the reduction table", (long long)p->total); }
     // group the records by destination (shared weights are written by up to 4 encoder applications)
     std::vector<ReduceSeg> segs;
     std::map<int, int> by_dst;
@@ -622,12 +622,16 @@ int build_plan(vsl_handle_s* h, int B, int T, int Lq, int Lc, Plan** out) {
         }
         ReduceSeg& s = segs[it->second];
         if (s.n != r.n || s.nsrc >= 4) { delete p; return fail("internal: inconsistent partial slabs for param offset %d", r.dst); }
-        s.src[s.nsrc] = (int)r.src; s.nslabs[s.nsrc] = r.nslabs; s.ss[s.nsrc] = r.ss;
+        s.src[s.nsrc] = (int)r.src; s.nslabs[s.nsrc] = r.nslabs; s.ss[s.nsrc] = r.ss; s.vn[s.nsrc] = r.vn;
         ++s.nsrc;
+    }
+    for (ReduceSeg& s : segs) {
+        s.vec = (s.n % 4 == 0) && (s.rl % 4 == 0) && (s.ds % 4 == 0) && (s.dst % 4 == 0);
+        for (int q = 0; q < s.nsrc; ++q) s.vec = s.vec && (s.src[q] % 4 == 0) && (s.ss[q] % 4 == 0) && (s.vn[q] % 4 == 0);
     }
     std::vector<int> blk;
     for (size_t i = 0; i < segs.size(); ++i)
-        for (int o = 0; o < segs[i].n; o += 256) { blk.push_back((int)i); blk.push_back(o); }
+        for (int o = 0; o < segs[i].n; o += 1024) { blk.push_back((int)i); blk.push_back(o); }
     p->nblocks = (int)blk.size() / 2;
     HIP_OK(hipMalloc(&p->segs_dev, segs.size() * sizeof(ReduceSeg)));
     HIP_OK(hipMalloc(&p->blk2seg_dev, blk.size() * sizeof(int)));

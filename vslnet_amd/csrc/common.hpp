@@ -108,6 +108,57 @@ __device__ __forceinline__ void gemm32(const float* __restrict__ As, int lda, in
         }
     }
 }
+// Same GEMM with the packed-weight fragments software-pipelined through registers: KB k-blocks (8 k each) are
+// fetched per stage, the next stage is in flight while the current one feeds the MFMAs.  The first stage can be
+// issued at kernel entry (bfrag_load) so that its L2/HBM latency hides under the kernel's LDS prologue.
+template <int NT, int KB>
+struct BFrag { float4 b[NT][KB]; };
+
+template <int NT, int KB>
+__device__ __forceinline__ void bfrag_load(BFrag<NT, KB>& f, const float* __restrict__ Bp, int ncols, int col0, int cstep,
+                                           int kb0, int nkb) {
+    const int lane = threadIdx.x & 63;
+    const float4* bp = reinterpret_cast<const float4*>(Bp) + (size_t)(col0 + (lane & 31)) * 2 + (lane >> 5);
+#pragma unroll
+    for (int q = 0; q < KB; ++q)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            f.b[t][q] = kb0 + q < nkb ? bp[((size_t)(kb0 + q) * ncols + t * cstep) * 2] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+template <int NT, int KB>
+__device__ __forceinline__ void gemm32p(const float* __restrict__ As, int lda, int K, const float* __restrict__ Bp,
+                                        int ncols, int col0, int cstep, f32x16 (&acc)[NT], BFrag<NT, KB>& cur) {
+    const int lane = threadIdx.x & 63;
+    const float* arow = As + (lane & 31) * lda + 4 * (lane >> 5);
+    const int nkb = K >> 3;
+    BFrag<NT, KB> nxt;
+    for (int kb0 = 0; kb0 < nkb; kb0 += KB) {
+        const bool more = kb0 + KB < nkb;
+        if (more) bfrag_load(nxt, Bp, ncols, col0, cstep, kb0 + KB, nkb);
+#pragma unroll
+        for (int q = 0; q < KB; ++q) {
+            if (kb0 + q < nkb) {
+                const float4 a = *reinterpret_cast<const float4*>(arow + (kb0 + q) * 8);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const float4 b = cur.b[t][q];
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[t], 0, 0, 0);
+                }
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int q = 0; q < KB; ++q)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) cur.b[t][q] = nxt.b[t][q];
+        }
+    }
+}
+
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
 template <int NT>
@@ -173,6 +224,128 @@ __device__ __forceinline__ void ln_row_bwd(float x0, float x1, float dy0, float 
     const float m2 = wave_sum(g0 * xh0 + g1 * xh1) * (1.0f / D);
     dx0 = rstd * (g0 - m1 - xh0 * m2);
     dx1 = rstd * (g1 - m1 - xh1 * m2);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Tile-wide LayerNorm: 8 consecutive lanes own one row (lane sub = tid & 7 holds the float4 columns
+// sub*4 + 32*j, j = 0..3), 32 rows per pass of the 256-thread workgroup -> two 3-step shuffle reductions per row
+// instead of a 6-step wave reduction per row executed serially by one wave.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float grp8_sum(float v) {
+    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+    return v;
+}
+__device__ __forceinline__ float sum4(const float4& v) { return (v.x + v.y) + (v.z + v.w); }
+
+// in place: tile[r][:] <- LN(tile[r][:]) * drop      for r < nrows (row stride ld floats).  `drow0` = global row of
+// tile row 0 for the dropout element index (row * 128 + col).
+__device__ __forceinline__ void ln_tile(float* tile, int nrows, int ld, const float* __restrict__ g,
+                                        const float* __restrict__ b, const Drop& dp, int drow0) {
+    const int sub = threadIdx.x & 7;
+    float4 gv[4], bv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        gv[j] = *reinterpret_cast<const float4*>(g + sub * 4 + 32 * j);
+        bv[j] = *reinterpret_cast<const float4*>(b + sub * 4 + 32 * j);
+    }
+    for (int r = threadIdx.x >> 3; r < nrows; r += NTHREADS / 8) {
+        float* row = tile + r * ld + sub * 4;
+        float4 v[4];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = *reinterpret_cast<const float4*>(row + 32 * j); s += sum4(v[j]); }
+        const float mu = grp8_sum(s) * (1.0f / D);
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j].x -= mu; v[j].y -= mu; v[j].z -= mu; v[j].w -= mu;
+            q += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
+        }
+        const float rstd = rsqrtf(grp8_sum(q) * (1.0f / D) + LN_EPS);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float4 o;
+            o.x = v[j].x * rstd * gv[j].x + bv[j].x; o.y = v[j].y * rstd * gv[j].y + bv[j].y;
+            o.z = v[j].z * rstd * gv[j].z + bv[j].z; o.w = v[j].w * rstd * gv[j].w + bv[j].w;
+            if (dp.thresh) {
+                const uint32_t base = (uint32_t)((drow0 + r) * D + sub * 4 + 32 * j);
+                o.x *= drop_mul(dp, base); o.y *= drop_mul(dp, base + 1); o.z *= drop_mul(dp, base + 2); o.w *= drop_mul(dp, base + 3);
+            }
+            *reinterpret_cast<float4*>(row + 32 * j) = o;
+        }
+    }
+}
+
+// LayerNorm backward on a 32-row tile.
+//   Ts : grad wrt the LN output (32 x 128, stride LDP) -- left in place (beta partial = its column sums)
+//   Xs : raw LN input rows (32 x 128, stride LDP)       -- overwritten with dy * xhat (gamma partial = column sums)
+//   out[r] = LN^T(Ts[r]) + resid[r] + extra[r]  for global rows r0 + rr < R ; partial slabs [blockIdx.x][128].
+__device__ __forceinline__ void ln_bwd_tile(float* Ts, float* Xs, const float* __restrict__ resid,
+                                            const float* __restrict__ resid2, const float* __restrict__ ln_g,
+                                            float* __restrict__ out, float* __restrict__ p_lng, float* __restrict__ p_lnb,
+                                            int r0, int R) {
+    const int tid = threadIdx.x, sub = tid & 7, rr = tid >> 3;
+    const int r = r0 + rr;
+    {
+        float* xr = Xs + rr * LDP + sub * 4;
+        const float* tr = Ts + rr * LDP + sub * 4;
+        float4 x[4], dy[4], rs[4];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            x[j] = *reinterpret_cast<const float4*>(xr + 32 * j);
+            dy[j] = *reinterpret_cast<const float4*>(tr + 32 * j);
+            rs[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < R) {
+                if (resid) rs[j] = *reinterpret_cast<const float4*>(resid + (size_t)r * D + sub * 4 + 32 * j);
+                if (resid2) {
+                    const float4 e = *reinterpret_cast<const float4*>(resid2 + (size_t)r * D + sub * 4 + 32 * j);
+                    rs[j].x += e.x; rs[j].y += e.y; rs[j].z += e.z; rs[j].w += e.w;
+                }
+            }
+            s += sum4(x[j]);
+        }
+        const float mu = grp8_sum(s) * (1.0f / D);
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            x[j].x -= mu; x[j].y -= mu; x[j].z -= mu; x[j].w -= mu;
+            q += x[j].x * x[j].x + x[j].y * x[j].y + x[j].z * x[j].z + x[j].w * x[j].w;
+        }
+        const float rstd = rsqrtf(grp8_sum(q) * (1.0f / D) + LN_EPS);
+        float m1 = 0.f, m2 = 0.f;
+        float4 gd[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 gv = *reinterpret_cast<const float4*>(ln_g + sub * 4 + 32 * j);
+            x[j].x *= rstd; x[j].y *= rstd; x[j].z *= rstd; x[j].w *= rstd;                       // xhat
+            gd[j] = make_float4(dy[j].x * gv.x, dy[j].y * gv.y, dy[j].z * gv.z, dy[j].w * gv.w);  // dy * gamma
+            m1 += sum4(gd[j]);
+            m2 += gd[j].x * x[j].x + gd[j].y * x[j].y + gd[j].z * x[j].z + gd[j].w * x[j].w;
+        }
+        m1 = grp8_sum(m1) * (1.0f / D);
+        m2 = grp8_sum(m2) * (1.0f / D);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float4 o;
+            o.x = rstd * (gd[j].x - m1 - x[j].x * m2) + rs[j].x; o.y = rstd * (gd[j].y - m1 - x[j].y * m2) + rs[j].y;
+            o.z = rstd * (gd[j].z - m1 - x[j].z * m2) + rs[j].z; o.w = rstd * (gd[j].w - m1 - x[j].w * m2) + rs[j].w;
+            if (r < R) *reinterpret_cast<float4*>(out + (size_t)r * D + sub * 4 + 32 * j) = o;
+            const bool ok = r < R;
+            *reinterpret_cast<float4*>(xr + 32 * j) = ok ? make_float4(dy[j].x * x[j].x, dy[j].y * x[j].y, dy[j].z * x[j].z, dy[j].w * x[j].w)
+                                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __syncthreads();
+    {
+        const int c = tid & 127;
+        const float* src = tid < 128 ? Xs : Ts;
+        float acc = 0.f;
+#pragma unroll 8
+        for (int i = 0; i < TILE_M; ++i) acc += src[i * LDP + c];
+        if (tid < 128) p_lng[(size_t)blockIdx.x * D + c] = acc;
+        else p_lnb[(size_t)blockIdx.x * D + c] = acc;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -154,61 +154,32 @@ void launch_extract_index(const float* sl, const float* el, int64_t* si, int64_t
 }
 
 // =========================================================================================================
-// shared epilogue:  Ts (32 x 128 LDS tile, grad wrt a LayerNorm OUTPUT, dropout already applied)
-//   -> LayerNorm backward against the raw input rows `xin` -> (+ residual grad) -> out ; gamma/beta partial slabs.
-//   red: LDS scratch of 4 * 256 floats.
-// =========================================================================================================
-__device__ __forceinline__ void ln_bwd_rows(const float* Ts, const float* __restrict__ xin, const float* __restrict__ resid,
-                                            const float* __restrict__ extra, const float* __restrict__ ln_g,
-                                            float* __restrict__ out,
-                                            float* __restrict__ p_lng, float* __restrict__ p_lnb, float* red, int r0, int R) {
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    float ag0 = 0.f, ag1 = 0.f, ab0 = 0.f, ab1 = 0.f;
-    for (int rr = w; rr < TILE_M; rr += 4) {
-        const int r = r0 + rr;
-        if (r >= R) continue;                                    // wave-uniform
-        const float x0 = xin[(size_t)r * D + lane], x1 = xin[(size_t)r * D + lane + 64];
-        const float dy0 = Ts[rr * LDP + lane], dy1 = Ts[rr * LDP + lane + 64];
-        float dx0, dx1, xh0, xh1;
-        ln_row_bwd(x0, x1, dy0, dy1, ln_g, dx0, dx1, xh0, xh1);
-        ag0 += dy0 * xh0; ag1 += dy1 * xh1; ab0 += dy0; ab1 += dy1;
-        if (resid) { dx0 += resid[(size_t)r * D + lane]; dx1 += resid[(size_t)r * D + lane + 64]; }
-        if (extra) { dx0 += extra[(size_t)r * D + lane]; dx1 += extra[(size_t)r * D + lane + 64]; }
-        out[(size_t)r * D + lane] = dx0;
-        out[(size_t)r * D + lane + 64] = dx1;
-    }
-    __syncthreads();
-    red[w * 256 + lane] = ag0; red[w * 256 + 64 + lane] = ag1;
-    red[w * 256 + 128 + lane] = ab0; red[w * 256 + 192 + lane] = ab1;
-    __syncthreads();
-    {
-        const float v = red[tid] + red[256 + tid] + red[512 + tid] + red[768 + tid];
-        if (tid < 128) p_lng[(size_t)blockIdx.x * D + tid] = v;
-        else p_lnb[(size_t)blockIdx.x * D + tid - 128] = v;
-    }
-}
-
-// =========================================================================================================
 // heads backward (a14, :349-352): dlogit -> dz = dlogit * w1 * (hid > 0) -> [dLN(feat) | dx] = dz W0 ;
 //   LN backward -> dfeat.  blockIdx.y selects start / end.
 // =========================================================================================================
 __global__ __launch_bounds__(256) void k_head_bwd(HeadBwdArgs a0, HeadBwdArgs a1, int R) {
     __shared__ __attribute__((aligned(16))) float Gs[TILE_M * LDP];
     __shared__ __attribute__((aligned(16))) float Hs[TILE_M * LDP];
-    __shared__ float red[1024];
+    __shared__ __attribute__((aligned(16))) float Fs[TILE_M * LDP];
     __shared__ float dl[TILE_M];
     const HeadBwdArgs a = blockIdx.y == 0 ? a0 : a1;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int r0 = blockIdx.x * TILE_M;
+    BFrag<2, 8> bf;
+    bfrag_load(bf, a.W0Tpack, 2 * D, 32 * w, D, 0, D / 8);
     if (tid < TILE_M) dl[tid] = r0 + tid < R ? a.dlogit[r0 + tid] : 0.f;
     load_tile128(Hs, a.hid, r0, TILE_M, R);
+    load_tile128(Fs, a.feat, r0, TILE_M, R);
     __syncthreads();
-    for (int e = tid; e < TILE_M * D; e += 256) {
-        const int rr = e >> 7, c = e & 127;
-        const float hv = Hs[rr * LDP + c];
-        const float dz = hv > 0.f ? dl[rr] * a.w1[c] : 0.f;
-        Gs[rr * LDP + c] = dz;
-        if (r0 + rr < R) a.gz[(size_t)(r0 + rr) * D + c] = dz;
+    for (int e = tid; e < TILE_M * 32; e += 256) {
+        const int rr = e >> 5, c = (e & 31) * 4;
+        const float4 hv = *reinterpret_cast<const float4*>(&Hs[rr * LDP + c]);
+        const float4 wv = *reinterpret_cast<const float4*>(a.w1 + c);
+        const float d = dl[rr];
+        const float4 dz = make_float4(hv.x > 0.f ? d * wv.x : 0.f, hv.y > 0.f ? d * wv.y : 0.f, hv.z > 0.f ? d * wv.z : 0.f,
+                                      hv.w > 0.f ? d * wv.w : 0.f);
+        *reinterpret_cast<float4*>(&Gs[rr * LDP + c]) = dz;
+        if (r0 + rr < R) *reinterpret_cast<float4*>(a.gz + (size_t)(r0 + rr) * D + c) = dz;
     }
     __syncthreads();
     {   // bias / w1 partials: threads 0..127 -> db0[c], 128..255 -> dw1[c]
@@ -220,7 +191,7 @@ __global__ __launch_bounds__(256) void k_head_bwd(HeadBwdArgs a0, HeadBwdArgs a1
     }
     f32x16 acc[2];
     zero_acc(acc);
-    gemm32<2>(Gs, LDP, D, a.W0Tpack, 2 * D, 32 * w, D, acc);
+    gemm32p<2, 8>(Gs, LDP, D, a.W0Tpack, 2 * D, 32 * w, D, acc, bf);
     __syncthreads();                       // everyone is done reading Hs/Gs
     const int col = 32 * w + (lane & 31);
 #pragma unroll
@@ -231,7 +202,7 @@ __global__ __launch_bounds__(256) void k_head_bwd(HeadBwdArgs a0, HeadBwdArgs a1
     }
     __syncthreads();
     if (a.ln_g) {
-        ln_bwd_rows(Hs, a.feat, nullptr, nullptr, a.ln_g, a.dfeat, a.p_lng, a.p_lnb, red, r0, R);
+        ln_bwd_tile(Hs, Fs, nullptr, nullptr, a.ln_g, a.dfeat, a.p_lng, a.p_lnb, r0, R);
     } else {
         for (int e = tid; e < TILE_M * D; e += 256) {
             const int rr = e >> 7, c = e & 127;
@@ -248,8 +219,7 @@ void launch_head_bwd(const HeadBwdArgs& a0, const HeadBwdArgs& a1, int R, hipStr
 //   grid = (k tiles of 128, row chunks of WG_ROWS, job * 3 + G block); each workgroup writes one partial slab tile.
 // =========================================================================================================
 __global__ __launch_bounds__(256) void k_wgrad(WgradBatch wb) {
-    __shared__ __attribute__((aligned(16))) float Gs[TILE_M * LDP];
-    __shared__ __attribute__((aligned(16))) float As[TILE_M * LDP];
+    extern __shared__ __attribute__((aligned(16))) float smem[];    // 2 x (G tile | A tile), 32 x LDP each
     const int ji = blockIdx.z / 3, gb = blockIdx.z % 3;
     const WgradJob& j = wb.j[ji];
     const int kt = blockIdx.x, ch = blockIdx.y;
@@ -257,19 +227,23 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradBatch wb) {
     if (gb >= j.nG || kt * 128 >= K || ch * WG_ROWS >= R) return;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const float* G = j.G[gb];
+    const float* Ablk = j.nA > 0 ? j.A[kt] : nullptr;
     f32x16 acc[4];
     zero_acc(acc);
     float bsum = 0.f;
     const int rbeg = ch * WG_ROWS, rend = min(R, rbeg + WG_ROWS);
-    for (int rs = rbeg; rs < rend; rs += TILE_M) {
-        for (int e = tid; e < TILE_M * 32; e += 256) {
+    float4 gst[4], ast[4];
+    auto gload = [&](int rs) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + q * 256;
             const int rr = e >> 5, c = (e & 31) * 4;
             const int r = rs + rr;
             float4 gv = make_float4(0.f, 0.f, 0.f, 0.f), av = gv;
             if (r < rend) {
                 gv = *reinterpret_cast<const float4*>(G + (size_t)r * D + c);
-                if (j.nA > 0) {
-                    av = *reinterpret_cast<const float4*>(j.A[kt] + (size_t)r * D + c);
+                if (Ablk) {
+                    av = *reinterpret_cast<const float4*>(Ablk + (size_t)r * D + c);
                 } else if (kt * 128 + c < K) {
                     const size_t off = (size_t)r * K + kt * 128 + c;
                     av = *reinterpret_cast<const float4*>(j.Afull + off);
@@ -280,15 +254,34 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradBatch wb) {
                     }
                 }
             }
-            *reinterpret_cast<float4*>(&Gs[rr * LDP + c]) = gv;
-            *reinterpret_cast<float4*>(&As[rr * LDP + c]) = av;
+            gst[q] = gv; ast[q] = av;
         }
-        __syncthreads();
+    };
+    auto sstore = [&](int buf) {
+        float* Gs = smem + buf * 2 * TILE_M * LDP;
+        float* As = Gs + TILE_M * LDP;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + q * 256;
+            *reinterpret_cast<float4*>(&Gs[(e >> 5) * LDP + (e & 31) * 4]) = gst[q];
+            *reinterpret_cast<float4*>(&As[(e >> 5) * LDP + (e & 31) * 4]) = ast[q];
+        }
+    };
+    gload(rbeg);
+    sstore(0);
+    __syncthreads();
+    int buf = 0;
+    for (int rs = rbeg; rs < rend; rs += TILE_M, buf ^= 1) {
+        const bool more = rs + TILE_M < rend;
+        if (more) gload(rs + TILE_M);                    // next tile in flight while the MFMAs run
+        const float* Gs = smem + buf * 2 * TILE_M * LDP;
+        const float* As = Gs + TILE_M * LDP;
         gemm_tn<4>(Gs, LDP, 32 * w, As, LDP, 0, TILE_M, acc);
         if (kt == 0 && tid < 128) {
 #pragma unroll 8
             for (int rr = 0; rr < TILE_M; ++rr) bsum += Gs[rr * LDP + tid];
         }
+        if (more) sstore(buf ^ 1);
         __syncthreads();
     }
     const int N = 128 * j.nG;
@@ -312,7 +305,10 @@ void launch_wgrad(const WgradBatch& wb, hipStream_t s) {
         kt = max(kt, (wb.j[i].K + 127) / 128);
         ch = max(ch, (wb.j[i].R + WG_ROWS - 1) / WG_ROWS);
     }
-    hipLaunchKernelGGL(k_wgrad, dim3(kt, ch, wb.n * 3), dim3(256), 0, s, wb);
+    const size_t shm = (size_t)4 * TILE_M * LDP * sizeof(float);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)k_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr = true; }
+    hipLaunchKernelGGL(k_wgrad, dim3(kt, ch, wb.n * 3), dim3(256), shm, s, wb);
 }
 
 // =========================================================================================================
@@ -326,6 +322,8 @@ __global__ __launch_bounds__(256) void k_conv_bwd_gemm(const float* __restrict__
     __shared__ __attribute__((aligned(16))) float Gs[TILE_M * LDP];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int r0 = blockIdx.x * TILE_M;
+    BFrag<1, 16> bf;
+    bfrag_load(bf, WTpack, D, 32 * w, 0, 0, D / 8);
     for (int e = tid; e < TILE_M * 32; e += 256) {
         const int rr = e >> 5, c = (e & 31) * 4;
         const int r = r0 + rr;
@@ -345,7 +343,7 @@ __global__ __launch_bounds__(256) void k_conv_bwd_gemm(const float* __restrict__
     __syncthreads();
     f32x16 acc[1];
     zero_acc(acc);
-    gemm32<1>(Gs, LDP, D, WTpack, D, 32 * w, 0, acc);
+    gemm32p<1, 16>(Gs, LDP, D, WTpack, D, 32 * w, 0, acc, bf);
     const int col = 32 * w + (lane & 31);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -362,59 +360,69 @@ __global__ __launch_bounds__(256) void k_conv_bwd_dwln(const float* __restrict__
                                                        const float* __restrict__ dy, const float* __restrict__ ln_g,
                                                        const float* __restrict__ ln_b, const float* __restrict__ dw_w,
                                                        const float* __restrict__ extra, float* __restrict__ dx,
-                                                       float* __restrict__ p_lng,
-                                                       float* __restrict__ p_lnb, float* __restrict__ p_dw, int R, int L) {
+                                                       float* __restrict__ p_lng, float* __restrict__ p_lnb,
+                                                       float* __restrict__ p_dw, int R, int L) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NH = TILE_M + 2 * HALO;
+    constexpr int NW = 16 + 2 * HALO;
     float* DUs = smem;                       // [38][LDP] du with halo
     float* Vs = DUs + NH * LDP;              // [38][LDP] LN(x') with halo (forward recompute)
     float* Ts = Vs + NH * LDP;               // [32][LDP] dv = grad wrt LN output
-    float* red = Ts + TILE_M * LDP;          // [1024]
-    const int tid = threadIdx.x, w = tid >> 6;
+    float* Xc = Ts + TILE_M * LDP;           // [32][LDP] raw x' of the centre rows
+    float* red = Xc + TILE_M * LDP;          // [2][896]
+    const int tid = threadIdx.x;
     const int r0 = blockIdx.x * TILE_M;
     load_tile128(DUs, du, r0 - HALO, NH, R);
-    load_tile128(Vs, xin, r0 - HALO, NH, R);
-    __syncthreads();
-    for (int rr = w; rr < NH; rr += 4) {
-        float mu, rs;
-        ln_row_inplace(Vs + rr * LDP, ln_g, ln_b, mu, rs);
+    for (int e = tid; e < NH * 32; e += 256) {
+        const int rr = e >> 5, c = (e & 31) * 4;
+        const int r = r0 - HALO + rr;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r >= 0 && r < R) v = *reinterpret_cast<const float4*>(xin + (size_t)r * D + c);
+        *reinterpret_cast<float4*>(&Vs[rr * LDP + c]) = v;
+        if (rr >= HALO && rr < HALO + TILE_M) *reinterpret_cast<float4*>(&Xc[(rr - HALO) * LDP + c]) = v;
     }
+    __syncthreads();
+    ln_tile(Vs, NH, LDP, ln_g, ln_b, Drop{0u, 0u, 1.f}, 0);
     __syncthreads();
     {
         const int c = tid & 127, hb = (tid >> 7) * 16;
-        float wk[DWK], gw[DWK];
+        float wk[DWK], gw[DWK], dwin[NW], vwin[NW];
+        int sid[NW];
 #pragma unroll
         for (int k = 0; k < DWK; ++k) { wk[k] = dw_w[c * DWK + k]; gw[k] = 0.f; }
-        for (int rr = hb; rr < hb + 16; ++rr) {
-            const int r = r0 + rr;
-            const int t = r % L;
+        int rg = r0 - HALO + hb;
+        int sm = rg >= 0 ? rg / L : -1, tt = rg >= 0 ? rg - sm * L : L + rg;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            dwin[i] = DUs[(hb + i) * LDP + c];
+            vwin[i] = Vs[(hb + i) * LDP + c];
+            sid[i] = (rg + i < R) ? sm : -2;
+            if (++tt == L) { tt = 0; ++sm; }
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            // forward: u[t] += w[k] v[t + k - 3]  =>  dv[t] += w[k] du[t - k + 3] ; dw[k] += du[t] v[t + k - 3]
             float dv = 0.f;
-            const float duc = r < R ? DUs[(rr + HALO) * LDP + c] : 0.f;
 #pragma unroll
             for (int k = 0; k < DWK; ++k) {
-                // forward: u[t] += w[k] v[t + k - 3]  =>  dv[t] += w[k] du[t - k + 3] ; dw[k] += du[t] v[t + k - 3]
-                const int ts = t - k + HALO;
-                if (ts >= 0 && ts < L) dv += wk[k] * DUs[(rr + 2 * HALO - k) * LDP + c];
-                const int tv = t + k - HALO;
-                if (tv >= 0 && tv < L) gw[k] += duc * Vs[(rr + k) * LDP + c];
+                dv += (sid[q + 2 * HALO - k] == sid[q + HALO]) ? wk[k] * dwin[q + 2 * HALO - k] : 0.f;
+                gw[k] += (sid[q + k] == sid[q + HALO]) ? dwin[q + HALO] * vwin[q + k] : 0.f;
             }
-            Ts[rr * LDP + c] = dv;
+            Ts[(hb + q) * LDP + c] = dv;
         }
-        // combine the two row halves of each channel, then write the depthwise-tap partial slab [tile][128*7]
 #pragma unroll
         for (int k = 0; k < DWK; ++k) red[(tid >> 7) * 896 + c * DWK + k] = gw[k];
     }
     __syncthreads();
     for (int e = tid; e < D * DWK; e += 256) p_dw[(size_t)blockIdx.x * D * DWK + e] = red[e] + red[896 + e];
-    __syncthreads();
-    ln_bwd_rows(Ts, xin, dy, extra, ln_g, dx, p_lng, p_lnb, red, r0, R);
+    ln_bwd_tile(Ts, Xc, dy, extra, ln_g, dx, p_lng, p_lnb, r0, R);
 }
 void launch_conv_bwd_dwln(const float* du, const float* xin, const float* dy, const float* ln_g, const float* ln_b,
                           const float* dw_w, const float* extra, float* dx, float* p_lng, float* p_lnb, float* p_dw,
                           int R, int L, hipStream_t s) {
-    const size_t shm = (size_t)((2 * (TILE_M + 2 * HALO) + TILE_M) * LDP + 1792) * sizeof(float);
+    const size_t shm = (size_t)((2 * (TILE_M + 2 * HALO) + 2 * TILE_M) * LDP + 1792) * sizeof(float);
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k_conv_bwd_dwln, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr = true; }
+    if (!attr) { (void)hipFuncSetAttribute((const void*)k_conv_bwd_dwln, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); attr = true; }
     hipLaunchKernelGGL(k_conv_bwd_dwln, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm, s, du, xin, dy, ln_g, ln_b, dw_w, extra,
                        dx, p_lng, p_lnb, p_dw, R, L);
 }
@@ -425,34 +433,38 @@ void launch_conv_bwd_dwln(const float* du, const float* xin, const float* dy, co
 //  k_attn_bwd_dq / k_attn_bwd_dkv : attention core (recompute P from Q, K and the saved LSE)
 //  k_qkv_bwd      : dh1 = [dQ|dK|dV] [Wq;Wk;Wv] ; dx = dr + LN1^T(dh1 * m1)
 // =========================================================================================================
-__global__ __launch_bounds__(256) void k_attn_out_bwd(const float* __restrict__ dy, const float* __restrict__ r_in,
-                                                      const float* __restrict__ ln_g, const float* __restrict__ WTpack,
-                                                      float* __restrict__ g_o, float* __restrict__ dr,
-                                                      float* __restrict__ p_lng, float* __restrict__ p_lnb, int R, Drop d4,
-                                                      Drop d5) {
+__global__ __launch_bounds__(256) void k_attn_out_bwd(const float* __restrict__ dy, const float* __restrict__ dy2,
+                                                      const float* __restrict__ r_in, const float* __restrict__ ln_g,
+                                                      const float* __restrict__ WTpack, float* __restrict__ g_o,
+                                                      float* __restrict__ dr, float* __restrict__ p_lng,
+                                                      float* __restrict__ p_lnb, int R, Drop d4, Drop d5) {
     __shared__ __attribute__((aligned(16))) float Gs[TILE_M * LDP];
-    __shared__ float red[1024];
+    __shared__ __attribute__((aligned(16))) float Xs[TILE_M * LDP];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int r0 = blockIdx.x * TILE_M;
+    BFrag<1, 16> bf;
+    bfrag_load(bf, WTpack, D, 32 * w, 0, 0, D / 8);
+    load_tile128(Xs, r_in, r0, TILE_M, R);
     for (int e = tid; e < TILE_M * 32; e += 256) {
         const int rr = e >> 5, c = (e & 31) * 4;
         const int r = r0 + rr;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r < R) {
             v = *reinterpret_cast<const float4*>(dy + (size_t)r * D + c);
+            if (dy2) { const float4 t = *reinterpret_cast<const float4*>(dy2 + (size_t)r * D + c); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
             if (d5.thresh) {
                 const uint32_t base = (uint32_t)(r * D + c);
                 v.x *= drop_mul(d5, base); v.y *= drop_mul(d5, base + 1);
                 v.z *= drop_mul(d5, base + 2); v.w *= drop_mul(d5, base + 3);
             }
-            if (g_o) *reinterpret_cast<float4*>(g_o + (size_t)r * D + c) = v;
+            *reinterpret_cast<float4*>(g_o + (size_t)r * D + c) = v;       // G operand of the out_layer weight gradient
         }
         *reinterpret_cast<float4*>(&Gs[rr * LDP + c]) = v;
     }
     __syncthreads();
     f32x16 acc[1];
     zero_acc(acc);
-    gemm32<1>(Gs, LDP, D, WTpack, D, 32 * w, 0, acc);
+    gemm32p<1, 16>(Gs, LDP, D, WTpack, D, 32 * w, 0, acc, bf);
     __syncthreads();
     const int col = 32 * w + (lane & 31);
 #pragma unroll
@@ -461,11 +473,11 @@ __global__ __launch_bounds__(256) void k_attn_out_bwd(const float* __restrict__ 
         Gs[row * LDP + col] = acc[0][r] * drop_mul(d4, (uint32_t)((r0 + row) * D + col));
     }
     __syncthreads();
-    ln_bwd_rows(Gs, r_in, dy, nullptr, ln_g, dr, p_lng, p_lnb, red, r0, R);
+    ln_bwd_tile(Gs, Xs, dy, dy2, ln_g, dr, p_lng, p_lnb, r0, R);
 }
-void launch_attn_out_bwd(const float* dy, const float* r, const float* ln_g, const float* WTpack, float* g_o, float* dr,
-                         float* p_lng, float* p_lnb, int R, Drop d4, Drop d5, hipStream_t s) {
-    hipLaunchKernelGGL(k_attn_out_bwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), 0, s, dy, r, ln_g, WTpack, g_o, dr, p_lng,
+void launch_attn_out_bwd(const float* dy, const float* dy2, const float* r, const float* ln_g, const float* WTpack, float* g_o,
+                         float* dr, float* p_lng, float* p_lnb, int R, Drop d4, Drop d5, hipStream_t s) {
+    hipLaunchKernelGGL(k_attn_out_bwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), 0, s, dy, dy2, r, ln_g, WTpack, g_o, dr, p_lng,
                        p_lnb, R, d4, d5);
 }
 
@@ -650,9 +662,12 @@ __global__ __launch_bounds__(256) void k_qkv_bwd(const float* __restrict__ dQ, c
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                         // [32][QKVP] = [dQ | dK | dV]
     float* Ts = As + TILE_M * QKVP;           // [32][LDP]
-    float* red = Ts + TILE_M * LDP;           // [1024]
+    float* Xs = Ts + TILE_M * LDP;            // [32][LDP] raw LN1 input
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int r0 = blockIdx.x * TILE_M;
+    BFrag<1, 16> bf;
+    bfrag_load(bf, WTpack, D, 32 * w, 0, 0, 3 * D / 8);
+    load_tile128(Xs, x, r0, TILE_M, R);
     for (int e = tid; e < TILE_M * 32; e += 256) {
         const int rr = e >> 5, c = (e & 31) * 4;
         const int r = r0 + rr;
@@ -669,7 +684,7 @@ __global__ __launch_bounds__(256) void k_qkv_bwd(const float* __restrict__ dQ, c
     __syncthreads();
     f32x16 acc[1];
     zero_acc(acc);
-    gemm32<1>(As, QKVP, 3 * D, WTpack, D, 32 * w, 0, acc);
+    gemm32p<1, 16>(As, QKVP, 3 * D, WTpack, D, 32 * w, 0, acc, bf);
     const int col = 32 * w + (lane & 31);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -677,34 +692,16 @@ __global__ __launch_bounds__(256) void k_qkv_bwd(const float* __restrict__ dQ, c
         Ts[row * LDP + col] = acc[0][r] * drop_mul(d1, (uint32_t)((r0 + row) * D + col));
     }
     __syncthreads();
-    ln_bwd_rows(Ts, x, dr, nullptr, ln_g, dx, p_lng, p_lnb, red, r0, R);
+    ln_bwd_tile(Ts, Xs, dr, nullptr, ln_g, dx, p_lng, p_lnb, r0, R);
 }
 void launch_qkv_bwd(const float* dQ, const float* dK, const float* dV, const float* x, const float* dr,
                     const float* ln_g, const float* WTpack, float* dx, float* p_lng, float* p_lnb, int R, Drop d1,
                     hipStream_t s) {
-    const size_t shm = (size_t)(TILE_M * QKVP + TILE_M * LDP + 1024) * sizeof(float);
+    const size_t shm = (size_t)(TILE_M * QKVP + 2 * TILE_M * LDP) * sizeof(float);
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)k_qkv_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr = true; }
     hipLaunchKernelGGL(k_qkv_bwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm, s, dQ, dK, dV, x, dr, ln_g, WTpack, dx, p_lng,
                        p_lnb, R, d1);
-}
-
-// positional-embedding gradient (a6, :202): dpos[t] = sum_b dx0[b, t] ; rows >= L of the table get zero
-__global__ __launch_bounds__(256) void k_pos_grad(const float* __restrict__ dx0, const float* __restrict__ extra,
-                                                  float* __restrict__ out, int B, int L, int max_pos) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= max_pos * D) return;
-    const int t = e >> 7, c = e & 127;
-    float acc = 0.f;
-    if (t < L)
-        for (int b = 0; b < B; ++b) {
-            const size_t o = ((size_t)b * L + t) * D + c;
-            acc += extra ? dx0[o] - extra[o] : dx0[o];     // `extra` was folded into dx0 but is not a grad of x + pos
-        }
-    out[e] = acc;
-}
-void launch_pos_grad(const float* dx0, const float* extra, float* out, int B, int L, int max_pos, hipStream_t s) {
-    hipLaunchKernelGGL(k_pos_grad, dim3((max_pos * D + 255) / 256), dim3(256), 0, s, dx0, extra, out, B, L, max_pos);
 }
 
 // =========================================================================================================
@@ -736,18 +733,33 @@ __global__ __launch_bounds__(256) void k_cqcat_bwd(const float* __restrict__ dg0
         *reinterpret_cast<float4*>(&Fs[rr * LDP + c]) = f;
     }
     __syncthreads();
-    for (int rr = w; rr < TILE_M; rr += 4) {
+    {
+        const int rr = tid >> 3, sub = tid & 7;
         const int r = r0 + rr;
-        const float d = wave_sum(Gs[rr * LDP + lane] * Fs[rr * LDP + lane] + Gs[rr * LDP + lane + 64] * Fs[rr * LDP + lane + 64]);
+        float* grow = Gs + rr * LDP + sub * 4;
+        const float* frow = Fs + rr * LDP + sub * 4;
+        float4 g4[4];
+        float d = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            g4[j] = *reinterpret_cast<const float4*>(grow + 32 * j);
+            const float4 f4 = *reinterpret_cast<const float4*>(frow + 32 * j);
+            d += g4[j].x * f4.x + g4[j].y * f4.y + g4[j].z * f4.z + g4[j].w * f4.w;
+        }
+        d = grp8_sum(d);
         float hv = 0.f, dl = 0.f;
         if (r < R) {
             hv = hscore[r];
             dl = (d + (dh_loss ? dh_loss[r] : 0.f)) * hv * (1.f - hv);      // sigmoid backward; mask_logits is additive
         }
         // df2 = dgated * h + dlogit * wh
-        Gs[rr * LDP + lane] = Gs[rr * LDP + lane] * hv + dl * wh[lane];
-        Gs[rr * LDP + lane + 64] = Gs[rr * LDP + lane + 64] * hv + dl * wh[lane + 64];
-        if (lane == 0) dlg[rr] = dl;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 wv = *reinterpret_cast<const float4*>(wh + sub * 4 + 32 * j);
+            *reinterpret_cast<float4*>(grow + 32 * j) = make_float4(g4[j].x * hv + dl * wv.x, g4[j].y * hv + dl * wv.y,
+                                                                    g4[j].z * hv + dl * wv.z, g4[j].w * hv + dl * wv.w);
+        }
+        if (sub == 0) dlg[rr] = dl;
     }
     __syncthreads();
     if (tid < 128) {
@@ -765,7 +777,11 @@ __global__ __launch_bounds__(256) void k_cqcat_bwd(const float* __restrict__ dg0
     }
     f32x16 acc[1];
     zero_acc(acc);
-    gemm32<1>(Gs, LDP, D, W1Tpack, D, 32 * w, 0, acc);
+    {
+        BFrag<1, 16> bf;
+        bfrag_load(bf, W1Tpack, D, 32 * w, 0, 0, D / 8);
+        gemm32p<1, 16>(Gs, LDP, D, W1Tpack, D, 32 * w, 0, acc, bf);
+    }
     const int col = 32 * w + (lane & 31);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -802,7 +818,11 @@ __global__ __launch_bounds__(256) void k_cq_out_bwd(const float* __restrict__ df
     __syncthreads();
     f32x16 acc[4];
     zero_acc(acc);
-    gemm32<4>(Gs, LDP, D, WTpack, 4 * D, 32 * w, D, acc);
+    {
+        BFrag<4, 4> bf;
+        bfrag_load(bf, WTpack, 4 * D, 32 * w, D, 0, D / 8);
+        gemm32p<4, 4>(Gs, LDP, D, WTpack, 4 * D, 32 * w, D, acc, bf);
+    }
     const int col = 32 * w + (lane & 31);
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -1102,7 +1122,11 @@ __global__ __launch_bounds__(256) void k_linear_bwd_data(const float* __restrict
     for (int cb = 0; cb < K; cb += 512) {
         f32x16 acc[4];
         zero_acc(acc);
-        gemm32<4>(Gs, LDP, D, WTpack, K, cb + 32 * w, D, acc);
+        {
+            BFrag<4, 4> bf;
+            bfrag_load(bf, WTpack, K, cb + 32 * w, D, 0, D / 8);
+            gemm32p<4, 4>(Gs, LDP, D, WTpack, K, cb + 32 * w, D, acc, bf);
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int col = cb + 32 * w + t * D + (lane & 31);
@@ -1122,35 +1146,53 @@ void launch_linear_bwd_data(const float* G, const float* WTpack, float* dA, int 
 
 // =========================================================================================================
 // a3 / a4 backward: unk_vec gradient, char-CNN weights / biases, char table (padding_idx = 0 gets none).
-//   one workgroup per EMB_CHUNK query words; partial slabs per workgroup.
+//   one workgroup per EMB_CHUNK query words; the 15000 conv weights live in LDS; partial slabs per workgroup.
 // =========================================================================================================
-__global__ __launch_bounds__(256) void k_embed_bwd(const float* __restrict__ dE, const int64_t* __restrict__ char_ids,
-                                                   const float* __restrict__ E, const int8_t* __restrict__ argpos,
-                                                   const float* __restrict__ char_tab, CharConvPtrs cc,
-                                                   float* __restrict__ p_cw, float* __restrict__ p_cb,
-                                                   float* __restrict__ p_tab, int Rq, int Lc, int word_dim, int char_dim,
-                                                   int char_size, Drop dc) {
+__global__ __launch_bounds__(256) void k_embed_bwd(const float* __restrict__ dE, const int64_t* __restrict__ word_ids,
+                                                   const int64_t* __restrict__ char_ids, const float* __restrict__ E,
+                                                   const int8_t* __restrict__ argpos, const float* __restrict__ char_tab,
+                                                   CharConvPtrs cc, float* __restrict__ p_cw, float* __restrict__ p_cb,
+                                                   float* __restrict__ p_tab, float* __restrict__ p_unk, int Rq, int Lc,
+                                                   int word_dim, int char_dim, int char_size, Drop dw, Drop dc) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Ce = smem;                         // [MAX_LC][64] dropped char embeddings of the current word
-    float* dCe = Ce + MAX_LC * 64;            // [MAX_LC][64] grad wrt them
-    float* gch = dCe + MAX_LC * 64;           // [100] grad of the 100 char features (0 where relu/max inactive)
+    const int wtot = char_dim * 300;          // 10*1 + 20*2 + 30*3 + 40*4 = 300 taps per input channel
+    float* Wl = smem;                         // [wtot] conv weights, flattened conv0 | conv1 | conv2 | conv3
+    float* Ce = Wl + ((wtot + 3) & ~3);       // [MAX_LC][64] dropped char embeddings of the current word
+    float* gch = Ce + MAX_LC * 64;            // [128] grad of the 100 char features (0 where relu/max inactive)
     float* tab = gch + 128;                   // [char_size][char_dim] table-gradient accumulator
     __shared__ int pos[128];
+    __shared__ int obase[128];                // LDS offset of channel oc's weights
+    __shared__ int okk[128];                  // kernel width of channel oc
     __shared__ int cids[MAX_LC];
     const int tid = threadIdx.x;
     const int EW = word_dim + 100;
-    const int wtot = char_dim * 300;          // 10*1 + 20*2 + 30*3 + 40*4 = 300 taps per input channel
-    // this thread's slice of the flattened conv weights: element e -> (conv, ch, ci, kk)
+    {   // stage the weights + the per-channel tables
+        const int s0 = 10 * char_dim, s1 = 20 * char_dim * 2, s2 = 30 * char_dim * 3;
+        for (int e = tid; e < wtot; e += 256) {
+            float v;
+            if (e < s0) v = cc.w[0][e]; else if (e < s0 + s1) v = cc.w[1][e - s0];
+            else if (e < s0 + s1 + s2) v = cc.w[2][e - s0 - s1]; else v = cc.w[3][e - s0 - s1 - s2];
+            Wl[e] = v;
+        }
+        if (tid < 100) {
+            int k, ch, base;
+            if (tid < 10) { k = 1; ch = tid; base = 0; } else if (tid < 30) { k = 2; ch = tid - 10; base = s0; }
+            else if (tid < 60) { k = 3; ch = tid - 30; base = s0 + s1; } else { k = 4; ch = tid - 60; base = s0 + s1 + s2; }
+            okk[tid] = k;
+            obase[tid] = base + ch * char_dim * k;
+        }
+        for (int e = tid; e < char_size * char_dim; e += 256) tab[e] = 0.f;
+    }
+    // this thread's slice of the flattened conv weights: element e -> (oc, ci, kk)
     constexpr int MAXE = 64;                  // ceil(15000 / 256) = 59
     float wacc[MAXE];
-    int wcode[MAXE];                          // (oc << 16) | (ci << 8) | kk of this thread's q-th weight element
+    int wcode[MAXE];
 #pragma unroll
     for (int q = 0; q < MAXE; ++q) {
         wacc[q] = 0.f;
         const int e = tid + q * 256;
         int oc = 0, ci = 0, kk = 0;
         if (e < wtot) {
-            // flattened order: conv0 (10, cd, 1), conv1 (20, cd, 2), conv2 (30, cd, 3), conv3 (40, cd, 4)
             int rem = e;
             const int s0 = 10 * char_dim, s1 = 20 * char_dim * 2, s2 = 30 * char_dim * 3;
             if (rem < s0) { oc = rem / char_dim; ci = rem % char_dim; kk = 0; }
@@ -1160,8 +1202,7 @@ __global__ __launch_bounds__(256) void k_embed_bwd(const float* __restrict__ dE,
         }
         wcode[q] = (oc << 16) | (ci << 8) | kk;
     }
-    float bacc = 0.f;
-    for (int e = tid; e < char_size * char_dim; e += 256) tab[e] = 0.f;
+    float bacc = 0.f, uacc0 = 0.f, uacc1 = 0.f;
     const int rbeg = blockIdx.x * EMB_CHUNK, rend = min(Rq, rbeg + EMB_CHUNK);
     for (int r = rbeg; r < rend; ++r) {
         __syncthreads();
@@ -1171,43 +1212,38 @@ __global__ __launch_bounds__(256) void k_embed_bwd(const float* __restrict__ dE,
             gch[tid] = v > 0.f ? dE[(size_t)r * EW + word_dim + tid] : 0.f;     // relu + max: grad only to an active arg-max
             pos[tid] = argpos[(size_t)r * 100 + tid];
         }
+        if (word_ids[r] == 1) {               // unk_vec row of the [pad; unk; glove] table (:41)
+            if (tid < word_dim) uacc0 += dE[(size_t)r * EW + tid] * drop_mul(dw, (uint32_t)(r * word_dim + tid));
+            if (tid + 256 < word_dim) uacc1 += dE[(size_t)r * EW + tid + 256] * drop_mul(dw, (uint32_t)(r * word_dim + tid + 256));
+        }
         __syncthreads();
         for (int e = tid; e < Lc * char_dim; e += 256) {
             const int p = e / char_dim, ci = e - p * char_dim;
             Ce[p * 64 + ci] = char_tab[(size_t)cids[p] * char_dim + ci] * drop_mul(dc, (uint32_t)((r * Lc + p) * char_dim + ci));
-            dCe[p * 64 + ci] = 0.f;
         }
         __syncthreads();
         if (tid < 100) bacc += gch[tid];
         // weight grads: dW[oc][ci][kk] += g[oc] * Ce[pos[oc] + kk][ci]
 #pragma unroll
         for (int q = 0; q < MAXE; ++q) {
-            const int e = tid + q * 256;
-            if (e < wtot) {
+            if (tid + q * 256 < wtot) {
                 const int oc = wcode[q] >> 16, ci = (wcode[q] >> 8) & 255, kk = wcode[q] & 255;
                 wacc[q] += gch[oc] * Ce[(pos[oc] + kk) * 64 + ci];
             }
         }
-        // dCe[p][ci] = sum_{oc, kk : pos[oc] + kk == p} g[oc] W[oc][ci][kk]   (thread = (p, ci))
+        // dCe[p][ci] = sum_{oc, kk : pos[oc] + kk == p} g[oc] W[oc][ci][kk] ; scattered straight into the table
+        // accumulator (thread = (p, ci); two positions of one word may hold the same character -> LDS atomics)
         for (int e = tid; e < Lc * char_dim; e += 256) {
             const int p = e / char_dim, ci = e - p * char_dim;
+            if (cids[p] == 0) continue;       // padding_idx = 0 (:51)
             float acc = 0.f;
             for (int oc = 0; oc < 100; ++oc) {
                 const float g = gch[oc];
-                if (g == 0.f) continue;
-                int conv, ch, k;
-                if (oc < 10) { conv = 0; ch = oc; k = 1; } else if (oc < 30) { conv = 1; ch = oc - 10; k = 2; }
-                else if (oc < 60) { conv = 2; ch = oc - 30; k = 3; } else { conv = 3; ch = oc - 60; k = 4; }
-                const int kk = p - pos[oc];
-                if (kk >= 0 && kk < k) acc += g * cc.w[conv][((size_t)ch * char_dim + ci) * k + kk];
+                const int kk = p - pos[oc], k = okk[oc];
+                if (g != 0.f && kk >= 0 && kk < k) acc += g * Wl[obase[oc] + ci * k + kk];
             }
-            dCe[p * 64 + ci] = acc * drop_mul(dc, (uint32_t)((r * Lc + p) * char_dim + ci));
+            atomicAdd(&tab[cids[p] * char_dim + ci], acc * drop_mul(dc, (uint32_t)((r * Lc + p) * char_dim + ci)));
         }
-        __syncthreads();
-        // scatter into the table accumulator; thread owns channel ci for all positions -> no intra-word races
-        if (tid < char_dim)
-            for (int p = 0; p < Lc; ++p)
-                if (cids[p] != 0) tab[cids[p] * char_dim + tid] += dCe[p * 64 + tid];
     }
     __syncthreads();
 #pragma unroll
@@ -1216,44 +1252,63 @@ __global__ __launch_bounds__(256) void k_embed_bwd(const float* __restrict__ dE,
         if (e < wtot) p_cw[(size_t)blockIdx.x * wtot + e] = wacc[q];
     }
     if (tid < 100) p_cb[(size_t)blockIdx.x * 100 + tid] = bacc;
+    if (tid < word_dim) p_unk[(size_t)blockIdx.x * word_dim + tid] = uacc0;
+    if (tid + 256 < word_dim) p_unk[(size_t)blockIdx.x * word_dim + tid + 256] = uacc1;
     for (int e = tid; e < char_size * char_dim; e += 256) p_tab[(size_t)blockIdx.x * char_size * char_dim + e] = tab[e];
-}
-// unk_vec gradient (:31-33, 41): sum over the words whose id == 1 of the (dropped-out) word-embedding gradient
-__global__ __launch_bounds__(256) void k_unk_grad(const float* __restrict__ dE, const int64_t* __restrict__ word_ids,
-                                                  float* __restrict__ g_unk, int Rq, int word_dim, Drop dw) {
-    const int EW = word_dim + 100;
-    for (int c = threadIdx.x; c < word_dim; c += 256) {
-        float acc = 0.f;
-        for (int r = 0; r < Rq; ++r)
-            if (word_ids[r] == 1) acc += dE[(size_t)r * EW + c] * drop_mul(dw, (uint32_t)(r * word_dim + c));
-        g_unk[c] = acc;
-    }
 }
 void launch_embed_bwd(const float* dE, const int64_t* word_ids, const int64_t* char_ids, const float* E,
                       const int8_t* argpos, const float* char_tab, CharConvPtrs cc, float* p_cw, float* p_cb, float* p_tab,
-                      float* g_unk, int Rq, int Lc, int word_dim, int char_dim, int char_size, Drop dw, Drop dc,
+                      float* p_unk, int Rq, int Lc, int word_dim, int char_dim, int char_size, Drop dw, Drop dc,
                       hipStream_t s) {
-    const size_t shm = (size_t)(2 * MAX_LC * 64 + 128 + char_size * char_dim) * sizeof(float);
-    hipLaunchKernelGGL(k_embed_bwd, dim3((Rq + EMB_CHUNK - 1) / EMB_CHUNK), dim3(256), shm, s, dE, char_ids, E, argpos, char_tab,
-                       cc, p_cw, p_cb, p_tab, Rq, Lc, word_dim, char_dim, char_size, dc);
-    hipLaunchKernelGGL(k_unk_grad, dim3(1), dim3(256), 0, s, dE, word_ids, g_unk, Rq, word_dim, dw);
+    const size_t shm = (size_t)(((char_dim * 300 + 3) & ~3) + MAX_LC * 64 + 128 + char_size * char_dim) * sizeof(float);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)k_embed_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    hipLaunchKernelGGL(k_embed_bwd, dim3((Rq + EMB_CHUNK - 1) / EMB_CHUNK), dim3(256), shm, s, dE, word_ids, char_ids, E, argpos,
+                       char_tab, cc, p_cw, p_cb, p_tab, p_unk, Rq, Lc, word_dim, char_dim, char_size, dw, dc);
 }
 
 // =========================================================================================================
 // final reduction of all partial slabs into the flat gradient bucket
 // =========================================================================================================
-__global__ __launch_bounds__(256) void k_reduce(const float* __restrict__ partial, float* __restrict__ grads,
+__global__ __launch_bounds__(256) void k_reduce(const float* __restrict__ ws, float* __restrict__ grads,
                                                 const ReduceSeg* __restrict__ segs, const int* __restrict__ blk2seg) {
     const int si = blk2seg[2 * blockIdx.x], off = blk2seg[2 * blockIdx.x + 1];
-    const ReduceSeg sg = segs[si];
-    const int i = off + threadIdx.x;
-    if (i >= sg.n) return;
-    float acc = 0.f;
-    for (int q = 0; q < sg.nsrc; ++q) {
-        const float* p = partial + sg.src[q] + i;
-        for (int s = 0; s < sg.nslabs[q]; ++s) acc += p[(size_t)s * sg.ss[q]];
+    const ReduceSeg* __restrict__ sgp = segs + si;
+    const int n = sgp->n, nsrc = sgp->nsrc, rl = sgp->rl, ds = sgp->ds, dst = sgp->dst;
+    const int i = off + threadIdx.x * 4;
+    if (i >= n) return;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (sgp->vec) {
+        for (int q = 0; q < nsrc; ++q) {
+            if (i >= sgp->vn[q]) continue;                         // this source covers only the first vn elements
+            const float* p = ws + sgp->src[q] + i;
+            const size_t ss = (size_t)sgp->ss[q];
+            int s = 0;
+            for (; s + 4 <= sgp->nslabs[q]; s += 4) {              // 4 independent 16-byte loads in flight
+                const float4 a = *reinterpret_cast<const float4*>(p + (size_t)s * ss);
+                const float4 b = *reinterpret_cast<const float4*>(p + (size_t)(s + 1) * ss);
+                const float4 c = *reinterpret_cast<const float4*>(p + (size_t)(s + 2) * ss);
+                const float4 d = *reinterpret_cast<const float4*>(p + (size_t)(s + 3) * ss);
+                acc.x += (a.x + b.x) + (c.x + d.x); acc.y += (a.y + b.y) + (c.y + d.y);
+                acc.z += (a.z + b.z) + (c.z + d.z); acc.w += (a.w + b.w) + (c.w + d.w);
+            }
+            for (; s < sgp->nslabs[q]; ++s) {
+                const float4 a = *reinterpret_cast<const float4*>(p + (size_t)s * ss);
+                acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+            }
+        }
+        *reinterpret_cast<float4*>(grads + dst + (i / rl) * ds + (i % rl)) = acc;
+    } else {
+        float a4[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int e = 0; e < 4 && i + e < n; ++e) {
+            for (int q = 0; q < nsrc; ++q) {
+                if (i + e >= sgp->vn[q]) continue;
+                const float* p = ws + sgp->src[q] + i + e;
+                for (int s = 0; s < sgp->nslabs[q]; ++s) a4[e] += p[(size_t)s * sgp->ss[q]];
+            }
+            grads[dst + ((i + e) / rl) * ds + ((i + e) % rl)] = a4[e];
+        }
     }
-    grads[sg.dst + (i / sg.rl) * sg.ds + (i % sg.rl)] = acc;
 }
 void launch_reduce(const float* partial, float* grads, const ReduceSeg* segs_dev, const int* blk2seg_dev, int nblocks,
                    hipStream_t s) {

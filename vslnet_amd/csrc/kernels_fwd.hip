@@ -78,7 +78,12 @@ __global__ __launch_bounds__(256) void k_vproj_fwd(const float* __restrict__ X, 
         const int buf = ch & 1;
         if (ch + 1 < nchunk) gload(ch + 1);             // next chunk in flight while the MFMAs run
         const int kc = min(VP_KC, Dv - ch * VP_KC);
-        gemm32<1>(As[buf], LDP, kc, Wpack + (size_t)ch * (VP_KC / 8) * D * 8, D, 32 * w, 0, acc);
+        {
+            const float* wp = Wpack + (size_t)ch * (VP_KC / 8) * D * 8;
+            BFrag<1, 8> bf;
+            bfrag_load(bf, wp, D, 32 * w, 0, 0, kc >> 3);
+            gemm32p<1, 8>(As[buf], LDP, kc, wp, D, 32 * w, 0, acc, bf);
+        }
         if (ch + 1 < nchunk) sstore(buf ^ 1);
         __syncthreads();
     }
@@ -186,8 +191,11 @@ __global__ __launch_bounds__(256) void k_linear_fwd(const float* __restrict__ A,
             if (r0 + rr < R && c < kc) v = *reinterpret_cast<const float4*>(A + (size_t)(r0 + rr) * K + k0 + c);
             *reinterpret_cast<float4*>(&As[rr * LDP + c]) = v;
         }
+        const float* wp = Wpack + (size_t)(k0 / 8) * D * 8;
+        BFrag<1, 16> bf;
+        bfrag_load(bf, wp, D, 32 * w, 0, 0, kc >> 3);
         __syncthreads();
-        gemm32<1>(As, LDP, kc, Wpack + (size_t)(k0 / 8) * D * 8, D, 32 * w, 0, acc);
+        gemm32p<1, 16>(As, LDP, kc, wp, D, 32 * w, 0, acc, bf);
         __syncthreads();
     }
     const int col = 32 * w + (lane & 31);
@@ -221,6 +229,8 @@ __global__ __launch_bounds__(256) void k_conv_layer_fwd(const float* __restrict_
     float* Us = Vs + NH * LDP;                          // [32][LDP] depthwise output = GEMM A operand
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int r0 = blockIdx.x * TILE_M;
+    BFrag<1, 16> bf;                                    // the whole 128 x 32 weight slice of this wave, in flight now
+    bfrag_load(bf, Wpack, D, 32 * w, 0, 0, D / 8);
     // ---- load rows r0-3 .. r0+34 (+ positional rows, :202)
     for (int e = tid; e < NH * 32; e += 256) {
         const int rr = e >> 5, c = (e & 31) * 4;
@@ -238,35 +248,38 @@ __global__ __launch_bounds__(256) void k_conv_layer_fwd(const float* __restrict_
         *reinterpret_cast<float4*>(&Vs[rr * LDP + c]) = v;
     }
     __syncthreads();
-    // ---- LayerNorm of all 38 rows (one wave per row)
-    for (int rr = w; rr < NH; rr += 4) {
-        float mu, rs;
-        ln_row_inplace(Vs + rr * LDP, ln_g, ln_b, mu, rs);
-    }
+    // ---- LayerNorm of all 38 rows
+    ln_tile(Vs, NH, LDP, ln_g, ln_b, Drop{0u, 0u, 1.f}, 0);
     __syncthreads();
-    // ---- depthwise conv k=7 along the sequence: thread = (channel c, half of the tile)
+    // ---- depthwise conv k=7 along the sequence: thread = (channel c, 16 rows); the 22-row window sits in registers
     {
         const int c = tid & 127, hb = (tid >> 7) * 16;
-        float wk[DWK];
+        float wk[DWK], win[16 + 2 * HALO];
+        int sid[16 + 2 * HALO];                         // sample index of every window row (neighbours must share it)
 #pragma unroll
         for (int k = 0; k < DWK; ++k) wk[k] = dw_w[c * DWK + k];
-        for (int rr = hb; rr < hb + 16; ++rr) {
-            const int t = (r0 + rr) % L;
+        int rg = r0 - HALO + hb;                        // global row of window entry 0
+        int sm = rg >= 0 ? rg / L : -1, tt = rg >= 0 ? rg - sm * L : L + rg;
+#pragma unroll
+        for (int i = 0; i < 16 + 2 * HALO; ++i) {
+            win[i] = Vs[(hb + i) * LDP + c];
+            sid[i] = (rg + i < R) ? sm : -2;
+            if (++tt == L) { tt = 0; ++sm; }
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
             float u = 0.f;
 #pragma unroll
-            for (int k = 0; k < DWK; ++k) {
-                const int tt = t + k - HALO;
-                if (tt >= 0 && tt < L) u += wk[k] * Vs[(rr + k) * LDP + c];
-            }
-            Us[rr * LDP + c] = u;
-            if (u_out && r0 + rr < R) u_out[(size_t)(r0 + rr) * D + c] = u;     // saved: A operand of the weight gradient
+            for (int k = 0; k < DWK; ++k) u += (sid[q + k] == sid[q + HALO]) ? wk[k] * win[q + k] : 0.f;
+            Us[(hb + q) * LDP + c] = u;
+            if (u_out && r0 + hb + q < R) u_out[(size_t)(r0 + hb + q) * D + c] = u;   // saved: A operand of the weight gradient
         }
     }
     __syncthreads();
     // ---- pointwise GEMM + bias + ReLU (+ dropout) + residual
     f32x16 acc[1];
     zero_acc(acc);
-    gemm32<1>(Us, LDP, D, Wpack, D, 32 * w, 0, acc);
+    gemm32p<1, 16>(Us, LDP, D, Wpack, D, 32 * w, 0, acc, bf);
     const int col = 32 * w + (lane & 31);
     const float bv = pw_b[col];
 #pragma unroll
@@ -306,26 +319,20 @@ __global__ __launch_bounds__(256) void k_ln_qkv_fwd(const float* __restrict__ x,
     __shared__ __attribute__((aligned(16))) float Hs[TILE_M * LDP];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int r0 = blockIdx.x * TILE_M;
+    BFrag<3, 4> bf;
+    bfrag_load(bf, Wpack, 3 * D, 32 * w, D, 0, D / 8);
     load_tile128(Hs, x, r0, TILE_M, R);
     __syncthreads();
-    for (int rr = w; rr < TILE_M; rr += 4) {
-        float mu, rs;
-        float* row = Hs + rr * LDP;
-        ln_row_inplace(row, ln_g, ln_b, mu, rs);
-        if (d1.thresh) {
-            const uint32_t base = (uint32_t)((r0 + rr) * D);
-            row[lane] *= drop_mul(d1, base + lane);
-            row[lane + 64] *= drop_mul(d1, base + lane + 64);
-        }
-        if (h1 && r0 + rr < R) {
-            h1[(size_t)(r0 + rr) * D + lane] = row[lane];
-            h1[(size_t)(r0 + rr) * D + lane + 64] = row[lane + 64];
-        }
-    }
+    ln_tile(Hs, TILE_M, LDP, ln_g, ln_b, d1, r0);
     __syncthreads();
+    if (h1)
+        for (int e = tid; e < TILE_M * 32; e += 256) {
+            const int rr = e >> 5, c = (e & 31) * 4;
+            if (r0 + rr < R) *reinterpret_cast<float4*>(h1 + (size_t)(r0 + rr) * D + c) = *reinterpret_cast<const float4*>(&Hs[rr * LDP + c]);
+        }
     f32x16 acc[3];
     zero_acc(acc);
-    gemm32<3>(Hs, LDP, D, Wpack, 3 * D, 32 * w, D, acc);
+    gemm32p<3, 4>(Hs, LDP, D, Wpack, 3 * D, 32 * w, D, acc, bf);
     const int col = 32 * w + (lane & 31);
     const float b0 = bq[col], b1 = bk[col], b2 = bv[col];
 #pragma unroll
@@ -455,6 +462,8 @@ __global__ __launch_bounds__(256) void k_attn_out_fwd(const float* __restrict__ 
     __shared__ __attribute__((aligned(16))) float Hs[TILE_M * LDP];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int r0 = blockIdx.x * TILE_M;
+    BFrag<1, 16> bf;
+    bfrag_load(bf, Wpack, D, 32 * w, 0, 0, D / 8);
     for (int e = tid; e < TILE_M * 32; e += 256) {
         const int rr = e >> 5, c = (e & 31) * 4;
         const int r = r0 + rr;
@@ -473,24 +482,16 @@ __global__ __launch_bounds__(256) void k_attn_out_fwd(const float* __restrict__ 
         *reinterpret_cast<float4*>(&Hs[rr * LDP + c]) = v;
     }
     __syncthreads();
-    for (int rr = w; rr < TILE_M; rr += 4) {
-        float mu, rs;
-        float* row = Hs + rr * LDP;
-        ln_row_inplace(row, ln_g, ln_b, mu, rs);
-        if (d4.thresh) {
-            const uint32_t base = (uint32_t)((r0 + rr) * D);
-            row[lane] *= drop_mul(d4, base + lane);
-            row[lane + 64] *= drop_mul(d4, base + lane + 64);
-        }
-        if (h2_out && r0 + rr < R) {
-            h2_out[(size_t)(r0 + rr) * D + lane] = row[lane];
-            h2_out[(size_t)(r0 + rr) * D + lane + 64] = row[lane + 64];
-        }
-    }
+    ln_tile(Hs, TILE_M, LDP, ln_g, ln_b, d4, r0);
     __syncthreads();
+    if (h2_out)
+        for (int e = tid; e < TILE_M * 32; e += 256) {
+            const int rr = e >> 5, c = (e & 31) * 4;
+            if (r0 + rr < R) *reinterpret_cast<float4*>(h2_out + (size_t)(r0 + rr) * D + c) = *reinterpret_cast<const float4*>(&Hs[rr * LDP + c]);
+        }
     f32x16 acc[1];
     zero_acc(acc);
-    gemm32<1>(Hs, LDP, D, Wpack, D, 32 * w, 0, acc);
+    gemm32p<1, 16>(Hs, LDP, D, Wpack, D, 32 * w, 0, acc, bf);
     const int col = 32 * w + (lane & 31);
     const float bvv = bo[col];
 #pragma unroll
@@ -736,7 +737,11 @@ __global__ __launch_bounds__(256) void k_cq_out(const float* __restrict__ C, con
         }
     f32x16 acc[1];
     zero_acc(acc);
-    gemm32<1>(Cat, CATP, 4 * D, Wpack, D, 32 * w, 0, acc);
+    {
+        BFrag<1, 16> bf;
+        bfrag_load(bf, Wpack, D, 32 * w, 0, 0, 4 * D / 8);
+        gemm32p<1, 16>(Cat, CATP, 4 * D, Wpack, D, 32 * w, 0, acc, bf);
+    }
     const int col = 32 * w + (lane & 31);
     const float bv = bias[col];
 #pragma unroll
@@ -767,11 +772,13 @@ __global__ __launch_bounds__(256) void k_cqcat_fwd(const float* __restrict__ f1,
     __shared__ float hs[TILE_M];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int r0 = blockIdx.x * TILE_M;
+    BFrag<1, 16> bf;
+    bfrag_load(bf, Wpack, D, 32 * w, 0, 0, D / 8);
     load_tile128(As, f1, r0, TILE_M, R);
     __syncthreads();
     f32x16 acc[1];
     zero_acc(acc);
-    gemm32<1>(As, LDP, D, Wpack, D, 32 * w, 0, acc);
+    gemm32p<1, 16>(As, LDP, D, Wpack, D, 32 * w, 0, acc, bf);
     const int col = 32 * w + (lane & 31);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -780,10 +787,18 @@ __global__ __launch_bounds__(256) void k_cqcat_fwd(const float* __restrict__ f1,
         Fs[row * LDP + col] = acc[0][r] + pb[(size_t)(gr / T) * D + col];
     }
     __syncthreads();
-    for (int rr = w; rr < TILE_M; rr += 4) {
-        const float* row = Fs + rr * LDP;
-        const float d = wave_sum(row[lane] * wh[lane] + row[lane + 64] * wh[lane + 64]);
-        if (lane == 0) {
+    {
+        const int rr = tid >> 3, sub = tid & 7;
+        const float* row = Fs + rr * LDP + sub * 4;
+        float d = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 fv = *reinterpret_cast<const float4*>(row + 32 * j);
+            const float4 wv = *reinterpret_cast<const float4*>(wh + sub * 4 + 32 * j);
+            d += fv.x * wv.x + fv.y * wv.y + fv.z * wv.z + fv.w * wv.w;
+        }
+        d = grp8_sum(d);
+        if (sub == 0) {
             const int gr = r0 + rr;
             float hv = 0.f;
             if (gr < R) {
@@ -825,6 +840,8 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadArgs a0, HeadArgs a1, cons
     const HeadArgs a = blockIdx.y == 0 ? a0 : a1;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int r0 = blockIdx.x * TILE_M;
+    BFrag<1, 16> bf;
+    bfrag_load(bf, a.W0pack, D, 32 * w, 0, 0, 2 * D / 8);
     for (int e = tid; e < TILE_M * 32; e += 256) {
         const int rr = e >> 5, c = (e & 31) * 4;
         const int r = r0 + rr;
@@ -838,19 +855,17 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadArgs a0, HeadArgs a1, cons
     }
     __syncthreads();
     if (a.ln_g) {                          // transformer head: LayerNorm on the encoder features (:347-348); rnn: none
-        for (int rr = w; rr < TILE_M; rr += 4) {
-            float mu, rs;
-            ln_row_inplace(As + rr * HDP, a.ln_g, a.ln_b, mu, rs);
-            if (a.lnfeat && r0 + rr < R) {
-                a.lnfeat[(size_t)(r0 + rr) * D + lane] = As[rr * HDP + lane];
-                a.lnfeat[(size_t)(r0 + rr) * D + lane + 64] = As[rr * HDP + lane + 64];
-            }
-        }
+        ln_tile(As, TILE_M, HDP, a.ln_g, a.ln_b, Drop{0u, 0u, 1.f}, 0);
         __syncthreads();
     }
+    if (a.lnfeat)
+        for (int e = tid; e < TILE_M * 32; e += 256) {
+            const int rr = e >> 5, c = (e & 31) * 4;
+            if (r0 + rr < R) *reinterpret_cast<float4*>(a.lnfeat + (size_t)(r0 + rr) * D + c) = *reinterpret_cast<const float4*>(&As[rr * HDP + c]);
+        }
     f32x16 acc[1];
     zero_acc(acc);
-    gemm32<1>(As, HDP, 2 * D, a.W0pack, D, 32 * w, 0, acc);
+    gemm32p<1, 16>(As, HDP, 2 * D, a.W0pack, D, 32 * w, 0, acc, bf);
     const int col = 32 * w + (lane & 31);
     const float bv = a.b0[col];
 #pragma unroll
@@ -862,11 +877,19 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadArgs a0, HeadArgs a1, cons
         if (gr < R) a.hid[(size_t)gr * D + col] = hv;
     }
     __syncthreads();
-    for (int rr = w; rr < TILE_M; rr += 4) {
-        const float* row = Hd + rr * LDP;
-        const float d = wave_sum(row[lane] * a.w1[lane] + row[lane + 64] * a.w1[lane + 64]);
+    {
+        const int rr = tid >> 3, sub = tid & 7;
+        const float* row = Hd + rr * LDP + sub * 4;
+        float d = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 fv = *reinterpret_cast<const float4*>(row + 32 * j);
+            const float4 wv = *reinterpret_cast<const float4*>(a.w1 + sub * 4 + 32 * j);
+            d += fv.x * wv.x + fv.y * wv.y + fv.z * wv.z + fv.w * wv.w;
+        }
+        d = grp8_sum(d);
         const int gr = r0 + rr;
-        if (lane == 0 && gr < R) a.logits[gr] = d + a.b1[0] + (1.f - vmask[gr]) * MASK_VALUE;
+        if (sub == 0 && gr < R) a.logits[gr] = d + a.b1[0] + (1.f - vmask[gr]) * MASK_VALUE;
     }
 }
 void launch_head_fwd(const HeadArgs& a0, const HeadArgs& a1, const float* x, const float* vmask, int R, hipStream_t s) {

@@ -69,7 +69,9 @@ struct ReduceSeg {        // grads[dst + (i / rl) * ds + i % rl] = sum over sour
     int dst, n;
     int rl, ds;           // destination row length / row stride (rl == n, ds == 0 for a contiguous destination)
     int nsrc;
-    int src[4], nslabs[4], ss[4];
+    int src[4], nslabs[4], ss[4]; // float offsets into the WORKSPACE (partial arena or any saved buffer), slab count, slab stride
+    int vec;                      // 1: n, every src, ss and vn are multiples of 4 floats -> 16-byte loads/stores
+    int vn[4];                    // source q contributes to elements i < vn[q] only (shorter sequences of a shared table)
 };
 
 // ---------------------------------------------------------------- forward
@@ -117,15 +119,14 @@ void launch_conv_bwd_gemm(const float* dy, const uint32_t* relu_mask, const floa
 void launch_conv_bwd_dwln(const float* du, const float* xin, const float* dy, const float* ln_g, const float* ln_b,
                           const float* dw_w, const float* extra, float* dx, float* p_lng, float* p_lnb, float* p_dw, int R, int L,
                           hipStream_t s);
-void launch_attn_out_bwd(const float* dy, const float* r, const float* ln_g, const float* WTpack, float* g_o, float* dr,
-                         float* p_lng, float* p_lnb, int R, Drop d4, Drop d5, hipStream_t s);
+void launch_attn_out_bwd(const float* dy, const float* dy2, const float* r, const float* ln_g, const float* WTpack, float* g_o,
+                         float* dr, float* p_lng, float* p_lnb, int R, Drop d4, Drop d5, hipStream_t s);
 void launch_attn_bwd(const float* Q, const float* K, const float* V, const float* att, const float* dr, const float* lse,
                      const float* mask, float* dQ, float* dK, float* dV, float* Dq, int B, int L, int H, int b_off, Drop d2,
                      Drop d3, hipStream_t s);
 void launch_qkv_bwd(const float* dQ, const float* dK, const float* dV, const float* x, const float* dr,
                     const float* ln_g, const float* WTpack, float* dx, float* p_lng, float* p_lnb, int R, Drop d1,
                     hipStream_t s);
-void launch_pos_grad(const float* dx0, const float* extra, float* out, int B, int L, int max_pos, hipStream_t s);
 void launch_cqcat_bwd(const float* dg0, const float* dg1, const float* dg2, const float* dh_loss, const float* f2,
                       const float* hscore, const float* wh, const float* W1Tpack, float* df2, float* df1, float* p_wh,
                       float* p_bh, int R, hipStream_t s);
@@ -148,11 +149,12 @@ void launch_cq_col_bwd(const CqColBwdArgs& a, int B, hipStream_t s);
 void launch_linear_bwd_data(const float* G, const float* WTpack, float* dA, int R, int K, hipStream_t s);
 void launch_embed_bwd(const float* dE, const int64_t* word_ids, const int64_t* char_ids, const float* E,
                       const int8_t* argpos, const float* char_tab, CharConvPtrs cc, float* p_cw /*[nchunk][15000]*/,
-                      float* p_cb /*[nchunk][100]*/, float* p_tab /*[nchunk][char_size*char_dim]*/, float* g_unk, int Rq,
-                      int Lc, int word_dim, int char_dim, int char_size, Drop dw, Drop dc, hipStream_t s);
-void launch_reduce(const float* partial, float* grads, const ReduceSeg* segs_dev, const int* blk2seg_dev, int nblocks,
+                      float* p_cb /*[nchunk][100]*/, float* p_tab /*[nchunk][char_size*char_dim]*/,
+                      float* p_unk /*[nchunk][word_dim]*/, int Rq, int Lc, int word_dim, int char_dim, int char_size, Drop dw,
+                      Drop dc, hipStream_t s);
+void launch_reduce(const float* ws, float* grads, const ReduceSeg* segs_dev, const int* blk2seg_dev, int nblocks,
                    hipStream_t s);
-constexpr int EMB_CHUNK = 32;     // query words per workgroup in the embedding backward
+constexpr int EMB_CHUNK = 8;     // query words per workgroup in the embedding backward
 constexpr int CHARW_TOTAL = 15000;
 
 }  // namespace vsl
