@@ -1,0 +1,98 @@
+"""Data-parallel exactness on CPU (gloo, world_size 2): sharding + global normalisers + ONE all-reduce(sum) of the flat
+gradient bucket reproduces the single-process gradients of the whole batch.  The compute engine is swapped
+for the CPU oracle here (test infrastructure) -- what is under test is vslnet_amd/dp.py."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from oracle import vslnet_oracle as O
+from vslnet_amd import dp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _flat_grads(P, cfg, batch, inv_batch, mask_sum):
+    Pg = {k: v.clone().requires_grad_(k not in O.FROZEN) for k, v in P.items()}
+    h, sl, el = O.forward(Pg, cfg, batch['word_ids'], batch['char_ids'], batch['vfeats'], batch['v_mask'], batch['q_mask'])
+    # per-rank partial losses with the GLOBAL normalisers (what vsl_loss does with inv_batch / mask_sum)
+    ce = torch.nn.functional.cross_entropy(sl, batch['s_labels'], reduction='sum') + \
+        torch.nn.functional.cross_entropy(el, batch['e_labels'], reduction='sum')
+    y = batch['h_labels'].float()
+    w = torch.where(y == 0.0, y + 1.0, 2.0 * y)
+    per = torch.nn.functional.binary_cross_entropy(h, y, reduction='none') * w
+    hl = (per * batch['v_mask']).sum() / (mask_sum + 1e-12)
+    (ce * inv_batch + 5.0 * hl).backward()
+    names = [k for k in Pg if k not in O.FROZEN]
+    return torch.cat([(Pg[k].grad if Pg[k].grad is not None else torch.zeros_like(Pg[k])).reshape(-1) for k in names])
+
+
+def _worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    cfg = O.make_cfg(video_feature_dim=32, max_pos_len=32, word_size=52)
+    P = O.random_params(cfg, seed=5)
+    full = O.synthetic_batch(cfg, B=5, T=20, Lq=6, Lc=5, seed=9, ragged=True)     # 5 % 2 != 0: uneven shards
+    inv_b, msum = dp.global_normalisers(full['lens'].tolist())
+    shard = dp.shard_batch(full, rank, world)
+    assert shard['vfeats'].shape[1] == full['vfeats'].shape[1]                   # padded to the GLOBAL max length
+    g = _flat_grads(P, cfg, shard, inv_b, msum)
+    dp.allreduce_flat_(g)
+    if rank == 0:
+        ref = _flat_grads(P, cfg, full, inv_b, msum)
+        out.put((float((g - ref).abs().max()), float(ref.abs().max())))
+    dist.destroy_process_group()
+
+
+def test_two_rank_allreduce_matches_single_process():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    err, scale = q.get(timeout=300)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert err <= 1e-5 * scale + 1e-7, (err, scale)
+
+
+def test_shard_slices_cover_the_batch():
+    for B in (1, 5, 8, 64, 257):
+        for N in (1, 2, 4, 8):
+            idx = []
+            for r in range(N):
+                s = dp.shard_slice(B, r, N)
+                idx += list(range(B))[s]
+            assert idx == list(range(B))
+
+
+def test_flat_adamw_matches_per_parameter_adamw():
+    """One AdamW over the flat bucket == torch.optim.AdamW over the individual tensors (same hyper-parameters)."""
+    torch.manual_seed(0)
+    layout = [('a.weight', 0, 12, (3, 4)), ('a.bias', 12, 4, (4,)), ('layer_norm.weight', 16, 4, (4,))]
+    flat = torch.randn(20)
+    params = [torch.nn.Parameter(flat[o:o + n].clone().view(s)) for _, o, n, s in layout]
+    ref = torch.optim.AdamW([{'params': [params[0]], 'weight_decay': 0.01}, {'params': params[1:], 'weight_decay': 0.0}],
+                            lr=1e-2, eps=1e-6)
+    opt = dp.FlatAdamW(flat, layout, lr=1e-2, num_train_steps=10 ** 9, clip_norm=0.0)
+    for _ in range(5):
+        g = torch.randn(20)
+        for p, (_, o, n, s) in zip(params, layout):
+            p.grad = g[o:o + n].view(s).clone()
+        ref.step()
+        opt.step(g)
+    got = torch.cat([p.detach().reshape(-1) for p in params])
+    assert torch.allclose(flat, got, atol=1e-6), float((flat - got).abs().max())

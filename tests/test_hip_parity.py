@@ -144,6 +144,8 @@ def test_losses_and_every_gradient(name):
         g = keep[nm].grad
         if nm == 'd_gated':      # three consumers: predictor encoder input + both span heads (VSLNet_t7.py:61, layers_t7.py:349-350)
             got = sum(eng.ws_view(k, shapes[nm]) for k in ('d_gated_enc', 'd_gated_hs', 'd_gated_he'))
+        elif nm == 'd_pred_s':   # two consumers: second encoder pass + start_layer_norm (layers_t7.py:346-347)
+            got = eng.ws_view('d_pred_s', shapes[nm]) + eng.ws_view('d_pred_s_head', shapes[nm])
         else:
             got = eng.ws_view(nm, shapes[nm])
         err = float((got.cpu() - g).abs().max())

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -48,6 +49,8 @@ struct ModelPk { int va_f, emb_f, emb_t; EncPk fe, pe; int cqa_f, cqa_t, cat1_f,
 
 struct EncWs { int64_t x0, y[4], u[4], mask[4], h1, q, k, v, lse, att, r, h2, out; int R, L; };
 
+struct EncTmp { int64_t dr, dq, dk, dv, Dq, go, du, gz[4], ga, gb; };   // backward temporaries of one encoder application
+
 struct SlabRec { int dst, n, nslabs, ss, rl, ds, vn; int64_t src; };
 
 struct Plan {
@@ -57,7 +60,8 @@ struct Plan {
     int64_t S, Srow, Scol, M, alpha, pooled, pb, cat, f1, f2, gated, hid_s, hid_e, lnf_s, lnf_e;
     // backward temporaries
     int64_t loss_scratch, gz_s, gz_e, dfeat_s, dfeat_e, dxh_s, dxh_e, g_s1, g_gated;
-    int64_t t_dr, t_dq, t_dk, t_dv, t_Dq, t_go, t_du, t_gz[4], t_ga, t_gb;
+    EncTmp tmp[4];                      // one set per encoder application: the applications' backward chains and their
+                                        // weight-gradient launches overlap on different streams
     int64_t df2, df1, dC, dc2q, dq2c, dSr, dSs, dQtot, dvf, dqf, dE;
     int64_t partial, partial_floats, total;
     std::vector<int64_t> part_offs;     // sequence of partial-arena allocations made by the backward
@@ -78,6 +82,11 @@ struct vsl_handle_s {
     std::vector<PackJob> jobs;
     PackJob* jobs_dev = nullptr;
     std::map<std::tuple<int, int, int, int>, Plan*> plans;
+    // side streams for the independent chains (query branch, weight gradients) + fork/join events
+    hipStream_t side[2] = {nullptr, nullptr};
+    std::vector<hipEvent_t> sync_pool;
+    size_t sync_used = 0;
+    bool multi_stream = true;
     // optional per-kernel timing with HIP events on the launch stream (vsl_profile_*), used by bench.py's roofline line
     bool prof_on = false;
     std::string prof_sel;
@@ -275,6 +284,16 @@ struct Ctx {
         return dry ? nullptr : ws + p->partial + o;
     }
     float* part_ptr(int64_t o) const { return dry ? nullptr : ws + p->partial + o; }
+    // make stream `to` wait for everything enqueued so far on stream `from`
+    void order(hipStream_t from, hipStream_t to) {
+        if (dry || from == to) return;
+        if (h->sync_used == h->sync_pool.size()) { hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); h->sync_pool.push_back(e); }
+        hipEvent_t e = h->sync_pool[h->sync_used++];
+        (void)hipEventRecord(e, from);
+        (void)hipStreamWaitEvent(to, e, 0);
+    }
+    hipStream_t side(int k) const { return (h->multi_stream && h->side[k]) ? h->side[k] : main; }
+    hipStream_t main = nullptr;
     size_t prof_e0 = 0;
     bool prof_live = false;
     hipEvent_t prof_event() {
@@ -335,13 +354,19 @@ void run_forward(Ctx& c) {
     const vsl_io& io = *c.io;
     const int B = p.B, T = p.T, Lq = p.Lq, R = B * T, Rq = B * Lq;
     LAUNCH("pack", launch_pack(io.params, c.W(p.pack), c.h->jobs_dev, (int)c.h->jobs.size(), c.s));
+    // fork: the query branch (embedding + query encoder pass) runs beside the video branch
+    hipStream_t sq = c.side(0);
+    c.order(c.main, sq);
     LAUNCH("vproj_fwd", launch_vproj_fwd(io.video_features, c.PK(K.va_f), c.P(P.va_b), c.W(p.vf), R, cf.video_feature_dim, c.drop(SITE_VIS), c.s));
+    enc_fwd(c, P.fe, K.fe, p.ve, c.W(p.vf), io.v_mask, B, 0);
+    c.s = sq;
     LAUNCH("embed_fwd", launch_embed_fwd(io.word_ids, io.char_ids, io.pad_vec, c.P(P.unk), io.glove_vec, c.P(P.char_tab), char_ptrs(c), c.W(p.E),
                      reinterpret_cast<int8_t*>(c.W(p.argpos)), Rq, p.Lc, cf.word_dim, cf.char_dim, c.drop(SITE_WORD),
                      c.drop(SITE_CHAR), c.s));
     LAUNCH("linear_fwd", launch_linear_fwd(c.W(p.E), c.PK(K.emb_f), c.P(P.emb_b), c.W(p.qf), Rq, cf.word_dim + 100, c.s));
-    enc_fwd(c, P.fe, K.fe, p.ve, c.W(p.vf), io.v_mask, B, 0);
     enc_fwd(c, P.fe, K.fe, p.qe, c.W(p.qf), io.q_mask, B, 1);
+    c.s = c.main;
+    c.order(sq, c.main);                   // join
     LAUNCH("cq_score", launch_cq_score(c.W(p.ve.out), c.W(p.qe.out), io.q_mask, c.P(P.w4C), c.P(P.w4Q), c.P(P.w4mlu), c.W(p.S), c.W(p.Srow), B, T,
                     Lq, 0, c.drop(SITE_CQ_C), c.drop(SITE_CQ_Q), c.s));
     LAUNCH("cq_col", launch_cq_col(c.W(p.ve.out), c.W(p.qe.out), c.W(p.S), io.v_mask, io.q_mask, c.P(P.pool_w), c.P(P.cat_w), c.P(P.cat_b),
@@ -364,31 +389,32 @@ WgradJob wjob() { WgradJob j; memset(&j, 0, sizeof j); return j; }
 
 // backward of one FeatureEncoder application: dy = grad wrt its output; writes grad wrt its input (dx0_out)
 void enc_bwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float* dy, const float* dy2, int64_t dx0_off,
-             const float* mask, int Bn, int app) {
+             const float* mask, int Bn, int app, hipStream_t sw) {
     float* dx0_out = c.dry ? nullptr : c.W(dx0_off);
     const Plan& p = *c.p;
+    const EncTmp& t = p.tmp[app];
     const int R = w.R, L = w.L, H = c.h->cfg.num_heads;
     const int ntiles = (R + TILE_M - 1) / TILE_M, nchunk = (R + WG_ROWS - 1) / WG_ROWS;
     float* p_ln2g = c.slab(P.ln2g, D, ntiles);
     float* p_ln2b = c.slab(P.ln2b, D, ntiles);
-    LAUNCH("attn_out_bwd", launch_attn_out_bwd(dy, dy2, c.W(w.r), c.P(P.ln2g), c.PK(K.o_t), c.W(p.t_go), c.W(p.t_dr), p_ln2g, p_ln2b, R,
+    LAUNCH("attn_out_bwd", launch_attn_out_bwd(dy, dy2, c.W(w.r), c.P(P.ln2g), c.PK(K.o_t), c.W(t.go), c.W(t.dr), p_ln2g, p_ln2b, R,
                                c.drop(app * 16 + 7), c.drop(app * 16 + 8), c.s));
-    LAUNCH("attn_bwd", launch_attn_bwd(c.W(w.q), c.W(w.k), c.W(w.v), c.W(w.att), c.W(p.t_dr), c.W(w.lse), mask, c.W(p.t_dq), c.W(p.t_dk),
-                           c.W(p.t_dv), c.W(p.t_Dq), Bn, L, H, 0, c.drop(app * 16 + 5), c.drop(app * 16 + 6), c.s));
+    LAUNCH("attn_bwd", launch_attn_bwd(c.W(w.q), c.W(w.k), c.W(w.v), c.W(w.att), c.W(t.dr), c.W(w.lse), mask, c.W(t.dq), c.W(t.dk),
+                           c.W(t.dv), c.W(t.Dq), Bn, L, H, 0, c.drop(app * 16 + 5), c.drop(app * 16 + 6), c.s));
     float* p_ln1g = c.slab(P.ln1g, D, ntiles);
     float* p_ln1b = c.slab(P.ln1b, D, ntiles);
-    LAUNCH("qkv_bwd", launch_qkv_bwd(c.W(p.t_dq), c.W(p.t_dk), c.W(p.t_dv), c.W(w.y[3]), c.W(p.t_dr), c.P(P.ln1g), c.PK(K.qkv_t),
-                          c.W(p.t_ga), p_ln1g, p_ln1b, R, c.drop(app * 16 + 4), c.s));
-    float* g = c.dry ? nullptr : c.W(p.t_ga);
-    float* other = c.dry ? nullptr : c.W(p.t_gb);
+    LAUNCH("qkv_bwd", launch_qkv_bwd(c.W(t.dq), c.W(t.dk), c.W(t.dv), c.W(w.y[3]), c.W(t.dr), c.P(P.ln1g), c.PK(K.qkv_t),
+                          c.W(t.ga), p_ln1g, p_ln1b, R, c.drop(app * 16 + 4), c.s));
+    float* g = c.dry ? nullptr : c.W(t.ga);
+    float* other = c.dry ? nullptr : c.W(t.gb);
     for (int i = 3; i >= 0; --i) {
-        LAUNCH("conv_bwd_gemm", launch_conv_bwd_gemm(g, reinterpret_cast<const uint32_t*>(c.W(w.mask[i])), c.PK(K.pw_t[i]), c.W(p.t_gz[i]),
-                                    c.W(p.t_du), R, c.drop(app * 16 + i), c.s));
+        LAUNCH("conv_bwd_gemm", launch_conv_bwd_gemm(g, reinterpret_cast<const uint32_t*>(c.W(w.mask[i])), c.PK(K.pw_t[i]), c.W(t.gz[i]),
+                                    c.W(t.du), R, c.drop(app * 16 + i), c.s));
         float* p_g = c.slab(P.lng[i], D, ntiles);
         float* p_b = c.slab(P.lnb[i], D, ntiles);
         float* p_dw = c.slab(P.dw[i], D * DWK, ntiles);
         float* out = i > 0 ? other : dx0_out;
-        LAUNCH("conv_bwd_dwln", launch_conv_bwd_dwln(c.W(p.t_du), i > 0 ? c.W(w.y[i - 1]) : c.W(w.x0), g, c.P(P.lng[i]), c.P(P.lnb[i]),
+        LAUNCH("conv_bwd_dwln", launch_conv_bwd_dwln(c.W(t.du), i > 0 ? c.W(w.y[i - 1]) : c.W(w.x0), g, c.P(P.lng[i]), c.P(P.lnb[i]),
                                     c.P(P.dw[i]), nullptr, out, p_g, p_b, p_dw, R, L, c.s));
         other = g;
         g = out;
@@ -398,14 +424,14 @@ void enc_bwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float*
     memset(&wb, 0, sizeof wb);
     {
         WgradJob j = wjob();
-        j.G[0] = c.dry ? nullptr : c.W(p.t_go); j.nG = 1; j.A[0] = c.dry ? nullptr : c.W(w.h2); j.nA = 1; j.K = D; j.R = R;
+        j.G[0] = c.dry ? nullptr : c.W(t.go); j.nG = 1; j.A[0] = c.dry ? nullptr : c.W(w.h2); j.nA = 1; j.K = D; j.R = R;
         j.out = c.slab(P.ow, D * D, nchunk);
         j.out_bias[0] = c.slab(P.ob, D, nchunk);
         wb.j[wb.n++] = j;
     }
     {
         WgradJob j = wjob();
-        if (!c.dry) { j.G[0] = c.W(p.t_dq); j.G[1] = c.W(p.t_dk); j.G[2] = c.W(p.t_dv); j.A[0] = c.W(w.h1); }
+        if (!c.dry) { j.G[0] = c.W(t.dq); j.G[1] = c.W(t.dk); j.G[2] = c.W(t.dv); j.A[0] = c.W(w.h1); }
         j.nG = 3; j.nA = 1; j.K = D; j.R = R;
         const int64_t o = c.part_alloc((int64_t)nchunk * 3 * D * D);
         c.reg(P.qw, D * D, p.partial + o, nchunk, 3 * D * D);
@@ -419,13 +445,19 @@ void enc_bwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float*
     }
     for (int i = 0; i < 4; ++i) {
         WgradJob j = wjob();
-        if (!c.dry) { j.G[0] = c.W(p.t_gz[i]); j.A[0] = c.W(w.u[i]); }
+        if (!c.dry) { j.G[0] = c.W(t.gz[i]); j.A[0] = c.W(w.u[i]); }
         j.nG = 1; j.nA = 1; j.K = D; j.R = R;
         j.out = c.slab(P.pw[i], D * D, nchunk);
         j.out_bias[0] = c.slab(P.pwb[i], D, nchunk);
         wb.j[wb.n++] = j;
     }
-    LAUNCH("wgrad", launch_wgrad(wb, c.s));
+    {   // the weight gradients only feed the final reduction: run them beside the next chain
+        hipStream_t keep = c.s;
+        c.order(keep, sw);
+        c.s = sw;
+        LAUNCH("wgrad", launch_wgrad(wb, c.s));
+        c.s = keep;
+    }
     // positional table (:202): dpos[t] = sum_b dx0[b, t] -- the per-sample rows of dx0 ARE the partial slabs
     c.reg(P.pos, c.h->cfg.max_pos_len * D, dx0_off, Bn, L * D, 0, 0, L * D);
 }
@@ -438,6 +470,10 @@ void run_backward(Ctx& c) {
     const int B = p.B, T = p.T, Lq = p.Lq, R = B * T, Rq = B * Lq;
     const int ntiles = (R + TILE_M - 1) / TILE_M, nchunk = (R + WG_ROWS - 1) / WG_ROWS, nchunk_q = (Rq + WG_ROWS - 1) / WG_ROWS;
     const vsl_io* io = c.io;
+    // streams: `main` carries the dependent dX chain; sw = every weight-gradient GEMM (they only feed the final
+    // reduction); sq = the query-side chain (query encoder pass + embedding stack) once CQAttention's backward is done
+    hipStream_t sw = c.dry ? nullptr : c.side(1), sq = c.dry ? nullptr : c.side(0);
+    auto on_stream = [&](hipStream_t st, auto&& fn) { hipStream_t keep = c.s; c.order(keep, st); c.s = st; fn(); c.s = keep; };
     // ---- span heads
     HeadBwdArgs hs, he;
     memset(&hs, 0, sizeof hs);
@@ -463,13 +499,13 @@ void run_backward(Ctx& c) {
             j.out = c.slab(e ? P.e0w : P.s0w, D * 2 * D, nchunk);
             wb.j[wb.n++] = j;
         }
-        LAUNCH("wgrad", launch_wgrad(wb, c.s));
+        on_stream(sw, [&] { LAUNCH("wgrad", launch_wgrad(wb, c.s)); });
     }
     // ---- predictor encoder, second pass (input = output of the first pass), then first pass
-    enc_bwd(c, P.pe, K.pe, p.p2, c.dry ? nullptr : c.W(p.dfeat_e), nullptr, p.g_s1, c.dry ? nullptr : io->v_mask, B, 3);
+    enc_bwd(c, P.pe, K.pe, p.p2, c.dry ? nullptr : c.W(p.dfeat_e), nullptr, p.g_s1, c.dry ? nullptr : io->v_mask, B, 3, sw);
     // grad wrt the first pass' output = (input grad of the second pass) + (LayerNorm path of the start head)
     enc_bwd(c, P.pe, K.pe, p.p1, c.dry ? nullptr : c.W(p.g_s1), c.dry ? nullptr : c.W(p.dfeat_s), p.g_gated,
-            c.dry ? nullptr : io->v_mask, B, 2);
+            c.dry ? nullptr : io->v_mask, B, 2, sw);
     // ---- gating + highlight + CQConcatenate
     float* p_hlw = c.slab(P.hl_w, D, ntiles);
     float* p_hlb = c.slab(P.hl_b, 1, ntiles);
@@ -495,7 +531,7 @@ void run_backward(Ctx& c) {
             j.out_bias[0] = c.slab(P.cqa_b, D, nchunk);
             wb.j[wb.n++] = j;
         }
-        LAUNCH("wgrad", launch_wgrad(wb, c.s));
+        on_stream(sw, [&] { LAUNCH("wgrad", launch_wgrad(wb, c.s)); });
     }
     // ---- CQAttention
     LAUNCH("cq_out_bwd", launch_cq_out_bwd(c.W(p.df1), c.W(p.ve.out), c.W(p.qe.out), c.W(p.Srow), c.W(p.M), c.PK(K.cqa_t), c.W(p.dC),
@@ -518,7 +554,9 @@ void run_backward(Ctx& c) {
         LAUNCH("cq_col_bwd", launch_cq_col_bwd(a, B, c.s));
     }
     // ---- shared feature encoder: video pass, then VisualProjection weight gradient
-    enc_bwd(c, P.fe, K.fe, p.ve, c.dry ? nullptr : c.W(p.dC), nullptr, p.dvf, c.dry ? nullptr : io->v_mask, B, 0);
+    // fork: from here the video side (main) and the query side (sq) are independent
+    c.order(c.s, sq);
+    enc_bwd(c, P.fe, K.fe, p.ve, c.dry ? nullptr : c.W(p.dC), nullptr, p.dvf, c.dry ? nullptr : io->v_mask, B, 0, sw);
     {
         WgradBatch wb;
         memset(&wb, 0, sizeof wb);
@@ -528,10 +566,12 @@ void run_backward(Ctx& c) {
         j.out = c.slab(P.va_w, D * cf.video_feature_dim, nchunk);
         j.out_bias[0] = c.slab(P.va_b, D, nchunk);
         wb.j[wb.n++] = j;
-        LAUNCH("wgrad", launch_wgrad(wb, c.s));
+        on_stream(sw, [&] { LAUNCH("wgrad", launch_wgrad(wb, c.s)); });
     }
-    // ---- query pass, then the embedding stack
-    enc_bwd(c, P.fe, K.fe, p.qe, c.dry ? nullptr : c.W(p.dQtot), nullptr, p.dqf, c.dry ? nullptr : io->q_mask, B, 1);
+    // ---- query pass, then the embedding stack (all on sq)
+    hipStream_t main_s = c.s;
+    c.s = sq;
+    enc_bwd(c, P.fe, K.fe, p.qe, c.dry ? nullptr : c.W(p.dQtot), nullptr, p.dqf, c.dry ? nullptr : io->q_mask, B, 1, sq);
     const int EW = cf.word_dim + 100;
     LAUNCH("linear_bwd_data", launch_linear_bwd_data(c.W(p.dqf), c.PK(K.emb_t), c.W(p.dE), Rq, EW, c.s));
     {
@@ -563,6 +603,9 @@ void run_backward(Ctx& c) {
                                 c.P(P.char_tab), char_ptrs(c), c.part_ptr(ow), c.part_ptr(ob), p_tab, p_unk, Rq,
                                 p.Lc, cf.word_dim, cf.char_dim, cf.char_size, c.drop(SITE_WORD), c.drop(SITE_CHAR), c.s));
     }
+    c.s = main_s;
+    c.order(sq, c.s);                      // join both side streams before the reduction
+    c.order(sw, c.s);
     LAUNCH("reduce", launch_reduce(c.ws, io->grads, p.segs_dev, p.blk2seg_dev, p.nblocks, c.s));
 }
 
@@ -591,10 +634,14 @@ int build_plan(vsl_handle_s* h, int B, int T, int Lq, int Lc, Plan** out) {
     p->loss_scratch = al(5 * (int64_t)B + 8);
     p->gz_s = al(R * D); p->gz_e = al(R * D); p->dfeat_s = al(R * D); p->dfeat_e = al(R * D);
     p->dxh_s = al(R * D); p->dxh_e = al(R * D); p->g_s1 = al(R * D); p->g_gated = al(R * D);
-    p->t_dr = al(R * D); p->t_dq = al(R * D); p->t_dk = al(R * D); p->t_dv = al(R * D); p->t_Dq = al((int64_t)B * H * T);
-    p->t_go = al(R * D); p->t_du = al(R * D);
-    for (int i = 0; i < 4; ++i) p->t_gz[i] = al(R * D);
-    p->t_ga = al(R * D); p->t_gb = al(R * D);
+    for (int ap = 0; ap < 4; ++ap) {
+        const int64_t Ra = ap == 1 ? Rq : R;
+        EncTmp& t = p->tmp[ap];
+        t.dr = al(Ra * D); t.dq = al(Ra * D); t.dk = al(Ra * D); t.dv = al(Ra * D); t.Dq = al((int64_t)B * H * (ap == 1 ? Lq : T));
+        t.go = al(Ra * D); t.du = al(Ra * D);
+        for (int i = 0; i < 4; ++i) t.gz[i] = al(Ra * D);
+        t.ga = al(Ra * D); t.gb = al(Ra * D);
+    }
     p->df2 = al(R * D); p->df1 = al(R * D); p->dC = al(R * D); p->dc2q = al(R * D); p->dq2c = al(R * D);
     p->dSr = al(R * Lq); p->dSs = al(R * Lq); p->dQtot = al(Rq * D); p->dvf = al(R * D); p->dqf = al(Rq * D); p->dE = al(Rq * EW);
     p->partial = al(0);
@@ -691,12 +738,22 @@ int vsl_create(const vsl_config* cfg, vsl_handle* out) {
         delete h;
         return fail("hipMalloc/hipMemcpy of the pack table failed");
     }
+    {
+        const char* e = getenv("VSL_MULTI_STREAM");
+        h->multi_stream = !(e && e[0] == '0');
+        if (h->multi_stream)
+            for (int k = 0; k < 2; ++k)
+                if (hipStreamCreateWithFlags(&h->side[k], hipStreamNonBlocking) != hipSuccess) { h->side[k] = nullptr; (void)hipGetLastError(); }
+    }
     *out = h;
     return 0;
 }
 
 int vsl_destroy(vsl_handle h) {
     if (!h) return 0;
+    for (int k = 0; k < 2; ++k) if (h->side[k]) (void)hipStreamDestroy(h->side[k]);
+    for (hipEvent_t e : h->sync_pool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->prof_pool) (void)hipEventDestroy(e);
     for (auto& kv : h->plans) {
         if (kv.second->segs_dev) (void)hipFree(kv.second->segs_dev);
         if (kv.second->blk2seg_dev) (void)hipFree(kv.second->blk2seg_dev);
@@ -740,7 +797,7 @@ int64_t vsl_workspace_offset(vsl_handle h, int B, int T, int Lq, int Lc, const c
         {"cq_score", p->S}, {"cq_srow", p->Srow}, {"cq_scol", p->Scol}, {"cq_M", p->M}, {"cq_attention", p->f1},
         {"cq_concat", p->f2}, {"gated", p->gated}, {"pred_s", p->p1.out}, {"pred_e", p->p2.out},
         {"d_gated_enc", p->g_gated}, {"d_gated_hs", p->dxh_s}, {"d_gated_he", p->dxh_e}, {"d_venc", p->dC}, {"d_qenc", p->dQtot}, {"d_video_affine", p->dvf}, {"d_embedding_net", p->dqf},
-        {"d_pred_s", p->g_s1}, {"d_cq_concat", p->df2}, {"d_cq_attention", p->df1}, {"d_emb_concat", p->dE}};
+        {"d_pred_s", p->g_s1}, {"d_pred_s_head", p->dfeat_s}, {"d_cq_concat", p->df2}, {"d_cq_attention", p->df1}, {"d_emb_concat", p->dE}};
     for (auto& kv : tab) if (n == kv.first) return kv.second;
     return -1;
 }
@@ -750,6 +807,8 @@ int vsl_forward(vsl_handle h, const vsl_io* io, void* hip_stream) {
     Plan* p = nullptr;
     if (int rc = get_plan(h, io->B, io->T, io->Lq, io->Lc, &p)) return rc;
     Ctx c{h, p, io, (hipStream_t)hip_stream, false, io->workspace};
+    c.main = c.s;
+    h->sync_used = 0;
     run_forward(c);
     HIP_OK(hipGetLastError());
     return 0;
@@ -775,6 +834,8 @@ int vsl_backward(vsl_handle h, const vsl_io* io, void* hip_stream) {
     Plan* p = nullptr;
     if (int rc = get_plan(h, io->B, io->T, io->Lq, io->Lc, &p)) return rc;
     Ctx c{h, p, io, (hipStream_t)hip_stream, false, io->workspace};
+    c.main = c.s;
+    h->sync_used = 0;
     run_backward(c);
     HIP_OK(hipGetLastError());
     return 0;

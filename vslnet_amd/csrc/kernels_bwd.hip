@@ -211,7 +211,12 @@ __global__ __launch_bounds__(256) void k_head_bwd(HeadBwdArgs a0, HeadBwdArgs a1
     }
 }
 void launch_head_bwd(const HeadBwdArgs& a0, const HeadBwdArgs& a1, int R, hipStream_t s) {
-    hipLaunchKernelGGL(k_head_bwd, dim3((R + TILE_M - 1) / TILE_M, 2), dim3(256), 0, s, a0, a1, R);
+    {
+        static size_t lds_sp = 0;
+        const size_t shm_sp = spread_lds(0, 50816, (R + TILE_M - 1) / TILE_M);
+        ensure_dynamic_lds((const void*)k_head_bwd, shm_sp + 50816, lds_sp, "k_head_bwd");
+        hipLaunchKernelGGL(k_head_bwd, dim3((R + TILE_M - 1) / TILE_M, 2), dim3(256), shm_sp, s, a0, a1, R);
+    }
 }
 
 // =========================================================================================================
@@ -306,9 +311,14 @@ void launch_wgrad(const WgradBatch& wb, hipStream_t s) {
         ch = max(ch, (wb.j[i].R + WG_ROWS - 1) / WG_ROWS);
     }
     const size_t shm = (size_t)4 * TILE_M * LDP * sizeof(float);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr = true; }
-    hipLaunchKernelGGL(k_wgrad, dim3(kt, ch, wb.n * 3), dim3(256), shm, s, wb);
+    static size_t lds_ok = 0;
+    ensure_dynamic_lds((const void*)k_wgrad, shm, lds_ok, "k_wgrad");
+    {
+        static size_t lds_sp = 0;
+        const size_t shm_sp = spread_lds(shm, 0, 0);
+        ensure_dynamic_lds((const void*)k_wgrad, shm_sp + 0, lds_sp, "k_wgrad");
+        hipLaunchKernelGGL(k_wgrad, dim3(kt, ch, wb.n * 3), dim3(256), shm_sp, s, wb);
+    }
 }
 
 // =========================================================================================================
@@ -353,7 +363,12 @@ __global__ __launch_bounds__(256) void k_conv_bwd_gemm(const float* __restrict__
 }
 void launch_conv_bwd_gemm(const float* dy, const uint32_t* relu_mask, const float* WTpack, float* gz, float* du, int R,
                           Drop dp, hipStream_t s) {
-    hipLaunchKernelGGL(k_conv_bwd_gemm, dim3((R + TILE_M - 1) / TILE_M), dim3(256), 0, s, dy, relu_mask, WTpack, gz, du, R, dp);
+    {
+        static size_t lds_sp = 0;
+        const size_t shm_sp = spread_lds(0, 16896, (R + TILE_M - 1) / TILE_M);
+        ensure_dynamic_lds((const void*)k_conv_bwd_gemm, shm_sp + 16896, lds_sp, "k_conv_bwd_gemm");
+        hipLaunchKernelGGL(k_conv_bwd_gemm, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm_sp, s, dy, relu_mask, WTpack, gz, du, R, dp);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_conv_bwd_dwln(const float* __restrict__ du, const float* __restrict__ xin,
@@ -421,8 +436,8 @@ void launch_conv_bwd_dwln(const float* du, const float* xin, const float* dy, co
                           const float* dw_w, const float* extra, float* dx, float* p_lng, float* p_lnb, float* p_dw,
                           int R, int L, hipStream_t s) {
     const size_t shm = (size_t)((2 * (TILE_M + 2 * HALO) + 2 * TILE_M) * LDP + 1792) * sizeof(float);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k_conv_bwd_dwln, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); attr = true; }
+    static size_t lds_ok = 0;
+    ensure_dynamic_lds((const void*)k_conv_bwd_dwln, shm, lds_ok, "k_conv_bwd_dwln");
     hipLaunchKernelGGL(k_conv_bwd_dwln, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm, s, du, xin, dy, ln_g, ln_b, dw_w, extra,
                        dx, p_lng, p_lnb, p_dw, R, L);
 }
@@ -477,8 +492,13 @@ __global__ __launch_bounds__(256) void k_attn_out_bwd(const float* __restrict__ 
 }
 void launch_attn_out_bwd(const float* dy, const float* dy2, const float* r, const float* ln_g, const float* WTpack, float* g_o,
                          float* dr, float* p_lng, float* p_lnb, int R, Drop d4, Drop d5, hipStream_t s) {
-    hipLaunchKernelGGL(k_attn_out_bwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), 0, s, dy, dy2, r, ln_g, WTpack, g_o, dr, p_lng,
+    {
+        static size_t lds_sp = 0;
+        const size_t shm_sp = spread_lds(0, 33792, (R + TILE_M - 1) / TILE_M);
+        ensure_dynamic_lds((const void*)k_attn_out_bwd, shm_sp + 33792, lds_sp, "k_attn_out_bwd");
+        hipLaunchKernelGGL(k_attn_out_bwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm_sp, s, dy, dy2, r, ln_g, WTpack, g_o, dr, p_lng,
                        p_lnb, R, d4, d5);
+    }
 }
 
 // dQ: wave owns 16 queries (lane: query qi = lane & 15, key group g = lane >> 4), K/V head slices in LDS.
@@ -641,12 +661,9 @@ void launch_attn_bwd(const float* Q, const float* K, const float* V, const float
     const int Lp = (L + 15) & ~15;
     const int kst = head_slice_stride(Lp);
     const size_t shm1 = (size_t)(2 * Lp * kst + Lp) * sizeof(float), shm2 = (size_t)(2 * Lp * kst + 2 * Lp) * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)k_attn_bwd_dq, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)k_attn_bwd_dkv, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
-    }
+    static size_t lds_ok1 = 0, lds_ok2 = 0;
+    ensure_dynamic_lds((const void*)k_attn_bwd_dq, shm1, lds_ok1, "k_attn_bwd_dq");
+    ensure_dynamic_lds((const void*)k_attn_bwd_dkv, shm2, lds_ok2, "k_attn_bwd_dkv");
     hipLaunchKernelGGL(k_attn_bwd_dq, dim3((L + 63) / 64, H, B), dim3(256), shm1, s, Q, K, V, att, dr, lse, mask, dQ, Dq, L, H,
                        b_off, d2, d3);
     hipLaunchKernelGGL(k_attn_bwd_dkv, dim3((L + 63) / 64, H, B), dim3(256), shm2, s, Q, K, V, dr, lse, Dq, mask, dK, dV, L, H,
@@ -698,8 +715,8 @@ void launch_qkv_bwd(const float* dQ, const float* dK, const float* dV, const flo
                     const float* ln_g, const float* WTpack, float* dx, float* p_lng, float* p_lnb, int R, Drop d1,
                     hipStream_t s) {
     const size_t shm = (size_t)(TILE_M * QKVP + 2 * TILE_M * LDP) * sizeof(float);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k_qkv_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr = true; }
+    static size_t lds_ok = 0;
+    ensure_dynamic_lds((const void*)k_qkv_bwd, shm, lds_ok, "k_qkv_bwd");
     hipLaunchKernelGGL(k_qkv_bwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm, s, dQ, dK, dV, x, dr, ln_g, WTpack, dx, p_lng,
                        p_lnb, R, d1);
 }
@@ -792,8 +809,13 @@ __global__ __launch_bounds__(256) void k_cqcat_bwd(const float* __restrict__ dg0
 void launch_cqcat_bwd(const float* dg0, const float* dg1, const float* dg2, const float* dh_loss, const float* f2,
                       const float* hscore, const float* wh, const float* W1Tpack, float* df2, float* df1, float* p_wh,
                       float* p_bh, int R, hipStream_t s) {
-    hipLaunchKernelGGL(k_cqcat_bwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), 0, s, dg0, dg1, dg2, dh_loss, f2, hscore, wh,
+    {
+        static size_t lds_sp = 0;
+        const size_t shm_sp = spread_lds(0, 33920, (R + TILE_M - 1) / TILE_M);
+        ensure_dynamic_lds((const void*)k_cqcat_bwd, shm_sp + 33920, lds_sp, "k_cqcat_bwd");
+        hipLaunchKernelGGL(k_cqcat_bwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm_sp, s, dg0, dg1, dg2, dh_loss, f2, hscore, wh,
                        W1Tpack, df2, df1, p_wh, p_bh, R);
+    }
 }
 
 // =========================================================================================================
@@ -895,8 +917,8 @@ void launch_cq_out_bwd(const float* df1, const float* C, const float* Qf, const 
                        const float* WTpack, float* dC, float* dc2q, float* dq2c, float* dSr, int B, int T, int Lq,
                        hipStream_t s) {
     const size_t shm = (size_t)(TILE_M * CATP + TILE_M * LDP + TILE_M * Lq + TILE_M * (Lq + 1)) * sizeof(float);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k_cq_out_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    static size_t lds_ok = 0;
+    ensure_dynamic_lds((const void*)k_cq_out_bwd, shm, lds_ok, "k_cq_out_bwd");
     hipLaunchKernelGGL(k_cq_out_bwd, dim3((T + TILE_M - 1) / TILE_M, B), dim3(256), shm, s, df1, C, Qf, Srow, M, WTpack, dC, dc2q,
                        dq2c, dSr, T, Lq);
 }
@@ -930,20 +952,33 @@ __global__ __launch_bounds__(256) void k_cq_col_bwd(CqColBwdArgs a) {
     const int ntile = (T + TILE_M - 1) / TILE_M;
 
     // ---- (1) dM[j][c] = sum_i Srow[i][j] dq2c[i][c] ; dQ(c2q)[j][c] = sum_i Srow[i][j] dc2q[i][c]
-    for (int jb = j0; jb < j1; jb += 8) {
-        float am[8], aq[8];
+    //      clips walked in bulk-staged 32-row tiles (Cs <- dq2c tile, Cd <- dc2q tile, St <- S_row tile)
+    {
+        float am[MAX_LQ / 2], aq[MAX_LQ / 2];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { am[q] = 0.f; aq[q] = 0.f; }
-        for (int t = 0; t < T; ++t) {
-            const float x3 = a.dq2c[(crow + t) * D + c], x1 = a.dc2q[(crow + t) * D + c];
-            const float* sr = a.Srow + (crow + t) * Lq + jb;
+        for (int q = 0; q < MAX_LQ / 2; ++q) { am[q] = 0.f; aq[q] = 0.f; }
+        for (int tl = 0; tl < ntile; ++tl) {
+            const int t0 = tl * TILE_M, nr = min(TILE_M, T - t0);
+            load_tile128(Cs, a.dq2c + crow * D, t0, TILE_M, T);
+            load_tile128(Cd, a.dc2q + crow * D, t0, TILE_M, T);
+            for (int e = tid; e < TILE_M * Lq; e += 256) {
+                const int i = e / Lq, j = e - i * Lq;
+                St[i * LQ1 + j] = i < nr ? a.Srow[(crow + t0) * Lq + e] : 0.f;
+            }
+            __syncthreads();
+#pragma unroll 4
+            for (int i = 0; i < TILE_M; ++i) {
+                const float x3 = Cs[i * LDP + c], x1 = Cd[i * LDP + c];
+                const float* sr = St + i * LQ1 + j0;
 #pragma unroll
-            for (int q = 0; q < 8; ++q)
-                if (jb + q < j1) { am[q] += sr[q] * x3; aq[q] += sr[q] * x1; }
+                for (int q = 0; q < MAX_LQ / 2; ++q)
+                    if (q < j1 - j0) { am[q] += sr[q] * x3; aq[q] += sr[q] * x1; }
+            }
+            __syncthreads();
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q)
-            if (jb + q < j1) { dMs[(jb + q) * LDP + c] = am[q]; dQs[(jb + q) * LDP + c] = aq[q]; }
+        for (int q = 0; q < MAX_LQ / 2; ++q)
+            if (q < j1 - j0) { dMs[(j0 + q) * LDP + c] = am[q]; dQs[(j0 + q) * LDP + c] = aq[q]; }
     }
     for (int e = tid; e < Lq * D; e += 256) {
         const int j = e >> 7, cc = e & 127;
@@ -957,6 +992,10 @@ __global__ __launch_bounds__(256) void k_cq_col_bwd(CqColBwdArgs a) {
     for (int tl = 0; tl < ntile; ++tl) {
         const int t0 = tl * TILE_M;
         load_tile128(Cs, a.C + crow * D, t0, TILE_M, T);
+        for (int e = tid; e < TILE_M * Lq; e += 256) {
+            const int i = e / Lq, j = e - i * Lq;
+            St[i * LQ1 + j] = t0 + i < T ? a.Scol[(crow + t0) * Lq + e] : 0.f;
+        }
         __syncthreads();
         {
             const int i = tid >> 3;
@@ -973,7 +1012,7 @@ __global__ __launch_bounds__(256) void k_cq_col_bwd(CqColBwdArgs a) {
         __syncthreads();
         if (tid < Lq) {
             float acc = 0.f;
-            for (int i = 0; i < TILE_M && t0 + i < T; ++i) acc += Sg[i * LQ1 + tid] * a.Scol[(crow + t0 + i) * Lq + tid];
+            for (int i = 0; i < TILE_M && t0 + i < T; ++i) acc += Sg[i * LQ1 + tid] * St[i * LQ1 + tid];
             csum[tid] += acc;
         }
         __syncthreads();
@@ -1062,20 +1101,41 @@ __global__ __launch_bounds__(256) void k_cq_col_bwd(CqColBwdArgs a) {
         dQs[j * LDP + cc] += cs2[j] * a.w4Q[cc] * drop_mul(a.dq, (uint32_t)(((b + a.b_off) * Lq + j) * D + cc));
     }
     // ---- (4) pooled-query path: pb = W2 pooled + bcat ; pooled = sum_j alpha_j Q[j] ; alpha = softmax(Q w + mask)
+    //      both 128-long reductions run with 8 independent loads in flight per thread and both thread halves busy
+    {
+        const int o = tid & 127, hh = tid >> 7;
+        float s8[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s8[q] = 0.f;
+        for (int t = hh * 8; t < T; t += 16) {            // dpb[o] = sum_t df2[b, t, o]
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (t + q < T) s8[q] += a.df2[(crow + t + q) * D + o];
+        }
+        v128[2 * D + hh * D + o] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+    }
+    __syncthreads();
     if (tid < D) {
-        float s = 0.f;
-        for (int t = 0; t < T; ++t) s += a.df2[(crow + t) * D + tid];
+        const float s = v128[2 * D + tid] + v128[3 * D + tid];
         v128[tid] = s;                                   // dpb[o]
         a.p_bcat[(size_t)b * D + tid] = s;
     }
     __syncthreads();
     for (int e = tid; e < D * D; e += 256)                // dW2[o][c] = dpb[o] * pooled[c]
         a.p_W2[(size_t)b * D * D + e] = v128[e >> 7] * a.pooled[(size_t)b * D + (e & 127)];
-    if (tid < D) {
-        float s = 0.f;
-        for (int o = 0; o < D; ++o) s += a.Wcat[(size_t)o * 2 * D + D + tid] * v128[o];
-        v128[D + tid] = s;                               // dpooled[c]
+    {
+        const int cc = tid & 127, hh = tid >> 7;
+        float s8[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s8[q] = 0.f;
+        for (int o = hh * 64; o < hh * 64 + 64; o += 8) { // dpooled[c] = sum_o Wcat[o][128 + c] * dpb[o]
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s8[q] += a.Wcat[(size_t)(o + q) * 2 * D + D + cc] * v128[o + q];
+        }
+        v128[2 * D + hh * D + cc] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
     }
+    __syncthreads();
+    if (tid < D) v128[D + tid] = v128[2 * D + tid] + v128[3 * D + tid];          // dpooled[c]
     __syncthreads();
     for (int j = w; j < Lq; j += 4) {                     // dalpha_j = dpooled . Q[j]
         const float* qr = a.Qf + (qrow + j) * D;
@@ -1093,6 +1153,7 @@ __global__ __launch_bounds__(256) void k_cq_col_bwd(CqColBwdArgs a) {
     __syncthreads();
     if (tid < D) {
         float s = 0.f;
+#pragma unroll 8
         for (int j = 0; j < Lq; ++j) s += sv[j] * a.Qf[(qrow + j) * D + tid];
         a.p_pool[(size_t)b * D + tid] = s;
     }
@@ -1104,8 +1165,8 @@ __global__ __launch_bounds__(256) void k_cq_col_bwd(CqColBwdArgs a) {
 void launch_cq_col_bwd(const CqColBwdArgs& a, int B, hipStream_t s) {
     const int Lq = a.Lq;
     const size_t shm = (size_t)(3 * Lq * LDP + 2 * TILE_M * LDP + 2 * TILE_M * (Lq + 1) + 2 * Lq + TILE_M + 4 * D + Lq) * sizeof(float);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k_cq_col_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    static size_t lds_ok = 0;
+    ensure_dynamic_lds((const void*)k_cq_col_bwd, shm, lds_ok, "k_cq_col_bwd");
     hipLaunchKernelGGL(k_cq_col_bwd, dim3(B), dim3(256), shm, s, a);
 }
 
@@ -1261,8 +1322,8 @@ void launch_embed_bwd(const float* dE, const int64_t* word_ids, const int64_t* c
                       float* p_unk, int Rq, int Lc, int word_dim, int char_dim, int char_size, Drop dw, Drop dc,
                       hipStream_t s) {
     const size_t shm = (size_t)(((char_dim * 300 + 3) & ~3) + MAX_LC * 64 + 128 + char_size * char_dim) * sizeof(float);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k_embed_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    static size_t lds_ok = 0;
+    ensure_dynamic_lds((const void*)k_embed_bwd, shm, lds_ok, "k_embed_bwd");
     hipLaunchKernelGGL(k_embed_bwd, dim3((Rq + EMB_CHUNK - 1) / EMB_CHUNK), dim3(256), shm, s, dE, word_ids, char_ids, E, argpos,
                        char_tab, cc, p_cw, p_cb, p_tab, p_unk, Rq, Lc, word_dim, char_dim, char_size, dw, dc);
 }

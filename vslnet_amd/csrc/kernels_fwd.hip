@@ -97,7 +97,12 @@ __global__ __launch_bounds__(256) void k_vproj_fwd(const float* __restrict__ X, 
 }
 void launch_vproj_fwd(const float* X, const float* Wpack, const float* bias, float* Y, int R, int Dv, Drop dp,
                       hipStream_t s) {
-    hipLaunchKernelGGL(k_vproj_fwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), 0, s, X, Wpack, bias, Y, R, Dv, dp);
+    {
+        static size_t lds_sp = 0;
+        const size_t shm_sp = spread_lds(0, 33792, (R + TILE_M - 1) / TILE_M);
+        ensure_dynamic_lds((const void*)k_vproj_fwd, shm_sp + 33792, lds_sp, "k_vproj_fwd");
+        hipLaunchKernelGGL(k_vproj_fwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm_sp, s, X, Wpack, bias, Y, R, Dv, dp);
+    }
 }
 
 // =========================================================================================================
@@ -207,7 +212,12 @@ __global__ __launch_bounds__(256) void k_linear_fwd(const float* __restrict__ A,
     }
 }
 void launch_linear_fwd(const float* A, const float* Wpack, const float* bias, float* Y, int R, int K, hipStream_t s) {
-    hipLaunchKernelGGL(k_linear_fwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), 0, s, A, Wpack, bias, Y, R, K);
+    {
+        static size_t lds_sp = 0;
+        const size_t shm_sp = spread_lds(0, 16896, (R + TILE_M - 1) / TILE_M);
+        ensure_dynamic_lds((const void*)k_linear_fwd, shm_sp + 16896, lds_sp, "k_linear_fwd");
+        hipLaunchKernelGGL(k_linear_fwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm_sp, s, A, Wpack, bias, Y, R, K);
+    }
 }
 
 // =========================================================================================================
@@ -303,8 +313,13 @@ void launch_conv_layer_fwd(const float* xin, const float* pos, float* x0_out, co
                            const float* dw_w, const float* Wpack, const float* pw_b, float* y_out, float* u_out,
                            uint32_t* relu_mask, int R, int L, Drop dp, hipStream_t s) {
     const size_t shm = (size_t)(2 * (TILE_M + 2 * HALO) + TILE_M) * LDP * sizeof(float);
-    hipLaunchKernelGGL(k_conv_layer_fwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm, s, xin, pos, x0_out, ln_g, ln_b,
+    {
+        static size_t lds_sp = 0;
+        const size_t shm_sp = spread_lds(shm, 0, (R + TILE_M - 1) / TILE_M);
+        ensure_dynamic_lds((const void*)k_conv_layer_fwd, shm_sp + 0, lds_sp, "k_conv_layer_fwd");
+        hipLaunchKernelGGL(k_conv_layer_fwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm_sp, s, xin, pos, x0_out, ln_g, ln_b,
                        dw_w, Wpack, pw_b, y_out, u_out, relu_mask, R, L, dp);
+    }
 }
 
 // =========================================================================================================
@@ -348,8 +363,13 @@ __global__ __launch_bounds__(256) void k_ln_qkv_fwd(const float* __restrict__ x,
 void launch_ln_qkv_fwd(const float* x, const float* ln_g, const float* ln_b, const float* Wpack, const float* bq,
                        const float* bk, const float* bv, float* h1, float* q, float* k, float* v, int R, Drop d1,
                        hipStream_t s) {
-    hipLaunchKernelGGL(k_ln_qkv_fwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), 0, s, x, ln_g, ln_b, Wpack, bq, bk, bv, h1, q,
+    {
+        static size_t lds_sp = 0;
+        const size_t shm_sp = spread_lds(0, 16896, (R + TILE_M - 1) / TILE_M);
+        ensure_dynamic_lds((const void*)k_ln_qkv_fwd, shm_sp + 16896, lds_sp, "k_ln_qkv_fwd");
+        hipLaunchKernelGGL(k_ln_qkv_fwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm_sp, s, x, ln_g, ln_b, Wpack, bq, bk, bv, h1, q,
                        k, v, R, d1);
+    }
 }
 
 // =========================================================================================================
@@ -445,8 +465,8 @@ void launch_attn_fwd(const float* Q, const float* K, const float* V, const float
     const int Lp = (L + 15) & ~15;
     const int kst = head_slice_stride(Lp);
     const size_t shm = (size_t)(2 * Lp * kst + Lp) * sizeof(float);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k_attn_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    static size_t lds_ok = 0;
+    ensure_dynamic_lds((const void*)k_attn_fwd, shm, lds_ok, "k_attn_fwd");
     hipLaunchKernelGGL(k_attn_fwd, dim3((L + 63) / 64, H, B), dim3(256), shm, s, Q, K, V, mask, att, lse, L, H, b_off, d2);
 }
 
@@ -505,8 +525,13 @@ __global__ __launch_bounds__(256) void k_attn_out_fwd(const float* __restrict__ 
 void launch_attn_out_fwd(const float* att, const float* x, const float* ln_g, const float* ln_b, const float* Wpack,
                          const float* bo, float* r_out, float* h2_out, float* y_out, int R, Drop d3, Drop d4, Drop d5,
                          hipStream_t s) {
-    hipLaunchKernelGGL(k_attn_out_fwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), 0, s, att, x, ln_g, ln_b, Wpack, bo, r_out,
+    {
+        static size_t lds_sp = 0;
+        const size_t shm_sp = spread_lds(0, 33792, (R + TILE_M - 1) / TILE_M);
+        ensure_dynamic_lds((const void*)k_attn_out_fwd, shm_sp + 33792, lds_sp, "k_attn_out_fwd");
+        hipLaunchKernelGGL(k_attn_out_fwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm_sp, s, att, x, ln_g, ln_b, Wpack, bo, r_out,
                        h2_out, y_out, R, d3, d4, d5);
+    }
 }
 
 // =========================================================================================================
@@ -599,51 +624,72 @@ __global__ __launch_bounds__(256) void k_cq_col(const float* __restrict__ C, con
                                                 const float* __restrict__ Wcat, const float* __restrict__ bcat,
                                                 float* __restrict__ Scol, float* __restrict__ M, float* __restrict__ alpha,
                                                 float* __restrict__ pooled, float* __restrict__ pb, int T, int Lq) {
+    // one workgroup per sample; the clips are walked in 32-row tiles that are bulk-staged through LDS (every global
+    // access is a coalesced tile load with many requests in flight -- no per-clip dependent loads)
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* cmax = smem;              // [Lq]
-    float* cinv = cmax + Lq;         // [Lq]
-    float* red = cinv + Lq;          // [256]
-    float* al = red + 256;           // [Lq]
-    float* pl = al + Lq;             // [128]
+    const int LQ1 = Lq + 1;
+    float* Cs = smem;                   // [32][LDP]  C tile
+    float* Ss = Cs + TILE_M * LDP;      // [32][LQ1]  masked score tile -> S_col tile
+    float* cmax = Ss + TILE_M * LQ1;    // [Lq]
+    float* cinv = cmax + Lq;            // [Lq]
+    float* al = cinv + Lq;              // [Lq]
+    float* pl = al + Lq;                // [128]
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int b = blockIdx.x;
     const size_t crow = (size_t)b * T, qrow = (size_t)b * Lq;
-    // ---- column statistics over the clips: one wave per column j
-    for (int j = w; j < Lq; j += 4) {
-        float mx = -3.0e38f;
-        for (int t = lane; t < T; t += 64) mx = fmaxf(mx, S[(crow + t) * Lq + j] + (1.f - cmask[crow + t]) * MASK_VALUE);
-        mx = wave_max(mx);
-        float sm = 0.f;
-        for (int t = lane; t < T; t += 64) sm += __expf(S[(crow + t) * Lq + j] + (1.f - cmask[crow + t]) * MASK_VALUE - mx);
-        sm = wave_sum(sm);
-        if (lane == 0) { cmax[j] = mx; cinv[j] = 1.0f / sm; }
-    }
-    __syncthreads();
-    for (int e = tid; e < T * Lq; e += 256) {
-        const int t = e / Lq, j = e - t * Lq;
-        Scol[crow * Lq + e] = __expf(S[crow * Lq + e] + (1.f - cmask[crow + t]) * MASK_VALUE - cmax[j]) * cinv[j];
-    }
-    __syncthreads();    // Scol of this sample is re-read below by other threads of this workgroup (same CU: L1-coherent)
-    // ---- M[j][c] = sum_t Scol[t][j] * C[t][c] : thread = (c, half of the j range)
-    {
-        const int c = tid & 127, jh = tid >> 7;
-        const int jn = (Lq + 1) / 2, j0 = jh * jn, j1 = min(Lq, j0 + jn);
-        for (int jb = j0; jb < j1; jb += 8) {
-            float acc[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) acc[q] = 0.f;
-            for (int t = 0; t < T; ++t) {
-                const float cv = C[(crow + t) * D + c];
-                const float* sr = Scol + (crow + t) * Lq + jb;
-#pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    if (jb + q < j1) acc[q] += sr[q] * cv;
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-                if (jb + q < j1) M[(qrow + jb + q) * D + c] = acc[q];
+    const int ntile = (T + TILE_M - 1) / TILE_M;
+    // ---- pass 1: running (max, sum) per query word over the clips
+    float rm = -3.0e38f, rs = 0.f;      // owned by thread j = tid < Lq
+    for (int tl = 0; tl < ntile; ++tl) {
+        const int t0 = tl * TILE_M, nr = min(TILE_M, T - t0);
+        for (int e = tid; e < nr * Lq; e += 256) {
+            const int i = e / Lq, j = e - i * Lq;
+            Ss[i * LQ1 + j] = S[(crow + t0) * Lq + e] + (1.f - cmask[crow + t0 + i]) * MASK_VALUE;
         }
+        __syncthreads();
+        if (tid < Lq) {
+            float mx = rm;
+            for (int i = 0; i < nr; ++i) mx = fmaxf(mx, Ss[i * LQ1 + tid]);
+            float sm = rs * __expf(rm - mx);
+            for (int i = 0; i < nr; ++i) sm += __expf(Ss[i * LQ1 + tid] - mx);
+            rm = mx; rs = sm;
+        }
+        __syncthreads();
     }
+    if (tid < Lq) { cmax[tid] = rm; cinv[tid] = 1.0f / rs; }
+    __syncthreads();
+    // ---- pass 2: S_col tile (written out) and M[j][c] = sum_t S_col[t][j] C[t][c]; thread = (c, half of the words)
+    const int c = tid & 127, jh = tid >> 7;
+    const int jn = (Lq + 1) / 2, j0 = jh * jn, j1 = min(Lq, j0 + jn);
+    float macc[MAX_LQ / 2];
+#pragma unroll
+    for (int q = 0; q < MAX_LQ / 2; ++q) macc[q] = 0.f;
+    for (int tl = 0; tl < ntile; ++tl) {
+        const int t0 = tl * TILE_M, nr = min(TILE_M, T - t0);
+        load_tile128(Cs, C + crow * D, t0, TILE_M, T);
+        for (int e = tid; e < TILE_M * Lq; e += 256) {
+            const int i = e / Lq, j = e - i * Lq;
+            float v = 0.f;
+            if (i < nr) {
+                v = __expf(S[(crow + t0) * Lq + e] + (1.f - cmask[crow + t0 + i]) * MASK_VALUE - cmax[j]) * cinv[j];
+                Scol[(crow + t0) * Lq + e] = v;
+            }
+            Ss[i * LQ1 + j] = v;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int i = 0; i < TILE_M; ++i) {
+            const float cv = Cs[i * LDP + c];
+            const float* sr = Ss + i * LQ1 + j0;
+#pragma unroll
+            for (int q = 0; q < MAX_LQ / 2; ++q)
+                if (q < j1 - j0) macc[q] += sr[q] * cv;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < MAX_LQ / 2; ++q)
+        if (q < j1 - j0) M[(qrow + j0 + q) * D + c] = macc[q];
     // ---- WeightedPool: alpha = softmax_j(Q[j].w + mask) ; pooled = sum_j alpha_j Q[j]
     for (int j = w; j < Lq; j += 4) {
         const float* row = Qf + (qrow + j) * D;
@@ -667,17 +713,25 @@ __global__ __launch_bounds__(256) void k_cq_col(const float* __restrict__ C, con
         pooled[(size_t)b * D + tid] = acc;
     }
     __syncthreads();
-    // ---- pb[o] = sum_c Wcat[o][128 + c] * pooled[c] + bcat[o]     (second half of the 2d -> d Conv1D)
-    for (int o = w; o < D; o += 4) {
-        const float* wr = Wcat + (size_t)o * 2 * D + D;
-        const float d = wave_sum(wr[lane] * pl[lane] + wr[lane + 64] * pl[lane + 64]);
-        if (lane == 0) pb[(size_t)b * D + o] = d + bcat[o];
+    // ---- pb[o] = sum_c Wcat[o][128 + c] * pooled[c] + bcat[o]     (second half of the 2d -> d Conv1D); 8 lanes per row
+    for (int o = tid >> 3; o < D; o += 32) {
+        const int sub = tid & 7;
+        const float* wr = Wcat + (size_t)o * 2 * D + D + sub * 4;
+        float d = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 wv = *reinterpret_cast<const float4*>(wr + 32 * q);
+            const float4 pv = *reinterpret_cast<const float4*>(pl + sub * 4 + 32 * q);
+            d += wv.x * pv.x + wv.y * pv.y + wv.z * pv.z + wv.w * pv.w;
+        }
+        d = grp8_sum(d);
+        if (sub == 0) pb[(size_t)b * D + o] = d + bcat[o];
     }
 }
 void launch_cq_col(const float* C, const float* Qf, const float* S, const float* cmask, const float* qmask,
                    const float* pool_w, const float* Wcat, const float* bcat, float* Scol, float* M, float* alpha,
                    float* pooled, float* pb, int B, int T, int Lq, hipStream_t s) {
-    const size_t shm = (size_t)(3 * Lq + 256 + D) * sizeof(float);
+    const size_t shm = (size_t)(TILE_M * LDP + TILE_M * (Lq + 1) + 3 * Lq + D + 8) * sizeof(float);
     hipLaunchKernelGGL(k_cq_col, dim3(B), dim3(256), shm, s, C, Qf, S, cmask, qmask, pool_w, Wcat, bcat, Scol, M, alpha,
                        pooled, pb, T, Lq);
 }
@@ -753,8 +807,8 @@ __global__ __launch_bounds__(256) void k_cq_out(const float* __restrict__ C, con
 void launch_cq_out(const float* C, const float* Qf, const float* Srow, const float* M, const float* Wpack,
                    const float* bias, float* cat_out, float* out, int B, int T, int Lq, hipStream_t s) {
     const size_t shm = (size_t)(TILE_M * CATP + TILE_M * LDP + TILE_M * Lq) * sizeof(float);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k_cq_out, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    static size_t lds_ok = 0;
+    ensure_dynamic_lds((const void*)k_cq_out, shm, lds_ok, "k_cq_out");
     hipLaunchKernelGGL(k_cq_out, dim3((T + TILE_M - 1) / TILE_M, B), dim3(256), shm, s, C, Qf, Srow, M, Wpack, bias, cat_out, out, T, Lq);
 }
 
@@ -823,8 +877,13 @@ __global__ __launch_bounds__(256) void k_cqcat_fwd(const float* __restrict__ f1,
 }
 void launch_cqcat_fwd(const float* f1, const float* Wpack, const float* pb, const float* wh, const float* bh,
                       const float* vmask, float* f2, float* hscore, float* gated, int R, int T, hipStream_t s) {
-    hipLaunchKernelGGL(k_cqcat_fwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), 0, s, f1, Wpack, pb, wh, bh, vmask, f2, hscore,
+    {
+        static size_t lds_sp = 0;
+        const size_t shm_sp = spread_lds(0, 33920, (R + TILE_M - 1) / TILE_M);
+        ensure_dynamic_lds((const void*)k_cqcat_fwd, shm_sp + 33920, lds_sp, "k_cqcat_fwd");
+        hipLaunchKernelGGL(k_cqcat_fwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm_sp, s, f1, Wpack, pb, wh, bh, vmask, f2, hscore,
                        gated, R, T);
+    }
 }
 
 // =========================================================================================================
@@ -894,7 +953,12 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadArgs a0, HeadArgs a1, cons
 }
 void launch_head_fwd(const HeadArgs& a0, const HeadArgs& a1, const float* x, const float* vmask, int R, hipStream_t s) {
     const size_t shm = (size_t)(TILE_M * HDP + TILE_M * LDP) * sizeof(float);
-    hipLaunchKernelGGL(k_head_fwd, dim3((R + TILE_M - 1) / TILE_M, 2), dim3(256), shm, s, a0, a1, x, vmask, R);
+    {
+        static size_t lds_sp = 0;
+        const size_t shm_sp = spread_lds(shm, 0, (R + TILE_M - 1) / TILE_M);
+        ensure_dynamic_lds((const void*)k_head_fwd, shm_sp + 0, lds_sp, "k_head_fwd");
+        hipLaunchKernelGGL(k_head_fwd, dim3((R + TILE_M - 1) / TILE_M, 2), dim3(256), shm_sp, s, a0, a1, x, vmask, R);
+    }
 }
 
 }  // namespace vsl

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include "common.hpp"
 
 namespace vsl {
@@ -73,6 +75,37 @@ struct ReduceSeg {        // grads[dst + (i / rl) * ds + i % rl] = sum over sour
     int vec;                      // 1: n, every src, ss and vn are multiples of 4 floats -> 16-byte loads/stores
     int vn[4];                    // source q contributes to elements i < vn[q] only (shorter sequences of a shared table)
 };
+
+// Opt a kernel into more than the default 64 KiB of dynamic LDS.  Requests exactly what the launch needs (static LDS
+// counts against the same 160 KiB), grows monotonically, and reports -- instead of silently poisoning
+// hipGetLastError() -- when the runtime refuses.
+inline void ensure_dynamic_lds(const void* func, size_t bytes, size_t& granted, const char* name) {
+    if (bytes <= granted || bytes <= 64 * 1024) return;
+    const hipError_t e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) {
+        fprintf(stderr, "[vslnet_hip] hipFuncSetAttribute(%s, %zu B dynamic LDS) failed: %s\n", name, bytes, hipGetErrorString(e));
+        (void)hipGetLastError();
+    } else {
+        granted = bytes;
+    }
+}
+
+// Workgroup spreading: the row-tile kernels launch about one 256-thread workgroup per CU (R / 32 = 256 at the headline
+// shape).  Several such workgroups fit one CU, and when the dispatcher co-locates them they serialise on that CU's four
+// matrix pipes while other CUs idle.  Requesting > 80 KiB of LDS per workgroup makes them mutually exclusive per CU.
+// Measured (profiles/r01_b_*): no gain alone and it blocks cross-stream co-residency, so it is OFF by default;
+// VSL_LDS_SPREAD=<bytes> (e.g. 86016) re-enables it for A/B runs.
+inline size_t lds_spread_bytes() {
+    static long v = -1;
+    if (v < 0) { const char* e = getenv("VSL_LDS_SPREAD"); v = e ? atol(e) : 0; }
+    return (size_t)v;
+}
+// dynamic-LDS size to launch with: at least `need`, padded so that static + dynamic >= the spread target
+inline size_t spread_lds(size_t need, size_t static_bytes, int nblocks) {
+    const size_t tgt = lds_spread_bytes();
+    if (tgt == 0 || nblocks > 2 * 256) return need;           // plenty of workgroups: let them share CUs
+    return (static_bytes + need >= tgt) ? need : tgt - static_bytes;
+}
 
 // ---------------------------------------------------------------- forward
 void launch_pack(const float* params, float* pack, const PackJob* jobs_dev, int njobs, hipStream_t s);
@@ -154,7 +187,7 @@ void launch_embed_bwd(const float* dE, const int64_t* word_ids, const int64_t* c
                       Drop dc, hipStream_t s);
 void launch_reduce(const float* ws, float* grads, const ReduceSeg* segs_dev, const int* blk2seg_dev, int nblocks,
                    hipStream_t s);
-constexpr int EMB_CHUNK = 8;     // query words per workgroup in the embedding backward
+constexpr int EMB_CHUNK = 4;     // query words per workgroup in the embedding backward
 constexpr int CHARW_TOTAL = 15000;
 
 }  // namespace vsl

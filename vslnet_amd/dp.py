@@ -1,0 +1,83 @@
+"""Data-parallel training of the VSLNet path: one process per GPU, `torch.distributed` (backend "nccl" == RCCL over
+xGMI on ROCm; "gloo" for the CPU tests).  The reference has no distributed code at all (single `--gpu_idx`,
+main_t7.py:31,66-67), so there is no call pattern to mirror; this is the scheme SURVEY.md 8(e) derives:
+
+  * the global minibatch is split contiguously, B / N samples per rank; every shard is padded to the GLOBAL max T / Lq
+    (the logits depend on the padded length -- SURVEY section 5 "pad-sensitivity");
+  * losses use the GLOBAL normalisers (1 / B_global for the two CrossEntropy means, sum(v_mask) over the whole batch for
+    the highlight loss) -- both known on the host before the step -- so per-rank gradients are plain partial sums;
+  * ONE all-reduce(sum) of the flat fp32 gradient bucket per step (0.5 - 1.1 M floats = 2 - 4.4 MB: latency-bound, one
+    RCCL call, no bucketing, nothing to overlap it with that is worth the complexity);
+  * identical clip-by-global-norm + AdamW on every rank (replicated 2.7 MB of weights).
+"""
+import math
+
+import torch
+
+
+def shard_slice(global_batch, rank, world):
+    """Contiguous split (sizes differ by at most one when B % N != 0)."""
+    base, rem = divmod(global_batch, world)
+    lo = rank * base + min(rank, rem)
+    return slice(lo, lo + base + (1 if rank < rem else 0))
+
+
+def shard_batch(batch, rank, world):
+    """Slice every per-sample tensor of a collated batch (dict of tensors with leading dim B).  The padded widths are left
+    untouched: the shard keeps the global max T / Lq / Lc."""
+    B = next(iter(batch.values())).shape[0]
+    s = shard_slice(B, rank, world)
+    return {k: (v[s].contiguous() if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == B else v) for k, v in batch.items()}
+
+
+def global_normalisers(lens_global):
+    """(1 / B_global, sum of the global video mask) from the host-side clip counts of the WHOLE batch
+    (vfeat_lens of train_collate_fn, data_loader_t7.py:33-34) -- no collective needed."""
+    return 1.0 / float(len(lens_global)), float(sum(int(x) for x in lens_global))
+
+
+def allreduce_flat_(flat_grads, group=None):
+    """The one exchange step: sum the flat gradient bucket over all ranks, in place."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=group)
+    return flat_grads
+
+
+class FlatAdamW:
+    """clip_grad_norm_(1.0) + AdamW + linear decay (main_t7.py:111-113, VSLNet_t7.py:8-17) on the FLAT buckets: six
+    element-wise passes over one 2.7 MB tensor instead of ~100 small per-parameter launches.  Weight decay 0.01 except
+    for names containing bias / layer_norm / LayerNorm (a 0/1 mask over the bucket).  Host-side helper (torch ops);
+    the fused HIP version is listed as 'next' in DESIGN.md."""
+
+    def __init__(self, flat, layout, lr, num_train_steps, warmup_proportion=0.0, clip_norm=1.0, betas=(0.9, 0.999), eps=1e-6,
+                 weight_decay=0.01):
+        self.flat, self.lr0, self.N, self.clip = flat, lr, float(num_train_steps), clip_norm
+        self.warm = float(num_train_steps) * warmup_proportion
+        self.b1, self.b2, self.eps = betas[0], betas[1], eps
+        self.m, self.v = torch.zeros_like(flat), torch.zeros_like(flat)
+        self.wd = torch.zeros_like(flat)
+        for name, off, numel, _ in layout:
+            if not any(k in name for k in ('bias', 'layer_norm', 'LayerNorm')):
+                self.wd[off:off + numel] = weight_decay
+        self.t = 0
+
+    def lr(self):
+        n = self.t
+        if n < self.warm:
+            return self.lr0 * n / max(1.0, self.warm)
+        return self.lr0 * max(0.0, (self.N - n) / max(1.0, self.N - self.warm))
+
+    @torch.no_grad()
+    def step(self, grads):
+        gn = float(torch.linalg.vector_norm(grads))
+        if self.clip and gn > self.clip:
+            grads = grads * (self.clip / (gn + 1e-6))
+        lr = self.lr()
+        self.t += 1
+        self.m.mul_(self.b1).add_(grads, alpha=1 - self.b1)
+        self.v.mul_(self.b2).addcmul_(grads, grads, value=1 - self.b2)
+        bc1, bc2 = 1 - self.b1 ** self.t, 1 - self.b2 ** self.t
+        self.flat.mul_(1 - lr * self.wd)
+        self.flat.addcdiv_(self.m, (self.v / bc2).sqrt_().add_(self.eps), value=-lr / bc1)
+        return gn
