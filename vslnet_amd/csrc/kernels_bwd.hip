@@ -928,6 +928,7 @@ void launch_cq_out_bwd(const float* df1, const float* C, const float* Qf, const 
 //   dM, dQ(c2q) ; column-softmax backward ; trilinear-score backward (w4C, w4Q, w4mlu, dC, dQ) ;
 //   WeightedPool + pooled-query bias backward.
 // =========================================================================================================
+#define CQ_STAMP(k) do { if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) a.dbg[k] = clock64(); } while (0)
 __global__ __launch_bounds__(256) void k_cq_col_bwd(CqColBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int T = a.T, Lq = a.Lq;
@@ -950,7 +951,9 @@ __global__ __launch_bounds__(256) void k_cq_col_bwd(CqColBwdArgs a) {
     const int c = tid & 127, hf = tid >> 7;
     const int jn = (Lq + 1) / 2, j0 = hf * jn, j1 = min(Lq, j0 + jn);
     const int ntile = (T + TILE_M - 1) / TILE_M;
+    const int nj_u = __builtin_amdgcn_readfirstlane(j1 - j0);      // words owned by this thread half: wave-uniform
 
+    CQ_STAMP(0);
     // ---- (1) dM[j][c] = sum_i Srow[i][j] dq2c[i][c] ; dQ(c2q)[j][c] = sum_i Srow[i][j] dc2q[i][c]
     //      clips walked in bulk-staged 32-row tiles (Cs <- dq2c tile, Cd <- dc2q tile, St <- S_row tile)
     {
@@ -966,13 +969,20 @@ __global__ __launch_bounds__(256) void k_cq_col_bwd(CqColBwdArgs a) {
                 St[i * LQ1 + j] = i < nr ? a.Srow[(crow + t0) * Lq + e] : 0.f;
             }
             __syncthreads();
-#pragma unroll 4
-            for (int i = 0; i < TILE_M; ++i) {
-                const float x3 = Cs[i * LDP + c], x1 = Cd[i * LDP + c];
-                const float* sr = St + i * LQ1 + j0;
+            // chunks of 8 words behind a WAVE-UNIFORM guard, unconditional inner body (a per-element predicate keeps the
+            // compiler from batching the LDS reads); reads past this thread's word range hit valid LDS and the
+            // corresponding accumulators are never stored
 #pragma unroll
-                for (int q = 0; q < MAX_LQ / 2; ++q)
-                    if (q < j1 - j0) { am[q] += sr[q] * x3; aq[q] += sr[q] * x1; }
+            for (int qc = 0; qc < MAX_LQ / 16; ++qc) {
+                if (qc * 8 < nj_u) {
+#pragma unroll 4
+                    for (int i = 0; i < TILE_M; ++i) {
+                        const float x3 = Cs[i * LDP + c], x1 = Cd[i * LDP + c];
+                        const float* sr = St + i * LQ1 + j0 + qc * 8;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) { am[qc * 8 + q] += sr[q] * x3; aq[qc * 8 + q] += sr[q] * x1; }
+                    }
+                }
             }
             __syncthreads();
         }
@@ -987,6 +997,7 @@ __global__ __launch_bounds__(256) void k_cq_col_bwd(CqColBwdArgs a) {
     if (tid < Lq) { csum[tid] = 0.f; cs2[tid] = 0.f; }
     __syncthreads();
 
+    CQ_STAMP(1);
     // ---- (2) sweep 1: dSt[i][j] = dM[j] . C[i] -> scratch ; csum[j] = sum_i dSt[i][j] * Scol[i][j]
     float* dS = a.scratch + crow * Lq;
     for (int tl = 0; tl < ntile; ++tl) {
@@ -1018,6 +1029,7 @@ __global__ __launch_bounds__(256) void k_cq_col_bwd(CqColBwdArgs a) {
         __syncthreads();
     }
 
+    CQ_STAMP(2);
     // ---- (3) sweep 2: full dS tile, then the trilinear backward
     float acc_w4C = 0.f, acc_mlu = 0.f;       // per-thread partials for channel c over this thread's rows
     for (int tl = 0; tl < ntile; ++tl) {
@@ -1043,45 +1055,71 @@ __global__ __launch_bounds__(256) void k_cq_col_bwd(CqColBwdArgs a) {
         if (tid >= 64 && tid < 64 + Lq) { const int j = tid - 64; float s = 0.f; for (int i = 0; i < TILE_M; ++i) s += Sg[i * LQ1 + j]; cs2[j] += s; }
         __syncthreads();
         {
-            // rows of this thread: hf * 16 .. + 15 ; channel c
+            // rows of this thread: hf * 16 .. + 15 ; channel c.  The direct part of dC is read up front (16 independent
+            // loads in flight) -- a read-modify-write inside the loop would serialise on memory latency.
             const float wC = a.w4C[c], wM = a.w4mlu[c];
-            for (int rr = hf * 16; rr < hf * 16 + 16; ++rr) {
-                const int t = t0 + rr;
-                if (t >= T) break;
-                float tq = 0.f, tm = 0.f;
-                for (int j = 0; j < Lq; ++j) {
-                    tq += Sg[rr * LQ1 + j] * Qds[j * LDP + c];        // sum_j dS[i][j] Qd[j][c]
-                    tm += St[rr * LQ1 + j] * dMs[j * LDP + c];        // sum_j Scol[i][j] dM[j][c]   (M = Scol^T C)
+            float dcv[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int t = t0 + hf * 16 + q;
+                dcv[q] = t < T ? a.dC[(crow + t) * D + c] : 0.f;
+            }
+            float tq[16], tm[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { tq[q] = 0.f; tm[q] = 0.f; }
+            for (int j = 0; j < Lq; ++j) {
+                const float qv = Qds[j * LDP + c], mv = dMs[j * LDP + c];
+                const float* sg = Sg + hf * 16 * LQ1 + j;
+                const float* st = St + hf * 16 * LQ1 + j;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    tq[q] += sg[q * LQ1] * qv;                        // sum_j dS[i][j] Qd[j][c]
+                    tm[q] += st[q * LQ1] * mv;                        // sum_j Scol[i][j] dM[j][c]   (M = Scol^T C)
                 }
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int rr = hf * 16 + q;
+                const int t = t0 + rr;
                 const float cdv = Cd[rr * LDP + c];
-                const float dcd = rsum[rr] * wC + wM * tq;            // grad wrt dropped-out C
+                const float dcd = rsum[rr] * wC + wM * tq[q];         // grad wrt dropped-out C
                 acc_w4C += rsum[rr] * cdv;
-                acc_mlu += tq * cdv;
-                const size_t o = (crow + t) * D + c;
-                a.dC[o] = a.dC[o] + tm + dcd * drop_mul(a.dc, (uint32_t)(((b + a.b_off) * T + t) * D + c));
+                acc_mlu += tq[q] * cdv;
+                dcv[q] += tm[q] + dcd * drop_mul(a.dc, (uint32_t)(((b + a.b_off) * T + t) * D + c));
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int t = t0 + hf * 16 + q;
+                if (t < T) a.dC[(crow + t) * D + c] = dcv[q];
             }
         }
         // dQ[j][c] += mask_q[j][c] * w4mlu[c] * sum_i dS[i][j] Cd[i][c]      (thread owns (c, its half of the words))
         {
             const float wM = a.w4mlu[c];
-            for (int jb = j0; jb < j1; jb += 8) {
-                float acc[8];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) acc[q] = 0.f;
-                for (int i = 0; i < TILE_M; ++i) {
-                    const float cv = Cd[i * LDP + c] * wM;
+            for (int qc = 0; qc < MAX_LQ / 16; ++qc) {
+                if (qc * 8 < nj_u) {
+                    float acc[8];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q)
-                        if (jb + q < j1) acc[q] += Sg[i * LQ1 + jb + q] * cv;
+                    for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+#pragma unroll 4
+                    for (int i = 0; i < TILE_M; ++i) {
+                        const float cv = Cd[i * LDP + c] * wM;
+                        const float* sg = Sg + i * LQ1 + j0 + qc * 8;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) acc[q] += sg[q] * cv;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int j = j0 + qc * 8 + q;
+                        if (j < j1) dQs[j * LDP + c] += acc[q] * drop_mul(a.dq, (uint32_t)(((b + a.b_off) * Lq + j) * D + c));
+                    }
                 }
-#pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    if (jb + q < j1)
-                        dQs[(jb + q) * LDP + c] += acc[q] * drop_mul(a.dq, (uint32_t)(((b + a.b_off) * Lq + jb + q) * D + c));
             }
         }
         __syncthreads();
     }
+    CQ_STAMP(3);
     // combine the two row-halves of the per-channel accumulators
     v128[hf * D + c] = acc_w4C;
     v128[2 * D + hf * D + c] = acc_mlu;
@@ -1100,6 +1138,7 @@ __global__ __launch_bounds__(256) void k_cq_col_bwd(CqColBwdArgs a) {
         const int j = e >> 7, cc = e & 127;
         dQs[j * LDP + cc] += cs2[j] * a.w4Q[cc] * drop_mul(a.dq, (uint32_t)(((b + a.b_off) * Lq + j) * D + cc));
     }
+    CQ_STAMP(4);
     // ---- (4) pooled-query path: pb = W2 pooled + bcat ; pooled = sum_j alpha_j Q[j] ; alpha = softmax(Q w + mask)
     //      both 128-long reductions run with 8 independent loads in flight per thread and both thread halves busy
     {
@@ -1157,17 +1196,32 @@ __global__ __launch_bounds__(256) void k_cq_col_bwd(CqColBwdArgs a) {
         for (int j = 0; j < Lq; ++j) s += sv[j] * a.Qf[(qrow + j) * D + tid];
         a.p_pool[(size_t)b * D + tid] = s;
     }
+    CQ_STAMP(5);
     for (int e = tid; e < Lq * D; e += 256) {
         const int j = e >> 7, cc = e & 127;
         a.dQ[(qrow + j) * D + cc] = dQs[j * LDP + cc] + a.alpha[qrow + j] * v128[D + cc] + sv[j] * a.pool_w[cc];
     }
+    CQ_STAMP(6);
 }
 void launch_cq_col_bwd(const CqColBwdArgs& a, int B, hipStream_t s) {
     const int Lq = a.Lq;
     const size_t shm = (size_t)(3 * Lq * LDP + 2 * TILE_M * LDP + 2 * TILE_M * (Lq + 1) + 2 * Lq + TILE_M + 4 * D + Lq) * sizeof(float);
     static size_t lds_ok = 0;
     ensure_dynamic_lds((const void*)k_cq_col_bwd, shm, lds_ok, "k_cq_col_bwd");
-    hipLaunchKernelGGL(k_cq_col_bwd, dim3(B), dim3(256), shm, s, a);
+    static long long* dbg = nullptr;
+    static int dbg_left = -1;
+    if (dbg_left < 0) { dbg_left = getenv("VSL_DEBUG_TIMING") ? 2 : 0; if (dbg_left) (void)hipMalloc(&dbg, 64 * sizeof(long long)); }
+    CqColBwdArgs a2 = a;
+    a2.dbg = dbg_left > 0 ? dbg : nullptr;
+    hipLaunchKernelGGL(k_cq_col_bwd, dim3(B), dim3(256), shm, s, a2);
+    if (dbg_left > 0) {
+        long long hst[8];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(hst, dbg, sizeof hst, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[cq_col_bwd cycles] step1 %lld | sweep1 %lld | sweep2 %lld | combine %lld | pooled %lld | tail %lld | total %lld\n",
+                hst[1] - hst[0], hst[2] - hst[1], hst[3] - hst[2], hst[4] - hst[3], hst[5] - hst[4], hst[6] - hst[5], hst[6] - hst[0]);
+        --dbg_left;
+    }
 }
 
 // =========================================================================================================

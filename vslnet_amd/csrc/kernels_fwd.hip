@@ -661,6 +661,7 @@ __global__ __launch_bounds__(256) void k_cq_col(const float* __restrict__ C, con
     // ---- pass 2: S_col tile (written out) and M[j][c] = sum_t S_col[t][j] C[t][c]; thread = (c, half of the words)
     const int c = tid & 127, jh = tid >> 7;
     const int jn = (Lq + 1) / 2, j0 = jh * jn, j1 = min(Lq, j0 + jn);
+    const int nj_u = __builtin_amdgcn_readfirstlane(j1 - j0);
     float macc[MAX_LQ / 2];
 #pragma unroll
     for (int q = 0; q < MAX_LQ / 2; ++q) macc[q] = 0.f;
@@ -677,13 +678,17 @@ __global__ __launch_bounds__(256) void k_cq_col(const float* __restrict__ C, con
             Ss[i * LQ1 + j] = v;
         }
         __syncthreads();
-#pragma unroll 4
-        for (int i = 0; i < TILE_M; ++i) {
-            const float cv = Cs[i * LDP + c];
-            const float* sr = Ss + i * LQ1 + j0;
 #pragma unroll
-            for (int q = 0; q < MAX_LQ / 2; ++q)
-                if (q < j1 - j0) macc[q] += sr[q] * cv;
+        for (int qc = 0; qc < MAX_LQ / 16; ++qc) {
+            if (qc * 8 < nj_u) {                   // wave-uniform guard, unconditional body (see k_cq_col_bwd)
+#pragma unroll 4
+                for (int i = 0; i < TILE_M; ++i) {
+                    const float cv = Cs[i * LDP + c];
+                    const float* sr = Ss + i * LQ1 + j0 + qc * 8;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) macc[qc * 8 + q] += sr[q] * cv;
+                }
+            }
         }
         __syncthreads();
     }

@@ -177,6 +177,7 @@ struct CqColBwdArgs {
     float *scratch;       // (B, T*Lq) workspace for dS
     int T, Lq, b_off;
     Drop dc, dq;
+    long long* dbg;       // optional phase timestamps (VSL_DEBUG_TIMING)
 };
 void launch_cq_col_bwd(const CqColBwdArgs& a, int B, hipStream_t s);
 void launch_linear_bwd_data(const float* G, const float* WTpack, float* dA, int R, int K, hipStream_t s);
@@ -187,7 +188,7 @@ void launch_embed_bwd(const float* dE, const int64_t* word_ids, const int64_t* c
                       Drop dc, hipStream_t s);
 void launch_reduce(const float* ws, float* grads, const ReduceSeg* segs_dev, const int* blk2seg_dev, int nblocks,
                    hipStream_t s);
-constexpr int EMB_CHUNK = 4;     // query words per workgroup in the embedding backward
+constexpr int EMB_CHUNK = 8;     // query words per workgroup in the embedding backward
 constexpr int CHARW_TOTAL = 15000;
 
 }  // namespace vsl
