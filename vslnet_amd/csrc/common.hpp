@@ -114,16 +114,63 @@ __device__ __forceinline__ void gemm32(const float* __restrict__ As, int lda, in
 template <int NT, int KB>
 struct BFrag { float4 b[NT][KB]; };
 
+// k-block rotation: workgroup g visits the k-blocks of a stage-aligned GEMM in the order (kb + rot(g)) mod nkb, so the
+// 256 workgroups that start together do not all hammer the same L2 lines of the (shared) weight at the same instant.
+// Only the fp32 summation order changes.  Enabled when nkb is a multiple of KB (every fixed-K GEMM of the model).
+__device__ __forceinline__ int kb_rot(int nkb) {
+#ifdef VSL_NO_KROT
+    return 0;
+#else
+    return (int)((blockIdx.x * 5u + blockIdx.y * 3u) % (unsigned)nkb);
+#endif
+}
 template <int NT, int KB>
 __device__ __forceinline__ void bfrag_load(BFrag<NT, KB>& f, const float* __restrict__ Bp, int ncols, int col0, int cstep,
                                            int kb0, int nkb) {
     const int lane = threadIdx.x & 63;
     const float4* bp = reinterpret_cast<const float4*>(Bp) + (size_t)(col0 + (lane & 31)) * 2 + (lane >> 5);
+    if (kb0 + KB <= nkb) {                 // full stage: straight-line loads (all in flight together)
+        const int rot = (nkb % KB == 0) ? kb_rot(nkb) : 0;
 #pragma unroll
-    for (int q = 0; q < KB; ++q)
+        for (int q = 0; q < KB; ++q) {
+            int kb = kb0 + q + rot;
+            kb = kb >= nkb ? kb - nkb : kb;
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
-            f.b[t][q] = kb0 + q < nkb ? bp[((size_t)(kb0 + q) * ncols + t * cstep) * 2] : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int t = 0; t < NT; ++t) f.b[t][q] = bp[((size_t)kb * ncols + t * cstep) * 2];
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < KB; ++q)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                f.b[t][q] = kb0 + q < nkb ? bp[((size_t)(kb0 + q) * ncols + t * cstep) * 2] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+template <int NT, int KB>
+__device__ __forceinline__ void mma_stage(const float* __restrict__ arow, int kb0, int rot, int nkb, const BFrag<NT, KB>& cur,
+                                          f32x16 (&acc)[NT]) {
+    constexpr int AB = KB < 8 ? KB : 8;   // A fragments are read from LDS in batches of up to 8 blocks
+#pragma unroll
+    for (int q0 = 0; q0 < KB; q0 += AB) {
+        float4 a[AB];
+#pragma unroll
+        for (int q = 0; q < AB; ++q) {
+            int kb = kb0 + q0 + q + rot;
+            kb = kb >= nkb ? kb - nkb : kb;
+            a[q] = *reinterpret_cast<const float4*>(arow + kb * 8);
+        }
+#pragma unroll
+        for (int q = 0; q < AB; ++q)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float4 b = cur.b[t][q0 + q];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, b.x, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, b.y, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, b.z, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, b.w, acc[t], 0, 0, 0);
+            }
+    }
 }
 
 template <int NT, int KB>
@@ -132,30 +179,36 @@ __device__ __forceinline__ void gemm32p(const float* __restrict__ As, int lda, i
     const int lane = threadIdx.x & 63;
     const float* arow = As + (lane & 31) * lda + 4 * (lane >> 5);
     const int nkb = K >> 3;
+    const int nfull = nkb / KB;            // stages whose KB k-blocks all exist: straight-line code, no per-block guard
+    const int rot = (nkb % KB == 0) ? kb_rot(nkb) : 0;
     BFrag<NT, KB> nxt;
-    for (int kb0 = 0; kb0 < nkb; kb0 += KB) {
+    for (int st = 0; st < nfull; ++st) {
+        const int kb0 = st * KB;
         const bool more = kb0 + KB < nkb;
         if (more) bfrag_load(nxt, Bp, ncols, col0, cstep, kb0 + KB, nkb);
-#pragma unroll
-        for (int q = 0; q < KB; ++q) {
-            if (kb0 + q < nkb) {
-                const float4 a = *reinterpret_cast<const float4*>(arow + (kb0 + q) * 8);
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const float4 b = cur.b[t][q];
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[t], 0, 0, 0);
-                }
-            }
-        }
+        mma_stage<NT, KB>(arow, kb0, rot, nkb, cur, acc);
         if (more) {
 #pragma unroll
             for (int q = 0; q < KB; ++q)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) cur.b[t][q] = nxt.b[t][q];
         }
+    }
+    for (int kb = nfull * KB; kb < nkb; ++kb) {         // ragged tail (K = 400): fragment q = kb - nfull*KB was zero-filled beyond nkb
+        const float4 a = *reinterpret_cast<const float4*>(arow + kb * 8);
+        const int q = kb - nfull * KB;
+#pragma unroll
+        for (int qq = 0; qq < KB; ++qq)
+            if (qq == q) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const float4 b = cur.b[t][qq];
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[t], 0, 0, 0);
+                }
+            }
     }
 }
 
@@ -351,15 +404,22 @@ __device__ __forceinline__ void ln_bwd_tile(float* Ts, float* Xs, const float* _
 // ---------------------------------------------------------------------------------------------------------
 // tile I/O
 // ---------------------------------------------------------------------------------------------------------
-// loads `nrows` rows x 128 floats starting at global row `row0` into LDS (stride LDP); rows outside [0, R) -> 0
+// loads `nrows` (<= 40) rows x 128 floats starting at global row `row0` into LDS (stride LDP); rows outside [0, R) -> 0.
+// All of a thread's 16-byte loads are issued before the first LDS store, so the tile costs ONE memory latency.
 __device__ __forceinline__ void load_tile128(float* __restrict__ dst, const float* __restrict__ src, int row0, int nrows,
                                              int R) {
-    for (int e = threadIdx.x; e < nrows * (D / 4); e += NTHREADS) {
-        const int rr = e >> 5, c4 = e & 31;
-        const int r = row0 + rr;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r >= 0 && r < R) v = *reinterpret_cast<const float4*>(src + (size_t)r * D + c4 * 4);
-        *reinterpret_cast<float4*>(dst + rr * LDP + c4 * 4) = v;
+    float4 v[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const int e = threadIdx.x + q * NTHREADS;
+        const int r = row0 + (e >> 5);
+        v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e < nrows * 32 && r >= 0 && r < R) v[q] = *reinterpret_cast<const float4*>(src + (size_t)r * D + (e & 31) * 4);
+    }
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const int e = threadIdx.x + q * NTHREADS;
+        if (e < nrows * 32) *reinterpret_cast<float4*>(dst + (e >> 5) * LDP + (e & 31) * 4) = v[q];
     }
 }
 

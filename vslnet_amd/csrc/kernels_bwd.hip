@@ -7,6 +7,27 @@
 
 namespace vsl {
 
+// VSL_DEBUG_TIMING: block 0 / thread 0 of an instrumented kernel stamps the shader clock at its phase boundaries
+__device__ long long g_stamps[32];
+#define STAMP(k) do { if (g_dbg_on && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_stamps[k] = clock64(); } while (0)
+__device__ int g_dbg_on = 0;
+static int dbg_budget(const char* name) {
+    static int inited = 0, on = 0;
+    if (!inited) { inited = 1; on = getenv("VSL_DEBUG_TIMING") != nullptr; if (on) { int one = 1; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_on), &one, sizeof one); } }
+    (void)name;
+    return on;
+}
+static void dbg_report(const char* name, int nst, hipStream_t s, int& left) {
+    if (left <= 0) return;
+    long long h[32];
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamps), sizeof h);
+    fprintf(stderr, "[%s cycles]", name);
+    for (int i = 1; i < nst; ++i) fprintf(stderr, " %lld", h[i] - h[i - 1]);
+    fprintf(stderr, " | total %lld\n", h[nst - 1] - h[0]);
+    --left;
+}
+
 // =========================================================================================================
 // a13 + a16 losses (layers_t7.py:291-299, 365-369) and their seeds d(total)/d(logits), d(total)/d(h_score)
 //   total = w_loc * (CE(start) + CE(end)) + w_hl * highlight      (main_t7.py:105-107 uses 1, 5)
@@ -166,10 +187,10 @@ __global__ __launch_bounds__(256) void k_head_bwd(HeadBwdArgs a0, HeadBwdArgs a1
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int r0 = blockIdx.x * TILE_M;
     BFrag<2, 8> bf;
-    bfrag_load(bf, a.W0Tpack, 2 * D, 32 * w, D, 0, D / 8);
     if (tid < TILE_M) dl[tid] = r0 + tid < R ? a.dlogit[r0 + tid] : 0.f;
     load_tile128(Hs, a.hid, r0, TILE_M, R);
     load_tile128(Fs, a.feat, r0, TILE_M, R);
+    bfrag_load(bf, a.W0Tpack, 2 * D, 32 * w, D, 0, D / 8);
     __syncthreads();
     for (int e = tid; e < TILE_M * 32; e += 256) {
         const int rr = e >> 5, c = (e & 31) * 4;
@@ -332,34 +353,57 @@ __global__ __launch_bounds__(256) void k_conv_bwd_gemm(const float* __restrict__
     __shared__ __attribute__((aligned(16))) float Gs[TILE_M * LDP];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int r0 = blockIdx.x * TILE_M;
+    STAMP(0);
     BFrag<1, 16> bf;
-    bfrag_load(bf, WTpack, D, 32 * w, 0, 0, D / 8);
-    for (int e = tid; e < TILE_M * 32; e += 256) {
-        const int rr = e >> 5, c = (e & 31) * 4;
-        const int r = r0 + rr;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < R) {
-            v = *reinterpret_cast<const float4*>(dy + (size_t)r * D + c);
-            const uint32_t bits = relu_mask[(size_t)r * 4 + (c >> 5)] >> (c & 31);
-            const uint32_t base = (uint32_t)(r * D + c);
-            v.x = (bits & 1u) ? v.x * drop_mul(dp, base) : 0.f;
-            v.y = (bits & 2u) ? v.y * drop_mul(dp, base + 1) : 0.f;
-            v.z = (bits & 4u) ? v.z * drop_mul(dp, base + 2) : 0.f;
-            v.w = (bits & 8u) ? v.w * drop_mul(dp, base + 3) : 0.f;
-            *reinterpret_cast<float4*>(gz + (size_t)r * D + c) = v;
+    {
+        float4 dv[4];
+        uint32_t mb[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + q * 256;
+            const int r = r0 + (e >> 5), c = (e & 31) * 4;
+            dv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            mb[q] = 0u;
+            if (r < R) {
+                dv[q] = *reinterpret_cast<const float4*>(dy + (size_t)r * D + c);
+                mb[q] = relu_mask[(size_t)r * 4 + (c >> 5)];
+            }
         }
-        *reinterpret_cast<float4*>(&Gs[rr * LDP + c]) = v;
+        // weight fragments are requested AFTER the tile: vector loads return in order, so the wait for the tile below
+        // does not include them and they keep streaming in behind the LDS stores / barrier
+        bfrag_load(bf, WTpack, D, 32 * w, 0, 0, D / 8);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + q * 256;
+            const int rr = e >> 5, c = (e & 31) * 4;
+            const int r = r0 + rr;
+            float4 v = dv[q];
+            if (r < R) {
+                const uint32_t bits = mb[q] >> (c & 31);
+                const uint32_t base = (uint32_t)(r * D + c);
+                v.x = (bits & 1u) ? v.x * drop_mul(dp, base) : 0.f;
+                v.y = (bits & 2u) ? v.y * drop_mul(dp, base + 1) : 0.f;
+                v.z = (bits & 4u) ? v.z * drop_mul(dp, base + 2) : 0.f;
+                v.w = (bits & 8u) ? v.w * drop_mul(dp, base + 3) : 0.f;
+                *reinterpret_cast<float4*>(gz + (size_t)r * D + c) = v;
+            }
+            *reinterpret_cast<float4*>(&Gs[rr * LDP + c]) = v;
+        }
     }
+    STAMP(1);
     __syncthreads();
+    STAMP(2);
     f32x16 acc[1];
     zero_acc(acc);
     gemm32p<1, 16>(Gs, LDP, D, WTpack, D, 32 * w, 0, acc, bf);
+    STAMP(3);
     const int col = 32 * w + (lane & 31);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int gr = r0 + acc_row(r, lane);
         if (gr < R) du[(size_t)gr * D + col] = acc[0][r];
     }
+    STAMP(4);
 }
 void launch_conv_bwd_gemm(const float* dy, const uint32_t* relu_mask, const float* WTpack, float* gz, float* du, int R,
                           Drop dp, hipStream_t s) {
@@ -368,6 +412,8 @@ void launch_conv_bwd_gemm(const float* dy, const uint32_t* relu_mask, const floa
         const size_t shm_sp = spread_lds(0, 16896, (R + TILE_M - 1) / TILE_M);
         ensure_dynamic_lds((const void*)k_conv_bwd_gemm, shm_sp + 16896, lds_sp, "k_conv_bwd_gemm");
         hipLaunchKernelGGL(k_conv_bwd_gemm, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm_sp, s, dy, relu_mask, WTpack, gz, du, R, dp);
+        static int left = 2;
+        if (dbg_budget("conv_bwd_gemm") && R > 4096) dbg_report("conv_bwd_gemm: loads-issued | landed+sync | gemm | stores", 5, s, left);
     }
 }
 
@@ -388,14 +434,8 @@ __global__ __launch_bounds__(256) void k_conv_bwd_dwln(const float* __restrict__
     const int tid = threadIdx.x;
     const int r0 = blockIdx.x * TILE_M;
     load_tile128(DUs, du, r0 - HALO, NH, R);
-    for (int e = tid; e < NH * 32; e += 256) {
-        const int rr = e >> 5, c = (e & 31) * 4;
-        const int r = r0 - HALO + rr;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r >= 0 && r < R) v = *reinterpret_cast<const float4*>(xin + (size_t)r * D + c);
-        *reinterpret_cast<float4*>(&Vs[rr * LDP + c]) = v;
-        if (rr >= HALO && rr < HALO + TILE_M) *reinterpret_cast<float4*>(&Xc[(rr - HALO) * LDP + c]) = v;
-    }
+    load_tile128(Vs, xin, r0 - HALO, NH, R);
+    load_tile128(Xc, xin, r0, TILE_M, R);
     __syncthreads();
     ln_tile(Vs, NH, LDP, ln_g, ln_b, Drop{0u, 0u, 1.f}, 0);
     __syncthreads();
@@ -458,24 +498,38 @@ __global__ __launch_bounds__(256) void k_attn_out_bwd(const float* __restrict__ 
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int r0 = blockIdx.x * TILE_M;
     BFrag<1, 16> bf;
-    bfrag_load(bf, WTpack, D, 32 * w, 0, 0, D / 8);
-    load_tile128(Xs, r_in, r0, TILE_M, R);
-    for (int e = tid; e < TILE_M * 32; e += 256) {
-        const int rr = e >> 5, c = (e & 31) * 4;
-        const int r = r0 + rr;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < R) {
-            v = *reinterpret_cast<const float4*>(dy + (size_t)r * D + c);
-            if (dy2) { const float4 t = *reinterpret_cast<const float4*>(dy2 + (size_t)r * D + c); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
-            if (d5.thresh) {
-                const uint32_t base = (uint32_t)(r * D + c);
-                v.x *= drop_mul(d5, base); v.y *= drop_mul(d5, base + 1);
-                v.z *= drop_mul(d5, base + 2); v.w *= drop_mul(d5, base + 3);
+    {
+        float4 a1[4], a2[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + q * 256;
+            const int r = r0 + (e >> 5), c = (e & 31) * 4;
+            a1[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            a2[q] = a1[q];
+            if (r < R) {
+                a1[q] = *reinterpret_cast<const float4*>(dy + (size_t)r * D + c);
+                if (dy2) a2[q] = *reinterpret_cast<const float4*>(dy2 + (size_t)r * D + c);
             }
-            *reinterpret_cast<float4*>(g_o + (size_t)r * D + c) = v;       // G operand of the out_layer weight gradient
         }
-        *reinterpret_cast<float4*>(&Gs[rr * LDP + c]) = v;
+        bfrag_load(bf, WTpack, D, 32 * w, 0, 0, D / 8);     // after the tile (in-order return), before the LN input tile
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + q * 256;
+            const int rr = e >> 5, c = (e & 31) * 4;
+            const int r = r0 + rr;
+            float4 v = make_float4(a1[q].x + a2[q].x, a1[q].y + a2[q].y, a1[q].z + a2[q].z, a1[q].w + a2[q].w);
+            if (r < R) {
+                if (d5.thresh) {
+                    const uint32_t base = (uint32_t)(r * D + c);
+                    v.x *= drop_mul(d5, base); v.y *= drop_mul(d5, base + 1);
+                    v.z *= drop_mul(d5, base + 2); v.w *= drop_mul(d5, base + 3);
+                }
+                *reinterpret_cast<float4*>(g_o + (size_t)r * D + c) = v;       // G operand of the out_layer weight gradient
+            }
+            *reinterpret_cast<float4*>(&Gs[rr * LDP + c]) = v;
+        }
     }
+    load_tile128(Xs, r_in, r0, TILE_M, R);                  // only needed by the LayerNorm backward after the GEMM
     __syncthreads();
     f32x16 acc[1];
     zero_acc(acc);
@@ -683,21 +737,31 @@ __global__ __launch_bounds__(256) void k_qkv_bwd(const float* __restrict__ dQ, c
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int r0 = blockIdx.x * TILE_M;
     BFrag<1, 16> bf;
-    bfrag_load(bf, WTpack, D, 32 * w, 0, 0, 3 * D / 8);
-    load_tile128(Xs, x, r0, TILE_M, R);
-    for (int e = tid; e < TILE_M * 32; e += 256) {
-        const int rr = e >> 5, c = (e & 31) * 4;
-        const int r = r0 + rr;
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), bq = a, cv = a;
-        if (r < R) {
-            a = *reinterpret_cast<const float4*>(dQ + (size_t)r * D + c);
-            bq = *reinterpret_cast<const float4*>(dK + (size_t)r * D + c);
-            cv = *reinterpret_cast<const float4*>(dV + (size_t)r * D + c);
+    {
+        float4 a[4], bq[4], cv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + q * 256;
+            const int r = r0 + (e >> 5), c = (e & 31) * 4;
+            a[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            bq[q] = a[q]; cv[q] = a[q];
+            if (r < R) {
+                a[q] = *reinterpret_cast<const float4*>(dQ + (size_t)r * D + c);
+                bq[q] = *reinterpret_cast<const float4*>(dK + (size_t)r * D + c);
+                cv[q] = *reinterpret_cast<const float4*>(dV + (size_t)r * D + c);
+            }
         }
-        *reinterpret_cast<float4*>(&As[rr * QKVP + c]) = a;
-        *reinterpret_cast<float4*>(&As[rr * QKVP + D + c]) = bq;
-        *reinterpret_cast<float4*>(&As[rr * QKVP + 2 * D + c]) = cv;
+        bfrag_load(bf, WTpack, D, 32 * w, 0, 0, 3 * D / 8);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + q * 256;
+            const int rr = e >> 5, c = (e & 31) * 4;
+            *reinterpret_cast<float4*>(&As[rr * QKVP + c]) = a[q];
+            *reinterpret_cast<float4*>(&As[rr * QKVP + D + c]) = bq[q];
+            *reinterpret_cast<float4*>(&As[rr * QKVP + 2 * D + c]) = cv[q];
+        }
     }
+    load_tile128(Xs, x, r0, TILE_M, R);                     // LN1 input rows: first used after the GEMM
     __syncthreads();
     f32x16 acc[1];
     zero_acc(acc);
@@ -736,18 +800,29 @@ __global__ __launch_bounds__(256) void k_cqcat_bwd(const float* __restrict__ dg0
     __shared__ float dlg[TILE_M];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int r0 = blockIdx.x * TILE_M;
-    for (int e = tid; e < TILE_M * 32; e += 256) {
-        const int rr = e >> 5, c = (e & 31) * 4;
-        const int r = r0 + rr;
-        float4 g = make_float4(0.f, 0.f, 0.f, 0.f), f = g;
-        if (r < R) {
-            g = *reinterpret_cast<const float4*>(dg0 + (size_t)r * D + c);
-            if (dg1) { const float4 t = *reinterpret_cast<const float4*>(dg1 + (size_t)r * D + c); g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w; }
-            if (dg2) { const float4 t = *reinterpret_cast<const float4*>(dg2 + (size_t)r * D + c); g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w; }
-            f = *reinterpret_cast<const float4*>(f2 + (size_t)r * D + c);
+    {
+        float4 g0[4], g1[4], g2[4], fv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + q * 256;
+            const int r = r0 + (e >> 5), c = (e & 31) * 4;
+            g0[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            g1[q] = g0[q]; g2[q] = g0[q]; fv[q] = g0[q];
+            if (r < R) {
+                g0[q] = *reinterpret_cast<const float4*>(dg0 + (size_t)r * D + c);
+                if (dg1) g1[q] = *reinterpret_cast<const float4*>(dg1 + (size_t)r * D + c);
+                if (dg2) g2[q] = *reinterpret_cast<const float4*>(dg2 + (size_t)r * D + c);
+                fv[q] = *reinterpret_cast<const float4*>(f2 + (size_t)r * D + c);
+            }
         }
-        *reinterpret_cast<float4*>(&Gs[rr * LDP + c]) = g;
-        *reinterpret_cast<float4*>(&Fs[rr * LDP + c]) = f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + q * 256;
+            const int rr = e >> 5, c = (e & 31) * 4;
+            *reinterpret_cast<float4*>(&Gs[rr * LDP + c]) = make_float4(g0[q].x + g1[q].x + g2[q].x, g0[q].y + g1[q].y + g2[q].y,
+                                                                       g0[q].z + g1[q].z + g2[q].z, g0[q].w + g1[q].w + g2[q].w);
+            *reinterpret_cast<float4*>(&Fs[rr * LDP + c]) = fv[q];
+        }
     }
     __syncthreads();
     {
@@ -1272,8 +1347,8 @@ __global__ __launch_bounds__(256) void k_embed_bwd(const float* __restrict__ dE,
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wtot = char_dim * 300;          // 10*1 + 20*2 + 30*3 + 40*4 = 300 taps per input channel
     float* Wl = smem;                         // [wtot] conv weights, flattened conv0 | conv1 | conv2 | conv3
-    float* Ce = Wl + ((wtot + 3) & ~3);       // [MAX_LC][64] dropped char embeddings of the current word
-    float* gch = Ce + MAX_LC * 64;            // [128] grad of the 100 char features (0 where relu/max inactive)
+    float* Ce = Wl + ((wtot + 7) & ~3);       // [MAX_LC + 4][64] dropped char embeddings of the current word (+ zero rows)
+    float* gch = Ce + (MAX_LC + 4) * 64;      // [128] grad of the 100 char features (0 where relu/max inactive)
     float* tab = gch + 128;                   // [char_size][char_dim] table-gradient accumulator
     __shared__ int pos[128];
     __shared__ int obase[128];                // LDS offset of channel oc's weights
@@ -1281,6 +1356,7 @@ __global__ __launch_bounds__(256) void k_embed_bwd(const float* __restrict__ dE,
     __shared__ int cids[MAX_LC];
     const int tid = threadIdx.x;
     const int EW = word_dim + 100;
+    STAMP(0);
     {   // stage the weights + the per-channel tables
         const int s0 = 10 * char_dim, s1 = 20 * char_dim * 2, s2 = 30 * char_dim * 3;
         for (int e = tid; e < wtot; e += 256) {
@@ -1289,6 +1365,7 @@ __global__ __launch_bounds__(256) void k_embed_bwd(const float* __restrict__ dE,
             else if (e < s0 + s1 + s2) v = cc.w[2][e - s0 - s1]; else v = cc.w[3][e - s0 - s1 - s2];
             Wl[e] = v;
         }
+        if (tid < 4) Wl[wtot + tid] = 0.f;                  // zero slot for invalid taps
         if (tid < 100) {
             int k, ch, base;
             if (tid < 10) { k = 1; ch = tid; base = 0; } else if (tid < 30) { k = 2; ch = tid - 10; base = s0; }
@@ -1297,6 +1374,8 @@ __global__ __launch_bounds__(256) void k_embed_bwd(const float* __restrict__ dE,
             obase[tid] = base + ch * char_dim * k;
         }
         for (int e = tid; e < char_size * char_dim; e += 256) tab[e] = 0.f;
+        for (int e = tid; e < 4 * 64; e += 256) Ce[MAX_LC * 64 + e] = 0.f;      // zero rows read by out-of-range taps
+        if (tid >= 100 && tid < 128) { gch[tid] = 0.f; pos[tid] = 0; okk[tid] = 1; obase[tid] = 0; }
     }
     // this thread's slice of the flattened conv weights: element e -> (oc, ci, kk)
     constexpr int MAXE = 64;                  // ceil(15000 / 256) = 59
@@ -1315,12 +1394,14 @@ __global__ __launch_bounds__(256) void k_embed_bwd(const float* __restrict__ dE,
             else if ((rem -= s1) < s2) { const int ch = rem / (char_dim * 3); rem -= ch * char_dim * 3; ci = rem / 3; kk = rem % 3; oc = 30 + ch; }
             else { rem -= s2; const int ch = rem / (char_dim * 4); rem -= ch * char_dim * 4; ci = rem / 4; kk = rem % 4; oc = 60 + ch; }
         }
-        wcode[q] = (oc << 16) | (ci << 8) | kk;
+        wcode[q] = e < wtot ? ((oc << 16) | (ci << 8) | kk) : (100 << 16);      // dummy element: channel 100 has g == 0
     }
+    STAMP(1);
     float bacc = 0.f, uacc0 = 0.f, uacc1 = 0.f;
     const int rbeg = blockIdx.x * EMB_CHUNK, rend = min(Rq, rbeg + EMB_CHUNK);
     for (int r = rbeg; r < rend; ++r) {
         __syncthreads();
+        if (r == rbeg) STAMP(2);
         if (tid < Lc) cids[tid] = (int)char_ids[(size_t)r * Lc + tid];
         if (tid < 100) {
             const float v = E[(size_t)r * EW + word_dim + tid];
@@ -1337,29 +1418,31 @@ __global__ __launch_bounds__(256) void k_embed_bwd(const float* __restrict__ dE,
             Ce[p * 64 + ci] = char_tab[(size_t)cids[p] * char_dim + ci] * drop_mul(dc, (uint32_t)((r * Lc + p) * char_dim + ci));
         }
         __syncthreads();
+        if (r == rbeg) STAMP(3);
         if (tid < 100) bacc += gch[tid];
         // weight grads: dW[oc][ci][kk] += g[oc] * Ce[pos[oc] + kk][ci]
 #pragma unroll
-        for (int q = 0; q < MAXE; ++q) {
-            if (tid + q * 256 < wtot) {
-                const int oc = wcode[q] >> 16, ci = (wcode[q] >> 8) & 255, kk = wcode[q] & 255;
-                wacc[q] += gch[oc] * Ce[(pos[oc] + kk) * 64 + ci];
-            }
+        for (int q = 0; q < MAXE; ++q) {                  // no per-element predicate: the 2-level LDS reads batch up
+            const int oc = wcode[q] >> 16, ci = (wcode[q] >> 8) & 255, kk = wcode[q] & 255;
+            wacc[q] += gch[oc] * Ce[(pos[oc] + kk) * 64 + ci];
         }
+        if (r == rbeg) STAMP(4);
         // dCe[p][ci] = sum_{oc, kk : pos[oc] + kk == p} g[oc] W[oc][ci][kk] ; scattered straight into the table
         // accumulator (thread = (p, ci); two positions of one word may hold the same character -> LDS atomics)
         for (int e = tid; e < Lc * char_dim; e += 256) {
             const int p = e / char_dim, ci = e - p * char_dim;
             if (cids[p] == 0) continue;       // padding_idx = 0 (:51)
             float acc = 0.f;
-            for (int oc = 0; oc < 100; ++oc) {
-                const float g = gch[oc];
+#pragma unroll 10
+            for (int oc = 0; oc < 100; ++oc) {            // branch-free: an invalid tap reads the zero slot Wl[wtot]
                 const int kk = p - pos[oc], k = okk[oc];
-                if (g != 0.f && kk >= 0 && kk < k) acc += g * Wl[obase[oc] + ci * k + kk];
+                const int idx = (kk >= 0 && kk < k) ? obase[oc] + ci * k + kk : wtot;
+                acc += gch[oc] * Wl[idx];
             }
             atomicAdd(&tab[cids[p] * char_dim + ci], acc * drop_mul(dc, (uint32_t)((r * Lc + p) * char_dim + ci)));
         }
     }
+    STAMP(5);
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < MAXE; ++q) {
@@ -1370,16 +1453,19 @@ __global__ __launch_bounds__(256) void k_embed_bwd(const float* __restrict__ dE,
     if (tid < word_dim) p_unk[(size_t)blockIdx.x * word_dim + tid] = uacc0;
     if (tid + 256 < word_dim) p_unk[(size_t)blockIdx.x * word_dim + tid + 256] = uacc1;
     for (int e = tid; e < char_size * char_dim; e += 256) p_tab[(size_t)blockIdx.x * char_size * char_dim + e] = tab[e];
+    STAMP(6);
 }
 void launch_embed_bwd(const float* dE, const int64_t* word_ids, const int64_t* char_ids, const float* E,
                       const int8_t* argpos, const float* char_tab, CharConvPtrs cc, float* p_cw, float* p_cb, float* p_tab,
                       float* p_unk, int Rq, int Lc, int word_dim, int char_dim, int char_size, Drop dw, Drop dc,
                       hipStream_t s) {
-    const size_t shm = (size_t)(((char_dim * 300 + 3) & ~3) + MAX_LC * 64 + 128 + char_size * char_dim) * sizeof(float);
+    const size_t shm = (size_t)(((char_dim * 300 + 7) & ~3) + (MAX_LC + 4) * 64 + 128 + char_size * char_dim) * sizeof(float);
     static size_t lds_ok = 0;
     ensure_dynamic_lds((const void*)k_embed_bwd, shm, lds_ok, "k_embed_bwd");
     hipLaunchKernelGGL(k_embed_bwd, dim3((Rq + EMB_CHUNK - 1) / EMB_CHUNK), dim3(256), shm, s, dE, word_ids, char_ids, E, argpos,
                        char_tab, cc, p_cw, p_cb, p_tab, p_unk, Rq, Lc, word_dim, char_dim, char_size, dw, dc);
+    static int left = 2;
+    if (dbg_budget("embed_bwd")) dbg_report("embed_bwd: stage-weights | decode | word0 loads | word0 gather | word0 dW | rest of words | stores", 7, s, left);
 }
 
 // =========================================================================================================

@@ -239,23 +239,36 @@ __global__ __launch_bounds__(256) void k_conv_layer_fwd(const float* __restrict_
     float* Us = Vs + NH * LDP;                          // [32][LDP] depthwise output = GEMM A operand
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int r0 = blockIdx.x * TILE_M;
-    BFrag<1, 16> bf;                                    // the whole 128 x 32 weight slice of this wave, in flight now
-    bfrag_load(bf, Wpack, D, 32 * w, 0, 0, D / 8);
-    // ---- load rows r0-3 .. r0+34 (+ positional rows, :202)
-    for (int e = tid; e < NH * 32; e += 256) {
-        const int rr = e >> 5, c = (e & 31) * 4;
-        const int r = r0 - HALO + rr;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r >= 0 && r < R) {
-            v = *reinterpret_cast<const float4*>(xin + (size_t)r * D + c);
-            if (pos) {
-                const float4 pv = *reinterpret_cast<const float4*>(pos + (size_t)(r % L) * D + c);
-                v.x += pv.x; v.y += pv.y; v.z += pv.z; v.w += pv.w;
-                if (x0_out && rr >= HALO && rr < HALO + TILE_M) *reinterpret_cast<float4*>(x0_out + (size_t)r * D + c) = v;
+    BFrag<1, 16> bf;                                    // the whole 128 x 32 weight slice of this wave
+    // ---- load rows r0-3 .. r0+34 (+ positional rows, :202): all loads first, then the stores
+    {
+        float4 xv[5], pv[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const int e = tid + q * 256;
+            const int rr = e >> 5, c = (e & 31) * 4;
+            const int r = r0 - HALO + rr;
+            xv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            pv[q] = xv[q];
+            if (e < NH * 32 && r >= 0 && r < R) {
+                xv[q] = *reinterpret_cast<const float4*>(xin + (size_t)r * D + c);
+                if (pos) pv[q] = *reinterpret_cast<const float4*>(pos + (size_t)(r % L) * D + c);
             }
         }
-        *reinterpret_cast<float4*>(&Xs[rr * LDP + c]) = v;
-        *reinterpret_cast<float4*>(&Vs[rr * LDP + c]) = v;
+        // requested AFTER the tile (vector loads return in order): streams in behind the LayerNorm / depthwise prologue
+        bfrag_load(bf, Wpack, D, 32 * w, 0, 0, D / 8);
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const int e = tid + q * 256;
+            const int rr = e >> 5, c = (e & 31) * 4;
+            const int r = r0 - HALO + rr;
+            if (e < NH * 32) {
+                const float4 v = make_float4(xv[q].x + pv[q].x, xv[q].y + pv[q].y, xv[q].z + pv[q].z, xv[q].w + pv[q].w);
+                if (x0_out && r >= 0 && r < R && rr >= HALO && rr < HALO + TILE_M) *reinterpret_cast<float4*>(x0_out + (size_t)r * D + c) = v;
+                *reinterpret_cast<float4*>(&Xs[rr * LDP + c]) = v;
+                *reinterpret_cast<float4*>(&Vs[rr * LDP + c]) = v;
+            }
+        }
     }
     __syncthreads();
     // ---- LayerNorm of all 38 rows
@@ -335,8 +348,8 @@ __global__ __launch_bounds__(256) void k_ln_qkv_fwd(const float* __restrict__ x,
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int r0 = blockIdx.x * TILE_M;
     BFrag<3, 4> bf;
-    bfrag_load(bf, Wpack, 3 * D, 32 * w, D, 0, D / 8);
     load_tile128(Hs, x, r0, TILE_M, R);
+    bfrag_load(bf, Wpack, 3 * D, 32 * w, D, 0, D / 8);
     __syncthreads();
     ln_tile(Hs, TILE_M, LDP, ln_g, ln_b, d1, r0);
     __syncthreads();
@@ -483,23 +496,37 @@ __global__ __launch_bounds__(256) void k_attn_out_fwd(const float* __restrict__ 
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int r0 = blockIdx.x * TILE_M;
     BFrag<1, 16> bf;
-    bfrag_load(bf, Wpack, D, 32 * w, 0, 0, D / 8);
-    for (int e = tid; e < TILE_M * 32; e += 256) {
-        const int rr = e >> 5, c = (e & 31) * 4;
-        const int r = r0 + rr;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < R) {
-            const float4 a = *reinterpret_cast<const float4*>(att + (size_t)r * D + c);
-            const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)r * D + c);
-            const uint32_t base = (uint32_t)(r * D + c);
-            v.x = a.x * drop_mul(d3, base) + xv.x;
-            v.y = a.y * drop_mul(d3, base + 1) + xv.y;
-            v.z = a.z * drop_mul(d3, base + 2) + xv.z;
-            v.w = a.w * drop_mul(d3, base + 3) + xv.w;
-            *reinterpret_cast<float4*>(r_out + (size_t)r * D + c) = v;
+    {
+        float4 av[4], xv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + q * 256;
+            const int r = r0 + (e >> 5), c = (e & 31) * 4;
+            av[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            xv[q] = av[q];
+            if (r < R) {
+                av[q] = *reinterpret_cast<const float4*>(att + (size_t)r * D + c);
+                xv[q] = *reinterpret_cast<const float4*>(x + (size_t)r * D + c);
+            }
         }
-        *reinterpret_cast<float4*>(&Rs[rr * LDP + c]) = v;
-        *reinterpret_cast<float4*>(&Hs[rr * LDP + c]) = v;
+        bfrag_load(bf, Wpack, D, 32 * w, 0, 0, D / 8);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + q * 256;
+            const int rr = e >> 5, c = (e & 31) * 4;
+            const int r = r0 + rr;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < R) {
+                const uint32_t base = (uint32_t)(r * D + c);
+                v.x = av[q].x * drop_mul(d3, base) + xv[q].x;
+                v.y = av[q].y * drop_mul(d3, base + 1) + xv[q].y;
+                v.z = av[q].z * drop_mul(d3, base + 2) + xv[q].z;
+                v.w = av[q].w * drop_mul(d3, base + 3) + xv[q].w;
+                *reinterpret_cast<float4*>(r_out + (size_t)r * D + c) = v;
+            }
+            *reinterpret_cast<float4*>(&Rs[rr * LDP + c]) = v;
+            *reinterpret_cast<float4*>(&Hs[rr * LDP + c]) = v;
+        }
     }
     __syncthreads();
     ln_tile(Hs, TILE_M, LDP, ln_g, ln_b, d4, r0);
@@ -832,8 +859,8 @@ __global__ __launch_bounds__(256) void k_cqcat_fwd(const float* __restrict__ f1,
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int r0 = blockIdx.x * TILE_M;
     BFrag<1, 16> bf;
-    bfrag_load(bf, Wpack, D, 32 * w, 0, 0, D / 8);
     load_tile128(As, f1, r0, TILE_M, R);
+    bfrag_load(bf, Wpack, D, 32 * w, 0, 0, D / 8);
     __syncthreads();
     f32x16 acc[1];
     zero_acc(acc);
@@ -905,17 +932,27 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadArgs a0, HeadArgs a1, cons
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int r0 = blockIdx.x * TILE_M;
     BFrag<1, 16> bf;
-    bfrag_load(bf, a.W0pack, D, 32 * w, 0, 0, 2 * D / 8);
-    for (int e = tid; e < TILE_M * 32; e += 256) {
-        const int rr = e >> 5, c = (e & 31) * 4;
-        const int r = r0 + rr;
-        float4 fv = make_float4(0.f, 0.f, 0.f, 0.f), xv = fv;
-        if (r < R) {
-            fv = *reinterpret_cast<const float4*>(a.feat + (size_t)r * D + c);
-            xv = *reinterpret_cast<const float4*>(x + (size_t)r * D + c);
+    {
+        float4 fv[4], xv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + q * 256;
+            const int r = r0 + (e >> 5), c = (e & 31) * 4;
+            fv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            xv[q] = fv[q];
+            if (r < R) {
+                fv[q] = *reinterpret_cast<const float4*>(a.feat + (size_t)r * D + c);
+                xv[q] = *reinterpret_cast<const float4*>(x + (size_t)r * D + c);
+            }
         }
-        *reinterpret_cast<float4*>(&As[rr * HDP + c]) = fv;
-        *reinterpret_cast<float4*>(&As[rr * HDP + D + c]) = xv;
+        bfrag_load(bf, a.W0pack, D, 32 * w, 0, 0, 2 * D / 8);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + q * 256;
+            const int rr = e >> 5, c = (e & 31) * 4;
+            *reinterpret_cast<float4*>(&As[rr * HDP + c]) = fv[q];
+            *reinterpret_cast<float4*>(&As[rr * HDP + D + c]) = xv[q];
+        }
     }
     __syncthreads();
     if (a.ln_g) {                          // transformer head: LayerNorm on the encoder features (:347-348); rnn: none
