@@ -81,6 +81,7 @@ struct vsl_handle_s {
     int64_t pack_floats = 0;
     std::vector<PackJob> jobs;
     PackJob* jobs_dev = nullptr;
+    int* wdecode_dev = nullptr;          // flattened char-conv weight index -> (oc << 16 | ci << 8 | kk), 64 * 256 entries
     std::map<std::tuple<int, int, int, int>, Plan*> plans;
     // side streams for the independent chains (query branch, weight gradients) + fork/join events
     hipStream_t side[2] = {nullptr, nullptr};
@@ -600,7 +601,7 @@ void run_backward(Ctx& c) {
         float* p_tab = c.slab(P.char_tab, cf.char_size * cf.char_dim, nce);
         float* p_unk = c.slab(P.unk, cf.word_dim, nce);
         LAUNCH("embed_bwd", launch_embed_bwd(c.W(p.dE), io->word_ids, io->char_ids, c.W(p.E), reinterpret_cast<const int8_t*>(c.W(p.argpos)),
-                                c.P(P.char_tab), char_ptrs(c), c.part_ptr(ow), c.part_ptr(ob), p_tab, p_unk, Rq,
+                                c.P(P.char_tab), char_ptrs(c), c.h->wdecode_dev, c.part_ptr(ow), c.part_ptr(ob), p_tab, p_unk, Rq,
                                 p.Lc, cf.word_dim, cf.char_dim, cf.char_size, c.drop(SITE_WORD), c.drop(SITE_CHAR), c.s));
     }
     c.s = main_s;
@@ -738,6 +739,24 @@ int vsl_create(const vsl_config* cfg, vsl_handle* out) {
         delete h;
         return fail("hipMalloc/hipMemcpy of the pack table failed");
     }
+    {   // decode table of the flattened char-conv weights (embedding backward)
+        const int cd = cfg->char_dim, wtot = cd * 300;
+        std::vector<int> dec(64 * 256, 100 << 16);                      // dummy: channel 100 has zero gradient
+        const int ch[4] = {10, 20, 30, 40};
+        int e = 0, oc0 = 0;
+        for (int cv = 0; cv < 4; ++cv) {
+            const int k = cv + 1;
+            for (int c2 = 0; c2 < ch[cv]; ++c2)
+                for (int ci = 0; ci < cd; ++ci)
+                    for (int kk = 0; kk < k; ++kk) dec[e++] = ((oc0 + c2) << 16) | (ci << 8) | kk;
+            oc0 += ch[cv];
+        }
+        if (e != wtot || hipMalloc(&h->wdecode_dev, dec.size() * sizeof(int)) != hipSuccess ||
+            hipMemcpy(h->wdecode_dev, dec.data(), dec.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+            delete h;
+            return fail("decode table setup failed");
+        }
+    }
     {
         const char* e = getenv("VSL_MULTI_STREAM");
         h->multi_stream = !(e && e[0] == '0');
@@ -760,6 +779,7 @@ int vsl_destroy(vsl_handle h) {
         delete kv.second;
     }
     if (h->jobs_dev) (void)hipFree(h->jobs_dev);
+    if (h->wdecode_dev) (void)hipFree(h->wdecode_dev);
     delete h;
     return 0;
 }

@@ -1336,8 +1336,16 @@ void launch_linear_bwd_data(const float* G, const float* WTpack, float* dA, int 
 
 // =========================================================================================================
 // a3 / a4 backward: unk_vec gradient, char-CNN weights / biases, char table (padding_idx = 0 gets none).
-//   one workgroup per EMB_CHUNK query words; the 15000 conv weights live in LDS; partial slabs per workgroup.
+//   One workgroup per EMB_CHUNK query words.  All per-word metadata of the chunk is staged with ONE bulk load phase;
+//   the 15000 conv weights live in LDS.
+//   (i)  dW[oc][ci][kk] += g[oc] * Ce[pos[oc] + kk][ci]   thread = 25 fixed (oc, ci) pairs, 4 tap accumulators each: one
+//        (g, pos) lookup per pair and word, shared by the taps and broadcast across the 64 lanes of a channel.
+//   (ii) dCe[p][ci] = sum_oc g[oc] * W[oc][ci][p - pos[oc]]: a parallel pre-pass resolves the data-dependent part into
+//        two [p][oc] tables (gradient or 0, weight offset + tap stride), so the gather loop streams sequential LDS
+//        addresses with a single dependent level; the result is scattered per character into the table accumulator
+//        (thread = (p, ci), serial over p -> no atomics).
 // =========================================================================================================
+constexpr int EB_NP = 25;                     // (100 channels x 64 lanes) / 256 threads
 __global__ __launch_bounds__(256) void k_embed_bwd(const float* __restrict__ dE, const int64_t* __restrict__ word_ids,
                                                    const int64_t* __restrict__ char_ids, const float* __restrict__ E,
                                                    const int8_t* __restrict__ argpos, const float* __restrict__ char_tab,
@@ -1346,126 +1354,182 @@ __global__ __launch_bounds__(256) void k_embed_bwd(const float* __restrict__ dE,
                                                    int word_dim, int char_dim, int char_size, Drop dw, Drop dc) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wtot = char_dim * 300;          // 10*1 + 20*2 + 30*3 + 40*4 = 300 taps per input channel
-    float* Wl = smem;                         // [wtot] conv weights, flattened conv0 | conv1 | conv2 | conv3
-    float* Ce = Wl + ((wtot + 7) & ~3);       // [MAX_LC + 4][64] dropped char embeddings of the current word (+ zero rows)
-    float* gch = Ce + (MAX_LC + 4) * 64;      // [128] grad of the 100 char features (0 where relu/max inactive)
-    float* tab = gch + 128;                   // [char_size][char_dim] table-gradient accumulator
-    __shared__ int pos[128];
-    __shared__ int obase[128];                // LDS offset of channel oc's weights
-    __shared__ int okk[128];                  // kernel width of channel oc
-    __shared__ int cids[MAX_LC];
+    float* Wl = smem;                         // [wtot + 4] conv weights, flattened conv0 | conv1 | conv2 | conv3
+    float* Ce = Wl + ((wtot + 7) & ~3);       // [EMB_CHUNK * Lc + 4][64] dropped char embeddings (+ zero rows)
+    float* gch = Ce + (EMB_CHUNK * Lc + 4) * 64;   // [EMB_CHUNK][128] grads of the 100 char features (0 where inactive)
+    float* gt = gch + EMB_CHUNK * 128;        // [Lc][100] per-word table: g[oc] where tap p - pos[oc] is valid, else 0
+    float* tab = gt + Lc * 100;               // [4 position quarters][char_size][char_dim] table-gradient accumulators
+    int* it = reinterpret_cast<int*>(tab + 4 * char_size * char_dim);  // [Lc][100] weight offset | tap stride << 24
+    __shared__ int pos[EMB_CHUNK * 128];
+    __shared__ int cids[EMB_CHUNK * MAX_LC];
+    __shared__ int obase[128], okk[128];
     const int tid = threadIdx.x;
     const int EW = word_dim + 100;
+    const int rbeg = blockIdx.x * EMB_CHUNK, nw = min(EMB_CHUNK, Rq - rbeg);
+    const int s0 = 10 * char_dim, s1 = 20 * char_dim * 2, s2 = 30 * char_dim * 3;
     STAMP(0);
-    {   // stage the weights + the per-channel tables
-        const int s0 = 10 * char_dim, s1 = 20 * char_dim * 2, s2 = 30 * char_dim * 3;
-        for (int e = tid; e < wtot; e += 256) {
-            float v;
-            if (e < s0) v = cc.w[0][e]; else if (e < s0 + s1) v = cc.w[1][e - s0];
-            else if (e < s0 + s1 + s2) v = cc.w[2][e - s0 - s1]; else v = cc.w[3][e - s0 - s1 - s2];
-            Wl[e] = v;
-        }
-        if (tid < 4) Wl[wtot + tid] = 0.f;                  // zero slot for invalid taps
-        if (tid < 100) {
-            int k, ch, base;
-            if (tid < 10) { k = 1; ch = tid; base = 0; } else if (tid < 30) { k = 2; ch = tid - 10; base = s0; }
-            else if (tid < 60) { k = 3; ch = tid - 30; base = s0 + s1; } else { k = 4; ch = tid - 60; base = s0 + s1 + s2; }
-            okk[tid] = k;
-            obase[tid] = base + ch * char_dim * k;
-        }
-        for (int e = tid; e < char_size * char_dim; e += 256) tab[e] = 0.f;
-        for (int e = tid; e < 4 * 64; e += 256) Ce[MAX_LC * 64 + e] = 0.f;      // zero rows read by out-of-range taps
-        if (tid >= 100 && tid < 128) { gch[tid] = 0.f; pos[tid] = 0; okk[tid] = 1; obase[tid] = 0; }
-    }
-    // this thread's slice of the flattened conv weights: element e -> (oc, ci, kk)
-    constexpr int MAXE = 64;                  // ceil(15000 / 256) = 59
-    float wacc[MAXE];
-    int wcode[MAXE];
+    // ---- bulk phase 1: weights + per-word metadata
+    for (int e0 = 0; e0 < wtot; e0 += 8 * 256) {
+        float v[8];
 #pragma unroll
-    for (int q = 0; q < MAXE; ++q) {
-        wacc[q] = 0.f;
-        const int e = tid + q * 256;
-        int oc = 0, ci = 0, kk = 0;
-        if (e < wtot) {
-            int rem = e;
-            const int s0 = 10 * char_dim, s1 = 20 * char_dim * 2, s2 = 30 * char_dim * 3;
-            if (rem < s0) { oc = rem / char_dim; ci = rem % char_dim; kk = 0; }
-            else if ((rem -= s0) < s1) { const int ch = rem / (char_dim * 2); rem -= ch * char_dim * 2; ci = rem / 2; kk = rem % 2; oc = 10 + ch; }
-            else if ((rem -= s1) < s2) { const int ch = rem / (char_dim * 3); rem -= ch * char_dim * 3; ci = rem / 3; kk = rem % 3; oc = 30 + ch; }
-            else { rem -= s2; const int ch = rem / (char_dim * 4); rem -= ch * char_dim * 4; ci = rem / 4; kk = rem % 4; oc = 60 + ch; }
+        for (int q = 0; q < 8; ++q) {
+            const int e = e0 + tid + q * 256;
+            v[q] = 0.f;
+            if (e < wtot) v[q] = e < s0 ? cc.w[0][e] : (e < s0 + s1 ? cc.w[1][e - s0] : (e < s0 + s1 + s2 ? cc.w[2][e - s0 - s1] : cc.w[3][e - s0 - s1 - s2]));
         }
-        wcode[q] = e < wtot ? ((oc << 16) | (ci << 8) | kk) : (100 << 16);      // dummy element: channel 100 has g == 0
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const int e = e0 + tid + q * 256; if (e < wtot) Wl[e] = v[q]; }
     }
-    STAMP(1);
-    float bacc = 0.f, uacc0 = 0.f, uacc1 = 0.f;
-    const int rbeg = blockIdx.x * EMB_CHUNK, rend = min(Rq, rbeg + EMB_CHUNK);
-    for (int r = rbeg; r < rend; ++r) {
-        __syncthreads();
-        if (r == rbeg) STAMP(2);
-        if (tid < Lc) cids[tid] = (int)char_ids[(size_t)r * Lc + tid];
-        if (tid < 100) {
-            const float v = E[(size_t)r * EW + word_dim + tid];
-            gch[tid] = v > 0.f ? dE[(size_t)r * EW + word_dim + tid] : 0.f;     // relu + max: grad only to an active arg-max
-            pos[tid] = argpos[(size_t)r * 100 + tid];
+    if (tid < 4) Wl[wtot + tid] = 0.f;        // zero slot for invalid taps
+    if (tid < 128) {
+        int k = 1, base = wtot;
+        if (tid < 10) { k = 1; base = tid * char_dim; }
+        else if (tid < 30) { k = 2; base = s0 + (tid - 10) * char_dim * 2; }
+        else if (tid < 60) { k = 3; base = s0 + s1 + (tid - 30) * char_dim * 3; }
+        else if (tid < 100) { k = 4; base = s0 + s1 + s2 + (tid - 60) * char_dim * 4; }
+        okk[tid] = k; obase[tid] = base;
+    }
+    for (int e = tid; e < 4 * char_size * char_dim; e += 256) tab[e] = 0.f;
+    for (int e = tid; e < 4 * 64; e += 256) Ce[EMB_CHUNK * Lc * 64 + e] = 0.f;
+    for (int e = tid; e < EMB_CHUNK * MAX_LC; e += 256) {
+        const int wi = e / MAX_LC, p = e - wi * MAX_LC;
+        cids[e] = (wi < nw && p < Lc) ? (int)char_ids[(size_t)(rbeg + wi) * Lc + p] : 0;
+    }
+    for (int e = tid; e < EMB_CHUNK * 128; e += 256) {
+        const int wi = e >> 7, oc = e & 127;
+        float g = 0.f;
+        int ps = 0;
+        if (wi < nw && oc < 100) {
+            const size_t o = (size_t)(rbeg + wi) * EW + word_dim + oc;
+            g = E[o] > 0.f ? dE[o] : 0.f;                                  // relu + max: grad only to an active arg-max
+            ps = argpos[(size_t)(rbeg + wi) * 100 + oc];
         }
+        gch[e] = g;
+        pos[e] = ps;
+    }
+    float bacc = 0.f, uacc0 = 0.f, uacc1 = 0.f;
+    for (int wi = 0; wi < nw; ++wi) {
+        const int r = rbeg + wi;
         if (word_ids[r] == 1) {               // unk_vec row of the [pad; unk; glove] table (:41)
             if (tid < word_dim) uacc0 += dE[(size_t)r * EW + tid] * drop_mul(dw, (uint32_t)(r * word_dim + tid));
             if (tid + 256 < word_dim) uacc1 += dE[(size_t)r * EW + tid + 256] * drop_mul(dw, (uint32_t)(r * word_dim + tid + 256));
         }
-        __syncthreads();
-        for (int e = tid; e < Lc * char_dim; e += 256) {
-            const int p = e / char_dim, ci = e - p * char_dim;
-            Ce[p * 64 + ci] = char_tab[(size_t)cids[p] * char_dim + ci] * drop_mul(dc, (uint32_t)((r * Lc + p) * char_dim + ci));
-        }
-        __syncthreads();
-        if (r == rbeg) STAMP(3);
-        if (tid < 100) bacc += gch[tid];
-        // weight grads: dW[oc][ci][kk] += g[oc] * Ce[pos[oc] + kk][ci]
+    }
+    __syncthreads();
+    STAMP(1);
+    // ---- bulk phase 2: gather the dropped-out char embeddings of every word of the chunk
+    for (int e = tid; e < EMB_CHUNK * Lc * 64; e += 256) {
+        const int wi = e / (Lc * 64), rem = e - wi * Lc * 64;
+        const int p = rem >> 6, ci = rem & 63;
+        float v = 0.f;
+        if (wi < nw && ci < char_dim)
+            v = char_tab[(size_t)cids[wi * MAX_LC + p] * char_dim + ci] * drop_mul(dc, (uint32_t)(((rbeg + wi) * Lc + p) * char_dim + ci));
+        Ce[e] = v;
+    }
+    __syncthreads();
+    STAMP(2);
+    // ---- (i) conv weight / bias gradients: pair q of this thread = (oc = (tid >> 6) + 4 q, ci = tid & 63)
+    float wacc[EB_NP][4];
 #pragma unroll
-        for (int q = 0; q < MAXE; ++q) {                  // no per-element predicate: the 2-level LDS reads batch up
-            const int oc = wcode[q] >> 16, ci = (wcode[q] >> 8) & 255, kk = wcode[q] & 255;
-            wacc[q] += gch[oc] * Ce[(pos[oc] + kk) * 64 + ci];
-        }
-        if (r == rbeg) STAMP(4);
-        // dCe[p][ci] = sum_{oc, kk : pos[oc] + kk == p} g[oc] W[oc][ci][kk] ; scattered straight into the table
-        // accumulator (thread = (p, ci); two positions of one word may hold the same character -> LDS atomics)
-        for (int e = tid; e < Lc * char_dim; e += 256) {
-            const int p = e / char_dim, ci = e - p * char_dim;
-            if (cids[p] == 0) continue;       // padding_idx = 0 (:51)
-            float acc = 0.f;
-#pragma unroll 10
-            for (int oc = 0; oc < 100; ++oc) {            // branch-free: an invalid tap reads the zero slot Wl[wtot]
-                const int kk = p - pos[oc], k = okk[oc];
-                const int idx = (kk >= 0 && kk < k) ? obase[oc] + ci * k + kk : wtot;
-                acc += gch[oc] * Wl[idx];
+    for (int q = 0; q < EB_NP; ++q) { wacc[q][0] = 0.f; wacc[q][1] = 0.f; wacc[q][2] = 0.f; wacc[q][3] = 0.f; }
+    {
+        const int ci = tid & 63, ocb = tid >> 6;
+        for (int wi = 0; wi < nw; ++wi) {
+            const float* g = gch + wi * 128;
+            const int* ps = pos + wi * 128;
+            const float* ce = Ce + wi * Lc * 64 + ci;
+            if (tid < 100) bacc += g[tid];
+#pragma unroll
+            for (int q = 0; q < EB_NP; ++q) {
+                const int oc = ocb + 4 * q;
+                const float gv = g[oc];
+                const float* row = ce + ps[oc] * 64;      // taps beyond the kernel width read later rows / zero rows: unused
+                wacc[q][0] += gv * row[0];
+                wacc[q][1] += gv * row[64];
+                wacc[q][2] += gv * row[128];
+                wacc[q][3] += gv * row[192];
             }
-            atomicAdd(&tab[cids[p] * char_dim + ci], acc * drop_mul(dc, (uint32_t)((r * Lc + p) * char_dim + ci)));
         }
     }
-    STAMP(5);
-    __syncthreads();
+    STAMP(3);
+    // ---- (ii) char-embedding gradients -> table accumulator
+    for (int wi = 0; wi < nw; ++wi) {
+        const int r = rbeg + wi;
+        for (int e = tid; e < Lc * 100; e += 256) {      // pre-pass: resolve (p, oc) -> (gradient or 0, weight offset, stride)
+            const int p = e / 100, oc = e - p * 100;
+            const int kk = p - pos[wi * 128 + oc], k = okk[oc];
+            const bool ok = kk >= 0 && kk < k;
+            gt[e] = ok ? gch[wi * 128 + oc] : 0.f;
+            it[e] = ok ? (obase[oc] + kk) | (k << 24) : wtot;
+        }
+        __syncthreads();
+        if (tid < 4 * 64) {                              // thread = (position quarter, ci): serial over its positions
+            const int ci = tid & 63, pq = tid >> 6;
+            if (ci < char_dim)
+                for (int p = pq; p < Lc; p += 4) {
+                    const int cid = cids[wi * MAX_LC + p];
+                    if (cid == 0) continue;              // padding_idx = 0 (:51)
+                    const float* gr = gt + p * 100;
+                    const int* ir = it + p * 100;
+                    float a0 = 0.f, a1 = 0.f;
+                    for (int oc0 = 0; oc0 < 100; oc0 += 20) {        // explicit batches: 20 table entries, then the 20
+                        int ii[20];                                 // dependent weight reads, then the FMAs
+                        float gg[20], ww[20];
 #pragma unroll
-    for (int q = 0; q < MAXE; ++q) {
-        const int e = tid + q * 256;
-        if (e < wtot) p_cw[(size_t)blockIdx.x * wtot + e] = wacc[q];
+                        for (int q = 0; q < 5; ++q) {
+                            const int4 iv = *reinterpret_cast<const int4*>(ir + oc0 + 4 * q);
+                            const float4 gv = *reinterpret_cast<const float4*>(gr + oc0 + 4 * q);
+                            ii[4 * q] = iv.x; ii[4 * q + 1] = iv.y; ii[4 * q + 2] = iv.z; ii[4 * q + 3] = iv.w;
+                            gg[4 * q] = gv.x; gg[4 * q + 1] = gv.y; gg[4 * q + 2] = gv.z; gg[4 * q + 3] = gv.w;
+                        }
+#pragma unroll
+                        for (int q = 0; q < 20; ++q) ww[q] = Wl[(ii[q] & 0xFFFFFF) + ci * (ii[q] >> 24)];
+#pragma unroll
+                        for (int q = 0; q < 20; q += 2) { a0 += gg[q] * ww[q]; a1 += gg[q + 1] * ww[q + 1]; }
+                    }
+                    // positions p, p+4, ... of one thread may hold the same character; different threads (pq) too ->
+                    // the per-quarter partial tables below keep this race-free without atomics
+                    tab[(pq * char_size + cid) * char_dim + ci] += (a0 + a1) * drop_mul(dc, (uint32_t)((r * Lc + p) * char_dim + ci));
+                }
+        }
+        __syncthreads();
+    }
+    STAMP(4);
+    {
+        const int ci = tid & 63, ocb = tid >> 6;
+#pragma unroll
+        for (int q = 0; q < EB_NP; ++q) {
+            const int oc = ocb + 4 * q;
+            if (ci < char_dim) {
+                const int k = okk[oc], base = obase[oc] + ci * k;
+                if (k > 0) p_cw[(size_t)blockIdx.x * wtot + base] = wacc[q][0];
+                if (k > 1) p_cw[(size_t)blockIdx.x * wtot + base + 1] = wacc[q][1];
+                if (k > 2) p_cw[(size_t)blockIdx.x * wtot + base + 2] = wacc[q][2];
+                if (k > 3) p_cw[(size_t)blockIdx.x * wtot + base + 3] = wacc[q][3];
+            }
+        }
     }
     if (tid < 100) p_cb[(size_t)blockIdx.x * 100 + tid] = bacc;
     if (tid < word_dim) p_unk[(size_t)blockIdx.x * word_dim + tid] = uacc0;
     if (tid + 256 < word_dim) p_unk[(size_t)blockIdx.x * word_dim + tid + 256] = uacc1;
-    for (int e = tid; e < char_size * char_dim; e += 256) p_tab[(size_t)blockIdx.x * char_size * char_dim + e] = tab[e];
-    STAMP(6);
+    for (int e = tid; e < char_size * char_dim; e += 256)
+        p_tab[(size_t)blockIdx.x * char_size * char_dim + e] = tab[e] + tab[char_size * char_dim + e] + tab[2 * char_size * char_dim + e] +
+                                                             tab[3 * char_size * char_dim + e];
+    STAMP(5);
 }
 void launch_embed_bwd(const float* dE, const int64_t* word_ids, const int64_t* char_ids, const float* E,
-                      const int8_t* argpos, const float* char_tab, CharConvPtrs cc, float* p_cw, float* p_cb, float* p_tab,
-                      float* p_unk, int Rq, int Lc, int word_dim, int char_dim, int char_size, Drop dw, Drop dc,
+                      const int8_t* argpos, const float* char_tab, CharConvPtrs cc, const int* wdecode, float* p_cw, float* p_cb,
+                      float* p_tab, float* p_unk, int Rq, int Lc, int word_dim, int char_dim, int char_size, Drop dw, Drop dc,
                       hipStream_t s) {
-    const size_t shm = (size_t)(((char_dim * 300 + 7) & ~3) + (MAX_LC + 4) * 64 + 128 + char_size * char_dim) * sizeof(float);
+    (void)wdecode;
+    const size_t shm = (size_t)(((char_dim * 300 + 7) & ~3) + (EMB_CHUNK * Lc + 4) * 64 + EMB_CHUNK * 128 + 2 * Lc * 100 +
+                                4 * char_size * char_dim) * sizeof(float);
     static size_t lds_ok = 0;
-    ensure_dynamic_lds((const void*)k_embed_bwd, shm, lds_ok, "k_embed_bwd");
+    ensure_dynamic_lds((const void*)k_embed_bwd, shm + 16 * 1024, lds_ok, "k_embed_bwd");
     hipLaunchKernelGGL(k_embed_bwd, dim3((Rq + EMB_CHUNK - 1) / EMB_CHUNK), dim3(256), shm, s, dE, word_ids, char_ids, E, argpos,
                        char_tab, cc, p_cw, p_cb, p_tab, p_unk, Rq, Lc, word_dim, char_dim, char_size, dw, dc);
     static int left = 2;
-    if (dbg_budget("embed_bwd")) dbg_report("embed_bwd: stage-weights | decode | word0 loads | word0 gather | word0 dW | rest of words | stores", 7, s, left);
+    if (dbg_budget("embed_bwd")) dbg_report("embed_bwd: bulk1 | gather | dW | dCe+table | stores", 6, s, left);
 }
 
 // =========================================================================================================

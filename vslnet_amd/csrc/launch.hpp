@@ -182,7 +182,8 @@ struct CqColBwdArgs {
 void launch_cq_col_bwd(const CqColBwdArgs& a, int B, hipStream_t s);
 void launch_linear_bwd_data(const float* G, const float* WTpack, float* dA, int R, int K, hipStream_t s);
 void launch_embed_bwd(const float* dE, const int64_t* word_ids, const int64_t* char_ids, const float* E,
-                      const int8_t* argpos, const float* char_tab, CharConvPtrs cc, float* p_cw /*[nchunk][15000]*/,
+                      const int8_t* argpos, const float* char_tab, CharConvPtrs cc, const int* wdecode /*[64*256] host-built*/,
+                      float* p_cw /*[nchunk][15000]*/,
                       float* p_cb /*[nchunk][100]*/, float* p_tab /*[nchunk][char_size*char_dim]*/,
                       float* p_unk /*[nchunk][word_dim]*/, int Rq, int Lc, int word_dim, int char_dim, int char_size, Drop dw,
                       Drop dc, hipStream_t s);
