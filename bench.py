@@ -197,7 +197,16 @@ def main():
             else:
                 roof.update(bound='hbm', achieved=round(work[1] / k_s / 1e9, 1), peak=PEAK_HBM / 1e9, unit='GB/s')
             roof['frac'] = round(roof['achieved'] / roof['peak'], 4)
-        roof['traffic'] = None                               # PMC pass: profiles/ 
+        roof['traffic'] = None
+        try:        # HBM bytes per launch of this kernel group from the committed PMC passes (profiles/r01_pmc_traffic.json)
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))['groups'].get(dominant)
+            if pmc and (B, T, Dv, Lq) == (64, 128, 1024, 20):
+                roof['traffic'] = pmc['traffic_bytes']
+                roof['traffic_unit'] = 'bytes/launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes)'
+                if work:
+                    roof['alg_bytes_per_launch'] = int(work[1] / max(1, kt[1] // args.steps))
+        except Exception:
+            pass
         roof['step_mfma_frac'] = round(fb * value / world / PEAK_MFMA_F32, 4)   # whole step vs the fp32 MFMA roof, per GPU
         out = {'metric': '(video,query) pairs/sec fwd+bwd, Charades I3D T=128 D=1024', 'value': round(value, 1),
                'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
