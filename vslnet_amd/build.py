@@ -28,16 +28,19 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    """Compile every HIP translation unit for gfx950 and link the shared library.  Returns its path."""
-    if not force and not _stale():
+def build(force=False, verbose=False, csrc=None, out=None):
+    """Compile every HIP translation unit for gfx950 and link the shared library.  Returns its path.
+    `csrc` / `out` build another source tree into another file (baseline builds for same-box A/B runs)."""
+    src_dir, lib = csrc or CSRC, out or LIB
+    if csrc is None and not force and not _stale():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = _hipcc()
+    tag = '' if out is None else '.' + os.path.basename(out)
 
     def cc(src):
-        obj = os.path.join(LIBDIR, src.replace('.hip', '.o'))
-        cmd = [hipcc] + FLAGS + ['-c', os.path.join(CSRC, src), '-o', obj]
+        obj = os.path.join(LIBDIR, src.replace('.hip', tag + '.o'))
+        cmd = [hipcc] + FLAGS + ['-c', os.path.join(src_dir, src), '-o', obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('hipcc failed for %s:\n%s' % (src, r.stderr[-4000:]))
@@ -47,10 +50,10 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(len(SOURCES)) as ex:
         objs = list(ex.map(cc, SOURCES))
-    r = subprocess.run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', LIB], capture_output=True, text=True)
+    r = subprocess.run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', lib], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError('link failed:\n' + r.stderr[-4000:])
-    return LIB
+    return lib
 
 
 if __name__ == '__main__':

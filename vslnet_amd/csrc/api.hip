@@ -49,9 +49,11 @@ struct ModelPk { int va_f, emb_f, emb_t; EncPk fe, pe; int cqa_f, cqa_t, cat1_f,
 
 struct EncWs { int64_t x0, y[4], u[4], mask[4], h1, q, k, v, lse, att, r, h2, out; int R, L; };
 
-struct EncTmp { int64_t dr, dq, dk, dv, Dq, go, du, gz[4], ga, gb; };   // backward temporaries of one encoder application
+struct EncTmp { int64_t dr, dq, dk, dv, Dq, go, du, du2, gz[4], ga, gb; };   // backward temporaries of one encoder application
 
 struct SlabRec { int dst, n, nslabs, ss, rl, ds, vn; int64_t src; };
+// the reduction runs in two launches: `early` = parameters whose partials are complete before the final video/query fork
+// (predictor, heads, CQ fusion), on a side stream; `late` = shared feature encoder, embedding stack, visual projection
 
 struct Plan {
     int B, T, Lq, Lc;
@@ -66,8 +68,8 @@ struct Plan {
     int64_t partial, partial_floats, total;
     std::vector<int64_t> part_offs;     // sequence of partial-arena allocations made by the backward
     ReduceSeg* segs_dev = nullptr;
-    int* blk2seg_dev = nullptr;
-    int nblocks = 0;
+    int* blk2seg_dev = nullptr;         // block table: [early blocks | late blocks]
+    int nblocks = 0, nblocks_early = 0;
 };
 
 }  // namespace
@@ -390,7 +392,9 @@ WgradJob wjob() { WgradJob j; memset(&j, 0, sizeof j); return j; }
 
 // backward of one FeatureEncoder application: dy = grad wrt its output; writes grad wrt its input (dx0_out)
 void enc_bwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float* dy, const float* dy2, int64_t dx0_off,
-             const float* mask, int Bn, int app, hipStream_t sw) {
+             const float* mask, int Bn, int app, hipStream_t sw, WgradBatch* defer_pw = nullptr) {
+    // sw: stream of the early (out_layer / q,k,v) weight gradients.  The pointwise-conv batch goes to `sw` too unless the
+    // caller asks for it back (defer_pw) to launch it on its own stream WITHOUT a cross-stream wait (each costs ~16 us).
     float* dx0_out = c.dry ? nullptr : c.W(dx0_off);
     const Plan& p = *c.p;
     const EncTmp& t = p.tmp[app];
@@ -404,60 +408,86 @@ void enc_bwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float*
                            c.W(t.dv), c.W(t.Dq), Bn, L, H, 0, c.drop(app * 16 + 5), c.drop(app * 16 + 6), c.s));
     float* p_ln1g = c.slab(P.ln1g, D, ntiles);
     float* p_ln1b = c.slab(P.ln1b, D, ntiles);
+    // conv block backward as a chain of fused kernels: [LN1/qkv backward + gemm(3)] -> [dwln(3) + gemm(2)] -> ... -> [dwln(0)]
+    auto gemm_args = [&](int i) {
+        ConvGemmArgs g;
+        memset(&g, 0, sizeof g);
+        if (i >= 0 && !c.dry) {
+            g.relu_mask = reinterpret_cast<const uint32_t*>(c.W(w.mask[i])); g.WTpack = c.PK(K.pw_t[i]);
+            g.gz = c.W(t.gz[i]); g.du = c.W(t.du); g.dp = c.drop(app * 16 + i);
+        }
+        return g;
+    };
     LAUNCH("qkv_bwd", launch_qkv_bwd(c.W(t.dq), c.W(t.dk), c.W(t.dv), c.W(w.y[3]), c.W(t.dr), c.P(P.ln1g), c.PK(K.qkv_t),
-                          c.W(t.ga), p_ln1g, p_ln1b, R, c.drop(app * 16 + 4), c.s));
-    float* g = c.dry ? nullptr : c.W(t.ga);
-    float* other = c.dry ? nullptr : c.W(t.gb);
-    for (int i = 3; i >= 0; --i) {
-        LAUNCH("conv_bwd_gemm", launch_conv_bwd_gemm(g, reinterpret_cast<const uint32_t*>(c.W(w.mask[i])), c.PK(K.pw_t[i]), c.W(t.gz[i]),
-                                    c.W(t.du), R, c.drop(app * 16 + i), c.s));
-        float* p_g = c.slab(P.lng[i], D, ntiles);
-        float* p_b = c.slab(P.lnb[i], D, ntiles);
-        float* p_dw = c.slab(P.dw[i], D * DWK, ntiles);
-        float* out = i > 0 ? other : dx0_out;
-        LAUNCH("conv_bwd_dwln", launch_conv_bwd_dwln(c.W(t.du), i > 0 ? c.W(w.y[i - 1]) : c.W(w.x0), g, c.P(P.lng[i]), c.P(P.lnb[i]),
-                                    c.P(P.dw[i]), nullptr, out, p_g, p_b, p_dw, R, L, c.s));
-        other = g;
-        g = out;
-    }
-    // weight gradients of this application: out_layer, fused q/k/v, 4 pointwise convs
-    WgradBatch wb;
-    memset(&wb, 0, sizeof wb);
-    {
-        WgradJob j = wjob();
-        j.G[0] = c.dry ? nullptr : c.W(t.go); j.nG = 1; j.A[0] = c.dry ? nullptr : c.W(w.h2); j.nA = 1; j.K = D; j.R = R;
-        j.out = c.slab(P.ow, D * D, nchunk);
-        j.out_bias[0] = c.slab(P.ob, D, nchunk);
-        wb.j[wb.n++] = j;
-    }
-    {
-        WgradJob j = wjob();
-        if (!c.dry) { j.G[0] = c.W(t.dq); j.G[1] = c.W(t.dk); j.G[2] = c.W(t.dv); j.A[0] = c.W(w.h1); }
-        j.nG = 3; j.nA = 1; j.K = D; j.R = R;
-        const int64_t o = c.part_alloc((int64_t)nchunk * 3 * D * D);
-        c.reg(P.qw, D * D, p.partial + o, nchunk, 3 * D * D);
-        c.reg(P.kw, D * D, p.partial + o + D * D, nchunk, 3 * D * D);
-        c.reg(P.vw, D * D, p.partial + o + 2 * D * D, nchunk, 3 * D * D);
-        j.out = c.part_ptr(o);
-        j.out_bias[0] = c.slab(P.qb, D, nchunk);
-        j.out_bias[1] = c.slab(P.kb, D, nchunk);
-        j.out_bias[2] = c.slab(P.vb, D, nchunk);
-        wb.j[wb.n++] = j;
-    }
-    for (int i = 0; i < 4; ++i) {
-        WgradJob j = wjob();
-        if (!c.dry) { j.G[0] = c.W(t.gz[i]); j.A[0] = c.W(w.u[i]); }
-        j.nG = 1; j.nA = 1; j.K = D; j.R = R;
-        j.out = c.slab(P.pw[i], D * D, nchunk);
-        j.out_bias[0] = c.slab(P.pwb[i], D, nchunk);
-        wb.j[wb.n++] = j;
-    }
-    {   // the weight gradients only feed the final reduction: run them beside the next chain
+                          c.W(t.ga), p_ln1g, p_ln1b, R, c.drop(app * 16 + 4), gemm_args(3), c.s));
+    {   // out_layer + fused q/k/v weight gradients: every input exists now -> side stream, beside the conv chain
+        WgradBatch wb;
+        memset(&wb, 0, sizeof wb);
+        {
+            WgradJob j = wjob();
+            j.G[0] = c.dry ? nullptr : c.W(t.go); j.nG = 1; j.A[0] = c.dry ? nullptr : c.W(w.h2); j.nA = 1; j.K = D; j.R = R;
+            j.out = c.slab(P.ow, D * D, nchunk);
+            j.out_bias[0] = c.slab(P.ob, D, nchunk);
+            wb.j[wb.n++] = j;
+        }
+        {
+            WgradJob j = wjob();
+            if (!c.dry) { j.G[0] = c.W(t.dq); j.G[1] = c.W(t.dk); j.G[2] = c.W(t.dv); j.A[0] = c.W(w.h1); }
+            j.nG = 3; j.nA = 1; j.K = D; j.R = R;
+            const int64_t o = c.part_alloc((int64_t)nchunk * 3 * D * D);
+            c.reg(P.qw, D * D, p.partial + o, nchunk, 3 * D * D);
+            c.reg(P.kw, D * D, p.partial + o + D * D, nchunk, 3 * D * D);
+            c.reg(P.vw, D * D, p.partial + o + 2 * D * D, nchunk, 3 * D * D);
+            j.out = c.part_ptr(o);
+            j.out_bias[0] = c.slab(P.qb, D, nchunk);
+            j.out_bias[1] = c.slab(P.kb, D, nchunk);
+            j.out_bias[2] = c.slab(P.vb, D, nchunk);
+            wb.j[wb.n++] = j;
+        }
         hipStream_t keep = c.s;
         c.order(keep, sw);
         c.s = sw;
         LAUNCH("wgrad", launch_wgrad(wb, c.s));
         c.s = keep;
+    }
+    float* g = c.dry ? nullptr : c.W(t.ga);
+    float* other = c.dry ? nullptr : c.W(t.gb);
+    for (int i = 3; i >= 0; --i) {
+        float* p_g = c.slab(P.lng[i], D, ntiles);
+        float* p_b = c.slab(P.lnb[i], D, ntiles);
+        float* p_dw = c.slab(P.dw[i], D * DWK, ntiles);
+        float* out = i > 0 ? other : dx0_out;
+        // du(i) was produced by the previous kernel of the chain; this one also produces du(i-1).  The two du buffers
+        // alternate (ga/gb carry dy, du/du2 carry du) so a kernel never reads a buffer another workgroup of it writes.
+        ConvGemmArgs nx = gemm_args(i - 1);
+        if (!c.dry) { nx.du = (i & 1) ? c.W(t.du2) : c.W(t.du); }
+        const float* du_in = c.dry ? nullptr : ((i & 1) ? c.W(t.du) : c.W(t.du2));
+        LAUNCH("conv_bwd_dwln", launch_conv_bwd_dwln(du_in, i > 0 ? c.W(w.y[i - 1]) : c.W(w.x0), g, c.P(P.lng[i]), c.P(P.lnb[i]),
+                                    c.P(P.dw[i]), nullptr, out, p_g, p_b, p_dw, R, L, nx, c.s));
+        other = g;
+        g = out;
+    }
+    // pointwise-conv weight gradients (inputs complete only now); Wo / QKV were launched right after qkv_bwd
+    {
+        WgradBatch wb;
+        memset(&wb, 0, sizeof wb);
+        for (int i = 0; i < 4; ++i) {
+            WgradJob j = wjob();
+            if (!c.dry) { j.G[0] = c.W(t.gz[i]); j.A[0] = c.W(w.u[i]); }
+            j.nG = 1; j.nA = 1; j.K = D; j.R = R;
+            j.out = c.slab(P.pw[i], D * D, nchunk);
+            j.out_bias[0] = c.slab(P.pwb[i], D, nchunk);
+            wb.j[wb.n++] = j;
+        }
+        if (defer_pw) {
+            *defer_pw = wb;
+        } else {
+            hipStream_t keep = c.s;
+            c.order(keep, sw);
+            c.s = sw;
+            LAUNCH("wgrad", launch_wgrad(wb, c.s));
+            c.s = keep;
+        }
     }
     // positional table (:202): dpos[t] = sum_b dx0[b, t] -- the per-sample rows of dx0 ARE the partial slabs
     c.reg(P.pos, c.h->cfg.max_pos_len * D, dx0_off, Bn, L * D, 0, 0, L * D);
@@ -555,10 +585,14 @@ void run_backward(Ctx& c) {
         LAUNCH("cq_col_bwd", launch_cq_col_bwd(a, B, c.s));
     }
     // ---- shared feature encoder: video pass, then VisualProjection weight gradient
+    // early reduction (predictor / heads / CQ parameters): all their partials exist once the launches above are done
+    on_stream(sw, [&] { LAUNCH("reduce", launch_reduce(c.ws, io->grads, p.segs_dev, p.blk2seg_dev, p.nblocks_early, c.s)); });
     // fork: from here the video side (main) and the query side (sq) are independent
     c.order(c.s, sq);
-    enc_bwd(c, P.fe, K.fe, p.ve, c.dry ? nullptr : c.W(p.dC), nullptr, p.dvf, c.dry ? nullptr : io->v_mask, B, 0, sw);
-    {
+    WgradBatch pw_video;
+    memset(&pw_video, 0, sizeof pw_video);
+    enc_bwd(c, P.fe, K.fe, p.ve, c.dry ? nullptr : c.W(p.dC), nullptr, p.dvf, c.dry ? nullptr : io->v_mask, B, 0, sw, &pw_video);
+    {   // tail of the main stream: VisualProjection + the video pass' pointwise weight gradients, back to back, no waits
         WgradBatch wb;
         memset(&wb, 0, sizeof wb);
         WgradJob j = wjob();
@@ -567,24 +601,27 @@ void run_backward(Ctx& c) {
         j.out = c.slab(P.va_w, D * cf.video_feature_dim, nchunk);
         j.out_bias[0] = c.slab(P.va_b, D, nchunk);
         wb.j[wb.n++] = j;
-        on_stream(sw, [&] { LAUNCH("wgrad", launch_wgrad(wb, c.s)); });
+        LAUNCH("wgrad", launch_wgrad(wb, c.s));
+        LAUNCH("wgrad", launch_wgrad(pw_video, c.s));
     }
     // ---- query pass, then the embedding stack (all on sq)
     hipStream_t main_s = c.s;
     c.s = sq;
-    enc_bwd(c, P.fe, K.fe, p.qe, c.dry ? nullptr : c.W(p.dQtot), nullptr, p.dqf, c.dry ? nullptr : io->q_mask, B, 1, sq);
+    WgradBatch pw_query;
+    memset(&pw_query, 0, sizeof pw_query);
+    enc_bwd(c, P.fe, K.fe, p.qe, c.dry ? nullptr : c.W(p.dQtot), nullptr, p.dqf, c.dry ? nullptr : io->q_mask, B, 1, sw, &pw_query);
     const int EW = cf.word_dim + 100;
     LAUNCH("linear_bwd_data", launch_linear_bwd_data(c.W(p.dqf), c.PK(K.emb_t), c.W(p.dE), Rq, EW, c.s));
+    WgradBatch wb_emb;
+    memset(&wb_emb, 0, sizeof wb_emb);
     {
-        WgradBatch wb;
-        memset(&wb, 0, sizeof wb);
         WgradJob j = wjob();
         if (!c.dry) { j.G[0] = c.W(p.dqf); j.Afull = c.W(p.E); }
         j.nG = 1; j.nA = 0; j.K = EW; j.R = Rq;
         j.out = c.slab(P.emb_w, D * EW, nchunk_q);
         j.out_bias[0] = c.slab(P.emb_b, D, nchunk_q);
-        wb.j[wb.n++] = j;
-        LAUNCH("wgrad", launch_wgrad(wb, c.s));
+        wb_emb.j[wb_emb.n++] = j;
+        for (int i = 0; i < pw_query.n && wb_emb.n < MAX_WJOBS; ++i) wb_emb.j[wb_emb.n++] = pw_query.j[i];   // one launch
     }
     {
         const int nce = (Rq + EMB_CHUNK - 1) / EMB_CHUNK;
@@ -604,10 +641,11 @@ void run_backward(Ctx& c) {
                                 c.P(P.char_tab), char_ptrs(c), c.h->wdecode_dev, c.part_ptr(ow), c.part_ptr(ob), p_tab, p_unk, Rq,
                                 p.Lc, cf.word_dim, cf.char_dim, cf.char_size, c.drop(SITE_WORD), c.drop(SITE_CHAR), c.s));
     }
+    LAUNCH("wgrad", launch_wgrad(wb_emb, c.s));            // embedding linear + query-pass pointwise convs, on sq, no wait
     c.s = main_s;
     c.order(sq, c.s);                      // join both side streams before the reduction
     c.order(sw, c.s);
-    LAUNCH("reduce", launch_reduce(c.ws, io->grads, p.segs_dev, p.blk2seg_dev, p.nblocks, c.s));
+    LAUNCH("reduce", launch_reduce(c.ws, io->grads, p.segs_dev, p.blk2seg_dev + 2 * p.nblocks_early, p.nblocks - p.nblocks_early, c.s));
 }
 
 int build_plan(vsl_handle_s* h, int B, int T, int Lq, int Lc, Plan** out) {
@@ -639,7 +677,7 @@ int build_plan(vsl_handle_s* h, int B, int T, int Lq, int Lc, Plan** out) {
         const int64_t Ra = ap == 1 ? Rq : R;
         EncTmp& t = p->tmp[ap];
         t.dr = al(Ra * D); t.dq = al(Ra * D); t.dk = al(Ra * D); t.dv = al(Ra * D); t.Dq = al((int64_t)B * H * (ap == 1 ? Lq : T));
-        t.go = al(Ra * D); t.du = al(Ra * D);
+        t.go = al(Ra * D); t.du = al(Ra * D); t.du2 = al(Ra * D);
         for (int i = 0; i < 4; ++i) t.gz[i] = al(Ra * D);
         t.ga = al(Ra * D); t.gb = al(Ra * D);
     }
@@ -677,9 +715,17 @@ int build_plan(vsl_handle_s* h, int B, int T, int Lq, int Lc, Plan** out) {
         s.vec = (s.n % 4 == 0) && (s.rl % 4 == 0) && (s.ds % 4 == 0) && (s.dst % 4 == 0);
         for (int q = 0; q < s.nsrc; ++q) s.vec = s.vec && (s.src[q] % 4 == 0) && (s.ss[q] % 4 == 0) && (s.vn[q] % 4 == 0);
     }
+    // early / late split by destination: everything up to the end of the shared feature encoder's parameters is `late`
+    const int late_end = h->P.w4C;       // params are laid out [embedding | visual | feature_encoder | cq... | predictor...]
     std::vector<int> blk;
-    for (size_t i = 0; i < segs.size(); ++i)
-        for (int o = 0; o < segs[i].n; o += 1024) { blk.push_back((int)i); blk.push_back(o); }
+    for (int pass = 0; pass < 2; ++pass) {
+        for (size_t i = 0; i < segs.size(); ++i) {
+            const bool late = segs[i].dst < late_end;
+            if (late != (pass == 1)) continue;
+            for (int o = 0; o < segs[i].n; o += 256) { blk.push_back((int)i); blk.push_back(o); }
+        }
+        if (pass == 0) p->nblocks_early = (int)blk.size() / 2;
+    }
     p->nblocks = (int)blk.size() / 2;
     HIP_OK(hipMalloc(&p->segs_dev, segs.size() * sizeof(ReduceSeg)));
     HIP_OK(hipMalloc(&p->blk2seg_dev, blk.size() * sizeof(int)));

@@ -333,10 +333,11 @@ __device__ __forceinline__ void ln_tile(float* tile, int nrows, int ld, const fl
 //   Ts : grad wrt the LN output (32 x 128, stride LDP) -- left in place (beta partial = its column sums)
 //   Xs : raw LN input rows (32 x 128, stride LDP)       -- overwritten with dy * xhat (gamma partial = column sums)
 //   out[r] = LN^T(Ts[r]) + resid[r] + extra[r]  for global rows r0 + rr < R ; partial slabs [blockIdx.x][128].
+//   lds_out (nullable): the result tile is also left in LDS (stride LDP; rows >= R zero) for a fused follow-up GEMM.
 __device__ __forceinline__ void ln_bwd_tile(float* Ts, float* Xs, const float* __restrict__ resid,
                                             const float* __restrict__ resid2, const float* __restrict__ ln_g,
                                             float* __restrict__ out, float* __restrict__ p_lng, float* __restrict__ p_lnb,
-                                            int r0, int R) {
+                                            int r0, int R, float* lds_out = nullptr) {
     const int tid = threadIdx.x, sub = tid & 7, rr = tid >> 3;
     const int r = r0 + rr;
     {
@@ -385,6 +386,7 @@ __device__ __forceinline__ void ln_bwd_tile(float* Ts, float* Xs, const float* _
             o.z = rstd * (gd[j].z - m1 - x[j].z * m2) + rs[j].z; o.w = rstd * (gd[j].w - m1 - x[j].w * m2) + rs[j].w;
             if (r < R) *reinterpret_cast<float4*>(out + (size_t)r * D + sub * 4 + 32 * j) = o;
             const bool ok = r < R;
+            if (lds_out) *reinterpret_cast<float4*>(lds_out + rr * LDP + sub * 4 + 32 * j) = ok ? o : make_float4(0.f, 0.f, 0.f, 0.f);
             *reinterpret_cast<float4*>(xr + 32 * j) = ok ? make_float4(dy[j].x * x[j].x, dy[j].y * x[j].y, dy[j].z * x[j].z, dy[j].w * x[j].w)
                                                          : make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -398,6 +400,56 @@ __device__ __forceinline__ void ln_bwd_tile(float* Ts, float* Xs, const float* _
         for (int i = 0; i < TILE_M; ++i) acc += src[i * LDP + c];
         if (tid < 128) p_lng[(size_t)blockIdx.x * D + c] = acc;
         else p_lnb[(size_t)blockIdx.x * D + c] = acc;
+    }
+}
+
+// Arguments of the data-gradient GEMM of one conv layer (du = (dy * dropmask * relu-bit) Wp), used stand-alone
+// (k_conv_bwd_gemm) or fused behind the kernel that produces dy (k_conv_bwd_dwln of the layer above, k_qkv_bwd).
+struct ConvGemmArgs {
+    const uint32_t* relu_mask;   // (R, 4) bit-mask saved by the forward ; nullptr = no fused stage
+    const float* WTpack;         // transpose pack of the pointwise weight
+    float* gz;                   // out (R,128): dz, the G operand of the weight gradient
+    float* du;                   // out (R,128)
+    Drop dp;
+};
+// Gs holds the dy tile (stride LDP, rows >= R zero).  Applies mask + dropout in place, writes gz, runs the GEMM with
+// the (already requested) weight fragments, writes du.  Contains two barriers.
+__device__ __forceinline__ void conv_gemm_stage(float* Gs, const ConvGemmArgs& a, BFrag<1, 16>& bf, int r0, int R) {
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    __syncthreads();
+    {
+        uint32_t mb[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + q * 256;
+            const int r = r0 + (e >> 5), c = (e & 31) * 4;
+            mb[q] = r < R ? a.relu_mask[(size_t)r * 4 + (c >> 5)] : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + q * 256;
+            const int rr = e >> 5, c = (e & 31) * 4;
+            const int r = r0 + rr;
+            float4 v = *reinterpret_cast<const float4*>(&Gs[rr * LDP + c]);
+            const uint32_t bits = mb[q] >> (c & 31);
+            const uint32_t base = (uint32_t)(r * D + c);
+            v.x = (bits & 1u) ? v.x * drop_mul(a.dp, base) : 0.f;
+            v.y = (bits & 2u) ? v.y * drop_mul(a.dp, base + 1) : 0.f;
+            v.z = (bits & 4u) ? v.z * drop_mul(a.dp, base + 2) : 0.f;
+            v.w = (bits & 8u) ? v.w * drop_mul(a.dp, base + 3) : 0.f;
+            if (r < R) *reinterpret_cast<float4*>(a.gz + (size_t)r * D + c) = v;
+            *reinterpret_cast<float4*>(&Gs[rr * LDP + c]) = v;
+        }
+    }
+    __syncthreads();
+    f32x16 acc[1];
+    zero_acc(acc);
+    gemm32p<1, 16>(Gs, LDP, D, a.WTpack, D, 32 * w, 0, acc, bf);
+    const int col = 32 * w + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int gr = r0 + acc_row(r, lane);
+        if (gr < R) a.du[(size_t)gr * D + col] = acc[0][r];
     }
 }
 

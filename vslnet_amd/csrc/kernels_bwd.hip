@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256) void k_conv_bwd_dwln(const float* __restrict__
                                                        const float* __restrict__ ln_b, const float* __restrict__ dw_w,
                                                        const float* __restrict__ extra, float* __restrict__ dx,
                                                        float* __restrict__ p_lng, float* __restrict__ p_lnb,
-                                                       float* __restrict__ p_dw, int R, int L) {
+                                                       float* __restrict__ p_dw, int R, int L, ConvGemmArgs nxt) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NH = TILE_M + 2 * HALO;
     constexpr int NW = 16 + 2 * HALO;
@@ -436,6 +436,8 @@ __global__ __launch_bounds__(256) void k_conv_bwd_dwln(const float* __restrict__
     load_tile128(DUs, du, r0 - HALO, NH, R);
     load_tile128(Vs, xin, r0 - HALO, NH, R);
     load_tile128(Xc, xin, r0, TILE_M, R);
+    BFrag<1, 16> bf;                         // weights of the fused data-gradient GEMM of the layer below: requested
+    if (nxt.relu_mask) bfrag_load(bf, nxt.WTpack, D, 32 * (tid >> 6), 0, 0, D / 8);   // now, consumed after this layer's work
     __syncthreads();
     ln_tile(Vs, NH, LDP, ln_g, ln_b, Drop{0u, 0u, 1.f}, 0);
     __syncthreads();
@@ -470,16 +472,17 @@ __global__ __launch_bounds__(256) void k_conv_bwd_dwln(const float* __restrict__
     }
     __syncthreads();
     for (int e = tid; e < D * DWK; e += 256) p_dw[(size_t)blockIdx.x * D * DWK + e] = red[e] + red[896 + e];
-    ln_bwd_tile(Ts, Xc, dy, extra, ln_g, dx, p_lng, p_lnb, r0, R);
+    ln_bwd_tile(Ts, Xc, dy, extra, ln_g, dx, p_lng, p_lnb, r0, R, nxt.relu_mask ? DUs : nullptr);
+    if (nxt.relu_mask) conv_gemm_stage(DUs, nxt, bf, r0, R);   // dx of this layer == dy of the layer below
 }
 void launch_conv_bwd_dwln(const float* du, const float* xin, const float* dy, const float* ln_g, const float* ln_b,
                           const float* dw_w, const float* extra, float* dx, float* p_lng, float* p_lnb, float* p_dw,
-                          int R, int L, hipStream_t s) {
+                          int R, int L, const ConvGemmArgs& nxt, hipStream_t s) {
     const size_t shm = (size_t)((2 * (TILE_M + 2 * HALO) + 2 * TILE_M) * LDP + 1792) * sizeof(float);
     static size_t lds_ok = 0;
     ensure_dynamic_lds((const void*)k_conv_bwd_dwln, shm, lds_ok, "k_conv_bwd_dwln");
     hipLaunchKernelGGL(k_conv_bwd_dwln, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm, s, du, xin, dy, ln_g, ln_b, dw_w, extra,
-                       dx, p_lng, p_lnb, p_dw, R, L);
+                       dx, p_lng, p_lnb, p_dw, R, L, nxt);
 }
 
 // =========================================================================================================
@@ -729,7 +732,8 @@ __global__ __launch_bounds__(256) void k_qkv_bwd(const float* __restrict__ dQ, c
                                                  const float* __restrict__ dV, const float* __restrict__ x,
                                                  const float* __restrict__ dr, const float* __restrict__ ln_g,
                                                  const float* __restrict__ WTpack, float* __restrict__ dx,
-                                                 float* __restrict__ p_lng, float* __restrict__ p_lnb, int R, Drop d1) {
+                                                 float* __restrict__ p_lng, float* __restrict__ p_lnb, int R, Drop d1,
+                                                 ConvGemmArgs nxt) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                         // [32][QKVP] = [dQ | dK | dV]
     float* Ts = As + TILE_M * QKVP;           // [32][LDP]
@@ -773,16 +777,19 @@ __global__ __launch_bounds__(256) void k_qkv_bwd(const float* __restrict__ dQ, c
         Ts[row * LDP + col] = acc[0][r] * drop_mul(d1, (uint32_t)((r0 + row) * D + col));
     }
     __syncthreads();
-    ln_bwd_tile(Ts, Xs, dr, nullptr, ln_g, dx, p_lng, p_lnb, r0, R);
+    BFrag<1, 16> bf2;                          // fused data-gradient GEMM of the last conv layer
+    if (nxt.relu_mask) bfrag_load(bf2, nxt.WTpack, D, 32 * w, 0, 0, D / 8);
+    ln_bwd_tile(Ts, Xs, dr, nullptr, ln_g, dx, p_lng, p_lnb, r0, R, nxt.relu_mask ? As : nullptr);
+    if (nxt.relu_mask) conv_gemm_stage(As, nxt, bf2, r0, R);
 }
 void launch_qkv_bwd(const float* dQ, const float* dK, const float* dV, const float* x, const float* dr,
                     const float* ln_g, const float* WTpack, float* dx, float* p_lng, float* p_lnb, int R, Drop d1,
-                    hipStream_t s) {
+                    const ConvGemmArgs& nxt, hipStream_t s) {
     const size_t shm = (size_t)(TILE_M * QKVP + 2 * TILE_M * LDP) * sizeof(float);
     static size_t lds_ok = 0;
     ensure_dynamic_lds((const void*)k_qkv_bwd, shm, lds_ok, "k_qkv_bwd");
     hipLaunchKernelGGL(k_qkv_bwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm, s, dQ, dK, dV, x, dr, ln_g, WTpack, dx, p_lng,
-                       p_lnb, R, d1);
+                       p_lnb, R, d1, nxt);
 }
 
 // =========================================================================================================
@@ -1537,41 +1544,73 @@ void launch_embed_bwd(const float* dE, const int64_t* word_ids, const int64_t* c
 // =========================================================================================================
 __global__ __launch_bounds__(256) void k_reduce(const float* __restrict__ ws, float* __restrict__ grads,
                                                 const ReduceSeg* __restrict__ segs, const int* __restrict__ blk2seg) {
+    // block = 256 destination elements: 64 float4 lanes x 4 slab groups (group g sums slabs s = g, g + 4, ...), each
+    // thread keeps 8 independent 16-byte loads in flight; the 4 group sums are combined through LDS.
+    __shared__ float4 part[4][64];
     const int si = blk2seg[2 * blockIdx.x], off = blk2seg[2 * blockIdx.x + 1];
     const ReduceSeg* __restrict__ sgp = segs + si;
     const int n = sgp->n, nsrc = sgp->nsrc, rl = sgp->rl, ds = sgp->ds, dst = sgp->dst;
-    const int i = off + threadIdx.x * 4;
-    if (i >= n) return;
+    const int l4 = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int i = off + l4 * 4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (sgp->vec) {
-        for (int q = 0; q < nsrc; ++q) {
-            if (i >= sgp->vn[q]) continue;                         // this source covers only the first vn elements
-            const float* p = ws + sgp->src[q] + i;
-            const size_t ss = (size_t)sgp->ss[q];
-            int s = 0;
-            for (; s + 4 <= sgp->nslabs[q]; s += 4) {              // 4 independent 16-byte loads in flight
-                const float4 a = *reinterpret_cast<const float4*>(p + (size_t)s * ss);
-                const float4 b = *reinterpret_cast<const float4*>(p + (size_t)(s + 1) * ss);
-                const float4 c = *reinterpret_cast<const float4*>(p + (size_t)(s + 2) * ss);
-                const float4 d = *reinterpret_cast<const float4*>(p + (size_t)(s + 3) * ss);
-                acc.x += (a.x + b.x) + (c.x + d.x); acc.y += (a.y + b.y) + (c.y + d.y);
-                acc.z += (a.z + b.z) + (c.z + d.z); acc.w += (a.w + b.w) + (c.w + d.w);
-            }
-            for (; s < sgp->nslabs[q]; ++s) {
-                const float4 a = *reinterpret_cast<const float4*>(p + (size_t)s * ss);
-                acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+        if (i < n) {
+            for (int q = 0; q < nsrc; ++q) {
+                if (i >= sgp->vn[q]) continue;                       // this source covers only the first vn elements
+                const float* p = ws + sgp->src[q] + i;
+                const size_t ss = (size_t)sgp->ss[q];
+                const int ns = sgp->nslabs[q];
+                int s = grp;
+                for (; s + 28 < ns; s += 32) {                       // 8 slabs of this group per iteration
+                    float4 v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(p + (size_t)(s + 4 * u) * ss);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+                }
+                for (; s < ns; s += 4) {
+                    const float4 a = *reinterpret_cast<const float4*>(p + (size_t)s * ss);
+                    acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+                }
             }
         }
-        *reinterpret_cast<float4*>(grads + dst + (i / rl) * ds + (i % rl)) = acc;
+        part[grp][l4] = acc;
+        __syncthreads();
+        if (grp == 0 && i < n) {
+            const float4 b1 = part[1][l4], b2 = part[2][l4], b3 = part[3][l4];
+            acc.x += (b1.x + b2.x) + b3.x; acc.y += (b1.y + b2.y) + b3.y; acc.z += (b1.z + b2.z) + b3.z; acc.w += (b1.w + b2.w) + b3.w;
+            *reinterpret_cast<float4*>(grads + dst + (i / rl) * ds + (i % rl)) = acc;
+        }
     } else {
-        float a4[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int e = 0; e < 4 && i + e < n; ++e) {
-            for (int q = 0; q < nsrc; ++q) {
-                if (i + e >= sgp->vn[q]) continue;
-                const float* p = ws + sgp->src[q] + i + e;
-                for (int s = 0; s < sgp->nslabs[q]; ++s) a4[e] += p[(size_t)s * sgp->ss[q]];
+        // ragged / unaligned segments (single biases, the 10- and 30-channel char-conv biases ...): same structure with
+        // scalar loads -- 64 elements per pass, 4 slab groups, 8 loads in flight (a serial walk over up to 256 slabs is
+        // 256 exposed memory latencies)
+        float* sp = reinterpret_cast<float*>(&part[0][0]);
+        for (int base = 0; base < 256; base += 64) {
+            const int e = off + base + l4;
+            float a = 0.f;
+            if (e < n) {
+                for (int q = 0; q < nsrc; ++q) {
+                    if (e >= sgp->vn[q]) continue;
+                    const float* p = ws + sgp->src[q] + e;
+                    const size_t ss = (size_t)sgp->ss[q];
+                    const int ns = sgp->nslabs[q];
+                    int s = grp;
+                    for (; s + 28 < ns; s += 32) {
+                        float v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(s + 4 * u) * ss];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) a += v[u];
+                    }
+                    for (; s < ns; s += 4) a += p[(size_t)s * ss];
+                }
             }
-            grads[dst + ((i + e) / rl) * ds + ((i + e) % rl)] = a4[e];
+            __syncthreads();
+            sp[grp * 64 + l4] = a;
+            __syncthreads();
+            if (grp == 0 && e < n)
+                grads[dst + (e / rl) * ds + (e % rl)] = (sp[l4] + sp[64 + l4]) + (sp[128 + l4] + sp[192 + l4]);
         }
     }
 }

@@ -151,7 +151,7 @@ void launch_conv_bwd_gemm(const float* dy, const uint32_t* relu_mask, const floa
                           Drop dp, hipStream_t s);
 void launch_conv_bwd_dwln(const float* du, const float* xin, const float* dy, const float* ln_g, const float* ln_b,
                           const float* dw_w, const float* extra, float* dx, float* p_lng, float* p_lnb, float* p_dw, int R, int L,
-                          hipStream_t s);
+                          const ConvGemmArgs& nxt, hipStream_t s);
 void launch_attn_out_bwd(const float* dy, const float* dy2, const float* r, const float* ln_g, const float* WTpack, float* g_o,
                          float* dr, float* p_lng, float* p_lnb, int R, Drop d4, Drop d5, hipStream_t s);
 void launch_attn_bwd(const float* Q, const float* K, const float* V, const float* att, const float* dr, const float* lse,
@@ -159,7 +159,7 @@ void launch_attn_bwd(const float* Q, const float* K, const float* V, const float
                      Drop d3, hipStream_t s);
 void launch_qkv_bwd(const float* dQ, const float* dK, const float* dV, const float* x, const float* dr,
                     const float* ln_g, const float* WTpack, float* dx, float* p_lng, float* p_lnb, int R, Drop d1,
-                    hipStream_t s);
+                    const ConvGemmArgs& nxt, hipStream_t s);
 void launch_cqcat_bwd(const float* dg0, const float* dg1, const float* dg2, const float* dh_loss, const float* f2,
                       const float* hscore, const float* wh, const float* W1Tpack, float* df2, float* df1, float* p_wh,
                       float* p_bh, int R, hipStream_t s);

@@ -49,9 +49,11 @@ def load_library():
     global _LIB
     if _LIB is not None:
         return _LIB
-    path = _build.LIB
-    if not os.path.exists(path) or _build._stale():
-        path = _build.build()
+    path = os.environ.get('VSLNET_HIP_LIB')        # A/B runs: an alternative build of the same ABI
+    if not path:
+        path = _build.LIB
+        if not os.path.exists(path) or _build._stale():
+            path = _build.build()
     lib = C.CDLL(path)
     lib.vsl_last_error.restype = C.c_char_p
     lib.vsl_create.argtypes = [C.POINTER(vsl_config), C.POINTER(C.c_void_p)]
