@@ -1,0 +1,17 @@
+"""Build vslnet_amd/lib/libvslnet_hip_base.so from the sources of a git revision (default HEAD), for same-box A/B runs:
+    VSLNET_HIP_LIB=vslnet_amd/lib/libvslnet_hip_base.so python bench.py ...   vs   python bench.py ..."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+rev = sys.argv[1] if len(sys.argv) > 1 else 'HEAD'
+tmp = '/tmp/vsl_base_src'
+files = ['vslnet_amd/csrc/api.hip', 'vslnet_amd/csrc/kernels_fwd.hip', 'vslnet_amd/csrc/kernels_bwd.hip',
+         'vslnet_amd/csrc/common.hpp', 'vslnet_amd/csrc/launch.hpp', 'include/vslnet_hip.h']
+for f in files:
+    os.makedirs(os.path.dirname(os.path.join(tmp, f)), exist_ok=True)
+    open(os.path.join(tmp, f), 'wb').write(subprocess.check_output(['git', 'show', '%s:%s' % (rev, f)], cwd=ROOT))
+from vslnet_amd import build  # noqa: E402
+print(build.build(csrc=os.path.join(tmp, 'vslnet_amd/csrc'), out=os.path.join(ROOT, 'vslnet_amd/lib/libvslnet_hip_base.so')))

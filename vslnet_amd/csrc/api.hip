@@ -64,7 +64,7 @@ struct Plan {
     int64_t loss_scratch, gz_s, gz_e, dfeat_s, dfeat_e, dxh_s, dxh_e, g_s1, g_gated;
     EncTmp tmp[4];                      // one set per encoder application: the applications' backward chains and their
                                         // weight-gradient launches overlap on different streams
-    int64_t df2, df1, dC, dc2q, dq2c, dSr, dSs, dQtot, dvf, dqf, dE;
+    int64_t df2, df1, dC, dSr, dSs, dQtot, dvf, dqf, dE, cqP1, cqP2, cqP3, cqP4, cqP5;
     int64_t partial, partial_floats, total;
     std::vector<int64_t> part_offs;     // sequence of partial-arena allocations made by the backward
     ReduceSeg* segs_dev = nullptr;
@@ -564,27 +564,26 @@ void run_backward(Ctx& c) {
         }
         on_stream(sw, [&] { LAUNCH("wgrad", launch_wgrad(wb, c.s)); });
     }
-    // ---- CQAttention
-    LAUNCH("cq_out_bwd", launch_cq_out_bwd(c.W(p.df1), c.W(p.ve.out), c.W(p.qe.out), c.W(p.Srow), c.W(p.M), c.PK(K.cqa_t), c.W(p.dC),
-                             c.W(p.dc2q), c.W(p.dq2c), c.W(p.dSr), B, T, Lq, c.s));
+    // ---- CQAttention + WeightedPool / pooled-bias backward: four tile-parallel kernels (kernels_bwd.hip)
     {
-        CqColBwdArgs a;
-        memset(&a, 0, sizeof a);
+        const int ntile = (T + TILE_M - 1) / TILE_M;
+        CqBwdArgs q;
+        memset(&q, 0, sizeof q);
         if (!c.dry) {
-            a.C = c.W(p.ve.out); a.Qf = c.W(p.qe.out); a.Srow = c.W(p.Srow); a.Scol = c.W(p.Scol); a.cmask = io->v_mask;
-            a.qmask = io->q_mask; a.alpha = c.W(p.alpha); a.pooled = c.W(p.pooled); a.w4C = c.P(P.w4C); a.w4Q = c.P(P.w4Q);
-            a.w4mlu = c.P(P.w4mlu); a.pool_w = c.P(P.pool_w); a.Wcat = c.P(P.cat_w); a.dc2q = c.W(p.dc2q); a.dq2c = c.W(p.dq2c);
-            a.dSr = c.W(p.dSr); a.df2 = c.W(p.df2); a.dC = c.W(p.dC); a.dQ = c.W(p.dQtot); a.scratch = c.W(p.dSs);
+            q.df1 = c.W(p.df1); q.df2 = c.W(p.df2); q.C = c.W(p.ve.out); q.Qf = c.W(p.qe.out); q.Srow = c.W(p.Srow);
+            q.Scol = c.W(p.Scol); q.M = c.W(p.M); q.alpha = c.W(p.alpha); q.pooled = c.W(p.pooled); q.WcqaT = c.PK(K.cqa_t);
+            q.w4C = c.P(P.w4C); q.w4Q = c.P(P.w4Q); q.w4mlu = c.P(P.w4mlu); q.pool_w = c.P(P.pool_w); q.Wcat = c.P(P.cat_w);
+            q.dC = c.W(p.dC); q.dQ = c.W(p.dQtot); q.dSr = c.W(p.dSr); q.dSs = c.W(p.dSs);
+            q.P1 = c.W(p.cqP1); q.P2 = c.W(p.cqP2); q.P3 = c.W(p.cqP3); q.P4 = c.W(p.cqP4); q.P5 = c.W(p.cqP5);
         }
-        a.T = T; a.Lq = Lq; a.b_off = 0; a.dc = c.drop(SITE_CQ_C); a.dq = c.drop(SITE_CQ_Q);
-        a.p_w4C = c.slab(P.w4C, D, B); a.p_w4Q = c.slab(P.w4Q, D, B); a.p_w4mlu = c.slab(P.w4mlu, D, B);
-        a.p_pool = c.slab(P.pool_w, D, B); a.p_bcat = c.slab(P.cat_b, D, B);
+        q.T = T; q.Lq = Lq; q.b_off = 0; q.dc = c.drop(SITE_CQ_C); q.dq = c.drop(SITE_CQ_Q);
+        q.p_w4C = c.slab(P.w4C, D, B * ntile); q.p_w4mlu = c.slab(P.w4mlu, D, B * ntile);
+        q.p_w4Q = c.slab(P.w4Q, D, B); q.p_pool = c.slab(P.pool_w, D, B); q.p_bcat = c.slab(P.cat_b, D, B);
         const int64_t o = c.part_alloc((int64_t)B * D * D);
         c.reg(P.cat_w + D, D * D, p.partial + o, B, D * D, D, 2 * D);          // second half of the (128, 256) weight
-        a.p_W2 = c.part_ptr(o);
-        LAUNCH("cq_col_bwd", launch_cq_col_bwd(a, B, c.s));
+        q.p_W2 = c.part_ptr(o);
+        LAUNCH("cq_bwd", launch_cq_bwd(q, B, c.s));
     }
-    // ---- shared feature encoder: video pass, then VisualProjection weight gradient
     // early reduction (predictor / heads / CQ parameters): all their partials exist once the launches above are done
     on_stream(sw, [&] { LAUNCH("reduce", launch_reduce(c.ws, io->grads, p.segs_dev, p.blk2seg_dev, p.nblocks_early, c.s)); });
     // fork: from here the video side (main) and the query side (sq) are independent
@@ -681,7 +680,12 @@ int build_plan(vsl_handle_s* h, int B, int T, int Lq, int Lc, Plan** out) {
         for (int i = 0; i < 4; ++i) t.gz[i] = al(Ra * D);
         t.ga = al(Ra * D); t.gb = al(Ra * D);
     }
-    p->df2 = al(R * D); p->df1 = al(R * D); p->dC = al(R * D); p->dc2q = al(R * D); p->dq2c = al(R * D);
+    p->df2 = al(R * D); p->df1 = al(R * D); p->dC = al(R * D);
+    {
+        const int64_t nt = (T + TILE_M - 1) / TILE_M;
+        p->cqP1 = al((int64_t)B * nt * 2 * Lq * D); p->cqP2 = al((int64_t)B * nt * Lq); p->cqP3 = al((int64_t)B * nt * Lq);
+        p->cqP4 = al((int64_t)B * nt * Lq * D); p->cqP5 = al((int64_t)B * nt * D);
+    }
     p->dSr = al(R * Lq); p->dSs = al(R * Lq); p->dQtot = al(Rq * D); p->dvf = al(R * D); p->dqf = al(Rq * D); p->dE = al(Rq * EW);
     p->partial = al(0);
     // dry-run the backward to lay out the partial arena and collect the reduction table

@@ -901,54 +901,57 @@ void launch_cqcat_bwd(const float* dg0, const float* dg1, const float* dg2, cons
 }
 
 // =========================================================================================================
-// a10 backward, row-tile part:  dcat = df1 Wcqa ; split into dC(direct), dc2q, dq2c ;
-//   dS_row = dc2q Q^T + dq2c M^T ; row-softmax backward -> dSr.
+// a10 / a11 backward (CQAttention :208-243, WeightedPool / CQConcatenate bias :246-274) as FOUR tile-parallel kernels.
+// Grid = (32-clip tiles, samples) for A, B, C -- every reduction over the clips of a sample goes through small per-tile
+// partials that the next kernel sums in its prologue -- and one workgroup per sample for the tiny finalise D.
+//   A: dcat = df1 Wcqa ; split into dC(direct), dc2q, dq2c ; dS_row + row-softmax backward -> dSr ;
+//      per-tile partials of dM = S_row^T dq2c and dQ(c2q) = S_row^T dc2q
+//   B: dM = sum of partials ; dS_col = C dM^T (-> scratch) ; per-tile partial of the column-softmax dot
+//   C: dS = dSr + S_col * (dS_col - dot) ; dC total ; per-tile partials of colsum(dS), dQ(trilinear), colsum(df2),
+//      and the w4C / w4mlu parameter slabs
+//   D: dQ total (+ WeightedPool / pooled-bias path), w4Q / pool / W2 / bias slabs
 // =========================================================================================================
-__global__ __launch_bounds__(256) void k_cq_out_bwd(const float* __restrict__ df1, const float* __restrict__ C,
-                                                    const float* __restrict__ Qf, const float* __restrict__ Srow,
-                                                    const float* __restrict__ M, const float* __restrict__ WTpack,
-                                                    float* __restrict__ dC, float* __restrict__ dc2q,
-                                                    float* __restrict__ dq2c, float* __restrict__ dSr, int T, int Lq) {
+__global__ __launch_bounds__(256) void k_cq_bwd_a(CqBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int T = a.T, Lq = a.Lq, LQ1 = Lq + 1;
     float* Dc = smem;                          // [32][CATP] grad wrt the concat tile
     float* Gs = Dc + TILE_M * CATP;            // [32][LDP]  df1 tile, later C tile
-    float* Ss = Gs + TILE_M * LDP;             // [32][Lq]   S_row
-    float* Sd = Ss + TILE_M * Lq;              // [32][Lq+1] dS_row
+    float* Ss = Gs + TILE_M * LDP;             // [32][LQ1]  S_row (+8 floats of slack for the chunked over-read)
+    float* Sd = Ss + TILE_M * LQ1 + 8;         // [32][LQ1]  dS_row
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const int b = blockIdx.y, t0 = blockIdx.x * TILE_M;
+    const int b = blockIdx.y, tl = blockIdx.x, t0 = tl * TILE_M, ntile = gridDim.x;
     const size_t crow = (size_t)b * T, qrow = (size_t)b * Lq;
-    load_tile128(Gs, df1 + crow * D, t0, TILE_M, T);
-    for (int e = tid; e < TILE_M * Lq; e += 256) Ss[e] = (t0 + e / Lq < T) ? Srow[(crow + t0) * Lq + e] : 0.f;
+    load_tile128(Gs, a.df1 + crow * D, t0, TILE_M, T);
+    for (int e = tid; e < TILE_M * Lq; e += 256) {
+        const int i = e / Lq, j = e - i * Lq;
+        Ss[i * LQ1 + j] = (t0 + i < T) ? a.Srow[(crow + t0) * Lq + e] : 0.f;
+    }
+    BFrag<4, 4> bf;
+    bfrag_load(bf, a.WcqaT, 4 * D, 32 * w, D, 0, D / 8);
     __syncthreads();
     f32x16 acc[4];
     zero_acc(acc);
-    {
-        BFrag<4, 4> bf;
-        bfrag_load(bf, WTpack, 4 * D, 32 * w, D, 0, D / 8);
-        gemm32p<4, 4>(Gs, LDP, D, WTpack, 4 * D, 32 * w, D, acc, bf);
-    }
+    gemm32p<4, 4>(Gs, LDP, D, a.WcqaT, 4 * D, 32 * w, D, acc, bf);
     const int col = 32 * w + (lane & 31);
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) Dc[acc_row(r, lane) * CATP + t * D + col] = acc[t][r];
     __syncthreads();
-    load_tile128(Gs, C + crow * D, t0, TILE_M, T);      // Gs now holds the C tile
+    load_tile128(Gs, a.C + crow * D, t0, TILE_M, T);      // Gs now holds the C tile
     __syncthreads();
+    const int c = tid & 127, hf = tid >> 7, hb = hf * 16;
     {
         // thread = (channel c, 16 rows): recompute c2q / q2c (:229-230), then the product-rule split of :231
-        const int c = tid & 127, hb = (tid >> 7) * 16;
         float a1[16], a2[16];
 #pragma unroll
         for (int q = 0; q < 16; ++q) { a1[q] = 0.f; a2[q] = 0.f; }
+#pragma unroll 4
         for (int j = 0; j < Lq; ++j) {
-            const float qv = Qf[(qrow + j) * D + c], mv = M[(qrow + j) * D + c];
+            const float qv = a.Qf[(qrow + j) * D + c], mv = a.M[(qrow + j) * D + c];
+            const float* sr = Ss + hb * LQ1 + j;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const float sv = Ss[(hb + q) * Lq + j];
-                a1[q] += sv * qv;
-                a2[q] += sv * mv;
-            }
+            for (int q = 0; q < 16; ++q) { a1[q] += sr[q * LQ1] * qv; a2[q] += sr[q * LQ1] * mv; }
         }
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
@@ -956,15 +959,10 @@ __global__ __launch_bounds__(256) void k_cq_out_bwd(const float* __restrict__ df
             float* d = Dc + rr * CATP;
             const float cv = Gs[rr * LDP + c];
             const float d0 = d[c], d1 = d[D + c], d2 = d[2 * D + c], d3 = d[3 * D + c];
-            const float g_c = d0 + d2 * a1[q] + d3 * a2[q];
-            const float g_c2q = d1 + d2 * cv;
-            const float g_q2c = d3 * cv;
-            d[D + c] = g_c2q;                  // keep in LDS for the dS dots below
+            const float g_c2q = d1 + d2 * cv, g_q2c = d3 * cv;
+            d[D + c] = g_c2q;                  // kept in LDS: dS dots and the dM / dQ partials below
             d[3 * D + c] = g_q2c;
-            if (t0 + rr < T) {
-                const size_t o = (crow + t0 + rr) * D + c;
-                dC[o] = g_c; dc2q[o] = g_c2q; dq2c[o] = g_q2c;
-            }
+            if (t0 + rr < T) a.dC[(crow + t0 + rr) * D + c] = d0 + d2 * a1[q] + d3 * a2[q];
         }
     }
     __syncthreads();
@@ -973,275 +971,281 @@ __global__ __launch_bounds__(256) void k_cq_out_bwd(const float* __restrict__ df
         const float4* r1 = reinterpret_cast<const float4*>(Dc + i * CATP + D);
         const float4* r3 = reinterpret_cast<const float4*>(Dc + i * CATP + 3 * D);
         for (int j = tid & 7; j < Lq; j += 8) {
-            const float4* qr = reinterpret_cast<const float4*>(Qf + (qrow + j) * D);
-            const float4* mr = reinterpret_cast<const float4*>(M + (qrow + j) * D);
-            float a = 0.f;
+            const float4* qr = reinterpret_cast<const float4*>(a.Qf + (qrow + j) * D);
+            const float4* mr = reinterpret_cast<const float4*>(a.M + (qrow + j) * D);
+            float s = 0.f;
 #pragma unroll 8
-            for (int c = 0; c < 32; ++c) {
-                const float4 x1 = r1[c], q4 = qr[c], x3 = r3[c], m4 = mr[c];
-                a += x1.x * q4.x + x1.y * q4.y + x1.z * q4.z + x1.w * q4.w + x3.x * m4.x + x3.y * m4.y + x3.z * m4.z + x3.w * m4.w;
+            for (int k = 0; k < 32; ++k) {
+                const float4 x1 = r1[k], q4 = qr[k], x3 = r3[k], m4 = mr[k];
+                s += x1.x * q4.x + x1.y * q4.y + x1.z * q4.z + x1.w * q4.w + x3.x * m4.x + x3.y * m4.y + x3.z * m4.z + x3.w * m4.w;
             }
-            Sd[i * (Lq + 1) + j] = a;
+            Sd[i * LQ1 + j] = s;
         }
+    }
+    // per-tile partials: dM_t[j][c] = sum_i Srow[i][j] dq2c[i][c] ; dQa_t[j][c] = sum_i Srow[i][j] dc2q[i][c]
+    {
+        const int jn = (Lq + 1) / 2, j0 = hf * jn, j1 = min(Lq, j0 + jn);
+        const int nj_u = __builtin_amdgcn_readfirstlane(j1 - j0);
+        float am[MAX_LQ / 2], aq[MAX_LQ / 2];
+#pragma unroll
+        for (int q = 0; q < MAX_LQ / 2; ++q) { am[q] = 0.f; aq[q] = 0.f; }
+#pragma unroll
+        for (int qc = 0; qc < MAX_LQ / 16; ++qc) {
+            if (qc * 8 < nj_u) {
+#pragma unroll 4
+                for (int i = 0; i < TILE_M; ++i) {
+                    const float x3 = Dc[i * CATP + 3 * D + c], x1 = Dc[i * CATP + D + c];
+                    const float* sr = Ss + i * LQ1 + j0 + qc * 8;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { am[qc * 8 + q] += sr[q] * x3; aq[qc * 8 + q] += sr[q] * x1; }
+                }
+            }
+        }
+        float* p1 = a.P1 + ((size_t)(b * ntile + tl) * 2) * Lq * D;
+#pragma unroll
+        for (int q = 0; q < MAX_LQ / 2; ++q)
+            if (q < j1 - j0) { p1[(size_t)(j0 + q) * D + c] = am[q]; p1[(size_t)(Lq + j0 + q) * D + c] = aq[q]; }
     }
     __syncthreads();
     for (int rr = w; rr < TILE_M; rr += 4) {     // softmax backward over the query words (dim=2, :225)
         const int t = t0 + rr;
         if (t >= T) continue;
-        const float s0 = lane < Lq ? Ss[rr * Lq + lane] : 0.f, s1 = lane + 64 < Lq ? Ss[rr * Lq + lane + 64] : 0.f;
-        const float g0 = lane < Lq ? Sd[rr * (Lq + 1) + lane] : 0.f, g1 = lane + 64 < Lq ? Sd[rr * (Lq + 1) + lane + 64] : 0.f;
+        const float s0 = lane < Lq ? Ss[rr * LQ1 + lane] : 0.f, s1 = lane + 64 < Lq ? Ss[rr * LQ1 + lane + 64] : 0.f;
+        const float g0 = lane < Lq ? Sd[rr * LQ1 + lane] : 0.f, g1 = lane + 64 < Lq ? Sd[rr * LQ1 + lane + 64] : 0.f;
         const float dot = wave_sum(s0 * g0 + s1 * g1);
-        if (lane < Lq) dSr[(crow + t) * Lq + lane] = s0 * (g0 - dot);
-        if (lane + 64 < Lq) dSr[(crow + t) * Lq + lane + 64] = s1 * (g1 - dot);
+        if (lane < Lq) a.dSr[(crow + t) * Lq + lane] = s0 * (g0 - dot);
+        if (lane + 64 < Lq) a.dSr[(crow + t) * Lq + lane + 64] = s1 * (g1 - dot);
     }
 }
-void launch_cq_out_bwd(const float* df1, const float* C, const float* Qf, const float* Srow, const float* M,
-                       const float* WTpack, float* dC, float* dc2q, float* dq2c, float* dSr, int B, int T, int Lq,
-                       hipStream_t s) {
-    const size_t shm = (size_t)(TILE_M * CATP + TILE_M * LDP + TILE_M * Lq + TILE_M * (Lq + 1)) * sizeof(float);
-    static size_t lds_ok = 0;
-    ensure_dynamic_lds((const void*)k_cq_out_bwd, shm, lds_ok, "k_cq_out_bwd");
-    hipLaunchKernelGGL(k_cq_out_bwd, dim3((T + TILE_M - 1) / TILE_M, B), dim3(256), shm, s, df1, C, Qf, Srow, M, WTpack, dC, dc2q,
-                       dq2c, dSr, T, Lq);
+
+// sums the per-tile partials of dM into LDS (dMs [Lq][LDP]); 8 loads in flight per thread
+__device__ __forceinline__ void cq_sum_dM(float* dMs, const float* __restrict__ P1, int b, int ntile, int Lq) {
+    for (int e = threadIdx.x; e < Lq * (D / 4); e += 256) {
+        const int j = e >> 5, c4 = (e & 31) * 4;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int t = 0; t < ntile; t += 4) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                v[u] = t + u < ntile ? *reinterpret_cast<const float4*>(P1 + ((size_t)(b * ntile + t + u) * 2) * Lq * D + (size_t)j * D + c4)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+        }
+        *reinterpret_cast<float4*>(dMs + j * LDP + c4) = s;
+    }
 }
 
-// =========================================================================================================
-// a10 / a11 backward, per-sample part (one workgroup per sample; everything that reduces over the clips):
-//   dM, dQ(c2q) ; column-softmax backward ; trilinear-score backward (w4C, w4Q, w4mlu, dC, dQ) ;
-//   WeightedPool + pooled-query bias backward.
-// =========================================================================================================
-#define CQ_STAMP(k) do { if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) a.dbg[k] = clock64(); } while (0)
-__global__ __launch_bounds__(256) void k_cq_col_bwd(CqColBwdArgs a) {
+__global__ __launch_bounds__(256) void k_cq_bwd_b(CqBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int T = a.T, Lq = a.Lq;
-    const int LQ1 = Lq + 1;
+    const int T = a.T, Lq = a.Lq, LQ1 = Lq + 1;
+    float* dMs = smem;                         // [Lq][LDP]
+    float* Cs = dMs + Lq * LDP;                // [32][LDP]
+    float* St = Cs + TILE_M * LDP;             // [32][LQ1] S_col tile
+    float* Sg = St + TILE_M * LQ1;             // [32][LQ1] dS_col tile
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y, tl = blockIdx.x, t0 = tl * TILE_M, ntile = gridDim.x;
+    const size_t crow = (size_t)b * T;
+    load_tile128(Cs, a.C + crow * D, t0, TILE_M, T);
+    for (int e = tid; e < TILE_M * Lq; e += 256) {
+        const int i = e / Lq, j = e - i * Lq;
+        St[i * LQ1 + j] = t0 + i < T ? a.Scol[(crow + t0) * Lq + e] : 0.f;
+    }
+    cq_sum_dM(dMs, a.P1, b, ntile, Lq);
+    __syncthreads();
+    {
+        const int i = tid >> 3;
+        const float4* cr = reinterpret_cast<const float4*>(Cs + i * LDP);
+        for (int j = tid & 7; j < Lq; j += 8) {
+            const float4* mr = reinterpret_cast<const float4*>(dMs + j * LDP);
+            float s = 0.f;
+#pragma unroll 8
+            for (int k = 0; k < 32; ++k) { const float4 x = cr[k], y = mr[k]; s += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w; }
+            Sg[i * LQ1 + j] = s;
+            if (t0 + i < T) a.dSs[(crow + t0 + i) * Lq + j] = s;
+        }
+    }
+    __syncthreads();
+    if (tid < Lq) {
+        float s = 0.f;
+        for (int i = 0; i < TILE_M; ++i) s += Sg[i * LQ1 + tid] * St[i * LQ1 + tid];
+        a.P2[(size_t)(b * ntile + tl) * Lq + tid] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cq_bwd_c(CqBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int T = a.T, Lq = a.Lq, LQ1 = Lq + 1;
     float* dMs = smem;                         // [Lq][LDP]  dM
-    float* dQs = dMs + Lq * LDP;               // [Lq][LDP]  dQ accumulator (un-dropped query grad)
-    float* Qds = dQs + Lq * LDP;               // [Lq][LDP]  dropped-out Q (as used by the trilinear score)
-    float* Cs = Qds + Lq * LDP;                // [32][LDP]  C tile
+    float* Qds = dMs + Lq * LDP;               // [Lq][LDP]  dropped-out Q (as used by the trilinear score)
+    float* Cs = Qds + Lq * LDP;                // [32][LDP]  C tile, later df2 tile
     float* Cd = Cs + TILE_M * LDP;             // [32][LDP]  dropped C tile
     float* St = Cd + TILE_M * LDP;             // [32][LQ1]  S_col tile
-    float* Sg = St + TILE_M * LQ1;             // [32][LQ1]  dS tile
-    float* csum = Sg + TILE_M * LQ1;           // [Lq] column dot for the softmax backward
-    float* cs2 = csum + Lq;                    // [Lq] column sums of dS
-    float* rsum = cs2 + Lq;                    // [32] row sums of dS
-    float* v128 = rsum + TILE_M;               // [4][128] small vectors: dpb, dpooled, (w4C acc), (w4mlu acc)
-    float* sv = v128 + 4 * D;                  // [Lq] small per-word scalars
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const int b = blockIdx.x;
+    float* Sg = St + TILE_M * LQ1 + 8;         // [32][LQ1]  dS tile (+ slack for the chunked over-read)
+    float* csum = Sg + TILE_M * LQ1 + 8;       // [Lq]
+    float* rsum = csum + Lq;                   // [32]
+    float* v128 = rsum + TILE_M;               // [4][128]
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y, tl = blockIdx.x, t0 = tl * TILE_M, ntile = gridDim.x;
     const size_t crow = (size_t)b * T, qrow = (size_t)b * Lq;
     const int c = tid & 127, hf = tid >> 7;
     const int jn = (Lq + 1) / 2, j0 = hf * jn, j1 = min(Lq, j0 + jn);
-    const int ntile = (T + TILE_M - 1) / TILE_M;
-    const int nj_u = __builtin_amdgcn_readfirstlane(j1 - j0);      // words owned by this thread half: wave-uniform
-
-    CQ_STAMP(0);
-    // ---- (1) dM[j][c] = sum_i Srow[i][j] dq2c[i][c] ; dQ(c2q)[j][c] = sum_i Srow[i][j] dc2q[i][c]
-    //      clips walked in bulk-staged 32-row tiles (Cs <- dq2c tile, Cd <- dc2q tile, St <- S_row tile)
-    {
-        float am[MAX_LQ / 2], aq[MAX_LQ / 2];
-#pragma unroll
-        for (int q = 0; q < MAX_LQ / 2; ++q) { am[q] = 0.f; aq[q] = 0.f; }
-        for (int tl = 0; tl < ntile; ++tl) {
-            const int t0 = tl * TILE_M, nr = min(TILE_M, T - t0);
-            load_tile128(Cs, a.dq2c + crow * D, t0, TILE_M, T);
-            load_tile128(Cd, a.dc2q + crow * D, t0, TILE_M, T);
-            for (int e = tid; e < TILE_M * Lq; e += 256) {
-                const int i = e / Lq, j = e - i * Lq;
-                St[i * LQ1 + j] = i < nr ? a.Srow[(crow + t0) * Lq + e] : 0.f;
-            }
-            __syncthreads();
-            // chunks of 8 words behind a WAVE-UNIFORM guard, unconditional inner body (a per-element predicate keeps the
-            // compiler from batching the LDS reads); reads past this thread's word range hit valid LDS and the
-            // corresponding accumulators are never stored
-#pragma unroll
-            for (int qc = 0; qc < MAX_LQ / 16; ++qc) {
-                if (qc * 8 < nj_u) {
-#pragma unroll 4
-                    for (int i = 0; i < TILE_M; ++i) {
-                        const float x3 = Cs[i * LDP + c], x1 = Cd[i * LDP + c];
-                        const float* sr = St + i * LQ1 + j0 + qc * 8;
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) { am[qc * 8 + q] += sr[q] * x3; aq[qc * 8 + q] += sr[q] * x1; }
-                    }
-                }
-            }
-            __syncthreads();
-        }
-#pragma unroll
-        for (int q = 0; q < MAX_LQ / 2; ++q)
-            if (q < j1 - j0) { dMs[(j0 + q) * LDP + c] = am[q]; dQs[(j0 + q) * LDP + c] = aq[q]; }
-    }
+    const int nj_u = __builtin_amdgcn_readfirstlane(j1 - j0);
+    // ---- prologue: tile loads + the cross-tile sums
+    load_tile128(Cs, a.C + crow * D, t0, TILE_M, T);
+    cq_sum_dM(dMs, a.P1, b, ntile, Lq);
     for (int e = tid; e < Lq * D; e += 256) {
         const int j = e >> 7, cc = e & 127;
         Qds[j * LDP + cc] = a.Qf[(qrow + j) * D + cc] * drop_mul(a.dq, (uint32_t)(((b + a.b_off) * Lq + j) * D + cc));
     }
-    if (tid < Lq) { csum[tid] = 0.f; cs2[tid] = 0.f; }
+    if (tid < Lq) {
+        float s = 0.f;
+        for (int t = 0; t < ntile; ++t) s += a.P2[(size_t)(b * ntile + t) * Lq + tid];
+        csum[tid] = s;
+    }
     __syncthreads();
-
-    CQ_STAMP(1);
-    // ---- (2) sweep 1: dSt[i][j] = dM[j] . C[i] -> scratch ; csum[j] = sum_i dSt[i][j] * Scol[i][j]
-    float* dS = a.scratch + crow * Lq;
-    for (int tl = 0; tl < ntile; ++tl) {
-        const int t0 = tl * TILE_M;
-        load_tile128(Cs, a.C + crow * D, t0, TILE_M, T);
-        for (int e = tid; e < TILE_M * Lq; e += 256) {
-            const int i = e / Lq, j = e - i * Lq;
-            St[i * LQ1 + j] = t0 + i < T ? a.Scol[(crow + t0) * Lq + e] : 0.f;
+    for (int e = tid; e < TILE_M * LQ1; e += 256) {
+        const int i = e / LQ1, j = e - i * LQ1;
+        float g = 0.f, st = 0.f;
+        if (j < Lq && t0 + i < T) {
+            const size_t o = (crow + t0 + i) * Lq + j;
+            st = a.Scol[o];
+            g = a.dSr[o] + st * (a.dSs[o] - csum[j]);
         }
-        __syncthreads();
-        {
-            const int i = tid >> 3;
-            const float4* cr = reinterpret_cast<const float4*>(Cs + i * LDP);
-            for (int j = tid & 7; j < Lq; j += 8) {
-                const float4* mr = reinterpret_cast<const float4*>(dMs + j * LDP);
-                float acc = 0.f;
-#pragma unroll 8
-                for (int k = 0; k < 32; ++k) { const float4 x = cr[k], y = mr[k]; acc += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w; }
-                Sg[i * LQ1 + j] = acc;
-                if (t0 + i < T) dS[(size_t)(t0 + i) * Lq + j] = acc;
-            }
-        }
-        __syncthreads();
-        if (tid < Lq) {
-            float acc = 0.f;
-            for (int i = 0; i < TILE_M && t0 + i < T; ++i) acc += Sg[i * LQ1 + tid] * St[i * LQ1 + tid];
-            csum[tid] += acc;
-        }
-        __syncthreads();
+        St[e] = st;
+        Sg[e] = g;
     }
-
-    CQ_STAMP(2);
-    // ---- (3) sweep 2: full dS tile, then the trilinear backward
-    float acc_w4C = 0.f, acc_mlu = 0.f;       // per-thread partials for channel c over this thread's rows
-    for (int tl = 0; tl < ntile; ++tl) {
-        const int t0 = tl * TILE_M;
-        load_tile128(Cs, a.C + crow * D, t0, TILE_M, T);
-        for (int e = tid; e < TILE_M * LQ1; e += 256) {
-            const int i = e / LQ1, j = e - i * LQ1;
-            float g = 0.f, st = 0.f;
-            if (j < Lq && t0 + i < T) {
-                st = a.Scol[(crow + t0 + i) * Lq + j];
-                g = a.dSr[(crow + t0 + i) * Lq + j] + st * (dS[(size_t)(t0 + i) * Lq + j] - csum[j]);
-            }
-            St[e] = st;
-            Sg[e] = g;
+    for (int e = tid; e < TILE_M * D; e += 256) {
+        const int rr = e >> 7, cc = e & 127;
+        const int t = t0 + rr;
+        Cd[rr * LDP + cc] = t < T ? Cs[rr * LDP + cc] * drop_mul(a.dc, (uint32_t)(((b + a.b_off) * T + t) * D + cc)) : 0.f;
+    }
+    __syncthreads();
+    if (tid < TILE_M) { float s = 0.f; for (int j = 0; j < Lq; ++j) s += Sg[tid * LQ1 + j]; rsum[tid] = s; }
+    if (tid >= 64 && tid < 64 + Lq) {          // per-tile partial of colsum(dS)
+        const int j = tid - 64;
+        float s = 0.f;
+        for (int i = 0; i < TILE_M; ++i) s += Sg[i * LQ1 + j];
+        a.P3[(size_t)(b * ntile + tl) * Lq + j] = s;
+    }
+    __syncthreads();
+    float acc_w4C = 0.f, acc_mlu = 0.f;
+    {
+        // rows of this thread: hf * 16 .. + 15 ; channel c
+        const float wC = a.w4C[c], wM = a.w4mlu[c];
+        float dcv[16], tq[16], tm[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int t = t0 + hf * 16 + q;
+            dcv[q] = t < T ? a.dC[(crow + t) * D + c] : 0.f;
+            tq[q] = 0.f; tm[q] = 0.f;
         }
-        __syncthreads();
-        for (int e = tid; e < TILE_M * D; e += 256) {
-            const int rr = e >> 7, cc = e & 127;
+        for (int j = 0; j < Lq; ++j) {
+            const float qv = Qds[j * LDP + c], mv = dMs[j * LDP + c];
+            const float* sg = Sg + hf * 16 * LQ1 + j;
+            const float* st = St + hf * 16 * LQ1 + j;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                tq[q] += sg[q * LQ1] * qv;                        // sum_j dS[i][j] Qd[j][c]
+                tm[q] += st[q * LQ1] * mv;                        // sum_j Scol[i][j] dM[j][c]   (M = Scol^T C)
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int rr = hf * 16 + q;
             const int t = t0 + rr;
-            Cd[rr * LDP + cc] = t < T ? Cs[rr * LDP + cc] * drop_mul(a.dc, (uint32_t)(((b + a.b_off) * T + t) * D + cc)) : 0.f;
+            const float cdv = Cd[rr * LDP + c];
+            const float dcd = rsum[rr] * wC + wM * tq[q];         // grad wrt dropped-out C
+            acc_w4C += rsum[rr] * cdv;
+            acc_mlu += tq[q] * cdv;
+            if (t < T) a.dC[(crow + t) * D + c] = dcv[q] + tm[q] + dcd * drop_mul(a.dc, (uint32_t)(((b + a.b_off) * T + t) * D + c));
         }
-        if (tid < TILE_M) { float s = 0.f; for (int j = 0; j < Lq; ++j) s += Sg[tid * LQ1 + j]; rsum[tid] = s; }
-        if (tid >= 64 && tid < 64 + Lq) { const int j = tid - 64; float s = 0.f; for (int i = 0; i < TILE_M; ++i) s += Sg[i * LQ1 + j]; cs2[j] += s; }
-        __syncthreads();
-        {
-            // rows of this thread: hf * 16 .. + 15 ; channel c.  The direct part of dC is read up front (16 independent
-            // loads in flight) -- a read-modify-write inside the loop would serialise on memory latency.
-            const float wC = a.w4C[c], wM = a.w4mlu[c];
-            float dcv[16];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int t = t0 + hf * 16 + q;
-                dcv[q] = t < T ? a.dC[(crow + t) * D + c] : 0.f;
-            }
-            float tq[16], tm[16];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) { tq[q] = 0.f; tm[q] = 0.f; }
-            for (int j = 0; j < Lq; ++j) {
-                const float qv = Qds[j * LDP + c], mv = dMs[j * LDP + c];
-                const float* sg = Sg + hf * 16 * LQ1 + j;
-                const float* st = St + hf * 16 * LQ1 + j;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    tq[q] += sg[q * LQ1] * qv;                        // sum_j dS[i][j] Qd[j][c]
-                    tm[q] += st[q * LQ1] * mv;                        // sum_j Scol[i][j] dM[j][c]   (M = Scol^T C)
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int rr = hf * 16 + q;
-                const int t = t0 + rr;
-                const float cdv = Cd[rr * LDP + c];
-                const float dcd = rsum[rr] * wC + wM * tq[q];         // grad wrt dropped-out C
-                acc_w4C += rsum[rr] * cdv;
-                acc_mlu += tq[q] * cdv;
-                dcv[q] += tm[q] + dcd * drop_mul(a.dc, (uint32_t)(((b + a.b_off) * T + t) * D + c));
-            }
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int t = t0 + hf * 16 + q;
-                if (t < T) a.dC[(crow + t) * D + c] = dcv[q];
-            }
-        }
-        // dQ[j][c] += mask_q[j][c] * w4mlu[c] * sum_i dS[i][j] Cd[i][c]      (thread owns (c, its half of the words))
-        {
-            const float wM = a.w4mlu[c];
-#pragma unroll
-            for (int qc = 0; qc < MAX_LQ / 16; ++qc) {
-                if (qc * 8 < nj_u) {
-                    float acc[8];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) acc[q] = 0.f;
-#pragma unroll 4
-                    for (int i = 0; i < TILE_M; ++i) {
-                        const float cv = Cd[i * LDP + c] * wM;
-                        const float* sg = Sg + i * LQ1 + j0 + qc * 8;
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) acc[q] += sg[q] * cv;
-                    }
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int j = j0 + qc * 8 + q;
-                        if (j < j1) dQs[j * LDP + c] += acc[q] * drop_mul(a.dq, (uint32_t)(((b + a.b_off) * Lq + j) * D + c));
-                    }
-                }
-            }
-        }
-        __syncthreads();
     }
-    CQ_STAMP(3);
-    // combine the two row-halves of the per-channel accumulators
+    {   // per-tile partial of dQ(trilinear)[j][c] = mask_q * w4mlu[c] * sum_i dS[i][j] Cd[i][c]
+        const float wM = a.w4mlu[c];
+        float* p4 = a.P4 + (size_t)(b * ntile + tl) * Lq * D;
+#pragma unroll
+        for (int qc = 0; qc < MAX_LQ / 16; ++qc) {
+            if (qc * 8 < nj_u) {
+                float acc[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+#pragma unroll 4
+                for (int i = 0; i < TILE_M; ++i) {
+                    const float cv = Cd[i * LDP + c] * wM;
+                    const float* sg = Sg + i * LQ1 + j0 + qc * 8;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) acc[q] += sg[q] * cv;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int j = j0 + qc * 8 + q;
+                    if (j < j1) p4[(size_t)j * D + c] = acc[q] * drop_mul(a.dq, (uint32_t)(((b + a.b_off) * Lq + j) * D + c));
+                }
+            }
+        }
+    }
     v128[hf * D + c] = acc_w4C;
     v128[2 * D + hf * D + c] = acc_mlu;
-    __syncthreads();
+    __syncthreads();                           // (also: everyone is done with Cs)
+    load_tile128(Cs, a.df2 + crow * D, t0, TILE_M, T);
     if (tid < D) {
-        a.p_w4C[(size_t)b * D + tid] = v128[tid] + v128[D + tid];
-        a.p_w4mlu[(size_t)b * D + tid] = v128[2 * D + tid] + v128[3 * D + tid];
-        // dw4Q[c] = sum_j cs2[j] Qd[j][c]
+        a.p_w4C[(size_t)(b * ntile + tl) * D + tid] = v128[tid] + v128[D + tid];
+        a.p_w4mlu[(size_t)(b * ntile + tl) * D + tid] = v128[2 * D + tid] + v128[3 * D + tid];
+    }
+    __syncthreads();
+    if (tid < D) {                             // per-tile partial of dpb[o] = sum_t df2[b, t, o]
         float s = 0.f;
-        for (int j = 0; j < Lq; ++j) s += cs2[j] * Qds[j * LDP + tid];
-        a.p_w4Q[(size_t)b * D + tid] = s;
+#pragma unroll 8
+        for (int i = 0; i < TILE_M; ++i) s += Cs[i * LDP + tid];
+        a.P5[(size_t)(b * ntile + tl) * D + tid] = s;
     }
-    __syncthreads();
-    // dQ += cs2[j] * w4Q * dropmask_q      (the s1 = Qd . w4Q term of the trilinear score)
-    for (int e = tid; e < Lq * D; e += 256) {
-        const int j = e >> 7, cc = e & 127;
-        dQs[j * LDP + cc] += cs2[j] * a.w4Q[cc] * drop_mul(a.dq, (uint32_t)(((b + a.b_off) * Lq + j) * D + cc));
+}
+
+__global__ __launch_bounds__(256) void k_cq_bwd_d(CqBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int Lq = a.Lq, ntile = a.ntile;
+    float* dQs = smem;                         // [Lq][LDP] dQ accumulator
+    float* cs2 = dQs + Lq * LDP;               // [Lq] colsum(dS)
+    float* sv = cs2 + Lq;                      // [Lq]
+    float* v128 = sv + Lq;                     // [4][128]
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int b = blockIdx.x;
+    const size_t qrow = (size_t)b * Lq;
+    if (tid < Lq) {
+        float s = 0.f;
+        for (int t = 0; t < ntile; ++t) s += a.P3[(size_t)(b * ntile + t) * Lq + tid];
+        cs2[tid] = s;
     }
-    CQ_STAMP(4);
-    // ---- (4) pooled-query path: pb = W2 pooled + bcat ; pooled = sum_j alpha_j Q[j] ; alpha = softmax(Q w + mask)
-    //      both 128-long reductions run with 8 independent loads in flight per thread and both thread halves busy
-    {
-        const int o = tid & 127, hh = tid >> 7;
-        float s8[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) s8[q] = 0.f;
-        for (int t = hh * 8; t < T; t += 16) {            // dpb[o] = sum_t df2[b, t, o]
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-                if (t + q < T) s8[q] += a.df2[(crow + t + q) * D + o];
-        }
-        v128[2 * D + hh * D + o] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
-    }
-    __syncthreads();
-    if (tid < D) {
-        const float s = v128[2 * D + tid] + v128[3 * D + tid];
-        v128[tid] = s;                                   // dpb[o]
+    if (tid < D) {                             // dpb[o] = sum over tiles of colsum(df2)
+        float s = 0.f;
+        for (int t = 0; t < ntile; ++t) s += a.P5[(size_t)(b * ntile + t) * D + tid];
+        v128[tid] = s;
         a.p_bcat[(size_t)b * D + tid] = s;
     }
     __syncthreads();
+    // dQ = sum_tiles (dQ(c2q) + dQ(trilinear)) + colsum(dS)[j] * w4Q * mask_q
+    for (int e = tid; e < Lq * (D / 4); e += 256) {
+        const int j = e >> 5, c4 = (e & 31) * 4;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int t = 0; t < ntile; ++t) {
+            const float4 x = *reinterpret_cast<const float4*>(a.P1 + ((size_t)(b * ntile + t) * 2 + 1) * Lq * D + (size_t)j * D + c4);
+            const float4 y = *reinterpret_cast<const float4*>(a.P4 + (size_t)(b * ntile + t) * Lq * D + (size_t)j * D + c4);
+            s.x += x.x + y.x; s.y += x.y + y.y; s.z += x.z + y.z; s.w += x.w + y.w;
+        }
+        const float4 wq = *reinterpret_cast<const float4*>(a.w4Q + c4);
+        const uint32_t base = (uint32_t)(((b + a.b_off) * Lq + j) * D + c4);
+        s.x += cs2[j] * wq.x * drop_mul(a.dq, base); s.y += cs2[j] * wq.y * drop_mul(a.dq, base + 1);
+        s.z += cs2[j] * wq.z * drop_mul(a.dq, base + 2); s.w += cs2[j] * wq.w * drop_mul(a.dq, base + 3);
+        *reinterpret_cast<float4*>(dQs + j * LDP + c4) = s;
+    }
+    if (tid < D) {                             // dw4Q[c] = sum_j colsum(dS)[j] * Qd[j][c]
+        float s = 0.f;
+#pragma unroll 4
+        for (int j = 0; j < Lq; ++j) s += cs2[j] * a.Qf[(qrow + j) * D + tid] * drop_mul(a.dq, (uint32_t)(((b + a.b_off) * Lq + j) * D + tid));
+        a.p_w4Q[(size_t)b * D + tid] = s;
+    }
+    // ---- pooled-query path: pb = W2 pooled + bcat ; pooled = sum_j alpha_j Q[j] ; alpha = softmax(Q w + mask)
     for (int e = tid; e < D * D; e += 256)                // dW2[o][c] = dpb[o] * pooled[c]
         a.p_W2[(size_t)b * D * D + e] = v128[e >> 7] * a.pooled[(size_t)b * D + (e & 127)];
     {
@@ -1278,32 +1282,29 @@ __global__ __launch_bounds__(256) void k_cq_col_bwd(CqColBwdArgs a) {
         for (int j = 0; j < Lq; ++j) s += sv[j] * a.Qf[(qrow + j) * D + tid];
         a.p_pool[(size_t)b * D + tid] = s;
     }
-    CQ_STAMP(5);
     for (int e = tid; e < Lq * D; e += 256) {
         const int j = e >> 7, cc = e & 127;
         a.dQ[(qrow + j) * D + cc] = dQs[j * LDP + cc] + a.alpha[qrow + j] * v128[D + cc] + sv[j] * a.pool_w[cc];
     }
-    CQ_STAMP(6);
 }
-void launch_cq_col_bwd(const CqColBwdArgs& a, int B, hipStream_t s) {
-    const int Lq = a.Lq;
-    const size_t shm = (size_t)(3 * Lq * LDP + 2 * TILE_M * LDP + 2 * TILE_M * (Lq + 1) + 2 * Lq + TILE_M + 4 * D + Lq) * sizeof(float);
-    static size_t lds_ok = 0;
-    ensure_dynamic_lds((const void*)k_cq_col_bwd, shm, lds_ok, "k_cq_col_bwd");
-    static long long* dbg = nullptr;
-    static int dbg_left = -1;
-    if (dbg_left < 0) { dbg_left = getenv("VSL_DEBUG_TIMING") ? 2 : 0; if (dbg_left) (void)hipMalloc(&dbg, 64 * sizeof(long long)); }
-    CqColBwdArgs a2 = a;
-    a2.dbg = dbg_left > 0 ? dbg : nullptr;
-    hipLaunchKernelGGL(k_cq_col_bwd, dim3(B), dim3(256), shm, s, a2);
-    if (dbg_left > 0) {
-        long long hst[8];
-        (void)hipStreamSynchronize(s);
-        (void)hipMemcpy(hst, dbg, sizeof hst, hipMemcpyDeviceToHost);
-        fprintf(stderr, "[cq_col_bwd cycles] step1 %lld | sweep1 %lld | sweep2 %lld | combine %lld | pooled %lld | tail %lld | total %lld\n",
-                hst[1] - hst[0], hst[2] - hst[1], hst[3] - hst[2], hst[4] - hst[3], hst[5] - hst[4], hst[6] - hst[5], hst[6] - hst[0]);
-        --dbg_left;
-    }
+
+void launch_cq_bwd(const CqBwdArgs& a0, int B, hipStream_t s) {
+    CqBwdArgs a = a0;
+    const int Lq = a.Lq, ntile = (a.T + TILE_M - 1) / TILE_M;
+    a.ntile = ntile;
+    const size_t shmA = (size_t)(TILE_M * CATP + TILE_M * LDP + 2 * TILE_M * (Lq + 1) + 8) * sizeof(float);
+    const size_t shmB = (size_t)(Lq * LDP + TILE_M * LDP + 2 * TILE_M * (Lq + 1)) * sizeof(float);
+    const size_t shmC = (size_t)(2 * Lq * LDP + 2 * TILE_M * LDP + 2 * TILE_M * (Lq + 1) + 16 + Lq + TILE_M + 4 * D) * sizeof(float);
+    const size_t shmD = (size_t)(Lq * LDP + 2 * Lq + 4 * D) * sizeof(float);
+    static size_t okA = 0, okB = 0, okC = 0, okD = 0;
+    ensure_dynamic_lds((const void*)k_cq_bwd_a, shmA, okA, "k_cq_bwd_a");
+    ensure_dynamic_lds((const void*)k_cq_bwd_b, shmB, okB, "k_cq_bwd_b");
+    ensure_dynamic_lds((const void*)k_cq_bwd_c, shmC, okC, "k_cq_bwd_c");
+    ensure_dynamic_lds((const void*)k_cq_bwd_d, shmD, okD, "k_cq_bwd_d");
+    hipLaunchKernelGGL(k_cq_bwd_a, dim3(ntile, B), dim3(256), shmA, s, a);
+    hipLaunchKernelGGL(k_cq_bwd_b, dim3(ntile, B), dim3(256), shmB, s, a);
+    hipLaunchKernelGGL(k_cq_bwd_c, dim3(ntile, B), dim3(256), shmC, s, a);
+    hipLaunchKernelGGL(k_cq_bwd_d, dim3(B), dim3(256), shmD, s, a);
 }
 
 // =========================================================================================================

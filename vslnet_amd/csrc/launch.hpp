@@ -163,23 +163,24 @@ void launch_qkv_bwd(const float* dQ, const float* dK, const float* dV, const flo
 void launch_cqcat_bwd(const float* dg0, const float* dg1, const float* dg2, const float* dh_loss, const float* f2,
                       const float* hscore, const float* wh, const float* W1Tpack, float* df2, float* df1, float* p_wh,
                       float* p_bh, int R, hipStream_t s);
-void launch_cq_out_bwd(const float* df1, const float* C, const float* Qf, const float* Srow, const float* M,
-                       const float* WTpack, float* dC, float* dc2q, float* dq2c, float* dSr, int B, int T, int Lq,
-                       hipStream_t s);
-struct CqColBwdArgs {
-    const float *C, *Qf, *Srow, *Scol, *cmask, *qmask, *alpha, *pooled;
+struct CqBwdArgs {
+    const float *df1, *df2, *C, *Qf, *Srow, *Scol, *M, *alpha, *pooled;      // saved forward tensors / incoming grads
+    const float *WcqaT;                                                        // transpose pack of cqa_linear (ncols 512)
     const float *w4C, *w4Q, *w4mlu, *pool_w, *Wcat;
-    const float *dc2q, *dq2c, *dSr, *df2;
-    float *dC;            // (B,T,128): in = direct part from cq_out_bwd, out = total grad wrt the video encoder output
-    float *dQ;            // (B,Lq,128) total grad wrt the query encoder output
-    float *p_w4C, *p_w4Q, *p_w4mlu, *p_pool, *p_bcat;   // per-sample partial slabs [B][128]
-    float *p_W2;          // per-sample partial slabs [B][128][128] for Wcat[:, 128:]
-    float *scratch;       // (B, T*Lq) workspace for dS
-    int T, Lq, b_off;
+    float *dC;            // (B,T,128) out: total grad wrt the video encoder output
+    float *dQ;            // (B,Lq,128) out: total grad wrt the query encoder output
+    float *dSr, *dSs;     // (B,T,Lq) scratch: row-softmax backward, dS_col
+    float *P1;            // [B][ntile][2][Lq][128] per-tile partials of dM and dQ(c2q)
+    float *P2, *P3;       // [B][ntile][Lq] partials of the column-softmax dot / colsum(dS)
+    float *P4;            // [B][ntile][Lq][128] partial of dQ(trilinear)
+    float *P5;            // [B][ntile][128] partial of colsum(df2)
+    float *p_w4C, *p_w4mlu;                              // parameter slabs [B * ntile][128]
+    float *p_w4Q, *p_pool, *p_bcat;                      // parameter slabs [B][128]
+    float *p_W2;                                         // [B][128][128] for Wcat[:, 128:]
+    int T, Lq, b_off, ntile;
     Drop dc, dq;
-    long long* dbg;       // optional phase timestamps (VSL_DEBUG_TIMING)
 };
-void launch_cq_col_bwd(const CqColBwdArgs& a, int B, hipStream_t s);
+void launch_cq_bwd(const CqBwdArgs& a, int B, hipStream_t s);
 void launch_linear_bwd_data(const float* G, const float* WTpack, float* dA, int R, int K, hipStream_t s);
 void launch_embed_bwd(const float* dE, const int64_t* word_ids, const int64_t* char_ids, const float* E,
                       const int8_t* argpos, const float* char_tab, CharConvPtrs cc, const int* wdecode /*[64*256] host-built*/,
