@@ -45,7 +45,7 @@ struct ModelP {
     EncP pe;
     int sln_g, sln_b, eln_g, eln_b, s0w, s0b, s1w, s1b, e0w, e0b, e1w, e1b;
 };
-struct ModelPk { int va_f, emb_f, emb_t; EncPk fe, pe; int cqa_f, cqa_t, cat1_f, cat1_t, s0_f, s0_t, e0_f, e0_t; };
+struct ModelPk { int va_f, emb_f, emb_t; EncPk fe, pe; int cqa_f, cqa_t, cat1_f, cat1_t, s0_f, s0_t, e0_f, e0_t, ccw_img; };
 
 struct EncWs { int64_t x0, y[4], u[4], mask[4], h1, q, k, v, lse, att, r, h2, out; int R, L; };
 
@@ -240,6 +240,17 @@ void build_packs(vsl_handle_s* h) {
     K.s0_t = pk.tr(P.s0w, D, 2 * D, 2 * D);
     K.e0_f = pk.fwd(P.e0w, D, 2 * D, 2 * D);
     K.e0_t = pk.tr(P.e0w, D, 2 * D, 2 * D);
+    // char-conv weights as one [ci][4 taps][100 channels] image; each job writes all 4 tap slots of its channels (zero
+    // beyond the kernel width), so the image is fully defined every step
+    K.ccw_img = (int)h->pack_floats;
+    h->pack_floats += (int64_t)c.char_dim * 400;
+    const int chn[4] = {10, 20, 30, 40};
+    int oc0 = 0;
+    for (int i = 0; i < 4; ++i) {
+        PackJob j{P.ccw[i], K.ccw_img, chn[i] * c.char_dim * 4, 1, i + 1, 3, c.char_dim, 0, oc0};
+        h->jobs.push_back(j);
+        oc0 += chn[i];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ plan
@@ -363,7 +374,7 @@ void run_forward(Ctx& c) {
     LAUNCH("vproj_fwd", launch_vproj_fwd(io.video_features, c.PK(K.va_f), c.P(P.va_b), c.W(p.vf), R, cf.video_feature_dim, c.drop(SITE_VIS), c.s));
     enc_fwd(c, P.fe, K.fe, p.ve, c.W(p.vf), io.v_mask, B, 0);
     c.s = sq;
-    LAUNCH("embed_fwd", launch_embed_fwd(io.word_ids, io.char_ids, io.pad_vec, c.P(P.unk), io.glove_vec, c.P(P.char_tab), char_ptrs(c), c.W(p.E),
+    LAUNCH("embed_fwd", launch_embed_fwd(io.word_ids, io.char_ids, io.pad_vec, c.P(P.unk), io.glove_vec, c.P(P.char_tab), char_ptrs(c), c.PK(K.ccw_img), c.W(p.E),
                      reinterpret_cast<int8_t*>(c.W(p.argpos)), Rq, p.Lc, cf.word_dim, cf.char_dim, c.drop(SITE_WORD),
                      c.drop(SITE_CHAR), c.s));
     LAUNCH("linear_fwd", launch_linear_fwd(c.W(p.E), c.PK(K.emb_f), c.P(P.emb_b), c.W(p.qf), Rq, cf.word_dim + 100, c.s));

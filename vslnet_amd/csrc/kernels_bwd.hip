@@ -1366,8 +1366,9 @@ __global__ __launch_bounds__(256) void k_embed_bwd(const float* __restrict__ dE,
     float* Ce = Wl + ((wtot + 7) & ~3);       // [EMB_CHUNK * Lc + 4][64] dropped char embeddings (+ zero rows)
     float* gch = Ce + (EMB_CHUNK * Lc + 4) * 64;   // [EMB_CHUNK][128] grads of the 100 char features (0 where inactive)
     float* gt = gch + EMB_CHUNK * 128;        // [Lc][100] per-word table: g[oc] where tap p - pos[oc] is valid, else 0
-    float* tab = gt + Lc * 100;               // [4 position quarters][char_size][char_dim] table-gradient accumulators
-    int* it = reinterpret_cast<int*>(tab + 4 * char_size * char_dim);  // [Lc][100] weight offset | tap stride << 24
+    float* tab = gt + Lc * 100;               // [char_size][char_dim] table-gradient accumulator
+    float* dce = tab + char_size * char_dim;  // [Lc][64] char-embedding gradients of the current word
+    int* it = reinterpret_cast<int*>(dce + Lc * 64);                   // [Lc][100] weight offset | tap stride << 24
     __shared__ int pos[EMB_CHUNK * 128];
     __shared__ int cids[EMB_CHUNK * MAX_LC];
     __shared__ int obase[128], okk[128];
@@ -1397,7 +1398,7 @@ __global__ __launch_bounds__(256) void k_embed_bwd(const float* __restrict__ dE,
         else if (tid < 100) { k = 4; base = s0 + s1 + s2 + (tid - 60) * char_dim * 4; }
         okk[tid] = k; obase[tid] = base;
     }
-    for (int e = tid; e < 4 * char_size * char_dim; e += 256) tab[e] = 0.f;
+    for (int e = tid; e < char_size * char_dim; e += 256) tab[e] = 0.f;
     for (int e = tid; e < 4 * 64; e += 256) Ce[EMB_CHUNK * Lc * 64 + e] = 0.f;
     for (int e = tid; e < EMB_CHUNK * MAX_LC; e += 256) {
         const int wi = e / MAX_LC, p = e - wi * MAX_LC;
@@ -1495,11 +1496,17 @@ __global__ __launch_bounds__(256) void k_embed_bwd(const float* __restrict__ dE,
 #pragma unroll
                         for (int q = 0; q < 20; q += 2) { a0 += gg[q] * ww[q]; a1 += gg[q + 1] * ww[q + 1]; }
                     }
-                    // positions p, p+4, ... of one thread may hold the same character; different threads (pq) too ->
-                    // the per-quarter partial tables below keep this race-free without atomics
-                    tab[(pq * char_size + cid) * char_dim + ci] += (a0 + a1) * drop_mul(dc, (uint32_t)((r * Lc + p) * char_dim + ci));
+                    dce[p * 64 + ci] = (a0 + a1) * drop_mul(dc, (uint32_t)((r * Lc + p) * char_dim + ci));
                 }
         }
+        __syncthreads();
+        // scatter per character: thread = input channel, serial over the positions (two positions of one word may hold
+        // the same character) -> one table accumulator, no atomics
+        if (tid < char_dim)
+            for (int p = 0; p < Lc; ++p) {
+                const int cid = cids[wi * MAX_LC + p];
+                if (cid != 0) tab[cid * char_dim + tid] += dce[p * 64 + tid];
+            }
         __syncthreads();
     }
     STAMP(4);
@@ -1521,8 +1528,7 @@ __global__ __launch_bounds__(256) void k_embed_bwd(const float* __restrict__ dE,
     if (tid < word_dim) p_unk[(size_t)blockIdx.x * word_dim + tid] = uacc0;
     if (tid + 256 < word_dim) p_unk[(size_t)blockIdx.x * word_dim + tid + 256] = uacc1;
     for (int e = tid; e < char_size * char_dim; e += 256)
-        p_tab[(size_t)blockIdx.x * char_size * char_dim + e] = tab[e] + tab[char_size * char_dim + e] + tab[2 * char_size * char_dim + e] +
-                                                             tab[3 * char_size * char_dim + e];
+        p_tab[(size_t)blockIdx.x * char_size * char_dim + e] = tab[e];
     STAMP(5);
 }
 void launch_embed_bwd(const float* dE, const int64_t* word_ids, const int64_t* char_ids, const float* E,
@@ -1530,8 +1536,8 @@ void launch_embed_bwd(const float* dE, const int64_t* word_ids, const int64_t* c
                       float* p_tab, float* p_unk, int Rq, int Lc, int word_dim, int char_dim, int char_size, Drop dw, Drop dc,
                       hipStream_t s) {
     (void)wdecode;
-    const size_t shm = (size_t)(((char_dim * 300 + 7) & ~3) + (EMB_CHUNK * Lc + 4) * 64 + EMB_CHUNK * 128 + 2 * Lc * 100 +
-                                4 * char_size * char_dim) * sizeof(float);
+    const size_t shm = (size_t)(((char_dim * 300 + 7) & ~3) + (EMB_CHUNK * Lc + 4) * 64 + EMB_CHUNK * 128 + 2 * Lc * 100 + Lc * 64 +
+                                char_size * char_dim) * sizeof(float);
     static size_t lds_ok = 0;
     ensure_dynamic_lds((const void*)k_embed_bwd, shm + 16 * 1024, lds_ok, "k_embed_bwd");
     hipLaunchKernelGGL(k_embed_bwd, dim3((Rq + EMB_CHUNK - 1) / EMB_CHUNK), dim3(256), shm, s, dE, word_ids, char_ids, E, argpos,

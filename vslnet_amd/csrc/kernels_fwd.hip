@@ -5,6 +5,26 @@
 
 namespace vsl {
 
+// VSL_DEBUG_TIMING: block 0 / thread 0 of an instrumented kernel stamps the shader clock at its phase boundaries
+__device__ long long g_stamps_f[32];
+__device__ int g_dbg_on_f = 0;
+#define FSTAMP(k) do { if (g_dbg_on_f && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_stamps_f[k] = clock64(); } while (0)
+static int fdbg_on() {
+    static int inited = 0, on = 0;
+    if (!inited) { inited = 1; on = getenv("VSL_DEBUG_TIMING") != nullptr; if (on) { int one = 1; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_on_f), &one, sizeof one); } }
+    return on;
+}
+static void fdbg_report(const char* name, int nst, hipStream_t s, int& left) {
+    if (left <= 0) return;
+    long long h[32];
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamps_f), sizeof h);
+    fprintf(stderr, "[%s cycles]", name);
+    for (int i = 1; i < nst; ++i) fprintf(stderr, " %lld", h[i] - h[i - 1]);
+    fprintf(stderr, " | total %lld\n", h[nst - 1] - h[0]);
+    --left;
+}
+
 // =========================================================================================================
 // weight packing (one launch per forward; jobs table lives in the plan)
 // =========================================================================================================
@@ -15,6 +35,19 @@ __global__ __launch_bounds__(256) void k_pack(const float* __restrict__ params, 
     for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
         int k, c;
         float v;
+        if (j.transpose == 3) {     // char-conv weight (nch, char_dim, 1, kw) -> image [ci][4 taps][100 channels]
+            // kn = nch * char_dim * 4 (every tap slot written: zero beyond the kernel width) ; ld = kw ; ncols = char_dim ;
+            // col_off = first channel of this conv
+            const int kw = j.ld, cd = j.ncols;
+            const int ch = e / (cd * 4), t = e - ch * cd * 4;
+            const int ci = t >> 2, kk = t & 3;
+            pack[j.dst + (ci * 4 + kk) * 100 + j.col_off + ch] = kk < kw ? params[j.src + (ch * cd + ci) * kw + kk] : 0.f;
+            continue;
+        }
+        if (j.transpose == 4) {     // zero fill of kn * cn floats
+            pack[j.dst + e] = 0.f;
+            continue;
+        }
         if (j.transpose) {          // Bm[k][c] = W[k][c]  (W row = contraction index): c is the fast source index
             k = e / j.cn; c = e - k * j.cn;
             v = params[j.src + (size_t)k * j.ld + c];
@@ -107,74 +140,127 @@ void launch_vproj_fwd(const float* X, const float* Wpack, const float* bias, flo
 
 // =========================================================================================================
 // a3/a4  word + character embedding (:25-72) -> concatenated (Rq, 300 + 100) row, ready for the a5 linear.
-//   one workgroup (128 threads) per query word.
-//   char CNN: 4 x [Conv2d(50 -> c, (1,k)) + bias + ReLU -> max over char positions]; the arg-max position is
-//   saved (int8) for the backward.  Requires k <= Lc <= MAX_LC.
+//   One workgroup per EF_CHUNK = 8 query words.
+//   word part : F.embedding over [pad; unk; glove] (:41) + dropout.
+//   char CNN  : 4 x [Conv2d(50 -> c, (1,k)) + bias + ReLU -> max over char positions]; the arg-max position is saved
+//               (int8) for the backward.  The 15000 conv weights are staged once per workgroup into LDS TRANSPOSED
+//               ([ci*k + kk][channel], channel fastest: conflict-free for lanes that own consecutive channels); the
+//               dropped-out char embeddings of the 8 words are staged transposed ([word][ci][position], zero padded) so
+//               the sliding window of a channel is 3 vector LDS reads.  thread = (word, channel) items, 8 positions
+//               at a time, no predicates in the inner loop.  Requires 4 <= Lc <= MAX_LC.
 // =========================================================================================================
-__device__ __forceinline__ void char_channel(int oc, int& conv, int& ch, int& k, int& woff, int& boff) {
-    // channel oc in [0,100): convs have 10/20/30/40 channels with kernel widths 1/2/3/4
-    if (oc < 10) { conv = 0; ch = oc; k = 1; }
-    else if (oc < 30) { conv = 1; ch = oc - 10; k = 2; }
-    else if (oc < 60) { conv = 2; ch = oc - 30; k = 3; }
-    else { conv = 3; ch = oc - 60; k = 4; }
-    woff = 0; boff = 0;
-}
-__global__ __launch_bounds__(128) void k_embed_fwd(const int64_t* __restrict__ word_ids, const int64_t* __restrict__ char_ids,
+constexpr int EF_CHUNK = 8;
+constexpr int EF_PT = 28;                   // padded positions per (word, ci) row: MAX_LC + 3 taps, multiple of 4
+__global__ __launch_bounds__(512) void k_embed_fwd(const int64_t* __restrict__ word_ids, const int64_t* __restrict__ char_ids,
                                                    const float* __restrict__ pad_vec, const float* __restrict__ unk_vec,
                                                    const float* __restrict__ glove, const float* __restrict__ char_tab,
-                                                   CharConvPtrs cc, float* __restrict__ E, int8_t* __restrict__ argpos,
-                                                   int Rq, int Lc, int word_dim, int char_dim, Drop dw, Drop dc) {
-    __shared__ float Ce[MAX_LC * 64];                    // dropped-out char embeddings [Lc][char_dim <= 64]
-    const int r = blockIdx.x, tid = threadIdx.x;
+                                                   CharConvPtrs cc, const float* __restrict__ wimg, float* __restrict__ E,
+                                                   int8_t* __restrict__ argpos, int Rq, int Lc, int word_dim, int char_dim,
+                                                   Drop dw, Drop dc) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Wt = smem;                                   // [char_dim][4 taps][100 channels], taps beyond a channel's width = 0
+    float* CeT = Wt + char_dim * 400;                   // [EF_CHUNK][char_dim][EF_PT]
+    __shared__ int cids[EF_CHUNK * MAX_LC];
+    const int tid = threadIdx.x, NT = blockDim.x;      // 512 threads: two waves per SIMD hide the LDS latency of the item loop
     const int EW = word_dim + 100;
-    // ---- word vector (F.embedding over [pad; unk; glove], :41) + dropout
-    const int64_t wid = word_ids[r];
-    const float* src = wid == 0 ? pad_vec : (wid == 1 ? unk_vec : glove + (size_t)(wid - 2) * word_dim);
-    for (int c = tid; c < word_dim; c += 128)
+    const int rbeg = blockIdx.x * EF_CHUNK, nw = min(EF_CHUNK, Rq - rbeg);
+    const int s0 = 10 * char_dim, s1 = 20 * char_dim * 2, s2 = 30 * char_dim * 3;
+    FSTAMP(0);
+    // ---- stage the weights: straight vector copy of the [ci][4 taps][100 channels] image k_pack built this step
+    //      (channel fastest: conflict-free for lanes that own consecutive channels; taps beyond a kernel width are 0)
+    for (int e0 = 0; e0 < char_dim * 100; e0 += 8 * NT) {
+        float4 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = e0 + tid + q * NT;
+            v[q] = e < char_dim * 100 ? reinterpret_cast<const float4*>(wimg)[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const int e = e0 + tid + q * NT; if (e < char_dim * 100) reinterpret_cast<float4*>(Wt)[e] = v[q]; }
+    }
+    FSTAMP(1);
+    // ---- char ids, then the transposed dropped-out embeddings (zero beyond Lc and beyond the chunk)
+    for (int e = tid; e < EF_CHUNK * MAX_LC; e += NT) {
+        const int wi = e / MAX_LC, pp = e - wi * MAX_LC;
+        cids[e] = (wi < nw && pp < Lc) ? (int)char_ids[(size_t)(rbeg + wi) * Lc + pp] : 0;
+    }
+    // ---- word vectors (independent of the above)
+    for (int e = tid; e < nw * word_dim; e += NT) {
+        const int wi = e / word_dim, c = e - wi * word_dim;
+        const int r = rbeg + wi;
+        const int64_t wid = word_ids[r];
+        const float* src = wid == 0 ? pad_vec : (wid == 1 ? unk_vec : glove + (size_t)(wid - 2) * word_dim);
         E[(size_t)r * EW + c] = src[c] * drop_mul(dw, (uint32_t)(r * word_dim + c));
-    // ---- char embeddings + dropout -> LDS
-    for (int e = tid; e < Lc * char_dim; e += 128) {
-        const int p = e / char_dim, ci = e - p * char_dim;
-        const int64_t cid = char_ids[(size_t)r * Lc + p];
-        Ce[p * 64 + ci] = char_tab[(size_t)cid * char_dim + ci] * drop_mul(dc, (uint32_t)((r * Lc + p) * char_dim + ci));
     }
     __syncthreads();
-    if (tid < 100) {
-        int conv, ch, k, wo, bo;
-        char_channel(tid, conv, ch, k, wo, bo);
-        const float* W = cc.w[conv] + (size_t)ch * char_dim * k;    // (c, char_dim, 1, k): [ch][ci][kk]
-        const float bias = cc.b[conv][ch];
+    FSTAMP(2);
+    for (int pr = tid; pr < EF_CHUNK * char_dim; pr += NT) {         // pair (word, ci): one padded row of EF_PT positions
+        const int wi = pr / char_dim, ci = pr - wi * char_dim;
+        float* row = CeT + pr * EF_PT;
+        float v[MAX_LC];
+#pragma unroll
+        for (int pp = 0; pp < MAX_LC; ++pp)                            // all gathers of the row issued together
+            v[pp] = (wi < nw && pp < Lc) ? char_tab[(size_t)cids[wi * MAX_LC + pp] * char_dim + ci] : 0.f;
+#pragma unroll
+        for (int pp = 0; pp < MAX_LC; ++pp)
+            row[pp] = (pp < Lc) ? v[pp] * drop_mul(dc, (uint32_t)(((rbeg + wi) * Lc + pp) * char_dim + ci)) : 0.f;
+#pragma unroll
+        for (int pp = MAX_LC; pp < EF_PT; ++pp) row[pp] = 0.f;
+    }
+    __syncthreads();
+    FSTAMP(3);
+    // ---- items (word, channel): 8 * 100 items over 256 threads
+    for (int item = tid; item < nw * 100; item += NT) {
+        const int wi = item / 100, oc = item - wi * 100;
+        int k, ch;
+        const float* bias;
+        if (oc < 10) { k = 1; ch = oc; bias = cc.b[0]; }
+        else if (oc < 30) { k = 2; ch = oc - 10; bias = cc.b[1]; }
+        else if (oc < 60) { k = 3; ch = oc - 30; bias = cc.b[2]; }
+        else { k = 4; ch = oc - 60; bias = cc.b[3]; }
+        const float bv = bias[ch];
+        const float* wt = Wt + oc;
+        const float* ce = CeT + wi * char_dim * EF_PT;
         const int npos = Lc - k + 1;
         float best = -1.f;
         int bestp = 0;
         for (int p0 = 0; p0 < npos; p0 += 8) {
             float acc[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) acc[q] = bias;
-            for (int ci = 0; ci < char_dim; ++ci)
-                for (int kk = 0; kk < k; ++kk) {
-                    const float wv = W[ci * k + kk];
+            for (int q = 0; q < 8; ++q) acc[q] = bv;
+#pragma unroll 5
+            for (int ci = 0; ci < char_dim; ++ci) {
+                const float4 x0 = *reinterpret_cast<const float4*>(ce + ci * EF_PT + p0);
+                const float4 x1 = *reinterpret_cast<const float4*>(ce + ci * EF_PT + p0 + 4);
+                const float4 x2 = *reinterpret_cast<const float4*>(ce + ci * EF_PT + p0 + 8);
+                const float win[12] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2.x, x2.y, x2.z, x2.w};
+                const float* wr = wt + ci * 400;
+                const float w0 = wr[0], w1 = wr[100], w2 = wr[200], w3 = wr[300];      // zero beyond the kernel width
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int p = p0 + q + kk;
-                        acc[q] += wv * (p < Lc ? Ce[p * 64 + ci] : 0.f);
-                    }
-                }
+                for (int q = 0; q < 8; ++q) acc[q] += w0 * win[q] + w1 * win[q + 1] + w2 * win[q + 2] + w3 * win[q + 3];
+            }
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const float v = fmaxf(acc[q], 0.f);                 // ReLU before the max (:58,69-70)
                 if (p0 + q < npos && v > best) { best = v; bestp = p0 + q; }
             }
         }
-        E[(size_t)r * EW + word_dim + tid] = best;
-        argpos[(size_t)r * 100 + tid] = (int8_t)bestp;
+        const int r = rbeg + wi;
+        E[(size_t)r * EW + word_dim + oc] = best;
+        argpos[(size_t)r * 100 + oc] = (int8_t)bestp;
     }
+    FSTAMP(4);
 }
 void launch_embed_fwd(const int64_t* word_ids, const int64_t* char_ids, const float* pad_vec, const float* unk_vec,
-                      const float* glove, const float* char_tab, CharConvPtrs cc, float* E, int8_t* argpos, int Rq,
-                      int Lc, int word_dim, int char_dim, Drop dw, Drop dc, hipStream_t s) {
-    hipLaunchKernelGGL(k_embed_fwd, dim3(Rq), dim3(128), 0, s, word_ids, char_ids, pad_vec, unk_vec, glove, char_tab, cc,
-                       E, argpos, Rq, Lc, word_dim, char_dim, dw, dc);
+                      const float* glove, const float* char_tab, CharConvPtrs cc, const float* wimg, float* E, int8_t* argpos,
+                      int Rq, int Lc, int word_dim, int char_dim, Drop dw, Drop dc, hipStream_t s) {
+    const size_t shm = (size_t)(char_dim * 400 + EF_CHUNK * char_dim * EF_PT) * sizeof(float);
+    static size_t lds_ok = 0;
+    ensure_dynamic_lds((const void*)k_embed_fwd, shm + 4096, lds_ok, "k_embed_fwd");
+    hipLaunchKernelGGL(k_embed_fwd, dim3((Rq + EF_CHUNK - 1) / EF_CHUNK), dim3(512), shm, s, word_ids, char_ids, pad_vec, unk_vec,
+                       glove, char_tab, cc, wimg, E, argpos, Rq, Lc, word_dim, char_dim, dw, dc);
+    static int left = 2;
+    if (fdbg_on()) fdbg_report("embed_fwd: weights | ids+words | CeT | items", 5, s, left);
 }
 
 // =========================================================================================================

@@ -13,7 +13,7 @@ struct PackJob {          // one weight -> packed B-operand copy (see common.hpp
     int dst;              // float offset into the pack buffer
     int kn, cn;           // extent of the contraction index / of the output-column index covered by this job
     int ld;               // leading dimension of the source matrix
-    int transpose;        // 0: Bm[k][c] = W[c][k] (forward pack)   1: Bm[k][c] = W[k][c] (data-gradient pack)
+    int transpose;        // 0: Bm[k][c] = W[c][k] (forward pack)   1: Bm[k][c] = W[k][c] (data-gradient pack)  2: copy  3: char-conv image  4: zero fill
     int ncols;            // total columns of the packed operand
     int k_off, col_off;   // placement inside the packed operand
 };
@@ -111,8 +111,8 @@ inline size_t spread_lds(size_t need, size_t static_bytes, int nblocks) {
 void launch_pack(const float* params, float* pack, const PackJob* jobs_dev, int njobs, hipStream_t s);
 void launch_vproj_fwd(const float* X, const float* Wpack, const float* bias, float* Y, int R, int Dv, Drop dp, hipStream_t s);
 void launch_embed_fwd(const int64_t* word_ids, const int64_t* char_ids, const float* pad_vec, const float* unk_vec,
-                      const float* glove, const float* char_tab, CharConvPtrs cc, float* E, int8_t* argpos, int Rq,
-                      int Lc, int word_dim, int char_dim, Drop dw, Drop dc, hipStream_t s);
+                      const float* glove, const float* char_tab, CharConvPtrs cc, const float* wimg, float* E, int8_t* argpos,
+                      int Rq, int Lc, int word_dim, int char_dim, Drop dw, Drop dc, hipStream_t s);
 void launch_linear_fwd(const float* A, const float* Wpack, const float* bias, float* Y, int R, int K, hipStream_t s);
 void launch_conv_layer_fwd(const float* xin, const float* pos, float* x0_out, const float* ln_g, const float* ln_b,
                            const float* dw_w, const float* Wpack, const float* pw_b, float* y_out, float* u_out,
