@@ -1,0 +1,144 @@
+"""GPU tests of what the golden (eval-mode) fixtures cannot pin: training-mode dropout and the larger BASELINE shapes.
+
+* dropout masks are counter-based hashes, so bit-parity with torch's CPU RNG is impossible: they are
+  tested statistically, for determinism, and -- most importantly -- for forward/backward consistency through a
+  finite-difference directional derivative of the training-mode loss at a FIXED seed.
+* BASELINE configs 3-5 (T=256 Dv=4096 ; T=256 ; T=1024) are checked against the oracle at a batch the oracle finishes in
+  seconds; the kernels' behaviour does not depend on B beyond the grid size.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vslnet_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(cfg, P):
+    from vslnet_amd.engine import Engine, flat_from_state_dict
+    eng = Engine(cfg)
+    return eng, flat_from_state_dict(eng, P)
+
+
+def _dev(b):
+    return {k: v.cuda().contiguous() for k, v in b.items()}
+
+
+def _fwd(eng, flat, P, d, training, seed):
+    return eng.forward(flat, P['embedding_net.word_emb.pad_vec'].cuda(), P['embedding_net.word_emb.glove_vec'].cuda(),
+                       d['word_ids'], d['char_ids'], d['vfeats'], d['v_mask'], d['q_mask'], training=training, seed=seed)
+
+
+def _loss(eng, flat, P, d, seed):
+    _fwd(eng, flat, P, d, True, seed)
+    losses, d_h, d_sl, d_el = eng.loss(d['s_labels'], d['e_labels'], d['h_labels'], 1.0, 5.0)
+    return float(losses[2].item()), (d_h, d_sl, d_el)
+
+
+def test_dropout_forward_backward_consistency_by_finite_differences():
+    cfg = O.make_cfg(video_feature_dim=64, max_pos_len=64, word_size=52, drop_rate=0.2)
+    P = O.random_params(cfg, seed=3)
+    d = _dev(O.synthetic_batch(cfg, B=4, T=48, Lq=9, Lc=7, seed=4, ragged=True))
+    eng, flat = _engine(cfg, P)
+    seed = 1234567
+    f0, seeds = _loss(eng, flat, P, d, seed)
+    g = eng.backward(*seeds, eng.new_flat()).clone()
+    f0b, _ = _loss(eng, flat, P, d, seed)
+    assert f0 == f0b, 'training-mode forward is not deterministic for a fixed seed'
+    f_other, _ = _loss(eng, flat, P, d, seed + 1)
+    assert f_other != f0, 'the dropout seed has no effect'
+    gd = g.double()
+    gn = float(gd.norm())
+    assert np.isfinite(gn) and gn > 0
+    rs = np.random.RandomState(0)
+    for trial in range(3):
+        # direction: the gradient itself (trial 0), then random sign-flipped versions of it (same scale per element)
+        v = gd / gn if trial == 0 else (gd * torch.from_numpy(rs.choice([-1.0, 1.0], size=gd.numel())).cuda()) / gn
+        pred = float((gd * v).sum())
+        eps = 0.02 / max(abs(pred), 1e-3)                      # predicted change of the loss ~ 2e-2 (fp32 noise ~ 3e-5)
+        fp, _ = _loss(eng, (flat.double() + eps * v).float(), P, d, seed)
+        fm, _ = _loss(eng, (flat.double() - eps * v).float(), P, d, seed)
+        fd = (fp - fm) / (2 * eps)
+        assert abs(fd - pred) <= 0.03 * abs(pred) + 2e-3, 'trial %d: finite difference %.6f vs g.v %.6f' % (trial, fd, pred)
+
+
+def test_dropout_mask_statistics_and_scaling():
+    """Word-embedding dropout (layers_t7.py:45) is directly observable in the saved concat buffer: kept entries equal
+    table / (1 - p), the rest are exactly 0, and the drop fraction is p within sampling error."""
+    p = 0.3
+    cfg = O.make_cfg(video_feature_dim=64, max_pos_len=32, word_size=500, drop_rate=p)
+    P = O.random_params(cfg, seed=5)
+    b = O.synthetic_batch(cfg, B=16, T=16, Lq=20, Lc=6, seed=6)
+    d = _dev(b)
+    eng, flat = _engine(cfg, P)
+    _fwd(eng, flat, P, d, True, 99)
+    E = eng.ws_view('emb_concat', (16, 20, cfg.word_dim + 100))[:, :, :cfg.word_dim].cpu()
+    table = torch.cat([P['embedding_net.word_emb.pad_vec'], P['embedding_net.word_emb.unk_vec'], P['embedding_net.word_emb.glove_vec']])
+    ref = table[b['word_ids']]
+    dropped = E == 0
+    n = E.numel()
+    frac = float(dropped.float().mean())
+    assert abs(frac - p) < 5 * np.sqrt(p * (1 - p) / n), frac
+    assert torch.allclose(E[~dropped], ref[~dropped] / (1 - p), rtol=1e-6, atol=1e-7)
+    # a different seed gives a different, equally dense mask; eval mode gives no dropout at all
+    _fwd(eng, flat, P, d, True, 100)
+    E2 = eng.ws_view('emb_concat', (16, 20, cfg.word_dim + 100))[:, :, :cfg.word_dim].cpu()
+    agree = float(((E2 == 0) == dropped).float().mean())
+    assert abs(agree - (p * p + (1 - p) * (1 - p))) < 0.01        # independent masks agree with prob p^2 + (1-p)^2
+    _fwd(eng, flat, P, d, False, 100)
+    E3 = eng.ws_view('emb_concat', (16, 20, cfg.word_dim + 100))[:, :, :cfg.word_dim].cpu()
+    assert torch.equal(E3, ref)
+
+
+@pytest.mark.parametrize('shape', [
+    dict(name='cfg3 TACoS C3D', T=256, Dv=4096, B=2, Lq=20, Lc=10),
+    dict(name='cfg4 ActivityNet', T=256, Dv=1024, B=3, Lq=33, Lc=12),
+    dict(name='cfg5 long video', T=1024, Dv=1024, B=1, Lq=20, Lc=10),
+    dict(name='edge: B=1 minimal chars, odd lengths', T=37, Dv=64, B=1, Lq=5, Lc=4),
+    dict(name='edge: max query length', T=40, Dv=64, B=2, Lq=64, Lc=24),
+])
+def test_baseline_shapes_against_oracle(shape):
+    cfg = O.make_cfg(video_feature_dim=shape['Dv'], max_pos_len=max(shape['T'], shape['Lq']), word_size=102)
+    P = O.random_params(cfg, seed=11)
+    b = O.synthetic_batch(cfg, shape['B'], shape['T'], shape['Lq'], shape['Lc'], seed=12, ragged=shape['B'] > 1)
+    d = _dev(b)
+    eng, flat = _engine(cfg, P)
+    h, sl, el = _fwd(eng, flat, P, d, False, 0)
+    losses, d_h, d_sl, d_el = eng.loss(d['s_labels'], d['e_labels'], d['h_labels'], 1.0, 5.0)
+    g = eng.backward(d_h, d_sl, d_el, eng.new_flat())
+    torch.cuda.synchronize()
+    Pg = {k: v.clone().requires_grad_(k not in O.FROZEN) for k, v in P.items()}
+    total, (oh, osl, oel, _, _) = O.total_loss(Pg, cfg, b)
+    total.backward()
+    fin = osl.detach().abs() < 1e29
+    scale = max(1.0, float(osl.detach()[fin].abs().max()))
+    assert float((sl.cpu() - osl.detach())[fin].abs().max()) <= 1e-4 * scale, shape['name']
+    assert float((el.cpu() - oel.detach())[fin].abs().max()) <= 1e-4 * scale
+    assert float((h.cpu() - oh.detach()).abs().max()) <= 2e-5
+    assert abs(float(losses[2]) - float(total.detach())) <= 1e-4 * max(1.0, abs(float(total.detach())))
+    gv = eng.views(g)
+    bad = []
+    for k, t in gv.items():
+        ref = Pg[k].grad if Pg[k].grad is not None else torch.zeros_like(Pg[k])
+        err = float((t.cpu() - ref).abs().max())
+        tol = 1e-4 * float(ref.abs().max()) + 1e-6
+        if not err <= tol:
+            bad.append((k, err, tol))
+    assert not bad, (shape['name'], bad[:5])
+    si, ei = eng.extract_index(sl, el)
+    osi, oei = O.extract_index(osl.detach(), oel.detach())
+    assert torch.equal(si.cpu(), osi) and torch.equal(ei.cpu(), oei)
+
+
+def test_limits_fail_loudly():
+    from vslnet_amd.engine import VslError
+    cfg = O.make_cfg(video_feature_dim=64, max_pos_len=32, word_size=52)
+    P = O.random_params(cfg, seed=1)
+    eng, flat = _engine(cfg, P)
+    d = _dev(O.synthetic_batch(cfg, B=1, T=40, Lq=5, Lc=5, seed=1))          # T > max_pos_len
+    with pytest.raises(IndexError):
+        _fwd(eng, flat, P, d, False, 0)
+    d = _dev(O.synthetic_batch(cfg, B=1, T=16, Lq=5, Lc=3, seed=1))          # Lc < 4: the widest char conv does not fit
+    with pytest.raises(VslError, match='Lc'):
+        _fwd(eng, flat, P, d, False, 0)

@@ -293,9 +293,12 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradBatch wb) {
             *reinterpret_cast<float4*>(&As[(e >> 5) * LDP + (e & 31) * 4]) = ast[q];
         }
     };
+    const bool st = g_dbg_on && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0;
+    if (st) g_stamps[0] = clock64();
     gload(rbeg);
     sstore(0);
     __syncthreads();
+    if (st) g_stamps[1] = clock64();
     int buf = 0;
     for (int rs = rbeg; rs < rend; rs += TILE_M, buf ^= 1) {
         const bool more = rs + TILE_M < rend;
@@ -310,6 +313,7 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradBatch wb) {
         if (more) sstore(buf ^ 1);
         __syncthreads();
     }
+    if (st) g_stamps[2] = clock64();
     const int N = 128 * j.nG;
     float* out = j.out + ((size_t)ch * N + gb * 128) * K;
 #pragma unroll
@@ -324,6 +328,7 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradBatch wb) {
         }
     }
     if (kt == 0 && tid < 128 && j.out_bias[gb]) j.out_bias[gb][(size_t)ch * D + tid] = bsum;
+    if (st) g_stamps[3] = clock64();
 }
 void launch_wgrad(const WgradBatch& wb, hipStream_t s) {
     int kt = 1, ch = 1;
@@ -336,9 +341,14 @@ void launch_wgrad(const WgradBatch& wb, hipStream_t s) {
     ensure_dynamic_lds((const void*)k_wgrad, shm, lds_ok, "k_wgrad");
     {
         static size_t lds_sp = 0;
-        const size_t shm_sp = spread_lds(shm, 0, 0);
+        // one weight-gradient workgroup per CU: two of them on one CU halve each other's MFMA rate while other CUs idle
+        // (cycle stamps: 6.5k vs 13k cycles per 32-row step).  84 KiB still leaves room for a main-chain kernel beside it.
+        static const bool wg_excl = !(getenv("VSL_WGRAD_EXCL") && getenv("VSL_WGRAD_EXCL")[0] == '0');
+        const size_t shm_sp = wg_excl ? (shm > 84 * 1024 ? shm : (size_t)84 * 1024) : spread_lds(shm, 0, 0);
         ensure_dynamic_lds((const void*)k_wgrad, shm_sp + 0, lds_sp, "k_wgrad");
         hipLaunchKernelGGL(k_wgrad, dim3(kt, ch, wb.n * 3), dim3(256), shm_sp, s, wb);
+        static int left = 12;
+        if (dbg_budget("wgrad")) { char nm[96]; snprintf(nm, sizeof nm, "wgrad n=%d K=%d R=%d: prologue | 8-step loop | stores", wb.n, wb.j[0].K, wb.j[0].R); dbg_report(nm, 4, s, left); }
     }
 }
 
