@@ -40,7 +40,7 @@ def build(force=False, verbose=False, csrc=None, out=None):
 
     def cc(src):
         obj = os.path.join(LIBDIR, src.replace('.hip', tag + '.o'))
-        cmd = [hipcc] + FLAGS + ['-c', os.path.join(src_dir, src), '-o', obj]
+        cmd = [hipcc] + FLAGS + os.environ.get('VSL_EXTRA_HIPCC_FLAGS', '').split() + ['-c', os.path.join(src_dir, src), '-o', obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('hipcc failed for %s:\n%s' % (src, r.stderr[-4000:]))

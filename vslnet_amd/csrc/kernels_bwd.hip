@@ -4,6 +4,7 @@
 // k_reduce into the flat gradient bucket (deterministic, no float atomics on global memory).
 #include "common.hpp"
 #include "launch.hpp"
+#include <type_traits>
 
 namespace vsl {
 
@@ -244,90 +245,139 @@ void launch_head_bwd(const HeadBwdArgs& a0, const HeadBwdArgs& a1, int R, hipStr
 // generic weight gradient  dW[n][k] = sum_r G[r][n] A[r][k]   (+ bias = column sums of G)
 //   grid = (k tiles of 128, row chunks of WG_ROWS, job * 3 + G block); each workgroup writes one partial slab tile.
 // =========================================================================================================
-__global__ __launch_bounds__(256) void k_wgrad(WgradBatch wb) {
+__global__ __launch_bounds__(512) void k_wgrad(WgradBatch wb) {
     extern __shared__ __attribute__((aligned(16))) float smem[];    // 2 x (G tile | A tile), 32 x LDP each
     const int ji = blockIdx.z / 3, gb = blockIdx.z % 3;
     const WgradJob& j = wb.j[ji];
     const int kt = blockIdx.x, ch = blockIdx.y;
     const int K = j.K, R = j.R;
     if (gb >= j.nG || kt * 128 >= K || ch * WG_ROWS >= R) return;
+    // 8 waves = 2 per SIMD: wave (nb, kh) owns output rows n = 32 nb .. +32, columns k = 64 kh .. +64 of the 128 x 128
+    // block, so one wave's load issue / LDS stores / barrier wait sit under the other wave's MFMAs.
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int nb = w & 3, kh = w >> 2;
     const float* G = j.G[gb];
     const float* Ablk = j.nA > 0 ? j.A[kt] : nullptr;
-    f32x16 acc[4];
+    const bool dropA = !Ablk && j.drop_on_A && j.dp.thresh;
+    f32x16 acc[2];
     zero_acc(acc);
-    float bsum = 0.f;
+    float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);         // column sums of G over this thread's rows (bias gradient)
     const int rbeg = ch * WG_ROWS, rend = min(R, rbeg + WG_ROWS);
-    float4 gst[4], ast[4];
-    auto gload = [&](int rs) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int e = tid + q * 256;
-            const int rr = e >> 5, c = (e & 31) * 4;
-            const int r = rs + rr;
-            float4 gv = make_float4(0.f, 0.f, 0.f, 0.f), av = gv;
-            if (r < rend) {
-                gv = *reinterpret_cast<const float4*>(G + (size_t)r * D + c);
-                if (Ablk) {
-                    av = *reinterpret_cast<const float4*>(Ablk + (size_t)r * D + c);
-                } else if (kt * 128 + c < K) {
-                    const size_t off = (size_t)r * K + kt * 128 + c;
-                    av = *reinterpret_cast<const float4*>(j.Afull + off);
-                    if (j.drop_on_A && j.dp.thresh) {
-                        const uint32_t base = (uint32_t)off;
-                        av.x *= drop_mul(j.dp, base); av.y *= drop_mul(j.dp, base + 1);
-                        av.z *= drop_mul(j.dp, base + 2); av.w *= drop_mul(j.dp, base + 3);
-                    }
-                }
-            }
-            gst[q] = gv; ast[q] = av;
-        }
+    const int c = (tid & 31) * 4, rr0 = tid >> 5;         // this thread's float4 column and first row of a tile
+    const bool kin = Ablk || kt * 128 + c < K;
+    const bool kin_all = Ablk || kt * 128 + 128 <= K;      // block-uniform: no column of this k-tile is outside K
+    struct TileRegs { float4 g[2], a[2]; };
+    // Loads are unconditional (row clamped into the chunk, column clamped into K) so that they compile to straight-line
+    // global_load_dwordx4 the wait counters can track; out-of-range values are zeroed when the tile is written to LDS.
+    // fp32 MFMAs run on the SIMD's FMA lanes, so every vector-ALU instruction in this loop is paid in full (measured: the
+    // loop time is MFMA cycles + 4 cycles x VALU instructions x waves, whatever the interleaving).  The store path is
+    // therefore specialised: the dropout hash only for a job that has a mask, the row / column masks only for the tile
+    // that can be ragged.
+    const uint32_t dseed = j.dp.seed, dthr = j.dp.thresh;
+    const float dscale = j.dp.scale;
+    const float* Gc = G + c;
+    const float* Ac = Ablk ? Ablk + c : j.Afull + (kin ? kt * 128 + c : 0);
+    const int astride = Ablk ? D : K;
+    const uint32_t dbase = (uint32_t)(kt * 128 + c);
+    auto load_g = [&](int rs, int q) -> float4 {
+        const int r = min(rs + rr0 + 16 * q, rend - 1);
+        return *reinterpret_cast<const float4*>(Gc + (size_t)r * D);
     };
-    auto sstore = [&](int buf) {
+    auto load_a = [&](int rs, int q) -> float4 {
+        const int r = min(rs + rr0 + 16 * q, rend - 1);
+        return *reinterpret_cast<const float4*>(Ac + (size_t)r * astride);
+    };
+    auto store_q = [&](auto drop_c, auto mask_c, int buf, int rs, int q, float4 gv, float4 av) {
         float* Gs = smem + buf * 2 * TILE_M * LDP;
         float* As = Gs + TILE_M * LDP;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int e = tid + q * 256;
-            *reinterpret_cast<float4*>(&Gs[(e >> 5) * LDP + (e & 31) * 4]) = gst[q];
-            *reinterpret_cast<float4*>(&As[(e >> 5) * LDP + (e & 31) * 4]) = ast[q];
+        const int r = rs + rr0 + 16 * q;
+        float ma = 1.f;
+        if (decltype(mask_c)::value) {
+            const float mg = r < rend ? 1.f : 0.f;
+            ma = (r < rend && kin) ? 1.f : 0.f;
+            gv.x *= mg; gv.y *= mg; gv.z *= mg; gv.w *= mg;
         }
+        if (decltype(drop_c)::value) {
+            const uint32_t base = (uint32_t)r * (uint32_t)K + dbase;
+            ma *= dscale;
+            av.x *= fmix32((base + 0u) * 0x9E3779B1u + dseed) >= dthr ? ma : 0.f;
+            av.y *= fmix32((base + 1u) * 0x9E3779B1u + dseed) >= dthr ? ma : 0.f;
+            av.z *= fmix32((base + 2u) * 0x9E3779B1u + dseed) >= dthr ? ma : 0.f;
+            av.w *= fmix32((base + 3u) * 0x9E3779B1u + dseed) >= dthr ? ma : 0.f;
+        } else if (decltype(mask_c)::value) {
+            av.x *= ma; av.y *= ma; av.z *= ma; av.w *= ma;
+        }
+        bs.x += gv.x; bs.y += gv.y; bs.z += gv.z; bs.w += gv.w;
+        *reinterpret_cast<float4*>(&Gs[(rr0 + 16 * q) * LDP + c]) = gv;
+        *reinterpret_cast<float4*>(&As[(rr0 + 16 * q) * LDP + c]) = av;
     };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
     const bool st = g_dbg_on && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0;
     if (st) g_stamps[0] = clock64();
-    gload(rbeg);
-    sstore(0);
+    // Pipeline: while tile i is multiplied out of LDS, tile i+1 (already in registers, requested one step earlier) is
+    // written to the other LDS buffer and tile i+2 is requested from memory, all between the MFMA batches.
+    TileRegs S0, S1;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) { S1.g[q] = load_g(rbeg, q); S1.a[q] = load_a(rbeg, q); }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) { S0.g[q] = load_g(rbeg + TILE_M, q); S0.a[q] = load_a(rbeg + TILE_M, q); }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        if (dropA) store_q(T_(), T_(), 0, rbeg, q, S1.g[q], S1.a[q]);
+        else store_q(F_(), T_(), 0, rbeg, q, S1.g[q], S1.a[q]);
+    }
     __syncthreads();
     if (st) g_stamps[1] = clock64();
-    int buf = 0;
-    for (int rs = rbeg; rs < rend; rs += TILE_M, buf ^= 1) {
-        const bool more = rs + TILE_M < rend;
-        if (more) gload(rs + TILE_M);                    // next tile in flight while the MFMAs run
-        const float* Gs = smem + buf * 2 * TILE_M * LDP;
+    auto step = [&](auto drop_c, auto mask_c, int rs, int buf, TileRegs& X, TileRegs& Y) {   // X holds tile rs+32,
+        const float* Gs = smem + buf * 2 * TILE_M * LDP;                                     // Y receives tile rs+64
         const float* As = Gs + TILE_M * LDP;
-        gemm_tn<4>(Gs, LDP, 32 * w, As, LDP, 0, TILE_M, acc);
-        if (kt == 0 && tid < 128) {
-#pragma unroll 8
-            for (int rr = 0; rr < TILE_M; ++rr) bsum += Gs[rr * LDP + tid];
-        }
-        if (more) sstore(buf ^ 1);
+        // past the end of the chunk the loads re-read its last row and the stores write zeros nobody reads
+        gemm_tn_p<2, TILE_M>(Gs, LDP, 32 * nb, As, LDP, 64 * kh, acc, [&](int b) {
+            if (b == 0) Y.g[0] = load_g(rs + 2 * TILE_M, 0);
+            else if (b == 1) Y.a[0] = load_a(rs + 2 * TILE_M, 0);
+            else if (b == 2) Y.g[1] = load_g(rs + 2 * TILE_M, 1);
+            else Y.a[1] = load_a(rs + 2 * TILE_M, 1);
+            if ((b & 1) == 0) store_q(drop_c, mask_c, buf ^ 1, rs + TILE_M, b >> 1, X.g[b >> 1], X.a[b >> 1]);
+        });
         __syncthreads();
-    }
+    };
+    auto run = [&](auto drop_c) {
+        for (int rs = rbeg; rs < rend; rs += 2 * TILE_M) {
+            // tile rs+32 (stored during this step) is complete iff rs + 64 <= rend and every column is inside K
+            if (rs + 2 * TILE_M <= rend && kin_all) step(drop_c, F_(), rs, 0, S0, S1); else step(drop_c, T_(), rs, 0, S0, S1);
+            if (rs + TILE_M < rend) {
+                if (rs + 3 * TILE_M <= rend && kin_all) step(drop_c, F_(), rs + TILE_M, 1, S1, S0);
+                else step(drop_c, T_(), rs + TILE_M, 1, S1, S0);
+            }
+        }
+    };
+    if (dropA) run(T_()); else run(F_());
     if (st) g_stamps[2] = clock64();
     const int N = 128 * j.nG;
     float* out = j.out + ((size_t)ch * N + gb * 128) * K;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int k = kt * 128 + 32 * t + (lane & 31);
+    for (int t = 0; t < 2; ++t) {
+        const int k = kt * 128 + 64 * kh + 32 * t + (lane & 31);
         if (k < K) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int n = 32 * w + acc_row(r, lane);
+                const int n = 32 * nb + acc_row(r, lane);
                 out[(size_t)n * K + k] = acc[t][r];
             }
         }
     }
-    if (kt == 0 && tid < 128 && j.out_bias[gb]) j.out_bias[gb][(size_t)ch * D + tid] = bsum;
+    if (kt == 0 && j.out_bias[gb]) {                      // block-uniform; the tile buffers are free after the last barrier
+        float* red = smem;                               // [16][128]
+        *reinterpret_cast<float4*>(&red[rr0 * D + c]) = bs;
+        __syncthreads();
+        if (tid < D) {
+            float v = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) v += red[g * D + tid];
+            j.out_bias[gb][(size_t)ch * D + tid] = v;
+        }
+    }
     if (st) g_stamps[3] = clock64();
 }
 void launch_wgrad(const WgradBatch& wb, hipStream_t s) {
@@ -346,7 +396,7 @@ void launch_wgrad(const WgradBatch& wb, hipStream_t s) {
         static const bool wg_excl = !(getenv("VSL_WGRAD_EXCL") && getenv("VSL_WGRAD_EXCL")[0] == '0');
         const size_t shm_sp = wg_excl ? (shm > 84 * 1024 ? shm : (size_t)84 * 1024) : spread_lds(shm, 0, 0);
         ensure_dynamic_lds((const void*)k_wgrad, shm_sp + 0, lds_sp, "k_wgrad");
-        hipLaunchKernelGGL(k_wgrad, dim3(kt, ch, wb.n * 3), dim3(256), shm_sp, s, wb);
+        hipLaunchKernelGGL(k_wgrad, dim3(kt, ch, wb.n * 3), dim3(512), shm_sp, s, wb);
         static int left = 12;
         if (dbg_budget("wgrad")) { char nm[96]; snprintf(nm, sizeof nm, "wgrad n=%d K=%d R=%d: prologue | 8-step loop | stores", wb.n, wb.j[0].K, wb.j[0].R); dbg_report(nm, 4, s, left); }
     }
