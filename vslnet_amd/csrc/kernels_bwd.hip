@@ -772,10 +772,177 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(const float* __restrict__ 
         *reinterpret_cast<float4*>(dV + (rowbase + key) * D + h * HD + 4 * g) = make_float4(dv[0], dv[1], dv[2], dv[3]);
     }
 }
+// Fused attention backward for Lp <= 128: ONE workgroup (16 waves) per (sample, head) computes S, P, dP and dS once.
+// Queries are processed in passes of 64 so that dS[64][keys] fits beside the head slices in < 80 KB of LDS: two workgroups
+// share a CU (one stages while the other computes) and a weight-gradient workgroup of another stream still fits too.
+//   phase 1: wave (ks = w & 7, qh = w >> 3) owns the 16 keys of strip ks and the query tiles qh, qh + 2 of the pass;
+//            dK / dV of the strip accumulate in registers over all passes, dS goes to LDS as a [query][key] matrix;
+//   phase 2: waves 0-3 each multiply the 16 rows of dS of one query tile with K  ->  dQ (4 independent MFMA chains).
+// The two dK / dV partials (qh = 0, 1) are added in a fixed order through LDS, so the result does not depend on
+// scheduling.  Against the two-kernel path this halves the exp / dropout-hash / S / dP work (fp32 MFMAs and the vector ALU
+// share the SIMD, so that work is not hidden behind anything) and removes one kernel boundary.
+constexpr int AB_LMAX = 128, AB_KST = 20, AB_QP = 64, AB_DSP = AB_LMAX + 4;
+constexpr size_t AB_LDS = (size_t)(4 * AB_LMAX * AB_KST + AB_QP * AB_DSP + 3 * AB_LMAX) * sizeof(float);
+__global__ __launch_bounds__(1024) void k_attn_bwd_fused(const float* __restrict__ Q, const float* __restrict__ K,
+                                                         const float* __restrict__ V, const float* __restrict__ att,
+                                                         const float* __restrict__ dr, const float* __restrict__ lse,
+                                                         const float* __restrict__ mask, float* __restrict__ dQ,
+                                                         float* __restrict__ dK, float* __restrict__ dV, int L, int H,
+                                                         int b_off, Drop d2, Drop d3) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ks = smem;                           // [128][20]
+    float* dSs = Ks + AB_LMAX * AB_KST;         // [64][132]   dS[query - qb][key] of the current pass
+    float* Ls = dSs + AB_QP * AB_DSP;           // LSE per query
+    float* Ds = Ls + AB_LMAX;                   // D = dA . O per query
+    float* Mb = Ds + AB_LMAX;                   // additive key bias
+    float* Qs = Mb + AB_LMAX;                   // [128][20]   Qs | Vs | As are dead after the last pass and become the
+    float* Vs = Qs + AB_LMAX * AB_KST;          // [128][20]   exchange area of the dK / dV partials
+    float* As = Vs + AB_LMAX * AB_KST;          // [128][20]   dA = dr * m3
+    const int Lp = (L + 15) & ~15;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const size_t rowbase = (size_t)b * L;
+    STAMP(0);
+    {
+        const int e = tid & 511, row = e >> 2, c4 = (e & 3) * 4;
+        const size_t off = (rowbase + row) * D + h * HD + c4;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tid < 512) {
+            float4 qv = z, kv = z;
+            if (row < L) {
+                qv = *reinterpret_cast<const float4*>(Q + off);
+                kv = *reinterpret_cast<const float4*>(K + off);
+            }
+            *reinterpret_cast<float4*>(&Qs[row * AB_KST + c4]) = qv;
+            *reinterpret_cast<float4*>(&Ks[row * AB_KST + c4]) = kv;
+            if (tid < AB_LMAX) {
+                Ls[tid] = tid < L ? lse[((size_t)b * H + h) * L + tid] : 0.f;
+                Mb[tid] = tid < L ? (1.0f - mask[rowbase + tid]) * MASK_VALUE : MASK_VALUE;
+            }
+        } else {
+            float4 vv = z, av = z, ov = z;
+            if (row < L) {
+                vv = *reinterpret_cast<const float4*>(V + off);
+                av = *reinterpret_cast<const float4*>(dr + off);
+                ov = *reinterpret_cast<const float4*>(att + off);
+                if (d3.thresh) {                    // r = drop3(att) + x  (:183-184)
+                    const uint32_t base = (uint32_t)off;
+                    av.x *= drop_mul(d3, base); av.y *= drop_mul(d3, base + 1);
+                    av.z *= drop_mul(d3, base + 2); av.w *= drop_mul(d3, base + 3);
+                }
+            }
+            *reinterpret_cast<float4*>(&Vs[row * AB_KST + c4]) = vv;
+            *reinterpret_cast<float4*>(&As[row * AB_KST + c4]) = av;
+            float dsum = av.x * ov.x + av.y * ov.y + av.z * ov.z + av.w * ov.w;     // D_q = dA . O (= sum_k dP_k P_k)
+            dsum += __shfl_xor(dsum, 1);
+            dsum += __shfl_xor(dsum, 2);
+            if ((e & 3) == 0) Ds[row] = dsum;
+        }
+    }
+    STAMP(1);
+    __syncthreads();
+    STAMP(2);
+    const int ki = lane & 15, g = lane >> 4;
+    const int hi = w >> 3;                      // which of the two dK / dV partials this wave produces
+    const float scale = 0.25f;
+    f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
+    const int key = 16 * (w & 7) + ki;
+    const bool has_keys = 16 * (w & 7) < Lp;
+    float4 kf = make_float4(0.f, 0.f, 0.f, 0.f), vf = kf;
+    float mb = MASK_VALUE;
+    if (has_keys) {
+        kf = *reinterpret_cast<const float4*>(&Ks[key * AB_KST + 4 * g]);
+        vf = *reinterpret_cast<const float4*>(&Vs[key * AB_KST + 4 * g]);
+        mb = Mb[key];
+    }
+    const uint32_t hb = (uint32_t)(((size_t)(b + b_off) * H + h) * L);
+    for (int qb = 0; qb < Lp; qb += AB_QP) {
+        const int qe = min(qb + AB_QP, Lp);
+        if (has_keys) {
+            for (int qt = qb + 16 * hi; qt < qe; qt += 32) {
+                // S tile (rows = queries qt + 4g + reg, col = key) and dPd tile, same shape
+                const float4 qa = *reinterpret_cast<const float4*>(&Qs[(qt + ki) * AB_KST + 4 * g]);
+                const float4 aa = *reinterpret_cast<const float4*>(&As[(qt + ki) * AB_KST + 4 * g]);
+                f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                sc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa.x, kf.x, sc, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x4f32(aa.x, vf.x, dp, 0, 0, 0);
+                sc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa.y, kf.y, sc, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x4f32(aa.y, vf.y, dp, 0, 0, 0);
+                sc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa.z, kf.z, sc, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x4f32(aa.z, vf.z, dp, 0, 0, 0);
+                sc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa.w, kf.w, sc, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x4f32(aa.w, vf.w, dp, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qq = qt + 4 * g + r;
+                    const float p = __expf(sc[r] * scale + mb - Ls[qq]);
+                    const float m2 = drop_mul(d2, (hb + (uint32_t)qq) * (uint32_t)L + (uint32_t)key);
+                    const float pd = p * m2;
+                    const float ds = p * (dp[r] * m2 - Ds[qq]) * scale;
+                    dSs[(qq - qb) * AB_DSP + key] = ds;
+                    // dV^T[dd][key] += dA[q][dd] * Pd[q][key] ; dK^T[dd][key] += Q[q][dd] * dS[q][key]
+                    dv = __builtin_amdgcn_mfma_f32_16x16x4f32(As[qq * AB_KST + ki], pd, dv, 0, 0, 0);
+                    dk = __builtin_amdgcn_mfma_f32_16x16x4f32(Qs[qq * AB_KST + ki], ds, dk, 0, 0, 0);
+                }
+            }
+        }
+        if (qb == 0) STAMP(3);
+        __syncthreads();                        // dS of this pass complete
+        if (qb == 0) STAMP(4);
+        // phase 2: dQ^T[dd][q] += K[key][dd] * dS[q][key], one query tile per wave, every key
+        const int qt2 = qb + 16 * w;
+        if (w < 4 && qt2 < qe) {
+            f32x4 dq[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float* kp = Ks + g * AB_KST + ki;
+            const float* sp = dSs + (16 * w + ki) * AB_DSP + g;
+            for (int k0 = 0; k0 < Lp; k0 += 16) {
+                float ka[4], sb[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { ka[i] = kp[(k0 + 4 * i) * AB_KST]; sb[i] = sp[k0 + 4 * i]; }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dq[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[i], sb[i], dq[i], 0, 0, 0);
+            }
+            const int q = qt2 + ki;
+            if (q < L)
+                *reinterpret_cast<float4*>(dQ + (rowbase + q) * D + h * HD + 4 * g) =
+                    make_float4(dq[0][0] + dq[1][0] + dq[2][0] + dq[3][0], dq[0][1] + dq[1][1] + dq[2][1] + dq[3][1],
+                                dq[0][2] + dq[1][2] + dq[2][2] + dq[3][2], dq[0][3] + dq[1][3] + dq[2][3] + dq[3][3]);
+        }
+        if (qb == 0) STAMP(5);
+        __syncthreads();                        // dS buffer (and, after the last pass, Qs / Vs / As) free
+        if (qb == 0) STAMP(6);
+    }
+    float* xkv = Qs;                            // [8 strips][64 lanes][8]
+    if (hi == 1) {
+        *reinterpret_cast<float4*>(&xkv[((w & 7) * 64 + lane) * 8]) = make_float4(dk[0], dk[1], dk[2], dk[3]);
+        *reinterpret_cast<float4*>(&xkv[((w & 7) * 64 + lane) * 8 + 4]) = make_float4(dv[0], dv[1], dv[2], dv[3]);
+    }
+    __syncthreads();
+    if (hi == 0 && key < L) {
+        const float4 k1 = *reinterpret_cast<const float4*>(&xkv[((w & 7) * 64 + lane) * 8]);
+        const float4 v1 = *reinterpret_cast<const float4*>(&xkv[((w & 7) * 64 + lane) * 8 + 4]);
+        const size_t off = (rowbase + key) * D + h * HD + 4 * g;
+        *reinterpret_cast<float4*>(dK + off) = make_float4(dk[0] + k1.x, dk[1] + k1.y, dk[2] + k1.z, dk[3] + k1.w);
+        *reinterpret_cast<float4*>(dV + off) = make_float4(dv[0] + v1.x, dv[1] + v1.y, dv[2] + v1.z, dv[3] + v1.w);
+    }
+    STAMP(7);
+}
 void launch_attn_bwd(const float* Q, const float* K, const float* V, const float* att, const float* dr, const float* lse,
                      const float* mask, float* dQ, float* dK, float* dV, float* Dq, int B, int L, int H, int b_off, Drop d2,
                      Drop d3, hipStream_t s) {
     const int Lp = (L + 15) & ~15;
+    static const bool fused_ok = !(getenv("VSL_ATTN_BWD_FUSED") && getenv("VSL_ATTN_BWD_FUSED")[0] == '0');
+    if (Lp <= AB_LMAX && fused_ok) {
+        static size_t lds_okf = 0;
+        ensure_dynamic_lds((const void*)k_attn_bwd_fused, AB_LDS, lds_okf, "k_attn_bwd_fused");
+        hipLaunchKernelGGL(k_attn_bwd_fused, dim3(H, B), dim3(1024), AB_LDS, s, Q, K, V, att, dr, lse, mask, dQ, dK, dV, L, H,
+                           b_off, d2, d3);
+        static int left = 3;
+        if (dbg_budget("attn_bwd") && L > 64) dbg_report("attn_bwd_fused: stage-issue | landed+sync | pass-0 phase1 | sync | phase2 | sync | pass 1 + final", 8, s, left);
+        return;
+    }
     const int kst = head_slice_stride(Lp);
     const size_t shm1 = (size_t)(2 * Lp * kst + Lp) * sizeof(float), shm2 = (size_t)(2 * Lp * kst + 2 * Lp) * sizeof(float);
     static size_t lds_ok1 = 0, lds_ok2 = 0;
