@@ -181,13 +181,22 @@ __device__ __forceinline__ void gemm32p(const float* __restrict__ As, int lda, i
     const int nkb = K >> 3;
     const int nfull = nkb / KB;            // stages whose KB k-blocks all exist: straight-line code, no per-block guard
     const int rot = (nkb % KB == 0) ? kb_rot(nkb) : 0;
+    // Two fragment sets used alternately (no register copies: fp32 MFMAs and v_mov share the SIMD), with scheduling
+    // barriers so that the loads of the next stage stay in front of the MFMAs of the current one -- left alone the
+    // compiler sinks every load to just before its first use and waits on it (load -> vmcnt(0) -> 4 MFMAs).
     BFrag<NT, KB> nxt;
-    for (int st = 0; st < nfull; ++st) {
-        const int kb0 = st * KB;
-        const bool more = kb0 + KB < nkb;
-        if (more) bfrag_load(nxt, Bp, ncols, col0, cstep, kb0 + KB, nkb);
+    for (int kb0 = 0; kb0 + KB <= nkb; kb0 += 2 * KB) {
+        const bool more_a = kb0 + KB < nkb;
+        if (more_a) bfrag_load(nxt, Bp, ncols, col0, cstep, kb0 + KB, nkb);
+        __builtin_amdgcn_sched_barrier(0);
         mma_stage<NT, KB>(arow, kb0, rot, nkb, cur, acc);
-        if (more) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (kb0 + 2 * KB <= nkb) {
+            if (kb0 + 2 * KB < nkb) bfrag_load(cur, Bp, ncols, col0, cstep, kb0 + 2 * KB, nkb);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_stage<NT, KB>(arow, kb0 + KB, rot, nkb, nxt, acc);
+            __builtin_amdgcn_sched_barrier(0);
+        } else if (more_a) {                 // odd number of full stages and a ragged tail: its fragments sit in nxt
 #pragma unroll
             for (int q = 0; q < KB; ++q)
 #pragma unroll

@@ -1141,108 +1141,155 @@ void launch_cqcat_bwd(const float* dg0, const float* dg1, const float* dg2, cons
 __global__ __launch_bounds__(256) void k_cq_bwd_a(CqBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int T = a.T, Lq = a.Lq, LQ1 = Lq + 1;
+    const int NTJ = (Lq + 31) >> 5, PJ = 32 * NTJ + 1;      // 32-wide query-word tiles of the small MFMA products
     float* Dc = smem;                          // [32][CATP] grad wrt the concat tile
     float* Gs = Dc + TILE_M * CATP;            // [32][LDP]  df1 tile, later C tile
-    float* Ss = Gs + TILE_M * LDP;             // [32][LQ1]  S_row (+8 floats of slack for the chunked over-read)
+    float* Ss = Gs + TILE_M * LDP;             // [32][LQ1]  S_row, pad column zeroed (+ slack for the 32-wide over-read)
     float* Sd = Ss + TILE_M * LQ1 + 8;         // [32][LQ1]  dS_row
+    float* Pp = Sd + TILE_M * LQ1 + 64;        // [4][32][PJ] per-wave partial sums of dS_row
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int b = blockIdx.y, tl = blockIdx.x, t0 = tl * TILE_M, ntile = gridDim.x;
     const size_t crow = (size_t)b * T, qrow = (size_t)b * Lq;
+    STAMP(0);
     load_tile128(Gs, a.df1 + crow * D, t0, TILE_M, T);
-    for (int e = tid; e < TILE_M * Lq; e += 256) {
-        const int i = e / Lq, j = e - i * Lq;
-        Ss[i * LQ1 + j] = (t0 + i < T) ? a.Srow[(crow + t0) * Lq + e] : 0.f;
+    for (int e = tid; e < TILE_M * LQ1; e += 256) {
+        const int i = e / LQ1, j = e - i * LQ1;
+        Ss[e] = (j < Lq && t0 + i < T) ? a.Srow[(crow + t0 + i) * Lq + j] : 0.f;
     }
+    if (tid < 72) Sd[TILE_M * LQ1 - 8 + tid] = 0.f;          // finite values wherever the over-reads of Ss / Sd land
     BFrag<4, 4> bf;
     bfrag_load(bf, a.WcqaT, 4 * D, 32 * w, D, 0, D / 8);
     __syncthreads();
+    STAMP(1);
     f32x16 acc[4];
     zero_acc(acc);
     gemm32p<4, 4>(Gs, LDP, D, a.WcqaT, 4 * D, 32 * w, D, acc, bf);
-    const int col = 32 * w + (lane & 31);
+    const int col = 32 * w + (lane & 31), hh = lane >> 5;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) Dc[acc_row(r, lane) * CATP + t * D + col] = acc[t][r];
+    STAMP(2);
     __syncthreads();
     load_tile128(Gs, a.C + crow * D, t0, TILE_M, T);      // Gs now holds the C tile
-    __syncthreads();
-    const int c = tid & 127, hf = tid >> 7, hb = hf * 16;
+    // recompute c2q = S_row Q and q2c = S_row M (:229-230) on the matrix cores: K = Lq, wave = 32 output channels
+    f32x16 c2q[1], q2c[1];
+    zero_acc(c2q);
+    zero_acc(q2c);
     {
-        // thread = (channel c, 16 rows): recompute c2q / q2c (:229-230), then the product-rule split of :231
-        float a1[16], a2[16];
+        const float* sa = Ss + (lane & 31) * LQ1 + hh;
+        for (int jc = 0; jc < Lq; jc += 16) {              // 8 k-steps per chunk: all loads first, then the MFMAs
+            float sv[8], qv[8], mv[8];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) { a1[q] = 0.f; a2[q] = 0.f; }
-#pragma unroll 4
-        for (int j = 0; j < Lq; ++j) {
-            const float qv = a.Qf[(qrow + j) * D + c], mv = a.M[(qrow + j) * D + c];
-            const float* sr = Ss + hb * LQ1 + j;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) { a1[q] += sr[q * LQ1] * qv; a2[q] += sr[q * LQ1] * mv; }
-        }
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int rr = hb + q;
-            float* d = Dc + rr * CATP;
-            const float cv = Gs[rr * LDP + c];
-            const float d0 = d[c], d1 = d[D + c], d2 = d[2 * D + c], d3 = d[3 * D + c];
-            const float g_c2q = d1 + d2 * cv, g_q2c = d3 * cv;
-            d[D + c] = g_c2q;                  // kept in LDS: dS dots and the dM / dQ partials below
-            d[3 * D + c] = g_q2c;
-            if (t0 + rr < T) a.dC[(crow + t0 + rr) * D + c] = d0 + d2 * a1[q] + d3 * a2[q];
-        }
-    }
-    __syncthreads();
-    {   // dS_row[i][j] = dc2q[i] . Q[j] + dq2c[i] . M[j]
-        const int i = tid >> 3;
-        const float4* r1 = reinterpret_cast<const float4*>(Dc + i * CATP + D);
-        const float4* r3 = reinterpret_cast<const float4*>(Dc + i * CATP + 3 * D);
-        for (int j = tid & 7; j < Lq; j += 8) {
-            const float4* qr = reinterpret_cast<const float4*>(a.Qf + (qrow + j) * D);
-            const float4* mr = reinterpret_cast<const float4*>(a.M + (qrow + j) * D);
-            float s = 0.f;
-#pragma unroll 8
-            for (int k = 0; k < 32; ++k) {
-                const float4 x1 = r1[k], q4 = qr[k], x3 = r3[k], m4 = mr[k];
-                s += x1.x * q4.x + x1.y * q4.y + x1.z * q4.z + x1.w * q4.w + x3.x * m4.x + x3.y * m4.y + x3.z * m4.z + x3.w * m4.w;
+            for (int u = 0; u < 8; ++u) {
+                const int j = jc + 2 * u + hh;
+                const bool ok = j < Lq;
+                sv[u] = ok ? sa[jc + 2 * u] : 0.f;
+                qv[u] = ok ? a.Qf[(qrow + j) * D + col] : 0.f;
+                mv[u] = ok ? a.M[(qrow + j) * D + col] : 0.f;
             }
-            Sd[i * LQ1 + j] = s;
-        }
-    }
-    // per-tile partials: dM_t[j][c] = sum_i Srow[i][j] dq2c[i][c] ; dQa_t[j][c] = sum_i Srow[i][j] dc2q[i][c]
-    {
-        const int jn = (Lq + 1) / 2, j0 = hf * jn, j1 = min(Lq, j0 + jn);
-        const int nj_u = __builtin_amdgcn_readfirstlane(j1 - j0);
-        float am[MAX_LQ / 2], aq[MAX_LQ / 2];
 #pragma unroll
-        for (int q = 0; q < MAX_LQ / 2; ++q) { am[q] = 0.f; aq[q] = 0.f; }
-#pragma unroll
-        for (int qc = 0; qc < MAX_LQ / 16; ++qc) {
-            if (qc * 8 < nj_u) {
-#pragma unroll 4
-                for (int i = 0; i < TILE_M; ++i) {
-                    const float x3 = Dc[i * CATP + 3 * D + c], x1 = Dc[i * CATP + D + c];
-                    const float* sr = Ss + i * LQ1 + j0 + qc * 8;
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) { am[qc * 8 + q] += sr[q] * x3; aq[qc * 8 + q] += sr[q] * x1; }
+            for (int u = 0; u < 8; ++u) {
+                if (jc + 2 * u < Lq) {
+                    c2q[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[u], qv[u], c2q[0], 0, 0, 0);
+                    q2c[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[u], mv[u], q2c[0], 0, 0, 0);
                 }
             }
         }
-        float* p1 = a.P1 + ((size_t)(b * ntile + tl) * 2) * Lq * D;
-#pragma unroll
-        for (int q = 0; q < MAX_LQ / 2; ++q)
-            if (q < j1 - j0) { p1[(size_t)(j0 + q) * D + c] = am[q]; p1[(size_t)(Lq + j0 + q) * D + c] = aq[q]; }
     }
     __syncthreads();
-    for (int rr = w; rr < TILE_M; rr += 4) {     // softmax backward over the query words (dim=2, :225)
-        const int t = t0 + rr;
-        if (t >= T) continue;
-        const float s0 = lane < Lq ? Ss[rr * LQ1 + lane] : 0.f, s1 = lane + 64 < Lq ? Ss[rr * LQ1 + lane + 64] : 0.f;
-        const float g0 = lane < Lq ? Sd[rr * LQ1 + lane] : 0.f, g1 = lane + 64 < Lq ? Sd[rr * LQ1 + lane + 64] : 0.f;
-        const float dot = wave_sum(s0 * g0 + s1 * g1);
-        if (lane < Lq) a.dSr[(crow + t) * Lq + lane] = s0 * (g0 - dot);
-        if (lane + 64 < Lq) a.dSr[(crow + t) * Lq + lane + 64] = s1 * (g1 - dot);
+    STAMP(3);
+    // product-rule split of :231 in the accumulator layout (lane = channel, 16 rows)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int rr = acc_row(r, lane);
+        float* d = Dc + rr * CATP;
+        const float cv = Gs[rr * LDP + col];
+        const float d0 = d[col], d1 = d[D + col], d2 = d[2 * D + col], d3 = d[3 * D + col];
+        d[D + col] = d1 + d2 * cv;             // dc2q, kept in LDS: dS dots and the dM / dQ partials below
+        d[3 * D + col] = d3 * cv;              // dq2c
+        if (t0 + rr < T) a.dC[(crow + t0 + rr) * D + col] = d0 + d2 * c2q[0][r] + d3 * q2c[0][r];
     }
+    __syncthreads();
+    STAMP(4);
+    {   // dS_row[i][j] = dc2q[i] . Q[j] + dq2c[i] . M[j]: a 32 x 32 MFMA tile per 32 query words, K = 256 split over
+        // the four waves (wave w: channels 32w .. 32w+31 of both halves), partial tiles summed in wave order through LDS
+        f32x16 ds[2];
+        zero_acc(ds);
+        const int i = lane & 31;
+        float4 bq[2][2][4];                                  // [part][nt][kq]: every B fragment is requested up front
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            const float* src = part ? a.M : a.Qf;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int kq = 0; kq < 4; ++kq) {
+                    const int j = 32 * nt + i;
+                    bq[part][nt][kq] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (nt < NTJ && j < Lq)
+                        bq[part][nt][kq] = *reinterpret_cast<const float4*>(src + (qrow + j) * D + (4 * w + kq) * 8 + 4 * hh);
+                }
+        }
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            const float* arow = Dc + i * CATP + (part ? 3 * D : D) + 4 * hh;
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq) {
+                const float4 av = *reinterpret_cast<const float4*>(arow + (4 * w + kq) * 8);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    if (nt < NTJ) {
+                        const float4 bv = bq[part][nt][kq];
+                        ds[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, ds[nt], 0, 0, 0);
+                        ds[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, ds[nt], 0, 0, 0);
+                        ds[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, ds[nt], 0, 0, 0);
+                        ds[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, ds[nt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+            if (nt < NTJ) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Pp[(w * TILE_M + acc_row(r, lane)) * PJ + 32 * nt + i] = ds[nt][r];
+            }
+    }
+    // per-tile partials on the matrix cores: dM_t[j][c] = sum_i Srow[i][j] dq2c[i][c] ; dQa_t[j][c] = sum_i Srow[i][j] dc2q[i][c]
+    {
+        float* p1 = a.P1 + ((size_t)(b * ntile + tl) * 2) * Lq * D;
+        for (int nt = 0; nt < NTJ; ++nt) {
+            f32x16 am[1], aq[1];
+            zero_acc(am);
+            zero_acc(aq);
+            gemm_tn_p<1, TILE_M>(Ss, LQ1, 32 * nt, Dc + 3 * D, CATP, 32 * w, am);
+            gemm_tn_p<1, TILE_M>(Ss, LQ1, 32 * nt, Dc + D, CATP, 32 * w, aq);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = 32 * nt + acc_row(r, lane);
+                if (j < Lq) { p1[(size_t)j * D + col] = am[0][r]; p1[(size_t)(Lq + j) * D + col] = aq[0][r]; }
+            }
+        }
+    }
+    STAMP(5);
+    __syncthreads();
+    STAMP(6);
+    if (tid < TILE_M) {                          // softmax backward over the query words (dim=2, :225), thread = clip
+        const int t = t0 + tid;
+        if (t < T) {
+            const float* sr = Ss + tid * LQ1;
+            float dot = 0.f;
+            for (int j = 0; j < Lq; ++j) {
+                const float g = Pp[tid * PJ + j] + Pp[(TILE_M + tid) * PJ + j] + Pp[(2 * TILE_M + tid) * PJ + j] +
+                                Pp[(3 * TILE_M + tid) * PJ + j];
+                Sd[tid * LQ1 + j] = g;
+                dot += sr[j] * g;
+            }
+            for (int j = 0; j < Lq; ++j) a.dSr[(crow + t) * Lq + j] = sr[j] * (Sd[tid * LQ1 + j] - dot);
+        }
+    }
+    STAMP(7);
 }
 
 // sums the per-tile partials of dM into LDS (dMs [Lq][LDP]); 8 loads in flight per thread
@@ -1519,7 +1566,7 @@ void launch_cq_bwd(const CqBwdArgs& a0, int B, hipStream_t s) {
     CqBwdArgs a = a0;
     const int Lq = a.Lq, ntile = (a.T + TILE_M - 1) / TILE_M;
     a.ntile = ntile;
-    const size_t shmA = (size_t)(TILE_M * CATP + TILE_M * LDP + 2 * TILE_M * (Lq + 1) + 8) * sizeof(float);
+    const size_t shmA = (size_t)(TILE_M * CATP + TILE_M * LDP + 2 * TILE_M * (Lq + 1) + 72 + 4 * TILE_M * (32 * ((Lq + 31) / 32) + 1)) * sizeof(float);
     const size_t shmB = (size_t)(Lq * LDP + TILE_M * LDP + 2 * TILE_M * (Lq + 1)) * sizeof(float);
     const size_t shmC = (size_t)(2 * Lq * LDP + 2 * TILE_M * LDP + 2 * TILE_M * (Lq + 1) + 16 + Lq + TILE_M + 4 * D) * sizeof(float);
     const size_t shmD = (size_t)(Lq * LDP + 2 * Lq + 4 * D) * sizeof(float);
@@ -1529,6 +1576,7 @@ void launch_cq_bwd(const CqBwdArgs& a0, int B, hipStream_t s) {
     ensure_dynamic_lds((const void*)k_cq_bwd_c, shmC, okC, "k_cq_bwd_c");
     ensure_dynamic_lds((const void*)k_cq_bwd_d, shmD, okD, "k_cq_bwd_d");
     hipLaunchKernelGGL(k_cq_bwd_a, dim3(ntile, B), dim3(256), shmA, s, a);
+    { static int left = 2; if (dbg_budget("cq_bwd_a")) dbg_report("cq_bwd_a: load | gemm512 | Dc store | C load + c2q/q2c | product rule | dS_row + partials | sync | softmax bwd", 8, s, left); }
     hipLaunchKernelGGL(k_cq_bwd_b, dim3(ntile, B), dim3(256), shmB, s, a);
     hipLaunchKernelGGL(k_cq_bwd_c, dim3(ntile, B), dim3(256), shmC, s, a);
     hipLaunchKernelGGL(k_cq_bwd_d, dim3(B), dim3(256), shmD, s, a);
