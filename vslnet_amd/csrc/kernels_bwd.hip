@@ -1362,9 +1362,6 @@ __global__ __launch_bounds__(256) void k_cq_bwd_c(CqBwdArgs a) {
     const int tid = threadIdx.x;
     const int b = blockIdx.y, tl = blockIdx.x, t0 = tl * TILE_M, ntile = gridDim.x;
     const size_t crow = (size_t)b * T, qrow = (size_t)b * Lq;
-    const int c = tid & 127, hf = tid >> 7;
-    const int jn = (Lq + 1) / 2, j0 = hf * jn, j1 = min(Lq, j0 + jn);
-    const int nj_u = __builtin_amdgcn_readfirstlane(j1 - j0);
     // ---- prologue: tile loads + the cross-tile sums
     load_tile128(Cs, a.C + crow * D, t0, TILE_M, T);
     cq_sum_dM(dMs, a.P1, b, ntile, Lq);
@@ -1404,63 +1401,66 @@ __global__ __launch_bounds__(256) void k_cq_bwd_c(CqBwdArgs a) {
     }
     __syncthreads();
     float acc_w4C = 0.f, acc_mlu = 0.f;
+    const int w = tid >> 6, lane = tid & 63, hh = lane >> 5, col = 32 * w + (lane & 31);
     {
-        // rows of this thread: hf * 16 .. + 15 ; channel c
-        const float wC = a.w4C[c], wM = a.w4mlu[c];
-        float dcv[16], tq[16], tm[16];
+        // tq = dS Qd and tm = S_col dM (K = Lq) on the matrix cores; wave = 32 channels, accumulator layout lane = channel
+        f32x16 tq[1], tm[1];
+        zero_acc(tq);
+        zero_acc(tm);
+        const float* sgp = Sg + (lane & 31) * LQ1 + hh;
+        const float* stp = St + (lane & 31) * LQ1 + hh;
+        for (int jc = 0; jc < Lq; jc += 16) {
+            float gv[8], sv[8], qv[8], mv[8];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int t = t0 + hf * 16 + q;
-            dcv[q] = t < T ? a.dC[(crow + t) * D + c] : 0.f;
-            tq[q] = 0.f; tm[q] = 0.f;
-        }
-        for (int j = 0; j < Lq; ++j) {
-            const float qv = Qds[j * LDP + c], mv = dMs[j * LDP + c];
-            const float* sg = Sg + hf * 16 * LQ1 + j;
-            const float* st = St + hf * 16 * LQ1 + j;
+            for (int u = 0; u < 8; ++u) {
+                const int j = jc + 2 * u + hh;
+                const bool ok = j < Lq;
+                gv[u] = ok ? sgp[jc + 2 * u] : 0.f;
+                sv[u] = ok ? stp[jc + 2 * u] : 0.f;
+                qv[u] = ok ? Qds[j * LDP + col] : 0.f;
+                mv[u] = ok ? dMs[j * LDP + col] : 0.f;
+            }
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                tq[q] += sg[q * LQ1] * qv;                        // sum_j dS[i][j] Qd[j][c]
-                tm[q] += st[q * LQ1] * mv;                        // sum_j Scol[i][j] dM[j][c]   (M = Scol^T C)
+            for (int u = 0; u < 8; ++u) {
+                if (jc + 2 * u < Lq) {
+                    tq[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(gv[u], qv[u], tq[0], 0, 0, 0);   // sum_j dS[i][j] Qd[j][c]
+                    tm[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[u], mv[u], tm[0], 0, 0, 0);   // sum_j Scol[i][j] dM[j][c]
+                }
             }
         }
+        const float wC = a.w4C[col], wM = a.w4mlu[col];
+        float dcv[16];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int rr = hf * 16 + q;
+        for (int r = 0; r < 16; ++r) {
+            const int t = t0 + acc_row(r, lane);
+            dcv[r] = t < T ? a.dC[(crow + t) * D + col] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rr = acc_row(r, lane);
             const int t = t0 + rr;
-            const float cdv = Cd[rr * LDP + c];
-            const float dcd = rsum[rr] * wC + wM * tq[q];         // grad wrt dropped-out C
+            const float cdv = Cd[rr * LDP + col];
+            const float dcd = rsum[rr] * wC + wM * tq[0][r];      // grad wrt dropped-out C
             acc_w4C += rsum[rr] * cdv;
-            acc_mlu += tq[q] * cdv;
-            if (t < T) a.dC[(crow + t) * D + c] = dcv[q] + tm[q] + dcd * drop_mul(a.dc, (uint32_t)(((b + a.b_off) * T + t) * D + c));
+            acc_mlu += tq[0][r] * cdv;
+            if (t < T) a.dC[(crow + t) * D + col] = dcv[r] + tm[0][r] + dcd * drop_mul(a.dc, (uint32_t)(((b + a.b_off) * T + t) * D + col));
         }
-    }
-    {   // per-tile partial of dQ(trilinear)[j][c] = mask_q * w4mlu[c] * sum_i dS[i][j] Cd[i][c]
-        const float wM = a.w4mlu[c];
+        // per-tile partial of dQ(trilinear)[j][c] = mask_q * w4mlu[c] * sum_i dS[i][j] Cd[i][c]
         float* p4 = a.P4 + (size_t)(b * ntile + tl) * Lq * D;
+        const int NTJ = (Lq + 31) >> 5;
+        for (int nt = 0; nt < NTJ; ++nt) {
+            f32x16 pq[1];
+            zero_acc(pq);
+            gemm_tn_p<1, TILE_M>(Sg, LQ1, 32 * nt, Cd, LDP, 32 * w, pq);
 #pragma unroll
-        for (int qc = 0; qc < MAX_LQ / 16; ++qc) {
-            if (qc * 8 < nj_u) {
-                float acc[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) acc[q] = 0.f;
-#pragma unroll 4
-                for (int i = 0; i < TILE_M; ++i) {
-                    const float cv = Cd[i * LDP + c] * wM;
-                    const float* sg = Sg + i * LQ1 + j0 + qc * 8;
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) acc[q] += sg[q] * cv;
-                }
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int j = j0 + qc * 8 + q;
-                    if (j < j1) p4[(size_t)j * D + c] = acc[q] * drop_mul(a.dq, (uint32_t)(((b + a.b_off) * Lq + j) * D + c));
-                }
+            for (int r = 0; r < 16; ++r) {
+                const int j = 32 * nt + acc_row(r, lane);
+                if (j < Lq) p4[(size_t)j * D + col] = pq[0][r] * wM * drop_mul(a.dq, (uint32_t)(((b + a.b_off) * Lq + j) * D + col));
             }
         }
     }
-    v128[hf * D + c] = acc_w4C;
-    v128[2 * D + hf * D + c] = acc_mlu;
+    v128[hh * D + col] = acc_w4C;
+    v128[2 * D + hh * D + col] = acc_mlu;
     __syncthreads();                           // (also: everyone is done with Cs)
     load_tile128(Cs, a.df2 + crow * D, t0, TILE_M, T);
     if (tid < D) {
