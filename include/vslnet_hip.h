@@ -109,6 +109,24 @@ int vsl_backward(vsl_handle h, const vsl_io* io, void* hip_stream);
 int vsl_extract_index(vsl_handle h, const float* start_logits, const float* end_logits, int B, int T,
                       int64_t* start_index, int64_t* end_index, void* hip_stream);
 
+/* Optimizer step on the flat buckets: clip_grad_norm_(grads, clip_norm) (main_t7.py:111) followed by AdamW with decoupled
+ * weight decay (build_optimizer_and_scheduler, VSLNet_t7.py:8-17: no decay for names containing "bias", "layer_norm" or
+ * "LayerNorm" -- the library derives that mask from its own parameter names).  Two kernels, no host synchronisation: the
+ * global norm stays on the device.  Semantics are torch.optim.AdamW's (the reference's transformers.AdamW no longer
+ * exists; SURVEY 8c "optimizer parity unpinned"):
+ *     g   = grads * min(1, clip_norm / (||grads||_2 + 1e-6))            (clip_norm <= 0: no clipping)
+ *     p  *= 1 - lr * weight_decay[param]
+ *     m   = b1 m + (1 - b1) g ;  v = b2 v + (1 - b2) g^2
+ *     p  -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+ * `step` is t (1-based).  exp_avg / exp_avg_sq are caller-owned buckets of vsl_param_floats() floats, zero at t = 1.
+ * grad_norm_out (nullable): device float that receives the un-clipped global norm.  `grads` is not modified. */
+typedef struct {
+    float lr, beta1, beta2, eps, weight_decay, clip_norm;
+    int32_t step;
+} vsl_adamw;
+int vsl_adamw_step(vsl_handle h, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                   const vsl_adamw* hp, float* grad_norm_out, void* hip_stream);
+
 /* workspace introspection for the parity tests: float offset of a named saved activation, -1 if unknown.
  * names: "video_affine", "embedding_net", "venc", "qenc", "cq_attention", "cq_concat", "gated", "pred_s", "pred_e" */
 int64_t vsl_workspace_offset(vsl_handle h, int B, int T, int Lq, int Lc, const char* name);

@@ -1,0 +1,97 @@
+"""Optimizer step on the flat buckets: clip_grad_norm_(1.0) + AdamW(eps 1e-6, wd 0.01 except bias / layer_norm)
++ linear decay, main_t7.py:111-113 / VSLNet_t7.py:8-17.  The reference's transformers.AdamW is gone from transformers 5.x
+("optimizer parity unpinned"), so the pin is torch.optim.AdamW + torch.nn.utils.clip_grad_norm_, which is what
+the reference's own import shim resolves to today."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vslnet_oracle as O
+from vslnet_amd import dp
+
+
+def _layout(P):
+    layout, off = [], 0
+    for k, v in P.items():
+        if k in O.FROZEN:
+            continue
+        layout.append((k, off, v.numel(), tuple(v.shape)))
+        off += (v.numel() + 3) & ~3
+    return layout, off
+
+
+def _reference_steps(P, layout, grads_seq, lr0, N):
+    params = {n: torch.nn.Parameter(P[n].clone()) for n, _, _, _ in layout}
+    no_decay = ('bias', 'layer_norm', 'LayerNorm')                                   # VSLNet_t7.py:9-13
+    groups = [{'params': [p for n, p in params.items() if not any(k in n for k in no_decay)], 'weight_decay': 0.01},
+              {'params': [p for n, p in params.items() if any(k in n for k in no_decay)], 'weight_decay': 0.0}]
+    opt = torch.optim.AdamW(groups, lr=lr0, eps=1e-6)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda n: max(0.0, (N - n) / N))   # linear decay, no warm-up
+    norms = []
+    for g in grads_seq:
+        for n, o, k, shp in layout:
+            params[n].grad = g[o:o + k].view(shp).clone()
+        norms.append(float(torch.nn.utils.clip_grad_norm_(list(params.values()), 1.0)))
+        opt.step()
+        sched.step()
+    return params, norms
+
+
+def _case(seed=0, scale=(0.01, 3.0, 0.2)):
+    cfg = O.make_cfg(video_feature_dim=64, max_pos_len=32, word_size=52)
+    P = O.random_params(cfg, seed=seed)
+    layout, n = _layout(P)
+    g = torch.Generator().manual_seed(seed + 1)
+    grads_seq = []
+    for s in scale:                                                                   # below and above the clip threshold
+        f = torch.zeros(n)
+        for _, o, k, _ in layout:
+            f[o:o + k] = torch.randn(k, generator=g) * s / np.sqrt(n)
+        grads_seq.append(f)
+    flat = torch.zeros(n)
+    for nm, o, k, _ in layout:
+        flat[o:o + k] = P[nm].reshape(-1)
+    return cfg, P, layout, flat, grads_seq
+
+
+def test_flat_adamw_torch_path_matches_torch_optim():
+    cfg, P, layout, flat, grads_seq = _case()
+    ref, norms = _reference_steps(P, layout, grads_seq, 1e-3, 100)
+    assert norms[0] < 1.0 < norms[1]                                                  # both clip branches are exercised
+    opt = dp.FlatAdamW(flat, layout, lr=1e-3, num_train_steps=100)
+    for g in grads_seq:
+        opt.step(g)
+    for n, o, k, shp in layout:
+        assert torch.allclose(flat[o:o + k].view(shp), ref[n].data, rtol=1e-5, atol=1e-7), n
+
+
+@pytest.mark.gpu
+def test_fused_adamw_kernels_match_torch_optim():
+    from vslnet_amd.engine import Engine, flat_from_state_dict
+    cfg, P, _, _, _ = _case()
+    eng = Engine(cfg)
+    layout = eng.layout
+    n = eng.param_floats
+    g = torch.Generator().manual_seed(7)
+    grads_seq = []
+    for s in (0.01, 3.0, 0.2):
+        f = torch.zeros(n)
+        for _, o, k, _ in layout:
+            f[o:o + k] = torch.randn(k, generator=g) * s / np.sqrt(n)
+        grads_seq.append(f)
+    ref, norms = _reference_steps(P, layout, grads_seq, 1e-3, 100)
+    flat = flat_from_state_dict(eng, P)
+    opt = dp.FlatAdamW(flat, layout, lr=1e-3, num_train_steps=100, engine=eng)
+    gn = torch.zeros(1, device='cuda')
+    for i, gr in enumerate(grads_seq):
+        gd = gr.cuda()
+        keep = gd.clone()
+        opt.step(gd)
+        assert torch.equal(gd, keep), 'the gradient bucket must not be modified'
+        eng.adamw_step(flat.clone(), gd, opt.m.clone(), opt.v.clone(), 0.0, i + 1, grad_norm_out=gn)   # lr 0: only reports the norm
+        assert abs(float(gn) - norms[i]) <= 1e-5 * norms[i]
+    out = eng.views(flat)
+    for nm, o, k, shp in layout:
+        assert torch.allclose(out[nm].cpu(), ref[nm].data, rtol=2e-5, atol=1e-7), nm
+    with pytest.raises(Exception):
+        eng.adamw_step(flat, grads_seq[0].cuda(), opt.m, opt.v, 1e-3, 0)               # step must be >= 1

@@ -3,5 +3,5 @@
 cd "$(dirname "$0")/.."
 for v in base new base new; do
   if [ $v = base ]; then export VSLNET_HIP_LIB=$PWD/vslnet_amd/lib/libvslnet_hip_base.so; else unset VSLNET_HIP_LIB; fi
-  echo -n "$v: "; python bench.py --steps 40 --warmup 5 --no-cpu-baseline "$@" 2>/dev/null | python -c "import json,sys;d=json.load(sys.stdin);print(d['value'],d['ms_per_step'])"
+  echo -n "$v: "; python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-optimizer "$@" 2>/dev/null | python -c "import json,sys;d=json.load(sys.stdin);print(d['value'],d['ms_per_step'])"
 done

@@ -5,6 +5,7 @@
 #include "launch.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -83,6 +84,8 @@ struct vsl_handle_s {
     int64_t pack_floats = 0;
     std::vector<PackJob> jobs;
     PackJob* jobs_dev = nullptr;
+    uint8_t* decay_dev = nullptr;        // per-element weight-decay flag of the flat bucket (vsl_adamw_step)
+    float* opt_scratch = nullptr;        // OPT_BLOCKS partial sums of grads^2
     int* wdecode_dev = nullptr;          // flattened char-conv weight index -> (oc << 16 | ci << 8 | kk), 64 * 256 entries
     std::map<std::tuple<int, int, int, int>, Plan*> plans;
     // side streams for the independent chains (query branch, weight gradients) + fork/join events
@@ -841,6 +844,8 @@ int vsl_destroy(vsl_handle h) {
     }
     if (h->jobs_dev) (void)hipFree(h->jobs_dev);
     if (h->wdecode_dev) (void)hipFree(h->wdecode_dev);
+    if (h->decay_dev) (void)hipFree(h->decay_dev);
+    if (h->opt_scratch) (void)hipFree(h->opt_scratch);
     delete h;
     return 0;
 }
@@ -928,6 +933,29 @@ int vsl_extract_index(vsl_handle h, const float* start_logits, const float* end_
     if (T > 8192) return fail("T too large");
     launch_extract_index(start_logits, end_logits, start_index, end_index, B, T, (hipStream_t)hip_stream);
     HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int vsl_adamw_step(vsl_handle h, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const vsl_adamw* hp,
+                   float* grad_norm_out, void* hip_stream) {
+    if (!h || !params || !grads || !exp_avg || !exp_avg_sq || !hp) return fail("vsl_adamw_step: null argument");
+    if (hp->step < 1) return fail("vsl_adamw_step: step must be >= 1 (got %d)", hp->step);
+    if (!h->decay_dev) {          // VSLNet_t7.py:9-13: no decay for bias / layer_norm / LayerNorm parameters
+        std::vector<uint8_t> mask((size_t)h->param_floats, 0);
+        for (const ParamInfo& p : h->params) {
+            const bool nd = p.name.find("bias") != std::string::npos || p.name.find("layer_norm") != std::string::npos ||
+                            p.name.find("LayerNorm") != std::string::npos;
+            if (!nd) std::fill(mask.begin() + p.off, mask.begin() + p.off + p.numel, (uint8_t)1);
+        }
+        if (hipMalloc(&h->decay_dev, mask.size()) != hipSuccess || hipMalloc(&h->opt_scratch, (OPT_BLOCKS + 4) * sizeof(float)) != hipSuccess)
+            return fail("vsl_adamw_step: hipMalloc failed");
+        if (hipMemcpy(h->decay_dev, mask.data(), mask.size(), hipMemcpyHostToDevice) != hipSuccess)
+            return fail("vsl_adamw_step: hipMemcpy failed");
+    }
+    const double bc1 = 1.0 - std::pow((double)hp->beta1, (double)hp->step), bc2 = 1.0 - std::pow((double)hp->beta2, (double)hp->step);
+    launch_adamw(params, grads, exp_avg, exp_avg_sq, h->decay_dev, h->opt_scratch, h->param_floats, hp->lr, hp->beta1, hp->beta2,
+                 hp->eps, hp->weight_decay, hp->clip_norm, (float)bc1, (float)std::sqrt(bc2), grad_norm_out, (hipStream_t)hip_stream);
+    if (hipGetLastError() != hipSuccess) return fail("vsl_adamw_step: launch failed");
     return 0;
 }
 

@@ -5,6 +5,7 @@
 #include "common.hpp"
 #include "launch.hpp"
 #include <type_traits>
+#include <algorithm>
 
 namespace vsl {
 
@@ -1899,6 +1900,68 @@ __global__ __launch_bounds__(256) void k_reduce(const float* __restrict__ ws, fl
 void launch_reduce(const float* partial, float* grads, const ReduceSeg* segs_dev, const int* blk2seg_dev, int nblocks,
                    hipStream_t s) {
     hipLaunchKernelGGL(k_reduce, dim3(nblocks), dim3(256), 0, s, partial, grads, segs_dev, blk2seg_dev);
+}
+
+// =========================================================================================================
+// optimizer step on the flat buckets (main_t7.py:111-112, VSLNet_t7.py:8-17): HBM-bound, 5 streams of n floats.
+//   k_sqsum : OPT_BLOCKS partial sums of grads^2 (grid-stride, float4), fixed summation order
+//   k_adamw : every block re-reduces the partials (256 floats, L2-resident) -> clip factor, then updates its elements
+// =========================================================================================================
+__global__ __launch_bounds__(256) void k_sqsum(const float* __restrict__ g, int64_t n4, float* __restrict__ partials) {
+    __shared__ float red[4];
+    float s = 0.f;
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = g4[i];
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                               float* __restrict__ v, const uint8_t* __restrict__ decay, const float* __restrict__ partials,
+                                               int64_t n4, float lr, float b1, float b2, float eps, float wd, float clip, float bc1,
+                                               float bc2_sqrt, float* __restrict__ norm_out) {
+    __shared__ float red[4];
+    float s = threadIdx.x < OPT_BLOCKS ? partials[threadIdx.x] : 0.f;
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+    if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out) *norm_out = norm;
+    const float coef = clip > 0.f ? fminf(1.0f, clip / (norm + 1e-6f)) : 1.0f;       // clip_grad_norm_
+    const float step_size = lr / bc1;
+    float4* p4 = reinterpret_cast<float4*>(p);
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    float4* m4 = reinterpret_cast<float4*>(m);
+    float4* v4 = reinterpret_cast<float4*>(v);
+    const uchar4* d4 = reinterpret_cast<const uchar4*>(decay);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 pv = p4[i], mv = m4[i], vv = v4[i];
+        const float4 gv = g4[i];
+        const uchar4 dk = d4[i];
+        auto upd = [&](float& pe, float& me, float& ve, float ge, unsigned char dke) {
+            ge *= coef;
+            pe *= 1.0f - lr * (dke ? wd : 0.f);
+            me = b1 * me + (1.0f - b1) * ge;
+            ve = b2 * ve + (1.0f - b2) * ge * ge;
+            pe -= step_size * me / (sqrtf(ve) / bc2_sqrt + eps);
+        };
+        upd(pv.x, mv.x, vv.x, gv.x, dk.x); upd(pv.y, mv.y, vv.y, gv.y, dk.y);
+        upd(pv.z, mv.z, vv.z, gv.z, dk.z); upd(pv.w, mv.w, vv.w, gv.w, dk.w);
+        p4[i] = pv; m4[i] = mv; v4[i] = vv;
+    }
+}
+void launch_adamw(float* params, const float* grads, float* m, float* v, const uint8_t* decay_mask, float* partials, int64_t n,
+                  float lr, float b1, float b2, float eps, float wd, float clip, float bc1, float bc2_sqrt, float* norm_out,
+                  hipStream_t s) {
+    const int64_t n4 = n / 4;                    // the bucket is a multiple of 4 floats (every tensor is 16-byte aligned)
+    hipLaunchKernelGGL(k_sqsum, dim3(OPT_BLOCKS), dim3(256), 0, s, grads, n4, partials);
+    const int nb = (int)std::min<int64_t>(1024, (n4 + 255) / 256);
+    hipLaunchKernelGGL(k_adamw, dim3(nb), dim3(256), 0, s, params, grads, m, v, decay_mask, partials, n4, lr, b1, b2, eps, wd, clip,
+                       bc1, bc2_sqrt, norm_out);
 }
 
 }  // namespace vsl

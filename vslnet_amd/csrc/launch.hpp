@@ -190,6 +190,11 @@ void launch_embed_bwd(const float* dE, const int64_t* word_ids, const int64_t* c
                       Drop dc, hipStream_t s);
 void launch_reduce(const float* ws, float* grads, const ReduceSeg* segs_dev, const int* blk2seg_dev, int nblocks,
                    hipStream_t s);
+// fused optimizer (vsl_adamw_step): sum of squares partials, then clip + AdamW
+constexpr int OPT_BLOCKS = 256;
+void launch_adamw(float* params, const float* grads, float* m, float* v, const uint8_t* decay_mask, float* partials /*[OPT_BLOCKS + 1]*/,
+                  int64_t n, float lr, float b1, float b2, float eps, float wd, float clip, float bc1, float bc2_sqrt,
+                  float* norm_out, hipStream_t s);
 constexpr int EMB_CHUNK = 8;     // query words per workgroup in the embedding backward
 constexpr int CHARW_TOTAL = 15000;
 

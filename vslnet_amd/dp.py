@@ -45,21 +45,25 @@ def allreduce_flat_(flat_grads, group=None):
 
 
 class FlatAdamW:
-    """clip_grad_norm_(1.0) + AdamW + linear decay (main_t7.py:111-113, VSLNet_t7.py:8-17) on the FLAT buckets: six
-    element-wise passes over one 2.7 MB tensor instead of ~100 small per-parameter launches.  Weight decay 0.01 except
-    for names containing bias / layer_norm / LayerNorm (a 0/1 mask over the bucket).  Host-side helper (torch ops);
-    the fused HIP version is listed as 'next' in DESIGN.md."""
+    """clip_grad_norm_(1.0) + AdamW + linear decay (main_t7.py:111-113, VSLNet_t7.py:8-17) on the FLAT buckets.
+    Weight decay 0.01 except for names containing bias / layer_norm / LayerNorm.  With an `engine` (GPU) the step is the
+    library's fused two-kernel `vsl_adamw_step` (no host synchronisation: the global norm never leaves the device);
+    without one (CPU / gloo tests) the same arithmetic runs as torch ops, which is also what the GPU test checks the
+    kernels against.  Update rule = torch.optim.AdamW's (eps 1e-6)."""
 
     def __init__(self, flat, layout, lr, num_train_steps, warmup_proportion=0.0, clip_norm=1.0, betas=(0.9, 0.999), eps=1e-6,
-                 weight_decay=0.01):
+                 weight_decay=0.01, engine=None):
         self.flat, self.lr0, self.N, self.clip = flat, lr, float(num_train_steps), clip_norm
         self.warm = float(num_train_steps) * warmup_proportion
-        self.b1, self.b2, self.eps = betas[0], betas[1], eps
+        self.b1, self.b2, self.eps, self.weight_decay = betas[0], betas[1], eps, weight_decay
         self.m, self.v = torch.zeros_like(flat), torch.zeros_like(flat)
-        self.wd = torch.zeros_like(flat)
-        for name, off, numel, _ in layout:
-            if not any(k in name for k in ('bias', 'layer_norm', 'LayerNorm')):
-                self.wd[off:off + numel] = weight_decay
+        self.engine = engine
+        self.wd = None
+        if engine is None:
+            self.wd = torch.zeros_like(flat)
+            for name, off, numel, _ in layout:
+                if not any(k in name for k in ('bias', 'layer_norm', 'LayerNorm')):
+                    self.wd[off:off + numel] = weight_decay
         self.t = 0
 
     def lr(self):
@@ -70,14 +74,18 @@ class FlatAdamW:
 
     @torch.no_grad()
     def step(self, grads):
-        gn = float(torch.linalg.vector_norm(grads))
-        if self.clip and gn > self.clip:
-            grads = grads * (self.clip / (gn + 1e-6))
         lr = self.lr()
         self.t += 1
+        if self.engine is not None:
+            self.engine.adamw_step(self.flat, grads, self.m, self.v, lr, self.t, (self.b1, self.b2), self.eps, self.weight_decay,
+                                   self.clip)
+            return
+        if self.clip:
+            gn = torch.linalg.vector_norm(grads)
+            grads = grads * torch.clamp(self.clip / (gn + 1e-6), max=1.0)
+        self.flat.mul_(1 - lr * self.wd)
         self.m.mul_(self.b1).add_(grads, alpha=1 - self.b1)
         self.v.mul_(self.b2).addcmul_(grads, grads, value=1 - self.b2)
         bc1, bc2 = 1 - self.b1 ** self.t, 1 - self.b2 ** self.t
-        self.flat.mul_(1 - lr * self.wd)
-        self.flat.addcdiv_(self.m, (self.v / bc2).sqrt_().add_(self.eps), value=-lr / bc1)
-        return gn
+        denom = (self.v.sqrt() / math.sqrt(bc2)).add_(self.eps)
+        self.flat.addcdiv_(self.m, denom, value=-lr / bc1)

@@ -39,9 +39,14 @@ class vsl_loss_io(C.Structure):
                 ('d_end_logits', C.c_void_p)]
 
 
+class vsl_adamw(C.Structure):
+    _fields_ = [('lr', C.c_float), ('beta1', C.c_float), ('beta2', C.c_float), ('eps', C.c_float), ('weight_decay', C.c_float),
+                ('clip_norm', C.c_float), ('step', C.c_int32)]
+
+
 ABI_SYMBOLS = ['vsl_last_error', 'vsl_create', 'vsl_destroy', 'vsl_param_count', 'vsl_param_info', 'vsl_param_floats',
                'vsl_workspace_floats', 'vsl_forward', 'vsl_loss', 'vsl_backward', 'vsl_extract_index',
-               'vsl_workspace_offset', 'vsl_profile_select', 'vsl_profile_read']
+               'vsl_adamw_step', 'vsl_workspace_offset', 'vsl_profile_select', 'vsl_profile_read']
 
 
 def load_library():
@@ -68,6 +73,7 @@ def load_library():
     lib.vsl_loss.argtypes = [C.c_void_p, C.POINTER(vsl_io), C.POINTER(vsl_loss_io), C.c_void_p]
     lib.vsl_backward.argtypes = [C.c_void_p, C.POINTER(vsl_io), C.c_void_p]
     lib.vsl_extract_index.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.vsl_adamw_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(vsl_adamw), C.c_void_p, C.c_void_p]
     lib.vsl_workspace_offset.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p]
     lib.vsl_workspace_offset.restype = C.c_int64
     lib.vsl_profile_select.argtypes = [C.c_void_p, C.c_char_p]
@@ -259,6 +265,18 @@ class Engine:
             out[name.value.decode()] = (ms.value, n.value)
             i += 1
         return out
+
+    def adamw_step(self, flat, grads, exp_avg, exp_avg_sq, lr, step, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.01,
+                   clip_norm=1.0, grad_norm_out=None):
+        """clip_grad_norm_ + AdamW on the flat buckets (main_t7.py:111-112), two kernels, no host synchronisation.
+        `step` is 1-based; `grad_norm_out` (optional 1-element device tensor) receives the un-clipped global norm."""
+        n = self.param_floats
+        for t, nm in ((flat, 'flat'), (grads, 'grads'), (exp_avg, 'exp_avg'), (exp_avg_sq, 'exp_avg_sq')):
+            _chk(t, torch.float32, (n,), nm)
+        hp = vsl_adamw(float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), float(clip_norm or 0.0), int(step))
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        self._call(self.lib.vsl_adamw_step(self.h, _ptr(flat), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq), C.byref(hp),
+                                           _ptr(grad_norm_out) if grad_norm_out is not None else None, stream))
 
     def extract_index(self, start_logits, end_logits):
         B, T = start_logits.shape
