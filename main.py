@@ -1,0 +1,222 @@
+"""Command line of the MI355X-native VSLNet path: same flags and behaviour as the reference's `main_t7.py` (flags :13-45,
+training loop :83-129, test mode :131-149; the TF spelling `--hidden_size` of main.py:27 is accepted for `--dim`).
+
+    python main.py --task charades --predictor transformer --mode train          # needs the reference's processed dataset
+    python main.py --task synthetic --predictor transformer --mode train --epochs 5
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 main.py --task synthetic ...   # data parallel
+
+What differs from the reference, by design:
+  * the model is `vslnet_amd.model.VSLNet` (hand-written gfx950 kernels behind the reference's module API);
+  * `--optimizer fused` (default) runs forward / losses / backward through the engine and the update as the library's fused
+    clip + AdamW step on the flat parameter bucket; `--optimizer torch` is the reference's loop verbatim in structure
+    (module API, `clip_grad_norm_`, `torch.optim.AdamW`, LambdaLR) -- single process only;
+  * under torch.distributed.run every rank draws the same shuffled global batch and keeps its contiguous slice; losses are
+    normalised with the GLOBAL batch size / mask sum, gradients are summed with one all-reduce of the flat bucket
+    (vslnet_amd/dp.py), the update is identical on every rank; rank 0 evaluates and writes checkpoints;
+  * `--task synthetic` builds a small learnable dataset in the reference's record format (no dataset files needed).
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+from vslnet_amd import data, dp, runner
+
+
+def build_parser():
+    p = argparse.ArgumentParser()
+    # data parameters (main_t7.py:14-18)
+    p.add_argument('--save_dir', type=str, default='datasets_t7', help='path to save processed dataset')
+    p.add_argument('--task', type=str, default='charades', help='[charades | activitynet | tacos | synthetic]')
+    p.add_argument('--fv', type=str, default='new', help='[new | org] for visual features')
+    p.add_argument('--max_pos_len', type=int, default=128, help='maximal position sequence length allowed')
+    # model parameters (:20-29)
+    p.add_argument('--word_size', type=int, default=None)
+    p.add_argument('--char_size', type=int, default=None)
+    p.add_argument('--word_dim', type=int, default=300)
+    p.add_argument('--video_feature_dim', type=int, default=1024)
+    p.add_argument('--char_dim', type=int, default=50)
+    p.add_argument('--dim', '--hidden_size', dest='dim', type=int, default=128, help='hidden size')
+    p.add_argument('--highlight_lambda', type=float, default=5.0)
+    p.add_argument('--num_heads', type=int, default=8)
+    p.add_argument('--drop_rate', type=float, default=0.2)
+    p.add_argument('--predictor', type=str, default='rnn', help='[rnn | transformer]')
+    # training / evaluation parameters (:31-45)
+    p.add_argument('--gpu_idx', type=str, default='0')
+    p.add_argument('--seed', type=int, default=12345)
+    p.add_argument('--mode', type=str, default='train', help='[train | test]')
+    p.add_argument('--epochs', type=int, default=100)
+    p.add_argument('--batch_size', type=int, default=16, help='GLOBAL batch size (split over the ranks under torchrun)')
+    p.add_argument('--num_train_steps', type=int, default=None)
+    p.add_argument('--init_lr', type=float, default=0.0001)
+    p.add_argument('--clip_norm', type=float, default=1.0)
+    p.add_argument('--warmup_proportion', type=float, default=0.0)
+    p.add_argument('--extend', type=float, default=0.1)
+    p.add_argument('--period', type=int, default=100)
+    p.add_argument('--model_dir', type=str, default='ckpt_t7')
+    p.add_argument('--model_name', type=str, default='vslnet')
+    p.add_argument('--suffix', type=str, default=None)
+    # additions of this build
+    p.add_argument('--optimizer', type=str, default='fused', help='[fused | torch]')
+    p.add_argument('--synthetic_train', type=int, default=512)
+    p.add_argument('--synthetic_test', type=int, default=128)
+    return p
+
+
+def model_home(configs):
+    """main_t7.py:70-74."""
+    home = os.path.join(configs.model_dir, '_'.join([configs.model_name, configs.task, configs.fv, str(configs.max_pos_len), configs.predictor]))
+    if configs.suffix is not None:
+        home = home + '_' + configs.suffix
+    return os.path.join(home, 'model')
+
+
+def _dist_env():
+    world, rank, local = (int(os.environ.get(k, d)) for k, d in (('WORLD_SIZE', '1'), ('RANK', '0'), ('LOCAL_RANK', '0')))
+    return world, rank, local
+
+
+def _to_device(batch, device):
+    return [t.to(device, non_blocking=True) if torch.is_tensor(t) else t for t in batch]
+
+
+def train(configs, dataset, features, device, world, rank, log=print):
+    from vslnet_amd.model.VSLNet import VSLNet, build_optimizer_and_scheduler
+    model_dir = model_home(configs)
+    gen = torch.Generator().manual_seed(configs.seed)                       # same shuffle on every rank
+    train_loader = data.get_train_loader(dataset['train_set'], features, configs, pin=True, generator=gen)
+    test_loader = data.get_test_loader(dataset['test_set'], features, configs, pin=True)
+    n_batches = len(train_loader)
+    configs.num_train_steps = n_batches * configs.epochs                    # main_t7.py:58
+    if rank == 0:
+        os.makedirs(model_dir, exist_ok=True)
+        with open(os.path.join(model_dir, 'configs.json'), 'w', encoding='utf-8') as f:
+            f.write(json.dumps(vars(configs), indent=4, sort_keys=True))
+    model = VSLNet(configs=configs, word_vectors=dataset['word_vector']).to(device)
+    fused = configs.optimizer == 'fused'
+    if not fused and world > 1:
+        raise ValueError('--optimizer torch is single-process; use --optimizer fused under torch.distributed.run')
+    if fused:
+        flat, grads = model.flat_parameters
+        eng = model._engine
+        opt = dp.FlatAdamW(flat, eng.layout, lr=configs.init_lr, num_train_steps=configs.num_train_steps,
+                           warmup_proportion=configs.warmup_proportion, clip_norm=configs.clip_norm, engine=eng)
+        pad_vec, glove_vec = model.embedding_net.word_emb.pad_vec.data, model.embedding_net.word_emb.glove_vec.data
+    else:
+        optimizer, scheduler = build_optimizer_and_scheduler(model, configs)
+    eval_period = max(1, n_batches // 2)
+    best_r1i7, global_step, history = -1.0, 0, []
+    score_writer = open(os.path.join(model_dir, 'eval_results.txt'), 'w', encoding='utf-8') if rank == 0 else None
+    log('start training...')
+    for epoch in range(configs.epochs):
+        model.train()
+        for batch in train_loader:
+            global_step += 1
+            _, vfeats, vfeat_lens, word_ids, char_ids, s_labels, e_labels, h_labels = batch
+            B = vfeats.shape[0]
+            if fused:
+                sl = dp.shard_slice(B, rank, world)
+                inv_batch, mask_sum = dp.global_normalisers(vfeat_lens.tolist())
+                vf, vl, wi, ci, s_l, e_l, h_l = _to_device([vfeats[sl], vfeat_lens, word_ids[sl], char_ids[sl], s_labels[sl],
+                                                           e_labels[sl], h_labels[sl]], device)
+                v_mask = runner.convert_length_to_mask(vl)[sl].contiguous()     # padded to the GLOBAL max length
+                q_mask = (wi != 0).float()
+                eng.forward(flat, pad_vec, glove_vec, wi.contiguous(), ci.contiguous(), vf.contiguous(), v_mask, q_mask,
+                            training=True, seed=(configs.seed << 20) + global_step * world + rank)
+                losses, d_h, d_sl, d_el = eng.loss(s_l.contiguous(), e_l.contiguous(), h_l.contiguous(), 1.0, configs.highlight_lambda,
+                                                   inv_batch=inv_batch, mask_sum=mask_sum)
+                eng.backward(d_h, d_sl, d_el, grads)
+                dp.allreduce_flat_(grads)
+                opt.step(grads)
+                loss_t = losses[2]
+            else:
+                vfeats, vfeat_lens, word_ids, char_ids, s_labels, e_labels, h_labels = _to_device(
+                    [vfeats, vfeat_lens, word_ids, char_ids, s_labels, e_labels, h_labels], device)
+                query_mask = (word_ids != 0).float()
+                video_mask = runner.convert_length_to_mask(vfeat_lens)
+                h_score, start_logits, end_logits = model(word_ids, char_ids, vfeats, video_mask, query_mask)
+                highlight_loss = model.compute_highlight_loss(h_score, h_labels, video_mask)
+                loc_loss = model.compute_loss(start_logits, end_logits, s_labels, e_labels)
+                loss_t = loc_loss + configs.highlight_lambda * highlight_loss
+                optimizer.zero_grad()
+                loss_t.backward()
+                torch.nn.utils.clip_grad_norm_(model.parameters(), configs.clip_norm)
+                optimizer.step()
+                scheduler.step()
+            if global_step % configs.period == 0 or global_step == 1:
+                lv = float(loss_t.item())
+                if world > 1:                                   # local partial sums of the global loss
+                    t = torch.tensor([lv], device=device)
+                    torch.distributed.all_reduce(t)
+                    lv = float(t.item())
+                history.append((global_step, lv))
+                log('step %6d | loss %.4f' % (global_step, lv))
+            if global_step % eval_period == 0 or global_step % n_batches == 0:
+                if rank == 0:
+                    model.eval()
+                    r1i3, r1i5, r1i7, mi, score_str = runner.eval_test(model, test_loader, device, 'test', epoch + 1, global_step)
+                    log('Epoch: %2d | Step: %5d | r1i3: %.2f | r1i5: %.2f | r1i7: %.2f | mIoU: %.2f' % (epoch + 1, global_step, r1i3, r1i5, r1i7, mi))
+                    score_writer.write(score_str)
+                    score_writer.flush()
+                    history.append((global_step, {'r1i3': r1i3, 'r1i5': r1i5, 'r1i7': r1i7, 'mIoU': mi}))
+                    if r1i7 >= best_r1i7:
+                        best_r1i7 = r1i7
+                        torch.save(model.state_dict(), os.path.join(model_dir, '{}_{}.t7'.format(configs.model_name, global_step)))
+                        runner.filter_checkpoints(model_dir, suffix='t7', max_to_keep=3)
+                    model.train()
+                if world > 1:
+                    torch.distributed.barrier()
+    if score_writer:
+        score_writer.close()
+    return {'history': history, 'model_dir': model_dir, 'steps': global_step}
+
+
+def test(configs, parser, argv, dataset, features, device, log=print):
+    from vslnet_amd.model.VSLNet import VSLNet
+    model_dir = model_home(configs)
+    if not os.path.exists(model_dir):
+        raise ValueError('No pre-trained weights exist')
+    with open(os.path.join(model_dir, 'configs.json'), encoding='utf-8') as f:
+        parser.set_defaults(**json.load(f))                                    # main_t7.py:136-138
+    configs = parser.parse_args(argv)
+    model = VSLNet(configs=configs, word_vectors=dataset['word_vector']).to(device)
+    model.load_state_dict(torch.load(runner.get_last_checkpoint(model_dir, suffix='t7'), map_location=device))
+    model.eval()
+    loader = data.get_test_loader(dataset['test_set'], features, configs, pin=True)
+    r1i3, r1i5, r1i7, mi, _ = runner.eval_test(model, loader, device, mode='test')
+    for name, v in (('Rank@1, IoU=0.3', r1i3), ('Rank@1, IoU=0.5', r1i5), ('Rank@1, IoU=0.7', r1i7), ('mean IoU'.ljust(15), mi)):
+        log('\x1b[1;31m{}:\t{:.2f}\x1b[0m'.format(name, v))
+    return {'r1i3': r1i3, 'r1i5': r1i5, 'r1i7': r1i7, 'mIoU': mi}
+
+
+def run(argv=None, log=print):
+    parser = build_parser()
+    configs = parser.parse_args(argv)
+    world, rank, local = _dist_env()
+    runner.set_th_config(configs.seed)
+    dataset, features = data.load_dataset(configs)
+    configs.char_size, configs.word_size = dataset['n_chars'], dataset['n_words']      # main_t7.py:52-53
+    if not torch.cuda.is_available():
+        raise RuntimeError('main.py needs an MI355X (ROCm device): the HIP path has no CPU fallback')
+    device = torch.device('cuda', local if world > 1 else int(configs.gpu_idx or 0))
+    torch.cuda.set_device(device)
+    if world > 1 and not torch.distributed.is_initialized():
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.distributed.init_process_group('nccl', device_id=device)
+    quiet = (lambda *a, **k: None) if rank != 0 else log
+    mode = configs.mode.lower()
+    try:
+        if mode == 'train':
+            return train(configs, dataset, features, device, world, rank, quiet)
+        if mode == 'test':
+            return test(configs, parser, argv, dataset, features, device, quiet)
+        raise ValueError('Unknown mode {}!!!'.format(configs.mode))
+    finally:
+        if world > 1 and torch.distributed.is_initialized():
+            torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    run(sys.argv[1:])

@@ -147,13 +147,76 @@ def run_host_helpers(ru, dl):
     print('host_helpers written')
 
 
+def host_pipeline_records(seed=11, n=13, dv=12):
+    """Synthetic dataset records in the reference's format (data_gen.py:178-181) + per-video features.  Deterministic;
+    tests/test_data_pipeline.py rebuilds the same inputs from this function (it is pure numpy, no reference import)."""
+    rs = np.random.RandomState(seed)
+    feats, records = {}, []
+    for i in range(n):
+        L = int(rs.randint(4, 30))
+        feats['v%d' % i] = rs.randn(L, dv).astype(np.float32)
+        dur = float(rs.uniform(5, 60))
+        st = float(rs.uniform(0, dur * 0.6))
+        et = float(min(dur, st + rs.uniform(0.5, dur * 0.5)))
+        nw = int(rs.randint(1, 9))
+        records.append({'sample_id': i, 'vid': 'v%d' % i, 's_time': st, 'e_time': et, 'duration': dur, 'v_len': L,
+                        's_ind': int(rs.randint(0, L)), 'e_ind': 0,
+                        'w_ids': [int(x) for x in rs.randint(1, 40, size=nw)],
+                        'c_ids': [[int(x) for x in rs.randint(1, 25, size=int(rs.randint(1, 7)))] for _ in range(nw)]})
+        records[-1]['e_ind'] = int(rs.randint(records[-1]['s_ind'], L))
+    return records, feats
+
+
+def run_host_pipeline(ru, dl):
+    """Pins for the batch pipeline / eval helpers of SURVEY 8(f) rows 1-2: collate functions (data_loader_t7.py:24-81),
+    padding (data_util.py:117-159), feature sampling (:59-73), index<->time (:92-114) and the eval metrics
+    (runner_utils_t7.py:55-101)."""
+    from util import data_util as du
+    records, feats = host_pipeline_records()
+    ds = dl.Dataset(records, feats)
+    out = {}
+    items = [ds[i] for i in range(len(ds))]
+    _, vf, vl, wi, ci, sl, el, hl = dl.train_collate_fn(items)
+    out.update(tr_vfeats=vf.numpy(), tr_vlens=vl.numpy(), tr_word_ids=wi.numpy(), tr_char_ids=ci.numpy(),
+               tr_s=sl.numpy(), tr_e=el.numpy(), tr_h=hl.numpy())
+    _, vf, vl, wi, ci = dl.test_collate_fn(items[:5])
+    out.update(te_vfeats=vf.numpy(), te_vlens=vl.numpy(), te_word_ids=wi.numpy(), te_char_ids=ci.numpy())
+    rs = np.random.RandomState(3)
+    for k, (L, m) in enumerate([(50, 16), (17, 16), (16, 16), (9, 16), (200, 32), (33, 32)]):
+        x = rs.randn(L, 5).astype(np.float32)
+        out['samp%d_in' % k] = x
+        out['samp%d_out' % k] = np.asarray(du.visual_feature_sampling(x, m))
+        out['samp%d_m' % k] = np.array(m)
+    t2i, i2t = [], []
+    for _ in range(12):
+        n = int(rs.randint(3, 40)); dur = float(rs.uniform(4, 90))
+        a = float(rs.uniform(0, dur * 0.7)); b = float(min(dur, a + rs.uniform(0.2, dur * 0.5)))
+        s, e, _ = du.time_to_index(a, b, n, dur)
+        t2i.append([a, b, n, dur, s, e])
+        si = int(rs.randint(0, n)); ei = int(rs.randint(si, n))
+        st, et = du.index_to_time(si, ei, n, dur)
+        i2t.append([si, ei, n, dur, float(st), float(et)])
+    out['time_to_index'] = np.array(t2i, dtype=np.float64)
+    out['index_to_time'] = np.array(i2t, dtype=np.float64)
+    ious = rs.rand(57)
+    out['metric_ious'] = ious
+    out['metric_acc'] = np.array([ru.calculate_iou_accuracy(list(ious), t) for t in (0.3, 0.5, 0.7)] + [float(np.mean(ious) * 100.0)])
+    path = os.path.join(ROOT, 'tests', 'golden', 'host_pipeline.npz')
+    np.savez_compressed(path, **out)
+    print('host_pipeline written', os.path.getsize(path) // 1024, 'KiB')
+
+
 def main():
     VSLNet, ru, dl = load_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == 'host_pipeline':
+        run_host_pipeline(ru, dl)
+        return
     os.makedirs(os.path.join(ROOT, 'tests', 'golden'), exist_ok=True)
     torch.set_num_threads(8)
     for name, spec in CASES.items():
         run_case(VSLNet, name, spec)
     run_host_helpers(ru, dl)
+    run_host_pipeline(ru, dl)
 
 
 if __name__ == '__main__':

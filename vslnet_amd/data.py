@@ -1,0 +1,218 @@
+"""Batch pipeline of the VSLNet path: what sits between the processed dataset and `VSLNet.forward`.
+
+Mirrors the behaviour of the reference's `util/data_util.py` (padding :117-159, feature resampling :59-73, index <-> time
+:92-114, feature loading :44-56) and `util/data_loader_t7.py` (Dataset :8-21, collate functions :24-81, loaders :84-95),
+written array-at-a-time instead of list-at-a-time: a batch is assembled straight into (optionally pinned) tensors, so the
+H2D copy of the (B, T, Dv) feature block can be asynchronous.  Pinned by tests/test_data_pipeline.py against fixtures
+generated from the reference's functions (oracle/make_golden.py: run_host_pipeline).
+
+Dataset generation itself (tokenisation with nltk, GloVe filtering: util/data_gen.py) is out of scope; `load_dataset` reads
+the pickle the reference writes (`<save_dir>/<task>_<fv>_<max_pos_len>.pkl`, data_gen.py:196-244) or builds a synthetic,
+learnable dataset of the same record format for `--task synthetic`.
+"""
+import glob
+import os
+import pickle
+
+import numpy as np
+import torch
+import torch.utils.data
+
+
+# ------------------------------------------------------------------------------------------------ index <-> time
+def index_to_time(start_index, end_index, num_units, duration):
+    """data_util.py:109-114 -- clip i covers [i, i + 1) * duration / num_units, evaluated in float32 like the reference."""
+    unit = np.float32
+    start = (np.arange(0, num_units).astype(unit) * duration / float(num_units))[start_index]
+    end = (np.arange(1, num_units + 1).astype(unit) * duration / float(num_units))[end_index]
+    return start, end
+
+
+def time_to_index(start_time, end_time, num_units, duration):
+    """data_util.py:98-106 -- the (start, end) clip pair whose interval has the highest IoU with [start_time, end_time];
+    first maximum in row-major order, like np.argmax over the reference's candidate grid.  Returns (s, e, overlaps)."""
+    s_t = (np.arange(0, num_units).astype(np.float32) / float(num_units) * duration).astype(np.float64)
+    e_t = (np.arange(1, num_units + 1).astype(np.float32) / float(num_units) * duration).astype(np.float64)
+    inter = np.maximum(0.0, np.minimum(e_t[None, :], end_time) - np.maximum(s_t[:, None], start_time))
+    union = np.maximum(1e-12, np.maximum(e_t[None, :], end_time) - np.minimum(s_t[:, None], start_time))
+    overlaps = inter / union
+    flat = int(np.argmax(overlaps))
+    return flat // num_units, flat % num_units, overlaps
+
+
+def resample_features(feature, max_num_clips):
+    """visual_feature_sampling, data_util.py:59-73: videos longer than max_num_clips are mean-pooled over
+    max_num_clips nearly equal windows (window i = rows round(i n / m) .. round((i+1) n / m), at least one row)."""
+    n = feature.shape[0]
+    if n <= max_num_clips:
+        return feature
+    edges = np.round(np.arange(0, max_num_clips + 1, 1.0) / max_num_clips * n).astype(np.int32)
+    edges = np.minimum(edges, n - 1)
+    lo, hi = edges[:-1], np.maximum(edges[1:], edges[:-1] + 1)          # an empty window takes its single start row
+    return np.stack([feature[a:b].mean(axis=0) if b - a > 1 else feature[a] for a, b in zip(lo, hi)])
+
+
+def load_video_features(root, max_position_length):
+    """data_util.py:44-56: {video id: (n_clips, Dv) float32}, resampled to at most max_position_length clips."""
+    out = {}
+    for path in sorted(glob.glob(os.path.join(root, '*.npy'))):
+        vid = os.path.basename(path).split('.')[0]
+        feat = np.load(path)
+        out[vid] = feat if max_position_length is None else resample_features(feat, max_position_length)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ padding
+def pad_words(word_ids):
+    """pad_seq (data_util.py:117-128) for a batch of word-id lists -> (B, Lq) int64, 0 = <PAD>."""
+    width = max(len(w) for w in word_ids)
+    out = np.zeros((len(word_ids), width), dtype=np.int64)
+    for i, w in enumerate(word_ids):
+        out[i, :len(w)] = w
+    return out
+
+
+def pad_chars(char_ids):
+    """pad_char_seq (data_util.py:131-143): (B, Lq, Lc) int64 with Lq = longest query, Lc = longest word of the batch."""
+    lq = max(len(q) for q in char_ids)
+    lc = max(len(w) for q in char_ids for w in q)
+    out = np.zeros((len(char_ids), lq, lc), dtype=np.int64)
+    for i, q in enumerate(char_ids):
+        for j, w in enumerate(q):
+            out[i, j, :len(w)] = w
+    return out
+
+
+def pad_videos(features, out=None):
+    """pad_video_seq (data_util.py:146-159): zero-pad to the longest video of the batch -> ((B, T, Dv) float32, lens)."""
+    lens = np.array([f.shape[0] for f in features], dtype=np.int64)
+    T, dv = int(lens.max()), features[0].shape[1]
+    if out is None:
+        out = np.zeros((len(features), T, dv), dtype=np.float32)
+    else:
+        out[...] = 0
+    for i, f in enumerate(features):
+        out[i, :f.shape[0]] = f
+    return out, lens
+
+
+def highlight_targets(s_inds, e_inds, lens, max_len, extend=0.1):
+    """train_collate_fn, data_loader_t7.py:41-52: 1 on the target span widened by round(extend * span) clips on both
+    sides (Python round = half-to-even, like np.rint), clipped to the video."""
+    s, e, lens = (np.asarray(x, dtype=np.int64) for x in (s_inds, e_inds, lens))
+    ext = np.rint(extend * (e - s + 1).astype(np.float64)).astype(np.int64)
+    lo = np.where(ext > 0, np.maximum(0, s - ext), s)
+    hi = np.where(ext > 0, np.minimum(e + ext, lens - 1), e)
+    pos = np.arange(max_len)[None, :]
+    return ((pos >= lo[:, None]) & (pos <= hi[:, None])).astype(np.int64)
+
+
+# ------------------------------------------------------------------------------------------------ dataset / collate
+class VideoQueryDataset(torch.utils.data.Dataset):
+    """data_loader_t7.py:8-21: record -> (record, (n, Dv) features, word ids, char ids, s_ind, e_ind)."""
+
+    def __init__(self, dataset, video_features):
+        self.dataset, self.video_features = dataset, video_features
+
+    def __len__(self):
+        return len(self.dataset)
+
+    def __getitem__(self, index):
+        r = self.dataset[index]
+        return r, self.video_features[r['vid']], r['w_ids'], r['c_ids'], int(r['s_ind']), int(r['e_ind'])
+
+
+def _pin(t, pin):
+    return t.pin_memory() if pin and torch.cuda.is_available() else t
+
+
+def collate_test(items, pin=False):
+    """test_collate_fn, data_loader_t7.py:64-81 -> (records, vfeats, vfeat_lens, word_ids, char_ids)."""
+    records, feats, words, chars = zip(*[(it[0], it[1], it[2], it[3]) for it in items])
+    vfeats, lens = pad_videos(feats)
+    return (records, _pin(torch.from_numpy(vfeats), pin), torch.from_numpy(lens), torch.from_numpy(pad_words(words)),
+            torch.from_numpy(pad_chars(chars)))
+
+
+def collate_train(items, pin=False, extend=0.1):
+    """train_collate_fn, data_loader_t7.py:24-61 -> (records, vfeats, vfeat_lens, word_ids, char_ids, s_labels, e_labels,
+    h_labels)."""
+    records, vfeats, lens, word_ids, char_ids = collate_test(items, pin)
+    s = np.array([it[4] for it in items], dtype=np.int64)
+    e = np.array([it[5] for it in items], dtype=np.int64)
+    h = highlight_targets(s, e, lens.numpy(), int(lens.max()), extend)
+    return records, vfeats, lens, word_ids, char_ids, torch.from_numpy(s), torch.from_numpy(e), torch.from_numpy(h)
+
+
+def get_train_loader(dataset, video_features, configs, pin=False, generator=None):
+    """data_loader_t7.py:84-88 (shuffled, 0 workers)."""
+    return torch.utils.data.DataLoader(VideoQueryDataset(dataset, video_features), batch_size=configs.batch_size, shuffle=True,
+                                       collate_fn=lambda b: collate_train(b, pin, getattr(configs, 'extend', 0.1)), generator=generator)
+
+
+def get_test_loader(dataset, video_features, configs, pin=False):
+    """data_loader_t7.py:91-95."""
+    return torch.utils.data.DataLoader(VideoQueryDataset(dataset, video_features), batch_size=configs.batch_size, shuffle=False,
+                                       collate_fn=lambda b: collate_test(b, pin))
+
+
+# ------------------------------------------------------------------------------------------------ datasets
+def dataset_path(configs):
+    """Where the reference's gen_or_load_dataset keeps its pickle (data_gen.py:201-206)."""
+    parts = [configs.task, configs.fv, str(configs.max_pos_len)] + ([configs.suffix] if getattr(configs, 'suffix', None) else [])
+    return os.path.join(configs.save_dir, '_'.join(parts) + '.pkl')
+
+
+def synthetic_dataset(configs, n_train=512, n_test=128, n_words=200, n_chars=30, seed=0):
+    """A dataset in the reference's record format (data_gen.py:178-181, 236-239) whose answer is recoverable from the
+    inputs: the first word of every query names one of 16 'events'; the clips inside the target span carry that event's
+    signature in their features.  Used by `--task synthetic`, the end-to-end tests and the convergence check."""
+    rs = np.random.RandomState(seed)
+    dv, tmax = configs.video_feature_dim, configs.max_pos_len
+    n_events = 16
+    signature = rs.randn(n_events, dv).astype(np.float32)
+    feats, sets = {}, []
+    for split, n in (('train', n_train), ('test', n_test)):
+        recs = []
+        for i in range(n):
+            vid = '%s%05d' % (split[:2], i)
+            L = int(rs.randint(max(8, tmax // 2), tmax + 1))
+            ev = int(rs.randint(n_events))
+            s = int(rs.randint(0, L - 2))
+            e = int(min(L - 1, s + rs.randint(1, max(2, L // 3))))
+            f = rs.randn(L, dv).astype(np.float32) * 0.5
+            f[s:e + 1] += signature[ev]
+            feats[vid] = f
+            dur = float(L) * 1.5
+            nw = int(rs.randint(3, 9))
+            w = [2 + ev] + [int(x) for x in rs.randint(2 + n_events, n_words, size=nw - 1)]
+            c = [[2 + (wi * 7 + k) % (n_chars - 2) for k in range(1 + wi % 6)] for wi in w]
+            st, et = index_to_time(s, e, L, dur)
+            recs.append({'sample_id': len(recs), 'vid': vid, 's_time': float(st), 'e_time': float(et), 'duration': dur,
+                         'words': ['w%d' % x for x in w], 's_ind': s, 'e_ind': e, 'v_len': L, 'w_ids': w, 'c_ids': c})
+        sets.append(recs)
+    vectors = rs.randn(n_words - 2, configs.word_dim).astype(np.float32) * 0.3
+    dataset = {'train_set': sets[0], 'val_set': None, 'test_set': sets[1], 'word_dict': None, 'char_dict': None,
+               'word_vector': vectors, 'n_train': n_train, 'n_val': 0, 'n_test': n_test, 'n_words': n_words, 'n_chars': n_chars}
+    return dataset, feats
+
+
+def load_dataset(configs):
+    """-> (dataset dict in the layout of data_gen.py:236-239, {vid: features}).  ValueError for an unknown task or a
+    missing processed dataset, like the reference (data_gen.py:229, main_t7.py:134)."""
+    if configs.task == 'synthetic':
+        return synthetic_dataset(configs, getattr(configs, 'synthetic_train', 512), getattr(configs, 'synthetic_test', 128),
+                                 seed=configs.seed)
+    if configs.task not in ('charades', 'activitynet', 'tacos'):
+        raise ValueError('Unknown task {}!!!'.format(configs.task))
+    path = dataset_path(configs)
+    if not os.path.exists(path):
+        raise ValueError('processed dataset %s not found: generate it with the reference\'s util/data_gen.py (needs nltk and the '
+                         'GloVe file; dataset generation is outside this build), or use --task synthetic' % path)
+    with open(path, 'rb') as f:
+        dataset = pickle.load(f)
+    feature_dir = os.path.join('data', 'features', configs.task, configs.fv)
+    features = load_video_features(feature_dir, configs.max_pos_len)
+    if not features:
+        raise ValueError('no *.npy video features under %s' % feature_dir)
+    return dataset, features

@@ -1,0 +1,84 @@
+"""Evaluation loop, metrics and checkpoint housekeeping of the VSLNet path.
+
+Mirrors `util/runner_utils_t7.py`: set_th_config :11-18, checkpoint helpers :21-45, convert_length_to_mask :48-52, IoU
+metrics :55-68, eval_test :71-101.  Span extraction runs in the library's scan kernel (`VSLNet.extract_index` ->
+vsl_extract_index), the metrics are host arithmetic on a few floats per sample."""
+import glob
+import os
+import random
+
+import numpy as np
+import torch
+
+from .data import index_to_time
+from .synthetic import convert_length_to_mask     # noqa: F401  (re-exported: runner_utils_t7.py:48-52)
+
+
+def set_th_config(seed):
+    """runner_utils_t7.py:11-18 (the cudnn switches have no ROCm meaning and are left alone)."""
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+
+
+def _step_of(path, suffix):
+    return int(os.path.basename(path).split('_')[1][:-(len(suffix) + 1)])
+
+
+def filter_checkpoints(model_dir, suffix='t7', max_to_keep=5):
+    """runner_utils_t7.py:21-32: keep the max_to_keep checkpoints with the highest step in `<name>_<step>.<suffix>`."""
+    paths = sorted(glob.glob(os.path.join(model_dir, '*.{}'.format(suffix))), key=lambda p: _step_of(p, suffix))
+    for p in paths[:max(0, len(paths) - max_to_keep)]:
+        os.remove(p)
+
+
+def get_last_checkpoint(model_dir, suffix='t7'):
+    """runner_utils_t7.py:35-45."""
+    paths = glob.glob(os.path.join(model_dir, '*.{}'.format(suffix)))
+    if not paths:
+        raise ValueError('no *.%s checkpoint in %s' % (suffix, model_dir))
+    return max(paths, key=lambda p: _step_of(p, suffix))
+
+
+def calculate_iou(i0, i1):
+    """runner_utils_t7.py:64-68: temporal IoU of two [start, end] intervals (hull as the union), floored at 0."""
+    hull = max(i0[1], i1[1]) - min(i0[0], i1[0])
+    inter = min(i0[1], i1[1]) - max(i0[0], i1[0])
+    return max(0.0, 1.0 * inter / hull)
+
+
+def calculate_iou_accuracy(ious, threshold):
+    """runner_utils_t7.py:55-61: percentage of samples with IoU >= threshold."""
+    ious = np.asarray(ious, dtype=np.float64)
+    return float((ious >= threshold).sum()) / float(len(ious)) * 100.0
+
+
+def summarise(ious, epoch=None, global_step=None):
+    """The metric block of eval_test (runner_utils_t7.py:90-101) -> (r1i3, r1i5, r1i7, mIoU, score string)."""
+    r1i3, r1i5, r1i7 = (calculate_iou_accuracy(ious, t) for t in (0.3, 0.5, 0.7))
+    mi = float(np.mean(ious) * 100.0)
+    text = 'Epoch {}, Step {}:\n'.format(epoch, global_step)
+    text += 'Rank@1, IoU=0.3: {:.2f}\tRank@1, IoU=0.5: {:.2f}\tRank@1, IoU=0.7: {:.2f}\tmean IoU: {:.2f}\n'.format(r1i3, r1i5, r1i7, mi)
+    return r1i3, r1i5, r1i7, mi, text
+
+
+def eval_test(model, data_loader, device, mode='test', epoch=None, global_step=None):
+    """runner_utils_t7.py:71-101.  The batch is moved with non-blocking copies (pinned staging when the loader pins), the
+    indices of the whole batch come back in one D2H copy."""
+    del mode
+    ious = []
+    with torch.no_grad():
+        for records, vfeats, vfeat_lens, word_ids, char_ids in data_loader:
+            vfeats, vfeat_lens = vfeats.to(device, non_blocking=True), vfeat_lens.to(device, non_blocking=True)
+            word_ids, char_ids = word_ids.to(device, non_blocking=True), char_ids.to(device, non_blocking=True)
+            query_mask = (word_ids != 0).float()
+            video_mask = convert_length_to_mask(vfeat_lens)
+            _, start_logits, end_logits = model(word_ids, char_ids, vfeats, video_mask, query_mask)
+            s_idx, e_idx = model.extract_index(start_logits, end_logits)
+            idx = torch.stack([s_idx, e_idx]).cpu().numpy()
+            for r, si, ei in zip(records, idx[0], idx[1]):
+                st, et = index_to_time(int(si), int(ei), r['v_len'], r['duration'])
+                ious.append(calculate_iou([st, et], [r['s_time'], r['e_time']]))
+    return summarise(ious, epoch, global_step)
