@@ -33,9 +33,9 @@ def test_unknown_task_and_missing_dataset_raise_value_error(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('optimizer', ['fused', 'torch'])
-def test_train_then_test_mode_on_synthetic_task(tmp_path, optimizer):
-    argv = ['--task', 'synthetic', '--predictor', 'transformer', '--max_pos_len', '32', '--video_feature_dim', '64', '--batch_size', '16',
+@pytest.mark.parametrize('optimizer,predictor', [('fused', 'transformer'), ('torch', 'transformer'), ('fused', 'rnn')])
+def test_train_then_test_mode_on_synthetic_task(tmp_path, optimizer, predictor):
+    argv = ['--task', 'synthetic', '--predictor', predictor, '--max_pos_len', '32', '--video_feature_dim', '64', '--batch_size', '16',
             '--epochs', '6', '--init_lr', '0.002', '--drop_rate', '0.1', '--period', '10', '--synthetic_train', '256', '--synthetic_test', '64',
             '--model_dir', str(tmp_path), '--optimizer', optimizer]
     lines = []
@@ -59,8 +59,12 @@ def test_train_then_test_mode_on_synthetic_task(tmp_path, optimizer):
     assert 'predictor.start_block.0.conv1d.weight' in sd and 'embedding_net.word_emb.glove_vec' in sd
 
 
-def test_rnn_predictor_is_reported_as_not_implemented():
+def test_rnn_predictor_has_the_reference_state_dict_entries():
     from vslnet_amd.model.VSLNet import VSLNet
     from vslnet_amd.synthetic import make_configs
-    with pytest.raises(NotImplementedError):
-        VSLNet(make_configs(predictor='rnn', word_size=20), None)
+    import numpy as np
+    sd = VSLNet(make_configs(predictor='rnn', word_size=20), np.zeros((18, 300), dtype=np.float32)).state_dict()
+    for enc in ('start_encoder', 'end_encoder'):
+        for n, shp in (('weight_ih_l0', (512, 128)), ('weight_hh_l0', (512, 128)), ('bias_ih_l0', (512,)), ('bias_hh_l0', (512,))):
+            assert tuple(sd['predictor.%s.lstm.%s' % (enc, n)].shape) == shp
+    assert not any(k.startswith('predictor.encoder.') or 'layer_norm' in k and k.startswith('predictor.') for k in sd)

@@ -36,8 +36,10 @@ def test_no_cpu_fallback_and_reference_errors():
         with pytest.raises(RuntimeError, match='no CPU fallback'):
             m(b['word_ids'], b['char_ids'], b['vfeats'], b['v_mask'], b['q_mask'])
     from model.VSLNet import VSLNet
-    with pytest.raises(NotImplementedError):      # rnn head: stated gap, fails loudly (no silent eager path)
-        VSLNet(O.make_cfg(predictor='rnn', word_size=52), np.zeros((50, 300), np.float32))
+    rnn = VSLNet(O.make_cfg(predictor='rnn', word_size=52), np.zeros((50, 300), np.float32))     # rnn head: schema of the reference
+    cfg_r, P_r, _, _ = load_golden('tiny_rnn')
+    want = [k for k in P_r if k.startswith('predictor.')]
+    assert [k for k in rnn.state_dict() if k.startswith('predictor.')] == want
     with pytest.raises(AssertionError, match='not a multiple of attention heads'):    # layers_t7.py:146
         VSLNet(O.make_cfg(num_heads=7, word_size=52), np.zeros((50, 300), np.float32))
     from model.layers import FeatureEncoder

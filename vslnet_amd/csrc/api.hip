@@ -45,10 +45,14 @@ struct ModelP {
     int w4C, w4Q, w4mlu, cqa_w, cqa_b, pool_w, cat_w, cat_b, hl_w, hl_b;
     EncP pe;
     int sln_g, sln_b, eln_g, eln_b, s0w, s0b, s1w, s1b, e0w, e0b, e1w, e1b;
+    int l_wih[2], l_whh[2], l_bih[2], l_bhh[2];     // rnn predictor: start / end DynamicRNN (layers_t7.py:302-313)
 };
-struct ModelPk { int va_f, emb_f, emb_t; EncPk fe, pe; int cqa_f, cqa_t, cat1_f, cat1_t, s0_f, s0_t, e0_f, e0_t, ccw_img; };
+struct ModelPk { int va_f, emb_f, emb_t; EncPk fe, pe; int cqa_f, cqa_t, cat1_f, cat1_t, s0_f, s0_t, e0_f, e0_t, ccw_img;
+                 int l_f[2], l_t[2], zero128; };
 
 struct EncWs { int64_t x0, y[4], u[4], mask[4], h1, q, k, v, lse, att, r, h2, out; int R, L; };
+
+struct LstmWs { int64_t gi, gates, cseq, hprev, out, dG; };   // one DynamicRNN: x W_ih^T, activated gates, c_t, h_{t-1}, h * mask, gate grads
 
 struct EncTmp { int64_t dr, dq, dk, dv, Dq, go, du, du2, gz[4], ga, gb; };   // backward temporaries of one encoder application
 
@@ -60,6 +64,7 @@ struct Plan {
     int B, T, Lq, Lc;
     int64_t pack, vf, E, argpos, qf;
     EncWs ve, qe, p1, p2;
+    LstmWs lstm[2];
     int64_t S, Srow, Scol, M, alpha, pooled, pb, cat, f1, f2, gated, hid_s, hid_e, lnf_s, lnf_e;
     // backward temporaries
     int64_t loss_scratch, gz_s, gz_e, dfeat_s, dfeat_e, dxh_s, dxh_e, g_s1, g_gated;
@@ -179,11 +184,23 @@ void build_params(vsl_handle_s* h) {
     P.cat_b = pb.add("cq_concat.conv1d.conv1d.bias", {d});
     P.hl_w = pb.add("highlight_layer.conv1d.conv1d.weight", {1, d, 1});
     P.hl_b = pb.add("highlight_layer.conv1d.conv1d.bias", {1});
-    build_encoder_params(pb, "predictor.encoder.", P.pe, c.max_pos_len);
-    P.sln_g = pb.add("predictor.start_layer_norm.weight", {d});
-    P.sln_b = pb.add("predictor.start_layer_norm.bias", {d});
-    P.eln_g = pb.add("predictor.end_layer_norm.weight", {d});
-    P.eln_b = pb.add("predictor.end_layer_norm.bias", {d});
+    if (c.predictor == 0) {          // rnn head (layers_t7.py:319-321): two nn.LSTM(d, d), gate order i,f,g,o
+        const char* nm[2] = {"predictor.start_encoder.lstm.", "predictor.end_encoder.lstm."};
+        for (int l = 0; l < 2; ++l) {
+            const std::string a = nm[l];
+            P.l_wih[l] = pb.add(a + "weight_ih_l0", {4 * d, d});
+            P.l_whh[l] = pb.add(a + "weight_hh_l0", {4 * d, d});
+            P.l_bih[l] = pb.add(a + "bias_ih_l0", {4 * d});
+            P.l_bhh[l] = pb.add(a + "bias_hh_l0", {4 * d});
+        }
+        P.sln_g = P.sln_b = P.eln_g = P.eln_b = -1;
+    } else {
+        build_encoder_params(pb, "predictor.encoder.", P.pe, c.max_pos_len);
+        P.sln_g = pb.add("predictor.start_layer_norm.weight", {d});
+        P.sln_b = pb.add("predictor.start_layer_norm.bias", {d});
+        P.eln_g = pb.add("predictor.end_layer_norm.weight", {d});
+        P.eln_b = pb.add("predictor.end_layer_norm.bias", {d});
+    }
     P.s0w = pb.add("predictor.start_block.0.conv1d.weight", {d, 2 * d, 1});
     P.s0b = pb.add("predictor.start_block.0.conv1d.bias", {d});
     P.s1w = pb.add("predictor.start_block.2.conv1d.weight", {1, d, 1});
@@ -234,7 +251,17 @@ void build_packs(vsl_handle_s* h) {
     K.emb_f = pk.fwd(P.emb_w, D, c.word_dim + 100, c.word_dim + 100);
     K.emb_t = pk.tr(P.emb_w, D, c.word_dim + 100, c.word_dim + 100);
     build_encoder_packs(pk, h, P.fe, K.fe);
-    build_encoder_packs(pk, h, P.pe, K.pe);
+    if (c.predictor == 0) {
+        for (int l = 0; l < 2; ++l) {
+            K.l_f[l] = pk.fwd(P.l_wih[l], 4 * D, D, D);      // gi = x W_ih^T  : (R,128) x (128,512)
+            K.l_t[l] = pk.tr(P.l_wih[l], 4 * D, D, D);       // dx = dG W_ih   : (R,512) x (512,128)
+        }
+        K.zero128 = (int)h->pack_floats;                    // a zero bias vector for the bias-less GEMM above
+        h->pack_floats += D;
+        h->jobs.push_back(PackJob{0, K.zero128, D, 1, 0, 4, 1, 0, 0});
+    } else {
+        build_encoder_packs(pk, h, P.pe, K.pe);
+    }
     K.cqa_f = pk.fwd(P.cqa_w, D, 4 * D, 4 * D);
     K.cqa_t = pk.tr(P.cqa_w, D, 4 * D, 4 * D);
     K.cat1_f = pk.fwd(P.cat_w, D, D, 2 * D);          // first half of the (128, 256) CQConcatenate weight
@@ -392,6 +419,21 @@ void run_forward(Ctx& c) {
                   Lq, c.s));
     LAUNCH("cqcat_fwd", launch_cqcat_fwd(c.W(p.f1), c.PK(K.cat1_f), c.W(p.pb), c.P(P.hl_w), c.P(P.hl_b), io.v_mask, c.W(p.f2), io.h_score,
                      c.W(p.gated), R, T, c.s));
+    if (cf.predictor == 0) {
+        // rnn head (:341-343): start = LSTM_s(x) * mask ; end = LSTM_e(start) * mask ; no LayerNorm in front of the span blocks
+        const float* xin = c.W(p.gated);
+        for (int l = 0; l < 2; ++l) {
+            const LstmWs& w = p.lstm[l];
+            LAUNCH("lstm_gi", launch_linear_bwd_data(xin, c.PK(K.l_f[l]), c.W(w.gi), R, 4 * D, c.s));   // (R,128) x (128,512), no bias
+            LAUNCH("lstm_fwd", launch_lstm_fwd(c.W(w.gi), c.P(P.l_whh[l]), c.P(P.l_bih[l]), c.P(P.l_bhh[l]), io.v_mask, c.W(w.gates),
+                                               c.W(w.cseq), c.W(w.hprev), c.W(w.out), B, T, c.s));
+            xin = c.W(w.out);
+        }
+        HeadArgs hs{c.W(p.lstm[0].out), nullptr, nullptr, c.PK(K.s0_f), c.P(P.s0b), c.P(P.s1w), c.P(P.s1b), c.W(p.hid_s), nullptr, io.start_logits};
+        HeadArgs he{c.W(p.lstm[1].out), nullptr, nullptr, c.PK(K.e0_f), c.P(P.e0b), c.P(P.e1w), c.P(P.e1b), c.W(p.hid_e), nullptr, io.end_logits};
+        LAUNCH("head_fwd", launch_head_fwd(hs, he, c.W(p.gated), io.v_mask, R, c.s));
+        return;
+    }
     enc_fwd(c, P.pe, K.pe, p.p1, c.W(p.gated), io.v_mask, B, 2);
     enc_fwd(c, P.pe, K.pe, p.p2, c.W(p.p1.out), io.v_mask, B, 3);
     HeadArgs hs{c.W(p.p1.out), c.P(P.sln_g), c.P(P.sln_b), c.PK(K.s0_f), c.P(P.s0b), c.P(P.s1w), c.P(P.s1b), c.W(p.hid_s),
@@ -523,34 +565,74 @@ void run_backward(Ctx& c) {
     HeadBwdArgs hs, he;
     memset(&hs, 0, sizeof hs);
     memset(&he, 0, sizeof he);
+    const bool rnn = cf.predictor == 0;
     if (!c.dry) {
-        hs = HeadBwdArgs{io->d_start_logits, c.W(p.hid_s), c.W(p.p1.out), c.P(P.sln_g), c.PK(K.s0_t), c.P(P.s1w), c.W(p.gz_s),
+        hs = HeadBwdArgs{io->d_start_logits, c.W(p.hid_s), c.W(p.p1.out), rnn ? nullptr : c.P(P.sln_g), c.PK(K.s0_t), c.P(P.s1w), c.W(p.gz_s),
                          c.W(p.dfeat_s), c.W(p.dxh_s), nullptr, nullptr, nullptr, nullptr, nullptr};
-        he = HeadBwdArgs{io->d_end_logits, c.W(p.hid_e), c.W(p.p2.out), c.P(P.eln_g), c.PK(K.e0_t), c.P(P.e1w), c.W(p.gz_e),
+        he = HeadBwdArgs{io->d_end_logits, c.W(p.hid_e), c.W(p.p2.out), rnn ? nullptr : c.P(P.eln_g), c.PK(K.e0_t), c.P(P.e1w), c.W(p.gz_e),
                          c.W(p.dfeat_e), c.W(p.dxh_e), nullptr, nullptr, nullptr, nullptr, nullptr};
     }
     hs.p_b0 = c.slab(P.s0b, D, ntiles); hs.p_w1 = c.slab(P.s1w, D, ntiles); hs.p_b1 = c.slab(P.s1b, 1, ntiles);
-    hs.p_lng = c.slab(P.sln_g, D, ntiles); hs.p_lnb = c.slab(P.sln_b, D, ntiles);
     he.p_b0 = c.slab(P.e0b, D, ntiles); he.p_w1 = c.slab(P.e1w, D, ntiles); he.p_b1 = c.slab(P.e1b, 1, ntiles);
-    he.p_lng = c.slab(P.eln_g, D, ntiles); he.p_lnb = c.slab(P.eln_b, D, ntiles);
+    if (!rnn) {
+        hs.p_lng = c.slab(P.sln_g, D, ntiles); hs.p_lnb = c.slab(P.sln_b, D, ntiles);
+        he.p_lng = c.slab(P.eln_g, D, ntiles); he.p_lnb = c.slab(P.eln_b, D, ntiles);
+    }
     LAUNCH("head_bwd", launch_head_bwd(hs, he, R, c.s));
     {
         WgradBatch wb;
         memset(&wb, 0, sizeof wb);
         for (int e = 0; e < 2; ++e) {
             WgradJob j = wjob();
-            if (!c.dry) { j.G[0] = c.W(e ? p.gz_e : p.gz_s); j.A[0] = c.W(e ? p.lnf_e : p.lnf_s); j.A[1] = c.W(p.gated); }
+            if (!c.dry) { j.G[0] = c.W(e ? p.gz_e : p.gz_s); j.A[0] = rnn ? c.W(p.lstm[e].out) : c.W(e ? p.lnf_e : p.lnf_s); j.A[1] = c.W(p.gated); }
             j.nG = 1; j.nA = 2; j.K = 2 * D; j.R = R;
             j.out = c.slab(e ? P.e0w : P.s0w, D * 2 * D, nchunk);
             wb.j[wb.n++] = j;
         }
         on_stream(sw, [&] { LAUNCH("wgrad", launch_wgrad(wb, c.s)); });
     }
+    if (rnn) {
+        // ---- rnn head: BPTT through the end LSTM, then the start LSTM (whose output also feeds the start span block)
+        for (int l = 1; l >= 0; --l) {
+            const LstmWs& w = p.lstm[l];
+            const float* d1 = c.dry ? nullptr : c.W(l ? p.dfeat_e : p.dfeat_s);
+            const float* d2 = (c.dry || l) ? nullptr : c.W(p.g_s1);
+            LAUNCH("lstm_bwd", launch_lstm_bwd(d1, d2, io->v_mask, c.W(w.gates), c.W(w.cseq), c.P(P.l_whh[l]), c.W(w.dG), B, T, c.s));
+            // dx = dG W_ih : (R,512) x (512,128), K-streamed GEMM kernel of the visual projection, no dropout, zero bias
+            LAUNCH("lstm_dx", launch_vproj_fwd(c.W(w.dG), c.PK(K.l_t[l]), c.PK(K.zero128), c.W(l ? p.g_s1 : p.g_gated), R, 4 * D, Drop{0u, 0u, 1.f}, c.s));
+            // weight gradients: dW_ih = dG^T x, dW_hh = dG^T h_prev, db_ih = db_hh = column sums of dG (two gate pairs per job)
+            WgradBatch wb;
+            memset(&wb, 0, sizeof wb);
+            for (int which = 0; which < 2; ++which) {                     // 0: W_ih (+ biases), 1: W_hh
+                for (int half = 0; half < 2; ++half) {
+                    WgradJob j = wjob();
+                    if (!c.dry) {
+                        j.G[0] = c.W(w.dG) + (2 * half) * D; j.G[1] = c.W(w.dG) + (2 * half + 1) * D;
+                        j.A[0] = which ? c.W(w.hprev) : (l ? c.W(p.lstm[0].out) : c.W(p.gated));
+                    }
+                    j.nG = 2; j.nA = 1; j.K = D; j.R = R; j.ldg = 4 * D;
+                    const int dst = (which ? P.l_whh[l] : P.l_wih[l]) + half * 2 * D * D;
+                    j.out = c.slab(dst, 2 * D * D, nchunk);
+                    if (which == 0) {
+                        for (int g = 0; g < 2; ++g) {
+                            const int64_t o = c.part_alloc((int64_t)nchunk * D);
+                            c.reg(P.l_bih[l] + (2 * half + g) * D, D, p.partial + o, nchunk, D);
+                            c.reg(P.l_bhh[l] + (2 * half + g) * D, D, p.partial + o, nchunk, D);
+                            j.out_bias[g] = c.part_ptr(o);
+                        }
+                    }
+                    wb.j[wb.n++] = j;
+                }
+            }
+            on_stream(sw, [&] { LAUNCH("wgrad", launch_wgrad(wb, c.s)); });
+        }
+    } else {
     // ---- predictor encoder, second pass (input = output of the first pass), then first pass
     enc_bwd(c, P.pe, K.pe, p.p2, c.dry ? nullptr : c.W(p.dfeat_e), nullptr, p.g_s1, c.dry ? nullptr : io->v_mask, B, 3, sw);
     // grad wrt the first pass' output = (input grad of the second pass) + (LayerNorm path of the start head)
     enc_bwd(c, P.pe, K.pe, p.p1, c.dry ? nullptr : c.W(p.g_s1), c.dry ? nullptr : c.W(p.dfeat_s), p.g_gated,
             c.dry ? nullptr : io->v_mask, B, 2, sw);
+    }
     // ---- gating + highlight + CQConcatenate
     float* p_hlw = c.slab(P.hl_w, D, ntiles);
     float* p_hlb = c.slab(P.hl_b, 1, ntiles);
@@ -678,7 +760,18 @@ int build_plan(vsl_handle_s* h, int B, int T, int Lq, int Lc, Plan** out) {
     p->pack = al(h->pack_floats);
     p->vf = al(R * D); p->E = al(Rq * EW); p->argpos = al((Rq * 100 + 3) / 4); p->qf = al(Rq * D);
     plan_encoder(al, p->ve, B, T, H); plan_encoder(al, p->qe, B, Lq, H);
-    plan_encoder(al, p->p1, B, T, H); plan_encoder(al, p->p2, B, T, H);
+    const bool rnn = cf.predictor == 0;
+    if (rnn) {
+        if (R * 4 * D >= (int64_t(1) << 31)) { delete p; return fail("B*T = %lld too large for the 32-bit offsets of the LSTM kernels", (long long)R); }
+        p->p1.R = p->p2.R = (int)R; p->p1.L = p->p2.L = T;
+        for (int l = 0; l < 2; ++l) {
+            LstmWs& w = p->lstm[l];
+            w.gi = al(R * 4 * D); w.gates = al(R * 4 * D); w.cseq = al(R * D); w.hprev = al(R * D); w.out = al(R * D); w.dG = al(R * 4 * D);
+        }
+        p->p1.out = p->lstm[0].out; p->p2.out = p->lstm[1].out;
+    } else {
+        plan_encoder(al, p->p1, B, T, H); plan_encoder(al, p->p2, B, T, H);
+    }
     p->S = al(R * Lq); p->Srow = al(R * Lq); p->Scol = al(R * Lq); p->M = al(Rq * D); p->alpha = al(Rq);
     p->pooled = al((int64_t)B * D); p->pb = al((int64_t)B * D); p->cat = al(R * 4 * D);
     p->f1 = al(R * D); p->f2 = al(R * D); p->gated = al(R * D);
@@ -686,7 +779,7 @@ int build_plan(vsl_handle_s* h, int B, int T, int Lq, int Lc, Plan** out) {
     p->loss_scratch = al(5 * (int64_t)B + 8);
     p->gz_s = al(R * D); p->gz_e = al(R * D); p->dfeat_s = al(R * D); p->dfeat_e = al(R * D);
     p->dxh_s = al(R * D); p->dxh_e = al(R * D); p->g_s1 = al(R * D); p->g_gated = al(R * D);
-    for (int ap = 0; ap < 4; ++ap) {
+    for (int ap = 0; ap < (rnn ? 2 : 4); ++ap) {
         const int64_t Ra = ap == 1 ? Rq : R;
         EncTmp& t = p->tmp[ap];
         t.dr = al(Ra * D); t.dq = al(Ra * D); t.dk = al(Ra * D); t.dv = al(Ra * D); t.Dq = al((int64_t)B * H * (ap == 1 ? Lq : T));
@@ -785,7 +878,7 @@ int vsl_create(const vsl_config* cfg, vsl_handle* out) {
     if (cfg->num_heads <= 0 || cfg->dim % cfg->num_heads != 0)
         return fail("The channels (%d) is not a multiple of attention heads (%d)", cfg->dim, cfg->num_heads);   // layers_t7.py:146
     if (cfg->dim / cfg->num_heads != HD) return fail("num_heads=%d: the attention kernels are specialised for head size 16 (8 heads)", cfg->num_heads);
-    if (cfg->predictor != 1) return fail("predictor='rnn' (DynamicRNN, layers_t7.py:302-313) is not implemented in HIP yet; use 'transformer'");
+    if (cfg->predictor != 0 && cfg->predictor != 1) return fail("predictor must be 0 ('rnn') or 1 ('transformer'), got %d", cfg->predictor);
     if (cfg->video_feature_dim <= 0 || cfg->video_feature_dim % 8) return fail("video_feature_dim=%d must be a positive multiple of 8", cfg->video_feature_dim);
     if ((cfg->word_dim + 100) % 8) return fail("word_dim + 100 = %d must be a multiple of 8", cfg->word_dim + 100);
     if (cfg->char_dim <= 0 || cfg->char_dim > 64) return fail("char_dim=%d must be in [1, 64]", cfg->char_dim);

@@ -277,12 +277,13 @@ __global__ __launch_bounds__(512) void k_wgrad(WgradBatch wb) {
     const uint32_t dseed = j.dp.seed, dthr = j.dp.thresh;
     const float dscale = j.dp.scale;
     const float* Gc = G + c;
+    const int ldg = j.ldg ? j.ldg : D;
     const float* Ac = Ablk ? Ablk + c : j.Afull + (kin ? kt * 128 + c : 0);
     const int astride = Ablk ? D : K;
     const uint32_t dbase = (uint32_t)(kt * 128 + c);
     auto load_g = [&](int rs, int q) -> float4 {
         const int r = min(rs + rr0 + 16 * q, rend - 1);
-        return *reinterpret_cast<const float4*>(Gc + (size_t)r * D);
+        return *reinterpret_cast<const float4*>(Gc + (size_t)r * ldg);
     };
     auto load_a = [&](int rs, int q) -> float4 {
         const int r = min(rs + rr0 + 16 * q, rend - 1);
@@ -1900,6 +1901,81 @@ __global__ __launch_bounds__(256) void k_reduce(const float* __restrict__ ws, fl
 void launch_reduce(const float* partial, float* grads, const ReduceSeg* segs_dev, const int* blk2seg_dev, int nblocks,
                    hipStream_t s) {
     hipLaunchKernelGGL(k_reduce, dim3(nblocks), dim3(256), 0, s, partial, grads, segs_dev, blk2seg_dev);
+}
+
+// =========================================================================================================
+// a15 backward: BPTT through the LSTM of k_lstm_fwd.  Same ownership (wave = 8 hidden units, lane pair = 2 samples each);
+// per step: gate gradients of the own cells -> LDS (16 x 512) and global (the G operand of dW_ih / dW_hh / db and the A
+// operand of dX = dG W_ih, all plain GEMMs afterwards) -> dh_{t-1} = dG_t W_hh on the matrix cores with W_hh in registers
+// (wave = 16 output columns x one half of the 512 gate rows; the two halves are added when read).  Two barriers per step.
+// =========================================================================================================
+constexpr int LS_M = 16;
+constexpr int LS_HP = D + 4;
+constexpr int LS_GP = 4 * D + 4;
+__global__ __launch_bounds__(1024) void k_lstm_bwd(const float* __restrict__ dout, const float* __restrict__ dout2,
+                                                   const float* __restrict__ mask, const float* __restrict__ gates,
+                                                   const float* __restrict__ cseq, const float* __restrict__ Whh,
+                                                   float* __restrict__ dG, int B, int T) {
+    __shared__ __attribute__((aligned(16))) float dGs[LS_M * LS_GP];
+    __shared__ __attribute__((aligned(16))) float Ph[2][LS_M * LS_HP];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int j = lane & 15, g4 = lane >> 4, hi = j >> 3;
+    const int u = 8 * w + (j & 7);
+    const int b0 = blockIdx.x * LS_M;
+    const int s0 = 4 * g4 + 2 * hi;
+    const int n0 = 16 * (w & 7), kh = w >> 3;            // matmul role: output columns n0 .. n0+15, gate rows 256 kh .. +255
+    float4 wr[16];                                       // B fragments: Bm[k = gate row][col] = W_hh[row][n0 + j]
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const float* p = Whh + (size_t)(256 * kh + 16 * q + 4 * g4) * D + n0 + j;
+        wr[q] = make_float4(p[0], p[D], p[2 * D], p[3 * D]);
+    }
+    float dcn[2] = {0.f, 0.f};
+    for (int t = T - 1; t >= 0; --t) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int b = min(b0 + s0 + e, B - 1);
+            const bool ok = b0 + s0 + e < B;
+            const size_t base = (size_t)b * T + t;
+            float dh = dout[base * D + u];
+            if (dout2) dh += dout2[base * D + u];
+            dh *= mask[base];
+            if (t < T - 1) dh += Ph[0][(s0 + e) * LS_HP + u] + Ph[1][(s0 + e) * LS_HP + u];
+            const float* gp = gates + base * (4 * D) + u;
+            const float ig = gp[0], fg = gp[D], gg = gp[2 * D], og = gp[3 * D];
+            const float ct = cseq[base * D + u], cp = t > 0 ? cseq[(base - 1) * D + u] : 0.f;
+            const float tc = tanhf(ct);
+            const float dc = dh * og * (1.f - tc * tc) + dcn[e];
+            float dv[4] = {dc * gg * ig * (1.f - ig), dc * cp * fg * (1.f - fg), dc * ig * (1.f - gg * gg), dh * tc * og * (1.f - og)};
+            dcn[e] = dc * fg;
+            if (!ok) { dv[0] = dv[1] = dv[2] = dv[3] = 0.f; }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) dGs[(s0 + e) * LS_GP + g * D + u] = dv[g];
+            if (ok) {
+                float* op = dG + base * (4 * D) + u;
+                op[0] = dv[0]; op[D] = dv[1]; op[2 * D] = dv[2]; op[3 * D] = dv[3];
+            }
+        }
+        if (t == 0) break;                               // dh_{-1} is not needed
+        __syncthreads();
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float* arow = dGs + j * LS_GP + 256 * kh + 4 * g4;          // A operand: sample = lane & 15
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float4 av = *reinterpret_cast<const float4*>(arow + 16 * q);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, wr[q].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, wr[q].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, wr[q].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, wr[q].w, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ph[kh][(4 * g4 + r) * LS_HP + n0 + j] = acc[r];
+        __syncthreads();
+    }
+}
+void launch_lstm_bwd(const float* dout, const float* dout2, const float* mask, const float* gates, const float* cseq,
+                     const float* Whh, float* dG, int B, int T, hipStream_t s) {
+    hipLaunchKernelGGL(k_lstm_bwd, dim3((B + LS_M - 1) / LS_M), dim3(1024), 0, s, dout, dout2, mask, gates, cseq, Whh, dG, B, T);
 }
 
 // =========================================================================================================

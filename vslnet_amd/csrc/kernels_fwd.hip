@@ -1089,4 +1089,112 @@ void launch_head_fwd(const HeadArgs& a0, const HeadArgs& a1, const float* x, con
     }
 }
 
+// =========================================================================================================
+// a15  DynamicRNN (layers_t7.py:302-313): single-layer nn.LSTM(128, 128), gate order i,f,g,o, run over ALL padded steps;
+// the returned sequence is h * mask.  gi = x W_ih^T is computed beforehand as one (B T, 128) x (128, 512) GEMM; this kernel
+// is the sequential part.  One 16-wave workgroup per 16 samples:
+//   * W_hh (256 KB) lives in REGISTERS for the whole sequence: wave w owns hidden units 8w .. 8w+7 and holds the 32
+//     gate rows of those units as MFMA B fragments (two 16-column tiles: [i | f] and [g | o]);
+//   * h_{t-1} (16 x 128) is the A operand, read from a double-buffered LDS tile -> one barrier per step;
+//   * a lane's accumulators hold one gate column for 4 samples; the lane pair (l, l ^ 8) swaps two samples' worth so that
+//     every lane finishes 2 (unit, sample) cells with all four gates: the cell state stays in registers;
+//   * the gi values are requested two steps ahead (they do not depend on the recurrence).
+// Saved for the backward: activated gates (B,T,512), c_t, h_{t-1} (the A operand of dW_hh), and the masked output.
+// =========================================================================================================
+constexpr int LS_M = 16;
+constexpr int LS_HP = D + 4;
+__device__ __forceinline__ float sigmoid_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
+__global__ __launch_bounds__(1024) void k_lstm_fwd(const float* __restrict__ gi, const float* __restrict__ Whh,
+                                                   const float* __restrict__ bih, const float* __restrict__ bhh,
+                                                   const float* __restrict__ mask, float* __restrict__ gates,
+                                                   float* __restrict__ cseq, float* __restrict__ hprev, float* __restrict__ out,
+                                                   int B, int T) {
+    __shared__ __attribute__((aligned(16))) float hs[2][LS_M * LS_HP];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int j = lane & 15, g4 = lane >> 4, hi = j >> 3;
+    const int u = 8 * w + (j & 7);                       // hidden unit of this lane's gate columns
+    const int b0 = blockIdx.x * LS_M;
+    float4 wa[8], wb[8];                                 // B fragments: tile A column = (hi ? f : i), tile B = (hi ? o : g)
+    {
+        const float* ra = Whh + (size_t)((hi ? 1 : 0) * D + u) * D + 4 * g4;
+        const float* rb = Whh + (size_t)((hi ? 3 : 2) * D + u) * D + 4 * g4;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { wa[q] = *reinterpret_cast<const float4*>(ra + 16 * q); wb[q] = *reinterpret_cast<const float4*>(rb + 16 * q); }
+    }
+    float bsum[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bsum[g] = bih[g * D + u] + bhh[g * D + u];
+    const int s0 = 4 * g4 + 2 * hi;                      // this lane finishes samples s0, s0 + 1 of the group
+    float cst[2] = {0.f, 0.f};
+    // 32-bit element offsets (the host checks B T 512 < 2^31) keep the address state of the loop in a handful of registers:
+    // with W_hh resident the kernel sits at the 128-register limit of a 1024-thread workgroup
+    int row[2];
+    bool okb[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) { okb[e] = b0 + s0 + e < B; row[e] = min(b0 + s0 + e, B - 1) * T; }
+    float Gc[2][4];                                      // gi of the next step: requested right after the current one is used
+    auto gi_load = [&](int t) {
+        const int tt = min(t, T - 1);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float* p = gi + (unsigned)((row[e] + tt) * (4 * D) + u);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) Gc[e][g] = p[g * D];
+        }
+    };
+    for (int i = tid; i < LS_M * LS_HP; i += 1024) hs[0][i] = 0.f;       // h_{-1} = 0
+    gi_load(0);
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        const int cur = t & 1;
+        f32x4 aa = {0.f, 0.f, 0.f, 0.f}, ab = {0.f, 0.f, 0.f, 0.f};
+        if (t > 0) {
+            const float* hrow = &hs[cur][j * LS_HP + 4 * g4];            // A operand: sample = lane & 15
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float4 hv = *reinterpret_cast<const float4*>(hrow + 16 * q);
+                aa = __builtin_amdgcn_mfma_f32_16x16x4f32(hv.x, wa[q].x, aa, 0, 0, 0);
+                ab = __builtin_amdgcn_mfma_f32_16x16x4f32(hv.x, wb[q].x, ab, 0, 0, 0);
+                aa = __builtin_amdgcn_mfma_f32_16x16x4f32(hv.y, wa[q].y, aa, 0, 0, 0);
+                ab = __builtin_amdgcn_mfma_f32_16x16x4f32(hv.y, wb[q].y, ab, 0, 0, 0);
+                aa = __builtin_amdgcn_mfma_f32_16x16x4f32(hv.z, wa[q].z, aa, 0, 0, 0);
+                ab = __builtin_amdgcn_mfma_f32_16x16x4f32(hv.z, wb[q].z, ab, 0, 0, 0);
+                aa = __builtin_amdgcn_mfma_f32_16x16x4f32(hv.w, wa[q].w, aa, 0, 0, 0);
+                ab = __builtin_amdgcn_mfma_f32_16x16x4f32(hv.w, wb[q].w, ab, 0, 0, 0);
+            }
+        }
+        // aa[r] / ab[r]: this lane's two gate columns for samples 4 g4 + r.  Keep r = 2 hi, 2 hi + 1; trade the other two.
+        const float ka0 = hi ? aa[2] : aa[0], ka1 = hi ? aa[3] : aa[1], kb0 = hi ? ab[2] : ab[0], kb1 = hi ? ab[3] : ab[1];
+        const float ra0 = __shfl_xor(hi ? aa[0] : aa[2], 8), ra1 = __shfl_xor(hi ? aa[1] : aa[3], 8);
+        const float rb0 = __shfl_xor(hi ? ab[0] : ab[2], 8), rb1 = __shfl_xor(hi ? ab[1] : ab[3], 8);
+        const float zi[2] = {hi ? ra0 : ka0, hi ? ra1 : ka1}, zf[2] = {hi ? ka0 : ra0, hi ? ka1 : ra1};
+        const float zg[2] = {hi ? rb0 : kb0, hi ? rb1 : kb1}, zo[2] = {hi ? kb0 : rb0, hi ? kb1 : rb1};
+        float hn[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float ig = sigmoid_acc(zi[e] + Gc[e][0] + bsum[0]), fg = sigmoid_acc(zf[e] + Gc[e][1] + bsum[1]);
+            const float gg = tanhf(zg[e] + Gc[e][2] + bsum[2]), og = sigmoid_acc(zo[e] + Gc[e][3] + bsum[3]);
+            const float cn = fg * cst[e] + ig * gg;
+            hn[e] = og * tanhf(cn);
+            cst[e] = cn;
+            hs[cur ^ 1][(s0 + e) * LS_HP + u] = hn[e];
+            if (okb[e]) {
+                const unsigned base = (unsigned)(row[e] + t);
+                float* gp = gates + base * (4 * D) + u;
+                gp[0] = ig; gp[D] = fg; gp[2 * D] = gg; gp[3 * D] = og;
+                cseq[base * D + u] = cn;
+                out[base * D + u] = hn[e] * mask[base];
+                if (t == 0) hprev[base * D + u] = 0.f;
+                if (t + 1 < T) hprev[(base + 1) * D + u] = hn[e];
+            }
+        }
+        gi_load(t + 1);
+        __syncthreads();
+    }
+}
+void launch_lstm_fwd(const float* gi, const float* Whh, const float* bih, const float* bhh, const float* mask, float* gates,
+                     float* cseq, float* hprev, float* out, int B, int T, hipStream_t s) {
+    hipLaunchKernelGGL(k_lstm_fwd, dim3((B + LS_M - 1) / LS_M), dim3(1024), 0, s, gi, Whh, bih, bhh, mask, gates, cseq, hprev, out, B, T);
+}
+
 }  // namespace vsl

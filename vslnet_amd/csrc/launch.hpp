@@ -58,6 +58,7 @@ struct WgradJob {
     const float* Afull;   // or one (R, K) matrix with leading dimension K (nA == 0)
     int nG, nA, K;
     int R;
+    int ldg;              // row stride of the G blocks in floats (0 = 128): the LSTM gate gradients are 512 wide
     int drop_on_A;        // apply dropout to Afull on load (VisualProjection input)
     Drop dp;
     float* out;           // partial slabs [nchunk][N][K]
@@ -146,6 +147,11 @@ void launch_extract_index(const float* sl, const float* el, int64_t* si, int64_t
 
 // ---------------------------------------------------------------- backward
 void launch_head_bwd(const HeadBwdArgs& a0, const HeadBwdArgs& a1, int R, hipStream_t s);
+// a15 DynamicRNN (layers_t7.py:302-313): recurrent part of nn.LSTM(128, 128); the input projection x W_ih^T is a plain GEMM
+void launch_lstm_fwd(const float* gi, const float* Whh, const float* bih, const float* bhh, const float* mask, float* gates,
+                     float* cseq, float* hprev, float* out, int B, int T, hipStream_t s);
+void launch_lstm_bwd(const float* dout, const float* dout2, const float* mask, const float* gates, const float* cseq,
+                     const float* Whh, float* dG, int B, int T, hipStream_t s);
 void launch_wgrad(const WgradBatch& wb, hipStream_t s);
 void launch_conv_bwd_gemm(const float* dy, const uint32_t* relu_mask, const float* WTpack, float* gz, float* du, int R,
                           Drop dp, hipStream_t s);

@@ -157,17 +157,29 @@ class HighLightLayer(_Fused):
         self.conv1d = Conv1D(dim, 1)
 
 
+class DynamicRNN(_Fused):
+    """layers_t7.py:302-313: parameter container of the single-layer nn.LSTM(dim, dim) (gate order i,f,g,o, PyTorch's
+    default uniform(-1/sqrt(dim), 1/sqrt(dim)) init -- VSLNet.init_parameters does not touch it).  The recurrence itself
+    runs in k_lstm_fwd / k_lstm_bwd."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.lstm = nn.LSTM(input_size=dim, hidden_size=dim, num_layers=1, bias=True, batch_first=True, bidirectional=False)
+
+
 class ConditionedPredictor(_Fused):
-    """layers_t7.py:316-369 (transformer head; the rnn head is not implemented in HIP yet)."""
+    """layers_t7.py:316-369: rnn head (two DynamicRNN, the end one fed by the start one) or transformer head (one shared
+    FeatureEncoder applied twice + LayerNorms), then the two span blocks."""
 
     def __init__(self, dim, num_heads, max_pos_len, drop_rate=0.0, predictor='rnn'):
         super().__init__()
         self.predictor = predictor
         if predictor == 'rnn':
-            raise NotImplementedError("predictor='rnn' (DynamicRNN, layers_t7.py:302-313) is not implemented in HIP yet; "
-                                      "use --predictor transformer")
-        self.encoder = FeatureEncoder(dim, num_heads, max_pos_len, drop_rate=drop_rate)
-        self.start_layer_norm = nn.LayerNorm(dim, eps=1e-6)
-        self.end_layer_norm = nn.LayerNorm(dim, eps=1e-6)
+            self.start_encoder = DynamicRNN(dim)
+            self.end_encoder = DynamicRNN(dim)
+        else:
+            self.encoder = FeatureEncoder(dim, num_heads, max_pos_len, drop_rate=drop_rate)
+            self.start_layer_norm = nn.LayerNorm(dim, eps=1e-6)
+            self.end_layer_norm = nn.LayerNorm(dim, eps=1e-6)
         self.start_block = nn.Sequential(Conv1D(2 * dim, dim), nn.ReLU(), Conv1D(dim, 1))
         self.end_block = nn.Sequential(Conv1D(2 * dim, dim), nn.ReLU(), Conv1D(dim, 1))
