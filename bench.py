@@ -25,14 +25,15 @@ PEAK_MFMA_F32 = 157.3e12       # MI355X_MICROARCH.md: fp32-in MFMA = fp32 vector
 PEAK_HBM = 8.0e12              # HBM3E spec
 
 
-def alg_flops_per_pair(T, Dv, Lq, Lc, d=128, NL=4, k=7):
+def alg_flops_per_pair(T, Dv, Lq, Lc, d=128, NL=4, k=7, predictor='transformer'):
     """matmul/conv FLOPs (2*MAC) per (video, query) pair, forward and forward+backward."""
     def enc(L):
         return NL * (2 * L * d * k + 2 * L * d * d) + 8 * L * d * d + 4 * L * L * d
     charcnn = sum(2 * Lq * (Lc - kk + 1) * 50 * kk * c for kk, c in zip((1, 2, 3, 4), (10, 20, 30, 40)))
     fwd = (2 * T * Dv * d + charcnn + 2 * Lq * 400 * d + enc(T) + enc(Lq)
            + (2 * T * d + 2 * Lq * d + 4 * T * Lq * d + 2 * T * T * Lq + 2 * T * T * d + 8 * T * d * d)
-           + (4 * Lq * d + 4 * T * d * d) + 2 * T * d + 2 * (4 * T * d * d + 2 * T * d) + 2 * enc(T))
+           + (4 * Lq * d + 4 * T * d * d) + 2 * T * d + 2 * (4 * T * d * d + 2 * T * d)
+           + (2 * enc(T) if predictor == 'transformer' else 2 * 16 * T * d * d))
     return fwd, 3 * fwd - 2 * T * Dv * d          # bwd = 2*fwd - (no dX for the input features)
 
 
@@ -108,6 +109,7 @@ def main():
     ap.add_argument('--lq', type=int, default=20)
     ap.add_argument('--lc', type=int, default=10)
     ap.add_argument('--drop-rate', type=float, default=0.2)
+    ap.add_argument('--predictor', default='transformer', help="'transformer' (headline, configs[1]) or 'rnn' (configs[0] shape)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-optimizer', action='store_true', help='time forward + losses + backward only (A/B runs)')
     ap.add_argument('--profile-all', action='store_true', help='also print the per-kernel HIP-event table to stderr')
@@ -128,7 +130,7 @@ def main():
     from vslnet_amd.model.VSLNet import VSLNet
     from vslnet_amd.synthetic import make_configs, synthetic_batch
     B, T, Dv, Lq, Lc = args.batch, args.T, args.dv, args.lq, args.lc
-    configs = make_configs(video_feature_dim=Dv, max_pos_len=max(T, Lq), drop_rate=args.drop_rate)
+    configs = make_configs(video_feature_dim=Dv, max_pos_len=max(T, Lq), drop_rate=args.drop_rate, predictor=args.predictor)
     torch.manual_seed(configs.seed)                         # identical random-init weights on every rank
     glove = torch.randn(configs.word_size - 2, configs.word_dim).numpy()
     model = VSLNet(configs, glove).cuda().train()
@@ -196,7 +198,7 @@ def main():
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         value = B * world * args.steps / dt
-        fwd, fb = alg_flops_per_pair(T, Dv, Lq, Lc)
+        fwd, fb = alg_flops_per_pair(T, Dv, Lq, Lc, predictor=args.predictor)
         work = kernel_work(dominant, B, T, Dv, Lq)
         k_s = kt[0] * 1e-3 / args.steps                      # seconds of this kernel group per step
         roof = {'kernel': dominant, 'launches_per_step': kt[1] // args.steps, 'ms_per_step': round(k_s * 1e3, 4)}
@@ -222,11 +224,11 @@ def main():
                'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                'ms_per_step': round(ms_step, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
                'dtype': 'f32', 'data': 'synthetic',
-               'config': {'workload': 'configs[1]: Charades-STA I3D shape, --predictor transformer, B=%d/GPU T=%d Dv=%d Lq=%d '
-                                      'Lc=%d drop_rate=%.1f train mode; step = forward + CE(start)+CE(end)+5*highlight + '
-                                      'backward%s%s' % (B, T, Dv, Lq, Lc, args.drop_rate,
-                                                        ' + RCCL all-reduce of the flat grad bucket' if world > 1 else '',
-                                                        '' if args.no_optimizer else ' + clip_grad_norm(1.0) + AdamW update (fused HIP)'),
+               'config': {'workload': 'configs[%d]: Charades-STA I3D shape, --predictor %s, B=%d/GPU T=%d Dv=%d Lq=%d Lc=%d drop_rate=%.1f '
+                                      'train mode; step = forward + CE(start)+CE(end)+5*highlight + backward%s%s'
+                                      % (1 if args.predictor == 'transformer' else 0, args.predictor, B, T, Dv, Lq, Lc, args.drop_rate,
+                                         ' + RCCL all-reduce of the flat grad bucket' if world > 1 else '',
+                                         '' if args.no_optimizer else ' + clip_grad_norm(1.0) + AdamW update (fused HIP)'),
                           'global_batch': B * world, 'parallelism': 'dp%d' % world,
                           'alg_mflop_per_pair': round(fb / 1e6, 1), 'loss': round(loss_val, 5)},
                'roofline': roof}

@@ -33,7 +33,7 @@ typedef struct {
     int32_t char_dim;          /* configs.char_dim = 50    (<= 64)                                        */
     int32_t word_size;         /* configs.word_size  = rows of [pad; unk; glove]                          */
     int32_t char_size;         /* configs.char_size  = rows of the character table                        */
-    int32_t predictor;         /* 0 = 'rnn' (not implemented in HIP yet -> error), 1 = 'transformer'      */
+    int32_t predictor;         /* 0 = 'rnn' (DynamicRNN, layers_t7.py:302-313), 1 = 'transformer'         */
     float drop_rate;           /* configs.drop_rate                                                        */
 } vsl_config;
 

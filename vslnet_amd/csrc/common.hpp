@@ -54,6 +54,13 @@ __device__ __forceinline__ float drop_mul(const Drop& d, uint32_t idx) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// gate non-linearities of the LSTM kernels on the hardware exp / rcp instructions (about 1 ulp each).  fp32 MFMAs and the
+// vector ALU share the SIMD, so the ~30-instruction libm expf / tanhf cost as much per step as the recurrent matmul itself.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoid_fast(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanh_fast(float x) { return 2.0f * sigmoid_fast(2.0f * x) - 1.0f; }
+
+// ---------------------------------------------------------------------------------------------------------
 // wave reductions (64 lanes)
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

@@ -1944,7 +1944,7 @@ __global__ __launch_bounds__(1024) void k_lstm_bwd(const float* __restrict__ dou
             const float* gp = gates + base * (4 * D) + u;
             const float ig = gp[0], fg = gp[D], gg = gp[2 * D], og = gp[3 * D];
             const float ct = cseq[base * D + u], cp = t > 0 ? cseq[(base - 1) * D + u] : 0.f;
-            const float tc = tanhf(ct);
+            const float tc = tanh_fast(ct);
             const float dc = dh * og * (1.f - tc * tc) + dcn[e];
             float dv[4] = {dc * gg * ig * (1.f - ig), dc * cp * fg * (1.f - fg), dc * ig * (1.f - gg * gg), dh * tc * og * (1.f - og)};
             dcn[e] = dc * fg;

@@ -1103,7 +1103,6 @@ void launch_head_fwd(const HeadArgs& a0, const HeadArgs& a1, const float* x, con
 // =========================================================================================================
 constexpr int LS_M = 16;
 constexpr int LS_HP = D + 4;
-__device__ __forceinline__ float sigmoid_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
 __global__ __launch_bounds__(1024) void k_lstm_fwd(const float* __restrict__ gi, const float* __restrict__ Whh,
                                                    const float* __restrict__ bih, const float* __restrict__ bhh,
                                                    const float* __restrict__ mask, float* __restrict__ gates,
@@ -1132,7 +1131,7 @@ __global__ __launch_bounds__(1024) void k_lstm_fwd(const float* __restrict__ gi,
     bool okb[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) { okb[e] = b0 + s0 + e < B; row[e] = min(b0 + s0 + e, B - 1) * T; }
-    float Gc[2][4];                                      // gi of the next step: requested right after the current one is used
+    float Gc[2][4], Mk[2];                               // gi and mask of the next step: requested right after the current one is used
     auto gi_load = [&](int t) {
         const int tt = min(t, T - 1);
 #pragma unroll
@@ -1140,6 +1139,7 @@ __global__ __launch_bounds__(1024) void k_lstm_fwd(const float* __restrict__ gi,
             const float* p = gi + (unsigned)((row[e] + tt) * (4 * D) + u);
 #pragma unroll
             for (int g = 0; g < 4; ++g) Gc[e][g] = p[g * D];
+            Mk[e] = mask[row[e] + tt];
         }
     };
     for (int i = tid; i < LS_M * LS_HP; i += 1024) hs[0][i] = 0.f;       // h_{-1} = 0
@@ -1147,6 +1147,7 @@ __global__ __launch_bounds__(1024) void k_lstm_fwd(const float* __restrict__ gi,
     __syncthreads();
     for (int t = 0; t < T; ++t) {
         const int cur = t & 1;
+        if (t == 6) FSTAMP(0);
         f32x4 aa = {0.f, 0.f, 0.f, 0.f}, ab = {0.f, 0.f, 0.f, 0.f};
         if (t > 0) {
             const float* hrow = &hs[cur][j * LS_HP + 4 * g4];            // A operand: sample = lane & 15
@@ -1163,19 +1164,21 @@ __global__ __launch_bounds__(1024) void k_lstm_fwd(const float* __restrict__ gi,
                 ab = __builtin_amdgcn_mfma_f32_16x16x4f32(hv.w, wb[q].w, ab, 0, 0, 0);
             }
         }
+        if (t == 6) FSTAMP(1);
         // aa[r] / ab[r]: this lane's two gate columns for samples 4 g4 + r.  Keep r = 2 hi, 2 hi + 1; trade the other two.
         const float ka0 = hi ? aa[2] : aa[0], ka1 = hi ? aa[3] : aa[1], kb0 = hi ? ab[2] : ab[0], kb1 = hi ? ab[3] : ab[1];
         const float ra0 = __shfl_xor(hi ? aa[0] : aa[2], 8), ra1 = __shfl_xor(hi ? aa[1] : aa[3], 8);
         const float rb0 = __shfl_xor(hi ? ab[0] : ab[2], 8), rb1 = __shfl_xor(hi ? ab[1] : ab[3], 8);
         const float zi[2] = {hi ? ra0 : ka0, hi ? ra1 : ka1}, zf[2] = {hi ? ka0 : ra0, hi ? ka1 : ra1};
         const float zg[2] = {hi ? rb0 : kb0, hi ? rb1 : kb1}, zo[2] = {hi ? kb0 : rb0, hi ? kb1 : rb1};
+        if (t == 6) FSTAMP(2);
         float hn[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            const float ig = sigmoid_acc(zi[e] + Gc[e][0] + bsum[0]), fg = sigmoid_acc(zf[e] + Gc[e][1] + bsum[1]);
-            const float gg = tanhf(zg[e] + Gc[e][2] + bsum[2]), og = sigmoid_acc(zo[e] + Gc[e][3] + bsum[3]);
+            const float ig = sigmoid_fast(zi[e] + Gc[e][0] + bsum[0]), fg = sigmoid_fast(zf[e] + Gc[e][1] + bsum[1]);
+            const float gg = tanh_fast(zg[e] + Gc[e][2] + bsum[2]), og = sigmoid_fast(zo[e] + Gc[e][3] + bsum[3]);
             const float cn = fg * cst[e] + ig * gg;
-            hn[e] = og * tanhf(cn);
+            hn[e] = og * tanh_fast(cn);
             cst[e] = cn;
             hs[cur ^ 1][(s0 + e) * LS_HP + u] = hn[e];
             if (okb[e]) {
@@ -1183,18 +1186,23 @@ __global__ __launch_bounds__(1024) void k_lstm_fwd(const float* __restrict__ gi,
                 float* gp = gates + base * (4 * D) + u;
                 gp[0] = ig; gp[D] = fg; gp[2 * D] = gg; gp[3 * D] = og;
                 cseq[base * D + u] = cn;
-                out[base * D + u] = hn[e] * mask[base];
+                out[base * D + u] = hn[e] * Mk[e];
                 if (t == 0) hprev[base * D + u] = 0.f;
                 if (t + 1 < T) hprev[(base + 1) * D + u] = hn[e];
             }
         }
+        if (t == 6) FSTAMP(3);
         gi_load(t + 1);
+        if (t == 6) FSTAMP(4);
         __syncthreads();
+        if (t == 6) FSTAMP(5);
     }
 }
 void launch_lstm_fwd(const float* gi, const float* Whh, const float* bih, const float* bhh, const float* mask, float* gates,
                      float* cseq, float* hprev, float* out, int B, int T, hipStream_t s) {
     hipLaunchKernelGGL(k_lstm_fwd, dim3((B + LS_M - 1) / LS_M), dim3(1024), 0, s, gi, Whh, bih, bhh, mask, gates, cseq, hprev, out, B, T);
+    static int left = 2;
+    if (fdbg_on() && T > 8) fdbg_report("lstm_fwd step 6: LDS+MFMA | shuffles | gates+stores | gi issue | barrier", 6, s, left);
 }
 
 }  // namespace vsl
