@@ -495,14 +495,43 @@ __global__ __launch_bounds__(256) void k_conv_bwd_dwln(const float* __restrict__
     float* red = Xc + TILE_M * LDP;          // [2][896]
     const int tid = threadIdx.x;
     const int r0 = blockIdx.x * TILE_M;
-    load_tile128(DUs, du, r0 - HALO, NH, R);
-    load_tile128(Vs, xin, r0 - HALO, NH, R);
-    load_tile128(Xc, xin, r0, TILE_M, R);
-    BFrag<1, 16> bf;                         // weights of the fused data-gradient GEMM of the layer below: requested
-    if (nxt.relu_mask) bfrag_load(bf, nxt.WTpack, D, 32 * (tid >> 6), 0, 0, D / 8);   // now, consumed after this layer's work
+    STAMP(0);
+    BFrag<1, 16> bf;                         // weights of the fused data-gradient GEMM of the layer below
+    ConvMaskWords mw;
+    {   // ONE batch of loads for both source tiles (du and x', rows r0-3 .. r0+34); the centre rows of x' are written to Xc
+        // from the same registers.  Three separate tile loads cost three memory latencies (7.6 k cycles).
+        float4 dv[5], xv[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const int e = tid + q * 256;
+            const int r = r0 - HALO + (e >> 5), c = (e & 31) * 4;
+            dv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            xv[q] = dv[q];
+            if (e < NH * 32 && r >= 0 && r < R) {
+                dv[q] = *reinterpret_cast<const float4*>(du + (size_t)r * D + c);
+                xv[q] = *reinterpret_cast<const float4*>(xin + (size_t)r * D + c);
+            }
+        }
+        if (nxt.relu_mask) {                 // requested behind the tiles (in-order return), consumed after this layer's work
+            conv_mask_prefetch(mw, nxt, r0, R);
+            bfrag_load(bf, nxt.WTpack, D, 32 * (tid >> 6), 0, 0, D / 8);
+        }
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const int e = tid + q * 256;
+            const int rr = e >> 5, c = (e & 31) * 4;
+            if (e < NH * 32) {
+                *reinterpret_cast<float4*>(&DUs[rr * LDP + c]) = dv[q];
+                *reinterpret_cast<float4*>(&Vs[rr * LDP + c]) = xv[q];
+                if (rr >= HALO && rr < HALO + TILE_M) *reinterpret_cast<float4*>(&Xc[(rr - HALO) * LDP + c]) = xv[q];
+            }
+        }
+    }
     __syncthreads();
+    STAMP(1);
     ln_tile(Vs, NH, LDP, ln_g, ln_b, Drop{0u, 0u, 1.f}, 0);
     __syncthreads();
+    STAMP(2);
     {
         const int c = tid & 127, hb = (tid >> 7) * 16;
         float wk[DWK], gw[DWK], dwin[NW], vwin[NW];
@@ -532,10 +561,14 @@ __global__ __launch_bounds__(256) void k_conv_bwd_dwln(const float* __restrict__
 #pragma unroll
         for (int k = 0; k < DWK; ++k) red[(tid >> 7) * 896 + c * DWK + k] = gw[k];
     }
+    STAMP(3);
     __syncthreads();
     for (int e = tid; e < D * DWK; e += 256) p_dw[(size_t)blockIdx.x * D * DWK + e] = red[e] + red[896 + e];
+    STAMP(4);
     ln_bwd_tile(Ts, Xc, dy, extra, ln_g, dx, p_lng, p_lnb, r0, R, nxt.relu_mask ? DUs : nullptr);
-    if (nxt.relu_mask) conv_gemm_stage(DUs, nxt, bf, r0, R);   // dx of this layer == dy of the layer below
+    STAMP(5);
+    if (nxt.relu_mask) conv_gemm_stage(DUs, nxt, bf, mw, r0, R);   // dx of this layer == dy of the layer below
+    STAMP(6);
 }
 void launch_conv_bwd_dwln(const float* du, const float* xin, const float* dy, const float* ln_g, const float* ln_b,
                           const float* dw_w, const float* extra, float* dx, float* p_lng, float* p_lnb, float* p_dw,
@@ -545,6 +578,8 @@ void launch_conv_bwd_dwln(const float* du, const float* xin, const float* dy, co
     ensure_dynamic_lds((const void*)k_conv_bwd_dwln, shm, lds_ok, "k_conv_bwd_dwln");
     hipLaunchKernelGGL(k_conv_bwd_dwln, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm, s, du, xin, dy, ln_g, ln_b, dw_w, extra,
                        dx, p_lng, p_lnb, p_dw, R, L, nxt);
+    static int left = 6;
+    if (dbg_budget("conv_bwd_dwln") && R > 4096) dbg_report("conv_bwd_dwln: loads | LN | depthwise bwd | sync | p_dw store | ln_bwd | fused gemm stage", 7, s, left);
 }
 
 // =========================================================================================================
@@ -1007,9 +1042,10 @@ __global__ __launch_bounds__(256) void k_qkv_bwd(const float* __restrict__ dQ, c
     }
     __syncthreads();
     BFrag<1, 16> bf2;                          // fused data-gradient GEMM of the last conv layer
-    if (nxt.relu_mask) bfrag_load(bf2, nxt.WTpack, D, 32 * w, 0, 0, D / 8);
+    ConvMaskWords mw2;
+    if (nxt.relu_mask) { conv_mask_prefetch(mw2, nxt, r0, R); bfrag_load(bf2, nxt.WTpack, D, 32 * w, 0, 0, D / 8); }
     ln_bwd_tile(Ts, Xs, dr, nullptr, ln_g, dx, p_lng, p_lnb, r0, R, nxt.relu_mask ? As : nullptr);
-    if (nxt.relu_mask) conv_gemm_stage(As, nxt, bf2, r0, R);
+    if (nxt.relu_mask) conv_gemm_stage(As, nxt, bf2, mw2, r0, R);
 }
 void launch_qkv_bwd(const float* dQ, const float* dK, const float* dV, const float* x, const float* dr,
                     const float* ln_g, const float* WTpack, float* dx, float* p_lng, float* p_lnb, int R, Drop d1,

@@ -2,6 +2,7 @@
 // (/root/reference/model/layers_t7.py unless noted).  Layout: activations are row-major (B*L, 128) fp32.
 #include "common.hpp"
 #include "launch.hpp"
+#include <type_traits>
 
 namespace vsl {
 
@@ -326,6 +327,7 @@ __global__ __launch_bounds__(256) void k_conv_layer_fwd(const float* __restrict_
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int r0 = blockIdx.x * TILE_M;
     BFrag<1, 16> bf;                                    // the whole 128 x 32 weight slice of this wave
+    FSTAMP(0);
     // ---- load rows r0-3 .. r0+34 (+ positional rows, :202): all loads first, then the stores
     {
         float4 xv[5], pv[5];
@@ -356,10 +358,13 @@ __global__ __launch_bounds__(256) void k_conv_layer_fwd(const float* __restrict_
             }
         }
     }
+    FSTAMP(1);
     __syncthreads();
+    FSTAMP(2);
     // ---- LayerNorm of all 38 rows
     ln_tile(Vs, NH, LDP, ln_g, ln_b, Drop{0u, 0u, 1.f}, 0);
     __syncthreads();
+    FSTAMP(3);
     // ---- depthwise conv k=7 along the sequence: thread = (channel c, 16 rows); the 22-row window sits in registers
     {
         const int c = tid & 127, hb = (tid >> 7) * 16;
@@ -384,29 +389,42 @@ __global__ __launch_bounds__(256) void k_conv_layer_fwd(const float* __restrict_
             if (u_out && r0 + hb + q < R) u_out[(size_t)(r0 + hb + q) * D + c] = u;   // saved: A operand of the weight gradient
         }
     }
+    FSTAMP(4);
     __syncthreads();
+    FSTAMP(5);
     // ---- pointwise GEMM + bias + ReLU (+ dropout) + residual
     f32x16 acc[1];
     zero_acc(acc);
     gemm32p<1, 16>(Us, LDP, D, Wpack, D, 32 * w, 0, acc, bf);
+    FSTAMP(6);
     const int col = 32 * w + (lane & 31);
     const float bv = pw_b[col];
+    // Epilogue without divergent control flow (per-element bounds / "dropout on?" tests compiled to ~80 branches and a full
+    // LDS wait per element: 7.2 k of the kernel's 24 k cycles).  Full tile and dropout on/off are block-uniform cases; the
+    // 32 ReLU bit-mask words of the wave are selected into lanes 0..31 and leave in ONE store.
+    const int myrow = lane & 31;                                     // lane < 32 stores the mask word of tile row `myrow`
+    const int myr = (myrow & 3) + 4 * (myrow >> 3), myhalf = (myrow >> 2) & 1;
+    uint32_t myword = 0u;
+    auto epilogue = [&](auto full_c, auto drop_c) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = acc_row(r, lane);
-        const int gr = r0 + row;
-        const float z = acc[0][r] + bv;
-        const unsigned long long bal = __ballot(z > 0.f);
-        if (lane == 0) {
-            const int glo = r0 + (r & 3) + 8 * (r >> 2);
-            if (glo < R) relu_mask[(size_t)glo * 4 + w] = (uint32_t)bal;
-            if (glo + 4 < R) relu_mask[(size_t)(glo + 4) * 4 + w] = (uint32_t)(bal >> 32);
+        for (int r = 0; r < 16; ++r) {
+            const int row = acc_row(r, lane);
+            const int gr = r0 + row;
+            const float z = acc[0][r] + bv;
+            const unsigned long long bal = __ballot(z > 0.f);
+            const uint32_t half = myhalf ? (uint32_t)(bal >> 32) : (uint32_t)bal;
+            myword = (r == myr) ? half : myword;
+            float a = fmaxf(z, 0.f);
+            if (decltype(drop_c)::value) a *= drop_keep_scale(dp, (uint32_t)(gr * D + col));
+            const float y = Xs[(row + HALO) * LDP + col] + a;
+            if (decltype(full_c)::value || gr < R) y_out[(size_t)gr * D + col] = y;
         }
-        if (gr < R) {
-            const float a = fmaxf(z, 0.f) * drop_mul(dp, (uint32_t)(gr * D + col));
-            y_out[(size_t)gr * D + col] = Xs[(row + HALO) * LDP + col] + a;
-        }
-    }
+    };
+    const bool full = r0 + TILE_M <= R;
+    if (full) { if (dp.thresh) epilogue(std::true_type(), std::true_type()); else epilogue(std::true_type(), std::false_type()); }
+    else      { if (dp.thresh) epilogue(std::false_type(), std::true_type()); else epilogue(std::false_type(), std::false_type()); }
+    if (lane < 32 && r0 + myrow < R) relu_mask[(size_t)(r0 + myrow) * 4 + w] = myword;
+    FSTAMP(7);
 }
 void launch_conv_layer_fwd(const float* xin, const float* pos, float* x0_out, const float* ln_g, const float* ln_b,
                            const float* dw_w, const float* Wpack, const float* pw_b, float* y_out, float* u_out,
@@ -418,6 +436,8 @@ void launch_conv_layer_fwd(const float* xin, const float* pos, float* x0_out, co
         ensure_dynamic_lds((const void*)k_conv_layer_fwd, shm_sp + 0, lds_sp, "k_conv_layer_fwd");
         hipLaunchKernelGGL(k_conv_layer_fwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm_sp, s, xin, pos, x0_out, ln_g, ln_b,
                        dw_w, Wpack, pw_b, y_out, u_out, relu_mask, R, L, dp);
+        static int left = 6;
+        if (fdbg_on() && R > 4096) fdbg_report("conv_layer_fwd: loads issued+stored | sync | LN | depthwise | sync | gemm | epilogue", 8, s, left);
     }
 }
 
