@@ -416,8 +416,26 @@ __device__ __forceinline__ void ln_tile(float* tile, int nrows, int ld, const fl
 //   Xs : raw LN input rows (32 x 128, stride LDP)       -- overwritten with dy * xhat (gamma partial = column sums)
 //   out[r] = LN^T(Ts[r]) + resid[r] + extra[r]  for global rows r0 + rr < R ; partial slabs [blockIdx.x][128].
 //   lds_out (nullable): the result tile is also left in LDS (stride LDP; rows >= R zero) for a fused follow-up GEMM.
-__device__ __forceinline__ void ln_bwd_tile(float* Ts, float* Xs, const float* __restrict__ resid,
-                                            const float* __restrict__ resid2, const float* __restrict__ ln_g,
+// The residual rows (resid + resid2) a thread adds in ln_bwd_tile: requested at kernel entry so that their memory latency is
+// not paid in the middle of the kernel.  Rows >= R are clamped for the load and zeroed.
+struct LnResid { float4 v[4]; };
+__device__ __forceinline__ void ln_resid_prefetch(LnResid& rs, const float* __restrict__ resid, const float* __restrict__ resid2,
+                                                  int r0, int R) {
+    const int sub = threadIdx.x & 7, r = r0 + (threadIdx.x >> 3);
+    const size_t off = (size_t)min(r, R - 1) * D + sub * 4;
+    const float keep = r < R ? 1.f : 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (resid) a = *reinterpret_cast<const float4*>(resid + off + 32 * j);
+        if (resid2) {
+            const float4 e = *reinterpret_cast<const float4*>(resid2 + off + 32 * j);
+            a.x += e.x; a.y += e.y; a.z += e.z; a.w += e.w;
+        }
+        rs.v[j] = make_float4(a.x * keep, a.y * keep, a.z * keep, a.w * keep);
+    }
+}
+__device__ __forceinline__ void ln_bwd_tile(float* Ts, float* Xs, const LnResid& pre, const float* __restrict__ ln_g,
                                             float* __restrict__ out, float* __restrict__ p_lng, float* __restrict__ p_lnb,
                                             int r0, int R, float* lds_out = nullptr) {
     const int tid = threadIdx.x, sub = tid & 7, rr = tid >> 3;
@@ -431,14 +449,7 @@ __device__ __forceinline__ void ln_bwd_tile(float* Ts, float* Xs, const float* _
         for (int j = 0; j < 4; ++j) {
             x[j] = *reinterpret_cast<const float4*>(xr + 32 * j);
             dy[j] = *reinterpret_cast<const float4*>(tr + 32 * j);
-            rs[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < R) {
-                if (resid) rs[j] = *reinterpret_cast<const float4*>(resid + (size_t)r * D + sub * 4 + 32 * j);
-                if (resid2) {
-                    const float4 e = *reinterpret_cast<const float4*>(resid2 + (size_t)r * D + sub * 4 + 32 * j);
-                    rs[j].x += e.x; rs[j].y += e.y; rs[j].z += e.z; rs[j].w += e.w;
-                }
-            }
+            rs[j] = pre.v[j];
             s += sum4(x[j]);
         }
         const float mu = grp8_sum(s) * (1.0f / D);

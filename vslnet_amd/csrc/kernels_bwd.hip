@@ -225,7 +225,10 @@ __global__ __launch_bounds__(256) void k_head_bwd(HeadBwdArgs a0, HeadBwdArgs a1
     }
     __syncthreads();
     if (a.ln_g) {
-        ln_bwd_tile(Hs, Fs, nullptr, nullptr, a.ln_g, a.dfeat, a.p_lng, a.p_lnb, r0, R);
+        LnResid nores;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) nores.v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        ln_bwd_tile(Hs, Fs, nores, a.ln_g, a.dfeat, a.p_lng, a.p_lnb, r0, R);
     } else {
         for (int e = tid; e < TILE_M * D; e += 256) {
             const int rr = e >> 7, c = e & 127;
@@ -498,6 +501,7 @@ __global__ __launch_bounds__(256) void k_conv_bwd_dwln(const float* __restrict__
     STAMP(0);
     BFrag<1, 16> bf;                         // weights of the fused data-gradient GEMM of the layer below
     ConvMaskWords mw;
+    LnResid lres;
     {   // ONE batch of loads for both source tiles (du and x', rows r0-3 .. r0+34); the centre rows of x' are written to Xc
         // from the same registers.  Three separate tile loads cost three memory latencies (7.6 k cycles).
         float4 dv[5], xv[5];
@@ -512,6 +516,7 @@ __global__ __launch_bounds__(256) void k_conv_bwd_dwln(const float* __restrict__
                 xv[q] = *reinterpret_cast<const float4*>(xin + (size_t)r * D + c);
             }
         }
+        ln_resid_prefetch(lres, dy, extra, r0, R);   // residual path of the LayerNorm backward: consumed last
         if (nxt.relu_mask) {                 // requested behind the tiles (in-order return), consumed after this layer's work
             conv_mask_prefetch(mw, nxt, r0, R);
             bfrag_load(bf, nxt.WTpack, D, 32 * (tid >> 6), 0, 0, D / 8);
@@ -565,7 +570,7 @@ __global__ __launch_bounds__(256) void k_conv_bwd_dwln(const float* __restrict__
     __syncthreads();
     for (int e = tid; e < D * DWK; e += 256) p_dw[(size_t)blockIdx.x * D * DWK + e] = red[e] + red[896 + e];
     STAMP(4);
-    ln_bwd_tile(Ts, Xc, dy, extra, ln_g, dx, p_lng, p_lnb, r0, R, nxt.relu_mask ? DUs : nullptr);
+    ln_bwd_tile(Ts, Xc, lres, ln_g, dx, p_lng, p_lnb, r0, R, nxt.relu_mask ? DUs : nullptr);
     STAMP(5);
     if (nxt.relu_mask) conv_gemm_stage(DUs, nxt, bf, mw, r0, R);   // dx of this layer == dy of the layer below
     STAMP(6);
@@ -629,6 +634,8 @@ __global__ __launch_bounds__(256) void k_attn_out_bwd(const float* __restrict__ 
             *reinterpret_cast<float4*>(&Gs[rr * LDP + c]) = v;
         }
     }
+    LnResid lres;
+    ln_resid_prefetch(lres, dy, dy2, r0, R);                // residual path of LN2's backward (same rows again, L2 hits), used last
     load_tile128(Xs, r_in, r0, TILE_M, R);                  // only needed by the LayerNorm backward after the GEMM
     __syncthreads();
     f32x16 acc[1];
@@ -642,7 +649,7 @@ __global__ __launch_bounds__(256) void k_attn_out_bwd(const float* __restrict__ 
         Gs[row * LDP + col] = acc[0][r] * drop_mul(d4, (uint32_t)((r0 + row) * D + col));
     }
     __syncthreads();
-    ln_bwd_tile(Gs, Xs, dy, dy2, ln_g, dr, p_lng, p_lnb, r0, R);
+    ln_bwd_tile(Gs, Xs, lres, ln_g, dr, p_lng, p_lnb, r0, R);
 }
 void launch_attn_out_bwd(const float* dy, const float* dy2, const float* r, const float* ln_g, const float* WTpack, float* g_o,
                          float* dr, float* p_lng, float* p_lnb, int R, Drop d4, Drop d5, hipStream_t s) {
@@ -1029,6 +1036,8 @@ __global__ __launch_bounds__(256) void k_qkv_bwd(const float* __restrict__ dQ, c
             *reinterpret_cast<float4*>(&As[rr * QKVP + 2 * D + c]) = cv[q];
         }
     }
+    LnResid lres;
+    ln_resid_prefetch(lres, dr, nullptr, r0, R);
     load_tile128(Xs, x, r0, TILE_M, R);                     // LN1 input rows: first used after the GEMM
     __syncthreads();
     f32x16 acc[1];
@@ -1044,7 +1053,7 @@ __global__ __launch_bounds__(256) void k_qkv_bwd(const float* __restrict__ dQ, c
     BFrag<1, 16> bf2;                          // fused data-gradient GEMM of the last conv layer
     ConvMaskWords mw2;
     if (nxt.relu_mask) { conv_mask_prefetch(mw2, nxt, r0, R); bfrag_load(bf2, nxt.WTpack, D, 32 * w, 0, 0, D / 8); }
-    ln_bwd_tile(Ts, Xs, dr, nullptr, ln_g, dx, p_lng, p_lnb, r0, R, nxt.relu_mask ? As : nullptr);
+    ln_bwd_tile(Ts, Xs, lres, ln_g, dx, p_lng, p_lnb, r0, R, nxt.relu_mask ? As : nullptr);
     if (nxt.relu_mask) conv_gemm_stage(As, nxt, bf2, mw2, r0, R);
 }
 void launch_qkv_bwd(const float* dQ, const float* dK, const float* dV, const float* x, const float* dr,
