@@ -91,7 +91,6 @@ struct vsl_handle_s {
     PackJob* jobs_dev = nullptr;
     uint8_t* decay_dev = nullptr;        // per-element weight-decay flag of the flat bucket (vsl_adamw_step)
     float* opt_scratch = nullptr;        // OPT_BLOCKS partial sums of grads^2
-    int* wdecode_dev = nullptr;          // flattened char-conv weight index -> (oc << 16 | ci << 8 | kk), 64 * 256 entries
     std::map<std::tuple<int, int, int, int>, Plan*> plans;
     // side streams for the independent chains (query branch, weight gradients) + fork/join events
     hipStream_t side[2] = {nullptr, nullptr};
@@ -373,12 +372,20 @@ enum { SITE_VIS = 64, SITE_WORD = 65, SITE_CHAR = 66, SITE_CQ_C = 67, SITE_CQ_Q 
 // ------------------------------------------------------------------------------------------------ forward
 void enc_fwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float* xin, const float* mask, int Bn, int app) {
     const int R = w.R, L = w.L, H = c.h->cfg.num_heads;
-    for (int i = 0; i < 4; ++i)
+    static const bool fuse_qkv = !(getenv("VSL_FUSE_QKV") && getenv("VSL_FUSE_QKV")[0] == '0');
+    for (int i = 0; i < 4; ++i) {
+        QkvFuse qf;
+        memset(&qf, 0, sizeof qf);
+        if (i == 3 && fuse_qkv)      // LN1 + QKV projection ride on the last conv layer's kernel
+            qf = QkvFuse{c.P(P.ln1g), c.P(P.ln1b), c.PK(K.qkv_f), c.P(P.qb), c.P(P.kb), c.P(P.vb), c.W(w.h1), c.W(w.q), c.W(w.k), c.W(w.v),
+                         c.drop(app * 16 + 4)};
         LAUNCH("conv_layer_fwd", launch_conv_layer_fwd(i == 0 ? xin : c.W(w.y[i - 1]), i == 0 ? c.P(P.pos) : nullptr, i == 0 ? c.W(w.x0) : nullptr,
                               c.P(P.lng[i]), c.P(P.lnb[i]), c.P(P.dw[i]), c.PK(K.pw_f[i]), c.P(P.pwb[i]), c.W(w.y[i]),
-                              c.W(w.u[i]), reinterpret_cast<uint32_t*>(c.W(w.mask[i])), R, L, c.drop(app * 16 + i), c.s));
-    LAUNCH("ln_qkv_fwd", launch_ln_qkv_fwd(c.W(w.y[3]), c.P(P.ln1g), c.P(P.ln1b), c.PK(K.qkv_f), c.P(P.qb), c.P(P.kb), c.P(P.vb), c.W(w.h1),
-                      c.W(w.q), c.W(w.k), c.W(w.v), R, c.drop(app * 16 + 4), c.s));
+                              c.W(w.u[i]), reinterpret_cast<uint32_t*>(c.W(w.mask[i])), R, L, c.drop(app * 16 + i), qf, c.s));
+    }
+    if (!fuse_qkv)
+        LAUNCH("ln_qkv_fwd", launch_ln_qkv_fwd(c.W(w.y[3]), c.P(P.ln1g), c.P(P.ln1b), c.PK(K.qkv_f), c.P(P.qb), c.P(P.kb), c.P(P.vb), c.W(w.h1),
+                          c.W(w.q), c.W(w.k), c.W(w.v), R, c.drop(app * 16 + 4), c.s));
     LAUNCH("attn_fwd", launch_attn_fwd(c.W(w.q), c.W(w.k), c.W(w.v), mask, c.W(w.att), c.W(w.lse), Bn, L, H, 0, c.drop(app * 16 + 5), c.s));
     LAUNCH("attn_out_fwd", launch_attn_out_fwd(c.W(w.att), c.W(w.y[3]), c.P(P.ln2g), c.P(P.ln2b), c.PK(K.o_f), c.P(P.ob), c.W(w.r), c.W(w.h2),
                         c.W(w.out), R, c.drop(app * 16 + 6), c.drop(app * 16 + 7), c.drop(app * 16 + 8), c.s));
@@ -733,7 +740,7 @@ void run_backward(Ctx& c) {
         float* p_tab = c.slab(P.char_tab, cf.char_size * cf.char_dim, nce);
         float* p_unk = c.slab(P.unk, cf.word_dim, nce);
         LAUNCH("embed_bwd", launch_embed_bwd(c.W(p.dE), io->word_ids, io->char_ids, c.W(p.E), reinterpret_cast<const int8_t*>(c.W(p.argpos)),
-                                c.P(P.char_tab), char_ptrs(c), c.h->wdecode_dev, c.part_ptr(ow), c.part_ptr(ob), p_tab, p_unk, Rq,
+                                c.P(P.char_tab), char_ptrs(c), c.part_ptr(ow), c.part_ptr(ob), p_tab, p_unk, Rq,
                                 p.Lc, cf.word_dim, cf.char_dim, cf.char_size, c.drop(SITE_WORD), c.drop(SITE_CHAR), c.s));
     }
     LAUNCH("wgrad", launch_wgrad(wb_emb, c.s));            // embedding linear + query-pass pointwise convs, on sq, no wait
@@ -896,24 +903,6 @@ int vsl_create(const vsl_config* cfg, vsl_handle* out) {
         delete h;
         return fail("hipMalloc/hipMemcpy of the pack table failed");
     }
-    {   // decode table of the flattened char-conv weights (embedding backward)
-        const int cd = cfg->char_dim, wtot = cd * 300;
-        std::vector<int> dec(64 * 256, 100 << 16);                      // dummy: channel 100 has zero gradient
-        const int ch[4] = {10, 20, 30, 40};
-        int e = 0, oc0 = 0;
-        for (int cv = 0; cv < 4; ++cv) {
-            const int k = cv + 1;
-            for (int c2 = 0; c2 < ch[cv]; ++c2)
-                for (int ci = 0; ci < cd; ++ci)
-                    for (int kk = 0; kk < k; ++kk) dec[e++] = ((oc0 + c2) << 16) | (ci << 8) | kk;
-            oc0 += ch[cv];
-        }
-        if (e != wtot || hipMalloc(&h->wdecode_dev, dec.size() * sizeof(int)) != hipSuccess ||
-            hipMemcpy(h->wdecode_dev, dec.data(), dec.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
-            delete h;
-            return fail("decode table setup failed");
-        }
-    }
     {
         const char* e = getenv("VSL_MULTI_STREAM");
         h->multi_stream = !(e && e[0] == '0');
@@ -936,7 +925,6 @@ int vsl_destroy(vsl_handle h) {
         delete kv.second;
     }
     if (h->jobs_dev) (void)hipFree(h->jobs_dev);
-    if (h->wdecode_dev) (void)hipFree(h->wdecode_dev);
     if (h->decay_dev) (void)hipFree(h->decay_dev);
     if (h->opt_scratch) (void)hipFree(h->opt_scratch);
     delete h;

@@ -496,8 +496,8 @@ __device__ __forceinline__ void ln_bwd_tile(float* Ts, float* Xs, const LnResid&
     }
 }
 
-// Arguments of the data-gradient GEMM of one conv layer (du = (dy * dropmask * relu-bit) Wp), used stand-alone
-// (k_conv_bwd_gemm) or fused behind the kernel that produces dy (k_conv_bwd_dwln of the layer above, k_qkv_bwd).
+// Arguments of the data-gradient GEMM of one conv layer (du = (dy * dropmask * relu-bit) Wp),
+// fused behind the kernel that produces dy (k_conv_bwd_dwln of the layer above, k_qkv_bwd).
 struct ConvGemmArgs {
     const uint32_t* relu_mask;   // (R, 4) bit-mask saved by the forward ; nullptr = no fused stage
     const float* WTpack;         // transpose pack of the pointwise weight

@@ -408,80 +408,11 @@ void launch_wgrad(const WgradBatch& wb, hipStream_t s) {
 }
 
 // =========================================================================================================
-// conv block backward (a7, :133-139), two kernels per layer:
-//  (1) k_conv_bwd_gemm : dz = dy * dropmask * relu-bit  (saved to gz for the weight gradient) ; du = dz Wp
+// conv block backward (a7, :133-139), one kernel per layer with two stages:
+//  (1) conv_gemm_stage (common.hpp, fused behind the kernel that produces dy): dz = dy * dropmask * relu-bit (saved to gz
+//      for the weight gradient) ; du = dz Wp
 //  (2) k_conv_bwd_dwln : dv = depthwise^T(du) ; dx = dy + LN^T(dv) ; partials for gamma, beta and the depthwise taps
 // =========================================================================================================
-__global__ __launch_bounds__(256) void k_conv_bwd_gemm(const float* __restrict__ dy, const uint32_t* __restrict__ relu_mask,
-                                                       const float* __restrict__ WTpack, float* __restrict__ gz,
-                                                       float* __restrict__ du, int R, Drop dp) {
-    __shared__ __attribute__((aligned(16))) float Gs[TILE_M * LDP];
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const int r0 = blockIdx.x * TILE_M;
-    STAMP(0);
-    BFrag<1, 16> bf;
-    {
-        float4 dv[4];
-        uint32_t mb[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int e = tid + q * 256;
-            const int r = r0 + (e >> 5), c = (e & 31) * 4;
-            dv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            mb[q] = 0u;
-            if (r < R) {
-                dv[q] = *reinterpret_cast<const float4*>(dy + (size_t)r * D + c);
-                mb[q] = relu_mask[(size_t)r * 4 + (c >> 5)];
-            }
-        }
-        // weight fragments are requested AFTER the tile: vector loads return in order, so the wait for the tile below
-        // does not include them and they keep streaming in behind the LDS stores / barrier
-        bfrag_load(bf, WTpack, D, 32 * w, 0, 0, D / 8);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int e = tid + q * 256;
-            const int rr = e >> 5, c = (e & 31) * 4;
-            const int r = r0 + rr;
-            float4 v = dv[q];
-            if (r < R) {
-                const uint32_t bits = mb[q] >> (c & 31);
-                const uint32_t base = (uint32_t)(r * D + c);
-                v.x = (bits & 1u) ? v.x * drop_mul(dp, base) : 0.f;
-                v.y = (bits & 2u) ? v.y * drop_mul(dp, base + 1) : 0.f;
-                v.z = (bits & 4u) ? v.z * drop_mul(dp, base + 2) : 0.f;
-                v.w = (bits & 8u) ? v.w * drop_mul(dp, base + 3) : 0.f;
-                *reinterpret_cast<float4*>(gz + (size_t)r * D + c) = v;
-            }
-            *reinterpret_cast<float4*>(&Gs[rr * LDP + c]) = v;
-        }
-    }
-    STAMP(1);
-    __syncthreads();
-    STAMP(2);
-    f32x16 acc[1];
-    zero_acc(acc);
-    gemm32p<1, 16>(Gs, LDP, D, WTpack, D, 32 * w, 0, acc, bf);
-    STAMP(3);
-    const int col = 32 * w + (lane & 31);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int gr = r0 + acc_row(r, lane);
-        if (gr < R) du[(size_t)gr * D + col] = acc[0][r];
-    }
-    STAMP(4);
-}
-void launch_conv_bwd_gemm(const float* dy, const uint32_t* relu_mask, const float* WTpack, float* gz, float* du, int R,
-                          Drop dp, hipStream_t s) {
-    {
-        static size_t lds_sp = 0;
-        const size_t shm_sp = spread_lds(0, 16896, (R + TILE_M - 1) / TILE_M);
-        ensure_dynamic_lds((const void*)k_conv_bwd_gemm, shm_sp + 16896, lds_sp, "k_conv_bwd_gemm");
-        hipLaunchKernelGGL(k_conv_bwd_gemm, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm_sp, s, dy, relu_mask, WTpack, gz, du, R, dp);
-        static int left = 2;
-        if (dbg_budget("conv_bwd_gemm") && R > 4096) dbg_report("conv_bwd_gemm: loads-issued | landed+sync | gemm | stores", 5, s, left);
-    }
-}
-
 __global__ __launch_bounds__(256) void k_conv_bwd_dwln(const float* __restrict__ du, const float* __restrict__ xin,
                                                        const float* __restrict__ dy, const float* __restrict__ ln_g,
                                                        const float* __restrict__ ln_b, const float* __restrict__ dw_w,
@@ -1854,10 +1785,9 @@ __global__ __launch_bounds__(256) void k_embed_bwd(const float* __restrict__ dE,
     STAMP(5);
 }
 void launch_embed_bwd(const float* dE, const int64_t* word_ids, const int64_t* char_ids, const float* E,
-                      const int8_t* argpos, const float* char_tab, CharConvPtrs cc, const int* wdecode, float* p_cw, float* p_cb,
+                      const int8_t* argpos, const float* char_tab, CharConvPtrs cc, float* p_cw, float* p_cb,
                       float* p_tab, float* p_unk, int Rq, int Lc, int word_dim, int char_dim, int char_size, Drop dw, Drop dc,
                       hipStream_t s) {
-    (void)wdecode;
     const size_t shm = (size_t)(((char_dim * 300 + 7) & ~3) + (EMB_CHUNK * Lc + 4) * 64 + EMB_CHUNK * 128 + 2 * Lc * 100 + Lc * 64 +
                                 char_size * char_dim) * sizeof(float);
     static size_t lds_ok = 0;

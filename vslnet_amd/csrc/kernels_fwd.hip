@@ -313,12 +313,13 @@ void launch_linear_fwd(const float* A, const float* Wpack, const float* bias, fl
 //   -> z = u Wp^T + b  ->  y = x' + drop(relu(z)).      Saves the relu bit-mask (R x 4 uint32) for the backward.
 // Tile = 32 rows + 3 halo rows each side (LayerNorm of the halo rows is recomputed).
 // =========================================================================================================
+template <bool QKV>
 __global__ __launch_bounds__(256) void k_conv_layer_fwd(const float* __restrict__ xin, const float* __restrict__ pos,
                                                         float* __restrict__ x0_out, const float* __restrict__ ln_g,
                                                         const float* __restrict__ ln_b, const float* __restrict__ dw_w,
                                                         const float* __restrict__ Wpack, const float* __restrict__ pw_b,
                                                         float* __restrict__ y_out, float* __restrict__ u_out,
-                                                        uint32_t* __restrict__ relu_mask, int R, int L, Drop dp) {
+                                                        uint32_t* __restrict__ relu_mask, int R, int L, Drop dp, QkvFuse qf) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NH = TILE_M + 2 * HALO;               // 38 rows
     float* Xs = smem;                                   // [38][LDP] raw x' (residual source)
@@ -397,6 +398,8 @@ __global__ __launch_bounds__(256) void k_conv_layer_fwd(const float* __restrict_
     zero_acc(acc);
     gemm32p<1, 16>(Us, LDP, D, Wpack, D, 32 * w, 0, acc, bf);
     FSTAMP(6);
+    BFrag<3, 4> bq3;                                     // first stage of the fused QKV weights: in flight during the epilogue
+    if (QKV) bfrag_load(bq3, qf.Wpack, 3 * D, 32 * w, D, 0, D / 8);
     const int col = 32 * w + (lane & 31);
     const float bv = pw_b[col];
     // Epilogue without divergent control flow (per-element bounds / "dropout on?" tests compiled to ~80 branches and a full
@@ -418,6 +421,7 @@ __global__ __launch_bounds__(256) void k_conv_layer_fwd(const float* __restrict_
             if (decltype(drop_c)::value) a *= drop_keep_scale(dp, (uint32_t)(gr * D + col));
             const float y = Xs[(row + HALO) * LDP + col] + a;
             if (decltype(full_c)::value || gr < R) y_out[(size_t)gr * D + col] = y;
+            if (QKV) Vs[row * LDP + col] = (decltype(full_c)::value || gr < R) ? y : 0.f;   // LN(x') rows are dead by now
         }
     };
     const bool full = r0 + TILE_M <= R;
@@ -425,20 +429,55 @@ __global__ __launch_bounds__(256) void k_conv_layer_fwd(const float* __restrict_
     else      { if (dp.thresh) epilogue(std::false_type(), std::true_type()); else epilogue(std::false_type(), std::false_type()); }
     if (lane < 32 && r0 + myrow < R) relu_mask[(size_t)(r0 + myrow) * 4 + w] = myword;
     FSTAMP(7);
+    if (QKV) {
+        // ---- a8, first half (:168-173) on the tile just produced: h1 = drop(LN1(y)) ; [q | k | v] = h1 W^T + b  (N = 384)
+        __syncthreads();
+        ln_tile(Vs, TILE_M, LDP, qf.ln_g, qf.ln_b, qf.d1, r0);
+        __syncthreads();
+        if (qf.h1)
+            for (int e = tid; e < TILE_M * 32; e += 256) {
+                const int rr = e >> 5, c = (e & 31) * 4;
+                if (r0 + rr < R) *reinterpret_cast<float4*>(qf.h1 + (size_t)(r0 + rr) * D + c) = *reinterpret_cast<const float4*>(&Vs[rr * LDP + c]);
+            }
+        f32x16 a3[3];
+        zero_acc(a3);
+        gemm32p<3, 4>(Vs, LDP, D, qf.Wpack, 3 * D, 32 * w, D, a3, bq3);
+        const float b0 = qf.bq[col], b1 = qf.bk[col], b2 = qf.bv[col];
+        if (full) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const size_t o = (size_t)(r0 + acc_row(r, lane)) * D + col;
+                qf.q[o] = a3[0][r] + b0; qf.k[o] = a3[1][r] + b1; qf.v[o] = a3[2][r] + b2;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gr = r0 + acc_row(r, lane);
+                if (gr < R) {
+                    const size_t o = (size_t)gr * D + col;
+                    qf.q[o] = a3[0][r] + b0; qf.k[o] = a3[1][r] + b1; qf.v[o] = a3[2][r] + b2;
+                }
+            }
+        }
+    }
 }
 void launch_conv_layer_fwd(const float* xin, const float* pos, float* x0_out, const float* ln_g, const float* ln_b,
                            const float* dw_w, const float* Wpack, const float* pw_b, float* y_out, float* u_out,
-                           uint32_t* relu_mask, int R, int L, Drop dp, hipStream_t s) {
+                           uint32_t* relu_mask, int R, int L, Drop dp, const QkvFuse& qkv, hipStream_t s) {
     const size_t shm = (size_t)(2 * (TILE_M + 2 * HALO) + TILE_M) * LDP * sizeof(float);
-    {
-        static size_t lds_sp = 0;
-        const size_t shm_sp = spread_lds(shm, 0, (R + TILE_M - 1) / TILE_M);
-        ensure_dynamic_lds((const void*)k_conv_layer_fwd, shm_sp + 0, lds_sp, "k_conv_layer_fwd");
-        hipLaunchKernelGGL(k_conv_layer_fwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm_sp, s, xin, pos, x0_out, ln_g, ln_b,
-                       dw_w, Wpack, pw_b, y_out, u_out, relu_mask, R, L, dp);
-        static int left = 6;
-        if (fdbg_on() && R > 4096) fdbg_report("conv_layer_fwd: loads issued+stored | sync | LN | depthwise | sync | gemm | epilogue", 8, s, left);
+    static size_t ok0 = 0, ok1 = 0;
+    const dim3 grid((R + TILE_M - 1) / TILE_M);
+    if (qkv.ln_g) {
+        ensure_dynamic_lds((const void*)k_conv_layer_fwd<true>, shm, ok1, "k_conv_layer_fwd<qkv>");
+        hipLaunchKernelGGL(k_conv_layer_fwd<true>, grid, dim3(256), shm, s, xin, pos, x0_out, ln_g, ln_b, dw_w, Wpack, pw_b, y_out, u_out,
+                           relu_mask, R, L, dp, qkv);
+    } else {
+        ensure_dynamic_lds((const void*)k_conv_layer_fwd<false>, shm, ok0, "k_conv_layer_fwd");
+        hipLaunchKernelGGL(k_conv_layer_fwd<false>, grid, dim3(256), shm, s, xin, pos, x0_out, ln_g, ln_b, dw_w, Wpack, pw_b, y_out, u_out,
+                           relu_mask, R, L, dp, qkv);
     }
+    static int left = 6;
+    if (fdbg_on() && R > 4096) fdbg_report("conv_layer_fwd: loads issued+stored | sync | LN | depthwise | sync | gemm | epilogue", 8, s, left);
 }
 
 // =========================================================================================================

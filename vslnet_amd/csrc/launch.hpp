@@ -115,9 +115,16 @@ void launch_embed_fwd(const int64_t* word_ids, const int64_t* char_ids, const fl
                       const float* glove, const float* char_tab, CharConvPtrs cc, const float* wimg, float* E, int8_t* argpos,
                       int Rq, int Lc, int word_dim, int char_dim, Drop dw, Drop dc, hipStream_t s);
 void launch_linear_fwd(const float* A, const float* Wpack, const float* bias, float* Y, int R, int K, hipStream_t s);
+// LN1 + fused QKV projection carried by the LAST conv layer's kernel (row-local, so it needs no halo): saves one kernel
+// boundary per encoder application.  ln_g == nullptr: plain conv layer.
+struct QkvFuse {
+    const float *ln_g, *ln_b, *Wpack, *bq, *bk, *bv;
+    float *h1, *q, *k, *v;
+    Drop d1;
+};
 void launch_conv_layer_fwd(const float* xin, const float* pos, float* x0_out, const float* ln_g, const float* ln_b,
                            const float* dw_w, const float* Wpack, const float* pw_b, float* y_out, float* u_out,
-                           uint32_t* relu_mask, int R, int L, Drop dp, hipStream_t s);
+                           uint32_t* relu_mask, int R, int L, Drop dp, const QkvFuse& qkv, hipStream_t s);
 void launch_ln_qkv_fwd(const float* x, const float* ln_g, const float* ln_b, const float* Wpack, const float* bq,
                        const float* bk, const float* bv, float* h1, float* q, float* k, float* v, int R, Drop d1,
                        hipStream_t s);
@@ -153,8 +160,6 @@ void launch_lstm_fwd(const float* gi, const float* Whh, const float* bih, const 
 void launch_lstm_bwd(const float* dout, const float* dout2, const float* mask, const float* gates, const float* cseq,
                      const float* Whh, float* dG, int B, int T, hipStream_t s);
 void launch_wgrad(const WgradBatch& wb, hipStream_t s);
-void launch_conv_bwd_gemm(const float* dy, const uint32_t* relu_mask, const float* WTpack, float* gz, float* du, int R,
-                          Drop dp, hipStream_t s);
 void launch_conv_bwd_dwln(const float* du, const float* xin, const float* dy, const float* ln_g, const float* ln_b,
                           const float* dw_w, const float* extra, float* dx, float* p_lng, float* p_lnb, float* p_dw, int R, int L,
                           const ConvGemmArgs& nxt, hipStream_t s);
@@ -189,7 +194,7 @@ struct CqBwdArgs {
 void launch_cq_bwd(const CqBwdArgs& a, int B, hipStream_t s);
 void launch_linear_bwd_data(const float* G, const float* WTpack, float* dA, int R, int K, hipStream_t s);
 void launch_embed_bwd(const float* dE, const int64_t* word_ids, const int64_t* char_ids, const float* E,
-                      const int8_t* argpos, const float* char_tab, CharConvPtrs cc, const int* wdecode /*[64*256] host-built*/,
+                      const int8_t* argpos, const float* char_tab, CharConvPtrs cc,
                       float* p_cw /*[nchunk][15000]*/,
                       float* p_cb /*[nchunk][100]*/, float* p_tab /*[nchunk][char_size*char_dim]*/,
                       float* p_unk /*[nchunk][word_dim]*/, int Rq, int Lc, int word_dim, int char_dim, int char_size, Drop dw,
