@@ -907,8 +907,15 @@ int vsl_create(const vsl_config* cfg, vsl_handle* out) {
         const char* e = getenv("VSL_MULTI_STREAM");
         h->multi_stream = !(e && e[0] == '0');
         if (h->multi_stream)
-            for (int k = 0; k < 2; ++k)
-                if (hipStreamCreateWithFlags(&h->side[k], hipStreamNonBlocking) != hipSuccess) { h->side[k] = nullptr; (void)hipGetLastError(); }
+            for (int k = 0; k < 2; ++k) {
+                // side(1) carries the weight gradients: nothing waits for them until the final reduction, so it may run at the
+                // lowest priority the device offers (VSL_WGRAD_PRIO=0 keeps the default) and leave CUs to the dependent chain
+                int lo = 0, hi = 0;
+                (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+                static const bool low_prio = !(getenv("VSL_WGRAD_PRIO") && getenv("VSL_WGRAD_PRIO")[0] == '0');
+                const int prio = (k == 1 && low_prio) ? lo : 0;
+                if (hipStreamCreateWithPriority(&h->side[k], hipStreamNonBlocking, prio) != hipSuccess) { h->side[k] = nullptr; (void)hipGetLastError(); }
+            }
     }
     *out = h;
     return 0;
