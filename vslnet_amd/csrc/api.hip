@@ -307,6 +307,8 @@ struct Ctx {
     size_t part_idx = 0;
     int64_t part_cur = 0;
     std::vector<SlabRec>* recs = nullptr;
+    std::vector<WgradBatch> pend;       // weight-gradient batches waiting for ONE ordering point (wgrad_async / wgrad_flush)
+    bool defer_w = false;
     const float* P(int off) const { return io->params + off; }
     const float* PK(int off) const { return ws + p->pack + off; }
     float* W(int64_t off) const { return ws + off; }
@@ -334,6 +336,15 @@ struct Ctx {
         hipEvent_t e = h->sync_pool[h->sync_used++];
         (void)hipEventRecord(e, from);
         (void)hipStreamWaitEvent(to, e, 0);
+    }
+    // one event record on `from`, two waiters
+    void order2(hipStream_t from, hipStream_t to1, hipStream_t to2) {
+        if (dry) return;
+        if (h->sync_used == h->sync_pool.size()) { hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); h->sync_pool.push_back(e); }
+        hipEvent_t e = h->sync_pool[h->sync_used++];
+        (void)hipEventRecord(e, from);
+        if (to1 != from) (void)hipStreamWaitEvent(to1, e, 0);
+        if (to2 != from && to2 != to1) (void)hipStreamWaitEvent(to2, e, 0);
     }
     hipStream_t side(int k) const { return (h->multi_stream && h->side[k]) ? h->side[k] : main; }
     hipStream_t main = nullptr;
@@ -364,6 +375,34 @@ struct Ctx {
     }
 };
 #define LAUNCH(name, stmt) do { if (!c.dry) { c.pb(name); stmt; c.pe(name); } } while (0)
+
+// Every cross-stream ordering point (event record on the producer + wait on the consumer) leaves a ~6-7 us bubble in the
+// producer stream (rocprofv3 timeline), so weight-gradient batches -- nothing waits for them before the final reduction --
+// are collected while `defer_w` is set and go to the side stream behind ONE event.
+void wgrad_async(Ctx& c, hipStream_t sw, const WgradBatch& wb) {
+    if (c.defer_w) { c.pend.push_back(wb); return; }
+    hipStream_t keep = c.s;
+    c.order(keep, sw);
+    c.s = sw;
+    LAUNCH("wgrad", launch_wgrad(wb, c.s));
+    c.s = keep;
+}
+void wgrad_flush(Ctx& c, hipStream_t sw) {
+    if (c.pend.empty()) return;
+    hipStream_t keep = c.s;
+    c.order(keep, sw);
+    c.s = sw;
+    for (const WgradBatch& wb : c.pend) LAUNCH("wgrad", launch_wgrad(wb, c.s));
+    c.s = keep;
+    c.pend.clear();
+}
+// after a fork the chain that finishes LAST should own the main stream: its join wait is then already satisfied (a wait on
+// an event that has just been signalled costs 10 - 22 us).  At the headline shape the query side is the long one.
+bool query_chain_is_longer(const Plan& p) {
+    static const char* e = getenv("VSL_SWAP_CHAINS");     // measured: -0.5 % alone, +0.5 % together with the batched ordering
+    (void)p;
+    return e && e[0] == '1';
+}
 
 // dropout site ids: encoder application `app` (0 video, 1 query, 2 predictor pass 1, 3 predictor pass 2) uses
 // app * 16 + {0..3 conv layers, 4 LN1 out, 5 attention probs, 6 attention out, 7 LN2 out, 8 out_layer}
@@ -408,9 +447,11 @@ void run_forward(Ctx& c) {
     // fork: the query branch (embedding + query encoder pass) runs beside the video branch
     hipStream_t sq = c.side(0);
     c.order(c.main, sq);
+    const bool qlong = query_chain_is_longer(p);        // the longer branch keeps the main stream (join wait already satisfied)
+    c.s = qlong ? sq : c.main;
     LAUNCH("vproj_fwd", launch_vproj_fwd(io.video_features, c.PK(K.va_f), c.P(P.va_b), c.W(p.vf), R, cf.video_feature_dim, c.drop(SITE_VIS), c.s));
     enc_fwd(c, P.fe, K.fe, p.ve, c.W(p.vf), io.v_mask, B, 0);
-    c.s = sq;
+    c.s = qlong ? c.main : sq;
     LAUNCH("embed_fwd", launch_embed_fwd(io.word_ids, io.char_ids, io.pad_vec, c.P(P.unk), io.glove_vec, c.P(P.char_tab), char_ptrs(c), c.PK(K.ccw_img), c.W(p.E),
                      reinterpret_cast<int8_t*>(c.W(p.argpos)), Rq, p.Lc, cf.word_dim, cf.char_dim, c.drop(SITE_WORD),
                      c.drop(SITE_CHAR), c.s));
@@ -507,11 +548,7 @@ void enc_bwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float*
             j.out_bias[2] = c.slab(P.vb, D, nchunk);
             wb.j[wb.n++] = j;
         }
-        hipStream_t keep = c.s;
-        c.order(keep, sw);
-        c.s = sw;
-        LAUNCH("wgrad", launch_wgrad(wb, c.s));
-        c.s = keep;
+        wgrad_async(c, sw, wb);
     }
     float* g = c.dry ? nullptr : c.W(t.ga);
     float* other = c.dry ? nullptr : c.W(t.gb);
@@ -542,15 +579,8 @@ void enc_bwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float*
             j.out_bias[0] = c.slab(P.pwb[i], D, nchunk);
             wb.j[wb.n++] = j;
         }
-        if (defer_pw) {
-            *defer_pw = wb;
-        } else {
-            hipStream_t keep = c.s;
-            c.order(keep, sw);
-            c.s = sw;
-            LAUNCH("wgrad", launch_wgrad(wb, c.s));
-            c.s = keep;
-        }
+        if (defer_pw) *defer_pw = wb;
+        else wgrad_async(c, sw, wb);
     }
     // positional table (:202): dpos[t] = sum_b dx0[b, t] -- the per-sample rows of dx0 ARE the partial slabs
     c.reg(P.pos, c.h->cfg.max_pos_len * D, dx0_off, Bn, L * D, 0, 0, L * D);
@@ -568,6 +598,9 @@ void run_backward(Ctx& c) {
     // reduction); sq = the query-side chain (query encoder pass + embedding stack) once CQAttention's backward is done
     hipStream_t sw = c.dry ? nullptr : c.side(1), sq = c.dry ? nullptr : c.side(0);
     auto on_stream = [&](hipStream_t st, auto&& fn) { hipStream_t keep = c.s; c.order(keep, st); c.s = st; fn(); c.s = keep; };
+    static const int batch_mode = getenv("VSL_WGRAD_BATCH") ? atoi(getenv("VSL_WGRAD_BATCH")) : 1;
+    const bool batch_w = batch_mode != 0;
+    c.defer_w = batch_w && !c.dry && cf.predictor == 1;
     // ---- span heads
     HeadBwdArgs hs, he;
     memset(&hs, 0, sizeof hs);
@@ -596,7 +629,7 @@ void run_backward(Ctx& c) {
             j.out = c.slab(e ? P.e0w : P.s0w, D * 2 * D, nchunk);
             wb.j[wb.n++] = j;
         }
-        on_stream(sw, [&] { LAUNCH("wgrad", launch_wgrad(wb, c.s)); });
+        wgrad_async(c, sw, wb);
     }
     if (rnn) {
         // ---- rnn head: BPTT through the end LSTM, then the start LSTM (whose output also feeds the start span block)
@@ -636,6 +669,7 @@ void run_backward(Ctx& c) {
     } else {
     // ---- predictor encoder, second pass (input = output of the first pass), then first pass
     enc_bwd(c, P.pe, K.pe, p.p2, c.dry ? nullptr : c.W(p.dfeat_e), nullptr, p.g_s1, c.dry ? nullptr : io->v_mask, B, 3, sw);
+    if (batch_mode != 2) wgrad_flush(c, sw);   // span heads + pass-2 weight gradients: one ordering point
     // grad wrt the first pass' output = (input grad of the second pass) + (LayerNorm path of the start head)
     enc_bwd(c, P.pe, K.pe, p.p1, c.dry ? nullptr : c.W(p.g_s1), c.dry ? nullptr : c.W(p.dfeat_s), p.g_gated,
             c.dry ? nullptr : io->v_mask, B, 2, sw);
@@ -665,7 +699,9 @@ void run_backward(Ctx& c) {
             j.out_bias[0] = c.slab(P.cqa_b, D, nchunk);
             wb.j[wb.n++] = j;
         }
-        on_stream(sw, [&] { LAUNCH("wgrad", launch_wgrad(wb, c.s)); });
+        wgrad_async(c, sw, wb);
+        wgrad_flush(c, sw);                 // pass-1 + fusion weight gradients: one ordering point
+        c.defer_w = false;
     }
     // ---- CQAttention + WeightedPool / pooled-bias backward: four tile-parallel kernels (kernels_bwd.hip)
     {
@@ -688,13 +724,17 @@ void run_backward(Ctx& c) {
         LAUNCH("cq_bwd", launch_cq_bwd(q, B, c.s));
     }
     // early reduction (predictor / heads / CQ parameters): all their partials exist once the launches above are done
-    on_stream(sw, [&] { LAUNCH("reduce", launch_reduce(c.ws, io->grads, p.segs_dev, p.blk2seg_dev, p.nblocks_early, c.s)); });
-    // fork: from here the video side (main) and the query side (sq) are independent
-    c.order(c.s, sq);
+    // ONE event for both consumers: the early reduction on sw and the fork of the query side onto sq
+    c.order2(c.s, sw, sq);
+    { hipStream_t keep = c.s; c.s = sw; LAUNCH("reduce", launch_reduce(c.ws, io->grads, p.segs_dev, p.blk2seg_dev, p.nblocks_early, c.s)); c.s = keep; }
+    // from here the video side and the query side are independent; the longer one keeps the main stream
+    hipStream_t main_s = c.s;
+    const bool qlong = query_chain_is_longer(p);
+    c.s = qlong ? sq : main_s;
     WgradBatch pw_video;
     memset(&pw_video, 0, sizeof pw_video);
     enc_bwd(c, P.fe, K.fe, p.ve, c.dry ? nullptr : c.W(p.dC), nullptr, p.dvf, c.dry ? nullptr : io->v_mask, B, 0, sw, &pw_video);
-    {   // tail of the main stream: VisualProjection + the video pass' pointwise weight gradients, back to back, no waits
+    {   // tail of the video stream: VisualProjection + the video pass' pointwise weight gradients, back to back, no waits
         WgradBatch wb;
         memset(&wb, 0, sizeof wb);
         WgradJob j = wjob();
@@ -706,9 +746,8 @@ void run_backward(Ctx& c) {
         LAUNCH("wgrad", launch_wgrad(wb, c.s));
         LAUNCH("wgrad", launch_wgrad(pw_video, c.s));
     }
-    // ---- query pass, then the embedding stack (all on sq)
-    hipStream_t main_s = c.s;
-    c.s = sq;
+    // ---- query pass, then the embedding stack (all on the other stream)
+    c.s = qlong ? main_s : sq;
     WgradBatch pw_query;
     memset(&pw_query, 0, sizeof pw_query);
     enc_bwd(c, P.fe, K.fe, p.qe, c.dry ? nullptr : c.W(p.dQtot), nullptr, p.dqf, c.dry ? nullptr : io->q_mask, B, 1, sw, &pw_query);
@@ -743,7 +782,7 @@ void run_backward(Ctx& c) {
                                 c.P(P.char_tab), char_ptrs(c), c.part_ptr(ow), c.part_ptr(ob), p_tab, p_unk, Rq,
                                 p.Lc, cf.word_dim, cf.char_dim, cf.char_size, c.drop(SITE_WORD), c.drop(SITE_CHAR), c.s));
     }
-    LAUNCH("wgrad", launch_wgrad(wb_emb, c.s));            // embedding linear + query-pass pointwise convs, on sq, no wait
+    LAUNCH("wgrad", launch_wgrad(wb_emb, c.s));            // embedding linear + query-pass pointwise convs, same stream, no wait
     c.s = main_s;
     c.order(sq, c.s);                      // join both side streams before the reduction
     c.order(sw, c.s);
