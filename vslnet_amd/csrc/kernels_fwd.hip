@@ -794,98 +794,98 @@ __global__ __launch_bounds__(256) void k_cq_col(const float* __restrict__ C, con
                                                 const float* __restrict__ S, const float* __restrict__ cmask,
                                                 const float* __restrict__ qmask, const float* __restrict__ pool_w,
                                                 const float* __restrict__ Wcat, const float* __restrict__ bcat,
-                                                float* __restrict__ Scol, float* __restrict__ M, float* __restrict__ alpha,
+                                                float* __restrict__ Scol, float* __restrict__ Mpart, float* __restrict__ alpha,
                                                 float* __restrict__ pooled, float* __restrict__ pb, int T, int Lq) {
-    // one workgroup per sample; the clips are walked in 32-row tiles that are bulk-staged through LDS (every global
-    // access is a coalesced tile load with many requests in flight -- no per-clip dependent loads)
+    // Tile-parallel: workgroup = (32-clip tile, sample).  The column-softmax statistics need every clip of the sample, so
+    // each workgroup recomputes them from the sample's whole score matrix (T x Lq floats, L2-resident, all 256 threads);
+    // it then writes its S_col tile and the per-tile partial of M = S_col^T C (MFMA, gemm_tn); k_cq_out adds the partials.
+    // Tile 0 also runs the small WeightedPool / pooled-bias path of the sample.
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int LQ1 = Lq + 1;
-    float* Cs = smem;                   // [32][LDP]  C tile
-    float* Ss = Cs + TILE_M * LDP;      // [32][LQ1]  masked score tile -> S_col tile
-    float* cmax = Ss + TILE_M * LQ1;    // [Lq]
-    float* cinv = cmax + Lq;            // [Lq]
-    float* al = cinv + Lq;              // [Lq]
-    float* pl = al + Lq;                // [128]
+    float* Cs = smem;                         // [32][LDP]  C tile
+    float* Ss = Cs + TILE_M * LDP;            // [32][LQ1]  S_col tile (+ slack for the 32-wide over-read of gemm_tn)
+    float* redm = Ss + TILE_M * LQ1 + 72;     // [8][64] partial column maxima
+    float* reds = redm + 8 * 64;              // [8][64] partial column sums
+    float* cmax = reds + 8 * 64;              // [64]
+    float* cinv = cmax + 64;                  // [64]
+    float* al = cinv + 64;                    // [64]
+    float* pl = al + 64;                      // [128]
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const int b = blockIdx.x;
+    const int b = blockIdx.y, tl = blockIdx.x, t0 = tl * TILE_M, ntile = gridDim.x;
     const size_t crow = (size_t)b * T, qrow = (size_t)b * Lq;
-    const int ntile = (T + TILE_M - 1) / TILE_M;
-    // ---- pass 1: running (max, sum) per query word over the clips
-    float rm = -3.0e38f, rs = 0.f;      // owned by thread j = tid < Lq
-    for (int tl = 0; tl < ntile; ++tl) {
-        const int t0 = tl * TILE_M, nr = min(TILE_M, T - t0);
-        for (int e = tid; e < nr * Lq; e += 256) {
-            const int i = e / Lq, j = e - i * Lq;
-            Ss[i * LQ1 + j] = S[(crow + t0) * Lq + e] + (1.f - cmask[crow + t0 + i]) * MASK_VALUE;
-        }
-        __syncthreads();
-        if (tid < Lq) {
-            float mx = rm;
-            for (int i = 0; i < nr; ++i) mx = fmaxf(mx, Ss[i * LQ1 + tid]);
-            float sm = rs * __expf(rm - mx);
-            for (int i = 0; i < nr; ++i) sm += __expf(Ss[i * LQ1 + tid] - mx);
-            rm = mx; rs = sm;
-        }
-        __syncthreads();
+    load_tile128(Cs, C + crow * D, t0, TILE_M, T);
+    // ---- column statistics over all T clips: thread = (word j, part); a part walks clips part, part + np, ...
+    const int JW = Lq <= 32 ? 32 : 64, np = 256 / JW;
+    const int j = tid & (JW - 1), part = tid / JW;
+    {
+        float mx = -3.0e38f;
+        if (j < Lq) for (int i = part; i < T; i += np) mx = fmaxf(mx, S[(crow + i) * Lq + j] + (1.f - cmask[crow + i]) * MASK_VALUE);
+        redm[part * 64 + j] = mx;
     }
-    if (tid < Lq) { cmax[tid] = rm; cinv[tid] = 1.0f / rs; }
     __syncthreads();
-    // ---- pass 2: S_col tile (written out) and M[j][c] = sum_t S_col[t][j] C[t][c]; thread = (c, half of the words)
-    const int c = tid & 127, jh = tid >> 7;
-    const int jn = (Lq + 1) / 2, j0 = jh * jn, j1 = min(Lq, j0 + jn);
-    const int nj_u = __builtin_amdgcn_readfirstlane(j1 - j0);
-    float macc[MAX_LQ / 2];
-#pragma unroll
-    for (int q = 0; q < MAX_LQ / 2; ++q) macc[q] = 0.f;
-    for (int tl = 0; tl < ntile; ++tl) {
-        const int t0 = tl * TILE_M, nr = min(TILE_M, T - t0);
-        load_tile128(Cs, C + crow * D, t0, TILE_M, T);
-        for (int e = tid; e < TILE_M * Lq; e += 256) {
-            const int i = e / Lq, j = e - i * Lq;
-            float v = 0.f;
-            if (i < nr) {
-                v = __expf(S[(crow + t0) * Lq + e] + (1.f - cmask[crow + t0 + i]) * MASK_VALUE - cmax[j]) * cinv[j];
-                Scol[(crow + t0) * Lq + e] = v;
-            }
-            Ss[i * LQ1 + j] = v;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int qc = 0; qc < MAX_LQ / 16; ++qc) {
-            if (qc * 8 < nj_u) {                   // wave-uniform guard, unconditional body (see k_cq_col_bwd)
-#pragma unroll 4
-                for (int i = 0; i < TILE_M; ++i) {
-                    const float cv = Cs[i * LDP + c];
-                    const float* sr = Ss + i * LQ1 + j0 + qc * 8;
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) macc[qc * 8 + q] += sr[q] * cv;
-                }
-            }
-        }
-        __syncthreads();
+    float gm = -3.0e38f;
+    for (int q = 0; q < np; ++q) gm = fmaxf(gm, redm[q * 64 + j]);
+    {
+        float sm = 0.f;
+        if (j < Lq) for (int i = part; i < T; i += np) sm += __expf(S[(crow + i) * Lq + j] + (1.f - cmask[crow + i]) * MASK_VALUE - gm);
+        reds[part * 64 + j] = sm;
     }
+    __syncthreads();
+    if (tid < JW) {
+        float sm = 0.f;
+        for (int q = 0; q < np; ++q) sm += reds[q * 64 + j];
+        cmax[j] = gm;
+        cinv[j] = 1.0f / sm;
+    }
+    if (tid < 72) Ss[TILE_M * LQ1 + tid] = 0.f;          // finite values where gemm_tn over-reads
+    __syncthreads();
+    // ---- S_col tile (:226-227), written out and kept in LDS with a zero pad column
+    for (int e = tid; e < TILE_M * LQ1; e += 256) {
+        const int i = e / LQ1, jj = e - i * LQ1;
+        float v = 0.f;
+        if (jj < Lq && t0 + i < T) {
+            const size_t o = (crow + t0 + i) * Lq + jj;
+            v = __expf(S[o] + (1.f - cmask[crow + t0 + i]) * MASK_VALUE - cmax[jj]) * cinv[jj];
+            Scol[o] = v;
+        }
+        Ss[e] = v;
+    }
+    __syncthreads();
+    // ---- partial of M[j][c] = sum_t S_col[t][j] C[t][c] over this tile's clips
+    {
+        float* mp = Mpart + (size_t)(b * ntile + tl) * Lq * D;
+        const int col = 32 * w + (lane & 31);
+        const int NTJ = (Lq + 31) >> 5;
+        for (int nt = 0; nt < NTJ; ++nt) {
+            f32x16 acc[1];
+            zero_acc(acc);
+            gemm_tn_p<1, TILE_M>(Ss, LQ1, 32 * nt, Cs, LDP, 32 * w, acc);
 #pragma unroll
-    for (int q = 0; q < MAX_LQ / 2; ++q)
-        if (q < j1 - j0) M[(qrow + j0 + q) * D + c] = macc[q];
+            for (int r = 0; r < 16; ++r) {
+                const int jj = 32 * nt + acc_row(r, lane);
+                if (jj < Lq) mp[(size_t)jj * D + col] = acc[0][r];
+            }
+        }
+    }
+    if (tl != 0) return;                       // block-uniform
     // ---- WeightedPool: alpha = softmax_j(Q[j].w + mask) ; pooled = sum_j alpha_j Q[j]
-    for (int j = w; j < Lq; j += 4) {
-        const float* row = Qf + (qrow + j) * D;
+    for (int jj = w; jj < Lq; jj += 4) {
+        const float* row = Qf + (qrow + jj) * D;
         const float d = wave_sum(row[lane] * pool_w[lane] + row[lane + 64] * pool_w[lane + 64]);
-        if (lane == 0) al[j] = d + (1.f - qmask[qrow + j]) * MASK_VALUE;
+        if (lane == 0) al[jj] = d + (1.f - qmask[qrow + jj]) * MASK_VALUE;
     }
     __syncthreads();
     if (w == 0) {
-        const float v0 = lane < Lq ? al[lane] : -3.0e38f, v1 = lane + 64 < Lq ? al[lane + 64] : -3.0e38f;
-        const float mx = wave_max(fmaxf(v0, v1));
-        const float e0 = lane < Lq ? __expf(v0 - mx) : 0.f, e1 = lane + 64 < Lq ? __expf(v1 - mx) : 0.f;
-        const float inv = 1.0f / wave_sum(e0 + e1);
+        const float v0 = lane < Lq ? al[lane] : -3.0e38f;
+        const float mx = wave_max(v0);
+        const float e0 = lane < Lq ? __expf(v0 - mx) : 0.f;
+        const float inv = 1.0f / wave_sum(e0);
         if (lane < Lq) { al[lane] = e0 * inv; alpha[qrow + lane] = e0 * inv; }
-        if (lane + 64 < Lq) { al[lane + 64] = e1 * inv; alpha[qrow + lane + 64] = e1 * inv; }
     }
     __syncthreads();
     if (tid < D) {
         float acc = 0.f;
-        for (int j = 0; j < Lq; ++j) acc += al[j] * Qf[(qrow + j) * D + tid];
+        for (int jj = 0; jj < Lq; ++jj) acc += al[jj] * Qf[(qrow + jj) * D + tid];
         pl[tid] = acc;
         pooled[(size_t)b * D + tid] = acc;
     }
@@ -906,59 +906,81 @@ __global__ __launch_bounds__(256) void k_cq_col(const float* __restrict__ C, con
     }
 }
 void launch_cq_col(const float* C, const float* Qf, const float* S, const float* cmask, const float* qmask,
-                   const float* pool_w, const float* Wcat, const float* bcat, float* Scol, float* M, float* alpha,
+                   const float* pool_w, const float* Wcat, const float* bcat, float* Scol, float* Mpart, float* alpha,
                    float* pooled, float* pb, int B, int T, int Lq, hipStream_t s) {
-    const size_t shm = (size_t)(TILE_M * LDP + TILE_M * (Lq + 1) + 3 * Lq + D + 8) * sizeof(float);
-    hipLaunchKernelGGL(k_cq_col, dim3(B), dim3(256), shm, s, C, Qf, S, cmask, qmask, pool_w, Wcat, bcat, Scol, M, alpha,
-                       pooled, pb, T, Lq);
+    const size_t shm = (size_t)(TILE_M * LDP + TILE_M * (Lq + 1) + 72 + 2 * 8 * 64 + 3 * 64 + D) * sizeof(float);
+    hipLaunchKernelGGL(k_cq_col, dim3((T + TILE_M - 1) / TILE_M, B), dim3(256), shm, s, C, Qf, S, cmask, qmask, pool_w, Wcat, bcat, Scol,
+                       Mpart, alpha, pooled, pb, T, Lq);
 }
 
-// builds the [32][4*128] concat tile (:231) in LDS from C, S_row, Q, M  (shared by forward and backward)
-__device__ __forceinline__ void cq_build_concat(float* Cat /*[32][CATP]*/, const float* Cs /*[32][LDP]*/,
-                                                const float* Ss /*[32][Lq]*/, const float* __restrict__ Qg,
-                                                const float* __restrict__ Mg, int Lq, int catp) {
-    const int c = threadIdx.x & 127, hb = (threadIdx.x >> 7) * 16;
-    float a1[16], a2[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) { a1[q] = 0.f; a2[q] = 0.f; }
-    for (int j = 0; j < Lq; ++j) {
-        const float qv = Qg[(size_t)j * D + c], mv = Mg[(size_t)j * D + c];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const float sv = Ss[(hb + q) * Lq + j];
-            a1[q] += sv * qv;
-            a2[q] += sv * mv;
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int rr = hb + q;
-        const float cv = Cs[rr * LDP + c];
-        float* o = Cat + rr * catp;
-        o[c] = cv;
-        o[D + c] = a1[q];
-        o[2 * D + c] = cv * a1[q];
-        o[3 * D + c] = cv * a2[q];
-    }
-}
 __global__ __launch_bounds__(256) void k_cq_out(const float* __restrict__ C, const float* __restrict__ Qf,
-                                                const float* __restrict__ Srow, const float* __restrict__ M,
-                                                const float* __restrict__ Wpack, const float* __restrict__ bias,
-                                                float* __restrict__ cat_out, float* __restrict__ out, int T, int Lq) {
+                                                const float* __restrict__ Srow, const float* __restrict__ Mpart,
+                                                float* __restrict__ M, const float* __restrict__ Wpack,
+                                                const float* __restrict__ bias, float* __restrict__ cat_out,
+                                                float* __restrict__ out, int T, int Lq) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int LQ1 = Lq + 1;
     float* Cat = smem;                        // [32][CATP]
     float* Cs = Cat + TILE_M * CATP;          // [32][LDP]
-    float* Ss = Cs + TILE_M * LDP;            // [32][Lq]
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const int b = blockIdx.y, t0 = blockIdx.x * TILE_M;
+    float* Ms = Cs + TILE_M * LDP;            // [Lq][LDP]   M = S_col^T C, summed here from k_cq_col's per-tile partials
+    float* Ss = Ms + Lq * LDP;                // [32][LQ1]   S_row tile, zero pad column
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, hh = lane >> 5;
+    const int b = blockIdx.y, t0 = blockIdx.x * TILE_M, ntile = gridDim.x;
     const size_t crow = (size_t)b * T, qrow = (size_t)b * Lq;
+    BFrag<1, 16> bf;
     load_tile128(Cs, C + crow * D, t0, TILE_M, T);
-    for (int e = tid; e < TILE_M * Lq; e += 256) {
-        const int rr = e / Lq;
-        Ss[e] = (t0 + rr < T) ? Srow[(crow + t0) * Lq + e] : 0.f;
+    for (int e = tid; e < Lq * (D / 4); e += 256) {
+        const int j = e >> 5, c4 = (e & 31) * 4;
+        float4 sm = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int t = 0; t < ntile; ++t) {
+            const float4 v = *reinterpret_cast<const float4*>(Mpart + ((size_t)(b * ntile + t) * Lq + j) * D + c4);
+            sm.x += v.x; sm.y += v.y; sm.z += v.z; sm.w += v.w;
+        }
+        *reinterpret_cast<float4*>(Ms + j * LDP + c4) = sm;
+        if (blockIdx.x == 0) *reinterpret_cast<float4*>(M + (qrow + j) * D + c4) = sm;     // saved for the backward
     }
+    for (int e = tid; e < TILE_M * LQ1; e += 256) {
+        const int rr = e / LQ1, j = e - rr * LQ1;
+        Ss[e] = (j < Lq && t0 + rr < T) ? Srow[(crow + t0 + rr) * Lq + j] : 0.f;
+    }
+    bfrag_load(bf, Wpack, D, 32 * w, 0, 0, 4 * D / 8);
     __syncthreads();
-    cq_build_concat(Cat, Cs, Ss, Qf + qrow * D, M + qrow * D, Lq, CATP);
+    // c2q = S_row Q, q2c = S_row M (:229-230) on the matrix cores (K = Lq, wave = 32 channels), then the concat tile (:231)
+    const int col = 32 * w + (lane & 31);
+    {
+        f32x16 c2q[1], q2c[1];
+        zero_acc(c2q);
+        zero_acc(q2c);
+        const float* sa = Ss + (lane & 31) * LQ1 + hh;
+        for (int jc = 0; jc < Lq; jc += 16) {
+            float sv[8], qv[8], mv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = jc + 2 * u + hh;
+                const bool ok = j < Lq;
+                sv[u] = ok ? sa[jc + 2 * u] : 0.f;
+                qv[u] = ok ? Qf[(qrow + j) * D + col] : 0.f;
+                mv[u] = ok ? Ms[j * LDP + col] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (jc + 2 * u < Lq) {
+                    c2q[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[u], qv[u], c2q[0], 0, 0, 0);
+                    q2c[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[u], mv[u], q2c[0], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rr = acc_row(r, lane);
+            const float cv = Cs[rr * LDP + col];
+            float* o = Cat + rr * CATP;
+            o[col] = cv;
+            o[D + col] = c2q[0][r];
+            o[2 * D + col] = cv * c2q[0][r];
+            o[3 * D + col] = cv * q2c[0][r];
+        }
+    }
     __syncthreads();
     if (cat_out)                                   // saved: A operand (R, 512) of the cqa_linear weight gradient
         for (int e = tid; e < TILE_M * D; e += 256) {
@@ -968,12 +990,7 @@ __global__ __launch_bounds__(256) void k_cq_out(const float* __restrict__ C, con
         }
     f32x16 acc[1];
     zero_acc(acc);
-    {
-        BFrag<1, 16> bf;
-        bfrag_load(bf, Wpack, D, 32 * w, 0, 0, 4 * D / 8);
-        gemm32p<1, 16>(Cat, CATP, 4 * D, Wpack, D, 32 * w, 0, acc, bf);
-    }
-    const int col = 32 * w + (lane & 31);
+    gemm32p<1, 16>(Cat, CATP, 4 * D, Wpack, D, 32 * w, 0, acc, bf);
     const float bv = bias[col];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -981,12 +998,13 @@ __global__ __launch_bounds__(256) void k_cq_out(const float* __restrict__ C, con
         if (t < T) out[(crow + t) * D + col] = acc[0][r] + bv;
     }
 }
-void launch_cq_out(const float* C, const float* Qf, const float* Srow, const float* M, const float* Wpack,
+void launch_cq_out(const float* C, const float* Qf, const float* Srow, const float* Mpart, float* M, const float* Wpack,
                    const float* bias, float* cat_out, float* out, int B, int T, int Lq, hipStream_t s) {
-    const size_t shm = (size_t)(TILE_M * CATP + TILE_M * LDP + TILE_M * Lq) * sizeof(float);
+    const size_t shm = (size_t)(TILE_M * CATP + TILE_M * LDP + Lq * LDP + TILE_M * (Lq + 1)) * sizeof(float);
     static size_t lds_ok = 0;
     ensure_dynamic_lds((const void*)k_cq_out, shm, lds_ok, "k_cq_out");
-    hipLaunchKernelGGL(k_cq_out, dim3((T + TILE_M - 1) / TILE_M, B), dim3(256), shm, s, C, Qf, Srow, M, Wpack, bias, cat_out, out, T, Lq);
+    hipLaunchKernelGGL(k_cq_out, dim3((T + TILE_M - 1) / TILE_M, B), dim3(256), shm, s, C, Qf, Srow, Mpart, M, Wpack, bias, cat_out, out,
+                       T, Lq);
 }
 
 // =========================================================================================================

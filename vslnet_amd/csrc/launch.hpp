@@ -137,9 +137,9 @@ void launch_cq_score(const float* C, const float* Qf, const float* qmask, const 
                      const float* w4mlu, float* S, float* Srow, int B, int T, int Lq, int b_off, Drop dc, Drop dq,
                      hipStream_t s);
 void launch_cq_col(const float* C, const float* Qf, const float* S, const float* cmask, const float* qmask,
-                   const float* pool_w, const float* Wcat, const float* bcat, float* Scol, float* M, float* alpha,
-                   float* pooled, float* pb, int B, int T, int Lq, hipStream_t s);
-void launch_cq_out(const float* C, const float* Qf, const float* Srow, const float* M, const float* Wpack,
+                   const float* pool_w, const float* Wcat, const float* bcat, float* Scol, float* Mpart /*[B][ntile][Lq][128]*/,
+                   float* alpha, float* pooled, float* pb, int B, int T, int Lq, hipStream_t s);
+void launch_cq_out(const float* C, const float* Qf, const float* Srow, const float* Mpart, float* M, const float* Wpack,
                    const float* bias, float* cat_out, float* out, int B, int T, int Lq, hipStream_t s);
 void launch_cqcat_fwd(const float* f1, const float* Wpack, const float* pb, const float* wh, const float* bh,
                       const float* vmask, float* f2, float* hscore, float* gated, int R, int T, hipStream_t s);
