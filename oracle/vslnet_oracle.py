@@ -103,12 +103,39 @@ def depthwise7(x, w):
     return F.conv1d(x.transpose(1, 2), w, padding=k // 2, groups=w.shape[0]).transpose(1, 2)
 
 
+# ReLU decisions of the last forward, in call order (conv layers of venc, qenc, [p1, p2], then the start / end span heads).
+# The gradient is discontinuous where a pre-activation crosses zero, so the GPU parity tests compare these sign patterns
+# with the ones the HIP path saved and only then decide which gradient gate applies (tests/helpers.py: relu_flips).
+RELU_SIGNS = None
+RELU_FORCED = None
+
+
+def record_relu_signs(on=True):
+    global RELU_SIGNS
+    RELU_SIGNS = [] if on else None
+
+
+def force_relu_signs(masks):
+    """Take the given branch (bool tensors, call order) at every ReLU of the next forward instead of sign(z): lets a test
+    evaluate the oracle's gradient ON THE BRANCH THE GPU PATH TOOK when a pre-activation sits inside the forward noise."""
+    global RELU_FORCED
+    RELU_FORCED = list(masks) if masks is not None else None
+
+
+def _relu(z, site):
+    if RELU_SIGNS is not None:
+        RELU_SIGNS.append((site, (z.detach() > 0)))
+    if RELU_FORCED is not None:
+        return z * RELU_FORCED.pop(0).to(z.dtype)
+    return torch.relu(z)
+
+
 def conv_layer(x, ln_g, ln_b, dw_w, pw_w, pw_b, p, training):
     """One iteration of DepthwiseSeparableConvBlock.forward, layers_t7.py:133-139."""
     v = layer_norm(x, ln_g, ln_b)
     u = depthwise7(v, dw_w)
     z = pointwise(u, pw_w, pw_b)
-    return _drop(torch.relu(z), p, training) + x
+    return _drop(_relu(z, 'conv'), p, training) + x
 
 
 def conv_block(P, pre, x, p, training, n_layers=4):
@@ -245,7 +272,7 @@ def span_head(P, name, feat, x):
     """start_block / end_block, layers_t7.py:328-337,349-350: Conv1D(2d->d) + ReLU + Conv1D(d->1)."""
     z = pointwise(torch.cat([feat, x], dim=2), P['predictor.%s_block.0.conv1d.weight' % name],
                   P['predictor.%s_block.0.conv1d.bias' % name])
-    return pointwise(torch.relu(z), P['predictor.%s_block.2.conv1d.weight' % name],
+    return pointwise(_relu(z, 'head_' + name), P['predictor.%s_block.2.conv1d.weight' % name],
                      P['predictor.%s_block.2.conv1d.bias' % name])[..., 0]
 
 

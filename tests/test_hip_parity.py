@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import vslnet_oracle as O
-from tests.helpers import load_golden, grad_tol
+from tests.helpers import load_golden, grad_tol, relu_flips
 
 pytestmark = pytest.mark.gpu
 
@@ -121,7 +121,18 @@ def test_losses_and_every_gradient(name):
     # oracle with autograd, keeping the gradients of the intermediate activations
     Pg = {k: v.clone().requires_grad_(k not in O.FROZEN) for k, v in P.items()}
     want = {}
+    O.record_relu_signs()
+    with torch.no_grad():
+        O.forward(P, cfg, b['word_ids'], b['char_ids'], b['vfeats'], b['v_mask'], b['q_mask'])
+    # The gradient is discontinuous in the activations: a pre-activation inside the ~1e-5 forward noise can put the two
+    # forwards on different branches of a ReLU.  The saved masks tell (tests/helpers.py); if it happened the oracle is
+    # evaluated on the branch the GPU path took, and the reference's own gradients (the golden file) are not comparable.
+    flips, hip_masks = relu_flips(eng, B, T, Lq)
+    O.record_relu_signs(False)
+    if flips:
+        O.force_relu_signs(hip_masks)
     oh, osl, oel = O.forward(Pg, cfg, b['word_ids'], b['char_ids'], b['vfeats'], b['v_mask'], b['q_mask'], want=want)
+    O.force_relu_signs(None)
     keep = {'d_gated': want['gated'], 'd_venc': want['venc'], 'd_qenc': want['qenc'], 'd_video_affine': want['video_affine'],
             'd_embedding_net': want['embedding_net'], 'd_pred_s': want['pred_parts']['pred_s'],
             'd_cq_concat': want['cq_concat'], 'd_cq_attention': want['cq_attention']}
@@ -135,6 +146,7 @@ def test_losses_and_every_gradient(name):
     rep.check('loc_loss', lo[0], z['out.loc_loss'], atol=2e-5)
     rep.check('highlight_loss', lo[1], z['out.highlight_loss'], atol=2e-5)
     sc = lambda g: 1e-4 * float(g.abs().max()) + 1e-6      # noqa: E731  (gradient gate as an absolute tolerance)
+    rep.rows.append('ReLU decisions differing from the oracle: %d%s' % (flips, ' -> oracle re-run on the GPU path branch' if flips else ''))
     for nm, t, g in [('d_start_logits', d_sl, osl.grad), ('d_end_logits', d_el, oel.grad), ('d_h_score', d_h, oh.grad)]:
         rep.check(nm, t, g, atol=sc(g))
     shapes = {'d_gated': (B, T, 128), 'd_venc': (B, T, 128), 'd_qenc': (B, Lq, 128), 'd_video_affine': (B, T, 128),
@@ -158,7 +170,7 @@ def test_losses_and_every_gradient(name):
     for k in z.files:
         if not k.startswith('grad.'):
             continue
-        g_ref = z[k]
+        g_ref = z[k] if not flips else (Pg[k[5:]].grad if Pg[k[5:]].grad is not None else torch.zeros_like(Pg[k[5:]])).numpy()
         got = gv[k[5:]].cpu().numpy()
         err = float(np.abs(got - g_ref).max())
         if not np.isfinite(err):

@@ -29,16 +29,28 @@ def _run(cfg, P, b):
     return eng, h, sl, el, losses, grads
 
 
-def _oracle(cfg, P, b):
-    Pg = {k: v.clone().requires_grad_(k not in O.FROZEN) for k, v in P.items()}
+def _oracle(cfg, P, b, eng=None):
+    """oracle forward + backward; with `eng`, on the ReLU branches the GPU path took (tests/helpers.py: relu_flips)"""
     want = {}
+    if eng is not None:
+        from tests.helpers import relu_flips
+        B, T = b['v_mask'].shape
+        O.record_relu_signs()
+        with torch.no_grad():
+            O.forward(P, cfg, b['word_ids'], b['char_ids'], b['vfeats'], b['v_mask'], b['q_mask'])
+        want['flips'], masks = relu_flips(eng, B, T, b['q_mask'].shape[1], predictor='rnn')
+        O.record_relu_signs(False)
+        if want['flips']:
+            O.force_relu_signs(masks)
+    Pg = {k: v.clone().requires_grad_(k not in O.FROZEN) for k, v in P.items()}
     oh, osl, oel = O.forward(Pg, cfg, b['word_ids'], b['char_ids'], b['vfeats'], b['v_mask'], b['q_mask'], want=want)
+    O.force_relu_signs(None)
     total = O.span_loss(osl, oel, b['s_labels'], b['e_labels']) + 5.0 * O.highlight_loss(oh, b['h_labels'], b['v_mask'])
     total.backward()
     return Pg, want, oh.detach(), osl.detach(), oel.detach(), float(total.detach())
 
 
-def _check_grads(eng, grads, ref, bad):
+def _check_grads(eng, grads, ref, bad, flips=0):
     for k, t in eng.views(grads).items():
         r = ref(k)
         err = float((t.cpu() - r).abs().max())
@@ -61,11 +73,13 @@ def test_rnn_head_matches_reference_golden():
     assert abs(float(losses[0]) - float(z['out.loc_loss'])) <= 2e-5 * max(1.0, abs(float(z['out.loc_loss'])))
     si, ei = eng.extract_index(sl, el)
     assert np.array_equal(si.cpu().numpy(), z['out.start_index']) and np.array_equal(ei.cpu().numpy(), z['out.end_index'])
+    Pg, want, _, _, _, _ = _oracle(cfg, P, b, eng)
     bad = []
-    _check_grads(eng, grads, lambda k: torch.from_numpy(z['grad.' + k]), bad)
-    assert not bad, bad[:6]
+    golden = lambda k: torch.from_numpy(z['grad.' + k])                                   # noqa: E731  the reference's own gradients,
+    forced = lambda k: Pg[k].grad if Pg[k].grad is not None else torch.zeros_like(Pg[k])  # noqa: E731  or the oracle on the GPU branch
+    _check_grads(eng, grads, forced if want['flips'] else golden, bad, want['flips'])
+    assert not bad, (want['flips'], bad[:6])
     # the LSTM outputs themselves (masked h sequences) against the oracle's taps
-    _, want, _, _, _, _ = _oracle(cfg, P, b)
     B, T = b['v_mask'].shape
     for nm in ('pred_s', 'pred_e'):
         assert float((eng.ws_view(nm, (B, T, 128)).cpu() - want['pred_parts'][nm].detach()).abs().max()) <= 1e-5, nm
@@ -77,12 +91,12 @@ def test_rnn_head_against_oracle(shape):
     P = O.random_params(cfg, seed=21)
     b = O.synthetic_batch(cfg, shape['B'], shape['T'], shape['Lq'], shape['Lc'], seed=22, ragged=True)
     eng, h, sl, el, losses, grads = _run(cfg, P, b)
-    Pg, _, oh, osl, oel, total = _oracle(cfg, P, b)
+    Pg, want, oh, osl, oel, total = _oracle(cfg, P, b, eng)
     fin = osl.abs() < 1e29
     scale = max(1.0, float(osl[fin].abs().max()))
     assert float((sl.cpu() - osl)[fin].abs().max()) <= 1e-4 * scale
     assert float((el.cpu() - oel)[fin].abs().max()) <= 1e-4 * scale
     assert abs(float(losses[2]) - total) <= 1e-4 * max(1.0, abs(total))
     bad = []
-    _check_grads(eng, grads, lambda k: Pg[k].grad if Pg[k].grad is not None else torch.zeros_like(Pg[k]), bad)
-    assert not bad, bad[:6]
+    _check_grads(eng, grads, lambda k: Pg[k].grad if Pg[k].grad is not None else torch.zeros_like(Pg[k]), bad, want['flips'])
+    assert not bad, (want['flips'], bad[:6])

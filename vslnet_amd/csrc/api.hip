@@ -1014,6 +1014,18 @@ int64_t vsl_workspace_offset(vsl_handle h, int B, int T, int Lq, int Lc, const c
         {"d_gated_enc", p->g_gated}, {"d_gated_hs", p->dxh_s}, {"d_gated_he", p->dxh_e}, {"d_venc", p->dC}, {"d_qenc", p->dQtot}, {"d_video_affine", p->dvf}, {"d_embedding_net", p->dqf},
         {"d_pred_s", p->g_s1}, {"d_pred_s_head", p->dfeat_s}, {"d_cq_concat", p->df2}, {"d_cq_attention", p->df1}, {"d_emb_concat", p->dE}};
     for (auto& kv : tab) if (n == kv.first) return kv.second;
+    // ReLU decisions of the forward (parity tests count sign flips against the oracle): "relu_<enc>_<layer>" = (R, 4) uint32
+    // bit-masks of conv layer 0..3 of venc / qenc / p1 / p2 ; "hid_s" / "hid_e" = post-ReLU activations of the span heads
+    if (n == "hid_s") return p->hid_s;
+    if (n == "hid_e") return p->hid_e;
+    const std::pair<const char*, const EncWs*> encs[] = {{"relu_venc_", &p->ve}, {"relu_qenc_", &p->qe}, {"relu_p1_", &p->p1}, {"relu_p2_", &p->p2}};
+    for (auto& kv : encs) {
+        const size_t len = strlen(kv.first);
+        if (n.size() == len + 1 && n.compare(0, len, kv.first) == 0 && n[len] >= '0' && n[len] <= '3') {
+            if (h->cfg.predictor == 0 && (kv.second == &p->p1 || kv.second == &p->p2)) return -1;
+            return kv.second->mask[n[len] - '0'];
+        }
+    }
     return -1;
 }
 

@@ -1791,7 +1791,7 @@ void launch_embed_bwd(const float* dE, const int64_t* word_ids, const int64_t* c
     const size_t shm = (size_t)(((char_dim * 300 + 7) & ~3) + (EMB_CHUNK * Lc + 4) * 64 + EMB_CHUNK * 128 + 2 * Lc * 100 + Lc * 64 +
                                 char_size * char_dim) * sizeof(float);
     static size_t lds_ok = 0;
-    ensure_dynamic_lds((const void*)k_embed_bwd, shm + 16 * 1024, lds_ok, "k_embed_bwd");
+    ensure_dynamic_lds((const void*)k_embed_bwd, shm, lds_ok, "k_embed_bwd");
     hipLaunchKernelGGL(k_embed_bwd, dim3((Rq + EMB_CHUNK - 1) / EMB_CHUNK), dim3(256), shm, s, dE, word_ids, char_ids, E, argpos,
                        char_tab, cc, p_cw, p_cb, p_tab, p_unk, Rq, Lc, word_dim, char_dim, char_size, dw, dc);
     static int left = 2;

@@ -720,72 +720,162 @@ __global__ __launch_bounds__(256) void k_cq_score(const float* __restrict__ C, c
                                                   const float* __restrict__ w4Q, const float* __restrict__ w4mlu,
                                                   float* __restrict__ S, float* __restrict__ Srow, int T, int Lq, int b_off,
                                                   Drop dc, Drop dq) {
+    // S[i][j] = Cd[i].w4C + Qd[j].w4Q + (Cd[i] * w4mlu).Qd[j]   (:233-243) on a 32-clip tile; Cd / Qd = dropped-out C / Q.
+    // The trilinear term is a 32 x 32 MFMA tile per 32 query words with K = 128 split over the four waves (partial tiles
+    // summed in wave order through LDS); the two rank-1 terms and the row softmax use 8 lanes per row.
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Cs = smem;                         // [32][LDP]  dropped C * w4mlu
-    float* Qs = Cs + TILE_M * LDP;            // [Lq][LDP]  dropped Q
-    float* s0 = Qs + Lq * LDP;                // [32]
-    float* s1 = s0 + TILE_M;                  // [Lq]
-    float* Sc = s1 + ((Lq + 3) & ~3);         // [32][Lq+1]
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int NTJ = (Lq + 31) >> 5, PJ = 32 * NTJ + 1;
+    float* Cs = smem;                         // [32][LDP]  Cd, then Cd * w4mlu
+    float* Qs = Cs + TILE_M * LDP;            // [32 NTJ][LDP]  Qd (rows >= Lq zero)
+    float* s0 = Qs + 32 * NTJ * LDP;          // [32]
+    float* s1 = s0 + TILE_M;                  // [64]
+    float* Pp = s1 + 64;                      // [4][32][PJ] per-wave partial tiles
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, hh = lane >> 5;
     const int b = blockIdx.y, t0 = blockIdx.x * TILE_M;
     const size_t crow = (size_t)b * T, qrow = (size_t)b * Lq;
-    for (int e = tid; e < TILE_M * D; e += 256) {
-        const int rr = e >> 7, c = e & 127;
-        const int t = t0 + rr;
-        float v = 0.f;
-        if (t < T) v = C[(crow + t) * D + c] * drop_mul(dc, (uint32_t)(((b + b_off) * T + t) * D + c));
-        Cs[rr * LDP + c] = v;
-    }
-    for (int e = tid; e < Lq * D; e += 256) {
-        const int j = e >> 7, c = e & 127;
-        Qs[j * LDP + c] = Qf[(qrow + j) * D + c] * drop_mul(dq, (uint32_t)(((b + b_off) * Lq + j) * D + c));
-    }
-    __syncthreads();
-    // s0[i] = Cd[i] . w4C ; s1[j] = Qd[j] . w4Q   (one wave per row)
-    for (int rr = w; rr < TILE_M + Lq; rr += 4) {
-        const float* row = rr < TILE_M ? Cs + rr * LDP : Qs + (rr - TILE_M) * LDP;
-        const float* wv = rr < TILE_M ? w4C : w4Q;
-        const float d = wave_sum(row[lane] * wv[lane] + row[lane + 64] * wv[lane + 64]);
-        if (lane == 0) { if (rr < TILE_M) s0[rr] = d; else s1[rr - TILE_M] = d; }
-    }
-    __syncthreads();
-    // scale C by w4mlu in place (after s0 used the unscaled values)
-    for (int e = tid; e < TILE_M * D; e += 256) Cs[(e >> 7) * LDP + (e & 127)] *= w4mlu[e & 127];
-    __syncthreads();
-    // S[i][j]: thread (i = tid >> 3, j = tid & 7, +8, ...)
-    {
-        const int i = tid >> 3;
-        const float4* cr = reinterpret_cast<const float4*>(Cs + i * LDP);
-        for (int j = tid & 7; j < Lq; j += 8) {
-            const float4* qr = reinterpret_cast<const float4*>(Qs + j * LDP);
-            float acc = 0.f;
-#pragma unroll 8
-            for (int c = 0; c < 32; ++c) {
-                const float4 a = cr[c], q4 = qr[c];
-                acc += a.x * q4.x + a.y * q4.y + a.z * q4.z + a.w * q4.w;
+    {   // one batch of 16-byte loads for both tiles, dropout applied on the way into LDS
+        float4 cv[4], qv[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + q * 256, rr = e >> 5, c = (e & 31) * 4;
+            const int t = min(t0 + rr, T - 1);
+            cv[q] = *reinterpret_cast<const float4*>(C + (crow + t) * D + c);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = tid + q * 256, j = e >> 5, c = (e & 31) * 4;
+            qv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q < 4 * NTJ) qv[q] = *reinterpret_cast<const float4*>(Qf + (qrow + min(j, Lq - 1)) * D + c);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + q * 256, rr = e >> 5, c = (e & 31) * 4;
+            const int t = t0 + rr;
+            float4 v = cv[q];
+            if (t < T) {
+                if (dc.thresh) {
+                    const uint32_t base = (uint32_t)(((b + b_off) * T + t) * D + c);
+                    v.x *= drop_keep_scale(dc, base); v.y *= drop_keep_scale(dc, base + 1);
+                    v.z *= drop_keep_scale(dc, base + 2); v.w *= drop_keep_scale(dc, base + 3);
+                }
+            } else v = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(&Cs[rr * LDP + c]) = v;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (q < 4 * NTJ) {
+                const int e = tid + q * 256, j = e >> 5, c = (e & 31) * 4;
+                float4 v = qv[q];
+                if (j < Lq) {
+                    if (dq.thresh) {
+                        const uint32_t base = (uint32_t)(((b + b_off) * Lq + j) * D + c);
+                        v.x *= drop_keep_scale(dq, base); v.y *= drop_keep_scale(dq, base + 1);
+                        v.z *= drop_keep_scale(dq, base + 2); v.w *= drop_keep_scale(dq, base + 3);
+                    }
+                } else v = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(&Qs[j * LDP + c]) = v;
             }
-            Sc[i * (Lq + 1) + j] = acc + s0[i] + s1[j];
         }
     }
     __syncthreads();
-    // row softmax over j with the query mask; one wave per row (Lq <= 128: lane handles j = lane, lane + 64)
-    for (int rr = w; rr < TILE_M; rr += 4) {
+    {   // s0[i] = Cd[i] . w4C ; s1[j] = Qd[j] . w4Q ; then Cd *= w4mlu in place.  8 lanes per row, 32 rows per pass.
+        const int sub = tid & 7, rr = tid >> 3;
+        float4 wc[4], wq[4], wm[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            wc[k] = *reinterpret_cast<const float4*>(w4C + sub * 4 + 32 * k);
+            wq[k] = *reinterpret_cast<const float4*>(w4Q + sub * 4 + 32 * k);
+            wm[k] = *reinterpret_cast<const float4*>(w4mlu + sub * 4 + 32 * k);
+        }
+        float d = 0.f;
+        float* crp = Cs + rr * LDP + sub * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float4 v = *reinterpret_cast<const float4*>(crp + 32 * k);
+            d += v.x * wc[k].x + v.y * wc[k].y + v.z * wc[k].z + v.w * wc[k].w;
+            v.x *= wm[k].x; v.y *= wm[k].y; v.z *= wm[k].z; v.w *= wm[k].w;
+            *reinterpret_cast<float4*>(crp + 32 * k) = v;
+        }
+        d = grp8_sum(d);
+        if (sub == 0) s0[rr] = d;
+        for (int jb = 0; jb < 32 * NTJ; jb += 32) {
+            const float* qrp = Qs + (jb + rr) * LDP + sub * 4;
+            float e = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float4 v = *reinterpret_cast<const float4*>(qrp + 32 * k);
+                e += v.x * wq[k].x + v.y * wq[k].y + v.z * wq[k].z + v.w * wq[k].w;
+            }
+            e = grp8_sum(e);
+            if (sub == 0) s1[jb + rr] = e;
+        }
+    }
+    __syncthreads();
+    {   // trilinear term: wave w contracts channels 32w .. 32w+31
+        f32x16 acc[2];
+        zero_acc(acc);
+        const int i = lane & 31;
+        const float* arow = Cs + i * LDP + 4 * hh;
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) {
+            const int kb = 4 * w + kq;
+            const float4 av = *reinterpret_cast<const float4*>(arow + kb * 8);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                if (nt < NTJ) {
+                    const float4 bv = *reinterpret_cast<const float4*>(Qs + (32 * nt + i) * LDP + kb * 8 + 4 * hh);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[nt], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+            if (nt < NTJ) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Pp[(w * TILE_M + acc_row(r, lane)) * PJ + 32 * nt + i] = acc[nt][r];
+            }
+    }
+    __syncthreads();
+    {   // raw score + row softmax over the query words (dim=2, :225) with the query mask; 8 lanes per clip
+        const int sub = tid & 7, rr = tid >> 3;
         const int t = t0 + rr;
-        if (t >= T) continue;
-        float v0 = -3.0e38f, v1 = -3.0e38f, r0 = 0.f, r1 = 0.f;
-        if (lane < Lq) { r0 = Sc[rr * (Lq + 1) + lane]; v0 = r0 + (1.f - qmask[qrow + lane]) * MASK_VALUE; }
-        if (lane + 64 < Lq) { r1 = Sc[rr * (Lq + 1) + lane + 64]; v1 = r1 + (1.f - qmask[qrow + lane + 64]) * MASK_VALUE; }
-        const float mx = wave_max(fmaxf(v0, v1));
-        const float e0 = lane < Lq ? __expf(v0 - mx) : 0.f, e1 = lane + 64 < Lq ? __expf(v1 - mx) : 0.f;
-        const float inv = 1.0f / wave_sum(e0 + e1);
-        if (lane < Lq) { S[(crow + t) * Lq + lane] = r0; Srow[(crow + t) * Lq + lane] = e0 * inv; }
-        if (lane + 64 < Lq) { S[(crow + t) * Lq + lane + 64] = r1; Srow[(crow + t) * Lq + lane + 64] = e1 * inv; }
+        float raw[8], v[8];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = sub + 8 * u;
+            raw[u] = 0.f; v[u] = -3.0e38f;
+            if (j < Lq) {
+                raw[u] = Pp[rr * PJ + j] + Pp[(TILE_M + rr) * PJ + j] + Pp[(2 * TILE_M + rr) * PJ + j] + Pp[(3 * TILE_M + rr) * PJ + j] +
+                         s0[rr] + s1[j];
+                v[u] = raw[u] + (1.f - qmask[qrow + j]) * MASK_VALUE;
+                mx = fmaxf(mx, v[u]);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 1)); mx = fmaxf(mx, __shfl_xor(mx, 2)); mx = fmaxf(mx, __shfl_xor(mx, 4));
+        float sm = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { v[u] = (sub + 8 * u < Lq) ? __expf(v[u] - mx) : 0.f; sm += v[u]; }
+        const float inv = 1.0f / grp8_sum(sm);
+        if (t < T) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = sub + 8 * u;
+                if (j < Lq) { S[(crow + t) * Lq + j] = raw[u]; Srow[(crow + t) * Lq + j] = v[u] * inv; }
+            }
+        }
     }
 }
 void launch_cq_score(const float* C, const float* Qf, const float* qmask, const float* w4C, const float* w4Q,
                      const float* w4mlu, float* S, float* Srow, int B, int T, int Lq, int b_off, Drop dc, Drop dq,
                      hipStream_t s) {
-    const size_t shm = (size_t)((TILE_M + Lq) * LDP + TILE_M + ((Lq + 3) & ~3) + TILE_M * (Lq + 1)) * sizeof(float);
+    const int NTJ = (Lq + 31) / 32;
+    const size_t shm = (size_t)((TILE_M + 32 * NTJ) * LDP + TILE_M + 64 + 4 * TILE_M * (32 * NTJ + 1)) * sizeof(float);
+    static size_t lds_ok = 0;
+    ensure_dynamic_lds((const void*)k_cq_score, shm, lds_ok, "k_cq_score");
     hipLaunchKernelGGL(k_cq_score, dim3((T + TILE_M - 1) / TILE_M, B), dim3(256), shm, s, C, Qf, qmask, w4C, w4Q, w4mlu, S,
                        Srow, T, Lq, b_off, dc, dq);
 }
