@@ -1607,6 +1607,7 @@ void launch_linear_bwd_data(const float* G, const float* WTpack, float* dA, int 
 //        (thread = (p, ci), serial over p -> no atomics).
 // =========================================================================================================
 constexpr int EB_NP = 25;                     // (100 channels x 64 lanes) / 256 threads
+constexpr int EB_GP = 301;                    // LDS row stride of the per-word tap matrix G (odd: conflict-free column reads)
 __global__ __launch_bounds__(256) void k_embed_bwd(const float* __restrict__ dE, const int64_t* __restrict__ word_ids,
                                                    const int64_t* __restrict__ char_ids, const float* __restrict__ E,
                                                    const int8_t* __restrict__ argpos, const float* __restrict__ char_tab,
@@ -1618,10 +1619,10 @@ __global__ __launch_bounds__(256) void k_embed_bwd(const float* __restrict__ dE,
     float* Wl = smem;                         // [wtot + 4] conv weights, flattened conv0 | conv1 | conv2 | conv3
     float* Ce = Wl + ((wtot + 7) & ~3);       // [EMB_CHUNK * Lc + 4][64] dropped char embeddings (+ zero rows)
     float* gch = Ce + (EMB_CHUNK * Lc + 4) * 64;   // [EMB_CHUNK][128] grads of the 100 char features (0 where inactive)
-    float* gt = gch + EMB_CHUNK * 128;        // [Lc][100] per-word table: g[oc] where tap p - pos[oc] is valid, else 0
-    float* tab = gt + Lc * 100;               // [char_size][char_dim] table-gradient accumulator
+    float* Gm = gch + EMB_CHUNK * 128;        // [16][EB_GP] G tile of the current word (zero except <= 300 entries)
+    float* tab = Gm + 16 * EB_GP;             // [char_size][char_dim] table-gradient accumulator
     float* dce = tab + char_size * char_dim;  // [Lc][64] char-embedding gradients of the current word
-    int* it = reinterpret_cast<int*>(dce + Lc * 64);                   // [Lc][100] weight offset | tap stride << 24
+    int* kmap = reinterpret_cast<int*>(dce + Lc * 64);   // [304] tap k -> oc | kk << 8 | k_oc << 10 | (weight offset of (oc, ci=0, kk)) << 13
     __shared__ int pos[EMB_CHUNK * 128];
     __shared__ int cids[EMB_CHUNK * MAX_LC];
     __shared__ int obase[128], okk[128];
@@ -1651,6 +1652,15 @@ __global__ __launch_bounds__(256) void k_embed_bwd(const float* __restrict__ dE,
         else if (tid < 100) { k = 4; base = s0 + s1 + s2 + (tid - 60) * char_dim * 4; }
         okk[tid] = k; obase[tid] = base;
     }
+    for (int e = tid; e < 304; e += 256) {       // tap table: conv c has 10 (c + 1) channels x (c + 1) taps
+        int oc = 100, kk = 0, k = 1, base = wtot;
+        if (e < 10) { oc = e; kk = 0; k = 1; base = oc * char_dim; }
+        else if (e < 50) { oc = 10 + (e - 10) / 2; kk = (e - 10) % 2; k = 2; base = s0 + (oc - 10) * char_dim * 2; }
+        else if (e < 140) { oc = 30 + (e - 50) / 3; kk = (e - 50) % 3; k = 3; base = s0 + s1 + (oc - 30) * char_dim * 3; }
+        else if (e < 300) { oc = 60 + (e - 140) / 4; kk = (e - 140) % 4; k = 4; base = s0 + s1 + s2 + (oc - 60) * char_dim * 4; }
+        kmap[e] = oc | (kk << 8) | (k << 10) | ((base + kk) << 13);
+    }
+    for (int e = tid; e < 16 * EB_GP; e += 256) Gm[e] = 0.f;
     for (int e = tid; e < char_size * char_dim; e += 256) tab[e] = 0.f;
     for (int e = tid; e < 4 * 64; e += 256) Ce[EMB_CHUNK * Lc * 64 + e] = 0.f;
     for (int e = tid; e < EMB_CHUNK * MAX_LC; e += 256) {
@@ -1714,53 +1724,61 @@ __global__ __launch_bounds__(256) void k_embed_bwd(const float* __restrict__ dE,
         }
     }
     STAMP(3);
-    // ---- (ii) char-embedding gradients -> table accumulator
-    for (int wi = 0; wi < nw; ++wi) {
-        const int r = rbeg + wi;
-        for (int e = tid; e < Lc * 100; e += 256) {      // pre-pass: resolve (p, oc) -> (gradient or 0, weight offset, stride)
-            const int p = e / 100, oc = e - p * 100;
-            const int kk = p - pos[wi * 128 + oc], k = okk[oc];
-            const bool ok = kk >= 0 && kk < k;
-            gt[e] = ok ? gch[wi * 128 + oc] : 0.f;
-            it[e] = ok ? (obase[oc] + kk) | (k << 24) : wtot;
+    // ---- (ii) char-embedding gradients -> table accumulator.  Per word this is a small dense product
+    //        dCe[p][ci] = sum_k G[p][k] W[k][ci],   k = (oc, tap) over the 300 taps of the four convs,
+    //      where G has ONE non-zero per k (the arg-max position of channel oc, shifted by the tap).  G (Lc x 300) is
+    //      scattered into LDS, the product runs on the matrix cores (wave = 16 input channels, 75 MFMAs of 16x16x4), the
+    //      entries are cleared again, and the result is scattered per character into the table accumulator.
+    {
+        const int w = tid >> 6, lane = tid & 63, jl = lane & 15, g4 = lane >> 4;
+        const int ci = 16 * w + jl;
+        const int nmt = (Lc + 15) >> 4;
+        // B operand of every MFMA (W[k][ci] for this lane's channel and its 75 k-slots): word-independent -> registers
+        float wreg[75];
+#pragma unroll
+        for (int q = 0; q < 75; ++q) {
+            const int m = kmap[4 * q + g4];
+            wreg[q] = Wl[(m >> 13) + ci * ((m >> 10) & 7)];
         }
-        __syncthreads();
-        if (tid < 4 * 64) {                              // thread = (position quarter, ci): serial over its positions
-            const int ci = tid & 63, pq = tid >> 6;
-            if (ci < char_dim)
-                for (int p = pq; p < Lc; p += 4) {
-                    const int cid = cids[wi * MAX_LC + p];
-                    if (cid == 0) continue;              // padding_idx = 0 (:51)
-                    const float* gr = gt + p * 100;
-                    const int* ir = it + p * 100;
-                    float a0 = 0.f, a1 = 0.f;
-                    for (int oc0 = 0; oc0 < 100; oc0 += 20) {        // explicit batches: 20 table entries, then the 20
-                        int ii[20];                                 // dependent weight reads, then the FMAs
-                        float gg[20], ww[20];
-#pragma unroll
-                        for (int q = 0; q < 5; ++q) {
-                            const int4 iv = *reinterpret_cast<const int4*>(ir + oc0 + 4 * q);
-                            const float4 gv = *reinterpret_cast<const float4*>(gr + oc0 + 4 * q);
-                            ii[4 * q] = iv.x; ii[4 * q + 1] = iv.y; ii[4 * q + 2] = iv.z; ii[4 * q + 3] = iv.w;
-                            gg[4 * q] = gv.x; gg[4 * q + 1] = gv.y; gg[4 * q + 2] = gv.z; gg[4 * q + 3] = gv.w;
-                        }
-#pragma unroll
-                        for (int q = 0; q < 20; ++q) ww[q] = Wl[(ii[q] & 0xFFFFFF) + ci * (ii[q] >> 24)];
-#pragma unroll
-                        for (int q = 0; q < 20; q += 2) { a0 += gg[q] * ww[q]; a1 += gg[q + 1] * ww[q + 1]; }
-                    }
-                    dce[p * 64 + ci] = (a0 + a1) * drop_mul(dc, (uint32_t)((r * Lc + p) * char_dim + ci));
+        for (int wi = 0; wi < nw; ++wi) {
+            const int r = rbeg + wi;
+            for (int mt = 0; mt < nmt; ++mt) {               // 16 positions at a time (G tile of 16 x 300 in LDS)
+                for (int e = tid; e < 300; e += 256) {       // one entry per tap: row = pos[oc] + kk
+                    const int km = kmap[e], oc = km & 0xFF, kk = (km >> 8) & 3;
+                    const int row = pos[wi * 128 + oc] + kk - 16 * mt;
+                    if (row >= 0 && row < 16) Gm[row * EB_GP + e] = gch[wi * 128 + oc];
                 }
-        }
-        __syncthreads();
-        // scatter per character: thread = input channel, serial over the positions (two positions of one word may hold
-        // the same character) -> one table accumulator, no atomics
-        if (tid < char_dim)
-            for (int p = 0; p < Lc; ++p) {
-                const int cid = cids[wi * MAX_LC + p];
-                if (cid != 0) tab[cid * char_dim + tid] += dce[p * 64 + tid];
+                __syncthreads();
+                f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+                const float* grow = Gm + jl * EB_GP + g4;    // A operand: row = position, k-slot = lane >> 4
+#pragma unroll
+                for (int q = 0; q < 74; q += 2) {
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(grow[4 * q], wreg[q], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(grow[4 * q + 4], wreg[q + 1], a1, 0, 0, 0);
+                }
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(grow[4 * 74], wreg[74], a0, 0, 0, 0);
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int p = 16 * mt + 4 * g4 + rr;
+                    if (p < Lc && ci < char_dim)
+                        dce[p * 64 + ci] = (a0[rr] + a1[rr]) * drop_mul(dc, (uint32_t)((r * Lc + p) * char_dim + ci));
+                }
+                __syncthreads();
+                for (int e = tid; e < 300; e += 256) {       // clear the entries of this tile
+                    const int km = kmap[e], oc = km & 0xFF, kk = (km >> 8) & 3;
+                    const int row = pos[wi * 128 + oc] + kk - 16 * mt;
+                    if (row >= 0 && row < 16) Gm[row * EB_GP + e] = 0.f;
+                }
             }
-        __syncthreads();
+            // scatter per character: thread = input channel, serial over the positions (two positions of one word may hold
+            // the same character) -> one table accumulator, no atomics.  (dce is complete: barrier after the last tile.)
+            if (tid < char_dim)
+                for (int p = 0; p < Lc; ++p) {
+                    const int cid = cids[wi * MAX_LC + p];
+                    if (cid != 0) tab[cid * char_dim + tid] += dce[p * 64 + tid];      // padding_idx = 0 (:51)
+                }
+            __syncthreads();
+        }
     }
     STAMP(4);
     {
@@ -1788,8 +1806,8 @@ void launch_embed_bwd(const float* dE, const int64_t* word_ids, const int64_t* c
                       const int8_t* argpos, const float* char_tab, CharConvPtrs cc, float* p_cw, float* p_cb,
                       float* p_tab, float* p_unk, int Rq, int Lc, int word_dim, int char_dim, int char_size, Drop dw, Drop dc,
                       hipStream_t s) {
-    const size_t shm = (size_t)(((char_dim * 300 + 7) & ~3) + (EMB_CHUNK * Lc + 4) * 64 + EMB_CHUNK * 128 + 2 * Lc * 100 + Lc * 64 +
-                                char_size * char_dim) * sizeof(float);
+    const size_t shm = (size_t)(((char_dim * 300 + 7) & ~3) + (EMB_CHUNK * Lc + 4) * 64 + EMB_CHUNK * 128 + 16 * EB_GP + Lc * 64 +
+                                char_size * char_dim + 304) * sizeof(float);
     static size_t lds_ok = 0;
     ensure_dynamic_lds((const void*)k_embed_bwd, shm, lds_ok, "k_embed_bwd");
     hipLaunchKernelGGL(k_embed_bwd, dim3((Rq + EMB_CHUNK - 1) / EMB_CHUNK), dim3(256), shm, s, dE, word_ids, char_ids, E, argpos,
