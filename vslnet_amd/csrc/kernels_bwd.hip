@@ -1621,8 +1621,8 @@ __global__ __launch_bounds__(256) void k_embed_bwd(const float* __restrict__ dE,
     float* gch = Ce + (EMB_CHUNK * Lc + 4) * 64;   // [EMB_CHUNK][128] grads of the 100 char features (0 where inactive)
     float* Gm = gch + EMB_CHUNK * 128;        // [16][EB_GP] G tile of the current word (zero except <= 300 entries)
     float* tab = Gm + 16 * EB_GP;             // [char_size][char_dim] table-gradient accumulator
-    float* dce = tab + char_size * char_dim;  // [Lc][64] char-embedding gradients of the current word
-    int* kmap = reinterpret_cast<int*>(dce + Lc * 64);   // [304] tap k -> oc | kk << 8 | k_oc << 10 | (weight offset of (oc, ci=0, kk)) << 13
+    float* dce = tab + char_size * char_dim;  // [2][Lc][64] char-embedding gradients of the current / previous word
+    int* kmap = reinterpret_cast<int*>(dce + 2 * Lc * 64);   // [304] tap k -> oc | kk << 8 | k_oc << 10 | (weight offset of (oc, ci=0, kk)) << 13
     __shared__ int pos[EMB_CHUNK * 128];
     __shared__ int cids[EMB_CHUNK * MAX_LC];
     __shared__ int obase[128], okk[128];
@@ -1631,17 +1631,32 @@ __global__ __launch_bounds__(256) void k_embed_bwd(const float* __restrict__ dE,
     const int rbeg = blockIdx.x * EMB_CHUNK, nw = min(EMB_CHUNK, Rq - rbeg);
     const int s0 = 10 * char_dim, s1 = 20 * char_dim * 2, s2 = 30 * char_dim * 3;
     STAMP(0);
-    // ---- bulk phase 1: weights + per-word metadata
-    for (int e0 = 0; e0 < wtot; e0 += 8 * 256) {
-        float v[8];
+    // ---- bulk phase 1: weights + per-word metadata.  The four conv weights are flattened back to back; every load of a
+    //      thread is issued before the first LDS store, so the 15000 floats cost ONE memory latency (they were 8 batches)
+    {
+        const int n0 = s0, n1 = s1, n2 = s2, n3 = 40 * char_dim * 4;
+        constexpr int MAXQ = 13;                         // ceil(64 * 40 * 4 / 4 / 256) float4 per thread for the widest conv
+        const float* src[4] = {cc.w[0], cc.w[1], cc.w[2], cc.w[3]};
+        const int cnt[4] = {n0, n1, n2, n3}, off[4] = {0, n0, n0 + n1, n0 + n1 + n2};
+        float4 v[4][MAXQ];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int e = e0 + tid + q * 256;
-            v[q] = 0.f;
-            if (e < wtot) v[q] = e < s0 ? cc.w[0][e] : (e < s0 + s1 ? cc.w[1][e - s0] : (e < s0 + s1 + s2 ? cc.w[2][e - s0 - s1] : cc.w[3][e - s0 - s1 - s2]));
-        }
+        for (int c4 = 0; c4 < 4; ++c4)
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { const int e = e0 + tid + q * 256; if (e < wtot) Wl[e] = v[q]; }
+            for (int q = 0; q < MAXQ; ++q) {
+                const int e = (tid + q * 256) * 4;
+                v[c4][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if ((c4 == 3 || q < (c4 == 0 ? 1 : c4 == 1 ? 3 : 7)) && e < cnt[c4]) v[c4][q] = *reinterpret_cast<const float4*>(src[c4] + e);
+            }
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4)
+#pragma unroll
+            for (int q = 0; q < MAXQ; ++q) {
+                const int e = (tid + q * 256) * 4;
+                if ((c4 == 3 || q < (c4 == 0 ? 1 : c4 == 1 ? 3 : 7)) && e < cnt[c4]) {      // counts are multiples of 4 (char_dim * 10 * ...)
+                    float* d = Wl + off[c4] + e;
+                    d[0] = v[c4][q].x; d[1] = v[c4][q].y; d[2] = v[c4][q].z; d[3] = v[c4][q].w;
+                }
+            }
     }
     if (tid < 4) Wl[wtot + tid] = 0.f;        // zero slot for invalid taps
     if (tid < 128) {
@@ -1740,14 +1755,22 @@ __global__ __launch_bounds__(256) void k_embed_bwd(const float* __restrict__ dE,
             const int m = kmap[4 * q + g4];
             wreg[q] = Wl[(m >> 13) + ci * ((m >> 10) & 7)];
         }
+        // work items = (word, 16-position tile).  fill(item) scatters the tile's entries of G; after the MFMAs of an item
+        // every thread clears its own entries and writes those of the NEXT item (same thread, program order: no barrier in
+        // between).  dce is double-buffered by word, so the serial per-character scatter of a finished word overlaps the
+        // fill / MFMAs of the next one.  Two barriers per item.
+        auto fill = [&](int wi, int mt, bool set) {
+            for (int e = tid; e < 300; e += 256) {           // one entry per tap: row = pos[oc] + kk
+                const int km = kmap[e], oc = km & 0xFF, kk = (km >> 8) & 3;
+                const int row = pos[wi * 128 + oc] + kk - 16 * mt;
+                if (row >= 0 && row < 16) Gm[row * EB_GP + e] = set ? gch[wi * 128 + oc] : 0.f;
+            }
+        };
+        if (nw > 0) fill(0, 0, true);
         for (int wi = 0; wi < nw; ++wi) {
             const int r = rbeg + wi;
-            for (int mt = 0; mt < nmt; ++mt) {               // 16 positions at a time (G tile of 16 x 300 in LDS)
-                for (int e = tid; e < 300; e += 256) {       // one entry per tap: row = pos[oc] + kk
-                    const int km = kmap[e], oc = km & 0xFF, kk = (km >> 8) & 3;
-                    const int row = pos[wi * 128 + oc] + kk - 16 * mt;
-                    if (row >= 0 && row < 16) Gm[row * EB_GP + e] = gch[wi * 128 + oc];
-                }
+            float* dcw = dce + (wi & 1) * Lc * 64;
+            for (int mt = 0; mt < nmt; ++mt) {
                 __syncthreads();
                 f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
                 const float* grow = Gm + jl * EB_GP + g4;    // A operand: row = position, k-slot = lane >> 4
@@ -1761,24 +1784,22 @@ __global__ __launch_bounds__(256) void k_embed_bwd(const float* __restrict__ dE,
                 for (int rr = 0; rr < 4; ++rr) {
                     const int p = 16 * mt + 4 * g4 + rr;
                     if (p < Lc && ci < char_dim)
-                        dce[p * 64 + ci] = (a0[rr] + a1[rr]) * drop_mul(dc, (uint32_t)((r * Lc + p) * char_dim + ci));
+                        dcw[p * 64 + ci] = (a0[rr] + a1[rr]) * drop_mul(dc, (uint32_t)((r * Lc + p) * char_dim + ci));
                 }
                 __syncthreads();
-                for (int e = tid; e < 300; e += 256) {       // clear the entries of this tile
-                    const int km = kmap[e], oc = km & 0xFF, kk = (km >> 8) & 3;
-                    const int row = pos[wi * 128 + oc] + kk - 16 * mt;
-                    if (row >= 0 && row < 16) Gm[row * EB_GP + e] = 0.f;
-                }
+                fill(wi, mt, false);
+                if (mt + 1 < nmt) fill(wi, mt + 1, true);
+                else if (wi + 1 < nw) fill(wi + 1, 0, true);
             }
             // scatter per character: thread = input channel, serial over the positions (two positions of one word may hold
-            // the same character) -> one table accumulator, no atomics.  (dce is complete: barrier after the last tile.)
+            // the same character) -> one table accumulator, no atomics
             if (tid < char_dim)
                 for (int p = 0; p < Lc; ++p) {
                     const int cid = cids[wi * MAX_LC + p];
-                    if (cid != 0) tab[cid * char_dim + tid] += dce[p * 64 + tid];      // padding_idx = 0 (:51)
+                    if (cid != 0) tab[cid * char_dim + tid] += dcw[p * 64 + tid];      // padding_idx = 0 (:51)
                 }
-            __syncthreads();
         }
+        __syncthreads();
     }
     STAMP(4);
     {
@@ -1806,7 +1827,7 @@ void launch_embed_bwd(const float* dE, const int64_t* word_ids, const int64_t* c
                       const int8_t* argpos, const float* char_tab, CharConvPtrs cc, float* p_cw, float* p_cb,
                       float* p_tab, float* p_unk, int Rq, int Lc, int word_dim, int char_dim, int char_size, Drop dw, Drop dc,
                       hipStream_t s) {
-    const size_t shm = (size_t)(((char_dim * 300 + 7) & ~3) + (EMB_CHUNK * Lc + 4) * 64 + EMB_CHUNK * 128 + 16 * EB_GP + Lc * 64 +
+    const size_t shm = (size_t)(((char_dim * 300 + 7) & ~3) + (EMB_CHUNK * Lc + 4) * 64 + EMB_CHUNK * 128 + 16 * EB_GP + 2 * Lc * 64 +
                                 char_size * char_dim + 304) * sizeof(float);
     static size_t lds_ok = 0;
     ensure_dynamic_lds((const void*)k_embed_bwd, shm, lds_ok, "k_embed_bwd");
