@@ -398,10 +398,14 @@ void wgrad_flush(Ctx& c, hipStream_t sw) {
 }
 // after a fork the chain that finishes LAST should own the main stream: its join wait is then already satisfied (a wait on
 // an event that has just been signalled costs 10 - 22 us).  At the headline shape the query side is the long one.
-bool query_chain_is_longer(const Plan& p) {
-    static const char* e = getenv("VSL_SWAP_CHAINS");     // measured: -0.5 % alone, +0.5 % together with the batched ordering
-    (void)p;
-    return e && e[0] == '1';
+bool query_chain_is_longer(const Plan& p, bool forward) {
+    // forward: embed_fwd + linear + query encoder (200 us) vs visual projection + video encoder (170 us) at the headline
+    // shape -> the query branch keeps main (saves the 23 us join).  backward: measured neutral -> off.  VSL_SWAP_FWD/BWD=0/1.
+    static const char* ef = getenv("VSL_SWAP_FWD");
+    static const char* eb = getenv("VSL_SWAP_BWD");
+    const char* e = forward ? ef : eb;
+    if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
+    return forward && (int64_t)p.B * p.T <= 8192 && (int64_t)p.B * p.Lq >= 1024;
 }
 
 // dropout site ids: encoder application `app` (0 video, 1 query, 2 predictor pass 1, 3 predictor pass 2) uses
@@ -447,7 +451,7 @@ void run_forward(Ctx& c) {
     // fork: the query branch (embedding + query encoder pass) runs beside the video branch
     hipStream_t sq = c.side(0);
     c.order(c.main, sq);
-    const bool qlong = query_chain_is_longer(p);        // the longer branch keeps the main stream (join wait already satisfied)
+    const bool qlong = query_chain_is_longer(p, true);  // the longer branch keeps the main stream (join wait already satisfied)
     c.s = qlong ? sq : c.main;
     LAUNCH("vproj_fwd", launch_vproj_fwd(io.video_features, c.PK(K.va_f), c.P(P.va_b), c.W(p.vf), R, cf.video_feature_dim, c.drop(SITE_VIS), c.s));
     enc_fwd(c, P.fe, K.fe, p.ve, c.W(p.vf), io.v_mask, B, 0);
@@ -730,7 +734,7 @@ void run_backward(Ctx& c) {
     { hipStream_t keep = c.s; c.s = sw; LAUNCH("reduce", launch_reduce(c.ws, io->grads, p.segs_dev, p.blk2seg_dev, p.nblocks_early, c.s)); c.s = keep; }
     // from here the video side and the query side are independent; the longer one keeps the main stream
     hipStream_t main_s = c.s;
-    const bool qlong = query_chain_is_longer(p);
+    const bool qlong = query_chain_is_longer(p, false);
     c.s = qlong ? sq : main_s;
     WgradBatch pw_video;
     memset(&pw_video, 0, sizeof pw_video);
