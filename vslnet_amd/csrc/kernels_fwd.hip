@@ -210,54 +210,96 @@ __global__ __launch_bounds__(512) void k_embed_fwd(const int64_t* __restrict__ w
     }
     __syncthreads();
     FSTAMP(3);
-    // ---- items (word, channel): 8 * 100 items over 256 threads
-    for (int item = tid; item < nw * 100; item += NT) {
-        const int wi = item / 100, oc = item - wi * 100;
-        int k, ch;
-        const float* bias;
-        if (oc < 10) { k = 1; ch = oc; bias = cc.b[0]; }
-        else if (oc < 30) { k = 2; ch = oc - 10; bias = cc.b[1]; }
-        else if (oc < 60) { k = 3; ch = oc - 30; bias = cc.b[2]; }
-        else { k = 4; ch = oc - 60; bias = cc.b[3]; }
-        const float bv = bias[ch];
-        const float* wt = Wt + oc;
-        const float* ce = CeT + wi * char_dim * EF_PT;
-        const int npos = Lc - k + 1;
-        float best = -1.f;
-        int bestp = 0;
-        for (int p0 = 0; p0 < npos; p0 += 8) {
-            float acc[8];
+    // ---- char CNN on the matrix cores: out[p][oc] = sum_{kk, ci} Ce[p + kk][ci] W[oc][ci][kk] is a (positions x 4*char_dim)
+    //      x (4*char_dim x 100) product per word (taps beyond a channel's kernel width are zero in the image).  wave = word,
+    //      16 positions per MFMA tile, 7 tiles of 16 channels share every A operand; bias + ReLU + max / arg-max over the
+    //      positions (:58, 69-70) happen in the accumulator registers and two shuffles.
+    {
+        const int w = tid >> 6, lane = tid & 63, jl = lane & 15, g4 = lane >> 4;
+        if (w < nw) {
+            const float* ce = CeT + w * char_dim * EF_PT;
+            const int ncg = (char_dim + 3) >> 2;
+            float best[7], bias[7];
+            int bestp[7], kw[7];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) acc[q] = bv;
-#pragma unroll 5
-            for (int ci = 0; ci < char_dim; ++ci) {
-                const float4 x0 = *reinterpret_cast<const float4*>(ce + ci * EF_PT + p0);
-                const float4 x1 = *reinterpret_cast<const float4*>(ce + ci * EF_PT + p0 + 4);
-                const float4 x2 = *reinterpret_cast<const float4*>(ce + ci * EF_PT + p0 + 8);
-                const float win[12] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2.x, x2.y, x2.z, x2.w};
-                const float* wr = wt + ci * 400;
-                const float w0 = wr[0], w1 = wr[100], w2 = wr[200], w3 = wr[300];      // zero beyond the kernel width
-#pragma unroll
-                for (int q = 0; q < 8; ++q) acc[q] += w0 * win[q] + w1 * win[q + 1] + w2 * win[q + 2] + w3 * win[q + 3];
+            for (int nt = 0; nt < 7; ++nt) {
+                const int oc = 16 * nt + jl;
+                best[nt] = -1.f; bestp[nt] = 0;
+                kw[nt] = oc < 10 ? 1 : oc < 30 ? 2 : oc < 60 ? 3 : 4;
+                bias[nt] = oc < 10 ? cc.b[0][oc] : oc < 30 ? cc.b[1][oc - 10] : oc < 60 ? cc.b[2][oc - 30] : oc < 100 ? cc.b[3][oc - 60] : 0.f;
             }
+            for (int mt = 0; 16 * mt < Lc; ++mt) {
+                f32x4 acc[7];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const float v = fmaxf(acc[q], 0.f);                 // ReLU before the max (:58,69-70)
-                if (p0 + q < npos && v > best) { best = v; bestp = p0 + q; }
+                for (int nt = 0; nt < 7; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    // operands of step cg + 1 are requested before the MFMAs of step cg (one-deep register pipeline)
+                    float av, bv[7], an, bn[7];
+                    auto ld = [&](int cg, float& a_, float (&b_)[7]) {
+                        const int ci = 4 * cg + g4;
+                        const bool okc = ci < char_dim;
+                        a_ = okc ? ce[ci * EF_PT + 16 * mt + jl + kk] : 0.f;
+                        const float* wr = Wt + (ci * 4 + kk) * 100 + jl;
+#pragma unroll
+                        for (int nt = 0; nt < 7; ++nt)
+                            if ((kk < 2) || (kk == 2 && nt >= 1) || (kk == 3 && nt >= 3))
+                                b_[nt] = (okc && 16 * nt + jl < 100) ? wr[16 * nt] : 0.f;
+                    };
+                    ld(0, av, bv);
+                    for (int cg = 0; cg < ncg; ++cg) {
+                        if (cg + 1 < ncg) ld(cg + 1, an, bn);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int nt = 0; nt < 7; ++nt) {
+                            // channel tiles whose widest kernel is narrower than this tap hold only zeros: skipped
+                            if ((kk < 2) || (kk == 2 && nt >= 1) || (kk == 3 && nt >= 3))
+                                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[nt], acc[nt], 0, 0, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        av = an;
+#pragma unroll
+                        for (int nt = 0; nt < 7; ++nt) bv[nt] = bn[nt];
+                    }
+                }
+#pragma unroll
+                for (int nt = 0; nt < 7; ++nt) {
+                    const int npos = Lc - kw[nt] + 1;
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int pp = 16 * mt + 4 * g4 + rr;
+                        const float v = fmaxf(acc[nt][rr] + bias[nt], 0.f);
+                        if (pp < npos && v > best[nt]) { best[nt] = v; bestp[nt] = pp; }     // first maximum wins
+                    }
+                }
+            }
+            const int r = rbeg + w;
+#pragma unroll
+            for (int nt = 0; nt < 7; ++nt) {
+                float bv = best[nt];
+                int bp = bestp[nt];
+#pragma unroll
+                for (int o = 16; o <= 32; o <<= 1) {               // combine the 4 position groups, lowest position on ties
+                    const float ov = __shfl_xor(bv, o);
+                    const int op = __shfl_xor(bp, o);
+                    if (ov > bv || (ov == bv && op < bp)) { bv = ov; bp = op; }
+                }
+                const int oc = 16 * nt + jl;
+                if (g4 == 0 && oc < 100) {
+                    E[(size_t)r * EW + word_dim + oc] = bv;
+                    argpos[(size_t)r * 100 + oc] = (int8_t)bp;
+                }
             }
         }
-        const int r = rbeg + wi;
-        E[(size_t)r * EW + word_dim + oc] = best;
-        argpos[(size_t)r * 100 + oc] = (int8_t)bestp;
     }
     FSTAMP(4);
 }
 void launch_embed_fwd(const int64_t* word_ids, const int64_t* char_ids, const float* pad_vec, const float* unk_vec,
                       const float* glove, const float* char_tab, CharConvPtrs cc, const float* wimg, float* E, int8_t* argpos,
                       int Rq, int Lc, int word_dim, int char_dim, Drop dw, Drop dc, hipStream_t s) {
-    const size_t shm = (size_t)(char_dim * 400 + EF_CHUNK * char_dim * EF_PT) * sizeof(float);
+    const size_t shm = (size_t)(char_dim * 400 + EF_CHUNK * char_dim * EF_PT + 32) * sizeof(float);   // + slack: invalid positions over-read
     static size_t lds_ok = 0;
-    ensure_dynamic_lds((const void*)k_embed_fwd, shm + 4096, lds_ok, "k_embed_fwd");
+    ensure_dynamic_lds((const void*)k_embed_fwd, shm, lds_ok, "k_embed_fwd");
     hipLaunchKernelGGL(k_embed_fwd, dim3((Rq + EF_CHUNK - 1) / EF_CHUNK), dim3(512), shm, s, word_ids, char_ids, pad_vec, unk_vec,
                        glove, char_tab, cc, wimg, E, argpos, Rq, Lc, word_dim, char_dim, dw, dc);
     static int left = 2;
