@@ -122,7 +122,8 @@ def main():
         raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d' % (args.gpus, world, args.gpus))
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or 'TORCHELASTIC_RUN_ID' in os.environ or os.environ.get('VSL_FORCE_DIST') == '1':
+        # (a single-rank torchrun launch takes the same RCCL path: init, all-reduce of the flat bucket, barrier)
         import torch.distributed as dist
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))     # RCCL over xGMI

@@ -1291,11 +1291,12 @@ __device__ __forceinline__ void cq_sum_dM(float* dMs, const float* __restrict__ 
 __global__ __launch_bounds__(256) void k_cq_bwd_b(CqBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int T = a.T, Lq = a.Lq, LQ1 = Lq + 1;
-    float* dMs = smem;                         // [Lq][LDP]
-    float* Cs = dMs + Lq * LDP;                // [32][LDP]
+    const int NTJ = (Lq + 31) >> 5, PJ = 32 * NTJ + 1;
+    float* dMs = smem;                         // [32 NTJ][LDP]  dM (rows >= Lq zero)
+    float* Cs = dMs + 32 * NTJ * LDP;          // [32][LDP]
     float* St = Cs + TILE_M * LDP;             // [32][LQ1] S_col tile
-    float* Sg = St + TILE_M * LQ1;             // [32][LQ1] dS_col tile
-    const int tid = threadIdx.x;
+    float* Pp = St + TILE_M * LQ1;             // [4][32][PJ] per-wave partial tiles of dS_col
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, hh = lane >> 5;
     const int b = blockIdx.y, tl = blockIdx.x, t0 = tl * TILE_M, ntile = gridDim.x;
     const size_t crow = (size_t)b * T;
     load_tile128(Cs, a.C + crow * D, t0, TILE_M, T);
@@ -1304,27 +1305,51 @@ __global__ __launch_bounds__(256) void k_cq_bwd_b(CqBwdArgs a) {
         St[i * LQ1 + j] = t0 + i < T ? a.Scol[(crow + t0) * Lq + e] : 0.f;
     }
     cq_sum_dM(dMs, a.P1, b, ntile, Lq);
+    for (int e = tid; e < (32 * NTJ - Lq) * (D / 4); e += 256)         // zero rows Lq .. 32 NTJ - 1 (B operand of the padded tile)
+        *reinterpret_cast<float4*>(dMs + (Lq + (e >> 5)) * LDP + (e & 31) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
-    {
-        const int i = tid >> 3;
-        const float4* cr = reinterpret_cast<const float4*>(Cs + i * LDP);
-        for (int j = tid & 7; j < Lq; j += 8) {
-            const float4* mr = reinterpret_cast<const float4*>(dMs + j * LDP);
-            float s = 0.f;
-#pragma unroll 8
-            for (int k = 0; k < 32; ++k) { const float4 x = cr[k], y = mr[k]; s += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w; }
-            Sg[i * LQ1 + j] = s;
-            if (t0 + i < T) a.dSs[(crow + t0 + i) * Lq + j] = s;
+    {   // dS_col[i][j] = C[i] . dM[j]: 32 x 32 MFMA tile per 32 query words, K = 128 split over the waves
+        f32x16 acc[2];
+        zero_acc(acc);
+        const int i = lane & 31;
+        const float* arow = Cs + i * LDP + 4 * hh;
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) {
+            const int kb = 4 * w + kq;
+            const float4 av = *reinterpret_cast<const float4*>(arow + kb * 8);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                if (nt < NTJ) {
+                    const float4 bv = *reinterpret_cast<const float4*>(dMs + (32 * nt + i) * LDP + kb * 8 + 4 * hh);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[nt], 0, 0, 0);
+                }
+            }
         }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+            if (nt < NTJ) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Pp[(w * TILE_M + acc_row(r, lane)) * PJ + 32 * nt + i] = acc[nt][r];
+            }
+    }
+    __syncthreads();
+    // sum the four partial tiles in wave order, write dS_col, and the per-tile partial of the column-softmax dot
+    for (int e = tid; e < TILE_M * Lq; e += 256) {
+        const int i = e / Lq, j = e - i * Lq;
+        const float sv = Pp[i * PJ + j] + Pp[(TILE_M + i) * PJ + j] + Pp[(2 * TILE_M + i) * PJ + j] + Pp[(3 * TILE_M + i) * PJ + j];
+        Pp[i * PJ + j] = sv;                                                    // only this thread touches (i, j)
+        if (t0 + i < T) a.dSs[(crow + t0) * Lq + e] = sv;
     }
     __syncthreads();
     if (tid < Lq) {
-        float s = 0.f;
-        for (int i = 0; i < TILE_M; ++i) s += Sg[i * LQ1 + tid] * St[i * LQ1 + tid];
-        a.P2[(size_t)(b * ntile + tl) * Lq + tid] = s;
+        float sacc = 0.f;
+        for (int i = 0; i < TILE_M; ++i) sacc += Pp[i * PJ + tid] * St[i * LQ1 + tid];
+        a.P2[(size_t)(b * ntile + tl) * Lq + tid] = sacc;
     }
 }
-
 __global__ __launch_bounds__(256) void k_cq_bwd_c(CqBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int T = a.T, Lq = a.Lq, LQ1 = Lq + 1;
@@ -1545,7 +1570,7 @@ void launch_cq_bwd(const CqBwdArgs& a0, int B, hipStream_t s) {
     const int Lq = a.Lq, ntile = (a.T + TILE_M - 1) / TILE_M;
     a.ntile = ntile;
     const size_t shmA = (size_t)(TILE_M * CATP + TILE_M * LDP + 2 * TILE_M * (Lq + 1) + 72 + 4 * TILE_M * (32 * ((Lq + 31) / 32) + 1)) * sizeof(float);
-    const size_t shmB = (size_t)(Lq * LDP + TILE_M * LDP + 2 * TILE_M * (Lq + 1)) * sizeof(float);
+    const size_t shmB = (size_t)(32 * ((Lq + 31) / 32) * LDP + TILE_M * LDP + TILE_M * (Lq + 1) + 4 * TILE_M * (32 * ((Lq + 31) / 32) + 1)) * sizeof(float);
     const size_t shmC = (size_t)(2 * Lq * LDP + 2 * TILE_M * LDP + 2 * TILE_M * (Lq + 1) + 16 + Lq + TILE_M + 4 * D) * sizeof(float);
     const size_t shmD = (size_t)(Lq * LDP + 2 * Lq + 4 * D) * sizeof(float);
     static size_t okA = 0, okB = 0, okC = 0, okD = 0;
