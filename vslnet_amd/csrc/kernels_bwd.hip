@@ -909,7 +909,8 @@ void launch_attn_bwd(const float* Q, const float* K, const float* V, const float
                      Drop d3, hipStream_t s) {
     const int Lp = (L + 15) & ~15;
     static const bool fused_ok = !(getenv("VSL_ATTN_BWD_FUSED") && getenv("VSL_ATTN_BWD_FUSED")[0] == '0');
-    if (Lp <= AB_LMAX && fused_ok) {
+    static const int fused_min = getenv("VSL_ATTN_FUSED_MIN") ? atoi(getenv("VSL_ATTN_FUSED_MIN")) : 0;
+    if (Lp <= AB_LMAX && Lp > fused_min && fused_ok) {
         static size_t lds_okf = 0;
         ensure_dynamic_lds((const void*)k_attn_bwd_fused, AB_LDS, lds_okf, "k_attn_bwd_fused");
         hipLaunchKernelGGL(k_attn_bwd_fused, dim3(H, B), dim3(1024), AB_LDS, s, Q, K, V, att, dr, lse, mask, dQ, dK, dV, L, H,
@@ -1641,8 +1642,7 @@ __global__ __launch_bounds__(256) void k_embed_bwd(const float* __restrict__ dE,
                                                    int word_dim, int char_dim, int char_size, Drop dw, Drop dc) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wtot = char_dim * 300;          // 10*1 + 20*2 + 30*3 + 40*4 = 300 taps per input channel
-    float* Wl = smem;                         // [wtot + 4] conv weights, flattened conv0 | conv1 | conv2 | conv3
-    float* Ce = Wl + ((wtot + 7) & ~3);       // [EMB_CHUNK * Lc + 4][64] dropped char embeddings (+ zero rows)
+    float* Ce = smem;                         // [EMB_CHUNK * Lc + 4][64] dropped char embeddings (+ zero rows)
     float* gch = Ce + (EMB_CHUNK * Lc + 4) * 64;   // [EMB_CHUNK][128] grads of the 100 char features (0 where inactive)
     float* Gm = gch + EMB_CHUNK * 128;        // [16][EB_GP] G tile of the current word (zero except <= 300 entries)
     float* tab = Gm + 16 * EB_GP;             // [char_size][char_dim] table-gradient accumulator
@@ -1656,34 +1656,8 @@ __global__ __launch_bounds__(256) void k_embed_bwd(const float* __restrict__ dE,
     const int rbeg = blockIdx.x * EMB_CHUNK, nw = min(EMB_CHUNK, Rq - rbeg);
     const int s0 = 10 * char_dim, s1 = 20 * char_dim * 2, s2 = 30 * char_dim * 3;
     STAMP(0);
-    // ---- bulk phase 1: weights + per-word metadata.  The four conv weights are flattened back to back; every load of a
-    //      thread is issued before the first LDS store, so the 15000 floats cost ONE memory latency (they were 8 batches)
-    {
-        const int n0 = s0, n1 = s1, n2 = s2, n3 = 40 * char_dim * 4;
-        constexpr int MAXQ = 13;                         // ceil(64 * 40 * 4 / 4 / 256) float4 per thread for the widest conv
-        const float* src[4] = {cc.w[0], cc.w[1], cc.w[2], cc.w[3]};
-        const int cnt[4] = {n0, n1, n2, n3}, off[4] = {0, n0, n0 + n1, n0 + n1 + n2};
-        float4 v[4][MAXQ];
-#pragma unroll
-        for (int c4 = 0; c4 < 4; ++c4)
-#pragma unroll
-            for (int q = 0; q < MAXQ; ++q) {
-                const int e = (tid + q * 256) * 4;
-                v[c4][q] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if ((c4 == 3 || q < (c4 == 0 ? 1 : c4 == 1 ? 3 : 7)) && e < cnt[c4]) v[c4][q] = *reinterpret_cast<const float4*>(src[c4] + e);
-            }
-#pragma unroll
-        for (int c4 = 0; c4 < 4; ++c4)
-#pragma unroll
-            for (int q = 0; q < MAXQ; ++q) {
-                const int e = (tid + q * 256) * 4;
-                if ((c4 == 3 || q < (c4 == 0 ? 1 : c4 == 1 ? 3 : 7)) && e < cnt[c4]) {      // counts are multiples of 4 (char_dim * 10 * ...)
-                    float* d = Wl + off[c4] + e;
-                    d[0] = v[c4][q].x; d[1] = v[c4][q].y; d[2] = v[c4][q].z; d[3] = v[c4][q].w;
-                }
-            }
-    }
-    if (tid < 4) Wl[wtot + tid] = 0.f;        // zero slot for invalid taps
+    // ---- bulk phase 1: per-word metadata (the conv weights are not staged: every lane reads its 75 B-operand values of
+    //      the MFMA product straight from the parameters, once)
     if (tid < 128) {
         int k = 1, base = wtot;
         if (tid < 10) { k = 1; base = tid * char_dim; }
@@ -1778,7 +1752,10 @@ __global__ __launch_bounds__(256) void k_embed_bwd(const float* __restrict__ dE,
 #pragma unroll
         for (int q = 0; q < 75; ++q) {
             const int m = kmap[4 * q + g4];
-            wreg[q] = Wl[(m >> 13) + ci * ((m >> 10) & 7)];
+            const int oc = m & 0xFF, kk = (m >> 8) & 3, kc = (m >> 10) & 7;
+            const int cv = kc - 1, ocl = oc - (cv == 0 ? 0 : cv == 1 ? 10 : cv == 2 ? 30 : 60);
+            const float* wp = cv == 0 ? cc.w[0] : cv == 1 ? cc.w[1] : cv == 2 ? cc.w[2] : cc.w[3];
+            wreg[q] = (ci < char_dim) ? wp[(ocl * char_dim + ci) * kc + kk] : 0.f;
         }
         // work items = (word, 16-position tile).  fill(item) scatters the tile's entries of G; after the MFMAs of an item
         // every thread clears its own entries and writes those of the NEXT item (same thread, program order: no barrier in
@@ -1852,7 +1829,7 @@ void launch_embed_bwd(const float* dE, const int64_t* word_ids, const int64_t* c
                       const int8_t* argpos, const float* char_tab, CharConvPtrs cc, float* p_cw, float* p_cb,
                       float* p_tab, float* p_unk, int Rq, int Lc, int word_dim, int char_dim, int char_size, Drop dw, Drop dc,
                       hipStream_t s) {
-    const size_t shm = (size_t)(((char_dim * 300 + 7) & ~3) + (EMB_CHUNK * Lc + 4) * 64 + EMB_CHUNK * 128 + 16 * EB_GP + 2 * Lc * 64 +
+    const size_t shm = (size_t)((EMB_CHUNK * Lc + 4) * 64 + EMB_CHUNK * 128 + 16 * EB_GP + 2 * Lc * 64 +
                                 char_size * char_dim + 304) * sizeof(float);
     static size_t lds_ok = 0;
     ensure_dynamic_lds((const void*)k_embed_bwd, shm, lds_ok, "k_embed_bwd");
