@@ -756,8 +756,11 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(const float* __restrict__ 
 // The two dK / dV partials (qh = 0, 1) are added in a fixed order through LDS, so the result does not depend on
 // scheduling.  Against the two-kernel path this halves the exp / dropout-hash / S / dP work (fp32 MFMAs and the vector ALU
 // share the SIMD, so that work is not hidden behind anything) and removes one kernel boundary.
-constexpr int AB_LMAX = 128, AB_KST = 20, AB_QP = 64, AB_DSP = AB_LMAX + 4;
-constexpr size_t AB_LDS = (size_t)(4 * AB_LMAX * AB_KST + AB_QP * AB_DSP + 3 * AB_LMAX) * sizeof(float);
+// LMAX = 128: 8 key strips x 2 query halves (the two dK / dV partials are added through LDS); LMAX = 256: 16 key strips, a
+// wave sees every query tile (no exchange), 152 KB of LDS, one workgroup per CU.
+constexpr int AB_KST = 20, AB_QP = 64;
+template <int LMAX> constexpr size_t ab_lds() { return (size_t)(4 * LMAX * AB_KST + AB_QP * (LMAX + 4) + 3 * LMAX) * sizeof(float); }
+template <int LMAX>
 __global__ __launch_bounds__(1024) void k_attn_bwd_fused(const float* __restrict__ Q, const float* __restrict__ K,
                                                          const float* __restrict__ V, const float* __restrict__ att,
                                                          const float* __restrict__ dr, const float* __restrict__ lse,
@@ -765,7 +768,8 @@ __global__ __launch_bounds__(1024) void k_attn_bwd_fused(const float* __restrict
                                                          float* __restrict__ dK, float* __restrict__ dV, int L, int H,
                                                          int b_off, Drop d2, Drop d3) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Ks = smem;                           // [128][20]
+    constexpr int AB_LMAX = LMAX, AB_DSP = LMAX + 4, NKS = LMAX / 16, NSPLIT = 16 / NKS;
+    float* Ks = smem;                           // [LMAX][20]
     float* dSs = Ks + AB_LMAX * AB_KST;         // [64][132]   dS[query - qb][key] of the current pass
     float* Ls = dSs + AB_QP * AB_DSP;           // LSE per query
     float* Ds = Ls + AB_LMAX;                   // D = dA . O per query
@@ -778,8 +782,8 @@ __global__ __launch_bounds__(1024) void k_attn_bwd_fused(const float* __restrict
     const int h = blockIdx.x, b = blockIdx.y;
     const size_t rowbase = (size_t)b * L;
     STAMP(0);
-    {
-        const int e = tid & 511, row = e >> 2, c4 = (e & 3) * 4;
+    for (int it = 0; it < LMAX / 128; ++it) {
+        const int e = (tid & 511) + 512 * it, row = e >> 2, c4 = (e & 3) * 4;
         const size_t off = (rowbase + row) * D + h * HD + c4;
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
         if (tid < 512) {
@@ -790,7 +794,7 @@ __global__ __launch_bounds__(1024) void k_attn_bwd_fused(const float* __restrict
             }
             *reinterpret_cast<float4*>(&Qs[row * AB_KST + c4]) = qv;
             *reinterpret_cast<float4*>(&Ks[row * AB_KST + c4]) = kv;
-            if (tid < AB_LMAX) {
+            if (it == 0 && tid < AB_LMAX) {
                 Ls[tid] = tid < L ? lse[((size_t)b * H + h) * L + tid] : 0.f;
                 Mb[tid] = tid < L ? (1.0f - mask[rowbase + tid]) * MASK_VALUE : MASK_VALUE;
             }
@@ -818,11 +822,11 @@ __global__ __launch_bounds__(1024) void k_attn_bwd_fused(const float* __restrict
     __syncthreads();
     STAMP(2);
     const int ki = lane & 15, g = lane >> 4;
-    const int hi = w >> 3;                      // which of the two dK / dV partials this wave produces
+    const int hi = w / NKS;                     // which of the NSPLIT dK / dV partials this wave produces
     const float scale = 0.25f;
     f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
-    const int key = 16 * (w & 7) + ki;
-    const bool has_keys = 16 * (w & 7) < Lp;
+    const int key = 16 * (w % NKS) + ki;
+    const bool has_keys = 16 * (w % NKS) < Lp;
     float4 kf = make_float4(0.f, 0.f, 0.f, 0.f), vf = kf;
     float mb = MASK_VALUE;
     if (has_keys) {
@@ -834,7 +838,7 @@ __global__ __launch_bounds__(1024) void k_attn_bwd_fused(const float* __restrict
     for (int qb = 0; qb < Lp; qb += AB_QP) {
         const int qe = min(qb + AB_QP, Lp);
         if (has_keys) {
-            for (int qt = qb + 16 * hi; qt < qe; qt += 32) {
+            for (int qt = qb + 16 * hi; qt < qe; qt += 16 * NSPLIT) {
                 // S tile (rows = queries qt + 4g + reg, col = key) and dPd tile, same shape
                 const float4 qa = *reinterpret_cast<const float4*>(&Qs[(qt + ki) * AB_KST + 4 * g]);
                 const float4 aa = *reinterpret_cast<const float4*>(&As[(qt + ki) * AB_KST + 4 * g]);
@@ -890,14 +894,17 @@ __global__ __launch_bounds__(1024) void k_attn_bwd_fused(const float* __restrict
         if (qb == 0) STAMP(6);
     }
     float* xkv = Qs;                            // [8 strips][64 lanes][8]
-    if (hi == 1) {
+    if (NSPLIT == 2 && hi == 1) {
         *reinterpret_cast<float4*>(&xkv[((w & 7) * 64 + lane) * 8]) = make_float4(dk[0], dk[1], dk[2], dk[3]);
         *reinterpret_cast<float4*>(&xkv[((w & 7) * 64 + lane) * 8 + 4]) = make_float4(dv[0], dv[1], dv[2], dv[3]);
     }
     __syncthreads();
     if (hi == 0 && key < L) {
-        const float4 k1 = *reinterpret_cast<const float4*>(&xkv[((w & 7) * 64 + lane) * 8]);
-        const float4 v1 = *reinterpret_cast<const float4*>(&xkv[((w & 7) * 64 + lane) * 8 + 4]);
+        float4 k1 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = k1;
+        if (NSPLIT == 2) {
+            k1 = *reinterpret_cast<const float4*>(&xkv[((w & 7) * 64 + lane) * 8]);
+            v1 = *reinterpret_cast<const float4*>(&xkv[((w & 7) * 64 + lane) * 8 + 4]);
+        }
         const size_t off = (rowbase + key) * D + h * HD + 4 * g;
         *reinterpret_cast<float4*>(dK + off) = make_float4(dk[0] + k1.x, dk[1] + k1.y, dk[2] + k1.z, dk[3] + k1.w);
         *reinterpret_cast<float4*>(dV + off) = make_float4(dv[0] + v1.x, dv[1] + v1.y, dv[2] + v1.z, dv[3] + v1.w);
@@ -910,11 +917,17 @@ void launch_attn_bwd(const float* Q, const float* K, const float* V, const float
     const int Lp = (L + 15) & ~15;
     static const bool fused_ok = !(getenv("VSL_ATTN_BWD_FUSED") && getenv("VSL_ATTN_BWD_FUSED")[0] == '0');
     static const int fused_min = getenv("VSL_ATTN_FUSED_MIN") ? atoi(getenv("VSL_ATTN_FUSED_MIN")) : 0;
-    if (Lp <= AB_LMAX && Lp > fused_min && fused_ok) {
-        static size_t lds_okf = 0;
-        ensure_dynamic_lds((const void*)k_attn_bwd_fused, AB_LDS, lds_okf, "k_attn_bwd_fused");
-        hipLaunchKernelGGL(k_attn_bwd_fused, dim3(H, B), dim3(1024), AB_LDS, s, Q, K, V, att, dr, lse, mask, dQ, dK, dV, L, H,
-                           b_off, d2, d3);
+    if (Lp <= 256 && Lp > fused_min && fused_ok) {
+        static size_t ok128 = 0, ok256 = 0;
+        if (Lp <= 128) {
+            ensure_dynamic_lds((const void*)k_attn_bwd_fused<128>, ab_lds<128>(), ok128, "k_attn_bwd_fused<128>");
+            hipLaunchKernelGGL(k_attn_bwd_fused<128>, dim3(H, B), dim3(1024), ab_lds<128>(), s, Q, K, V, att, dr, lse, mask, dQ, dK, dV, L, H,
+                               b_off, d2, d3);
+        } else {
+            ensure_dynamic_lds((const void*)k_attn_bwd_fused<256>, ab_lds<256>(), ok256, "k_attn_bwd_fused<256>");
+            hipLaunchKernelGGL(k_attn_bwd_fused<256>, dim3(H, B), dim3(1024), ab_lds<256>(), s, Q, K, V, att, dr, lse, mask, dQ, dK, dV, L, H,
+                               b_off, d2, d3);
+        }
         static int left = 3;
         if (dbg_budget("attn_bwd") && L > 64) dbg_report("attn_bwd_fused: stage-issue | landed+sync | pass-0 phase1 | sync | phase2 | sync | pass 1 + final", 8, s, left);
         return;
