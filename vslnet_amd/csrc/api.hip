@@ -468,10 +468,10 @@ void run_forward(Ctx& c) {
     // M = S_col^T C is produced as per-tile partials (the backward's cqP1 arena is free until then) and summed by cq_out
     LAUNCH("cq_col", launch_cq_col(c.W(p.ve.out), c.W(p.qe.out), c.W(p.S), io.v_mask, io.q_mask, c.P(P.pool_w), c.P(P.cat_w), c.P(P.cat_b),
                   c.W(p.Scol), c.W(p.cqP1), c.W(p.alpha), c.W(p.pooled), c.W(p.pb), B, T, Lq, c.s));
+    // cq_out also carries CQConcatenate + HighLightLayer + gating (row-local on the tile it produces)
     LAUNCH("cq_out", launch_cq_out(c.W(p.ve.out), c.W(p.qe.out), c.W(p.Srow), c.W(p.cqP1), c.W(p.M), c.PK(K.cqa_f), c.P(P.cqa_b), c.W(p.cat),
-                  c.W(p.f1), B, T, Lq, c.s));
-    LAUNCH("cqcat_fwd", launch_cqcat_fwd(c.W(p.f1), c.PK(K.cat1_f), c.W(p.pb), c.P(P.hl_w), c.P(P.hl_b), io.v_mask, c.W(p.f2), io.h_score,
-                     c.W(p.gated), R, T, c.s));
+                  c.W(p.f1), c.PK(K.cat1_f), c.W(p.pb), c.P(P.hl_w), c.P(P.hl_b), io.v_mask, c.W(p.f2), io.h_score, c.W(p.gated), B, T, Lq,
+                  c.s));
     if (cf.predictor == 0) {
         // rnn head (:341-343): start = LSTM_s(x) * mask ; end = LSTM_e(start) * mask ; no LayerNorm in front of the span blocks
         const float* xin = c.W(p.gated);

@@ -98,13 +98,27 @@ __global__ __launch_bounds__(256) void k_loss_b(int B, float inv_batch, float ma
         losses[0] = loc; losses[1] = hl; losses[2] = w_loc * loc + w_hl * hl; losses[3] = d;
     }
 }
+// gradient seeds + (block (0,0)) the loss values: every block re-reduces the B per-sample partials itself (a few hundred
+// floats, L2-resident), which saves the single-block kernel between k_loss_a and this one on the critical path
 __global__ __launch_bounds__(256) void k_loss_c(const float* __restrict__ sl, const float* __restrict__ el,
                                                 const float* __restrict__ h, const int64_t* __restrict__ s_lab,
                                                 const int64_t* __restrict__ e_lab, const int64_t* __restrict__ h_lab,
-                                                const float* __restrict__ vmask, int B, int T, float inv_batch, float w_loc,
-                                                float w_hl, const float* __restrict__ scratch,
-                                                const float* __restrict__ losses, float* __restrict__ d_sl,
-                                                float* __restrict__ d_el, float* __restrict__ d_h) {
+                                                const float* __restrict__ vmask, int B, int T, float inv_batch,
+                                                float mask_sum_override, float w_loc, float w_hl,
+                                                const float* __restrict__ scratch, float* __restrict__ losses,
+                                                float* __restrict__ d_sl, float* __restrict__ d_el, float* __restrict__ d_h) {
+    __shared__ float red[8];
+    float ce = 0.f, num = 0.f, den = 0.f;
+    for (int bb = threadIdx.x; bb < B; bb += 256) { ce += scratch[2 * B + bb]; num += scratch[3 * B + bb]; den += scratch[4 * B + bb]; }
+    ce = block_reduce(ce, red, false);
+    num = block_reduce(num, red, false);
+    den = block_reduce(den, red, false);
+    const float dsum = mask_sum_override > 0.f ? mask_sum_override : den;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        const float loc = ce * inv_batch;                                   // CrossEntropyLoss(mean) twice (:367-368)
+        const float hl = num / (dsum + 1e-12f);                             // (:298)
+        losses[0] = loc; losses[1] = hl; losses[2] = w_loc * loc + w_hl * hl; losses[3] = dsum;
+    }
     const int b = blockIdx.y;
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= T) return;
@@ -115,17 +129,18 @@ __global__ __launch_bounds__(256) void k_loss_c(const float* __restrict__ sl, co
     const float y = (float)h_lab[i], p = h[i], m = vmask[i];
     const float wgt = y == 0.f ? 1.f : 2.f * y;
     // d BCE / dp = (p - y) / max(p (1 - p), 1e-12)   (torch's binary_cross_entropy_backward)
-    d_h[i] = w_hl * wgt * m / (losses[3] + 1e-12f) * (p - y) / fmaxf(p * (1.f - p), 1e-12f);
+    d_h[i] = w_hl * wgt * m / (dsum + 1e-12f) * (p - y) / fmaxf(p * (1.f - p), 1e-12f);
 }
 void launch_loss(const float* sl, const float* el, const float* h, const int64_t* s_lab, const int64_t* e_lab,
                  const int64_t* h_lab, const float* vmask, int B, int T, float inv_batch, float mask_sum_override,
                  float w_loc, float w_hl, float* scratch, float* losses, float* d_sl, float* d_el, float* d_h,
                  hipStream_t s) {
     hipLaunchKernelGGL(k_loss_a, dim3(B), dim3(256), 0, s, sl, el, h, s_lab, e_lab, h_lab, vmask, B, T, scratch);
-    hipLaunchKernelGGL(k_loss_b, dim3(1), dim3(256), 0, s, B, inv_batch, mask_sum_override, w_loc, w_hl, scratch, losses);
     if (d_sl)
         hipLaunchKernelGGL(k_loss_c, dim3((T + 255) / 256, B), dim3(256), 0, s, sl, el, h, s_lab, e_lab, h_lab, vmask, B, T,
-                           inv_batch, w_loc, w_hl, scratch, losses, d_sl, d_el, d_h);
+                           inv_batch, mask_sum_override, w_loc, w_hl, scratch, losses, d_sl, d_el, d_h);
+    else
+        hipLaunchKernelGGL(k_loss_b, dim3(1), dim3(256), 0, s, B, inv_batch, mask_sum_override, w_loc, w_hl, scratch, losses);
 }
 
 // a17 extract_index (:355-363): argmax over the upper-triangular outer product of the two softmaxes, computed as

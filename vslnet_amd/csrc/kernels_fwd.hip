@@ -1045,11 +1045,16 @@ void launch_cq_col(const float* C, const float* Qf, const float* S, const float*
                        Mpart, alpha, pooled, pb, T, Lq);
 }
 
+// CQConcatenate + HighLightLayer + gating (a11 / a12, VSLNet_t7.py:60) ride on the same kernel (row-local on the tile just produced)
+struct CqCatFuse {
+    const float *W1pack, *pb, *wh, *bh, *vmask;
+    float *f2, *hscore, *gated;
+};
 __global__ __launch_bounds__(256) void k_cq_out(const float* __restrict__ C, const float* __restrict__ Qf,
                                                 const float* __restrict__ Srow, const float* __restrict__ Mpart,
                                                 float* __restrict__ M, const float* __restrict__ Wpack,
                                                 const float* __restrict__ bias, float* __restrict__ cat_out,
-                                                float* __restrict__ out, int T, int Lq) {
+                                                float* __restrict__ out, int T, int Lq, CqCatFuse cf) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int LQ1 = Lq + 1;
     float* Cat = smem;                        // [32][CATP]
@@ -1123,20 +1128,72 @@ __global__ __launch_bounds__(256) void k_cq_out(const float* __restrict__ C, con
     f32x16 acc[1];
     zero_acc(acc);
     gemm32p<1, 16>(Cat, CATP, 4 * D, Wpack, D, 32 * w, 0, acc, bf);
+    BFrag<1, 16> bf2;                              // weights of the fused CQConcatenate GEMM: in flight during the epilogue
+    bfrag_load(bf2, cf.W1pack, D, 32 * w, 0, 0, D / 8);
     const float bv = bias[col];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int t = t0 + acc_row(r, lane);
-        if (t < T) out[(crow + t) * D + col] = acc[0][r] + bv;
+        const int row = acc_row(r, lane);
+        const int t = t0 + row;
+        const float v = acc[0][r] + bv;
+        if (t < T) out[(crow + t) * D + col] = v;
+        Cs[row * LDP + col] = t < T ? v : 0.f;     // the C tile is dead: A operand of the next GEMM
+    }
+    __syncthreads();
+    // ---- f2 = f1 W1^T + (W2 pooled + b) ; h = sigmoid(mask_logits(f2 . w_h + b_h)) ; gated = f2 * h
+    float* Fs = Cat;                               // [32][LDP] (the concat tile is dead after the barrier above)
+    float* hs = Ss;                                // [32]
+    f32x16 a2[1];
+    zero_acc(a2);
+    gemm32p<1, 16>(Cs, LDP, D, cf.W1pack, D, 32 * w, 0, a2, bf2);
+    {
+        const float pbv = cf.pb[(size_t)b * D + col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Fs[acc_row(r, lane) * LDP + col] = a2[0][r] + pbv;
+    }
+    __syncthreads();
+    {
+        const int rr = tid >> 3, sub = tid & 7;
+        const float* row = Fs + rr * LDP + sub * 4;
+        float d = 0.f;
+#pragma unroll
+        for (int jq = 0; jq < 4; ++jq) {
+            const float4 fv = *reinterpret_cast<const float4*>(row + 32 * jq);
+            const float4 wv = *reinterpret_cast<const float4*>(cf.wh + sub * 4 + 32 * jq);
+            d += fv.x * wv.x + fv.y * wv.y + fv.z * wv.z + fv.w * wv.w;
+        }
+        d = grp8_sum(d);
+        if (sub == 0) {
+            const int t = t0 + rr;
+            float hv = 0.f;
+            if (t < T) {
+                const float lg = d + cf.bh[0] + (1.f - cf.vmask[crow + t]) * MASK_VALUE;      // mask_logits (:286)
+                hv = 1.0f / (1.0f + __expf(-lg));
+                cf.hscore[crow + t] = hv;
+            }
+            hs[rr] = hv;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < TILE_M * 32; e += 256) {
+        const int rr = e >> 5, c = (e & 31) * 4;
+        const int t = t0 + rr;
+        if (t < T) {
+            const float4 v = *reinterpret_cast<const float4*>(&Fs[rr * LDP + c]);
+            const float hv = hs[rr];
+            *reinterpret_cast<float4*>(cf.f2 + (crow + t) * D + c) = v;
+            *reinterpret_cast<float4*>(cf.gated + (crow + t) * D + c) = make_float4(v.x * hv, v.y * hv, v.z * hv, v.w * hv);
+        }
     }
 }
 void launch_cq_out(const float* C, const float* Qf, const float* Srow, const float* Mpart, float* M, const float* Wpack,
-                   const float* bias, float* cat_out, float* out, int B, int T, int Lq, hipStream_t s) {
-    const size_t shm = (size_t)(TILE_M * CATP + TILE_M * LDP + Lq * LDP + TILE_M * (Lq + 1)) * sizeof(float);
+                   const float* bias, float* cat_out, float* out, const float* W1pack, const float* pb, const float* wh,
+                   const float* bh, const float* vmask, float* f2, float* hscore, float* gated, int B, int T, int Lq, hipStream_t s) {
+    const size_t shm = (size_t)(TILE_M * CATP + TILE_M * LDP + Lq * LDP + TILE_M * (Lq + 1) + 32) * sizeof(float);
     static size_t lds_ok = 0;
     ensure_dynamic_lds((const void*)k_cq_out, shm, lds_ok, "k_cq_out");
     hipLaunchKernelGGL(k_cq_out, dim3((T + TILE_M - 1) / TILE_M, B), dim3(256), shm, s, C, Qf, Srow, Mpart, M, Wpack, bias, cat_out, out,
-                       T, Lq);
+                       T, Lq, CqCatFuse{W1pack, pb, wh, bh, vmask, f2, hscore, gated});
 }
 
 // =========================================================================================================
