@@ -423,13 +423,26 @@ __global__ __launch_bounds__(256) void k_conv_layer_fwd(const float* __restrict_
             sid[i] = (rg + i < R) ? sm : -2;
             if (++tt == L) { tt = 0; ++sm; }
         }
+        // a block whose 22-row window lies inside one sample (wave-uniform; 6 of 8 blocks at T = 128) needs no boundary tests
+        const bool interior = rg >= 0 && sid[0] == sid[16 + 2 * HALO - 1] && sid[0] >= 0;
+        if (interior) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            float u = 0.f;
+            for (int q = 0; q < 16; ++q) {
+                float u = 0.f;
 #pragma unroll
-            for (int k = 0; k < DWK; ++k) u += (sid[q + k] == sid[q + HALO]) ? wk[k] * win[q + k] : 0.f;
-            Us[(hb + q) * LDP + c] = u;
-            if (u_out && r0 + hb + q < R) u_out[(size_t)(r0 + hb + q) * D + c] = u;   // saved: A operand of the weight gradient
+                for (int k = 0; k < DWK; ++k) u += wk[k] * win[q + k];
+                Us[(hb + q) * LDP + c] = u;
+                if (u_out) u_out[(size_t)(r0 + hb + q) * D + c] = u;                 // saved: A operand of the weight gradient
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                float u = 0.f;
+#pragma unroll
+                for (int k = 0; k < DWK; ++k) u += (sid[q + k] == sid[q + HALO]) ? wk[k] * win[q + k] : 0.f;
+                Us[(hb + q) * LDP + c] = u;
+                if (u_out && r0 + hb + q < R) u_out[(size_t)(r0 + hb + q) * D + c] = u;
+            }
         }
     }
     FSTAMP(4);
