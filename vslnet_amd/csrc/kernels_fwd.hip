@@ -592,32 +592,21 @@ void launch_ln_qkv_fwd(const float* x, const float* ln_g, const float* ln_b, con
 //   online softmax is lane-local (+2 shuffles across the 4 key groups) and P feeds the PV MFMA from registers.
 //   Saves LSE = m + log(l) per (b, h, q) for the backward.
 // =========================================================================================================
+constexpr int AF_KB = 256;          // keys staged per block: 42 KB of LDS whatever L is -> 3+ workgroups per CU at L = 1024
 __global__ __launch_bounds__(256) void k_attn_fwd(const float* __restrict__ Q, const float* __restrict__ K,
                                                   const float* __restrict__ V, const float* __restrict__ mask,
                                                   float* __restrict__ att, float* __restrict__ lse, int L, int H,
                                                   int b_off, Drop d2) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int Lp = (L + 15) & ~15;
-    const int kst = head_slice_stride(Lp);
-    float* Ks = smem;                 // [Lp][kst]
-    float* Vs = Ks + Lp * kst;        // [Lp][kst]
-    float* Mb = Vs + Lp * kst;        // [Lp] additive key bias
+    const int KB = min(Lp, AF_KB);
+    constexpr int kst = 20;
+    float* Ks = smem;                 // [KB][20]  K / V head slices of the current key block
+    float* Vs = Ks + KB * kst;        // [KB][20]
+    float* Mb = Vs + KB * kst;        // [KB] additive key bias
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int b = blockIdx.z, h = blockIdx.y;
     const size_t rowbase = (size_t)b * L;
-    for (int e = tid; e < Lp * 4; e += 256) {
-        const int key = e >> 2, c4 = (e & 3) * 4;
-        float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-        if (key < L) {
-            kv = *reinterpret_cast<const float4*>(K + (rowbase + key) * D + h * HD + c4);
-            vv = *reinterpret_cast<const float4*>(V + (rowbase + key) * D + h * HD + c4);
-        }
-        *reinterpret_cast<float4*>(&Ks[key * kst + c4]) = kv;
-        *reinterpret_cast<float4*>(&Vs[key * kst + c4]) = vv;
-    }
-    for (int key = tid; key < Lp; key += 256)
-        Mb[key] = key < L ? (1.0f - mask[rowbase + key]) * MASK_VALUE : MASK_VALUE;
-    __syncthreads();
     const int qi = lane & 15, g = lane >> 4;
     const int q = blockIdx.x * 64 + w * 16 + qi;
     const bool qok = q < L;
@@ -627,40 +616,56 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const float* __restrict__ Q, c
     float m = -3.0e38f, l = 0.f;
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
     const uint32_t pbase = (uint32_t)(((size_t)(b + b_off) * H + h) * L + q) * (uint32_t)L;
-    for (int kt = 0; kt < Lp; kt += 16) {
-        // S^T tile: rows = keys kt + 4g + reg, col = query qi
-        const float4 kf = *reinterpret_cast<const float4*>(&Ks[(kt + qi) * kst + 4 * g]);
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf.x, s, 0, 0, 0);
-        s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf.y, s, 0, 0, 0);
-        s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf.z, s, 0, 0, 0);
-        s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf.w, s, 0, 0, 0);
-        float p[4];
-        float tmax = -3.0e38f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            p[r] = s[r] * scale + Mb[kt + 4 * g + r];
-            tmax = fmaxf(tmax, p[r]);
+    for (int kb0 = 0; kb0 < Lp; kb0 += AF_KB) {
+        const int nk = min(AF_KB, Lp - kb0);
+        if (kb0) __syncthreads();                  // every wave is done with the previous block
+        for (int e = tid; e < nk * 4; e += 256) {
+            const int key = kb0 + (e >> 2), c4 = (e & 3) * 4;
+            float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+            if (key < L) {
+                kv = *reinterpret_cast<const float4*>(K + (rowbase + key) * D + h * HD + c4);
+                vv = *reinterpret_cast<const float4*>(V + (rowbase + key) * D + h * HD + c4);
+            }
+            *reinterpret_cast<float4*>(&Ks[(e >> 2) * kst + c4]) = kv;
+            *reinterpret_cast<float4*>(&Vs[(e >> 2) * kst + c4]) = vv;
         }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-        const float mn = fmaxf(m, tmax);
-        const float alpha = __expf(m - mn);
-        m = mn;
-        l *= alpha;
+        for (int kk = tid; kk < nk; kk += 256) Mb[kk] = kb0 + kk < L ? (1.0f - mask[rowbase + kb0 + kk]) * MASK_VALUE : MASK_VALUE;
+        __syncthreads();
+        for (int kt = 0; kt < nk; kt += 16) {
+            // S^T tile: rows = keys kb0 + kt + 4g + reg, col = query qi
+            const float4 kf = *reinterpret_cast<const float4*>(&Ks[(kt + qi) * kst + 4 * g]);
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf.x, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf.y, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf.z, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf.w, s, 0, 0, 0);
+            float p[4];
+            float tmax = -3.0e38f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            p[r] = __expf(p[r] - mn);
-            l += p[r];
-            o[r] *= alpha;
-        }
-        // O^T += V^T P^T : A[i = dd][k = key] = V[key][dd], B[k = key][j = q] = P (in registers)
+            for (int r = 0; r < 4; ++r) {
+                p[r] = s[r] * scale + Mb[kt + 4 * g + r];
+                tmax = fmaxf(tmax, p[r]);
+            }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+            const float mn = fmaxf(m, tmax);
+            const float alpha = __expf(m - mn);
+            m = mn;
+            l *= alpha;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int key = kt + 4 * g + r;
-            const float pd = p[r] * drop_mul(d2, pbase + key);
-            const float vv = Vs[key * kst + qi];
-            o = __builtin_amdgcn_mfma_f32_16x16x4f32(vv, pd, o, 0, 0, 0);
+            for (int r = 0; r < 4; ++r) {
+                p[r] = __expf(p[r] - mn);
+                l += p[r];
+                o[r] *= alpha;
+            }
+            // O^T += V^T P^T : A[i = dd][k = key] = V[key][dd], B[k = key][j = q] = P (in registers)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt + 4 * g + r;
+                const float pd = p[r] * drop_mul(d2, pbase + kb0 + key);
+                const float vv = Vs[key * kst + qi];
+                o = __builtin_amdgcn_mfma_f32_16x16x4f32(vv, pd, o, 0, 0, 0);
+            }
         }
     }
     l += __shfl_xor(l, 16);
@@ -676,8 +681,8 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const float* __restrict__ Q, c
 void launch_attn_fwd(const float* Q, const float* K, const float* V, const float* mask, float* att, float* lse, int B,
                      int L, int H, int b_off, Drop d2, hipStream_t s) {
     const int Lp = (L + 15) & ~15;
-    const int kst = head_slice_stride(Lp);
-    const size_t shm = (size_t)(2 * Lp * kst + Lp) * sizeof(float);
+    const int KB = Lp < AF_KB ? Lp : AF_KB;
+    const size_t shm = (size_t)(2 * KB * 20 + KB) * sizeof(float);
     static size_t lds_ok = 0;
     ensure_dynamic_lds((const void*)k_attn_fwd, shm, lds_ok, "k_attn_fwd");
     hipLaunchKernelGGL(k_attn_fwd, dim3((L + 63) / 64, H, B), dim3(256), shm, s, Q, K, V, mask, att, lse, L, H, b_off, d2);
