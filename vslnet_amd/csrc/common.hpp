@@ -27,12 +27,10 @@ constexpr float MASK_VALUE = -1e30f;
 constexpr int DWK = 7;          // depthwise kernel size
 constexpr int HALO = 3;
 constexpr int HD = 16;          // attention head size the kernels are specialised for (dim 128 / 8 heads)
-// LDS row stride of a (L, 16) head slice: padded to 20 floats, un-padded when the slices would not fit 160 KB
-__host__ __device__ __forceinline__ int head_slice_stride(int Lp) { return Lp > 768 ? 16 : 20; }
 constexpr int CATP = 4 * D + 4; // LDS row stride of the CQAttention concat tile
 constexpr int MAX_LC = 24;      // max characters per word (LDS budget of k_embed_bwd)
 constexpr int MAX_LQ = 64;      // max query words (LDS budget of k_cq_col_bwd)
-constexpr int MAX_L = 1024;     // max clips per video (K/V head slices resident in LDS)
+constexpr int MAX_L = 1024;     // max clips per video (tested limit; the attention kernels stream K/V in 256-row blocks)
 
 // ---------------------------------------------------------------------------------------------------------
 // dropout

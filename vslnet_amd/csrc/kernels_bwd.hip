@@ -623,7 +623,9 @@ void launch_attn_out_bwd(const float* dy, const float* dy2, const float* r, cons
     }
 }
 
-// dQ: wave owns 16 queries (lane: query qi = lane & 15, key group g = lane >> 4), K/V head slices in LDS.
+// dQ: wave owns 16 queries (lane: query qi = lane & 15, key group g = lane >> 4); the K / V head slices stream through LDS in
+// blocks of AB2_KB keys (42 KB at any L, several workgroups per CU).  Used for L > 256 (the fused kernel covers the rest).
+constexpr int AB2_KB = 256;
 __global__ __launch_bounds__(256) void k_attn_bwd_dq(const float* __restrict__ Q, const float* __restrict__ K,
                                                      const float* __restrict__ V, const float* __restrict__ att,
                                                      const float* __restrict__ dr, const float* __restrict__ lse,
@@ -631,25 +633,14 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(const float* __restrict__ Q
                                                      float* __restrict__ Dq, int L, int H, int b_off, Drop d2, Drop d3) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int Lp = (L + 15) & ~15;
-    const int kst = head_slice_stride(Lp);
+    const int KB = min(Lp, AB2_KB);
+    constexpr int kst = 20;
     float* Ks = smem;
-    float* Vs = Ks + Lp * kst;
-    float* Mb = Vs + Lp * kst;
+    float* Vs = Ks + KB * kst;
+    float* Mb = Vs + KB * kst;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int b = blockIdx.z, h = blockIdx.y;
     const size_t rowbase = (size_t)b * L;
-    for (int e = tid; e < Lp * 4; e += 256) {
-        const int key = e >> 2, c4 = (e & 3) * 4;
-        float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-        if (key < L) {
-            kv = *reinterpret_cast<const float4*>(K + (rowbase + key) * D + h * HD + c4);
-            vv = *reinterpret_cast<const float4*>(V + (rowbase + key) * D + h * HD + c4);
-        }
-        *reinterpret_cast<float4*>(&Ks[key * kst + c4]) = kv;
-        *reinterpret_cast<float4*>(&Vs[key * kst + c4]) = vv;
-    }
-    for (int key = tid; key < Lp; key += 256) Mb[key] = key < L ? (1.0f - mask[rowbase + key]) * MASK_VALUE : MASK_VALUE;
-    __syncthreads();
     const int qi = lane & 15, g = lane >> 4;
     const int q = blockIdx.x * 64 + w * 16 + qi;
     const bool qok = q < L;
@@ -674,30 +665,47 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(const float* __restrict__ Q
     const float scale = 0.25f;
     const uint32_t pbase = (uint32_t)(((size_t)(b + b_off) * H + h) * L + q) * (uint32_t)L;
     f32x4 dq = {0.f, 0.f, 0.f, 0.f};
-    for (int kt = 0; kt < Lp; kt += 16) {
-        const float4 kf = *reinterpret_cast<const float4*>(&Ks[(kt + qi) * kst + 4 * g]);
-        const float4 vf = *reinterpret_cast<const float4*>(&Vs[(kt + qi) * kst + 4 * g]);
-        f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-        s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf.x, s, 0, 0, 0);
-        s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf.y, s, 0, 0, 0);
-        s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf.z, s, 0, 0, 0);
-        s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf.w, s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.x, da.x, dp, 0, 0, 0);   // dPd^T[key][q] = V[key] . dA[q]
-        dp = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.y, da.y, dp, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.z, da.z, dp, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.w, da.w, dp, 0, 0, 0);
+    for (int kb0 = 0; kb0 < Lp; kb0 += AB2_KB) {
+        const int nk = min(AB2_KB, Lp - kb0);
+        if (kb0) __syncthreads();
+        for (int e = tid; e < nk * 4; e += 256) {
+            const int key = kb0 + (e >> 2), c4 = (e & 3) * 4;
+            float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+            if (key < L) {
+                kv = *reinterpret_cast<const float4*>(K + (rowbase + key) * D + h * HD + c4);
+                vv = *reinterpret_cast<const float4*>(V + (rowbase + key) * D + h * HD + c4);
+            }
+            *reinterpret_cast<float4*>(&Ks[(e >> 2) * kst + c4]) = kv;
+            *reinterpret_cast<float4*>(&Vs[(e >> 2) * kst + c4]) = vv;
+        }
+        for (int kk = tid; kk < nk; kk += 256) Mb[kk] = kb0 + kk < L ? (1.0f - mask[rowbase + kb0 + kk]) * MASK_VALUE : MASK_VALUE;
+        __syncthreads();
+        for (int kt = 0; kt < nk; kt += 16) {
+            const float4 kf = *reinterpret_cast<const float4*>(&Ks[(kt + qi) * kst + 4 * g]);
+            const float4 vf = *reinterpret_cast<const float4*>(&Vs[(kt + qi) * kst + 4 * g]);
+            f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+            s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf.x, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf.y, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf.z, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf.w, s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.x, da.x, dp, 0, 0, 0);   // dPd^T[key][q] = V[key] . dA[q]
+            dp = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.y, da.y, dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.z, da.z, dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.w, da.w, dp, 0, 0, 0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int key = kt + 4 * g + r;
-            const float p = __expf(s[r] * scale + Mb[key] - lq);
-            const float ds = p * (dp[r] * drop_mul(d2, pbase + key) - dsum) * scale;
-            // dQ^T[dd][q] += K[key][dd] * dS[q][key]
-            dq = __builtin_amdgcn_mfma_f32_16x16x4f32(Ks[key * kst + qi], ds, dq, 0, 0, 0);
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt + 4 * g + r;
+                const float p = __expf(s[r] * scale + Mb[key] - lq);
+                const float ds = p * (dp[r] * drop_mul(d2, pbase + kb0 + key) - dsum) * scale;
+                // dQ^T[dd][q] += K[key][dd] * dS[q][key]
+                dq = __builtin_amdgcn_mfma_f32_16x16x4f32(Ks[key * kst + qi], ds, dq, 0, 0, 0);
+            }
         }
     }
     if (qok) *reinterpret_cast<float4*>(dQ + (rowbase + q) * D + h * HD + 4 * g) = make_float4(dq[0], dq[1], dq[2], dq[3]);
 }
-// dK, dV: wave owns 16 keys (lane: key ki = lane & 15, query group g = lane >> 4), Q / dA head slices in LDS.
+// dK, dV: wave owns 16 keys (lane: key ki = lane & 15, query group g = lane >> 4); the Q / dA head slices (+ LSE, D) stream
+// through LDS in blocks of AB2_KB queries.
 __global__ __launch_bounds__(256) void k_attn_bwd_dkv(const float* __restrict__ Q, const float* __restrict__ K,
                                                       const float* __restrict__ V, const float* __restrict__ dr,
                                                       const float* __restrict__ lse, const float* __restrict__ Dq,
@@ -705,35 +713,15 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(const float* __restrict__ 
                                                       float* __restrict__ dV, int L, int H, int b_off, Drop d2, Drop d3) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int Lp = (L + 15) & ~15;
-    const int kst = head_slice_stride(Lp);
+    const int KB = min(Lp, AB2_KB);
+    constexpr int kst = 20;
     float* Qs = smem;
-    float* As = Qs + Lp * kst;          // dA = dr * m3
-    float* Ls = As + Lp * kst;          // LSE per query
-    float* Ds = Ls + Lp;                // D per query
+    float* As = Qs + KB * kst;          // dA = dr * m3
+    float* Ls = As + KB * kst;          // LSE per query
+    float* Ds = Ls + KB;                // D per query
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int b = blockIdx.z, h = blockIdx.y;
     const size_t rowbase = (size_t)b * L;
-    for (int e = tid; e < Lp * 4; e += 256) {
-        const int qq = e >> 2, c4 = (e & 3) * 4;
-        float4 qv = make_float4(0.f, 0.f, 0.f, 0.f), av = qv;
-        if (qq < L) {
-            const size_t off = (rowbase + qq) * D + h * HD + c4;
-            qv = *reinterpret_cast<const float4*>(Q + off);
-            av = *reinterpret_cast<const float4*>(dr + off);
-            if (d3.thresh) {
-                const uint32_t base = (uint32_t)off;
-                av.x *= drop_mul(d3, base); av.y *= drop_mul(d3, base + 1);
-                av.z *= drop_mul(d3, base + 2); av.w *= drop_mul(d3, base + 3);
-            }
-        }
-        *reinterpret_cast<float4*>(&Qs[qq * kst + c4]) = qv;
-        *reinterpret_cast<float4*>(&As[qq * kst + c4]) = av;
-    }
-    for (int qq = tid; qq < Lp; qq += 256) {
-        Ls[qq] = qq < L ? lse[((size_t)b * H + h) * L + qq] : 0.f;
-        Ds[qq] = qq < L ? Dq[((size_t)b * H + h) * L + qq] : 0.f;
-    }
-    __syncthreads();
     const int ki = lane & 15, g = lane >> 4;
     const int key = blockIdx.x * 64 + w * 16 + ki;
     const bool kok = key < L;
@@ -747,29 +735,54 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(const float* __restrict__ 
     const float scale = 0.25f;
     const uint32_t hb = (uint32_t)(((size_t)(b + b_off) * H + h) * L);
     f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
-    for (int qt = 0; qt < Lp; qt += 16) {
-        // S tile (rows = queries qt + 4g + reg, col = key ki) and dPd tile, same shape
-        const float4 qa = *reinterpret_cast<const float4*>(&Qs[(qt + ki) * kst + 4 * g]);
-        const float4 aa = *reinterpret_cast<const float4*>(&As[(qt + ki) * kst + 4 * g]);
-        f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-        s = __builtin_amdgcn_mfma_f32_16x16x4f32(qa.x, kf.x, s, 0, 0, 0);
-        s = __builtin_amdgcn_mfma_f32_16x16x4f32(qa.y, kf.y, s, 0, 0, 0);
-        s = __builtin_amdgcn_mfma_f32_16x16x4f32(qa.z, kf.z, s, 0, 0, 0);
-        s = __builtin_amdgcn_mfma_f32_16x16x4f32(qa.w, kf.w, s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x4f32(aa.x, vf.x, dp, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x4f32(aa.y, vf.y, dp, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x4f32(aa.z, vf.z, dp, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x4f32(aa.w, vf.w, dp, 0, 0, 0);
+    for (int qb0 = 0; qb0 < Lp; qb0 += AB2_KB) {
+        const int nq = min(AB2_KB, Lp - qb0);
+        if (qb0) __syncthreads();
+        for (int e = tid; e < nq * 4; e += 256) {
+            const int qq = qb0 + (e >> 2), c4 = (e & 3) * 4;
+            float4 qv = make_float4(0.f, 0.f, 0.f, 0.f), av = qv;
+            if (qq < L) {
+                const size_t off = (rowbase + qq) * D + h * HD + c4;
+                qv = *reinterpret_cast<const float4*>(Q + off);
+                av = *reinterpret_cast<const float4*>(dr + off);
+                if (d3.thresh) {
+                    const uint32_t base = (uint32_t)off;
+                    av.x *= drop_mul(d3, base); av.y *= drop_mul(d3, base + 1);
+                    av.z *= drop_mul(d3, base + 2); av.w *= drop_mul(d3, base + 3);
+                }
+            }
+            *reinterpret_cast<float4*>(&Qs[(e >> 2) * kst + c4]) = qv;
+            *reinterpret_cast<float4*>(&As[(e >> 2) * kst + c4]) = av;
+        }
+        for (int qq = tid; qq < nq; qq += 256) {
+            Ls[qq] = qb0 + qq < L ? lse[((size_t)b * H + h) * L + qb0 + qq] : 0.f;
+            Ds[qq] = qb0 + qq < L ? Dq[((size_t)b * H + h) * L + qb0 + qq] : 0.f;
+        }
+        __syncthreads();
+        for (int qt = 0; qt < nq; qt += 16) {
+            // S tile (rows = queries qb0 + qt + 4g + reg, col = key ki) and dPd tile, same shape
+            const float4 qa = *reinterpret_cast<const float4*>(&Qs[(qt + ki) * kst + 4 * g]);
+            const float4 aa = *reinterpret_cast<const float4*>(&As[(qt + ki) * kst + 4 * g]);
+            f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+            s = __builtin_amdgcn_mfma_f32_16x16x4f32(qa.x, kf.x, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_16x16x4f32(qa.y, kf.y, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_16x16x4f32(qa.z, kf.z, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_16x16x4f32(qa.w, kf.w, s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x4f32(aa.x, vf.x, dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x4f32(aa.y, vf.y, dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x4f32(aa.z, vf.z, dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x4f32(aa.w, vf.w, dp, 0, 0, 0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int qq = qt + 4 * g + r;
-            const float p = __expf(s[r] * scale + mb - Ls[qq]);
-            const float m2 = drop_mul(d2, (hb + (uint32_t)qq) * (uint32_t)L + (uint32_t)key);
-            const float pd = p * m2;
-            const float ds = p * (dp[r] * m2 - Ds[qq]) * scale;
-            // dV^T[dd][key] += dA[q][dd] * Pd[q][key] ; dK^T[dd][key] += Q[q][dd] * dS[q][key]
-            dv = __builtin_amdgcn_mfma_f32_16x16x4f32(As[qq * kst + ki], pd, dv, 0, 0, 0);
-            dk = __builtin_amdgcn_mfma_f32_16x16x4f32(Qs[qq * kst + ki], ds, dk, 0, 0, 0);
+            for (int r = 0; r < 4; ++r) {
+                const int ql = qt + 4 * g + r;
+                const float p = __expf(s[r] * scale + mb - Ls[ql]);
+                const float m2 = drop_mul(d2, (hb + (uint32_t)(qb0 + ql)) * (uint32_t)L + (uint32_t)key);
+                const float pd = p * m2;
+                const float ds = p * (dp[r] * m2 - Ds[ql]) * scale;
+                // dV^T[dd][key] += dA[q][dd] * Pd[q][key] ; dK^T[dd][key] += Q[q][dd] * dS[q][key]
+                dv = __builtin_amdgcn_mfma_f32_16x16x4f32(As[ql * kst + ki], pd, dv, 0, 0, 0);
+                dk = __builtin_amdgcn_mfma_f32_16x16x4f32(Qs[ql * kst + ki], ds, dk, 0, 0, 0);
+            }
         }
     }
     if (kok) {
@@ -962,8 +975,8 @@ void launch_attn_bwd(const float* Q, const float* K, const float* V, const float
         if (dbg_budget("attn_bwd") && L > 64) dbg_report("attn_bwd_fused: stage-issue | landed+sync | pass-0 phase1 | sync | phase2 | sync | pass 1 + final", 8, s, left);
         return;
     }
-    const int kst = head_slice_stride(Lp);
-    const size_t shm1 = (size_t)(2 * Lp * kst + Lp) * sizeof(float), shm2 = (size_t)(2 * Lp * kst + 2 * Lp) * sizeof(float);
+    const int KB = Lp < AB2_KB ? Lp : AB2_KB;
+    const size_t shm1 = (size_t)(2 * KB * 20 + KB) * sizeof(float), shm2 = (size_t)(2 * KB * 20 + 2 * KB) * sizeof(float);
     static size_t lds_ok1 = 0, lds_ok2 = 0;
     ensure_dynamic_lds((const void*)k_attn_bwd_dq, shm1, lds_ok1, "k_attn_bwd_dq");
     ensure_dynamic_lds((const void*)k_attn_bwd_dkv, shm2, lds_ok2, "k_attn_bwd_dkv");
