@@ -709,9 +709,9 @@ void run_backward(Ctx& c) {
         c.defer_w = false;
     }
     // ---- CQAttention + WeightedPool / pooled-bias backward: four tile-parallel kernels (kernels_bwd.hip)
+    CqBwdArgs q;
     {
         const int ntile = (T + TILE_M - 1) / TILE_M;
-        CqBwdArgs q;
         memset(&q, 0, sizeof q);
         if (!c.dry) {
             q.df1 = c.W(p.df1); q.df2 = c.W(p.df2); q.C = c.W(p.ve.out); q.Qf = c.W(p.qe.out); q.Srow = c.W(p.Srow);
@@ -729,6 +729,7 @@ void run_backward(Ctx& c) {
         LAUNCH("cq_bwd", launch_cq_bwd(q, B, c.s));
     }
     // early reduction (predictor / heads / CQ parameters): all their partials exist once the launches above are done
+    // (the pooled-query parameters of k_cq_bwd_d belong to the late reduction: that kernel opens the query chain below).
     // ONE event for both consumers: the early reduction on sw and the fork of the query side onto sq
     c.order2(c.s, sw, sq);
     { hipStream_t keep = c.s; c.s = sw; LAUNCH("reduce", launch_reduce(c.ws, io->grads, p.segs_dev, p.blk2seg_dev, p.nblocks_early, c.s)); c.s = keep; }
@@ -753,6 +754,7 @@ void run_backward(Ctx& c) {
     }
     // ---- query pass, then the embedding stack (all on the other stream)
     c.s = qlong ? main_s : sq;
+    LAUNCH("cq_bwd_d", launch_cq_bwd_query(q, B, c.s));     // dQ: only the query side consumes it
     WgradBatch pw_query;
     memset(&pw_query, 0, sizeof pw_query);
     enc_bwd(c, P.fe, K.fe, p.qe, c.dry ? nullptr : c.W(p.dQtot), nullptr, p.dqf, c.dry ? nullptr : io->q_mask, B, 1, sw, &pw_query);
@@ -878,11 +880,15 @@ int build_plan(vsl_handle_s* h, int B, int T, int Lq, int Lc, Plan** out) {
         for (int q = 0; q < s.nsrc; ++q) s.vec = s.vec && (s.src[q] % 4 == 0) && (s.ss[q] % 4 == 0) && (s.vn[q] % 4 == 0);
     }
     // early / late split by destination: everything up to the end of the shared feature encoder's parameters is `late`
+    // plus what k_cq_bwd_d produces on the query stream after the fork (w4Q, pooled-query weight, second half of / bias of
+    // the CQConcatenate projection)
     const int late_end = h->P.w4C;       // params are laid out [embedding | visual | feature_encoder | cq... | predictor...]
+    const int late_q[4] = {h->P.w4Q, h->P.pool_w, h->P.cat_b, h->P.cat_w + D};
     std::vector<int> blk;
     for (int pass = 0; pass < 2; ++pass) {
         for (size_t i = 0; i < segs.size(); ++i) {
-            const bool late = segs[i].dst < late_end;
+            bool late = segs[i].dst < late_end;
+            for (int d : late_q) late = late || segs[i].dst == d;
             if (late != (pass == 1)) continue;
             for (int o = 0; o < segs[i].n; o += 256) { blk.push_back((int)i); blk.push_back(o); }
         }

@@ -262,15 +262,18 @@ void launch_head_bwd(const HeadBwdArgs& a0, const HeadBwdArgs& a1, int R, hipStr
 
 // =========================================================================================================
 // generic weight gradient  dW[n][k] = sum_r G[r][n] A[r][k]   (+ bias = column sums of G)
-//   grid = (k tiles of 128, row chunks of WG_ROWS, job * 3 + G block); each workgroup writes one partial slab tile.
+//   grid = one workgroup per (job, G block, row chunk of WG_ROWS, k tile of 128); each writes one partial slab tile.
 // =========================================================================================================
 __global__ __launch_bounds__(512) void k_wgrad(WgradBatch wb) {
     extern __shared__ __attribute__((aligned(16))) float smem[];    // 2 x (G tile | A tile), 32 x LDP each
-    const int ji = blockIdx.z / 3, gb = blockIdx.z % 3;
+    // compact 1-D grid: every workgroup has work (an empty one would still hold a CU's LDS while it starts and exits)
+    int ji = 0;
+    while (ji + 1 < wb.n && (int)blockIdx.x >= wb.start[ji + 1]) ++ji;
     const WgradJob& j = wb.j[ji];
-    const int kt = blockIdx.x, ch = blockIdx.y;
     const int K = j.K, R = j.R;
-    if (gb >= j.nG || kt * 128 >= K || ch * WG_ROWS >= R) return;
+    const int nkt = (K + 127) >> 7, nch = (R + WG_ROWS - 1) / WG_ROWS;
+    const int local = blockIdx.x - wb.start[ji];
+    const int kt = local % nkt, ch = (local / nkt) % nch, gb = local / (nkt * nch);
     // 8 waves = 2 per SIMD: wave (nb, kh) owns output rows n = 32 nb .. +32, columns k = 64 kh .. +64 of the 128 x 128
     // block, so one wave's load issue / LDS stores / barrier wait sit under the other wave's MFMAs.
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(512) void k_wgrad(WgradBatch wb) {
     };
     using T_ = std::true_type;
     using F_ = std::false_type;
-    const bool st = g_dbg_on && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0;
+    const bool st = g_dbg_on && blockIdx.x == 0 && threadIdx.x == 0;
     if (st) g_stamps[0] = clock64();
     // Pipeline: while tile i is multiplied out of LDS, tile i+1 (already in registers, requested one step earlier) is
     // written to the other LDS buffer and tile i+2 is requested from memory, all between the MFMA batches.
@@ -400,12 +403,15 @@ __global__ __launch_bounds__(512) void k_wgrad(WgradBatch wb) {
     }
     if (st) g_stamps[3] = clock64();
 }
-void launch_wgrad(const WgradBatch& wb, hipStream_t s) {
-    int kt = 1, ch = 1;
+void launch_wgrad(const WgradBatch& wb0, hipStream_t s) {
+    WgradBatch wb = wb0;
+    int total = 0;
     for (int i = 0; i < wb.n; ++i) {
-        kt = max(kt, (wb.j[i].K + 127) / 128);
-        ch = max(ch, (wb.j[i].R + WG_ROWS - 1) / WG_ROWS);
+        wb.start[i] = total;
+        total += wb.j[i].nG * ((wb.j[i].K + 127) / 128) * ((wb.j[i].R + WG_ROWS - 1) / WG_ROWS);
     }
+    wb.start[wb.n] = total;
+    if (total == 0) return;
     const size_t shm = (size_t)4 * TILE_M * LDP * sizeof(float);
     static size_t lds_ok = 0;
     ensure_dynamic_lds((const void*)k_wgrad, shm, lds_ok, "k_wgrad");
@@ -416,7 +422,7 @@ void launch_wgrad(const WgradBatch& wb, hipStream_t s) {
         static const bool wg_excl = !(getenv("VSL_WGRAD_EXCL") && getenv("VSL_WGRAD_EXCL")[0] == '0');
         const size_t shm_sp = wg_excl ? (shm > 84 * 1024 ? shm : (size_t)84 * 1024) : spread_lds(shm, 0, 0);
         ensure_dynamic_lds((const void*)k_wgrad, shm_sp + 0, lds_sp, "k_wgrad");
-        hipLaunchKernelGGL(k_wgrad, dim3(kt, ch, wb.n * 3), dim3(512), shm_sp, s, wb);
+        hipLaunchKernelGGL(k_wgrad, dim3(total), dim3(512), shm_sp, s, wb);
         static int left = 12;
         if (dbg_budget("wgrad")) { char nm[96]; snprintf(nm, sizeof nm, "wgrad n=%d K=%d R=%d: prologue | 8-step loop | stores", wb.n, wb.j[0].K, wb.j[0].R); dbg_report(nm, 4, s, left); }
     }
@@ -1629,16 +1635,23 @@ void launch_cq_bwd(const CqBwdArgs& a0, int B, hipStream_t s) {
     const size_t shmA = (size_t)(TILE_M * CATP + TILE_M * LDP + 2 * TILE_M * (Lq + 1) + 72 + 4 * TILE_M * (32 * ((Lq + 31) / 32) + 1)) * sizeof(float);
     const size_t shmB = (size_t)(32 * ((Lq + 31) / 32) * LDP + TILE_M * LDP + TILE_M * (Lq + 1) + 4 * TILE_M * (32 * ((Lq + 31) / 32) + 1)) * sizeof(float);
     const size_t shmC = (size_t)(2 * Lq * LDP + 2 * TILE_M * LDP + 2 * TILE_M * (Lq + 1) + 16 + Lq + TILE_M + 4 * D) * sizeof(float);
-    const size_t shmD = (size_t)(Lq * LDP + 2 * Lq + 4 * D) * sizeof(float);
-    static size_t okA = 0, okB = 0, okC = 0, okD = 0;
+    static size_t okA = 0, okB = 0, okC = 0;
     ensure_dynamic_lds((const void*)k_cq_bwd_a, shmA, okA, "k_cq_bwd_a");
     ensure_dynamic_lds((const void*)k_cq_bwd_b, shmB, okB, "k_cq_bwd_b");
     ensure_dynamic_lds((const void*)k_cq_bwd_c, shmC, okC, "k_cq_bwd_c");
-    ensure_dynamic_lds((const void*)k_cq_bwd_d, shmD, okD, "k_cq_bwd_d");
     hipLaunchKernelGGL(k_cq_bwd_a, dim3(ntile, B), dim3(256), shmA, s, a);
     { static int left = 2; if (dbg_budget("cq_bwd_a")) dbg_report("cq_bwd_a: load | gemm512 | Dc store | C load + c2q/q2c | product rule | dS_row + partials | sync | softmax bwd", 8, s, left); }
     hipLaunchKernelGGL(k_cq_bwd_b, dim3(ntile, B), dim3(256), shmB, s, a);
     hipLaunchKernelGGL(k_cq_bwd_c, dim3(ntile, B), dim3(256), shmC, s, a);
+}
+// the per-sample tail (dQ, pooled-query path): nothing on the video side reads its outputs, so it runs on the query stream
+void launch_cq_bwd_query(const CqBwdArgs& a0, int B, hipStream_t s) {
+    CqBwdArgs a = a0;
+    const int Lq = a.Lq;
+    a.ntile = (a.T + TILE_M - 1) / TILE_M;
+    const size_t shmD = (size_t)(Lq * LDP + 2 * Lq + 4 * D) * sizeof(float);
+    static size_t okD = 0;
+    ensure_dynamic_lds((const void*)k_cq_bwd_d, shmD, okD, "k_cq_bwd_d");
     hipLaunchKernelGGL(k_cq_bwd_d, dim3(B), dim3(256), shmD, s, a);
 }
 

@@ -65,8 +65,8 @@ struct WgradJob {
     float* out_bias[3];   // partial slabs [nchunk][128] per G block (nullable)
 };
 constexpr int WG_ROWS = 256;
-constexpr int MAX_WJOBS = 8;
-struct WgradBatch { WgradJob j[MAX_WJOBS]; int n; };
+constexpr int MAX_WJOBS = 12;
+struct WgradBatch { WgradJob j[MAX_WJOBS]; int n; int start[MAX_WJOBS + 1]; };   // start: first workgroup of each job (launch_wgrad fills it)
 
 struct ReduceSeg {        // grads[dst + (i / rl) * ds + i % rl] = sum over sources q, slabs s of partial[src[q] + s * ss[q] + i],  i < n
     int dst, n;
@@ -192,7 +192,8 @@ struct CqBwdArgs {
     int T, Lq, b_off, ntile;
     Drop dc, dq;
 };
-void launch_cq_bwd(const CqBwdArgs& a, int B, hipStream_t s);
+void launch_cq_bwd(const CqBwdArgs& a, int B, hipStream_t s);          // kernels a, b, c: dC final, dQ partials
+void launch_cq_bwd_query(const CqBwdArgs& a, int B, hipStream_t s);    // kernel d: dQ + pooled-query parameters
 void launch_linear_bwd_data(const float* G, const float* WTpack, float* dA, int R, int K, hipStream_t s);
 void launch_embed_bwd(const float* dE, const int64_t* word_ids, const int64_t* char_ids, const float* E,
                       const int8_t* argpos, const float* char_tab, CharConvPtrs cc,
@@ -207,7 +208,7 @@ constexpr int OPT_BLOCKS = 256;
 void launch_adamw(float* params, const float* grads, float* m, float* v, const uint8_t* decay_mask, float* partials /*[OPT_BLOCKS + 1]*/,
                   int64_t n, float lr, float b1, float b2, float eps, float wd, float clip, float bc1, float bc2_sqrt,
                   float* norm_out, hipStream_t s);
-constexpr int EMB_CHUNK = 8;     // query words per workgroup in the embedding backward
+constexpr int EMB_CHUNK = 4;     // query words per workgroup in the embedding backward
 constexpr int CHARW_TOTAL = 15000;
 
 }  // namespace vsl
