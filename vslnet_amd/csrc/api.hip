@@ -750,7 +750,6 @@ void run_backward(Ctx& c) {
         j.out_bias[0] = c.slab(P.va_b, D, nchunk);
         wb.j[wb.n++] = j;
         LAUNCH("wgrad", launch_wgrad(wb, c.s));
-        LAUNCH("wgrad", launch_wgrad(pw_video, c.s));
     }
     // ---- query pass, then the embedding stack (all on the other stream)
     c.s = qlong ? main_s : sq;
@@ -759,18 +758,25 @@ void run_backward(Ctx& c) {
     memset(&pw_query, 0, sizeof pw_query);
     enc_bwd(c, P.fe, K.fe, p.qe, c.dry ? nullptr : c.W(p.dQtot), nullptr, p.dqf, c.dry ? nullptr : io->q_mask, B, 1, sw, &pw_query);
     const int EW = cf.word_dim + 100;
-    LAUNCH("linear_bwd_data", launch_linear_bwd_data(c.W(p.dqf), c.PK(K.emb_t), c.W(p.dE), Rq, EW, c.s));
-    WgradBatch wb_emb;
-    memset(&wb_emb, 0, sizeof wb_emb);
-    {
+    {   // every remaining weight gradient (video + query pointwise convs, embedding linear) in ONE launch on the video
+        // stream, beside the embedding backward that ends the query stream
+        WgradBatch wb_tail = pw_video;
         WgradJob j = wjob();
         if (!c.dry) { j.G[0] = c.W(p.dqf); j.Afull = c.W(p.E); }
         j.nG = 1; j.nA = 0; j.K = EW; j.R = Rq;
         j.out = c.slab(P.emb_w, D * EW, nchunk_q);
         j.out_bias[0] = c.slab(P.emb_b, D, nchunk_q);
-        wb_emb.j[wb_emb.n++] = j;
-        for (int i = 0; i < pw_query.n && wb_emb.n < MAX_WJOBS; ++i) wb_emb.j[wb_emb.n++] = pw_query.j[i];   // one launch
+        wb_tail.j[wb_tail.n++] = j;
+        const bool fits = wb_tail.n + pw_query.n <= MAX_WJOBS;
+        for (int i = 0; fits && i < pw_query.n; ++i) wb_tail.j[wb_tail.n++] = pw_query.j[i];
+        hipStream_t qs = c.s, vs = qlong ? sq : main_s;
+        c.order(qs, vs);
+        c.s = vs;
+        LAUNCH("wgrad", launch_wgrad(wb_tail, c.s));
+        if (!fits) LAUNCH("wgrad", launch_wgrad(pw_query, c.s));
+        c.s = qs;
     }
+    LAUNCH("linear_bwd_data", launch_linear_bwd_data(c.W(p.dqf), c.PK(K.emb_t), c.W(p.dE), Rq, EW, c.s));
     {
         const int nce = (Rq + EMB_CHUNK - 1) / EMB_CHUNK;
         const int wtot = cf.char_dim * 300;
@@ -789,7 +795,6 @@ void run_backward(Ctx& c) {
                                 c.P(P.char_tab), char_ptrs(c), c.part_ptr(ow), c.part_ptr(ob), p_tab, p_unk, Rq,
                                 p.Lc, cf.word_dim, cf.char_dim, cf.char_size, c.drop(SITE_WORD), c.drop(SITE_CHAR), c.s));
     }
-    LAUNCH("wgrad", launch_wgrad(wb_emb, c.s));            // embedding linear + query-pass pointwise convs, same stream, no wait
     c.s = main_s;
     c.order(sq, c.s);                      // join both side streams before the reduction
     c.order(sw, c.s);
