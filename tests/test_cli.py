@@ -14,7 +14,8 @@ def test_flags_and_defaults_match_reference_cli():
     want = dict(save_dir='datasets_t7', task='charades', fv='new', max_pos_len=128, word_size=None, char_size=None, word_dim=300,
                 video_feature_dim=1024, char_dim=50, dim=128, highlight_lambda=5.0, num_heads=8, drop_rate=0.2, predictor='rnn',
                 gpu_idx='0', seed=12345, mode='train', epochs=100, batch_size=16, num_train_steps=None, init_lr=0.0001,
-                clip_norm=1.0, warmup_proportion=0.0, extend=0.1, period=100, model_dir='ckpt_t7', model_name='vslnet', suffix=None)
+                clip_norm=1.0, warmup_proportion=0.0, extend=0.1, period=100, model_dir='ckpt_t7', model_name='vslnet', suffix=None,
+                data='resident')
     for k, v in want.items():
         assert getattr(ns, k) == v, k
     assert cli.build_parser().parse_args(['--hidden_size', '64']).dim == 64              # TF spelling (main.py:27)
@@ -33,11 +34,12 @@ def test_unknown_task_and_missing_dataset_raise_value_error(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('optimizer,predictor', [('fused', 'transformer'), ('torch', 'transformer'), ('fused', 'rnn')])
-def test_train_then_test_mode_on_synthetic_task(tmp_path, optimizer, predictor):
+@pytest.mark.parametrize('optimizer,predictor,source', [('fused', 'transformer', 'resident'), ('torch', 'transformer', 'resident'),
+                                                        ('fused', 'rnn', 'resident'), ('fused', 'transformer', 'loader')])
+def test_train_then_test_mode_on_synthetic_task(tmp_path, optimizer, predictor, source):
     argv = ['--task', 'synthetic', '--predictor', predictor, '--max_pos_len', '32', '--video_feature_dim', '64', '--batch_size', '16',
             '--epochs', '6', '--init_lr', '0.002', '--drop_rate', '0.1', '--period', '10', '--synthetic_train', '256', '--synthetic_test', '64',
-            '--model_dir', str(tmp_path), '--optimizer', optimizer]
+            '--model_dir', str(tmp_path), '--optimizer', optimizer, '--data', source]
     lines = []
     out = cli.run(argv + ['--mode', 'train'], log=lines.append)
     losses = [v for _, v in out['history'] if isinstance(v, float)]

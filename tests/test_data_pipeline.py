@@ -87,3 +87,45 @@ def test_synthetic_dataset_has_reference_record_format():
     assert int(batch[3].max()) < ds['n_words'] and int(batch[4].max()) < ds['n_chars']
     s, e, _ = data.time_to_index(r['s_time'], r['e_time'], r['v_len'], r['duration'])
     assert (s, e) == (r['s_ind'], r['e_ind'])                   # times and indices of a record are consistent
+
+
+def _small_cfg(batch_size):
+    import argparse
+    return argparse.Namespace(video_feature_dim=16, max_pos_len=24, batch_size=batch_size, word_dim=8, extend=0.1, seed=3)
+
+
+def test_resident_split_yields_the_loader_batches():
+    """HBM-resident split (device gathers) == DataLoader + collate functions, batch for batch: same shapes (batch-wide
+    padding widths), same contents, for the train tuple, the test tuple and the per-rank shards of the fused loop."""
+    cfg = _small_cfg(7)                                          # 40 records: ragged last batch
+    ds, feats = data.synthetic_dataset(cfg, n_train=40, n_test=13, seed=5)
+    order = np.random.RandomState(0).permutation(40)
+    ref = torch.utils.data.DataLoader(data.VideoQueryDataset(ds['train_set'], feats), batch_size=cfg.batch_size, sampler=list(order),
+                                      collate_fn=lambda b: data.collate_train(b, False, cfg.extend))
+    split = data.ResidentSplit(ds['train_set'], feats, cfg, 'cpu', train=True)
+    got = list(split.shards(0, 1, order=order))
+    assert len(got) == len(ref) == len(split)
+    for want, b in zip(ref, got):
+        assert [r['sample_id'] for r in want[0]] == [r['sample_id'] for r in b['records']]
+        assert np.array_equal(want[2].numpy(), b['lens_global'])
+        for w, g in zip(want[1:2] + want[3:], (b['vfeats'], b['word_ids'], b['char_ids'], b['s_labels'], b['e_labels'], b['h_labels'])):
+            assert w.shape == g.shape and w.dtype == g.dtype and torch.equal(w, g)
+        assert torch.equal(runner.convert_length_to_mask(want[2]), b['v_mask'])
+    # two ranks: contiguous halves of every global batch, global widths
+    for want, b0, b1 in zip(ref, split.shards(0, 2, order=order), split.shards(1, 2, order=order)):
+        assert torch.equal(want[1], torch.cat([b0['vfeats'], b1['vfeats']]))
+        assert torch.equal(want[7], torch.cat([b0['h_labels'], b1['h_labels']]))
+        assert np.array_equal(b0['lens_global'], b1['lens_global'])
+    # the host-loader adapter produces the same dicts
+    for b, l in zip(got, data.loader_shards(ref, 'cpu')):
+        assert all(torch.equal(b[k], l[k]) for k in ('vfeats', 'v_mask', 'word_ids', 'char_ids', 's_labels', 'e_labels', 'h_labels'))
+    # evaluation tuples, in dataset order
+    test_ref = data.get_test_loader(ds['test_set'], feats, cfg)
+    for want, have in zip(test_ref, data.ResidentSplit(ds['test_set'], feats, cfg, 'cpu', train=False)):
+        assert len(have) == 5 and all(torch.equal(w, h) for w, h in zip(want[1:], have[1:]))
+    # training order: a permutation drawn from the generator, reproducible
+    a = data.ResidentSplit(ds['train_set'], feats, cfg, 'cpu', train=True, generator=torch.Generator().manual_seed(1))
+    b = data.ResidentSplit(ds['train_set'], feats, cfg, 'cpu', train=True, generator=torch.Generator().manual_seed(1))
+    ids = lambda sp: [r['sample_id'] for bt in sp for r in bt[0]]
+    ia = ids(a)
+    assert sorted(ia) == list(range(40)) and ia == ids(b) and ia != ids(a)      # second epoch: a new permutation
