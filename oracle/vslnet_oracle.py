@@ -108,6 +108,7 @@ def depthwise7(x, w):
 # with the ones the HIP path saved and only then decide which gradient gate applies (tests/helpers.py: relu_flips).
 RELU_SIGNS = None
 RELU_FORCED = None
+RELU_FORCED_DEV = 0.0      # largest |pre-activation| on which a forced branch differed from the sign seen in that same forward
 
 
 def record_relu_signs(on=True):
@@ -118,15 +119,29 @@ def record_relu_signs(on=True):
 def force_relu_signs(masks):
     """Take the given branch (bool tensors, call order) at every ReLU of the next forward instead of sign(z): lets a test
     evaluate the oracle's gradient ON THE BRANCH THE GPU PATH TOOK when a pre-activation sits inside the forward noise."""
-    global RELU_FORCED
+    global RELU_FORCED, RELU_FORCED_DEV
     RELU_FORCED = list(masks) if masks is not None else None
+    if masks is not None:
+        RELU_FORCED_DEV = 0.0
+
+
+def forced_relu_deviation():
+    """After a forced forward: the largest |z| at which the forced decision contradicted sign(z) of THIS forward.  A test
+    asserts it is inside the forward noise -- a forced branch is only legitimate where the pre-activation is ~0 (torch's own
+    no_grad and autograd forwards already differ by ~1e-7 there: mkldnn picks different primitives)."""
+    return RELU_FORCED_DEV
 
 
 def _relu(z, site):
+    global RELU_FORCED_DEV
     if RELU_SIGNS is not None:
         RELU_SIGNS.append((site, (z.detach() > 0)))
     if RELU_FORCED is not None:
-        return z * RELU_FORCED.pop(0).to(z.dtype)
+        m = RELU_FORCED.pop(0)
+        dis = z.detach().abs()[m != (z.detach() > 0)]
+        if dis.numel():
+            RELU_FORCED_DEV = max(RELU_FORCED_DEV, float(dis.max()))
+        return z * m.to(z.dtype)
     return torch.relu(z)
 
 

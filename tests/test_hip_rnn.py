@@ -40,11 +40,11 @@ def _oracle(cfg, P, b, eng=None):
             O.forward(P, cfg, b['word_ids'], b['char_ids'], b['vfeats'], b['v_mask'], b['q_mask'])
         want['flips'], masks = relu_flips(eng, B, T, b['q_mask'].shape[1], predictor='rnn')
         O.record_relu_signs(False)
-        if want['flips']:
-            O.force_relu_signs(masks)
+        O.force_relu_signs(masks)
     Pg = {k: v.clone().requires_grad_(k not in O.FROZEN) for k, v in P.items()}
     oh, osl, oel = O.forward(Pg, cfg, b['word_ids'], b['char_ids'], b['vfeats'], b['v_mask'], b['q_mask'], want=want)
     O.force_relu_signs(None)
+    assert eng is None or O.forced_relu_deviation() <= 2e-5, O.forced_relu_deviation()
     total = O.span_loss(osl, oel, b['s_labels'], b['e_labels']) + 5.0 * O.highlight_loss(oh, b['h_labels'], b['v_mask'])
     total.backward()
     return Pg, want, oh.detach(), osl.detach(), oel.detach(), float(total.detach())

@@ -117,11 +117,13 @@ def test_baseline_shapes_against_oracle(shape):
     # gradients are discontinuous where a ReLU pre-activation crosses zero; when the saved masks show that the two forwards
     # disagree on a branch (likely among the 131 k pre-activations per layer of the long-video shape) the oracle is evaluated
     # on the branch the GPU path took, so the strict gate 1e-4 * ||g||inf + 1e-6 holds in every case
-    if flips:
-        O.force_relu_signs(hip_masks)
+    # (always: torch's own no_grad and autograd forwards can land on different sides of a |z| ~ 1e-8 pre-activation, so the
+    # count above is not enough; the branch taken is legitimate iff the pre-activation it overrides is inside the noise)
+    O.force_relu_signs(hip_masks)
     Pg = {k: v.clone().requires_grad_(k not in O.FROZEN) for k, v in P.items()}
     total, (oh, osl, oel, _, _) = O.total_loss(Pg, cfg, b)
     O.force_relu_signs(None)
+    assert O.forced_relu_deviation() <= 2e-5, (shape['name'], flips, O.forced_relu_deviation())
     total.backward()
     fin = osl.detach().abs() < 1e29
     scale = max(1.0, float(osl.detach()[fin].abs().max()))
@@ -134,6 +136,11 @@ def test_baseline_shapes_against_oracle(shape):
         ref = Pg[k].grad if Pg[k].grad is not None else torch.zeros_like(Pg[k])
         err = float((t.cpu() - ref).abs().max())
         tol = 1e-4 * float(ref.abs().max()) + 1e-6
+        if k == 'cq_attention.w4Q' and shape['Lq'] == 1:
+            # one query word: the softmax over j is the constant 1, so dw4Q is structurally zero (w4Q only acts
+            # through that softmax).  What both sides compute is the cancellation residue of sum_i S_col (dS - dot); the gate
+            # for a structural zero is absolute, at the size of that residue (|dot| ~ 1, softmax normalised to ~1e-6)
+            tol = 2e-5
         if not err <= tol:
             bad.append((k, err, tol))
     assert not bad, (shape['name'], flips, bad[:5])

@@ -1,0 +1,32 @@
+"""Random-shape parity sweep on the GPU: forward logits, losses, every gradient and extract_index against the oracle
+(the body of tests/test_hip_training.py::test_baseline_shapes_against_oracle) for shapes the fixed test list does not hold:
+ragged row counts, odd feature widths, one-word queries, single clips ...   usage: python tools/fuzz_parity.py [n] [seed]"""
+import sys
+import traceback
+
+import numpy as np
+
+sys.path.insert(0, '.')
+from tests.test_hip_training import test_baseline_shapes_against_oracle as check  # noqa: E402
+
+
+def main(n=24, seed=0):
+    rs = np.random.RandomState(seed)
+    bad = 0
+    for i in range(n):
+        shape = dict(name='fuzz %d' % i, B=int(rs.randint(1, 7)), T=int(rs.choice([4, 7, 16, 31, 32, 33, 50, 64, 97, 128, 160])),
+                     Lq=int(rs.choice([1, 2, 3, 8, 20, 31, 32, 33, 47])), Lc=int(rs.choice([4, 5, 10, 17, 24])),
+                     Dv=int(rs.choice([4, 36, 64, 100, 500, 1024])))
+        try:
+            check(shape)
+            print('ok   ', shape, flush=True)
+        except Exception as e:  # noqa: BLE001
+            bad += 1
+            print('FAIL ', shape, repr(e)[:600], flush=True)
+            traceback.print_exc(limit=2)
+    print('%d / %d shapes failed' % (bad, n))
+    return bad
+
+
+if __name__ == '__main__':
+    sys.exit(1 if main(*(int(a) for a in sys.argv[1:3])) else 0)

@@ -941,7 +941,7 @@ int vsl_create(const vsl_config* cfg, vsl_handle* out) {
         return fail("The channels (%d) is not a multiple of attention heads (%d)", cfg->dim, cfg->num_heads);   // layers_t7.py:146
     if (cfg->dim / cfg->num_heads != HD) return fail("num_heads=%d: the attention kernels are specialised for head size 16 (8 heads)", cfg->num_heads);
     if (cfg->predictor != 0 && cfg->predictor != 1) return fail("predictor must be 0 ('rnn') or 1 ('transformer'), got %d", cfg->predictor);
-    if (cfg->video_feature_dim <= 0 || cfg->video_feature_dim % 8) return fail("video_feature_dim=%d must be a positive multiple of 8", cfg->video_feature_dim);
+    if (cfg->video_feature_dim <= 0 || cfg->video_feature_dim % 4) return fail("video_feature_dim=%d must be a positive multiple of 4 (rows are read as float4)", cfg->video_feature_dim);
     if ((cfg->word_dim + 100) % 8) return fail("word_dim + 100 = %d must be a multiple of 8", cfg->word_dim + 100);
     if (cfg->char_dim <= 0 || cfg->char_dim > 64) return fail("char_dim=%d must be in [1, 64]", cfg->char_dim);
     if (cfg->char_size <= 0 || cfg->char_size * cfg->char_dim > 16384) return fail("char table too large for the LDS accumulator");
@@ -1034,6 +1034,14 @@ int64_t vsl_workspace_offset(vsl_handle h, int B, int T, int Lq, int Lc, const c
     if (n == "hid_s") return p->hid_s;
     if (n == "hid_e") return p->hid_e;
     const std::pair<const char*, const EncWs*> encs[] = {{"relu_venc_", &p->ve}, {"relu_qenc_", &p->qe}, {"relu_p1_", &p->p1}, {"relu_p2_", &p->p2}};
+    // "<enc>_y<layer>": output of conv layer 0..3 of that pass (R, 128) ; "<enc>_x0": its input + positional rows
+    const std::pair<const char*, const EncWs*> acts[] = {{"venc_y", &p->ve}, {"qenc_y", &p->qe}, {"p1_y", &p->p1}, {"p2_y", &p->p2}};
+    for (auto& kv : acts) {
+        const size_t len = strlen(kv.first);
+        if (h->cfg.predictor == 0 && (kv.second == &p->p1 || kv.second == &p->p2)) continue;
+        if (n.size() == len + 1 && n.compare(0, len, kv.first) == 0 && n[len] >= '0' && n[len] <= '3') return kv.second->y[n[len] - '0'];
+        if (n.size() == len + 1 && n.compare(0, len - 1, kv.first, len - 1) == 0 && n.compare(len - 1, 2, "x0") == 0) return kv.second->x0;
+    }
     for (auto& kv : encs) {
         const size_t len = strlen(kv.first);
         if (n.size() == len + 1 && n.compare(0, len, kv.first) == 0 && n[len] >= '0' && n[len] <= '3') {

@@ -32,7 +32,8 @@ static void fdbg_report(const char* name, int nst, hipStream_t s, int& left) {
 __global__ __launch_bounds__(256) void k_pack(const float* __restrict__ params, float* __restrict__ pack,
                                               const PackJob* __restrict__ jobs) {
     const PackJob j = jobs[blockIdx.y];
-    const int n = j.kn * j.cn;
+    const int kn8 = j.transpose == 0 ? (j.kn + 7) & ~7 : j.kn;     // forward pack: zero the k rows that pad the last 8-block
+    const int n = kn8 * j.cn;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
         int k, c;
         float v;
@@ -53,8 +54,8 @@ __global__ __launch_bounds__(256) void k_pack(const float* __restrict__ params, 
             k = e / j.cn; c = e - k * j.cn;
             v = params[j.src + (size_t)k * j.ld + c];
         } else {                    // Bm[k][c] = W[c][k]: k is the fast source index
-            c = e / j.kn; k = e - c * j.kn;
-            v = params[j.src + (size_t)c * j.ld + k];
+            c = e / kn8; k = e - c * kn8;
+            v = k < j.kn ? params[j.src + (size_t)c * j.ld + k] : 0.f;
         }
         pack[j.dst + pack_index(j.k_off + k, j.col_off + c, j.ncols)] = v;
     }
@@ -111,7 +112,9 @@ __global__ __launch_bounds__(256) void k_vproj_fwd(const float* __restrict__ X, 
     for (int ch = 0; ch < nchunk; ++ch) {
         const int buf = ch & 1;
         if (ch + 1 < nchunk) gload(ch + 1);             // next chunk in flight while the MFMAs run
-        const int kc = min(VP_KC, Dv - ch * VP_KC);
+        // Dv need only be a multiple of 4 (ActivityNet C3D: 500): the last 8-wide k block is zero in the LDS tile (gload) and
+        // in the packed weight (k_pack) beyond Dv
+        const int kc = (min(VP_KC, Dv - ch * VP_KC) + 7) & ~7;
         {
             const float* wp = Wpack + (size_t)ch * (VP_KC / 8) * D * 8;
             BFrag<1, 8> bf;
