@@ -97,6 +97,7 @@ def test_dropout_mask_statistics_and_scaling():
     dict(name='cfg5 long video', T=1024, Dv=1024, B=1, Lq=20, Lc=10),
     dict(name='edge: B=1 minimal chars, odd lengths', T=37, Dv=64, B=1, Lq=5, Lc=4),
     dict(name='edge: max query length', T=40, Dv=64, B=2, Lq=64, Lc=24),
+    dict(name='edge: ActivityNet C3D width (500 = 4 * 125), one-word queries, ragged row count', T=50, Dv=500, B=3, Lq=1, Lc=4),
 ])
 def test_baseline_shapes_against_oracle(shape):
     cfg = O.make_cfg(video_feature_dim=shape['Dv'], max_pos_len=max(shape['T'], shape['Lq']), word_size=102)
