@@ -36,10 +36,43 @@ def _loss(eng, flat, P, d, seed):
     return float(losses[2].item()), (d_h, d_sl, d_el)
 
 
-def test_dropout_forward_backward_consistency_by_finite_differences():
-    cfg = O.make_cfg(video_feature_dim=64, max_pos_len=64, word_size=52, drop_rate=0.2)
+@pytest.mark.parametrize('dv', [64, 500, 1024])
+def test_visual_projection_weight_gradient_uses_the_forward_dropout_mask(dv):
+    """Exact identity instead of finite differences (whose noise is ~3 % at these widths): with m the dropout mask of the
+    features, vf = (X * m) W^T + b and dW = G^T (X * m), so for ANY matrix Z:  <dW, Z> = <G, (X * m) Z^T>, and the right-hand
+    product is what the forward writes when the weight is Z and the bias 0 (same seed -> same mask).  Covers every k-chunk
+    of the forward GEMM and every k-tile of the weight-gradient kernel, incl. a width that is not a multiple of 8 or 128."""
+    cfg = O.make_cfg(video_feature_dim=dv, max_pos_len=64, word_size=52, drop_rate=0.2)
     P = O.random_params(cfg, seed=3)
-    d = _dev(O.synthetic_batch(cfg, B=4, T=48, Lq=9, Lc=7, seed=4, ragged=True))
+    B, T = 3, 37
+    d = _dev(O.synthetic_batch(cfg, B=B, T=T, Lq=4, Lc=5, seed=4, ragged=True))
+    eng, flat = _engine(cfg, P)
+    seed = 424242
+    _, seeds = _loss(eng, flat, P, d, seed)
+    g = eng.backward(*seeds, eng.new_flat())
+    dW = eng.views(g)['video_affine.linear.conv1d.weight'].double().squeeze(-1).clone()      # (128, dv)
+    G = eng.ws_view('d_video_affine', (B * T, 128)).double().clone()
+    Z = torch.randn(128, dv, generator=torch.Generator().manual_seed(1)).cuda()
+    flat_z = flat.clone()
+    vz = eng.views(flat_z)
+    vz['video_affine.linear.conv1d.weight'].copy_(Z.unsqueeze(-1))
+    vz['video_affine.linear.conv1d.bias'].zero_()
+    _fwd(eng, flat_z, P, d, True, seed)
+    vf_z = eng.ws_view('video_affine', (B * T, 128)).double()
+    lhs, rhs = float((dW * Z.double()).sum()), float((G * vf_z).sum())
+    scale = float((G.abs() * vf_z.abs()).sum())
+    assert abs(lhs - rhs) <= 1e-5 * scale, (lhs, rhs, scale)
+    # and the mask really is there: without it the identity fails by far more than the tolerance
+    _fwd(eng, flat_z, P, d, False, seed)
+    rhs_nomask = float((G * eng.ws_view('video_affine', (B * T, 128)).double()).sum())
+    assert abs(lhs - rhs_nomask) > 1e-3 * scale
+
+
+@pytest.mark.parametrize('dv,B,T,Lq,Lc,predictor', [(64, 4, 48, 9, 7, 'transformer'), (64, 5, 33, 6, 5, 'rnn')])
+def test_dropout_forward_backward_consistency_by_finite_differences(dv, B, T, Lq, Lc, predictor):
+    cfg = O.make_cfg(video_feature_dim=dv, max_pos_len=64, word_size=52, drop_rate=0.2, predictor=predictor)
+    P = O.random_params(cfg, seed=3)
+    d = _dev(O.synthetic_batch(cfg, B=B, T=T, Lq=Lq, Lc=Lc, seed=4, ragged=True))
     eng, flat = _engine(cfg, P)
     seed = 1234567
     f0, seeds = _loss(eng, flat, P, d, seed)
@@ -53,8 +86,10 @@ def test_dropout_forward_backward_consistency_by_finite_differences():
     assert np.isfinite(gn) and gn > 0
     rs = np.random.RandomState(0)
     for trial in range(3):
-        # direction: the gradient itself (trial 0), then random sign-flipped versions of it (same scale per element)
-        v = gd / gn if trial == 0 else (gd * torch.from_numpy(rs.choice([-1.0, 1.0], size=gd.numel())).cuda()) / gn
+        # direction: the gradient itself (trial 0), then the gradient restricted to a random half of the parameters (the
+        # predicted slope is then the norm of that half: never small, so eps stays in the linear range)
+        v = gd if trial == 0 else gd * torch.from_numpy(rs.choice([0.0, 1.0], size=gd.numel())).cuda()
+        v = v / float(v.norm())
         pred = float((gd * v).sum())
         eps = 0.02 / max(abs(pred), 1e-3)                      # predicted change of the loss ~ 2e-2 (fp32 noise ~ 3e-5)
         fp, _ = _loss(eng, (flat.double() + eps * v).float(), P, d, seed)
