@@ -31,9 +31,27 @@ CHAR_KERNELS = (1, 2, 3, 4)
 CHAR_CHANNELS = (10, 20, 30, 40)
 
 
+# Training-mode parity: nn.Dropout draws from torch's generator, the HIP path from a counter-based hash.  A test can hand
+# the oracle the HIP path's masks: DROP_FORCED(call_number, shape, p) -> multiplier tensor (0 or 1/(1-p)); the dropout
+# sites are numbered in call order (visual, word, char, 9 per encoder pass [conv 0-3, LN1, probabilities, attention output,
+# LN2, out projection] for video / query, CQ context, CQ query, then the two predictor passes).
+DROP_FORCED = None
+DROP_CALLS = 0
+
+
+def force_dropout(fn):
+    global DROP_FORCED, DROP_CALLS
+    DROP_FORCED, DROP_CALLS = fn, 0
+
+
 def _drop(x, p, training):
     """nn.Dropout(p) with inverted scaling (layers_t7.py: every nn.Dropout site)."""
+    global DROP_CALLS
     if training and p > 0.0:
+        if DROP_FORCED is not None:
+            m = DROP_FORCED(DROP_CALLS, tuple(x.shape), p)
+            DROP_CALLS += 1
+            return x * m
         return F.dropout(x, p=p, training=True)
     return x
 

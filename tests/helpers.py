@@ -56,3 +56,43 @@ def relu_flips(eng, B, T, Lq, predictor='transformer'):
         flips += int((act != sites[len(encs) + k][1]).sum())
         masks.append(act)
     return flips, masks
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# the HIP path's dropout masks, recomputed on the host (vslnet_amd/csrc/common.hpp: drop_keep_scale, api.hip: Ctx::drop)
+# ---------------------------------------------------------------------------------------------------------------------------
+_M32 = np.uint64(0xFFFFFFFF)
+
+
+def _fmix32(h):
+    h = h & _M32
+    h ^= h >> np.uint64(16)
+    h = (h * np.uint64(0x85EBCA6B)) & _M32
+    h ^= h >> np.uint64(13)
+    h = (h * np.uint64(0xC2B2AE35)) & _M32
+    h ^= h >> np.uint64(16)
+    return h
+
+
+def hip_site_seed(seed, site):
+    seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    x = (seed & 0xFFFFFFFF) ^ (((seed >> 32) * 0x9E3779B1) & 0xFFFFFFFF) ^ ((site * 0x85EBCA77 + 0x165667B1) & 0xFFFFFFFF)
+    return int(_fmix32(np.array([x], dtype=np.uint64))[0])
+
+
+# site ids in the order the oracle reaches its dropout calls (api.hip: SITE_* = 64.., encoder pass `app` * 16 + 0..8)
+HIP_DROP_SITES = [64, 65, 66] + list(range(0, 9)) + list(range(16, 25)) + [67, 68] + list(range(32, 41)) + list(range(48, 57))
+
+
+def hip_dropout(seed):
+    """-> callable for O.force_dropout: multiplier of element i (row-major index in the tensor the reference applies
+    nn.Dropout to) at the k-th dropout call = keep(fmix32(i * 0x9E3779B1 + seed_site)) / (1 - p)."""
+    def mask(call_no, shape, p):
+        site = HIP_DROP_SITES[call_no]
+        n = int(np.prod(shape))
+        idx = np.arange(n, dtype=np.uint64)
+        h = _fmix32(((idx * np.uint64(0x9E3779B1)) & _M32) + np.uint64(hip_site_seed(seed, site)))
+        thresh = np.uint64(min(4294967295.0, float(np.float32(p)) * 4294967296.0))
+        scale = np.float32(1.0) / (np.float32(1.0) - np.float32(p))
+        return torch.from_numpy(np.where(h >= thresh, scale, np.float32(0.0)).astype(np.float32).reshape(shape))
+    return mask

@@ -98,6 +98,54 @@ def test_dropout_forward_backward_consistency_by_finite_differences(dv, B, T, Lq
         assert abs(fd - pred) <= 0.03 * abs(pred) + 2e-3, 'trial %d: finite difference %.6f vs g.v %.6f' % (trial, fd, pred)
 
 
+@pytest.mark.parametrize('dv,B,T,Lq,Lc,predictor', [(64, 3, 40, 7, 6, 'transformer'), (1024, 2, 128, 20, 10, 'transformer'),
+                                                    (500, 4, 33, 5, 4, 'rnn')])
+def test_training_mode_matches_oracle_on_the_same_dropout_masks(dv, B, T, Lq, Lc, predictor):
+    """drop_rate 0.2 (the benchmark's mode), all 41 dropout sites: the oracle is handed the HIP path's masks -- recomputed on
+    the host from the documented counter-based hash (tests/helpers.py) -- and must then agree with the training-mode forward
+    (logits 1e-4) and with every gradient (1e-4 * |g|inf + 1e-6), like the eval-mode parity tests."""
+    from tests.helpers import relu_flips, hip_dropout
+    cfg = O.make_cfg(video_feature_dim=dv, max_pos_len=max(T, Lq), word_size=102, drop_rate=0.2, predictor=predictor)
+    P = O.random_params(cfg, seed=21)
+    b = O.synthetic_batch(cfg, B, T, Lq, Lc, seed=22, ragged=True)
+    d = _dev(b)
+    eng, flat = _engine(cfg, P)
+    seed = (7 << 33) + 12345                     # exercises the high word of the 64-bit seed too
+    h, sl, el = _fwd(eng, flat, P, d, True, seed)
+    losses, d_h, d_sl, d_el = eng.loss(d['s_labels'], d['e_labels'], d['h_labels'], 1.0, 5.0)
+    g = eng.backward(d_h, d_sl, d_el, eng.new_flat())
+    torch.cuda.synchronize()
+    O.record_relu_signs()
+    O.force_dropout(hip_dropout(seed))
+    with torch.no_grad():
+        O.total_loss(P, cfg, b, training=True)
+    _, hip_masks = relu_flips(eng, B, T, Lq, predictor=predictor)
+    O.record_relu_signs(False)
+    O.force_relu_signs(hip_masks)
+    O.force_dropout(hip_dropout(seed))
+    Pg = {k: v.clone().requires_grad_(k not in O.FROZEN) for k, v in P.items()}
+    total, (oh, osl, oel, _, _) = O.total_loss(Pg, cfg, b, training=True)
+    n_sites = O.DROP_CALLS
+    O.force_relu_signs(None)
+    O.force_dropout(None)
+    assert n_sites == (41 if predictor == 'transformer' else 23)
+    assert O.forced_relu_deviation() <= 2e-5
+    total.backward()
+    fin = osl.detach().abs() < 1e29
+    scale = max(1.0, float(osl.detach()[fin].abs().max()))
+    assert float((sl.cpu() - osl.detach())[fin].abs().max()) <= 1e-4 * scale
+    assert float((el.cpu() - oel.detach())[fin].abs().max()) <= 1e-4 * scale
+    assert float((h.cpu() - oh.detach()).abs().max()) <= 2e-5
+    assert abs(float(losses[2]) - float(total.detach())) <= 1e-4 * max(1.0, abs(float(total.detach())))
+    bad = []
+    for k, t in eng.views(g).items():
+        ref = Pg[k].grad if Pg[k].grad is not None else torch.zeros_like(Pg[k])
+        err, tol = float((t.cpu() - ref).abs().max()), 1e-4 * float(ref.abs().max()) + 1e-6
+        if not err <= tol:
+            bad.append((k, err, tol))
+    assert not bad, bad[:6]
+
+
 def test_dropout_mask_statistics_and_scaling():
     """Word-embedding dropout (layers_t7.py:45) is directly observable in the saved concat buffer: kept entries equal
     table / (1 - p), the rest are exactly 0, and the drop fraction is p within sampling error."""
