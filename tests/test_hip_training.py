@@ -146,6 +146,63 @@ def test_training_mode_matches_oracle_on_the_same_dropout_masks(dv, B, T, Lq, Lc
     assert not bad, bad[:6]
 
 
+def test_headline_shape_at_full_size():
+    """BASELINE configs[1] exactly as bench.py runs it (B=64, T=128, Dv=1024, Lq=20, Lc=10, drop_rate 0.2, train mode):
+    (1) against the oracle on the same dropout masks -- logits 1e-4, every gradient 1e-4 * |g|inf + 1e-6;
+    (2) size-independent property the data-parallel path rests on: with the GLOBAL normalisers (1/B, sum of the mask) the
+        gradients of two half batches add up to the gradient of the full batch (eval mode: masks are per-launch)."""
+    from tests.helpers import relu_flips, hip_dropout
+    B, T, Lq, Lc = 64, 128, 20, 10
+    cfg = O.make_cfg(video_feature_dim=1024, max_pos_len=128, word_size=1002, drop_rate=0.2)
+    P = O.random_params(cfg, seed=12345)
+    b = O.synthetic_batch(cfg, B, T, Lq, Lc, seed=0, ragged=True)
+    d = _dev(b)
+    eng, flat = _engine(cfg, P)
+    seed = 20260928
+    h, sl, el = _fwd(eng, flat, P, d, True, seed)
+    losses, d_h, d_sl, d_el = eng.loss(d['s_labels'], d['e_labels'], d['h_labels'], 1.0, 5.0)
+    g = eng.backward(d_h, d_sl, d_el, eng.new_flat()).clone()
+    torch.cuda.synchronize()
+    O.record_relu_signs()
+    O.force_dropout(hip_dropout(seed))
+    with torch.no_grad():
+        O.total_loss(P, cfg, b, training=True)
+    flips, hip_masks = relu_flips(eng, B, T, Lq)
+    O.record_relu_signs(False)
+    O.force_relu_signs(hip_masks)
+    O.force_dropout(hip_dropout(seed))
+    Pg = {k: v.clone().requires_grad_(k not in O.FROZEN) for k, v in P.items()}
+    total, (oh, osl, oel, _, _) = O.total_loss(Pg, cfg, b, training=True)
+    O.force_relu_signs(None)
+    O.force_dropout(None)
+    assert O.forced_relu_deviation() <= 2e-5, (flips, O.forced_relu_deviation())
+    total.backward()
+    fin = osl.detach().abs() < 1e29
+    scale = max(1.0, float(osl.detach()[fin].abs().max()))
+    assert float((sl.cpu() - osl.detach())[fin].abs().max()) <= 1e-4 * scale
+    assert float((el.cpu() - oel.detach())[fin].abs().max()) <= 1e-4 * scale
+    assert abs(float(losses[2]) - float(total.detach())) <= 1e-4 * max(1.0, abs(float(total.detach())))
+    bad = []
+    for k, t in eng.views(g).items():
+        ref = Pg[k].grad if Pg[k].grad is not None else torch.zeros_like(Pg[k])
+        err, tol = float((t.cpu() - ref).abs().max()), 1e-4 * float(ref.abs().max()) + 1e-6
+        if not err <= tol:
+            bad.append((k, err, tol))
+    assert not bad, (flips, bad[:6])
+    # ---- (2) shards add up (eval mode)
+    def grads_of(rows, inv_batch, mask_sum):
+        dd = {k: v[rows].contiguous() for k, v in d.items()}
+        _fwd(eng, flat, P, dd, False, 0)
+        _, dh, dsl, del_ = eng.loss(dd['s_labels'], dd['e_labels'], dd['h_labels'], 1.0, 5.0, inv_batch=inv_batch, mask_sum=mask_sum)
+        return eng.backward(dh, dsl, del_, eng.new_flat()).double().clone()
+    msum = float(b['v_mask'].sum())
+    full = grads_of(slice(0, B), 1.0 / B, msum)
+    parts = grads_of(slice(0, B // 2), 1.0 / B, msum) + grads_of(slice(B // 2, B), 1.0 / B, msum)
+    for k, t in eng.views(full).items():
+        err = float((t - eng.views(parts)[k]).abs().max())
+        assert err <= 2e-5 * float(t.abs().max()) + 1e-7, (k, err)
+
+
 def test_dropout_mask_statistics_and_scaling():
     """Word-embedding dropout (layers_t7.py:45) is directly observable in the saved concat buffer: kept entries equal
     table / (1 - p), the rest are exactly 0, and the drop fraction is p within sampling error."""
