@@ -162,7 +162,7 @@ def main():
 
     def step(i):
         eng.forward(flat, pad_vec, glove_vec, batch['word_ids'], batch['char_ids'], batch['vfeats'], batch['v_mask'],
-                    batch['q_mask'], training=True, seed=(rank << 32) + i)
+                    batch['q_mask'], training=True, seed=i, sample_offset=rank * B)
         losses, d_h, d_sl, d_el = eng.loss(batch['s_labels'], batch['e_labels'], batch['h_labels'], 1.0,
                                            configs.highlight_lambda, inv_batch=inv_batch, mask_sum=mask_sum)
         eng.backward(d_h, d_sl, d_el, grads)

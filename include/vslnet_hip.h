@@ -65,6 +65,10 @@ typedef struct {
     const float* d_start_logits;   /* (B, T)                                                                        */
     const float* d_end_logits;     /* (B, T)                                                                        */
     float* grads;                  /* flat gradient bucket, same layout as `params` (overwritten, not accumulated) */
+    /* data parallel: index of this shard's first sample in the GLOBAL batch.  The dropout element counters continue
+     * from it, so for one seed the masks -- and with the global loss normalisers the summed gradient -- do not depend
+     * on how many ranks the batch is split over (shards keep the global padded T / Lq / Lc).  0 = single process.  */
+    int32_t sample_offset;
 } vsl_io;
 
 /* labels + weights for the fused loss (replaces compute_loss / compute_highlight_loss, VSLNet_t7.py:67-72, and the

@@ -11,7 +11,9 @@ What differs from the reference, by design:
     clip + AdamW step on the flat parameter bucket; `--optimizer torch` is the reference's loop verbatim in structure
     (module API, `clip_grad_norm_`, `torch.optim.AdamW`, LambdaLR) -- single process only;
   * under torch.distributed.run every rank draws the same shuffled global batch and keeps its contiguous slice; losses are
-    normalised with the GLOBAL batch size / mask sum, gradients are summed with one all-reduce of the flat bucket
+    normalised with the GLOBAL batch size / mask sum, the dropout counters continue at the shard's first sample (so the
+    masks, hence the training trajectory, do not depend on the number of ranks), gradients are summed with one all-reduce
+    of the flat bucket
     (vslnet_amd/dp.py), the update is identical on every rank; rank 0 evaluates and writes checkpoints;
   * `--data resident` (default): each split is uploaded to HBM once (vslnet_amd/data.py: ResidentSplit) and a batch is a
     device gather with the shapes / contents of the reference's collate functions; `--data loader` keeps the reference's
@@ -139,7 +141,7 @@ def train(configs, dataset, features, device, world, rank, log=print):
                 inv_batch, mask_sum = dp.global_normalisers(batch['lens_global'])
                 q_mask = (batch['word_ids'] != 0).float()
                 eng.forward(flat, pad_vec, glove_vec, batch['word_ids'], batch['char_ids'], batch['vfeats'], batch['v_mask'], q_mask,
-                            training=True, seed=(configs.seed << 20) + global_step * world + rank)
+                            training=True, seed=(configs.seed << 20) + global_step, sample_offset=batch['row0'])
                 losses, d_h, d_sl, d_el = eng.loss(batch['s_labels'], batch['e_labels'], batch['h_labels'], 1.0, configs.highlight_lambda,
                                                    inv_batch=inv_batch, mask_sum=mask_sum)
                 eng.backward(d_h, d_sl, d_el, grads)

@@ -149,8 +149,8 @@ def test_training_mode_matches_oracle_on_the_same_dropout_masks(dv, B, T, Lq, Lc
 def test_headline_shape_at_full_size():
     """BASELINE configs[1] exactly as bench.py runs it (B=64, T=128, Dv=1024, Lq=20, Lc=10, drop_rate 0.2, train mode):
     (1) against the oracle on the same dropout masks -- logits 1e-4, every gradient 1e-4 * |g|inf + 1e-6;
-    (2) size-independent property the data-parallel path rests on: with the GLOBAL normalisers (1/B, sum of the mask) the
-        gradients of two half batches add up to the gradient of the full batch (eval mode: masks are per-launch)."""
+    (2) size-independent property the data-parallel path rests on: with the GLOBAL normalisers (1/B, sum of the mask) and
+        `sample_offset`, the training-mode gradients of three uneven shards add up to the gradient of the full batch."""
     from tests.helpers import relu_flips, hip_dropout
     B, T, Lq, Lc = 64, 128, 20, 10
     cfg = O.make_cfg(video_feature_dim=1024, max_pos_len=128, word_size=1002, drop_rate=0.2)
@@ -189,15 +189,17 @@ def test_headline_shape_at_full_size():
         if not err <= tol:
             bad.append((k, err, tol))
     assert not bad, (flips, bad[:6])
-    # ---- (2) shards add up (eval mode)
-    def grads_of(rows, inv_batch, mask_sum):
-        dd = {k: v[rows].contiguous() for k, v in d.items()}
-        _fwd(eng, flat, P, dd, False, 0)
-        _, dh, dsl, del_ = eng.loss(dd['s_labels'], dd['e_labels'], dd['h_labels'], 1.0, 5.0, inv_batch=inv_batch, mask_sum=mask_sum)
+    # ---- (2) shards add up, in TRAINING mode: `sample_offset` continues the dropout counters, so the masks of a shard are
+    #      the rows of the full batch's masks and N ranks reproduce the single-process gradient
+    def grads_of(lo, hi):
+        dd = {k: v[lo:hi].contiguous() for k, v in d.items()}
+        eng.forward(flat, P['embedding_net.word_emb.pad_vec'].cuda(), P['embedding_net.word_emb.glove_vec'].cuda(), dd['word_ids'],
+                    dd['char_ids'], dd['vfeats'], dd['v_mask'], dd['q_mask'], training=True, seed=seed, sample_offset=lo)
+        _, dh, dsl, del_ = eng.loss(dd['s_labels'], dd['e_labels'], dd['h_labels'], 1.0, 5.0, inv_batch=1.0 / B,
+                                    mask_sum=float(b['v_mask'].sum()))
         return eng.backward(dh, dsl, del_, eng.new_flat()).double().clone()
-    msum = float(b['v_mask'].sum())
-    full = grads_of(slice(0, B), 1.0 / B, msum)
-    parts = grads_of(slice(0, B // 2), 1.0 / B, msum) + grads_of(slice(B // 2, B), 1.0 / B, msum)
+    parts = grads_of(0, 24) + grads_of(24, 40) + grads_of(40, B)
+    full = g.double()
     for k, t in eng.views(full).items():
         err = float((t - eng.views(parts)[k]).abs().max())
         assert err <= 2e-5 * float(t.abs().max()) + 1e-7, (k, err)

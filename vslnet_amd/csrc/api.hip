@@ -361,12 +361,27 @@ struct Ctx {
     void pe(const char* name) {
         if (prof_live) { const size_t e1 = h->prof_used; (void)hipEventRecord(prof_event(), s); h->prof_recs.push_back({name, prof_e0, e1}); }
     }
+    // elements one sample owns in the tensor dropped at `site` (the masks are keyed by the row-major element index)
+    uint32_t site_elems(int site) const {
+        const vsl_config& cf = h->cfg;
+        const uint32_t T = p->T, Lq = p->Lq;
+        if (site == 64) return T * cf.video_feature_dim;              // SITE_VIS
+        if (site == 65) return Lq * cf.word_dim;                      // SITE_WORD
+        if (site == 66) return Lq * p->Lc * cf.char_dim;              // SITE_CHAR
+        if (site == 67) return T * D;                                 // SITE_CQ_C
+        if (site == 68) return Lq * D;                                // SITE_CQ_Q
+        const uint32_t L = (site >> 4) == 1 ? Lq : T;                 // encoder pass 1 = query
+        return (site & 15) == 5 ? cf.num_heads * L * L : L * D;       // 5 = attention probabilities (B, H, L, L)
+    }
     Drop drop(int site) const {
         Drop d{0u, 0u, 1.0f};
         const float pr = h->cfg.drop_rate;
         if (io && io->training && pr > 0.f) {
             uint32_t x = (uint32_t)io->seed ^ ((uint32_t)(io->seed >> 32) * 0x9E3779B1u) ^ ((uint32_t)site * 0x85EBCA77u + 0x165667B1u);
             x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+            // keep = fmix32(element * 0x9E3779B1 + seed): a shard that starts at sample s of the global batch continues the
+            // element counter at s * site_elems, which folds into the seed (no cost in the kernels)
+            x += (uint32_t)io->sample_offset * site_elems(site) * 0x9E3779B1u;
             d.seed = x;
             d.thresh = (uint32_t)std::min(4294967295.0, (double)pr * 4294967296.0);
             d.scale = 1.0f / (1.0f - pr);

@@ -171,7 +171,8 @@ class ResidentSplit:
 
     Iterating yields the reference's tuples (records, vfeats, vfeat_lens[host], word_ids, char_ids[, s, e, h]) with device
     tensors -- `runner.eval_test` and the module-API loop take them unchanged.  `shards(rank, world)` yields the dicts the
-    fused data-parallel loop consumes (only this rank's rows are gathered; widths and normalisers stay global)."""
+    fused data-parallel loop consumes (only this rank's rows are gathered; widths and normalisers stay global; `row0` = index
+    of the shard's first sample in the global batch, the `sample_offset` of the dropout counters)."""
 
     def __init__(self, records, video_features, configs, device, train, generator=None):
         self.records, self.device, self.train = list(records), torch.device(device), train
@@ -240,7 +241,7 @@ class ResidentSplit:
             g = self._gather(idx_dev, T, Lq, Lc)
             l_dev = self.d_lens[idx_dev]
             v_mask = (torch.arange(T, device=self.device)[None, :] < l_dev[:, None]).float()
-            b = {'records': [self.records[i] for i in idx[lo:hi]], 'lens_global': lens, 'vfeats': g[0], 'v_mask': v_mask,
+            b = {'records': [self.records[i] for i in idx[lo:hi]], 'lens_global': lens, 'row0': lo, 'vfeats': g[0], 'v_mask': v_mask,
                  'word_ids': g[1], 'char_ids': g[2]}
             if self.train:
                 b.update(s_labels=g[3], e_labels=g[4], h_labels=g[5])
@@ -263,7 +264,7 @@ def loader_shards(loader, device, rank=0, world=1):
         mv = lambda t: t[sl].to(device, non_blocking=True).contiguous()
         l_dev = lens[sl].to(device, non_blocking=True)
         T = int(lens.max())
-        b = {'records': list(records[sl]), 'lens_global': lens.numpy(), 'vfeats': mv(vfeats),
+        b = {'records': list(records[sl]), 'lens_global': lens.numpy(), 'row0': lo, 'vfeats': mv(vfeats),
              'v_mask': (torch.arange(T, device=device)[None, :] < l_dev[:, None]).float(),
              'word_ids': mv(batch[3]), 'char_ids': mv(batch[4])}
         if len(batch) > 5:

@@ -29,7 +29,7 @@ class vsl_io(C.Structure):
                 ('h_score', C.c_void_p), ('start_logits', C.c_void_p), ('end_logits', C.c_void_p),
                 ('workspace', C.c_void_p), ('training', C.c_int32), ('seed', C.c_uint64),
                 ('d_h_score', C.c_void_p), ('d_start_logits', C.c_void_p), ('d_end_logits', C.c_void_p),
-                ('grads', C.c_void_p)]
+                ('grads', C.c_void_p), ('sample_offset', C.c_int32)]
 
 
 class vsl_loss_io(C.Structure):
@@ -174,7 +174,9 @@ class Engine:
         return self._last_ws[off:off + n].view(shape)
 
     # ---- the three calls ------------------------------------------------------------------------------------
-    def forward(self, flat, pad_vec, glove_vec, word_ids, char_ids, vfeats, v_mask, q_mask, training=False, seed=0):
+    def forward(self, flat, pad_vec, glove_vec, word_ids, char_ids, vfeats, v_mask, q_mask, training=False, seed=0,
+                sample_offset=0):
+        """`sample_offset`: index of this shard's first sample in the global batch (data parallel; vslnet_hip.h)."""
         B, T, Dv = vfeats.shape
         Lq, Lc = char_ids.shape[1], char_ids.shape[2]
         _chk(flat, torch.float32, (self.param_floats,), 'params')
@@ -194,7 +196,7 @@ class Engine:
         io.v_mask, io.q_mask = _ptr(v_mask), _ptr(q_mask)
         io.h_score, io.start_logits, io.end_logits = _ptr(out[0]), _ptr(out[1]), _ptr(out[2])
         io.workspace = _ptr(ws)
-        io.training, io.seed = int(bool(training)), int(seed) & 0xFFFFFFFFFFFFFFFF
+        io.training, io.seed, io.sample_offset = int(bool(training)), int(seed) & 0xFFFFFFFFFFFFFFFF, int(sample_offset)
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         self._call(self.lib.vsl_forward(self.h, C.byref(io), stream))
         self._last, self._last_ws = io, ws
