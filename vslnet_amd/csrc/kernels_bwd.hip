@@ -1658,12 +1658,24 @@ void launch_cq_bwd_query(const CqBwdArgs& a0, int B, hipStream_t s) {
 // =========================================================================================================
 // generic data gradient  dA (R, K) = G (R, 128) W   (transpose pack, ncols = K) ; used for a5 (K = 400)
 // =========================================================================================================
+// Optional row map (seg > 0): logical row r of the launch is physical row (r / seg) * stride + off + r % seg of G and dA --
+// the rows of one TIME CHUNK of a (B, T, .) tensor (seg = chunk length, stride = T, off = first step), which lets the
+// recurrent kernels of the rnn head be pipelined chunk by chunk.
 __global__ __launch_bounds__(256) void k_linear_bwd_data(const float* __restrict__ G, const float* __restrict__ WTpack,
-                                                         float* __restrict__ dA, int R, int K) {
+                                                         float* __restrict__ dA, int R, int K, int seg, int stride, int off) {
     __shared__ __attribute__((aligned(16))) float Gs[TILE_M * LDP];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int r0 = blockIdx.x * TILE_M;
-    load_tile128(Gs, G, r0, TILE_M, R);
+    auto phys = [&](int r) { return seg > 0 ? (r / seg) * stride + off + r % seg : r; };
+    if (seg > 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + q * 256, rr = e >> 5, r = r0 + rr;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < R) v = *reinterpret_cast<const float4*>(G + (size_t)phys(r) * D + (e & 31) * 4);
+            *reinterpret_cast<float4*>(Gs + rr * LDP + (e & 31) * 4) = v;
+        }
+    } else load_tile128(Gs, G, r0, TILE_M, R);
     __syncthreads();
     for (int cb = 0; cb < K; cb += 512) {
         f32x16 acc[4];
@@ -1680,14 +1692,15 @@ __global__ __launch_bounds__(256) void k_linear_bwd_data(const float* __restrict
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int gr = r0 + acc_row(r, lane);
-                    if (gr < R) dA[(size_t)gr * K + col] = acc[t][r];
+                    if (gr < R) dA[(size_t)phys(gr) * K + col] = acc[t][r];
                 }
             }
         }
     }
 }
-void launch_linear_bwd_data(const float* G, const float* WTpack, float* dA, int R, int K, hipStream_t s) {
-    hipLaunchKernelGGL(k_linear_bwd_data, dim3((R + TILE_M - 1) / TILE_M), dim3(256), 0, s, G, WTpack, dA, R, K);
+void launch_linear_bwd_data(const float* G, const float* WTpack, float* dA, int R, int K, hipStream_t s, int seg, int stride,
+                            int off) {
+    hipLaunchKernelGGL(k_linear_bwd_data, dim3((R + TILE_M - 1) / TILE_M), dim3(256), 0, s, G, WTpack, dA, R, K, seg, stride, off);
 }
 
 // =========================================================================================================
@@ -2000,7 +2013,8 @@ constexpr int LS_GP = 4 * D + 4;
 __global__ __launch_bounds__(1024) void k_lstm_bwd(const float* __restrict__ dout, const float* __restrict__ dout2,
                                                    const float* __restrict__ mask, const float* __restrict__ gates,
                                                    const float* __restrict__ cseq, const float* __restrict__ Whh,
-                                                   float* __restrict__ dG, int B, int T) {
+                                                   float* __restrict__ dG, int B, int T, float* __restrict__ carry, int t0,
+                                                   int t1) {
     __shared__ __attribute__((aligned(16))) float dGs[LS_M * LS_GP];
     __shared__ __attribute__((aligned(16))) float Ph[2][LS_M * LS_HP];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
@@ -2015,8 +2029,18 @@ __global__ __launch_bounds__(1024) void k_lstm_bwd(const float* __restrict__ dou
         const float* p = Whh + (size_t)(256 * kh + 16 * q + 4 * g4) * D + n0 + j;
         wr[q] = make_float4(p[0], p[D], p[2 * D], p[3 * D]);
     }
+    // a launch covers the steps [t0, t1) in reverse; a later time chunk hands dc_{t1} and dh_{t1 - 1} over through `carry`
     float dcn[2] = {0.f, 0.f};
-    for (int t = T - 1; t >= 0; --t) {
+    if (t1 < T) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int b = min(b0 + s0 + e, B - 1);
+            dcn[e] = carry[((size_t)b * 2 + 0) * D + u];
+            Ph[0][(s0 + e) * LS_HP + u] = carry[((size_t)b * 2 + 1) * D + u];
+            Ph[1][(s0 + e) * LS_HP + u] = 0.f;
+        }
+    }
+    for (int t = t1 - 1; t >= t0; --t) {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int b = min(b0 + s0 + e, B - 1);
@@ -2057,10 +2081,21 @@ __global__ __launch_bounds__(1024) void k_lstm_bwd(const float* __restrict__ dou
         for (int r = 0; r < 4; ++r) Ph[kh][(4 * g4 + r) * LS_HP + n0 + j] = acc[r];
         __syncthreads();
     }
+    if (t0 > 0) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+            if (b0 + s0 + e < B) {
+                const int b = b0 + s0 + e;
+                carry[((size_t)b * 2 + 0) * D + u] = dcn[e];
+                carry[((size_t)b * 2 + 1) * D + u] = Ph[0][(s0 + e) * LS_HP + u] + Ph[1][(s0 + e) * LS_HP + u];
+            }
+    }
 }
 void launch_lstm_bwd(const float* dout, const float* dout2, const float* mask, const float* gates, const float* cseq,
-                     const float* Whh, float* dG, int B, int T, hipStream_t s) {
-    hipLaunchKernelGGL(k_lstm_bwd, dim3((B + LS_M - 1) / LS_M), dim3(1024), 0, s, dout, dout2, mask, gates, cseq, Whh, dG, B, T);
+                     const float* Whh, float* dG, int B, int T, hipStream_t s, float* carry, int t0, int t1) {
+    if (t1 < 0) t1 = T;
+    hipLaunchKernelGGL(k_lstm_bwd, dim3((B + LS_M - 1) / LS_M), dim3(1024), 0, s, dout, dout2, mask, gates, cseq, Whh, dG, B, T, carry,
+                       t0, t1);
 }
 
 // =========================================================================================================

@@ -73,10 +73,12 @@ void launch_pack(const float* params, float* pack, const PackJob* jobs_dev, int 
 constexpr int VP_KC = 128;
 __global__ __launch_bounds__(256) void k_vproj_fwd(const float* __restrict__ X, const float* __restrict__ Wpack,
                                                    const float* __restrict__ bias, float* __restrict__ Y, int R, int Dv,
-                                                   Drop dp) {
+                                                   Drop dp, int seg, int stride, int off) {
     __shared__ __attribute__((aligned(16))) float As[2][TILE_M * LDP];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int r0 = blockIdx.x * TILE_M;
+    // seg > 0 (GEMM use by the rnn head, no dropout): logical row r = physical row (r / seg) * stride + off + r % seg of X and Y
+    auto phys = [&](int r) { return seg > 0 ? (r / seg) * stride + off + r % seg : r; };
     f32x16 acc[1];
     zero_acc(acc);
     const int nchunk = (Dv + VP_KC - 1) / VP_KC;
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(256) void k_vproj_fwd(const float* __restrict__ X, 
             const int r = r0 + rr;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (r < R && c < Dv) {
-                v = *reinterpret_cast<const float4*>(X + (size_t)r * Dv + c);
+                v = *reinterpret_cast<const float4*>(X + (size_t)phys(r) * Dv + c);
                 if (dp.thresh) {
                     const uint32_t base = (uint32_t)((size_t)r * Dv + c);
                     v.x *= drop_mul(dp, base); v.y *= drop_mul(dp, base + 1);
@@ -129,16 +131,16 @@ __global__ __launch_bounds__(256) void k_vproj_fwd(const float* __restrict__ X, 
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int gr = r0 + acc_row(r, lane);
-        if (gr < R) Y[(size_t)gr * D + col] = acc[0][r] + bv;
+        if (gr < R) Y[(size_t)phys(gr) * D + col] = acc[0][r] + bv;
     }
 }
 void launch_vproj_fwd(const float* X, const float* Wpack, const float* bias, float* Y, int R, int Dv, Drop dp,
-                      hipStream_t s) {
+                      hipStream_t s, int seg, int stride, int off) {
     {
         static size_t lds_sp = 0;
         const size_t shm_sp = spread_lds(0, 33792, (R + TILE_M - 1) / TILE_M);
         ensure_dynamic_lds((const void*)k_vproj_fwd, shm_sp + 33792, lds_sp, "k_vproj_fwd");
-        hipLaunchKernelGGL(k_vproj_fwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm_sp, s, X, Wpack, bias, Y, R, Dv, dp);
+        hipLaunchKernelGGL(k_vproj_fwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm_sp, s, X, Wpack, bias, Y, R, Dv, dp, seg, stride, off);
     }
 }
 
@@ -1394,7 +1396,7 @@ __global__ __launch_bounds__(1024) void k_lstm_fwd(const float* __restrict__ gi,
                                                    const float* __restrict__ bih, const float* __restrict__ bhh,
                                                    const float* __restrict__ mask, float* __restrict__ gates,
                                                    float* __restrict__ cseq, float* __restrict__ hprev, float* __restrict__ out,
-                                                   int B, int T) {
+                                                   int B, int T, int t0, int t1) {
     __shared__ __attribute__((aligned(16))) float hs[2][LS_M * LS_HP];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int j = lane & 15, g4 = lane >> 4, hi = j >> 3;
@@ -1411,7 +1413,7 @@ __global__ __launch_bounds__(1024) void k_lstm_fwd(const float* __restrict__ gi,
 #pragma unroll
     for (int g = 0; g < 4; ++g) bsum[g] = bih[g * D + u] + bhh[g * D + u];
     const int s0 = 4 * g4 + 2 * hi;                      // this lane finishes samples s0, s0 + 1 of the group
-    float cst[2] = {0.f, 0.f};
+    float cst[2] = {0.f, 0.f};                           // c_{t0 - 1}: zero, or what the previous time chunk left in cseq
     // 32-bit element offsets (the host checks B T 512 < 2^31) keep the address state of the loop in a handful of registers:
     // with W_hh resident the kernel sits at the 128-register limit of a 1024-thread workgroup
     int row[2];
@@ -1429,12 +1431,21 @@ __global__ __launch_bounds__(1024) void k_lstm_fwd(const float* __restrict__ gi,
             Mk[e] = mask[row[e] + tt];
         }
     };
-    for (int i = tid; i < LS_M * LS_HP; i += 1024) hs[0][i] = 0.f;       // h_{-1} = 0
-    gi_load(0);
+    // a launch covers the steps [t0, t1): the state it starts from is what the previous chunk saved for the backward anyway
+    // (hprev[t0] = h_{t0 - 1}, cseq[t0 - 1]), so the sequence can be cut into chunks that pipeline with the next LSTM
+    for (int i = tid; i < LS_M * D; i += 1024) {
+        const int sm = i >> 7, uu = i & 127;
+        hs[t0 & 1][sm * LS_HP + uu] = t0 > 0 ? hprev[(unsigned)((min(b0 + sm, B - 1) * T + t0) * D + uu)] : 0.f;
+    }
+    if (t0 > 0) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) cst[e] = cseq[(unsigned)((row[e] + t0 - 1) * D + u)];
+    }
+    gi_load(t0);
     __syncthreads();
-    for (int t = 0; t < T; ++t) {
+    for (int t = t0; t < t1; ++t) {
         const int cur = t & 1;
-        if (t == 6) FSTAMP(0);
+        if (t == t0 + 6) FSTAMP(0);
         f32x4 aa = {0.f, 0.f, 0.f, 0.f}, ab = {0.f, 0.f, 0.f, 0.f};
         if (t > 0) {
             const float* hrow = &hs[cur][j * LS_HP + 4 * g4];            // A operand: sample = lane & 15
@@ -1451,14 +1462,14 @@ __global__ __launch_bounds__(1024) void k_lstm_fwd(const float* __restrict__ gi,
                 ab = __builtin_amdgcn_mfma_f32_16x16x4f32(hv.w, wb[q].w, ab, 0, 0, 0);
             }
         }
-        if (t == 6) FSTAMP(1);
+        if (t == t0 + 6) FSTAMP(1);
         // aa[r] / ab[r]: this lane's two gate columns for samples 4 g4 + r.  Keep r = 2 hi, 2 hi + 1; trade the other two.
         const float ka0 = hi ? aa[2] : aa[0], ka1 = hi ? aa[3] : aa[1], kb0 = hi ? ab[2] : ab[0], kb1 = hi ? ab[3] : ab[1];
         const float ra0 = __shfl_xor(hi ? aa[0] : aa[2], 8), ra1 = __shfl_xor(hi ? aa[1] : aa[3], 8);
         const float rb0 = __shfl_xor(hi ? ab[0] : ab[2], 8), rb1 = __shfl_xor(hi ? ab[1] : ab[3], 8);
         const float zi[2] = {hi ? ra0 : ka0, hi ? ra1 : ka1}, zf[2] = {hi ? ka0 : ra0, hi ? ka1 : ra1};
         const float zg[2] = {hi ? rb0 : kb0, hi ? rb1 : kb1}, zo[2] = {hi ? kb0 : rb0, hi ? kb1 : rb1};
-        if (t == 6) FSTAMP(2);
+        if (t == t0 + 6) FSTAMP(2);
         float hn[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
@@ -1478,16 +1489,18 @@ __global__ __launch_bounds__(1024) void k_lstm_fwd(const float* __restrict__ gi,
                 if (t + 1 < T) hprev[(base + 1) * D + u] = hn[e];
             }
         }
-        if (t == 6) FSTAMP(3);
+        if (t == t0 + 6) FSTAMP(3);
         gi_load(t + 1);
-        if (t == 6) FSTAMP(4);
+        if (t == t0 + 6) FSTAMP(4);
         __syncthreads();
-        if (t == 6) FSTAMP(5);
+        if (t == t0 + 6) FSTAMP(5);
     }
 }
 void launch_lstm_fwd(const float* gi, const float* Whh, const float* bih, const float* bhh, const float* mask, float* gates,
-                     float* cseq, float* hprev, float* out, int B, int T, hipStream_t s) {
-    hipLaunchKernelGGL(k_lstm_fwd, dim3((B + LS_M - 1) / LS_M), dim3(1024), 0, s, gi, Whh, bih, bhh, mask, gates, cseq, hprev, out, B, T);
+                     float* cseq, float* hprev, float* out, int B, int T, hipStream_t s, int t0, int t1) {
+    if (t1 < 0) t1 = T;
+    hipLaunchKernelGGL(k_lstm_fwd, dim3((B + LS_M - 1) / LS_M), dim3(1024), 0, s, gi, Whh, bih, bhh, mask, gates, cseq, hprev, out, B, T,
+                       t0, t1);
     static int left = 2;
     if (fdbg_on() && T > 8) fdbg_report("lstm_fwd step 6: LDS+MFMA | shuffles | gates+stores | gi issue | barrier", 6, s, left);
 }

@@ -110,7 +110,8 @@ inline size_t spread_lds(size_t need, size_t static_bytes, int nblocks) {
 
 // ---------------------------------------------------------------- forward
 void launch_pack(const float* params, float* pack, const PackJob* jobs_dev, int njobs, hipStream_t s);
-void launch_vproj_fwd(const float* X, const float* Wpack, const float* bias, float* Y, int R, int Dv, Drop dp, hipStream_t s);
+void launch_vproj_fwd(const float* X, const float* Wpack, const float* bias, float* Y, int R, int Dv, Drop dp, hipStream_t s,
+                      int seg = 0, int stride = 0, int off = 0);   // seg > 0: rows of one time chunk (see launch_linear_bwd_data)
 void launch_embed_fwd(const int64_t* word_ids, const int64_t* char_ids, const float* pad_vec, const float* unk_vec,
                       const float* glove, const float* char_tab, CharConvPtrs cc, const float* wimg, float* E, int8_t* argpos,
                       int Rq, int Lc, int word_dim, int char_dim, Drop dw, Drop dc, hipStream_t s);
@@ -157,9 +158,10 @@ void launch_extract_index(const float* sl, const float* el, int64_t* si, int64_t
 void launch_head_bwd(const HeadBwdArgs& a0, const HeadBwdArgs& a1, int R, hipStream_t s);
 // a15 DynamicRNN (layers_t7.py:302-313): recurrent part of nn.LSTM(128, 128); the input projection x W_ih^T is a plain GEMM
 void launch_lstm_fwd(const float* gi, const float* Whh, const float* bih, const float* bhh, const float* mask, float* gates,
-                     float* cseq, float* hprev, float* out, int B, int T, hipStream_t s);
+                     float* cseq, float* hprev, float* out, int B, int T, hipStream_t s, int t0 = 0, int t1 = -1);   // steps [t0, t1)
 void launch_lstm_bwd(const float* dout, const float* dout2, const float* mask, const float* gates, const float* cseq,
-                     const float* Whh, float* dG, int B, int T, hipStream_t s);
+                     const float* Whh, float* dG, int B, int T, hipStream_t s, float* carry = nullptr, int t0 = 0, int t1 = -1);
+                     // steps [t0, t1) in reverse; carry (B, 2, 128): dc / dh handed from one time chunk to the next
 void launch_wgrad(const WgradBatch& wb, hipStream_t s);
 void launch_conv_bwd_dwln(const float* du, const float* xin, const float* dy, const float* ln_g, const float* ln_b,
                           const float* dw_w, const float* extra, float* dx, float* p_lng, float* p_lnb, float* p_dw, int R, int L,
@@ -194,7 +196,8 @@ struct CqBwdArgs {
 };
 void launch_cq_bwd(const CqBwdArgs& a, int B, hipStream_t s);          // kernels a, b, c: dC final, dQ partials
 void launch_cq_bwd_query(const CqBwdArgs& a, int B, hipStream_t s);    // kernel d: dQ + pooled-query parameters
-void launch_linear_bwd_data(const float* G, const float* WTpack, float* dA, int R, int K, hipStream_t s);
+void launch_linear_bwd_data(const float* G, const float* WTpack, float* dA, int R, int K, hipStream_t s, int seg = 0, int stride = 0,
+                            int off = 0);      // seg > 0: rows of one time chunk of a (B, T, .) tensor
 void launch_embed_bwd(const float* dE, const int64_t* word_ids, const int64_t* char_ids, const float* E,
                       const int8_t* argpos, const float* char_tab, CharConvPtrs cc,
                       float* p_cw /*[nchunk][15000]*/,
