@@ -11,13 +11,15 @@ BENCH="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats -d $O/stats -o s -- $BENCH > $O/stats_bench.json 2> $O/stats.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o f -- $BENCH > /dev/null 2> $O/fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o w -- $BENCH > /dev/null 2> $O/write.err
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/mfma -o m -- $BENCH > /dev/null 2> $O/mfma.err
 cd $R
 python tools/rocpd_stats.py $(find $O/stats -name "*.db" | head -1) > $O/${TAG}_kernel_stats.txt
 python tools/rocpd_pmc.py $(find $O/fetch -name "*.db" | head -1) > $O/${TAG}_pmc_fetch_size.txt
 python tools/rocpd_pmc.py $(find $O/write -name "*.db" | head -1) > $O/${TAG}_pmc_write_size.txt
+python tools/rocpd_mfma.py $(find $O/mfma -name "*.db" | head -1) > $O/${TAG}_pmc_mfma_busy.txt
 python tools/make_pmc_json.py $(find $O/fetch -name "*.db" | head -1) $(find $O/write -name "*.db" | head -1) 26 $O/r01_pmc_traffic.json
 cp $O/r01_pmc_traffic.json profiles/r01_pmc_traffic.json
 python bench.py > $O/${TAG}_bench.json 2> $O/bench.err
 python bench.py --steps 30 --warmup 10 --no-cpu-baseline --profile-all 2> $O/${TAG}_hip_event_table.txt > /dev/null
-rm -rf $O/stats $O/fetch $O/write
+rm -rf $O/stats $O/fetch $O/write $O/mfma
 tail -c 1500 $O/${TAG}_bench.json
