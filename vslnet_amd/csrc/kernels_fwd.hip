@@ -1219,79 +1219,6 @@ void launch_cq_out(const float* C, const float* Qf, const float* Srow, const flo
                        T, Lq, CqCatFuse{W1pack, pb, wh, bh, vmask, f2, hscore, gated});
 }
 
-// =========================================================================================================
-// a11 + a12  CQConcatenate conv (first half of the 2d -> d Conv1D on the context + per-sample pooled-query bias pb)
-//            fused with HighLightLayer (:282-289) and the gating  features * h  (VSLNet_t7.py:60).
-// =========================================================================================================
-__global__ __launch_bounds__(256) void k_cqcat_fwd(const float* __restrict__ f1, const float* __restrict__ Wpack,
-                                                   const float* __restrict__ pb, const float* __restrict__ wh,
-                                                   const float* __restrict__ bh, const float* __restrict__ vmask,
-                                                   float* __restrict__ f2, float* __restrict__ hscore,
-                                                   float* __restrict__ gated, int R, int T) {
-    __shared__ __attribute__((aligned(16))) float As[TILE_M * LDP];
-    __shared__ __attribute__((aligned(16))) float Fs[TILE_M * LDP];
-    __shared__ float hs[TILE_M];
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const int r0 = blockIdx.x * TILE_M;
-    BFrag<1, 16> bf;
-    load_tile128(As, f1, r0, TILE_M, R);
-    bfrag_load(bf, Wpack, D, 32 * w, 0, 0, D / 8);
-    __syncthreads();
-    f32x16 acc[1];
-    zero_acc(acc);
-    gemm32p<1, 16>(As, LDP, D, Wpack, D, 32 * w, 0, acc, bf);
-    const int col = 32 * w + (lane & 31);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = acc_row(r, lane);
-        const int gr = min(r0 + row, R - 1);
-        Fs[row * LDP + col] = acc[0][r] + pb[(size_t)(gr / T) * D + col];
-    }
-    __syncthreads();
-    {
-        const int rr = tid >> 3, sub = tid & 7;
-        const float* row = Fs + rr * LDP + sub * 4;
-        float d = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float4 fv = *reinterpret_cast<const float4*>(row + 32 * j);
-            const float4 wv = *reinterpret_cast<const float4*>(wh + sub * 4 + 32 * j);
-            d += fv.x * wv.x + fv.y * wv.y + fv.z * wv.z + fv.w * wv.w;
-        }
-        d = grp8_sum(d);
-        if (sub == 0) {
-            const int gr = r0 + rr;
-            float hv = 0.f;
-            if (gr < R) {
-                const float lg = d + bh[0] + (1.f - vmask[gr]) * MASK_VALUE;      // mask_logits (:286)
-                hv = 1.0f / (1.0f + __expf(-lg));
-                hscore[gr] = hv;
-            }
-            hs[rr] = hv;
-        }
-    }
-    __syncthreads();
-    for (int e = tid; e < TILE_M * 32; e += 256) {
-        const int rr = e >> 5, c = (e & 31) * 4;
-        const int gr = r0 + rr;
-        if (gr < R) {
-            const float4 v = *reinterpret_cast<const float4*>(&Fs[rr * LDP + c]);
-            const float hv = hs[rr];
-            *reinterpret_cast<float4*>(f2 + (size_t)gr * D + c) = v;
-            *reinterpret_cast<float4*>(gated + (size_t)gr * D + c) = make_float4(v.x * hv, v.y * hv, v.z * hv, v.w * hv);
-        }
-    }
-}
-void launch_cqcat_fwd(const float* f1, const float* Wpack, const float* pb, const float* wh, const float* bh,
-                      const float* vmask, float* f2, float* hscore, float* gated, int R, int T, hipStream_t s) {
-    {
-        static size_t lds_sp = 0;
-        const size_t shm_sp = spread_lds(0, 33920, (R + TILE_M - 1) / TILE_M);
-        ensure_dynamic_lds((const void*)k_cqcat_fwd, shm_sp + 33920, lds_sp, "k_cqcat_fwd");
-        hipLaunchKernelGGL(k_cqcat_fwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm_sp, s, f1, Wpack, pb, wh, bh, vmask, f2, hscore,
-                       gated, R, T);
-    }
-}
 
 // =========================================================================================================
 // a14 heads (:328-337, 347-352): logits = mask_logits( Conv1D(d->1)( relu( Conv1D(2d->d)([LN(feat), x]) ) ) )

@@ -143,8 +143,6 @@ void launch_cq_col(const float* C, const float* Qf, const float* S, const float*
 void launch_cq_out(const float* C, const float* Qf, const float* Srow, const float* Mpart, float* M, const float* Wpack,
                    const float* bias, float* cat_out, float* out, const float* W1pack, const float* pb, const float* wh,
                    const float* bh, const float* vmask, float* f2, float* hscore, float* gated, int B, int T, int Lq, hipStream_t s);
-void launch_cqcat_fwd(const float* f1, const float* Wpack, const float* pb, const float* wh, const float* bh,
-                      const float* vmask, float* f2, float* hscore, float* gated, int R, int T, hipStream_t s);
 void launch_head_fwd(const HeadArgs& a0, const HeadArgs& a1, const float* x, const float* vmask, int R, hipStream_t s);
 
 // ---------------------------------------------------------------- losses / eval
