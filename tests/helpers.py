@@ -38,24 +38,27 @@ def relu_flips(eng, B, T, Lq, predictor='transformer'):
     A disagreement needs a pre-activation within the ~1e-5 forward noise of zero, but it changes the gradient of that element
     discontinuously (the tolerances of SURVEY 8c assume none).  Tests that find one re-run the oracle on the GPU path's branch
     (O.force_relu_signs) and keep the strict gate."""
-    import torch
     from oracle import vslnet_oracle as O
     sites = list(O.RELU_SIGNS)
+    masks = hip_relu_masks(eng, B, T, Lq, predictor)
+    assert [s for s, _ in sites] == ['conv'] * (len(masks) - 2) + ['head_start', 'head_end'], [s for s, _ in sites]
+    flips = sum(int((m != sg).sum()) for m, (_, sg) in zip(masks, sites))
+    return flips, masks
+
+
+def hip_relu_masks(eng, B, T, Lq, predictor='transformer'):
+    """The ReLU decisions the last HIP forward saved, as bool tensors in the oracle's call order."""
+    import torch
     encs = [('venc', T)] * 4 + [('qenc', Lq)] * 4
     if predictor == 'transformer':
         encs += [('p1', T)] * 4 + [('p2', T)] * 4
-    assert [s for s, _ in sites] == ['conv'] * len(encs) + ['head_start', 'head_end'], [s for s, _ in sites]
-    flips, masks = 0, []
+    masks = []
     for idx, (enc, L) in enumerate(encs):
         words = eng.ws_view('relu_%s_%d' % (enc, idx % 4), (B * L * 4,)).view(torch.int32).cpu().view(B * L, 4)
-        bits = ((words.unsqueeze(-1) >> torch.arange(32, dtype=torch.int32)) & 1).bool().view(B, L, 128)
-        flips += int((bits != sites[idx][1]).sum())
-        masks.append(bits)
-    for k, name in enumerate(('s', 'e')):
-        act = eng.ws_view('hid_' + name, (B, T, 128)).cpu() > 0
-        flips += int((act != sites[len(encs) + k][1]).sum())
-        masks.append(act)
-    return flips, masks
+        masks.append(((words.unsqueeze(-1) >> torch.arange(32, dtype=torch.int32)) & 1).bool().view(B, L, 128))
+    for name in ('s', 'e'):
+        masks.append(eng.ws_view('hid_' + name, (B, T, 128)).cpu() > 0)
+    return masks
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
