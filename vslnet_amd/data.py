@@ -183,6 +183,12 @@ class ResidentSplit:
         vpos = {v: i for i, v in enumerate(vids)}
         vlen = np.array([video_features[v].shape[0] for v in vids], dtype=np.int64)
         tmax, dv = int(vlen.max()), int(video_features[vids[0]].shape[1])
+        need = len(vids) * tmax * dv * 4
+        if self.device.type == 'cuda':
+            free, _ = torch.cuda.mem_get_info(self.device)
+            if need > 0.8 * free:
+                raise MemoryError('the %s split needs %.1f GiB of device memory for its features (%d videos x %d clips x %d), %.1f GiB '
+                                  'are free: use --data loader' % ('train' if train else 'test', need / 2 ** 30, len(vids), tmax, dv, free / 2 ** 30))
         self.feats = torch.zeros((len(vids), tmax, dv), dtype=torch.float32, device=self.device)
         for i, v in enumerate(vids):                                       # one upload per video, once
             self.feats[i, :vlen[i]] = torch.from_numpy(np.ascontiguousarray(video_features[v], dtype=np.float32)).to(self.device)
