@@ -58,7 +58,16 @@ def load_library():
     if not path:
         path = _build.LIB
         if not os.path.exists(path) or _build._stale():
-            path = _build.build()
+            # several ranks of one node may get here together (torch.distributed.run): one builds, the others wait for it
+            import fcntl
+            os.makedirs(_build.LIBDIR, exist_ok=True)
+            with open(os.path.join(_build.LIBDIR, '.build.lock'), 'w') as lock:
+                fcntl.flock(lock, fcntl.LOCK_EX)
+                try:
+                    if not os.path.exists(path) or _build._stale():
+                        path = _build.build()
+                finally:
+                    fcntl.flock(lock, fcntl.LOCK_UN)
     lib = C.CDLL(path)
     lib.vsl_last_error.restype = C.c_char_p
     lib.vsl_create.argtypes = [C.POINTER(vsl_config), C.POINTER(C.c_void_p)]
