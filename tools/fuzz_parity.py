@@ -8,6 +8,7 @@ import numpy as np
 
 sys.path.insert(0, '.')
 from tests.test_hip_training import test_baseline_shapes_against_oracle as check  # noqa: E402
+from tests.test_hip_rnn import test_rnn_head_against_oracle as check_rnn  # noqa: E402
 
 
 def main(n=24, seed=0):
@@ -18,7 +19,12 @@ def main(n=24, seed=0):
                      Lq=int(rs.choice([1, 2, 3, 8, 20, 31, 32, 33, 47])), Lc=int(rs.choice([4, 5, 10, 17, 24])),
                      Dv=int(rs.choice([4, 36, 64, 100, 500, 1024])))
         try:
-            check(shape)
+            if i % 4 == 3:                      # every fourth shape goes through the rnn head (chunk-pipelined LSTMs, Dv = 64)
+                # (that test fixes max_pos_len = 128 and has no structural-zero gate for one-word queries)
+                shape = dict(name=shape['name'] + ' rnn', B=shape['B'] * 4 - 1, T=min(shape['T'], 128), Lq=max(shape['Lq'], 2), Lc=shape['Lc'])
+                check_rnn(shape)
+            else:
+                check(shape)
             print('ok   ', shape, flush=True)
         except Exception as e:  # noqa: BLE001
             bad += 1
