@@ -96,3 +96,69 @@ def test_flat_adamw_matches_per_parameter_adamw():
         opt.step(g)
     got = torch.cat([p.detach().reshape(-1) for p in params])
     assert torch.allclose(flat, got, atol=1e-6), float((flat - got).abs().max())
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# the same property through the HIP engine: two processes (sharing the one GPU of the test box, gradients exchanged with gloo
+# through host copies -- RCCL needs one device per rank) train three steps in TRAINING mode on the halves of a batch and end
+# up with the parameters a single process reaches on the whole batch: sample_offset keeps the dropout masks, the global
+# normalisers keep the losses, the fused optimizer runs identically on every rank.
+# ---------------------------------------------------------------------------------------------------------------------------
+def _hip_train(rank, world, batch, steps=3):
+    from vslnet_amd.engine import Engine, flat_from_state_dict
+    cfg = O.make_cfg(video_feature_dim=64, max_pos_len=48, word_size=52, drop_rate=0.2)
+    P = O.random_params(cfg, seed=5)
+    eng = Engine(cfg)
+    flat = flat_from_state_dict(eng, P)
+    grads = eng.new_flat()
+    opt = dp.FlatAdamW(flat, eng.layout, lr=1e-3, num_train_steps=100, clip_norm=1.0, engine=eng)
+    B = batch['vfeats'].shape[0]
+    inv_b, msum = dp.global_normalisers(batch['lens'].tolist())
+    sl = dp.shard_slice(B, rank, world)
+    d = {k: v[sl].cuda().contiguous() for k, v in batch.items() if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == B}
+    pad, glove = P['embedding_net.word_emb.pad_vec'].cuda(), P['embedding_net.word_emb.glove_vec'].cuda()
+    for step in range(steps):
+        eng.forward(flat, pad, glove, d['word_ids'], d['char_ids'], d['vfeats'], d['v_mask'], d['q_mask'], training=True,
+                    seed=1000 + step, sample_offset=sl.start)
+        _, dh, dsl, del_ = eng.loss(d['s_labels'], d['e_labels'], d['h_labels'], 1.0, 5.0, inv_batch=inv_b, mask_sum=msum)
+        eng.backward(dh, dsl, del_, grads)
+        if world > 1:
+            g = grads.cpu()
+            dp.allreduce_flat_(g)
+            grads.copy_(g)
+        opt.step(grads)
+    torch.cuda.synchronize()
+    return flat.cpu()
+
+
+def _hip_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    cfg = O.make_cfg(video_feature_dim=64, max_pos_len=48, word_size=52, drop_rate=0.2)
+    batch = O.synthetic_batch(cfg, B=7, T=40, Lq=6, Lc=5, seed=9, ragged=True)       # 7 % 2 != 0: uneven shards
+    flat = _hip_train(rank, world, batch)
+    if rank == 0:
+        out.put(flat.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_train_like_one_process_on_the_gpu():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_hip_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    two = torch.from_numpy(q.get(timeout=600))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    cfg = O.make_cfg(video_feature_dim=64, max_pos_len=48, word_size=52, drop_rate=0.2)
+    one = _hip_train(0, 1, O.synthetic_batch(cfg, B=7, T=40, Lq=6, Lc=5, seed=9, ragged=True))
+    start = _hip_train(0, 1, O.synthetic_batch(cfg, B=7, T=40, Lq=6, Lc=5, seed=9, ragged=True), steps=0)
+    moved = float((one - start).abs().max())
+    assert moved > 1e-3                                                          # three real updates happened
+    assert float((two - one).abs().max()) <= 2e-3 * moved, (float((two - one).abs().max()), moved)
