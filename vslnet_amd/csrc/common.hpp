@@ -59,6 +59,24 @@ __device__ __forceinline__ float drop_keep_scale(const Drop& d, uint32_t idx) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// XCD-aware block order.  Workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with a private L2.  The
+// attention kernels read 64-byte head slices out of 512-byte rows, so the 8 heads of a sample should share an L2: with
+// the default order they sit on 8 different XCDs and every row is fetched 8 times.  xcd_swizzle gives every XCD a
+// contiguous chunk of the LOGICAL block order (x fastest, then y, then z): chunk = whole samples when the grid is a
+// multiple of 8 workgroups, identity otherwise.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void xcd_swizzle(int& bx, int& by, int& bz) {
+    const int nx = gridDim.x, ny = gridDim.y, nwg = nx * ny * gridDim.z;
+    if (nwg & 7) { bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z; return; }
+    const int bid = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
+    const int l = (bid & 7) * (nwg >> 3) + (bid >> 3);
+    bx = l % nx;
+    const int r = l / nx;
+    by = r % ny;
+    bz = r / ny;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // gate non-linearities of the LSTM kernels on the hardware exp / rcp instructions (about 1 ulp each).  fp32 MFMAs and the
 // vector ALU share the SIMD, so the ~30-instruction libm expf / tanhf cost as much per step as the recurrent matmul itself.
 // ---------------------------------------------------------------------------------------------------------

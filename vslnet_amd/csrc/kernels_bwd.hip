@@ -645,10 +645,11 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(const float* __restrict__ Q
     float* Vs = Ks + KB * kst;
     float* Mb = Vs + KB * kst;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const int b = blockIdx.z, h = blockIdx.y;
+    int bxs, h, b;
+    xcd_swizzle(bxs, h, b);                        // all heads of a sample on one XCD (common.hpp)
     const size_t rowbase = (size_t)b * L;
     const int qi = lane & 15, g = lane >> 4;
-    const int q = blockIdx.x * 64 + w * 16 + qi;
+    const int q = bxs * 64 + w * 16 + qi;
     const bool qok = q < L;
     float4 qf = make_float4(0.f, 0.f, 0.f, 0.f), da = qf, of = qf;
     float lq = 0.f;
@@ -726,10 +727,11 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(const float* __restrict__ 
     float* Ls = As + KB * kst;          // LSE per query
     float* Ds = Ls + KB;                // D per query
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const int b = blockIdx.z, h = blockIdx.y;
+    int bxs, h, b;
+    xcd_swizzle(bxs, h, b);                        // all heads of a sample on one XCD (common.hpp)
     const size_t rowbase = (size_t)b * L;
     const int ki = lane & 15, g = lane >> 4;
-    const int key = blockIdx.x * 64 + w * 16 + ki;
+    const int key = bxs * 64 + w * 16 + ki;
     const bool kok = key < L;
     float4 kf = make_float4(0.f, 0.f, 0.f, 0.f), vf = kf;
     float mb = MASK_VALUE;
@@ -828,7 +830,8 @@ __global__ __launch_bounds__(1024) void k_attn_bwd_fused(const float* __restrict
     float* As = Vs + AB_LMAX * AB_KST;          // [128][20]   dA = dr * m3
     const int Lp = (L + 15) & ~15;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const int h = blockIdx.x, b = blockIdx.y;
+    int h, b, bzs;
+    xcd_swizzle(h, b, bzs);                     // grid (H, B): all heads of a sample on one XCD (common.hpp)
     const size_t rowbase = (size_t)b * L;
     STAMP(0);
     for (int it = 0; it < LMAX / 128; ++it) {

@@ -610,10 +610,11 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const float* __restrict__ Q, c
     float* Vs = Ks + KB * kst;        // [KB][20]
     float* Mb = Vs + KB * kst;        // [KB] additive key bias
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const int b = blockIdx.z, h = blockIdx.y;
+    int bxs, h, b;
+    xcd_swizzle(bxs, h, b);                        // all heads of a sample on one XCD: its rows are fetched into one L2
     const size_t rowbase = (size_t)b * L;
     const int qi = lane & 15, g = lane >> 4;
-    const int q = blockIdx.x * 64 + w * 16 + qi;
+    const int q = bxs * 64 + w * 16 + qi;
     const bool qok = q < L;
     float4 qf = make_float4(0.f, 0.f, 0.f, 0.f);
     if (qok) qf = *reinterpret_cast<const float4*>(Q + (rowbase + q) * D + h * HD + 4 * g);
