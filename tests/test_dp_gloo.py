@@ -161,4 +161,15 @@ def test_two_ranks_train_like_one_process_on_the_gpu():
     start = _hip_train(0, 1, O.synthetic_batch(cfg, B=7, T=40, Lq=6, Lc=5, seed=9, ragged=True), steps=0)
     moved = float((one - start).abs().max())
     assert moved > 1e-3                                                          # three real updates happened
-    assert float((two - one).abs().max()) <= 2e-3 * moved, (float((two - one).abs().max()), moved)
+    # Parameters whose gradient is structurally zero (key bias -- softmax shift invariance -- and the final 1-channel
+    # biases) receive pure rounding noise (~1e-8, it depends on the summation order and hence on the sharding); AdamW divides
+    # it by sqrt(v) + 1e-6, so those few entries random-walk by a fraction of lr per step in BOTH runs.  They are bounded, not
+    # compared.
+    from vslnet_amd.engine import Engine
+    eng = Engine(cfg)
+    noise = torch.zeros(one.numel(), dtype=torch.bool)
+    for name, off, n, _ in eng.layout:
+        if name.endswith('key.conv1d.bias') or name.endswith('_block.2.conv1d.bias'):
+            noise[off:off + n] = True
+    assert float((two - one)[noise].abs().max()) <= 3 * 1e-3                     # at most lr per step
+    assert float((two - one)[~noise].abs().max()) <= 2e-3 * moved, (float((two - one)[~noise].abs().max()), moved)

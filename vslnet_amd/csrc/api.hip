@@ -431,6 +431,24 @@ enum { SITE_VIS = 64, SITE_WORD = 65, SITE_CHAR = 66, SITE_CQ_C = 67, SITE_CQ_Q 
 void enc_fwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float* xin, const float* mask, int Bn, int app) {
     const int R = w.R, L = w.L, H = c.h->cfg.num_heads;
     static const bool fuse_qkv = !(getenv("VSL_FUSE_QKV") && getenv("VSL_FUSE_QKV")[0] == '0');
+    static const bool conv_block = !(getenv("VSL_CONVBLOCK") && getenv("VSL_CONVBLOCK")[0] == '0');
+    if (conv_block && fuse_qkv) {
+        // the whole conv block + LN1 / QKV in ONE launch (kernels_enc.hip: 12-row recomputed halo)
+        CbFwdArgs a;
+        memset(&a, 0, sizeof a);
+        if (!c.dry) {
+            a.xin = xin; a.pos = c.P(P.pos); a.x0_out = c.W(w.x0);
+            for (int i = 0; i < 4; ++i) {
+                a.ln_g[i] = c.P(P.lng[i]); a.ln_b[i] = c.P(P.lnb[i]); a.dw_w[i] = c.P(P.dw[i]); a.Wpack[i] = c.PK(K.pw_f[i]);
+                a.pw_b[i] = c.P(P.pwb[i]); a.y[i] = c.W(w.y[i]); a.u[i] = c.W(w.u[i]);
+                a.relu_mask[i] = reinterpret_cast<uint32_t*>(c.W(w.mask[i])); a.dp[i] = c.drop(app * 16 + i);
+            }
+            a.qf = QkvFuse{c.P(P.ln1g), c.P(P.ln1b), c.PK(K.qkv_f), c.P(P.qb), c.P(P.kb), c.P(P.vb), c.W(w.h1), c.W(w.q), c.W(w.k), c.W(w.v),
+                           c.drop(app * 16 + 4)};
+            a.R = R; a.L = L;
+        }
+        LAUNCH("convblock_fwd", launch_convblock_fwd(a, c.s));
+    } else
     for (int i = 0; i < 4; ++i) {
         QkvFuse qf;
         memset(&qf, 0, sizeof qf);

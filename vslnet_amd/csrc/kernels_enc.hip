@@ -1,0 +1,340 @@
+// Fused conv-block kernels of one FeatureEncoder application (gfx950).
+//
+// a6/a7 DepthwiseSeparableConvBlock (/root/reference/model/layers_t7.py:118-140) is four layers of
+//     x <- x + drop(relu(pointwise(depthwise7(LN(x)))))
+// Each layer reaches 3 rows up and down the sequence, so a row tile cannot run the block alone -- unless it recomputes
+// its neighbours' rows: a workgroup owns 32 rows and carries a 12-row halo on each side that shrinks by 3 rows per
+// layer (56 -> 50 -> 44 -> 38 -> 32 rows).  The dropout masks are counter-based hashes of the element index, so the
+// recomputed rows are bit-identical to the owner's.  One launch replaces four (forward) / four + the fused GEMM stage
+// (backward): 3 kernel boundaries, 3 tile loads from memory and 3 store drains less per encoder application, at the
+// price of 1.5x (forward) / 1.75x (backward) of the block's matrix work -- the row-tile kernels ran their matrix
+// pipes at 5 - 7 % (profiles/r01_j_pmc_mfma_busy.txt), so the price is paid out of idle cycles.
+//
+// Matrix work: v_mfma_f32_16x16x4_f32 (16-row granularity fits the shrinking row ranges: 4, 3, 3, 2 half-blocks).
+// 8 waves; wave w owns output columns [16 w, 16 w + 16) of every row block, so a weight slice (128 x 16 = 8 KB = 32
+// registers per lane) is fetched by exactly one wave, straight from the packed layout of common.hpp, one layer ahead.
+#include "common.hpp"
+#include "launch.hpp"
+#include <type_traits>
+
+namespace vsl {
+
+__device__ long long g_stamps_e[32];
+__device__ int g_dbg_on_e = 0;
+#define ESTAMP(k) do { if (g_dbg_on_e && blockIdx.x == 0 && threadIdx.x == 0) g_stamps_e[k] = clock64(); } while (0)
+static int edbg_on() {
+    static int inited = 0, on = 0;
+    if (!inited) { inited = 1; on = getenv("VSL_DEBUG_TIMING") != nullptr; if (on) { int one = 1; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_on_e), &one, sizeof one); } }
+    return on;
+}
+static void edbg_report(const char* name, int nst, hipStream_t s, int& left) {
+    if (left <= 0) return;
+    long long h[32];
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamps_e), sizeof h);
+    fprintf(stderr, "[%s cycles]", name);
+    for (int i = 1; i < nst; ++i) fprintf(stderr, " %lld", h[i] - h[i - 1]);
+    fprintf(stderr, " | total %lld\n", h[nst - 1] - h[0]);
+    --left;
+}
+
+constexpr int CB_T = 512;                       // threads per workgroup (8 waves, 2 per SIMD)
+constexpr int CB_HALO = 4 * HALO;               // 12 rows each side
+constexpr int CB_NW = TILE_M + 2 * CB_HALO;     // 56-row window
+
+// ---------------------------------------------------------------------------------------------------------
+// 16x16x4 fp32 MFMA GEMM on LDS row blocks.  Operand lane maps (lane = 16 g + i):
+//   A: A[row i][k = g]      B: B[k = g][col i]      C/D reg r: D[row 4 g + r][col i]
+// One float4 of A (row i, k = 16 kq + 4 g + 0..3) and one float4 of the packed weight (same k's, col i) feed 4 MFMAs:
+// MFMA m of step kq contracts k = 16 kq + 4 g + m over g = 0..3.
+// ---------------------------------------------------------------------------------------------------------
+struct BF16 { float4 b[8]; };                   // a wave's 128 x 16 weight slice
+__device__ __forceinline__ void bf16_load(BF16& f, const float* __restrict__ Bp, int ncols, int col0) {
+    const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+    const float4* bp = reinterpret_cast<const float4*>(Bp) + ((size_t)(g >> 1) * ncols + col0 + j) * 2 + (g & 1);
+#pragma unroll
+    for (int kq = 0; kq < 8; ++kq) f.b[kq] = bp[(size_t)(2 * kq) * ncols * 2];
+}
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// acc[nb][rb] (16 x 16) += As[16 rb + 0..15][0..127] * B_nb ; NB weight slices share every A fragment
+template <int NRB, int NB>
+__device__ __forceinline__ void gemm16(const float* __restrict__ As, int lda, const BF16 (&bf)[NB], f32x4 (&acc)[NB][NRB]) {
+    const int lane = threadIdx.x & 63;
+    const float* arow = As + (lane & 15) * lda + 4 * (lane >> 4);
+#pragma unroll
+    for (int kq = 0; kq < 8; ++kq) {
+        float4 a[NRB];
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) a[rb] = *reinterpret_cast<const float4*>(arow + rb * 16 * lda + kq * 16);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) acc[nb][rb] = mfma16(a[rb].x, bf[nb].b[kq].x, acc[nb][rb]);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) acc[nb][rb] = mfma16(a[rb].y, bf[nb].b[kq].y, acc[nb][rb]);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) acc[nb][rb] = mfma16(a[rb].z, bf[nb].b[kq].z, acc[nb][rb]);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) acc[nb][rb] = mfma16(a[rb].w, bf[nb].b[kq].w, acc[nb][rb]);
+    }
+}
+
+// LayerNorm of up to 64 rows by 512 threads: 8 lanes per row (lane sub owns float4 columns 4 sub + 32 j).  gamma / beta in
+// LDS.  dst[r] = LN(src[r]) * dropout ; `drow0` = global row of row 0 (dropout element index = row * 128 + col).
+__device__ __forceinline__ void ln_rows512(const float* __restrict__ src, float* __restrict__ dst, int nrows,
+                                           const float* __restrict__ g, const float* __restrict__ b, const Drop& dp, int drow0) {
+    const int sub = threadIdx.x & 7, r = threadIdx.x >> 3;
+    if (r >= nrows) return;
+    const float* s = src + r * LDP + sub * 4;
+    float* d = dst + r * LDP + sub * 4;
+    float4 v[4];
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = *reinterpret_cast<const float4*>(s + 32 * j); sum += sum4(v[j]); }
+    const float mu = grp8_sum(sum) * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        v[j].x -= mu; v[j].y -= mu; v[j].z -= mu; v[j].w -= mu;
+        q += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
+    }
+    const float rstd = rsqrtf(grp8_sum(q) * (1.0f / D) + LN_EPS);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float4 gv = *reinterpret_cast<const float4*>(g + sub * 4 + 32 * j);
+        const float4 bv = *reinterpret_cast<const float4*>(b + sub * 4 + 32 * j);
+        float4 o;
+        o.x = v[j].x * rstd * gv.x + bv.x; o.y = v[j].y * rstd * gv.y + bv.y;
+        o.z = v[j].z * rstd * gv.z + bv.z; o.w = v[j].w * rstd * gv.w + bv.w;
+        if (dp.thresh) {
+            const uint32_t base = (uint32_t)((drow0 + r) * D + sub * 4 + 32 * j);
+            o.x *= drop_keep_scale(dp, base); o.y *= drop_keep_scale(dp, base + 1);
+            o.z *= drop_keep_scale(dp, base + 2); o.w *= drop_keep_scale(dp, base + 3);
+        }
+        *reinterpret_cast<float4*>(d + 32 * j) = o;
+    }
+}
+
+// =========================================================================================================
+// forward: x0 = xin + pos ; 4 x [ v = LN(x) ; u = depthwise7(v) ; z = u Wp^T + b ; x += drop(relu(z)) ] ; then, row-local on
+// the 32 owner rows, a8's first half (:168-173): h1 = drop(LN1(x)) ; [q | k | v] = h1 W^T + b.
+// Saves (owner rows only) x0, every layer's output y, depthwise output u (A operand of the weight gradient) and ReLU
+// bit-mask, h1, q, k, v.
+// LDS: residual stream [56] + one [68]-row buffer that holds LN(x), then (in place, after the depthwise windows are in
+// registers) the depthwise output = 72 KB with the small parameters, so two workgroups -- e.g. the video and the query
+// pass, which run on different streams -- share a CU.
+// =========================================================================================================
+constexpr int CB_VU = CB_NW + 12;               // rows of the LN / depthwise buffer: GEMM blocks of 16 from row 3 reach row 66
+constexpr int CB_PS = 384;                      // per-layer small parameters in LDS: ln_g | ln_b | pw_b
+__global__ __launch_bounds__(CB_T, 4) void k_convblock_fwd(CbFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Xs = smem;                       // [56][LDP] residual stream
+    float* VU = Xs + CB_NW * LDP;           // [68][LDP] LN(x), then depthwise output = GEMM A operand (rows indexed by window row)
+    float* Ps = VU + CB_VU * LDP;           // [4][CB_PS] per-layer small parameters | ln1_g | ln1_b | bq | bk | bv
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int R = a.R, L = a.L;
+    const int r0 = blockIdx.x * TILE_M, rw0 = r0 - CB_HALO;       // global row of window row 0
+    ESTAMP(0);
+    // ---- window rows rw0 .. rw0 + 55 (+ positional rows, :202): every load first
+    float4 xv[4], pv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = tid + q * CB_T;
+        const int r = rw0 + (e >> 5), c = (e & 31) * 4;
+        xv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        pv[q] = xv[q];
+        if (e < CB_NW * 32 && r >= 0 && r < R) {
+            xv[q] = *reinterpret_cast<const float4*>(a.xin + (size_t)r * D + c);
+            pv[q] = *reinterpret_cast<const float4*>(a.pos + (size_t)(r % L) * D + c);
+        }
+    }
+    // small parameters of all four layers and of the LN1 / QKV stage -> LDS ; depthwise taps of the thread's channel -> registers
+    {
+        float pl[4], pq[2];
+#pragma unroll
+        for (int l = 0; l < 4; ++l) pl[l] = tid < 128 ? a.ln_g[l][tid] : tid < 256 ? a.ln_b[l][tid - 128] : tid < 384 ? a.pw_b[l][tid - 256] : 0.f;
+        pq[0] = tid < 128 ? a.qf.ln_g[tid] : tid < 256 ? a.qf.ln_b[tid - 128] : 0.f;
+        pq[1] = tid < 128 ? a.qf.bq[tid] : tid < 256 ? a.qf.bk[tid - 128] : tid < 384 ? a.qf.bv[tid - 256] : 0.f;
+#pragma unroll
+        for (int l = 0; l < 4; ++l) if (tid < 384) Ps[l * CB_PS + tid] = pl[l];
+        if (tid < 256) Ps[4 * CB_PS + tid] = pq[0];
+        if (tid < 384) Ps[4 * CB_PS + 256 + tid] = pq[1];
+    }
+    BF16 bfA[1], bfB[1];
+    bf16_load(bfA[0], a.Wpack[0], D, 16 * w);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = tid + q * CB_T;
+        const int wr = e >> 5, c = (e & 31) * 4;
+        if (e < CB_NW * 32) {
+            const float4 v = make_float4(xv[q].x + pv[q].x, xv[q].y + pv[q].y, xv[q].z + pv[q].z, xv[q].w + pv[q].w);
+            const int r = rw0 + wr;
+            if (wr >= CB_HALO && wr < CB_HALO + TILE_M && r < R) *reinterpret_cast<float4*>(a.x0_out + (size_t)r * D + c) = v;
+            *reinterpret_cast<float4*>(&Xs[wr * LDP + c]) = v;
+        }
+    }
+    // a window that lies inside one sample needs no boundary tests in the depthwise conv (block-uniform)
+    const bool interior = rw0 >= 0 && rw0 + CB_NW <= R && (rw0 % L) + CB_NW <= L;
+    const bool full = r0 + TILE_M <= R;
+    __syncthreads();
+    ESTAMP(1);
+    const Drop nodrop{0u, 0u, 1.f};
+    const int col = 16 * w + (lane & 15), g4 = 4 * (lane >> 4);
+
+    auto layer = [&](auto LC, BF16 (&cur)[1], auto&& prefetch) {
+        constexpr int l = decltype(LC)::value;
+        constexpr int in0 = 3 * l, nin = CB_NW - 6 * l;          // LayerNorm rows
+        constexpr int o0 = in0 + 3, n = nin - 6;                 // rows this layer produces
+        constexpr int NRB = (n + 15) / 16, QS = (n + 3) / 4;     // 16-row blocks ; rows per depthwise segment
+        const float* P = Ps + l * CB_PS;
+        const Drop dp = a.dp[l];
+        float wkc[DWK];                                          // depthwise taps of this thread's channel: in flight during the LayerNorm
+#pragma unroll
+        for (int k = 0; k < DWK; ++k) wkc[k] = a.dw_w[l][(tid & 127) * DWK + k];
+        ln_rows512(Xs + in0 * LDP, VU + in0 * LDP, nin, P, P + 128, nodrop, 0);
+        __syncthreads();
+        // ---- depthwise conv k = 7 along the sequence: thread = (channel, quarter of the row range), window in registers
+        {
+            const int c = tid & 127, seg = tid >> 7;
+            const int os = o0 + seg * QS;                        // first produced window row of the segment
+            float win[QS + 2 * HALO], uo[QS];
+#pragma unroll
+            for (int i = 0; i < QS + 2 * HALO; ++i) win[i] = VU[min(os - HALO + i, CB_NW - 1) * LDP + c];
+            if (interior) {
+#pragma unroll
+                for (int i = 0; i < QS; ++i) {
+                    float u = 0.f;
+#pragma unroll
+                    for (int k = 0; k < DWK; ++k) u += wkc[k] * win[i + k];
+                    uo[i] = u;
+                }
+            } else {
+                int t = (rw0 + os) % L;                          // position of the produced row inside its sample
+                t = t < 0 ? t + L : t;
+#pragma unroll
+                for (int i = 0; i < QS; ++i) {
+                    float u = 0.f;
+#pragma unroll
+                    for (int k = 0; k < DWK; ++k) u += ((unsigned)(t + k - HALO) < (unsigned)L) ? wkc[k] * win[i + k] : 0.f;
+                    uo[i] = u;
+                    t = t + 1 == L ? 0 : t + 1;
+                }
+            }
+            __syncthreads();                                     // every window is in registers: the buffer turns into the GEMM operand
+            float* ug = a.u[l] + (ptrdiff_t)(rw0 + os) * D + c;
+#pragma unroll
+            for (int i = 0; i < QS; ++i) {
+                if (os + i < o0 + n) {                           // wave-uniform
+                    VU[(os + i) * LDP + c] = uo[i];
+                    const int wr = os + i;
+                    if (wr >= CB_HALO && wr < CB_HALO + TILE_M && (full || rw0 + wr < R)) ug[(ptrdiff_t)i * D] = uo[i];   // saved: A operand of the weight gradient
+                }
+            }
+        }
+        __syncthreads();
+        // ---- pointwise GEMM + bias + ReLU (+ dropout) + residual, in place on the residual stream
+        f32x4 acc[1][NRB];
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) acc[0][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        gemm16<NRB, 1>(VU + o0 * LDP, LDP, cur, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        prefetch();                                              // weight slice of the next stage: most of a layer ahead of its use
+        __builtin_amdgcn_sched_barrier(0);
+        const float bv = P[256 + col];
+        uint16_t* mk = reinterpret_cast<uint16_t*>(a.relu_mask[l]);
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) {
+            unsigned long long bal[4];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int row = 16 * rb + g4 + rr;               // relative to o0
+                const int o = o0 + row;
+                const float z = acc[0][rb][rr] + bv;
+                bal[rr] = __ballot(z > 0.f);
+                float av = fmaxf(z, 0.f);
+                if (dp.thresh) av *= drop_keep_scale(dp, (uint32_t)((rw0 + o) * D + col));
+                if (rb < NRB - 1 || row < n) Xs[o * LDP + col] += av;
+            }
+            // ReLU decisions of the owner rows: lane i < 16 stores the 16 bits of tile row i (uint16 view of the (R, 4) words)
+            const int t0 = o0 + 16 * rb;                         // folds after unrolling
+            if (t0 < CB_HALO + TILE_M && t0 + 16 > CB_HALO) {
+                const int i = lane & 15, rr = i & 3;
+                const unsigned long long b01 = (rr & 1) ? bal[1] : bal[0], b23 = (rr & 1) ? bal[3] : bal[2];
+                const unsigned long long bsel = (rr & 2) ? b23 : b01;
+                const uint32_t bits = (uint32_t)(bsel >> (16 * (i >> 2))) & 0xFFFFu;
+                const int o = t0 + i;
+                if (lane < 16 && o >= CB_HALO && o < CB_HALO + TILE_M && rw0 + o < R) mk[(size_t)(rw0 + o) * 8 + w] = (uint16_t)bits;
+            }
+        }
+        __syncthreads();
+        // owner rows of the layer output -> memory (16-byte stores)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int e = tid + q * CB_T;
+            const int rr = e >> 5, c = (e & 31) * 4;
+            if (full || r0 + rr < R)
+                *reinterpret_cast<float4*>(a.y[l] + (size_t)(r0 + rr) * D + c) = *reinterpret_cast<const float4*>(&Xs[(CB_HALO + rr) * LDP + c]);
+        }
+    };
+    layer(std::integral_constant<int, 0>(), bfA, [&] { bf16_load(bfB[0], a.Wpack[1], D, 16 * w); });
+    ESTAMP(2);
+    layer(std::integral_constant<int, 1>(), bfB, [&] { bf16_load(bfA[0], a.Wpack[2], D, 16 * w); });
+    ESTAMP(3);
+    layer(std::integral_constant<int, 2>(), bfA, [&] { bf16_load(bfB[0], a.Wpack[3], D, 16 * w); });
+    ESTAMP(4);
+    layer(std::integral_constant<int, 3>(), bfB, [&] { bf16_load(bfA[0], a.qf.Wpack, 3 * D, 16 * w); });
+    ESTAMP(5);
+    // ---- a8, first half (:168-173) on the owner rows: h1 = drop(LN1(y3)) ; [q | k | v] = h1 W^T + b  (wave w = head w)
+    {
+        const float* Pq = Ps + 4 * CB_PS;
+        ln_rows512(Xs + CB_HALO * LDP, VU, TILE_M, Pq, Pq + 128, a.qf.d1, r0);
+        bf16_load(bfB[0], a.qf.Wpack, 3 * D, D + 16 * w);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        if (a.qf.h1) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int e = tid + q * CB_T;
+                const int rr = e >> 5, c = (e & 31) * 4;
+                if (full || r0 + rr < R)
+                    *reinterpret_cast<float4*>(a.qf.h1 + (size_t)(r0 + rr) * D + c) = *reinterpret_cast<const float4*>(&VU[rr * LDP + c]);
+            }
+        }
+        auto proj = [&](BF16 (&cur)[1], float* __restrict__ outp, int t) {
+            f32x4 acc[1][2];
+            acc[0][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[0][1] = acc[0][0];
+            gemm16<2, 1>(VU, LDP, cur, acc);
+            const float bv = Pq[256 + t * D + col];
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int gr = r0 + 16 * rb + g4 + rr;
+                    if (full || gr < R) outp[(size_t)gr * D + col] = acc[0][rb][rr] + bv;
+                }
+        };
+        proj(bfA, a.qf.q, 0);
+        bf16_load(bfA[0], a.qf.Wpack, 3 * D, 2 * D + 16 * w);
+        __builtin_amdgcn_sched_barrier(0);
+        proj(bfB, a.qf.k, 1);
+        proj(bfA, a.qf.v, 2);
+    }
+    ESTAMP(6);
+}
+constexpr size_t CB_FWD_LDS = (size_t)((CB_NW + CB_VU) * LDP + 4 * CB_PS + 640) * sizeof(float);
+void launch_convblock_fwd(const CbFwdArgs& a, hipStream_t s) {
+    static size_t ok = 0;
+    ensure_dynamic_lds((const void*)k_convblock_fwd, CB_FWD_LDS, ok, "k_convblock_fwd");
+    hipLaunchKernelGGL(k_convblock_fwd, dim3((a.R + TILE_M - 1) / TILE_M), dim3(CB_T), CB_FWD_LDS, s, a);
+    static int left = 6;
+    if (edbg_on() && a.R > 4096) edbg_report("convblock_fwd: load | L0 | L1 | L2 | L3 | qkv", 7, s, left);
+}
+
+}  // namespace vsl

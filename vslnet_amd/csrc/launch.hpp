@@ -126,6 +126,18 @@ struct QkvFuse {
 void launch_conv_layer_fwd(const float* xin, const float* pos, float* x0_out, const float* ln_g, const float* ln_b,
                            const float* dw_w, const float* Wpack, const float* pw_b, float* y_out, float* u_out,
                            uint32_t* relu_mask, int R, int L, Drop dp, const QkvFuse& qkv, hipStream_t s);
+// fused conv block of one encoder application (kernels_enc.hip): 4 layers + LN1 / QKV in one launch, 12-row recomputed halo
+struct CbFwdArgs {
+    const float *xin, *pos;
+    float* x0_out;
+    const float *ln_g[4], *ln_b[4], *dw_w[4], *Wpack[4], *pw_b[4];
+    float *y[4], *u[4];
+    uint32_t* relu_mask[4];
+    Drop dp[4];
+    QkvFuse qf;
+    int R, L;
+};
+void launch_convblock_fwd(const CbFwdArgs& a, hipStream_t s);
 void launch_ln_qkv_fwd(const float* x, const float* ln_g, const float* ln_b, const float* Wpack, const float* bq,
                        const float* bk, const float* bv, float* h1, float* q, float* k, float* v, int R, Drop d1,
                        hipStream_t s);
