@@ -105,7 +105,10 @@ def test_flat_adamw_matches_per_parameter_adamw():
 # normalisers keep the losses, the fused optimizer runs identically on every rank.
 # ---------------------------------------------------------------------------------------------------------------------------
 def _hip_train(rank, world, batch, steps=3):
+    """-> (parameters after every step, ReLU decisions of every step's forward as one packed uint8 array per step)."""
+    import numpy as np
     from vslnet_amd.engine import Engine, flat_from_state_dict
+    from tests.helpers import hip_relu_masks
     cfg = O.make_cfg(video_feature_dim=64, max_pos_len=48, word_size=52, drop_rate=0.2)
     P = O.random_params(cfg, seed=5)
     eng = Engine(cfg)
@@ -117,18 +120,23 @@ def _hip_train(rank, world, batch, steps=3):
     sl = dp.shard_slice(B, rank, world)
     d = {k: v[sl].cuda().contiguous() for k, v in batch.items() if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == B}
     pad, glove = P['embedding_net.word_emb.pad_vec'].cuda(), P['embedding_net.word_emb.glove_vec'].cuda()
+    T, Lq = d['v_mask'].shape[1], d['q_mask'].shape[1]
+    flats, decisions = [flat.cpu().clone()], []
     for step in range(steps):
         eng.forward(flat, pad, glove, d['word_ids'], d['char_ids'], d['vfeats'], d['v_mask'], d['q_mask'], training=True,
                     seed=1000 + step, sample_offset=sl.start)
         _, dh, dsl, del_ = eng.loss(d['s_labels'], d['e_labels'], d['h_labels'], 1.0, 5.0, inv_batch=inv_b, mask_sum=msum)
         eng.backward(dh, dsl, del_, grads)
+        # (sites, B_shard, L * 128) packed: the caller lines the shards up along the batch axis
+        decisions.append([np.packbits(m.reshape(m.shape[0], -1).numpy(), axis=1) for m in hip_relu_masks(eng, sl.stop - sl.start, T, Lq)])
         if world > 1:
             g = grads.cpu()
             dp.allreduce_flat_(g)
             grads.copy_(g)
         opt.step(grads)
+        flats.append(flat.cpu().clone())
     torch.cuda.synchronize()
-    return flat.cpu()
+    return flats, decisions
 
 
 def _hip_worker(rank, world, port, out):
@@ -137,39 +145,51 @@ def _hip_worker(rank, world, port, out):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     cfg = O.make_cfg(video_feature_dim=64, max_pos_len=48, word_size=52, drop_rate=0.2)
     batch = O.synthetic_batch(cfg, B=7, T=40, Lq=6, Lc=5, seed=9, ragged=True)       # 7 % 2 != 0: uneven shards
-    flat = _hip_train(rank, world, batch)
-    if rank == 0:
-        out.put(flat.numpy())
+    flats, decisions = _hip_train(rank, world, batch)
+    out.put((rank, [f.numpy() for f in flats] if rank == 0 else None, decisions))
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.gpu
 def test_two_ranks_train_like_one_process_on_the_gpu():
+    import numpy as np
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_hip_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    two = torch.from_numpy(q.get(timeout=600))
+    got = sorted([q.get(timeout=600), q.get(timeout=600)], key=lambda t: t[0])
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
+    two = [torch.from_numpy(f) for f in got[0][1]]
     cfg = O.make_cfg(video_feature_dim=64, max_pos_len=48, word_size=52, drop_rate=0.2)
-    one = _hip_train(0, 1, O.synthetic_batch(cfg, B=7, T=40, Lq=6, Lc=5, seed=9, ragged=True))
-    start = _hip_train(0, 1, O.synthetic_batch(cfg, B=7, T=40, Lq=6, Lc=5, seed=9, ragged=True), steps=0)
-    moved = float((one - start).abs().max())
+    one, dec1 = _hip_train(0, 1, O.synthetic_batch(cfg, B=7, T=40, Lq=6, Lc=5, seed=9, ragged=True))
+    moved = float((one[-1] - one[0]).abs().max())
     assert moved > 1e-3                                                          # three real updates happened
     # Parameters whose gradient is structurally zero (key bias -- softmax shift invariance -- and the final 1-channel
     # biases) receive pure rounding noise (~1e-8, it depends on the summation order and hence on the sharding); AdamW divides
-    # it by sqrt(v) + 1e-6, so those few entries random-walk by a fraction of lr per step in BOTH runs.  They are bounded, not
-    # compared.
+    # it by sqrt(v) + 1e-6, so those few entries random-walk by a fraction of lr per step in BOTH runs: bounded, not compared.
     from vslnet_amd.engine import Engine
-    eng = Engine(cfg)
-    noise = torch.zeros(one.numel(), dtype=torch.bool)
-    for name, off, n, _ in eng.layout:
+    noise = torch.zeros(one[0].numel(), dtype=torch.bool)
+    for name, off, n, _ in Engine(cfg).layout:
         if name.endswith('key.conv1d.bias') or name.endswith('_block.2.conv1d.bias'):
             noise[off:off + n] = True
-    assert float((two - one)[noise].abs().max()) <= 3 * 1e-3                     # at most lr per step
-    assert float((two - one)[~noise].abs().max()) <= 2e-3 * moved, (float((two - one)[~noise].abs().max()), moved)
+    # A ReLU pre-activation within rounding noise of zero may land on the other side in a shard run (the summation order of
+    # the per-tile partial sums depends on where the shard's tiles start); the gradient then changes discontinuously.  The
+    # saved decisions tell: the parameters are compared strictly up to the first step whose forward moved a decision, and
+    # loosely (same order of magnitude as one flipped unit) afterwards.
+    first_moved = None
+    for step in range(3):
+        two_dec = [np.concatenate([got[0][2][step][s], got[1][2][step][s]], axis=0) for s in range(len(dec1[step]))]
+        if any(not np.array_equal(a, b) for a, b in zip(two_dec, dec1[step])):
+            first_moved = step
+            break
+    for k in range(1, 4):                                                        # parameters after k updates
+        diff = (two[k] - one[k]).abs()
+        assert float(diff[noise].max()) <= k * 1e-3                              # at most lr per step
+        strict = first_moved is None or k <= first_moved
+        tol = 2e-3 * moved if strict else 0.1 * moved
+        assert float(diff[~noise].max()) <= tol, (k, first_moved, float(diff[~noise].max()), moved)

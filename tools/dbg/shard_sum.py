@@ -39,3 +39,12 @@ for k in vf:
     rows.append((d / (s + 1e-12), d, s, k))
 for r in sorted(rows, reverse=True)[:12]:
     print('%.3e  abs %.3e  max %.3e  %s' % r)
+print('--- elementwise Adam sensitivity |dg| / (|g| + 1e-6)')
+rows = []
+for k in vf:
+    a, s_ = vf[k].flatten(), vs[k].flatten()
+    sens = (a - s_).abs() / (a.abs() + 1e-6)
+    i = int(sens.argmax())
+    rows.append((float(sens[i]), float(a[i]), float(s_[i]), i, k))
+for r in sorted(rows, reverse=True)[:10]:
+    print('%.3e  full %.4e  shards %.4e  idx %d  %s' % r)

@@ -144,16 +144,10 @@ __device__ __forceinline__ void gemm32(const float* __restrict__ As, int lda, in
 template <int NT, int KB>
 struct BFrag { float4 b[NT][KB]; };
 
-// k-block rotation: workgroup g visits the k-blocks of a stage-aligned GEMM in the order (kb + rot(g)) mod nkb, so the
-// 256 workgroups that start together do not all hammer the same L2 lines of the (shared) weight at the same instant.
-// Only the fp32 summation order changes.  Enabled when nkb is a multiple of KB (every fixed-K GEMM of the model).
-__device__ __forceinline__ int kb_rot(int nkb) {
-#ifdef VSL_NO_KROT
-    return 0;
-#else
-    return (int)((blockIdx.x * 5u + blockIdx.y * 3u) % (unsigned)nkb);
-#endif
-}
+// k-block order: every workgroup contracts k in the same order, so a row's result does not depend on which tile (and, under
+// data parallelism, which shard) it lands in.  (Round 1 rotated the order per workgroup to spread L2 traffic: no measured
+// gain, and it made the rounding of a row depend on blockIdx.)
+__device__ __forceinline__ int kb_rot(int) { return 0; }
 template <int NT, int KB>
 __device__ __forceinline__ void bfrag_load(BFrag<NT, KB>& f, const float* __restrict__ Bp, int ncols, int col0, int cstep,
                                            int kb0, int nkb) {

@@ -38,6 +38,16 @@ static void edbg_report(const char* name, int nst, hipStream_t s, int& left) {
     --left;
 }
 
+static void edbg_report2(const char* name, int i0, int i1, hipStream_t s, int& left) {
+    if (left <= 0) return;
+    long long h[32];
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamps_e), sizeof h);
+    fprintf(stderr, "[%s cycles] (from stamp 1: %lld)", name, h[i0] - h[1]);
+    for (int i = i0 + 1; i < i1; ++i) fprintf(stderr, " %lld", h[i] - h[i - 1]);
+    fprintf(stderr, "\n");
+}
+
 constexpr int CB_T = 512;                       // threads per workgroup (8 waves, 2 per SIMD)
 constexpr int CB_HALO = 4 * HALO;               // 12 rows each side
 constexpr int CB_NW = TILE_M + 2 * CB_HALO;     // 56-row window
@@ -88,12 +98,20 @@ __device__ __forceinline__ void gemm16(const float* __restrict__ As, int lda, co
 
 // LayerNorm of up to 64 rows by 512 threads: 8 lanes per row (lane sub owns float4 columns 4 sub + 32 j).  gamma / beta in
 // LDS.  dst[r] = LN(src[r]) * dropout ; `drow0` = global row of row 0 (dropout element index = row * 128 + col).
+// Rows outside [keep_lo, keep_hi) are written as zeros: rows of a neighbouring sample act as the conv's zero padding.
 __device__ __forceinline__ void ln_rows512(const float* __restrict__ src, float* __restrict__ dst, int nrows,
-                                           const float* __restrict__ g, const float* __restrict__ b, const Drop& dp, int drow0) {
+                                           const float* __restrict__ g, const float* __restrict__ b, const Drop& dp, int drow0,
+                                           int keep_lo = 0, int keep_hi = 1 << 30) {
     const int sub = threadIdx.x & 7, r = threadIdx.x >> 3;
     if (r >= nrows) return;
     const float* s = src + r * LDP + sub * 4;
     float* d = dst + r * LDP + sub * 4;
+    if (r < keep_lo || r >= keep_hi) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(d + 32 * j) = z;
+        return;
+    }
     float4 v[4];
     float sum = 0.f;
 #pragma unroll
@@ -169,6 +187,9 @@ __global__ __launch_bounds__(CB_T, 4) void k_convblock_fwd(CbFwdArgs a) {
     }
     BF16 bfA[1], bfB[1];
     bf16_load(bfA[0], a.Wpack[0], D, 16 * w);
+    float wkc[DWK];                                              // depthwise taps of this thread's channel, fetched a layer ahead
+#pragma unroll
+    for (int k = 0; k < DWK; ++k) wkc[k] = a.dw_w[0][(tid & 127) * DWK + k];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int e = tid + q * CB_T;
@@ -183,6 +204,13 @@ __global__ __launch_bounds__(CB_T, 4) void k_convblock_fwd(CbFwdArgs a) {
     // a window that lies inside one sample needs no boundary tests in the depthwise conv (block-uniform)
     const bool interior = rw0 >= 0 && rw0 + CB_NW <= R && (rw0 % L) + CB_NW <= L;
     const bool full = r0 + TILE_M <= R;
+    // Owner rows inside ONE sample (every tile when L % 32 == 0): the window rows of other samples only ever act as that
+    // sample's zero padding (their own outputs feed no owner row), so their LayerNorm output is written as zeros and the
+    // depthwise conv runs without per-tap tests.  [klo, khi) = window rows of the owner sample.
+    const int s_own = r0 / L;
+    const bool one_owner = full && (r0 + TILE_M - 1) / L == s_own;
+    const int klo = max(0, s_own * L - rw0), khi = min(CB_NW, (s_own + 1) * L - rw0);
+    const bool plain = interior || one_owner;
     __syncthreads();
     ESTAMP(1);
     const Drop nodrop{0u, 0u, 1.f};
@@ -195,11 +223,10 @@ __global__ __launch_bounds__(CB_T, 4) void k_convblock_fwd(CbFwdArgs a) {
         constexpr int NRB = (n + 15) / 16, QS = (n + 3) / 4;     // 16-row blocks ; rows per depthwise segment
         const float* P = Ps + l * CB_PS;
         const Drop dp = a.dp[l];
-        float wkc[DWK];                                          // depthwise taps of this thread's channel: in flight during the LayerNorm
-#pragma unroll
-        for (int k = 0; k < DWK; ++k) wkc[k] = a.dw_w[l][(tid & 127) * DWK + k];
-        ln_rows512(Xs + in0 * LDP, VU + in0 * LDP, nin, P, P + 128, nodrop, 0);
+        if (one_owner) ln_rows512(Xs + in0 * LDP, VU + in0 * LDP, nin, P, P + 128, nodrop, 0, klo - in0, khi - in0);
+        else ln_rows512(Xs + in0 * LDP, VU + in0 * LDP, nin, P, P + 128, nodrop, 0);
         __syncthreads();
+        if (l == 0) ESTAMP(8);
         // ---- depthwise conv k = 7 along the sequence: thread = (channel, quarter of the row range), window in registers
         {
             const int c = tid & 127, seg = tid >> 7;
@@ -207,7 +234,7 @@ __global__ __launch_bounds__(CB_T, 4) void k_convblock_fwd(CbFwdArgs a) {
             float win[QS + 2 * HALO], uo[QS];
 #pragma unroll
             for (int i = 0; i < QS + 2 * HALO; ++i) win[i] = VU[min(os - HALO + i, CB_NW - 1) * LDP + c];
-            if (interior) {
+            if (plain) {
 #pragma unroll
                 for (int i = 0; i < QS; ++i) {
                     float u = 0.f;
@@ -239,6 +266,7 @@ __global__ __launch_bounds__(CB_T, 4) void k_convblock_fwd(CbFwdArgs a) {
             }
         }
         __syncthreads();
+        if (l == 0) ESTAMP(9);
         // ---- pointwise GEMM + bias + ReLU (+ dropout) + residual, in place on the residual stream
         f32x4 acc[1][NRB];
 #pragma unroll
@@ -246,7 +274,12 @@ __global__ __launch_bounds__(CB_T, 4) void k_convblock_fwd(CbFwdArgs a) {
         gemm16<NRB, 1>(VU + o0 * LDP, LDP, cur, acc);
         __builtin_amdgcn_sched_barrier(0);
         prefetch();                                              // weight slice of the next stage: most of a layer ahead of its use
+        if (l < 3) {
+#pragma unroll
+            for (int k = 0; k < DWK; ++k) wkc[k] = a.dw_w[l < 3 ? l + 1 : 3][(tid & 127) * DWK + k];
+        }
         __builtin_amdgcn_sched_barrier(0);
+        if (l == 0) ESTAMP(10);
         const float bv = P[256 + col];
         uint16_t* mk = reinterpret_cast<uint16_t*>(a.relu_mask[l]);
 #pragma unroll
@@ -273,7 +306,9 @@ __global__ __launch_bounds__(CB_T, 4) void k_convblock_fwd(CbFwdArgs a) {
                 if (lane < 16 && o >= CB_HALO && o < CB_HALO + TILE_M && rw0 + o < R) mk[(size_t)(rw0 + o) * 8 + w] = (uint16_t)bits;
             }
         }
+        if (l == 0) ESTAMP(11);
         __syncthreads();
+        if (l == 0) ESTAMP(12);
         // owner rows of the layer output -> memory (16-byte stores)
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -334,7 +369,7 @@ void launch_convblock_fwd(const CbFwdArgs& a, hipStream_t s) {
     ensure_dynamic_lds((const void*)k_convblock_fwd, CB_FWD_LDS, ok, "k_convblock_fwd");
     hipLaunchKernelGGL(k_convblock_fwd, dim3((a.R + TILE_M - 1) / TILE_M), dim3(CB_T), CB_FWD_LDS, s, a);
     static int left = 6;
-    if (edbg_on() && a.R > 4096) edbg_report("convblock_fwd: load | L0 | L1 | L2 | L3 | qkv", 7, s, left);
+    if (edbg_on() && a.R > 4096) { int l2 = left; edbg_report("convblock_fwd: load | L0 | L1 | L2 | L3 | qkv", 7, s, left); edbg_report2("  L0: LN | dw | gemm | epilogue | barrier", 8, 13, s, l2); }
 }
 
 }  // namespace vsl
