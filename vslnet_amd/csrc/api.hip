@@ -597,8 +597,9 @@ void enc_bwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float*
         }
         return g;
     };
+    static const bool conv_block = !(getenv("VSL_CONVBLOCK_BWD") && getenv("VSL_CONVBLOCK_BWD")[0] == '0');
     LAUNCH("qkv_bwd", launch_qkv_bwd(c.W(t.dq), c.W(t.dk), c.W(t.dv), c.W(w.y[3]), c.W(t.dr), c.P(P.ln1g), c.PK(K.qkv_t),
-                          c.W(t.ga), p_ln1g, p_ln1b, R, c.drop(app * 16 + 4), gemm_args(3), c.s));
+                          c.W(t.ga), p_ln1g, p_ln1b, R, c.drop(app * 16 + 4), gemm_args(conv_block ? -1 : 3), c.s));
     {   // out_layer + fused q/k/v weight gradients: every input exists now -> side stream, beside the conv chain
         WgradBatch wb;
         memset(&wb, 0, sizeof wb);
@@ -627,6 +628,26 @@ void enc_bwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float*
     }
     float* g = c.dry ? nullptr : c.W(t.ga);
     float* other = c.dry ? nullptr : c.W(t.gb);
+    if (conv_block) {
+        // the four layers in ONE launch (kernels_enc.hip: 12-row recomputed halo); slab order = the per-layer chain's
+        CbBwdArgs a;
+        memset(&a, 0, sizeof a);
+        for (int i = 3; i >= 0; --i) {
+            a.p_lng[i] = c.slab(P.lng[i], D, ntiles);
+            a.p_lnb[i] = c.slab(P.lnb[i], D, ntiles);
+            a.p_dw[i] = c.slab(P.dw[i], D * DWK, ntiles);
+        }
+        if (!c.dry) {
+            a.dy = g; a.dx0 = dx0_out; a.R = R; a.L = L;
+            for (int i = 0; i < 4; ++i) {
+                a.x[i] = i > 0 ? c.W(w.y[i - 1]) : c.W(w.x0);
+                a.relu_mask[i] = reinterpret_cast<const uint32_t*>(c.W(w.mask[i])); a.WTpack[i] = c.PK(K.pw_t[i]);
+                a.ln_g[i] = c.P(P.lng[i]); a.ln_b[i] = c.P(P.lnb[i]); a.dw_w[i] = c.P(P.dw[i]);
+                a.dp[i] = c.drop(app * 16 + i); a.gz[i] = c.W(t.gz[i]);
+            }
+        }
+        LAUNCH("convblock_bwd", launch_convblock_bwd(a, c.s));
+    } else
     for (int i = 3; i >= 0; --i) {
         float* p_g = c.slab(P.lng[i], D, ntiles);
         float* p_b = c.slab(P.lnb[i], D, ntiles);

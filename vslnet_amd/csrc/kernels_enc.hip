@@ -372,4 +372,302 @@ void launch_convblock_fwd(const CbFwdArgs& a, hipStream_t s) {
     if (edbg_on() && a.R > 4096) { int l2 = left; edbg_report("convblock_fwd: load | L0 | L1 | L2 | L3 | qkv", 7, s, left); edbg_report2("  L0: LN | dw | gemm | epilogue | barrier", 8, 13, s, l2); }
 }
 
+// =========================================================================================================
+// backward of the conv block (autograd of layers_t7.py:131-140, four layers in one launch).  dy = grad wrt the block output on
+// the 56-row window; per layer l = 3..0, on a row range that shrinks by 3 rows each side:
+//   A  dz = dy * relu-bit * dropout           (saved to gz[l] on the owner rows: G operand of the pointwise weight gradient)
+//   B  du = dz Wp                              (16x16x4 MFMA, 4 / 4 / 3 / 3 row blocks)
+//   C  dv = depthwise^T(du) ; per-tile partials of the depthwise taps, LayerNorm gamma / beta over the OWNER rows
+//   D  dy <- dy + LN^T(dv)                     (becomes the dy of the layer below; layer 0 writes dx0)
+// The LayerNorm input x_l of a layer is re-normalised in LDS (xhat, rstd) for C and D.  Phase C works per (channel, row
+// segment) with the 4 segments of a channel in 4 adjacent lanes, so the partial sums are combined with two quad shuffles.
+// LDS 91 KB: fits beside a weight-gradient workgroup (66 KB) of the side stream.
+// =========================================================================================================
+constexpr int CB_XR = CB_NW - 6;                // rows of the x / xhat buffer (window rows 3 .. 52)
+__global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* DY = smem;                       // [56][LDP] grad wrt the current layer's output (in place)
+    float* GU = DY + CB_NW * LDP;           // [68][LDP] dz (GEMM A operand) -> du -> dv
+    float* Xh = GU + CB_VU * LDP;           // [50][LDP] x_l, normalised in place; row = window row - 3
+    float* RS = Xh + CB_XR * LDP;           // [64] rstd per window row
+    float* VF = RS + 64;                    // [64] 1 = the window row belongs to the owner sample / is inside [0, R)
+    float* GB = VF + 64;                    // [128] gamma of the current layer (row layout reads)
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int R = a.R, L = a.L;
+    const int r0 = blockIdx.x * TILE_M, rw0 = r0 - CB_HALO;
+    const bool interior = rw0 >= 0 && rw0 + CB_NW <= R && (rw0 % L) + CB_NW <= L;
+    const bool full = r0 + TILE_M <= R;
+    const int s_own = r0 / L;
+    const bool one_owner = full && (r0 + TILE_M - 1) / L == s_own;
+    const int klo = max(0, s_own * L - rw0), khi = min(CB_NW, (s_own + 1) * L - rw0);
+    const bool plain = interior || one_owner;
+    // element layout of phases A / loads: thread owns float4 column c4 of window rows wq + 16 q
+    const int wq = tid >> 5, c4 = (tid & 31) * 4;
+    // column layout of phase C
+    const int cc = tid >> 2, seg = tid & 3;
+    ESTAMP(0);
+    float4 xv[4];
+    uint32_t mw[4];
+    auto fetch_layer = [&](int l) {         // x_l rows and ReLU words of the window, for phase A of layer l
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int wr = wq + 16 * q, r = rw0 + wr;
+            const bool ok = wr < CB_NW && r >= 0 && r < R;
+            const size_t rc = (size_t)min(max(r, 0), R - 1);
+            const float4 v = *reinterpret_cast<const float4*>(a.x[l] + rc * D + c4);
+            const uint32_t m = a.relu_mask[l][rc * 4 + (c4 >> 5)];
+            xv[q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            mw[q] = ok ? m : 0u;
+        }
+    };
+    {
+        float4 dv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int wr = wq + 16 * q, r = rw0 + wr;
+            dv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (wr < CB_NW && r >= 0 && r < R) dv[q] = *reinterpret_cast<const float4*>(a.dy + (size_t)r * D + c4);
+        }
+        fetch_layer(3);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int wr = wq + 16 * q;
+            if (wr < CB_NW) *reinterpret_cast<float4*>(&DY[wr * LDP + c4]) = dv[q];
+        }
+    }
+    BF16 bfA[1], bfB[1];
+    bf16_load(bfA[0], a.WTpack[3], D, 16 * w);
+    float wk[DWK], gc, bc, gnext = 0.f;
+#pragma unroll
+    for (int k = 0; k < DWK; ++k) wk[k] = a.dw_w[3][cc * DWK + k];
+    gc = a.ln_g[3][cc]; bc = a.ln_b[3][cc];
+    if (tid < D) gnext = a.ln_g[3][tid];
+    if (tid < 64) {
+        const int r = rw0 + tid;
+        VF[tid] = (one_owner ? (tid >= klo && tid < khi) : (tid < CB_NW && r >= 0 && r < R)) ? 1.f : 0.f;
+    }
+    const int col = 16 * w + (lane & 15), g4 = 4 * (lane >> 4);
+    ESTAMP(1);
+
+    auto layer = [&](auto LC, BF16 (&cur)[1], BF16 (&nxt)[1]) {
+        constexpr int l = decltype(LC)::value;
+        constexpr int ra = 3 * (3 - l), rb_ = CB_NW - ra;            // rows of dy / dz / du
+        constexpr int n = rb_ - ra, NRB = (n + 15) / 16;
+        constexpr int xlo = (ra + 3 < 9 ? ra + 3 : 9);                // x rows kept: [xlo, 56 - xlo)
+        constexpr int nD = n - 6;                                     // rows of phases C / D: [ra + 3, rb_ - 3)
+        constexpr int NHL = 3 * l, HQ = (NHL + 1) / 2;                // halo rows per side in phase C, per thread
+        const Drop dp = a.dp[l];
+        // ---- A: dz = dy * relu-bit * dropout -> GU (+ gz on the owner rows) ; x_l -> Xh ; gamma -> GB
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int wr = wq + 16 * q;
+            if (wr >= ra && wr < rb_) {
+                float4 v = *reinterpret_cast<const float4*>(&DY[wr * LDP + c4]);
+                const uint32_t bits = mw[q] >> (c4 & 31);
+                float m[4] = {1.f, 1.f, 1.f, 1.f};
+                if (dp.thresh) {
+                    const uint32_t base = (uint32_t)((rw0 + wr) * D + c4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) m[i] = drop_keep_scale(dp, base + i);
+                }
+                v.x = (bits & 1u) ? v.x * m[0] : 0.f;
+                v.y = (bits & 2u) ? v.y * m[1] : 0.f;
+                v.z = (bits & 4u) ? v.z * m[2] : 0.f;
+                v.w = (bits & 8u) ? v.w * m[3] : 0.f;
+                *reinterpret_cast<float4*>(&GU[wr * LDP + c4]) = v;
+                if (wr >= CB_HALO && wr < CB_HALO + TILE_M && (full || rw0 + wr < R))
+                    *reinterpret_cast<float4*>(a.gz[l] + (size_t)(rw0 + wr) * D + c4) = v;
+            }
+            if (wr >= xlo && wr < CB_NW - xlo) *reinterpret_cast<float4*>(&Xh[(wr - 3) * LDP + c4]) = xv[q];
+        }
+        if (tid < D) GB[tid] = gnext;
+        __syncthreads();
+        // ---- x_l -> xhat in place, rstd per row (8 lanes per row)
+        {
+            const int r8 = tid >> 3, sub = tid & 7;
+            if (r8 < CB_NW - 2 * xlo) {
+                float* xr = Xh + (xlo + r8 - 3) * LDP + sub * 4;
+                float4 v[4];
+                float sum = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v[j] = *reinterpret_cast<const float4*>(xr + 32 * j); sum += sum4(v[j]); }
+                const float mu = grp8_sum(sum) * (1.0f / D);
+                float qv = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[j].x -= mu; v[j].y -= mu; v[j].z -= mu; v[j].w -= mu;
+                    qv += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
+                }
+                const float rstd = rsqrtf(grp8_sum(qv) * (1.0f / D) + LN_EPS);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    *reinterpret_cast<float4*>(xr + 32 * j) = make_float4(v[j].x * rstd, v[j].y * rstd, v[j].z * rstd, v[j].w * rstd);
+                if (sub == 0) RS[xlo + r8] = rstd;
+            }
+        }
+        // ---- B: du = dz Wp
+        f32x4 acc[1][NRB];
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) acc[0][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        gemm16<NRB, 1>(GU + ra * LDP, LDP, cur, acc);
+        __syncthreads();
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int row = ra + 16 * rb + g4 + rr;
+                GU[row * LDP + col] = acc[0][rb][rr] * VF[min(row, 63)];    // rows of another sample: zero padding of this one's conv
+            }
+        __syncthreads();
+        // ---- C: dv = depthwise^T(du) ; partial sums over the owner rows
+        float dvo[8], dvh[HQ > 0 ? HQ : 1];
+        float gw[DWK], slb = 0.f, slg = 0.f;
+#pragma unroll
+        for (int k = 0; k < DWK; ++k) gw[k] = 0.f;
+        const int t0 = CB_HALO + 8 * seg;                             // this thread's 8 owner rows
+        const int hs = ((seg >> 1) ? CB_HALO + TILE_M : CB_HALO - NHL) + (seg & 1) * HQ;   // and its halo rows (l > 0)
+        {
+            float dwin[14], vv[14], xc[8];
+#pragma unroll
+            for (int j = 0; j < 14; ++j) {
+                dwin[j] = GU[(t0 - 3 + j) * LDP + cc];
+                const float xh = Xh[(t0 - 6 + j) * LDP + cc];
+                vv[j] = (xh * gc + bc) * VF[t0 - 3 + j];
+                if (j >= 3 && j < 11) xc[j - 3] = xh;
+            }
+            if (plain) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float dv = 0.f;
+#pragma unroll
+                    for (int k = 0; k < DWK; ++k) { dv += wk[k] * dwin[i + 6 - k]; gw[k] += dwin[i + 3] * vv[i + k]; }
+                    dvo[i] = dv;
+                    slb += dv; slg += dv * xc[i];
+                }
+            } else {
+                int p = (r0 + 8 * seg) % L;                             // position of the row inside its sample
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float dv = 0.f;
+#pragma unroll
+                    for (int k = 0; k < DWK; ++k) {
+                        dv += ((unsigned)(p - k + HALO) < (unsigned)L) ? wk[k] * dwin[i + 6 - k] : 0.f;
+                        gw[k] += ((unsigned)(p + k - HALO) < (unsigned)L) ? dwin[i + 3] * vv[i + k] : 0.f;
+                    }
+                    dvo[i] = dv;
+                    slb += dv; slg += dv * xc[i];
+                    p = p + 1 == L ? 0 : p + 1;
+                }
+            }
+        }
+        if (HQ > 0) {
+            float hwin[HQ + 6];
+#pragma unroll
+            for (int j = 0; j < HQ + 6; ++j) hwin[j] = GU[min(max(hs - 3 + j, 0), CB_VU - 1) * LDP + cc];
+            if (plain) {
+#pragma unroll
+                for (int i = 0; i < HQ; ++i) {
+                    float dv = 0.f;
+#pragma unroll
+                    for (int k = 0; k < DWK; ++k) dv += wk[k] * hwin[i + 6 - k];
+                    dvh[i] = dv;
+                }
+            } else {
+                int p = (rw0 + hs) % L;
+                p = p < 0 ? p + L : p;
+#pragma unroll
+                for (int i = 0; i < HQ; ++i) {
+                    float dv = 0.f;
+#pragma unroll
+                    for (int k = 0; k < DWK; ++k) dv += ((unsigned)(p - k + HALO) < (unsigned)L) ? wk[k] * hwin[i + 6 - k] : 0.f;
+                    dvh[i] = dv;
+                    p = p + 1 == L ? 0 : p + 1;
+                }
+            }
+        }
+        __syncthreads();                                              // every du window is in registers
+#pragma unroll
+        for (int i = 0; i < 8; ++i) GU[(t0 + i) * LDP + cc] = dvo[i];
+        if (HQ > 0) {
+#pragma unroll
+            for (int i = 0; i < HQ; ++i)
+                if ((seg & 1) * HQ + i < NHL) GU[(hs + i) * LDP + cc] = dvh[i];
+        }
+        // the 4 segments of a channel sit in 4 adjacent lanes
+#pragma unroll
+        for (int k = 0; k < DWK; ++k) { gw[k] += __shfl_xor(gw[k], 1); gw[k] += __shfl_xor(gw[k], 2); }
+        slb += __shfl_xor(slb, 1); slb += __shfl_xor(slb, 2);
+        slg += __shfl_xor(slg, 1); slg += __shfl_xor(slg, 2);
+        if (seg == 0) {
+#pragma unroll
+            for (int k = 0; k < DWK; ++k) a.p_dw[l][(size_t)blockIdx.x * D * DWK + cc * DWK + k] = gw[k];
+            a.p_lnb[l][(size_t)blockIdx.x * D + cc] = slb;
+            a.p_lng[l][(size_t)blockIdx.x * D + cc] = slg;
+        }
+        // everything the layer below needs from memory: requested now, consumed after phase D
+        if (l > 0) {
+            constexpr int lm = l > 0 ? l - 1 : 0;
+            fetch_layer(lm);
+            bf16_load(nxt[0], a.WTpack[lm], D, 16 * w);
+#pragma unroll
+            for (int k = 0; k < DWK; ++k) wk[k] = a.dw_w[lm][cc * DWK + k];
+            gc = a.ln_g[lm][cc]; bc = a.ln_b[lm][cc];
+            if (tid < D) gnext = a.ln_g[lm][tid];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        // ---- D: dy <- dy + LN^T(dv)   (8 lanes per row)
+        {
+            const int r8 = tid >> 3, sub = tid & 7;
+            if (r8 < nD) {
+                const int wr = ra + 3 + r8;
+                const float* dvr = GU + wr * LDP + sub * 4;
+                const float* xr = Xh + (wr - 3) * LDP + sub * 4;
+                float* dyr = DY + wr * LDP + sub * 4;
+                const float rstd = RS[wr];
+                float4 gd[4], xh[4];
+                float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 dv = *reinterpret_cast<const float4*>(dvr + 32 * j);
+                    const float4 gv = *reinterpret_cast<const float4*>(GB + sub * 4 + 32 * j);
+                    xh[j] = *reinterpret_cast<const float4*>(xr + 32 * j);
+                    gd[j] = make_float4(dv.x * gv.x, dv.y * gv.y, dv.z * gv.z, dv.w * gv.w);
+                    m1 += sum4(gd[j]);
+                    m2 += gd[j].x * xh[j].x + gd[j].y * xh[j].y + gd[j].z * xh[j].z + gd[j].w * xh[j].w;
+                }
+                m1 = grp8_sum(m1) * (1.0f / D);
+                m2 = grp8_sum(m2) * (1.0f / D);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 dy = *reinterpret_cast<const float4*>(dyr + 32 * j);
+                    float4 o;
+                    o.x = dy.x + rstd * (gd[j].x - m1 - xh[j].x * m2); o.y = dy.y + rstd * (gd[j].y - m1 - xh[j].y * m2);
+                    o.z = dy.z + rstd * (gd[j].z - m1 - xh[j].z * m2); o.w = dy.w + rstd * (gd[j].w - m1 - xh[j].w * m2);
+                    if (l > 0) *reinterpret_cast<float4*>(dyr + 32 * j) = o;
+                    else if (full || rw0 + wr < R) *reinterpret_cast<float4*>(a.dx0 + (size_t)(rw0 + wr) * D + sub * 4 + 32 * j) = o;
+                }
+            }
+        }
+        if (l > 0) __syncthreads();
+    };
+    __syncthreads();
+    layer(std::integral_constant<int, 3>(), bfA, bfB);
+    ESTAMP(2);
+    layer(std::integral_constant<int, 2>(), bfB, bfA);
+    ESTAMP(3);
+    layer(std::integral_constant<int, 1>(), bfA, bfB);
+    ESTAMP(4);
+    layer(std::integral_constant<int, 0>(), bfB, bfA);
+    ESTAMP(5);
+}
+constexpr size_t CB_BWD_LDS = (size_t)((CB_NW + CB_VU + CB_XR) * LDP + 64 + 64 + 128) * sizeof(float);
+void launch_convblock_bwd(const CbBwdArgs& a, hipStream_t s) {
+    static size_t ok = 0;
+    ensure_dynamic_lds((const void*)k_convblock_bwd, CB_BWD_LDS, ok, "k_convblock_bwd");
+    hipLaunchKernelGGL(k_convblock_bwd, dim3((a.R + TILE_M - 1) / TILE_M), dim3(CB_T), CB_BWD_LDS, s, a);
+    static int left = 6;
+    if (edbg_on() && a.R > 4096) edbg_report("convblock_bwd: load | L3 | L2 | L1 | L0", 6, s, left);
+}
+
 }  // namespace vsl

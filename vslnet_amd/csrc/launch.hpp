@@ -138,6 +138,19 @@ struct CbFwdArgs {
     int R, L;
 };
 void launch_convblock_fwd(const CbFwdArgs& a, hipStream_t s);
+struct CbBwdArgs {
+    const float* dy;               // (R,128) grad wrt the block output
+    const float* x[4];             // LayerNorm inputs of layers 0..3 (x0, y0, y1, y2)
+    const uint32_t* relu_mask[4];
+    const float* WTpack[4];        // transpose packs of the pointwise weights
+    const float *ln_g[4], *ln_b[4], *dw_w[4];
+    Drop dp[4];
+    float* gz[4];                  // out (R,128): dz per layer, G operand of the pointwise weight gradients
+    float* dx0;                    // out (R,128): grad wrt the block input (x + pos)
+    float *p_lng[4], *p_lnb[4], *p_dw[4];   // partial slabs [ntiles][128] / [ntiles][128 * 7]
+    int R, L;
+};
+void launch_convblock_bwd(const CbBwdArgs& a, hipStream_t s);
 void launch_ln_qkv_fwd(const float* x, const float* ln_g, const float* ln_b, const float* Wpack, const float* bq,
                        const float* bk, const float* bv, float* h1, float* q, float* k, float* v, int R, Drop d1,
                        hipStream_t s);
