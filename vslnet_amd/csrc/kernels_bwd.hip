@@ -404,6 +404,8 @@ __global__ __launch_bounds__(512) void k_wgrad(WgradBatch wb) {
     if (st) g_stamps[3] = clock64();
 }
 void launch_wgrad(const WgradBatch& wb0, hipStream_t s) {
+    static const bool v2 = !(getenv("VSL_WGRAD2") && getenv("VSL_WGRAD2")[0] == '0');
+    if (v2) { launch_wgrad2(wb0, s); return; }
     WgradBatch wb = wb0;
     int total = 0;
     for (int i = 0; i < wb.n; ++i) {
