@@ -139,12 +139,18 @@ def train(configs, dataset, features, device, world, rank, log=print):
             if fused:
                 # this rank's rows, padded to the GLOBAL batch widths; the losses are normalised with the global batch
                 inv_batch, mask_sum = dp.global_normalisers(batch['lens_global'])
-                q_mask = (batch['word_ids'] != 0).float()
-                eng.forward(flat, pad_vec, glove_vec, batch['word_ids'], batch['char_ids'], batch['vfeats'], batch['v_mask'], q_mask,
-                            training=True, seed=(configs.seed << 20) + global_step, sample_offset=batch['row0'])
-                losses, d_h, d_sl, d_el = eng.loss(batch['s_labels'], batch['e_labels'], batch['h_labels'], 1.0, configs.highlight_lambda,
-                                                   inv_batch=inv_batch, mask_sum=mask_sum)
-                eng.backward(d_h, d_sl, d_el, grads)
+                if batch['vfeats'].shape[0] == 0:
+                    # the last batch of an epoch can hold fewer samples than there are ranks (TACoS: 10146 % 16 = 2): a rank
+                    # without rows contributes a zero bucket and still joins the exchange and the (replicated) update
+                    grads.zero_()
+                    losses = torch.zeros(4, device=device)
+                else:
+                    q_mask = (batch['word_ids'] != 0).float()
+                    eng.forward(flat, pad_vec, glove_vec, batch['word_ids'], batch['char_ids'], batch['vfeats'], batch['v_mask'], q_mask,
+                                training=True, seed=(configs.seed << 20) + global_step, sample_offset=batch['row0'])
+                    losses, d_h, d_sl, d_el = eng.loss(batch['s_labels'], batch['e_labels'], batch['h_labels'], 1.0,
+                                                       configs.highlight_lambda, inv_batch=inv_batch, mask_sum=mask_sum)
+                    eng.backward(d_h, d_sl, d_el, grads)
                 dp.allreduce_flat_(grads)
                 opt.step(grads)
                 loss_t = losses[2]

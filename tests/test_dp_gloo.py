@@ -69,6 +69,41 @@ def test_two_rank_allreduce_matches_single_process():
     assert err <= 1e-5 * scale + 1e-7, (err, scale)
 
 
+def _worker_short(rank, world, port, out):
+    """the last batch of an epoch with fewer samples than ranks: a rank without rows sends a zero bucket (main.py)"""
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    cfg = O.make_cfg(video_feature_dim=32, max_pos_len=32, word_size=52)
+    P = O.random_params(cfg, seed=5)
+    full = O.synthetic_batch(cfg, B=1, T=20, Lq=6, Lc=5, seed=9, ragged=True)     # 1 sample, 2 ranks
+    inv_b, msum = dp.global_normalisers(full['lens'].tolist())
+    shard = dp.shard_batch(full, rank, world)
+    n = shard['vfeats'].shape[0]
+    assert n == (1 if rank == 0 else 0)
+    ref = _flat_grads(P, cfg, full, inv_b, msum)
+    g = _flat_grads(P, cfg, shard, inv_b, msum) if n else torch.zeros_like(ref)
+    dp.allreduce_flat_(g)
+    if rank == 0:
+        out.put((float((g - ref).abs().max()), float(ref.abs().max())))
+    dist.destroy_process_group()
+
+
+def test_rank_without_rows_joins_the_exchange_with_zeros():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_short, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    err, scale = q.get(timeout=300)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert err <= 1e-6 * scale + 1e-9, (err, scale)
+
+
 def test_shard_slices_cover_the_batch():
     for B in (1, 5, 8, 64, 257):
         for N in (1, 2, 4, 8):
@@ -193,3 +228,25 @@ def test_two_ranks_train_like_one_process_on_the_gpu():
         strict = first_moved is None or k <= first_moved
         tol = 2e-3 * moved if strict else 0.1 * moved
         assert float(diff[~noise].max()) <= tol, (k, first_moved, float(diff[~noise].max()), moved)
+
+
+@pytest.mark.gpu
+def test_bench_self_launches_two_ranks_over_rccl():
+    """`python bench.py --gpus 2` without torchrun: re-exec under torch.distributed.run, one rank per GPU, gradient exchange
+    = ONE RCCL all-reduce of the flat bucket.  Needs two devices (skipped on the 1-GPU test box); on one device the same
+    command must fail with a clear message instead of hanging."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--no-cpu-baseline',
+           '--batch', '8', '--T', '32', '--dv', '64']
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and 'device' in (r.stderr + r.stdout)
+        pytest.skip('one device: the 2-rank RCCL run needs two')
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
+    out = json.loads(line)
+    assert out['n_gpus'] == 2 and out['value'] > 0 and out['config']['global_batch'] == 16

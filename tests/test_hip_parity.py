@@ -182,3 +182,20 @@ def test_losses_and_every_gradient(name):
         n += 1
     assert n == len(eng.layout)
     rep.finish()
+
+
+def test_one_engine_serves_many_shapes_from_one_workspace():
+    """The collate narrows every batch to its own max T / Lq / Lc: an engine sees many shapes.  It keeps ONE workspace (grown to
+    the largest) and a bounded plan cache; a shape that comes back after others gives bit-identical logits."""
+    cfg, P, b, z, eng, flat = _setup('real_tf')
+    h0, sl0, el0 = [t.clone() for t in _run_forward(eng, flat, P, b)]
+    ws0 = eng._ws
+    B, T = b['v_mask'].shape
+    for cut in (T - 7, T // 2, T - 1):                       # narrower batches of the same samples
+        nb = dict(b)
+        nb['vfeats'], nb['v_mask'] = b['vfeats'][:, :cut].contiguous(), b['v_mask'][:, :cut].contiguous()
+        _run_forward(eng, flat, P, nb)
+    h1, sl1, el1 = _run_forward(eng, flat, P, b)
+    torch.cuda.synchronize()
+    assert eng._ws is ws0                                    # smaller shapes reuse the same buffer
+    assert torch.equal(sl0, sl1) and torch.equal(el0, el1) and torch.equal(h0, h1)

@@ -85,9 +85,10 @@ def test_rnn_head_matches_reference_golden():
         assert float((eng.ws_view(nm, (B, T, 128)).cpu() - want['pred_parts'][nm].detach()).abs().max()) <= 1e-5, nm
 
 
-@pytest.mark.parametrize('shape', [dict(B=21, T=37, Lq=6, Lc=5), dict(B=3, T=128, Lq=20, Lc=10)])
+@pytest.mark.parametrize('shape', [dict(B=21, T=37, Lq=6, Lc=5), dict(B=3, T=128, Lq=20, Lc=10),
+                                   dict(B=16, T=128, Lq=20, Lc=10, Dv=1024)])     # the last one = BASELINE configs[0] as written
 def test_rnn_head_against_oracle(shape):
-    cfg = O.make_cfg(video_feature_dim=64, max_pos_len=128, word_size=60, predictor='rnn')
+    cfg = O.make_cfg(video_feature_dim=shape.get('Dv', 64), max_pos_len=128, word_size=60, predictor='rnn')
     P = O.random_params(cfg, seed=21)
     b = O.synthetic_batch(cfg, shape['B'], shape['T'], shape['Lq'], shape['Lc'], seed=22, ragged=True)
     eng, h, sl, el, losses, grads = _run(cfg, P, b)

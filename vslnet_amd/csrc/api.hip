@@ -76,6 +76,7 @@ struct Plan {
     ReduceSeg* segs_dev = nullptr;
     int* blk2seg_dev = nullptr;         // block table: [early blocks | late blocks]
     int nblocks = 0, nblocks_early = 0;
+    uint64_t last_use = 0;              // LRU stamp of the plan cache (get_plan)
 };
 
 }  // namespace
@@ -92,6 +93,7 @@ struct vsl_handle_s {
     uint8_t* decay_dev = nullptr;        // per-element weight-decay flag of the flat bucket (vsl_adamw_step)
     float* opt_scratch = nullptr;        // OPT_BLOCKS partial sums of grads^2
     std::map<std::tuple<int, int, int, int>, Plan*> plans;
+    uint64_t plan_clock = 0;
     // side streams for the independent chains (query branch, weight gradients) + fork/join events
     hipStream_t side[2] = {nullptr, nullptr};
     std::vector<hipEvent_t> sync_pool;
@@ -933,7 +935,8 @@ int build_plan(vsl_handle_s* h, int B, int T, int Lq, int Lc, Plan** out) {
         return fail("sequence length (T=%d, Lq=%d) exceeds max_pos_len=%d: the positional table has no such row "
                     "(layers_t7.py:196 -- IndexError in the reference)", T, Lq, cf.max_pos_len);
     if (T > MAX_L) return fail("T=%d > %d clips not supported by the LDS-resident attention kernels", T, MAX_L);
-    if (Lq > MAX_LQ) return fail("Lq=%d > %d query words not supported yet", Lq, MAX_LQ);
+    if (Lq > MAX_LQ) return fail("Lq=%d > %d query words: the CQAttention kernels keep the whole query of a sample in LDS "
+                                 "(the reference truncates at max_pos_len words, data_gen.py:188)", Lq, MAX_LQ);
     if (Lc < 4 || Lc > MAX_LC) return fail("Lc=%d must be in [4, %d] (the widest char conv has kernel 4, layers_t7.py:52)", Lc, MAX_LC);
     Plan* p = new Plan();
     p->B = B; p->T = T; p->Lq = Lq; p->Lc = Lc;
@@ -1034,12 +1037,32 @@ int build_plan(vsl_handle_s* h, int B, int T, int Lq, int Lc, Plan** out) {
     return 0;
 }
 
+void free_plan(Plan* p) {
+    if (!p) return;
+    if (p->segs_dev) (void)hipFree(p->segs_dev);
+    if (p->blk2seg_dev) (void)hipFree(p->blk2seg_dev);
+    delete p;
+}
+
+// Per-shape plans (workspace layout + reduction tables).  The collate narrows every batch to its own max T / Lq / Lc, so a
+// long training run visits hundreds of shapes: the cache is bounded and evicts the least recently used plan together with
+// its two device tables.  (A forward and its backward use the same shape back to back, so a live plan is never evicted.)
+constexpr size_t MAX_PLANS = 64;
 int get_plan(vsl_handle_s* h, int B, int T, int Lq, int Lc, Plan** out) {
     auto key = std::make_tuple(B, T, Lq, Lc);
     auto it = h->plans.find(key);
-    if (it != h->plans.end()) { *out = it->second; return 0; }
+    if (it != h->plans.end()) { it->second->last_use = ++h->plan_clock; *out = it->second; return 0; }
     Plan* p = nullptr;
     if (int rc = build_plan(h, B, T, Lq, Lc, &p)) return rc;
+    if (h->plans.size() >= MAX_PLANS) {
+        auto victim = h->plans.begin();
+        for (auto jt = h->plans.begin(); jt != h->plans.end(); ++jt)
+            if (jt->second->last_use < victim->second->last_use) victim = jt;
+        (void)hipDeviceSynchronize();            // its tables may still be read by an enqueued reduction
+        free_plan(victim->second);
+        h->plans.erase(victim);
+    }
+    p->last_use = ++h->plan_clock;
     h->plans[key] = p;
     *out = p;
     return 0;

@@ -28,8 +28,9 @@ constexpr int DWK = 7;          // depthwise kernel size
 constexpr int HALO = 3;
 constexpr int HD = 16;          // attention head size the kernels are specialised for (dim 128 / 8 heads)
 constexpr int CATP = 4 * D + 4; // LDS row stride of the CQAttention concat tile
-constexpr int MAX_LC = 24;      // max characters per word (LDS budget of k_embed_bwd)
-constexpr int MAX_LQ = 64;      // max query words (LDS budget of k_cq_col_bwd)
+constexpr int MAX_LC = 40;      // max characters per word (LDS budget of k_embed_fwd: 8 words x char_dim x (MAX_LC + 4) floats)
+constexpr int MAX_LQ = 96;      // max query words (LDS budget of the CQAttention kernels: k_cq_bwd_a needs 151 KB at Lq = 82;
+                                // ActivityNet's longest query has 82 words, TACoS' 64 -- SURVEY 8d)
 constexpr int MAX_L = 1024;     // max clips per video (tested limit; the attention kernels stream K/V in 256-row blocks)
 
 // ---------------------------------------------------------------------------------------------------------

@@ -1260,9 +1260,10 @@ __global__ __launch_bounds__(256) void k_cq_bwd_a(CqBwdArgs a) {
     STAMP(4);
     {   // dS_row[i][j] = dc2q[i] . Q[j] + dq2c[i] . M[j]: a 32 x 32 MFMA tile per 32 query words, K = 256 split over
         // the four waves (wave w: channels 32w .. 32w+31 of both halves), partial tiles summed in wave order through LDS
+        const int i = lane & 31;
+        for (int nb = 0; nb < NTJ; nb += 2) {                   // two 32-word tiles per pass (one pass up to 64 query words)
         f32x16 ds[2];
         zero_acc(ds);
-        const int i = lane & 31;
         float4 bq[2][2][4];                                  // [part][nt][kq]: every B fragment is requested up front
 #pragma unroll
         for (int part = 0; part < 2; ++part) {
@@ -1271,9 +1272,9 @@ __global__ __launch_bounds__(256) void k_cq_bwd_a(CqBwdArgs a) {
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int kq = 0; kq < 4; ++kq) {
-                    const int j = 32 * nt + i;
+                    const int j = 32 * (nb + nt) + i;
                     bq[part][nt][kq] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (nt < NTJ && j < Lq)
+                    if (nb + nt < NTJ && j < Lq)
                         bq[part][nt][kq] = *reinterpret_cast<const float4*>(src + (qrow + j) * D + (4 * w + kq) * 8 + 4 * hh);
                 }
         }
@@ -1285,7 +1286,7 @@ __global__ __launch_bounds__(256) void k_cq_bwd_a(CqBwdArgs a) {
                 const float4 av = *reinterpret_cast<const float4*>(arow + (4 * w + kq) * 8);
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
-                    if (nt < NTJ) {
+                    if (nb + nt < NTJ) {
                         const float4 bv = bq[part][nt][kq];
                         ds[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, ds[nt], 0, 0, 0);
                         ds[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, ds[nt], 0, 0, 0);
@@ -1297,10 +1298,11 @@ __global__ __launch_bounds__(256) void k_cq_bwd_a(CqBwdArgs a) {
         }
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
-            if (nt < NTJ) {
+            if (nb + nt < NTJ) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) Pp[(w * TILE_M + acc_row(r, lane)) * PJ + 32 * nt + i] = ds[nt][r];
+                for (int r = 0; r < 16; ++r) Pp[(w * TILE_M + acc_row(r, lane)) * PJ + 32 * (nb + nt) + i] = ds[nt][r];
             }
+        }
     }
     // per-tile partials on the matrix cores: dM_t[j][c] = sum_i Srow[i][j] dq2c[i][c] ; dQa_t[j][c] = sum_i Srow[i][j] dc2q[i][c]
     {
@@ -1376,7 +1378,7 @@ __global__ __launch_bounds__(256) void k_cq_bwd_b(CqBwdArgs a) {
     for (int e = tid; e < (32 * NTJ - Lq) * (D / 4); e += 256)         // zero rows Lq .. 32 NTJ - 1 (B operand of the padded tile)
         *reinterpret_cast<float4*>(dMs + (Lq + (e >> 5)) * LDP + (e & 31) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
-    {   // dS_col[i][j] = C[i] . dM[j]: 32 x 32 MFMA tile per 32 query words, K = 128 split over the waves
+    for (int nb = 0; nb < NTJ; nb += 2) {   // dS_col[i][j] = C[i] . dM[j]: 32 x 32 MFMA tile per 32 query words, K = 128 split over the waves
         f32x16 acc[2];
         zero_acc(acc);
         const int i = lane & 31;
@@ -1387,8 +1389,8 @@ __global__ __launch_bounds__(256) void k_cq_bwd_b(CqBwdArgs a) {
             const float4 av = *reinterpret_cast<const float4*>(arow + kb * 8);
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                if (nt < NTJ) {
-                    const float4 bv = *reinterpret_cast<const float4*>(dMs + (32 * nt + i) * LDP + kb * 8 + 4 * hh);
+                if (nb + nt < NTJ) {
+                    const float4 bv = *reinterpret_cast<const float4*>(dMs + (32 * (nb + nt) + i) * LDP + kb * 8 + 4 * hh);
                     acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[nt], 0, 0, 0);
                     acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[nt], 0, 0, 0);
                     acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[nt], 0, 0, 0);
@@ -1398,9 +1400,9 @@ __global__ __launch_bounds__(256) void k_cq_bwd_b(CqBwdArgs a) {
         }
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
-            if (nt < NTJ) {
+            if (nb + nt < NTJ) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) Pp[(w * TILE_M + acc_row(r, lane)) * PJ + 32 * nt + i] = acc[nt][r];
+                for (int r = 0; r < 16; ++r) Pp[(w * TILE_M + acc_row(r, lane)) * PJ + 32 * (nb + nt) + i] = acc[nt][r];
             }
     }
     __syncthreads();

@@ -156,7 +156,7 @@ void launch_vproj_fwd(const float* X, const float* Wpack, const float* bias, flo
 //               at a time, no predicates in the inner loop.  Requires 4 <= Lc <= MAX_LC.
 // =========================================================================================================
 constexpr int EF_CHUNK = 8;
-constexpr int EF_PT = 28;                   // padded positions per (word, ci) row: MAX_LC + 3 taps, multiple of 4
+constexpr int EF_PT = MAX_LC + 4;           // padded positions per (word, ci) row: MAX_LC + 3 taps, multiple of 4
 __global__ __launch_bounds__(512) void k_embed_fwd(const int64_t* __restrict__ word_ids, const int64_t* __restrict__ char_ids,
                                                    const float* __restrict__ pad_vec, const float* __restrict__ unk_vec,
                                                    const float* __restrict__ glove, const float* __restrict__ char_tab,
@@ -794,8 +794,8 @@ __global__ __launch_bounds__(256) void k_cq_score(const float* __restrict__ C, c
     float* Cs = smem;                         // [32][LDP]  Cd, then Cd * w4mlu
     float* Qs = Cs + TILE_M * LDP;            // [32 NTJ][LDP]  Qd (rows >= Lq zero)
     float* s0 = Qs + 32 * NTJ * LDP;          // [32]
-    float* s1 = s0 + TILE_M;                  // [64]
-    float* Pp = s1 + 64;                      // [4][32][PJ] per-wave partial tiles
+    float* s1 = s0 + TILE_M;                  // [32 NTJ]
+    float* Pp = s1 + 32 * NTJ;                // [4][32][PJ] per-wave partial tiles
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, hh = lane >> 5;
     const int b = blockIdx.y, t0 = blockIdx.x * TILE_M;
     const size_t crow = (size_t)b * T, qrow = (size_t)b * Lq;
@@ -807,12 +807,32 @@ __global__ __launch_bounds__(256) void k_cq_score(const float* __restrict__ C, c
             const int t = min(t0 + rr, T - 1);
             cv[q] = *reinterpret_cast<const float4*>(C + (crow + t) * D + c);
         }
+        auto load_q = [&](int q0) {               // query rows 8 q0 .. : 8 float4 per thread (64 words) per pass
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int e = tid + q * 256, j = e >> 5, c = (e & 31) * 4;
-            qv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (q < 4 * NTJ) qv[q] = *reinterpret_cast<const float4*>(Qf + (qrow + min(j, Lq - 1)) * D + c);
-        }
+            for (int q = 0; q < 8; ++q) {
+                const int e = tid + (q0 + q) * 256, j = e >> 5, c = (e & 31) * 4;
+                qv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (q0 + q < 4 * NTJ) qv[q] = *reinterpret_cast<const float4*>(Qf + (qrow + min(j, Lq - 1)) * D + c);
+            }
+        };
+        auto store_q = [&](int q0) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (q0 + q < 4 * NTJ) {
+                    const int e = tid + (q0 + q) * 256, j = e >> 5, c = (e & 31) * 4;
+                    float4 v = qv[q];
+                    if (j < Lq) {
+                        if (dq.thresh) {
+                            const uint32_t base = (uint32_t)(((b + b_off) * Lq + j) * D + c);
+                            v.x *= drop_keep_scale(dq, base); v.y *= drop_keep_scale(dq, base + 1);
+                            v.z *= drop_keep_scale(dq, base + 2); v.w *= drop_keep_scale(dq, base + 3);
+                        }
+                    } else v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    *reinterpret_cast<float4*>(&Qs[j * LDP + c]) = v;
+                }
+            }
+        };
+        load_q(0);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int e = tid + q * 256, rr = e >> 5, c = (e & 31) * 4;
@@ -827,21 +847,8 @@ __global__ __launch_bounds__(256) void k_cq_score(const float* __restrict__ C, c
             } else v = make_float4(0.f, 0.f, 0.f, 0.f);
             *reinterpret_cast<float4*>(&Cs[rr * LDP + c]) = v;
         }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            if (q < 4 * NTJ) {
-                const int e = tid + q * 256, j = e >> 5, c = (e & 31) * 4;
-                float4 v = qv[q];
-                if (j < Lq) {
-                    if (dq.thresh) {
-                        const uint32_t base = (uint32_t)(((b + b_off) * Lq + j) * D + c);
-                        v.x *= drop_keep_scale(dq, base); v.y *= drop_keep_scale(dq, base + 1);
-                        v.z *= drop_keep_scale(dq, base + 2); v.w *= drop_keep_scale(dq, base + 3);
-                    }
-                } else v = make_float4(0.f, 0.f, 0.f, 0.f);
-                *reinterpret_cast<float4*>(&Qs[j * LDP + c]) = v;
-            }
-        }
+        store_q(0);
+        for (int q0 = 8; q0 < 4 * NTJ; q0 += 8) { load_q(q0); store_q(q0); }     // queries beyond 64 words (ActivityNet: up to 82)
     }
     __syncthreads();
     {   // s0[i] = Cd[i] . w4C ; s1[j] = Qd[j] . w4Q ; then Cd *= w4mlu in place.  8 lanes per row, 32 rows per pass.
@@ -877,7 +884,7 @@ __global__ __launch_bounds__(256) void k_cq_score(const float* __restrict__ C, c
         }
     }
     __syncthreads();
-    {   // trilinear term: wave w contracts channels 32w .. 32w+31
+    for (int nb = 0; nb < NTJ; nb += 2) {   // trilinear term: wave w contracts channels 32w .. 32w+31 ; two 32-word tiles per pass
         f32x16 acc[2];
         zero_acc(acc);
         const int i = lane & 31;
@@ -888,8 +895,8 @@ __global__ __launch_bounds__(256) void k_cq_score(const float* __restrict__ C, c
             const float4 av = *reinterpret_cast<const float4*>(arow + kb * 8);
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                if (nt < NTJ) {
-                    const float4 bv = *reinterpret_cast<const float4*>(Qs + (32 * nt + i) * LDP + kb * 8 + 4 * hh);
+                if (nb + nt < NTJ) {
+                    const float4 bv = *reinterpret_cast<const float4*>(Qs + (32 * (nb + nt) + i) * LDP + kb * 8 + 4 * hh);
                     acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[nt], 0, 0, 0);
                     acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[nt], 0, 0, 0);
                     acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[nt], 0, 0, 0);
@@ -899,19 +906,20 @@ __global__ __launch_bounds__(256) void k_cq_score(const float* __restrict__ C, c
         }
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
-            if (nt < NTJ) {
+            if (nb + nt < NTJ) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) Pp[(w * TILE_M + acc_row(r, lane)) * PJ + 32 * nt + i] = acc[nt][r];
+                for (int r = 0; r < 16; ++r) Pp[(w * TILE_M + acc_row(r, lane)) * PJ + 32 * (nb + nt) + i] = acc[nt][r];
             }
     }
     __syncthreads();
     {   // raw score + row softmax over the query words (dim=2, :225) with the query mask; 8 lanes per clip
         const int sub = tid & 7, rr = tid >> 3;
         const int t = t0 + rr;
-        float raw[8], v[8];
+        constexpr int NU = MAX_LQ / 8;            // words per lane
+        float raw[NU], v[NU];
         float mx = -3.0e38f;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < NU; ++u) {
             const int j = sub + 8 * u;
             raw[u] = 0.f; v[u] = -3.0e38f;
             if (j < Lq) {
@@ -924,11 +932,11 @@ __global__ __launch_bounds__(256) void k_cq_score(const float* __restrict__ C, c
         mx = fmaxf(mx, __shfl_xor(mx, 1)); mx = fmaxf(mx, __shfl_xor(mx, 2)); mx = fmaxf(mx, __shfl_xor(mx, 4));
         float sm = 0.f;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { v[u] = (sub + 8 * u < Lq) ? __expf(v[u] - mx) : 0.f; sm += v[u]; }
+        for (int u = 0; u < NU; ++u) { v[u] = (sub + 8 * u < Lq) ? __expf(v[u] - mx) : 0.f; sm += v[u]; }
         const float inv = 1.0f / grp8_sum(sm);
         if (t < T) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < NU; ++u) {
                 const int j = sub + 8 * u;
                 if (j < Lq) { S[(crow + t) * Lq + j] = raw[u]; Srow[(crow + t) * Lq + j] = v[u] * inv; }
             }
@@ -939,7 +947,7 @@ void launch_cq_score(const float* C, const float* Qf, const float* qmask, const 
                      const float* w4mlu, float* S, float* Srow, int B, int T, int Lq, int b_off, Drop dc, Drop dq,
                      hipStream_t s) {
     const int NTJ = (Lq + 31) / 32;
-    const size_t shm = (size_t)((TILE_M + 32 * NTJ) * LDP + TILE_M + 64 + 4 * TILE_M * (32 * NTJ + 1)) * sizeof(float);
+    const size_t shm = (size_t)((TILE_M + 32 * NTJ) * LDP + TILE_M + 32 * NTJ + 4 * TILE_M * (32 * NTJ + 1)) * sizeof(float);
     static size_t lds_ok = 0;
     ensure_dynamic_lds((const void*)k_cq_score, shm, lds_ok, "k_cq_score");
     hipLaunchKernelGGL(k_cq_score, dim3((T + TILE_M - 1) / TILE_M, B), dim3(256), shm, s, C, Qf, qmask, w4C, w4Q, w4mlu, S,
@@ -960,36 +968,37 @@ __global__ __launch_bounds__(256) void k_cq_col(const float* __restrict__ C, con
     const int LQ1 = Lq + 1;
     float* Cs = smem;                         // [32][LDP]  C tile
     float* Ss = Cs + TILE_M * LDP;            // [32][LQ1]  S_col tile (+ slack for the 32-wide over-read of gemm_tn)
-    float* redm = Ss + TILE_M * LQ1 + 72;     // [8][64] partial column maxima
-    float* reds = redm + 8 * 64;              // [8][64] partial column sums
-    float* cmax = reds + 8 * 64;              // [64]
-    float* cinv = cmax + 64;                  // [64]
-    float* al = cinv + 64;                    // [64]
-    float* pl = al + 64;                      // [128]
+    constexpr int JS = 128;                   // word stride of the statistics arrays (Lq <= MAX_LQ <= 128)
+    float* redm = Ss + TILE_M * LQ1 + 72;     // [8][JS] partial column maxima
+    float* reds = redm + 8 * JS;              // [8][JS] partial column sums
+    float* cmax = reds + 8 * JS;              // [JS]
+    float* cinv = cmax + JS;                  // [JS]
+    float* al = cinv + JS;                    // [JS]
+    float* pl = al + JS;                      // [128]
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int b = blockIdx.y, tl = blockIdx.x, t0 = tl * TILE_M, ntile = gridDim.x;
     const size_t crow = (size_t)b * T, qrow = (size_t)b * Lq;
     load_tile128(Cs, C + crow * D, t0, TILE_M, T);
     // ---- column statistics over all T clips: thread = (word j, part); a part walks clips part, part + np, ...
-    const int JW = Lq <= 32 ? 32 : 64, np = 256 / JW;
+    const int JW = Lq <= 32 ? 32 : Lq <= 64 ? 64 : 128, np = 256 / JW;
     const int j = tid & (JW - 1), part = tid / JW;
     {
         float mx = -3.0e38f;
         if (j < Lq) for (int i = part; i < T; i += np) mx = fmaxf(mx, S[(crow + i) * Lq + j] + (1.f - cmask[crow + i]) * MASK_VALUE);
-        redm[part * 64 + j] = mx;
+        redm[part * JS + j] = mx;
     }
     __syncthreads();
     float gm = -3.0e38f;
-    for (int q = 0; q < np; ++q) gm = fmaxf(gm, redm[q * 64 + j]);
+    for (int q = 0; q < np; ++q) gm = fmaxf(gm, redm[q * JS + j]);
     {
         float sm = 0.f;
         if (j < Lq) for (int i = part; i < T; i += np) sm += __expf(S[(crow + i) * Lq + j] + (1.f - cmask[crow + i]) * MASK_VALUE - gm);
-        reds[part * 64 + j] = sm;
+        reds[part * JS + j] = sm;
     }
     __syncthreads();
     if (tid < JW) {
         float sm = 0.f;
-        for (int q = 0; q < np; ++q) sm += reds[q * 64 + j];
+        for (int q = 0; q < np; ++q) sm += reds[q * JS + j];
         cmax[j] = gm;
         cinv[j] = 1.0f / sm;
     }
@@ -1031,12 +1040,13 @@ __global__ __launch_bounds__(256) void k_cq_col(const float* __restrict__ C, con
         if (lane == 0) al[jj] = d + (1.f - qmask[qrow + jj]) * MASK_VALUE;
     }
     __syncthreads();
-    if (w == 0) {
-        const float v0 = lane < Lq ? al[lane] : -3.0e38f;
-        const float mx = wave_max(v0);
-        const float e0 = lane < Lq ? __expf(v0 - mx) : 0.f;
-        const float inv = 1.0f / wave_sum(e0);
+    if (w == 0) {                              // a lane owns words lane and lane + 64
+        const float v0 = lane < Lq ? al[lane] : -3.0e38f, v1 = lane + 64 < Lq ? al[lane + 64] : -3.0e38f;
+        const float mx = wave_max(fmaxf(v0, v1));
+        const float e0 = lane < Lq ? __expf(v0 - mx) : 0.f, e1 = lane + 64 < Lq ? __expf(v1 - mx) : 0.f;
+        const float inv = 1.0f / wave_sum(e0 + e1);
         if (lane < Lq) { al[lane] = e0 * inv; alpha[qrow + lane] = e0 * inv; }
+        if (lane + 64 < Lq) { al[lane + 64] = e1 * inv; alpha[qrow + lane + 64] = e1 * inv; }
     }
     __syncthreads();
     if (tid < D) {
@@ -1064,7 +1074,7 @@ __global__ __launch_bounds__(256) void k_cq_col(const float* __restrict__ C, con
 void launch_cq_col(const float* C, const float* Qf, const float* S, const float* cmask, const float* qmask,
                    const float* pool_w, const float* Wcat, const float* bcat, float* Scol, float* Mpart, float* alpha,
                    float* pooled, float* pb, int B, int T, int Lq, hipStream_t s) {
-    const size_t shm = (size_t)(TILE_M * LDP + TILE_M * (Lq + 1) + 72 + 2 * 8 * 64 + 3 * 64 + D) * sizeof(float);
+    const size_t shm = (size_t)(TILE_M * LDP + TILE_M * (Lq + 1) + 72 + 2 * 8 * 128 + 3 * 128 + D) * sizeof(float);
     hipLaunchKernelGGL(k_cq_col, dim3((T + TILE_M - 1) / TILE_M, B), dim3(256), shm, s, C, Qf, S, cmask, qmask, pool_w, Wcat, bcat, Scol,
                        Mpart, alpha, pooled, pb, T, Lq);
 }

@@ -138,7 +138,7 @@ class Engine:
         for i in range(self.lib.vsl_param_count(h)):
             self._call(self.lib.vsl_param_info(h, i, name, 256, C.byref(off), C.byref(num), C.byref(nd), dims))
             self.layout.append((name.value.decode(), off.value, num.value, tuple(dims[j] for j in range(nd.value))))
-        self._ws = {}
+        self._ws, self._grown = None, False
         self._last = None
 
     def __del__(self):
@@ -163,13 +163,17 @@ class Engine:
         return {n: flat[o:o + k].view(shp) for n, o, k, shp in self.layout}
 
     def workspace(self, B, T, Lq, Lc):
-        key = (B, T, Lq, Lc)
-        if key not in self._ws:
-            n = C.c_int64()
-            with torch.cuda.device(self.device):
-                self._call(self.lib.vsl_workspace_floats(self.h, B, T, Lq, Lc, C.byref(n)))
-            self._ws[key] = torch.empty(n.value, dtype=torch.float32, device=self.device)
-        return self._ws[key]
+        """ONE caller-owned workspace, grown to the largest shape seen: its contents only live from a forward to the
+        backward of the same batch, and the collate narrows every batch to its own max T / Lq / Lc, so real-data training
+        visits hundreds of shapes -- a workspace per shape would grow without bound beside the HBM-resident dataset."""
+        n = C.c_int64()
+        with torch.cuda.device(self.device):
+            self._call(self.lib.vsl_workspace_floats(self.h, B, T, Lq, Lc, C.byref(n)))
+        if self._ws is None or self._ws.numel() < n.value:
+            self._ws = None                                  # drop the old one first (the last forward may still hold it)
+            self._ws = torch.empty(int(n.value * 1.25) if self._grown else n.value, dtype=torch.float32, device=self.device)
+            self._grown = True
+        return self._ws
 
     def ws_view(self, name, shape):
         """Saved activation `name` of the LAST forward as a tensor view (parity tests)."""
