@@ -156,17 +156,20 @@ void launch_vproj_fwd(const float* X, const float* Wpack, const float* bias, flo
 //               at a time, no predicates in the inner loop.  Requires 4 <= Lc <= MAX_LC.
 // =========================================================================================================
 constexpr int EF_CHUNK = 8;
-constexpr int EF_PT = MAX_LC + 4;           // padded positions per (word, ci) row: MAX_LC + 3 taps, multiple of 4
+// LCM = compile-time bound of Lc (24 covers Charades / TACoS words; 40 the longest ActivityNet tokens): EF_PT = LCM + 4 padded
+// positions per (word, ci) row (LCM + 3 taps, multiple of 4)
+template <int LCM>
 __global__ __launch_bounds__(512) void k_embed_fwd(const int64_t* __restrict__ word_ids, const int64_t* __restrict__ char_ids,
                                                    const float* __restrict__ pad_vec, const float* __restrict__ unk_vec,
                                                    const float* __restrict__ glove, const float* __restrict__ char_tab,
                                                    CharConvPtrs cc, const float* __restrict__ wimg, float* __restrict__ E,
                                                    int8_t* __restrict__ argpos, int Rq, int Lc, int word_dim, int char_dim,
                                                    Drop dw, Drop dc) {
+    constexpr int EF_PT = LCM + 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Wt = smem;                                   // [char_dim][4 taps][100 channels], taps beyond a channel's width = 0
     float* CeT = Wt + char_dim * 400;                   // [EF_CHUNK][char_dim][EF_PT]
-    __shared__ int cids[EF_CHUNK * MAX_LC];
+    __shared__ int cids[EF_CHUNK * LCM];
     const int tid = threadIdx.x, NT = blockDim.x;      // 512 threads: two waves per SIMD hide the LDS latency of the item loop
     const int EW = word_dim + 100;
     const int rbeg = blockIdx.x * EF_CHUNK, nw = min(EF_CHUNK, Rq - rbeg);
@@ -186,8 +189,8 @@ __global__ __launch_bounds__(512) void k_embed_fwd(const int64_t* __restrict__ w
     }
     FSTAMP(1);
     // ---- char ids, then the transposed dropped-out embeddings (zero beyond Lc and beyond the chunk)
-    for (int e = tid; e < EF_CHUNK * MAX_LC; e += NT) {
-        const int wi = e / MAX_LC, pp = e - wi * MAX_LC;
+    for (int e = tid; e < EF_CHUNK * LCM; e += NT) {
+        const int wi = e / LCM, pp = e - wi * LCM;
         cids[e] = (wi < nw && pp < Lc) ? (int)char_ids[(size_t)(rbeg + wi) * Lc + pp] : 0;
     }
     // ---- word vectors (independent of the above)
@@ -203,15 +206,15 @@ __global__ __launch_bounds__(512) void k_embed_fwd(const int64_t* __restrict__ w
     for (int pr = tid; pr < EF_CHUNK * char_dim; pr += NT) {         // pair (word, ci): one padded row of EF_PT positions
         const int wi = pr / char_dim, ci = pr - wi * char_dim;
         float* row = CeT + pr * EF_PT;
-        float v[MAX_LC];
+        float v[LCM];
 #pragma unroll
-        for (int pp = 0; pp < MAX_LC; ++pp)                            // all gathers of the row issued together
-            v[pp] = (wi < nw && pp < Lc) ? char_tab[(size_t)cids[wi * MAX_LC + pp] * char_dim + ci] : 0.f;
+        for (int pp = 0; pp < LCM; ++pp)                            // all gathers of the row issued together
+            v[pp] = (wi < nw && pp < Lc) ? char_tab[(size_t)cids[wi * LCM + pp] * char_dim + ci] : 0.f;
 #pragma unroll
-        for (int pp = 0; pp < MAX_LC; ++pp)
+        for (int pp = 0; pp < LCM; ++pp)
             row[pp] = (pp < Lc) ? v[pp] * drop_mul(dc, (uint32_t)(((rbeg + wi) * Lc + pp) * char_dim + ci)) : 0.f;
 #pragma unroll
-        for (int pp = MAX_LC; pp < EF_PT; ++pp) row[pp] = 0.f;
+        for (int pp = LCM; pp < EF_PT; ++pp) row[pp] = 0.f;
     }
     __syncthreads();
     FSTAMP(3);
@@ -302,11 +305,19 @@ __global__ __launch_bounds__(512) void k_embed_fwd(const int64_t* __restrict__ w
 void launch_embed_fwd(const int64_t* word_ids, const int64_t* char_ids, const float* pad_vec, const float* unk_vec,
                       const float* glove, const float* char_tab, CharConvPtrs cc, const float* wimg, float* E, int8_t* argpos,
                       int Rq, int Lc, int word_dim, int char_dim, Drop dw, Drop dc, hipStream_t s) {
-    const size_t shm = (size_t)(char_dim * 400 + EF_CHUNK * char_dim * EF_PT + 32) * sizeof(float);   // + slack: invalid positions over-read
-    static size_t lds_ok = 0;
-    ensure_dynamic_lds((const void*)k_embed_fwd, shm, lds_ok, "k_embed_fwd");
-    hipLaunchKernelGGL(k_embed_fwd, dim3((Rq + EF_CHUNK - 1) / EF_CHUNK), dim3(512), shm, s, word_ids, char_ids, pad_vec, unk_vec,
-                       glove, char_tab, cc, wimg, E, argpos, Rq, Lc, word_dim, char_dim, dw, dc);
+    const int lcm = Lc <= 24 ? 24 : MAX_LC;
+    const size_t shm = (size_t)(char_dim * 400 + EF_CHUNK * char_dim * (lcm + 4) + 32) * sizeof(float);   // + slack: invalid positions over-read
+    static size_t ok24 = 0, ok40 = 0;
+    const dim3 grid((Rq + EF_CHUNK - 1) / EF_CHUNK);
+    if (lcm == 24) {
+        ensure_dynamic_lds((const void*)k_embed_fwd<24>, shm, ok24, "k_embed_fwd<24>");
+        hipLaunchKernelGGL(k_embed_fwd<24>, grid, dim3(512), shm, s, word_ids, char_ids, pad_vec, unk_vec, glove, char_tab, cc, wimg, E,
+                           argpos, Rq, Lc, word_dim, char_dim, dw, dc);
+    } else {
+        ensure_dynamic_lds((const void*)k_embed_fwd<MAX_LC>, shm, ok40, "k_embed_fwd<40>");
+        hipLaunchKernelGGL(k_embed_fwd<MAX_LC>, grid, dim3(512), shm, s, word_ids, char_ids, pad_vec, unk_vec, glove, char_tab, cc, wimg,
+                           E, argpos, Rq, Lc, word_dim, char_dim, dw, dc);
+    }
     static int left = 2;
     if (fdbg_on()) fdbg_report("embed_fwd: weights | ids+words | CeT | items", 5, s, left);
 }
@@ -781,6 +792,7 @@ void launch_attn_out_fwd(const float* att, const float* x, const float* ln_g, co
 //      plus a11's WeightedPool (:253-259) and the per-sample bias  pb = W2 pooled + b  of CQConcatenate (:268-274).
 //  (3) k_cq_out  : c2q = S_row Q, q2c = S_row M, concat [C, c2q, C*c2q, C*q2c] (:231) -> Conv1D 4d->d (:232).
 // =========================================================================================================
+template <int NU>   // words per lane of the row softmax: 8 (Lq <= 64) or MAX_LQ / 8
 __global__ __launch_bounds__(256) void k_cq_score(const float* __restrict__ C, const float* __restrict__ Qf,
                                                   const float* __restrict__ qmask, const float* __restrict__ w4C,
                                                   const float* __restrict__ w4Q, const float* __restrict__ w4mlu,
@@ -915,7 +927,6 @@ __global__ __launch_bounds__(256) void k_cq_score(const float* __restrict__ C, c
     {   // raw score + row softmax over the query words (dim=2, :225) with the query mask; 8 lanes per clip
         const int sub = tid & 7, rr = tid >> 3;
         const int t = t0 + rr;
-        constexpr int NU = MAX_LQ / 8;            // words per lane
         float raw[NU], v[NU];
         float mx = -3.0e38f;
 #pragma unroll
@@ -948,10 +959,15 @@ void launch_cq_score(const float* C, const float* Qf, const float* qmask, const 
                      hipStream_t s) {
     const int NTJ = (Lq + 31) / 32;
     const size_t shm = (size_t)((TILE_M + 32 * NTJ) * LDP + TILE_M + 32 * NTJ + 4 * TILE_M * (32 * NTJ + 1)) * sizeof(float);
-    static size_t lds_ok = 0;
-    ensure_dynamic_lds((const void*)k_cq_score, shm, lds_ok, "k_cq_score");
-    hipLaunchKernelGGL(k_cq_score, dim3((T + TILE_M - 1) / TILE_M, B), dim3(256), shm, s, C, Qf, qmask, w4C, w4Q, w4mlu, S,
-                       Srow, T, Lq, b_off, dc, dq);
+    static size_t ok8 = 0, okn = 0;
+    const dim3 grid((T + TILE_M - 1) / TILE_M, B);
+    if (Lq <= 64) {
+        ensure_dynamic_lds((const void*)k_cq_score<8>, shm, ok8, "k_cq_score<8>");
+        hipLaunchKernelGGL(k_cq_score<8>, grid, dim3(256), shm, s, C, Qf, qmask, w4C, w4Q, w4mlu, S, Srow, T, Lq, b_off, dc, dq);
+    } else {
+        ensure_dynamic_lds((const void*)k_cq_score<MAX_LQ / 8>, shm, okn, "k_cq_score<12>");
+        hipLaunchKernelGGL(k_cq_score<MAX_LQ / 8>, grid, dim3(256), shm, s, C, Qf, qmask, w4C, w4Q, w4mlu, S, Srow, T, Lq, b_off, dc, dq);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_cq_col(const float* __restrict__ C, const float* __restrict__ Qf,
