@@ -206,10 +206,41 @@ def run_host_pipeline(ru, dl):
     print('host_pipeline written', os.path.getsize(path) // 1024, 'KiB')
 
 
+INIT_SEED = 777
+
+
+def sd_checksums(sd):
+    """per-tensor (sum, abs-sum, last element) in float64: what the fixtures keep of a state_dict"""
+    out = {}
+    for k, v in sd.items():
+        v64 = v.detach().double()
+        out[k] = np.array([float(v64.sum()), float(v64.abs().sum()), float(v64.flatten()[-1])])
+    return out
+
+
+def run_init(VSLNet):
+    """a19 (VSLNet_t7.py:42-50): the reference constructed under torch.manual_seed(INIT_SEED) -- checksums of its freshly
+    initialised state_dict for both predictor heads.  The build's module must reproduce them bit for bit under the same seed."""
+    out = {'seed': np.int64(INIT_SEED)}
+    for pred in ('transformer', 'rnn'):
+        cfg = O.make_cfg(video_feature_dim=64, max_pos_len=32, word_size=52, predictor=pred)
+        glove = np.random.RandomState(0).randn(cfg.word_size - 2, cfg.word_dim).astype(np.float32)
+        torch.manual_seed(INIT_SEED)
+        sd = VSLNet(configs=cfg, word_vectors=glove).state_dict()
+        out['keys.' + pred] = np.array(list(sd.keys()))
+        for k, c in sd_checksums(sd).items():
+            out['%s.%s' % (pred, k)] = c
+    np.savez_compressed(os.path.join(ROOT, 'tests', 'golden', 'init.npz'), **out)
+    print('init.npz written')
+
+
 def main():
     VSLNet, ru, dl = load_reference()
     if len(sys.argv) > 1 and sys.argv[1] == 'host_pipeline':
         run_host_pipeline(ru, dl)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'init':
+        run_init(VSLNet)
         return
     os.makedirs(os.path.join(ROOT, 'tests', 'golden'), exist_ok=True)
     torch.set_num_threads(8)
@@ -217,6 +248,7 @@ def main():
         run_case(VSLNet, name, spec)
     run_host_helpers(ru, dl)
     run_host_pipeline(ru, dl)
+    run_init(VSLNet)
 
 
 if __name__ == '__main__':

@@ -107,3 +107,33 @@ def test_host_helpers_against_reference():
     assert np.array_equal(O.convert_length_to_mask(lens).numpy(), z['mask'])
     h = O.highlight_labels(z['s_labels'], z['e_labels'], z['vlens'], int(z['vlens'].max()))
     assert np.array_equal(h.numpy(), z['h_labels'])
+
+
+def test_init_matches_reference_under_the_same_seed():
+    """a19 (VSLNet_t7.py:42-50): tests/golden/init.npz holds checksums of the reference's freshly initialised state_dict
+    (constructed under torch.manual_seed; oracle/make_golden.py run_init).  The build's module -- same sub-module order, same
+    initialisers, LSTM.reset_parameters() for the rnn head -- must reproduce every tensor bit for bit under the same seed."""
+    import os
+    from tests.helpers import GOLDEN
+    from vslnet_amd.model.VSLNet import VSLNet
+    z = np.load(os.path.join(GOLDEN, 'init.npz'), allow_pickle=False)
+    for pred in ('transformer', 'rnn'):
+        cfg = O.make_cfg(video_feature_dim=64, max_pos_len=32, word_size=52, predictor=pred)
+        glove = np.random.RandomState(0).randn(cfg.word_size - 2, cfg.word_dim).astype(np.float32)
+        torch.manual_seed(int(z['seed']))
+        sd = VSLNet(cfg, glove).state_dict()
+        assert list(sd.keys()) == [str(k) for k in z['keys.' + pred]]
+        for k, v in sd.items():
+            v64 = v.detach().double()
+            got = np.array([float(v64.sum()), float(v64.abs().sum()), float(v64.flatten()[-1])])
+            assert np.array_equal(got, z['%s.%s' % (pred, k)]), (pred, k, got, z['%s.%s' % (pred, k)])
+
+
+def test_untrained_word_table_branch_fails_loudly():
+    """layers_t7.py:36-37 (word_vectors=None -> trainable nn.Embedding) is the one constructor branch the HIP path does not
+    implement (main_t7.py:83 always passes GloVe): it must say so instead of building a model that cannot run."""
+    import pytest
+    from vslnet_amd.model.VSLNet import VSLNet
+    cfg = O.make_cfg(video_feature_dim=64, max_pos_len=32, word_size=52)
+    with pytest.raises(NotImplementedError, match='layers_t7.py:36-37'):
+        VSLNet(cfg, None)

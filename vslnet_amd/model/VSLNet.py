@@ -106,12 +106,16 @@ class VSLNet(nn.Module):
         self._seed = int(getattr(configs, 'seed', 12345))
 
     def init_parameters(self):
-        """VSLNet_t7.py:42-50: Xavier-uniform conv/linear weights, zero biases."""
+        """VSLNet_t7.py:42-50: Xavier-uniform conv/linear weights, zero biases, nn.LSTM.reset_parameters() for the rnn head.
+        Same module order and the same initialisers as the reference, so the same torch seed gives bit-identical weights
+        (pinned by tests/test_oracle_golden.py::test_init_matches_reference_under_the_same_seed)."""
         def init_weights(m):
             if isinstance(m, (nn.Conv2d, nn.Conv1d, nn.Linear)):
                 nn.init.xavier_uniform_(m.weight)
                 if m.bias is not None:
                     nn.init.zeros_(m.bias)
+            elif isinstance(m, nn.LSTM):
+                m.reset_parameters()
         self.apply(init_weights)
 
     # ---- flat parameter bucket ------------------------------------------------------------------------------------

@@ -36,7 +36,11 @@ class WordEmbedding(_Fused):
     def __init__(self, num_words, word_dim, drop_rate, word_vectors=None):
         super().__init__()
         if word_vectors is None:
-            raise NotImplementedError('the HIP path implements the pretrained (GloVe) WordEmbedding branch only')
+            # layers_t7.py:36-37, 43-44: a fully trainable nn.Embedding(num_words, word_dim).  main_t7.py:83 always passes the
+            # GloVe matrix, so the HIP embedding kernels cover the [pad; unk; glove] table only (gradient to unk_vec alone).
+            raise NotImplementedError('VSLNet(word_vectors=None): the trainable-word-table branch of WordEmbedding '
+                                      '(layers_t7.py:36-37) is not implemented by the HIP path; pass the GloVe matrix '
+                                      '(main_t7.py:83 always does)')
         self.is_pretrained = True
         self.pad_vec = nn.Parameter(torch.zeros(1, word_dim), requires_grad=False)
         unk = torch.empty(1, word_dim)
