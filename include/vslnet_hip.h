@@ -127,6 +127,10 @@ int vsl_extract_index(vsl_handle h, const float* start_logits, const float* end_
 typedef struct {
     float lr, beta1, beta2, eps, weight_decay, clip_norm;
     int32_t step;
+    /* 0: torch.optim.AdamW ordering (above).  1: the historical transformers.AdamW the reference was written against
+     * (VSLNet_t7.py:5,14; class removed from transformers 5.x, semantics from its published source):
+     *     p -= lr * sqrt(1 - b2^t) / (1 - b1^t) * m / (sqrt(v) + eps) ;  then  p -= lr * weight_decay[param] * p          */
+    int32_t hf_order;
 } vsl_adamw;
 int vsl_adamw_step(vsl_handle h, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                    const vsl_adamw* hp, float* grad_norm_out, void* hip_stream);

@@ -64,7 +64,8 @@ def build_parser():
     p.add_argument('--init_lr', type=float, default=0.0001)
     p.add_argument('--clip_norm', type=float, default=1.0)
     p.add_argument('--warmup_proportion', type=float, default=0.0)
-    p.add_argument('--extend', type=float, default=0.1)
+    p.add_argument('--extend', type=float, default=0.1, help='accepted and ignored: the reference collate hard-codes 0.1 (data_loader_t7.py:42)')
+    p.add_argument('--adamw', default='torch', choices=('torch', 'hf'), help="update ordering of the fused optimizer: torch.optim.AdamW, or the historical transformers.AdamW the reference imports")
     p.add_argument('--period', type=int, default=100)
     p.add_argument('--model_dir', type=str, default='ckpt_t7')
     p.add_argument('--model_name', type=str, default='vslnet')
@@ -124,7 +125,8 @@ def train(configs, dataset, features, device, world, rank, log=print):
         flat, grads = model.flat_parameters
         eng = model._engine
         opt = dp.FlatAdamW(flat, eng.layout, lr=configs.init_lr, num_train_steps=configs.num_train_steps,
-                           warmup_proportion=configs.warmup_proportion, clip_norm=configs.clip_norm, engine=eng)
+                           warmup_proportion=configs.warmup_proportion, clip_norm=configs.clip_norm, engine=eng,
+                           hf_order=configs.adamw == 'hf')
         pad_vec, glove_vec = model.embedding_net.word_emb.pad_vec.data, model.embedding_net.word_emb.glove_vec.data
     else:
         optimizer, scheduler = build_optimizer_and_scheduler(model, configs)

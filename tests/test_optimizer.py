@@ -95,3 +95,59 @@ def test_fused_adamw_kernels_match_torch_optim():
         assert torch.allclose(out[nm].cpu(), ref[nm].data, rtol=2e-5, atol=1e-7), nm
     with pytest.raises(Exception):
         eng.adamw_step(flat, grads_seq[0].cuda(), opt.m, opt.v, 1e-3, 0)               # step must be >= 1
+
+
+def _hf_adamw_steps(P, layout, grads_seq, lr0, total, eps=1e-6, wd=0.01, clip=1.0):
+    """The historical transformers.AdamW (the class VSLNet_t7.py:5 imports; removed from transformers 5.x), restated from its
+    published source, per parameter, in float64: exp_avg / exp_avg_sq update, step_size = lr * sqrt(1 - b2^t) / (1 - b1^t),
+    p -= step_size * m / (sqrt(v) + eps), THEN p -= lr * wd * p; decay skipped for names with bias / layer_norm / LayerNorm
+    (VSLNet_t7.py:9-13); clip_grad_norm_(1.0) first (main_t7.py:111); linear decay of lr (VSLNet_t7.py:15-16)."""
+    p = {n: P[n].double().clone() for n, _, _, _ in layout}
+    m = {n: torch.zeros_like(v) for n, v in p.items()}
+    v2 = {n: torch.zeros_like(v) for n, v in p.items()}
+    for t, g in enumerate(grads_seq, 1):
+        lr = lr0 * (total - (t - 1)) / total
+        g = g.double()
+        coef = min(1.0, clip / (float(g.norm()) + 1e-6))
+        for n, o, k, shp in layout:
+            ge = g[o:o + k].view(shp) * coef
+            m[n].mul_(0.9).add_(ge, alpha=0.1)
+            v2[n].mul_(0.999).addcmul_(ge, ge, value=0.001)
+            step = lr * (1 - 0.999 ** t) ** 0.5 / (1 - 0.9 ** t)
+            p[n].addcdiv_(m[n], v2[n].sqrt() + eps, value=-step)
+            if not any(s in n for s in ('bias', 'layer_norm', 'LayerNorm')):
+                p[n].add_(p[n], alpha=-lr * wd)
+    return p
+
+
+def test_flat_adamw_hf_order_matches_transformers_adamw_restatement():
+    cfg, P, layout, flat, grads_seq = _case()
+    ref = _hf_adamw_steps(P, layout, grads_seq, 1e-3, 100)
+    opt = dp.FlatAdamW(flat, layout, lr=1e-3, num_train_steps=100, hf_order=True)
+    for g in grads_seq:
+        opt.step(g)
+    for n, o, k, shp in layout:
+        assert torch.allclose(flat[o:o + k].view(shp).double(), ref[n], rtol=1e-5, atol=1e-7), n
+
+
+@pytest.mark.gpu
+def test_fused_adamw_kernels_hf_order():
+    from vslnet_amd.engine import Engine, flat_from_state_dict
+    cfg, P, _, _, _ = _case()
+    eng = Engine(cfg)
+    layout, n = eng.layout, eng.param_floats
+    g = torch.Generator().manual_seed(7)
+    grads_seq = []
+    for s in (0.01, 3.0, 0.2):
+        f = torch.zeros(n)
+        for _, o, k, _ in layout:
+            f[o:o + k] = torch.randn(k, generator=g) * s / np.sqrt(n)
+        grads_seq.append(f)
+    ref = _hf_adamw_steps(P, layout, grads_seq, 1e-3, 100)
+    flat = flat_from_state_dict(eng, P)
+    opt = dp.FlatAdamW(flat, layout, lr=1e-3, num_train_steps=100, engine=eng, hf_order=True)
+    for gr in grads_seq:
+        opt.step(gr.cuda())
+    out = eng.views(flat)
+    for nm, o, k, shp in layout:
+        assert torch.allclose(out[nm].cpu().double(), ref[nm], rtol=2e-5, atol=1e-7), nm

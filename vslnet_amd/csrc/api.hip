@@ -1267,7 +1267,8 @@ int vsl_adamw_step(vsl_handle h, float* params, const float* grads, float* exp_a
     }
     const double bc1 = 1.0 - std::pow((double)hp->beta1, (double)hp->step), bc2 = 1.0 - std::pow((double)hp->beta2, (double)hp->step);
     launch_adamw(params, grads, exp_avg, exp_avg_sq, h->decay_dev, h->opt_scratch, h->param_floats, hp->lr, hp->beta1, hp->beta2,
-                 hp->eps, hp->weight_decay, hp->clip_norm, (float)bc1, (float)std::sqrt(bc2), grad_norm_out, (hipStream_t)hip_stream);
+                 hp->eps, hp->weight_decay, hp->clip_norm, (float)bc1, (float)std::sqrt(bc2), grad_norm_out, (hipStream_t)hip_stream,
+                 hp->hf_order);
     if (hipGetLastError() != hipSuccess) return fail("vsl_adamw_step: launch failed");
     return 0;
 }

@@ -2126,7 +2126,7 @@ __global__ __launch_bounds__(256) void k_sqsum(const float* __restrict__ g, int6
 __global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                float* __restrict__ v, const uint8_t* __restrict__ decay, const float* __restrict__ partials,
                                                int64_t n4, float lr, float b1, float b2, float eps, float wd, float clip, float bc1,
-                                               float bc2_sqrt, float* __restrict__ norm_out) {
+                                               float bc2_sqrt, float* __restrict__ norm_out, int hf_order) {
     __shared__ float red[4];
     float s = threadIdx.x < OPT_BLOCKS ? partials[threadIdx.x] : 0.f;
     s = wave_sum(s);
@@ -2147,10 +2147,14 @@ __global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, const floa
         const uchar4 dk = d4[i];
         auto upd = [&](float& pe, float& me, float& ve, float ge, unsigned char dke) {
             ge *= coef;
-            pe *= 1.0f - lr * (dke ? wd : 0.f);
+            if (!hf_order) pe *= 1.0f - lr * (dke ? wd : 0.f);
             me = b1 * me + (1.0f - b1) * ge;
             ve = b2 * ve + (1.0f - b2) * ge * ge;
-            pe -= step_size * me / (sqrtf(ve) / bc2_sqrt + eps);
+            if (!hf_order) pe -= step_size * me / (sqrtf(ve) / bc2_sqrt + eps);
+            else {                                   // transformers.AdamW: eps outside the bias correction, decay after the update
+                pe -= step_size * bc2_sqrt * me / (sqrtf(ve) + eps);
+                pe -= lr * (dke ? wd : 0.f) * pe;
+            }
         };
         upd(pv.x, mv.x, vv.x, gv.x, dk.x); upd(pv.y, mv.y, vv.y, gv.y, dk.y);
         upd(pv.z, mv.z, vv.z, gv.z, dk.z); upd(pv.w, mv.w, vv.w, gv.w, dk.w);
@@ -2159,12 +2163,12 @@ __global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, const floa
 }
 void launch_adamw(float* params, const float* grads, float* m, float* v, const uint8_t* decay_mask, float* partials, int64_t n,
                   float lr, float b1, float b2, float eps, float wd, float clip, float bc1, float bc2_sqrt, float* norm_out,
-                  hipStream_t s) {
+                  hipStream_t s, int hf_order) {
     const int64_t n4 = n / 4;                    // the bucket is a multiple of 4 floats (every tensor is 16-byte aligned)
     hipLaunchKernelGGL(k_sqsum, dim3(OPT_BLOCKS), dim3(256), 0, s, grads, n4, partials);
     const int nb = (int)std::min<int64_t>(1024, (n4 + 255) / 256);
     hipLaunchKernelGGL(k_adamw, dim3(nb), dim3(256), 0, s, params, grads, m, v, decay_mask, partials, n4, lr, b1, b2, eps, wd, clip,
-                       bc1, bc2_sqrt, norm_out);
+                       bc1, bc2_sqrt, norm_out, hf_order);
 }
 
 }  // namespace vsl

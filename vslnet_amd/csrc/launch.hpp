@@ -234,7 +234,7 @@ void launch_reduce(const float* ws, float* grads, const ReduceSeg* segs_dev, con
 constexpr int OPT_BLOCKS = 256;
 void launch_adamw(float* params, const float* grads, float* m, float* v, const uint8_t* decay_mask, float* partials /*[OPT_BLOCKS + 1]*/,
                   int64_t n, float lr, float b1, float b2, float eps, float wd, float clip, float bc1, float bc2_sqrt,
-                  float* norm_out, hipStream_t s);
+                  float* norm_out, hipStream_t s, int hf_order = 0);
 constexpr int EMB_CHUNK = 4;     // query words per workgroup in the embedding backward
 constexpr int CHARW_TOTAL = 15000;
 

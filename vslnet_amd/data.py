@@ -96,6 +96,9 @@ def pad_videos(features, out=None):
     return out, lens
 
 
+REF_EXTEND = 0.1      # train_collate_fn hard-codes the highlight extension (data_loader_t7.py:42); --extend is accepted and ignored, like the reference
+
+
 def highlight_targets(s_inds, e_inds, lens, max_len, extend=0.1):
     """train_collate_fn, data_loader_t7.py:41-52: 1 on the target span widened by round(extend * span) clips on both
     sides (Python round = half-to-even, like np.rint), clipped to the video."""
@@ -147,7 +150,7 @@ def collate_train(items, pin=False, extend=0.1):
 def get_train_loader(dataset, video_features, configs, pin=False, generator=None):
     """data_loader_t7.py:84-88 (shuffled, 0 workers)."""
     return torch.utils.data.DataLoader(VideoQueryDataset(dataset, video_features), batch_size=configs.batch_size, shuffle=True,
-                                       collate_fn=lambda b: collate_train(b, pin, getattr(configs, 'extend', 0.1)), generator=generator)
+                                       collate_fn=lambda b: collate_train(b, pin, REF_EXTEND), generator=generator)
 
 
 def get_test_loader(dataset, video_features, configs, pin=False):
@@ -177,7 +180,7 @@ class ResidentSplit:
     def __init__(self, records, video_features, configs, device, train, generator=None):
         self.records, self.device, self.train = list(records), torch.device(device), train
         self.batch_size, self.generator = configs.batch_size, generator
-        extend = getattr(configs, 'extend', 0.1)
+        extend = REF_EXTEND            # data_loader_t7.py:42 hard-codes 0.1; its --extend flag (main_t7.py:40) is dead
         n = len(self.records)
         vids = sorted({r['vid'] for r in self.records})
         vpos = {v: i for i, v in enumerate(vids)}
@@ -319,12 +322,45 @@ def synthetic_dataset(configs, n_train=512, n_test=128, n_words=200, n_chars=30,
     return dataset, feats
 
 
+# limits of the HIP engine (vslnet_amd/csrc/common.hpp: MAX_LQ, MAX_LC; api.hip vsl_create): checked against the WHOLE dataset
+# before the first step, so that one long query or token cannot abort a run in the middle of an epoch
+ENGINE_MAX_WORDS, ENGINE_MAX_CHARS, ENGINE_MAX_CHAR_DIM = 96, 40, 64
+
+
+def validate_dataset(dataset, configs):
+    """Host-side checks the reference gets for free from nn.Embedding's IndexError: every id inside its table, every length
+    inside the engine's limits.  Raises ValueError naming the first offending record."""
+    n_words, n_chars = int(dataset['n_words']), int(dataset['n_chars'])
+    if int(getattr(configs, 'char_dim', 50)) > ENGINE_MAX_CHAR_DIM:
+        raise ValueError('--char_dim %d: the HIP embedding kernels hold a word\'s character rows in LDS and support char_dim <= %d'
+                         % (configs.char_dim, ENGINE_MAX_CHAR_DIM))
+    for split in ('train_set', 'val_set', 'test_set'):
+        for r in dataset.get(split) or []:
+            w = np.asarray(r['w_ids'], dtype=np.int64)
+            where = '%s record %s (vid %s)' % (split, r.get('sample_id', '?'), r.get('vid', '?'))
+            if len(w) == 0 or len(w) > min(ENGINE_MAX_WORDS, int(configs.max_pos_len)):
+                raise ValueError('%s: %d query words; supported: 1 .. min(max_pos_len=%d, %d) (the CQAttention kernels keep a whole '
+                                 'query in LDS)' % (where, len(w), configs.max_pos_len, ENGINE_MAX_WORDS))
+            if w.min() < 0 or w.max() >= n_words:
+                raise ValueError('%s: word id %d outside [0, %d)' % (where, int(w.max() if w.max() >= n_words else w.min()), n_words))
+            for c in r['c_ids']:
+                c = np.asarray(c, dtype=np.int64)
+                if len(c) > ENGINE_MAX_CHARS:
+                    raise ValueError('%s: a token of %d characters; supported: <= %d' % (where, len(c), ENGINE_MAX_CHARS))
+                if len(c) and (c.min() < 0 or c.max() >= n_chars):
+                    raise ValueError('%s: char id outside [0, %d)' % (where, n_chars))
+            if 's_ind' in r and not (0 <= int(r['s_ind']) <= int(r['e_ind'])):
+                raise ValueError('%s: span labels (%s, %s)' % (where, r['s_ind'], r['e_ind']))
+
+
 def load_dataset(configs):
     """-> (dataset dict in the layout of data_gen.py:236-239, {vid: features}).  ValueError for an unknown task or a
     missing processed dataset, like the reference (data_gen.py:229, main_t7.py:134)."""
     if configs.task == 'synthetic':
-        return synthetic_dataset(configs, getattr(configs, 'synthetic_train', 512), getattr(configs, 'synthetic_test', 128),
-                                 seed=configs.seed)
+        dataset, feats = synthetic_dataset(configs, getattr(configs, 'synthetic_train', 512), getattr(configs, 'synthetic_test', 128),
+                                           seed=configs.seed)
+        validate_dataset(dataset, configs)
+        return dataset, feats
     if configs.task not in ('charades', 'activitynet', 'tacos'):
         raise ValueError('Unknown task {}!!!'.format(configs.task))
     path = dataset_path(configs)
@@ -337,4 +373,5 @@ def load_dataset(configs):
     features = load_video_features(feature_dir, configs.max_pos_len)
     if not features:
         raise ValueError('no *.npy video features under %s' % feature_dir)
+    validate_dataset(dataset, configs)
     return dataset, features

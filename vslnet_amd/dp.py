@@ -49,10 +49,13 @@ class FlatAdamW:
     Weight decay 0.01 except for names containing bias / layer_norm / LayerNorm.  With an `engine` (GPU) the step is the
     library's fused two-kernel `vsl_adamw_step` (no host synchronisation: the global norm never leaves the device);
     without one (CPU / gloo tests) the same arithmetic runs as torch ops, which is also what the GPU test checks the
-    kernels against.  Update rule = torch.optim.AdamW's (eps 1e-6)."""
+    kernels against.  Update rule = torch.optim.AdamW's (eps 1e-6); `hf_order=True` reproduces the historical
+    transformers.AdamW the reference imports (VSLNet_t7.py:5): eps outside the bias correction, decoupled decay applied after
+    the update."""
 
     def __init__(self, flat, layout, lr, num_train_steps, warmup_proportion=0.0, clip_norm=1.0, betas=(0.9, 0.999), eps=1e-6,
-                 weight_decay=0.01, engine=None):
+                 weight_decay=0.01, engine=None, hf_order=False):
+        self.hf_order = bool(hf_order)
         self.flat, self.lr0, self.N, self.clip = flat, lr, float(num_train_steps), clip_norm
         self.warm = float(num_train_steps) * warmup_proportion
         self.b1, self.b2, self.eps, self.weight_decay = betas[0], betas[1], eps, weight_decay
@@ -78,14 +81,19 @@ class FlatAdamW:
         self.t += 1
         if self.engine is not None:
             self.engine.adamw_step(self.flat, grads, self.m, self.v, lr, self.t, (self.b1, self.b2), self.eps, self.weight_decay,
-                                   self.clip)
+                                   self.clip, hf_order=self.hf_order)
             return
         if self.clip:
             gn = torch.linalg.vector_norm(grads)
             grads = grads * torch.clamp(self.clip / (gn + 1e-6), max=1.0)
-        self.flat.mul_(1 - lr * self.wd)
+        if not self.hf_order:
+            self.flat.mul_(1 - lr * self.wd)
         self.m.mul_(self.b1).add_(grads, alpha=1 - self.b1)
         self.v.mul_(self.b2).addcmul_(grads, grads, value=1 - self.b2)
         bc1, bc2 = 1 - self.b1 ** self.t, 1 - self.b2 ** self.t
+        if self.hf_order:
+            self.flat.addcdiv_(self.m, self.v.sqrt().add_(self.eps), value=-lr * math.sqrt(bc2) / bc1)
+            self.flat.sub_(self.flat * self.wd, alpha=lr)
+            return
         denom = (self.v.sqrt() / math.sqrt(bc2)).add_(self.eps)
         self.flat.addcdiv_(self.m, denom, value=-lr / bc1)
