@@ -634,10 +634,11 @@ void enc_bwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float*
         // the four layers in ONE launch (kernels_enc.hip: 12-row recomputed halo); slab order = the per-layer chain's
         CbBwdArgs a;
         memset(&a, 0, sizeof a);
+        const int nsl = convblock_slabs(R, L);
         for (int i = 3; i >= 0; --i) {
-            a.p_lng[i] = c.slab(P.lng[i], D, ntiles);
-            a.p_lnb[i] = c.slab(P.lnb[i], D, ntiles);
-            a.p_dw[i] = c.slab(P.dw[i], D * DWK, ntiles);
+            a.p_lng[i] = c.slab(P.lng[i], D, nsl);
+            a.p_lnb[i] = c.slab(P.lnb[i], D, nsl);
+            a.p_dw[i] = c.slab(P.dw[i], D * DWK, nsl);
         }
         if (!c.dry) {
             a.dy = g; a.dx0 = dx0_out; a.R = R; a.L = L;

@@ -149,16 +149,20 @@ __device__ __forceinline__ void ln_rows512(const float* __restrict__ src, float*
 // registers) the depthwise output = 72 KB with the small parameters, so two workgroups -- e.g. the video and the query
 // pass, which run on different streams -- share a CU.
 // =========================================================================================================
-constexpr int CB_VU = CB_NW + 12;               // rows of the LN / depthwise buffer: GEMM blocks of 16 from row 3 reach row 66
 constexpr int CB_PS = 384;                      // per-layer small parameters in LDS: ln_g | ln_b | pw_b
-__global__ __launch_bounds__(CB_T, 4) void k_convblock_fwd(CbFwdArgs a) {
+// SH = rows a layer's valid range shrinks by on each side: 3 = row tiles with a recomputed halo (12 + 32 + 12 rows);
+// 0 = SAMPLE tiles for sequences of at most 32 rows (the query pass: Lq = 20): one workgroup per sample, its rows at the top
+// of a 32-row window, no halo and no recomputation -- rows >= L and the taps that leave the window are the conv's zero padding.
+template <int SH>
+__global__ __launch_bounds__(CB_T, SH ? 4 : 2) void k_convblock_fwd(CbFwdArgs a) {
+    constexpr int HL = 4 * SH, NW = TILE_M + 2 * HL, VUR = SH ? NW + 12 : NW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Xs = smem;                       // [56][LDP] residual stream
-    float* VU = Xs + CB_NW * LDP;           // [68][LDP] LN(x), then depthwise output = GEMM A operand (rows indexed by window row)
-    float* Ps = VU + CB_VU * LDP;           // [4][CB_PS] per-layer small parameters | ln1_g | ln1_b | bq | bk | bv
+    float* VU = Xs + NW * LDP;           // [68][LDP] LN(x), then depthwise output = GEMM A operand (rows indexed by window row)
+    float* Ps = VU + VUR * LDP;           // [4][CB_PS] per-layer small parameters | ln1_g | ln1_b | bq | bk | bv
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int R = a.R, L = a.L;
-    const int r0 = blockIdx.x * TILE_M, rw0 = r0 - CB_HALO;       // global row of window row 0
+    const int r0 = SH ? blockIdx.x * TILE_M : blockIdx.x * L, rw0 = r0 - HL;      // global row of window row 0
     ESTAMP(0);
     // ---- window rows rw0 .. rw0 + 55 (+ positional rows, :202): every load first
     float4 xv[4], pv[4];
@@ -168,9 +172,9 @@ __global__ __launch_bounds__(CB_T, 4) void k_convblock_fwd(CbFwdArgs a) {
         const int r = rw0 + (e >> 5), c = (e & 31) * 4;
         xv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
         pv[q] = xv[q];
-        if (e < CB_NW * 32 && r >= 0 && r < R) {
+        if (e < NW * 32 && (SH ? (r >= 0 && r < R) : (e >> 5) < L)) {
             xv[q] = *reinterpret_cast<const float4*>(a.xin + (size_t)r * D + c);
-            pv[q] = *reinterpret_cast<const float4*>(a.pos + (size_t)(r % L) * D + c);
+            pv[q] = *reinterpret_cast<const float4*>(a.pos + (size_t)(SH ? r % L : e >> 5) * D + c);
         }
     }
     // small parameters of all four layers and of the LN1 / QKV stage -> LDS ; depthwise taps of the thread's channel -> registers
@@ -194,23 +198,24 @@ __global__ __launch_bounds__(CB_T, 4) void k_convblock_fwd(CbFwdArgs a) {
     for (int q = 0; q < 4; ++q) {
         const int e = tid + q * CB_T;
         const int wr = e >> 5, c = (e & 31) * 4;
-        if (e < CB_NW * 32) {
+        if (e < NW * 32) {
             const float4 v = make_float4(xv[q].x + pv[q].x, xv[q].y + pv[q].y, xv[q].z + pv[q].z, xv[q].w + pv[q].w);
             const int r = rw0 + wr;
-            if (wr >= CB_HALO && wr < CB_HALO + TILE_M && r < R) *reinterpret_cast<float4*>(a.x0_out + (size_t)r * D + c) = v;
+            if (wr >= HL && wr < HL + TILE_M && (SH ? r < R : wr < L)) *reinterpret_cast<float4*>(a.x0_out + (size_t)r * D + c) = v;
             *reinterpret_cast<float4*>(&Xs[wr * LDP + c]) = v;
         }
     }
     // a window that lies inside one sample needs no boundary tests in the depthwise conv (block-uniform)
-    const bool interior = rw0 >= 0 && rw0 + CB_NW <= R && (rw0 % L) + CB_NW <= L;
-    const bool full = r0 + TILE_M <= R;
-    // Owner rows inside ONE sample (every tile when L % 32 == 0): the window rows of other samples only ever act as that
-    // sample's zero padding (their own outputs feed no owner row), so their LayerNorm output is written as zeros and the
-    // depthwise conv runs without per-tap tests.  [klo, khi) = window rows of the owner sample.
+    const bool interior = SH && rw0 >= 0 && rw0 + NW <= R && (rw0 % L) + NW <= L;
+    const bool full = SH && r0 + TILE_M <= R;
+    // Owner rows inside ONE sample (every tile when L % 32 == 0, and always in sample mode): the window rows of other samples
+    // only ever act as that sample's zero padding (their own outputs feed no owner row), so their LayerNorm output is written
+    // as zeros and the depthwise conv runs without per-tap tests.  [klo, khi) = window rows of the owner sample.
     const int s_own = r0 / L;
-    const bool one_owner = full && (r0 + TILE_M - 1) / L == s_own;
-    const int klo = max(0, s_own * L - rw0), khi = min(CB_NW, (s_own + 1) * L - rw0);
+    const bool one_owner = !SH || (full && (r0 + TILE_M - 1) / L == s_own);
+    const int klo = max(0, s_own * L - rw0), khi = min(NW, (s_own + 1) * L - rw0);
     const bool plain = interior || one_owner;
+    auto row_ok = [&](int wr) { return SH ? (full || rw0 + wr < R) : wr < L; };     // may window row wr (an owner row) be stored?
     __syncthreads();
     ESTAMP(1);
     const Drop nodrop{0u, 0u, 1.f};
@@ -218,8 +223,8 @@ __global__ __launch_bounds__(CB_T, 4) void k_convblock_fwd(CbFwdArgs a) {
 
     auto layer = [&](auto LC, BF16 (&cur)[1], auto&& prefetch) {
         constexpr int l = decltype(LC)::value;
-        constexpr int in0 = 3 * l, nin = CB_NW - 6 * l;          // LayerNorm rows
-        constexpr int o0 = in0 + 3, n = nin - 6;                 // rows this layer produces
+        constexpr int in0 = SH * l, nin = NW - 2 * SH * l;       // LayerNorm rows
+        constexpr int o0 = in0 + SH, n = nin - 2 * SH;           // rows this layer produces
         constexpr int NRB = (n + 15) / 16, QS = (n + 3) / 4;     // 16-row blocks ; rows per depthwise segment
         const float* P = Ps + l * CB_PS;
         const Drop dp = a.dp[l];
@@ -233,7 +238,11 @@ __global__ __launch_bounds__(CB_T, 4) void k_convblock_fwd(CbFwdArgs a) {
             const int os = o0 + seg * QS;                        // first produced window row of the segment
             float win[QS + 2 * HALO], uo[QS];
 #pragma unroll
-            for (int i = 0; i < QS + 2 * HALO; ++i) win[i] = VU[min(os - HALO + i, CB_NW - 1) * LDP + c];
+            for (int i = 0; i < QS + 2 * HALO; ++i) {
+                const int wr = os - HALO + i;
+                win[i] = VU[min(max(wr, 0), NW - 1) * LDP + c];
+                if (!SH && (wr < 0 || wr >= NW)) win[i] = 0.f;    // sample tiles: taps that leave the window = zero padding
+            }
             if (plain) {
 #pragma unroll
                 for (int i = 0; i < QS; ++i) {
@@ -261,7 +270,7 @@ __global__ __launch_bounds__(CB_T, 4) void k_convblock_fwd(CbFwdArgs a) {
                 if (os + i < o0 + n) {                           // wave-uniform
                     VU[(os + i) * LDP + c] = uo[i];
                     const int wr = os + i;
-                    if (wr >= CB_HALO && wr < CB_HALO + TILE_M && (full || rw0 + wr < R)) ug[(ptrdiff_t)i * D] = uo[i];   // saved: A operand of the weight gradient
+                    if (wr >= HL && wr < HL + TILE_M && row_ok(wr)) ug[(ptrdiff_t)i * D] = uo[i];   // saved: A operand of the weight gradient
                 }
             }
         }
@@ -297,13 +306,13 @@ __global__ __launch_bounds__(CB_T, 4) void k_convblock_fwd(CbFwdArgs a) {
             }
             // ReLU decisions of the owner rows: lane i < 16 stores the 16 bits of tile row i (uint16 view of the (R, 4) words)
             const int t0 = o0 + 16 * rb;                         // folds after unrolling
-            if (t0 < CB_HALO + TILE_M && t0 + 16 > CB_HALO) {
+            if (t0 < HL + TILE_M && t0 + 16 > HL) {
                 const int i = lane & 15, rr = i & 3;
                 const unsigned long long b01 = (rr & 1) ? bal[1] : bal[0], b23 = (rr & 1) ? bal[3] : bal[2];
                 const unsigned long long bsel = (rr & 2) ? b23 : b01;
                 const uint32_t bits = (uint32_t)(bsel >> (16 * (i >> 2))) & 0xFFFFu;
                 const int o = t0 + i;
-                if (lane < 16 && o >= CB_HALO && o < CB_HALO + TILE_M && rw0 + o < R) mk[(size_t)(rw0 + o) * 8 + w] = (uint16_t)bits;
+                if (lane < 16 && o >= HL && o < HL + TILE_M && row_ok(o)) mk[(size_t)(rw0 + o) * 8 + w] = (uint16_t)bits;
             }
         }
         if (l == 0) ESTAMP(11);
@@ -314,8 +323,8 @@ __global__ __launch_bounds__(CB_T, 4) void k_convblock_fwd(CbFwdArgs a) {
         for (int q = 0; q < 2; ++q) {
             const int e = tid + q * CB_T;
             const int rr = e >> 5, c = (e & 31) * 4;
-            if (full || r0 + rr < R)
-                *reinterpret_cast<float4*>(a.y[l] + (size_t)(r0 + rr) * D + c) = *reinterpret_cast<const float4*>(&Xs[(CB_HALO + rr) * LDP + c]);
+            if (row_ok(HL + rr))
+                *reinterpret_cast<float4*>(a.y[l] + (size_t)(r0 + rr) * D + c) = *reinterpret_cast<const float4*>(&Xs[(HL + rr) * LDP + c]);
         }
     };
     layer(std::integral_constant<int, 0>(), bfA, [&] { bf16_load(bfB[0], a.Wpack[1], D, 16 * w); });
@@ -329,7 +338,7 @@ __global__ __launch_bounds__(CB_T, 4) void k_convblock_fwd(CbFwdArgs a) {
     // ---- a8, first half (:168-173) on the owner rows: h1 = drop(LN1(y3)) ; [q | k | v] = h1 W^T + b  (wave w = head w)
     {
         const float* Pq = Ps + 4 * CB_PS;
-        ln_rows512(Xs + CB_HALO * LDP, VU, TILE_M, Pq, Pq + 128, a.qf.d1, r0);
+        ln_rows512(Xs + HL * LDP, VU, TILE_M, Pq, Pq + 128, a.qf.d1, r0);
         bf16_load(bfB[0], a.qf.Wpack, 3 * D, D + 16 * w);
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
@@ -338,7 +347,7 @@ __global__ __launch_bounds__(CB_T, 4) void k_convblock_fwd(CbFwdArgs a) {
             for (int q = 0; q < 2; ++q) {
                 const int e = tid + q * CB_T;
                 const int rr = e >> 5, c = (e & 31) * 4;
-                if (full || r0 + rr < R)
+                if (row_ok(HL + rr))
                     *reinterpret_cast<float4*>(a.qf.h1 + (size_t)(r0 + rr) * D + c) = *reinterpret_cast<const float4*>(&VU[rr * LDP + c]);
             }
         }
@@ -352,7 +361,7 @@ __global__ __launch_bounds__(CB_T, 4) void k_convblock_fwd(CbFwdArgs a) {
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) {
                     const int gr = r0 + 16 * rb + g4 + rr;
-                    if (full || gr < R) outp[(size_t)gr * D + col] = acc[0][rb][rr] + bv;
+                    if (row_ok(HL + 16 * rb + g4 + rr)) outp[(size_t)gr * D + col] = acc[0][rb][rr] + bv;
                 }
         };
         proj(bfA, a.qf.q, 0);
@@ -363,11 +372,16 @@ __global__ __launch_bounds__(CB_T, 4) void k_convblock_fwd(CbFwdArgs a) {
     }
     ESTAMP(6);
 }
-constexpr size_t CB_FWD_LDS = (size_t)((CB_NW + CB_VU) * LDP + 4 * CB_PS + 640) * sizeof(float);
+constexpr size_t cb_fwd_lds(int sh) { return (size_t)((TILE_M + 8 * sh + (sh ? TILE_M + 8 * sh + 12 : TILE_M)) * LDP + 4 * CB_PS + 640) * sizeof(float); }
 void launch_convblock_fwd(const CbFwdArgs& a, hipStream_t s) {
-    static size_t ok = 0;
-    ensure_dynamic_lds((const void*)k_convblock_fwd, CB_FWD_LDS, ok, "k_convblock_fwd");
-    hipLaunchKernelGGL(k_convblock_fwd, dim3((a.R + TILE_M - 1) / TILE_M), dim3(CB_T), CB_FWD_LDS, s, a);
+    static size_t ok3 = 0, ok0 = 0;
+    if (a.L <= TILE_M) {                    // sample tiles: one workgroup per sample
+        ensure_dynamic_lds((const void*)k_convblock_fwd<0>, cb_fwd_lds(0), ok0, "k_convblock_fwd<0>");
+        hipLaunchKernelGGL(k_convblock_fwd<0>, dim3(a.R / a.L), dim3(CB_T), cb_fwd_lds(0), s, a);
+        return;
+    }
+    ensure_dynamic_lds((const void*)k_convblock_fwd<3>, cb_fwd_lds(3), ok3, "k_convblock_fwd<3>");
+    hipLaunchKernelGGL(k_convblock_fwd<3>, dim3((a.R + TILE_M - 1) / TILE_M), dim3(CB_T), cb_fwd_lds(3), s, a);
     static int left = 6;
     if (edbg_on() && a.R > 4096) { int l2 = left; edbg_report("convblock_fwd: load | L0 | L1 | L2 | L3 | qkv", 7, s, left); edbg_report2("  L0: LN | dw | gemm | epilogue | barrier", 8, 13, s, l2); }
 }
@@ -383,24 +397,27 @@ void launch_convblock_fwd(const CbFwdArgs& a, hipStream_t s) {
 // segment) with the 4 segments of a channel in 4 adjacent lanes, so the partial sums are combined with two quad shuffles.
 // LDS 91 KB: fits beside a weight-gradient workgroup (66 KB) of the side stream.
 // =========================================================================================================
-constexpr int CB_XR = CB_NW - 6;                // rows of the x / xhat buffer (window rows 3 .. 52)
+template <int SH>        // 3: row tiles with a recomputed halo ; 0: sample tiles for L <= 32 (see k_convblock_fwd)
 __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
+    constexpr int HL = 4 * SH, NW = TILE_M + 2 * HL, VUR = SH ? NW + 12 : NW, XR = NW - 2 * SH;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* DY = smem;                       // [56][LDP] grad wrt the current layer's output (in place)
-    float* GU = DY + CB_NW * LDP;           // [68][LDP] dz (GEMM A operand) -> du -> dv
-    float* Xh = GU + CB_VU * LDP;           // [50][LDP] x_l, normalised in place; row = window row - 3
-    float* RS = Xh + CB_XR * LDP;           // [64] rstd per window row
+    float* GU = DY + NW * LDP;           // [68][LDP] dz (GEMM A operand) -> du -> dv
+    float* Xh = GU + VUR * LDP;              // [50][LDP] x_l, normalised in place; row = window row - SH
+    float* RS = Xh + XR * LDP;           // [64] rstd per window row
     float* VF = RS + 64;                    // [64] 1 = the window row belongs to the owner sample / is inside [0, R)
     float* GB = VF + 64;                    // [128] gamma of the current layer (row layout reads)
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int R = a.R, L = a.L;
-    const int r0 = blockIdx.x * TILE_M, rw0 = r0 - CB_HALO;
-    const bool interior = rw0 >= 0 && rw0 + CB_NW <= R && (rw0 % L) + CB_NW <= L;
-    const bool full = r0 + TILE_M <= R;
+    const int r0 = SH ? blockIdx.x * TILE_M : blockIdx.x * L, rw0 = r0 - HL;
+    const bool interior = SH && rw0 >= 0 && rw0 + NW <= R && (rw0 % L) + NW <= L;
+    const bool full = SH && r0 + TILE_M <= R;
     const int s_own = r0 / L;
-    const bool one_owner = full && (r0 + TILE_M - 1) / L == s_own;
-    const int klo = max(0, s_own * L - rw0), khi = min(CB_NW, (s_own + 1) * L - rw0);
+    const bool one_owner = !SH || (full && (r0 + TILE_M - 1) / L == s_own);
+    const int klo = max(0, s_own * L - rw0), khi = min(NW, (s_own + 1) * L - rw0);
     const bool plain = interior || one_owner;
+    auto row_ok = [&](int wr) { return SH ? (full || rw0 + wr < R) : wr < L; };     // may window row wr (an owner row) be stored?
+    auto row_in = [&](int wr) { return wr < NW && (SH ? (rw0 + wr >= 0 && rw0 + wr < R) : wr < L); };   // does it exist (in this sample)?
     // element layout of phases A / loads: thread owns float4 column c4 of window rows wq + 16 q
     const int wq = tid >> 5, c4 = (tid & 31) * 4;
     // column layout of phase C
@@ -412,7 +429,7 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int wr = wq + 16 * q, r = rw0 + wr;
-            const bool ok = wr < CB_NW && r >= 0 && r < R;
+            const bool ok = row_in(wr);
             const size_t rc = (size_t)min(max(r, 0), R - 1);
             const float4 v = *reinterpret_cast<const float4*>(a.x[l] + rc * D + c4);
             const uint32_t m = a.relu_mask[l][rc * 4 + (c4 >> 5)];
@@ -426,13 +443,13 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
         for (int q = 0; q < 4; ++q) {
             const int wr = wq + 16 * q, r = rw0 + wr;
             dv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (wr < CB_NW && r >= 0 && r < R) dv[q] = *reinterpret_cast<const float4*>(a.dy + (size_t)r * D + c4);
+            if (row_in(wr)) dv[q] = *reinterpret_cast<const float4*>(a.dy + (size_t)r * D + c4);
         }
         fetch_layer(3);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int wr = wq + 16 * q;
-            if (wr < CB_NW) *reinterpret_cast<float4*>(&DY[wr * LDP + c4]) = dv[q];
+            if (wr < NW) *reinterpret_cast<float4*>(&DY[wr * LDP + c4]) = dv[q];
         }
     }
     BF16 bfA[1], bfB[1];
@@ -443,19 +460,18 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
     gc = a.ln_g[3][cc]; bc = a.ln_b[3][cc];
     if (tid < D) gnext = a.ln_g[3][tid];
     if (tid < 64) {
-        const int r = rw0 + tid;
-        VF[tid] = (one_owner ? (tid >= klo && tid < khi) : (tid < CB_NW && r >= 0 && r < R)) ? 1.f : 0.f;
+        VF[tid] = (one_owner ? (tid >= klo && tid < khi) : row_in(tid)) ? 1.f : 0.f;
     }
     const int col = 16 * w + (lane & 15), g4 = 4 * (lane >> 4);
     ESTAMP(1);
 
     auto layer = [&](auto LC, BF16 (&cur)[1], BF16 (&nxt)[1]) {
         constexpr int l = decltype(LC)::value;
-        constexpr int ra = 3 * (3 - l), rb_ = CB_NW - ra;            // rows of dy / dz / du
+        constexpr int ra = SH * (3 - l), rb_ = NW - ra;              // rows of dy / dz / du
         constexpr int n = rb_ - ra, NRB = (n + 15) / 16;
-        constexpr int xlo = (ra + 3 < 9 ? ra + 3 : 9);                // x rows kept: [xlo, 56 - xlo)
-        constexpr int nD = n - 6;                                     // rows of phases C / D: [ra + 3, rb_ - 3)
-        constexpr int NHL = 3 * l, HQ = (NHL + 1) / 2;                // halo rows per side in phase C, per thread
+        constexpr int xlo = (ra + SH < HL - SH ? ra + SH : HL - SH);  // x rows kept: [xlo, NW - xlo)
+        constexpr int nD = n - 2 * SH;                                // rows of phases C / D: [ra + SH, rb_ - SH)
+        constexpr int NHL = SH * l, HQ = (NHL + 1) / 2;               // halo rows per side in phase C, per thread
         const Drop dp = a.dp[l];
         // ---- A: dz = dy * relu-bit * dropout -> GU (+ gz on the owner rows) ; x_l -> Xh ; gamma -> GB
 #pragma unroll
@@ -475,18 +491,18 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
                 v.z = (bits & 4u) ? v.z * m[2] : 0.f;
                 v.w = (bits & 8u) ? v.w * m[3] : 0.f;
                 *reinterpret_cast<float4*>(&GU[wr * LDP + c4]) = v;
-                if (wr >= CB_HALO && wr < CB_HALO + TILE_M && (full || rw0 + wr < R))
+                if (wr >= HL && wr < HL + TILE_M && row_ok(wr))
                     *reinterpret_cast<float4*>(a.gz[l] + (size_t)(rw0 + wr) * D + c4) = v;
             }
-            if (wr >= xlo && wr < CB_NW - xlo) *reinterpret_cast<float4*>(&Xh[(wr - 3) * LDP + c4]) = xv[q];
+            if (wr >= xlo && wr < NW - xlo) *reinterpret_cast<float4*>(&Xh[(wr - SH) * LDP + c4]) = xv[q];
         }
         if (tid < D) GB[tid] = gnext;
         __syncthreads();
         // ---- x_l -> xhat in place, rstd per row (8 lanes per row)
         {
             const int r8 = tid >> 3, sub = tid & 7;
-            if (r8 < CB_NW - 2 * xlo) {
-                float* xr = Xh + (xlo + r8 - 3) * LDP + sub * 4;
+            if (r8 < NW - 2 * xlo) {
+                float* xr = Xh + (xlo + r8 - SH) * LDP + sub * 4;
                 float4 v[4];
                 float sum = 0.f;
 #pragma unroll
@@ -524,15 +540,18 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
         float gw[DWK], slb = 0.f, slg = 0.f;
 #pragma unroll
         for (int k = 0; k < DWK; ++k) gw[k] = 0.f;
-        const int t0 = CB_HALO + 8 * seg;                             // this thread's 8 owner rows
-        const int hs = ((seg >> 1) ? CB_HALO + TILE_M : CB_HALO - NHL) + (seg & 1) * HQ;   // and its halo rows (l > 0)
+        const int t0 = HL + 8 * seg;                                  // this thread's 8 owner rows
+        const int hs = ((seg >> 1) ? HL + TILE_M : HL - NHL) + (seg & 1) * HQ;   // and its halo rows (l > 0)
         {
             float dwin[14], vv[14], xc[8];
 #pragma unroll
             for (int j = 0; j < 14; ++j) {
-                dwin[j] = GU[(t0 - 3 + j) * LDP + cc];
-                const float xh = Xh[(t0 - 6 + j) * LDP + cc];
-                vv[j] = (xh * gc + bc) * VF[t0 - 3 + j];
+                const int wr = t0 - 3 + j;                            // sample tiles: rows outside the window = zero padding
+                const bool in = SH || (wr >= 0 && wr < NW);
+                const int wc = SH ? wr : min(max(wr, 0), NW - 1);
+                dwin[j] = in ? GU[wc * LDP + cc] : 0.f;
+                const float xh = Xh[(wc - SH) * LDP + cc];
+                vv[j] = in ? (xh * gc + bc) * VF[wc] : 0.f;
                 if (j >= 3 && j < 11) xc[j - 3] = xh;
             }
             if (plain) {
@@ -542,7 +561,9 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
 #pragma unroll
                     for (int k = 0; k < DWK; ++k) { dv += wk[k] * dwin[i + 6 - k]; gw[k] += dwin[i + 3] * vv[i + k]; }
                     dvo[i] = dv;
-                    slb += dv; slg += dv * xc[i];
+                    // sample tiles: rows L .. 31 of the window lie outside the sample but receive dv from its last rows
+                    slb += SH ? dv : dv * VF[t0 + i];
+                    slg += dv * xc[i];
                 }
             } else {
                 int p = (r0 + 8 * seg) % L;                             // position of the row inside its sample
@@ -563,7 +584,7 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
         if (HQ > 0) {
             float hwin[HQ + 6];
 #pragma unroll
-            for (int j = 0; j < HQ + 6; ++j) hwin[j] = GU[min(max(hs - 3 + j, 0), CB_VU - 1) * LDP + cc];
+            for (int j = 0; j < HQ + 6; ++j) hwin[j] = GU[min(max(hs - 3 + j, 0), VUR - 1) * LDP + cc];
             if (plain) {
 #pragma unroll
                 for (int i = 0; i < HQ; ++i) {
@@ -620,9 +641,9 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
         {
             const int r8 = tid >> 3, sub = tid & 7;
             if (r8 < nD) {
-                const int wr = ra + 3 + r8;
+                const int wr = ra + SH + r8;
                 const float* dvr = GU + wr * LDP + sub * 4;
-                const float* xr = Xh + (wr - 3) * LDP + sub * 4;
+                const float* xr = Xh + (wr - SH) * LDP + sub * 4;
                 float* dyr = DY + wr * LDP + sub * 4;
                 const float rstd = RS[wr];
                 float4 gd[4], xh[4];
@@ -645,7 +666,7 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
                     o.x = dy.x + rstd * (gd[j].x - m1 - xh[j].x * m2); o.y = dy.y + rstd * (gd[j].y - m1 - xh[j].y * m2);
                     o.z = dy.z + rstd * (gd[j].z - m1 - xh[j].z * m2); o.w = dy.w + rstd * (gd[j].w - m1 - xh[j].w * m2);
                     if (l > 0) *reinterpret_cast<float4*>(dyr + 32 * j) = o;
-                    else if (full || rw0 + wr < R) *reinterpret_cast<float4*>(a.dx0 + (size_t)(rw0 + wr) * D + sub * 4 + 32 * j) = o;
+                    else if (row_ok(wr)) *reinterpret_cast<float4*>(a.dx0 + (size_t)(rw0 + wr) * D + sub * 4 + 32 * j) = o;
                 }
             }
         }
@@ -661,13 +682,20 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
     layer(std::integral_constant<int, 0>(), bfB, bfA);
     ESTAMP(5);
 }
-constexpr size_t CB_BWD_LDS = (size_t)((CB_NW + CB_VU + CB_XR) * LDP + 64 + 64 + 128) * sizeof(float);
+constexpr size_t cb_bwd_lds(int sh) { return (size_t)((TILE_M + 8 * sh + (sh ? TILE_M + 8 * sh + 12 : TILE_M) + TILE_M + 6 * sh) * LDP + 64 + 64 + 128) * sizeof(float); }
 void launch_convblock_bwd(const CbBwdArgs& a, hipStream_t s) {
-    static size_t ok = 0;
-    ensure_dynamic_lds((const void*)k_convblock_bwd, CB_BWD_LDS, ok, "k_convblock_bwd");
-    hipLaunchKernelGGL(k_convblock_bwd, dim3((a.R + TILE_M - 1) / TILE_M), dim3(CB_T), CB_BWD_LDS, s, a);
+    static size_t ok3 = 0, ok0 = 0;
+    if (a.L <= TILE_M) {                    // sample tiles: one workgroup per sample (partial slabs per SAMPLE: convblock_slabs())
+        ensure_dynamic_lds((const void*)k_convblock_bwd<0>, cb_bwd_lds(0), ok0, "k_convblock_bwd<0>");
+        hipLaunchKernelGGL(k_convblock_bwd<0>, dim3(a.R / a.L), dim3(CB_T), cb_bwd_lds(0), s, a);
+        return;
+    }
+    ensure_dynamic_lds((const void*)k_convblock_bwd<3>, cb_bwd_lds(3), ok3, "k_convblock_bwd<3>");
+    hipLaunchKernelGGL(k_convblock_bwd<3>, dim3((a.R + TILE_M - 1) / TILE_M), dim3(CB_T), cb_bwd_lds(3), s, a);
     static int left = 6;
     if (edbg_on() && a.R > 4096) edbg_report("convblock_bwd: load | L3 | L2 | L1 | L0", 6, s, left);
 }
+// partial slabs the backward writes per parameter: one per workgroup
+int convblock_slabs(int R, int L) { return L <= TILE_M ? R / L : (R + TILE_M - 1) / TILE_M; }
 
 }  // namespace vsl

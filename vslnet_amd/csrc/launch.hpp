@@ -151,6 +151,7 @@ struct CbBwdArgs {
     int R, L;
 };
 void launch_convblock_bwd(const CbBwdArgs& a, hipStream_t s);
+int convblock_slabs(int R, int L);        // partial slabs per parameter of launch_convblock_bwd (= its grid)
 void launch_ln_qkv_fwd(const float* x, const float* ln_g, const float* ln_b, const float* Wpack, const float* bq,
                        const float* bk, const float* bv, float* h1, float* q, float* k, float* v, int R, Drop d1,
                        hipStream_t s);
