@@ -199,3 +199,40 @@ def test_one_engine_serves_many_shapes_from_one_workspace():
     torch.cuda.synchronize()
     assert eng._ws is ws0                                    # smaller shapes reuse the same buffer
     assert torch.equal(sl0, sl1) and torch.equal(el0, el1) and torch.equal(h0, h1)
+
+
+@pytest.mark.parametrize('B,T,Lq', [(7, 40, 6), (5, 128, 20), (3, 33, 33)])
+def test_saved_relu_decisions_match_the_saved_activations(B, T, Lq):
+    """The ReLU bit-masks the forward saves for the backward must be the decisions it actually took: in eval mode a conv layer
+    writes y = x + relu(z), so bit(row, channel) = (y - x > 0) wherever relu(z) survives the rounding of the sum.  Every conv
+    layer of all four encoder applications, on row counts that are not multiples of the 32-row tile (windows that cross sample
+    boundaries, partial last tile); and the masks of two identical forwards are identical.  (Found a wave-order dependent
+    ballot in round 2 that only this direct comparison exposes.)"""
+    from vslnet_amd.engine import Engine, flat_from_state_dict
+    from tests.helpers import hip_relu_masks
+    cfg = O.make_cfg(video_feature_dim=64, max_pos_len=max(T, Lq, 48), word_size=52)
+    P = O.random_params(cfg, seed=5)
+    b = O.synthetic_batch(cfg, B=B, T=T, Lq=Lq, Lc=5, seed=9, ragged=True)
+    eng = Engine(cfg)
+    flat = flat_from_state_dict(eng, P)
+    runs = []
+    for _ in range(2):
+        _run_forward(eng, flat, P, b)
+        torch.cuda.synchronize()
+        runs.append(hip_relu_masks(eng, B, T, Lq))
+    for m0, m1 in zip(*runs):
+        assert torch.equal(m0, m1), 'two identical forwards saved different ReLU decisions'
+    masks = runs[0]
+    site = 0
+    for enc, L in (('venc', T), ('qenc', Lq), ('p1', T), ('p2', T)):
+        x = eng.ws_view(enc + '_x0', (B, L, 128)).cpu()
+        for layer in range(4):
+            y = eng.ws_view('%s_y%d' % (enc, layer), (B, L, 128)).cpu()
+            took = (y - x) > 0
+            m = masks[site]
+            # a set bit whose relu(z) was rounded away in x + relu(z) cannot be seen in y - x: only that direction may differ
+            assert not bool((took & ~m).any()), (enc, layer, int((took & ~m).sum()))
+            lost = int((m & ~took).sum())
+            assert lost <= 1e-4 * m.numel(), (enc, layer, lost)
+            x = y
+            site += 1

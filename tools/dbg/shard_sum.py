@@ -23,14 +23,14 @@ def run(lo, hi):
     taps = {n: eng.ws_view(n, (hi - lo, T, 128)).clone() for n in ('venc_x0', 'venc_y0', 'venc_y1', 'venc_y2', 'venc_y3', 'venc', 'gated', 'p1_y3', 'pred_s', 'pred_e')}
     return g.clone(), sl.clone(), masks, taps
 gf, slf, mf, tf = run(0, B)
-cut = B // 2
+cut = int(os.environ.get("CUT", B // 2))
 g1, sl1, m1, t1 = run(0, cut)
 g2, sl2, m2, t2 = run(cut, B)
 print('logit diff shard1 %.3e shard2 %.3e' % (float((sl1 - slf[:cut]).abs().max()), float((sl2 - slf[cut:]).abs().max())))
 for n in tf:
     print('%-10s %.3e %.3e' % (n, float((t1[n] - tf[n][:cut]).abs().max()), float((t2[n] - tf[n][cut:]).abs().max())))
 flips = sum(int((a != f[:cut]).sum()) for a, f in zip(m1, mf)) + sum(int((a != f[cut:]).sum()) for a, f in zip(m2, mf))
-print('relu flips', flips)
+print('relu flips', flips, 'per site', [int((a != f[:cut]).sum()) + int((b2 != f[cut:]).sum()) for a, b2, f in zip(m1, m2, mf)])
 gs = g1 + g2
 vf, vs = eng.views(gf), eng.views(gs)
 rows = []

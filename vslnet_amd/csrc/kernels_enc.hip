@@ -155,11 +155,12 @@ constexpr int CB_PS = 384;                      // per-layer small parameters in
 // of a 32-row window, no halo and no recomputation -- rows >= L and the taps that leave the window are the conv's zero padding.
 template <int SH>
 __global__ __launch_bounds__(CB_T, SH ? 4 : 2) void k_convblock_fwd(CbFwdArgs a) {
-    constexpr int HL = 4 * SH, NW = TILE_M + 2 * HL, VUR = SH ? NW + 12 : NW;
+    // sample tiles: 3 zero rows above and below the window in the LN / depthwise buffer stand for the taps that leave it
+    constexpr int HL = 4 * SH, NW = TILE_M + 2 * HL, VOFF = SH ? 0 : HALO, VUR = SH ? NW + 12 : NW + 2 * HALO;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Xs = smem;                       // [56][LDP] residual stream
-    float* VU = Xs + NW * LDP;           // [68][LDP] LN(x), then depthwise output = GEMM A operand (rows indexed by window row)
-    float* Ps = VU + VUR * LDP;           // [4][CB_PS] per-layer small parameters | ln1_g | ln1_b | bq | bk | bv
+    float* VU = Xs + NW * LDP + VOFF * LDP; // (pointer to window row 0; sample tiles: rows -3 .. -1 and 32 .. 34 are the zero pad)           // [68][LDP] LN(x), then depthwise output = GEMM A operand (rows indexed by window row)
+    float* Ps = Xs + (NW + VUR) * LDP;           // [4][CB_PS] per-layer small parameters | ln1_g | ln1_b | bq | bk | bv
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int R = a.R, L = a.L;
     const int r0 = SH ? blockIdx.x * TILE_M : blockIdx.x * L, rw0 = r0 - HL;      // global row of window row 0
@@ -189,11 +190,6 @@ __global__ __launch_bounds__(CB_T, SH ? 4 : 2) void k_convblock_fwd(CbFwdArgs a)
         if (tid < 256) Ps[4 * CB_PS + tid] = pq[0];
         if (tid < 384) Ps[4 * CB_PS + 256 + tid] = pq[1];
     }
-    BF16 bfA[1], bfB[1];
-    bf16_load(bfA[0], a.Wpack[0], D, 16 * w);
-    float wkc[DWK];                                              // depthwise taps of this thread's channel, fetched a layer ahead
-#pragma unroll
-    for (int k = 0; k < DWK; ++k) wkc[k] = a.dw_w[0][(tid & 127) * DWK + k];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int e = tid + q * CB_T;
@@ -205,6 +201,16 @@ __global__ __launch_bounds__(CB_T, SH ? 4 : 2) void k_convblock_fwd(CbFwdArgs a)
             *reinterpret_cast<float4*>(&Xs[wr * LDP + c]) = v;
         }
     }
+    if (!SH && tid < 2 * HALO * 32) {            // zero pad rows of the sample-tile buffer (never written again)
+        const int pr = tid >> 5, c = (tid & 31) * 4;
+        *reinterpret_cast<float4*>(&VU[(pr < HALO ? pr - HALO : NW + pr - HALO) * LDP + c]) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // first weight slice and depthwise taps: requested once the window registers are free (first used after LayerNorm 0)
+    BF16 bfA[1], bfB[1];
+    bf16_load(bfA[0], a.Wpack[0], D, 16 * w);
+    float wkc[DWK];                                              // depthwise taps of this thread's channel, fetched a layer ahead
+#pragma unroll
+    for (int k = 0; k < DWK; ++k) wkc[k] = a.dw_w[0][(tid & 127) * DWK + k];
     // a window that lies inside one sample needs no boundary tests in the depthwise conv (block-uniform)
     const bool interior = SH && rw0 >= 0 && rw0 + NW <= R && (rw0 % L) + NW <= L;
     const bool full = SH && r0 + TILE_M <= R;
@@ -238,11 +244,7 @@ __global__ __launch_bounds__(CB_T, SH ? 4 : 2) void k_convblock_fwd(CbFwdArgs a)
             const int os = o0 + seg * QS;                        // first produced window row of the segment
             float win[QS + 2 * HALO], uo[QS];
 #pragma unroll
-            for (int i = 0; i < QS + 2 * HALO; ++i) {
-                const int wr = os - HALO + i;
-                win[i] = VU[min(max(wr, 0), NW - 1) * LDP + c];
-                if (!SH && (wr < 0 || wr >= NW)) win[i] = 0.f;    // sample tiles: taps that leave the window = zero padding
-            }
+            for (int i = 0; i < QS + 2 * HALO; ++i) win[i] = VU[(SH ? min(os - HALO + i, NW - 1) : os - HALO + i) * LDP + c];
             if (plain) {
 #pragma unroll
                 for (int i = 0; i < QS; ++i) {
@@ -291,28 +293,41 @@ __global__ __launch_bounds__(CB_T, SH ? 4 : 2) void k_convblock_fwd(CbFwdArgs a)
         if (l == 0) ESTAMP(10);
         const float bv = P[256 + col];
         uint16_t* mk = reinterpret_cast<uint16_t*>(a.relu_mask[l]);
+        const int mybit = 1 << (lane & 15);
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) {
-            unsigned long long bal[4];
+            const int t0 = o0 + 16 * rb;                         // folds after unrolling
+            const bool owner_tile = t0 < HL + TILE_M && t0 + 16 > HL;
+            int pos01 = 0, pos23 = 0;                            // this lane's decision bits of rows rr = 0, 1 | 2, 3 (16 bits each)
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const int row = 16 * rb + g4 + rr;               // relative to o0
                 const int o = o0 + row;
                 const float z = acc[0][rb][rr] + bv;
-                bal[rr] = __ballot(z > 0.f);
                 float av = fmaxf(z, 0.f);
                 if (dp.thresh) av *= drop_keep_scale(dp, (uint32_t)((rw0 + o) * D + col));
                 if (rb < NRB - 1 || row < n) Xs[o * LDP + col] += av;
+                const int bit = z > 0.f ? (mybit << (16 * (rr & 1))) : 0;
+                if (rr < 2) pos01 |= bit; else pos23 |= bit;
             }
-            // ReLU decisions of the owner rows: lane i < 16 stores the 16 bits of tile row i (uint16 view of the (R, 4) words)
-            const int t0 = o0 + 16 * rb;                         // folds after unrolling
-            if (t0 < HL + TILE_M && t0 + 16 > HL) {
-                const int i = lane & 15, rr = i & 3;
-                const unsigned long long b01 = (rr & 1) ? bal[1] : bal[0], b23 = (rr & 1) ? bal[3] : bal[2];
-                const unsigned long long bsel = (rr & 2) ? b23 : b01;
-                const uint32_t bits = (uint32_t)(bsel >> (16 * (i >> 2))) & 0xFFFFu;
-                const int o = t0 + i;
-                if (lane < 16 && o >= HL && o < HL + TILE_M && row_ok(o)) mk[(size_t)(rw0 + o) * 8 + w] = (uint16_t)bits;
+            // ReLU decisions of the owner rows (uint16 view of the (R, 4) words): OR over the 16 lanes of a row with four DPP steps
+            // (quad swaps, half-row mirror, row mirror), two rows per register.  Not __ballot: four ballots kept in SGPR pairs
+            // across the rr loop came out wrong for the waves 4..7 of a workgroup, timing dependent
+            // (tests/test_hip_parity.py::test_saved_relu_decisions_match_the_saved_activations).
+            if (owner_tile) {
+                auto row_or = [](int v) {
+                    v |= __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);       // quad_perm [1,0,3,2]
+                    v |= __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);       // quad_perm [2,3,0,1]
+                    v |= __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);      // row_half_mirror
+                    v |= __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);      // row_mirror
+                    return v;
+                };
+                pos01 = row_or(pos01);
+                pos23 = row_or(pos23);
+                // lane j = 0..3 of the 16-lane row stores row rr = j
+                const int j = lane & 15, o = t0 + g4 + (j & 3);
+                const uint32_t wv = (uint32_t)((j & 2) ? pos23 : pos01) >> (16 * (j & 1));
+                if (j < 4 && o >= HL && o < HL + TILE_M && row_ok(o)) mk[(size_t)(rw0 + o) * 8 + w] = (uint16_t)wv;
             }
         }
         if (l == 0) ESTAMP(11);
@@ -372,7 +387,7 @@ __global__ __launch_bounds__(CB_T, SH ? 4 : 2) void k_convblock_fwd(CbFwdArgs a)
     }
     ESTAMP(6);
 }
-constexpr size_t cb_fwd_lds(int sh) { return (size_t)((TILE_M + 8 * sh + (sh ? TILE_M + 8 * sh + 12 : TILE_M)) * LDP + 4 * CB_PS + 640) * sizeof(float); }
+constexpr size_t cb_fwd_lds(int sh) { return (size_t)((TILE_M + 8 * sh + (sh ? TILE_M + 8 * sh + 12 : TILE_M + 2 * HALO)) * LDP + 4 * CB_PS + 640) * sizeof(float); }
 void launch_convblock_fwd(const CbFwdArgs& a, hipStream_t s) {
     static size_t ok3 = 0, ok0 = 0;
     if (a.L <= TILE_M) {                    // sample tiles: one workgroup per sample
