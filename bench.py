@@ -171,6 +171,7 @@ def main():
     ap.add_argument('--lc', type=int, default=10)
     ap.add_argument('--drop-rate', type=float, default=0.2)
     ap.add_argument('--predictor', default='transformer', help="'transformer' (headline, configs[1]) or 'rnn' (configs[0] shape)")
+    ap.add_argument('--dtype', default='f32', choices=('f32', 'bf16'), help="'bf16' = the separate throughput mode: bfloat16 features in HBM + bf16-MFMA VisualProjection (fp32 elsewhere); never the parity / headline line")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-optimizer', action='store_true', help='time forward + losses + backward only (A/B runs)')
     ap.add_argument('--profile-all', action='store_true', help='also print the per-kernel HIP-event table to stderr')
@@ -207,6 +208,8 @@ def main():
     eng = model._engine
     pad_vec, glove_vec = model.embedding_net.word_emb.pad_vec.data, model.embedding_net.word_emb.glove_vec.data
     batch = synthetic_batch(configs, B, T, Lq, Lc, seed=100 + rank)
+    if args.dtype == 'bf16':
+        batch['vfeats'] = batch['vfeats'].to(torch.bfloat16).contiguous()
     inv_batch = 1.0 / (B * world)
     mask_sum = float(batch['v_mask'].sum().item()) * world   # full-length synthetic clips: same on every rank
 
@@ -307,7 +310,8 @@ def main():
         out = {'metric': '(video,query) pairs/sec fwd+bwd, Charades I3D T=128 D=1024', 'value': round(value, 1),
                'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                'ms_per_step': round(ms_step, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-               'dtype': 'f32', 'data': 'synthetic',
+               'dtype': 'f32' if args.dtype == 'f32' else 'bf16 features + bf16-MFMA VisualProjection, f32 elsewhere (throughput mode, not the parity path)',
+               'data': 'synthetic',
                'config': {'workload': 'configs[%d]: Charades-STA I3D shape, --predictor %s, B=%d/GPU T=%d Dv=%d Lq=%d Lc=%d drop_rate=%.1f '
                                       'train mode; step = forward + CE(start)+CE(end)+5*highlight + backward%s%s'
                                       % (1 if args.predictor == 'transformer' else 0, args.predictor, B, T, Dv, Lq, Lc, args.drop_rate,

@@ -69,6 +69,12 @@ typedef struct {
      * from it, so for one seed the masks -- and with the global loss normalisers the summed gradient -- do not depend
      * on how many ranks the batch is split over (shards keep the global padded T / Lq / Lc).  0 = single process.  */
     int32_t sample_offset;
+    /* bf16 THROUGHPUT mode (BASELINE configs[1] says "bf16"; the reference itself is fp32 end to end, so this is a separate mode
+     * with its own tolerance, never the parity path): when non-NULL, the (B, T, video_feature_dim) features are read from this
+     * bfloat16 copy instead of `video_features` (which may then be NULL) -- half the bytes of the only large HBM stream -- and
+     * VisualProjection runs on the bf16 matrix cores (bf16 features x bf16-rounded weight, fp32 accumulate; the dropout scale is
+     * applied to the fp32 sum).  Its weight gradient reads the same bf16 features (fp32 MFMA).  Everything else stays fp32. */
+    const uint16_t* video_features_bf16;
 } vsl_io;
 
 /* labels + weights for the fused loss (replaces compute_loss / compute_highlight_loss, VSLNet_t7.py:67-72, and the

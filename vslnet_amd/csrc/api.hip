@@ -47,7 +47,7 @@ struct ModelP {
     int sln_g, sln_b, eln_g, eln_b, s0w, s0b, s1w, s1b, e0w, e0b, e1w, e1b;
     int l_wih[2], l_whh[2], l_bih[2], l_bhh[2];     // rnn predictor: start / end DynamicRNN (layers_t7.py:302-313)
 };
-struct ModelPk { int va_f, emb_f, emb_t; EncPk fe, pe; int cqa_f, cqa_t, cat1_f, cat1_t, s0_f, s0_t, e0_f, e0_t, ccw_img;
+struct ModelPk { int va_f, va_f16, emb_f, emb_t; EncPk fe, pe; int cqa_f, cqa_t, cat1_f, cat1_t, s0_f, s0_t, e0_f, e0_t, ccw_img;
                  int l_f[2], l_t[2], zero128; };
 
 struct EncWs { int64_t x0, y[4], u[4], mask[4], h1, q, k, v, lse, att, r, h2, out; int R, L; };
@@ -249,6 +249,10 @@ void build_packs(vsl_handle_s* h) {
     ModelPk& K = h->K;
     const ModelP& P = h->P;
     K.va_f = pk.fwd(P.va_w, D, c.video_feature_dim, c.video_feature_dim);
+    // bf16 throughput mode: the same weight rounded to bfloat16 in the operand layout of v_mfma_f32_32x32x16_bf16
+    K.va_f16 = (int)h->pack_floats;
+    h->pack_floats += (int64_t)((c.video_feature_dim + 15) / 16) * D * 16 / 2;
+    h->jobs.push_back(PackJob{P.va_w, K.va_f16, c.video_feature_dim, D, c.video_feature_dim, 5, D, 0, 0});
     K.emb_f = pk.fwd(P.emb_w, D, c.word_dim + 100, c.word_dim + 100);
     K.emb_t = pk.tr(P.emb_w, D, c.word_dim + 100, c.word_dim + 100);
     build_encoder_packs(pk, h, P.fe, K.fe);
@@ -502,7 +506,11 @@ void run_forward(Ctx& c) {
     c.order(c.main, sq);
     const bool qlong = query_chain_is_longer(p, true);  // the longer branch keeps the main stream (join wait already satisfied)
     c.s = qlong ? sq : c.main;
-    LAUNCH("vproj_fwd", launch_vproj_fwd(io.video_features, c.PK(K.va_f), c.P(P.va_b), c.W(p.vf), R, cf.video_feature_dim, c.drop(SITE_VIS), c.s));
+    if (io.video_features_bf16)      // bf16 throughput mode
+        LAUNCH("vproj_fwd", launch_vproj_fwd_bf16(io.video_features_bf16, reinterpret_cast<const uint16_t*>(c.PK(K.va_f16)), c.P(P.va_b), c.W(p.vf), R,
+                                                  cf.video_feature_dim, c.drop(SITE_VIS), c.s));
+    else
+        LAUNCH("vproj_fwd", launch_vproj_fwd(io.video_features, c.PK(K.va_f), c.P(P.va_b), c.W(p.vf), R, cf.video_feature_dim, c.drop(SITE_VIS), c.s));
     enc_fwd(c, P.fe, K.fe, p.ve, c.W(p.vf), io.v_mask, B, 0);
     c.s = qlong ? c.main : sq;
     LAUNCH("embed_fwd", launch_embed_fwd(io.word_ids, io.char_ids, io.pad_vec, c.P(P.unk), io.glove_vec, c.P(P.char_tab), char_ptrs(c), c.PK(K.ccw_img), c.W(p.E),
@@ -872,7 +880,10 @@ void run_backward(Ctx& c) {
         WgradBatch wb;
         memset(&wb, 0, sizeof wb);
         WgradJob j = wjob();
-        if (!c.dry) { j.G[0] = c.W(p.dvf); j.Afull = io->video_features; }
+        if (!c.dry) {
+            j.G[0] = c.W(p.dvf); j.Afull = io->video_features;
+            if (io->video_features_bf16) { j.Afull = reinterpret_cast<const float*>(io->video_features_bf16); j.a_bf16 = 1; }
+        }
         j.nG = 1; j.nA = 0; j.K = cf.video_feature_dim; j.R = R; j.drop_on_A = 1; j.dp = c.drop(SITE_VIS);
         j.out = c.slab(P.va_w, D * cf.video_feature_dim, nchunk);
         j.out_bias[0] = c.slab(P.va_b, D, nchunk);
@@ -1071,9 +1082,11 @@ int get_plan(vsl_handle_s* h, int B, int T, int Lq, int Lc, Plan** out) {
 
 int check_io(vsl_handle_s* h, const vsl_io* io) {
     if (!h || !io) return fail("null handle / io");
-    if (!io->params || !io->pad_vec || !io->glove_vec || !io->word_ids || !io->char_ids || !io->video_features ||
+    if (!io->params || !io->pad_vec || !io->glove_vec || !io->word_ids || !io->char_ids || (!io->video_features && !io->video_features_bf16) ||
         !io->v_mask || !io->q_mask || !io->h_score || !io->start_logits || !io->end_logits || !io->workspace)
         return fail("vsl_io has a null device pointer");
+    if (io->video_features_bf16 && (h->cfg.video_feature_dim % 8 != 0))
+        return fail("bf16 features need video_feature_dim %% 8 == 0 (got %d)", h->cfg.video_feature_dim);
     return 0;
 }
 

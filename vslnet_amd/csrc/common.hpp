@@ -11,6 +11,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 #include <type_traits>
 
 namespace vsl {
@@ -45,6 +46,13 @@ struct Drop {
 __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
     h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
     return h;
+}
+// round-to-nearest-even fp32 -> bfloat16 bits (finite inputs), and the exact widening back
+__host__ __device__ __forceinline__ uint16_t f32_to_bf16(float v) {
+    uint32_t b;
+    memcpy(&b, &v, 4);
+    b += 0x7FFFu + ((b >> 16) & 1u);
+    return (uint16_t)(b >> 16);
 }
 // multiplier applied to element `idx` of the site: 0 or 1/(1-p)
 __device__ __forceinline__ float drop_mul(const Drop& d, uint32_t idx) {

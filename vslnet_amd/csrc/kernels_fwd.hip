@@ -32,6 +32,16 @@ static void fdbg_report(const char* name, int nst, hipStream_t s, int& left) {
 __global__ __launch_bounds__(256) void k_pack(const float* __restrict__ params, float* __restrict__ pack,
                                               const PackJob* __restrict__ jobs) {
     const PackJob j = jobs[blockIdx.y];
+    if (j.transpose == 5) {         // bf16 forward pack (round to nearest even), K zero-padded to 16
+        const int kn16 = (j.kn + 15) & ~15;
+        uint16_t* p16 = reinterpret_cast<uint16_t*>(pack + j.dst);
+        for (int e = blockIdx.x * 256 + threadIdx.x; e < kn16 * j.cn; e += gridDim.x * 256) {
+            const int c = e / kn16, k = e - c * kn16;
+            const float v = k < j.kn ? params[j.src + (size_t)c * j.ld + k] : 0.f;
+            p16[((size_t)(k >> 4) * j.ncols + c) * 16 + (k & 15)] = f32_to_bf16(v);
+        }
+        return;
+    }
     const int kn8 = j.transpose == 0 ? (j.kn + 7) & ~7 : j.kn;     // forward pack: zero the k rows that pad the last 8-block
     const int n = kn8 * j.cn;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
@@ -142,6 +152,90 @@ void launch_vproj_fwd(const float* X, const float* Wpack, const float* bias, flo
         ensure_dynamic_lds((const void*)k_vproj_fwd, shm_sp + 33792, lds_sp, "k_vproj_fwd");
         hipLaunchKernelGGL(k_vproj_fwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm_sp, s, X, Wpack, bias, Y, R, Dv, dp, seg, stride, off);
     }
+}
+
+// =========================================================================================================
+// a2 in the bf16 THROUGHPUT mode (vsl_io.video_features_bf16): Y = (keep(X16) W16^T) / (1 - p) + b on the bf16 matrix cores
+// (v_mfma_f32_32x32x16_bf16: 16x the fp32 rate), X16 = bfloat16 features (half the HBM bytes), W16 = bf16-rounded weight
+// (PackJob type 5), products exact in fp32, fp32 accumulation.  The dropout keeps / zeroes the bf16 inputs exactly and the
+// scale 1 / (1 - p) multiplies the fp32 sum.  Same tiling as the fp32 kernel: 32 rows per workgroup, K streamed in 128-wide
+// chunks through a double-buffered LDS tile (8 KB each).  Lane maps of the MFMA: A lane (i = l & 31, h = l >> 5) = 8
+// consecutive k of row i starting at 8 h; B likewise for column i; C/D as for 32x32x2 (acc_row).
+// =========================================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int VPB_LD = VP_KC + 8;       // bf16 elements per LDS row (272 B: 16-byte aligned rows, conflict-free b128 reads)
+__global__ __launch_bounds__(256) void k_vproj_fwd_bf16(const uint16_t* __restrict__ X, const uint16_t* __restrict__ Wp,
+                                                        const float* __restrict__ bias, float* __restrict__ Y, int R, int Dv, Drop dp) {
+    __shared__ __attribute__((aligned(16))) uint16_t As[2][TILE_M * VPB_LD];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, i = lane & 31, h = lane >> 5;
+    const int r0 = blockIdx.x * TILE_M;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int nchunk = (Dv + VP_KC - 1) / VP_KC;
+    uint4 stage[2];
+    auto gload = [&](int ch) {              // 32 rows x 128 k = 512 x 16 B: two per thread ; dropout = zeroing, exact in bf16
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int e = tid + q * 256;
+            const int rr = e >> 4, c = (e & 15) * 8 + ch * VP_KC;
+            const int r = r0 + rr;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (r < R && c < Dv) {          // Dv is a multiple of 8 in this mode (checked by the launcher)
+                v = *reinterpret_cast<const uint4*>(X + (size_t)r * Dv + c);
+                if (dp.thresh) {
+                    const uint32_t base = (uint32_t)((size_t)r * Dv + c);
+                    uint32_t* u = reinterpret_cast<uint32_t*>(&v);
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const uint32_t lo = fmix32((base + 2 * p) * 0x9E3779B1u + dp.seed) >= dp.thresh ? 0x0000FFFFu : 0u;
+                        const uint32_t hi = fmix32((base + 2 * p + 1) * 0x9E3779B1u + dp.seed) >= dp.thresh ? 0xFFFF0000u : 0u;
+                        u[p] &= lo | hi;
+                    }
+                }
+            }
+            stage[q] = v;
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int e = tid + q * 256;
+            *reinterpret_cast<uint4*>(&As[buf][(e >> 4) * VPB_LD + (e & 15) * 8]) = stage[q];
+        }
+    };
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int buf = ch & 1;
+        if (ch + 1 < nchunk) gload(ch + 1);
+        const int nk16 = (min(VP_KC, Dv - ch * VP_KC) + 15) >> 4;          // 16-wide k blocks in this chunk (zero padded in both operands)
+        const uint16_t* wp = Wp + ((size_t)(ch * (VP_KC / 16)) * D + 32 * w + i) * 16 + 8 * h;
+        uint4 bq[VP_KC / 16];
+#pragma unroll
+        for (int kk = 0; kk < VP_KC / 16; ++kk)
+            bq[kk] = kk < nk16 ? *reinterpret_cast<const uint4*>(wp + (size_t)kk * D * 16) : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int kk = 0; kk < VP_KC / 16; ++kk) {
+            if (kk < nk16) {
+                const uint4 av = *reinterpret_cast<const uint4*>(&As[buf][i * VPB_LD + kk * 16 + 8 * h]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bq[kk]), acc, 0, 0, 0);
+            }
+        }
+        if (ch + 1 < nchunk) sstore(buf ^ 1);
+        __syncthreads();
+    }
+    const int col = 32 * w + i;
+    const float bv = bias[col], sc = dp.thresh ? dp.scale : 1.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int gr = r0 + acc_row(r, lane);
+        if (gr < R) Y[(size_t)gr * D + col] = acc[r] * sc + bv;
+    }
+}
+void launch_vproj_fwd_bf16(const uint16_t* X, const uint16_t* Wpack16, const float* bias, float* Y, int R, int Dv, Drop dp, hipStream_t s) {
+    hipLaunchKernelGGL(k_vproj_fwd_bf16, dim3((R + TILE_M - 1) / TILE_M), dim3(256), 0, s, X, Wpack16, bias, Y, R, Dv, dp);
 }
 
 // =========================================================================================================

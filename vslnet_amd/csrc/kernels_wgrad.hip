@@ -17,7 +17,7 @@ namespace vsl {
 constexpr int WG2_T = 256;
 constexpr int WG2_PF = 16;           // row pairs in flight per wave (16 x 16 B per lane)
 
-template <bool DROP>
+template <bool DROP, bool ABF16>     // ABF16: Afull is bfloat16 (bf16 throughput mode: the video features), widened to fp32 on load
 __global__ __launch_bounds__(WG2_T, 2) void k_wgrad2(WgradBatch wb) {
     int ji = 0;
     while (ji + 1 < wb.n && (int)blockIdx.x >= wb.start[ji + 1]) ++ji;
@@ -50,10 +50,15 @@ __global__ __launch_bounds__(WG2_T, 2) void k_wgrad2(WgradBatch wb) {
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     float2 bs = make_float2(0.f, 0.f);
     float2 gq[WG2_PF], aq[WG2_PF];
+    const uint16_t* Ap16 = reinterpret_cast<const uint16_t*>(j.Afull) + (kin ? kglob : 0);
     auto ld = [&](int p, float2& g, float2& a) {            // rows past the chunk re-read its last row (masked when used)
         const size_t row = (size_t)min(rbeg + 2 * p + h, rend - 1);
         g = *reinterpret_cast<const float2*>(Gp + row * ldg);
-        a = *reinterpret_cast<const float2*>(Ap + row * lda);
+        if (ABF16) {          // the raw pair travels through the ring in a.x; widened where it is used (a conversion here would wait for the load)
+            a.x = __uint_as_float(*reinterpret_cast<const uint32_t*>(Ap16 + row * lda));
+        } else {
+            a = *reinterpret_cast<const float2*>(Ap + row * lda);
+        }
     };
 #pragma unroll
     for (int q = 0; q < WG2_PF; ++q) ld(q, gq[q], aq[q]);
@@ -64,6 +69,10 @@ __global__ __launch_bounds__(WG2_T, 2) void k_wgrad2(WgradBatch wb) {
         for (int q = 0; q < WG2_PF; ++q) {
             float2 g = gq[q];
             float2 a = aq[q];
+            if (ABF16) {      // two bf16 = the high halves of two floats
+                const uint32_t u = __float_as_uint(a.x);
+                a = make_float2(__uint_as_float(u << 16), __uint_as_float(u & 0xFFFF0000u));
+            }
             const int row = rbeg + 2 * (p0 + q) + h;
             if (decltype(masked_c)::value) {
                 const float mg = row < rend ? 1.f : 0.f;
@@ -116,33 +125,32 @@ void launch_wgrad2(const WgradBatch& wb0, hipStream_t s) {
     }
     wb.start[wb.n] = total;
     if (total == 0) return;
-    // the dropout hash (VisualProjection input) is a separate instantiation: jobs with a mask are launched on their own
-    bool any_drop = false, all_drop = true;
-    for (int i = 0; i < wb.n; ++i) {
-        const bool d = wb.j[i].nA == 0 && wb.j[i].drop_on_A && wb.j[i].dp.thresh;
-        any_drop = any_drop || d; all_drop = all_drop && d;
-    }
-    if (any_drop && !all_drop) {             // mixed batch: split
-        WgradBatch a, b;
-        a.n = b.n = 0;
-        for (int i = 0; i < wb.n; ++i) {
-            const bool d = wb.j[i].nA == 0 && wb.j[i].drop_on_A && wb.j[i].dp.thresh;
-            (d ? a : b).j[(d ? a : b).n++] = wb.j[i];
+    // the dropout hash (VisualProjection input) and the bf16 operand are separate instantiations: such jobs are launched on their own
+    auto kind = [](const WgradJob& j) { return (j.nA == 0 && j.drop_on_A && j.dp.thresh ? 1 : 0) | (j.nA == 0 && j.a_bf16 ? 2 : 0); };
+    const int k0 = kind(wb.j[0]);
+    bool mixed = false;
+    for (int i = 1; i < wb.n; ++i) mixed = mixed || kind(wb.j[i]) != k0;
+    if (mixed) {                             // split by kind, keeping the order
+        for (int kd = 0; kd < 4; ++kd) {
+            WgradBatch part;
+            part.n = 0;
+            for (int i = 0; i < wb.n; ++i) if (kind(wb.j[i]) == kd) part.j[part.n++] = wb.j[i];
+            if (part.n) launch_wgrad2(part, s);
         }
-        launch_wgrad2(a, s);
-        launch_wgrad2(b, s);
         return;
     }
     // dynamic LDS is requested only to bound how many of these workgroups share a CU (they would serialise on its matrix pipes
     // while other CUs idle): VSL_WGRAD_LDS=<bytes>, default 66 KB = two per CU at most, and one beside a 93 KB chain kernel
     static const size_t pad = getenv("VSL_WGRAD_LDS") ? (size_t)atol(getenv("VSL_WGRAD_LDS")) : (size_t)66 * 1024;
-    static size_t ok0 = 0, ok1 = 0;
-    if (any_drop) {
-        ensure_dynamic_lds((const void*)k_wgrad2<true>, pad, ok1, "k_wgrad2<drop>");
-        hipLaunchKernelGGL(k_wgrad2<true>, dim3(total), dim3(WG2_T), pad, s, wb);
-    } else {
-        ensure_dynamic_lds((const void*)k_wgrad2<false>, pad, ok0, "k_wgrad2");
-        hipLaunchKernelGGL(k_wgrad2<false>, dim3(total), dim3(WG2_T), pad, s, wb);
+    static size_t ok[4] = {0, 0, 0, 0};
+    const void* fn[4] = {(const void*)k_wgrad2<false, false>, (const void*)k_wgrad2<true, false>, (const void*)k_wgrad2<false, true>,
+                         (const void*)k_wgrad2<true, true>};
+    ensure_dynamic_lds(fn[k0], pad, ok[k0], "k_wgrad2");
+    switch (k0) {
+        case 0: hipLaunchKernelGGL((k_wgrad2<false, false>), dim3(total), dim3(WG2_T), pad, s, wb); break;
+        case 1: hipLaunchKernelGGL((k_wgrad2<true, false>), dim3(total), dim3(WG2_T), pad, s, wb); break;
+        case 2: hipLaunchKernelGGL((k_wgrad2<false, true>), dim3(total), dim3(WG2_T), pad, s, wb); break;
+        default: hipLaunchKernelGGL((k_wgrad2<true, true>), dim3(total), dim3(WG2_T), pad, s, wb); break;
     }
 }
 

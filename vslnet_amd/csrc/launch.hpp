@@ -60,6 +60,7 @@ struct WgradJob {
     int R;
     int ldg;              // row stride of the G blocks in floats (0 = 128): the LSTM gate gradients are 512 wide
     int drop_on_A;        // apply dropout to Afull on load (VisualProjection input)
+    int a_bf16;           // Afull points to bfloat16 data (bf16 throughput mode: the features), widened on load
     Drop dp;
     float* out;           // partial slabs [nchunk][N][K]
     float* out_bias[3];   // partial slabs [nchunk][128] per G block (nullable)
@@ -112,6 +113,8 @@ inline size_t spread_lds(size_t need, size_t static_bytes, int nblocks) {
 void launch_pack(const float* params, float* pack, const PackJob* jobs_dev, int njobs, hipStream_t s);
 void launch_vproj_fwd(const float* X, const float* Wpack, const float* bias, float* Y, int R, int Dv, Drop dp, hipStream_t s,
                       int seg = 0, int stride = 0, int off = 0);   // seg > 0: rows of one time chunk (see launch_linear_bwd_data)
+// bf16 throughput mode: X bf16 (R, Dv), packed bf16 weight (PackJob type 5), fp32 accumulate / bias / output
+void launch_vproj_fwd_bf16(const uint16_t* X, const uint16_t* Wpack16, const float* bias, float* Y, int R, int Dv, Drop dp, hipStream_t s);
 void launch_embed_fwd(const int64_t* word_ids, const int64_t* char_ids, const float* pad_vec, const float* unk_vec,
                       const float* glove, const float* char_tab, CharConvPtrs cc, const float* wimg, float* E, int8_t* argpos,
                       int Rq, int Lc, int word_dim, int char_dim, Drop dw, Drop dc, hipStream_t s);

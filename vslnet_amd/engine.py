@@ -29,7 +29,7 @@ class vsl_io(C.Structure):
                 ('h_score', C.c_void_p), ('start_logits', C.c_void_p), ('end_logits', C.c_void_p),
                 ('workspace', C.c_void_p), ('training', C.c_int32), ('seed', C.c_uint64),
                 ('d_h_score', C.c_void_p), ('d_start_logits', C.c_void_p), ('d_end_logits', C.c_void_p),
-                ('grads', C.c_void_p), ('sample_offset', C.c_int32)]
+                ('grads', C.c_void_p), ('sample_offset', C.c_int32), ('video_features_bf16', C.c_void_p)]
 
 
 class vsl_loss_io(C.Structure):
@@ -189,13 +189,16 @@ class Engine:
     # ---- the three calls ------------------------------------------------------------------------------------
     def forward(self, flat, pad_vec, glove_vec, word_ids, char_ids, vfeats, v_mask, q_mask, training=False, seed=0,
                 sample_offset=0):
-        """`sample_offset`: index of this shard's first sample in the global batch (data parallel; vslnet_hip.h)."""
+        """`sample_offset`: index of this shard's first sample in the global batch (data parallel; vslnet_hip.h).
+        `vfeats` in torch.bfloat16 selects the bf16 THROUGHPUT mode (vsl_io.video_features_bf16): bf16 features in HBM and a
+        bf16-MFMA VisualProjection; everything downstream stays fp32.  Not the parity path."""
         B, T, Dv = vfeats.shape
+        bf16 = vfeats.dtype == torch.bfloat16
         Lq, Lc = char_ids.shape[1], char_ids.shape[2]
         _chk(flat, torch.float32, (self.param_floats,), 'params')
         _chk(word_ids, torch.int64, (B, Lq), 'word_ids')
         _chk(char_ids, torch.int64, (B, Lq, Lc), 'char_ids')
-        _chk(vfeats, torch.float32, (B, T, self.cfg.video_feature_dim), 'video_features')
+        _chk(vfeats, torch.bfloat16 if bf16 else torch.float32, (B, T, self.cfg.video_feature_dim), 'video_features')
         _chk(v_mask, torch.float32, (B, T), 'v_mask')
         _chk(q_mask, torch.float32, (B, Lq), 'q_mask')
         _chk(pad_vec, torch.float32, (1, self.cfg.word_dim), 'pad_vec')
@@ -205,7 +208,8 @@ class Engine:
         io = vsl_io()
         io.B, io.T, io.Lq, io.Lc = B, T, Lq, Lc
         io.params, io.pad_vec, io.glove_vec = _ptr(flat), _ptr(pad_vec), _ptr(glove_vec)
-        io.word_ids, io.char_ids, io.video_features = _ptr(word_ids), _ptr(char_ids), _ptr(vfeats)
+        io.word_ids, io.char_ids = _ptr(word_ids), _ptr(char_ids)
+        io.video_features, io.video_features_bf16 = (None, _ptr(vfeats)) if bf16 else (_ptr(vfeats), None)
         io.v_mask, io.q_mask = _ptr(v_mask), _ptr(q_mask)
         io.h_score, io.start_logits, io.end_logits = _ptr(out[0]), _ptr(out[1]), _ptr(out[2])
         io.workspace = _ptr(ws)
