@@ -1,8 +1,9 @@
 #!/bin/bash
-# One gpurun call: kernel-trace stats, the two PMC passes (each in its own run), the traffic json, then the final bench line.
-# usage (on the GPU box, from the repo root): bash tools/collect_evidence.sh r01_c
+# One gpurun call: kernel-trace stats, the PMC passes (each in its own run, as MI355X_MICROARCH.md prescribes), the profile json
+# bench.py quotes as the static half of its roofline object, then the final bench line and the HIP-event table.
+# usage (on the GPU box, from the repo root): bash tools/collect_evidence.sh r02_a
 set -u
-TAG=${1:-r01_c}
+TAG=${1:-r02_a}
 R=$PWD
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -13,13 +14,16 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o f -- $BENCH > /dev/null
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o w -- $BENCH > /dev/null 2> $O/write.err
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/mfma -o m -- $BENCH > /dev/null 2> $O/mfma.err
 cd $R
-python tools/rocpd_stats.py $(find $O/stats -name "*.db" | head -1) > $O/${TAG}_kernel_stats.txt
-python tools/rocpd_pmc.py $(find $O/fetch -name "*.db" | head -1) > $O/${TAG}_pmc_fetch_size.txt
-python tools/rocpd_pmc.py $(find $O/write -name "*.db" | head -1) > $O/${TAG}_pmc_write_size.txt
+SDB=$(find $O/stats -name "*.db" | head -1); FDB=$(find $O/fetch -name "*.db" | head -1); WDB=$(find $O/write -name "*.db" | head -1)
+python tools/rocpd_stats.py $SDB > $O/${TAG}_kernel_stats.txt
+python tools/rocpd_timeline.py $SDB 15 > $O/${TAG}_timeline.txt
+python tools/rocpd_pmc.py $FDB > $O/${TAG}_pmc_fetch_size.txt
+python tools/rocpd_pmc.py $WDB > $O/${TAG}_pmc_write_size.txt
 python tools/rocpd_mfma.py $(find $O/mfma -name "*.db" | head -1) > $O/${TAG}_pmc_mfma_busy.txt
-python tools/make_pmc_json.py $(find $O/fetch -name "*.db" | head -1) $(find $O/write -name "*.db" | head -1) 26 $O/r01_pmc_traffic.json
-cp $O/r01_pmc_traffic.json profiles/r01_pmc_traffic.json
+python tools/make_profile_json.py $SDB $FDB $WDB $O/${TAG}_profile.json $TAG
+cp $O/${TAG}_profile.json profiles/r02_profile.json
 python bench.py > $O/${TAG}_bench.json 2> $O/bench.err
 python bench.py --steps 30 --warmup 10 --no-cpu-baseline --profile-all 2> $O/${TAG}_hip_event_table.txt > /dev/null
+python bench.py --steps 30 --warmup 10 --no-cpu-baseline --dtype bf16 > $O/${TAG}_bench_bf16_mode.json 2>/dev/null
 rm -rf $O/stats $O/fetch $O/write $O/mfma
-tail -c 1500 $O/${TAG}_bench.json
+tail -c 2500 $O/${TAG}_bench.json

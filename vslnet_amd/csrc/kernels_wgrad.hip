@@ -139,9 +139,10 @@ void launch_wgrad2(const WgradBatch& wb0, hipStream_t s) {
         }
         return;
     }
-    // dynamic LDS is requested only to bound how many of these workgroups share a CU (they would serialise on its matrix pipes
-    // while other CUs idle): VSL_WGRAD_LDS=<bytes>, default 66 KB = two per CU at most, and one beside a 93 KB chain kernel
-    static const size_t pad = getenv("VSL_WGRAD_LDS") ? (size_t)atol(getenv("VSL_WGRAD_LDS")) : (size_t)66 * 1024;
+    // dynamic LDS is requested only to bound how many of these workgroups share a CU (two of them serialise on its matrix pipes
+    // while other CUs idle): VSL_WGRAD_LDS=<bytes>, default 84 KB = one per CU.  Measured at the headline shape, ms/step with
+    // 0 / 66 / 84 / 96 KB: 1.119 / 1.115 / 1.104 / 1.107 (profiles/r02_notes.md)
+    static const size_t pad = getenv("VSL_WGRAD_LDS") ? (size_t)atol(getenv("VSL_WGRAD_LDS")) : (size_t)84 * 1024;
     static size_t ok[4] = {0, 0, 0, 0};
     const void* fn[4] = {(const void*)k_wgrad2<false, false>, (const void*)k_wgrad2<true, false>, (const void*)k_wgrad2<false, true>,
                          (const void*)k_wgrad2<true, true>};
