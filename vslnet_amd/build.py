@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libvslnet_hip.so')
-SOURCES = ['kernels_fwd.hip', 'kernels_bwd.hip', 'kernels_enc.hip', 'kernels_wgrad.hip', 'api.hip']
+SOURCES = ['kernels_fwd.hip', 'kernels_bwd.hip', 'kernels_enc.hip', 'kernels_wgrad.hip', 'kernels_lstm.hip', 'api.hip']
 HEADERS = ['common.hpp', 'launch.hpp', os.path.join('..', '..', 'include', 'vslnet_hip.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value', '-Wno-pass-failed']
 

@@ -2101,6 +2101,8 @@ __global__ __launch_bounds__(1024) void k_lstm_bwd(const float* __restrict__ dou
 void launch_lstm_bwd(const float* dout, const float* dout2, const float* mask, const float* gates, const float* cseq,
                      const float* Whh, float* dG, int B, int T, hipStream_t s, float* carry, int t0, int t1) {
     if (t1 < 0) t1 = T;
+    static const bool four = !(getenv("VSL_LSTM4") && getenv("VSL_LSTM4")[0] == '0');
+    if (four) { launch_lstm4_bwd(dout, dout2, mask, gates, cseq, Whh, dG, B, T, s, carry, t0, t1); return; }
     hipLaunchKernelGGL(k_lstm_bwd, dim3((B + LS_M - 1) / LS_M), dim3(1024), 0, s, dout, dout2, mask, gates, cseq, Whh, dG, B, T, carry,
                        t0, t1);
 }

@@ -1547,6 +1547,8 @@ __global__ __launch_bounds__(1024) void k_lstm_fwd(const float* __restrict__ gi,
 void launch_lstm_fwd(const float* gi, const float* Whh, const float* bih, const float* bhh, const float* mask, float* gates,
                      float* cseq, float* hprev, float* out, int B, int T, hipStream_t s, int t0, int t1) {
     if (t1 < 0) t1 = T;
+    static const bool four = !(getenv("VSL_LSTM4") && getenv("VSL_LSTM4")[0] == '0');
+    if (four) { launch_lstm4_fwd(gi, Whh, bih, bhh, mask, gates, cseq, hprev, out, B, T, s, t0, t1); return; }
     hipLaunchKernelGGL(k_lstm_fwd, dim3((B + LS_M - 1) / LS_M), dim3(1024), 0, s, gi, Whh, bih, bhh, mask, gates, cseq, hprev, out, B, T,
                        t0, t1);
     static int left = 2;

@@ -189,6 +189,11 @@ void launch_lstm_fwd(const float* gi, const float* Whh, const float* bih, const 
 void launch_lstm_bwd(const float* dout, const float* dout2, const float* mask, const float* gates, const float* cseq,
                      const float* Whh, float* dG, int B, int T, hipStream_t s, float* carry = nullptr, int t0 = 0, int t1 = -1);
                      // steps [t0, t1) in reverse; carry (B, 2, 128): dc / dh handed from one time chunk to the next
+// 4-sample-group LSTM kernels (kernels_lstm.hip); launch_lstm_fwd / launch_lstm_bwd dispatch to them unless VSL_LSTM4=0
+void launch_lstm4_fwd(const float* gi, const float* Whh, const float* bih, const float* bhh, const float* mask, float* gates,
+                      float* cseq, float* hprev, float* out, int B, int T, hipStream_t s, int t0, int t1);
+void launch_lstm4_bwd(const float* dout, const float* dout2, const float* mask, const float* gates, const float* cseq,
+                      const float* Whh, float* dG, int B, int T, hipStream_t s, float* carry, int t0, int t1);
 void launch_wgrad(const WgradBatch& wb, hipStream_t s);     // dispatches to launch_wgrad2 (kernels_wgrad.hip) unless VSL_WGRAD2=0
 void launch_wgrad2(const WgradBatch& wb, hipStream_t s);
 void launch_conv_bwd_dwln(const float* du, const float* xin, const float* dy, const float* ln_g, const float* ln_b,
