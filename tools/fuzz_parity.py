@@ -15,13 +15,13 @@ def main(n=24, seed=0):
     rs = np.random.RandomState(seed)
     bad = 0
     for i in range(n):
-        shape = dict(name='fuzz %d' % i, B=int(rs.randint(1, 7)), T=int(rs.choice([4, 7, 16, 31, 32, 33, 50, 64, 97, 128, 160])),
-                     Lq=int(rs.choice([1, 2, 3, 8, 20, 31, 32, 33, 47])), Lc=int(rs.choice([4, 5, 10, 17, 24])),
+        shape = dict(name='fuzz %d' % i, B=int(rs.randint(1, 7)), T=int(rs.choice([4, 7, 16, 31, 32, 33, 40, 50, 64, 97, 128, 160, 256])),
+                     Lq=int(rs.choice([1, 2, 3, 8, 20, 31, 32, 33, 47, 64, 65, 82, 96])), Lc=int(rs.choice([4, 5, 10, 17, 24, 25, 40])),
                      Dv=int(rs.choice([4, 36, 64, 100, 500, 1024])))
         try:
             if i % 4 == 3:                      # every fourth shape goes through the rnn head (chunk-pipelined LSTMs, Dv = 64)
                 # (that test fixes max_pos_len = 128 and has no structural-zero gate for one-word queries)
-                shape = dict(name=shape['name'] + ' rnn', B=shape['B'] * 4 - 1, T=min(shape['T'], 128), Lq=max(shape['Lq'], 2), Lc=shape['Lc'])
+                shape = dict(name=shape['name'] + ' rnn', B=shape['B'] * 4 - 1, T=min(shape['T'], 128), Lq=min(max(shape['Lq'], 2), 128), Lc=shape['Lc'])
                 check_rnn(shape)
             else:
                 check(shape)
