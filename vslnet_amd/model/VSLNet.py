@@ -54,8 +54,10 @@ class _ForwardFn(torch.autograd.Function):
         if ctx.token != model._step:
             raise RuntimeError('VSLNet.backward: another forward ran since this graph was built; the HIP engine keeps the '
                                'saved activations of the latest forward only')
-        g = model._engine.backward(d_h.contiguous(), d_sl.contiguous(), d_el.contiguous(), model._flat_grad)
-        views = model._engine.views(g.clone())
+        # a fresh bucket per backward (autograd keeps what is returned): vsl_backward overwrites every element, so it is neither
+        # zeroed nor copied
+        g = model._engine.backward(d_h.contiguous(), d_sl.contiguous(), d_el.contiguous(), torch.empty_like(model._flat_grad))
+        views = model._engine.views(g)
         return (None,) * 6 + tuple(views[n] for n in model._flat_names)
 
 
