@@ -605,4 +605,21 @@ __device__ __forceinline__ void load_tile128(float* __restrict__ dst, const floa
     }
 }
 
+// Reductions over the four lanes {i, i+16, i+32, i+48} of a wave (the k-groups of one MFMA column), result in all four: gfx950's
+// v_permlane32_swap / v_permlane16_swap exchange half-waves / odd-even rows in the VALU -- no LDS round trip like ds_bpermute.
+__device__ __forceinline__ float kgroup_max(float x) {
+    const unsigned u = __float_as_uint(x);
+    auto a = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const unsigned v = __float_as_uint(fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1])));
+    auto b = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float kgroup_sum(float x) {
+    const unsigned u = __float_as_uint(x);
+    auto a = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const unsigned v = __float_as_uint(__uint_as_float(a[0]) + __uint_as_float(a[1]));
+    auto b = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 }  // namespace vsl

@@ -713,4 +713,176 @@ void launch_convblock_bwd(const CbBwdArgs& a, hipStream_t s) {
 // partial slabs the backward writes per parameter: one per workgroup
 int convblock_slabs(int R, int L) { return L <= TILE_M ? R / L : (R + TILE_M - 1) / TILE_M; }
 
+// =========================================================================================================
+// a8, second and third part in ONE launch (layers_t7.py:174-190): attention core + output block.
+//   workgroup = (32 queries of one sample) x all 8 heads: wave h = head h, two 16-query blocks, lane = one query column (S^T = K Q^T, so
+//   the online softmax is lane-local, as in k_attn_fwd).  K / V fragments come straight from L2 in MFMA operand shape (a key row of a
+//   head is 64 contiguous bytes), one key tile ahead -- no LDS staging, no barrier inside the key loop.  The eight 32 x 16 head outputs
+//   meet in one LDS tile, and the same workgroup finishes the block on it: r = drop(att) + x -> LN2 -> dropout -> Wo GEMM -> dropout -> + r.
+//   Saves att, LSE, r, h2 for the backward exactly like the two-kernel path (VSL_ATTN_BLOCK=0).
+// =========================================================================================================
+__global__ __launch_bounds__(CB_T, 2) void k_attn_block_fwd(AttnBlockArgs a) {
+    __shared__ __attribute__((aligned(16))) float Rs[TILE_M * LDP];          // att, then r = drop(att) + x
+    __shared__ __attribute__((aligned(16))) float Hs[TILE_M * LDP];          // drop(LN2(r)): GEMM A operand
+    __shared__ float Pn[384];                                                 // ln2_g | ln2_b | bo
+    extern __shared__ __attribute__((aligned(16))) float Mb[];               // key bias of the sample, padded to whole key tiles
+    const int tid = threadIdx.x, h = tid >> 6, lane = tid & 63;
+    const int L = a.L, H = 8;
+    const int b = blockIdx.y, q0 = blockIdx.x * TILE_M;
+    const size_t rowbase = (size_t)b * L;
+    const int qi = lane & 15, g = lane >> 4;
+    ESTAMP(0);
+    const int Lp = (L + 15) & ~15;
+    for (int k = tid; k < Lp; k += CB_T) Mb[k] = k < L ? (1.0f - a.mask[rowbase + k]) * MASK_VALUE : MASK_VALUE;
+    // per-wave (= per-head) uniform bases + 32-bit lane offsets, so a fragment load is one saddr + voffset instruction
+    const int hw = __builtin_amdgcn_readfirstlane(h);
+    const float* __restrict__ Qh = a.Q + rowbase * D + hw * HD;
+    const float* __restrict__ Kh = a.K + rowbase * D + hw * HD;
+    const float* __restrict__ Vh = a.V + rowbase * D + hw * HD;
+    float4 qf[2];
+    float m[2], l[2];
+    f32x4 o[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int q = q0 + 16 * qb + qi;
+        qf[qb] = q < L ? *reinterpret_cast<const float4*>(Qh + (unsigned)(q * D + 4 * g)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        m[qb] = -3.0e38f; l[qb] = 0.f; o[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float scale = 0.25f;                    // 1 / sqrt(16), applied AFTER QK^T like the reference (:175)
+    // operands of one key tile: K row (kt + qi), cols 4g..4g+3 ; V[kt + 4g + r][qi] ; key bias of keys kt + 4g + r (LDS)
+    struct KT { float4 kf; float vv[4]; float4 mb; };
+    const unsigned koff = (unsigned)(qi * D + 4 * g), voff = (unsigned)(4 * g * D + qi);
+    auto load_kt = [&](int kt, KT& t) {
+        if (kt + 16 <= L) {                                       // whole tile: no clamps, constant row strides fold into the instruction
+            t.kf = *reinterpret_cast<const float4*>(Kh + (koff + (unsigned)(kt * D)));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t.vv[r] = Vh[voff + (unsigned)(kt * D) + (unsigned)(r * D)];
+        } else {                                                  // ragged last tile: rows past L read row L - 1 (masked by the key bias)
+            t.kf = *reinterpret_cast<const float4*>(Kh + (unsigned)(min(kt + qi, L - 1) * D + 4 * g));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t.vv[r] = Vh[(unsigned)(min(kt + 4 * g + r, L - 1) * D + qi)];
+        }
+    };
+    KT cur, nxt;
+    load_kt(0, cur);
+    // not needed before the output stage: out_layer fragments, the residual rows x, LN2 / bias vectors
+    BF16 bf[1];
+    bf16_load(bf[0], a.Wpack, D, 16 * h);
+    float4 xv[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int e = tid + q * CB_T, rr = e >> 5, c = (e & 31) * 4;
+        xv[q] = q0 + rr < L ? *reinterpret_cast<const float4*>(a.x + (rowbase + q0 + rr) * D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (tid < 384) Pn[tid] = tid < 128 ? a.ln_g[tid] : tid < 256 ? a.ln_b[tid - 128] : a.bo[tid - 256];
+    __syncthreads();
+    cur.mb = *reinterpret_cast<const float4*>(&Mb[4 * g]);
+    ESTAMP(1);
+    for (int kt = 0; kt < Lp; kt += 16) {
+        if (kt + 16 < Lp) { load_kt(kt + 16, nxt); nxt.mb = *reinterpret_cast<const float4*>(&Mb[kt + 16 + 4 * g]); }
+        __builtin_amdgcn_sched_barrier(0);
+        const float mbv[4] = {cur.mb.x, cur.mb.y, cur.mb.z, cur.mb.w};
+        f32x4 s[2];
+        float p[2][4], alpha[2];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            s[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            s[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.kf.x, qf[qb].x, s[qb], 0, 0, 0);
+            s[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.kf.y, qf[qb].y, s[qb], 0, 0, 0);
+            s[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.kf.z, qf[qb].z, s[qb], 0, 0, 0);
+            s[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.kf.w, qf[qb].w, s[qb], 0, 0, 0);
+        }
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            float tmax = -3.0e38f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { p[qb][r] = s[qb][r] * scale + mbv[r]; tmax = fmaxf(tmax, p[qb][r]); }
+            const float mn = fmaxf(m[qb], kgroup_max(tmax));
+            alpha[qb] = __expf(m[qb] - mn);
+            m[qb] = mn;
+            l[qb] *= alpha[qb];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                p[qb][r] = __expf(p[qb][r] - mn);
+                l[qb] += p[qb][r];
+                o[qb][r] *= alpha[qb];
+            }
+        }
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            const int q = q0 + 16 * qb + qi;
+            const uint32_t pbase = (uint32_t)(((size_t)(b + a.b_off) * H + h) * L + q) * (uint32_t)L + (uint32_t)(kt + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p[qb][r] *= drop_mul(a.d2, pbase + r);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) o[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.vv[r], p[qb][r], o[qb], 0, 0, 0);
+        cur = nxt;
+    }
+    ESTAMP(2);
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const float lt = kgroup_sum(l[qb]);
+        const int q = q0 + 16 * qb + qi;
+        const float inv = 1.0f / lt;
+        const float4 ov = make_float4(o[qb][0] * inv, o[qb][1] * inv, o[qb][2] * inv, o[qb][3] * inv);   // lane (qi, g): O[q][4g + reg]
+        *reinterpret_cast<float4*>(&Rs[(16 * qb + qi) * LDP + h * HD + 4 * g]) = ov;
+        if (q < L) {
+            *reinterpret_cast<float4*>(a.att + (rowbase + q) * D + h * HD + 4 * g) = ov;
+            if (g == 0) a.lse[((size_t)b * H + h) * L + q] = m[qb] + __logf(lt);
+        }
+    }
+    __syncthreads();
+    ESTAMP(3);
+    // ---- r = drop(att) + x (:183-184)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int e = tid + q * CB_T, rr = e >> 5, c = (e & 31) * 4;
+        const int r = (int)rowbase + q0 + rr;
+        float4 v = *reinterpret_cast<const float4*>(&Rs[rr * LDP + c]);
+        if (q0 + rr < L) {
+            const uint32_t base = (uint32_t)(r * D + c);
+            v.x = v.x * drop_mul(a.d3, base) + xv[q].x; v.y = v.y * drop_mul(a.d3, base + 1) + xv[q].y;
+            v.z = v.z * drop_mul(a.d3, base + 2) + xv[q].z; v.w = v.w * drop_mul(a.d3, base + 3) + xv[q].w;
+            *reinterpret_cast<float4*>(a.r_out + (size_t)r * D + c) = v;
+        } else v = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(&Rs[rr * LDP + c]) = v;
+    }
+    __syncthreads();
+    ESTAMP(4);
+    ln_rows512(Rs, Hs, TILE_M, Pn, Pn + 128, a.d4, (int)rowbase + q0);
+    __syncthreads();
+    ESTAMP(5);
+    if (a.h2_out) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int e = tid + q * CB_T, rr = e >> 5, c = (e & 31) * 4;
+            if (q0 + rr < L) *reinterpret_cast<float4*>(a.h2_out + (rowbase + q0 + rr) * D + c) = *reinterpret_cast<const float4*>(&Hs[rr * LDP + c]);
+        }
+    }
+    f32x4 acc[1][2];
+    acc[0][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[0][1] = acc[0][0];
+    gemm16<2, 1>(Hs, LDP, bf, acc);
+    const int col = 16 * h + qi;
+    const float bv = Pn[256 + col];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int row = 16 * rb + 4 * g + rr;
+            if (q0 + row < L) {
+                const int r = (int)rowbase + q0 + row;
+                a.y_out[(size_t)r * D + col] = (acc[0][rb][rr] + bv) * drop_mul(a.d5, (uint32_t)(r * D + col)) + Rs[row * LDP + col];
+            }
+        }
+    ESTAMP(6);
+}
+void launch_attn_block_fwd(const AttnBlockArgs& a, int B, hipStream_t s) {
+    hipLaunchKernelGGL(k_attn_block_fwd, dim3((a.L + TILE_M - 1) / TILE_M, B), dim3(CB_T), (size_t)((a.L + 15) & ~15) * sizeof(float), s, a);
+    static int left = 3;
+    if (edbg_on() && B > 16) edbg_report("attn_block_fwd", 7, s, left);
+}
+
 }  // namespace vsl

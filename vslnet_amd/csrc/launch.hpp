@@ -163,6 +163,15 @@ void launch_attn_fwd(const float* Q, const float* K, const float* V, const float
 void launch_attn_out_fwd(const float* att, const float* x, const float* ln_g, const float* ln_b, const float* Wpack,
                          const float* bo, float* r_out, float* h2_out, float* y_out, int R, Drop d3, Drop d4, Drop d5,
                          hipStream_t s);
+// attention core + output block of one encoder application in one launch (kernels_enc.hip)
+struct AttnBlockArgs {
+    const float *Q, *K, *V, *mask, *x;            // q, k, v (R,128) ; key mask (B, L) ; residual input x = conv-block output
+    const float *ln_g, *ln_b, *Wpack, *bo;         // LN2, out_layer (forward pack), its bias
+    float *att, *lse, *r_out, *h2_out, *y_out;     // saved: att (R,128), LSE (B,H,L), r, h2 ; y = block output
+    int L, b_off;
+    Drop d2, d3, d4, d5;
+};
+void launch_attn_block_fwd(const AttnBlockArgs& a, int B, hipStream_t s);
 void launch_cq_score(const float* C, const float* Qf, const float* qmask, const float* w4C, const float* w4Q,
                      const float* w4mlu, float* S, float* Srow, int B, int T, int Lq, int b_off, Drop dc, Drop dq,
                      hipStream_t s);
