@@ -206,7 +206,8 @@ __global__ __launch_bounds__(512, 2) void k_lstm4_bwd(const float* __restrict__ 
 //   lane (u = 16 w + b, j): gate column j * 128 + u, W_hh row in 128 registers; h is read from LDS as wave-uniform broadcasts.
 //   the four gates of a unit sit in one quad: each lane activates ITS gate (tanh(x) = 2 sigmoid(2x) - 1, the same formula tanh_fast
 //   uses), DPP quad broadcasts hand all four to every lane, the cell update is computed redundantly by the quad -- no LDS transposition.
-//   backward: wave w contracts gate rows 128 (w >> 1) .. + 127 into columns 64 (w & 1) + lane; the four partial rows meet in LDS.
+//   backward: lane (u, j) contracts gate rows 128 j .. + 127 into column u and the quad adds its four slices with DPP: one LDS
+//   exchange (the step's 512 gate gradients) and one barrier per step; everything a step loads is fetched a step ahead.
 // Used for B <= 256 (VSL_LSTM1=0 keeps the 4-sample kernels); saved tensors, chunk / carry interface identical.
 // =========================================================================================================
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -276,38 +277,49 @@ __global__ __launch_bounds__(512, 2) void k_lstm1_bwd(const float* __restrict__ 
                                                       const float* __restrict__ mask, const float* __restrict__ gates,
                                                       const float* __restrict__ cseq, const float* __restrict__ Whh,
                                                       float* __restrict__ dG, int T, float* __restrict__ carry, int t0, int t1) {
-    __shared__ __attribute__((aligned(16))) float dGs[4 * D];             // gate gradients of the step
-    __shared__ __attribute__((aligned(16))) float Pp[4][D];               // partial rows of dh_{t-1}, one per 128-row slice
+    __shared__ __attribute__((aligned(16))) float dGs[2][4 * L4_HP];      // gate gradients of the step, one padded row per gate (double-buffered: one barrier per step)
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int b = lane >> 2, j = lane & 3;
-    const int u = 16 * w + b;                             // cell u, this lane's gate j
-    const int kq = w >> 1, n = 64 * (w & 1) + lane;       // product: rows 128 kq .. + 127, column n
+    const int u = 16 * w + b;                             // cell u ; this lane's gate j ; product: rows 128 j .. + 127 into column u
     const int bb = blockIdx.x;
-    f32x2 wr[D / 2];                                      // W_hh[128 kq + 2 i .. + 1][n]
+    f32x2 wr[D / 2];                                      // W_hh[128 j + 2 i .. + 1][u]
 #pragma unroll
-    for (int i = 0; i < D / 2; ++i) wr[i] = f32x2{Whh[(size_t)(128 * kq + 2 * i) * D + n], Whh[(size_t)(128 * kq + 2 * i + 1) * D + n]};
+    for (int i = 0; i < D / 2; ++i) wr[i] = f32x2{Whh[(size_t)(128 * j + 2 * i) * D + u], Whh[(size_t)(128 * j + 2 * i + 1) * D + u]};
     float dcn = 0.f, dhr = 0.f;
     if (t1 < T) { dcn = carry[((size_t)bb * 2 + 0) * D + u]; dhr = carry[((size_t)bb * 2 + 1) * D + u]; }
+    // everything a step reads from memory is independent of the recurrence: fetched one step ahead
+    float n_do, n_mk, n_act, n_cp;
+    auto fetch = [&](int t) {
+        const int tt = max(t, 0);
+        const unsigned base = (unsigned)(bb * T + tt);
+        n_do = dout[base * D + u];
+        if (dout2) n_do += dout2[base * D + u];
+        n_mk = mask[base];
+        n_act = gates[base * (4 * D) + j * D + u];
+        n_cp = tt > 0 ? cseq[(base - 1) * D + u] : 0.f;
+    };
+    float ct = cseq[(unsigned)((bb * T + t1 - 1) * D + u)];
+    fetch(t1 - 1);
     for (int t = t1 - 1; t >= t0; --t) {
         const unsigned base = (unsigned)(bb * T + t);
-        float dh = dout[base * D + u];
-        if (dout2) dh += dout2[base * D + u];
-        dh *= mask[base];
+        const int cur = t & 1;
+        float dh = n_do * n_mk;
+        const float act = n_act, cp = n_cp;
+        fetch(t - 1);
         if (t < T - 1) dh += dhr;
-        const float act = gates[base * (4 * D) + j * D + u];
         const float ig = quad_bcast<0>(act), fg = quad_bcast<1>(act), gg = quad_bcast<2>(act), og = quad_bcast<3>(act);
-        const float ct = cseq[base * D + u], cp = t > 0 ? cseq[(base - 1) * D + u] : 0.f;
         const float tc = tanh_fast(ct);
         const float dc = dh * og * (1.f - tc * tc) + dcn;
         const float dv = j == 0 ? dc * gg * ig * (1.f - ig) : j == 1 ? dc * cp * fg * (1.f - fg) : j == 2 ? dc * ig * (1.f - gg * gg)
                                                                                                          : dh * tc * og * (1.f - og);
         dcn = dc * fg;
-        dGs[j * D + u] = dv;
+        ct = cp;
+        dGs[cur][j * L4_HP + u] = dv;
         dG[base * (4 * D) + j * D + u] = dv;
         if (t == 0) break;                               // dh_{-1} is not needed
         __syncthreads();
         f32x2 a0 = {0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
-        const float4* gp = reinterpret_cast<const float4*>(dGs + 128 * kq);
+        const float4* gp = reinterpret_cast<const float4*>(dGs[cur] + L4_HP * j);
 #pragma unroll
         for (int q = 0; q < D / 8; ++q) {
             const float4 g0 = gp[2 * q], g1 = gp[2 * q + 1];
@@ -317,9 +329,10 @@ __global__ __launch_bounds__(512, 2) void k_lstm1_bwd(const float* __restrict__ 
             a3 = __builtin_elementwise_fma(f32x2{g1.z, g1.w}, wr[4 * q + 3], a3);
         }
         const f32x2 as = (a0 + a1) + (a2 + a3);
-        Pp[kq][n] = as.x + as.y;
-        __syncthreads();
-        dhr = (Pp[0][u] + Pp[1][u]) + (Pp[2][u] + Pp[3][u]);              // fixed order: deterministic
+        float pr = as.x + as.y;                                            // rows 128 j .. + 127 ; the quad holds the four slices
+        pr += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(pr), 0xB1, 0xF, 0xF, false));   // lanes (0,1) (2,3)
+        pr += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(pr), 0x4E, 0xF, 0xF, false));   // pairs: same value in all four lanes
+        dhr = pr;
     }
     if (t0 > 0 && j == 0) {
         carry[((size_t)bb * 2 + 0) * D + u] = dcn;
