@@ -469,7 +469,7 @@ void enc_fwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float*
         LAUNCH("ln_qkv_fwd", launch_ln_qkv_fwd(c.W(w.y[3]), c.P(P.ln1g), c.P(P.ln1b), c.PK(K.qkv_f), c.P(P.qb), c.P(P.kb), c.P(P.vb), c.W(w.h1),
                           c.W(w.q), c.W(w.k), c.W(w.v), R, c.drop(app * 16 + 4), c.s));
     static const bool attn_block = !(getenv("VSL_ATTN_BLOCK") && getenv("VSL_ATTN_BLOCK")[0] == '0');
-    if (attn_block && H == 8) {
+    if (attn_block && H == 8 && L <= 256) {      // longer sequences: K / V staged in LDS per 64 queries wins (T = 1024: 3.29 vs 3.33 ms)
         AttnBlockArgs ab{c.W(w.q), c.W(w.k), c.W(w.v), mask, c.W(w.y[3]), c.P(P.ln2g), c.P(P.ln2b), c.PK(K.o_f), c.P(P.ob),
                          c.W(w.att), c.W(w.lse), c.W(w.r), c.W(w.h2), c.W(w.out), L, 0,
                          c.drop(app * 16 + 5), c.drop(app * 16 + 6), c.drop(app * 16 + 7), c.drop(app * 16 + 8)};

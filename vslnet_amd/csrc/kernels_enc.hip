@@ -728,7 +728,9 @@ __global__ __launch_bounds__(CB_T, 2) void k_attn_block_fwd(AttnBlockArgs a) {
     extern __shared__ __attribute__((aligned(16))) float Mb[];               // key bias of the sample, padded to whole key tiles
     const int tid = threadIdx.x, h = tid >> 6, lane = tid & 63;
     const int L = a.L, H = 8;
-    const int b = blockIdx.y, q0 = blockIdx.x * TILE_M;
+    int bxs, b, bzs;
+    xcd_swizzle(bxs, b, bzs);                       // the query tiles of a sample on one XCD: its K / V rows sit in one L2
+    const int q0 = bxs * TILE_M;
     const size_t rowbase = (size_t)b * L;
     const int qi = lane & 15, g = lane >> 4;
     ESTAMP(0);
