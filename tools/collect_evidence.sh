@@ -25,5 +25,8 @@ cp $O/${TAG}_profile.json profiles/r02_profile.json
 python bench.py > $O/${TAG}_bench.json 2> $O/bench.err
 python bench.py --steps 30 --warmup 10 --no-cpu-baseline --profile-all 2> $O/${TAG}_hip_event_table.txt > /dev/null
 python bench.py --steps 30 --warmup 10 --no-cpu-baseline --dtype bf16 > $O/${TAG}_bench_bf16_mode.json 2>/dev/null
+python bench.py --steps 30 --warmup 10 --no-cpu-baseline --predictor rnn --batch 16 > $O/${TAG}_bench_rnn_b16_configs0.json 2>/dev/null
+python bench.py --steps 30 --warmup 10 --no-cpu-baseline --predictor rnn --batch 64 > $O/${TAG}_bench_rnn_b64.json 2>/dev/null
+bash tools/bench_shapes.sh > $O/${TAG}_bench_shapes.txt 2>/dev/null
 rm -rf $O/stats $O/fetch $O/write $O/mfma
 tail -c 2500 $O/${TAG}_bench.json
