@@ -18,25 +18,6 @@
 
 namespace vsl {
 
-__device__ long long g_stamps_l[16];
-__device__ int g_dbg_on_l = 0;
-#define LSTAMP(k) do { if (g_dbg_on_l && blockIdx.x == 0 && threadIdx.x == 0 && t == t0 + 6) g_stamps_l[k] = clock64(); } while (0)
-static int ldbg_on() {
-    static int inited = 0, on = 0;
-    if (!inited) { inited = 1; on = getenv("VSL_DEBUG_TIMING") != nullptr; if (on) { int one = 1; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_on_l), &one, sizeof one); } }
-    return on;
-}
-static void ldbg_report(const char* name, int nst, hipStream_t s, int& left) {
-    if (left <= 0) return;
-    long long h[16];
-    (void)hipStreamSynchronize(s);
-    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamps_l), sizeof h);
-    fprintf(stderr, "[%s cycles]", name);
-    for (int i = 1; i < nst; ++i) fprintf(stderr, " %lld", h[i] - h[i - 1]);
-    fprintf(stderr, " | total %lld\n", h[nst - 1] - h[0]);
-    --left;
-}
-
 constexpr int L4_HP = D + 4;            // LDS row stride of h / partial tiles
 constexpr int L4_GP = 4 * D + 4;        // LDS row stride of the gate-gradient rows
 
@@ -99,7 +80,6 @@ __global__ __launch_bounds__(512, 2) void k_lstm4_fwd(const float* __restrict__ 
     float* zw = zs[w];
     for (int t = t0; t < t1; ++t) {
         const int cur = t & 1;
-        LSTAMP(0);
         f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
         if (t > 0) {
             const float* hrow = &hs[cur][j * L4_HP + 8 * b];              // A operand: block b = h[samples 0-3][8 b .. 8 b + 7]
@@ -110,7 +90,6 @@ __global__ __launch_bounds__(512, 2) void k_lstm4_fwd(const float* __restrict__ 
         // register r = pre-activation of gate j, unit u, sample r  ->  scratch [sample][unit][gate]  ->  lane reads its sample's 4 gates
 #pragma unroll
         for (int r = 0; r < 4; ++r) zw[r * 64 + lane] = (a0[r] + a1[r]) + (a2[r] + a3[r]);
-        LSTAMP(1);
         const float4 z = *reinterpret_cast<const float4*>(&zw[(j * 16 + b) * 4]);
         const float ig = sigmoid_fast(z.x + Gc[0] + bsum[0]), fg = sigmoid_fast(z.y + Gc[1] + bsum[1]);
         const float gg = tanh_fast(z.z + Gc[2] + bsum[2]), og = sigmoid_fast(z.w + Gc[3] + bsum[3]);
@@ -118,7 +97,6 @@ __global__ __launch_bounds__(512, 2) void k_lstm4_fwd(const float* __restrict__ 
         const float hn = og * tanh_fast(cn);
         cst = cn;
         hs[cur ^ 1][j * L4_HP + u] = hn;
-        LSTAMP(2);
         if (ok) {
             const unsigned base = (unsigned)(row + t);
             float* gp = gates + base * (4 * D) + u;
@@ -128,11 +106,8 @@ __global__ __launch_bounds__(512, 2) void k_lstm4_fwd(const float* __restrict__ 
             if (t == 0) hprev[base * D + u] = 0.f;
             if (t + 1 < T) hprev[(base + 1) * D + u] = hn;
         }
-        LSTAMP(3);
         gi_load(t + 1);
-        LSTAMP(4);
         __syncthreads();
-        LSTAMP(5);
     }
 }
 
@@ -208,6 +183,8 @@ __global__ __launch_bounds__(512, 2) void k_lstm4_bwd(const float* __restrict__ 
 //   uses), DPP quad broadcasts hand all four to every lane, the cell update is computed redundantly by the quad -- no LDS transposition.
 //   backward: lane (u, j) contracts gate rows 128 j .. + 127 into column u and the quad adds its four slices with DPP: one LDS
 //   exchange (the step's 512 gate gradients) and one barrier per step; everything a step loads is fetched a step ahead.
+//   (Tried: h through DPP row_newbcast into v_fmac_f32_dpp -- 2 LDS reads per lane and step instead of 32 -- is no faster: 128 vs 118 us,
+//   the DPP FMAs issue at half rate; profiles/r02_notes.md.)
 // Used for B <= 256 (VSL_LSTM1=0 keeps the 4-sample kernels); saved tensors, chunk / carry interface identical.
 // =========================================================================================================
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -235,7 +212,15 @@ __global__ __launch_bounds__(512, 2) void k_lstm1_fwd(const float* __restrict__ 
     const float sc = j == 2 ? 2.0f : 1.0f;               // gate 2 is the tanh gate
     float cst = t0 > 0 ? cseq[(unsigned)((row + t0 - 1) * D + u)] : 0.f;
     if (j == 0) hs[t0 & 1][u] = t0 > 0 ? hprev[(unsigned)((row + t0) * D + u)] : 0.f;
-    float Gc = gi[(unsigned)((row + t0) * (4 * D) + j * D + u)], Mk = mask[row + t0];
+    if (j == 3 && t0 == 0) hprev[(unsigned)(row * D + u)] = 0.f;
+    // per-lane cursors, advanced by one time step per iteration: the loop holds no address arithmetic beyond the increments.
+    // One store per step carries the lane's activated gate; a second one the quad's cell results (lane j = 0: c_t, 1: masked h_t, 2: h_t as
+    // next step's hprev row).
+    const float* gip = gi + (size_t)(row + t0) * (4 * D) + j * D + u;
+    float* gtp = gates + (size_t)(row + t0) * (4 * D) + j * D + u;
+    float* qp = (j == 0 ? cseq : j == 1 ? out : hprev + D) + (size_t)(row + t0) * D + u;
+    const float* mkp = mask + row;
+    float Gc = *gip, Mk = mkp[t0];
     __syncthreads();
     for (int t = t0; t < t1; ++t) {
         const int cur = t & 1;
@@ -260,15 +245,16 @@ __global__ __launch_bounds__(512, 2) void k_lstm1_fwd(const float* __restrict__ 
         const float hn = og * tanh_fast(cn);
         cst = cn;
         if (j == 0) hs[cur ^ 1][u] = hn;
-        const unsigned base = (unsigned)(row + t);
-        gates[base * (4 * D) + j * D + u] = act;
-        if (j == 0) cseq[base * D + u] = cn;
-        if (j == 1) out[base * D + u] = hn * Mk;
-        if (j == 2 && t + 1 < T) hprev[(base + 1) * D + u] = hn;
-        if (j == 3 && t == 0) hprev[base * D + u] = 0.f;
-        const int tn = min(t + 1, T - 1);
-        Gc = gi[(unsigned)((row + tn) * (4 * D) + j * D + u)];
-        Mk = mask[row + tn];
+        *gtp = act;
+        gtp += 4 * D;
+        const float qv = j == 0 ? cn : j == 1 ? hn * Mk : hn;
+        if (j < 2 || (j == 2 && t + 1 < T)) *qp = qv;
+        qp += D;
+        if (t + 1 < T) {                                  // uniform
+            gip += 4 * D;
+            Gc = *gip;
+            Mk = mkp[t + 1];
+        }
         __syncthreads();
     }
 }
@@ -352,8 +338,6 @@ void launch_lstm4_fwd(const float* gi, const float* Whh, const float* bih, const
         return;
     }
     hipLaunchKernelGGL(k_lstm4_fwd, dim3((B + 3) / 4), dim3(512), 0, s, gi, Whh, bih, bhh, mask, gates, cseq, hprev, out, B, T, t0, t1);
-    static int left = 4;
-    if (ldbg_on() && t1 - t0 > 8) ldbg_report("lstm4_fwd step 6: h + MFMA + scratch write | gates | stores | gi issue | barrier", 6, s, left);
 }
 void launch_lstm4_bwd(const float* dout, const float* dout2, const float* mask, const float* gates, const float* cseq,
                       const float* Whh, float* dG, int B, int T, hipStream_t s, float* carry, int t0, int t1) {
