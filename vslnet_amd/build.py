@@ -28,11 +28,15 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False, csrc=None, out=None):
+def build(force=False, verbose=False, csrc=None, out=None, stamps=False):
     """Compile every HIP translation unit for gfx950 and link the shared library.  Returns its path.
-    `csrc` / `out` build another source tree into another file (baseline builds for same-box A/B runs)."""
+    `csrc` / `out` build another source tree into another file (baseline builds for same-box A/B runs).
+    `stamps=True` builds lib/libvslnet_hip_stamps.so with the in-kernel phase stamps compiled in (-DVSL_STAMPS; run with
+    VSLNET_HIP_LIB=<that file> VSL_DEBUG_TIMING=1): the product library carries none, a disabled stamp still costs a memory round trip."""
+    if stamps and out is None:
+        out = os.path.join(LIBDIR, 'libvslnet_hip_stamps.so')
     src_dir, lib = csrc or CSRC, out or LIB
-    if csrc is None and not force and not _stale():
+    if csrc is None and out is None and not force and not _stale():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = _hipcc()
@@ -40,7 +44,7 @@ def build(force=False, verbose=False, csrc=None, out=None):
 
     def cc(src):
         obj = os.path.join(LIBDIR, src.replace('.hip', tag + '.o'))
-        cmd = [hipcc] + FLAGS + os.environ.get('VSL_EXTRA_HIPCC_FLAGS', '').split() + ['-c', os.path.join(src_dir, src), '-o', obj]
+        cmd = [hipcc] + FLAGS + (['-DVSL_STAMPS'] if stamps else []) + os.environ.get('VSL_EXTRA_HIPCC_FLAGS', '').split() + ['-c', os.path.join(src_dir, src), '-o', obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('hipcc failed for %s:\n%s' % (src, r.stderr[-4000:]))
@@ -57,4 +61,4 @@ def build(force=False, verbose=False, csrc=None, out=None):
 
 
 if __name__ == '__main__':
-    print(build(force='--force' in sys.argv, verbose=True))
+    print(build(force='--force' in sys.argv, verbose=True, stamps='--stamps' in sys.argv))

@@ -11,7 +11,15 @@ namespace vsl {
 
 // VSL_DEBUG_TIMING: block 0 / thread 0 of an instrumented kernel stamps the shader clock at its phase boundaries
 __device__ long long g_stamps[32];
+// The stamps are compiled in only with -DVSL_STAMPS (vslnet_amd.build.build(stamps=True) -> libvslnet_hip_stamps.so): even a disabled
+// stamp reads its enable flag from memory and waits for it (vmcnt(0)), which drains every prefetch in flight at that point.
+#ifdef VSL_STAMPS
 #define STAMP(k) do { if (g_dbg_on && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_stamps[k] = clock64(); } while (0)
+#define STAMPS_ON(expr) (expr)
+#else
+#define STAMP(k) do { } while (0)
+#define STAMPS_ON(expr) false
+#endif
 __device__ int g_dbg_on = 0;
 static int dbg_budget(const char* name) {
     static int inited = 0, on = 0;
@@ -336,7 +344,7 @@ __global__ __launch_bounds__(512) void k_wgrad(WgradBatch wb) {
     };
     using T_ = std::true_type;
     using F_ = std::false_type;
-    const bool st = g_dbg_on && blockIdx.x == 0 && threadIdx.x == 0;
+    const bool st = STAMPS_ON(g_dbg_on && blockIdx.x == 0 && threadIdx.x == 0);
     if (st) g_stamps[0] = clock64();
     // Pipeline: while tile i is multiplied out of LDS, tile i+1 (already in registers, requested one step earlier) is
     // written to the other LDS buffer and tile i+2 is requested from memory, all between the MFMA batches.

@@ -21,8 +21,15 @@ namespace vsl {
 
 __device__ long long g_stamps_e[32];
 __device__ int g_dbg_on_e = 0;
+#ifdef VSL_STAMPS       // see kernels_bwd.hip: stamps are a separate build
 #define ESTAMP(k) do { if (g_dbg_on_e && blockIdx.x == 0 && threadIdx.x == 0) g_stamps_e[k] = clock64(); } while (0)
+#else
+#define ESTAMP(k) do { } while (0)
+#endif
 static int edbg_on() {
+#ifndef VSL_STAMPS
+    return 0;
+#endif
     static int inited = 0, on = 0;
     if (!inited) { inited = 1; on = getenv("VSL_DEBUG_TIMING") != nullptr; if (on) { int one = 1; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_on_e), &one, sizeof one); } }
     return on;

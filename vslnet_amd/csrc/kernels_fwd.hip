@@ -9,8 +9,15 @@ namespace vsl {
 // VSL_DEBUG_TIMING: block 0 / thread 0 of an instrumented kernel stamps the shader clock at its phase boundaries
 __device__ long long g_stamps_f[32];
 __device__ int g_dbg_on_f = 0;
+#ifdef VSL_STAMPS       // see kernels_bwd.hip: stamps are a separate build
 #define FSTAMP(k) do { if (g_dbg_on_f && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_stamps_f[k] = clock64(); } while (0)
+#else
+#define FSTAMP(k) do { } while (0)
+#endif
 static int fdbg_on() {
+#ifndef VSL_STAMPS
+    return 0;
+#endif
     static int inited = 0, on = 0;
     if (!inited) { inited = 1; on = getenv("VSL_DEBUG_TIMING") != nullptr; if (on) { int one = 1; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_on_f), &one, sizeof one); } }
     return on;
