@@ -98,6 +98,17 @@ struct vsl_handle_s {
     hipStream_t side[2] = {nullptr, nullptr};
     std::vector<hipEvent_t> sync_pool;
     size_t sync_used = 0;
+    // stop events riding on the kernel dispatches of the current call (launch.hpp VSL_LAUNCH); last one per stream
+    std::vector<hipEvent_t> stop_pool;
+    size_t stop_used = 0;
+    bool stop_events = false;
+    hipStream_t ev_stream[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_last[4] = {nullptr, nullptr, nullptr, nullptr};
+    int ev_n = 0;
+    hipEvent_t last_event(hipStream_t s) const {
+        for (int i = 0; i < ev_n; ++i) if (ev_stream[i] == s) return ev_last[i];
+        return nullptr;
+    }
     bool multi_stream = true;
     // optional per-kernel timing with HIP events on the launch stream (vsl_profile_*), used by bench.py's roofline line
     bool prof_on = false;
@@ -303,6 +314,18 @@ void plan_encoder(Bump& al, EncWs& w, int Bn, int L, int H) {
     w.att = al(R * D); w.r = al(R * D); w.h2 = al(R * D); w.out = al(R * D);
 }
 
+// the handle whose call is enqueuing kernels on this thread (set for the duration of vsl_forward / vsl_backward)
+static thread_local vsl_handle_s* g_cur = nullptr;
+struct CallScope {
+    explicit CallScope(vsl_handle_s* h) {
+        static const bool off = getenv("VSL_STOP_EVENTS") && getenv("VSL_STOP_EVENTS")[0] == '0';
+        h->sync_used = 0; h->stop_used = 0; h->ev_n = 0;
+        h->stop_events = h->multi_stream && !off && !h->prof_on;
+        g_cur = h;
+    }
+    ~CallScope() { g_cur = nullptr; }
+};
+
 struct Ctx {
     vsl_handle_s* h;
     Plan* p;
@@ -338,6 +361,7 @@ struct Ctx {
     // make stream `to` wait for everything enqueued so far on stream `from`
     void order(hipStream_t from, hipStream_t to) {
         if (dry || from == to) return;
+        if (hipEvent_t le = h->last_event(from)) { (void)hipStreamWaitEvent(to, le, 0); return; }   // rides on from's last kernel
         if (h->sync_used == h->sync_pool.size()) { hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); h->sync_pool.push_back(e); }
         hipEvent_t e = h->sync_pool[h->sync_used++];
         (void)hipEventRecord(e, from);
@@ -346,6 +370,11 @@ struct Ctx {
     // one event record on `from`, two waiters
     void order2(hipStream_t from, hipStream_t to1, hipStream_t to2) {
         if (dry) return;
+        if (hipEvent_t le = h->last_event(from)) {
+            if (to1 != from) (void)hipStreamWaitEvent(to1, le, 0);
+            if (to2 != from && to2 != to1) (void)hipStreamWaitEvent(to2, le, 0);
+            return;
+        }
         if (h->sync_used == h->sync_pool.size()) { hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); h->sync_pool.push_back(e); }
         hipEvent_t e = h->sync_pool[h->sync_used++];
         (void)hipEventRecord(e, from);
@@ -1100,6 +1129,20 @@ int check_io(vsl_handle_s* h, const vsl_io* io) {
 
 }  // namespace
 
+namespace vsl {
+hipEvent_t vsl_stop_event(hipStream_t s) {
+    vsl_handle_s* h = g_cur;
+    if (!h || !h->stop_events) return nullptr;
+    int i = 0;
+    while (i < h->ev_n && h->ev_stream[i] != s) ++i;
+    if (i == h->ev_n) { if (h->ev_n == 4) return nullptr; h->ev_stream[h->ev_n++] = s; }
+    if (h->stop_used == h->stop_pool.size()) { hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); h->stop_pool.push_back(e); }
+    hipEvent_t e = h->stop_pool[h->stop_used++];
+    h->ev_last[i] = e;
+    return e;
+}
+}  // namespace vsl
+
 // =================================================================================================== C ABI
 extern "C" {
 
@@ -1152,6 +1195,7 @@ int vsl_destroy(vsl_handle h) {
     if (!h) return 0;
     for (int k = 0; k < 2; ++k) if (h->side[k]) (void)hipStreamDestroy(h->side[k]);
     for (hipEvent_t e : h->sync_pool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->stop_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->prof_pool) (void)hipEventDestroy(e);
     for (auto& kv : h->plans) {
         if (kv.second->segs_dev) (void)hipFree(kv.second->segs_dev);
@@ -1229,7 +1273,7 @@ int vsl_forward(vsl_handle h, const vsl_io* io, void* hip_stream) {
     if (int rc = get_plan(h, io->B, io->T, io->Lq, io->Lc, &p)) return rc;
     Ctx c{h, p, io, (hipStream_t)hip_stream, false, io->workspace};
     c.main = c.s;
-    h->sync_used = 0;
+    CallScope scope(h);
     run_forward(c);
     HIP_OK(hipGetLastError());
     return 0;
@@ -1256,7 +1300,7 @@ int vsl_backward(vsl_handle h, const vsl_io* io, void* hip_stream) {
     if (int rc = get_plan(h, io->B, io->T, io->Lq, io->Lc, &p)) return rc;
     Ctx c{h, p, io, (hipStream_t)hip_stream, false, io->workspace};
     c.main = c.s;
-    h->sync_used = 0;
+    CallScope scope(h);
     run_backward(c);
     HIP_OK(hipGetLastError());
     return 0;

@@ -143,12 +143,12 @@ void launch_loss(const float* sl, const float* el, const float* h, const int64_t
                  const int64_t* h_lab, const float* vmask, int B, int T, float inv_batch, float mask_sum_override,
                  float w_loc, float w_hl, float* scratch, float* losses, float* d_sl, float* d_el, float* d_h,
                  hipStream_t s) {
-    hipLaunchKernelGGL(k_loss_a, dim3(B), dim3(256), 0, s, sl, el, h, s_lab, e_lab, h_lab, vmask, B, T, scratch);
+    VSL_LAUNCH(k_loss_a, dim3(B), dim3(256), 0, s, sl, el, h, s_lab, e_lab, h_lab, vmask, B, T, scratch);
     if (d_sl)
-        hipLaunchKernelGGL(k_loss_c, dim3((T + 255) / 256, B), dim3(256), 0, s, sl, el, h, s_lab, e_lab, h_lab, vmask, B, T,
+        VSL_LAUNCH(k_loss_c, dim3((T + 255) / 256, B), dim3(256), 0, s, sl, el, h, s_lab, e_lab, h_lab, vmask, B, T,
                            inv_batch, mask_sum_override, w_loc, w_hl, scratch, losses, d_sl, d_el, d_h);
     else
-        hipLaunchKernelGGL(k_loss_b, dim3(1), dim3(256), 0, s, B, inv_batch, mask_sum_override, w_loc, w_hl, scratch, losses);
+        VSL_LAUNCH(k_loss_b, dim3(1), dim3(256), 0, s, B, inv_batch, mask_sum_override, w_loc, w_hl, scratch, losses);
 }
 
 // a17 extract_index (:355-363): argmax over the upper-triangular outer product of the two softmaxes, computed as
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void k_extract_index(const float* __restrict__
     }
 }
 void launch_extract_index(const float* sl, const float* el, int64_t* si, int64_t* ei, int B, int T, hipStream_t s) {
-    hipLaunchKernelGGL(k_extract_index, dim3(B), dim3(256), (size_t)(2 * T + 8) * sizeof(float), s, sl, el, si, ei, T);
+    VSL_LAUNCH(k_extract_index, dim3(B), dim3(256), (size_t)(2 * T + 8) * sizeof(float), s, sl, el, si, ei, T);
 }
 
 // =========================================================================================================
@@ -264,7 +264,7 @@ void launch_head_bwd(const HeadBwdArgs& a0, const HeadBwdArgs& a1, int R, hipStr
         static size_t lds_sp = 0;
         const size_t shm_sp = spread_lds(0, 50816, (R + TILE_M - 1) / TILE_M);
         ensure_dynamic_lds((const void*)k_head_bwd, shm_sp + 50816, lds_sp, "k_head_bwd");
-        hipLaunchKernelGGL(k_head_bwd, dim3((R + TILE_M - 1) / TILE_M, 2), dim3(256), shm_sp, s, a0, a1, R);
+        VSL_LAUNCH(k_head_bwd, dim3((R + TILE_M - 1) / TILE_M, 2), dim3(256), shm_sp, s, a0, a1, R);
     }
 }
 
@@ -432,7 +432,7 @@ void launch_wgrad(const WgradBatch& wb0, hipStream_t s) {
         static const bool wg_excl = !(getenv("VSL_WGRAD_EXCL") && getenv("VSL_WGRAD_EXCL")[0] == '0');
         const size_t shm_sp = wg_excl ? (shm > 84 * 1024 ? shm : (size_t)84 * 1024) : spread_lds(shm, 0, 0);
         ensure_dynamic_lds((const void*)k_wgrad, shm_sp + 0, lds_sp, "k_wgrad");
-        hipLaunchKernelGGL(k_wgrad, dim3(total), dim3(512), shm_sp, s, wb);
+        VSL_LAUNCH(k_wgrad, dim3(total), dim3(512), shm_sp, s, wb);
         static int left = 12;
         if (dbg_budget("wgrad")) { char nm[96]; snprintf(nm, sizeof nm, "wgrad n=%d K=%d R=%d: prologue | 8-step loop | stores", wb.n, wb.j[0].K, wb.j[0].R); dbg_report(nm, 4, s, left); }
     }
@@ -558,7 +558,7 @@ void launch_conv_bwd_dwln(const float* du, const float* xin, const float* dy, co
     const size_t shm = (size_t)((2 * (TILE_M + 2 * HALO) + 2 * TILE_M) * LDP + 1792) * sizeof(float);
     static size_t lds_ok = 0;
     ensure_dynamic_lds((const void*)k_conv_bwd_dwln, shm, lds_ok, "k_conv_bwd_dwln");
-    hipLaunchKernelGGL(k_conv_bwd_dwln, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm, s, du, xin, dy, ln_g, ln_b, dw_w, extra,
+    VSL_LAUNCH(k_conv_bwd_dwln, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm, s, du, xin, dy, ln_g, ln_b, dw_w, extra,
                        dx, p_lng, p_lnb, p_dw, R, L, nxt);
     static int left = 6;
     if (dbg_budget("conv_bwd_dwln") && R > 4096) dbg_report("conv_bwd_dwln: loads | LN | depthwise bwd | sync | p_dw store | ln_bwd | fused gemm stage", 7, s, left);
@@ -634,7 +634,7 @@ void launch_attn_out_bwd(const float* dy, const float* dy2, const float* r, cons
         static size_t lds_sp = 0;
         const size_t shm_sp = spread_lds(0, 33792, (R + TILE_M - 1) / TILE_M);
         ensure_dynamic_lds((const void*)k_attn_out_bwd, shm_sp + 33792, lds_sp, "k_attn_out_bwd");
-        hipLaunchKernelGGL(k_attn_out_bwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm_sp, s, dy, dy2, r, ln_g, WTpack, g_o, dr, p_lng,
+        VSL_LAUNCH(k_attn_out_bwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm_sp, s, dy, dy2, r, ln_g, WTpack, g_o, dr, p_lng,
                        p_lnb, R, d4, d5);
     }
 }
@@ -983,11 +983,11 @@ void launch_attn_bwd(const float* Q, const float* K, const float* V, const float
         static size_t ok128 = 0, ok256 = 0;
         if (Lp <= 128) {
             ensure_dynamic_lds((const void*)k_attn_bwd_fused<128>, ab_lds<128>(), ok128, "k_attn_bwd_fused<128>");
-            hipLaunchKernelGGL(k_attn_bwd_fused<128>, dim3(H, B), dim3(1024), ab_lds<128>(), s, Q, K, V, att, dr, lse, mask, dQ, dK, dV, L, H,
+            VSL_LAUNCH(k_attn_bwd_fused<128>, dim3(H, B), dim3(1024), ab_lds<128>(), s, Q, K, V, att, dr, lse, mask, dQ, dK, dV, L, H,
                                b_off, d2, d3);
         } else {
             ensure_dynamic_lds((const void*)k_attn_bwd_fused<256>, ab_lds<256>(), ok256, "k_attn_bwd_fused<256>");
-            hipLaunchKernelGGL(k_attn_bwd_fused<256>, dim3(H, B), dim3(1024), ab_lds<256>(), s, Q, K, V, att, dr, lse, mask, dQ, dK, dV, L, H,
+            VSL_LAUNCH(k_attn_bwd_fused<256>, dim3(H, B), dim3(1024), ab_lds<256>(), s, Q, K, V, att, dr, lse, mask, dQ, dK, dV, L, H,
                                b_off, d2, d3);
         }
         static int left = 3;
@@ -999,9 +999,9 @@ void launch_attn_bwd(const float* Q, const float* K, const float* V, const float
     static size_t lds_ok1 = 0, lds_ok2 = 0;
     ensure_dynamic_lds((const void*)k_attn_bwd_dq, shm1, lds_ok1, "k_attn_bwd_dq");
     ensure_dynamic_lds((const void*)k_attn_bwd_dkv, shm2, lds_ok2, "k_attn_bwd_dkv");
-    hipLaunchKernelGGL(k_attn_bwd_dq, dim3((L + 63) / 64, H, B), dim3(256), shm1, s, Q, K, V, att, dr, lse, mask, dQ, Dq, L, H,
+    VSL_LAUNCH(k_attn_bwd_dq, dim3((L + 63) / 64, H, B), dim3(256), shm1, s, Q, K, V, att, dr, lse, mask, dQ, Dq, L, H,
                        b_off, d2, d3);
-    hipLaunchKernelGGL(k_attn_bwd_dkv, dim3((L + 63) / 64, H, B), dim3(256), shm2, s, Q, K, V, dr, lse, Dq, mask, dK, dV, L, H,
+    VSL_LAUNCH(k_attn_bwd_dkv, dim3((L + 63) / 64, H, B), dim3(256), shm2, s, Q, K, V, dr, lse, Dq, mask, dK, dV, L, H,
                        b_off, d2, d3);
 }
 
@@ -1069,7 +1069,7 @@ void launch_qkv_bwd(const float* dQ, const float* dK, const float* dV, const flo
     const size_t shm = (size_t)(TILE_M * QKVP + 2 * TILE_M * LDP) * sizeof(float);
     static size_t lds_ok = 0;
     ensure_dynamic_lds((const void*)k_qkv_bwd, shm, lds_ok, "k_qkv_bwd");
-    hipLaunchKernelGGL(k_qkv_bwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm, s, dQ, dK, dV, x, dr, ln_g, WTpack, dx, p_lng,
+    VSL_LAUNCH(k_qkv_bwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm, s, dQ, dK, dV, x, dr, ln_g, WTpack, dx, p_lng,
                        p_lnb, R, d1, nxt);
 }
 
@@ -1176,7 +1176,7 @@ void launch_cqcat_bwd(const float* dg0, const float* dg1, const float* dg2, cons
         static size_t lds_sp = 0;
         const size_t shm_sp = spread_lds(0, 33920, (R + TILE_M - 1) / TILE_M);
         ensure_dynamic_lds((const void*)k_cqcat_bwd, shm_sp + 33920, lds_sp, "k_cqcat_bwd");
-        hipLaunchKernelGGL(k_cqcat_bwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm_sp, s, dg0, dg1, dg2, dh_loss, f2, hscore, wh,
+        VSL_LAUNCH(k_cqcat_bwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm_sp, s, dg0, dg1, dg2, dh_loss, f2, hscore, wh,
                        W1Tpack, df2, df1, p_wh, p_bh, R);
     }
 }
@@ -1654,10 +1654,10 @@ void launch_cq_bwd(const CqBwdArgs& a0, int B, hipStream_t s) {
     ensure_dynamic_lds((const void*)k_cq_bwd_a, shmA, okA, "k_cq_bwd_a");
     ensure_dynamic_lds((const void*)k_cq_bwd_b, shmB, okB, "k_cq_bwd_b");
     ensure_dynamic_lds((const void*)k_cq_bwd_c, shmC, okC, "k_cq_bwd_c");
-    hipLaunchKernelGGL(k_cq_bwd_a, dim3(ntile, B), dim3(256), shmA, s, a);
+    VSL_LAUNCH(k_cq_bwd_a, dim3(ntile, B), dim3(256), shmA, s, a);
     { static int left = 2; if (dbg_budget("cq_bwd_a")) dbg_report("cq_bwd_a: load | gemm512 | Dc store | C load + c2q/q2c | product rule | dS_row + partials | sync | softmax bwd", 8, s, left); }
-    hipLaunchKernelGGL(k_cq_bwd_b, dim3(ntile, B), dim3(256), shmB, s, a);
-    hipLaunchKernelGGL(k_cq_bwd_c, dim3(ntile, B), dim3(256), shmC, s, a);
+    VSL_LAUNCH(k_cq_bwd_b, dim3(ntile, B), dim3(256), shmB, s, a);
+    VSL_LAUNCH(k_cq_bwd_c, dim3(ntile, B), dim3(256), shmC, s, a);
 }
 // the per-sample tail (dQ, pooled-query path): nothing on the video side reads its outputs, so it runs on the query stream
 void launch_cq_bwd_query(const CqBwdArgs& a0, int B, hipStream_t s) {
@@ -1667,7 +1667,7 @@ void launch_cq_bwd_query(const CqBwdArgs& a0, int B, hipStream_t s) {
     const size_t shmD = (size_t)(Lq * LDP + 2 * Lq + 4 * D) * sizeof(float);
     static size_t okD = 0;
     ensure_dynamic_lds((const void*)k_cq_bwd_d, shmD, okD, "k_cq_bwd_d");
-    hipLaunchKernelGGL(k_cq_bwd_d, dim3(B), dim3(256), shmD, s, a);
+    VSL_LAUNCH(k_cq_bwd_d, dim3(B), dim3(256), shmD, s, a);
 }
 
 // =========================================================================================================
@@ -1715,7 +1715,7 @@ __global__ __launch_bounds__(256) void k_linear_bwd_data(const float* __restrict
 }
 void launch_linear_bwd_data(const float* G, const float* WTpack, float* dA, int R, int K, hipStream_t s, int seg, int stride,
                             int off) {
-    hipLaunchKernelGGL(k_linear_bwd_data, dim3((R + TILE_M - 1) / TILE_M), dim3(256), 0, s, G, WTpack, dA, R, K, seg, stride, off);
+    VSL_LAUNCH(k_linear_bwd_data, dim3((R + TILE_M - 1) / TILE_M), dim3(256), 0, s, G, WTpack, dA, R, K, seg, stride, off);
 }
 
 // =========================================================================================================
@@ -1930,7 +1930,7 @@ void launch_embed_bwd(const float* dE, const int64_t* word_ids, const int64_t* c
                                 char_size * char_dim + 304) * sizeof(float);
     static size_t lds_ok = 0;
     ensure_dynamic_lds((const void*)k_embed_bwd, shm, lds_ok, "k_embed_bwd");
-    hipLaunchKernelGGL(k_embed_bwd, dim3((Rq + EMB_CHUNK - 1) / EMB_CHUNK), dim3(256), shm, s, dE, word_ids, char_ids, E, argpos,
+    VSL_LAUNCH(k_embed_bwd, dim3((Rq + EMB_CHUNK - 1) / EMB_CHUNK), dim3(256), shm, s, dE, word_ids, char_ids, E, argpos,
                        char_tab, cc, p_cw, p_cb, p_tab, p_unk, Rq, Lc, word_dim, char_dim, char_size, dw, dc);
     static int left = 2;
     if (dbg_budget("embed_bwd")) dbg_report("embed_bwd: bulk1 | gather | dW | dCe+table | stores", 6, s, left);
@@ -2013,7 +2013,7 @@ __global__ __launch_bounds__(256) void k_reduce(const float* __restrict__ ws, fl
 }
 void launch_reduce(const float* partial, float* grads, const ReduceSeg* segs_dev, const int* blk2seg_dev, int nblocks,
                    hipStream_t s) {
-    hipLaunchKernelGGL(k_reduce, dim3(nblocks), dim3(256), 0, s, partial, grads, segs_dev, blk2seg_dev);
+    VSL_LAUNCH(k_reduce, dim3(nblocks), dim3(256), 0, s, partial, grads, segs_dev, blk2seg_dev);
 }
 
 // =========================================================================================================
@@ -2111,7 +2111,7 @@ void launch_lstm_bwd(const float* dout, const float* dout2, const float* mask, c
     if (t1 < 0) t1 = T;
     static const bool four = !(getenv("VSL_LSTM4") && getenv("VSL_LSTM4")[0] == '0');
     if (four) { launch_lstm4_bwd(dout, dout2, mask, gates, cseq, Whh, dG, B, T, s, carry, t0, t1); return; }
-    hipLaunchKernelGGL(k_lstm_bwd, dim3((B + LS_M - 1) / LS_M), dim3(1024), 0, s, dout, dout2, mask, gates, cseq, Whh, dG, B, T, carry,
+    VSL_LAUNCH(k_lstm_bwd, dim3((B + LS_M - 1) / LS_M), dim3(1024), 0, s, dout, dout2, mask, gates, cseq, Whh, dG, B, T, carry,
                        t0, t1);
 }
 
@@ -2175,9 +2175,9 @@ void launch_adamw(float* params, const float* grads, float* m, float* v, const u
                   float lr, float b1, float b2, float eps, float wd, float clip, float bc1, float bc2_sqrt, float* norm_out,
                   hipStream_t s, int hf_order) {
     const int64_t n4 = n / 4;                    // the bucket is a multiple of 4 floats (every tensor is 16-byte aligned)
-    hipLaunchKernelGGL(k_sqsum, dim3(OPT_BLOCKS), dim3(256), 0, s, grads, n4, partials);
+    VSL_LAUNCH(k_sqsum, dim3(OPT_BLOCKS), dim3(256), 0, s, grads, n4, partials);
     const int nb = (int)std::min<int64_t>(1024, (n4 + 255) / 256);
-    hipLaunchKernelGGL(k_adamw, dim3(nb), dim3(256), 0, s, params, grads, m, v, decay_mask, partials, n4, lr, b1, b2, eps, wd, clip,
+    VSL_LAUNCH(k_adamw, dim3(nb), dim3(256), 0, s, params, grads, m, v, decay_mask, partials, n4, lr, b1, b2, eps, wd, clip,
                        bc1, bc2_sqrt, norm_out, hf_order);
 }
 

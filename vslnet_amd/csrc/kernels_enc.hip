@@ -399,11 +399,11 @@ void launch_convblock_fwd(const CbFwdArgs& a, hipStream_t s) {
     static size_t ok3 = 0, ok0 = 0;
     if (a.L <= TILE_M) {                    // sample tiles: one workgroup per sample
         ensure_dynamic_lds((const void*)k_convblock_fwd<0>, cb_fwd_lds(0), ok0, "k_convblock_fwd<0>");
-        hipLaunchKernelGGL(k_convblock_fwd<0>, dim3(a.R / a.L), dim3(CB_T), cb_fwd_lds(0), s, a);
+        VSL_LAUNCH(k_convblock_fwd<0>, dim3(a.R / a.L), dim3(CB_T), cb_fwd_lds(0), s, a);
         return;
     }
     ensure_dynamic_lds((const void*)k_convblock_fwd<3>, cb_fwd_lds(3), ok3, "k_convblock_fwd<3>");
-    hipLaunchKernelGGL(k_convblock_fwd<3>, dim3((a.R + TILE_M - 1) / TILE_M), dim3(CB_T), cb_fwd_lds(3), s, a);
+    VSL_LAUNCH(k_convblock_fwd<3>, dim3((a.R + TILE_M - 1) / TILE_M), dim3(CB_T), cb_fwd_lds(3), s, a);
     static int left = 6;
     if (edbg_on() && a.R > 4096) { int l2 = left; edbg_report("convblock_fwd: load | L0 | L1 | L2 | L3 | qkv", 7, s, left); edbg_report2("  L0: LN | dw | gemm | epilogue | barrier", 8, 13, s, l2); }
 }
@@ -709,11 +709,11 @@ void launch_convblock_bwd(const CbBwdArgs& a, hipStream_t s) {
     static size_t ok3 = 0, ok0 = 0;
     if (a.L <= TILE_M) {                    // sample tiles: one workgroup per sample (partial slabs per SAMPLE: convblock_slabs())
         ensure_dynamic_lds((const void*)k_convblock_bwd<0>, cb_bwd_lds(0), ok0, "k_convblock_bwd<0>");
-        hipLaunchKernelGGL(k_convblock_bwd<0>, dim3(a.R / a.L), dim3(CB_T), cb_bwd_lds(0), s, a);
+        VSL_LAUNCH(k_convblock_bwd<0>, dim3(a.R / a.L), dim3(CB_T), cb_bwd_lds(0), s, a);
         return;
     }
     ensure_dynamic_lds((const void*)k_convblock_bwd<3>, cb_bwd_lds(3), ok3, "k_convblock_bwd<3>");
-    hipLaunchKernelGGL(k_convblock_bwd<3>, dim3((a.R + TILE_M - 1) / TILE_M), dim3(CB_T), cb_bwd_lds(3), s, a);
+    VSL_LAUNCH(k_convblock_bwd<3>, dim3((a.R + TILE_M - 1) / TILE_M), dim3(CB_T), cb_bwd_lds(3), s, a);
     static int left = 6;
     if (edbg_on() && a.R > 4096) edbg_report("convblock_bwd: load | L3 | L2 | L1 | L0", 6, s, left);
 }
@@ -889,7 +889,7 @@ __global__ __launch_bounds__(CB_T, 2) void k_attn_block_fwd(AttnBlockArgs a) {
     ESTAMP(6);
 }
 void launch_attn_block_fwd(const AttnBlockArgs& a, int B, hipStream_t s) {
-    hipLaunchKernelGGL(k_attn_block_fwd, dim3((a.L + TILE_M - 1) / TILE_M, B), dim3(CB_T), (size_t)((a.L + 15) & ~15) * sizeof(float), s, a);
+    VSL_LAUNCH(k_attn_block_fwd, dim3((a.L + TILE_M - 1) / TILE_M, B), dim3(CB_T), (size_t)((a.L + 15) & ~15) * sizeof(float), s, a);
     static int left = 3;
     if (edbg_on() && B > 16) edbg_report("attn_block_fwd", 7, s, left);
 }

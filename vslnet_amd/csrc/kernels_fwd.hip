@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void k_pack(const float* __restrict__ params, 
 }
 void launch_pack(const float* params, float* pack, const PackJob* jobs_dev, int njobs, hipStream_t s) {
     if (njobs == 0) return;
-    hipLaunchKernelGGL(k_pack, dim3(64, njobs), dim3(256), 0, s, params, pack, jobs_dev);
+    VSL_LAUNCH(k_pack, dim3(64, njobs), dim3(256), 0, s, params, pack, jobs_dev);
 }
 
 // =========================================================================================================
@@ -157,7 +157,7 @@ void launch_vproj_fwd(const float* X, const float* Wpack, const float* bias, flo
         static size_t lds_sp = 0;
         const size_t shm_sp = spread_lds(0, 33792, (R + TILE_M - 1) / TILE_M);
         ensure_dynamic_lds((const void*)k_vproj_fwd, shm_sp + 33792, lds_sp, "k_vproj_fwd");
-        hipLaunchKernelGGL(k_vproj_fwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm_sp, s, X, Wpack, bias, Y, R, Dv, dp, seg, stride, off);
+        VSL_LAUNCH(k_vproj_fwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm_sp, s, X, Wpack, bias, Y, R, Dv, dp, seg, stride, off);
     }
 }
 
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void k_vproj_fwd_bf16(const uint16_t* __restri
     }
 }
 void launch_vproj_fwd_bf16(const uint16_t* X, const uint16_t* Wpack16, const float* bias, float* Y, int R, int Dv, Drop dp, hipStream_t s) {
-    hipLaunchKernelGGL(k_vproj_fwd_bf16, dim3((R + TILE_M - 1) / TILE_M), dim3(256), 0, s, X, Wpack16, bias, Y, R, Dv, dp);
+    VSL_LAUNCH(k_vproj_fwd_bf16, dim3((R + TILE_M - 1) / TILE_M), dim3(256), 0, s, X, Wpack16, bias, Y, R, Dv, dp);
 }
 
 // =========================================================================================================
@@ -412,11 +412,11 @@ void launch_embed_fwd(const int64_t* word_ids, const int64_t* char_ids, const fl
     const dim3 grid((Rq + EF_CHUNK - 1) / EF_CHUNK);
     if (lcm == 24) {
         ensure_dynamic_lds((const void*)k_embed_fwd<24>, shm, ok24, "k_embed_fwd<24>");
-        hipLaunchKernelGGL(k_embed_fwd<24>, grid, dim3(512), shm, s, word_ids, char_ids, pad_vec, unk_vec, glove, char_tab, cc, wimg, E,
+        VSL_LAUNCH(k_embed_fwd<24>, grid, dim3(512), shm, s, word_ids, char_ids, pad_vec, unk_vec, glove, char_tab, cc, wimg, E,
                            argpos, Rq, Lc, word_dim, char_dim, dw, dc);
     } else {
         ensure_dynamic_lds((const void*)k_embed_fwd<MAX_LC>, shm, ok40, "k_embed_fwd<40>");
-        hipLaunchKernelGGL(k_embed_fwd<MAX_LC>, grid, dim3(512), shm, s, word_ids, char_ids, pad_vec, unk_vec, glove, char_tab, cc, wimg,
+        VSL_LAUNCH(k_embed_fwd<MAX_LC>, grid, dim3(512), shm, s, word_ids, char_ids, pad_vec, unk_vec, glove, char_tab, cc, wimg,
                            E, argpos, Rq, Lc, word_dim, char_dim, dw, dc);
     }
     static int left = 2;
@@ -462,7 +462,7 @@ void launch_linear_fwd(const float* A, const float* Wpack, const float* bias, fl
         static size_t lds_sp = 0;
         const size_t shm_sp = spread_lds(0, 16896, (R + TILE_M - 1) / TILE_M);
         ensure_dynamic_lds((const void*)k_linear_fwd, shm_sp + 16896, lds_sp, "k_linear_fwd");
-        hipLaunchKernelGGL(k_linear_fwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm_sp, s, A, Wpack, bias, Y, R, K);
+        VSL_LAUNCH(k_linear_fwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm_sp, s, A, Wpack, bias, Y, R, K);
     }
 }
 
@@ -641,11 +641,11 @@ void launch_conv_layer_fwd(const float* xin, const float* pos, float* x0_out, co
     const dim3 grid((R + TILE_M - 1) / TILE_M);
     if (qkv.ln_g) {
         ensure_dynamic_lds((const void*)k_conv_layer_fwd<true>, shm, ok1, "k_conv_layer_fwd<qkv>");
-        hipLaunchKernelGGL(k_conv_layer_fwd<true>, grid, dim3(256), shm, s, xin, pos, x0_out, ln_g, ln_b, dw_w, Wpack, pw_b, y_out, u_out,
+        VSL_LAUNCH(k_conv_layer_fwd<true>, grid, dim3(256), shm, s, xin, pos, x0_out, ln_g, ln_b, dw_w, Wpack, pw_b, y_out, u_out,
                            relu_mask, R, L, dp, qkv);
     } else {
         ensure_dynamic_lds((const void*)k_conv_layer_fwd<false>, shm, ok0, "k_conv_layer_fwd");
-        hipLaunchKernelGGL(k_conv_layer_fwd<false>, grid, dim3(256), shm, s, xin, pos, x0_out, ln_g, ln_b, dw_w, Wpack, pw_b, y_out, u_out,
+        VSL_LAUNCH(k_conv_layer_fwd<false>, grid, dim3(256), shm, s, xin, pos, x0_out, ln_g, ln_b, dw_w, Wpack, pw_b, y_out, u_out,
                            relu_mask, R, L, dp, qkv);
     }
     static int left = 6;
@@ -697,7 +697,7 @@ void launch_ln_qkv_fwd(const float* x, const float* ln_g, const float* ln_b, con
         static size_t lds_sp = 0;
         const size_t shm_sp = spread_lds(0, 16896, (R + TILE_M - 1) / TILE_M);
         ensure_dynamic_lds((const void*)k_ln_qkv_fwd, shm_sp + 16896, lds_sp, "k_ln_qkv_fwd");
-        hipLaunchKernelGGL(k_ln_qkv_fwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm_sp, s, x, ln_g, ln_b, Wpack, bq, bk, bv, h1, q,
+        VSL_LAUNCH(k_ln_qkv_fwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm_sp, s, x, ln_g, ln_b, Wpack, bq, bk, bv, h1, q,
                        k, v, R, d1);
     }
 }
@@ -803,7 +803,7 @@ void launch_attn_fwd(const float* Q, const float* K, const float* V, const float
     const size_t shm = (size_t)(2 * KB * 20 + KB) * sizeof(float);
     static size_t lds_ok = 0;
     ensure_dynamic_lds((const void*)k_attn_fwd, shm, lds_ok, "k_attn_fwd");
-    hipLaunchKernelGGL(k_attn_fwd, dim3((L + 63) / 64, H, B), dim3(256), shm, s, Q, K, V, mask, att, lse, L, H, b_off, d2);
+    VSL_LAUNCH(k_attn_fwd, dim3((L + 63) / 64, H, B), dim3(256), shm, s, Q, K, V, mask, att, lse, L, H, b_off, d2);
 }
 
 // =========================================================================================================
@@ -879,7 +879,7 @@ void launch_attn_out_fwd(const float* att, const float* x, const float* ln_g, co
         static size_t lds_sp = 0;
         const size_t shm_sp = spread_lds(0, 33792, (R + TILE_M - 1) / TILE_M);
         ensure_dynamic_lds((const void*)k_attn_out_fwd, shm_sp + 33792, lds_sp, "k_attn_out_fwd");
-        hipLaunchKernelGGL(k_attn_out_fwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm_sp, s, att, x, ln_g, ln_b, Wpack, bo, r_out,
+        VSL_LAUNCH(k_attn_out_fwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm_sp, s, att, x, ln_g, ln_b, Wpack, bo, r_out,
                        h2_out, y_out, R, d3, d4, d5);
     }
 }
@@ -1064,10 +1064,10 @@ void launch_cq_score(const float* C, const float* Qf, const float* qmask, const 
     const dim3 grid((T + TILE_M - 1) / TILE_M, B);
     if (Lq <= 64) {
         ensure_dynamic_lds((const void*)k_cq_score<8>, shm, ok8, "k_cq_score<8>");
-        hipLaunchKernelGGL(k_cq_score<8>, grid, dim3(256), shm, s, C, Qf, qmask, w4C, w4Q, w4mlu, S, Srow, T, Lq, b_off, dc, dq);
+        VSL_LAUNCH(k_cq_score<8>, grid, dim3(256), shm, s, C, Qf, qmask, w4C, w4Q, w4mlu, S, Srow, T, Lq, b_off, dc, dq);
     } else {
         ensure_dynamic_lds((const void*)k_cq_score<MAX_LQ / 8>, shm, okn, "k_cq_score<12>");
-        hipLaunchKernelGGL(k_cq_score<MAX_LQ / 8>, grid, dim3(256), shm, s, C, Qf, qmask, w4C, w4Q, w4mlu, S, Srow, T, Lq, b_off, dc, dq);
+        VSL_LAUNCH(k_cq_score<MAX_LQ / 8>, grid, dim3(256), shm, s, C, Qf, qmask, w4C, w4Q, w4mlu, S, Srow, T, Lq, b_off, dc, dq);
     }
 }
 
@@ -1192,7 +1192,7 @@ void launch_cq_col(const float* C, const float* Qf, const float* S, const float*
                    const float* pool_w, const float* Wcat, const float* bcat, float* Scol, float* Mpart, float* alpha,
                    float* pooled, float* pb, int B, int T, int Lq, hipStream_t s) {
     const size_t shm = (size_t)(TILE_M * LDP + TILE_M * (Lq + 1) + 72 + 2 * 8 * 128 + 3 * 128 + D) * sizeof(float);
-    hipLaunchKernelGGL(k_cq_col, dim3((T + TILE_M - 1) / TILE_M, B), dim3(256), shm, s, C, Qf, S, cmask, qmask, pool_w, Wcat, bcat, Scol,
+    VSL_LAUNCH(k_cq_col, dim3((T + TILE_M - 1) / TILE_M, B), dim3(256), shm, s, C, Qf, S, cmask, qmask, pool_w, Wcat, bcat, Scol,
                        Mpart, alpha, pooled, pb, T, Lq);
 }
 
@@ -1343,7 +1343,7 @@ void launch_cq_out(const float* C, const float* Qf, const float* Srow, const flo
     const size_t shm = (size_t)(TILE_M * CATP + TILE_M * LDP + Lq * LDP + TILE_M * (Lq + 1) + 32) * sizeof(float);
     static size_t lds_ok = 0;
     ensure_dynamic_lds((const void*)k_cq_out, shm, lds_ok, "k_cq_out");
-    hipLaunchKernelGGL(k_cq_out, dim3((T + TILE_M - 1) / TILE_M, B), dim3(256), shm, s, C, Qf, Srow, Mpart, M, Wpack, bias, cat_out, out,
+    VSL_LAUNCH(k_cq_out, dim3((T + TILE_M - 1) / TILE_M, B), dim3(256), shm, s, C, Qf, Srow, Mpart, M, Wpack, bias, cat_out, out,
                        T, Lq, CqCatFuse{W1pack, pb, wh, bh, vmask, f2, hscore, gated});
 }
 
@@ -1429,7 +1429,7 @@ void launch_head_fwd(const HeadArgs& a0, const HeadArgs& a1, const float* x, con
         static size_t lds_sp = 0;
         const size_t shm_sp = spread_lds(shm, 0, (R + TILE_M - 1) / TILE_M);
         ensure_dynamic_lds((const void*)k_head_fwd, shm_sp + 0, lds_sp, "k_head_fwd");
-        hipLaunchKernelGGL(k_head_fwd, dim3((R + TILE_M - 1) / TILE_M, 2), dim3(256), shm_sp, s, a0, a1, x, vmask, R);
+        VSL_LAUNCH(k_head_fwd, dim3((R + TILE_M - 1) / TILE_M, 2), dim3(256), shm_sp, s, a0, a1, x, vmask, R);
     }
 }
 
@@ -1556,7 +1556,7 @@ void launch_lstm_fwd(const float* gi, const float* Whh, const float* bih, const 
     if (t1 < 0) t1 = T;
     static const bool four = !(getenv("VSL_LSTM4") && getenv("VSL_LSTM4")[0] == '0');
     if (four) { launch_lstm4_fwd(gi, Whh, bih, bhh, mask, gates, cseq, hprev, out, B, T, s, t0, t1); return; }
-    hipLaunchKernelGGL(k_lstm_fwd, dim3((B + LS_M - 1) / LS_M), dim3(1024), 0, s, gi, Whh, bih, bhh, mask, gates, cseq, hprev, out, B, T,
+    VSL_LAUNCH(k_lstm_fwd, dim3((B + LS_M - 1) / LS_M), dim3(1024), 0, s, gi, Whh, bih, bhh, mask, gates, cseq, hprev, out, B, T,
                        t0, t1);
     static int left = 2;
     if (fdbg_on() && T > 8) fdbg_report("lstm_fwd step 6: LDS+MFMA | shuffles | gates+stores | gi issue | barrier", 6, s, left);

@@ -334,18 +334,18 @@ static bool lstm_one_sample(int B) {
 void launch_lstm4_fwd(const float* gi, const float* Whh, const float* bih, const float* bhh, const float* mask, float* gates,
                       float* cseq, float* hprev, float* out, int B, int T, hipStream_t s, int t0, int t1) {
     if (lstm_one_sample(B)) {
-        hipLaunchKernelGGL(k_lstm1_fwd, dim3(B), dim3(512), 0, s, gi, Whh, bih, bhh, mask, gates, cseq, hprev, out, T, t0, t1);
+        VSL_LAUNCH(k_lstm1_fwd, dim3(B), dim3(512), 0, s, gi, Whh, bih, bhh, mask, gates, cseq, hprev, out, T, t0, t1);
         return;
     }
-    hipLaunchKernelGGL(k_lstm4_fwd, dim3((B + 3) / 4), dim3(512), 0, s, gi, Whh, bih, bhh, mask, gates, cseq, hprev, out, B, T, t0, t1);
+    VSL_LAUNCH(k_lstm4_fwd, dim3((B + 3) / 4), dim3(512), 0, s, gi, Whh, bih, bhh, mask, gates, cseq, hprev, out, B, T, t0, t1);
 }
 void launch_lstm4_bwd(const float* dout, const float* dout2, const float* mask, const float* gates, const float* cseq,
                       const float* Whh, float* dG, int B, int T, hipStream_t s, float* carry, int t0, int t1) {
     if (lstm_one_sample(B)) {
-        hipLaunchKernelGGL(k_lstm1_bwd, dim3(B), dim3(512), 0, s, dout, dout2, mask, gates, cseq, Whh, dG, T, carry, t0, t1);
+        VSL_LAUNCH(k_lstm1_bwd, dim3(B), dim3(512), 0, s, dout, dout2, mask, gates, cseq, Whh, dG, T, carry, t0, t1);
         return;
     }
-    hipLaunchKernelGGL(k_lstm4_bwd, dim3((B + 3) / 4), dim3(512), 0, s, dout, dout2, mask, gates, cseq, Whh, dG, B, T, carry, t0, t1);
+    VSL_LAUNCH(k_lstm4_bwd, dim3((B + 3) / 4), dim3(512), 0, s, dout, dout2, mask, gates, cseq, Whh, dG, B, T, carry, t0, t1);
 }
 
 }  // namespace vsl

@@ -148,10 +148,10 @@ void launch_wgrad2(const WgradBatch& wb0, hipStream_t s) {
                          (const void*)k_wgrad2<true, true>};
     ensure_dynamic_lds(fn[k0], pad, ok[k0], "k_wgrad2");
     switch (k0) {
-        case 0: hipLaunchKernelGGL((k_wgrad2<false, false>), dim3(total), dim3(WG2_T), pad, s, wb); break;
-        case 1: hipLaunchKernelGGL((k_wgrad2<true, false>), dim3(total), dim3(WG2_T), pad, s, wb); break;
-        case 2: hipLaunchKernelGGL((k_wgrad2<false, true>), dim3(total), dim3(WG2_T), pad, s, wb); break;
-        default: hipLaunchKernelGGL((k_wgrad2<true, true>), dim3(total), dim3(WG2_T), pad, s, wb); break;
+        case 0: VSL_LAUNCH((k_wgrad2<false, false>), dim3(total), dim3(WG2_T), pad, s, wb); break;
+        case 1: VSL_LAUNCH((k_wgrad2<true, false>), dim3(total), dim3(WG2_T), pad, s, wb); break;
+        case 2: VSL_LAUNCH((k_wgrad2<false, true>), dim3(total), dim3(WG2_T), pad, s, wb); break;
+        default: VSL_LAUNCH((k_wgrad2<true, true>), dim3(total), dim3(WG2_T), pad, s, wb); break;
     }
 }
 

@@ -1,6 +1,7 @@
 // Host-side launcher prototypes + small POD argument structs shared by kernels_fwd.hip, kernels_bwd.hip, api.hip.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -81,6 +82,18 @@ struct ReduceSeg {        // grads[dst + (i / rl) * ds + i % rl] = sum over sour
 // Opt a kernel into more than the default 64 KiB of dynamic LDS.  Requests exactly what the launch needs (static LDS
 // counts against the same 160 KiB), grows monotonically, and reports -- instead of silently poisoning
 // hipGetLastError() -- when the runtime refuses.
+// Every kernel of a multi-stream step is launched with a STOP EVENT on its own dispatch packet (hipExtLaunchKernelGGL): a cross-stream
+// ordering point is then a bare hipStreamWaitEvent on the producer's last kernel.  hipEventRecord puts a marker packet into the producer
+// stream instead, which costs it 4-5 us per fork and 7 us more per join (tools/ubench/event_fork.hip: chain 21.6 / fork by record 26.9 /
+// fork by stop event 23.3 / stop event on every dispatch, no waiter 21.6 us per link).  api.hip hands out the events (nullptr = plain launch).
+hipEvent_t vsl_stop_event(hipStream_t s);
+#define VSL_LAUNCH(kernel, grid, block, shm, stream, ...)                                                                   \
+    do {                                                                                                                   \
+        hipEvent_t ev__ = vsl::vsl_stop_event(stream);                                                                     \
+        if (ev__) hipExtLaunchKernelGGL(kernel, grid, block, shm, stream, nullptr, ev__, 0, __VA_ARGS__);                  \
+        else hipLaunchKernelGGL(kernel, grid, block, shm, stream, __VA_ARGS__);                                            \
+    } while (0)
+
 inline void ensure_dynamic_lds(const void* func, size_t bytes, size_t& granted, const char* name) {
     if (bytes <= granted || bytes <= 64 * 1024) return;
     const hipError_t e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
