@@ -83,18 +83,40 @@ def hip_site_seed(seed, site):
     return int(_fmix32(np.array([x], dtype=np.uint64))[0])
 
 
+def hip_site_key(seed, site):
+    """second per-site word (api.hip Ctx::drop): xor-ed in between the two multiply rounds of the element hash"""
+    k = np.array([hip_site_seed(seed, site) ^ 0x68E31DA4], dtype=np.uint64)
+    k ^= k >> np.uint64(15)
+    k = (k * np.uint64(0x2C1B3C6D)) & _M32
+    k ^= k >> np.uint64(12)
+    k = (k * np.uint64(0x297A2D39)) & _M32
+    k ^= k >> np.uint64(15)
+    return int(k[0])
+
+
+def _drop_hash(idx, seed, key):
+    """common.hpp drop_hash"""
+    h = ((idx * np.uint64(0x9E3779B1)) + np.uint64(seed)) & _M32
+    h ^= h >> np.uint64(16)
+    h = (h * np.uint64(0x85EBCA6B)) & _M32
+    h ^= (h >> np.uint64(13)) ^ np.uint64(key)
+    h = (h * np.uint64(0xC2B2AE35)) & _M32
+    h ^= h >> np.uint64(16)
+    return h
+
+
 # site ids in the order the oracle reaches its dropout calls (api.hip: SITE_* = 64.., encoder pass `app` * 16 + 0..8)
 HIP_DROP_SITES = [64, 65, 66] + list(range(0, 9)) + list(range(16, 25)) + [67, 68] + list(range(32, 41)) + list(range(48, 57))
 
 
 def hip_dropout(seed):
     """-> callable for O.force_dropout: multiplier of element i (row-major index in the tensor the reference applies
-    nn.Dropout to) at the k-th dropout call = keep(fmix32(i * 0x9E3779B1 + seed_site)) / (1 - p)."""
+    nn.Dropout to) at the k-th dropout call = keep(drop_hash(i, seed_site, key_site)) / (1 - p)."""
     def mask(call_no, shape, p):
         site = HIP_DROP_SITES[call_no]
         n = int(np.prod(shape))
         idx = np.arange(n, dtype=np.uint64)
-        h = _fmix32(((idx * np.uint64(0x9E3779B1)) & _M32) + np.uint64(hip_site_seed(seed, site)))
+        h = _drop_hash(idx, hip_site_seed(seed, site), hip_site_key(seed, site))
         thresh = np.uint64(min(4294967295.0, float(np.float32(p)) * 4294967296.0))
         scale = np.float32(1.0) / (np.float32(1.0) - np.float32(p))
         return torch.from_numpy(np.where(h >= thresh, scale, np.float32(0.0)).astype(np.float32).reshape(shape))

@@ -409,12 +409,15 @@ struct Ctx {
         return (site & 15) == 5 ? cf.num_heads * L * L : L * D;       // 5 = attention probabilities (B, H, L, L)
     }
     Drop drop(int site) const {
-        Drop d{0u, 0u, 1.0f};
+        Drop d{0u, 0u, 1.0f, 0u};
         const float pr = h->cfg.drop_rate;
         if (io && io->training && pr > 0.f) {
             uint32_t x = (uint32_t)io->seed ^ ((uint32_t)(io->seed >> 32) * 0x9E3779B1u) ^ ((uint32_t)site * 0x85EBCA77u + 0x165667B1u);
             x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
-            // keep = fmix32(element * 0x9E3779B1 + seed): a shard that starts at sample s of the global batch continues the
+            uint32_t k = x ^ 0x68E31DA4u;               // the site key: a second, independent hash of (step seed, site)
+            k ^= k >> 15; k *= 0x2C1B3C6Du; k ^= k >> 12; k *= 0x297A2D39u; k ^= k >> 15;
+            d.key = k;
+            // keep = drop_hash(element, seed, key), element enters as element * 0x9E3779B1 + seed: a shard that starts at sample s of the global batch continues the
             // element counter at s * site_elems, which folds into the seed (no cost in the kernels)
             x += (uint32_t)io->sample_offset * site_elems(site) * 0x9E3779B1u;
             d.seed = x;

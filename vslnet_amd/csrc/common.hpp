@@ -7,7 +7,7 @@
 //    no barrier) and feeds 4 MFMAs.  See pack_index().
 //  * row tiles: every row-wise kernel owns TILE_M = 32 consecutive rows of the flattened (B*L, 128) activation;
 //    the tile lives in LDS with a +4 float row pad (ds_read_b128 conflict-free: row stride == 4 banks mod 64).
-//  * counter-based dropout: keep(site_seed, element) = fmix32 hash >= p * 2^32, reproducible in the backward.
+//  * counter-based dropout: keep(site seed + key, element) = drop_hash >= p * 2^32, reproducible in the backward.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -38,9 +38,11 @@ constexpr int MAX_L = 1024;     // max clips per video (tested limit; the attent
 // dropout
 // ---------------------------------------------------------------------------------------------------------
 struct Drop {
-    uint32_t seed;     // per-site seed (host mixes step, site id)
+    uint32_t seed;     // per-site seed (host mixes step, site id; a shard's sample offset is folded in additively)
     uint32_t thresh;   // p * 2^32 ; 0 => dropout disabled (eval / drop_rate 0)
     float scale;       // 1 / (1 - p)
+    uint32_t key;      // second per-site word, xor-ed in BETWEEN the two multiply rounds: without it the masks of two sites (or steps) would
+                       // be shifted windows of one 2^32-periodic sequence (element * odd + seed is a translation)
 };
 
 __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
@@ -54,17 +56,22 @@ __host__ __device__ __forceinline__ uint16_t f32_to_bf16(float v) {
     b += 0x7FFFu + ((b >> 16) & 1u);
     return (uint16_t)(b >> 16);
 }
+// the keep decision's hash: murmur3's finaliser over (element * golden + seed) with the site key folded into the middle xor
+// (v_xor3_b32: no extra instruction)
+__device__ __forceinline__ uint32_t drop_hash(uint32_t idx, uint32_t seed, uint32_t key) {
+    uint32_t h = idx * 0x9E3779B1u + seed;
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= (h >> 13) ^ key; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
 // multiplier applied to element `idx` of the site: 0 or 1/(1-p)
 __device__ __forceinline__ float drop_mul(const Drop& d, uint32_t idx) {
     if (d.thresh == 0u) return 1.0f;
-    const uint32_t h = fmix32(idx * 0x9E3779B1u + d.seed);
-    return h >= d.thresh ? d.scale : 0.0f;
+    return drop_hash(idx, d.seed, d.key) >= d.thresh ? d.scale : 0.0f;
 }
 
 // same multiplier WITHOUT the "dropout enabled?" test: for call sites that have already branched on d.thresh (block-uniform)
 __device__ __forceinline__ float drop_keep_scale(const Drop& d, uint32_t idx) {
-    const uint32_t h = fmix32(idx * 0x9E3779B1u + d.seed);
-    return h >= d.thresh ? d.scale : 0.0f;
+    return drop_hash(idx, d.seed, d.key) >= d.thresh ? d.scale : 0.0f;
 }
 
 // ---------------------------------------------------------------------------------------------------------

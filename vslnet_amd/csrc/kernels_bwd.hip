@@ -303,7 +303,7 @@ __global__ __launch_bounds__(512) void k_wgrad(WgradBatch wb) {
     // loop time is MFMA cycles + 4 cycles x VALU instructions x waves, whatever the interleaving).  The store path is
     // therefore specialised: the dropout hash only for a job that has a mask, the row / column masks only for the tile
     // that can be ragged.
-    const uint32_t dseed = j.dp.seed, dthr = j.dp.thresh;
+    const uint32_t dseed = j.dp.seed, dthr = j.dp.thresh, dkey = j.dp.key;
     const float dscale = j.dp.scale;
     const float* Gc = G + c;
     const int ldg = j.ldg ? j.ldg : D;
@@ -331,10 +331,10 @@ __global__ __launch_bounds__(512) void k_wgrad(WgradBatch wb) {
         if (decltype(drop_c)::value) {
             const uint32_t base = (uint32_t)r * (uint32_t)K + dbase;
             ma *= dscale;
-            av.x *= fmix32((base + 0u) * 0x9E3779B1u + dseed) >= dthr ? ma : 0.f;
-            av.y *= fmix32((base + 1u) * 0x9E3779B1u + dseed) >= dthr ? ma : 0.f;
-            av.z *= fmix32((base + 2u) * 0x9E3779B1u + dseed) >= dthr ? ma : 0.f;
-            av.w *= fmix32((base + 3u) * 0x9E3779B1u + dseed) >= dthr ? ma : 0.f;
+            av.x *= drop_hash(base + 0u, dseed, dkey) >= dthr ? ma : 0.f;
+            av.y *= drop_hash(base + 1u, dseed, dkey) >= dthr ? ma : 0.f;
+            av.z *= drop_hash(base + 2u, dseed, dkey) >= dthr ? ma : 0.f;
+            av.w *= drop_hash(base + 3u, dseed, dkey) >= dthr ? ma : 0.f;
         } else if (decltype(mask_c)::value) {
             av.x *= ma; av.y *= ma; av.z *= ma; av.w *= ma;
         }

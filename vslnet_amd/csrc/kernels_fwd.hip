@@ -195,8 +195,8 @@ __global__ __launch_bounds__(256) void k_vproj_fwd_bf16(const uint16_t* __restri
                     uint32_t* u = reinterpret_cast<uint32_t*>(&v);
 #pragma unroll
                     for (int p = 0; p < 4; ++p) {
-                        const uint32_t lo = fmix32((base + 2 * p) * 0x9E3779B1u + dp.seed) >= dp.thresh ? 0x0000FFFFu : 0u;
-                        const uint32_t hi = fmix32((base + 2 * p + 1) * 0x9E3779B1u + dp.seed) >= dp.thresh ? 0xFFFF0000u : 0u;
+                        const uint32_t lo = drop_hash(base + 2 * p, dp.seed, dp.key) >= dp.thresh ? 0x0000FFFFu : 0u;
+                        const uint32_t hi = drop_hash(base + 2 * p + 1, dp.seed, dp.key) >= dp.thresh ? 0xFFFF0000u : 0u;
                         u[p] &= lo | hi;
                     }
                 }

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(WG2_T, 2) void k_wgrad2(WgradBatch wb) {
     const float* Ap = blocks ? j.A[kt] + kloc : j.Afull + (kin ? kglob : 0);
     const int rbeg = ch * WG_ROWS, rend = min(R, rbeg + WG_ROWS);
     const int np = (rend - rbeg + 1) >> 1;                  // row pairs
-    const uint32_t dseed = j.dp.seed, dthr = j.dp.thresh;
+    const uint32_t dseed = j.dp.seed, dthr = j.dp.thresh, dkey = j.dp.key;
     const float dscale = j.dp.scale;
 
     f32x16 acc[2][2];
@@ -80,8 +80,8 @@ __global__ __launch_bounds__(WG2_T, 2) void k_wgrad2(WgradBatch wb) {
             }
             if (DROP) {
                 const uint32_t base = (uint32_t)row * (uint32_t)K + (uint32_t)kglob;
-                a.x *= fmix32(base * 0x9E3779B1u + dseed) >= dthr ? dscale : 0.f;
-                a.y *= fmix32((base + 1u) * 0x9E3779B1u + dseed) >= dthr ? dscale : 0.f;
+                a.x *= drop_hash(base, dseed, dkey) >= dthr ? dscale : 0.f;
+                a.y *= drop_hash(base + 1u, dseed, dkey) >= dthr ? dscale : 0.f;
             }
             bs.x += g.x; bs.y += g.y;
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(g.x, a.x, acc[0][0], 0, 0, 0);
