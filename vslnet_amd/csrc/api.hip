@@ -320,7 +320,7 @@ struct CallScope {
     explicit CallScope(vsl_handle_s* h) {
         static const bool off = getenv("VSL_STOP_EVENTS") && getenv("VSL_STOP_EVENTS")[0] == '0';
         h->sync_used = 0; h->stop_used = 0; h->ev_n = 0;
-        h->stop_events = h->multi_stream && !off && !h->prof_on;
+        h->stop_events = h->multi_stream && !off;
         g_cur = h;
     }
     ~CallScope() { g_cur = nullptr; }
