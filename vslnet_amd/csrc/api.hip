@@ -117,6 +117,7 @@ struct vsl_handle_s {
     size_t prof_used = 0;
     struct ProfRec { const char* name; size_t e0, e1; };
     std::vector<ProfRec> prof_recs;
+    const char* prof_name = nullptr;     // name of the LAUNCH being enqueued when it is profiled (vsl_launch_events)
 };
 
 namespace {
@@ -383,19 +384,9 @@ struct Ctx {
     }
     hipStream_t side(int k) const { return (h->multi_stream && h->side[k]) ? h->side[k] : main; }
     hipStream_t main = nullptr;
-    size_t prof_e0 = 0;
-    bool prof_live = false;
-    hipEvent_t prof_event() {
-        if (h->prof_used == h->prof_pool.size()) { hipEvent_t e; (void)hipEventCreate(&e); h->prof_pool.push_back(e); }
-        return h->prof_pool[h->prof_used++];
-    }
-    void pb(const char* name) {
-        prof_live = h->prof_on && (h->prof_sel == "*" || h->prof_sel == name);
-        if (prof_live) { prof_e0 = h->prof_used; (void)hipEventRecord(prof_event(), s); }
-    }
-    void pe(const char* name) {
-        if (prof_live) { const size_t e1 = h->prof_used; (void)hipEventRecord(prof_event(), s); h->prof_recs.push_back({name, prof_e0, e1}); }
-    }
+    // built-in profiler: a selected LAUNCH hands its name to vsl_launch_events, which puts timing events on the kernel's own packet
+    void pb(const char* name) { h->prof_name = (h->prof_on && (h->prof_sel == "*" || h->prof_sel == name)) ? name : nullptr; }
+    void pe(const char*) { h->prof_name = nullptr; }
     // elements one sample owns in the tensor dropped at `site` (the masks are keyed by the row-major element index)
     uint32_t site_elems(int site) const {
         const vsl_config& cf = h->cfg;
@@ -1133,16 +1124,27 @@ int check_io(vsl_handle_s* h, const vsl_io* io) {
 }  // namespace
 
 namespace vsl {
-hipEvent_t vsl_stop_event(hipStream_t s) {
+void vsl_launch_events(hipStream_t s, hipEvent_t* start, hipEvent_t* stop) {
     vsl_handle_s* h = g_cur;
-    if (!h || !h->stop_events) return nullptr;
-    int i = 0;
-    while (i < h->ev_n && h->ev_stream[i] != s) ++i;
-    if (i == h->ev_n) { if (h->ev_n == 4) return nullptr; h->ev_stream[h->ev_n++] = s; }
-    if (h->stop_used == h->stop_pool.size()) { hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); h->stop_pool.push_back(e); }
-    hipEvent_t e = h->stop_pool[h->stop_used++];
-    h->ev_last[i] = e;
-    return e;
+    if (!h || !(h->stop_events || h->prof_name)) return;
+    hipEvent_t e;
+    if (h->prof_name) {                      // profiled launch: timing events, start + stop, one record per kernel
+        while (h->prof_pool.size() < h->prof_used + 2) { hipEvent_t t; (void)hipEventCreate(&t); h->prof_pool.push_back(t); }
+        h->prof_recs.push_back({h->prof_name, h->prof_used, h->prof_used + 1});
+        *start = h->prof_pool[h->prof_used];
+        e = h->prof_pool[h->prof_used + 1];
+        h->prof_used += 2;
+    } else {
+        if (h->stop_used == h->stop_pool.size()) { hipEvent_t t; (void)hipEventCreateWithFlags(&t, hipEventDisableTiming); h->stop_pool.push_back(t); }
+        e = h->stop_pool[h->stop_used++];
+    }
+    *stop = e;
+    if (h->stop_events) {                    // remember the stream's last kernel for Ctx::order
+        int i = 0;
+        while (i < h->ev_n && h->ev_stream[i] != s) ++i;
+        if (i == h->ev_n) { if (h->ev_n == 4) return; h->ev_stream[h->ev_n++] = s; }
+        h->ev_last[i] = e;
+    }
 }
 }  // namespace vsl
 

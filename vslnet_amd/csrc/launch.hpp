@@ -85,12 +85,15 @@ struct ReduceSeg {        // grads[dst + (i / rl) * ds + i % rl] = sum over sour
 // Every kernel of a multi-stream step is launched with a STOP EVENT on its own dispatch packet (hipExtLaunchKernelGGL): a cross-stream
 // ordering point is then a bare hipStreamWaitEvent on the producer's last kernel.  hipEventRecord puts a marker packet into the producer
 // stream instead, which costs it 4-5 us per fork and 7 us more per join (tools/ubench/event_fork.hip: chain 21.6 / fork by record 26.9 /
-// fork by stop event 23.3 / stop event on every dispatch, no waiter 21.6 us per link).  api.hip hands out the events (nullptr = plain launch).
-hipEvent_t vsl_stop_event(hipStream_t s);
+// fork by stop event 23.3 / stop event on every dispatch, no waiter 21.6 us per link).  api.hip hands out the events (none = plain launch).
+// The same hook serves the built-in profiler (vsl_profile_select): a profiled launch gets a timing START and STOP event on its own packet, so
+// the measured interval is the kernel's execution and the stream carries no extra marker packets.
+void vsl_launch_events(hipStream_t s, hipEvent_t* start, hipEvent_t* stop);
 #define VSL_LAUNCH(kernel, grid, block, shm, stream, ...)                                                                   \
     do {                                                                                                                   \
-        hipEvent_t ev__ = vsl::vsl_stop_event(stream);                                                                     \
-        if (ev__) hipExtLaunchKernelGGL(kernel, grid, block, shm, stream, nullptr, ev__, 0, __VA_ARGS__);                  \
+        hipEvent_t st__ = nullptr, sp__ = nullptr;                                                                         \
+        vsl::vsl_launch_events(stream, &st__, &sp__);                                                                      \
+        if (sp__) hipExtLaunchKernelGGL(kernel, grid, block, shm, stream, st__, sp__, 0, __VA_ARGS__);                     \
         else hipLaunchKernelGGL(kernel, grid, block, shm, stream, __VA_ARGS__);                                            \
     } while (0)
 
