@@ -167,7 +167,8 @@ __global__ __launch_bounds__(CB_T, SH ? 4 : 2) void k_convblock_fwd(CbFwdArgs a)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Xs = smem;                       // [56][LDP] residual stream
     float* VU = Xs + NW * LDP + VOFF * LDP; // (pointer to window row 0; sample tiles: rows -3 .. -1 and 32 .. 34 are the zero pad)           // [68][LDP] LN(x), then depthwise output = GEMM A operand (rows indexed by window row)
-    float* Ps = Xs + (NW + VUR) * LDP;           // [4][CB_PS] per-layer small parameters | ln1_g | ln1_b | bq | bk | bv
+    float* Us = Xs + (NW + VUR) * LDP;           // [56][LDP] depthwise output = GEMM A operand (its own buffer: no barrier between the window reads and these writes)
+    float* Ps = Us + NW * LDP;                   // [4][CB_PS] per-layer small parameters | ln1_g | ln1_b | bq | bk | bv
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int R = a.R, L = a.L;
     const int r0 = SH ? blockIdx.x * TILE_M : blockIdx.x * L, rw0 = r0 - HL;      // global row of window row 0
@@ -272,12 +273,11 @@ __global__ __launch_bounds__(CB_T, SH ? 4 : 2) void k_convblock_fwd(CbFwdArgs a)
                     t = t + 1 == L ? 0 : t + 1;
                 }
             }
-            __syncthreads();                                     // every window is in registers: the buffer turns into the GEMM operand
             float* ug = a.u[l] + (ptrdiff_t)(rw0 + os) * D + c;
 #pragma unroll
             for (int i = 0; i < QS; ++i) {
                 if (os + i < o0 + n) {                           // wave-uniform
-                    VU[(os + i) * LDP + c] = uo[i];
+                    Us[(os + i) * LDP + c] = uo[i];
                     const int wr = os + i;
                     if (wr >= HL && wr < HL + TILE_M && row_ok(wr)) ug[(ptrdiff_t)i * D] = uo[i];   // saved: A operand of the weight gradient
                 }
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(CB_T, SH ? 4 : 2) void k_convblock_fwd(CbFwdArgs a)
         f32x4 acc[1][NRB];
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) acc[0][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
-        gemm16<NRB, 1>(VU + o0 * LDP, LDP, cur, acc);
+        gemm16<NRB, 1>(Us + o0 * LDP, LDP, cur, acc);
         __builtin_amdgcn_sched_barrier(0);
         prefetch();                                              // weight slice of the next stage: most of a layer ahead of its use
         if (l < 3) {
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(CB_T, SH ? 4 : 2) void k_convblock_fwd(CbFwdArgs a)
     }
     ESTAMP(6);
 }
-constexpr size_t cb_fwd_lds(int sh) { return (size_t)((TILE_M + 8 * sh + (sh ? TILE_M + 8 * sh + 12 : TILE_M + 2 * HALO)) * LDP + 4 * CB_PS + 640) * sizeof(float); }
+constexpr size_t cb_fwd_lds(int sh) { return (size_t)((2 * (TILE_M + 8 * sh) + (sh ? TILE_M + 8 * sh + 12 : TILE_M + 2 * HALO)) * LDP + 4 * CB_PS + 640) * sizeof(float); }
 void launch_convblock_fwd(const CbFwdArgs& a, hipStream_t s) {
     static size_t ok3 = 0, ok0 = 0;
     if (a.L <= TILE_M) {                    // sample tiles: one workgroup per sample
