@@ -88,14 +88,11 @@ void launch_pack(const float* params, float* pack, const PackJob* jobs_dev, int 
 //     (global -> regs -> LDS so the dropout mask is applied on the fly), B operand from the packed weight.
 // =========================================================================================================
 constexpr int VP_KC = 128;
-__global__ __launch_bounds__(512) void k_vproj_fwd(const float* __restrict__ X, const float* __restrict__ Wpack,
+__global__ __launch_bounds__(256) void k_vproj_fwd(const float* __restrict__ X, const float* __restrict__ Wpack,
                                                    const float* __restrict__ bias, float* __restrict__ Y, int R, int Dv,
                                                    Drop dp, int seg, int stride, int off) {
-    // two K groups of four waves: group g streams the chunks g, g + 2, ... through its own double-buffered tile, so every SIMD holds two
-    // waves and one group's weight-fragment / tile latency hides under the other's MFMAs (one 4-wave group alone: 41 us at Dv = 1024,
-    // a third of the matrix rate).  The two partial tiles meet in LDS at the end.
-    __shared__ __attribute__((aligned(16))) float As[2][2][TILE_M * LDP];
-    const int tid = threadIdx.x, g = tid >> 8, t = tid & 255, w = t >> 6, lane = tid & 63;
+    __shared__ __attribute__((aligned(16))) float As[2][TILE_M * LDP];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int r0 = blockIdx.x * TILE_M;
     // seg > 0 (GEMM use by the rnn head, no dropout): logical row r = physical row (r / seg) * stride + off + r % seg of X and Y
     auto phys = [&](int r) { return seg > 0 ? (r / seg) * stride + off + r % seg : r; };
@@ -106,7 +103,7 @@ __global__ __launch_bounds__(512) void k_vproj_fwd(const float* __restrict__ X, 
     auto gload = [&](int ch) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int e = t + q * 256;                   // 1024 float4 per chunk: row = e >> 5, c4 = e & 31
+            const int e = tid + q * 256;                 // 1024 float4 per chunk: row = e >> 5, c4 = e & 31
             const int rr = e >> 5, c = (e & 31) * 4 + ch * VP_KC;
             const int r = r0 + rr;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -124,52 +121,43 @@ __global__ __launch_bounds__(512) void k_vproj_fwd(const float* __restrict__ X, 
     auto sstore = [&](int buf) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int e = t + q * 256;
-            *reinterpret_cast<float4*>(&As[g][buf][(e >> 5) * LDP + (e & 31) * 4]) = stage[q];
+            const int e = tid + q * 256;
+            *reinterpret_cast<float4*>(&As[buf][(e >> 5) * LDP + (e & 31) * 4]) = stage[q];
         }
     };
-    if (g < nchunk) { gload(g); sstore(0); }
+    gload(0);
+    sstore(0);
     __syncthreads();
-    for (int it = 0; 2 * it < nchunk; ++it) {           // uniform trip count; a group without a chunk only keeps the barriers
-        const int ch = 2 * it + g, buf = it & 1;
-        if (ch < nchunk) {
-            if (ch + 2 < nchunk) gload(ch + 2);         // the group's next chunk in flight while the MFMAs run
-            // Dv need only be a multiple of 4 (ActivityNet C3D: 500): the last 8-wide k block is zero in the LDS tile (gload) and
-            // in the packed weight (k_pack) beyond Dv
-            const int kc = (min(VP_KC, Dv - ch * VP_KC) + 7) & ~7;
-            {
-                const float* wp = Wpack + (size_t)ch * (VP_KC / 8) * D * 8;
-                BFrag<1, 8> bf;
-                bfrag_load(bf, wp, D, 32 * w, 0, 0, kc >> 3);
-                gemm32p<1, 8>(As[g][buf], LDP, kc, wp, D, 32 * w, 0, acc, bf);
-            }
-            if (ch + 2 < nchunk) sstore(buf ^ 1);
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int buf = ch & 1;
+        if (ch + 1 < nchunk) gload(ch + 1);             // next chunk in flight while the MFMAs run
+        // Dv need only be a multiple of 4 (ActivityNet C3D: 500): the last 8-wide k block is zero in the LDS tile (gload) and
+        // in the packed weight (k_pack) beyond Dv
+        const int kc = (min(VP_KC, Dv - ch * VP_KC) + 7) & ~7;
+        {
+            const float* wp = Wpack + (size_t)ch * (VP_KC / 8) * D * 8;
+            BFrag<1, 8> bf;
+            bfrag_load(bf, wp, D, 32 * w, 0, 0, kc >> 3);
+            gemm32p<1, 8>(As[buf], LDP, kc, wp, D, 32 * w, 0, acc, bf);
         }
+        if (ch + 1 < nchunk) sstore(buf ^ 1);
         __syncthreads();
     }
     const int col = 32 * w + (lane & 31);
-    float* red = &As[0][0][0];                           // 32 x LDP partial tile of group 1
-    if (g == 1) {
+    const float bv = bias[col];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) red[acc_row(r, lane) * LDP + col] = acc[0][r];
-    }
-    __syncthreads();
-    if (g == 0) {
-        const float bv = bias[col];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rr = acc_row(r, lane), gr = r0 + rr;
-            if (gr < R) Y[(size_t)phys(gr) * D + col] = (acc[0][r] + red[rr * LDP + col]) + bv;
-        }
+    for (int r = 0; r < 16; ++r) {
+        const int gr = r0 + acc_row(r, lane);
+        if (gr < R) Y[(size_t)phys(gr) * D + col] = acc[0][r] + bv;
     }
 }
 void launch_vproj_fwd(const float* X, const float* Wpack, const float* bias, float* Y, int R, int Dv, Drop dp,
                       hipStream_t s, int seg, int stride, int off) {
     {
         static size_t lds_sp = 0;
-        const size_t shm_sp = spread_lds(0, 67584, (R + TILE_M - 1) / TILE_M);
-        ensure_dynamic_lds((const void*)k_vproj_fwd, shm_sp + 67584, lds_sp, "k_vproj_fwd");
-        VSL_LAUNCH(k_vproj_fwd, dim3((R + TILE_M - 1) / TILE_M), dim3(512), shm_sp, s, X, Wpack, bias, Y, R, Dv, dp, seg, stride, off);
+        const size_t shm_sp = spread_lds(0, 33792, (R + TILE_M - 1) / TILE_M);
+        ensure_dynamic_lds((const void*)k_vproj_fwd, shm_sp + 33792, lds_sp, "k_vproj_fwd");
+        VSL_LAUNCH(k_vproj_fwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm_sp, s, X, Wpack, bias, Y, R, Dv, dp, seg, stride, off);
     }
 }
 
