@@ -424,8 +424,9 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
     constexpr int HL = 4 * SH, NW = TILE_M + 2 * HL, VUR = SH ? NW + 12 : NW, XR = NW - 2 * SH;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* DY = smem;                       // [56][LDP] grad wrt the current layer's output (in place)
-    float* GU = DY + NW * LDP;           // [68][LDP] dz (GEMM A operand) -> du -> dv
-    float* Xh = GU + VUR * LDP;              // [50][LDP] x_l, normalised in place; row = window row - SH
+    float* GU = DY + NW * LDP;           // [68][LDP] dz (GEMM A operand), later dv
+    float* DU = GU + VUR * LDP;          // [68][LDP] du: its own buffer, so neither the GEMM's reads nor the conv windows need a barrier of their own
+    float* Xh = DU + VUR * LDP;              // [50][LDP] x_l, normalised in place; row = window row - SH
     float* RS = Xh + XR * LDP;           // [64] rstd per window row
     float* VF = RS + 64;                    // [64] 1 = the window row belongs to the owner sample / is inside [0, R)
     float* GB = VF + 64;                    // [128] gamma of the current layer (row layout reads)
@@ -548,13 +549,12 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) acc[0][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
         gemm16<NRB, 1>(GU + ra * LDP, LDP, cur, acc);
-        __syncthreads();
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const int row = ra + 16 * rb + g4 + rr;
-                GU[row * LDP + col] = acc[0][rb][rr] * VF[min(row, 63)];    // rows of another sample: zero padding of this one's conv
+                DU[row * LDP + col] = acc[0][rb][rr] * VF[min(row, 63)];    // rows of another sample: zero padding of this one's conv
             }
         __syncthreads();
         // ---- C: dv = depthwise^T(du) ; partial sums over the owner rows
@@ -571,7 +571,7 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
                 const int wr = t0 - 3 + j;                            // sample tiles: rows outside the window = zero padding
                 const bool in = SH || (wr >= 0 && wr < NW);
                 const int wc = SH ? wr : min(max(wr, 0), NW - 1);
-                dwin[j] = in ? GU[wc * LDP + cc] : 0.f;
+                dwin[j] = in ? DU[wc * LDP + cc] : 0.f;
                 const float xh = Xh[(wc - SH) * LDP + cc];
                 vv[j] = in ? (xh * gc + bc) * VF[wc] : 0.f;
                 if (j >= 3 && j < 11) xc[j - 3] = xh;
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
         if (HQ > 0) {
             float hwin[HQ + 6];
 #pragma unroll
-            for (int j = 0; j < HQ + 6; ++j) hwin[j] = GU[min(max(hs - 3 + j, 0), VUR - 1) * LDP + cc];
+            for (int j = 0; j < HQ + 6; ++j) hwin[j] = DU[min(max(hs - 3 + j, 0), VUR - 1) * LDP + cc];
             if (plain) {
 #pragma unroll
                 for (int i = 0; i < HQ; ++i) {
@@ -628,7 +628,7 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
                 }
             }
         }
-        __syncthreads();                                              // every du window is in registers
+        // dv goes where dz was (dead since the barrier behind the GEMM)
 #pragma unroll
         for (int i = 0; i < 8; ++i) GU[(t0 + i) * LDP + cc] = dvo[i];
         if (HQ > 0) {
@@ -704,7 +704,7 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
     layer(std::integral_constant<int, 0>(), bfB, bfA);
     ESTAMP(5);
 }
-constexpr size_t cb_bwd_lds(int sh) { return (size_t)((TILE_M + 8 * sh + (sh ? TILE_M + 8 * sh + 12 : TILE_M) + TILE_M + 6 * sh) * LDP + 64 + 64 + 128) * sizeof(float); }
+constexpr size_t cb_bwd_lds(int sh) { return (size_t)((TILE_M + 8 * sh + 2 * (sh ? TILE_M + 8 * sh + 12 : TILE_M) + TILE_M + 6 * sh) * LDP + 64 + 64 + 128) * sizeof(float); }
 void launch_convblock_bwd(const CbBwdArgs& a, hipStream_t s) {
     static size_t ok3 = 0, ok0 = 0;
     if (a.L <= TILE_M) {                    // sample tiles: one workgroup per sample (partial slabs per SAMPLE: convblock_slabs())
