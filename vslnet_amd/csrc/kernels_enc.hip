@@ -429,7 +429,7 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
     float* Xh = DU + VUR * LDP;              // [50][LDP] x_l, normalised in place; row = window row - SH
     float* RS = Xh + XR * LDP;           // [64] rstd per window row
     float* VF = RS + 64;                    // [64] 1 = the window row belongs to the owner sample / is inside [0, R)
-    float* GB = VF + 64;                    // [128] gamma of the current layer (row layout reads)
+    float* GB = VF + 64;                    // [2][128] gamma of the current layer (row layout reads), double-buffered across layers
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int R = a.R, L = a.L;
     const int r0 = SH ? blockIdx.x * TILE_M : blockIdx.x * L, rw0 = r0 - HL;
@@ -441,21 +441,23 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
     const bool plain = interior || one_owner;
     auto row_ok = [&](int wr) { return SH ? (full || rw0 + wr < R) : wr < L; };     // may window row wr (an owner row) be stored?
     auto row_in = [&](int wr) { return wr < NW && (SH ? (rw0 + wr >= 0 && rw0 + wr < R) : wr < L); };   // does it exist (in this sample)?
-    // element layout of phases A / loads: thread owns float4 column c4 of window rows wq + 16 q
-    const int wq = tid >> 5, c4 = (tid & 31) * 4;
+    // row layout of the loads and of phases A, LN, D: 8 lanes per window row, lane `sub` owns the columns 4 sub + 32 j .. + 3 (j = 0..3).
+    // One thread keeps one row for the whole kernel, so what phase D of a layer writes (dy) and reads (dv, xhat) is exactly what phase
+    // A of the next layer reads / overwrites: no barrier between them.
+    const int r8 = tid >> 3, sub = tid & 7;
     // column layout of phase C
     const int cc = tid >> 2, seg = tid & 3;
     ESTAMP(0);
     float4 xv[4];
     uint32_t mw[4];
     auto fetch_layer = [&](int l) {         // x_l rows and ReLU words of the window, for phase A of layer l
+        const int r = rw0 + r8;
+        const bool ok = row_in(r8);
+        const size_t rc = (size_t)min(max(r, 0), R - 1);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int wr = wq + 16 * q, r = rw0 + wr;
-            const bool ok = row_in(wr);
-            const size_t rc = (size_t)min(max(r, 0), R - 1);
-            const float4 v = *reinterpret_cast<const float4*>(a.x[l] + rc * D + c4);
-            const uint32_t m = a.relu_mask[l][rc * 4 + (c4 >> 5)];
+            const float4 v = *reinterpret_cast<const float4*>(a.x[l] + rc * D + sub * 4 + 32 * q);
+            const uint32_t m = a.relu_mask[l][rc * 4 + q];
             xv[q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
             mw[q] = ok ? m : 0u;
         }
@@ -464,16 +466,13 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
         float4 dv[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int wr = wq + 16 * q, r = rw0 + wr;
             dv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row_in(wr)) dv[q] = *reinterpret_cast<const float4*>(a.dy + (size_t)r * D + c4);
+            if (row_in(r8)) dv[q] = *reinterpret_cast<const float4*>(a.dy + (size_t)(rw0 + r8) * D + sub * 4 + 32 * q);
         }
         fetch_layer(3);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int wr = wq + 16 * q;
-            if (wr < NW) *reinterpret_cast<float4*>(&DY[wr * LDP + c4]) = dv[q];
-        }
+        for (int q = 0; q < 4; ++q)
+            if (r8 < NW) *reinterpret_cast<float4*>(&DY[r8 * LDP + sub * 4 + 32 * q]) = dv[q];
     }
     BF16 bfA[1], bfB[1];
     bf16_load(bfA[0], a.WTpack[3], D, 16 * w);
@@ -499,7 +498,7 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
         // ---- A: dz = dy * relu-bit * dropout -> GU (+ gz on the owner rows) ; x_l -> Xh ; gamma -> GB
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int wr = wq + 16 * q;
+            const int wr = r8, c4 = sub * 4 + 32 * q;
             if (wr >= ra && wr < rb_) {
                 float4 v = *reinterpret_cast<const float4*>(&DY[wr * LDP + c4]);
                 const uint32_t bits = mw[q] >> (c4 & 31);
@@ -519,13 +518,13 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
             }
             if (wr >= xlo && wr < NW - xlo) *reinterpret_cast<float4*>(&Xh[(wr - SH) * LDP + c4]) = xv[q];
         }
-        if (tid < D) GB[tid] = gnext;
+        float* GBl = GB + (l & 1) * D;
+        if (tid < D) GBl[tid] = gnext;
         __syncthreads();
         // ---- x_l -> xhat in place, rstd per row (8 lanes per row)
         {
-            const int r8 = tid >> 3, sub = tid & 7;
-            if (r8 < NW - 2 * xlo) {
-                float* xr = Xh + (xlo + r8 - SH) * LDP + sub * 4;
+            if (r8 >= xlo && r8 < NW - xlo) {
+                float* xr = Xh + (r8 - SH) * LDP + sub * 4;
                 float4 v[4];
                 float sum = 0.f;
 #pragma unroll
@@ -541,7 +540,7 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     *reinterpret_cast<float4*>(xr + 32 * j) = make_float4(v[j].x * rstd, v[j].y * rstd, v[j].z * rstd, v[j].w * rstd);
-                if (sub == 0) RS[xlo + r8] = rstd;
+                if (sub == 0) RS[r8] = rstd;
             }
         }
         // ---- B: du = dz Wp
@@ -661,9 +660,8 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
         __syncthreads();
         // ---- D: dy <- dy + LN^T(dv)   (8 lanes per row)
         {
-            const int r8 = tid >> 3, sub = tid & 7;
-            if (r8 < nD) {
-                const int wr = ra + SH + r8;
+            if (r8 >= ra + SH && r8 < ra + SH + nD) {
+                const int wr = r8;
                 const float* dvr = GU + wr * LDP + sub * 4;
                 const float* xr = Xh + (wr - SH) * LDP + sub * 4;
                 float* dyr = DY + wr * LDP + sub * 4;
@@ -673,7 +671,7 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float4 dv = *reinterpret_cast<const float4*>(dvr + 32 * j);
-                    const float4 gv = *reinterpret_cast<const float4*>(GB + sub * 4 + 32 * j);
+                    const float4 gv = *reinterpret_cast<const float4*>(GBl + sub * 4 + 32 * j);
                     xh[j] = *reinterpret_cast<const float4*>(xr + 32 * j);
                     gd[j] = make_float4(dv.x * gv.x, dv.y * gv.y, dv.z * gv.z, dv.w * gv.w);
                     m1 += sum4(gd[j]);
@@ -692,7 +690,7 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
                 }
             }
         }
-        if (l > 0) __syncthreads();
+        // no barrier: phase A of the next layer touches only what this thread itself read and wrote above
     };
     __syncthreads();
     layer(std::integral_constant<int, 3>(), bfA, bfB);
@@ -704,7 +702,7 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
     layer(std::integral_constant<int, 0>(), bfB, bfA);
     ESTAMP(5);
 }
-constexpr size_t cb_bwd_lds(int sh) { return (size_t)((TILE_M + 8 * sh + 2 * (sh ? TILE_M + 8 * sh + 12 : TILE_M) + TILE_M + 6 * sh) * LDP + 64 + 64 + 128) * sizeof(float); }
+constexpr size_t cb_bwd_lds(int sh) { return (size_t)((TILE_M + 8 * sh + 2 * (sh ? TILE_M + 8 * sh + 12 : TILE_M) + TILE_M + 6 * sh) * LDP + 64 + 64 + 256) * sizeof(float); }
 void launch_convblock_bwd(const CbBwdArgs& a, hipStream_t s) {
     static size_t ok3 = 0, ok0 = 0;
     if (a.L <= TILE_M) {                    // sample tiles: one workgroup per sample (partial slabs per SAMPLE: convblock_slabs())
