@@ -1080,7 +1080,8 @@ __global__ __launch_bounds__(256) void k_cq_col(const float* __restrict__ C, con
     // Tile-parallel: workgroup = (32-clip tile, sample).  The column-softmax statistics need every clip of the sample, so
     // each workgroup recomputes them from the sample's whole score matrix (T x Lq floats, L2-resident, all 256 threads);
     // it then writes its S_col tile and the per-tile partial of M = S_col^T C (MFMA, gemm_tn); k_cq_out adds the partials.
-    // Tile 0 also runs the small WeightedPool / pooled-bias path of the sample.
+    // One EXTRA workgroup per sample (blockIdx.x = number of tiles) runs the small WeightedPool / pooled-bias path beside the tiles
+    // (it used to ride on tile 0 and made that workgroup the critical one).
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int LQ1 = Lq + 1;
     float* Cs = smem;                         // [32][LDP]  C tile
@@ -1093,15 +1094,30 @@ __global__ __launch_bounds__(256) void k_cq_col(const float* __restrict__ C, con
     float* al = cinv + JS;                    // [JS]
     float* pl = al + JS;                      // [128]
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const int b = blockIdx.y, tl = blockIdx.x, t0 = tl * TILE_M, ntile = gridDim.x;
+    const int b = blockIdx.y, tl = blockIdx.x, t0 = tl * TILE_M, ntile = gridDim.x - 1;
     const size_t crow = (size_t)b * T, qrow = (size_t)b * Lq;
+    if (tl < ntile) {                           // block-uniform
     load_tile128(Cs, C + crow * D, t0, TILE_M, T);
-    // ---- column statistics over all T clips: thread = (word j, part); a part walks clips part, part + np, ...
+    // ---- column statistics over all T clips: thread = (word j, part); a part walks clips part, part + np, ... -- eight loads in
+    //      flight at a time (one load per trip of a data-dependent loop costs a full memory latency per clip)
     const int JW = Lq <= 32 ? 32 : Lq <= 64 ? 64 : 128, np = 256 / JW;
     const int j = tid & (JW - 1), part = tid / JW;
+    auto walk = [&](auto&& fold) {
+        if (j >= Lq) return;
+        for (int i0 = part; i0 < T; i0 += 8 * np) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = min(i0 + u * np, T - 1);
+                v[u] = S[(crow + i) * Lq + j] + (1.f - cmask[crow + i]) * MASK_VALUE;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (i0 + u * np < T) fold(v[u]);
+        }
+    };
     {
         float mx = -3.0e38f;
-        if (j < Lq) for (int i = part; i < T; i += np) mx = fmaxf(mx, S[(crow + i) * Lq + j] + (1.f - cmask[crow + i]) * MASK_VALUE);
+        walk([&](float v) { mx = fmaxf(mx, v); });
         redm[part * JS + j] = mx;
     }
     __syncthreads();
@@ -1109,7 +1125,7 @@ __global__ __launch_bounds__(256) void k_cq_col(const float* __restrict__ C, con
     for (int q = 0; q < np; ++q) gm = fmaxf(gm, redm[q * JS + j]);
     {
         float sm = 0.f;
-        if (j < Lq) for (int i = part; i < T; i += np) sm += __expf(S[(crow + i) * Lq + j] + (1.f - cmask[crow + i]) * MASK_VALUE - gm);
+        walk([&](float v) { sm += __expf(v - gm); });
         reds[part * JS + j] = sm;
     }
     __syncthreads();
@@ -1149,7 +1165,8 @@ __global__ __launch_bounds__(256) void k_cq_col(const float* __restrict__ C, con
             }
         }
     }
-    if (tl != 0) return;                       // block-uniform
+    return;
+    }
     // ---- WeightedPool: alpha = softmax_j(Q[j].w + mask) ; pooled = sum_j alpha_j Q[j]
     for (int jj = w; jj < Lq; jj += 4) {
         const float* row = Qf + (qrow + jj) * D;
@@ -1168,7 +1185,13 @@ __global__ __launch_bounds__(256) void k_cq_col(const float* __restrict__ C, con
     __syncthreads();
     if (tid < D) {
         float acc = 0.f;
-        for (int jj = 0; jj < Lq; ++jj) acc += al[jj] * Qf[(qrow + jj) * D + tid];
+        for (int j0 = 0; j0 < Lq; j0 += 8) {        // eight rows in flight; same summation order as one row at a time
+            float qv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) qv[u] = Qf[(qrow + min(j0 + u, Lq - 1)) * D + tid];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (j0 + u < Lq) acc += al[j0 + u] * qv[u];
+        }
         pl[tid] = acc;
         pooled[(size_t)b * D + tid] = acc;
     }
@@ -1192,7 +1215,7 @@ void launch_cq_col(const float* C, const float* Qf, const float* S, const float*
                    const float* pool_w, const float* Wcat, const float* bcat, float* Scol, float* Mpart, float* alpha,
                    float* pooled, float* pb, int B, int T, int Lq, hipStream_t s) {
     const size_t shm = (size_t)(TILE_M * LDP + TILE_M * (Lq + 1) + 72 + 2 * 8 * 128 + 3 * 128 + D) * sizeof(float);
-    VSL_LAUNCH(k_cq_col, dim3((T + TILE_M - 1) / TILE_M, B), dim3(256), shm, s, C, Qf, S, cmask, qmask, pool_w, Wcat, bcat, Scol,
+    VSL_LAUNCH(k_cq_col, dim3((T + TILE_M - 1) / TILE_M + 1, B), dim3(256), shm, s, C, Qf, S, cmask, qmask, pool_w, Wcat, bcat, Scol,
                        Mpart, alpha, pooled, pb, T, Lq);
 }
 
