@@ -217,6 +217,29 @@ def test_headline_shape_at_full_size():
         assert err <= rel * float(t.abs().max()) + 1e-6, (k, err, moved)
 
 
+@pytest.mark.parametrize('B,T,Lq,Lc,predictor', [(64, 128, 20, 10, 'transformer'), (5, 83, 9, 7, 'transformer'), (16, 128, 20, 10, 'rnn')])
+def test_a_training_step_is_bitwise_reproducible(B, T, Lq, Lc, predictor):
+    """Race detector for the fused kernels (barriers removed between phases that touch thread-private rows, three streams, stop-event
+    ordering): the same step six times -> logits, losses and all 104 gradients bit-identical, at the headline shape (one workgroup
+    per CU on every fused kernel), a ragged small batch and configs[0]'s rnn head."""
+    cfg = O.make_cfg(video_feature_dim=1024, max_pos_len=128, word_size=302, drop_rate=0.2, predictor=predictor)
+    P = O.random_params(cfg, seed=5)
+    d = _dev(O.synthetic_batch(cfg, B=B, T=T, Lq=Lq, Lc=Lc, seed=11, ragged=True))
+    eng, flat = _engine(cfg, P)
+    ref = None
+    for _ in range(6):
+        h, sl, el = _fwd(eng, flat, P, d, True, 777)
+        losses, d_h, d_sl, d_el = eng.loss(d['s_labels'], d['e_labels'], d['h_labels'], 1.0, 5.0)
+        g = eng.backward(d_h, d_sl, d_el, eng.new_flat())
+        torch.cuda.synchronize()
+        cur = [t.clone() for t in (h, sl, el, losses, g)]
+        if ref is None:
+            ref = cur
+        else:
+            for a, b in zip(ref, cur):
+                assert torch.equal(a, b)
+
+
 def test_dropout_mask_statistics_and_scaling():
     """Word-embedding dropout (layers_t7.py:45) is directly observable in the saved concat buffer: kept entries equal
     table / (1 - p), the rest are exactly 0, and the drop fraction is p within sampling error."""
