@@ -161,14 +161,17 @@ constexpr int CB_PS = 384;                      // per-layer small parameters in
 // 0 = SAMPLE tiles for sequences of at most 32 rows (the query pass: Lq = 20): one workgroup per sample, its rows at the top
 // of a 32-row window, no halo and no recomputation -- rows >= L and the taps that leave the window are the conv's zero padding.
 template <int SH>
-__global__ __launch_bounds__(CB_T, SH ? 4 : 2) void k_convblock_fwd(CbFwdArgs a) {
+__global__ __launch_bounds__(CB_T, 2) void k_convblock_fwd(CbFwdArgs a) {
     // sample tiles: 3 zero rows above and below the window in the LN / depthwise buffer stand for the taps that leave it
     constexpr int HL = 4 * SH, NW = TILE_M + 2 * HL, VOFF = SH ? 0 : HALO, VUR = SH ? NW + 12 : NW + 2 * HALO;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Xs = smem;                       // [56][LDP] residual stream
     float* VU = Xs + NW * LDP + VOFF * LDP; // (pointer to window row 0; sample tiles: rows -3 .. -1 and 32 .. 34 are the zero pad)           // [68][LDP] LN(x), then depthwise output = GEMM A operand (rows indexed by window row)
-    float* Us = Xs + (NW + VUR) * LDP;           // [56][LDP] depthwise output = GEMM A operand (its own buffer: no barrier between the window reads and these writes)
-    float* Ps = Us + NW * LDP;                   // [4][CB_PS] per-layer small parameters | ln1_g | ln1_b | bq | bk | bv
+    // depthwise output = GEMM A operand.  Row tiles: its own buffer, so no barrier between the window reads and these writes (104 KB; one
+    // workgroup per CU either way).  Sample tiles: in place in VU behind a barrier -- 45 KB, so a query-pass workgroup still fits beside a
+    // video-pass one (the two passes run concurrently on two streams).
+    float* Us = SH ? Xs + (NW + VUR) * LDP : VU;
+    float* Ps = Xs + (NW + VUR + (SH ? NW : 0)) * LDP;   // [4][CB_PS] per-layer small parameters | ln1_g | ln1_b | bq | bk | bv
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int R = a.R, L = a.L;
     const int r0 = SH ? blockIdx.x * TILE_M : blockIdx.x * L, rw0 = r0 - HL;      // global row of window row 0
@@ -273,6 +276,7 @@ __global__ __launch_bounds__(CB_T, SH ? 4 : 2) void k_convblock_fwd(CbFwdArgs a)
                     t = t + 1 == L ? 0 : t + 1;
                 }
             }
+            if (!SH) __syncthreads();                            // every window is in registers: the buffer turns into the GEMM operand
             float* ug = a.u[l] + (ptrdiff_t)(rw0 + os) * D + c;
 #pragma unroll
             for (int i = 0; i < QS; ++i) {
@@ -394,7 +398,7 @@ __global__ __launch_bounds__(CB_T, SH ? 4 : 2) void k_convblock_fwd(CbFwdArgs a)
     }
     ESTAMP(6);
 }
-constexpr size_t cb_fwd_lds(int sh) { return (size_t)((2 * (TILE_M + 8 * sh) + (sh ? TILE_M + 8 * sh + 12 : TILE_M + 2 * HALO)) * LDP + 4 * CB_PS + 640) * sizeof(float); }
+constexpr size_t cb_fwd_lds(int sh) { return (size_t)(((sh ? 2 : 1) * (TILE_M + 8 * sh) + (sh ? TILE_M + 8 * sh + 12 : TILE_M + 2 * HALO)) * LDP + 4 * CB_PS + 640) * sizeof(float); }
 void launch_convblock_fwd(const CbFwdArgs& a, hipStream_t s) {
     static size_t ok3 = 0, ok0 = 0;
     if (a.L <= TILE_M) {                    // sample tiles: one workgroup per sample
