@@ -240,6 +240,31 @@ def test_a_training_step_is_bitwise_reproducible(B, T, Lq, Lc, predictor):
                 assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize('B,T', [(64, 128), (5, 83), (3, 700)])
+def test_one_launch_loss_equals_the_two_kernel_path(B, T):
+    """vsl_loss with the global mask sum supplied (the data-parallel path, bench.py) runs ONE kernel: per-sample gradient seeds plus a
+    last-arriver reduction of the loss values.  Against the default path (mask sum computed on the device, two kernels): same losses and
+    seeds to rounding, six calls in a row bit-identical (the arrival counter resets itself)."""
+    cfg = O.make_cfg(video_feature_dim=64, max_pos_len=1024, word_size=52, drop_rate=0.0)
+    P = O.random_params(cfg, seed=2)
+    d = _dev(O.synthetic_batch(cfg, B=B, T=T, Lq=6, Lc=5, seed=9, ragged=True))
+    eng, flat = _engine(cfg, P)
+    _fwd(eng, flat, P, d, False, 0)
+    ref = [t.clone() for t in eng.loss(d['s_labels'], d['e_labels'], d['h_labels'], 1.0, 5.0)]
+    msum = float(d['v_mask'].sum().item())
+    first = None
+    for _ in range(6):
+        cur = [t.clone() for t in eng.loss(d['s_labels'], d['e_labels'], d['h_labels'], 1.0, 5.0, inv_batch=1.0 / B, mask_sum=msum)]
+        torch.cuda.synchronize()
+        if first is None:
+            first = cur
+        for a, b in zip(first, cur):
+            assert torch.equal(a, b)
+    assert abs(float(first[0][3]) - msum) <= 1e-3
+    for a, b in zip(ref, first):
+        assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(a.abs().max()))
+
+
 def test_dropout_mask_statistics_and_scaling():
     """Word-embedding dropout (layers_t7.py:45) is directly observable in the saved concat buffer: kept entries equal
     table / (1 - p), the rest are exactly 0, and the drop fraction is p within sampling error."""

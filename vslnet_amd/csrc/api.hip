@@ -90,6 +90,7 @@ struct vsl_handle_s {
     int64_t pack_floats = 0;
     std::vector<PackJob> jobs;
     PackJob* jobs_dev = nullptr;
+    unsigned* loss_counter = nullptr;    // arrival counter of k_loss_fused (zero between calls)
     uint8_t* decay_dev = nullptr;        // per-element weight-decay flag of the flat bucket (vsl_adamw_step)
     float* opt_scratch = nullptr;        // OPT_BLOCKS partial sums of grads^2
     std::map<std::tuple<int, int, int, int>, Plan*> plans;
@@ -1172,6 +1173,10 @@ int vsl_create(const vsl_config* cfg, vsl_handle* out) {
     h->cfg = *cfg;
     build_params(h);
     build_packs(h);
+    if (hipMalloc(&h->loss_counter, sizeof(unsigned)) != hipSuccess || hipMemset(h->loss_counter, 0, sizeof(unsigned)) != hipSuccess) {
+        delete h;
+        return fail("hipMalloc of the loss counter failed");
+    }
     if (hipMalloc(&h->jobs_dev, h->jobs.size() * sizeof(PackJob)) != hipSuccess ||
         hipMemcpy(h->jobs_dev, h->jobs.data(), h->jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice) != hipSuccess) {
         delete h;
@@ -1208,6 +1213,7 @@ int vsl_destroy(vsl_handle h) {
         delete kv.second;
     }
     if (h->jobs_dev) (void)hipFree(h->jobs_dev);
+    if (h->loss_counter) (void)hipFree(h->loss_counter);
     if (h->decay_dev) (void)hipFree(h->decay_dev);
     if (h->opt_scratch) (void)hipFree(h->opt_scratch);
     delete h;
@@ -1293,7 +1299,7 @@ int vsl_loss(vsl_handle h, const vsl_io* io, const vsl_loss_io* l, void* hip_str
     if (int rc = get_plan(h, io->B, io->T, io->Lq, io->Lc, &p)) return rc;
     launch_loss(io->start_logits, io->end_logits, io->h_score, l->start_labels, l->end_labels, l->h_labels, io->v_mask, io->B,
                 io->T, l->inv_batch, l->mask_sum, l->w_loc, l->w_highlight, io->workspace + p->loss_scratch, l->losses,
-                l->d_start_logits, l->d_end_logits, l->d_h_score, (hipStream_t)hip_stream);
+                l->d_start_logits, l->d_end_logits, l->d_h_score, (hipStream_t)hip_stream, h->loss_counter);
     HIP_OK(hipGetLastError());
     return 0;
 }

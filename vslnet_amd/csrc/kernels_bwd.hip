@@ -139,10 +139,82 @@ __global__ __launch_bounds__(256) void k_loss_c(const float* __restrict__ sl, co
     // d BCE / dp = (p - y) / max(p (1 - p), 1e-12)   (torch's binary_cross_entropy_backward)
     d_h[i] = w_hl * wgt * m / (dsum + 1e-12f) * (p - y) / fmaxf(p * (1.f - p), 1e-12f);
 }
+// One launch when the caller supplies the global mask sum (the data-parallel path and bench.py do): the sample's workgroup writes its
+// gradient seeds itself -- they need nothing from other samples then -- and the LAST workgroup to arrive (agent-scope counter) adds the
+// per-sample partials in index order, so the loss values do not depend on which one that is.  Saves k_loss_c on the critical chain.
+__global__ __launch_bounds__(256) void k_loss_fused(const float* __restrict__ sl, const float* __restrict__ el,
+                                                    const float* __restrict__ h, const int64_t* __restrict__ s_lab,
+                                                    const int64_t* __restrict__ e_lab, const int64_t* __restrict__ h_lab,
+                                                    const float* __restrict__ vmask, int B, int T, float inv_batch, float mask_sum,
+                                                    float w_loc, float w_hl, float* __restrict__ scratch, float* __restrict__ losses,
+                                                    float* __restrict__ d_sl, float* __restrict__ d_el, float* __restrict__ d_h,
+                                                    unsigned* __restrict__ counter) {
+    __shared__ float red[8];
+    __shared__ unsigned last;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* s = sl + (size_t)b * T;
+    const float* e = el + (size_t)b * T;
+    float ms = -3.0e38f, me = -3.0e38f;
+    for (int t = tid; t < T; t += 256) { ms = fmaxf(ms, s[t]); me = fmaxf(me, e[t]); }
+    ms = block_reduce(ms, red, true);
+    me = block_reduce(me, red, true);
+    float ss = 0.f, se = 0.f, num = 0.f;
+    for (int t = tid; t < T; t += 256) {
+        ss += expf(s[t] - ms);
+        se += expf(e[t] - me);
+        const float m = vmask[(size_t)b * T + t];
+        const float y = (float)h_lab[(size_t)b * T + t];
+        const float p = h[(size_t)b * T + t];
+        const float wgt = y == 0.f ? 1.f : 2.f * y;                         // (:293)
+        const float lp = fmaxf(logf(p), -100.f), lq = fmaxf(logf(1.f - p), -100.f);   // BCELoss log clamp
+        num += -(y * lp + (1.f - y) * lq) * wgt * m;
+    }
+    ss = block_reduce(ss, red, false);
+    se = block_reduce(se, red, false);
+    num = block_reduce(num, red, false);
+    const float lses = ms + logf(ss), lsee = me + logf(se);
+    const float cs = w_loc * inv_batch;
+    const int sb = (int)s_lab[b], eb = (int)e_lab[b];
+    for (int t = tid; t < T; t += 256) {
+        const size_t i = (size_t)b * T + t;
+        d_sl[i] = cs * (expf(s[t] - lses) - (t == sb ? 1.f : 0.f));
+        d_el[i] = cs * (expf(e[t] - lsee) - (t == eb ? 1.f : 0.f));
+        const float y = (float)h_lab[i], p = h[i], m = vmask[i];
+        const float wgt = y == 0.f ? 1.f : 2.f * y;
+        d_h[i] = w_hl * wgt * m / (mask_sum + 1e-12f) * (p - y) / fmaxf(p * (1.f - p), 1e-12f);
+    }
+    if (tid == 0) {
+        scratch[2 * B + b] = (lses - s[sb]) + (lsee - e[eb]);
+        scratch[3 * B + b] = num;
+        __threadfence();                                                    // release the partials at agent scope
+        last = atomicAdd(counter, 1u) == (unsigned)(B - 1) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();                                                        // acquire
+    float ce = 0.f, nm = 0.f;
+    for (int bb = tid; bb < B; bb += 256) {                                 // L2 reads: another CU wrote these
+        ce += __hip_atomic_load(scratch + 2 * B + bb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        nm += __hip_atomic_load(scratch + 3 * B + bb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    ce = block_reduce(ce, red, false);
+    nm = block_reduce(nm, red, false);
+    if (tid == 0) {
+        const float loc = ce * inv_batch, hl = nm / (mask_sum + 1e-12f);
+        losses[0] = loc; losses[1] = hl; losses[2] = w_loc * loc + w_hl * hl; losses[3] = mask_sum;
+        *counter = 0u;                                                      // ready for the next call (stream order)
+    }
+}
 void launch_loss(const float* sl, const float* el, const float* h, const int64_t* s_lab, const int64_t* e_lab,
                  const int64_t* h_lab, const float* vmask, int B, int T, float inv_batch, float mask_sum_override,
                  float w_loc, float w_hl, float* scratch, float* losses, float* d_sl, float* d_el, float* d_h,
-                 hipStream_t s) {
+                 hipStream_t s, unsigned* counter) {
+    static const bool fused = !(getenv("VSL_LOSS_FUSED") && getenv("VSL_LOSS_FUSED")[0] == '0');
+    if (fused && counter && d_sl && mask_sum_override > 0.f) {
+        VSL_LAUNCH(k_loss_fused, dim3(B), dim3(256), 0, s, sl, el, h, s_lab, e_lab, h_lab, vmask, B, T, inv_batch, mask_sum_override,
+                   w_loc, w_hl, scratch, losses, d_sl, d_el, d_h, counter);
+        return;
+    }
     VSL_LAUNCH(k_loss_a, dim3(B), dim3(256), 0, s, sl, el, h, s_lab, e_lab, h_lab, vmask, B, T, scratch);
     if (d_sl)
         VSL_LAUNCH(k_loss_c, dim3((T + 255) / 256, B), dim3(256), 0, s, sl, el, h, s_lab, e_lab, h_lab, vmask, B, T,

@@ -203,7 +203,7 @@ void launch_head_fwd(const HeadArgs& a0, const HeadArgs& a1, const float* x, con
 void launch_loss(const float* sl, const float* el, const float* h, const int64_t* s_lab, const int64_t* e_lab,
                  const int64_t* h_lab, const float* vmask, int B, int T, float inv_batch, float mask_sum_override,
                  float w_loc, float w_hl, float* scratch, float* losses /*[4]: loc, hl, total, mask_sum*/, float* d_sl,
-                 float* d_el, float* d_h, hipStream_t s);
+                 float* d_el, float* d_h, hipStream_t s, unsigned* counter = nullptr);
 void launch_extract_index(const float* sl, const float* el, int64_t* si, int64_t* ei, int B, int T, hipStream_t s);
 
 // ---------------------------------------------------------------- backward
