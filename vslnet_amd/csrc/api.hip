@@ -444,13 +444,15 @@ void wgrad_flush(Ctx& c, hipStream_t sw) {
 // after a fork the chain that finishes LAST should own the main stream: its join wait is then already satisfied (a wait on
 // an event that has just been signalled costs 10 - 22 us).  At the headline shape the query side is the long one.
 bool query_chain_is_longer(const Plan& p, bool forward) {
-    // forward: embed_fwd + linear + query encoder (200 us) vs visual projection + video encoder (170 us) at the headline
-    // shape -> the query branch keeps main (saves the 23 us join).  backward: measured neutral -> off.  VSL_SWAP_FWD/BWD=0/1.
+    // With the fused kernels of round 2 the video branch is the long one in both directions at every BASELINE shape (forward at the
+    // headline shape: vproj 41 + conv block 46 + attention 24 us against embed 30 + linear 17 + conv block 32 + attention 11):
+    // the main stream keeps it.  Measured FWD/BWD swap = 00 / 01 / 10 / 11: cfg2 1.031 / 1.034 / 1.036 / 1.032 ms, cfg4 1.116 / 1.132 /
+    // 1.121 / 1.141.  VSL_SWAP_FWD / VSL_SWAP_BWD = 1 hand the main stream to the query branch for A/B runs.
+    (void)p;
     static const char* ef = getenv("VSL_SWAP_FWD");
     static const char* eb = getenv("VSL_SWAP_BWD");
     const char* e = forward ? ef : eb;
-    if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
-    return forward && (int64_t)p.B * p.T <= 8192 && (int64_t)p.B * p.Lq >= 1024;
+    return e && e[0] == '1';
 }
 
 // dropout site ids: encoder application `app` (0 video, 1 query, 2 predictor pass 1, 3 predictor pass 2) uses
