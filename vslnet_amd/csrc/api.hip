@@ -1195,7 +1195,8 @@ int vsl_create(const vsl_config* cfg, vsl_handle* out) {
                 (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
                 static const bool low_prio = !(getenv("VSL_WGRAD_PRIO") && getenv("VSL_WGRAD_PRIO")[0] == '0');
                 static const bool hi_query = getenv("VSL_QUERY_PRIO") && getenv("VSL_QUERY_PRIO")[0] == '1';
-                const int prio = (k == 1 && low_prio) ? lo : (k == 0 && hi_query) ? hi : 0;
+                static const bool lo_query = getenv("VSL_QUERY_PRIO") && getenv("VSL_QUERY_PRIO")[0] == '-';
+                const int prio = (k == 1 && low_prio) ? lo : (k == 0 && hi_query) ? hi : (k == 0 && lo_query) ? lo : 0;
                 if (hipStreamCreateWithPriority(&h->side[k], hipStreamNonBlocking, prio) != hipSuccess) { h->side[k] = nullptr; (void)hipGetLastError(); }
             }
     }
