@@ -132,17 +132,17 @@ def test_resident_split_yields_the_loader_batches():
 
 
 def test_dataset_is_validated_against_the_engine_limits_up_front():
-    """One 97-word query, a 41-character token or an out-of-range id must stop the run at load time with the record named,
+    """One 129-word query, a 41-character token or an out-of-range id must stop the run at load time with the record named,
     not abort vsl_forward in the middle of an epoch (the reference would raise IndexError from nn.Embedding)."""
     import copy
     import pytest
     from types import SimpleNamespace
     from vslnet_amd import data
-    cfg = SimpleNamespace(max_pos_len=128, char_dim=50)
+    cfg = SimpleNamespace(max_pos_len=256, char_dim=50)
     rec = {'sample_id': 7, 'vid': 'v', 'w_ids': [2, 3, 4], 'c_ids': [[2, 3], [4], [5, 6, 7]], 's_ind': 1, 'e_ind': 2}
     ds = {'n_words': 10, 'n_chars': 9, 'train_set': [rec], 'val_set': None, 'test_set': []}
     data.validate_dataset(ds, cfg)
-    for mutate, msg in ((lambda r: r.update(w_ids=[2] * 97, c_ids=[[2]] * 97), 'query words'),
+    for mutate, msg in ((lambda r: r.update(w_ids=[2] * 129, c_ids=[[2]] * 129), 'query words'),
                         (lambda r: r.update(w_ids=[2, 3, 10]), 'word id'),
                         (lambda r: r['c_ids'].__setitem__(0, [2] * 41), 'characters'),
                         (lambda r: r['c_ids'].__setitem__(1, [9]), 'char id')):

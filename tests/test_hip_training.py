@@ -100,6 +100,8 @@ def test_dropout_forward_backward_consistency_by_finite_differences(dv, B, T, Lq
 
 @pytest.mark.parametrize('dv,B,T,Lq,Lc,predictor', [(64, 3, 40, 7, 6, 'transformer'), (1024, 2, 128, 20, 10, 'transformer'),
                                                     (500, 4, 33, 5, 4, 'rnn'),
+                                                    (64, 2, 40, 82, 30, 'transformer'),     # ActivityNet's longest query
+                                                    (64, 2, 36, 128, 5, 'transformer'),     # the reference's bound (max_pos_len words): lean CQAttention layouts
                                                     (1024, 16, 128, 20, 10, 'rnn')])       # BASELINE configs[0] as written
 def test_training_mode_matches_oracle_on_the_same_dropout_masks(dv, B, T, Lq, Lc, predictor):
     """drop_rate 0.2 (the benchmark's mode), all 41 dropout sites: the oracle is handed the HIP path's masks -- recomputed on
@@ -300,7 +302,9 @@ def test_dropout_mask_statistics_and_scaling():
     dict(name='edge: B=1 minimal chars, odd lengths', T=37, Dv=64, B=1, Lq=5, Lc=4),
     dict(name='edge: TACoS-size query', T=40, Dv=64, B=2, Lq=64, Lc=24),
     dict(name='ActivityNet extremes: longest query (82 words), 30-char word', T=256, Dv=1024, B=2, Lq=82, Lc=30),
-    dict(name='edge: engine limits Lq=96, Lc=40', T=48, Dv=64, B=2, Lq=96, Lc=40),
+    dict(name='edge: Lq=96 (last length on the 4-partial-tile CQAttention layout), Lc=40', T=48, Dv=64, B=2, Lq=96, Lc=40),
+    dict(name='edge: engine limits Lq=128 = the reference max_pos_len bound, Lc=40', T=72, Dv=64, B=2, Lq=128, Lc=40),
+    dict(name='edge: Lq=97 (first length on the lean layout), full word tiles absent', T=33, Dv=64, B=3, Lq=97, Lc=5),
     dict(name='edge: ActivityNet C3D width (500 = 4 * 125), one-word queries, ragged row count', T=50, Dv=500, B=3, Lq=1, Lc=4),
 ])
 def test_baseline_shapes_against_oracle(shape):

@@ -30,8 +30,10 @@ constexpr int HALO = 3;
 constexpr int HD = 16;          // attention head size the kernels are specialised for (dim 128 / 8 heads)
 constexpr int CATP = 4 * D + 4; // LDS row stride of the CQAttention concat tile
 constexpr int MAX_LC = 40;      // max characters per word (LDS budget of k_embed_fwd: 8 words x char_dim x (MAX_LC + 4) floats)
-constexpr int MAX_LQ = 96;      // max query words (LDS budget of the CQAttention kernels: k_cq_bwd_a needs 151 KB at Lq = 82;
-                                // ActivityNet's longest query has 82 words, TACoS' 64 -- SURVEY 8d)
+constexpr int MAX_LQ = 128;     // max query words = the reference's own bound (queries are cut at max_pos_len = 128 words, data_gen.py:188).
+                                // The CQAttention kernels keep a sample's whole query in LDS; above 96 words (no dataset: ActivityNet's longest
+                                // query has 82, TACoS' 64 -- SURVEY 8d) they switch to leaner layouts (CQ_BIG_LQ below)
+constexpr int CQ_BIG_LQ = 96;   // Lq > CQ_BIG_LQ: one wave per 32-word tile instead of four K-partial tiles, aliased / unstaged buffers
 constexpr int MAX_L = 1024;     // max clips per video (tested limit; the attention kernels stream K/V in 256-row blocks)
 
 // ---------------------------------------------------------------------------------------------------------

@@ -1272,7 +1272,8 @@ __global__ __launch_bounds__(256) void k_cq_bwd_a(CqBwdArgs a) {
     float* Gs = Dc + TILE_M * CATP;            // [32][LDP]  df1 tile, later C tile
     float* Ss = Gs + TILE_M * LDP;             // [32][LQ1]  S_row, pad column zeroed (+ slack for the 32-wide over-read)
     float* Sd = Ss + TILE_M * LQ1 + 8;         // [32][LQ1]  dS_row
-    float* Pp = Sd + TILE_M * LQ1 + 64;        // [4][32][PJ] per-wave partial sums of dS_row
+    float* Pp = Sd + TILE_M * LQ1 + 64;        // [4][32][PJ] per-wave partial sums of dS_row ; Lq > CQ_BIG_LQ: [32][PJ], one wave per word tile
+    const bool big = Lq > CQ_BIG_LQ;            // NTJ = 4 then
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int b = blockIdx.y, tl = blockIdx.x, t0 = tl * TILE_M, ntile = gridDim.x;
     const size_t crow = (size_t)b * T, qrow = (size_t)b * Lq;
@@ -1341,6 +1342,32 @@ __global__ __launch_bounds__(256) void k_cq_bwd_a(CqBwdArgs a) {
     {   // dS_row[i][j] = dc2q[i] . Q[j] + dq2c[i] . M[j]: a 32 x 32 MFMA tile per 32 query words, K = 256 split over
         // the four waves (wave w: channels 32w .. 32w+31 of both halves), partial tiles summed in wave order through LDS
         const int i = lane & 31;
+        if (big) {                                              // wave w = word tile w over the whole K = 256: no partial tiles
+            f32x16 dsw[1];
+            zero_acc(dsw);
+            const int j = 32 * w + i;
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+                const float* src = part ? a.M : a.Qf;
+                const float* arow = Dc + i * CATP + (part ? 3 * D : D) + 4 * hh;
+                for (int kb = 0; kb < D / 8; kb += 4) {
+                    float4 bq4[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        bq4[q] = j < Lq ? *reinterpret_cast<const float4*>(src + (qrow + j) * D + (kb + q) * 8 + 4 * hh) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 av = *reinterpret_cast<const float4*>(arow + (kb + q) * 8);
+                        dsw[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bq4[q].x, dsw[0], 0, 0, 0);
+                        dsw[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bq4[q].y, dsw[0], 0, 0, 0);
+                        dsw[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bq4[q].z, dsw[0], 0, 0, 0);
+                        dsw[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bq4[q].w, dsw[0], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Pp[acc_row(r, lane) * PJ + 32 * w + i] = dsw[0][r];
+        } else
         for (int nb = 0; nb < NTJ; nb += 2) {                   // two 32-word tiles per pass (one pass up to 64 query words)
         f32x16 ds[2];
         zero_acc(ds);
@@ -1409,8 +1436,9 @@ __global__ __launch_bounds__(256) void k_cq_bwd_a(CqBwdArgs a) {
             const float* sr = Ss + tid * LQ1;
             float dot = 0.f;
             for (int j = 0; j < Lq; ++j) {
-                const float g = Pp[tid * PJ + j] + Pp[(TILE_M + tid) * PJ + j] + Pp[(2 * TILE_M + tid) * PJ + j] +
-                                Pp[(3 * TILE_M + tid) * PJ + j];
+                const float g = big ? Pp[tid * PJ + j]
+                                    : Pp[tid * PJ + j] + Pp[(TILE_M + tid) * PJ + j] + Pp[(2 * TILE_M + tid) * PJ + j] +
+                                      Pp[(3 * TILE_M + tid) * PJ + j];
                 Sd[tid * LQ1 + j] = g;
                 dot += sr[j] * g;
             }
@@ -1445,7 +1473,8 @@ __global__ __launch_bounds__(256) void k_cq_bwd_b(CqBwdArgs a) {
     float* dMs = smem;                         // [32 NTJ][LDP]  dM (rows >= Lq zero)
     float* Cs = dMs + 32 * NTJ * LDP;          // [32][LDP]
     float* St = Cs + TILE_M * LDP;             // [32][LQ1] S_col tile
-    float* Pp = St + TILE_M * LQ1;             // [4][32][PJ] per-wave partial tiles of dS_col
+    float* Pp = St + TILE_M * LQ1;             // [4][32][PJ] per-wave partial tiles of dS_col ; Lq > CQ_BIG_LQ: [32][PJ], one wave per word tile
+    const bool big = Lq > CQ_BIG_LQ;            // NTJ = 4 then
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, hh = lane >> 5;
     const int b = blockIdx.y, tl = blockIdx.x, t0 = tl * TILE_M, ntile = gridDim.x;
     const size_t crow = (size_t)b * T;
@@ -1458,6 +1487,24 @@ __global__ __launch_bounds__(256) void k_cq_bwd_b(CqBwdArgs a) {
     for (int e = tid; e < (32 * NTJ - Lq) * (D / 4); e += 256)         // zero rows Lq .. 32 NTJ - 1 (B operand of the padded tile)
         *reinterpret_cast<float4*>(dMs + (Lq + (e >> 5)) * LDP + (e & 31) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
+    if (big) {                              // wave w = word tile w over the whole K = 128
+        f32x16 accw[1];
+        zero_acc(accw);
+        const int i = lane & 31;
+        const float* arow = Cs + i * LDP + 4 * hh;
+        const float* brow = dMs + (32 * w + i) * LDP + 4 * hh;
+#pragma unroll
+        for (int kb = 0; kb < D / 8; ++kb) {
+            const float4 av = *reinterpret_cast<const float4*>(arow + kb * 8);
+            const float4 bv = *reinterpret_cast<const float4*>(brow + kb * 8);
+            accw[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, accw[0], 0, 0, 0);
+            accw[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, accw[0], 0, 0, 0);
+            accw[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, accw[0], 0, 0, 0);
+            accw[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, accw[0], 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Pp[acc_row(r, lane) * PJ + 32 * w + i] = accw[0][r];
+    } else
     for (int nb = 0; nb < NTJ; nb += 2) {   // dS_col[i][j] = C[i] . dM[j]: 32 x 32 MFMA tile per 32 query words, K = 128 split over the waves
         f32x16 acc[2];
         zero_acc(acc);
@@ -1489,7 +1536,8 @@ __global__ __launch_bounds__(256) void k_cq_bwd_b(CqBwdArgs a) {
     // sum the four partial tiles in wave order, write dS_col, and the per-tile partial of the column-softmax dot
     for (int e = tid; e < TILE_M * Lq; e += 256) {
         const int i = e / Lq, j = e - i * Lq;
-        const float sv = Pp[i * PJ + j] + Pp[(TILE_M + i) * PJ + j] + Pp[(2 * TILE_M + i) * PJ + j] + Pp[(3 * TILE_M + i) * PJ + j];
+        const float sv = big ? Pp[i * PJ + j]
+                             : Pp[i * PJ + j] + Pp[(TILE_M + i) * PJ + j] + Pp[(2 * TILE_M + i) * PJ + j] + Pp[(3 * TILE_M + i) * PJ + j];
         Pp[i * PJ + j] = sv;                                                    // only this thread touches (i, j)
         if (t0 + i < T) a.dSs[(crow + t0) * Lq + e] = sv;
     }
@@ -1504,8 +1552,9 @@ __global__ __launch_bounds__(256) void k_cq_bwd_c(CqBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int T = a.T, Lq = a.Lq, LQ1 = Lq + 1;
     float* dMs = smem;                         // [Lq][LDP]  dM
+    const bool big = Lq > CQ_BIG_LQ;            // then the dropped-out Q is not staged: its one use reads memory and re-applies the mask
     float* Qds = dMs + Lq * LDP;               // [Lq][LDP]  dropped-out Q (as used by the trilinear score)
-    float* Cs = Qds + Lq * LDP;                // [32][LDP]  C tile, later df2 tile
+    float* Cs = Qds + (big ? 0 : Lq * LDP);    // [32][LDP]  C tile, later df2 tile
     float* Cd = Cs + TILE_M * LDP;             // [32][LDP]  dropped C tile
     float* St = Cd + TILE_M * LDP;             // [32][LQ1]  S_col tile
     float* Sg = St + TILE_M * LQ1 + 8;         // [32][LQ1]  dS tile (+ slack for the chunked over-read)
@@ -1518,6 +1567,7 @@ __global__ __launch_bounds__(256) void k_cq_bwd_c(CqBwdArgs a) {
     // ---- prologue: tile loads + the cross-tile sums
     load_tile128(Cs, a.C + crow * D, t0, TILE_M, T);
     cq_sum_dM(dMs, a.P1, b, ntile, Lq);
+    if (!big)
     for (int e = tid; e < Lq * D; e += 256) {
         const int j = e >> 7, cc = e & 127;
         Qds[j * LDP + cc] = a.Qf[(qrow + j) * D + cc] * drop_mul(a.dq, (uint32_t)(((b + a.b_off) * Lq + j) * D + cc));
@@ -1570,7 +1620,8 @@ __global__ __launch_bounds__(256) void k_cq_bwd_c(CqBwdArgs a) {
                 const bool ok = j < Lq;
                 gv[u] = ok ? sgp[jc + 2 * u] : 0.f;
                 sv[u] = ok ? stp[jc + 2 * u] : 0.f;
-                qv[u] = ok ? Qds[j * LDP + col] : 0.f;
+                qv[u] = !ok ? 0.f : !big ? Qds[j * LDP + col]
+                                          : a.Qf[(qrow + j) * D + col] * drop_mul(a.dq, (uint32_t)(((b + a.b_off) * Lq + j) * D + col));
                 mv[u] = ok ? dMs[j * LDP + col] : 0.f;
             }
 #pragma unroll
@@ -1719,9 +1770,10 @@ void launch_cq_bwd(const CqBwdArgs& a0, int B, hipStream_t s) {
     CqBwdArgs a = a0;
     const int Lq = a.Lq, ntile = (a.T + TILE_M - 1) / TILE_M;
     a.ntile = ntile;
-    const size_t shmA = (size_t)(TILE_M * CATP + TILE_M * LDP + 2 * TILE_M * (Lq + 1) + 72 + 4 * TILE_M * (32 * ((Lq + 31) / 32) + 1)) * sizeof(float);
-    const size_t shmB = (size_t)(32 * ((Lq + 31) / 32) * LDP + TILE_M * LDP + TILE_M * (Lq + 1) + 4 * TILE_M * (32 * ((Lq + 31) / 32) + 1)) * sizeof(float);
-    const size_t shmC = (size_t)(2 * Lq * LDP + 2 * TILE_M * LDP + 2 * TILE_M * (Lq + 1) + 16 + Lq + TILE_M + 4 * D) * sizeof(float);
+    const int npart = Lq > CQ_BIG_LQ ? 1 : 4;         // partial tiles of the small MFMA products (see the kernels)
+    const size_t shmA = (size_t)(TILE_M * CATP + TILE_M * LDP + 2 * TILE_M * (Lq + 1) + 72 + npart * TILE_M * (32 * ((Lq + 31) / 32) + 1)) * sizeof(float);
+    const size_t shmB = (size_t)(32 * ((Lq + 31) / 32) * LDP + TILE_M * LDP + TILE_M * (Lq + 1) + npart * TILE_M * (32 * ((Lq + 31) / 32) + 1)) * sizeof(float);
+    const size_t shmC = (size_t)((Lq > CQ_BIG_LQ ? 1 : 2) * Lq * LDP + 2 * TILE_M * LDP + 2 * TILE_M * (Lq + 1) + 16 + Lq + TILE_M + 4 * D) * sizeof(float);
     static size_t okA = 0, okB = 0, okC = 0;
     ensure_dynamic_lds((const void*)k_cq_bwd_a, shmA, okA, "k_cq_bwd_a");
     ensure_dynamic_lds((const void*)k_cq_bwd_b, shmB, okB, "k_cq_bwd_b");

@@ -2,6 +2,7 @@
 // (/root/reference/model/layers_t7.py unless noted).  Layout: activations are row-major (B*L, 128) fp32.
 #include "common.hpp"
 #include "launch.hpp"
+#include <algorithm>
 #include <type_traits>
 
 namespace vsl {
@@ -893,7 +894,7 @@ void launch_attn_out_fwd(const float* att, const float* x, const float* ln_g, co
 //      plus a11's WeightedPool (:253-259) and the per-sample bias  pb = W2 pooled + b  of CQConcatenate (:268-274).
 //  (3) k_cq_out  : c2q = S_row Q, q2c = S_row M, concat [C, c2q, C*c2q, C*q2c] (:231) -> Conv1D 4d->d (:232).
 // =========================================================================================================
-template <int NU>   // words per lane of the row softmax: 8 (Lq <= 64) or MAX_LQ / 8
+template <int NU>   // words per lane of the row softmax: 8 (Lq <= 64), 12 (<= 96) or 16 (<= MAX_LQ = 128)
 __global__ __launch_bounds__(256) void k_cq_score(const float* __restrict__ C, const float* __restrict__ Qf,
                                                   const float* __restrict__ qmask, const float* __restrict__ w4C,
                                                   const float* __restrict__ w4Q, const float* __restrict__ w4mlu,
@@ -1060,14 +1061,17 @@ void launch_cq_score(const float* C, const float* Qf, const float* qmask, const 
                      hipStream_t s) {
     const int NTJ = (Lq + 31) / 32;
     const size_t shm = (size_t)((TILE_M + 32 * NTJ) * LDP + TILE_M + 32 * NTJ + 4 * TILE_M * (32 * NTJ + 1)) * sizeof(float);
-    static size_t ok8 = 0, okn = 0;
+    static size_t ok8 = 0, ok12 = 0, ok16 = 0;
     const dim3 grid((T + TILE_M - 1) / TILE_M, B);
     if (Lq <= 64) {
         ensure_dynamic_lds((const void*)k_cq_score<8>, shm, ok8, "k_cq_score<8>");
         VSL_LAUNCH(k_cq_score<8>, grid, dim3(256), shm, s, C, Qf, qmask, w4C, w4Q, w4mlu, S, Srow, T, Lq, b_off, dc, dq);
+    } else if (Lq <= 96) {
+        ensure_dynamic_lds((const void*)k_cq_score<12>, shm, ok12, "k_cq_score<12>");
+        VSL_LAUNCH(k_cq_score<12>, grid, dim3(256), shm, s, C, Qf, qmask, w4C, w4Q, w4mlu, S, Srow, T, Lq, b_off, dc, dq);
     } else {
-        ensure_dynamic_lds((const void*)k_cq_score<MAX_LQ / 8>, shm, okn, "k_cq_score<12>");
-        VSL_LAUNCH(k_cq_score<MAX_LQ / 8>, grid, dim3(256), shm, s, C, Qf, qmask, w4C, w4Q, w4mlu, S, Srow, T, Lq, b_off, dc, dq);
+        ensure_dynamic_lds((const void*)k_cq_score<16>, shm, ok16, "k_cq_score<16>");
+        VSL_LAUNCH(k_cq_score<16>, grid, dim3(256), shm, s, C, Qf, qmask, w4C, w4Q, w4mlu, S, Srow, T, Lq, b_off, dc, dq);
     }
 }
 
@@ -1231,10 +1235,13 @@ __global__ __launch_bounds__(256) void k_cq_out(const float* __restrict__ C, con
                                                 float* __restrict__ out, int T, int Lq, CqCatFuse cf) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int LQ1 = Lq + 1;
+    // Lq > CQ_BIG_LQ: M lives where the concat tile will be written (it is dead by then, behind one extra barrier): 101 instead of 167 KB
+    const bool big = Lq > CQ_BIG_LQ;
+    const int cat_floats = big ? max(TILE_M * CATP, Lq * LDP) : TILE_M * CATP;
     float* Cat = smem;                        // [32][CATP]
-    float* Cs = Cat + TILE_M * CATP;          // [32][LDP]
-    float* Ms = Cs + TILE_M * LDP;            // [Lq][LDP]   M = S_col^T C, summed here from k_cq_col's per-tile partials
-    float* Ss = Ms + Lq * LDP;                // [32][LQ1]   S_row tile, zero pad column
+    float* Cs = Cat + cat_floats;             // [32][LDP]
+    float* Ms = big ? Cat : Cs + TILE_M * LDP;   // [Lq][LDP]   M = S_col^T C, summed here from k_cq_col's per-tile partials
+    float* Ss = Cs + TILE_M * LDP + (big ? 0 : Lq * LDP);   // [32][LQ1]   S_row tile, zero pad column
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, hh = lane >> 5;
     const int b = blockIdx.y, t0 = blockIdx.x * TILE_M, ntile = gridDim.x;
     const size_t crow = (size_t)b * T, qrow = (size_t)b * Lq;
@@ -1281,6 +1288,7 @@ __global__ __launch_bounds__(256) void k_cq_out(const float* __restrict__ C, con
                 }
             }
         }
+        if (big) __syncthreads();                  // block-uniform: every wave is done with M before the concat tile overwrites it
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int rr = acc_row(r, lane);
@@ -1363,7 +1371,8 @@ __global__ __launch_bounds__(256) void k_cq_out(const float* __restrict__ C, con
 void launch_cq_out(const float* C, const float* Qf, const float* Srow, const float* Mpart, float* M, const float* Wpack,
                    const float* bias, float* cat_out, float* out, const float* W1pack, const float* pb, const float* wh,
                    const float* bh, const float* vmask, float* f2, float* hscore, float* gated, int B, int T, int Lq, hipStream_t s) {
-    const size_t shm = (size_t)(TILE_M * CATP + TILE_M * LDP + Lq * LDP + TILE_M * (Lq + 1) + 32) * sizeof(float);
+    const size_t shm = (Lq > CQ_BIG_LQ ? (size_t)(std::max(TILE_M * CATP, Lq * LDP) + TILE_M * LDP + TILE_M * (Lq + 1) + 32)
+                                       : (size_t)(TILE_M * CATP + TILE_M * LDP + Lq * LDP + TILE_M * (Lq + 1) + 32)) * sizeof(float);
     static size_t lds_ok = 0;
     ensure_dynamic_lds((const void*)k_cq_out, shm, lds_ok, "k_cq_out");
     VSL_LAUNCH(k_cq_out, dim3((T + TILE_M - 1) / TILE_M, B), dim3(256), shm, s, C, Qf, Srow, Mpart, M, Wpack, bias, cat_out, out,

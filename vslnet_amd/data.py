@@ -324,7 +324,7 @@ def synthetic_dataset(configs, n_train=512, n_test=128, n_words=200, n_chars=30,
 
 # limits of the HIP engine (vslnet_amd/csrc/common.hpp: MAX_LQ, MAX_LC; api.hip vsl_create): checked against the WHOLE dataset
 # before the first step, so that one long query or token cannot abort a run in the middle of an epoch
-ENGINE_MAX_WORDS, ENGINE_MAX_CHARS, ENGINE_MAX_CHAR_DIM = 96, 40, 64
+ENGINE_MAX_WORDS, ENGINE_MAX_CHARS, ENGINE_MAX_CHAR_DIM = 128, 40, 64
 
 
 def validate_dataset(dataset, configs):
