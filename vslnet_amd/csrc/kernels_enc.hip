@@ -730,12 +730,15 @@ int convblock_slabs(int R, int L) { return L <= TILE_M ? R / L : (R + TILE_M - 1
 //   meet in one LDS tile, and the same workgroup finishes the block on it: r = drop(att) + x -> LN2 -> dropout -> Wo GEMM -> dropout -> + r.
 //   Saves att, LSE, r, h2 for the backward exactly like the two-kernel path (VSL_ATTN_BLOCK=0).
 // =========================================================================================================
-__global__ __launch_bounds__(CB_T, 2) void k_attn_block_fwd(AttnBlockArgs a) {
+template <int QB>     // 16-query blocks per wave: 2 = 8 waves (wave = head), 1 = 16 waves (wave = head x query block): twice the waves per SIMD
+__global__ __launch_bounds__(1024 / QB, QB) void k_attn_block_fwd(AttnBlockArgs a) {
+    constexpr int NT = 1024 / QB, NQ = 1024 / NT;      // threads ; float4 items per thread of a 32 x 128 tile
     __shared__ __attribute__((aligned(16))) float Rs[TILE_M * LDP];          // att, then r = drop(att) + x
     __shared__ __attribute__((aligned(16))) float Hs[TILE_M * LDP];          // drop(LN2(r)): GEMM A operand
     __shared__ float Pn[384];                                                 // ln2_g | ln2_b | bo
     extern __shared__ __attribute__((aligned(16))) float Mb[];               // key bias of the sample, padded to whole key tiles
-    const int tid = threadIdx.x, h = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, h = (tid >> 6) & 7, lane = tid & 63;
+    const int qoff = QB == 2 ? 0 : 16 * (tid >> 9);      // first query row of this wave inside the tile
     const int L = a.L, H = 8;
     int bxs, b, bzs;
     xcd_swizzle(bxs, b, bzs);                       // the query tiles of a sample on one XCD: its K / V rows sit in one L2
@@ -744,18 +747,18 @@ __global__ __launch_bounds__(CB_T, 2) void k_attn_block_fwd(AttnBlockArgs a) {
     const int qi = lane & 15, g = lane >> 4;
     ESTAMP(0);
     const int Lp = (L + 15) & ~15;
-    for (int k = tid; k < Lp; k += CB_T) Mb[k] = k < L ? (1.0f - a.mask[rowbase + k]) * MASK_VALUE : MASK_VALUE;
+    for (int k = tid; k < Lp; k += NT) Mb[k] = k < L ? (1.0f - a.mask[rowbase + k]) * MASK_VALUE : MASK_VALUE;
     // per-wave (= per-head) uniform bases + 32-bit lane offsets, so a fragment load is one saddr + voffset instruction
     const int hw = __builtin_amdgcn_readfirstlane(h);
     const float* __restrict__ Qh = a.Q + rowbase * D + hw * HD;
     const float* __restrict__ Kh = a.K + rowbase * D + hw * HD;
     const float* __restrict__ Vh = a.V + rowbase * D + hw * HD;
-    float4 qf[2];
-    float m[2], l[2];
-    f32x4 o[2];
+    float4 qf[QB];
+    float m[QB], l[QB];
+    f32x4 o[QB];
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-        const int q = q0 + 16 * qb + qi;
+    for (int qb = 0; qb < QB; ++qb) {
+        const int q = q0 + qoff + 16 * qb + qi;
         qf[qb] = q < L ? *reinterpret_cast<const float4*>(Qh + (unsigned)(q * D + 4 * g)) : make_float4(0.f, 0.f, 0.f, 0.f);
         m[qb] = -3.0e38f; l[qb] = 0.f; o[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -779,10 +782,10 @@ __global__ __launch_bounds__(CB_T, 2) void k_attn_block_fwd(AttnBlockArgs a) {
     // not needed before the output stage: out_layer fragments, the residual rows x, LN2 / bias vectors
     BF16 bf[1];
     bf16_load(bf[0], a.Wpack, D, 16 * h);
-    float4 xv[2];
+    float4 xv[NQ];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int e = tid + q * CB_T, rr = e >> 5, c = (e & 31) * 4;
+    for (int q = 0; q < NQ; ++q) {
+        const int e = tid + q * NT, rr = e >> 5, c = (e & 31) * 4;
         xv[q] = q0 + rr < L ? *reinterpret_cast<const float4*>(a.x + (rowbase + q0 + rr) * D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (tid < 384) Pn[tid] = tid < 128 ? a.ln_g[tid] : tid < 256 ? a.ln_b[tid - 128] : a.bo[tid - 256];
@@ -793,10 +796,10 @@ __global__ __launch_bounds__(CB_T, 2) void k_attn_block_fwd(AttnBlockArgs a) {
         if (kt + 16 < Lp) { load_kt(kt + 16, nxt); nxt.mb = *reinterpret_cast<const float4*>(&Mb[kt + 16 + 4 * g]); }
         __builtin_amdgcn_sched_barrier(0);
         const float mbv[4] = {cur.mb.x, cur.mb.y, cur.mb.z, cur.mb.w};
-        f32x4 s[2];
-        float p[2][4], alpha[2];
+        f32x4 s[QB];
+        float p[QB][4], alpha[QB];
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
+        for (int qb = 0; qb < QB; ++qb) {
             s[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
             s[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.kf.x, qf[qb].x, s[qb], 0, 0, 0);
             s[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.kf.y, qf[qb].y, s[qb], 0, 0, 0);
@@ -804,7 +807,7 @@ __global__ __launch_bounds__(CB_T, 2) void k_attn_block_fwd(AttnBlockArgs a) {
             s[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.kf.w, qf[qb].w, s[qb], 0, 0, 0);
         }
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
+        for (int qb = 0; qb < QB; ++qb) {
             float tmax = -3.0e38f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) { p[qb][r] = s[qb][r] * scale + mbv[r]; tmax = fmaxf(tmax, p[qb][r]); }
@@ -820,8 +823,8 @@ __global__ __launch_bounds__(CB_T, 2) void k_attn_block_fwd(AttnBlockArgs a) {
             }
         }
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-            const int q = q0 + 16 * qb + qi;
+        for (int qb = 0; qb < QB; ++qb) {
+            const int q = q0 + qoff + 16 * qb + qi;
             const uint32_t pbase = (uint32_t)(((size_t)(b + a.b_off) * H + h) * L + q) * (uint32_t)L + (uint32_t)(kt + 4 * g);
 #pragma unroll
             for (int r = 0; r < 4; ++r) p[qb][r] *= drop_mul(a.d2, pbase + r);
@@ -829,17 +832,17 @@ __global__ __launch_bounds__(CB_T, 2) void k_attn_block_fwd(AttnBlockArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int qb = 0; qb < 2; ++qb) o[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.vv[r], p[qb][r], o[qb], 0, 0, 0);
+            for (int qb = 0; qb < QB; ++qb) o[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.vv[r], p[qb][r], o[qb], 0, 0, 0);
         cur = nxt;
     }
     ESTAMP(2);
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
+    for (int qb = 0; qb < QB; ++qb) {
         const float lt = kgroup_sum(l[qb]);
-        const int q = q0 + 16 * qb + qi;
+        const int q = q0 + qoff + 16 * qb + qi;
         const float inv = 1.0f / lt;
         const float4 ov = make_float4(o[qb][0] * inv, o[qb][1] * inv, o[qb][2] * inv, o[qb][3] * inv);   // lane (qi, g): O[q][4g + reg]
-        *reinterpret_cast<float4*>(&Rs[(16 * qb + qi) * LDP + h * HD + 4 * g]) = ov;
+        *reinterpret_cast<float4*>(&Rs[(qoff + 16 * qb + qi) * LDP + h * HD + 4 * g]) = ov;
         if (q < L) {
             *reinterpret_cast<float4*>(a.att + (rowbase + q) * D + h * HD + 4 * g) = ov;
             if (g == 0) a.lse[((size_t)b * H + h) * L + q] = m[qb] + __logf(lt);
@@ -849,8 +852,8 @@ __global__ __launch_bounds__(CB_T, 2) void k_attn_block_fwd(AttnBlockArgs a) {
     ESTAMP(3);
     // ---- r = drop(att) + x (:183-184)
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int e = tid + q * CB_T, rr = e >> 5, c = (e & 31) * 4;
+    for (int q = 0; q < NQ; ++q) {
+        const int e = tid + q * NT, rr = e >> 5, c = (e & 31) * 4;
         const int r = (int)rowbase + q0 + rr;
         float4 v = *reinterpret_cast<const float4*>(&Rs[rr * LDP + c]);
         if (q0 + rr < L) {
@@ -868,21 +871,22 @@ __global__ __launch_bounds__(CB_T, 2) void k_attn_block_fwd(AttnBlockArgs a) {
     ESTAMP(5);
     if (a.h2_out) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int e = tid + q * CB_T, rr = e >> 5, c = (e & 31) * 4;
+        for (int q = 0; q < NQ; ++q) {
+            const int e = tid + q * NT, rr = e >> 5, c = (e & 31) * 4;
             if (q0 + rr < L) *reinterpret_cast<float4*>(a.h2_out + (rowbase + q0 + rr) * D + c) = *reinterpret_cast<const float4*>(&Hs[rr * LDP + c]);
         }
     }
-    f32x4 acc[1][2];
-    acc[0][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[0][1] = acc[0][0];
-    gemm16<2, 1>(Hs, LDP, bf, acc);
+    f32x4 acc[1][QB];
+#pragma unroll
+    for (int rb = 0; rb < QB; ++rb) acc[0][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    gemm16<QB, 1>(Hs + qoff * LDP, LDP, bf, acc);
     const int col = 16 * h + qi;
     const float bv = Pn[256 + col];
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+    for (int rb = 0; rb < QB; ++rb)
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-            const int row = 16 * rb + 4 * g + rr;
+            const int row = qoff + 16 * rb + 4 * g + rr;
             if (q0 + row < L) {
                 const int r = (int)rowbase + q0 + row;
                 a.y_out[(size_t)r * D + col] = (acc[0][rb][rr] + bv) * drop_mul(a.d5, (uint32_t)(r * D + col)) + Rs[row * LDP + col];
@@ -891,7 +895,14 @@ __global__ __launch_bounds__(CB_T, 2) void k_attn_block_fwd(AttnBlockArgs a) {
     ESTAMP(6);
 }
 void launch_attn_block_fwd(const AttnBlockArgs& a, int B, hipStream_t s) {
-    VSL_LAUNCH(k_attn_block_fwd, dim3((a.L + TILE_M - 1) / TILE_M, B), dim3(CB_T), (size_t)((a.L + 15) & ~15) * sizeof(float), s, a);
+    // 16 waves (wave = head x 16-query block) up to L = 128, 8 waves (wave = head, two query blocks) beyond: measured ms/step 8 / 16 waves
+    // at cfg2 (L = 128) 1.030 / 1.023, at cfg4 (L = 256) 1.110 / 1.112.  VSL_ATTN_WAVES=8 / 16 forces one.
+    static const char* ew = getenv("VSL_ATTN_WAVES");
+    const bool w16 = ew ? ew[0] != '8' : a.L <= 128;
+    const dim3 grid((a.L + TILE_M - 1) / TILE_M, B);
+    const size_t shm = (size_t)((a.L + 15) & ~15) * sizeof(float);
+    if (w16) VSL_LAUNCH(k_attn_block_fwd<1>, grid, dim3(1024), shm, s, a);
+    else VSL_LAUNCH(k_attn_block_fwd<2>, grid, dim3(512), shm, s, a);
     static int left = 3;
     if (edbg_on() && B > 16) edbg_report("attn_block_fwd", 7, s, left);
 }
