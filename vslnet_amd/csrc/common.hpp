@@ -102,16 +102,46 @@ __device__ __forceinline__ float sigmoid_fast(float x) { return __frcp_rn(1.0f +
 __device__ __forceinline__ float tanh_fast(float x) { return 2.0f * sigmoid_fast(2.0f * x) - 1.0f; }
 
 // ---------------------------------------------------------------------------------------------------------
-// wave reductions (64 lanes)
+// Cross-lane exchanges of the butterfly reductions WITHOUT the LDS crossbar: __shfl_xor compiles to ds_bpermute_b32 (an LDS round
+// trip of 100+ cycles per step, and every LayerNorm row is two 3-step reductions); DPP modifiers and gfx950's permlane swaps do the
+// same exchanges in the vector ALU.  Each helper returns the partner's value of the named butterfly step, so `v op= xorN(v)` is
+// bit-identical to the shuffle version:
+//   xor 1, 2      quad_perm (exact)
+//   xor 4         row_half_mirror: lane i <- 7 - i of its 8-lane group, = lane i ^ 4 once the quads are uniform (after the xor 1, 2 steps)
+//                 -- or row_ror:4 once lanes i and i ^ 8 agree (descending butterflies, after the xor 8 step)
+//   xor 8         row_ror:8 (exact)
+//   xor 16, 32    v_permlane16_swap / v_permlane32_swap of the value with itself: one result holds the lane's own value, the other
+//                 the partner's (which is which depends on the lane; + and max are commutative)
 // ---------------------------------------------------------------------------------------------------------
+#define VSL_DPP(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xF, 0xF, true))
+__device__ __forceinline__ float lane_xor1(float v) { return VSL_DPP(v, 0xB1); }
+__device__ __forceinline__ float lane_xor2(float v) { return VSL_DPP(v, 0x4E); }
+__device__ __forceinline__ float lane_half_mirror(float v) { return VSL_DPP(v, 0x141); }
+__device__ __forceinline__ float lane_ror4(float v) { return VSL_DPP(v, 0x124); }
+__device__ __forceinline__ float lane_xor8(float v) { return VSL_DPP(v, 0x128); }
+template <class OP> __device__ __forceinline__ float lane_pair16(float v, OP op) {
+    const unsigned u = __float_as_uint(v);
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return op(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+template <class OP> __device__ __forceinline__ float lane_pair32(float v, OP op) {
+    const unsigned u = __float_as_uint(v);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return op(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+// wave reductions (64 lanes), butterfly 32, 16, 8, 4, 2, 1 as before
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    auto add = [](float a, float b) { return a + b; };
+    v = lane_pair32(v, add);
+    v = lane_pair16(v, add);
+    v += lane_xor8(v); v += lane_ror4(v); v += lane_xor2(v); v += lane_xor1(v);
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    auto mx = [](float a, float b) { return fmaxf(a, b); };
+    v = lane_pair32(v, mx);
+    v = lane_pair16(v, mx);
+    v = fmaxf(v, lane_xor8(v)); v = fmaxf(v, lane_ror4(v)); v = fmaxf(v, lane_xor2(v)); v = fmaxf(v, lane_xor1(v));
     return v;
 }
 
@@ -391,11 +421,11 @@ __device__ __forceinline__ void ln_row_bwd(float x0, float x1, float dy0, float 
 
 // ---------------------------------------------------------------------------------------------------------
 // Tile-wide LayerNorm: 8 consecutive lanes own one row (lane sub = tid & 7 holds the float4 columns
-// sub*4 + 32*j, j = 0..3), 32 rows per pass of the 256-thread workgroup -> two 3-step shuffle reductions per row
+// sub*4 + 32*j, j = 0..3), 32 rows per pass of the 256-thread workgroup -> two 3-step DPP reductions per row
 // instead of a 6-step wave reduction per row executed serially by one wave.
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float grp8_sum(float v) {
-    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+    v += lane_xor1(v); v += lane_xor2(v); v += lane_half_mirror(v);
     return v;
 }
 __device__ __forceinline__ float sum4(const float4& v) { return (v.x + v.y) + (v.z + v.w); }

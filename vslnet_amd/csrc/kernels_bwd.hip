@@ -748,8 +748,8 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(const float* __restrict__ Q
         lq = lse[((size_t)b * H + h) * L + q];
     }
     float dsum = da.x * of.x + da.y * of.y + da.z * of.z + da.w * of.w;     // D_q = dA . O  (= sum_k dP_k P_k)
-    dsum += __shfl_xor(dsum, 16);
-    dsum += __shfl_xor(dsum, 32);
+    dsum = lane_pair16(dsum, [](float a, float b) { return a + b; });
+    dsum = lane_pair32(dsum, [](float a, float b) { return a + b; });
     if (qok && g == 0) Dq[((size_t)b * H + h) * L + q] = dsum;
     const float scale = 0.25f;
     const uint32_t pbase = (uint32_t)(((size_t)(b + b_off) * H + h) * L + q) * (uint32_t)L;
@@ -947,8 +947,8 @@ __global__ __launch_bounds__(1024) void k_attn_bwd_fused(const float* __restrict
             *reinterpret_cast<float4*>(&Vs[row * AB_KST + c4]) = vv;
             *reinterpret_cast<float4*>(&As[row * AB_KST + c4]) = av;
             float dsum = av.x * ov.x + av.y * ov.y + av.z * ov.z + av.w * ov.w;     // D_q = dA . O (= sum_k dP_k P_k)
-            dsum += __shfl_xor(dsum, 1);
-            dsum += __shfl_xor(dsum, 2);
+            dsum += lane_xor1(dsum);
+            dsum += lane_xor2(dsum);
             if ((e & 3) == 0) Ds[row] = dsum;
         }
     }

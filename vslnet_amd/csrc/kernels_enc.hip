@@ -641,9 +641,9 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
         }
         // the 4 segments of a channel sit in 4 adjacent lanes
 #pragma unroll
-        for (int k = 0; k < DWK; ++k) { gw[k] += __shfl_xor(gw[k], 1); gw[k] += __shfl_xor(gw[k], 2); }
-        slb += __shfl_xor(slb, 1); slb += __shfl_xor(slb, 2);
-        slg += __shfl_xor(slg, 1); slg += __shfl_xor(slg, 2);
+        for (int k = 0; k < DWK; ++k) { gw[k] += lane_xor1(gw[k]); gw[k] += lane_xor2(gw[k]); }
+        slb += lane_xor1(slb); slb += lane_xor2(slb);
+        slg += lane_xor1(slg); slg += lane_xor2(slg);
         if (seg == 0) {
 #pragma unroll
             for (int k = 0; k < DWK; ++k) a.p_dw[l][(size_t)blockIdx.x * D * DWK + cc * DWK + k] = gw[k];

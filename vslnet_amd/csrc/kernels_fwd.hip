@@ -765,8 +765,8 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const float* __restrict__ Q, c
                 p[r] = s[r] * scale + Mb[kt + 4 * g + r];
                 tmax = fmaxf(tmax, p[r]);
             }
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+            tmax = lane_pair16(tmax, [](float a, float b) { return fmaxf(a, b); });
+            tmax = lane_pair32(tmax, [](float a, float b) { return fmaxf(a, b); });
             const float mn = fmaxf(m, tmax);
             const float alpha = __expf(m - mn);
             m = mn;
@@ -787,8 +787,8 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const float* __restrict__ Q, c
             }
         }
     }
-    l += __shfl_xor(l, 16);
-    l += __shfl_xor(l, 32);
+    l = lane_pair16(l, [](float a, float b) { return a + b; });
+    l = lane_pair32(l, [](float a, float b) { return a + b; });
     if (qok) {
         const float inv = 1.0f / l;
         // lane (qi, g) holds O[q][dd = 4g + reg]
@@ -1042,7 +1042,7 @@ __global__ __launch_bounds__(256) void k_cq_score(const float* __restrict__ C, c
                 mx = fmaxf(mx, v[u]);
             }
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 1)); mx = fmaxf(mx, __shfl_xor(mx, 2)); mx = fmaxf(mx, __shfl_xor(mx, 4));
+        mx = fmaxf(mx, lane_xor1(mx)); mx = fmaxf(mx, lane_xor2(mx)); mx = fmaxf(mx, lane_half_mirror(mx));
         float sm = 0.f;
 #pragma unroll
         for (int u = 0; u < NU; ++u) { v[u] = (sub + 8 * u < Lq) ? __expf(v[u] - mx) : 0.f; sm += v[u]; }

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(WG2_T, 2) void k_wgrad2(WgradBatch wb) {
             }
     }
     if (kt == 0 && kh == 0 && j.out_bias[gb]) {
-        bs.x += __shfl_xor(bs.x, 32); bs.y += __shfl_xor(bs.y, 32);
+        bs.x = lane_pair32(bs.x, [](float a, float b) { return a + b; }); bs.y = lane_pair32(bs.y, [](float a, float b) { return a + b; });
         if (h == 0) *reinterpret_cast<float2*>(j.out_bias[gb] + (size_t)ch * D + 64 * nh + 2 * i) = bs;
     }
 }
