@@ -160,7 +160,10 @@ constexpr int CB_PS = 384;                      // per-layer small parameters in
 // SH = rows a layer's valid range shrinks by on each side: 3 = row tiles with a recomputed halo (12 + 32 + 12 rows);
 // 0 = SAMPLE tiles for sequences of at most 32 rows (the query pass: Lq = 20): one workgroup per sample, its rows at the top
 // of a 32-row window, no halo and no recomputation -- rows >= L and the taps that leave the window are the conv's zero padding.
-template <int SH>
+// FULL: R and L are multiples of the 32-row tile (every BASELINE shape): every tile is whole and lies inside one sample, so the boundary
+// flags below are compile-time constants and the per-row store / tap predicates disappear (12 % of the kernel's instructions were
+// v_cmp / v_cndmask / exec-mask branches).
+template <int SH, bool FULL>
 __global__ __launch_bounds__(CB_T, 2) void k_convblock_fwd(CbFwdArgs a) {
     // sample tiles: 3 zero rows above and below the window in the LN / depthwise buffer stand for the taps that leave it
     constexpr int HL = 4 * SH, NW = TILE_M + 2 * HL, VOFF = SH ? 0 : HALO, VUR = SH ? NW + 12 : NW + 2 * HALO;
@@ -224,15 +227,15 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_fwd(CbFwdArgs a) {
     for (int k = 0; k < DWK; ++k) wkc[k] = a.dw_w[0][(tid & 127) * DWK + k];
     // a window that lies inside one sample needs no boundary tests in the depthwise conv (block-uniform)
     const bool interior = SH && rw0 >= 0 && rw0 + NW <= R && (rw0 % L) + NW <= L;
-    const bool full = SH && r0 + TILE_M <= R;
+    const bool full = FULL || (SH && r0 + TILE_M <= R);
     // Owner rows inside ONE sample (every tile when L % 32 == 0, and always in sample mode): the window rows of other samples
     // only ever act as that sample's zero padding (their own outputs feed no owner row), so their LayerNorm output is written
     // as zeros and the depthwise conv runs without per-tap tests.  [klo, khi) = window rows of the owner sample.
     const int s_own = r0 / L;
-    const bool one_owner = !SH || (full && (r0 + TILE_M - 1) / L == s_own);
+    const bool one_owner = FULL || !SH || (full && (r0 + TILE_M - 1) / L == s_own);
     const int klo = max(0, s_own * L - rw0), khi = min(NW, (s_own + 1) * L - rw0);
-    const bool plain = interior || one_owner;
-    auto row_ok = [&](int wr) { return SH ? (full || rw0 + wr < R) : wr < L; };     // may window row wr (an owner row) be stored?
+    const bool plain = FULL || interior || one_owner;
+    auto row_ok = [&](int wr) { return FULL || (SH ? (full || rw0 + wr < R) : wr < L); };     // may window row wr (an owner row) be stored?
     __syncthreads();
     ESTAMP(1);
     const Drop nodrop{0u, 0u, 1.f};
@@ -400,14 +403,19 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_fwd(CbFwdArgs a) {
 }
 constexpr size_t cb_fwd_lds(int sh) { return (size_t)(((sh ? 2 : 1) * (TILE_M + 8 * sh) + (sh ? TILE_M + 8 * sh + 12 : TILE_M + 2 * HALO)) * LDP + 4 * CB_PS + 640) * sizeof(float); }
 void launch_convblock_fwd(const CbFwdArgs& a, hipStream_t s) {
-    static size_t ok3 = 0, ok0 = 0;
+    static size_t ok3 = 0, ok3f = 0, ok0 = 0;
     if (a.L <= TILE_M) {                    // sample tiles: one workgroup per sample
-        ensure_dynamic_lds((const void*)k_convblock_fwd<0>, cb_fwd_lds(0), ok0, "k_convblock_fwd<0>");
-        VSL_LAUNCH(k_convblock_fwd<0>, dim3(a.R / a.L), dim3(CB_T), cb_fwd_lds(0), s, a);
+        ensure_dynamic_lds((const void*)k_convblock_fwd<0, false>, cb_fwd_lds(0), ok0, "k_convblock_fwd<0>");
+        VSL_LAUNCH((k_convblock_fwd<0, false>), dim3(a.R / a.L), dim3(CB_T), cb_fwd_lds(0), s, a);
         return;
     }
-    ensure_dynamic_lds((const void*)k_convblock_fwd<3>, cb_fwd_lds(3), ok3, "k_convblock_fwd<3>");
-    VSL_LAUNCH(k_convblock_fwd<3>, dim3((a.R + TILE_M - 1) / TILE_M), dim3(CB_T), cb_fwd_lds(3), s, a);
+    if (a.R % TILE_M == 0 && a.L % TILE_M == 0) {       // whole tiles inside one sample each: the predicate-free instantiation
+        ensure_dynamic_lds((const void*)k_convblock_fwd<3, true>, cb_fwd_lds(3), ok3f, "k_convblock_fwd<3, full>");
+        VSL_LAUNCH((k_convblock_fwd<3, true>), dim3(a.R / TILE_M), dim3(CB_T), cb_fwd_lds(3), s, a);
+    } else {
+        ensure_dynamic_lds((const void*)k_convblock_fwd<3, false>, cb_fwd_lds(3), ok3, "k_convblock_fwd<3>");
+        VSL_LAUNCH((k_convblock_fwd<3, false>), dim3((a.R + TILE_M - 1) / TILE_M), dim3(CB_T), cb_fwd_lds(3), s, a);
+    }
     static int left = 6;
     if (edbg_on() && a.R > 4096) { int l2 = left; edbg_report("convblock_fwd: load | L0 | L1 | L2 | L3 | qkv", 7, s, left); edbg_report2("  L0: LN | dw | gemm | epilogue | barrier", 8, 13, s, l2); }
 }
@@ -423,7 +431,7 @@ void launch_convblock_fwd(const CbFwdArgs& a, hipStream_t s) {
 // segment) with the 4 segments of a channel in 4 adjacent lanes, so the partial sums are combined with two quad shuffles.
 // LDS 91 KB: fits beside a weight-gradient workgroup (66 KB) of the side stream.
 // =========================================================================================================
-template <int SH>        // 3: row tiles with a recomputed halo ; 0: sample tiles for L <= 32 (see k_convblock_fwd)
+template <int SH, bool FULL>        // SH 3: row tiles with a recomputed halo ; 0: sample tiles for L <= 32 ; FULL: see k_convblock_fwd
 __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
     constexpr int HL = 4 * SH, NW = TILE_M + 2 * HL, VUR = SH ? NW + 12 : NW, XR = NW - 2 * SH;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -438,12 +446,12 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
     const int R = a.R, L = a.L;
     const int r0 = SH ? blockIdx.x * TILE_M : blockIdx.x * L, rw0 = r0 - HL;
     const bool interior = SH && rw0 >= 0 && rw0 + NW <= R && (rw0 % L) + NW <= L;
-    const bool full = SH && r0 + TILE_M <= R;
+    const bool full = FULL || (SH && r0 + TILE_M <= R);
     const int s_own = r0 / L;
-    const bool one_owner = !SH || (full && (r0 + TILE_M - 1) / L == s_own);
+    const bool one_owner = FULL || !SH || (full && (r0 + TILE_M - 1) / L == s_own);
     const int klo = max(0, s_own * L - rw0), khi = min(NW, (s_own + 1) * L - rw0);
-    const bool plain = interior || one_owner;
-    auto row_ok = [&](int wr) { return SH ? (full || rw0 + wr < R) : wr < L; };     // may window row wr (an owner row) be stored?
+    const bool plain = FULL || interior || one_owner;
+    auto row_ok = [&](int wr) { return FULL || (SH ? (full || rw0 + wr < R) : wr < L); };     // may window row wr (an owner row) be stored?
     auto row_in = [&](int wr) { return wr < NW && (SH ? (rw0 + wr >= 0 && rw0 + wr < R) : wr < L); };   // does it exist (in this sample)?
     // row layout of the loads and of phases A, LN, D: 8 lanes per window row, lane `sub` owns the columns 4 sub + 32 j .. + 3 (j = 0..3).
     // One thread keeps one row for the whole kernel, so what phase D of a layer writes (dy) and reads (dv, xhat) is exactly what phase
@@ -708,14 +716,19 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
 }
 constexpr size_t cb_bwd_lds(int sh) { return (size_t)((TILE_M + 8 * sh + 2 * (sh ? TILE_M + 8 * sh + 12 : TILE_M) + TILE_M + 6 * sh) * LDP + 64 + 64 + 256) * sizeof(float); }
 void launch_convblock_bwd(const CbBwdArgs& a, hipStream_t s) {
-    static size_t ok3 = 0, ok0 = 0;
+    static size_t ok3 = 0, ok3f = 0, ok0 = 0;
     if (a.L <= TILE_M) {                    // sample tiles: one workgroup per sample (partial slabs per SAMPLE: convblock_slabs())
-        ensure_dynamic_lds((const void*)k_convblock_bwd<0>, cb_bwd_lds(0), ok0, "k_convblock_bwd<0>");
-        VSL_LAUNCH(k_convblock_bwd<0>, dim3(a.R / a.L), dim3(CB_T), cb_bwd_lds(0), s, a);
+        ensure_dynamic_lds((const void*)k_convblock_bwd<0, false>, cb_bwd_lds(0), ok0, "k_convblock_bwd<0>");
+        VSL_LAUNCH((k_convblock_bwd<0, false>), dim3(a.R / a.L), dim3(CB_T), cb_bwd_lds(0), s, a);
         return;
     }
-    ensure_dynamic_lds((const void*)k_convblock_bwd<3>, cb_bwd_lds(3), ok3, "k_convblock_bwd<3>");
-    VSL_LAUNCH(k_convblock_bwd<3>, dim3((a.R + TILE_M - 1) / TILE_M), dim3(CB_T), cb_bwd_lds(3), s, a);
+    if (a.R % TILE_M == 0 && a.L % TILE_M == 0) {
+        ensure_dynamic_lds((const void*)k_convblock_bwd<3, true>, cb_bwd_lds(3), ok3f, "k_convblock_bwd<3, full>");
+        VSL_LAUNCH((k_convblock_bwd<3, true>), dim3(a.R / TILE_M), dim3(CB_T), cb_bwd_lds(3), s, a);
+    } else {
+        ensure_dynamic_lds((const void*)k_convblock_bwd<3, false>, cb_bwd_lds(3), ok3, "k_convblock_bwd<3>");
+        VSL_LAUNCH((k_convblock_bwd<3, false>), dim3((a.R + TILE_M - 1) / TILE_M), dim3(CB_T), cb_bwd_lds(3), s, a);
+    }
     static int left = 6;
     if (edbg_on() && a.R > 4096) edbg_report("convblock_bwd: load | L3 | L2 | L1 | L0", 6, s, left);
 }
