@@ -1002,26 +1002,38 @@ __global__ __launch_bounds__(1024) void k_attn_bwd_fused(const float* __restrict
         if (qb == 0) STAMP(3);
         __syncthreads();                        // dS of this pass complete
         if (qb == 0) STAMP(4);
-        // phase 2: dQ^T[dd][q] += K[key][dd] * dS[q][key], one query tile per wave, every key
-        const int qt2 = qb + 16 * w;
-        if (w < 4 && qt2 < qe) {
+        // phase 2: dQ^T[dd][q] += K[key][dd] * dS[q][key].  All 16 waves: wave = (query tile w & 3, key-tile residue w >> 2 mod 4); the four
+        // partial tiles of a query tile meet in the (then dead) dS buffer and are added in residue order.  (One query tile per wave over
+        // every key kept 12 of the 16 waves idle for a third of the pass.)
+        const int qt2 = qb + 16 * (w & 3), kr = w >> 2;
+        f32x4 dqs = {0.f, 0.f, 0.f, 0.f};
+        if (qt2 < qe) {
             f32x4 dq[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) dq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             const float* kp = Ks + g * AB_KST + ki;
-            const float* sp = dSs + (16 * w + ki) * AB_DSP + g;
-            for (int k0 = 0; k0 < Lp; k0 += 16) {
+            const float* sp = dSs + (16 * (w & 3) + ki) * AB_DSP + g;
+            for (int k0 = 16 * kr; k0 < Lp; k0 += 64) {
                 float ka[4], sb[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { ka[i] = kp[(k0 + 4 * i) * AB_KST]; sb[i] = sp[k0 + 4 * i]; }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) dq[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[i], sb[i], dq[i], 0, 0, 0);
             }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dqs[c] = (dq[0][c] + dq[1][c]) + (dq[2][c] + dq[3][c]);
+        }
+        __syncthreads();                        // every wave has read its dS rows: the buffer becomes the exchange area
+        float4* xq = reinterpret_cast<float4*>(dSs);          // [3 residues][4 query tiles][64 lanes]
+        if (kr > 0) xq[((kr - 1) * 4 + (w & 3)) * 64 + lane] = make_float4(dqs[0], dqs[1], dqs[2], dqs[3]);
+        __syncthreads();
+        if (kr == 0 && qt2 < qe) {
+            const float4 p1 = xq[(0 * 4 + w) * 64 + lane], p2 = xq[(1 * 4 + w) * 64 + lane], p3 = xq[(2 * 4 + w) * 64 + lane];
             const int q = qt2 + ki;
             if (q < L)
                 *reinterpret_cast<float4*>(dQ + (rowbase + q) * D + h * HD + 4 * g) =
-                    make_float4(dq[0][0] + dq[1][0] + dq[2][0] + dq[3][0], dq[0][1] + dq[1][1] + dq[2][1] + dq[3][1],
-                                dq[0][2] + dq[1][2] + dq[2][2] + dq[3][2], dq[0][3] + dq[1][3] + dq[2][3] + dq[3][3]);
+                    make_float4(((dqs[0] + p1.x) + p2.x) + p3.x, ((dqs[1] + p1.y) + p2.y) + p3.y,
+                                ((dqs[2] + p1.z) + p2.z) + p3.z, ((dqs[3] + p1.w) + p2.w) + p3.w);
         }
         if (qb == 0) STAMP(5);
         __syncthreads();                        // dS buffer (and, after the last pass, Qs / Vs / As) free
