@@ -86,6 +86,7 @@ def test_rnn_head_matches_reference_golden():
 
 
 @pytest.mark.parametrize('shape', [dict(B=21, T=37, Lq=6, Lc=5), dict(B=3, T=128, Lq=20, Lc=10),
+                                   dict(B=259, T=9, Lq=3, Lc=4),                  # B > 256: the 4-sample MFMA-group LSTM kernels (ragged last group)
                                    dict(B=16, T=128, Lq=20, Lc=10, Dv=1024)])     # the last one = BASELINE configs[0] as written
 def test_rnn_head_against_oracle(shape):
     cfg = O.make_cfg(video_feature_dim=shape.get('Dv', 64), max_pos_len=128, word_size=60, predictor='rnn')
