@@ -11,6 +11,9 @@ LIB = os.path.join(LIBDIR, 'libvslnet_hip.so')
 SOURCES = ['kernels_fwd.hip', 'kernels_bwd.hip', 'kernels_enc.hip', 'kernels_wgrad.hip', 'kernels_lstm.hip', 'api.hip']
 HEADERS = ['common.hpp', 'launch.hpp', os.path.join('..', '..', 'include', 'vslnet_hip.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value', '-Wno-pass-failed']
+# per-file flags.  kernels_wgrad.hip: the split-bf16 loop is hand-scheduled scalar fp32 code; SLP vectorisation turns its subtractions into
+# v_pk_add_f32 + v_mov packing, which is slower beside MFMAs (MI355X_MICROARCH.md, price of fillers)
+FILE_FLAGS = {'kernels_wgrad.hip': ['-fno-slp-vectorize']}
 
 
 def _hipcc():
@@ -44,7 +47,7 @@ def build(force=False, verbose=False, csrc=None, out=None, stamps=False):
 
     def cc(src):
         obj = os.path.join(LIBDIR, src.replace('.hip', tag + '.o'))
-        cmd = [hipcc] + FLAGS + (['-DVSL_STAMPS'] if stamps else []) + os.environ.get('VSL_EXTRA_HIPCC_FLAGS', '').split() + ['-c', os.path.join(src_dir, src), '-o', obj]
+        cmd = [hipcc] + FLAGS + FILE_FLAGS.get(src, []) + (['-DVSL_STAMPS'] if stamps else []) + os.environ.get('VSL_EXTRA_HIPCC_FLAGS', '').split() + ['-c', os.path.join(src_dir, src), '-o', obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('hipcc failed for %s:\n%s' % (src, r.stderr[-4000:]))

@@ -116,6 +116,211 @@ __global__ __launch_bounds__(WG2_T, 2) void k_wgrad2(WgradBatch wb) {
         if (h == 0) *reinterpret_cast<float2*>(j.out_bias[gb] + (size_t)ch * D + 64 * nh + 2 * i) = bs;
     }
 }
+// =====================================================================================================================
+// k_wgrad3: the same product on the BF16 matrix cores at fp32 grade (round 3).
+//
+// v_mfma_f32_32x32x16_bf16 runs at 16x the rate of the fp32-input MFMA and, unlike it, overlaps with vector-ALU work
+// (tools/ubench/split_bf16.hip: an MFMA wave beside a VALU wave 64 | 85 -> 64 | 95 cycles; the fp32 MFMA was additive).  Every fp32
+// operand x is split EXACTLY into three bfloat16 terms x = h + m + l (round-to-nearest at each level: |m| <= 2^-8 |x|, |l| <= 2^-16 |x|,
+// l is exact because at most 8 significant bits remain) and the six products of weight >= 2^-16 -- hh, hm, mh, hl, lh, mm -- are
+// accumulated in fp32 by the MFMA; the dropped ml, lm, ll are <= 2^-23 |g||a|: the class of ONE fp32 rounding of the product, which the
+// fp32 chain commits as well.  Measured against an fp64 reference (same ubench, R = 8192): error / max sum|g||a| = 1.6e-8 against 2.2e-8
+// for the fp32 MFMA chain -- the split path is no less accurate than the kernel it replaces.
+//
+// A step = 16 rows = one K slice of the MFMA: lane (i, h) holds rows 8 h .. 8 h + 7 of its 2 G columns and 2 A columns (the float2 loads
+// of k_wgrad2, so the output mapping is unchanged); two rows of a column pack into one operand dword.  Per step and wave: 16 pairs x 11
+// vector instructions (v_cvt_pk_bf16_f32, shift / and, 2 subtractions per level) against 24 MFMAs (768 matrix cycles): the split of step
+// s + 1 is woven between the MFMAs of step s by hand (sched_barrier per MFMA), the raw rows of step s + 3 are requested as soon as a row
+// pair has been split.  No LDS, no barrier.  Built with -fno-slp-vectorize: packed fp32 adds (v_pk_add_f32 + v_mov packing) are slower.
+// =====================================================================================================================
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+template <int I0, int I1, class F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I0 < I1) { f(std::integral_constant<int, I0>()); static_for<I0 + 1, I1>(f); }
+}
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {       // {bf16(a) low half, bf16(b) high half}, RNE: v_cvt_pk_bf16_f32
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ void split3(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
+    h = cvt_pk_bf16(x0, x1);
+    const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xFFFF0000u);
+    m = cvt_pk_bf16(r0, r1);
+    const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xFFFF0000u);
+    l = cvt_pk_bf16(s0, s1);
+}
+__device__ __forceinline__ f32x16 mfma_bf16(u32x4_t a, u32x4_t b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
+constexpr int WG3_STEP = 16;                       // rows per step
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+// Raw buffer descriptor over [p, p + bytes): loads past the end return 0 -- rows past R need neither a clamp nor a mask.  The range check
+// covers the VGPR + immediate offset only (not the SGPR offset), so a step's descriptor is rebuilt from its own base (scalar ALU).
+struct BufRange { uint32_t lo, hi, bytes; };           // wave-uniform
+__device__ __forceinline__ BufRange make_range(const void* p, uint32_t bytes) {
+    const uint64_t u = reinterpret_cast<uint64_t>(p);      // uniform by construction; readfirstlane makes that provable (no waterfall loop)
+    return BufRange{(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)u), (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(u >> 32)),
+                    (uint32_t)__builtin_amdgcn_readfirstlane(bytes)};
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_at(const BufRange& b, uint32_t off) {      // descriptor of [p + off, p + bytes), off < 2^31
+    const uint32_t o = __builtin_amdgcn_readfirstlane(off);
+    const uint32_t lo = b.lo + o, hi = b.hi + (lo < o ? 1u : 0u);
+    const int n = max((int)b.bytes - (int)o, 0);
+    const uint64_t base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(hi) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane(lo);
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(base), 0, __builtin_amdgcn_readfirstlane(n), 0x00020000);
+}
+template <bool DROP, bool ABF16>
+__global__ __launch_bounds__(WG2_T, 1) void k_wgrad3(WgradBatch wb) {
+    int ji = 0;
+    while (ji + 1 < wb.n && (int)blockIdx.x >= wb.start[ji + 1]) ++ji;
+    const WgradJob& j = wb.j[ji];
+    const int K = j.K, R = j.R;
+    const int nkt = (K + 127) >> 7, nch = (R + WG_ROWS - 1) / WG_ROWS;
+    const int local = blockIdx.x - wb.start[ji];
+    const int kt = local % nkt, ch = (local / nkt) % nch, gb = local / (nkt * nch);
+    const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, i = lane & 31, h = lane >> 5;
+    const int nh = wv & 1, kh = wv >> 1;                    // this wave's 64 x 64 quadrant of the 128 x 128 block
+    const int ldg = j.ldg ? j.ldg : D;
+    const bool blocks = j.nA > 0;
+    const int lda = blocks ? D : K;
+    const int kloc = 64 * kh + 2 * i;                       // column inside the 128-wide k tile
+    const int kglob = kt * 128 + kloc;                      // column of dW
+    const bool kin = kglob < K;                             // K is even: both columns of the pair are in or out together
+    const int rbeg = ch * WG_ROWS, rend = min(R, rbeg + WG_ROWS), nrows = rend - rbeg;
+    const uint32_t dseed = j.dp.seed, dthr = j.dp.thresh, dkey = j.dp.key;
+    const float dscale = j.dp.scale;
+    constexpr int ASZ = ABF16 ? 2 : 4;                      // bytes per A element
+    // Buffer descriptors over the chunk's rows [rbeg, rend) of the two operands: address = descriptor base + per-lane offset of the lane's row q
+    // (8 + 8 loop-invariant registers) + the step's offset in an SGPR -- no address arithmetic in the loop; rows >= R read as zeros.
+    // (the ranges end with the CHUNK: the run-ahead loads of the steps past it read zeros too, so the bias sums need no guard)
+    const BufRange grg = make_range(j.G[gb] + (size_t)rbeg * ldg, (uint32_t)nrows * (uint32_t)ldg * 4u);
+    const BufRange arg = make_range(reinterpret_cast<const char*>(blocks ? j.A[kt] : j.Afull) + (size_t)rbeg * lda * ASZ,
+                                    (uint32_t)nrows * (uint32_t)lda * (uint32_t)ASZ);
+    uint32_t goff[8], aoff[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        goff[q] = (uint32_t)((8 * h + q) * ldg + 64 * nh + 2 * i) * 4u;
+        aoff[q] = (uint32_t)((8 * h + q) * lda + (blocks ? kloc : (kin ? kglob : 0))) * (uint32_t)ASZ;
+    }
+    const uint32_t gstep = (uint32_t)(WG3_STEP * ldg) * 4u, astep = (uint32_t)(WG3_STEP * lda * ASZ);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float bs[2] = {0.f, 0.f};
+    struct Raw { float2 g[8]; float2 a[8]; };             // this lane's 8 rows of a step (ABF16: a[q].x carries the raw bf16 pair)
+    struct Ops { u32x4_t g[3][2], a[3][2]; };             // [term h / m / l][column], 4 dwords = 8 bf16 = the lane's 8 rows
+    constexpr int NM = 4 * (ABF16 ? 3 : 6), NPAIR = 16;   // bf16 features are their own (exact) h term: 3 products
+    const int ns = ((nrows + 2 * WG3_STEP - 1) / (2 * WG3_STEP)) * 2;       // steps, even (a step past the rows multiplies zeros)
+
+    auto run = [&](auto bias_c) {
+        constexpr bool BIAS = decltype(bias_c)::value;
+        auto ld_rows = [&](int s, int p, Raw& x) {        // row pair p (rows 2p, 2p+1 of the lane) of step s, both operands
+            const __amdgpu_buffer_rsrc_t grs = rsrc_at(grg, (uint32_t)s * gstep), ars = rsrc_at(arg, (uint32_t)s * astep);
+#pragma unroll
+            for (int q = 2 * p; q < 2 * p + 2; ++q) {
+                const u32x2_t gv = __builtin_amdgcn_raw_buffer_load_b64(grs, goff[q], 0, 0);
+                x.g[q] = make_float2(__uint_as_float(gv[0]), __uint_as_float(gv[1]));
+                if (ABF16) x.a[q].x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ars, aoff[q], 0, 0));
+                else {
+                    const u32x2_t av = __builtin_amdgcn_raw_buffer_load_b64(ars, aoff[q], 0, 0);
+                    x.a[q] = make_float2(__uint_as_float(av[0]), __uint_as_float(av[1]));
+                }
+            }
+        };
+        // pair pi of step s: pi = 4 * rowpair + column (columns 0, 1 = G ; 2, 3 = A)
+        auto split_pair = [&](int s, int pi, const Raw& x, Ops& o) {
+            const int jp = pi >> 2, c = pi & 3;
+            uint32_t hh, mm, ll;
+            if (c < 2) {
+                const float g0 = c ? x.g[2 * jp].y : x.g[2 * jp].x, g1 = c ? x.g[2 * jp + 1].y : x.g[2 * jp + 1].x;
+                if (BIAS) bs[c] += g0 + g1;
+                split3(g0, g1, hh, mm, ll);
+                o.g[0][c][jp] = hh; o.g[1][c][jp] = mm; o.g[2][c][jp] = ll;
+            } else if (ABF16) {
+                const int ca = c - 2;
+                const uint32_t u0 = __float_as_uint(x.a[2 * jp].x), u1 = __float_as_uint(x.a[2 * jp + 1].x);
+                uint32_t v = ca ? __builtin_amdgcn_perm(u1, u0, 0x07060302u) : __builtin_amdgcn_perm(u1, u0, 0x05040100u);   // column ca of rows 2jp, 2jp+1
+                if (DROP) {       // exact zeroing of the bf16 inputs; the 1/(1-p) scale is applied to the fp32 sums at the end
+                    const uint32_t base = (uint32_t)(rbeg + WG3_STEP * s + 8 * h + 2 * jp) * (uint32_t)K + (uint32_t)(kglob + ca);
+                    if (drop_hash(base, dseed, dkey) < dthr) v &= 0xFFFF0000u;
+                    if (drop_hash(base + (uint32_t)K, dseed, dkey) < dthr) v &= 0x0000FFFFu;
+                }
+                o.a[0][ca][jp] = v;
+            } else {
+                const int ca = c - 2;
+                float a0 = ca ? x.a[2 * jp].y : x.a[2 * jp].x, a1 = ca ? x.a[2 * jp + 1].y : x.a[2 * jp + 1].x;
+                if (DROP) {
+                    const uint32_t base = (uint32_t)(rbeg + WG3_STEP * s + 8 * h + 2 * jp) * (uint32_t)K + (uint32_t)(kglob + ca);
+                    a0 *= drop_hash(base, dseed, dkey) >= dthr ? dscale : 0.f;
+                    a1 *= drop_hash(base + (uint32_t)K, dseed, dkey) >= dthr ? dscale : 0.f;
+                }
+                split3(a0, a1, hh, mm, ll);
+                o.a[0][ca][jp] = hh; o.a[1][ca][jp] = mm; o.a[2][ca][jp] = ll;
+            }
+        };
+        // MFMA m of a step: product type outer (small terms first), block inner -> consecutive MFMAs hit different accumulators
+        auto mma1 = [&](int m, const Ops& o) {
+            constexpr int TG6[6] = {1, 0, 2, 0, 1, 0}, TA6[6] = {1, 2, 0, 1, 0, 0};      // (g term, a term): mm, hl, lh, hm, mh, hh
+            constexpr int TG3[3] = {2, 1, 0};                                             // bf16 A: l a, m a, h a
+            const int t = m >> 2, a = (m >> 1) & 1, b = m & 1;
+            if (ABF16) acc[a][b] = mfma_bf16(o.g[TG3[t]][a], o.a[0][b], acc[a][b]);
+            else acc[a][b] = mfma_bf16(o.g[TG6[t]][a], o.a[TA6[t]][b], acc[a][b]);
+        };
+        Raw x0, x1;
+        Ops o0, o1;
+        auto step = [&](int s, const Ops& cur, Ops& nxt, Raw& xs) {   // MFMAs of step s ; split of step s + 1 (raw rows in xs) ; loads of step s + 3
+            static_for<0, NM>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                mma1(m, cur);
+                constexpr int p0 = (m * NPAIR + NM - 1) / NM, p1 = ((m + 1) * NPAIR + NM - 1) / NM;       // pairs pi with pi * NM / NPAIR == m
+                static_for<p0, p1>([&](auto pc) {
+                    constexpr int pi = decltype(pc)::value;
+                    split_pair(s + 1, pi, xs, nxt);
+                    if constexpr ((pi & 3) == 3) ld_rows(s + 3, pi >> 2, xs);      // the row pair is dead: reload it
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+        static_for<0, 4>([&](auto pc) { ld_rows(0, decltype(pc)::value, x0); });
+        static_for<0, 4>([&](auto pc) { ld_rows(1, decltype(pc)::value, x1); });
+        static_for<0, NPAIR>([&](auto pc) { split_pair(0, decltype(pc)::value, x0, o0); });
+        static_for<0, 4>([&](auto pc) { ld_rows(2, decltype(pc)::value, x0); });
+        __builtin_amdgcn_sched_barrier(0);
+        for (int s = 0; s < ns; s += 2) {
+            step(s, o0, o1, x1);
+            step(s + 1, o1, o0, x0);
+        }
+    };
+    const bool want_bias = kt == 0 && kh == 0 && j.out_bias[gb] != nullptr;      // wave-uniform
+    if (want_bias) run(std::true_type()); else run(std::false_type());
+    // ---- partial slab: lane, register r of acc[a][b] = dW[n = 64 nh + 2 * acc_row(r) + a][k = kglob_of(lane & 31) + b]
+    const int N = 128 * j.nG;
+    float* out = j.out + ((size_t)ch * N + gb * 128 + 64 * nh) * K + kglob;
+    const float osc = (ABF16 && DROP) ? dscale : 1.f;
+    if (kin) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = 2 * acc_row(r, lane) + a;
+                *reinterpret_cast<float2*>(out + (size_t)n * K) = make_float2(acc[a][0][r] * osc, acc[a][1][r] * osc);
+            }
+    }
+    if (want_bias) {
+        float2 b2 = make_float2(bs[0], bs[1]);
+        b2.x = lane_pair32(b2.x, [](float a, float b) { return a + b; }); b2.y = lane_pair32(b2.y, [](float a, float b) { return a + b; });
+        if (h == 0) *reinterpret_cast<float2*>(j.out_bias[gb] + (size_t)ch * D + 64 * nh + 2 * i) = b2;
+    }
+}
+
 void launch_wgrad2(const WgradBatch& wb0, hipStream_t s) {
     WgradBatch wb = wb0;
     int total = 0;
@@ -147,6 +352,22 @@ void launch_wgrad2(const WgradBatch& wb0, hipStream_t s) {
     const void* fn[4] = {(const void*)k_wgrad2<false, false>, (const void*)k_wgrad2<true, false>, (const void*)k_wgrad2<false, true>,
                          (const void*)k_wgrad2<true, true>};
     ensure_dynamic_lds(fn[k0], pad, ok[k0], "k_wgrad2");
+    // fp32-grade product on the bf16 matrix cores (k_wgrad3) unless VSL_WGRAD_F32=1 selects the fp32-input MFMA kernel of round 2 (A/B runs)
+    static const bool f32_path = getenv("VSL_WGRAD_F32") && getenv("VSL_WGRAD_F32")[0] == '1';
+    if (!f32_path) {
+        static const size_t pad3 = getenv("VSL_WGRAD_LDS") ? (size_t)atol(getenv("VSL_WGRAD_LDS")) : (size_t)0;
+        static size_t ok3[4] = {0, 0, 0, 0};
+        const void* fn3[4] = {(const void*)k_wgrad3<false, false>, (const void*)k_wgrad3<true, false>, (const void*)k_wgrad3<false, true>,
+                              (const void*)k_wgrad3<true, true>};
+        ensure_dynamic_lds(fn3[k0], pad3, ok3[k0], "k_wgrad3");
+        switch (k0) {
+            case 0: VSL_LAUNCH((k_wgrad3<false, false>), dim3(total), dim3(WG2_T), pad3, s, wb); break;
+            case 1: VSL_LAUNCH((k_wgrad3<true, false>), dim3(total), dim3(WG2_T), pad3, s, wb); break;
+            case 2: VSL_LAUNCH((k_wgrad3<false, true>), dim3(total), dim3(WG2_T), pad3, s, wb); break;
+            default: VSL_LAUNCH((k_wgrad3<true, true>), dim3(total), dim3(WG2_T), pad3, s, wb); break;
+        }
+        return;
+    }
     switch (k0) {
         case 0: VSL_LAUNCH((k_wgrad2<false, false>), dim3(total), dim3(WG2_T), pad, s, wb); break;
         case 1: VSL_LAUNCH((k_wgrad2<true, false>), dim3(total), dim3(WG2_T), pad, s, wb); break;
