@@ -8,12 +8,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libvslnet_hip.so')
-SOURCES = ['kernels_fwd.hip', 'kernels_bwd.hip', 'kernels_enc.hip', 'kernels_wgrad.hip', 'kernels_lstm.hip', 'api.hip']
+SOURCES = ['kernels_fwd.hip', 'kernels_bwd.hip', 'kernels_enc.hip', 'kernels_wgrad.hip', 'kernels_split.hip', 'kernels_lstm.hip', 'api.hip']
 HEADERS = ['common.hpp', 'launch.hpp', os.path.join('..', '..', 'include', 'vslnet_hip.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value', '-Wno-pass-failed']
 # per-file flags.  kernels_wgrad.hip: the split-bf16 loop is hand-scheduled scalar fp32 code; SLP vectorisation turns its subtractions into
 # v_pk_add_f32 + v_mov packing, which is slower beside MFMAs (MI355X_MICROARCH.md, price of fillers)
-FILE_FLAGS = {'kernels_wgrad.hip': ['-fno-slp-vectorize']}
+FILE_FLAGS = {'kernels_wgrad.hip': ['-fno-slp-vectorize'], 'kernels_split.hip': ['-fno-slp-vectorize']}
 
 
 def _hipcc():
@@ -55,8 +55,9 @@ def build(force=False, verbose=False, csrc=None, out=None, stamps=False):
             sys.stderr.write(r.stderr)
         return obj
 
-    with ThreadPoolExecutor(len(SOURCES)) as ex:
-        objs = list(ex.map(cc, SOURCES))
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(src_dir, s))]      # (a baseline revision may predate a translation unit)
+    with ThreadPoolExecutor(len(srcs)) as ex:
+        objs = list(ex.map(cc, srcs))
     r = subprocess.run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', lib], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError('link failed:\n' + r.stderr[-4000:])

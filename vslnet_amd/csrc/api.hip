@@ -47,7 +47,7 @@ struct ModelP {
     int sln_g, sln_b, eln_g, eln_b, s0w, s0b, s1w, s1b, e0w, e0b, e1w, e1b;
     int l_wih[2], l_whh[2], l_bih[2], l_bhh[2];     // rnn predictor: start / end DynamicRNN (layers_t7.py:302-313)
 };
-struct ModelPk { int va_f, va_f16, emb_f, emb_t; EncPk fe, pe; int cqa_f, cqa_t, cat1_f, cat1_t, s0_f, s0_t, e0_f, e0_t, ccw_img;
+struct ModelPk { int va_f, va_f16, va_f3, l_t3[2], emb_f, emb_t; EncPk fe, pe; int cqa_f, cqa_t, cat1_f, cat1_t, s0_f, s0_t, e0_f, e0_t, ccw_img;
                  int l_f[2], l_t[2], zero128; };
 
 struct EncWs { int64_t x0, y[4], u[4], mask[4], h1, q, k, v, lse, att, r, h2, out; int R, L; };
@@ -235,6 +235,20 @@ struct PackBuilder {
         h->jobs.push_back(PackJob{src, dst, Kd, N, ld, 0, N, 0, 0});
         return dst;
     }
+    // split packs (three bf16 planes, common.hpp pack3_index) of the same two operands
+    // (kpad: the contraction extent is zero-padded to a multiple of it -- a K-chunked kernel then needs no tail guards)
+    int fwd3(int src, int N, int Kd, int ld, int kpad = 16) {
+        const int dst = (int)h->pack_floats, Kp = (Kd + kpad - 1) / kpad * kpad;
+        h->pack_floats += (int64_t)((pack3_floats(Kp, N) + 3) & ~size_t(3));
+        h->jobs.push_back(PackJob{src, dst, Kd, N, ld, 6, N, 0, 0, Kp, Kp});
+        return dst;
+    }
+    int tr3(int src, int N, int Kd, int ld, int kpad = 16) {
+        const int dst = (int)h->pack_floats, Np = (N + kpad - 1) / kpad * kpad;
+        h->pack_floats += (int64_t)((pack3_floats(Np, Kd) + 3) & ~size_t(3));
+        h->jobs.push_back(PackJob{src, dst, N, Kd, ld, 7, Kd, 0, 0, Np, Np});
+        return dst;
+    }
     // transpose pack of W (N x K): Bm[k = n][c] = W[n][c], ncols = K
     int tr(int src, int N, int Kd, int ld) {
         const int dst = (int)h->pack_floats;
@@ -266,6 +280,7 @@ void build_packs(vsl_handle_s* h) {
     K.va_f16 = (int)h->pack_floats;
     h->pack_floats += (int64_t)((c.video_feature_dim + 15) / 16) * D * 16 / 2;
     h->jobs.push_back(PackJob{P.va_w, K.va_f16, c.video_feature_dim, D, c.video_feature_dim, 5, D, 0, 0});
+    K.va_f3 = pk.fwd3(P.va_w, D, c.video_feature_dim, c.video_feature_dim, 128);      // split pack: fp32 grade on the bf16 matrix cores
     K.emb_f = pk.fwd(P.emb_w, D, c.word_dim + 100, c.word_dim + 100);
     K.emb_t = pk.tr(P.emb_w, D, c.word_dim + 100, c.word_dim + 100);
     build_encoder_packs(pk, h, P.fe, K.fe);
@@ -273,6 +288,7 @@ void build_packs(vsl_handle_s* h) {
         for (int l = 0; l < 2; ++l) {
             K.l_f[l] = pk.fwd(P.l_wih[l], 4 * D, D, D);      // gi = x W_ih^T  : (R,128) x (128,512)
             K.l_t[l] = pk.tr(P.l_wih[l], 4 * D, D, D);       // dx = dG W_ih   : (R,512) x (512,128)
+            K.l_t3[l] = pk.tr3(P.l_wih[l], 4 * D, D, D, 128);
         }
         K.zero128 = (int)h->pack_floats;                    // a zero bias vector for the bias-less GEMM above
         h->pack_floats += D;
@@ -544,6 +560,10 @@ void run_forward(Ctx& c) {
         LAUNCH("vproj_fwd", launch_vproj_fwd_bf16(io.video_features_bf16, reinterpret_cast<const uint16_t*>(c.PK(K.va_f16)), c.P(P.va_b), c.W(p.vf), R,
                                                   cf.video_feature_dim, c.drop(SITE_VIS), c.s));
     else
+        if (split_gemm_enabled())
+        LAUNCH("vproj_fwd", launch_vproj_fwd3(io.video_features, reinterpret_cast<const uint16_t*>(c.PK(K.va_f3)), c.P(P.va_b), c.W(p.vf), R, cf.video_feature_dim,
+                                              c.drop(SITE_VIS), c.s));
+    else
         LAUNCH("vproj_fwd", launch_vproj_fwd(io.video_features, c.PK(K.va_f), c.P(P.va_b), c.W(p.vf), R, cf.video_feature_dim, c.drop(SITE_VIS), c.s));
     enc_fwd(c, P.fe, K.fe, p.ve, c.W(p.vf), io.v_mask, B, 0);
     c.s = qlong ? c.main : sq;
@@ -789,6 +809,10 @@ void run_backward(Ctx& c) {
         auto dx = [&](int l, int t0, int t1) {
             const LstmWs& w = p.lstm[l];
             const bool all = t0 == 0 && t1 == T;
+            if (split_gemm_enabled())
+                LAUNCH("lstm_dx", launch_vproj_fwd3(c.W(w.dG), reinterpret_cast<const uint16_t*>(c.PK(K.l_t3[l])), c.PK(K.zero128), c.W(l ? p.g_s1 : p.g_gated),
+                                                   all ? R : B * (t1 - t0), 4 * D, Drop{0u, 0u, 1.f}, c.s, all ? 0 : t1 - t0, T, t0));
+            else
             LAUNCH("lstm_dx", launch_vproj_fwd(c.W(w.dG), c.PK(K.l_t[l]), c.PK(K.zero128), c.W(l ? p.g_s1 : p.g_gated), all ? R : B * (t1 - t0),
                                               4 * D, Drop{0u, 0u, 1.f}, c.s, all ? 0 : t1 - t0, T, t0));
         };

@@ -293,6 +293,56 @@ __device__ __forceinline__ void gemm32p(const float* __restrict__ As, int lda, i
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// fp32-grade products on the BF16 matrix cores (round 3; tools/ubench/split_bf16.hip priced it).
+// v_mfma_f32_32x32x16_bf16 runs at 16x the rate of the fp32-input MFMA and overlaps with vector-ALU work.  Every fp32 operand x is split
+// EXACTLY into three bfloat16 terms x = h + m + l (round-to-nearest at each level: |m| <= 2^-8 |x|, |l| <= 2^-16 |x|; l is exact because
+// at most 8 significant bits remain) and the six products of weight >= 2^-16 -- hh, hm, mh, hl, lh, mm -- are accumulated in fp32 by the
+// MFMA; the dropped ml, lm, ll are <= 2^-23 |a||b|, the class of ONE fp32 rounding of the product.  Measured against fp64 (R = 8192 rows):
+// error / max sum|a||b| = 1.6e-8 against 2.2e-8 for the fp32 MFMA chain.
+// Kernels that use these helpers live in translation units built with -fno-slp-vectorize (vslnet_amd/build.py): the SLP vectoriser turns
+// the subtractions into v_pk_add_f32 + v_mov packing, which is slower beside MFMAs.
+// ---------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+template <int I0, int I1, class F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I0 < I1) { f(std::integral_constant<int, I0>()); static_for<I0 + 1, I1>(f); }
+}
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {       // {bf16(a) low half, bf16(b) high half}, RNE: v_cvt_pk_bf16_f32
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+// (x0, x1) -> packed pairs of the three terms: 11 vector instructions
+__device__ __forceinline__ void split3(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
+    h = cvt_pk_bf16(x0, x1);
+    const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xFFFF0000u);
+    m = cvt_pk_bf16(r0, r1);
+    const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xFFFF0000u);
+    l = cvt_pk_bf16(s0, s1);
+}
+__device__ __forceinline__ f32x16 mfma_bf16(u32x4_t a, u32x4_t b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma16_bf16(u32x4_t a, u32x4_t b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+// host-side / k_pack: the three terms of one value (bf16 bit patterns)
+__host__ __device__ __forceinline__ float bf16_to_f32(uint16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; }
+__host__ __device__ __forceinline__ void split3_scalar(float x, uint16_t& h, uint16_t& m, uint16_t& l) {
+    h = f32_to_bf16(x);
+    const float r = x - bf16_to_f32(h);
+    m = f32_to_bf16(r);
+    l = f32_to_bf16(r - bf16_to_f32(m));
+}
+// "split pack" of a weight used as the B operand of Y = A Bm: three bf16 planes (h, m, l), each [K16 / 16][ncols][16] -- lane (col, half)
+// of v_mfma_f32_32x32x16_bf16 (or lane (col, k group) of 16x16x32) reads its 8 consecutive k as one 16-byte load, a wave reads 1 KiB.
+__host__ __device__ __forceinline__ size_t pack3_plane(int K, int ncols) { return (size_t)((K + 15) / 16) * ncols * 16; }     // bf16 elements
+__host__ __device__ __forceinline__ size_t pack3_index(int k, int col, int ncols) { return ((size_t)(k >> 4) * ncols + col) * 16 + (k & 15); }
+__host__ __device__ __forceinline__ size_t pack3_floats(int K, int ncols) { return (3 * pack3_plane(K, ncols) + 1) / 2; }
+
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
 template <int NT>

@@ -50,6 +50,22 @@ __global__ __launch_bounds__(256) void k_pack(const float* __restrict__ params, 
         }
         return;
     }
+    if (j.transpose == 6 || j.transpose == 7) {     // split pack: three bf16 planes of the operand's terms, K zero-padded to 16
+        const int kn16 = j.kfill ? j.kfill : (j.kn + 15) & ~15;     // (a job that is not the last k segment of its operand has kn % 16 == 0)
+        uint16_t* p16 = reinterpret_cast<uint16_t*>(pack + j.dst);
+        const size_t plane = pack3_plane(j.ktot ? j.ktot : j.kn, j.ncols);
+        for (int e = blockIdx.x * 256 + threadIdx.x; e < kn16 * j.cn; e += gridDim.x * 256) {
+            int c, k;
+            float v = 0.f;
+            if (j.transpose == 6) { c = e / kn16; k = e - c * kn16; if (k < j.kn) v = params[j.src + (size_t)c * j.ld + k]; }       // Bm[k][c] = W[c][k]
+            else { k = e / j.cn; c = e - k * j.cn; if (k < j.kn) v = params[j.src + (size_t)k * j.ld + c]; }                        // Bm[k][c] = W[k][c]
+            uint16_t th, tm, tl;
+            split3_scalar(v, th, tm, tl);
+            const size_t o = pack3_index(j.k_off + k, j.col_off + c, j.ncols);
+            p16[o] = th; p16[plane + o] = tm; p16[2 * plane + o] = tl;
+        }
+        return;
+    }
     const int kn8 = j.transpose == 0 ? (j.kn + 7) & ~7 : j.kn;     // forward pack: zero the k rows that pad the last 8-block
     const int n = kn8 * j.cn;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {

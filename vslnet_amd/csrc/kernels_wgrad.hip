@@ -133,30 +133,7 @@ __global__ __launch_bounds__(WG2_T, 2) void k_wgrad2(WgradBatch wb) {
 // s + 1 is woven between the MFMAs of step s by hand (sched_barrier per MFMA), the raw rows of step s + 3 are requested as soon as a row
 // pair has been split.  No LDS, no barrier.  Built with -fno-slp-vectorize: packed fp32 adds (v_pk_add_f32 + v_mov packing) are slower.
 // =====================================================================================================================
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-template <int I0, int I1, class F> __device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I0 < I1) { f(std::integral_constant<int, I0>()); static_for<I0 + 1, I1>(f); }
-}
-__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {       // {bf16(a) low half, bf16(b) high half}, RNE: v_cvt_pk_bf16_f32
-    typedef float f32x2_t __attribute__((ext_vector_type(2)));
-    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-    const f32x2_t v = {a, b};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
-}
-__device__ __forceinline__ void split3(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
-    h = cvt_pk_bf16(x0, x1);
-    const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xFFFF0000u);
-    m = cvt_pk_bf16(r0, r1);
-    const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xFFFF0000u);
-    l = cvt_pk_bf16(s0, s1);
-}
-__device__ __forceinline__ f32x16 mfma_bf16(u32x4_t a, u32x4_t b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
-}
-
 constexpr int WG3_STEP = 16;                       // rows per step
-typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 // Raw buffer descriptor over [p, p + bytes): loads past the end return 0 -- rows past R need neither a clamp nor a mask.  The range check
 // covers the VGPR + immediate offset only (not the SGPR offset), so a step's descriptor is rebuilt from its own base (scalar ALU).
 struct BufRange { uint32_t lo, hi, bytes; };           // wave-uniform

@@ -15,8 +15,11 @@ struct PackJob {          // one weight -> packed B-operand copy (see common.hpp
     int kn, cn;           // extent of the contraction index / of the output-column index covered by this job
     int ld;               // leading dimension of the source matrix
     int transpose;        // 0: Bm[k][c] = W[c][k] (forward pack)   1: Bm[k][c] = W[k][c] (data-gradient pack)  2: copy  3: char-conv image  4: zero fill
+                          // 5: bf16 forward pack   6 / 7: SPLIT packs (three bf16 planes h, m, l; common.hpp pack3_index) of the forward / data-gradient operand
     int ncols;            // total columns of the packed operand
     int k_off, col_off;   // placement inside the packed operand
+    int ktot;             // split packs: contraction extent of the whole operand incl. padding (plane size); 0 = kn
+    int kfill;            // split packs: k rows this job writes (rows >= kn as zeros); 0 = kn rounded up to 16
 };
 
 struct CharConvPtrs { const float* w[4]; const float* b[4]; };
@@ -131,6 +134,10 @@ void launch_vproj_fwd(const float* X, const float* Wpack, const float* bias, flo
                       int seg = 0, int stride = 0, int off = 0);   // seg > 0: rows of one time chunk (see launch_linear_bwd_data)
 // bf16 throughput mode: X bf16 (R, Dv), packed bf16 weight (PackJob type 5), fp32 accumulate / bias / output
 void launch_vproj_fwd_bf16(const uint16_t* X, const uint16_t* Wpack16, const float* bias, float* Y, int R, int Dv, Drop dp, hipStream_t s);
+// fp32-grade on the bf16 matrix cores (kernels_split.hip): W3 = split pack (PackJob type 6 / 7) of the (Dv, 128) operand
+void launch_vproj_fwd3(const float* X, const uint16_t* W3, const float* bias, float* Y, int R, int Dv, Drop dp, hipStream_t s,
+                       int seg = 0, int stride = 0, int off = 0);
+bool split_gemm_enabled();       // false when VSL_F32_GEMM=1 selects the fp32-input MFMA kernels of round 2 (A/B runs)
 void launch_embed_fwd(const int64_t* word_ids, const int64_t* char_ids, const float* pad_vec, const float* unk_vec,
                       const float* glove, const float* char_tab, CharConvPtrs cc, const float* wimg, float* E, int8_t* argpos,
                       int Rq, int Lc, int word_dim, int char_dim, Drop dw, Drop dc, hipStream_t s);
