@@ -13,7 +13,7 @@ HEADERS = ['common.hpp', 'launch.hpp', os.path.join('..', '..', 'include', 'vsln
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value', '-Wno-pass-failed']
 # per-file flags.  kernels_wgrad.hip: the split-bf16 loop is hand-scheduled scalar fp32 code; SLP vectorisation turns its subtractions into
 # v_pk_add_f32 + v_mov packing, which is slower beside MFMAs (MI355X_MICROARCH.md, price of fillers)
-FILE_FLAGS = {'kernels_wgrad.hip': ['-fno-slp-vectorize'], 'kernels_split.hip': ['-fno-slp-vectorize']}
+FILE_FLAGS = {'kernels_wgrad.hip': ['-fno-slp-vectorize'], 'kernels_split.hip': ['-fno-slp-vectorize'], 'kernels_enc.hip': ['-fno-slp-vectorize']}
 
 
 def _hipcc():

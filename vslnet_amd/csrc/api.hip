@@ -38,7 +38,7 @@ namespace {
 struct ParamInfo { std::string name; int64_t off, numel; int ndim; int64_t dims[4]; };
 
 struct EncP { int pos, dw[4], pw[4], pwb[4], lng[4], lnb[4], qw, qb, kw, kb, vw, vb, ln1g, ln1b, ln2g, ln2b, ow, ob; };
-struct EncPk { int pw_f[4], pw_t[4], qkv_f, qkv_t, o_f, o_t; };
+struct EncPk { int pw_f[4], pw_t[4], qkv_f, qkv_t, o_f, o_t; int pw_f3[4], pw_t3[4], qkv_f3, qkv_t3, o_f3, o_t3; };   // ..3: split packs
 struct ModelP {
     int unk, char_tab, ccw[4], ccb[4], emb_w, emb_b, va_w, va_b;
     EncP fe;
@@ -269,6 +269,16 @@ void build_encoder_packs(PackBuilder& pk, vsl_handle_s* h, const EncP& e, EncPk&
     for (int i = 0; i < 3; ++i) h->jobs.push_back(PackJob{qkv[i], k.qkv_t, D, D, D, 1, D, i * D, 0});
     k.o_f = pk.fwd(e.ow, D, D, D);
     k.o_t = pk.tr(e.ow, D, D, D);
+    // split packs (fp32 grade on the bf16 matrix cores)
+    for (int i = 0; i < 4; ++i) { k.pw_f3[i] = pk.fwd3(e.pw[i], D, D, D); k.pw_t3[i] = pk.tr3(e.pw[i], D, D, D); }
+    k.qkv_f3 = (int)h->pack_floats;
+    h->pack_floats += (int64_t)((pack3_floats(D, 3 * D) + 3) & ~size_t(3));
+    for (int i = 0; i < 3; ++i) h->jobs.push_back(PackJob{qkv[i], k.qkv_f3, D, D, D, 6, 3 * D, 0, i * D, D, D});
+    k.qkv_t3 = (int)h->pack_floats;
+    h->pack_floats += (int64_t)((pack3_floats(3 * D, D) + 3) & ~size_t(3));
+    for (int i = 0; i < 3; ++i) h->jobs.push_back(PackJob{qkv[i], k.qkv_t3, D, D, D, 7, D, i * D, 0, 3 * D, D});
+    k.o_f3 = pk.fwd3(e.ow, D, D, D);
+    k.o_t3 = pk.tr3(e.ow, D, D, D);
 }
 void build_packs(vsl_handle_s* h) {
     const vsl_config& c = h->cfg;
@@ -493,6 +503,10 @@ void enc_fwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float*
             }
             a.qf = QkvFuse{c.P(P.ln1g), c.P(P.ln1b), c.PK(K.qkv_f), c.P(P.qb), c.P(P.kb), c.P(P.vb), c.W(w.h1), c.W(w.q), c.W(w.k), c.W(w.v),
                            c.drop(app * 16 + 4)};
+            if (split_gemm_enabled()) {
+                for (int i = 0; i < 4; ++i) a.W3[i] = reinterpret_cast<const uint16_t*>(c.PK(K.pw_f3[i]));
+                a.Wqkv3 = reinterpret_cast<const uint16_t*>(c.PK(K.qkv_f3));
+            }
             a.R = R; a.L = L;
         }
         LAUNCH("convblock_fwd", launch_convblock_fwd(a, c.s));

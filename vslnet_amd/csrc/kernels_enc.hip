@@ -103,6 +103,60 @@ __device__ __forceinline__ void gemm16(const float* __restrict__ As, int lda, co
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The same GEMM on the BF16 matrix cores at fp32 grade (common.hpp: 3-way split, 6 products), v_mfma_f32_16x16x32_bf16.
+//   A: three bf16 planes (terms h, m, l) of the activation tile in LDS, row stride CB_LDB elements; the kernel phase that produces the
+//      tile splits every value ONCE while storing it.  Lane (i = lane & 15, g = lane >> 4) reads row i, k = 32 ks + 8 g .. + 7 as one
+//      ds_read_b128 (288-byte rows: conflict-free for this lane map).
+//   B: the wave's 128 x 16 slice of the weight's split pack (PackJob type 6 / 7), 3 x 4 x 16 bytes per lane = 48 registers.
+//   C/D as for 16x16x4: reg r <-> row 4 g + r, column i.
+// Per 16-row block and K = 32 step: 3 A reads, 6 MFMAs (16 passes of the matrix pipe against 32 x 4 for the fp32-input MFMA), and the bf16
+// MFMAs overlap with the vector work of the SIMD's other wave.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int CB_LDB = 144;
+struct B3 { u32x4_t b[3][4]; };                 // [term][K = 32 step]
+__device__ __forceinline__ void b3_load(B3& f, const uint16_t* __restrict__ W3, int K, int ncols, int col0) {
+    const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+    const size_t plane = pack3_plane(K, ncols);
+    const uint16_t* p = W3 + ((size_t)(g >> 1) * ncols + col0 + j) * 16 + 8 * (g & 1);
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) f.b[t][ks] = *reinterpret_cast<const u32x4_t*>(p + t * plane + (size_t)(2 * ks) * ncols * 16);
+}
+// acc[rb] (16 x 16) += A[16 rb + 0..15][0..127] * B ; Ah = plane h at the block range's first row, `ps` = elements between planes
+template <int NRB>
+__device__ __forceinline__ void gemm16s(const uint16_t* __restrict__ Ah, int ps, const B3& bf, f32x4 (&acc)[1][NRB]) {
+    const int lane = threadIdx.x & 63;
+    const uint16_t* ar = Ah + (lane & 15) * CB_LDB + 8 * (lane >> 4);
+    constexpr int TA[6] = {1, 0, 2, 0, 1, 0}, TB[6] = {1, 2, 0, 1, 0, 0};       // (a term, b term): mm, hl, lh, hm, mh, hh -- small terms first
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        u32x4_t a[NRB][3];
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) a[rb][t] = *reinterpret_cast<const u32x4_t*>(ar + t * ps + rb * 16 * CB_LDB + ks * 32);
+#pragma unroll
+        for (int p = 0; p < 6; ++p)
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) acc[0][rb] = mfma16_bf16(a[rb][TA[p]], bf.b[TB[p]][ks], acc[0][rb]);      // consecutive MFMAs: different accumulators
+    }
+}
+// Stores two adjacent channels' values of one row as a split pair.  Thread = channel c, values of rows i0 / i1 = i0 + 1 of its segment:
+// even lanes take row i0 of channels (c, c + 1), odd lanes row i1 of channels (c - 1, c) -- one quad-permute DPP exchange per row pair.
+__device__ __forceinline__ void split_store_pair(uint16_t* __restrict__ P0, int ps, int row0, int c, float v0, float v1, bool ok0, bool ok1) {
+    const bool odd = c & 1;
+    const float recv = lane_xor1(odd ? v0 : v1);
+    const float x0 = odd ? recv : v0, x1 = odd ? v1 : recv;
+    uint32_t th, tm, tl;
+    split3(x0, x1, th, tm, tl);
+    if (odd ? ok1 : ok0) {
+        uint32_t* d = reinterpret_cast<uint32_t*>(P0 + (row0 + (odd ? 1 : 0)) * CB_LDB + (c & ~1));
+        d[0] = th; d[ps / 2] = tm; d[ps] = tl;
+    }
+}
+
 // LayerNorm of up to 64 rows by 512 threads: 8 lanes per row (lane sub owns float4 columns 4 sub + 32 j).  gamma / beta in
 // LDS.  dst[r] = LN(src[r]) * dropout ; `drow0` = global row of row 0 (dropout element index = row * 128 + col).
 // Rows outside [keep_lo, keep_hi) are written as zeros: rows of a neighbouring sample act as the conv's zero padding.
@@ -147,6 +201,49 @@ __device__ __forceinline__ void ln_rows512(const float* __restrict__ src, float*
     }
 }
 
+// The same LayerNorm (all rows kept) whose output goes to the three bf16 planes of a split-GEMM A operand (row stride CB_LDB, `ps`
+// elements between planes) and, optionally, straight to memory (`gout`: row 0 of the tile, rows < gn are stored).
+__device__ __forceinline__ void ln_rows512_split(const float* __restrict__ src, uint16_t* __restrict__ P0, int ps, int nrows,
+                                                 const float* __restrict__ g, const float* __restrict__ b, const Drop& dp, int drow0,
+                                                 float* __restrict__ gout, int gn) {
+    const int sub = threadIdx.x & 7, r = threadIdx.x >> 3;
+    if (r >= nrows) return;
+    const float* s = src + r * LDP + sub * 4;
+    float4 v[4];
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = *reinterpret_cast<const float4*>(s + 32 * j); sum += sum4(v[j]); }
+    const float mu = grp8_sum(sum) * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        v[j].x -= mu; v[j].y -= mu; v[j].z -= mu; v[j].w -= mu;
+        q += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
+    }
+    const float rstd = rsqrtf(grp8_sum(q) * (1.0f / D) + LN_EPS);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float4 gv = *reinterpret_cast<const float4*>(g + sub * 4 + 32 * j);
+        const float4 bv = *reinterpret_cast<const float4*>(b + sub * 4 + 32 * j);
+        float4 o;
+        o.x = v[j].x * rstd * gv.x + bv.x; o.y = v[j].y * rstd * gv.y + bv.y;
+        o.z = v[j].z * rstd * gv.z + bv.z; o.w = v[j].w * rstd * gv.w + bv.w;
+        if (dp.thresh) {
+            const uint32_t base = (uint32_t)((drow0 + r) * D + sub * 4 + 32 * j);
+            o.x *= drop_keep_scale(dp, base); o.y *= drop_keep_scale(dp, base + 1);
+            o.z *= drop_keep_scale(dp, base + 2); o.w *= drop_keep_scale(dp, base + 3);
+        }
+        if (gout && r < gn) *reinterpret_cast<float4*>(gout + (size_t)r * D + sub * 4 + 32 * j) = o;
+        uint32_t h0, m0, l0, h1, m1, l1;
+        split3(o.x, o.y, h0, m0, l0);
+        split3(o.z, o.w, h1, m1, l1);
+        uint16_t* d = P0 + r * CB_LDB + sub * 4 + 32 * j;
+        *reinterpret_cast<u32x2_t*>(d) = u32x2_t{h0, h1};
+        *reinterpret_cast<u32x2_t*>(d + ps) = u32x2_t{m0, m1};
+        *reinterpret_cast<u32x2_t*>(d + 2 * ps) = u32x2_t{l0, l1};
+    }
+}
+
 // =========================================================================================================
 // forward: x0 = xin + pos ; 4 x [ v = LN(x) ; u = depthwise7(v) ; z = u Wp^T + b ; x += drop(relu(z)) ] ; then, row-local on
 // the 32 owner rows, a8's first half (:168-173): h1 = drop(LN1(x)) ; [q | k | v] = h1 W^T + b.
@@ -163,7 +260,9 @@ constexpr int CB_PS = 384;                      // per-layer small parameters in
 // FULL: R and L are multiples of the 32-row tile (every BASELINE shape): every tile is whole and lies inside one sample, so the boundary
 // flags below are compile-time constants and the per-row store / tap predicates disappear (12 % of the kernel's instructions were
 // v_cmp / v_cndmask / exec-mask branches).
-template <int SH, bool FULL>
+// SPLIT: the five GEMMs on the bf16 matrix cores at fp32 grade (gemm16s): the depthwise output / LN1 output is split into three bf16 planes
+// while it is stored (LDS +18 KB for the row tiles), the weight slices come from the split packs.
+template <int SH, bool FULL, bool SPLIT>
 __global__ __launch_bounds__(CB_T, 2) void k_convblock_fwd(CbFwdArgs a) {
     // sample tiles: 3 zero rows above and below the window in the LN / depthwise buffer stand for the taps that leave it
     constexpr int HL = 4 * SH, NW = TILE_M + 2 * HL, VOFF = SH ? 0 : HALO, VUR = SH ? NW + 12 : NW + 2 * HALO;
@@ -174,7 +273,10 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_fwd(CbFwdArgs a) {
     // workgroup per CU either way).  Sample tiles: in place in VU behind a barrier -- 45 KB, so a query-pass workgroup still fits beside a
     // video-pass one (the two passes run concurrently on two streams).
     float* Us = SH ? Xs + (NW + VUR) * LDP : VU;
-    float* Ps = Xs + (NW + VUR + (SH ? NW : 0)) * LDP;   // [4][CB_PS] per-layer small parameters | ln1_g | ln1_b | bq | bk | bv
+    // SPLIT: three bf16 planes [NW][CB_LDB] of the GEMM A operand (window rows) instead of the fp32 Us
+    uint16_t* Ub = reinterpret_cast<uint16_t*>(Xs + (NW + VUR) * LDP);
+    constexpr int UPS = NW * CB_LDB;                     // elements between planes
+    float* Ps = SPLIT ? Xs + (NW + VUR) * LDP + 3 * UPS / 2 : Xs + (NW + VUR + (SH ? NW : 0)) * LDP;   // [4][CB_PS] per-layer small parameters | ln1_g | ln1_b | bq | bk | bv
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int R = a.R, L = a.L;
     const int r0 = SH ? blockIdx.x * TILE_M : blockIdx.x * L, rw0 = r0 - HL;      // global row of window row 0
@@ -221,7 +323,9 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_fwd(CbFwdArgs a) {
     }
     // first weight slice and depthwise taps: requested once the window registers are free (first used after LayerNorm 0)
     BF16 bfA[1], bfB[1];
-    bf16_load(bfA[0], a.Wpack[0], D, 16 * w);
+    B3 b3A, b3B;
+    if (SPLIT) b3_load(b3A, a.W3[0], D, D, 16 * w);
+    else bf16_load(bfA[0], a.Wpack[0], D, 16 * w);
     float wkc[DWK];                                              // depthwise taps of this thread's channel, fetched a layer ahead
 #pragma unroll
     for (int k = 0; k < DWK; ++k) wkc[k] = a.dw_w[0][(tid & 127) * DWK + k];
@@ -241,7 +345,7 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_fwd(CbFwdArgs a) {
     const Drop nodrop{0u, 0u, 1.f};
     const int col = 16 * w + (lane & 15), g4 = 4 * (lane >> 4);
 
-    auto layer = [&](auto LC, BF16 (&cur)[1], auto&& prefetch) {
+    auto layer = [&](auto LC, auto& cur, auto&& prefetch) {
         constexpr int l = decltype(LC)::value;
         constexpr int in0 = SH * l, nin = NW - 2 * SH * l;       // LayerNorm rows
         constexpr int o0 = in0 + SH, n = nin - 2 * SH;           // rows this layer produces
@@ -279,15 +383,20 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_fwd(CbFwdArgs a) {
                     t = t + 1 == L ? 0 : t + 1;
                 }
             }
-            if (!SH) __syncthreads();                            // every window is in registers: the buffer turns into the GEMM operand
+            if (!SH && !SPLIT) __syncthreads();                  // every window is in registers: the buffer turns into the GEMM operand
             float* ug = a.u[l] + (ptrdiff_t)(rw0 + os) * D + c;
 #pragma unroll
             for (int i = 0; i < QS; ++i) {
                 if (os + i < o0 + n) {                           // wave-uniform
-                    Us[(os + i) * LDP + c] = uo[i];
+                    if (!SPLIT) Us[(os + i) * LDP + c] = uo[i];
                     const int wr = os + i;
                     if (wr >= HL && wr < HL + TILE_M && row_ok(wr)) ug[(ptrdiff_t)i * D] = uo[i];   // saved: A operand of the weight gradient
                 }
+            }
+            if (SPLIT) {                                         // GEMM operand: three bf16 planes, two channels of a row per dword
+#pragma unroll
+                for (int i = 0; i < QS; i += 2)
+                    split_store_pair(Ub, UPS, os + i, c, uo[i], i + 1 < QS ? uo[i + 1] : 0.f, os + i < o0 + n, i + 1 < QS && os + i + 1 < o0 + n);
             }
         }
         __syncthreads();
@@ -296,7 +405,8 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_fwd(CbFwdArgs a) {
         f32x4 acc[1][NRB];
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) acc[0][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
-        gemm16<NRB, 1>(Us + o0 * LDP, LDP, cur, acc);
+        if constexpr (SPLIT) gemm16s<NRB>(Ub + o0 * CB_LDB, UPS, cur, acc);
+        else gemm16<NRB, 1>(Us + o0 * LDP, LDP, cur, acc);
         __builtin_amdgcn_sched_barrier(0);
         prefetch();                                              // weight slice of the next stage: most of a layer ahead of its use
         if (l < 3) {
@@ -356,6 +466,12 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_fwd(CbFwdArgs a) {
                 *reinterpret_cast<float4*>(a.y[l] + (size_t)(r0 + rr) * D + c) = *reinterpret_cast<const float4*>(&Xs[(HL + rr) * LDP + c]);
         }
     };
+    if constexpr (SPLIT) {
+        layer(std::integral_constant<int, 0>(), b3A, [&] { b3_load(b3B, a.W3[1], D, D, 16 * w); });
+        layer(std::integral_constant<int, 1>(), b3B, [&] { b3_load(b3A, a.W3[2], D, D, 16 * w); });
+        layer(std::integral_constant<int, 2>(), b3A, [&] { b3_load(b3B, a.W3[3], D, D, 16 * w); });
+        layer(std::integral_constant<int, 3>(), b3B, [&] { b3_load(b3A, a.Wqkv3, D, 3 * D, 16 * w); });
+    } else {
     layer(std::integral_constant<int, 0>(), bfA, [&] { bf16_load(bfB[0], a.Wpack[1], D, 16 * w); });
     ESTAMP(2);
     layer(std::integral_constant<int, 1>(), bfB, [&] { bf16_load(bfA[0], a.Wpack[2], D, 16 * w); });
@@ -363,8 +479,36 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_fwd(CbFwdArgs a) {
     layer(std::integral_constant<int, 2>(), bfA, [&] { bf16_load(bfB[0], a.Wpack[3], D, 16 * w); });
     ESTAMP(4);
     layer(std::integral_constant<int, 3>(), bfB, [&] { bf16_load(bfA[0], a.qf.Wpack, 3 * D, 16 * w); });
+    }
     ESTAMP(5);
     // ---- a8, first half (:168-173) on the owner rows: h1 = drop(LN1(y3)) ; [q | k | v] = h1 W^T + b  (wave w = head w)
+    if constexpr (SPLIT) {
+        const float* Pq = Ps + 4 * CB_PS;
+        // LN1 output: three bf16 planes in the (now free) GEMM operand buffer, rows 0..31 ; h1 goes to memory straight from the registers
+        const int gn = FULL ? TILE_M : (SH ? min(TILE_M, R - r0) : L);
+        ln_rows512_split(Xs + HL * LDP, Ub, UPS, TILE_M, Pq, Pq + 128, a.qf.d1, r0, a.qf.h1 ? a.qf.h1 + (size_t)r0 * D : nullptr, gn);
+        b3_load(b3B, a.Wqkv3, D, 3 * D, D + 16 * w);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        auto proj = [&](const B3& cur, float* __restrict__ outp, int t) {
+            f32x4 acc[1][2];
+            acc[0][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[0][1] = acc[0][0];
+            gemm16s<2>(Ub, UPS, cur, acc);
+            const float bv = Pq[256 + t * D + col];
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int gr = r0 + 16 * rb + g4 + rr;
+                    if (row_ok(HL + 16 * rb + g4 + rr)) outp[(size_t)gr * D + col] = acc[0][rb][rr] + bv;
+                }
+        };
+        proj(b3A, a.qf.q, 0);
+        b3_load(b3A, a.Wqkv3, D, 3 * D, 2 * D + 16 * w);
+        __builtin_amdgcn_sched_barrier(0);
+        proj(b3B, a.qf.k, 1);
+        proj(b3A, a.qf.v, 2);
+    } else
     {
         const float* Pq = Ps + 4 * CB_PS;
         ln_rows512(Xs + HL * LDP, VU, TILE_M, Pq, Pq + 128, a.qf.d1, r0);
@@ -402,19 +546,26 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_fwd(CbFwdArgs a) {
     ESTAMP(6);
 }
 constexpr size_t cb_fwd_lds(int sh) { return (size_t)(((sh ? 2 : 1) * (TILE_M + 8 * sh) + (sh ? TILE_M + 8 * sh + 12 : TILE_M + 2 * HALO)) * LDP + 4 * CB_PS + 640) * sizeof(float); }
+constexpr size_t cb_fwd_lds_split(int sh) {
+    return (size_t)(((TILE_M + 8 * sh) + (sh ? TILE_M + 8 * sh + 12 : TILE_M + 2 * HALO)) * LDP + 3 * (TILE_M + 8 * sh) * CB_LDB / 2 + 4 * CB_PS + 640) * sizeof(float);
+}
+template <int SH, bool FULL, bool SPLIT>
+static void launch_cbf(const CbFwdArgs& a, int grid, hipStream_t s) {
+    static size_t ok = 0;
+    const size_t lds = SPLIT ? cb_fwd_lds_split(SH) : cb_fwd_lds(SH);
+    ensure_dynamic_lds((const void*)k_convblock_fwd<SH, FULL, SPLIT>, lds, ok, "k_convblock_fwd");
+    VSL_LAUNCH((k_convblock_fwd<SH, FULL, SPLIT>), dim3(grid), dim3(CB_T), lds, s, a);
+}
 void launch_convblock_fwd(const CbFwdArgs& a, hipStream_t s) {
-    static size_t ok3 = 0, ok3f = 0, ok0 = 0;
+    const bool split = a.W3[0] != nullptr;
     if (a.L <= TILE_M) {                    // sample tiles: one workgroup per sample
-        ensure_dynamic_lds((const void*)k_convblock_fwd<0, false>, cb_fwd_lds(0), ok0, "k_convblock_fwd<0>");
-        VSL_LAUNCH((k_convblock_fwd<0, false>), dim3(a.R / a.L), dim3(CB_T), cb_fwd_lds(0), s, a);
+        if (split) launch_cbf<0, false, true>(a, a.R / a.L, s); else launch_cbf<0, false, false>(a, a.R / a.L, s);
         return;
     }
     if (a.R % TILE_M == 0 && a.L % TILE_M == 0) {       // whole tiles inside one sample each: the predicate-free instantiation
-        ensure_dynamic_lds((const void*)k_convblock_fwd<3, true>, cb_fwd_lds(3), ok3f, "k_convblock_fwd<3, full>");
-        VSL_LAUNCH((k_convblock_fwd<3, true>), dim3(a.R / TILE_M), dim3(CB_T), cb_fwd_lds(3), s, a);
+        if (split) launch_cbf<3, true, true>(a, a.R / TILE_M, s); else launch_cbf<3, true, false>(a, a.R / TILE_M, s);
     } else {
-        ensure_dynamic_lds((const void*)k_convblock_fwd<3, false>, cb_fwd_lds(3), ok3, "k_convblock_fwd<3>");
-        VSL_LAUNCH((k_convblock_fwd<3, false>), dim3((a.R + TILE_M - 1) / TILE_M), dim3(CB_T), cb_fwd_lds(3), s, a);
+        if (split) launch_cbf<3, false, true>(a, (a.R + TILE_M - 1) / TILE_M, s); else launch_cbf<3, false, false>(a, (a.R + TILE_M - 1) / TILE_M, s);
     }
     static int left = 6;
     if (edbg_on() && a.R > 4096) { int l2 = left; edbg_report("convblock_fwd: load | L0 | L1 | L2 | L3 | qkv", 7, s, left); edbg_report2("  L0: LN | dw | gemm | epilogue | barrier", 8, 13, s, l2); }

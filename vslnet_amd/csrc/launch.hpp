@@ -154,6 +154,8 @@ void launch_conv_layer_fwd(const float* xin, const float* pos, float* x0_out, co
                            uint32_t* relu_mask, int R, int L, Drop dp, const QkvFuse& qkv, hipStream_t s);
 // fused conv block of one encoder application (kernels_enc.hip): 4 layers + LN1 / QKV in one launch, 12-row recomputed halo
 struct CbFwdArgs {
+    const uint16_t* W3[4];         // split packs (PackJob type 6) of the four pointwise weights ; nullptr = fp32-input MFMA path
+    const uint16_t* Wqkv3;         // split pack of the fused (128, 384) QKV operand
     const float *xin, *pos;
     float* x0_out;
     const float *ln_g[4], *ln_b[4], *dw_w[4], *Wpack[4], *pw_b[4];
