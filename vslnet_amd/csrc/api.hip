@@ -723,6 +723,7 @@ void enc_bwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float*
                 a.relu_mask[i] = reinterpret_cast<const uint32_t*>(c.W(w.mask[i])); a.WTpack[i] = c.PK(K.pw_t[i]);
                 a.ln_g[i] = c.P(P.lng[i]); a.ln_b[i] = c.P(P.lnb[i]); a.dw_w[i] = c.P(P.dw[i]);
                 a.dp[i] = c.drop(app * 16 + i); a.gz[i] = c.W(t.gz[i]);
+                if (split_gemm_enabled()) a.WT3[i] = reinterpret_cast<const uint16_t*>(c.PK(K.pw_t3[i]));
             }
         }
         LAUNCH("convblock_bwd", launch_convblock_bwd(a, c.s));

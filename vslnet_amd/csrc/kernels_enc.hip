@@ -582,13 +582,18 @@ void launch_convblock_fwd(const CbFwdArgs& a, hipStream_t s) {
 // segment) with the 4 segments of a channel in 4 adjacent lanes, so the partial sums are combined with two quad shuffles.
 // LDS 91 KB: fits beside a weight-gradient workgroup (66 KB) of the side stream.
 // =========================================================================================================
-template <int SH, bool FULL>        // SH 3: row tiles with a recomputed halo ; 0: sample tiles for L <= 32 ; FULL: see k_convblock_fwd
+// SPLIT: du = dz Wp on the bf16 matrix cores at fp32 grade (gemm16s): phase A stores dz as three bf16 planes, which share their LDS with dv
+// (GU) -- dz is dead before phase C writes dv, but the next layer's phase A overwrites what phase D still reads: one more barrier per layer.
+template <int SH, bool FULL, bool SPLIT>        // SH 3: row tiles with a recomputed halo ; 0: sample tiles for L <= 32 ; FULL: see k_convblock_fwd
 __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
     constexpr int HL = 4 * SH, NW = TILE_M + 2 * HL, VUR = SH ? NW + 12 : NW, XR = NW - 2 * SH;
+    constexpr int ZPS = NW * CB_LDB;                     // SPLIT: elements between the dz planes
+    constexpr int GUF = SPLIT ? (3 * ZPS / 2 > VUR * LDP ? 3 * ZPS / 2 : VUR * LDP) : VUR * LDP;      // floats of the dz / dv region
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* DY = smem;                       // [56][LDP] grad wrt the current layer's output (in place)
     float* GU = DY + NW * LDP;           // [68][LDP] dz (GEMM A operand), later dv
-    float* DU = GU + VUR * LDP;          // [68][LDP] du: its own buffer, so neither the GEMM's reads nor the conv windows need a barrier of their own
+    uint16_t* Pz = reinterpret_cast<uint16_t*>(GU);      // SPLIT: dz as three bf16 planes [NW][CB_LDB]
+    float* DU = GU + GUF;                // [68][LDP] du: its own buffer, so neither the GEMM's reads nor the conv windows need a barrier of their own
     float* Xh = DU + VUR * LDP;              // [50][LDP] x_l, normalised in place; row = window row - SH
     float* RS = Xh + XR * LDP;           // [64] rstd per window row
     float* VF = RS + 64;                    // [64] 1 = the window row belongs to the owner sample / is inside [0, R)
@@ -638,7 +643,9 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
             if (r8 < NW) *reinterpret_cast<float4*>(&DY[r8 * LDP + sub * 4 + 32 * q]) = dv[q];
     }
     BF16 bfA[1], bfB[1];
-    bf16_load(bfA[0], a.WTpack[3], D, 16 * w);
+    B3 b3A, b3B;
+    if (SPLIT) b3_load(b3A, a.WT3[3], D, D, 16 * w);
+    else bf16_load(bfA[0], a.WTpack[3], D, 16 * w);
     float wk[DWK], gc, bc, gnext = 0.f;
 #pragma unroll
     for (int k = 0; k < DWK; ++k) wk[k] = a.dw_w[3][cc * DWK + k];
@@ -650,7 +657,7 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
     const int col = 16 * w + (lane & 15), g4 = 4 * (lane >> 4);
     ESTAMP(1);
 
-    auto layer = [&](auto LC, BF16 (&cur)[1], BF16 (&nxt)[1]) {
+    auto layer = [&](auto LC, auto& cur, auto& nxt) {
         constexpr int l = decltype(LC)::value;
         constexpr int ra = SH * (3 - l), rb_ = NW - ra;              // rows of dy / dz / du
         constexpr int n = rb_ - ra, NRB = (n + 15) / 16;
@@ -675,7 +682,15 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
                 v.y = (bits & 2u) ? v.y * m[1] : 0.f;
                 v.z = (bits & 4u) ? v.z * m[2] : 0.f;
                 v.w = (bits & 8u) ? v.w * m[3] : 0.f;
-                *reinterpret_cast<float4*>(&GU[wr * LDP + c4]) = v;
+                if constexpr (SPLIT) {
+                    uint32_t h0, m0, l0, h1, m1, l1;
+                    split3(v.x, v.y, h0, m0, l0);
+                    split3(v.z, v.w, h1, m1, l1);
+                    uint16_t* d = Pz + wr * CB_LDB + c4;
+                    *reinterpret_cast<u32x2_t*>(d) = u32x2_t{h0, h1};
+                    *reinterpret_cast<u32x2_t*>(d + ZPS) = u32x2_t{m0, m1};
+                    *reinterpret_cast<u32x2_t*>(d + 2 * ZPS) = u32x2_t{l0, l1};
+                } else *reinterpret_cast<float4*>(&GU[wr * LDP + c4]) = v;
                 if (wr >= HL && wr < HL + TILE_M && row_ok(wr))
                     *reinterpret_cast<float4*>(a.gz[l] + (size_t)(rw0 + wr) * D + c4) = v;
             }
@@ -710,7 +725,8 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
         f32x4 acc[1][NRB];
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) acc[0][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
-        gemm16<NRB, 1>(GU + ra * LDP, LDP, cur, acc);
+        if constexpr (SPLIT) gemm16s<NRB>(Pz + ra * CB_LDB, ZPS, cur, acc);
+        else gemm16<NRB, 1>(GU + ra * LDP, LDP, cur, acc);
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
@@ -813,7 +829,8 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
         if (l > 0) {
             constexpr int lm = l > 0 ? l - 1 : 0;
             fetch_layer(lm);
-            bf16_load(nxt[0], a.WTpack[lm], D, 16 * w);
+            if constexpr (SPLIT) b3_load(nxt, a.WT3[lm], D, D, 16 * w);
+            else bf16_load(nxt[0], a.WTpack[lm], D, 16 * w);
 #pragma unroll
             for (int k = 0; k < DWK; ++k) wk[k] = a.dw_w[lm][cc * DWK + k];
             gc = a.ln_g[lm][cc]; bc = a.ln_b[lm][cc];
@@ -853,9 +870,17 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
                 }
             }
         }
-        // no barrier: phase A of the next layer touches only what this thread itself read and wrote above
+        // no barrier: phase A of the next layer touches only what this thread itself read and wrote above -- except the dz planes of the
+        // split path, which lie over the dv rows other threads are still reading
+        if (SPLIT && l > 0) __syncthreads();
     };
     __syncthreads();
+    if constexpr (SPLIT) {
+        layer(std::integral_constant<int, 3>(), b3A, b3B);
+        layer(std::integral_constant<int, 2>(), b3B, b3A);
+        layer(std::integral_constant<int, 1>(), b3A, b3B);
+        layer(std::integral_constant<int, 0>(), b3B, b3A);
+    } else {
     layer(std::integral_constant<int, 3>(), bfA, bfB);
     ESTAMP(2);
     layer(std::integral_constant<int, 2>(), bfB, bfA);
@@ -863,22 +888,31 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
     layer(std::integral_constant<int, 1>(), bfA, bfB);
     ESTAMP(4);
     layer(std::integral_constant<int, 0>(), bfB, bfA);
+    }
     ESTAMP(5);
 }
 constexpr size_t cb_bwd_lds(int sh) { return (size_t)((TILE_M + 8 * sh + 2 * (sh ? TILE_M + 8 * sh + 12 : TILE_M) + TILE_M + 6 * sh) * LDP + 64 + 64 + 256) * sizeof(float); }
+constexpr size_t cb_bwd_lds_split(int sh) {
+    const int nw = TILE_M + 8 * sh, vur = sh ? nw + 12 : nw, zf = 3 * nw * CB_LDB / 2, guf = zf > vur * LDP ? zf : vur * LDP;
+    return (size_t)((nw + vur + TILE_M + 6 * sh) * LDP + guf + 64 + 64 + 256) * sizeof(float);
+}
+template <int SH, bool FULL, bool SPLIT>
+static void launch_cbb(const CbBwdArgs& a, int grid, hipStream_t s) {
+    static size_t ok = 0;
+    const size_t lds = SPLIT ? cb_bwd_lds_split(SH) : cb_bwd_lds(SH);
+    ensure_dynamic_lds((const void*)k_convblock_bwd<SH, FULL, SPLIT>, lds, ok, "k_convblock_bwd");
+    VSL_LAUNCH((k_convblock_bwd<SH, FULL, SPLIT>), dim3(grid), dim3(CB_T), lds, s, a);
+}
 void launch_convblock_bwd(const CbBwdArgs& a, hipStream_t s) {
-    static size_t ok3 = 0, ok3f = 0, ok0 = 0;
+    const bool split = a.WT3[3] != nullptr;
     if (a.L <= TILE_M) {                    // sample tiles: one workgroup per sample (partial slabs per SAMPLE: convblock_slabs())
-        ensure_dynamic_lds((const void*)k_convblock_bwd<0, false>, cb_bwd_lds(0), ok0, "k_convblock_bwd<0>");
-        VSL_LAUNCH((k_convblock_bwd<0, false>), dim3(a.R / a.L), dim3(CB_T), cb_bwd_lds(0), s, a);
+        if (split) launch_cbb<0, false, true>(a, a.R / a.L, s); else launch_cbb<0, false, false>(a, a.R / a.L, s);
         return;
     }
     if (a.R % TILE_M == 0 && a.L % TILE_M == 0) {
-        ensure_dynamic_lds((const void*)k_convblock_bwd<3, true>, cb_bwd_lds(3), ok3f, "k_convblock_bwd<3, full>");
-        VSL_LAUNCH((k_convblock_bwd<3, true>), dim3(a.R / TILE_M), dim3(CB_T), cb_bwd_lds(3), s, a);
+        if (split) launch_cbb<3, true, true>(a, a.R / TILE_M, s); else launch_cbb<3, true, false>(a, a.R / TILE_M, s);
     } else {
-        ensure_dynamic_lds((const void*)k_convblock_bwd<3, false>, cb_bwd_lds(3), ok3, "k_convblock_bwd<3>");
-        VSL_LAUNCH((k_convblock_bwd<3, false>), dim3((a.R + TILE_M - 1) / TILE_M), dim3(CB_T), cb_bwd_lds(3), s, a);
+        if (split) launch_cbb<3, false, true>(a, (a.R + TILE_M - 1) / TILE_M, s); else launch_cbb<3, false, false>(a, (a.R + TILE_M - 1) / TILE_M, s);
     }
     static int left = 6;
     if (edbg_on() && a.R > 4096) edbg_report("convblock_bwd: load | L3 | L2 | L1 | L0", 6, s, left);

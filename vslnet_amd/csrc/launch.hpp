@@ -167,6 +167,7 @@ struct CbFwdArgs {
 };
 void launch_convblock_fwd(const CbFwdArgs& a, hipStream_t s);
 struct CbBwdArgs {
+    const uint16_t* WT3[4];        // split packs (PackJob type 7) of the pointwise weights' data-gradient operand ; nullptr = fp32-input MFMA path
     const float* dy;               // (R,128) grad wrt the block output
     const float* x[4];             // LayerNorm inputs of layers 0..3 (x0, y0, y1, y2)
     const uint32_t* relu_mask[4];
