@@ -54,7 +54,7 @@ struct EncWs { int64_t x0, y[4], u[4], mask[4], h1, q, k, v, lse, att, r, h2, ou
 
 struct LstmWs { int64_t gi, gates, cseq, hprev, out, dG, carry; };   // one DynamicRNN: x W_ih^T, activated gates, c_t, h_{t-1}, h * mask, gate grads, (B,2,128) dc/dh hand-over between time chunks
 
-struct EncTmp { int64_t dr, dq, dk, dv, Dq, go, du, du2, gz[4], ga, gb; };   // backward temporaries of one encoder application
+struct EncTmp { int64_t dr, dq, dk, dv, Dq, go, gz[4], ga; };   // backward temporaries of one encoder application
 
 struct SlabRec { int dst, n, nslabs, ss, rl, ds, vn; int64_t src; };
 // the reduction runs in two launches: `early` = parameters whose partials are complete before the final video/query fork
@@ -106,10 +106,13 @@ struct vsl_handle_s {
     hipStream_t ev_stream[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_last[4] = {nullptr, nullptr, nullptr, nullptr};
     int ev_n = 0;
+    bool ev_dirty[4] = {false, false, false, false};     // a wait was enqueued on the stream AFTER its last kernel: that kernel's stop event no
+                                                         // longer stands for "everything enqueued so far" (the shortcut is not transitive)
     hipEvent_t last_event(hipStream_t s) const {
-        for (int i = 0; i < ev_n; ++i) if (ev_stream[i] == s) return ev_last[i];
+        for (int i = 0; i < ev_n; ++i) if (ev_stream[i] == s) return ev_dirty[i] ? nullptr : ev_last[i];
         return nullptr;
     }
+    void mark_waiting(hipStream_t s) { for (int i = 0; i < ev_n; ++i) if (ev_stream[i] == s) ev_dirty[i] = true; }
     bool multi_stream = true;
     // optional per-kernel timing with HIP events on the launch stream (vsl_profile_*), used by bench.py's roofline line
     bool prof_on = false;
@@ -348,6 +351,7 @@ struct CallScope {
     explicit CallScope(vsl_handle_s* h) {
         static const bool off = getenv("VSL_STOP_EVENTS") && getenv("VSL_STOP_EVENTS")[0] == '0';
         h->sync_used = 0; h->stop_used = 0; h->ev_n = 0;
+        for (bool& d : h->ev_dirty) d = false;
         h->stop_events = h->multi_stream && !off;
         g_cur = h;
     }
@@ -389,25 +393,27 @@ struct Ctx {
     // make stream `to` wait for everything enqueued so far on stream `from`
     void order(hipStream_t from, hipStream_t to) {
         if (dry || from == to) return;
-        if (hipEvent_t le = h->last_event(from)) { (void)hipStreamWaitEvent(to, le, 0); return; }   // rides on from's last kernel
+        // rides on from's last kernel -- unless `from` itself was made to wait for something after that kernel (then a marker is recorded)
+        if (hipEvent_t le = h->last_event(from)) { (void)hipStreamWaitEvent(to, le, 0); h->mark_waiting(to); return; }
         if (h->sync_used == h->sync_pool.size()) { hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); h->sync_pool.push_back(e); }
         hipEvent_t e = h->sync_pool[h->sync_used++];
         (void)hipEventRecord(e, from);
         (void)hipStreamWaitEvent(to, e, 0);
+        h->mark_waiting(to);
     }
     // one event record on `from`, two waiters
     void order2(hipStream_t from, hipStream_t to1, hipStream_t to2) {
         if (dry) return;
         if (hipEvent_t le = h->last_event(from)) {
-            if (to1 != from) (void)hipStreamWaitEvent(to1, le, 0);
-            if (to2 != from && to2 != to1) (void)hipStreamWaitEvent(to2, le, 0);
+            if (to1 != from) { (void)hipStreamWaitEvent(to1, le, 0); h->mark_waiting(to1); }
+            if (to2 != from && to2 != to1) { (void)hipStreamWaitEvent(to2, le, 0); h->mark_waiting(to2); }
             return;
         }
         if (h->sync_used == h->sync_pool.size()) { hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); h->sync_pool.push_back(e); }
         hipEvent_t e = h->sync_pool[h->sync_used++];
         (void)hipEventRecord(e, from);
-        if (to1 != from) (void)hipStreamWaitEvent(to1, e, 0);
-        if (to2 != from && to2 != to1) (void)hipStreamWaitEvent(to2, e, 0);
+        if (to1 != from) { (void)hipStreamWaitEvent(to1, e, 0); h->mark_waiting(to1); }
+        if (to2 != from && to2 != to1) { (void)hipStreamWaitEvent(to2, e, 0); h->mark_waiting(to2); }
     }
     hipStream_t side(int k) const { return (h->multi_stream && h->side[k]) ? h->side[k] : main; }
     hipStream_t main = nullptr;
@@ -488,9 +494,7 @@ enum { SITE_VIS = 64, SITE_WORD = 65, SITE_CHAR = 66, SITE_CQ_C = 67, SITE_CQ_Q 
 // ------------------------------------------------------------------------------------------------ forward
 void enc_fwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float* xin, const float* mask, int Bn, int app) {
     const int R = w.R, L = w.L, H = c.h->cfg.num_heads;
-    static const bool fuse_qkv = !(getenv("VSL_FUSE_QKV") && getenv("VSL_FUSE_QKV")[0] == '0');
-    static const bool conv_block = !(getenv("VSL_CONVBLOCK") && getenv("VSL_CONVBLOCK")[0] == '0');
-    if (conv_block && fuse_qkv) {
+    {
         // the whole conv block + LN1 / QKV in ONE launch (kernels_enc.hip: 12-row recomputed halo)
         CbFwdArgs a;
         memset(&a, 0, sizeof a);
@@ -510,22 +514,8 @@ void enc_fwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float*
             a.R = R; a.L = L;
         }
         LAUNCH("convblock_fwd", launch_convblock_fwd(a, c.s));
-    } else
-    for (int i = 0; i < 4; ++i) {
-        QkvFuse qf;
-        memset(&qf, 0, sizeof qf);
-        if (i == 3 && fuse_qkv)      // LN1 + QKV projection ride on the last conv layer's kernel
-            qf = QkvFuse{c.P(P.ln1g), c.P(P.ln1b), c.PK(K.qkv_f), c.P(P.qb), c.P(P.kb), c.P(P.vb), c.W(w.h1), c.W(w.q), c.W(w.k), c.W(w.v),
-                         c.drop(app * 16 + 4)};
-        LAUNCH("conv_layer_fwd", launch_conv_layer_fwd(i == 0 ? xin : c.W(w.y[i - 1]), i == 0 ? c.P(P.pos) : nullptr, i == 0 ? c.W(w.x0) : nullptr,
-                              c.P(P.lng[i]), c.P(P.lnb[i]), c.P(P.dw[i]), c.PK(K.pw_f[i]), c.P(P.pwb[i]), c.W(w.y[i]),
-                              c.W(w.u[i]), reinterpret_cast<uint32_t*>(c.W(w.mask[i])), R, L, c.drop(app * 16 + i), qf, c.s));
     }
-    if (!fuse_qkv)
-        LAUNCH("ln_qkv_fwd", launch_ln_qkv_fwd(c.W(w.y[3]), c.P(P.ln1g), c.P(P.ln1b), c.PK(K.qkv_f), c.P(P.qb), c.P(P.kb), c.P(P.vb), c.W(w.h1),
-                          c.W(w.q), c.W(w.k), c.W(w.v), R, c.drop(app * 16 + 4), c.s));
-    static const bool attn_block = !(getenv("VSL_ATTN_BLOCK") && getenv("VSL_ATTN_BLOCK")[0] == '0');
-    if (attn_block && H == 8 && L <= 256) {      // longer sequences: K / V staged in LDS per 64 queries wins (T = 1024: 3.29 vs 3.33 ms)
+    if (H == 8 && L <= 256) {      // longer sequences: K / V staged in LDS per 64 queries wins (T = 1024: 3.29 vs 3.33 ms)
         AttnBlockArgs ab{c.W(w.q), c.W(w.k), c.W(w.v), mask, c.W(w.y[3]), c.P(P.ln2g), c.P(P.ln2b), c.PK(K.o_f), c.P(P.ob),
                          c.W(w.att), c.W(w.lse), c.W(w.r), c.W(w.h2), c.W(w.out), L, 0,
                          c.drop(app * 16 + 5), c.drop(app * 16 + 6), c.drop(app * 16 + 7), c.drop(app * 16 + 8)};
@@ -665,19 +655,8 @@ void enc_bwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float*
                            c.W(t.dv), c.W(t.Dq), Bn, L, H, 0, c.drop(app * 16 + 5), c.drop(app * 16 + 6), c.s));
     float* p_ln1g = c.slab(P.ln1g, D, ntiles);
     float* p_ln1b = c.slab(P.ln1b, D, ntiles);
-    // conv block backward as a chain of fused kernels: [LN1/qkv backward + gemm(3)] -> [dwln(3) + gemm(2)] -> ... -> [dwln(0)]
-    auto gemm_args = [&](int i) {
-        ConvGemmArgs g;
-        memset(&g, 0, sizeof g);
-        if (i >= 0 && !c.dry) {
-            g.relu_mask = reinterpret_cast<const uint32_t*>(c.W(w.mask[i])); g.WTpack = c.PK(K.pw_t[i]);
-            g.gz = c.W(t.gz[i]); g.du = c.W(t.du); g.dp = c.drop(app * 16 + i);
-        }
-        return g;
-    };
-    static const bool conv_block = !(getenv("VSL_CONVBLOCK_BWD") && getenv("VSL_CONVBLOCK_BWD")[0] == '0');
     LAUNCH("qkv_bwd", launch_qkv_bwd(c.W(t.dq), c.W(t.dk), c.W(t.dv), c.W(w.y[3]), c.W(t.dr), c.P(P.ln1g), c.PK(K.qkv_t),
-                          c.W(t.ga), p_ln1g, p_ln1b, R, c.drop(app * 16 + 4), gemm_args(conv_block ? -1 : 3), c.s));
+                          c.W(t.ga), p_ln1g, p_ln1b, R, c.drop(app * 16 + 4), c.s));
     {   // out_layer + fused q/k/v weight gradients: every input exists now -> side stream, beside the conv chain
         WgradBatch wb;
         memset(&wb, 0, sizeof wb);
@@ -705,8 +684,7 @@ void enc_bwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float*
         wgrad_async(c, sw, wb);
     }
     float* g = c.dry ? nullptr : c.W(t.ga);
-    float* other = c.dry ? nullptr : c.W(t.gb);
-    if (conv_block) {
+    {
         // the four layers in ONE launch (kernels_enc.hip: 12-row recomputed halo); slab order = the per-layer chain's
         CbBwdArgs a;
         memset(&a, 0, sizeof a);
@@ -727,21 +705,6 @@ void enc_bwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float*
             }
         }
         LAUNCH("convblock_bwd", launch_convblock_bwd(a, c.s));
-    } else
-    for (int i = 3; i >= 0; --i) {
-        float* p_g = c.slab(P.lng[i], D, ntiles);
-        float* p_b = c.slab(P.lnb[i], D, ntiles);
-        float* p_dw = c.slab(P.dw[i], D * DWK, ntiles);
-        float* out = i > 0 ? other : dx0_out;
-        // du(i) was produced by the previous kernel of the chain; this one also produces du(i-1).  The two du buffers
-        // alternate (ga/gb carry dy, du/du2 carry du) so a kernel never reads a buffer another workgroup of it writes.
-        ConvGemmArgs nx = gemm_args(i - 1);
-        if (!c.dry) { nx.du = (i & 1) ? c.W(t.du2) : c.W(t.du); }
-        const float* du_in = c.dry ? nullptr : ((i & 1) ? c.W(t.du) : c.W(t.du2));
-        LAUNCH("conv_bwd_dwln", launch_conv_bwd_dwln(du_in, i > 0 ? c.W(w.y[i - 1]) : c.W(w.x0), g, c.P(P.lng[i]), c.P(P.lnb[i]),
-                                    c.P(P.dw[i]), nullptr, out, p_g, p_b, p_dw, R, L, nx, c.s));
-        other = g;
-        g = out;
     }
     // pointwise-conv weight gradients (inputs complete only now); Wo / QKV were launched right after qkv_bwd
     {
@@ -1055,9 +1018,9 @@ int build_plan(vsl_handle_s* h, int B, int T, int Lq, int Lc, Plan** out) {
         const int64_t Ra = ap == 1 ? Rq : R;
         EncTmp& t = p->tmp[ap];
         t.dr = al(Ra * D); t.dq = al(Ra * D); t.dk = al(Ra * D); t.dv = al(Ra * D); t.Dq = al((int64_t)B * H * (ap == 1 ? Lq : T));
-        t.go = al(Ra * D); t.du = al(Ra * D); t.du2 = al(Ra * D);
+        t.go = al(Ra * D);
         for (int i = 0; i < 4; ++i) t.gz[i] = al(Ra * D);
-        t.ga = al(Ra * D); t.gb = al(Ra * D);
+        t.ga = al(Ra * D);
     }
     p->df2 = al(R * D); p->df1 = al(R * D); p->dC = al(R * D);
     {
@@ -1186,6 +1149,7 @@ void vsl_launch_events(hipStream_t s, hipEvent_t* start, hipEvent_t* stop) {
         while (i < h->ev_n && h->ev_stream[i] != s) ++i;
         if (i == h->ev_n) { if (h->ev_n == 4) return; h->ev_stream[h->ev_n++] = s; }
         h->ev_last[i] = e;
+        h->ev_dirty[i] = false;              // the new kernel runs behind every wait enqueued before it
     }
 }
 }  // namespace vsl

@@ -604,74 +604,6 @@ __device__ __forceinline__ void ln_bwd_tile(float* Ts, float* Xs, const LnResid&
     }
 }
 
-// Arguments of the data-gradient GEMM of one conv layer (du = (dy * dropmask * relu-bit) Wp),
-// fused behind the kernel that produces dy (k_conv_bwd_dwln of the layer above, k_qkv_bwd).
-struct ConvGemmArgs {
-    const uint32_t* relu_mask;   // (R, 4) bit-mask saved by the forward ; nullptr = no fused stage
-    const float* WTpack;         // transpose pack of the pointwise weight
-    float* gz;                   // out (R,128): dz, the G operand of the weight gradient
-    float* du;                   // out (R,128)
-    Drop dp;
-};
-// The ReLU bit-mask words a thread needs in conv_gemm_stage; requested at kernel entry (conv_mask_prefetch) so that their
-// latency is not paid between the stage's two barriers.
-struct ConvMaskWords { uint32_t w[4]; };
-__device__ __forceinline__ void conv_mask_prefetch(ConvMaskWords& m, const ConvGemmArgs& a, int r0, int R) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int e = threadIdx.x + q * 256;
-        const int r = min(r0 + (e >> 5), R - 1), c = (e & 31) * 4;
-        m.w[q] = a.relu_mask[(size_t)r * 4 + (c >> 5)];
-    }
-}
-// Gs holds the dy tile (stride LDP, rows >= R zero).  Applies mask + dropout in place, writes gz, runs the GEMM with
-// the (already requested) weight fragments, writes du.  Contains two barriers.  Full tile / dropout on-off are
-// block-uniform cases: no per-element control flow.
-__device__ __forceinline__ void conv_gemm_stage(float* Gs, const ConvGemmArgs& a, BFrag<1, 16>& bf, const ConvMaskWords& mw, int r0, int R) {
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const bool full = r0 + TILE_M <= R;
-    __syncthreads();
-    auto apply = [&](auto full_c, auto drop_c) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int e = tid + q * 256;
-            const int rr = e >> 5, c = (e & 31) * 4;
-            const int r = r0 + rr;
-            float4 v = *reinterpret_cast<const float4*>(&Gs[rr * LDP + c]);
-            const uint32_t bits = mw.w[q] >> (c & 31);
-            float m[4] = {1.f, 1.f, 1.f, 1.f};
-            if (decltype(drop_c)::value) {
-                const uint32_t base = (uint32_t)(r * D + c);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) m[i] = drop_keep_scale(a.dp, base + i);
-            }
-            v.x = (bits & 1u) ? v.x * m[0] : 0.f;
-            v.y = (bits & 2u) ? v.y * m[1] : 0.f;
-            v.z = (bits & 4u) ? v.z * m[2] : 0.f;
-            v.w = (bits & 8u) ? v.w * m[3] : 0.f;
-            if (decltype(full_c)::value || r < R) *reinterpret_cast<float4*>(a.gz + (size_t)r * D + c) = v;
-            *reinterpret_cast<float4*>(&Gs[rr * LDP + c]) = v;
-        }
-    };
-    if (full) { if (a.dp.thresh) apply(std::true_type(), std::true_type()); else apply(std::true_type(), std::false_type()); }
-    else      { if (a.dp.thresh) apply(std::false_type(), std::true_type()); else apply(std::false_type(), std::false_type()); }
-    __syncthreads();
-    f32x16 acc[1];
-    zero_acc(acc);
-    gemm32p<1, 16>(Gs, LDP, D, a.WTpack, D, 32 * w, 0, acc, bf);
-    const int col = 32 * w + (lane & 31);
-    if (full) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) a.du[(size_t)(r0 + acc_row(r, lane)) * D + col] = acc[0][r];
-    } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int gr = r0 + acc_row(r, lane);
-            if (gr < R) a.du[(size_t)gr * D + col] = acc[0][r];
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // tile I/O
 // ---------------------------------------------------------------------------------------------------------

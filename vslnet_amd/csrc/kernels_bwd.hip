@@ -209,8 +209,7 @@ void launch_loss(const float* sl, const float* el, const float* h, const int64_t
                  const int64_t* h_lab, const float* vmask, int B, int T, float inv_batch, float mask_sum_override,
                  float w_loc, float w_hl, float* scratch, float* losses, float* d_sl, float* d_el, float* d_h,
                  hipStream_t s, unsigned* counter) {
-    static const bool fused = !(getenv("VSL_LOSS_FUSED") && getenv("VSL_LOSS_FUSED")[0] == '0');
-    if (fused && counter && d_sl && mask_sum_override > 0.f) {
+    if (counter && d_sl && mask_sum_override > 0.f) {     // the caller supplies the global mask sum (data-parallel path): one launch
         VSL_LAUNCH(k_loss_fused, dim3(B), dim3(256), 0, s, sl, el, h, s_lab, e_lab, h_lab, vmask, B, T, inv_batch, mask_sum_override,
                    w_loc, w_hl, scratch, losses, d_sl, d_el, d_h, counter);
         return;
@@ -340,301 +339,8 @@ void launch_head_bwd(const HeadBwdArgs& a0, const HeadBwdArgs& a1, int R, hipStr
     }
 }
 
-// =========================================================================================================
-// generic weight gradient  dW[n][k] = sum_r G[r][n] A[r][k]   (+ bias = column sums of G)
-//   grid = one workgroup per (job, G block, row chunk of WG_ROWS, k tile of 128); each writes one partial slab tile.
-// =========================================================================================================
-__global__ __launch_bounds__(512) void k_wgrad(WgradBatch wb) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];    // 2 x (G tile | A tile), 32 x LDP each
-    // compact 1-D grid: every workgroup has work (an empty one would still hold a CU's LDS while it starts and exits)
-    int ji = 0;
-    while (ji + 1 < wb.n && (int)blockIdx.x >= wb.start[ji + 1]) ++ji;
-    const WgradJob& j = wb.j[ji];
-    const int K = j.K, R = j.R;
-    const int nkt = (K + 127) >> 7, nch = (R + WG_ROWS - 1) / WG_ROWS;
-    const int local = blockIdx.x - wb.start[ji];
-    const int kt = local % nkt, ch = (local / nkt) % nch, gb = local / (nkt * nch);
-    // 8 waves = 2 per SIMD: wave (nb, kh) owns output rows n = 32 nb .. +32, columns k = 64 kh .. +64 of the 128 x 128
-    // block, so one wave's load issue / LDS stores / barrier wait sit under the other wave's MFMAs.
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const int nb = w & 3, kh = w >> 2;
-    const float* G = j.G[gb];
-    const float* Ablk = j.nA > 0 ? j.A[kt] : nullptr;
-    const bool dropA = !Ablk && j.drop_on_A && j.dp.thresh;
-    f32x16 acc[2];
-    zero_acc(acc);
-    float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);         // column sums of G over this thread's rows (bias gradient)
-    const int rbeg = ch * WG_ROWS, rend = min(R, rbeg + WG_ROWS);
-    const int c = (tid & 31) * 4, rr0 = tid >> 5;         // this thread's float4 column and first row of a tile
-    const bool kin = Ablk || kt * 128 + c < K;
-    const bool kin_all = Ablk || kt * 128 + 128 <= K;      // block-uniform: no column of this k-tile is outside K
-    struct TileRegs { float4 g[2], a[2]; };
-    // Loads are unconditional (row clamped into the chunk, column clamped into K) so that they compile to straight-line
-    // global_load_dwordx4 the wait counters can track; out-of-range values are zeroed when the tile is written to LDS.
-    // fp32 MFMAs run on the SIMD's FMA lanes, so every vector-ALU instruction in this loop is paid in full (measured: the
-    // loop time is MFMA cycles + 4 cycles x VALU instructions x waves, whatever the interleaving).  The store path is
-    // therefore specialised: the dropout hash only for a job that has a mask, the row / column masks only for the tile
-    // that can be ragged.
-    const uint32_t dseed = j.dp.seed, dthr = j.dp.thresh, dkey = j.dp.key;
-    const float dscale = j.dp.scale;
-    const float* Gc = G + c;
-    const int ldg = j.ldg ? j.ldg : D;
-    const float* Ac = Ablk ? Ablk + c : j.Afull + (kin ? kt * 128 + c : 0);
-    const int astride = Ablk ? D : K;
-    const uint32_t dbase = (uint32_t)(kt * 128 + c);
-    auto load_g = [&](int rs, int q) -> float4 {
-        const int r = min(rs + rr0 + 16 * q, rend - 1);
-        return *reinterpret_cast<const float4*>(Gc + (size_t)r * ldg);
-    };
-    auto load_a = [&](int rs, int q) -> float4 {
-        const int r = min(rs + rr0 + 16 * q, rend - 1);
-        return *reinterpret_cast<const float4*>(Ac + (size_t)r * astride);
-    };
-    auto store_q = [&](auto drop_c, auto mask_c, int buf, int rs, int q, float4 gv, float4 av) {
-        float* Gs = smem + buf * 2 * TILE_M * LDP;
-        float* As = Gs + TILE_M * LDP;
-        const int r = rs + rr0 + 16 * q;
-        float ma = 1.f;
-        if (decltype(mask_c)::value) {
-            const float mg = r < rend ? 1.f : 0.f;
-            ma = (r < rend && kin) ? 1.f : 0.f;
-            gv.x *= mg; gv.y *= mg; gv.z *= mg; gv.w *= mg;
-        }
-        if (decltype(drop_c)::value) {
-            const uint32_t base = (uint32_t)r * (uint32_t)K + dbase;
-            ma *= dscale;
-            av.x *= drop_hash(base + 0u, dseed, dkey) >= dthr ? ma : 0.f;
-            av.y *= drop_hash(base + 1u, dseed, dkey) >= dthr ? ma : 0.f;
-            av.z *= drop_hash(base + 2u, dseed, dkey) >= dthr ? ma : 0.f;
-            av.w *= drop_hash(base + 3u, dseed, dkey) >= dthr ? ma : 0.f;
-        } else if (decltype(mask_c)::value) {
-            av.x *= ma; av.y *= ma; av.z *= ma; av.w *= ma;
-        }
-        bs.x += gv.x; bs.y += gv.y; bs.z += gv.z; bs.w += gv.w;
-        *reinterpret_cast<float4*>(&Gs[(rr0 + 16 * q) * LDP + c]) = gv;
-        *reinterpret_cast<float4*>(&As[(rr0 + 16 * q) * LDP + c]) = av;
-    };
-    using T_ = std::true_type;
-    using F_ = std::false_type;
-    const bool st = STAMPS_ON(g_dbg_on && blockIdx.x == 0 && threadIdx.x == 0);
-    if (st) g_stamps[0] = clock64();
-    // Pipeline: while tile i is multiplied out of LDS, tile i+1 (already in registers, requested one step earlier) is
-    // written to the other LDS buffer and tile i+2 is requested from memory, all between the MFMA batches.
-    TileRegs S0, S1;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) { S1.g[q] = load_g(rbeg, q); S1.a[q] = load_a(rbeg, q); }
-#pragma unroll
-    for (int q = 0; q < 2; ++q) { S0.g[q] = load_g(rbeg + TILE_M, q); S0.a[q] = load_a(rbeg + TILE_M, q); }
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        if (dropA) store_q(T_(), T_(), 0, rbeg, q, S1.g[q], S1.a[q]);
-        else store_q(F_(), T_(), 0, rbeg, q, S1.g[q], S1.a[q]);
-    }
-    __syncthreads();
-    if (st) g_stamps[1] = clock64();
-    auto step = [&](auto drop_c, auto mask_c, int rs, int buf, TileRegs& X, TileRegs& Y) {   // X holds tile rs+32,
-        const float* Gs = smem + buf * 2 * TILE_M * LDP;                                     // Y receives tile rs+64
-        const float* As = Gs + TILE_M * LDP;
-        // past the end of the chunk the loads re-read its last row and the stores write zeros nobody reads
-        gemm_tn_p<2, TILE_M>(Gs, LDP, 32 * nb, As, LDP, 64 * kh, acc, [&](int b) {
-            if (b == 0) Y.g[0] = load_g(rs + 2 * TILE_M, 0);
-            else if (b == 1) Y.a[0] = load_a(rs + 2 * TILE_M, 0);
-            else if (b == 2) Y.g[1] = load_g(rs + 2 * TILE_M, 1);
-            else Y.a[1] = load_a(rs + 2 * TILE_M, 1);
-            if ((b & 1) == 0) store_q(drop_c, mask_c, buf ^ 1, rs + TILE_M, b >> 1, X.g[b >> 1], X.a[b >> 1]);
-        });
-        __syncthreads();
-    };
-    auto run = [&](auto drop_c) {
-        for (int rs = rbeg; rs < rend; rs += 2 * TILE_M) {
-            // tile rs+32 (stored during this step) is complete iff rs + 64 <= rend and every column is inside K
-            if (rs + 2 * TILE_M <= rend && kin_all) step(drop_c, F_(), rs, 0, S0, S1); else step(drop_c, T_(), rs, 0, S0, S1);
-            if (rs + TILE_M < rend) {
-                if (rs + 3 * TILE_M <= rend && kin_all) step(drop_c, F_(), rs + TILE_M, 1, S1, S0);
-                else step(drop_c, T_(), rs + TILE_M, 1, S1, S0);
-            }
-        }
-    };
-    if (dropA) run(T_()); else run(F_());
-    if (st) g_stamps[2] = clock64();
-    const int N = 128 * j.nG;
-    float* out = j.out + ((size_t)ch * N + gb * 128) * K;
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int k = kt * 128 + 64 * kh + 32 * t + (lane & 31);
-        if (k < K) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int n = 32 * nb + acc_row(r, lane);
-                out[(size_t)n * K + k] = acc[t][r];
-            }
-        }
-    }
-    if (kt == 0 && j.out_bias[gb]) {                      // block-uniform; the tile buffers are free after the last barrier
-        float* red = smem;                               // [16][128]
-        *reinterpret_cast<float4*>(&red[rr0 * D + c]) = bs;
-        __syncthreads();
-        if (tid < D) {
-            float v = 0.f;
-#pragma unroll
-            for (int g = 0; g < 16; ++g) v += red[g * D + tid];
-            j.out_bias[gb][(size_t)ch * D + tid] = v;
-        }
-    }
-    if (st) g_stamps[3] = clock64();
-}
-void launch_wgrad(const WgradBatch& wb0, hipStream_t s) {
-    static const bool v2 = !(getenv("VSL_WGRAD2") && getenv("VSL_WGRAD2")[0] == '0');
-    if (v2) { launch_wgrad2(wb0, s); return; }
-    WgradBatch wb = wb0;
-    int total = 0;
-    for (int i = 0; i < wb.n; ++i) {
-        wb.start[i] = total;
-        total += wb.j[i].nG * ((wb.j[i].K + 127) / 128) * ((wb.j[i].R + WG_ROWS - 1) / WG_ROWS);
-    }
-    wb.start[wb.n] = total;
-    if (total == 0) return;
-    const size_t shm = (size_t)4 * TILE_M * LDP * sizeof(float);
-    static size_t lds_ok = 0;
-    ensure_dynamic_lds((const void*)k_wgrad, shm, lds_ok, "k_wgrad");
-    {
-        static size_t lds_sp = 0;
-        // one weight-gradient workgroup per CU: two of them on one CU halve each other's MFMA rate while other CUs idle
-        // (cycle stamps: 6.5k vs 13k cycles per 32-row step).  84 KiB still leaves room for a main-chain kernel beside it.
-        static const bool wg_excl = !(getenv("VSL_WGRAD_EXCL") && getenv("VSL_WGRAD_EXCL")[0] == '0');
-        const size_t shm_sp = wg_excl ? (shm > 84 * 1024 ? shm : (size_t)84 * 1024) : spread_lds(shm, 0, 0);
-        ensure_dynamic_lds((const void*)k_wgrad, shm_sp + 0, lds_sp, "k_wgrad");
-        VSL_LAUNCH(k_wgrad, dim3(total), dim3(512), shm_sp, s, wb);
-        static int left = 12;
-        if (dbg_budget("wgrad")) { char nm[96]; snprintf(nm, sizeof nm, "wgrad n=%d K=%d R=%d: prologue | 8-step loop | stores", wb.n, wb.j[0].K, wb.j[0].R); dbg_report(nm, 4, s, left); }
-    }
-}
-
-// =========================================================================================================
-// conv block backward (a7, :133-139), one kernel per layer with two stages:
-//  (1) conv_gemm_stage (common.hpp, fused behind the kernel that produces dy): dz = dy * dropmask * relu-bit (saved to gz
-//      for the weight gradient) ; du = dz Wp
-//  (2) k_conv_bwd_dwln : dv = depthwise^T(du) ; dx = dy + LN^T(dv) ; partials for gamma, beta and the depthwise taps
-// =========================================================================================================
-__global__ __launch_bounds__(256) void k_conv_bwd_dwln(const float* __restrict__ du, const float* __restrict__ xin,
-                                                       const float* __restrict__ dy, const float* __restrict__ ln_g,
-                                                       const float* __restrict__ ln_b, const float* __restrict__ dw_w,
-                                                       const float* __restrict__ extra, float* __restrict__ dx,
-                                                       float* __restrict__ p_lng, float* __restrict__ p_lnb,
-                                                       float* __restrict__ p_dw, int R, int L, ConvGemmArgs nxt) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int NH = TILE_M + 2 * HALO;
-    constexpr int NW = 16 + 2 * HALO;
-    float* DUs = smem;                       // [38][LDP] du with halo
-    float* Vs = DUs + NH * LDP;              // [38][LDP] LN(x') with halo (forward recompute)
-    float* Ts = Vs + NH * LDP;               // [32][LDP] dv = grad wrt LN output
-    float* Xc = Ts + TILE_M * LDP;           // [32][LDP] raw x' of the centre rows
-    float* red = Xc + TILE_M * LDP;          // [2][896]
-    const int tid = threadIdx.x;
-    const int r0 = blockIdx.x * TILE_M;
-    STAMP(0);
-    BFrag<1, 16> bf;                         // weights of the fused data-gradient GEMM of the layer below
-    ConvMaskWords mw;
-    LnResid lres;
-    {   // ONE batch of loads for both source tiles (du and x', rows r0-3 .. r0+34); the centre rows of x' are written to Xc
-        // from the same registers.  Three separate tile loads cost three memory latencies (7.6 k cycles).
-        float4 dv[5], xv[5];
-#pragma unroll
-        for (int q = 0; q < 5; ++q) {
-            const int e = tid + q * 256;
-            const int r = r0 - HALO + (e >> 5), c = (e & 31) * 4;
-            dv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            xv[q] = dv[q];
-            if (e < NH * 32 && r >= 0 && r < R) {
-                dv[q] = *reinterpret_cast<const float4*>(du + (size_t)r * D + c);
-                xv[q] = *reinterpret_cast<const float4*>(xin + (size_t)r * D + c);
-            }
-        }
-        ln_resid_prefetch(lres, dy, extra, r0, R);   // residual path of the LayerNorm backward: consumed last
-        if (nxt.relu_mask) {                 // requested behind the tiles (in-order return), consumed after this layer's work
-            conv_mask_prefetch(mw, nxt, r0, R);
-            bfrag_load(bf, nxt.WTpack, D, 32 * (tid >> 6), 0, 0, D / 8);
-        }
-#pragma unroll
-        for (int q = 0; q < 5; ++q) {
-            const int e = tid + q * 256;
-            const int rr = e >> 5, c = (e & 31) * 4;
-            if (e < NH * 32) {
-                *reinterpret_cast<float4*>(&DUs[rr * LDP + c]) = dv[q];
-                *reinterpret_cast<float4*>(&Vs[rr * LDP + c]) = xv[q];
-                if (rr >= HALO && rr < HALO + TILE_M) *reinterpret_cast<float4*>(&Xc[(rr - HALO) * LDP + c]) = xv[q];
-            }
-        }
-    }
-    __syncthreads();
-    STAMP(1);
-    ln_tile(Vs, NH, LDP, ln_g, ln_b, Drop{0u, 0u, 1.f}, 0);
-    __syncthreads();
-    STAMP(2);
-    {
-        const int c = tid & 127, hb = (tid >> 7) * 16;
-        float wk[DWK], gw[DWK], dwin[NW], vwin[NW];
-        int sid[NW];
-#pragma unroll
-        for (int k = 0; k < DWK; ++k) { wk[k] = dw_w[c * DWK + k]; gw[k] = 0.f; }
-        int rg = r0 - HALO + hb;
-        int sm = rg >= 0 ? rg / L : -1, tt = rg >= 0 ? rg - sm * L : L + rg;
-#pragma unroll
-        for (int i = 0; i < NW; ++i) {
-            dwin[i] = DUs[(hb + i) * LDP + c];
-            vwin[i] = Vs[(hb + i) * LDP + c];
-            sid[i] = (rg + i < R) ? sm : -2;
-            if (++tt == L) { tt = 0; ++sm; }
-        }
-        // forward: u[t] += w[k] v[t + k - 3]  =>  dv[t] += w[k] du[t - k + 3] ; dw[k] += du[t] v[t + k - 3]
-        // a block whose 22-row window lies inside one sample (wave-uniform; 6 of 8 blocks at T = 128) needs no boundary tests
-        const bool interior = rg >= 0 && sid[0] == sid[NW - 1] && sid[0] >= 0;
-        if (interior) {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                float dv = 0.f;
-#pragma unroll
-                for (int k = 0; k < DWK; ++k) {
-                    dv += wk[k] * dwin[q + 2 * HALO - k];
-                    gw[k] += dwin[q + HALO] * vwin[q + k];
-                }
-                Ts[(hb + q) * LDP + c] = dv;
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                float dv = 0.f;
-#pragma unroll
-                for (int k = 0; k < DWK; ++k) {
-                    dv += (sid[q + 2 * HALO - k] == sid[q + HALO]) ? wk[k] * dwin[q + 2 * HALO - k] : 0.f;
-                    gw[k] += (sid[q + k] == sid[q + HALO]) ? dwin[q + HALO] * vwin[q + k] : 0.f;
-                }
-                Ts[(hb + q) * LDP + c] = dv;
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < DWK; ++k) red[(tid >> 7) * 896 + c * DWK + k] = gw[k];
-    }
-    STAMP(3);
-    __syncthreads();
-    for (int e = tid; e < D * DWK; e += 256) p_dw[(size_t)blockIdx.x * D * DWK + e] = red[e] + red[896 + e];
-    STAMP(4);
-    ln_bwd_tile(Ts, Xc, lres, ln_g, dx, p_lng, p_lnb, r0, R, nxt.relu_mask ? DUs : nullptr);
-    STAMP(5);
-    if (nxt.relu_mask) conv_gemm_stage(DUs, nxt, bf, mw, r0, R);   // dx of this layer == dy of the layer below
-    STAMP(6);
-}
-void launch_conv_bwd_dwln(const float* du, const float* xin, const float* dy, const float* ln_g, const float* ln_b,
-                          const float* dw_w, const float* extra, float* dx, float* p_lng, float* p_lnb, float* p_dw,
-                          int R, int L, const ConvGemmArgs& nxt, hipStream_t s) {
-    const size_t shm = (size_t)((2 * (TILE_M + 2 * HALO) + 2 * TILE_M) * LDP + 1792) * sizeof(float);
-    static size_t lds_ok = 0;
-    ensure_dynamic_lds((const void*)k_conv_bwd_dwln, shm, lds_ok, "k_conv_bwd_dwln");
-    VSL_LAUNCH(k_conv_bwd_dwln, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm, s, du, xin, dy, ln_g, ln_b, dw_w, extra,
-                       dx, p_lng, p_lnb, p_dw, R, L, nxt);
-    static int left = 6;
-    if (dbg_budget("conv_bwd_dwln") && R > 4096) dbg_report("conv_bwd_dwln: loads | LN | depthwise bwd | sync | p_dw store | ln_bwd | fused gemm stage", 7, s, left);
-}
+// Weight gradients: kernels_wgrad.hip (k_wgrad3 on the bf16 matrix cores; k_wgrad2, the fp32-input MFMA kernel of round 2, with VSL_WGRAD_F32=1)
+void launch_wgrad(const WgradBatch& wb, hipStream_t s) { launch_wgrad2(wb, s); }
 
 // =========================================================================================================
 // MHA block backward (a8, :167-190)
@@ -1094,8 +800,7 @@ __global__ __launch_bounds__(256) void k_qkv_bwd(const float* __restrict__ dQ, c
                                                  const float* __restrict__ dV, const float* __restrict__ x,
                                                  const float* __restrict__ dr, const float* __restrict__ ln_g,
                                                  const float* __restrict__ WTpack, float* __restrict__ dx,
-                                                 float* __restrict__ p_lng, float* __restrict__ p_lnb, int R, Drop d1,
-                                                 ConvGemmArgs nxt) {
+                                                 float* __restrict__ p_lng, float* __restrict__ p_lnb, int R, Drop d1) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                         // [32][QKVP] = [dQ | dK | dV]
     float* Ts = As + TILE_M * QKVP;           // [32][LDP]
@@ -1141,20 +846,15 @@ __global__ __launch_bounds__(256) void k_qkv_bwd(const float* __restrict__ dQ, c
         Ts[row * LDP + col] = acc[0][r] * drop_mul(d1, (uint32_t)((r0 + row) * D + col));
     }
     __syncthreads();
-    BFrag<1, 16> bf2;                          // fused data-gradient GEMM of the last conv layer
-    ConvMaskWords mw2;
-    if (nxt.relu_mask) { conv_mask_prefetch(mw2, nxt, r0, R); bfrag_load(bf2, nxt.WTpack, D, 32 * w, 0, 0, D / 8); }
-    ln_bwd_tile(Ts, Xs, lres, ln_g, dx, p_lng, p_lnb, r0, R, nxt.relu_mask ? As : nullptr);
-    if (nxt.relu_mask) conv_gemm_stage(As, nxt, bf2, mw2, r0, R);
+    ln_bwd_tile(Ts, Xs, lres, ln_g, dx, p_lng, p_lnb, r0, R);
 }
 void launch_qkv_bwd(const float* dQ, const float* dK, const float* dV, const float* x, const float* dr,
-                    const float* ln_g, const float* WTpack, float* dx, float* p_lng, float* p_lnb, int R, Drop d1,
-                    const ConvGemmArgs& nxt, hipStream_t s) {
+                    const float* ln_g, const float* WTpack, float* dx, float* p_lng, float* p_lnb, int R, Drop d1, hipStream_t s) {
     const size_t shm = (size_t)(TILE_M * QKVP + 2 * TILE_M * LDP) * sizeof(float);
     static size_t lds_ok = 0;
     ensure_dynamic_lds((const void*)k_qkv_bwd, shm, lds_ok, "k_qkv_bwd");
     VSL_LAUNCH(k_qkv_bwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm, s, dQ, dK, dV, x, dr, ln_g, WTpack, dx, p_lng,
-                       p_lnb, R, d1, nxt);
+                       p_lnb, R, d1);
 }
 
 // =========================================================================================================
@@ -2152,103 +1852,10 @@ void launch_reduce(const float* partial, float* grads, const ReduceSeg* segs_dev
     VSL_LAUNCH(k_reduce, dim3(nblocks), dim3(256), 0, s, partial, grads, segs_dev, blk2seg_dev);
 }
 
-// =========================================================================================================
-// a15 backward: BPTT through the LSTM of k_lstm_fwd.  Same ownership (wave = 8 hidden units, lane pair = 2 samples each);
-// per step: gate gradients of the own cells -> LDS (16 x 512) and global (the G operand of dW_ih / dW_hh / db and the A
-// operand of dX = dG W_ih, all plain GEMMs afterwards) -> dh_{t-1} = dG_t W_hh on the matrix cores with W_hh in registers
-// (wave = 16 output columns x one half of the 512 gate rows; the two halves are added when read).  Two barriers per step.
-// =========================================================================================================
-constexpr int LS_M = 16;
-constexpr int LS_HP = D + 4;
-constexpr int LS_GP = 4 * D + 4;
-__global__ __launch_bounds__(1024) void k_lstm_bwd(const float* __restrict__ dout, const float* __restrict__ dout2,
-                                                   const float* __restrict__ mask, const float* __restrict__ gates,
-                                                   const float* __restrict__ cseq, const float* __restrict__ Whh,
-                                                   float* __restrict__ dG, int B, int T, float* __restrict__ carry, int t0,
-                                                   int t1) {
-    __shared__ __attribute__((aligned(16))) float dGs[LS_M * LS_GP];
-    __shared__ __attribute__((aligned(16))) float Ph[2][LS_M * LS_HP];
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const int j = lane & 15, g4 = lane >> 4, hi = j >> 3;
-    const int u = 8 * w + (j & 7);
-    const int b0 = blockIdx.x * LS_M;
-    const int s0 = 4 * g4 + 2 * hi;
-    const int n0 = 16 * (w & 7), kh = w >> 3;            // matmul role: output columns n0 .. n0+15, gate rows 256 kh .. +255
-    float4 wr[16];                                       // B fragments: Bm[k = gate row][col] = W_hh[row][n0 + j]
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const float* p = Whh + (size_t)(256 * kh + 16 * q + 4 * g4) * D + n0 + j;
-        wr[q] = make_float4(p[0], p[D], p[2 * D], p[3 * D]);
-    }
-    // a launch covers the steps [t0, t1) in reverse; a later time chunk hands dc_{t1} and dh_{t1 - 1} over through `carry`
-    float dcn[2] = {0.f, 0.f};
-    if (t1 < T) {
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int b = min(b0 + s0 + e, B - 1);
-            dcn[e] = carry[((size_t)b * 2 + 0) * D + u];
-            Ph[0][(s0 + e) * LS_HP + u] = carry[((size_t)b * 2 + 1) * D + u];
-            Ph[1][(s0 + e) * LS_HP + u] = 0.f;
-        }
-    }
-    for (int t = t1 - 1; t >= t0; --t) {
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int b = min(b0 + s0 + e, B - 1);
-            const bool ok = b0 + s0 + e < B;
-            const size_t base = (size_t)b * T + t;
-            float dh = dout[base * D + u];
-            if (dout2) dh += dout2[base * D + u];
-            dh *= mask[base];
-            if (t < T - 1) dh += Ph[0][(s0 + e) * LS_HP + u] + Ph[1][(s0 + e) * LS_HP + u];
-            const float* gp = gates + base * (4 * D) + u;
-            const float ig = gp[0], fg = gp[D], gg = gp[2 * D], og = gp[3 * D];
-            const float ct = cseq[base * D + u], cp = t > 0 ? cseq[(base - 1) * D + u] : 0.f;
-            const float tc = tanh_fast(ct);
-            const float dc = dh * og * (1.f - tc * tc) + dcn[e];
-            float dv[4] = {dc * gg * ig * (1.f - ig), dc * cp * fg * (1.f - fg), dc * ig * (1.f - gg * gg), dh * tc * og * (1.f - og)};
-            dcn[e] = dc * fg;
-            if (!ok) { dv[0] = dv[1] = dv[2] = dv[3] = 0.f; }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) dGs[(s0 + e) * LS_GP + g * D + u] = dv[g];
-            if (ok) {
-                float* op = dG + base * (4 * D) + u;
-                op[0] = dv[0]; op[D] = dv[1]; op[2 * D] = dv[2]; op[3 * D] = dv[3];
-            }
-        }
-        if (t == 0) break;                               // dh_{-1} is not needed
-        __syncthreads();
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        const float* arow = dGs + j * LS_GP + 256 * kh + 4 * g4;          // A operand: sample = lane & 15
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const float4 av = *reinterpret_cast<const float4*>(arow + 16 * q);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, wr[q].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, wr[q].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, wr[q].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, wr[q].w, acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Ph[kh][(4 * g4 + r) * LS_HP + n0 + j] = acc[r];
-        __syncthreads();
-    }
-    if (t0 > 0) {
-#pragma unroll
-        for (int e = 0; e < 2; ++e)
-            if (b0 + s0 + e < B) {
-                const int b = b0 + s0 + e;
-                carry[((size_t)b * 2 + 0) * D + u] = dcn[e];
-                carry[((size_t)b * 2 + 1) * D + u] = Ph[0][(s0 + e) * LS_HP + u] + Ph[1][(s0 + e) * LS_HP + u];
-            }
-    }
-}
 void launch_lstm_bwd(const float* dout, const float* dout2, const float* mask, const float* gates, const float* cseq,
                      const float* Whh, float* dG, int B, int T, hipStream_t s, float* carry, int t0, int t1) {
     if (t1 < 0) t1 = T;
-    static const bool four = !(getenv("VSL_LSTM4") && getenv("VSL_LSTM4")[0] == '0');
-    if (four) { launch_lstm4_bwd(dout, dout2, mask, gates, cseq, Whh, dG, B, T, s, carry, t0, t1); return; }
-    VSL_LAUNCH(k_lstm_bwd, dim3((B + LS_M - 1) / LS_M), dim3(1024), 0, s, dout, dout2, mask, gates, cseq, Whh, dG, B, T, carry,
-                       t0, t1);
+    launch_lstm4_bwd(dout, dout2, mask, gates, cseq, Whh, dG, B, T, s, carry, t0, t1);
 }
 
 // =========================================================================================================

@@ -484,242 +484,6 @@ void launch_linear_fwd(const float* A, const float* Wpack, const float* bias, fl
 }
 
 // =========================================================================================================
-// a6/a7  one DepthwiseSeparableConvBlock layer (:131-140), fused:
-//   x' = x (+ pos[t])  ->  v = LN(x')  ->  u = depthwise7(v) (zero outside the sample, padded rows NOT masked)
-//   -> z = u Wp^T + b  ->  y = x' + drop(relu(z)).      Saves the relu bit-mask (R x 4 uint32) for the backward.
-// Tile = 32 rows + 3 halo rows each side (LayerNorm of the halo rows is recomputed).
-// =========================================================================================================
-template <bool QKV>
-__global__ __launch_bounds__(256) void k_conv_layer_fwd(const float* __restrict__ xin, const float* __restrict__ pos,
-                                                        float* __restrict__ x0_out, const float* __restrict__ ln_g,
-                                                        const float* __restrict__ ln_b, const float* __restrict__ dw_w,
-                                                        const float* __restrict__ Wpack, const float* __restrict__ pw_b,
-                                                        float* __restrict__ y_out, float* __restrict__ u_out,
-                                                        uint32_t* __restrict__ relu_mask, int R, int L, Drop dp, QkvFuse qf) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int NH = TILE_M + 2 * HALO;               // 38 rows
-    float* Xs = smem;                                   // [38][LDP] raw x' (residual source)
-    float* Vs = Xs + NH * LDP;                          // [38][LDP] LN(x')
-    float* Us = Vs + NH * LDP;                          // [32][LDP] depthwise output = GEMM A operand
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const int r0 = blockIdx.x * TILE_M;
-    BFrag<1, 16> bf;                                    // the whole 128 x 32 weight slice of this wave
-    FSTAMP(0);
-    // ---- load rows r0-3 .. r0+34 (+ positional rows, :202): all loads first, then the stores
-    {
-        float4 xv[5], pv[5];
-#pragma unroll
-        for (int q = 0; q < 5; ++q) {
-            const int e = tid + q * 256;
-            const int rr = e >> 5, c = (e & 31) * 4;
-            const int r = r0 - HALO + rr;
-            xv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            pv[q] = xv[q];
-            if (e < NH * 32 && r >= 0 && r < R) {
-                xv[q] = *reinterpret_cast<const float4*>(xin + (size_t)r * D + c);
-                if (pos) pv[q] = *reinterpret_cast<const float4*>(pos + (size_t)(r % L) * D + c);
-            }
-        }
-        // requested AFTER the tile (vector loads return in order): streams in behind the LayerNorm / depthwise prologue
-        bfrag_load(bf, Wpack, D, 32 * w, 0, 0, D / 8);
-#pragma unroll
-        for (int q = 0; q < 5; ++q) {
-            const int e = tid + q * 256;
-            const int rr = e >> 5, c = (e & 31) * 4;
-            const int r = r0 - HALO + rr;
-            if (e < NH * 32) {
-                const float4 v = make_float4(xv[q].x + pv[q].x, xv[q].y + pv[q].y, xv[q].z + pv[q].z, xv[q].w + pv[q].w);
-                if (x0_out && r >= 0 && r < R && rr >= HALO && rr < HALO + TILE_M) *reinterpret_cast<float4*>(x0_out + (size_t)r * D + c) = v;
-                *reinterpret_cast<float4*>(&Xs[rr * LDP + c]) = v;
-                *reinterpret_cast<float4*>(&Vs[rr * LDP + c]) = v;
-            }
-        }
-    }
-    FSTAMP(1);
-    __syncthreads();
-    FSTAMP(2);
-    // ---- LayerNorm of all 38 rows
-    ln_tile(Vs, NH, LDP, ln_g, ln_b, Drop{0u, 0u, 1.f}, 0);
-    __syncthreads();
-    FSTAMP(3);
-    // ---- depthwise conv k=7 along the sequence: thread = (channel c, 16 rows); the 22-row window sits in registers
-    {
-        const int c = tid & 127, hb = (tid >> 7) * 16;
-        float wk[DWK], win[16 + 2 * HALO];
-        int sid[16 + 2 * HALO];                         // sample index of every window row (neighbours must share it)
-#pragma unroll
-        for (int k = 0; k < DWK; ++k) wk[k] = dw_w[c * DWK + k];
-        int rg = r0 - HALO + hb;                        // global row of window entry 0
-        int sm = rg >= 0 ? rg / L : -1, tt = rg >= 0 ? rg - sm * L : L + rg;
-#pragma unroll
-        for (int i = 0; i < 16 + 2 * HALO; ++i) {
-            win[i] = Vs[(hb + i) * LDP + c];
-            sid[i] = (rg + i < R) ? sm : -2;
-            if (++tt == L) { tt = 0; ++sm; }
-        }
-        // a block whose 22-row window lies inside one sample (wave-uniform; 6 of 8 blocks at T = 128) needs no boundary tests
-        const bool interior = rg >= 0 && sid[0] == sid[16 + 2 * HALO - 1] && sid[0] >= 0;
-        if (interior) {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                float u = 0.f;
-#pragma unroll
-                for (int k = 0; k < DWK; ++k) u += wk[k] * win[q + k];
-                Us[(hb + q) * LDP + c] = u;
-                if (u_out) u_out[(size_t)(r0 + hb + q) * D + c] = u;                 // saved: A operand of the weight gradient
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                float u = 0.f;
-#pragma unroll
-                for (int k = 0; k < DWK; ++k) u += (sid[q + k] == sid[q + HALO]) ? wk[k] * win[q + k] : 0.f;
-                Us[(hb + q) * LDP + c] = u;
-                if (u_out && r0 + hb + q < R) u_out[(size_t)(r0 + hb + q) * D + c] = u;
-            }
-        }
-    }
-    FSTAMP(4);
-    __syncthreads();
-    FSTAMP(5);
-    // ---- pointwise GEMM + bias + ReLU (+ dropout) + residual
-    f32x16 acc[1];
-    zero_acc(acc);
-    gemm32p<1, 16>(Us, LDP, D, Wpack, D, 32 * w, 0, acc, bf);
-    FSTAMP(6);
-    BFrag<3, 4> bq3;                                     // first stage of the fused QKV weights: in flight during the epilogue
-    if (QKV) bfrag_load(bq3, qf.Wpack, 3 * D, 32 * w, D, 0, D / 8);
-    const int col = 32 * w + (lane & 31);
-    const float bv = pw_b[col];
-    // Epilogue without divergent control flow (per-element bounds / "dropout on?" tests compiled to ~80 branches and a full
-    // LDS wait per element: 7.2 k of the kernel's 24 k cycles).  Full tile and dropout on/off are block-uniform cases; the
-    // 32 ReLU bit-mask words of the wave are selected into lanes 0..31 and leave in ONE store.
-    const int myrow = lane & 31;                                     // lane < 32 stores the mask word of tile row `myrow`
-    const int myr = (myrow & 3) + 4 * (myrow >> 3), myhalf = (myrow >> 2) & 1;
-    uint32_t myword = 0u;
-    auto epilogue = [&](auto full_c, auto drop_c) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = acc_row(r, lane);
-            const int gr = r0 + row;
-            const float z = acc[0][r] + bv;
-            const unsigned long long bal = __ballot(z > 0.f);
-            const uint32_t half = myhalf ? (uint32_t)(bal >> 32) : (uint32_t)bal;
-            myword = (r == myr) ? half : myword;
-            float a = fmaxf(z, 0.f);
-            if (decltype(drop_c)::value) a *= drop_keep_scale(dp, (uint32_t)(gr * D + col));
-            const float y = Xs[(row + HALO) * LDP + col] + a;
-            if (decltype(full_c)::value || gr < R) y_out[(size_t)gr * D + col] = y;
-            if (QKV) Vs[row * LDP + col] = (decltype(full_c)::value || gr < R) ? y : 0.f;   // LN(x') rows are dead by now
-        }
-    };
-    const bool full = r0 + TILE_M <= R;
-    if (full) { if (dp.thresh) epilogue(std::true_type(), std::true_type()); else epilogue(std::true_type(), std::false_type()); }
-    else      { if (dp.thresh) epilogue(std::false_type(), std::true_type()); else epilogue(std::false_type(), std::false_type()); }
-    if (lane < 32 && r0 + myrow < R) relu_mask[(size_t)(r0 + myrow) * 4 + w] = myword;
-    FSTAMP(7);
-    if (QKV) {
-        // ---- a8, first half (:168-173) on the tile just produced: h1 = drop(LN1(y)) ; [q | k | v] = h1 W^T + b  (N = 384)
-        __syncthreads();
-        ln_tile(Vs, TILE_M, LDP, qf.ln_g, qf.ln_b, qf.d1, r0);
-        __syncthreads();
-        if (qf.h1)
-            for (int e = tid; e < TILE_M * 32; e += 256) {
-                const int rr = e >> 5, c = (e & 31) * 4;
-                if (r0 + rr < R) *reinterpret_cast<float4*>(qf.h1 + (size_t)(r0 + rr) * D + c) = *reinterpret_cast<const float4*>(&Vs[rr * LDP + c]);
-            }
-        f32x16 a3[3];
-        zero_acc(a3);
-        gemm32p<3, 4>(Vs, LDP, D, qf.Wpack, 3 * D, 32 * w, D, a3, bq3);
-        const float b0 = qf.bq[col], b1 = qf.bk[col], b2 = qf.bv[col];
-        if (full) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const size_t o = (size_t)(r0 + acc_row(r, lane)) * D + col;
-                qf.q[o] = a3[0][r] + b0; qf.k[o] = a3[1][r] + b1; qf.v[o] = a3[2][r] + b2;
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int gr = r0 + acc_row(r, lane);
-                if (gr < R) {
-                    const size_t o = (size_t)gr * D + col;
-                    qf.q[o] = a3[0][r] + b0; qf.k[o] = a3[1][r] + b1; qf.v[o] = a3[2][r] + b2;
-                }
-            }
-        }
-    }
-}
-void launch_conv_layer_fwd(const float* xin, const float* pos, float* x0_out, const float* ln_g, const float* ln_b,
-                           const float* dw_w, const float* Wpack, const float* pw_b, float* y_out, float* u_out,
-                           uint32_t* relu_mask, int R, int L, Drop dp, const QkvFuse& qkv, hipStream_t s) {
-    const size_t shm = (size_t)(2 * (TILE_M + 2 * HALO) + TILE_M) * LDP * sizeof(float);
-    static size_t ok0 = 0, ok1 = 0;
-    const dim3 grid((R + TILE_M - 1) / TILE_M);
-    if (qkv.ln_g) {
-        ensure_dynamic_lds((const void*)k_conv_layer_fwd<true>, shm, ok1, "k_conv_layer_fwd<qkv>");
-        VSL_LAUNCH(k_conv_layer_fwd<true>, grid, dim3(256), shm, s, xin, pos, x0_out, ln_g, ln_b, dw_w, Wpack, pw_b, y_out, u_out,
-                           relu_mask, R, L, dp, qkv);
-    } else {
-        ensure_dynamic_lds((const void*)k_conv_layer_fwd<false>, shm, ok0, "k_conv_layer_fwd");
-        VSL_LAUNCH(k_conv_layer_fwd<false>, grid, dim3(256), shm, s, xin, pos, x0_out, ln_g, ln_b, dw_w, Wpack, pw_b, y_out, u_out,
-                           relu_mask, R, L, dp, qkv);
-    }
-    static int left = 6;
-    if (fdbg_on() && R > 4096) fdbg_report("conv_layer_fwd: loads issued+stored | sync | LN | depthwise | sync | gemm | epilogue", 8, s, left);
-}
-
-// =========================================================================================================
-// a8 (first half)  h1 = drop(LN1(x));  Q,K,V = h1 W{q,k,v}^T + b   (:168-173).  One GEMM with N = 384.
-// =========================================================================================================
-__global__ __launch_bounds__(256) void k_ln_qkv_fwd(const float* __restrict__ x, const float* __restrict__ ln_g,
-                                                    const float* __restrict__ ln_b, const float* __restrict__ Wpack,
-                                                    const float* __restrict__ bq, const float* __restrict__ bk,
-                                                    const float* __restrict__ bv, float* __restrict__ h1,
-                                                    float* __restrict__ q, float* __restrict__ k, float* __restrict__ v,
-                                                    int R, Drop d1) {
-    __shared__ __attribute__((aligned(16))) float Hs[TILE_M * LDP];
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const int r0 = blockIdx.x * TILE_M;
-    BFrag<3, 4> bf;
-    load_tile128(Hs, x, r0, TILE_M, R);
-    bfrag_load(bf, Wpack, 3 * D, 32 * w, D, 0, D / 8);
-    __syncthreads();
-    ln_tile(Hs, TILE_M, LDP, ln_g, ln_b, d1, r0);
-    __syncthreads();
-    if (h1)
-        for (int e = tid; e < TILE_M * 32; e += 256) {
-            const int rr = e >> 5, c = (e & 31) * 4;
-            if (r0 + rr < R) *reinterpret_cast<float4*>(h1 + (size_t)(r0 + rr) * D + c) = *reinterpret_cast<const float4*>(&Hs[rr * LDP + c]);
-        }
-    f32x16 acc[3];
-    zero_acc(acc);
-    gemm32p<3, 4>(Hs, LDP, D, Wpack, 3 * D, 32 * w, D, acc, bf);
-    const int col = 32 * w + (lane & 31);
-    const float b0 = bq[col], b1 = bk[col], b2 = bv[col];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int gr = r0 + acc_row(r, lane);
-        if (gr < R) {
-            q[(size_t)gr * D + col] = acc[0][r] + b0;
-            k[(size_t)gr * D + col] = acc[1][r] + b1;
-            v[(size_t)gr * D + col] = acc[2][r] + b2;
-        }
-    }
-}
-void launch_ln_qkv_fwd(const float* x, const float* ln_g, const float* ln_b, const float* Wpack, const float* bq,
-                       const float* bk, const float* bv, float* h1, float* q, float* k, float* v, int R, Drop d1,
-                       hipStream_t s) {
-    {
-        static size_t lds_sp = 0;
-        const size_t shm_sp = spread_lds(0, 16896, (R + TILE_M - 1) / TILE_M);
-        ensure_dynamic_lds((const void*)k_ln_qkv_fwd, shm_sp + 16896, lds_sp, "k_ln_qkv_fwd");
-        VSL_LAUNCH(k_ln_qkv_fwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm_sp, s, x, ln_g, ln_b, Wpack, bq, bk, bv, h1, q,
-                       k, v, R, d1);
-    }
-}
-
-// =========================================================================================================
 // a8 (attention core)  S = Q K^T / sqrt(hd) + (1 - mask[key]) * -1e30 ; P = softmax ; O = drop(P) V   (:174-182)
 //   head size 16, fp32 MFMA 16x16x4.  Workgroup = (64 queries, head, sample); wave = 16 queries.
 //   K/V head slices live in LDS; scores are computed transposed (S^T = K Q^T) so every lane owns one query column:
@@ -1481,133 +1245,11 @@ void launch_head_fwd(const HeadArgs& a0, const HeadArgs& a1, const float* x, con
     }
 }
 
-// =========================================================================================================
-// a15  DynamicRNN (layers_t7.py:302-313): single-layer nn.LSTM(128, 128), gate order i,f,g,o, run over ALL padded steps;
-// the returned sequence is h * mask.  gi = x W_ih^T is computed beforehand as one (B T, 128) x (128, 512) GEMM; this kernel
-// is the sequential part.  One 16-wave workgroup per 16 samples:
-//   * W_hh (256 KB) lives in REGISTERS for the whole sequence: wave w owns hidden units 8w .. 8w+7 and holds the 32
-//     gate rows of those units as MFMA B fragments (two 16-column tiles: [i | f] and [g | o]);
-//   * h_{t-1} (16 x 128) is the A operand, read from a double-buffered LDS tile -> one barrier per step;
-//   * a lane's accumulators hold one gate column for 4 samples; the lane pair (l, l ^ 8) swaps two samples' worth so that
-//     every lane finishes 2 (unit, sample) cells with all four gates: the cell state stays in registers;
-//   * the gi values are requested two steps ahead (they do not depend on the recurrence).
-// Saved for the backward: activated gates (B,T,512), c_t, h_{t-1} (the A operand of dW_hh), and the masked output.
-// =========================================================================================================
-constexpr int LS_M = 16;
-constexpr int LS_HP = D + 4;
-__global__ __launch_bounds__(1024) void k_lstm_fwd(const float* __restrict__ gi, const float* __restrict__ Whh,
-                                                   const float* __restrict__ bih, const float* __restrict__ bhh,
-                                                   const float* __restrict__ mask, float* __restrict__ gates,
-                                                   float* __restrict__ cseq, float* __restrict__ hprev, float* __restrict__ out,
-                                                   int B, int T, int t0, int t1) {
-    __shared__ __attribute__((aligned(16))) float hs[2][LS_M * LS_HP];
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const int j = lane & 15, g4 = lane >> 4, hi = j >> 3;
-    const int u = 8 * w + (j & 7);                       // hidden unit of this lane's gate columns
-    const int b0 = blockIdx.x * LS_M;
-    float4 wa[8], wb[8];                                 // B fragments: tile A column = (hi ? f : i), tile B = (hi ? o : g)
-    {
-        const float* ra = Whh + (size_t)((hi ? 1 : 0) * D + u) * D + 4 * g4;
-        const float* rb = Whh + (size_t)((hi ? 3 : 2) * D + u) * D + 4 * g4;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) { wa[q] = *reinterpret_cast<const float4*>(ra + 16 * q); wb[q] = *reinterpret_cast<const float4*>(rb + 16 * q); }
-    }
-    float bsum[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) bsum[g] = bih[g * D + u] + bhh[g * D + u];
-    const int s0 = 4 * g4 + 2 * hi;                      // this lane finishes samples s0, s0 + 1 of the group
-    float cst[2] = {0.f, 0.f};                           // c_{t0 - 1}: zero, or what the previous time chunk left in cseq
-    // 32-bit element offsets (the host checks B T 512 < 2^31) keep the address state of the loop in a handful of registers:
-    // with W_hh resident the kernel sits at the 128-register limit of a 1024-thread workgroup
-    int row[2];
-    bool okb[2];
-#pragma unroll
-    for (int e = 0; e < 2; ++e) { okb[e] = b0 + s0 + e < B; row[e] = min(b0 + s0 + e, B - 1) * T; }
-    float Gc[2][4], Mk[2];                               // gi and mask of the next step: requested right after the current one is used
-    auto gi_load = [&](int t) {
-        const int tt = min(t, T - 1);
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const float* p = gi + (unsigned)((row[e] + tt) * (4 * D) + u);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) Gc[e][g] = p[g * D];
-            Mk[e] = mask[row[e] + tt];
-        }
-    };
-    // a launch covers the steps [t0, t1): the state it starts from is what the previous chunk saved for the backward anyway
-    // (hprev[t0] = h_{t0 - 1}, cseq[t0 - 1]), so the sequence can be cut into chunks that pipeline with the next LSTM
-    for (int i = tid; i < LS_M * D; i += 1024) {
-        const int sm = i >> 7, uu = i & 127;
-        hs[t0 & 1][sm * LS_HP + uu] = t0 > 0 ? hprev[(unsigned)((min(b0 + sm, B - 1) * T + t0) * D + uu)] : 0.f;
-    }
-    if (t0 > 0) {
-#pragma unroll
-        for (int e = 0; e < 2; ++e) cst[e] = cseq[(unsigned)((row[e] + t0 - 1) * D + u)];
-    }
-    gi_load(t0);
-    __syncthreads();
-    for (int t = t0; t < t1; ++t) {
-        const int cur = t & 1;
-        if (t == t0 + 6) FSTAMP(0);
-        f32x4 aa = {0.f, 0.f, 0.f, 0.f}, ab = {0.f, 0.f, 0.f, 0.f};
-        if (t > 0) {
-            const float* hrow = &hs[cur][j * LS_HP + 4 * g4];            // A operand: sample = lane & 15
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const float4 hv = *reinterpret_cast<const float4*>(hrow + 16 * q);
-                aa = __builtin_amdgcn_mfma_f32_16x16x4f32(hv.x, wa[q].x, aa, 0, 0, 0);
-                ab = __builtin_amdgcn_mfma_f32_16x16x4f32(hv.x, wb[q].x, ab, 0, 0, 0);
-                aa = __builtin_amdgcn_mfma_f32_16x16x4f32(hv.y, wa[q].y, aa, 0, 0, 0);
-                ab = __builtin_amdgcn_mfma_f32_16x16x4f32(hv.y, wb[q].y, ab, 0, 0, 0);
-                aa = __builtin_amdgcn_mfma_f32_16x16x4f32(hv.z, wa[q].z, aa, 0, 0, 0);
-                ab = __builtin_amdgcn_mfma_f32_16x16x4f32(hv.z, wb[q].z, ab, 0, 0, 0);
-                aa = __builtin_amdgcn_mfma_f32_16x16x4f32(hv.w, wa[q].w, aa, 0, 0, 0);
-                ab = __builtin_amdgcn_mfma_f32_16x16x4f32(hv.w, wb[q].w, ab, 0, 0, 0);
-            }
-        }
-        if (t == t0 + 6) FSTAMP(1);
-        // aa[r] / ab[r]: this lane's two gate columns for samples 4 g4 + r.  Keep r = 2 hi, 2 hi + 1; trade the other two.
-        const float ka0 = hi ? aa[2] : aa[0], ka1 = hi ? aa[3] : aa[1], kb0 = hi ? ab[2] : ab[0], kb1 = hi ? ab[3] : ab[1];
-        const float ra0 = __shfl_xor(hi ? aa[0] : aa[2], 8), ra1 = __shfl_xor(hi ? aa[1] : aa[3], 8);
-        const float rb0 = __shfl_xor(hi ? ab[0] : ab[2], 8), rb1 = __shfl_xor(hi ? ab[1] : ab[3], 8);
-        const float zi[2] = {hi ? ra0 : ka0, hi ? ra1 : ka1}, zf[2] = {hi ? ka0 : ra0, hi ? ka1 : ra1};
-        const float zg[2] = {hi ? rb0 : kb0, hi ? rb1 : kb1}, zo[2] = {hi ? kb0 : rb0, hi ? kb1 : rb1};
-        if (t == t0 + 6) FSTAMP(2);
-        float hn[2];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const float ig = sigmoid_fast(zi[e] + Gc[e][0] + bsum[0]), fg = sigmoid_fast(zf[e] + Gc[e][1] + bsum[1]);
-            const float gg = tanh_fast(zg[e] + Gc[e][2] + bsum[2]), og = sigmoid_fast(zo[e] + Gc[e][3] + bsum[3]);
-            const float cn = fg * cst[e] + ig * gg;
-            hn[e] = og * tanh_fast(cn);
-            cst[e] = cn;
-            hs[cur ^ 1][(s0 + e) * LS_HP + u] = hn[e];
-            if (okb[e]) {
-                const unsigned base = (unsigned)(row[e] + t);
-                float* gp = gates + base * (4 * D) + u;
-                gp[0] = ig; gp[D] = fg; gp[2 * D] = gg; gp[3 * D] = og;
-                cseq[base * D + u] = cn;
-                out[base * D + u] = hn[e] * Mk[e];
-                if (t == 0) hprev[base * D + u] = 0.f;
-                if (t + 1 < T) hprev[(base + 1) * D + u] = hn[e];
-            }
-        }
-        if (t == t0 + 6) FSTAMP(3);
-        gi_load(t + 1);
-        if (t == t0 + 6) FSTAMP(4);
-        __syncthreads();
-        if (t == t0 + 6) FSTAMP(5);
-    }
-}
+// a15 DynamicRNN: the recurrence lives in kernels_lstm.hip (one-sample workgroups up to B = 256, 4-sample MFMA groups beyond)
 void launch_lstm_fwd(const float* gi, const float* Whh, const float* bih, const float* bhh, const float* mask, float* gates,
                      float* cseq, float* hprev, float* out, int B, int T, hipStream_t s, int t0, int t1) {
     if (t1 < 0) t1 = T;
-    static const bool four = !(getenv("VSL_LSTM4") && getenv("VSL_LSTM4")[0] == '0');
-    if (four) { launch_lstm4_fwd(gi, Whh, bih, bhh, mask, gates, cseq, hprev, out, B, T, s, t0, t1); return; }
-    VSL_LAUNCH(k_lstm_fwd, dim3((B + LS_M - 1) / LS_M), dim3(1024), 0, s, gi, Whh, bih, bhh, mask, gates, cseq, hprev, out, B, T,
-                       t0, t1);
-    static int left = 2;
-    if (fdbg_on() && T > 8) fdbg_report("lstm_fwd step 6: LDS+MFMA | shuffles | gates+stores | gi issue | barrier", 6, s, left);
+    launch_lstm4_fwd(gi, Whh, bih, bhh, mask, gates, cseq, hprev, out, B, T, s, t0, t1);
 }
 
 }  // namespace vsl

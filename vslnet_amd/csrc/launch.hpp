@@ -142,16 +142,12 @@ void launch_embed_fwd(const int64_t* word_ids, const int64_t* char_ids, const fl
                       const float* glove, const float* char_tab, CharConvPtrs cc, const float* wimg, float* E, int8_t* argpos,
                       int Rq, int Lc, int word_dim, int char_dim, Drop dw, Drop dc, hipStream_t s);
 void launch_linear_fwd(const float* A, const float* Wpack, const float* bias, float* Y, int R, int K, hipStream_t s);
-// LN1 + fused QKV projection carried by the LAST conv layer's kernel (row-local, so it needs no halo): saves one kernel
-// boundary per encoder application.  ln_g == nullptr: plain conv layer.
+// LN1 + fused QKV projection at the end of the conv-block kernel (row-local on the owner rows)
 struct QkvFuse {
     const float *ln_g, *ln_b, *Wpack, *bq, *bk, *bv;
     float *h1, *q, *k, *v;
     Drop d1;
 };
-void launch_conv_layer_fwd(const float* xin, const float* pos, float* x0_out, const float* ln_g, const float* ln_b,
-                           const float* dw_w, const float* Wpack, const float* pw_b, float* y_out, float* u_out,
-                           uint32_t* relu_mask, int R, int L, Drop dp, const QkvFuse& qkv, hipStream_t s);
 // fused conv block of one encoder application (kernels_enc.hip): 4 layers + LN1 / QKV in one launch, 12-row recomputed halo
 struct CbFwdArgs {
     const uint16_t* W3[4];         // split packs (PackJob type 6) of the four pointwise weights ; nullptr = fp32-input MFMA path
@@ -181,9 +177,6 @@ struct CbBwdArgs {
 };
 void launch_convblock_bwd(const CbBwdArgs& a, hipStream_t s);
 int convblock_slabs(int R, int L);        // partial slabs per parameter of launch_convblock_bwd (= its grid)
-void launch_ln_qkv_fwd(const float* x, const float* ln_g, const float* ln_b, const float* Wpack, const float* bq,
-                       const float* bk, const float* bv, float* h1, float* q, float* k, float* v, int R, Drop d1,
-                       hipStream_t s);
 void launch_attn_fwd(const float* Q, const float* K, const float* V, const float* mask, float* att, float* lse, int B,
                      int L, int H, int b_off, Drop d2, hipStream_t s);
 void launch_attn_out_fwd(const float* att, const float* x, const float* ln_g, const float* ln_b, const float* Wpack,
@@ -224,24 +217,20 @@ void launch_lstm_fwd(const float* gi, const float* Whh, const float* bih, const 
 void launch_lstm_bwd(const float* dout, const float* dout2, const float* mask, const float* gates, const float* cseq,
                      const float* Whh, float* dG, int B, int T, hipStream_t s, float* carry = nullptr, int t0 = 0, int t1 = -1);
                      // steps [t0, t1) in reverse; carry (B, 2, 128): dc / dh handed from one time chunk to the next
-// 4-sample-group LSTM kernels (kernels_lstm.hip); launch_lstm_fwd / launch_lstm_bwd dispatch to them unless VSL_LSTM4=0
+// kernels_lstm.hip: one-sample workgroups (B <= 256) or 4-sample MFMA groups; launch_lstm_fwd / launch_lstm_bwd forward to them
 void launch_lstm4_fwd(const float* gi, const float* Whh, const float* bih, const float* bhh, const float* mask, float* gates,
                       float* cseq, float* hprev, float* out, int B, int T, hipStream_t s, int t0, int t1);
 void launch_lstm4_bwd(const float* dout, const float* dout2, const float* mask, const float* gates, const float* cseq,
                       const float* Whh, float* dG, int B, int T, hipStream_t s, float* carry, int t0, int t1);
-void launch_wgrad(const WgradBatch& wb, hipStream_t s);     // dispatches to launch_wgrad2 (kernels_wgrad.hip) unless VSL_WGRAD2=0
+void launch_wgrad(const WgradBatch& wb, hipStream_t s);     // = launch_wgrad2 (kernels_wgrad.hip)
 void launch_wgrad2(const WgradBatch& wb, hipStream_t s);
-void launch_conv_bwd_dwln(const float* du, const float* xin, const float* dy, const float* ln_g, const float* ln_b,
-                          const float* dw_w, const float* extra, float* dx, float* p_lng, float* p_lnb, float* p_dw, int R, int L,
-                          const ConvGemmArgs& nxt, hipStream_t s);
 void launch_attn_out_bwd(const float* dy, const float* dy2, const float* r, const float* ln_g, const float* WTpack, float* g_o,
                          float* dr, float* p_lng, float* p_lnb, int R, Drop d4, Drop d5, hipStream_t s);
 void launch_attn_bwd(const float* Q, const float* K, const float* V, const float* att, const float* dr, const float* lse,
                      const float* mask, float* dQ, float* dK, float* dV, float* Dq, int B, int L, int H, int b_off, Drop d2,
                      Drop d3, hipStream_t s);
 void launch_qkv_bwd(const float* dQ, const float* dK, const float* dV, const float* x, const float* dr,
-                    const float* ln_g, const float* WTpack, float* dx, float* p_lng, float* p_lnb, int R, Drop d1,
-                    const ConvGemmArgs& nxt, hipStream_t s);
+                    const float* ln_g, const float* WTpack, float* dx, float* p_lng, float* p_lnb, int R, Drop d1, hipStream_t s);
 void launch_cqcat_bwd(const float* dg0, const float* dg1, const float* dg2, const float* dh_loss, const float* f2,
                       const float* hscore, const float* wh, const float* W1Tpack, float* df2, float* df1, float* p_wh,
                       float* p_bh, int R, hipStream_t s);
