@@ -75,7 +75,17 @@ typedef struct {
      * VisualProjection runs on the bf16 matrix cores (bf16 features x bf16-rounded weight, fp32 accumulate; the dropout scale is
      * applied to the fp32 sum).  Its weight gradient reads the same bf16 features (fp32 MFMA).  Everything else stays fp32. */
     const uint16_t* video_features_bf16;
+    /* data parallel, optional (NULL = off): a caller-owned hipEvent_t that vsl_backward records as soon as the gradients of the
+     * parameters at float offsets >= vsl_early_grad_offset() are FINAL in `grads` (the predictor block: about 55 % into the backward).
+     * The caller can start their all-reduce on another stream behind this event while the rest of the backward runs; the remaining
+     * offsets are final when vsl_backward's work on the caller's stream completes.  No reference counterpart (main_t7.py has no
+     * distributed code); it is what makes the ONE exchange of SURVEY 8(e) overlap with the backward. */
+    void* early_grads_event;
 } vsl_io;
+/* Every struct of this header must be zero-initialised by the caller before the fields are set: new optional fields are appended, and
+ * zero means "off".  vsl_abi_version() changes whenever a struct layout or an entry point's meaning changes; a binding checks it once. */
+#define VSL_ABI_VERSION 3
+int vsl_abi_version(void);
 
 /* labels + weights for the fused loss (replaces compute_loss / compute_highlight_loss, VSLNet_t7.py:67-72, and the
  * combination `loc + highlight_lambda * hl` of main_t7.py:107).  Data-parallel callers pass the GLOBAL normalisers. */
@@ -115,6 +125,9 @@ int vsl_forward(vsl_handle h, const vsl_io* io, void* hip_stream);
 int vsl_loss(vsl_handle h, const vsl_io* io, const vsl_loss_io* l, void* hip_stream);
 /* autograd backward of everything in vsl_forward (main_t7.py:110); needs the same io (workspace, seed) */
 int vsl_backward(vsl_handle h, const vsl_io* io, void* hip_stream);
+/* first float offset of the parameter block whose gradients are final when vsl_io.early_grads_event fires (== vsl_param_floats()
+ * when the configuration has no such block: the rnn predictor) */
+int64_t vsl_early_grad_offset(vsl_handle h);
 /* ConditionedPredictor.extract_index (layers_t7.py:355-363) */
 int vsl_extract_index(vsl_handle h, const float* start_logits, const float* end_logits, int B, int T,
                       int64_t* start_index, int64_t* end_index, void* hip_stream);

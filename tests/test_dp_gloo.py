@@ -69,6 +69,50 @@ def test_two_rank_allreduce_matches_single_process():
     assert err <= 1e-5 * scale + 1e-7, (err, scale)
 
 
+def _worker_two_segments(rank, world, port, out):
+    """the exchange as bench.py / dp.OverlappedExchange issue it: two all-reduce calls, the predictor block first"""
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    cfg = O.make_cfg(video_feature_dim=32, max_pos_len=32, word_size=52)
+    P = O.random_params(cfg, seed=5)
+    full = O.synthetic_batch(cfg, B=5, T=20, Lq=6, Lc=5, seed=9, ragged=True)
+    inv_b, msum = dp.global_normalisers(full['lens'].tolist())
+    g = _flat_grads(P, cfg, dp.shard_batch(full, rank, world), inv_b, msum)
+    # the split the engine reports (vsl_early_grad_offset): first parameter of the predictor block in the flat layout
+    names = [k for k in P if k not in O.FROZEN]
+    off, split = 0, None
+    for k in names:
+        if split is None and k.startswith('predictor.'):
+            split = off
+        off += P[k].numel()
+    assert split is not None and 0 < split < g.numel()
+    one = g.clone()
+    dp.two_segment_allreduce_(g, split)
+    dp.allreduce_flat_(one)
+    if rank == 0:
+        ref = _flat_grads(P, cfg, full, inv_b, msum)
+        out.put((float((g - ref).abs().max()), float(ref.abs().max()), bool(torch.equal(g, one)), split, g.numel()))
+    dist.destroy_process_group()
+
+
+def test_two_segment_exchange_equals_the_single_allreduce():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_two_segments, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    err, scale, same, split, n = q.get(timeout=300)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert err <= 1e-5 * scale + 1e-7, (err, scale)
+    assert same, 'two calls over [split:] and [:split] must give the bits of one call'
+    assert 0 < split < n
+
+
 def _worker_short(rank, world, port, out):
     """the last batch of an epoch with fewer samples than ranks: a rank without rows sends a zero bucket (main.py)"""
     import torch.distributed as dist

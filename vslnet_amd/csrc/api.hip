@@ -905,6 +905,8 @@ void run_backward(Ctx& c) {
     // ONE event for both consumers: the early reduction on sw and the fork of the query side onto sq
     c.order2(c.s, sw, sq);
     { hipStream_t keep = c.s; c.s = sw; LAUNCH("reduce", launch_reduce(c.ws, io->grads, p.segs_dev, p.blk2seg_dev, p.nblocks_early, c.s)); c.s = keep; }
+    // data parallel: the predictor block of the gradient bucket is final now -- the caller's all-reduce of it can start (vslnet_hip.h)
+    if (!c.dry && io->early_grads_event && cf.predictor == 1) (void)hipEventRecord((hipEvent_t)io->early_grads_event, sw);
     // from here the video side and the query side are independent; the longer one keeps the main stream
     hipStream_t main_s = c.s;
     const bool qlong = query_chain_is_longer(p, false);
@@ -1321,6 +1323,17 @@ int vsl_backward(vsl_handle h, const vsl_io* io, void* hip_stream) {
     run_backward(c);
     HIP_OK(hipGetLastError());
     return 0;
+}
+
+int vsl_abi_version(void) { return VSL_ABI_VERSION; }
+
+int64_t vsl_early_grad_offset(vsl_handle h) {
+    if (!h) return -1;
+    if (h->cfg.predictor != 1) return h->param_floats;
+    int64_t off = h->param_floats;
+    for (const ParamInfo& pi : h->params)
+        if (pi.name.rfind("predictor.", 0) == 0) off = std::min<int64_t>(off, pi.off);
+    return off;
 }
 
 int vsl_extract_index(vsl_handle h, const float* start_logits, const float* end_logits, int B, int T, int64_t* start_index,

@@ -6,8 +6,9 @@ main_t7.py:31,66-67), so there is no call pattern to mirror; this is the scheme 
     (the logits depend on the padded length -- SURVEY section 5 "pad-sensitivity");
   * losses use the GLOBAL normalisers (1 / B_global for the two CrossEntropy means, sum(v_mask) over the whole batch for
     the highlight loss) -- both known on the host before the step -- so per-rank gradients are plain partial sums;
-  * ONE all-reduce(sum) of the flat fp32 gradient bucket per step (0.5 - 1.1 M floats = 2 - 4.4 MB: latency-bound, one
-    RCCL call, no bucketing, nothing to overlap it with that is worth the complexity);
+  * ONE exchange (sum) of the flat fp32 gradient bucket per step (0.5 - 1.1 M floats = 2 - 4.4 MB: latency-bound), issued as TWO
+    all-reduce calls: the predictor block (final about 55 % into the backward; the library fires an event, vsl_io.early_grads_event)
+    goes out on a side stream while the rest of the backward runs, the remainder follows the backward (`OverlappedExchange`);
   * identical clip-by-global-norm + AdamW on every rank (replicated 2.7 MB of weights).
 """
 import math
@@ -42,6 +43,47 @@ def allreduce_flat_(flat_grads, group=None):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=group)
     return flat_grads
+
+
+def two_segment_allreduce_(flat_grads, split, group=None):
+    """The exchange of `OverlappedExchange` without streams or events (CPU / gloo tests): two all-reduce calls, [split:] first."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if split < flat_grads.numel():
+            dist.all_reduce(flat_grads[split:], op=dist.ReduceOp.SUM, group=group)
+        if split > 0:
+            dist.all_reduce(flat_grads[:split], op=dist.ReduceOp.SUM, group=group)
+    return flat_grads
+
+
+class OverlappedExchange:
+    """backward + the gradient exchange of one step.  grads[split:] (the predictor block) is all-reduced on a side stream as soon as
+    the library reports it final, grads[:split] on the caller's stream behind the whole backward; the caller's stream then waits for
+    the side stream.  Both calls go to the same communicator in the same order on every rank."""
+
+    def __init__(self, engine, group=None):
+        self.engine, self.group = engine, group
+        self.split = engine.early_grad_offset()
+        self.side = torch.cuda.Stream(device=engine.device)
+        self.event = torch.cuda.Event(enable_timing=False)
+
+    def backward(self, d_h, d_sl, d_el, grads, skip_exchange=False):
+        import torch.distributed as dist
+        cur = torch.cuda.current_stream(self.engine.device)
+        overlapped = not skip_exchange and self.split < grads.numel()
+        self.engine.backward(d_h, d_sl, d_el, grads, early_event=self.event if overlapped else None)
+        if skip_exchange:
+            return grads
+        if overlapped:
+            self.side.wait_event(self.event)
+            with torch.cuda.stream(self.side):
+                dist.all_reduce(grads[self.split:], op=dist.ReduceOp.SUM, group=self.group)
+            if self.split > 0:
+                dist.all_reduce(grads[:self.split], op=dist.ReduceOp.SUM, group=self.group)
+            cur.wait_stream(self.side)
+        else:
+            dist.all_reduce(grads, op=dist.ReduceOp.SUM, group=self.group)
+        return grads
 
 
 class FlatAdamW:

@@ -29,7 +29,8 @@ class vsl_io(C.Structure):
                 ('h_score', C.c_void_p), ('start_logits', C.c_void_p), ('end_logits', C.c_void_p),
                 ('workspace', C.c_void_p), ('training', C.c_int32), ('seed', C.c_uint64),
                 ('d_h_score', C.c_void_p), ('d_start_logits', C.c_void_p), ('d_end_logits', C.c_void_p),
-                ('grads', C.c_void_p), ('sample_offset', C.c_int32), ('video_features_bf16', C.c_void_p)]
+                ('grads', C.c_void_p), ('sample_offset', C.c_int32), ('video_features_bf16', C.c_void_p),
+                ('early_grads_event', C.c_void_p)]
 
 
 class vsl_loss_io(C.Structure):
@@ -44,9 +45,15 @@ class vsl_adamw(C.Structure):
                 ('clip_norm', C.c_float), ('step', C.c_int32), ('hf_order', C.c_int32)]
 
 
+class VslError(RuntimeError):
+    pass
+
+
 ABI_SYMBOLS = ['vsl_last_error', 'vsl_create', 'vsl_destroy', 'vsl_param_count', 'vsl_param_info', 'vsl_param_floats',
                'vsl_workspace_floats', 'vsl_forward', 'vsl_loss', 'vsl_backward', 'vsl_extract_index',
-               'vsl_adamw_step', 'vsl_workspace_offset', 'vsl_profile_select', 'vsl_profile_read']
+               'vsl_adamw_step', 'vsl_workspace_offset', 'vsl_profile_select', 'vsl_profile_read', 'vsl_abi_version',
+               'vsl_early_grad_offset']
+ABI_VERSION = 3                                     # include/vslnet_hip.h: VSL_ABI_VERSION
 
 
 def load_library():
@@ -69,6 +76,10 @@ def load_library():
                 finally:
                     fcntl.flock(lock, fcntl.LOCK_UN)
     lib = C.CDLL(path)
+    if not hasattr(lib, 'vsl_abi_version') or lib.vsl_abi_version() != ABI_VERSION:
+        raise VslError('%s implements another ABI version than this binding (%d): rebuild it (python -m vslnet_amd.build --force)' % (path, ABI_VERSION))
+    lib.vsl_early_grad_offset.argtypes = [C.c_void_p]
+    lib.vsl_early_grad_offset.restype = C.c_int64
     lib.vsl_last_error.restype = C.c_char_p
     lib.vsl_create.argtypes = [C.POINTER(vsl_config), C.POINTER(C.c_void_p)]
     lib.vsl_destroy.argtypes = [C.c_void_p]
@@ -89,10 +100,6 @@ def load_library():
     lib.vsl_profile_read.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
     _LIB = lib
     return lib
-
-
-class VslError(RuntimeError):
-    pass
 
 
 def _ptr(t):
@@ -254,8 +261,13 @@ class Engine:
         self._call(self.lib.vsl_loss(self.h, C.byref(io), C.byref(l), stream))
         return (losses,) + ((d[0], d[1], d[2]) if want_grads else (None, None, None))
 
-    def backward(self, d_h, d_sl, d_el, grads):
-        """Backward of the LAST forward; writes the flat gradient bucket `grads` (same layout as the params)."""
+    def early_grad_offset(self):
+        """First float offset of the block of `grads` that is final when `backward(..., early_event=)` fires its event."""
+        return int(self.lib.vsl_early_grad_offset(self.h))
+
+    def backward(self, d_h, d_sl, d_el, grads, early_event=None):
+        """Backward of the LAST forward; writes the flat gradient bucket `grads` (same layout as the params).
+        `early_event` (torch.cuda.Event, data parallel): recorded by the library as soon as grads[early_grad_offset():] is final."""
         io = self._last
         B, T = io.B, io.T
         if d_h is not None:
@@ -264,6 +276,10 @@ class Engine:
         _chk(d_el, torch.float32, (B, T), 'd_end_logits')
         _chk(grads, torch.float32, (self.param_floats,), 'grads')
         io.d_h_score, io.d_start_logits, io.d_end_logits, io.grads = _ptr(d_h), _ptr(d_sl), _ptr(d_el), _ptr(grads)
+        io.early_grads_event = None
+        if early_event is not None:
+            early_event.record(torch.cuda.current_stream(self.device))     # creates the handle lazily; harmless: recorded again by the library
+            io.early_grads_event = C.c_void_p(early_event.cuda_event)
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         self._call(self.lib.vsl_backward(self.h, C.byref(io), stream))
         return grads
