@@ -54,7 +54,7 @@ struct EncWs { int64_t x0, y[4], u[4], mask[4], h1, q, k, v, lse, att, r, h2, ou
 
 struct LstmWs { int64_t gi, gates, cseq, hprev, out, dG, carry; };   // one DynamicRNN: x W_ih^T, activated gates, c_t, h_{t-1}, h * mask, gate grads, (B,2,128) dc/dh hand-over between time chunks
 
-struct EncTmp { int64_t dr, dq, dk, dv, Dq, go, gz[4], ga; };   // backward temporaries of one encoder application
+struct EncTmp { int64_t dr, dq, dk, dv, go, gz[4], ga; };   // backward temporaries of one encoder application
 
 struct SlabRec { int dst, n, nslabs, ss, rl, ds, vn; int64_t src; };
 // the reduction runs in two launches: `early` = parameters whose partials are complete before the final video/query fork
@@ -652,11 +652,11 @@ void enc_bwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float*
     LAUNCH("attn_out_bwd", launch_attn_out_bwd(dy, dy2, c.W(w.r), c.P(P.ln2g), c.PK(K.o_t), c.W(t.go), c.W(t.dr), p_ln2g, p_ln2b, R,
                                c.drop(app * 16 + 7), c.drop(app * 16 + 8), c.s));
     LAUNCH("attn_bwd", launch_attn_bwd(c.W(w.q), c.W(w.k), c.W(w.v), c.W(w.att), c.W(t.dr), c.W(w.lse), mask, c.W(t.dq), c.W(t.dk),
-                           c.W(t.dv), c.W(t.Dq), Bn, L, H, 0, c.drop(app * 16 + 5), c.drop(app * 16 + 6), c.s));
+                           c.W(t.dv), Bn, L, H, 0, c.drop(app * 16 + 5), c.drop(app * 16 + 6), c.s));
     float* p_ln1g = c.slab(P.ln1g, D, ntiles);
     float* p_ln1b = c.slab(P.ln1b, D, ntiles);
     LAUNCH("qkv_bwd", launch_qkv_bwd(c.W(t.dq), c.W(t.dk), c.W(t.dv), c.W(w.y[3]), c.W(t.dr), c.P(P.ln1g), c.PK(K.qkv_t),
-                          c.W(t.ga), p_ln1g, p_ln1b, R, c.drop(app * 16 + 4), c.s));
+                          c.W(t.ga), p_ln1g, p_ln1b, R, c.drop(app * 16 + 4), c.s, attn_bwd_dq_slabs(L)));
     {   // out_layer + fused q/k/v weight gradients: every input exists now -> side stream, beside the conv chain
         WgradBatch wb;
         memset(&wb, 0, sizeof wb);
@@ -1019,7 +1019,7 @@ int build_plan(vsl_handle_s* h, int B, int T, int Lq, int Lc, Plan** out) {
     for (int ap = 0; ap < (rnn ? 2 : 4); ++ap) {
         const int64_t Ra = ap == 1 ? Rq : R;
         EncTmp& t = p->tmp[ap];
-        t.dr = al(Ra * D); t.dq = al(Ra * D); t.dk = al(Ra * D); t.dv = al(Ra * D); t.Dq = al((int64_t)B * H * (ap == 1 ? Lq : T));
+        t.dr = al(Ra * D); t.dq = al(Ra * D * attn_bwd_dq_slabs(ap == 1 ? Lq : T)); t.dk = al(Ra * D); t.dv = al(Ra * D);
         t.go = al(Ra * D);
         for (int i = 0; i < 4; ++i) t.gz[i] = al(Ra * D);
         t.ga = al(Ra * D);

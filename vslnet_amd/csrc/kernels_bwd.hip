@@ -417,175 +417,6 @@ void launch_attn_out_bwd(const float* dy, const float* dy2, const float* r, cons
     }
 }
 
-// dQ: wave owns 16 queries (lane: query qi = lane & 15, key group g = lane >> 4); the K / V head slices stream through LDS in
-// blocks of AB2_KB keys (42 KB at any L, several workgroups per CU).  Used for L > 256 (the fused kernel covers the rest).
-constexpr int AB2_KB = 256;
-__global__ __launch_bounds__(256) void k_attn_bwd_dq(const float* __restrict__ Q, const float* __restrict__ K,
-                                                     const float* __restrict__ V, const float* __restrict__ att,
-                                                     const float* __restrict__ dr, const float* __restrict__ lse,
-                                                     const float* __restrict__ mask, float* __restrict__ dQ,
-                                                     float* __restrict__ Dq, int L, int H, int b_off, Drop d2, Drop d3) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int Lp = (L + 15) & ~15;
-    const int KB = min(Lp, AB2_KB);
-    constexpr int kst = 20;
-    float* Ks = smem;
-    float* Vs = Ks + KB * kst;
-    float* Mb = Vs + KB * kst;
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    int bxs, h, b;
-    xcd_swizzle(bxs, h, b);                        // all heads of a sample on one XCD (common.hpp)
-    const size_t rowbase = (size_t)b * L;
-    const int qi = lane & 15, g = lane >> 4;
-    const int q = bxs * 64 + w * 16 + qi;
-    const bool qok = q < L;
-    float4 qf = make_float4(0.f, 0.f, 0.f, 0.f), da = qf, of = qf;
-    float lq = 0.f;
-    if (qok) {
-        const size_t off = (rowbase + q) * D + h * HD + 4 * g;
-        qf = *reinterpret_cast<const float4*>(Q + off);
-        da = *reinterpret_cast<const float4*>(dr + off);
-        of = *reinterpret_cast<const float4*>(att + off);
-        if (d3.thresh) {                    // r = drop3(att) + x  (:183-184)
-            const uint32_t base = (uint32_t)off;
-            da.x *= drop_mul(d3, base); da.y *= drop_mul(d3, base + 1);
-            da.z *= drop_mul(d3, base + 2); da.w *= drop_mul(d3, base + 3);
-        }
-        lq = lse[((size_t)b * H + h) * L + q];
-    }
-    float dsum = da.x * of.x + da.y * of.y + da.z * of.z + da.w * of.w;     // D_q = dA . O  (= sum_k dP_k P_k)
-    dsum = lane_pair16(dsum, [](float a, float b) { return a + b; });
-    dsum = lane_pair32(dsum, [](float a, float b) { return a + b; });
-    if (qok && g == 0) Dq[((size_t)b * H + h) * L + q] = dsum;
-    const float scale = 0.25f;
-    const uint32_t pbase = (uint32_t)(((size_t)(b + b_off) * H + h) * L + q) * (uint32_t)L;
-    f32x4 dq = {0.f, 0.f, 0.f, 0.f};
-    for (int kb0 = 0; kb0 < Lp; kb0 += AB2_KB) {
-        const int nk = min(AB2_KB, Lp - kb0);
-        if (kb0) __syncthreads();
-        for (int e = tid; e < nk * 4; e += 256) {
-            const int key = kb0 + (e >> 2), c4 = (e & 3) * 4;
-            float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-            if (key < L) {
-                kv = *reinterpret_cast<const float4*>(K + (rowbase + key) * D + h * HD + c4);
-                vv = *reinterpret_cast<const float4*>(V + (rowbase + key) * D + h * HD + c4);
-            }
-            *reinterpret_cast<float4*>(&Ks[(e >> 2) * kst + c4]) = kv;
-            *reinterpret_cast<float4*>(&Vs[(e >> 2) * kst + c4]) = vv;
-        }
-        for (int kk = tid; kk < nk; kk += 256) Mb[kk] = kb0 + kk < L ? (1.0f - mask[rowbase + kb0 + kk]) * MASK_VALUE : MASK_VALUE;
-        __syncthreads();
-        for (int kt = 0; kt < nk; kt += 16) {
-            const float4 kf = *reinterpret_cast<const float4*>(&Ks[(kt + qi) * kst + 4 * g]);
-            const float4 vf = *reinterpret_cast<const float4*>(&Vs[(kt + qi) * kst + 4 * g]);
-            f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-            s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf.x, s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf.y, s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf.z, s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf.w, s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.x, da.x, dp, 0, 0, 0);   // dPd^T[key][q] = V[key] . dA[q]
-            dp = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.y, da.y, dp, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.z, da.z, dp, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_16x16x4f32(vf.w, da.w, dp, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kt + 4 * g + r;
-                const float p = __expf(s[r] * scale + Mb[key] - lq);
-                const float ds = p * (dp[r] * drop_mul(d2, pbase + kb0 + key) - dsum) * scale;
-                // dQ^T[dd][q] += K[key][dd] * dS[q][key]
-                dq = __builtin_amdgcn_mfma_f32_16x16x4f32(Ks[key * kst + qi], ds, dq, 0, 0, 0);
-            }
-        }
-    }
-    if (qok) *reinterpret_cast<float4*>(dQ + (rowbase + q) * D + h * HD + 4 * g) = make_float4(dq[0], dq[1], dq[2], dq[3]);
-}
-// dK, dV: wave owns 16 keys (lane: key ki = lane & 15, query group g = lane >> 4); the Q / dA head slices (+ LSE, D) stream
-// through LDS in blocks of AB2_KB queries.
-__global__ __launch_bounds__(256) void k_attn_bwd_dkv(const float* __restrict__ Q, const float* __restrict__ K,
-                                                      const float* __restrict__ V, const float* __restrict__ dr,
-                                                      const float* __restrict__ lse, const float* __restrict__ Dq,
-                                                      const float* __restrict__ mask, float* __restrict__ dK,
-                                                      float* __restrict__ dV, int L, int H, int b_off, Drop d2, Drop d3) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int Lp = (L + 15) & ~15;
-    const int KB = min(Lp, AB2_KB);
-    constexpr int kst = 20;
-    float* Qs = smem;
-    float* As = Qs + KB * kst;          // dA = dr * m3
-    float* Ls = As + KB * kst;          // LSE per query
-    float* Ds = Ls + KB;                // D per query
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    int bxs, h, b;
-    xcd_swizzle(bxs, h, b);                        // all heads of a sample on one XCD (common.hpp)
-    const size_t rowbase = (size_t)b * L;
-    const int ki = lane & 15, g = lane >> 4;
-    const int key = bxs * 64 + w * 16 + ki;
-    const bool kok = key < L;
-    float4 kf = make_float4(0.f, 0.f, 0.f, 0.f), vf = kf;
-    float mb = MASK_VALUE;
-    if (kok) {
-        kf = *reinterpret_cast<const float4*>(K + (rowbase + key) * D + h * HD + 4 * g);
-        vf = *reinterpret_cast<const float4*>(V + (rowbase + key) * D + h * HD + 4 * g);
-        mb = (1.0f - mask[rowbase + key]) * MASK_VALUE;
-    }
-    const float scale = 0.25f;
-    const uint32_t hb = (uint32_t)(((size_t)(b + b_off) * H + h) * L);
-    f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
-    for (int qb0 = 0; qb0 < Lp; qb0 += AB2_KB) {
-        const int nq = min(AB2_KB, Lp - qb0);
-        if (qb0) __syncthreads();
-        for (int e = tid; e < nq * 4; e += 256) {
-            const int qq = qb0 + (e >> 2), c4 = (e & 3) * 4;
-            float4 qv = make_float4(0.f, 0.f, 0.f, 0.f), av = qv;
-            if (qq < L) {
-                const size_t off = (rowbase + qq) * D + h * HD + c4;
-                qv = *reinterpret_cast<const float4*>(Q + off);
-                av = *reinterpret_cast<const float4*>(dr + off);
-                if (d3.thresh) {
-                    const uint32_t base = (uint32_t)off;
-                    av.x *= drop_mul(d3, base); av.y *= drop_mul(d3, base + 1);
-                    av.z *= drop_mul(d3, base + 2); av.w *= drop_mul(d3, base + 3);
-                }
-            }
-            *reinterpret_cast<float4*>(&Qs[(e >> 2) * kst + c4]) = qv;
-            *reinterpret_cast<float4*>(&As[(e >> 2) * kst + c4]) = av;
-        }
-        for (int qq = tid; qq < nq; qq += 256) {
-            Ls[qq] = qb0 + qq < L ? lse[((size_t)b * H + h) * L + qb0 + qq] : 0.f;
-            Ds[qq] = qb0 + qq < L ? Dq[((size_t)b * H + h) * L + qb0 + qq] : 0.f;
-        }
-        __syncthreads();
-        for (int qt = 0; qt < nq; qt += 16) {
-            // S tile (rows = queries qb0 + qt + 4g + reg, col = key ki) and dPd tile, same shape
-            const float4 qa = *reinterpret_cast<const float4*>(&Qs[(qt + ki) * kst + 4 * g]);
-            const float4 aa = *reinterpret_cast<const float4*>(&As[(qt + ki) * kst + 4 * g]);
-            f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-            s = __builtin_amdgcn_mfma_f32_16x16x4f32(qa.x, kf.x, s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_16x16x4f32(qa.y, kf.y, s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_16x16x4f32(qa.z, kf.z, s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_16x16x4f32(qa.w, kf.w, s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_16x16x4f32(aa.x, vf.x, dp, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_16x16x4f32(aa.y, vf.y, dp, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_16x16x4f32(aa.z, vf.z, dp, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_16x16x4f32(aa.w, vf.w, dp, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ql = qt + 4 * g + r;
-                const float p = __expf(s[r] * scale + mb - Ls[ql]);
-                const float m2 = drop_mul(d2, (hb + (uint32_t)(qb0 + ql)) * (uint32_t)L + (uint32_t)key);
-                const float pd = p * m2;
-                const float ds = p * (dp[r] * m2 - Ds[ql]) * scale;
-                // dV^T[dd][key] += dA[q][dd] * Pd[q][key] ; dK^T[dd][key] += Q[q][dd] * dS[q][key]
-                dv = __builtin_amdgcn_mfma_f32_16x16x4f32(As[ql * kst + ki], pd, dv, 0, 0, 0);
-                dk = __builtin_amdgcn_mfma_f32_16x16x4f32(Qs[ql * kst + ki], ds, dk, 0, 0, 0);
-            }
-        }
-    }
-    if (kok) {
-        *reinterpret_cast<float4*>(dK + (rowbase + key) * D + h * HD + 4 * g) = make_float4(dk[0], dk[1], dk[2], dk[3]);
-        *reinterpret_cast<float4*>(dV + (rowbase + key) * D + h * HD + 4 * g) = make_float4(dv[0], dv[1], dv[2], dv[3]);
-    }
-}
 // Fused attention backward for Lp <= 128: ONE workgroup (16 waves) per (sample, head) computes S, P, dP and dS once.
 // Queries are processed in passes of 64 so that dS[64][keys] fits beside the head slices in < 80 KB of LDS: two workgroups
 // share a CU (one stages while the other computes) and a weight-gradient workgroup of another stream still fits too.
@@ -763,8 +594,170 @@ __global__ __launch_bounds__(1024) void k_attn_bwd_fused(const float* __restrict
     }
     STAMP(7);
 }
+// Single-pass attention backward for L > 256 (round 3; replaces k_attn_bwd_dq + k_attn_bwd_dkv, which computed S, P, dP and dS twice).
+// Workgroup (16 waves) = (key block of 256 keys, head, sample).  The block's K / V head slices stay in LDS; the queries stream through in
+// passes of 64 (Q, dA = dr * m3, LSE, D = dA . O staged per pass).  Per pass, as in k_attn_bwd_fused<256>:
+//   phase 1: wave w owns the 16 keys of strip w and all four query tiles of the pass: S, P, dP, dS ONCE; dK / dV of the strip accumulate
+//            in registers over every pass of the sequence; dS goes to LDS as a [query][key] matrix;
+//   phase 2: dQ^T[dd][q] += K[key][dd] dS[q][key] over the block's keys (wave = query tile x key residue, partials added in residue order).
+// dK / dV are complete; dQ is a partial over this key block and goes to slab `kb` of dQ (slab stride = the (R, 128) tensor): k_qkv_bwd adds
+// the slabs while it stages its tile (and leaves the sum in slab 0 for the weight gradient).  122 KB of LDS, one workgroup per CU.
+constexpr int ABL_KB = 256;
+constexpr size_t abl_lds() { return (size_t)(2 * ABL_KB * AB_KST + ABL_KB + AB_QP * (ABL_KB + 4) + 2 * AB_QP * AB_KST + 2 * AB_QP) * sizeof(float); }
+__global__ __launch_bounds__(1024) void k_attn_bwd_long(const float* __restrict__ Q, const float* __restrict__ K,
+                                                        const float* __restrict__ V, const float* __restrict__ att,
+                                                        const float* __restrict__ dr, const float* __restrict__ lse,
+                                                        const float* __restrict__ mask, float* __restrict__ dQ,
+                                                        float* __restrict__ dK, float* __restrict__ dV, int L, int H,
+                                                        int b_off, size_t slab, Drop d2, Drop d3) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int AB_DSP = ABL_KB + 4;
+    float* Ks = smem;                           // [256][20]
+    float* Vs = Ks + ABL_KB * AB_KST;           // [256][20]
+    float* Mb = Vs + ABL_KB * AB_KST;           // additive key bias of the block
+    float* dSs = Mb + ABL_KB;                   // [64][260] dS[query - qb][key - k0] of the current pass
+    float* Qs = dSs + AB_QP * AB_DSP;           // [64][20] queries of the pass
+    float* As = Qs + AB_QP * AB_KST;            // [64][20] dA = dr * m3
+    float* Ls = As + AB_QP * AB_KST;            // [64] LSE
+    float* Ds = Ls + AB_QP;                     // [64] D = dA . O
+    const int Lp = (L + 15) & ~15;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    int kb, h, b;
+    xcd_swizzle(kb, h, b);                      // grid (key blocks, H, B)
+    const size_t rowbase = (size_t)b * L;
+    const int k0 = kb * ABL_KB, nkeys = min(ABL_KB, Lp - k0);       // padded keys of this block (multiple of 16)
+    {   // the block's K / V slices: 256 rows x 4 float4 each = 1024 items per tensor
+        const int row = tid >> 2, c4 = (tid & 3) * 4;
+        float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+        if (k0 + row < L) {
+            const size_t off = (rowbase + k0 + row) * D + h * HD + c4;
+            kv = *reinterpret_cast<const float4*>(K + off);
+            vv = *reinterpret_cast<const float4*>(V + off);
+        }
+        *reinterpret_cast<float4*>(&Ks[row * AB_KST + c4]) = kv;
+        *reinterpret_cast<float4*>(&Vs[row * AB_KST + c4]) = vv;
+        if (tid < ABL_KB) Mb[tid] = k0 + tid < L ? (1.0f - mask[rowbase + k0 + tid]) * MASK_VALUE : MASK_VALUE;
+    }
+    const int ki = lane & 15, g = lane >> 4;
+    const float scale = 0.25f;
+    f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
+    const int keyl = 16 * w + ki;               // key inside the block
+    const bool has_keys = 16 * w < nkeys;
+    const uint32_t hb = (uint32_t)(((size_t)(b + b_off) * H + h) * L);
+    float4 kf = make_float4(0.f, 0.f, 0.f, 0.f), vf = kf;
+    float mb = MASK_VALUE;
+    // rows of the next pass: requested a pass ahead (threads 0-255: one float4 of Q, dA and att each)
+    float4 nq, na, no;
+    float nl = 0.f;
+    auto fetch = [&](int qb) {
+        const int row = qb + (tid >> 2), c4 = (tid & 3) * 4;
+        nq = make_float4(0.f, 0.f, 0.f, 0.f); na = nq; no = nq; nl = 0.f;
+        if (tid < 256 && row < L) {
+            const size_t off = (rowbase + row) * D + h * HD + c4;
+            nq = *reinterpret_cast<const float4*>(Q + off);
+            na = *reinterpret_cast<const float4*>(dr + off);
+            no = *reinterpret_cast<const float4*>(att + off);
+            if ((tid & 3) == 0) nl = lse[((size_t)b * H + h) * L + row];
+        }
+    };
+    auto stage = [&](int qb) {                  // (the previous pass' readers are behind a barrier)
+        if (tid < 256) {
+            const int rl = tid >> 2, c4 = (tid & 3) * 4;
+            float4 av = na;
+            if (d3.thresh && qb + rl < L) {     // r = drop3(att) + x  (:183-184)
+                const uint32_t base = (uint32_t)((rowbase + qb + rl) * D + h * HD + c4);
+                av.x *= drop_mul(d3, base); av.y *= drop_mul(d3, base + 1);
+                av.z *= drop_mul(d3, base + 2); av.w *= drop_mul(d3, base + 3);
+            }
+            *reinterpret_cast<float4*>(&Qs[rl * AB_KST + c4]) = nq;
+            *reinterpret_cast<float4*>(&As[rl * AB_KST + c4]) = av;
+            float dsum = av.x * no.x + av.y * no.y + av.z * no.z + av.w * no.w;     // D_q = dA . O (= sum_k dP_k P_k)
+            dsum += lane_xor1(dsum);
+            dsum += lane_xor2(dsum);
+            if ((tid & 3) == 0) { Ds[rl] = dsum; Ls[rl] = nl; }
+        }
+    };
+    fetch(0);
+    __syncthreads();
+    if (has_keys) {
+        kf = *reinterpret_cast<const float4*>(&Ks[keyl * AB_KST + 4 * g]);
+        vf = *reinterpret_cast<const float4*>(&Vs[keyl * AB_KST + 4 * g]);
+        mb = Mb[keyl];
+    }
+    for (int qb = 0; qb < Lp; qb += AB_QP) {
+        const int qe = min(qb + AB_QP, Lp);
+        stage(qb);
+        if (qb + AB_QP < Lp) fetch(qb + AB_QP);
+        __syncthreads();
+        if (has_keys) {
+            for (int qt = qb; qt < qe; qt += 16) {
+                const int ql0 = qt - qb;
+                const float4 qa = *reinterpret_cast<const float4*>(&Qs[(ql0 + ki) * AB_KST + 4 * g]);
+                const float4 aa = *reinterpret_cast<const float4*>(&As[(ql0 + ki) * AB_KST + 4 * g]);
+                f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                sc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa.x, kf.x, sc, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x4f32(aa.x, vf.x, dp, 0, 0, 0);
+                sc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa.y, kf.y, sc, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x4f32(aa.y, vf.y, dp, 0, 0, 0);
+                sc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa.z, kf.z, sc, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x4f32(aa.z, vf.z, dp, 0, 0, 0);
+                sc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa.w, kf.w, sc, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x4f32(aa.w, vf.w, dp, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ql = ql0 + 4 * g + r;
+                    const float p = __expf(sc[r] * scale + mb - Ls[ql]);
+                    const float m2 = drop_mul(d2, (hb + (uint32_t)(qb + ql)) * (uint32_t)L + (uint32_t)(k0 + keyl));
+                    const float pd = p * m2;
+                    const float ds = p * (dp[r] * m2 - Ds[ql]) * scale;
+                    dSs[ql * AB_DSP + keyl] = ds;
+                    dv = __builtin_amdgcn_mfma_f32_16x16x4f32(As[ql * AB_KST + ki], pd, dv, 0, 0, 0);
+                    dk = __builtin_amdgcn_mfma_f32_16x16x4f32(Qs[ql * AB_KST + ki], ds, dk, 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                        // dS of this pass complete
+        const int qt2 = qb + 16 * (w & 3), kr = w >> 2;
+        f32x4 dqs = {0.f, 0.f, 0.f, 0.f};
+        if (qt2 < qe) {
+            f32x4 dq[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float* kp = Ks + g * AB_KST + ki;
+            const float* sp = dSs + (16 * (w & 3) + ki) * AB_DSP + g;
+            for (int kk = 16 * kr; kk < nkeys; kk += 64) {
+                float ka[4], sb[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { ka[i] = kp[(kk + 4 * i) * AB_KST]; sb[i] = sp[kk + 4 * i]; }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dq[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[i], sb[i], dq[i], 0, 0, 0);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dqs[c] = (dq[0][c] + dq[1][c]) + (dq[2][c] + dq[3][c]);
+        }
+        __syncthreads();                        // every wave has read its dS rows: the buffer becomes the exchange area
+        float4* xq = reinterpret_cast<float4*>(dSs);          // [3 residues][4 query tiles][64 lanes]
+        if (kr > 0) xq[((kr - 1) * 4 + (w & 3)) * 64 + lane] = make_float4(dqs[0], dqs[1], dqs[2], dqs[3]);
+        __syncthreads();
+        if (kr == 0 && qt2 < qe) {
+            const float4 p1 = xq[(0 * 4 + w) * 64 + lane], p2 = xq[(1 * 4 + w) * 64 + lane], p3 = xq[(2 * 4 + w) * 64 + lane];
+            const int q = qt2 + ki;
+            if (q < L)
+                *reinterpret_cast<float4*>(dQ + (size_t)kb * slab + (rowbase + q) * D + h * HD + 4 * g) =
+                    make_float4(((dqs[0] + p1.x) + p2.x) + p3.x, ((dqs[1] + p1.y) + p2.y) + p3.y,
+                                ((dqs[2] + p1.z) + p2.z) + p3.z, ((dqs[3] + p1.w) + p2.w) + p3.w);
+        }
+        __syncthreads();                        // dS buffer, Qs / As / Ls / Ds free for the next pass
+    }
+    if (has_keys && k0 + keyl < L) {
+        const size_t off = (rowbase + k0 + keyl) * D + h * HD + 4 * g;
+        *reinterpret_cast<float4*>(dK + off) = make_float4(dk[0], dk[1], dk[2], dk[3]);
+        *reinterpret_cast<float4*>(dV + off) = make_float4(dv[0], dv[1], dv[2], dv[3]);
+    }
+}
+int attn_bwd_dq_slabs(int L) { const int Lp = (L + 15) & ~15; return Lp <= 256 ? 1 : (Lp + ABL_KB - 1) / ABL_KB; }
 void launch_attn_bwd(const float* Q, const float* K, const float* V, const float* att, const float* dr, const float* lse,
-                     const float* mask, float* dQ, float* dK, float* dV, float* Dq, int B, int L, int H, int b_off, Drop d2,
+                     const float* mask, float* dQ, float* dK, float* dV, int B, int L, int H, int b_off, Drop d2,
                      Drop d3, hipStream_t s) {
     const int Lp = (L + 15) & ~15;
     static const bool fused_ok = !(getenv("VSL_ATTN_BWD_FUSED") && getenv("VSL_ATTN_BWD_FUSED")[0] == '0');
@@ -784,15 +777,11 @@ void launch_attn_bwd(const float* Q, const float* K, const float* V, const float
         if (dbg_budget("attn_bwd") && L > 64) dbg_report("attn_bwd_fused: stage-issue | landed+sync | pass-0 phase1 | sync | phase2 | sync | pass 1 + final", 8, s, left);
         return;
     }
-    const int KB = Lp < AB2_KB ? Lp : AB2_KB;
-    const size_t shm1 = (size_t)(2 * KB * 20 + KB) * sizeof(float), shm2 = (size_t)(2 * KB * 20 + 2 * KB) * sizeof(float);
-    static size_t lds_ok1 = 0, lds_ok2 = 0;
-    ensure_dynamic_lds((const void*)k_attn_bwd_dq, shm1, lds_ok1, "k_attn_bwd_dq");
-    ensure_dynamic_lds((const void*)k_attn_bwd_dkv, shm2, lds_ok2, "k_attn_bwd_dkv");
-    VSL_LAUNCH(k_attn_bwd_dq, dim3((L + 63) / 64, H, B), dim3(256), shm1, s, Q, K, V, att, dr, lse, mask, dQ, Dq, L, H,
-                       b_off, d2, d3);
-    VSL_LAUNCH(k_attn_bwd_dkv, dim3((L + 63) / 64, H, B), dim3(256), shm2, s, Q, K, V, dr, lse, Dq, mask, dK, dV, L, H,
-                       b_off, d2, d3);
+    // L > 256: one pass over S / dP per key block of 256; dQ arrives as attn_bwd_dq_slabs(L) partial slabs (k_qkv_bwd adds them)
+    static size_t okl = 0;
+    ensure_dynamic_lds((const void*)k_attn_bwd_long, abl_lds(), okl, "k_attn_bwd_long");
+    VSL_LAUNCH(k_attn_bwd_long, dim3((Lp + ABL_KB - 1) / ABL_KB, H, B), dim3(1024), abl_lds(), s, Q, K, V, att, dr, lse, mask, dQ, dK, dV,
+               L, H, b_off, (size_t)B * L * D, d2, d3);
 }
 
 constexpr int QKVP = 3 * D + 4;
@@ -800,7 +789,8 @@ __global__ __launch_bounds__(256) void k_qkv_bwd(const float* __restrict__ dQ, c
                                                  const float* __restrict__ dV, const float* __restrict__ x,
                                                  const float* __restrict__ dr, const float* __restrict__ ln_g,
                                                  const float* __restrict__ WTpack, float* __restrict__ dx,
-                                                 float* __restrict__ p_lng, float* __restrict__ p_lnb, int R, Drop d1) {
+                                                 float* __restrict__ p_lng, float* __restrict__ p_lnb, int R, Drop d1, int dq_slabs,
+                                                 size_t dq_slab) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                         // [32][QKVP] = [dQ | dK | dV]
     float* Ts = As + TILE_M * QKVP;           // [32][LDP]
@@ -818,6 +808,13 @@ __global__ __launch_bounds__(256) void k_qkv_bwd(const float* __restrict__ dQ, c
             bq[q] = a[q]; cv[q] = a[q];
             if (r < R) {
                 a[q] = *reinterpret_cast<const float4*>(dQ + (size_t)r * D + c);
+                if (dq_slabs > 1) {     // L > 256: dQ arrives as one partial per key block (k_attn_bwd_long); the sum stays in slab 0 (weight gradient)
+                    for (int sl = 1; sl < dq_slabs; ++sl) {
+                        const float4 e = *reinterpret_cast<const float4*>(dQ + (size_t)sl * dq_slab + (size_t)r * D + c);
+                        a[q].x += e.x; a[q].y += e.y; a[q].z += e.z; a[q].w += e.w;
+                    }
+                    *reinterpret_cast<float4*>(const_cast<float*>(dQ) + (size_t)r * D + c) = a[q];
+                }
                 bq[q] = *reinterpret_cast<const float4*>(dK + (size_t)r * D + c);
                 cv[q] = *reinterpret_cast<const float4*>(dV + (size_t)r * D + c);
             }
@@ -849,12 +846,13 @@ __global__ __launch_bounds__(256) void k_qkv_bwd(const float* __restrict__ dQ, c
     ln_bwd_tile(Ts, Xs, lres, ln_g, dx, p_lng, p_lnb, r0, R);
 }
 void launch_qkv_bwd(const float* dQ, const float* dK, const float* dV, const float* x, const float* dr,
-                    const float* ln_g, const float* WTpack, float* dx, float* p_lng, float* p_lnb, int R, Drop d1, hipStream_t s) {
+                    const float* ln_g, const float* WTpack, float* dx, float* p_lng, float* p_lnb, int R, Drop d1, hipStream_t s,
+                    int dq_slabs) {
     const size_t shm = (size_t)(TILE_M * QKVP + 2 * TILE_M * LDP) * sizeof(float);
     static size_t lds_ok = 0;
     ensure_dynamic_lds((const void*)k_qkv_bwd, shm, lds_ok, "k_qkv_bwd");
     VSL_LAUNCH(k_qkv_bwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm, s, dQ, dK, dV, x, dr, ln_g, WTpack, dx, p_lng,
-                       p_lnb, R, d1);
+                       p_lnb, R, d1, dq_slabs, (size_t)R * D);
 }
 
 // =========================================================================================================

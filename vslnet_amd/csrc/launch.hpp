@@ -227,10 +227,12 @@ void launch_wgrad2(const WgradBatch& wb, hipStream_t s);
 void launch_attn_out_bwd(const float* dy, const float* dy2, const float* r, const float* ln_g, const float* WTpack, float* g_o,
                          float* dr, float* p_lng, float* p_lnb, int R, Drop d4, Drop d5, hipStream_t s);
 void launch_attn_bwd(const float* Q, const float* K, const float* V, const float* att, const float* dr, const float* lse,
-                     const float* mask, float* dQ, float* dK, float* dV, float* Dq, int B, int L, int H, int b_off, Drop d2,
+                     const float* mask, float* dQ, float* dK, float* dV, int B, int L, int H, int b_off, Drop d2,
                      Drop d3, hipStream_t s);
+int attn_bwd_dq_slabs(int L);             // L > 256: dQ is written as this many (R, 128) partial slabs (one per 256-key block); k_qkv_bwd adds them
 void launch_qkv_bwd(const float* dQ, const float* dK, const float* dV, const float* x, const float* dr,
-                    const float* ln_g, const float* WTpack, float* dx, float* p_lng, float* p_lnb, int R, Drop d1, hipStream_t s);
+                    const float* ln_g, const float* WTpack, float* dx, float* p_lng, float* p_lnb, int R, Drop d1, hipStream_t s,
+                    int dq_slabs = 1);
 void launch_cqcat_bwd(const float* dg0, const float* dg1, const float* dg2, const float* dh_loss, const float* f2,
                       const float* hscore, const float* wh, const float* W1Tpack, float* df2, float* df1, float* p_wh,
                       float* p_bh, int R, hipStream_t s);
