@@ -126,7 +126,8 @@ def depthwise7(x, w):
 # with the ones the HIP path saved and only then decide which gradient gate applies (tests/helpers.py: relu_flips).
 RELU_SIGNS = None
 RELU_FORCED = None
-RELU_FORCED_DEV = 0.0      # largest |pre-activation| on which a forced branch differed from the sign seen in that same forward
+RELU_FORCED_DEV = 0.0      # largest |pre-activation| on which a forced branch differed from the sign seen in that same forward (reported, not gated)
+RELU_FORCED_RATIO = 0.0    # the same in units of the pre-activation's own fp32 noise scale: |z| / (2^-24 * (sum_k |a_k w_k| + |b|))
 
 
 def record_relu_signs(on=True):
@@ -137,10 +138,11 @@ def record_relu_signs(on=True):
 def force_relu_signs(masks):
     """Take the given branch (bool tensors, call order) at every ReLU of the next forward instead of sign(z): lets a test
     evaluate the oracle's gradient ON THE BRANCH THE GPU PATH TOOK when a pre-activation sits inside the forward noise."""
-    global RELU_FORCED, RELU_FORCED_DEV
+    global RELU_FORCED, RELU_FORCED_DEV, RELU_FORCED_RATIO
     RELU_FORCED = list(masks) if masks is not None else None
     if masks is not None:
         RELU_FORCED_DEV = 0.0
+        RELU_FORCED_RATIO = 0.0
 
 
 def forced_relu_deviation():
@@ -150,15 +152,28 @@ def forced_relu_deviation():
     return RELU_FORCED_DEV
 
 
-def _relu(z, site):
-    global RELU_FORCED_DEV
+def forced_relu_noise_ratio():
+    """After a forced forward: max over the contradicted decisions of |z| / (u * S), u = 2^-24, S = sum_k |a_k w_k| + |b| of that
+    pre-activation's own dot product (the quantity every fp32 summation-order error bound is proportional to).  tests/helpers.py
+    (RELU_NOISE_KAPPA) derives the bound it is asserted against."""
+    return RELU_FORCED_RATIO
+
+
+def _relu(z, site, operands=None):
+    """operands = (a, w, b) of z = pointwise(a, w, b): only read while a branch is being forced, for the noise scale S."""
+    global RELU_FORCED_DEV, RELU_FORCED_RATIO
     if RELU_SIGNS is not None:
         RELU_SIGNS.append((site, (z.detach() > 0)))
     if RELU_FORCED is not None:
         m = RELU_FORCED.pop(0)
-        dis = z.detach().abs()[m != (z.detach() > 0)]
+        bad = m != (z.detach() > 0)
+        dis = z.detach().abs()[bad]
         if dis.numel():
             RELU_FORCED_DEV = max(RELU_FORCED_DEV, float(dis.max()))
+            if operands is not None:
+                a, w, b = operands
+                S = pointwise(a.detach().abs(), w.detach().abs(), None if b is None else b.detach().abs())
+                RELU_FORCED_RATIO = max(RELU_FORCED_RATIO, float((dis / (S[bad] * 2.0 ** -24)).max()))
         return z * m.to(z.dtype)
     return torch.relu(z)
 
@@ -168,7 +183,7 @@ def conv_layer(x, ln_g, ln_b, dw_w, pw_w, pw_b, p, training):
     v = layer_norm(x, ln_g, ln_b)
     u = depthwise7(v, dw_w)
     z = pointwise(u, pw_w, pw_b)
-    return _drop(_relu(z, 'conv'), p, training) + x
+    return _drop(_relu(z, 'conv', (u, pw_w, pw_b)), p, training) + x
 
 
 def conv_block(P, pre, x, p, training, n_layers=4):
@@ -303,9 +318,10 @@ def dynamic_rnn(P, pre, x, mask):
 
 def span_head(P, name, feat, x):
     """start_block / end_block, layers_t7.py:328-337,349-350: Conv1D(2d->d) + ReLU + Conv1D(d->1)."""
-    z = pointwise(torch.cat([feat, x], dim=2), P['predictor.%s_block.0.conv1d.weight' % name],
-                  P['predictor.%s_block.0.conv1d.bias' % name])
-    return pointwise(_relu(z, 'head_' + name), P['predictor.%s_block.2.conv1d.weight' % name],
+    cat = torch.cat([feat, x], dim=2)
+    z = pointwise(cat, P['predictor.%s_block.0.conv1d.weight' % name], P['predictor.%s_block.0.conv1d.bias' % name])
+    return pointwise(_relu(z, 'head_' + name, (cat, P['predictor.%s_block.0.conv1d.weight' % name], P['predictor.%s_block.0.conv1d.bias' % name])),
+                     P['predictor.%s_block.2.conv1d.weight' % name],
                      P['predictor.%s_block.2.conv1d.bias' % name])[..., 0]
 
 

@@ -6,6 +6,7 @@ import pytest
 import torch
 
 from oracle import vslnet_oracle as O
+from tests.helpers import assert_forced_relu_inside_noise
 from tests.helpers import load_golden, grad_tol, relu_flips
 
 pytestmark = pytest.mark.gpu
@@ -132,7 +133,7 @@ def test_losses_and_every_gradient(name):
     O.force_relu_signs(hip_masks)          # always: see forced_relu_deviation (oracle) -- legitimate only inside the forward noise
     oh, osl, oel = O.forward(Pg, cfg, b['word_ids'], b['char_ids'], b['vfeats'], b['v_mask'], b['q_mask'], want=want)
     O.force_relu_signs(None)
-    assert O.forced_relu_deviation() <= 2e-5, (flips, O.forced_relu_deviation())
+    assert_forced_relu_inside_noise(O, flips)
     keep = {'d_gated': want['gated'], 'd_venc': want['venc'], 'd_qenc': want['qenc'], 'd_video_affine': want['video_affine'],
             'd_embedding_net': want['embedding_net'], 'd_pred_s': want['pred_parts']['pred_s'],
             'd_cq_concat': want['cq_concat'], 'd_cq_attention': want['cq_attention']}

@@ -11,6 +11,7 @@ import pytest
 import torch
 
 from oracle import vslnet_oracle as O
+from tests.helpers import assert_forced_relu_inside_noise
 
 pytestmark = pytest.mark.gpu
 
@@ -132,7 +133,7 @@ def test_training_mode_matches_oracle_on_the_same_dropout_masks(dv, B, T, Lq, Lc
     O.force_relu_signs(None)
     O.force_dropout(None)
     assert n_sites == (41 if predictor == 'transformer' else 23)
-    assert O.forced_relu_deviation() <= 2e-5
+    assert_forced_relu_inside_noise(O)
     total.backward()
     fin = osl.detach().abs() < 1e29
     scale = max(1.0, float(osl.detach()[fin].abs().max()))
@@ -178,7 +179,7 @@ def test_headline_shape_at_full_size():
     total, (oh, osl, oel, _, _) = O.total_loss(Pg, cfg, b, training=True)
     O.force_relu_signs(None)
     O.force_dropout(None)
-    assert O.forced_relu_deviation() <= 2e-5, (flips, O.forced_relu_deviation())
+    assert_forced_relu_inside_noise(O, flips)
     total.backward()
     fin = osl.detach().abs() < 1e29
     scale = max(1.0, float(osl.detach()[fin].abs().max()))
@@ -381,7 +382,7 @@ def test_baseline_shapes_against_oracle(shape):
     Pg = {k: v.clone().requires_grad_(k not in O.FROZEN) for k, v in P.items()}
     total, (oh, osl, oel, _, _) = O.total_loss(Pg, cfg, b)
     O.force_relu_signs(None)
-    assert O.forced_relu_deviation() <= 2e-5, (shape['name'], flips, O.forced_relu_deviation())
+    assert_forced_relu_inside_noise(O, (shape['name'], flips))
     total.backward()
     fin = osl.detach().abs() < 1e29
     scale = max(1.0, float(osl.detach()[fin].abs().max()))

@@ -1,4 +1,3 @@
-python -m pytest tests/test_hip_parity.py tests/test_hip_training.py -m gpu -x -q > gpurun_out/r3a_pytest.log 2>&1; tail -3 gpurun_out/r3a_pytest.log
-grep -n "Error\|error\|assert\|mismatch" gpurun_out/r3a_pytest.log | head -10
-bash tools/bench_shapes.sh 2>&1 | head -4
-bash tools/prof_serial.sh --batch 16 --T 1024; head -8 gpurun_out/stats_serial.txt
+python -m pytest tests/test_hip_parity.py tests/test_hip_training.py tests/test_hip_rnn.py tests/test_bf16_mode.py -m gpu -x -q -s 2>&1 | grep "relu-noise\|passed\|failed" | sort | uniq -c | sort -k7 -g | tail -12
+echo "--- fp32 kernels"
+VSL_F32_GEMM=1 VSL_WGRAD_F32=1 python -m pytest tests/test_hip_parity.py tests/test_hip_training.py -m gpu -x -q -s 2>&1 | grep "relu-noise\|passed\|failed" | sort | uniq -c | sort -k7 -g | tail -6
