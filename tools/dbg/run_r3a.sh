@@ -1,3 +1,3 @@
-python -m pytest tests/test_hip_parity.py tests/test_hip_training.py tests/test_hip_rnn.py tests/test_bf16_mode.py -m gpu -x -q -s 2>&1 | grep "relu-noise\|passed\|failed" | sort | uniq -c | sort -k7 -g | tail -12
-echo "--- fp32 kernels"
-VSL_F32_GEMM=1 VSL_WGRAD_F32=1 python -m pytest tests/test_hip_parity.py tests/test_hip_training.py -m gpu -x -q -s 2>&1 | grep "relu-noise\|passed\|failed" | sort | uniq -c | sort -k7 -g | tail -6
+python -m pytest tests/test_hip_parity.py tests/test_hip_training.py -m gpu -x -q 2>&1 | tail -2
+for i in 1 2 3; do python bench.py --steps 60 --warmup 10 --no-cpu-baseline 2>/dev/null | python -c "import json,sys;d=json.load(sys.stdin);print(d['value'],d['ms_per_step'])"; done
+bash tools/bench_shapes.sh 2>&1 | sed -n 2,6p

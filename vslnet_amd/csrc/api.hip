@@ -476,15 +476,16 @@ void wgrad_flush(Ctx& c, hipStream_t sw) {
 // after a fork the chain that finishes LAST should own the main stream: its join wait is then already satisfied (a wait on
 // an event that has just been signalled costs 10 - 22 us).  At the headline shape the query side is the long one.
 bool query_chain_is_longer(const Plan& p, bool forward) {
-    // With the fused kernels of round 2 the video branch is the long one in both directions at every BASELINE shape (forward at the
-    // headline shape: vproj 41 + conv block 46 + attention 24 us against embed 30 + linear 17 + conv block 32 + attention 11):
-    // the main stream keeps it.  Measured FWD/BWD swap = 00 / 01 / 10 / 11: cfg2 1.031 / 1.034 / 1.036 / 1.032 ms, cfg4 1.116 / 1.132 /
-    // 1.121 / 1.141.  VSL_SWAP_FWD / VSL_SWAP_BWD = 1 hand the main stream to the query branch for A/B runs.
-    (void)p;
+    // Forward: the video branch (VisualProjection 19 + conv block 35 + attention 24 us) and the query branch (embedding 30 + linear 17 +
+    // conv block 25 + attention 11) are about even at the headline shape; the main stream keeps the video branch (swap: +0.6 %).
+    // Backward: since the split-bf16 kernels of round 3 the QUERY side ends last (cq_bwd_d .. embed_bwd: 147 us of isolated kernels against
+    // 133 for the video side), so it owns the main stream and the final join finds the video stream's event long signalled: 0.934-0.938 ->
+    // 0.930 ms with optimizer (profiles/r03_notes.md).  VSL_SWAP_FWD / VSL_SWAP_BWD = 0 / 1 override for A/B runs.
     static const char* ef = getenv("VSL_SWAP_FWD");
     static const char* eb = getenv("VSL_SWAP_BWD");
     const char* e = forward ? ef : eb;
-    return e && e[0] == '1';
+    if (e) return e[0] == '1';
+    return !forward && p.T <= 128;          // longer videos: the video side's attention backward grows with T^2 and ends last again
 }
 
 // dropout site ids: encoder application `app` (0 video, 1 query, 2 predictor pass 1, 3 predictor pass 2) uses
