@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 PEAK_MFMA_F32 = 157.3e12       # MI355X_MICROARCH.md: fp32-in MFMA = fp32 vector peak
 PEAK_HBM = 8.0e12              # HBM3E spec
 PEAK_MFMA_BF16 = 2.5e15        # dense bf16 MFMA (the split kernels issue 6 bf16 products per fp32-grade product)
+CPU_THREADS = 16               # cpu_baseline's intra-op threads: the best of the sweep on the GPU boxes (tools/cpu_threads_sweep.py, profiles/r03_notes.md)
 PROFILE_JSON = 'r03_profile.json'   # tools/collect_evidence.sh -> tools/make_profile_json.py
 
 
@@ -126,9 +127,10 @@ def cpu_baseline(configs, T, Lq, Lc, threads=None, budget_s=25.0):
     import statistics
     from oracle import vslnet_oracle as O
     phys, logical, model = host_cpu()
-    # the reference's CPU path saturates well before a large box's hardware threads (and gets pathologically slow when
-    # oversubscribed): one thread per physical core, capped at 32
-    nthr = max(1, min(threads or 32, phys))
+    # the reference's CPU path saturates well before a large box's hardware threads and gets pathologically slow when oversubscribed.
+    # Sweep on the GPU box's EPYC 9575F (tools/cpu_threads_sweep.py, pairs/s at B = 16 | B = 64): 4 threads 75 | 86, 8: 100 | 107,
+    # 12: 100 | 115, 16: 100 | 130, 32: 56 | 89, 64: 26 | 43, 128: 8 | 12 -> 16 threads
+    nthr = max(1, min(threads or CPU_THREADS, phys))
     torch.set_num_threads(nthr)
     cfg = O.make_cfg(video_feature_dim=configs.video_feature_dim, max_pos_len=configs.max_pos_len,
                      word_size=configs.word_size, drop_rate=configs.drop_rate)

@@ -23,6 +23,7 @@ What differs from the reference, by design:
 import argparse
 import json
 import os
+import time
 
 # RCCL brings its own streams; with ROCm's default of 4 hardware queues per process the library's two side streams then share
 # a queue with another stream and the fork/join overlap of the step is lost (measured: 1.25 -> 1.51 ms/step as soon as the
@@ -133,10 +134,31 @@ def train(configs, dataset, features, device, world, rank, log=print):
     eval_period = max(1, n_batches // 2)
     best_r1i7, global_step, history = -1.0, 0, []
     score_writer = open(os.path.join(model_dir, 'eval_results.txt'), 'w', encoding='utf-8') if rank == 0 else None
+    ckpt = runner.CheckpointWriter(device) if rank == 0 else None      # main_t7.py:125-126 without stalling the step
     log('start training...')
+    # VSL_E2E_TRACE=1: host-side seconds per phase of the loop (tools/e2e_rate.py prints them): what the CLI adds around the bench step
+    trace = {'batch': 0.0, 'step_enqueue': 0.0, 'log': 0.0, 'eval': 0.0, 'checkpoint': 0.0} if os.environ.get('VSL_E2E_TRACE') == '1' else None
+    if os.environ.get('VSL_E2E_TRACE') == '2':            # attribution run: synchronise at every phase boundary (serialises host and GPU)
+        trace = {'batch': 0.0, 'step_enqueue': 0.0, 'log': 0.0, 'eval': 0.0, 'checkpoint': 0.0}
+
+        def clock():
+            torch.cuda.synchronize()
+            return time.perf_counter()
+    else:
+        clock = time.perf_counter
+    epoch_end = []                                                         # wall clock at the end of every epoch (device idle)
     for epoch in range(configs.epochs):
         model.train()
-        for batch in (shards() if fused else train_loader):
+        it = iter(shards() if fused else train_loader)
+        while True:
+            t0 = clock()
+            try:
+                batch = next(it)
+            except StopIteration:
+                break
+            t1 = clock()
+            if trace is not None:
+                trace['batch'] += t1 - t0
             global_step += 1
             if fused:
                 # this rank's rows, padded to the GLOBAL batch widths; the losses are normalised with the global batch
@@ -171,6 +193,9 @@ def train(configs, dataset, features, device, world, rank, log=print):
                 torch.nn.utils.clip_grad_norm_(model.parameters(), configs.clip_norm)
                 optimizer.step()
                 scheduler.step()
+            t2 = clock()
+            if trace is not None:
+                trace['step_enqueue'] += t2 - t1
             if global_step % configs.period == 0 or global_step == 1:
                 lv = float(loss_t.item())
                 if world > 1:                                   # local partial sums of the global loss
@@ -179,24 +204,36 @@ def train(configs, dataset, features, device, world, rank, log=print):
                     lv = float(t.item())
                 history.append((global_step, lv))
                 log('step %6d | loss %.4f' % (global_step, lv))
+            t3 = clock()
+            if trace is not None:
+                trace['log'] += t3 - t2
             if global_step % eval_period == 0 or global_step % n_batches == 0:
                 if rank == 0:
                     model.eval()
                     r1i3, r1i5, r1i7, mi, score_str = runner.eval_test(model, test_loader, device, 'test', epoch + 1, global_step)
+                    t4 = clock()
+                    if trace is not None:
+                        trace['eval'] += t4 - t3
                     log('Epoch: %2d | Step: %5d | r1i3: %.2f | r1i5: %.2f | r1i7: %.2f | mIoU: %.2f' % (epoch + 1, global_step, r1i3, r1i5, r1i7, mi))
                     score_writer.write(score_str)
                     score_writer.flush()
                     history.append((global_step, {'r1i3': r1i3, 'r1i5': r1i5, 'r1i7': r1i7, 'mIoU': mi}))
                     if r1i7 >= best_r1i7:
                         best_r1i7 = r1i7
-                        torch.save(model.state_dict(), os.path.join(model_dir, '{}_{}.t7'.format(configs.model_name, global_step)))
-                        runner.filter_checkpoints(model_dir, suffix='t7', max_to_keep=3)
+                        ckpt.save_flat(model, os.path.join(model_dir, '{}_{}.t7'.format(configs.model_name, global_step)), model_dir,
+                                       suffix='t7', max_to_keep=3)
+                        if trace is not None:
+                            trace['checkpoint'] += clock() - t4
                     model.train()
                 if world > 1:
                     torch.distributed.barrier()
+        torch.cuda.synchronize(device)
+        epoch_end.append(time.perf_counter())
     if score_writer:
         score_writer.close()
-    return {'history': history, 'model_dir': model_dir, 'steps': global_step}
+    if ckpt is not None:
+        ckpt.close()                                                       # every checkpoint is on disk when train() returns
+    return {'history': history, 'model_dir': model_dir, 'steps': global_step, 'trace': trace, 'epoch_end': epoch_end}
 
 
 def test(configs, parser, argv, dataset, features, device, log=print):

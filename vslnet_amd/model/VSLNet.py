@@ -155,6 +155,16 @@ class VSLNet(nn.Module):
         self._engine_for(None)
         return self._flat, self._flat_grad
 
+    def state_dict_from_flat(self, host_flat):
+        """`self.state_dict()` (same keys, order, shapes) with the trainable entries taken from a HOST copy of the flat bucket and the
+        frozen ones (pad_vec, glove_vec) from a host copy made once -- the checkpoint writer's path (runner.CheckpointWriter.save_flat)."""
+        from collections import OrderedDict
+        eng = self._engine_for(None)
+        views = {n: host_flat[o:o + k].view(shp) for n, o, k, shp in eng.layout}
+        if getattr(self, '_frozen_host', None) is None:
+            self._frozen_host = {k: v.detach().cpu() for k, v in self.state_dict().items() if k not in views}
+        return OrderedDict((k, views[k] if k in views else self._frozen_host[k]) for k in self.state_dict().keys())
+
     # ---- reference API ---------------------------------------------------------------------------------------------
     def forward(self, word_ids, char_ids, video_features, v_mask, q_mask):
         self._engine_for(video_features.device)

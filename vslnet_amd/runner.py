@@ -34,6 +34,93 @@ def filter_checkpoints(model_dir, suffix='t7', max_to_keep=5):
         os.remove(p)
 
 
+class _LazyState:
+    """state_dict of a flat-bucket module from a host copy of the bucket (built on the worker thread)."""
+
+    def __init__(self, model, host_flat):
+        self.model, self.host = model, host_flat
+
+    def build(self):
+        return self.model.state_dict_from_flat(self.host.clone())        # (a private copy: the pinned buffer is reused two saves later)
+
+
+class CheckpointWriter:
+    """`torch.save(model.state_dict(), path)` + `filter_checkpoints` (main_t7.py:125-126) off the training loop: the state is copied to
+    pinned host memory on a side stream (the step's kernels keep running), a worker thread writes the file and prunes old ones.
+    The reference saves whenever r1i7 >= the best so far, i.e. at every evaluation while the metric ties; a synchronous save costs
+    ~14 ms (D2H of the state, pickle, file write) = 15 training steps at the headline shape (tools/e2e_rate.py)."""
+
+    def __init__(self, device):
+        import queue
+        import threading
+        self.device = torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.device) if self.device.type == 'cuda' else None
+        self.q = queue.Queue()
+        self.err = None
+        self.thread = threading.Thread(target=self._work, daemon=True)
+        self.thread.start()
+
+    def _work(self):
+        while True:
+            item = self.q.get()
+            if item is None:
+                return
+            state, event, path, model_dir, suffix, keep = item
+            try:
+                if event is not None:
+                    event.synchronize()
+                if isinstance(state, _LazyState):
+                    state = state.build()
+                torch.save(state, path)
+                filter_checkpoints(model_dir, suffix=suffix, max_to_keep=keep)
+            except Exception as e:                       # surfaced by close()
+                self.err = e
+
+    def save(self, state_dict, path, model_dir, suffix='t7', max_to_keep=3):
+        if self.stream is None:
+            self.q.put(({k: v.clone() for k, v in state_dict.items()}, None, path, model_dir, suffix, max_to_keep))
+            return
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))          # the values as of this point of the training stream
+        with torch.cuda.stream(self.stream):
+            host = {}
+            for k, v in state_dict.items():
+                h = torch.empty(v.shape, dtype=v.dtype, device='cpu', pin_memory=True)
+                h.copy_(v, non_blocking=True)
+                host[k] = h
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        # the optimizer must not overwrite the parameters before the copies have read them
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        self.q.put((host, ev, path, model_dir, suffix, max_to_keep))
+
+    def save_flat(self, model, path, model_dir, suffix='t7', max_to_keep=3):
+        """The same for a module whose trainable parameters live in ONE flat bucket (vslnet_amd.model.VSLNet): a device-side snapshot of the
+        bucket on the training stream (4.4 MB, microseconds; the optimizer may go on at once), ONE device-to-host copy of it on the side
+        stream, and the worker thread rebuilds the reference's state_dict (same keys, shapes, order) from views of the host copy.  The
+        per-tensor path above costs ~110 small copies the training stream has to wait for (3.4 ms per checkpoint)."""
+        flat, _ = model.flat_parameters
+        snap = flat.clone()
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            if getattr(self, '_pin', None) is None or self._pin[0].numel() != snap.numel():
+                self._pin = [torch.empty(snap.shape, dtype=snap.dtype, device='cpu', pin_memory=True) for _ in range(2)]
+                self._pin_i = 0
+            self._pin_i ^= 1
+            host = self._pin[self._pin_i]                 # two buffers: the worker may still be writing the previous checkpoint
+            host.copy_(snap, non_blocking=True)
+            snap.record_stream(self.stream)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self.q.put((_LazyState(model, host), ev, path, model_dir, suffix, max_to_keep))
+
+    def close(self):
+        self.q.put(None)
+        self.thread.join()
+        if self.err is not None:
+            raise self.err
+
+
 def get_last_checkpoint(model_dir, suffix='t7'):
     """runner_utils_t7.py:35-45."""
     paths = glob.glob(os.path.join(model_dir, '*.{}'.format(suffix)))
