@@ -1096,9 +1096,11 @@ void free_plan(Plan* p) {
 }
 
 // Per-shape plans (workspace layout + reduction tables).  The collate narrows every batch to its own max T / Lq / Lc, so a
-// long training run visits hundreds of shapes: the cache is bounded and evicts the least recently used plan together with
-// its two device tables.  (A forward and its backward use the same shape back to back, so a live plan is never evicted.)
-constexpr size_t MAX_PLANS = 64;
+// long training run visits hundreds of shapes (Charades at batch 16: T in 40..128 x Lq in 4..10 x Lc in 5..12).  A plan is two small
+// device tables (< 100 KB), a miss costs a rebuild, two hipMalloc and -- on eviction -- a device synchronise, so the cache holds every
+// shape a realistic run sees (64 entries thrashed under shuffled real-data batches) and evicts the least recently used one
+// beyond that.  (A forward and its backward use the same shape back to back, so a live plan is never evicted.)
+constexpr size_t MAX_PLANS = 2048;
 int get_plan(vsl_handle_s* h, int B, int T, int Lq, int Lc, Plan** out) {
     auto key = std::make_tuple(B, T, Lq, Lc);
     auto it = h->plans.find(key);

@@ -177,7 +177,10 @@ class Engine:
         with torch.cuda.device(self.device):
             self._call(self.lib.vsl_workspace_floats(self.h, B, T, Lq, Lc, C.byref(n)))
         if self._ws is None or self._ws.numel() < n.value:
-            self._ws = None                                  # drop the old one first (the last forward may still hold it)
+            # drop EVERY reference to the old one first (the last forward's io / keep-alive tuple hold it too): old and new must not
+            # coexist at the growth peak beside an HBM-resident dataset
+            self._ws = None
+            self._last = self._last_ws = self._keep = None
             self._ws = torch.empty(int(n.value * 1.25) if self._grown else n.value, dtype=torch.float32, device=self.device)
             self._grown = True
         return self._ws
