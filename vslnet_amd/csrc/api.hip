@@ -657,7 +657,8 @@ void enc_bwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float*
     float* p_ln1g = c.slab(P.ln1g, D, ntiles);
     float* p_ln1b = c.slab(P.ln1b, D, ntiles);
     LAUNCH("qkv_bwd", launch_qkv_bwd(c.W(t.dq), c.W(t.dk), c.W(t.dv), c.W(w.y[3]), c.W(t.dr), c.P(P.ln1g), c.PK(K.qkv_t),
-                          c.W(t.ga), p_ln1g, p_ln1b, R, c.drop(app * 16 + 4), c.s, attn_bwd_dq_slabs(L)));
+                          c.W(t.ga), p_ln1g, p_ln1b, R, c.drop(app * 16 + 4), c.s, attn_bwd_dq_slabs(L),
+                          split_gemm_enabled() ? reinterpret_cast<const uint16_t*>(c.PK(K.qkv_t3)) : nullptr));
     {   // out_layer + fused q/k/v weight gradients: every input exists now -> side stream, beside the conv chain
         WgradBatch wb;
         memset(&wb, 0, sizeof wb);

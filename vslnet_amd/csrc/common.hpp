@@ -343,6 +343,78 @@ __host__ __device__ __forceinline__ size_t pack3_plane(int K, int ncols) { retur
 __host__ __device__ __forceinline__ size_t pack3_index(int k, int col, int ncols) { return ((size_t)(k >> 4) * ncols + col) * 16 + (k & 15); }
 __host__ __device__ __forceinline__ size_t pack3_floats(int K, int ncols) { return (3 * pack3_plane(K, ncols) + 1) / 2; }
 
+// ---------------------------------------------------------------------------------------------------------
+// Row-tile GEMM on the bf16 matrix cores from PRE-SPLIT operands:  acc[t] (32 x 32) += A[32][K] * Bm[:, col0 + t * cstep + 0..31]
+//   A : three bf16 planes (terms h, m, l) of the 32-row tile in LDS, `ldb` elements per row (a multiple of 8 with ldb * 2 % 128 == 16:
+//       conflict-free ds_read_b128), `ps` elements between planes.  The kernel splits every value ONCE where it stages the tile (a per-wave
+//       split in the GEMM loop does not pay: profiles/r03_notes.md).
+//   W3: split pack of Bm (PackJob type 6 / 7), K a multiple of 16.
+// Lane (i, h) reads row i, k = 16 s + 8 h .. + 7 of each plane (one step ahead) and column col0 + i of each weight plane (GS3_NB steps ahead
+// in a register ring); 6 MFMAs per step and tile, two alternating accumulators when there is one tile.
+// ---------------------------------------------------------------------------------------------------------
+struct Frag3 { u32x4_t t[3]; };
+constexpr int GS3_NB = 4;
+template <int NT>
+__device__ __forceinline__ void gemm32pl(const uint16_t* __restrict__ Ap, int ldb, int ps, int K, const uint16_t* __restrict__ W3, int ncols,
+                                         int col0, int cstep, f32x16 (&acc)[NT]) {
+    const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
+    const uint16_t* ar = Ap + i * ldb + 8 * h;
+    const size_t plane = pack3_plane(K, ncols);
+    const uint16_t* bp = W3 + ((size_t)(col0 + i)) * 16 + 8 * h;
+    const int ns = K >> 4;
+    f32x16 acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+    Frag3 a[2], b[GS3_NB][NT];
+    auto aread = [&](int s, Frag3& f) {
+        const uint16_t* p = ar + 16 * min(s, ns - 1);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) f.t[q] = *reinterpret_cast<const u32x4_t*>(p + q * ps);
+    };
+    auto bload = [&](int s, Frag3 (&f)[NT]) {
+        const uint16_t* p = bp + (size_t)min(s, ns - 1) * ncols * 16;         // past the end: a harmless re-read
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) f[t].t[q] = *reinterpret_cast<const u32x4_t*>(p + q * plane + (size_t)t * cstep * 16);
+    };
+    static_for<0, GS3_NB>([&](auto uc) { bload(decltype(uc)::value, b[decltype(uc)::value]); });
+    aread(0, a[0]);
+    for (int s0 = 0; s0 < ns; s0 += GS3_NB)
+        static_for<0, GS3_NB>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            const int s = s0 + u;
+            if (s < ns) {
+                aread(s + 1, a[(u + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                constexpr int TA[6] = {1, 0, 2, 0, 1, 0}, TB[6] = {1, 2, 0, 1, 0, 0};       // (a term, b term): mm, hl, lh, hm, mh, hh
+#pragma unroll
+                for (int p = 0; p < 6; ++p)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        if (NT == 1 && (p & 1)) acc2 = mfma_bf16(a[u & 1].t[TA[p]], b[u][t].t[TB[p]], acc2);
+                        else acc[t] = mfma_bf16(a[u & 1].t[TA[p]], b[u][t].t[TB[p]], acc[t]);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+                bload(s + GS3_NB, b[u]);
+            }
+        });
+    if (NT == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][r] += acc2[r];
+    }
+}
+// stores a float4 of a row tile (row r, columns c .. c + 3) into the three planes
+__device__ __forceinline__ void split_store4(uint16_t* __restrict__ P0, int ldb, int ps, int r, int c, const float4& v) {
+    uint32_t h0, m0, l0, h1, m1, l1;
+    split3(v.x, v.y, h0, m0, l0);
+    split3(v.z, v.w, h1, m1, l1);
+    uint16_t* d = P0 + r * ldb + c;
+    *reinterpret_cast<u32x2_t*>(d) = u32x2_t{h0, h1};
+    *reinterpret_cast<u32x2_t*>(d + ps) = u32x2_t{m0, m1};
+    *reinterpret_cast<u32x2_t*>(d + 2 * ps) = u32x2_t{l0, l1};
+}
+
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
 template <int NT>

@@ -69,7 +69,10 @@ struct WgradJob {
     float* out;           // partial slabs [nchunk][N][K]
     float* out_bias[3];   // partial slabs [nchunk][128] per G block (nullable)
 };
-constexpr int WG_ROWS = 256;
+#ifndef VSL_WG_ROWS
+#define VSL_WG_ROWS 256
+#endif
+constexpr int WG_ROWS = VSL_WG_ROWS;     // rows per weight-gradient chunk = workgroup (one partial slab each)
 constexpr int MAX_WJOBS = 12;
 struct WgradBatch { WgradJob j[MAX_WJOBS]; int n; int start[MAX_WJOBS + 1]; };   // start: first workgroup of each job (launch_wgrad fills it)
 
@@ -232,7 +235,7 @@ void launch_attn_bwd(const float* Q, const float* K, const float* V, const float
 int attn_bwd_dq_slabs(int L);             // L > 256: dQ is written as this many (R, 128) partial slabs (one per 256-key block); k_qkv_bwd adds them
 void launch_qkv_bwd(const float* dQ, const float* dK, const float* dV, const float* x, const float* dr,
                     const float* ln_g, const float* WTpack, float* dx, float* p_lng, float* p_lnb, int R, Drop d1, hipStream_t s,
-                    int dq_slabs = 1);
+                    int dq_slabs = 1, const uint16_t* WT3 = nullptr);      // WT3: split pack of the (384, 128) operand -> bf16 matrix cores
 void launch_cqcat_bwd(const float* dg0, const float* dg1, const float* dg2, const float* dh_loss, const float* f2,
                       const float* hscore, const float* wh, const float* W1Tpack, float* df2, float* df1, float* p_wh,
                       float* p_bh, int R, hipStream_t s);

@@ -76,10 +76,13 @@ def load_library():
                 finally:
                     fcntl.flock(lock, fcntl.LOCK_UN)
     lib = C.CDLL(path)
-    if not hasattr(lib, 'vsl_abi_version') or lib.vsl_abi_version() != ABI_VERSION:
+    explicit = bool(os.environ.get('VSLNET_HIP_LIB'))     # an A/B baseline built from an older revision (tools/build_base.py) may predate the check:
+    #                                                       new vsl_io fields are appended, so an older library simply does not read them
+    if not explicit and (not hasattr(lib, 'vsl_abi_version') or lib.vsl_abi_version() != ABI_VERSION):
         raise VslError('%s implements another ABI version than this binding (%d): rebuild it (python -m vslnet_amd.build --force)' % (path, ABI_VERSION))
-    lib.vsl_early_grad_offset.argtypes = [C.c_void_p]
-    lib.vsl_early_grad_offset.restype = C.c_int64
+    if hasattr(lib, 'vsl_early_grad_offset'):
+        lib.vsl_early_grad_offset.argtypes = [C.c_void_p]
+        lib.vsl_early_grad_offset.restype = C.c_int64
     lib.vsl_last_error.restype = C.c_char_p
     lib.vsl_create.argtypes = [C.POINTER(vsl_config), C.POINTER(C.c_void_p)]
     lib.vsl_destroy.argtypes = [C.c_void_p]
