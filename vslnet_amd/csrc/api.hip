@@ -47,7 +47,7 @@ struct ModelP {
     int sln_g, sln_b, eln_g, eln_b, s0w, s0b, s1w, s1b, e0w, e0b, e1w, e1b;
     int l_wih[2], l_whh[2], l_bih[2], l_bhh[2];     // rnn predictor: start / end DynamicRNN (layers_t7.py:302-313)
 };
-struct ModelPk { int va_f, va_f16, va_f3, l_t3[2], emb_f, emb_t; EncPk fe, pe; int cqa_f, cqa_t, cat1_f, cat1_t, s0_f, s0_t, e0_f, e0_t, ccw_img;
+struct ModelPk { int va_f, va_f16, va_f3, l_t3[2], emb_f, emb_t, emb_f3, emb_t3, emb_t3_cols; EncPk fe, pe; int cqa_f, cqa_t, cat1_f, cat1_t, s0_f, s0_t, e0_f, e0_t, ccw_img;
                  int l_f[2], l_t[2], zero128; };
 
 struct EncWs { int64_t x0, y[4], u[4], mask[4], h1, q, k, v, lse, att, r, h2, out; int R, L; };
@@ -296,6 +296,14 @@ void build_packs(vsl_handle_s* h) {
     K.va_f3 = pk.fwd3(P.va_w, D, c.video_feature_dim, c.video_feature_dim, 128);      // split pack: fp32 grade on the bf16 matrix cores
     K.emb_f = pk.fwd(P.emb_w, D, c.word_dim + 100, c.word_dim + 100);
     K.emb_t = pk.tr(P.emb_w, D, c.word_dim + 100, c.word_dim + 100);
+    K.emb_f3 = pk.fwd3(P.emb_w, D, c.word_dim + 100, c.word_dim + 100);
+    {   // data-gradient operand with its column count padded to whole 128-column tiles (the pad columns are never stored)
+        const int EWc = (c.word_dim + 100 + 127) / 128 * 128;
+        K.emb_t3_cols = EWc;
+        K.emb_t3 = (int)h->pack_floats;
+        h->pack_floats += (int64_t)((pack3_floats(D, EWc) + 3) & ~size_t(3));
+        h->jobs.push_back(PackJob{P.emb_w, K.emb_t3, D, c.word_dim + 100, c.word_dim + 100, 7, EWc, 0, 0, D, D});
+    }
     build_encoder_packs(pk, h, P.fe, K.fe);
     if (c.predictor == 0) {
         for (int l = 0; l < 2; ++l) {
@@ -575,6 +583,9 @@ void run_forward(Ctx& c) {
     LAUNCH("embed_fwd", launch_embed_fwd(io.word_ids, io.char_ids, io.pad_vec, c.P(P.unk), io.glove_vec, c.P(P.char_tab), char_ptrs(c), c.PK(K.ccw_img), c.W(p.E),
                      reinterpret_cast<int8_t*>(c.W(p.argpos)), Rq, p.Lc, cf.word_dim, cf.char_dim, c.drop(SITE_WORD),
                      c.drop(SITE_CHAR), c.s));
+    if (split_gemm_enabled() && (cf.word_dim + 100) % 16 == 0)
+        LAUNCH("linear_fwd", launch_linear_fwd3(c.W(p.E), reinterpret_cast<const uint16_t*>(c.PK(K.emb_f3)), c.P(P.emb_b), c.W(p.qf), Rq, cf.word_dim + 100, c.s));
+    else
     LAUNCH("linear_fwd", launch_linear_fwd(c.W(p.E), c.PK(K.emb_f), c.P(P.emb_b), c.W(p.qf), Rq, cf.word_dim + 100, c.s));
     enc_fwd(c, P.fe, K.fe, p.qe, c.W(p.qf), io.q_mask, B, 1);
     c.s = c.main;
@@ -955,6 +966,9 @@ void run_backward(Ctx& c) {
         if (!fits) LAUNCH("wgrad", launch_wgrad(pw_query, c.s));
         c.s = qs;
     }
+    if (split_gemm_enabled())
+        LAUNCH("linear_bwd_data", launch_linear_bwd_data3(c.W(p.dqf), reinterpret_cast<const uint16_t*>(c.PK(K.emb_t3)), c.W(p.dE), Rq, EW, K.emb_t3_cols, c.s));
+    else
     LAUNCH("linear_bwd_data", launch_linear_bwd_data(c.W(p.dqf), c.PK(K.emb_t), c.W(p.dE), Rq, EW, c.s));
     {
         const int nce = (Rq + EMB_CHUNK - 1) / EMB_CHUNK;

@@ -354,31 +354,38 @@ __host__ __device__ __forceinline__ size_t pack3_floats(int K, int ncols) { retu
 // ---------------------------------------------------------------------------------------------------------
 struct Frag3 { u32x4_t t[3]; };
 constexpr int GS3_NB = 4;
+template <int NT> struct Ring3 { Frag3 b[GS3_NB][NT]; };
+// weight fragments of K = 16 step s (past the end: a harmless re-read of the last step)
+template <int NT>
+__device__ __forceinline__ void ring3_load(Frag3 (&f)[NT], const uint16_t* __restrict__ W3, int K, int ncols, int col0, int cstep, int s) {
+    const int lane = threadIdx.x & 63, ns = K >> 4;
+    const size_t plane = pack3_plane(K, ncols);
+    const uint16_t* p = W3 + ((size_t)min(s, ns - 1) * ncols + col0 + (lane & 31)) * 16 + 8 * (lane >> 5);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) f[t].t[q] = *reinterpret_cast<const u32x4_t*>(p + q * plane + (size_t)t * cstep * 16);
+}
+// the first GS3_NB steps: a kernel calls this at its entry, so that the fragments' latency hides under the staging of the A tile
+template <int NT>
+__device__ __forceinline__ void ring3_prefetch(Ring3<NT>& r, const uint16_t* __restrict__ W3, int K, int ncols, int col0, int cstep) {
+    static_for<0, GS3_NB>([&](auto uc) { ring3_load<NT>(r.b[decltype(uc)::value], W3, K, ncols, col0, cstep, decltype(uc)::value); });
+}
 template <int NT>
 __device__ __forceinline__ void gemm32pl(const uint16_t* __restrict__ Ap, int ldb, int ps, int K, const uint16_t* __restrict__ W3, int ncols,
-                                         int col0, int cstep, f32x16 (&acc)[NT]) {
+                                         int col0, int cstep, f32x16 (&acc)[NT], Ring3<NT>& ring) {
     const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
     const uint16_t* ar = Ap + i * ldb + 8 * h;
-    const size_t plane = pack3_plane(K, ncols);
-    const uint16_t* bp = W3 + ((size_t)(col0 + i)) * 16 + 8 * h;
     const int ns = K >> 4;
     f32x16 acc2;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
-    Frag3 a[2], b[GS3_NB][NT];
+    Frag3 a[2];
     auto aread = [&](int s, Frag3& f) {
         const uint16_t* p = ar + 16 * min(s, ns - 1);
 #pragma unroll
         for (int q = 0; q < 3; ++q) f.t[q] = *reinterpret_cast<const u32x4_t*>(p + q * ps);
     };
-    auto bload = [&](int s, Frag3 (&f)[NT]) {
-        const uint16_t* p = bp + (size_t)min(s, ns - 1) * ncols * 16;         // past the end: a harmless re-read
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int q = 0; q < 3; ++q) f[t].t[q] = *reinterpret_cast<const u32x4_t*>(p + q * plane + (size_t)t * cstep * 16);
-    };
-    static_for<0, GS3_NB>([&](auto uc) { bload(decltype(uc)::value, b[decltype(uc)::value]); });
     aread(0, a[0]);
     for (int s0 = 0; s0 < ns; s0 += GS3_NB)
         static_for<0, GS3_NB>([&](auto uc) {
@@ -392,17 +399,24 @@ __device__ __forceinline__ void gemm32pl(const uint16_t* __restrict__ Ap, int ld
                 for (int p = 0; p < 6; ++p)
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
-                        if (NT == 1 && (p & 1)) acc2 = mfma_bf16(a[u & 1].t[TA[p]], b[u][t].t[TB[p]], acc2);
-                        else acc[t] = mfma_bf16(a[u & 1].t[TA[p]], b[u][t].t[TB[p]], acc[t]);
+                        if (NT == 1 && (p & 1)) acc2 = mfma_bf16(a[u & 1].t[TA[p]], ring.b[u][t].t[TB[p]], acc2);
+                        else acc[t] = mfma_bf16(a[u & 1].t[TA[p]], ring.b[u][t].t[TB[p]], acc[t]);
                     }
                 __builtin_amdgcn_sched_barrier(0);
-                bload(s + GS3_NB, b[u]);
+                ring3_load<NT>(ring.b[u], W3, K, ncols, col0, cstep, s + GS3_NB);
             }
         });
     if (NT == 1) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][r] += acc2[r];
     }
+}
+template <int NT>
+__device__ __forceinline__ void gemm32pl(const uint16_t* __restrict__ Ap, int ldb, int ps, int K, const uint16_t* __restrict__ W3, int ncols,
+                                         int col0, int cstep, f32x16 (&acc)[NT]) {
+    Ring3<NT> ring;
+    ring3_prefetch<NT>(ring, W3, K, ncols, col0, cstep);
+    gemm32pl<NT>(Ap, ldb, ps, K, W3, ncols, col0, cstep, acc, ring);
 }
 // stores a float4 of a row tile (row r, columns c .. c + 3) into the three planes
 __device__ __forceinline__ void split_store4(uint16_t* __restrict__ P0, int ldb, int ps, int r, int c, const float4& v) {

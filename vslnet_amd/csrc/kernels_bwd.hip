@@ -1331,14 +1331,30 @@ __global__ __launch_bounds__(256) void k_cq_bwd_d(CqBwdArgs a) {
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int b = blockIdx.x;
     const size_t qrow = (size_t)b * Lq;
+    // Every cross-tile / cross-word sum below issues its loads in batches before the (ordered) additions: the kernel is one workgroup per
+    // sample with nothing else to hide a memory round trip per loop iteration (82 % of its wave cycles were parked; 26 -> 18 us).  Round 2
+    // measured the same change as a net loss because the query chain then took CUs from the (then critical) video chain; since round 3 the
+    // query chain IS the critical tail of the backward.
     if (tid < Lq) {
         float s = 0.f;
-        for (int t = 0; t < ntile; ++t) s += a.P3[(size_t)(b * ntile + t) * Lq + tid];
+        for (int t0 = 0; t0 < ntile; t0 += 4) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = t0 + u < ntile ? a.P3[(size_t)(b * ntile + t0 + u) * Lq + tid] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s += v[u];
+        }
         cs2[tid] = s;
     }
     if (tid < D) {                             // dpb[o] = sum over tiles of colsum(df2)
         float s = 0.f;
-        for (int t = 0; t < ntile; ++t) s += a.P5[(size_t)(b * ntile + t) * D + tid];
+        for (int t0 = 0; t0 < ntile; t0 += 4) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = t0 + u < ntile ? a.P5[(size_t)(b * ntile + t0 + u) * D + tid] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s += v[u];
+        }
         v128[tid] = s;
         a.p_bcat[(size_t)b * D + tid] = s;
     }
@@ -1347,10 +1363,17 @@ __global__ __launch_bounds__(256) void k_cq_bwd_d(CqBwdArgs a) {
     for (int e = tid; e < Lq * (D / 4); e += 256) {
         const int j = e >> 5, c4 = (e & 31) * 4;
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int t = 0; t < ntile; ++t) {
-            const float4 x = *reinterpret_cast<const float4*>(a.P1 + ((size_t)(b * ntile + t) * 2 + 1) * Lq * D + (size_t)j * D + c4);
-            const float4 y = *reinterpret_cast<const float4*>(a.P4 + (size_t)(b * ntile + t) * Lq * D + (size_t)j * D + c4);
-            s.x += x.x + y.x; s.y += x.y + y.y; s.z += x.z + y.z; s.w += x.w + y.w;
+        for (int t0 = 0; t0 < ntile; t0 += 4) {
+            float4 x[4], y[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = min(t0 + u, ntile - 1);
+                x[u] = *reinterpret_cast<const float4*>(a.P1 + ((size_t)(b * ntile + t) * 2 + 1) * Lq * D + (size_t)j * D + c4);
+                y[u] = *reinterpret_cast<const float4*>(a.P4 + (size_t)(b * ntile + t) * Lq * D + (size_t)j * D + c4);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (t0 + u < ntile) { s.x += x[u].x + y[u].x; s.y += x[u].y + y[u].y; s.z += x[u].z + y[u].z; s.w += x[u].w + y[u].w; }
         }
         const float4 wq = *reinterpret_cast<const float4*>(a.w4Q + c4);
         const uint32_t base = (uint32_t)(((b + a.b_off) * Lq + j) * D + c4);
@@ -1360,8 +1383,14 @@ __global__ __launch_bounds__(256) void k_cq_bwd_d(CqBwdArgs a) {
     }
     if (tid < D) {                             // dw4Q[c] = sum_j colsum(dS)[j] * Qd[j][c]
         float s = 0.f;
-#pragma unroll 4
-        for (int j = 0; j < Lq; ++j) s += cs2[j] * a.Qf[(qrow + j) * D + tid] * drop_mul(a.dq, (uint32_t)(((b + a.b_off) * Lq + j) * D + tid));
+        for (int j0 = 0; j0 < Lq; j0 += 8) {
+            float qv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) qv[u] = a.Qf[(qrow + min(j0 + u, Lq - 1)) * D + tid];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (j0 + u < Lq) s += cs2[j0 + u] * qv[u] * drop_mul(a.dq, (uint32_t)(((b + a.b_off) * Lq + j0 + u) * D + tid));
+        }
         a.p_w4Q[(size_t)b * D + tid] = s;
     }
     // ---- pooled-query path: pb = W2 pooled + bcat ; pooled = sum_j alpha_j Q[j] ; alpha = softmax(Q w + mask)
@@ -1397,8 +1426,14 @@ __global__ __launch_bounds__(256) void k_cq_bwd_d(CqBwdArgs a) {
     __syncthreads();
     if (tid < D) {
         float s = 0.f;
-#pragma unroll 8
-        for (int j = 0; j < Lq; ++j) s += sv[j] * a.Qf[(qrow + j) * D + tid];
+        for (int j0 = 0; j0 < Lq; j0 += 8) {
+            float qv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) qv[u] = a.Qf[(qrow + min(j0 + u, Lq - 1)) * D + tid];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (j0 + u < Lq) s += sv[j0 + u] * qv[u];
+        }
         a.p_pool[(size_t)b * D + tid] = s;
     }
     for (int e = tid; e < Lq * D; e += 256) {
@@ -1556,6 +1591,9 @@ __global__ __launch_bounds__(256) void k_embed_bwd(const float* __restrict__ dE,
         pos[e] = ps;
     }
     float bacc = 0.f, uacc0 = 0.f, uacc1 = 0.f;
+        // (Measured in round 3: packing the rows of all words of the chunk densely and running groups of 2 - 3 16-row tiles between two
+        // barriers -- instead of one word and one tile per barrier pair -- is no faster: 49.8 us (2 tiles, 75 KB of LDS = 2 workgroups per CU)
+        // and 81.9 us (3 tiles, 94 KB = 1 per CU = two rounds) against 45.6; inside the step 0.9108 against 0.9120 ms over four same-box pairs.)
     for (int wi = 0; wi < nw; ++wi) {
         const int r = rbeg + wi;
         if (word_ids[r] == 1) {               // unk_vec row of the [pad; unk; glove] table (:41)

@@ -276,4 +276,90 @@ void launch_qkv_bwd(const float* dQ, const float* dK, const float* dV, const flo
                        p_lnb, R, d1, dq_slabs, (size_t)R * D, WT3);
 }
 
+// =========================================================================================================
+// a5 Embedding.linear (layers_t7.py:81-87): Y = A W^T + b, A = [word | char] rows (R, K = word_dim + 100), and its data gradient
+// dA = G W.  The query side is 40 row tiles at the headline shape -- pure latency -- and sits on the critical path of both directions
+// (forward: ahead of the query encoder pass; backward: the tail of the step), so both kernels stage their WHOLE tile once, split it into
+// bf16 planes on the way (one barrier) and run the product on the bf16 matrix cores.  fp32-input versions: k_linear_fwd (K streamed in four
+// chunks with two barriers each, 16.6 us) and k_linear_bwd_data (16.0 us), still used by the rnn head's gate projections.
+// =========================================================================================================
+__global__ __launch_bounds__(256) void k_linear_fwd3(const float* __restrict__ A, const uint16_t* __restrict__ W3, const float* __restrict__ bias,
+                                                     float* __restrict__ Y, int R, int K, int ldb) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t pl[];     // three planes [32][ldb]
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int r0 = blockIdx.x * TILE_M, k4 = K >> 2;
+    Ring3<1> ring;
+    ring3_prefetch<1>(ring, W3, K, D, 32 * w, 0);                    // weight fragments first: in flight during the staging
+    constexpr int MAXQ = 16;                                         // K <= 512: the whole tile in ONE round of loads (one memory latency)
+    float4 v[MAXQ];
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) {
+        const int e = tid + q * 256, rr = e / k4, c = (e - rr * k4) * 4;
+        v[q] = (e < TILE_M * k4 && r0 + rr < R) ? *reinterpret_cast<const float4*>(A + (size_t)(r0 + rr) * K + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) {
+        const int e = tid + q * 256, rr = e / k4, c = (e - rr * k4) * 4;
+        if (e < TILE_M * k4) split_store4(pl, ldb, TILE_M * ldb, rr, c, v[q]);
+    }
+    __syncthreads();
+    f32x16 acc[1];
+    zero_acc(acc);
+    gemm32pl<1>(pl, ldb, TILE_M * ldb, K, W3, D, 32 * w, 0, acc, ring);
+    const int col = 32 * w + (lane & 31);
+    const float bv = bias[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int gr = r0 + acc_row(r, lane);
+        if (gr < R) Y[(size_t)gr * D + col] = acc[0][r] + bv;
+    }
+}
+static int plane_ld(int K) { int l = K + 8; while (((l / 8) & 1) == 0) l += 8; return l; }      // row stride / 16 bytes odd: conflict-free b128 reads
+void launch_linear_fwd3(const float* A, const uint16_t* W3, const float* bias, float* Y, int R, int K, hipStream_t s) {
+    if (K > 512 || K % 16) { fprintf(stderr, "[vslnet_hip] launch_linear_fwd3: K=%d unsupported\n", K); return; }
+    const int ldb = plane_ld(K);
+    const size_t shm = (size_t)3 * TILE_M * ldb * sizeof(uint16_t);
+    static size_t ok = 0;
+    ensure_dynamic_lds((const void*)k_linear_fwd3, shm, ok, "k_linear_fwd3");
+    VSL_LAUNCH(k_linear_fwd3, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm, s, A, W3, bias, Y, R, K, ldb);
+}
+// dA (R, K) = G (R, 128) Bm, Bm = split transpose pack with ncols = Kc >= K columns (Kc a multiple of 128: whole column tiles)
+__global__ __launch_bounds__(256) void k_linear_bwd_data3(const float* __restrict__ G, const uint16_t* __restrict__ WT3, float* __restrict__ dA,
+                                                          int R, int K, int Kc) {
+    __shared__ __attribute__((aligned(16))) uint16_t pl[3 * TILE_M * (D + 8)];
+    constexpr int LD = D + 8;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int r0 = blockIdx.x * TILE_M;
+    {
+        float4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + q * 256, rr = e >> 5;
+            v[q] = r0 + rr < R ? *reinterpret_cast<const float4*>(G + (size_t)(r0 + rr) * D + (e & 31) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int e = tid + q * 256; split_store4(pl, LD, TILE_M * LD, e >> 5, (e & 31) * 4, v[q]); }
+    }
+    __syncthreads();
+    for (int cb = 0; cb < Kc; cb += 512) {
+        f32x16 acc[4];
+        zero_acc(acc);
+        gemm32pl<4>(pl, LD, TILE_M * LD, D, WT3, Kc, cb + 32 * w, D, acc);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int col = cb + 32 * w + t * D + (lane & 31);
+            if (col < K) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int gr = r0 + acc_row(r, lane);
+                    if (gr < R) dA[(size_t)gr * K + col] = acc[t][r];
+                }
+            }
+        }
+    }
+}
+void launch_linear_bwd_data3(const float* G, const uint16_t* WT3, float* dA, int R, int K, int Kc, hipStream_t s) {
+    VSL_LAUNCH(k_linear_bwd_data3, dim3((R + TILE_M - 1) / TILE_M), dim3(256), 0, s, G, WT3, dA, R, K, Kc);
+}
+
 }  // namespace vsl

@@ -140,6 +140,8 @@ void launch_vproj_fwd_bf16(const uint16_t* X, const uint16_t* Wpack16, const flo
 // fp32-grade on the bf16 matrix cores (kernels_split.hip): W3 = split pack (PackJob type 6 / 7) of the (Dv, 128) operand
 void launch_vproj_fwd3(const float* X, const uint16_t* W3, const float* bias, float* Y, int R, int Dv, Drop dp, hipStream_t s,
                        int seg = 0, int stride = 0, int off = 0);
+void launch_linear_fwd3(const float* A, const uint16_t* W3, const float* bias, float* Y, int R, int K, hipStream_t s);
+void launch_linear_bwd_data3(const float* G, const uint16_t* WT3, float* dA, int R, int K, int Kc, hipStream_t s);   // Kc: columns of the split pack
 bool split_gemm_enabled();       // false when VSL_F32_GEMM=1 selects the fp32-input MFMA kernels of round 2 (A/B runs)
 void launch_embed_fwd(const int64_t* word_ids, const int64_t* char_ids, const float* pad_vec, const float* unk_vec,
                       const float* glove, const float* char_tab, CharConvPtrs cc, const float* wimg, float* E, int8_t* argpos,
