@@ -30,7 +30,7 @@ typedef struct {
     int32_t max_pos_len;       /* configs.max_pos_len      (rows of the positional table; T, Lq <= it)    */
     int32_t video_feature_dim; /* configs.video_feature_dim (multiple of 4: 1024 I3D, 4096 / 500 C3D)         */
     int32_t word_dim;          /* configs.word_dim = 300   (word_dim + 100 must be a multiple of 8)       */
-    int32_t char_dim;          /* configs.char_dim = 50    (<= 64)                                        */
+    int32_t char_dim;          /* configs.char_dim = 50    (<= 128)                                       */
     int32_t word_size;         /* configs.word_size  = rows of [pad; unk; glove]                          */
     int32_t char_size;         /* configs.char_size  = rows of the character table                        */
     int32_t predictor;         /* 0 = 'rnn' (DynamicRNN, layers_t7.py:302-313), 1 = 'transformer'         */

@@ -39,6 +39,8 @@ CASES = {
     'tiny_rnn': (dict(video_feature_dim=64, max_pos_len=32, word_size=52, predictor='rnn'), 3, 24, 7, 6, True),
     'real_tf':  (dict(video_feature_dim=1024, max_pos_len=128, word_size=52), 2, 128, 20, 10, True),
     'long_tf':  (dict(video_feature_dim=64, max_pos_len=256, word_size=52), 2, 200, 12, 5, True),
+    # main_t7.py:24: "--char_dim ... 100 for activitynet"
+    'chardim100_tf': (dict(video_feature_dim=64, max_pos_len=32, word_size=52, char_dim=100), 3, 24, 7, 12, True),
 }
 
 
@@ -241,6 +243,10 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == 'init':
         run_init(VSLNet)
+        return
+    if len(sys.argv) > 2 and sys.argv[1] == 'case':          # one model fixture, the others untouched
+        torch.set_num_threads(8)
+        run_case(VSLNet, sys.argv[2], CASES[sys.argv[2]])
         return
     os.makedirs(os.path.join(ROOT, 'tests', 'golden'), exist_ok=True)
     torch.set_num_threads(8)

@@ -151,4 +151,5 @@ def test_dataset_is_validated_against_the_engine_limits_up_front():
         with pytest.raises(ValueError, match=msg):
             data.validate_dataset(bad, cfg)
     with pytest.raises(ValueError, match='char_dim'):
-        data.validate_dataset(ds, SimpleNamespace(max_pos_len=128, char_dim=100))
+        data.validate_dataset(ds, SimpleNamespace(max_pos_len=128, char_dim=129))
+    data.validate_dataset(ds, SimpleNamespace(max_pos_len=128, char_dim=100))      # main_t7.py:24's ActivityNet setting

@@ -11,7 +11,7 @@ from tests.helpers import load_golden, grad_tol, relu_flips
 
 pytestmark = pytest.mark.gpu
 
-CASES = ['tiny_tf', 'real_tf', 'long_tf']
+CASES = ['tiny_tf', 'real_tf', 'long_tf', 'chardim100_tf']
 ATOL = 1e-4
 
 

@@ -99,17 +99,21 @@ def test_dropout_forward_backward_consistency_by_finite_differences(dv, B, T, Lq
         assert abs(fd - pred) <= 0.03 * abs(pred) + 2e-3, 'trial %d: finite difference %.6f vs g.v %.6f' % (trial, fd, pred)
 
 
-@pytest.mark.parametrize('dv,B,T,Lq,Lc,predictor', [(64, 3, 40, 7, 6, 'transformer'), (1024, 2, 128, 20, 10, 'transformer'),
-                                                    (500, 4, 33, 5, 4, 'rnn'),
-                                                    (64, 2, 40, 82, 30, 'transformer'),     # ActivityNet's longest query
-                                                    (64, 2, 36, 128, 5, 'transformer'),     # the reference's bound (max_pos_len words): lean CQAttention layouts
-                                                    (1024, 16, 128, 20, 10, 'rnn')])       # BASELINE configs[0] as written
-def test_training_mode_matches_oracle_on_the_same_dropout_masks(dv, B, T, Lq, Lc, predictor):
+@pytest.mark.parametrize('dv,B,T,Lq,Lc,predictor,char_dim', [
+    (64, 3, 40, 7, 6, 'transformer', 50), (1024, 2, 128, 20, 10, 'transformer', 50),
+    (500, 4, 33, 5, 4, 'rnn', 50),
+    (64, 2, 40, 82, 30, 'transformer', 50),     # ActivityNet's longest query
+    (64, 2, 36, 128, 5, 'transformer', 50),     # the reference's bound (max_pos_len words): lean CQAttention layouts
+    (1024, 16, 128, 20, 10, 'rnn', 50),         # BASELINE configs[0] as written
+    (64, 3, 40, 7, 20, 'transformer', 100),     # main_t7.py:24's ActivityNet char_dim: two input-channel blocks x two position tiles forward, 7 channel tiles backward
+    (64, 2, 30, 9, 40, 'transformer', 128),     # the engine's bounds: longest token, widest character embedding
+    (64, 5, 24, 6, 8, 'transformer', 72)])      # a width that is no multiple of 16
+def test_training_mode_matches_oracle_on_the_same_dropout_masks(dv, B, T, Lq, Lc, predictor, char_dim):
     """drop_rate 0.2 (the benchmark's mode), all 41 dropout sites: the oracle is handed the HIP path's masks -- recomputed on
     the host from the documented counter-based hash (tests/helpers.py) -- and must then agree with the training-mode forward
     (logits 1e-4) and with every gradient (1e-4 * |g|inf + 1e-6), like the eval-mode parity tests."""
     from tests.helpers import relu_flips, hip_dropout
-    cfg = O.make_cfg(video_feature_dim=dv, max_pos_len=max(T, Lq), word_size=102, drop_rate=0.2, predictor=predictor)
+    cfg = O.make_cfg(video_feature_dim=dv, max_pos_len=max(T, Lq), word_size=102, drop_rate=0.2, predictor=predictor, char_dim=char_dim)
     P = O.random_params(cfg, seed=21)
     b = O.synthetic_batch(cfg, B, T, Lq, Lc, seed=22, ragged=True)
     d = _dev(b)

@@ -9,7 +9,7 @@ import torch
 from oracle import vslnet_oracle as O
 from tests.helpers import load_golden, grad_tol
 
-CASES = ['tiny_tf', 'tiny_rnn', 'real_tf', 'long_tf']
+CASES = ['tiny_tf', 'tiny_rnn', 'real_tf', 'long_tf', 'chardim100_tf']
 ATOL = 2e-5
 
 

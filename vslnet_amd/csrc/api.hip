@@ -47,7 +47,7 @@ struct ModelP {
     int sln_g, sln_b, eln_g, eln_b, s0w, s0b, s1w, s1b, e0w, e0b, e1w, e1b;
     int l_wih[2], l_whh[2], l_bih[2], l_bhh[2];     // rnn predictor: start / end DynamicRNN (layers_t7.py:302-313)
 };
-struct ModelPk { int va_f, va_f16, va_f3, l_t3[2], emb_f, emb_t, emb_f3, emb_t3, emb_t3_cols; EncPk fe, pe; int cqa_f, cqa_t, cat1_f, cat1_t, s0_f, s0_t, e0_f, e0_t, ccw_img;
+struct ModelPk { int va_f, va_f16, va_f3, l_t3[2], emb_f, emb_t, emb_f3, emb_t3, emb_t3_cols; EncPk fe, pe; int cqa_f, cqa_t, cat1_f, cat1_t, s0_f, s0_t, e0_f, e0_t, ccw_img, ccw_imgb;
                  int l_f[2], l_t[2], zero128; };
 
 struct EncWs { int64_t x0, y[4], u[4], mask[4], h1, q, k, v, lse, att, r, h2, out; int R, L; };
@@ -333,6 +333,16 @@ void build_packs(vsl_handle_s* h) {
     int oc0 = 0;
     for (int i = 0; i < 4; ++i) {
         PackJob j{P.ccw[i], K.ccw_img, chn[i] * c.char_dim * 4, 1, i + 1, 3, c.char_dim, 0, oc0};
+        h->jobs.push_back(j);
+        oc0 += chn[i];
+    }
+    // the same weights as the B operands of the embedding backward's dCe product, in lane order (kernels_fwd.hip, type 8)
+    K.ccw_imgb = (int)h->pack_floats;
+    const int ebn = ((c.char_dim + 15) / 16) * EB_IMG_Q * 64;
+    h->pack_floats += ebn;
+    oc0 = 0;
+    for (int i = 0; i < 4; ++i) {
+        PackJob j{P.ccw[i], K.ccw_imgb, ebn, 1, i + 1, 8, c.char_dim, chn[i], oc0};
         h->jobs.push_back(j);
         oc0 += chn[i];
     }
@@ -971,7 +981,7 @@ void run_backward(Ctx& c) {
     else
     LAUNCH("linear_bwd_data", launch_linear_bwd_data(c.W(p.dqf), c.PK(K.emb_t), c.W(p.dE), Rq, EW, c.s));
     {
-        const int nce = (Rq + EMB_CHUNK - 1) / EMB_CHUNK;
+        const int ebc = embed_bwd_chunk(Rq, p.Lc, cf.char_dim), nce = (Rq + ebc - 1) / ebc;
         const int wtot = cf.char_dim * 300;
         const int64_t ow = c.part_alloc((int64_t)nce * wtot), ob = c.part_alloc((int64_t)nce * 100);
         const int ch[4] = {10, 20, 30, 40};
@@ -985,7 +995,7 @@ void run_backward(Ctx& c) {
         float* p_tab = c.slab(P.char_tab, cf.char_size * cf.char_dim, nce);
         float* p_unk = c.slab(P.unk, cf.word_dim, nce);
         LAUNCH("embed_bwd", launch_embed_bwd(c.W(p.dE), io->word_ids, io->char_ids, c.W(p.E), reinterpret_cast<const int8_t*>(c.W(p.argpos)),
-                                c.P(P.char_tab), char_ptrs(c), c.part_ptr(ow), c.part_ptr(ob), p_tab, p_unk, Rq,
+                                c.P(P.char_tab), c.PK(K.ccw_imgb), c.part_ptr(ow), c.part_ptr(ob), p_tab, p_unk, Rq,
                                 p.Lc, cf.word_dim, cf.char_dim, cf.char_size, c.drop(SITE_WORD), c.drop(SITE_CHAR), c.s));
     }
     c.s = main_s;
@@ -1188,8 +1198,8 @@ int vsl_create(const vsl_config* cfg, vsl_handle* out) {
     if (cfg->predictor != 0 && cfg->predictor != 1) return fail("predictor must be 0 ('rnn') or 1 ('transformer'), got %d", cfg->predictor);
     if (cfg->video_feature_dim <= 0 || cfg->video_feature_dim % 4) return fail("video_feature_dim=%d must be a positive multiple of 4 (rows are read as float4)", cfg->video_feature_dim);
     if ((cfg->word_dim + 100) % 8) return fail("word_dim + 100 = %d must be a multiple of 8", cfg->word_dim + 100);
-    if (cfg->char_dim <= 0 || cfg->char_dim > 64) return fail("char_dim=%d must be in [1, 64]", cfg->char_dim);
-    if (cfg->char_size <= 0 || cfg->char_size * cfg->char_dim > 16384) return fail("char table too large for the LDS accumulator");
+    if (cfg->char_dim <= 0 || cfg->char_dim > 128) return fail("char_dim=%d must be in [1, 128]", cfg->char_dim);
+    if (cfg->char_size <= 0 || cfg->char_size * cfg->char_dim > 65536) return fail("char table of %d x %d floats: every embedding-backward workgroup writes one partial copy, 65536 floats is the limit", cfg->char_size, cfg->char_dim);
     if (cfg->max_pos_len <= 0 || cfg->word_size < 2) return fail("bad max_pos_len / word_size");
     if (cfg->drop_rate < 0.f || cfg->drop_rate >= 1.f) return fail("drop_rate must be in [0, 1)");
     int ndev = 0;

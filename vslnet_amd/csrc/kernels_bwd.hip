@@ -1520,65 +1520,66 @@ void launch_linear_bwd_data(const float* G, const float* WTpack, float* dA, int 
 
 // =========================================================================================================
 // a3 / a4 backward: unk_vec gradient, char-CNN weights / biases, char table (padding_idx = 0 gets none).
-//   One workgroup per EMB_CHUNK query words.  All per-word metadata of the chunk is staged with ONE bulk load phase;
-//   the 15000 conv weights live in LDS.
-//   (i)  dW[oc][ci][kk] += g[oc] * Ce[pos[oc] + kk][ci]   thread = 25 fixed (oc, ci) pairs, 4 tap accumulators each: one
-//        (g, pos) lookup per pair and word, shared by the taps and broadcast across the 64 lanes of a channel.
-//   (ii) dCe[p][ci] = sum_oc g[oc] * W[oc][ci][p - pos[oc]]: a parallel pre-pass resolves the data-dependent part into
-//        two [p][oc] tables (gradient or 0, weight offset + tap stride), so the gather loop streams sequential LDS
-//        addresses with a single dependent level; the result is scattered per character into the table accumulator
-//        (thread = (p, ci), serial over p -> no atomics).
+//   One workgroup of 8 waves per `chunk` query words (embed_bwd_chunk: as many as keep the grid inside one round of the 256 CUs);
+//   the rows (word, position) of the chunk are packed densely.  Nothing here is sized by char_dim beyond an LDS row stride of 64
+//   or 128 floats (char_dim <= 128; main_t7.py:24 prescribes 100 for ActivityNet).  After two shared staging phases the waves split
+//   into two roles that never meet again:
+//   waves 4-7 (i)   dW[oc][ci][kk] += g[oc] * Ce[pos[oc] + kk][ci]   thread = 25 fixed (oc, ci) pairs, 4 tap accumulators each: one
+//         {pos, g} lookup per pair and word (one 8-byte LDS broadcast), shared by the taps.  Exact fp32 FMAs.
+//   waves 0-3 (ii)  dCe[row][ci] = sum_k G[row][k] W[k][ci] over the k = (tap, channel) pairs of the four convs, where G has ONE
+//         non-zero per (word, k): the arg-max position of the channel shifted by the tap.  The product runs on the matrix cores (wave
+//         = 16 input channels, 76 MFMAs of 16x16x4 per 16-row tile) and G is never materialised: a lane builds its A operand from the
+//         {pos, g} pair of (word, channel) -- g * (pos + tap == position) -- so there is no scatter, no clear and no barrier between
+//         tiles.  k runs tap-major over aligned channel ranges (tap 0: channels 0..99, tap 1: 8..99, tap 2: 28..99, tap 3: 60..99; the
+//         channels below a conv's first one carry zero weights), which makes (tap, channel) of an unrolled step a compile-time
+//         constant plus lane >> 4.  The B operands (76 values per lane) come from an image k_pack lays out in lane order.
+//         (iii) table[cid][ci] += dCe[row][ci] for the character of every row: ALSO a product on the matrix cores,
+//         onehot[cid][row] x dCe[row][ci] (the one-hot operand is exact, the accumulation order is fixed: deterministic, no atomics,
+//         no serial per-character loop, no LDS accumulator).  The wave that produced a channel tile of dCe consumes it: no barrier.
+//   (Round 2 scattered G into LDS one word at a time -- two barriers, a clear and a 10-step serial table update per word: phases (ii)
+//   + (iii) were 53 k of the kernel's 91 k cycles, and (i) ran before them on the same four waves.)
 // =========================================================================================================
-constexpr int EB_NP = 25;                     // (100 channels x 64 lanes) / 256 threads
-constexpr int EB_GP = 301;                    // LDS row stride of the per-word tap matrix G (odd: conflict-free column reads)
-__global__ __launch_bounds__(256) void k_embed_bwd(const float* __restrict__ dE, const int64_t* __restrict__ word_ids,
+constexpr int EB_NP = 25;                     // (100 channels x 64 lanes) / 256 threads of the dW role
+constexpr int EB_NQ = 76;                     // k-steps of 4 (tap, channel) pairs: 25 + 23 + 18 + 10
+constexpr int EB_GS = 305;                    // LDS row stride of G (odd: conflict-free column reads)
+__host__ __device__ constexpr int eb_tap(int q) { return q < 25 ? 0 : q < 48 ? 1 : q < 66 ? 2 : 3; }
+__host__ __device__ constexpr int eb_oc0(int q) { return q < 25 ? 4 * q : q < 48 ? 8 + 4 * (q - 25) : q < 66 ? 28 + 4 * (q - 48) : 60 + 4 * (q - 66); }
+__global__ __launch_bounds__(512) void k_embed_bwd(const float* __restrict__ dE, const int64_t* __restrict__ word_ids,
                                                    const int64_t* __restrict__ char_ids, const float* __restrict__ E,
                                                    const int8_t* __restrict__ argpos, const float* __restrict__ char_tab,
-                                                   CharConvPtrs cc, float* __restrict__ p_cw, float* __restrict__ p_cb,
+                                                   const float* __restrict__ wimg_b, float* __restrict__ p_cw, float* __restrict__ p_cb,
                                                    float* __restrict__ p_tab, float* __restrict__ p_unk, int Rq, int Lc,
-                                                   int word_dim, int char_dim, int char_size, Drop dw, Drop dc) {
+                                                   int word_dim, int char_dim, int char_size, int cdp, int chunk, Drop dw, Drop dc) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wtot = char_dim * 300;          // 10*1 + 20*2 + 30*3 + 40*4 = 300 taps per input channel
-    float* Ce = smem;                         // [EMB_CHUNK * Lc + 4][64] dropped char embeddings (+ zero rows)
-    float* gch = Ce + (EMB_CHUNK * Lc + 4) * 64;   // [EMB_CHUNK][128] grads of the 100 char features (0 where inactive)
-    float* Gm = gch + EMB_CHUNK * 128;        // [16][EB_GP] G tile of the current word (zero except <= 300 entries)
-    float* tab = Gm + 16 * EB_GP;             // [char_size][char_dim] table-gradient accumulator
-    float* dce = tab + char_size * char_dim;  // [2][Lc][64] char-embedding gradients of the current / previous word
-    int* kmap = reinterpret_cast<int*>(dce + 2 * Lc * 64);   // [304] tap k -> oc | kk << 8 | k_oc << 10 | (weight offset of (oc, ci=0, kk)) << 13
-    __shared__ int pos[EMB_CHUNK * 128];
-    __shared__ int cids[EMB_CHUNK * MAX_LC];
-    __shared__ int obase[128], okk[128];
-    const int tid = threadIdx.x;
+    const int ds = cdp + 16;                  // row stride of dce: the 4 k-rows of a B operand land in disjoint banks
+    float* Ce = smem;                         // [chunk * Lc + 4][cdp] dropped char embeddings (+ zero rows)
+    float* dce = Ce + (chunk * Lc + 4) * cdp;                     // [chunk * Lc][ds] char-embedding gradients
+    int2* gp = reinterpret_cast<int2*>(dce + chunk * Lc * ds);    // [chunk][128] {arg-max position, gradient bits} (0 where inactive)
+    int* cids = reinterpret_cast<int*>(gp + chunk * 128);         // [chunk * Lc + 4] character of every row
+    float* Gm = reinterpret_cast<float*>(cids + ((chunk * Lc + 4 + 3) & ~3));   // [16 * ceil(rows / 16)][EB_GS] the tap matrix G (<= 300 non-zeros per word)
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, jl = lane & 15, g4 = lane >> 4;
     const int EW = word_dim + 100;
-    const int rbeg = blockIdx.x * EMB_CHUNK, nw = min(EMB_CHUNK, Rq - rbeg);
-    const int s0 = 10 * char_dim, s1 = 20 * char_dim * 2, s2 = 30 * char_dim * 3;
+    const int rbeg = blockIdx.x * chunk, nw = min(chunk, Rq - rbeg);
+    const int nrow = nw * Lc;
+    const int nct = (char_dim + 15) >> 4;
     STAMP(0);
-    // ---- bulk phase 1: per-word metadata (the conv weights are not staged: every lane reads its 75 B-operand values of
-    //      the MFMA product straight from the parameters, once)
-    if (tid < 128) {
-        int k = 1, base = wtot;
-        if (tid < 10) { k = 1; base = tid * char_dim; }
-        else if (tid < 30) { k = 2; base = s0 + (tid - 10) * char_dim * 2; }
-        else if (tid < 60) { k = 3; base = s0 + s1 + (tid - 30) * char_dim * 3; }
-        else if (tid < 100) { k = 4; base = s0 + s1 + s2 + (tid - 60) * char_dim * 4; }
-        okk[tid] = k; obase[tid] = base;
+    // B operand of every MFMA of phase (ii): row-independent -> registers; the first channel tile of the wave is requested before
+    // anything else so its latency hides behind the staging phases
+    float wreg[EB_NQ];
+    auto load_w = [&](int ct) {
+        const float* src = wimg_b + (size_t)ct * EB_NQ * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < EB_NQ; ++q) wreg[q] = src[q * 64];
+    };
+    if (w < 4 && w < nct) load_w(w);
+    // ---- staging phase 1: G cleared, per-word metadata with all loads issued together
+    {
+        const int n4 = (((chunk * Lc + 15) >> 4) * 16 * EB_GS + 3) >> 2;
+        for (int e = tid; e < n4; e += 512) reinterpret_cast<float4*>(Gm)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    for (int e = tid; e < 304; e += 256) {       // tap table: conv c has 10 (c + 1) channels x (c + 1) taps
-        int oc = 100, kk = 0, k = 1, base = wtot;
-        if (e < 10) { oc = e; kk = 0; k = 1; base = oc * char_dim; }
-        else if (e < 50) { oc = 10 + (e - 10) / 2; kk = (e - 10) % 2; k = 2; base = s0 + (oc - 10) * char_dim * 2; }
-        else if (e < 140) { oc = 30 + (e - 50) / 3; kk = (e - 50) % 3; k = 3; base = s0 + s1 + (oc - 30) * char_dim * 3; }
-        else if (e < 300) { oc = 60 + (e - 140) / 4; kk = (e - 140) % 4; k = 4; base = s0 + s1 + s2 + (oc - 60) * char_dim * 4; }
-        kmap[e] = oc | (kk << 8) | (k << 10) | ((base + kk) << 13);
-    }
-    for (int e = tid; e < 16 * EB_GP; e += 256) Gm[e] = 0.f;
-    for (int e = tid; e < char_size * char_dim; e += 256) tab[e] = 0.f;
-    for (int e = tid; e < 4 * 64; e += 256) Ce[EMB_CHUNK * Lc * 64 + e] = 0.f;
-    for (int e = tid; e < EMB_CHUNK * MAX_LC; e += 256) {
-        const int wi = e / MAX_LC, p = e - wi * MAX_LC;
-        cids[e] = (wi < nw && p < Lc) ? (int)char_ids[(size_t)(rbeg + wi) * Lc + p] : 0;
-    }
-    for (int e = tid; e < EMB_CHUNK * 128; e += 256) {
+    for (int e = tid; e < chunk * Lc + 4; e += 512) cids[e] = e < nrow ? (int)char_ids[(size_t)rbeg * Lc + e] : 0;
+    for (int e = tid; e < chunk * 128; e += 512) {
         const int wi = e >> 7, oc = e & 127;
         float g = 0.f;
         int ps = 0;
@@ -1587,156 +1588,167 @@ __global__ __launch_bounds__(256) void k_embed_bwd(const float* __restrict__ dE,
             g = E[o] > 0.f ? dE[o] : 0.f;                                  // relu + max: grad only to an active arg-max
             ps = argpos[(size_t)(rbeg + wi) * 100 + oc];
         }
-        gch[e] = g;
-        pos[e] = ps;
+        gp[e] = make_int2(ps, __float_as_int(g));
     }
-    float bacc = 0.f, uacc0 = 0.f, uacc1 = 0.f;
-        // (Measured in round 3: packing the rows of all words of the chunk densely and running groups of 2 - 3 16-row tiles between two
-        // barriers -- instead of one word and one tile per barrier pair -- is no faster: 49.8 us (2 tiles, 75 KB of LDS = 2 workgroups per CU)
-        // and 81.9 us (3 tiles, 94 KB = 1 per CU = two rounds) against 45.6; inside the step 0.9108 against 0.9120 ms over four same-box pairs.)
-    for (int wi = 0; wi < nw; ++wi) {
-        const int r = rbeg + wi;
-        if (word_ids[r] == 1) {               // unk_vec row of the [pad; unk; glove] table (:41)
-            if (tid < word_dim) uacc0 += dE[(size_t)r * EW + tid] * drop_mul(dw, (uint32_t)(r * word_dim + tid));
-            if (tid + 256 < word_dim) uacc1 += dE[(size_t)r * EW + tid + 256] * drop_mul(dw, (uint32_t)(r * word_dim + tid + 256));
-        }
+    float uacc = 0.f;
+    if (tid < word_dim) {
+        // unk_vec row of the [pad; unk; glove] table (:41): every row load of the chunk issued unconditionally, then masked
+        float u[EMB_CHUNK_MAX];
+#pragma unroll
+        for (int wi = 0; wi < EMB_CHUNK_MAX; ++wi) u[wi] = wi < nw ? dE[(size_t)(rbeg + wi) * EW + tid] : 0.f;
+#pragma unroll
+        for (int wi = 0; wi < EMB_CHUNK_MAX; ++wi)
+            if (wi < nw && word_ids[rbeg + wi] == 1) uacc += u[wi] * drop_mul(dw, (uint32_t)((rbeg + wi) * word_dim + tid));
     }
     __syncthreads();
     STAMP(1);
-    // ---- bulk phase 2: gather the dropped-out char embeddings of every word of the chunk
-    for (int e = tid; e < EMB_CHUNK * Lc * 64; e += 256) {
-        const int wi = e / (Lc * 64), rem = e - wi * Lc * 64;
-        const int p = rem >> 6, ci = rem & 63;
-        float v = 0.f;
-        if (wi < nw && ci < char_dim)
-            v = char_tab[(size_t)cids[wi * MAX_LC + p] * char_dim + ci] * drop_mul(dc, (uint32_t)(((rbeg + wi) * Lc + p) * char_dim + ci));
-        Ce[e] = v;
+    // ---- staging phase 2: scatter G (one entry per (word, tap): row = word * Lc + pos[oc] + kk, column = the tap-major k of (kk, oc));
+    //      gather the dropped-out char embeddings of every row of the chunk (+ 4 zero rows: taps past the last row)
+    for (int e = tid; e < nw * 300; e += 512) {
+        const int wi = e / 300, k = e - wi * 300;
+        // taps in conv order: 10 x 1, 20 x 2, 30 x 3, 40 x 4
+        int oc, kk;
+        if (k < 10) { oc = k; kk = 0; }
+        else if (k < 50) { oc = 10 + ((k - 10) >> 1); kk = (k - 10) & 1; }
+        else if (k < 140) { oc = 30 + (k - 50) / 3; kk = (k - 50) - 3 * (oc - 30); }
+        else { oc = 60 + ((k - 140) >> 2); kk = (k - 140) & 3; }
+        const int2 pg = gp[wi * 128 + oc];
+        const int col = kk == 0 ? oc : kk == 1 ? 100 + oc - 8 : kk == 2 ? 192 + oc - 28 : 264 + oc - 60;
+        Gm[(wi * Lc + pg.x + kk) * EB_GS + col] = __int_as_float(pg.y);
+    }
+    {
+        const int sh = cdp == 64 ? 6 : 7;
+        for (int e = tid; e < (chunk * Lc + 4) * cdp; e += 512) {
+            const int row = e >> sh, ci = e & (cdp - 1);
+            float v = 0.f;
+            if (row < nrow && ci < char_dim)
+                v = char_tab[(size_t)cids[row] * char_dim + ci] * drop_mul(dc, (uint32_t)((rbeg * Lc + row) * char_dim + ci));
+            Ce[e] = v;
+        }
     }
     __syncthreads();
     STAMP(2);
-    // ---- (i) conv weight / bias gradients: pair q of this thread = (oc = (tid >> 6) + 4 q, ci = tid & 63)
-    float wacc[EB_NP][4];
+    if (w >= 4) {
+        // ---- (i) conv weight / bias gradients: pair q of this thread = (oc = ((tid >> 6) - 4) + 4 q, ci = cih + (tid & 63))
+        const int s0 = 10 * char_dim, s1 = 20 * char_dim * 2, s2 = 30 * char_dim * 3;
+        const int t = tid - 256;
+        float bacc = 0.f;
+        for (int cih = 0; cih < char_dim; cih += 64) {
+            float wacc[EB_NP][4];
 #pragma unroll
-    for (int q = 0; q < EB_NP; ++q) { wacc[q][0] = 0.f; wacc[q][1] = 0.f; wacc[q][2] = 0.f; wacc[q][3] = 0.f; }
-    {
-        const int ci = tid & 63, ocb = tid >> 6;
-        for (int wi = 0; wi < nw; ++wi) {
-            const float* g = gch + wi * 128;
-            const int* ps = pos + wi * 128;
-            const float* ce = Ce + wi * Lc * 64 + ci;
-            if (tid < 100) bacc += g[tid];
+            for (int q = 0; q < EB_NP; ++q) { wacc[q][0] = 0.f; wacc[q][1] = 0.f; wacc[q][2] = 0.f; wacc[q][3] = 0.f; }
+            const int ci = cih + lane, ocb = w - 4;
+            for (int wi = 0; wi < nw; ++wi) {
+                const int2* g = gp + wi * 128;
+                const float* ce = Ce + wi * Lc * cdp + ci;
+                if (cih == 0 && t < 100) bacc += __int_as_float(g[t].y);
 #pragma unroll
-            for (int q = 0; q < EB_NP; ++q) {
-                const int oc = ocb + 4 * q;
-                const float gv = g[oc];
-                const float* row = ce + ps[oc] * 64;      // taps beyond the kernel width read later rows / zero rows: unused
-                wacc[q][0] += gv * row[0];
-                wacc[q][1] += gv * row[64];
-                wacc[q][2] += gv * row[128];
-                wacc[q][3] += gv * row[192];
+                for (int q = 0; q < EB_NP; ++q) {
+                    const int2 pg = g[ocb + 4 * q];
+                    const float gv = __int_as_float(pg.y);
+                    const float* row = ce + pg.x * cdp;       // taps beyond the kernel width read later rows / zero rows: unused
+                    wacc[q][0] += gv * row[0];
+                    wacc[q][1] += gv * row[cdp];
+                    wacc[q][2] += gv * row[2 * cdp];
+                    wacc[q][3] += gv * row[3 * cdp];
+                }
+            }
+            if (ci < char_dim) {
+                float* dst = p_cw + (size_t)blockIdx.x * wtot;
+#pragma unroll
+                for (int q = 0; q < EB_NP; ++q) {
+                    const int oc = ocb + 4 * q;               // slab offsets are multiples of 4 floats: the vector stores are aligned
+                    if (oc < 10) dst[oc * char_dim + ci] = wacc[q][0];
+                    else if (oc < 30) *reinterpret_cast<float2*>(dst + s0 + ((oc - 10) * char_dim + ci) * 2) = make_float2(wacc[q][0], wacc[q][1]);
+                    else if (oc < 60) {
+                        float* d3 = dst + s0 + s1 + ((oc - 30) * char_dim + ci) * 3;
+                        d3[0] = wacc[q][0]; d3[1] = wacc[q][1]; d3[2] = wacc[q][2];
+                    } else
+                        *reinterpret_cast<float4*>(dst + s0 + s1 + s2 + ((oc - 60) * char_dim + ci) * 4) =
+                            make_float4(wacc[q][0], wacc[q][1], wacc[q][2], wacc[q][3]);
+                }
             }
         }
-    }
-    STAMP(3);
-    // ---- (ii) char-embedding gradients -> table accumulator.  Per word this is a small dense product
-    //        dCe[p][ci] = sum_k G[p][k] W[k][ci],   k = (oc, tap) over the 300 taps of the four convs,
-    //      where G has ONE non-zero per k (the arg-max position of channel oc, shifted by the tap).  G (Lc x 300) is
-    //      scattered into LDS, the product runs on the matrix cores (wave = 16 input channels, 75 MFMAs of 16x16x4), the
-    //      entries are cleared again, and the result is scattered per character into the table accumulator.
-    {
-        const int w = tid >> 6, lane = tid & 63, jl = lane & 15, g4 = lane >> 4;
-        const int ci = 16 * w + jl;
-        const int nmt = (Lc + 15) >> 4;
-        // B operand of every MFMA (W[k][ci] for this lane's channel and its 75 k-slots): word-independent -> registers
-        float wreg[75];
-#pragma unroll
-        for (int q = 0; q < 75; ++q) {
-            const int m = kmap[4 * q + g4];
-            const int oc = m & 0xFF, kk = (m >> 8) & 3, kc = (m >> 10) & 7;
-            const int cv = kc - 1, ocl = oc - (cv == 0 ? 0 : cv == 1 ? 10 : cv == 2 ? 30 : 60);
-            const float* wp = cv == 0 ? cc.w[0] : cv == 1 ? cc.w[1] : cv == 2 ? cc.w[2] : cc.w[3];
-            wreg[q] = (ci < char_dim) ? wp[(ocl * char_dim + ci) * kc + kk] : 0.f;
-        }
-        // work items = (word, 16-position tile).  fill(item) scatters the tile's entries of G; after the MFMAs of an item
-        // every thread clears its own entries and writes those of the NEXT item (same thread, program order: no barrier in
-        // between).  dce is double-buffered by word, so the serial per-character scatter of a finished word overlaps the
-        // fill / MFMAs of the next one.  Two barriers per item.
-        auto fill = [&](int wi, int mt, bool set) {
-            for (int e = tid; e < 300; e += 256) {           // one entry per tap: row = pos[oc] + kk
-                const int km = kmap[e], oc = km & 0xFF, kk = (km >> 8) & 3;
-                const int row = pos[wi * 128 + oc] + kk - 16 * mt;
-                if (row >= 0 && row < 16) Gm[row * EB_GP + e] = set ? gch[wi * 128 + oc] : 0.f;
-            }
-        };
-        if (nw > 0) fill(0, 0, true);
-        for (int wi = 0; wi < nw; ++wi) {
-            const int r = rbeg + wi;
-            float* dcw = dce + (wi & 1) * Lc * 64;
-            for (int mt = 0; mt < nmt; ++mt) {
-                __syncthreads();
+        if (t < 100) p_cb[(size_t)blockIdx.x * 100 + t] = bacc;
+    } else {
+        // ---- (ii) + (iii)
+        const int nrt = (nrow + 15) >> 4, nmc = (char_size + 15) >> 4;
+        for (int ct = w; ct < nct; ct += 4) {
+            const int ci = 16 * ct + jl;
+            if (ct != w) load_w(ct);
+            for (int rt = 0; rt < nrt; ++rt) {
+                const float* grow = Gm + (16 * rt + jl) * EB_GS + g4;     // A operand: row = (word, position), k-slot = lane >> 4
                 f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-                const float* grow = Gm + jl * EB_GP + g4;    // A operand: row = position, k-slot = lane >> 4
 #pragma unroll
-                for (int q = 0; q < 74; q += 2) {
+                for (int q = 0; q < EB_NQ; q += 2) {
                     a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(grow[4 * q], wreg[q], a0, 0, 0, 0);
                     a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(grow[4 * q + 4], wreg[q + 1], a1, 0, 0, 0);
                 }
-                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(grow[4 * 74], wreg[74], a0, 0, 0, 0);
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) {
-                    const int p = 16 * mt + 4 * g4 + rr;
-                    if (p < Lc && ci < char_dim)
-                        dcw[p * 64 + ci] = (a0[rr] + a1[rr]) * drop_mul(dc, (uint32_t)((r * Lc + p) * char_dim + ci));
+                    const int ro = 16 * rt + 4 * g4 + rr;
+                    if (ro < nrow)
+                        dce[ro * ds + ci] = ci < char_dim ? (a0[rr] + a1[rr]) * drop_mul(dc, (uint32_t)((rbeg * Lc + ro) * char_dim + ci)) : 0.f;
                 }
-                __syncthreads();
-                fill(wi, mt, false);
-                if (mt + 1 < nmt) fill(wi, mt + 1, true);
-                else if (wi + 1 < nw) fill(wi + 1, 0, true);
             }
-            // scatter per character: thread = input channel, serial over the positions (two positions of one word may hold
-            // the same character) -> one table accumulator, no atomics
-            if (tid < char_dim)
-                for (int p = 0; p < Lc; ++p) {
-                    const int cid = cids[wi * MAX_LC + p];
-                    if (cid != 0) tab[cid * char_dim + tid] += dcw[p * 64 + tid];      // padding_idx = 0 (:51)
-                }
-        }
-        __syncthreads();
-    }
-    STAMP(4);
-    {
-        const int ci = tid & 63, ocb = tid >> 6;
+            STAMP(3);
+            // (iii): the rows of this channel tile were written by this very wave (LDS is in order within a wave)
+            for (int mc0 = 0; mc0 < nmc; mc0 += 4) {
+                f32x4 acc[4];
 #pragma unroll
-        for (int q = 0; q < EB_NP; ++q) {
-            const int oc = ocb + 4 * q;
-            if (ci < char_dim) {
-                const int k = okk[oc], base = obase[oc] + ci * k;
-                if (k > 0) p_cw[(size_t)blockIdx.x * wtot + base] = wacc[q][0];
-                if (k > 1) p_cw[(size_t)blockIdx.x * wtot + base + 1] = wacc[q][1];
-                if (k > 2) p_cw[(size_t)blockIdx.x * wtot + base + 2] = wacc[q][2];
-                if (k > 3) p_cw[(size_t)blockIdx.x * wtot + base + 3] = wacc[q][3];
+                for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int r0 = 0; r0 < nrow; r0 += 16) {
+                    int cv[4];
+                    float bv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int row = r0 + 4 * u + g4;
+                        const bool ok = row < nrow;
+                        cv[u] = ok ? cids[row] : -1;
+                        bv[u] = ok ? dce[row * ds + ci] : 0.f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int m = 0; m < 4; ++m)
+                            if (mc0 + m < nmc)
+                                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(cv[u] == 16 * (mc0 + m) + jl ? 1.f : 0.f, bv[u], acc[m], 0, 0, 0);
+                }
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int co = 16 * (mc0 + m) + 4 * g4 + rr;
+                        if (co < char_size && ci < char_dim)
+                            p_tab[(size_t)blockIdx.x * char_size * char_dim + co * char_dim + ci] = co != 0 ? acc[m][rr] : 0.f;   // padding_idx = 0 (:51)
+                    }
             }
         }
+        STAMP(4);
     }
-    if (tid < 100) p_cb[(size_t)blockIdx.x * 100 + tid] = bacc;
-    if (tid < word_dim) p_unk[(size_t)blockIdx.x * word_dim + tid] = uacc0;
-    if (tid + 256 < word_dim) p_unk[(size_t)blockIdx.x * word_dim + tid + 256] = uacc1;
-    for (int e = tid; e < char_size * char_dim; e += 256)
-        p_tab[(size_t)blockIdx.x * char_size * char_dim + e] = tab[e];
-    STAMP(5);
+    if (tid < word_dim) p_unk[(size_t)blockIdx.x * word_dim + tid] = uacc;
+}
+// words per workgroup: the smallest chunk whose grid fits one round of the 256 CUs, at least 4 (slab traffic), at most 8 and at most
+// 80 (char_dim <= 64) / 48 rows (the LDS footprint: 145 / 113 KB at the bound)
+int embed_bwd_chunk(int Rq, int Lc, int char_dim) {
+    int c = (Rq + 255) / 256;
+    c = c < 4 ? 4 : c > EMB_CHUNK_MAX ? EMB_CHUNK_MAX : c;
+    const int rmax = (char_dim <= 64 ? 80 : 48) / Lc;
+    return c > rmax ? (rmax < 1 ? 1 : rmax) : c;
 }
 void launch_embed_bwd(const float* dE, const int64_t* word_ids, const int64_t* char_ids, const float* E,
-                      const int8_t* argpos, const float* char_tab, CharConvPtrs cc, float* p_cw, float* p_cb,
+                      const int8_t* argpos, const float* char_tab, const float* wimg_b, float* p_cw, float* p_cb,
                       float* p_tab, float* p_unk, int Rq, int Lc, int word_dim, int char_dim, int char_size, Drop dw, Drop dc,
                       hipStream_t s) {
-    const size_t shm = (size_t)((EMB_CHUNK * Lc + 4) * 64 + EMB_CHUNK * 128 + 16 * EB_GP + 2 * Lc * 64 +
-                                char_size * char_dim + 304) * sizeof(float);
+    const int cdp = char_dim <= 64 ? 64 : 128, chunk = embed_bwd_chunk(Rq, Lc, char_dim);
+    const size_t shm = (size_t)((chunk * Lc + 4) * cdp + chunk * Lc * (cdp + 16) + chunk * 256 + ((chunk * Lc + 4 + 3) & ~3) +
+                                ((chunk * Lc + 15) / 16) * 16 * EB_GS + 4) * sizeof(float);
     static size_t lds_ok = 0;
     ensure_dynamic_lds((const void*)k_embed_bwd, shm, lds_ok, "k_embed_bwd");
-    VSL_LAUNCH(k_embed_bwd, dim3((Rq + EMB_CHUNK - 1) / EMB_CHUNK), dim3(256), shm, s, dE, word_ids, char_ids, E, argpos,
-                       char_tab, cc, p_cw, p_cb, p_tab, p_unk, Rq, Lc, word_dim, char_dim, char_size, dw, dc);
+    VSL_LAUNCH(k_embed_bwd, dim3((Rq + chunk - 1) / chunk), dim3(512), shm, s, dE, word_ids, char_ids, E, argpos,
+                       char_tab, wimg_b, p_cw, p_cb, p_tab, p_unk, Rq, Lc, word_dim, char_dim, char_size, cdp, chunk, dw, dc);
     static int left = 2;
-    if (dbg_budget("embed_bwd")) dbg_report("embed_bwd: bulk1 | gather | dW | dCe+table | stores", 6, s, left);
+    if (dbg_budget("embed_bwd")) dbg_report("embed_bwd: metadata | gather | dCe | table (waves 0-3)", 5, s, left);
 }
 
 // =========================================================================================================

@@ -80,6 +80,18 @@ __global__ __launch_bounds__(256) void k_pack(const float* __restrict__ params, 
             pack[j.dst + (ci * 4 + kk) * 100 + j.col_off + ch] = kk < kw ? params[j.src + (ch * cd + ci) * kw + kk] : 0.f;
             continue;
         }
+        if (j.transpose == 8) {     // char-conv weight -> B operands of k_embed_bwd's dCe product in lane order: [channel tile][76 k-steps][64 lanes]
+            // kn = channel tiles * 76 * 64 ; ld = kw ; ncols = char_dim ; col_off = first channel of this conv ; k_off = its channel count.
+            // k-step q covers tap eb_tap(q), channels eb_oc0(q) + (lane >> 4); this job writes the slots of ITS channels (zero where the
+            // tap lies beyond the kernel width or the input channel beyond char_dim), the four jobs together define the whole image
+            const int kw = j.ld, cd = j.ncols;
+            const int ct = e / (EB_IMG_Q * 64), rem = e - ct * EB_IMG_Q * 64, q = rem >> 6, ln = rem & 63;
+            const int kk = q < 25 ? 0 : q < 48 ? 1 : q < 66 ? 2 : 3;
+            const int oc = (q < 25 ? 4 * q : q < 48 ? 8 + 4 * (q - 25) : q < 66 ? 28 + 4 * (q - 48) : 60 + 4 * (q - 66)) + (ln >> 4);
+            const int ocl = oc - j.col_off, ci = 16 * ct + (ln & 15);
+            if (ocl >= 0 && ocl < j.k_off) pack[j.dst + e] = (ci < cd && kk < kw) ? params[j.src + (ocl * cd + ci) * kw + kk] : 0.f;
+            continue;
+        }
         if (j.transpose == 4) {     // zero fill of kn * cn floats
             pack[j.dst + e] = 0.f;
             continue;
@@ -282,36 +294,55 @@ __global__ __launch_bounds__(512) void k_embed_fwd(const int64_t* __restrict__ w
                                                    const float* __restrict__ glove, const float* __restrict__ char_tab,
                                                    CharConvPtrs cc, const float* __restrict__ wimg, float* __restrict__ E,
                                                    int8_t* __restrict__ argpos, int Rq, int Lc, int word_dim, int char_dim,
-                                                   Drop dw, Drop dc) {
+                                                   int cb, Drop dw, Drop dc) {
     constexpr int EF_PT = LCM + 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Wt = smem;                                   // [char_dim][4 taps][100 channels], taps beyond a channel's width = 0
-    float* CeT = Wt + char_dim * 400;                   // [EF_CHUNK][char_dim][EF_PT]
+    float* Wt = smem;                                   // [cb][4 taps][100 channels], taps beyond a channel's width = 0
+    float* CeT = Wt + cb * 400;                         // [EF_CHUNK][cb][EF_PT]
     __shared__ int cids[EF_CHUNK * LCM];
     const int tid = threadIdx.x, NT = blockDim.x;      // 512 threads: two waves per SIMD hide the LDS latency of the item loop
     const int EW = word_dim + 100;
     const int rbeg = blockIdx.x * EF_CHUNK, nw = min(EF_CHUNK, Rq - rbeg);
-    const int s0 = 10 * char_dim, s1 = 20 * char_dim * 2, s2 = 30 * char_dim * 3;
     FSTAMP(0);
-    // ---- stage the weights: straight vector copy of the [ci][4 taps][100 channels] image k_pack built this step
-    //      (channel fastest: conflict-free for lanes that own consecutive channels; taps beyond a kernel width are 0)
-    for (int e0 = 0; e0 < char_dim * 100; e0 += 8 * NT) {
-        float4 v[8];
+    // ---- one block of `cb` input channels at a time (cb = char_dim up to 64: a single block; main_t7.py:24's char_dim 100 = two of 52):
+    //      the LDS footprint is set by cb, not by char_dim, and the accumulators of a position tile run across the blocks
+    auto stage_w = [&](int c0, int cbn) {
+        // weights: straight vector copy of rows c0 .. c0 + cbn of the [ci][4 taps][100 channels] image k_pack built this step
+        // (channel fastest: conflict-free for lanes that own consecutive channels; taps beyond a kernel width are 0)
+        const float4* wsrc = reinterpret_cast<const float4*>(wimg + (size_t)c0 * 400);
+        for (int e0 = 0; e0 < cbn * 100; e0 += 8 * NT) {
+            float4 v[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int e = e0 + tid + q * NT;
-            v[q] = e < char_dim * 100 ? reinterpret_cast<const float4*>(wimg)[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int q = 0; q < 8; ++q) {
+                const int e = e0 + tid + q * NT;
+                v[q] = e < cbn * 100 ? wsrc[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const int e = e0 + tid + q * NT; if (e < cbn * 100) reinterpret_cast<float4*>(Wt)[e] = v[q]; }
         }
+    };
+    auto stage_ce = [&](int c0, int cbn) {
+        // the transposed dropped-out embeddings (zero beyond Lc and beyond the chunk)
+        for (int pr = tid; pr < EF_CHUNK * cbn; pr += NT) {              // pair (word, ci): one padded row of EF_PT positions
+            const int wi = pr / cbn, cl = pr - wi * cbn, ci = c0 + cl;
+            float* row = CeT + (wi * cb + cl) * EF_PT;
+            float v[LCM];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { const int e = e0 + tid + q * NT; if (e < char_dim * 100) reinterpret_cast<float4*>(Wt)[e] = v[q]; }
-    }
-    FSTAMP(1);
-    // ---- char ids, then the transposed dropped-out embeddings (zero beyond Lc and beyond the chunk)
+            for (int pp = 0; pp < LCM; ++pp)                            // all gathers of the row issued together
+                v[pp] = (wi < nw && pp < Lc) ? char_tab[(size_t)cids[wi * LCM + pp] * char_dim + ci] : 0.f;
+#pragma unroll
+            for (int pp = 0; pp < LCM; ++pp)
+                row[pp] = (pp < Lc) ? v[pp] * drop_mul(dc, (uint32_t)(((rbeg + wi) * Lc + pp) * char_dim + ci)) : 0.f;
+#pragma unroll
+            for (int pp = LCM; pp < EF_PT; ++pp) row[pp] = 0.f;
+        }
+    };
+    if (cb >= char_dim) stage_w(0, char_dim);       // single block: the weight copy overlaps the id / word-vector phase
+    // ---- char ids and word vectors (independent of everything below)
     for (int e = tid; e < EF_CHUNK * LCM; e += NT) {
         const int wi = e / LCM, pp = e - wi * LCM;
         cids[e] = (wi < nw && pp < Lc) ? (int)char_ids[(size_t)(rbeg + wi) * Lc + pp] : 0;
     }
-    // ---- word vectors (independent of the above)
     for (int e = tid; e < nw * word_dim; e += NT) {
         const int wi = e / word_dim, c = e - wi * word_dim;
         const int r = rbeg + wi;
@@ -320,85 +351,79 @@ __global__ __launch_bounds__(512) void k_embed_fwd(const int64_t* __restrict__ w
         E[(size_t)r * EW + c] = src[c] * drop_mul(dw, (uint32_t)(r * word_dim + c));
     }
     __syncthreads();
-    FSTAMP(2);
-    for (int pr = tid; pr < EF_CHUNK * char_dim; pr += NT) {         // pair (word, ci): one padded row of EF_PT positions
-        const int wi = pr / char_dim, ci = pr - wi * char_dim;
-        float* row = CeT + pr * EF_PT;
-        float v[LCM];
-#pragma unroll
-        for (int pp = 0; pp < LCM; ++pp)                            // all gathers of the row issued together
-            v[pp] = (wi < nw && pp < Lc) ? char_tab[(size_t)cids[wi * LCM + pp] * char_dim + ci] : 0.f;
-#pragma unroll
-        for (int pp = 0; pp < LCM; ++pp)
-            row[pp] = (pp < Lc) ? v[pp] * drop_mul(dc, (uint32_t)(((rbeg + wi) * Lc + pp) * char_dim + ci)) : 0.f;
-#pragma unroll
-        for (int pp = LCM; pp < EF_PT; ++pp) row[pp] = 0.f;
-    }
-    __syncthreads();
-    FSTAMP(3);
+    FSTAMP(1);
     // ---- char CNN on the matrix cores: out[p][oc] = sum_{kk, ci} Ce[p + kk][ci] W[oc][ci][kk] is a (positions x 4*char_dim)
     //      x (4*char_dim x 100) product per word (taps beyond a channel's kernel width are zero in the image).  wave = word,
     //      16 positions per MFMA tile, 7 tiles of 16 channels share every A operand; bias + ReLU + max / arg-max over the
     //      positions (:58, 69-70) happen in the accumulator registers and two shuffles.
     {
         const int w = tid >> 6, lane = tid & 63, jl = lane & 15, g4 = lane >> 4;
-        if (w < nw) {
-            const float* ce = CeT + w * char_dim * EF_PT;
-            const int ncg = (char_dim + 3) >> 2;
-            float best[7], bias[7];
-            int bestp[7], kw[7];
+        const bool single = cb >= char_dim;
+        if (single) { stage_ce(0, char_dim); __syncthreads(); }
+        FSTAMP(2);
+        const float* ce = CeT + w * cb * EF_PT;
+        float best[7], bias[7];
+        int bestp[7], kw[7];
+#pragma unroll
+        for (int nt = 0; nt < 7; ++nt) {
+            const int oc = 16 * nt + jl;
+            best[nt] = -1.f; bestp[nt] = 0;
+            kw[nt] = oc < 10 ? 1 : oc < 30 ? 2 : oc < 60 ? 3 : 4;
+            bias[nt] = oc < 10 ? cc.b[0][oc] : oc < 30 ? cc.b[1][oc - 10] : oc < 60 ? cc.b[2][oc - 30] : oc < 100 ? cc.b[3][oc - 60] : 0.f;
+        }
+        for (int mt = 0; 16 * mt < Lc; ++mt) {
+            f32x4 acc[7];
+#pragma unroll
+            for (int nt = 0; nt < 7; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int c0 = 0; c0 < char_dim; c0 += cb) {
+                const int cbn = min(cb, char_dim - c0);
+                if (!single) { __syncthreads(); stage_w(c0, cbn); stage_ce(c0, cbn); __syncthreads(); }     // (block-uniform: every wave takes the barriers)
+                if (w < nw) {
+                    const int ncg = (cbn + 3) >> 2;
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        // operands of step cg + 1 are requested before the MFMAs of step cg (one-deep register pipeline)
+                        float av, bv[7], an, bn[7];
+                        auto ld = [&](int cg, float& a_, float (&b_)[7]) {
+                            const int ci = 4 * cg + g4;
+                            const bool okc = ci < cbn;
+                            a_ = okc ? ce[ci * EF_PT + 16 * mt + jl + kk] : 0.f;
+                            const float* wr = Wt + (ci * 4 + kk) * 100 + jl;
+#pragma unroll
+                            for (int nt = 0; nt < 7; ++nt)
+                                if ((kk < 2) || (kk == 2 && nt >= 1) || (kk == 3 && nt >= 3))
+                                    b_[nt] = (okc && 16 * nt + jl < 100) ? wr[16 * nt] : 0.f;
+                        };
+                        ld(0, av, bv);
+                        for (int cg = 0; cg < ncg; ++cg) {
+                            if (cg + 1 < ncg) ld(cg + 1, an, bn);
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int nt = 0; nt < 7; ++nt) {
+                                // channel tiles whose widest kernel is narrower than this tap hold only zeros: skipped
+                                if ((kk < 2) || (kk == 2 && nt >= 1) || (kk == 3 && nt >= 3))
+                                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[nt], acc[nt], 0, 0, 0);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                            av = an;
+#pragma unroll
+                            for (int nt = 0; nt < 7; ++nt) bv[nt] = bn[nt];
+                        }
+                    }
+                }
+            }
 #pragma unroll
             for (int nt = 0; nt < 7; ++nt) {
-                const int oc = 16 * nt + jl;
-                best[nt] = -1.f; bestp[nt] = 0;
-                kw[nt] = oc < 10 ? 1 : oc < 30 ? 2 : oc < 60 ? 3 : 4;
-                bias[nt] = oc < 10 ? cc.b[0][oc] : oc < 30 ? cc.b[1][oc - 10] : oc < 60 ? cc.b[2][oc - 30] : oc < 100 ? cc.b[3][oc - 60] : 0.f;
-            }
-            for (int mt = 0; 16 * mt < Lc; ++mt) {
-                f32x4 acc[7];
+                const int npos = Lc - kw[nt] + 1;
 #pragma unroll
-                for (int nt = 0; nt < 7; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    // operands of step cg + 1 are requested before the MFMAs of step cg (one-deep register pipeline)
-                    float av, bv[7], an, bn[7];
-                    auto ld = [&](int cg, float& a_, float (&b_)[7]) {
-                        const int ci = 4 * cg + g4;
-                        const bool okc = ci < char_dim;
-                        a_ = okc ? ce[ci * EF_PT + 16 * mt + jl + kk] : 0.f;
-                        const float* wr = Wt + (ci * 4 + kk) * 100 + jl;
-#pragma unroll
-                        for (int nt = 0; nt < 7; ++nt)
-                            if ((kk < 2) || (kk == 2 && nt >= 1) || (kk == 3 && nt >= 3))
-                                b_[nt] = (okc && 16 * nt + jl < 100) ? wr[16 * nt] : 0.f;
-                    };
-                    ld(0, av, bv);
-                    for (int cg = 0; cg < ncg; ++cg) {
-                        if (cg + 1 < ncg) ld(cg + 1, an, bn);
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int nt = 0; nt < 7; ++nt) {
-                            // channel tiles whose widest kernel is narrower than this tap hold only zeros: skipped
-                            if ((kk < 2) || (kk == 2 && nt >= 1) || (kk == 3 && nt >= 3))
-                                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[nt], acc[nt], 0, 0, 0);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                        av = an;
-#pragma unroll
-                        for (int nt = 0; nt < 7; ++nt) bv[nt] = bn[nt];
-                    }
-                }
-#pragma unroll
-                for (int nt = 0; nt < 7; ++nt) {
-                    const int npos = Lc - kw[nt] + 1;
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) {
-                        const int pp = 16 * mt + 4 * g4 + rr;
-                        const float v = fmaxf(acc[nt][rr] + bias[nt], 0.f);
-                        if (pp < npos && v > best[nt]) { best[nt] = v; bestp[nt] = pp; }     // first maximum wins
-                    }
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int pp = 16 * mt + 4 * g4 + rr;
+                    const float v = fmaxf(acc[nt][rr] + bias[nt], 0.f);
+                    if (pp < npos && v > best[nt]) { best[nt] = v; bestp[nt] = pp; }     // first maximum wins
                 }
             }
+        }
+        if (w < nw) {
             const int r = rbeg + w;
 #pragma unroll
             for (int nt = 0; nt < 7; ++nt) {
@@ -418,26 +443,29 @@ __global__ __launch_bounds__(512) void k_embed_fwd(const int64_t* __restrict__ w
             }
         }
     }
-    FSTAMP(4);
+    FSTAMP(3);
 }
 void launch_embed_fwd(const int64_t* word_ids, const int64_t* char_ids, const float* pad_vec, const float* unk_vec,
                       const float* glove, const float* char_tab, CharConvPtrs cc, const float* wimg, float* E, int8_t* argpos,
                       int Rq, int Lc, int word_dim, int char_dim, Drop dw, Drop dc, hipStream_t s) {
     const int lcm = Lc <= 24 ? 24 : MAX_LC;
-    const size_t shm = (size_t)(char_dim * 400 + EF_CHUNK * char_dim * (lcm + 4) + 32) * sizeof(float);   // + slack: invalid positions over-read
+    // input-channel block: everything up to 64 channels in one block, beyond that equal blocks of at most 52 (multiples of 4)
+    const int nblk = char_dim <= 64 ? 1 : (char_dim + 51) / 52;
+    const int cb = nblk == 1 ? char_dim : (((char_dim + nblk - 1) / nblk) + 3) & ~3;
+    const size_t shm = (size_t)(cb * 400 + EF_CHUNK * cb * (lcm + 4) + 32) * sizeof(float);   // + slack: invalid positions over-read
     static size_t ok24 = 0, ok40 = 0;
     const dim3 grid((Rq + EF_CHUNK - 1) / EF_CHUNK);
     if (lcm == 24) {
         ensure_dynamic_lds((const void*)k_embed_fwd<24>, shm, ok24, "k_embed_fwd<24>");
         VSL_LAUNCH(k_embed_fwd<24>, grid, dim3(512), shm, s, word_ids, char_ids, pad_vec, unk_vec, glove, char_tab, cc, wimg, E,
-                           argpos, Rq, Lc, word_dim, char_dim, dw, dc);
+                           argpos, Rq, Lc, word_dim, char_dim, cb, dw, dc);
     } else {
         ensure_dynamic_lds((const void*)k_embed_fwd<MAX_LC>, shm, ok40, "k_embed_fwd<40>");
         VSL_LAUNCH(k_embed_fwd<MAX_LC>, grid, dim3(512), shm, s, word_ids, char_ids, pad_vec, unk_vec, glove, char_tab, cc, wimg,
-                           E, argpos, Rq, Lc, word_dim, char_dim, dw, dc);
+                           E, argpos, Rq, Lc, word_dim, char_dim, cb, dw, dc);
     }
     static int left = 2;
-    if (fdbg_on()) fdbg_report("embed_fwd: weights | ids+words | CeT | items", 5, s, left);
+    if (fdbg_on()) fdbg_report("embed_fwd: ids+words | weights+CeT | items", 4, s, left);
 }
 
 // =========================================================================================================

@@ -14,7 +14,7 @@ struct PackJob {          // one weight -> packed B-operand copy (see common.hpp
     int dst;              // float offset into the pack buffer
     int kn, cn;           // extent of the contraction index / of the output-column index covered by this job
     int ld;               // leading dimension of the source matrix
-    int transpose;        // 0: Bm[k][c] = W[c][k] (forward pack)   1: Bm[k][c] = W[k][c] (data-gradient pack)  2: copy  3: char-conv image  4: zero fill
+    int transpose;        // 0: Bm[k][c] = W[c][k] (forward pack)   1: Bm[k][c] = W[k][c] (data-gradient pack)  2: copy  3: char-conv image  4: zero fill  8: char-conv B-operand image of k_embed_bwd
                           // 5: bf16 forward pack   6 / 7: SPLIT packs (three bf16 planes h, m, l; common.hpp pack3_index) of the forward / data-gradient operand
     int ncols;            // total columns of the packed operand
     int k_off, col_off;   // placement inside the packed operand
@@ -263,8 +263,8 @@ void launch_cq_bwd_query(const CqBwdArgs& a, int B, hipStream_t s);    // kernel
 void launch_linear_bwd_data(const float* G, const float* WTpack, float* dA, int R, int K, hipStream_t s, int seg = 0, int stride = 0,
                             int off = 0);      // seg > 0: rows of one time chunk of a (B, T, .) tensor
 void launch_embed_bwd(const float* dE, const int64_t* word_ids, const int64_t* char_ids, const float* E,
-                      const int8_t* argpos, const float* char_tab, CharConvPtrs cc,
-                      float* p_cw /*[nchunk][15000]*/,
+                      const int8_t* argpos, const float* char_tab, const float* wimg_b /* type-8 pack */,
+                      float* p_cw /*[nchunk][300 char_dim]*/,
                       float* p_cb /*[nchunk][100]*/, float* p_tab /*[nchunk][char_size*char_dim]*/,
                       float* p_unk /*[nchunk][word_dim]*/, int Rq, int Lc, int word_dim, int char_dim, int char_size, Drop dw,
                       Drop dc, hipStream_t s);
@@ -275,8 +275,9 @@ constexpr int OPT_BLOCKS = 256;
 void launch_adamw(float* params, const float* grads, float* m, float* v, const uint8_t* decay_mask, float* partials /*[OPT_BLOCKS + 1]*/,
                   int64_t n, float lr, float b1, float b2, float eps, float wd, float clip, float bc1, float bc2_sqrt,
                   float* norm_out, hipStream_t s, int hf_order = 0);
-constexpr int EMB_CHUNK = 4;     // query words per workgroup in the embedding backward (5 = one workgroup per CU at Rq = 1280: same 45 us -- the
-                                 // kernel's time is per-workgroup fixed cost, not rounds; 8: 59 us)
+constexpr int EMB_CHUNK_MAX = 8;  // most query words per workgroup in the embedding backward
+int embed_bwd_chunk(int Rq, int Lc, int char_dim);      // words per workgroup the launcher uses (the number of partial slabs follows from it)
+constexpr int EB_IMG_Q = 76;      // k-steps of the embedding backward's B-operand image ([channel tile][76][64 lanes], PackJob type 8)
 constexpr int CHARW_TOTAL = 15000;
 
 }  // namespace vsl

@@ -324,7 +324,7 @@ def synthetic_dataset(configs, n_train=512, n_test=128, n_words=200, n_chars=30,
 
 # limits of the HIP engine (vslnet_amd/csrc/common.hpp: MAX_LQ, MAX_LC; api.hip vsl_create): checked against the WHOLE dataset
 # before the first step, so that one long query or token cannot abort a run in the middle of an epoch
-ENGINE_MAX_WORDS, ENGINE_MAX_CHARS, ENGINE_MAX_CHAR_DIM = 128, 40, 64
+ENGINE_MAX_WORDS, ENGINE_MAX_CHARS, ENGINE_MAX_CHAR_DIM = 128, 40, 128
 
 
 def validate_dataset(dataset, configs):
@@ -332,7 +332,7 @@ def validate_dataset(dataset, configs):
     inside the engine's limits.  Raises ValueError naming the first offending record."""
     n_words, n_chars = int(dataset['n_words']), int(dataset['n_chars'])
     if int(getattr(configs, 'char_dim', 50)) > ENGINE_MAX_CHAR_DIM:
-        raise ValueError('--char_dim %d: the HIP embedding kernels hold a word\'s character rows in LDS and support char_dim <= %d'
+        raise ValueError('--char_dim %d: the HIP embedding kernels stage character rows in LDS with a row stride of at most %d floats'
                          % (configs.char_dim, ENGINE_MAX_CHAR_DIM))
     for split in ('train_set', 'val_set', 'test_set'):
         for r in dataset.get(split) or []:
