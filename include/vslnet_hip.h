@@ -35,6 +35,10 @@ typedef struct {
     int32_t char_size;         /* configs.char_size  = rows of the character table                        */
     int32_t predictor;         /* 0 = 'rnn' (DynamicRNN, layers_t7.py:302-313), 1 = 'transformer'         */
     float drop_rate;           /* configs.drop_rate                                                        */
+    int32_t word_table;        /* 0: WordEmbedding(word_vectors=GloVe): frozen [pad; glove] + trainable unk_vec (layers_t7.py:29-34)
+                                * 1: WordEmbedding(word_vectors=None): trainable nn.Embedding(word_size, word_dim, padding_idx=0)
+                                *    (:36) -- the parameter "embedding_net.word_emb.word_emb.weight" replaces unk_vec and
+                                *    vsl_io.pad_vec / glove_vec are ignored (may be NULL)                                  */
 } vsl_config;
 
 /* One forward / backward problem instance.  Replaces the argument list of VSLNet.forward (VSLNet_t7.py:52) plus
@@ -84,7 +88,7 @@ typedef struct {
 } vsl_io;
 /* Every struct of this header must be zero-initialised by the caller before the fields are set: new optional fields are appended, and
  * zero means "off".  vsl_abi_version() changes whenever a struct layout or an entry point's meaning changes; a binding checks it once. */
-#define VSL_ABI_VERSION 3
+#define VSL_ABI_VERSION 4
 int vsl_abi_version(void);
 
 /* labels + weights for the fused loss (replaces compute_loss / compute_highlight_loss, VSLNet_t7.py:67-72, and the

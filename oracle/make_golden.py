@@ -41,6 +41,8 @@ CASES = {
     'long_tf':  (dict(video_feature_dim=64, max_pos_len=256, word_size=52), 2, 200, 12, 5, True),
     # main_t7.py:24: "--char_dim ... 100 for activitynet"
     'chardim100_tf': (dict(video_feature_dim=64, max_pos_len=32, word_size=52, char_dim=100), 3, 24, 7, 12, True),
+    # WordEmbedding(word_vectors=None): the trainable nn.Embedding branch (layers_t7.py:36, 43-44)
+    'wordtable_tf': (dict(video_feature_dim=64, max_pos_len=32, word_size=52, word_table=True), 3, 24, 7, 6, True),
 }
 
 
@@ -52,7 +54,7 @@ def run_case(VSLNet, name, spec):
     cfg = O.make_cfg(**over)
     torch.manual_seed(12345)
     glove = np.zeros((cfg.word_size - 2, cfg.word_dim), np.float32)     # overwritten by load_state_dict
-    model = VSLNet(configs=cfg, word_vectors=glove)
+    model = VSLNet(configs=cfg, word_vectors=None if getattr(cfg, 'word_table', False) else glove)
     # weights come from the build's own seeded factory and are loaded into the reference model with
     # strict=True -- this both keeps the fixture small (no weights stored, only checksums) and pins the
     # state_dict schema (names + shapes) against the reference.
@@ -224,9 +226,9 @@ def run_init(VSLNet):
     """a19 (VSLNet_t7.py:42-50): the reference constructed under torch.manual_seed(INIT_SEED) -- checksums of its freshly
     initialised state_dict for both predictor heads.  The build's module must reproduce them bit for bit under the same seed."""
     out = {'seed': np.int64(INIT_SEED)}
-    for pred in ('transformer', 'rnn'):
-        cfg = O.make_cfg(video_feature_dim=64, max_pos_len=32, word_size=52, predictor=pred)
-        glove = np.random.RandomState(0).randn(cfg.word_size - 2, cfg.word_dim).astype(np.float32)
+    for pred in ('transformer', 'rnn', 'transformer_wordtable'):
+        cfg = O.make_cfg(video_feature_dim=64, max_pos_len=32, word_size=52, predictor=pred.split('_')[0])
+        glove = None if pred.endswith('wordtable') else np.random.RandomState(0).randn(cfg.word_size - 2, cfg.word_dim).astype(np.float32)
         torch.manual_seed(INIT_SEED)
         sd = VSLNet(configs=cfg, word_vectors=glove).state_dict()
         out['keys.' + pred] = np.array(list(sd.keys()))

@@ -85,7 +85,10 @@ def visual_projection(P, vfeat, p, training):
 
 
 def word_embedding(P, word_ids, p, training):
-    """WordEmbedding.forward (pretrained branch), layers_t7.py:39-45: table = [pad; unk; glove]."""
+    """WordEmbedding.forward, layers_t7.py:39-45: table = [pad; unk; glove] (word vectors given) or the trainable
+    nn.Embedding(word_size, word_dim, padding_idx=0) of the word_vectors=None branch (:36, 43-44)."""
+    if 'embedding_net.word_emb.word_emb.weight' in P:
+        return _drop(F.embedding(word_ids, P['embedding_net.word_emb.word_emb.weight'], padding_idx=0), p, training)
     table = torch.cat([P['embedding_net.word_emb.pad_vec'], P['embedding_net.word_emb.unk_vec'],
                        P['embedding_net.word_emb.glove_vec']], dim=0)
     return _drop(table[word_ids], p, training)
@@ -417,9 +420,12 @@ def param_shapes(cfg):
     """state_dict key -> shape for the transformer / rnn variants."""
     d, Dv = cfg.dim, cfg.video_feature_dim
     S = {}
-    S['embedding_net.word_emb.pad_vec'] = (1, cfg.word_dim)
-    S['embedding_net.word_emb.unk_vec'] = (1, cfg.word_dim)
-    S['embedding_net.word_emb.glove_vec'] = (cfg.word_size - 2, cfg.word_dim)
+    if getattr(cfg, 'word_table', False):               # WordEmbedding(word_vectors=None), layers_t7.py:36
+        S['embedding_net.word_emb.word_emb.weight'] = (cfg.word_size, cfg.word_dim)
+    else:
+        S['embedding_net.word_emb.pad_vec'] = (1, cfg.word_dim)
+        S['embedding_net.word_emb.unk_vec'] = (1, cfg.word_dim)
+        S['embedding_net.word_emb.glove_vec'] = (cfg.word_size - 2, cfg.word_dim)
     S['embedding_net.char_emb.char_emb.weight'] = (cfg.char_size, cfg.char_dim)
     for i, (k, c) in enumerate(zip(CHAR_KERNELS, CHAR_CHANNELS)):
         S['embedding_net.char_emb.char_convs.%d.0.weight' % i] = (c, cfg.char_dim, 1, k)
@@ -488,10 +494,10 @@ def random_params(cfg, seed=12345, perturb=True):
     for k, shp in param_shapes(cfg).items():
         if k.endswith('pad_vec'):
             t = torch.zeros(shp)
-        elif k.endswith('glove_vec') or 'position_embeddings' in k or k.endswith('char_emb.weight'):
+        elif k.endswith('glove_vec') or 'position_embeddings' in k or k.endswith('char_emb.weight') or k.endswith('word_emb.weight'):
             t = torch.randn(shp, generator=g)
-            if k.endswith('char_emb.weight'):
-                t[0] = 0.0                                                 # padding_idx=0 row (layers_t7.py:51)
+            if k.endswith('char_emb.weight') or k.endswith('word_emb.weight'):
+                t[0] = 0.0                                                 # padding_idx=0 row (layers_t7.py:36, 51)
         elif ('layer_norm' in k) and k.endswith('weight'):
             t = torch.ones(shp) + (0.1 * torch.randn(shp, generator=g) if perturb else 0.0)
         elif k.endswith('bias') or 'lstm.bias' in k:

@@ -11,7 +11,7 @@ from tests.helpers import load_golden, grad_tol, relu_flips
 
 pytestmark = pytest.mark.gpu
 
-CASES = ['tiny_tf', 'real_tf', 'long_tf', 'chardim100_tf']
+CASES = ['tiny_tf', 'real_tf', 'long_tf', 'chardim100_tf', 'wordtable_tf']
 ATOL = 1e-4
 
 
@@ -28,7 +28,8 @@ def _setup(name):
 
 
 def _run_forward(eng, flat, P, b, training=False, seed=0):
-    return eng.forward(flat, _dev(P['embedding_net.word_emb.pad_vec']), _dev(P['embedding_net.word_emb.glove_vec']),
+    pad, glove = P.get('embedding_net.word_emb.pad_vec'), P.get('embedding_net.word_emb.glove_vec')     # absent: trainable word table
+    return eng.forward(flat, None if pad is None else _dev(pad), None if glove is None else _dev(glove),
                        _dev(b['word_ids']), _dev(b['char_ids']), _dev(b['vfeats']), _dev(b['v_mask']), _dev(b['q_mask']),
                        training=training, seed=seed)
 

@@ -27,7 +27,8 @@ def _dev(b):
 
 
 def _fwd(eng, flat, P, d, training, seed):
-    return eng.forward(flat, P['embedding_net.word_emb.pad_vec'].cuda(), P['embedding_net.word_emb.glove_vec'].cuda(),
+    pad, glove = P.get('embedding_net.word_emb.pad_vec'), P.get('embedding_net.word_emb.glove_vec')     # absent: trainable word table
+    return eng.forward(flat, None if pad is None else pad.cuda(), None if glove is None else glove.cuda(),
                        d['word_ids'], d['char_ids'], d['vfeats'], d['v_mask'], d['q_mask'], training=training, seed=seed)
 
 
@@ -107,13 +108,15 @@ def test_dropout_forward_backward_consistency_by_finite_differences(dv, B, T, Lq
     (1024, 16, 128, 20, 10, 'rnn', 50),         # BASELINE configs[0] as written
     (64, 3, 40, 7, 20, 'transformer', 100),     # main_t7.py:24's ActivityNet char_dim: two input-channel blocks x two position tiles forward, 7 channel tiles backward
     (64, 2, 30, 9, 40, 'transformer', 128),     # the engine's bounds: longest token, widest character embedding
-    (64, 5, 24, 6, 8, 'transformer', 72)])      # a width that is no multiple of 16
+    (64, 5, 24, 6, 8, 'transformer', 72),       # a width that is no multiple of 16
+    (64, 6, 24, 9, 6, 'transformer', -50)])     # (negative: WordEmbedding(word_vectors=None), the trainable table; 54 words over 100 ids: repeats)
 def test_training_mode_matches_oracle_on_the_same_dropout_masks(dv, B, T, Lq, Lc, predictor, char_dim):
     """drop_rate 0.2 (the benchmark's mode), all 41 dropout sites: the oracle is handed the HIP path's masks -- recomputed on
     the host from the documented counter-based hash (tests/helpers.py) -- and must then agree with the training-mode forward
     (logits 1e-4) and with every gradient (1e-4 * |g|inf + 1e-6), like the eval-mode parity tests."""
     from tests.helpers import relu_flips, hip_dropout
-    cfg = O.make_cfg(video_feature_dim=dv, max_pos_len=max(T, Lq), word_size=102, drop_rate=0.2, predictor=predictor, char_dim=char_dim)
+    cfg = O.make_cfg(video_feature_dim=dv, max_pos_len=max(T, Lq), word_size=102, drop_rate=0.2, predictor=predictor, char_dim=abs(char_dim),
+                     word_table=char_dim < 0)
     P = O.random_params(cfg, seed=21)
     b = O.synthetic_batch(cfg, B, T, Lq, Lc, seed=22, ragged=True)
     d = _dev(b)

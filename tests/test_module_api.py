@@ -10,13 +10,14 @@ from tests.helpers import load_golden, grad_tol
 
 def _module(cfg, P):
     from model.VSLNet import VSLNet
-    m = VSLNet(cfg, np.zeros((cfg.word_size - 2, cfg.word_dim), np.float32))
+    m = VSLNet(cfg, None if getattr(cfg, 'word_table', False) else np.zeros((cfg.word_size - 2, cfg.word_dim), np.float32))
     m.load_state_dict(P, strict=True)
     return m
 
 
-def test_state_dict_schema_matches_reference():
-    cfg, P, b, z = load_golden('tiny_tf')
+@pytest.mark.parametrize('name', ['tiny_tf', 'wordtable_tf'])      # GloVe vectors given / WordEmbedding(word_vectors=None)
+def test_state_dict_schema_matches_reference(name):
+    cfg, P, b, z = load_golden(name)
     m = _module(cfg, P)
     sd = m.state_dict()
     ref_keys = [k[6:] for k in z.files if k.startswith('sdsum.')]
@@ -24,7 +25,8 @@ def test_state_dict_schema_matches_reference():
     shapes = O.param_shapes(cfg)
     for k, v in sd.items():
         assert tuple(v.shape) == tuple(shapes[k]), k
-    assert not sd['embedding_net.word_emb.glove_vec'].requires_grad
+    if name == 'tiny_tf':
+        assert not sd['embedding_net.word_emb.glove_vec'].requires_grad
     trainable = sum(p.numel() for p in m.parameters() if p.requires_grad)
     assert trainable == sum(int(np.prod(z['grad.' + n].shape)) for n, p in m.named_parameters() if p.requires_grad)
 
@@ -67,7 +69,7 @@ def test_optimizer_groups_and_linear_schedule():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('name', ['tiny_tf', 'real_tf'])
+@pytest.mark.parametrize('name', ['tiny_tf', 'real_tf', 'wordtable_tf'])
 def test_module_forward_backward_matches_reference(name):
     cfg, P, b, z = load_golden(name)
     m = _module(cfg, P).to('cuda').eval()

@@ -9,7 +9,7 @@ import torch
 from oracle import vslnet_oracle as O
 from tests.helpers import load_golden, grad_tol
 
-CASES = ['tiny_tf', 'tiny_rnn', 'real_tf', 'long_tf', 'chardim100_tf']
+CASES = ['tiny_tf', 'tiny_rnn', 'real_tf', 'long_tf', 'chardim100_tf', 'wordtable_tf']
 ATOL = 2e-5
 
 
@@ -117,9 +117,9 @@ def test_init_matches_reference_under_the_same_seed():
     from tests.helpers import GOLDEN
     from vslnet_amd.model.VSLNet import VSLNet
     z = np.load(os.path.join(GOLDEN, 'init.npz'), allow_pickle=False)
-    for pred in ('transformer', 'rnn'):
-        cfg = O.make_cfg(video_feature_dim=64, max_pos_len=32, word_size=52, predictor=pred)
-        glove = np.random.RandomState(0).randn(cfg.word_size - 2, cfg.word_dim).astype(np.float32)
+    for pred in ('transformer', 'rnn', 'transformer_wordtable'):
+        cfg = O.make_cfg(video_feature_dim=64, max_pos_len=32, word_size=52, predictor=pred.split('_')[0])
+        glove = None if pred.endswith('wordtable') else np.random.RandomState(0).randn(cfg.word_size - 2, cfg.word_dim).astype(np.float32)
         torch.manual_seed(int(z['seed']))
         sd = VSLNet(cfg, glove).state_dict()
         assert list(sd.keys()) == [str(k) for k in z['keys.' + pred]]
@@ -127,13 +127,3 @@ def test_init_matches_reference_under_the_same_seed():
             v64 = v.detach().double()
             got = np.array([float(v64.sum()), float(v64.abs().sum()), float(v64.flatten()[-1])])
             assert np.array_equal(got, z['%s.%s' % (pred, k)]), (pred, k, got, z['%s.%s' % (pred, k)])
-
-
-def test_untrained_word_table_branch_fails_loudly():
-    """layers_t7.py:36-37 (word_vectors=None -> trainable nn.Embedding) is the one constructor branch the HIP path does not
-    implement (main_t7.py:83 always passes GloVe): it must say so instead of building a model that cannot run."""
-    import pytest
-    from vslnet_amd.model.VSLNet import VSLNet
-    cfg = O.make_cfg(video_feature_dim=64, max_pos_len=32, word_size=52)
-    with pytest.raises(NotImplementedError, match='layers_t7.py:36-37'):
-        VSLNet(cfg, None)

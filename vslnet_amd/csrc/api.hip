@@ -178,7 +178,8 @@ void build_params(vsl_handle_s* h) {
     ParamBuilder pb{h};
     ModelP& P = h->P;
     const int64_t d = D;
-    P.unk = pb.add("embedding_net.word_emb.unk_vec", {1, c.word_dim});
+    if (c.word_table) P.unk = pb.add("embedding_net.word_emb.word_emb.weight", {c.word_size, c.word_dim});      // rows 0 / 1 stand where pad_vec / unk_vec do
+    else P.unk = pb.add("embedding_net.word_emb.unk_vec", {1, c.word_dim});
     P.char_tab = pb.add("embedding_net.char_emb.char_emb.weight", {c.char_size, c.char_dim});
     const int ch[4] = {10, 20, 30, 40};
     for (int i = 0; i < 4; ++i) {
@@ -590,7 +591,8 @@ void run_forward(Ctx& c) {
         LAUNCH("vproj_fwd", launch_vproj_fwd(io.video_features, c.PK(K.va_f), c.P(P.va_b), c.W(p.vf), R, cf.video_feature_dim, c.drop(SITE_VIS), c.s));
     enc_fwd(c, P.fe, K.fe, p.ve, c.W(p.vf), io.v_mask, B, 0);
     c.s = qlong ? c.main : sq;
-    LAUNCH("embed_fwd", launch_embed_fwd(io.word_ids, io.char_ids, io.pad_vec, c.P(P.unk), io.glove_vec, c.P(P.char_tab), char_ptrs(c), c.PK(K.ccw_img), c.W(p.E),
+    const bool wt = cf.word_table != 0;       // trainable word table: its rows 0, 1, 2.. are pad, unk, the vocabulary
+    LAUNCH("embed_fwd", launch_embed_fwd(io.word_ids, io.char_ids, wt ? c.P(P.unk) : io.pad_vec, c.P(P.unk) + (wt ? cf.word_dim : 0), wt ? c.P(P.unk) + 2 * cf.word_dim : io.glove_vec, c.P(P.char_tab), char_ptrs(c), c.PK(K.ccw_img), c.W(p.E),
                      reinterpret_cast<int8_t*>(c.W(p.argpos)), Rq, p.Lc, cf.word_dim, cf.char_dim, c.drop(SITE_WORD),
                      c.drop(SITE_CHAR), c.s));
     if (split_gemm_enabled() && (cf.word_dim + 100) % 16 == 0)
@@ -993,11 +995,13 @@ void run_backward(Ctx& c) {
             wo += wn; bo += ch[i];
         }
         float* p_tab = c.slab(P.char_tab, cf.char_size * cf.char_dim, nce);
-        float* p_unk = c.slab(P.unk, cf.word_dim, nce);
+        float* p_unk = cf.word_table ? nullptr : c.slab(P.unk, cf.word_dim, nce);
         LAUNCH("embed_bwd", launch_embed_bwd(c.W(p.dE), io->word_ids, io->char_ids, c.W(p.E), reinterpret_cast<const int8_t*>(c.W(p.argpos)),
                                 c.P(P.char_tab), c.PK(K.ccw_imgb), c.part_ptr(ow), c.part_ptr(ob), p_tab, p_unk, Rq,
                                 p.Lc, cf.word_dim, cf.char_dim, cf.char_size, c.drop(SITE_WORD), c.drop(SITE_CHAR), c.s));
     }
+    if (cf.word_table && !c.dry)
+        LAUNCH("word_table_bwd", launch_word_table_bwd(c.W(p.dE), io->word_ids, io->grads + P.unk, Rq, cf.word_size, cf.word_dim, c.drop(SITE_WORD), c.s));
     c.s = main_s;
     c.order(sq, c.s);                      // join both side streams before the reduction
     c.order(sw, c.s);
@@ -1148,7 +1152,7 @@ int get_plan(vsl_handle_s* h, int B, int T, int Lq, int Lc, Plan** out) {
 
 int check_io(vsl_handle_s* h, const vsl_io* io) {
     if (!h || !io) return fail("null handle / io");
-    if (!io->params || !io->pad_vec || !io->glove_vec || !io->word_ids || !io->char_ids || (!io->video_features && !io->video_features_bf16) ||
+    if (!io->params || (!h->cfg.word_table && (!io->pad_vec || !io->glove_vec)) || !io->word_ids || !io->char_ids || (!io->video_features && !io->video_features_bf16) ||
         !io->v_mask || !io->q_mask || !io->h_score || !io->start_logits || !io->end_logits || !io->workspace)
         return fail("vsl_io has a null device pointer");
     if (io->video_features_bf16 && (h->cfg.video_feature_dim % 8 != 0))
@@ -1198,6 +1202,8 @@ int vsl_create(const vsl_config* cfg, vsl_handle* out) {
     if (cfg->predictor != 0 && cfg->predictor != 1) return fail("predictor must be 0 ('rnn') or 1 ('transformer'), got %d", cfg->predictor);
     if (cfg->video_feature_dim <= 0 || cfg->video_feature_dim % 4) return fail("video_feature_dim=%d must be a positive multiple of 4 (rows are read as float4)", cfg->video_feature_dim);
     if ((cfg->word_dim + 100) % 8) return fail("word_dim + 100 = %d must be a multiple of 8", cfg->word_dim + 100);
+    if (cfg->word_table != 0 && cfg->word_table != 1) return fail("word_table must be 0 (frozen vectors + unk_vec) or 1 (trainable table), got %d", cfg->word_table);
+    if (cfg->word_table && (cfg->word_dim > 512 || cfg->word_size < 2)) return fail("trainable word table: word_dim=%d must be <= 512 and word_size=%d >= 2", cfg->word_dim, cfg->word_size);
     if (cfg->char_dim <= 0 || cfg->char_dim > 128) return fail("char_dim=%d must be in [1, 128]", cfg->char_dim);
     if (cfg->char_size <= 0 || cfg->char_size * cfg->char_dim > 65536) return fail("char table of %d x %d floats: every embedding-backward workgroup writes one partial copy, 65536 floats is the limit", cfg->char_size, cfg->char_dim);
     if (cfg->max_pos_len <= 0 || cfg->word_size < 2) return fail("bad max_pos_len / word_size");

@@ -1591,7 +1591,7 @@ __global__ __launch_bounds__(512) void k_embed_bwd(const float* __restrict__ dE,
         gp[e] = make_int2(ps, __float_as_int(g));
     }
     float uacc = 0.f;
-    if (tid < word_dim) {
+    if (p_unk && tid < word_dim) {
         // unk_vec row of the [pad; unk; glove] table (:41): every row load of the chunk issued unconditionally, then masked
         float u[EMB_CHUNK_MAX];
 #pragma unroll
@@ -1726,7 +1726,7 @@ __global__ __launch_bounds__(512) void k_embed_bwd(const float* __restrict__ dE,
         }
         STAMP(4);
     }
-    if (tid < word_dim) p_unk[(size_t)blockIdx.x * word_dim + tid] = uacc;
+    if (p_unk && tid < word_dim) p_unk[(size_t)blockIdx.x * word_dim + tid] = uacc;
 }
 // words per workgroup: the smallest chunk whose grid fits one round of the 256 CUs, at least 4 (slab traffic), at most 8 and at most
 // 80 (char_dim <= 64) / 48 rows (the LDS footprint: 145 / 113 KB at the bound)
@@ -1749,6 +1749,51 @@ void launch_embed_bwd(const float* dE, const int64_t* word_ids, const int64_t* c
                        char_tab, wimg_b, p_cw, p_cb, p_tab, p_unk, Rq, Lc, word_dim, char_dim, char_size, cdp, chunk, dw, dc);
     static int left = 2;
     if (dbg_budget("embed_bwd")) dbg_report("embed_bwd: metadata | gather | dCe | table (waves 0-3)", 5, s, left);
+}
+
+// =========================================================================================================
+// a3 backward of the TRAINABLE word table (WordEmbedding(word_vectors=None), layers_t7.py:36: nn.Embedding(word_size, word_dim,
+// padding_idx=0)): gtab[wid] = sum over the occurrences of wid in the batch of dE[r][:word_dim] * dropout mask, rows that do not occur
+// and row 0 are zero.  Dense gradient, as torch.optim.AdamW sees it.  One workgroup per occurrence r: it owns the table row only if no
+// earlier row holds the same word, and then adds the occurrences in ascending r -- a fixed order: deterministic without atomics.  The
+// table region is cleared by k_zero4 first (the reduction kernel does not cover it).
+// =========================================================================================================
+__global__ __launch_bounds__(256) void k_zero4(float4* __restrict__ dst, int64_t n4) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += (int64_t)gridDim.x * 256) dst[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__global__ __launch_bounds__(128) void k_word_table_bwd(const float* __restrict__ dE, const int64_t* __restrict__ word_ids,
+                                                        float* __restrict__ gtab, int Rq, int word_dim, Drop dw) {
+    const int r = blockIdx.x, tid = threadIdx.x, EW = word_dim + 100;
+    const int64_t wid = word_ids[r];
+    if (wid == 0) return;                              // padding_idx = 0
+    __shared__ int seen;
+    if (tid == 0) seen = 0;
+    __syncthreads();
+    bool mine = false;
+    for (int q = tid; q < r; q += 128) mine |= word_ids[q] == wid;
+    if (mine) seen = 1;
+    __syncthreads();
+    if (seen) return;                                  // an earlier occurrence owns this table row
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};              // word_dim <= 512
+    for (int q = r; q < Rq; ++q)
+        if (word_ids[q] == wid) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = tid + 128 * j;
+                if (c < word_dim) acc[j] += dE[(size_t)q * EW + c] * drop_mul(dw, (uint32_t)(q * word_dim + c));
+            }
+        }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = tid + 128 * j;
+        if (c < word_dim) gtab[(size_t)wid * word_dim + c] = acc[j];
+    }
+}
+void launch_word_table_bwd(const float* dE, const int64_t* word_ids, float* gtab, int Rq, int word_size, int word_dim, Drop dw, hipStream_t s) {
+    const int64_t n4 = (int64_t)word_size * word_dim / 4;       // (the flat bucket keeps every parameter 4-float aligned; word_dim % 4 == 0)
+    const int zb = (int)((n4 + 255) / 256 < 1024 ? (n4 + 255) / 256 : 1024);
+    VSL_LAUNCH(k_zero4, dim3(zb), dim3(256), 0, s, reinterpret_cast<float4*>(gtab), n4);
+    VSL_LAUNCH(k_word_table_bwd, dim3(Rq), dim3(128), 0, s, dE, word_ids, gtab, Rq, word_dim, dw);
 }
 
 // =========================================================================================================

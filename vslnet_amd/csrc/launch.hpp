@@ -268,6 +268,8 @@ void launch_embed_bwd(const float* dE, const int64_t* word_ids, const int64_t* c
                       float* p_cb /*[nchunk][100]*/, float* p_tab /*[nchunk][char_size*char_dim]*/,
                       float* p_unk /*[nchunk][word_dim]*/, int Rq, int Lc, int word_dim, int char_dim, int char_size, Drop dw,
                       Drop dc, hipStream_t s);
+void launch_word_table_bwd(const float* dE, const int64_t* word_ids, float* gtab /*(word_size, word_dim) inside the gradient bucket*/, int Rq,
+                           int word_size, int word_dim, Drop dw, hipStream_t s);
 void launch_reduce(const float* ws, float* grads, const ReduceSeg* segs_dev, const int* blk2seg_dev, int nblocks,
                    hipStream_t s);
 // fused optimizer (vsl_adamw_step): sum of squares partials, then clip + AdamW

@@ -18,7 +18,8 @@ _LIB = None
 class vsl_config(C.Structure):
     _fields_ = [('dim', C.c_int32), ('num_heads', C.c_int32), ('max_pos_len', C.c_int32),
                 ('video_feature_dim', C.c_int32), ('word_dim', C.c_int32), ('char_dim', C.c_int32),
-                ('word_size', C.c_int32), ('char_size', C.c_int32), ('predictor', C.c_int32), ('drop_rate', C.c_float)]
+                ('word_size', C.c_int32), ('char_size', C.c_int32), ('predictor', C.c_int32), ('drop_rate', C.c_float),
+                ('word_table', C.c_int32)]
 
 
 class vsl_io(C.Structure):
@@ -53,7 +54,7 @@ ABI_SYMBOLS = ['vsl_last_error', 'vsl_create', 'vsl_destroy', 'vsl_param_count',
                'vsl_workspace_floats', 'vsl_forward', 'vsl_loss', 'vsl_backward', 'vsl_extract_index',
                'vsl_adamw_step', 'vsl_workspace_offset', 'vsl_profile_select', 'vsl_profile_read', 'vsl_abi_version',
                'vsl_early_grad_offset']
-ABI_VERSION = 3                                     # include/vslnet_hip.h: VSL_ABI_VERSION
+ABI_VERSION = 4                                     # include/vslnet_hip.h: VSL_ABI_VERSION
 
 
 def load_library():
@@ -118,7 +119,9 @@ def _chk(t, dtype, shape, name):
 class Engine:
     """One `vsl_handle` + caller-owned buffers.  Mirrors what VSLNet.__init__ / forward / backward need."""
 
-    def __init__(self, configs, device=None):
+    def __init__(self, configs, device=None, word_table=None):
+        """`word_table=True` (or configs.word_table): WordEmbedding(word_vectors=None), the trainable nn.Embedding branch
+        (layers_t7.py:36); forward() then takes pad_vec = glove_vec = None."""
         if not torch.cuda.is_available():
             raise VslError('vslnet_amd needs an MI355X (gfx950) visible to PyTorch-ROCm; there is no CPU fallback')
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
@@ -128,7 +131,8 @@ class Engine:
             raise ValueError('unknown predictor %r' % (configs.predictor,))
         self.cfg = vsl_config(int(configs.dim), int(configs.num_heads), int(configs.max_pos_len),
                               int(configs.video_feature_dim), int(configs.word_dim), int(configs.char_dim),
-                              int(configs.word_size), int(configs.char_size), pred, float(configs.drop_rate))
+                              int(configs.word_size), int(configs.char_size), pred, float(configs.drop_rate),
+                              int(bool(getattr(configs, 'word_table', False) if word_table is None else word_table)))
         self.configs = configs
         h = C.c_void_p()
         with torch.cuda.device(self.device):
@@ -214,8 +218,11 @@ class Engine:
         _chk(vfeats, torch.bfloat16 if bf16 else torch.float32, (B, T, self.cfg.video_feature_dim), 'video_features')
         _chk(v_mask, torch.float32, (B, T), 'v_mask')
         _chk(q_mask, torch.float32, (B, Lq), 'q_mask')
-        _chk(pad_vec, torch.float32, (1, self.cfg.word_dim), 'pad_vec')
-        _chk(glove_vec, torch.float32, (self.cfg.word_size - 2, self.cfg.word_dim), 'glove_vec')
+        if self.cfg.word_table:
+            pad_vec = glove_vec = None                  # rows 0, 1, 2.. of the trainable table inside `flat` stand in
+        else:
+            _chk(pad_vec, torch.float32, (1, self.cfg.word_dim), 'pad_vec')
+            _chk(glove_vec, torch.float32, (self.cfg.word_size - 2, self.cfg.word_dim), 'glove_vec')
         ws = self.workspace(B, T, Lq, Lc)
         out = torch.empty(3, B, T, dtype=torch.float32, device=self.device)
         io = vsl_io()

@@ -41,8 +41,9 @@ class _ForwardFn(torch.autograd.Function):
     def forward(ctx, model, word_ids, char_ids, vfeats, v_mask, q_mask, *params):
         eng = model._engine_for(vfeats.device)
         model._step += 1
-        h, sl, el = eng.forward(model._flat, model.embedding_net.word_emb.pad_vec.data,
-                                model.embedding_net.word_emb.glove_vec.data, word_ids.contiguous(), char_ids.contiguous(),
+        we = model.embedding_net.word_emb
+        h, sl, el = eng.forward(model._flat, we.pad_vec.data if we.is_pretrained else None,
+                                we.glove_vec.data if we.is_pretrained else None, word_ids.contiguous(), char_ids.contiguous(),
                                 vfeats.contiguous().float(), v_mask.contiguous().float(), q_mask.contiguous().float(),
                                 training=model.training, seed=(model._seed << 20) + model._step)
         ctx.model, ctx.token = model, model._step
@@ -134,7 +135,7 @@ class VSLNet(nn.Module):
         if pdev.type != 'cuda':
             raise RuntimeError('VSLNet (vslnet_amd) runs on an MI355X only: move the module with .to("cuda") first; there is '
                                'no CPU fallback')
-        eng = Engine(self.configs, device=pdev)
+        eng = Engine(self.configs, device=pdev, word_table=not self.embedding_net.word_emb.is_pretrained)
         named = dict(self.named_parameters())
         flat = eng.new_flat()
         for n, o, k, shp in eng.layout:

@@ -31,22 +31,20 @@ class Conv1D(_Fused):
 
 
 class WordEmbedding(_Fused):
-    """layers_t7.py:25-45 (pretrained branch only: pad_vec / unk_vec / glove_vec)."""
+    """layers_t7.py:25-45: frozen [pad; glove] vectors + a trainable unk_vec when word vectors are given (what main_t7.py:83 does),
+    a trainable nn.Embedding(num_words, word_dim, padding_idx=0) otherwise (vsl_config.word_table = 1)."""
 
     def __init__(self, num_words, word_dim, drop_rate, word_vectors=None):
         super().__init__()
-        if word_vectors is None:
-            # layers_t7.py:36-37, 43-44: a fully trainable nn.Embedding(num_words, word_dim).  main_t7.py:83 always passes the
-            # GloVe matrix, so the HIP embedding kernels cover the [pad; unk; glove] table only (gradient to unk_vec alone).
-            raise NotImplementedError('VSLNet(word_vectors=None): the trainable-word-table branch of WordEmbedding '
-                                      '(layers_t7.py:36-37) is not implemented by the HIP path; pass the GloVe matrix '
-                                      '(main_t7.py:83 always does)')
-        self.is_pretrained = True
-        self.pad_vec = nn.Parameter(torch.zeros(1, word_dim), requires_grad=False)
-        unk = torch.empty(1, word_dim)
-        nn.init.xavier_uniform_(unk)
-        self.unk_vec = nn.Parameter(unk)
-        self.glove_vec = nn.Parameter(torch.as_tensor(word_vectors, dtype=torch.float32).clone(), requires_grad=False)
+        self.is_pretrained = word_vectors is not None
+        if self.is_pretrained:
+            self.pad_vec = nn.Parameter(torch.zeros(1, word_dim), requires_grad=False)
+            unk = torch.empty(1, word_dim)
+            nn.init.xavier_uniform_(unk)
+            self.unk_vec = nn.Parameter(unk)
+            self.glove_vec = nn.Parameter(torch.as_tensor(word_vectors, dtype=torch.float32).clone(), requires_grad=False)
+        else:
+            self.word_emb = nn.Embedding(num_words, word_dim, padding_idx=0)
 
 
 class CharacterEmbedding(_Fused):
