@@ -298,6 +298,133 @@ __global__ __launch_bounds__(WG2_T, 1) void k_wgrad3(WgradBatch wb) {
     }
 }
 
+// =====================================================================================================================
+// k_wgrad4: the split products of k_wgrad3 with every operand element split ONCE per workgroup (round 3, second half).
+//
+// k_wgrad3 is LDS-free: each of its four waves splits the G columns and the A columns of its own 64 x 64 quadrant, so inside a
+// 128 x 128 block every element is split twice, and the VisualProjection job (K = 1024: eight k tiles) splits -- and, for A, hashes --
+// G sixteen times: 50 M split pairs + hashes for 9.4 M distinct elements (26 us).  Here the 8 waves of a workgroup stage a 16-row step of
+// both operands together: thread = one row pair x one column pair of G and of A (coalesced 8-byte loads, dropout, exact 3-way split),
+// written as bf16 planes [operand][term][row half][column][8 rows] -- a lane's MFMA operand (its column, rows 8h .. 8h+7) is one
+// ds_read_b128 and a wave reads 1 KiB without a bank conflict.  wave = 64 (n) x 32 (k) of the block: 9
+// operand reads feed 12 MFMAs per step.  Two LDS buffers, ONE barrier per step (the reads of step s - 1 precede every wave's arrival at
+// barrier s, the writes of step s + 1 follow it); raw rows travel three steps ahead in registers.  48 KB of LDS.
+// =====================================================================================================================
+constexpr int WG4_T = 512, WG4_NB = 4;
+// dword index of row pair rg (rows 2 rg, 2 rg + 1) of column c: the two 8-row halves of a column live in separate arrays, so the 16 lanes of a
+// ds_read_b128 phase (consecutive columns, one half) cover all 64 banks once
+__device__ __forceinline__ int wg4_idx(int buf, int o, int p, int c, int rg) { return (((((buf * 2 + o) * 3 + p) * 2 + (rg >> 2)) * 128 + c) << 2) + (rg & 3); }
+template <bool DROP>
+__global__ __launch_bounds__(WG4_T, 1) void k_wgrad4(WgradBatch wb) {
+    __shared__ __attribute__((aligned(16))) uint32_t Ps[2 * 2 * 3 * 128 * 8];
+    int ji = 0;
+    while (ji + 1 < wb.n && (int)blockIdx.x >= wb.start[ji + 1]) ++ji;
+    const WgradJob& j = wb.j[ji];
+    const int K = j.K, R = j.R;
+    const int nkt = (K + 127) >> 7, nch = (R + WG_ROWS - 1) / WG_ROWS;
+    const int local = blockIdx.x - wb.start[ji];
+    const int kt = local % nkt, ch = (local / nkt) % nch, gb = local / (nkt * nch);
+    const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int ldg = j.ldg ? j.ldg : D;
+    const bool blocks = j.nA > 0;
+    const int lda = blocks ? D : K;
+    const int rbeg = ch * WG_ROWS, rend = min(R, rbeg + WG_ROWS), nrows = rend - rbeg;
+    const uint32_t dseed = j.dp.seed, dthr = j.dp.thresh, dkey = j.dp.key;
+    const float dscale = j.dp.scale;
+    // ---- staging role: row pair rg of the step (rows 2 rg, 2 rg + 1), column pair cp (columns 2 cp, 2 cp + 1) of both operands.
+    //      lane = (rg, cp & 7): the 64 lanes of a wave write 32 distinct banks (all lanes on one row pair would hit 8)
+    const int rg = lane >> 3, cp = 8 * wv + (lane & 7);
+    const float* gsrc = j.G[gb] + (size_t)(rbeg + 2 * rg) * ldg + 2 * cp;
+    const int kcol = kt * 128 + 2 * cp;                       // column of dW / of Afull
+    const bool kin = kcol < K;                                // K is even
+    const float* asrc = (blocks ? j.A[kt] + 2 * cp : j.Afull + (kin ? kcol : 0)) + (size_t)(rbeg + 2 * rg) * lda;
+    // ---- MFMA role: wave = rows 64 nh .. + 63 (two 32-row blocks) x columns 32 kq .. + 31 of the 128 x 128 block
+    const int nh = wv & 1, kq = wv >> 1, i = lane & 31, h = lane >> 5;
+    const bool want_bias = kt == 0 && j.out_bias[gb] != nullptr;
+    f32x16 acc[2];
+    zero_acc(acc);
+    float bs0 = 0.f, bs1 = 0.f;
+    float2 rawg[WG4_NB][2], rawa[WG4_NB][2];
+    auto ld = [&](int s, float2 (&g)[2], float2 (&a)[2]) {
+        const int r0 = 16 * s + 2 * rg;                       // first row of the pair inside the chunk
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const bool ok = r0 + q < nrows;
+            g[q] = ok ? *reinterpret_cast<const float2*>(gsrc + (size_t)(16 * s + q) * ldg) : make_float2(0.f, 0.f);
+            a[q] = (ok && kin) ? *reinterpret_cast<const float2*>(asrc + (size_t)(16 * s + q) * lda) : make_float2(0.f, 0.f);
+        }
+    };
+    auto stage = [&](int s, int buf, const float2 (&g)[2], const float2 (&a)[2]) {
+        uint32_t hh, mm, ll;
+        if (want_bias) { bs0 += g[0].x + g[1].x; bs1 += g[0].y + g[1].y; }
+        split3(g[0].x, g[1].x, hh, mm, ll);
+        Ps[wg4_idx(buf, 0, 0, 2 * cp, rg)] = hh; Ps[wg4_idx(buf, 0, 1, 2 * cp, rg)] = mm; Ps[wg4_idx(buf, 0, 2, 2 * cp, rg)] = ll;
+        split3(g[0].y, g[1].y, hh, mm, ll);
+        Ps[wg4_idx(buf, 0, 0, 2 * cp + 1, rg)] = hh; Ps[wg4_idx(buf, 0, 1, 2 * cp + 1, rg)] = mm; Ps[wg4_idx(buf, 0, 2, 2 * cp + 1, rg)] = ll;
+        float a00 = a[0].x, a01 = a[0].y, a10 = a[1].x, a11 = a[1].y;
+        if (DROP) {
+            const uint32_t base = (uint32_t)(rbeg + 16 * s + 2 * rg) * (uint32_t)K + (uint32_t)kcol;
+            a00 *= drop_hash(base, dseed, dkey) >= dthr ? dscale : 0.f;
+            a01 *= drop_hash(base + 1u, dseed, dkey) >= dthr ? dscale : 0.f;
+            a10 *= drop_hash(base + (uint32_t)K, dseed, dkey) >= dthr ? dscale : 0.f;
+            a11 *= drop_hash(base + (uint32_t)K + 1u, dseed, dkey) >= dthr ? dscale : 0.f;
+        }
+        split3(a00, a10, hh, mm, ll);
+        Ps[wg4_idx(buf, 1, 0, 2 * cp, rg)] = hh; Ps[wg4_idx(buf, 1, 1, 2 * cp, rg)] = mm; Ps[wg4_idx(buf, 1, 2, 2 * cp, rg)] = ll;
+        split3(a01, a11, hh, mm, ll);
+        Ps[wg4_idx(buf, 1, 0, 2 * cp + 1, rg)] = hh; Ps[wg4_idx(buf, 1, 1, 2 * cp + 1, rg)] = mm; Ps[wg4_idx(buf, 1, 2, 2 * cp + 1, rg)] = ll;
+    };
+    auto mma = [&](int buf) {
+        u32x4_t g3[2][3], a3[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a) g3[a][p] = *reinterpret_cast<const u32x4_t*>(Ps + wg4_idx(buf, 0, p, 64 * nh + 32 * a + i, 4 * h));
+            a3[p] = *reinterpret_cast<const u32x4_t*>(Ps + wg4_idx(buf, 1, p, 32 * kq + i, 4 * h));
+        }
+        constexpr int TG6[6] = {1, 0, 2, 0, 1, 0}, TA6[6] = {1, 2, 0, 1, 0, 0};      // (g term, a term): mm, hl, lh, hm, mh, hh (small terms first)
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) acc[a] = mfma_bf16(g3[a][TG6[t]], a3[TA6[t]], acc[a]);
+    };
+    const int ns = ((nrows + 16 * WG4_NB - 1) / (16 * WG4_NB)) * WG4_NB;      // steps, a multiple of the ring (a step past the rows multiplies zeros)
+    static_for<0, WG4_NB - 1>([&](auto uc) { constexpr int u = decltype(uc)::value; ld(u, rawg[u], rawa[u]); });
+    stage(0, 0, rawg[0], rawa[0]);
+    for (int s0 = 0; s0 < ns; s0 += WG4_NB) {
+        static_for<0, WG4_NB>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            const int s = s0 + u;
+            ld(s + WG4_NB - 1, rawg[(u + WG4_NB - 1) % WG4_NB], rawa[(u + WG4_NB - 1) % WG4_NB]);       // the slot step s - 1 was staged from
+            __syncthreads();
+            stage(s + 1, (u + 1) & 1, rawg[(u + 1) % WG4_NB], rawa[(u + 1) % WG4_NB]);
+            mma(u & 1);
+        });
+    }
+    // ---- partial slab: register r of acc[a] = dW[n = 64 nh + 32 a + acc_row(r)][k = kt * 128 + 32 kq + i]
+    const int N = 128 * j.nG;
+    const int kglob = kt * 128 + 32 * kq + i;
+    float* out = j.out + ((size_t)ch * N + gb * 128 + 64 * nh) * K + kglob;
+    if (kglob < K) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) out[(size_t)(32 * a + acc_row(r, lane)) * K] = acc[a][r];
+    }
+    if (want_bias) {            // column sums of G: the 8 row pairs of a column pair sit in 8 lanes (lane >> 3) of one wave
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(Ps);
+        red[rg * 128 + 2 * cp] = bs0; red[rg * 128 + 2 * cp + 1] = bs1;
+        __syncthreads();
+        if (tid < 128) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t += red[q * 128 + tid];
+            j.out_bias[gb][(size_t)ch * D + tid] = t;
+        }
+    }
+}
+
 void launch_wgrad2(const WgradBatch& wb0, hipStream_t s) {
     WgradBatch wb = wb0;
     int total = 0;
@@ -331,6 +458,12 @@ void launch_wgrad2(const WgradBatch& wb0, hipStream_t s) {
     ensure_dynamic_lds(fn[k0], pad, ok[k0], "k_wgrad2");
     // fp32-grade product on the bf16 matrix cores (k_wgrad3) unless VSL_WGRAD_F32=1 selects the fp32-input MFMA kernel of round 2 (A/B runs)
     static const bool f32_path = getenv("VSL_WGRAD_F32") && getenv("VSL_WGRAD_F32")[0] == '1';
+    static const bool wg4 = !(getenv("VSL_WGRAD4") && getenv("VSL_WGRAD4")[0] == '0');
+    if (!f32_path && wg4 && k0 < 2) {        // fp32 operands: split once per workgroup through LDS (the bf16-feature jobs keep k_wgrad3)
+        if (k0 == 0) VSL_LAUNCH((k_wgrad4<false>), dim3(total), dim3(WG4_T), 0, s, wb);
+        else VSL_LAUNCH((k_wgrad4<true>), dim3(total), dim3(WG4_T), 0, s, wb);
+        return;
+    }
     if (!f32_path) {
         static const size_t pad3 = getenv("VSL_WGRAD_LDS") ? (size_t)atol(getenv("VSL_WGRAD_LDS")) : (size_t)0;
         static size_t ok3[4] = {0, 0, 0, 0};
