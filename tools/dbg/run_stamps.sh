@@ -1,6 +1,8 @@
 export VSL_DEBUG_TIMING=1 VSL_MULTI_STREAM=0
-for v in amps 1 2 3; do
-export VSLNET_HIP_LIB=$PWD/vslnet_amd/lib/libvslnet_hip_st$v.so
-timeout 400 python bench.py --steps 3 --warmup 2 --no-cpu-baseline > gpurun_out/stamps_$v.log 2>&1
-echo "variant $v"; grep "embed_bwd" gpurun_out/stamps_$v.log | head -2
-done
+export VSLNET_HIP_LIB=$PWD/vslnet_amd/lib/libvslnet_hip_stamps.so
+timeout 400 python bench.py --steps 3 --warmup 2 --no-cpu-baseline > gpurun_out/stamps.log 2>&1
+grep "wgrad4" gpurun_out/stamps.log | head -5
+unset VSLNET_HIP_LIB VSL_DEBUG_TIMING
+timeout 600 bash tools/prof_serial.sh > gpurun_out/r3f_serial.log 2>&1; grep "wgrad\|total kernel" gpurun_out/stats_serial.txt
+unset VSL_MULTI_STREAM
+for rep in 1 2; do for n in 0 1; do export VSL_WGRAD4=$n; echo -n "wgrad4=$n: "; timeout 300 python bench.py --steps 100 --warmup 10 --no-cpu-baseline 2>/dev/null | python -c "import json,sys;d=json.load(sys.stdin);print(d['value'],d['ms_per_step'])"; done; done 2>&1 | tee gpurun_out/ab.log

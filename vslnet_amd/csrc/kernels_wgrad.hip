@@ -374,19 +374,21 @@ __global__ __launch_bounds__(WG4_T, 1) void k_wgrad4(WgradBatch wb) {
         split3(a01, a11, hh, mm, ll);
         Ps[wg4_idx(buf, 1, 0, 2 * cp + 1, rg)] = hh; Ps[wg4_idx(buf, 1, 1, 2 * cp + 1, rg)] = mm; Ps[wg4_idx(buf, 1, 2, 2 * cp + 1, rg)] = ll;
     };
-    auto mma = [&](int buf) {
-        u32x4_t g3[2][3], a3[3];
+    struct Frag { u32x4_t g[2][3], a[3]; };
+    auto frag_load = [&](int buf, Frag& f) {
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
 #pragma unroll
-            for (int a = 0; a < 2; ++a) g3[a][p] = *reinterpret_cast<const u32x4_t*>(Ps + wg4_idx(buf, 0, p, 64 * nh + 32 * a + i, 4 * h));
-            a3[p] = *reinterpret_cast<const u32x4_t*>(Ps + wg4_idx(buf, 1, p, 32 * kq + i, 4 * h));
+            for (int a = 0; a < 2; ++a) f.g[a][p] = *reinterpret_cast<const u32x4_t*>(Ps + wg4_idx(buf, 0, p, 64 * nh + 32 * a + i, 4 * h));
+            f.a[p] = *reinterpret_cast<const u32x4_t*>(Ps + wg4_idx(buf, 1, p, 32 * kq + i, 4 * h));
         }
+    };
+    auto mma = [&](const Frag& f) {
         constexpr int TG6[6] = {1, 0, 2, 0, 1, 0}, TA6[6] = {1, 2, 0, 1, 0, 0};      // (g term, a term): mm, hl, lh, hm, mh, hh (small terms first)
 #pragma unroll
         for (int t = 0; t < 6; ++t)
 #pragma unroll
-            for (int a = 0; a < 2; ++a) acc[a] = mfma_bf16(g3[a][TG6[t]], a3[TA6[t]], acc[a]);
+            for (int a = 0; a < 2; ++a) acc[a] = mfma_bf16(f.g[a][TG6[t]], f.a[TA6[t]], acc[a]);
     };
     const int ns = ((nrows + 16 * WG4_NB - 1) / (16 * WG4_NB)) * WG4_NB;      // steps, a multiple of the ring (a step past the rows multiplies zeros)
     static_for<0, WG4_NB - 1>([&](auto uc) { constexpr int u = decltype(uc)::value; ld(u, rawg[u], rawa[u]); });
@@ -397,8 +399,15 @@ __global__ __launch_bounds__(WG4_T, 1) void k_wgrad4(WgradBatch wb) {
             const int s = s0 + u;
             ld(s + WG4_NB - 1, rawg[(u + WG4_NB - 1) % WG4_NB], rawa[(u + WG4_NB - 1) % WG4_NB]);       // the slot step s - 1 was staged from
             __syncthreads();
+            // the operand reads of step s are issued BEFORE the staging of step s + 1 (the other buffer): their latency hides behind the
+            // split arithmetic (21.3 -> 19.1 us).  Measured and dropped: MFMAs before the staging in half / all of the waves (19.3 / 19.3 us);
+            // producer / consumer wave roles with 64 x 64 consumer tiles (12 reads per 24 MFMAs: 20.1 us) -- the step is a mix of LDS
+            // bandwidth (96 KB per step), the barrier and the matrix pipe, none of them alone
+            Frag f;
+            frag_load(u & 1, f);
+            __builtin_amdgcn_sched_barrier(0);
             stage(s + 1, (u + 1) & 1, rawg[(u + 1) % WG4_NB], rawa[(u + 1) % WG4_NB]);
-            mma(u & 1);
+            mma(f);
         });
     }
     // ---- partial slab: register r of acc[a] = dW[n = 64 nh + 32 a + acc_row(r)][k = kt * 128 + 32 kq + i]
@@ -460,8 +469,11 @@ void launch_wgrad2(const WgradBatch& wb0, hipStream_t s) {
     static const bool f32_path = getenv("VSL_WGRAD_F32") && getenv("VSL_WGRAD_F32")[0] == '1';
     static const bool wg4 = !(getenv("VSL_WGRAD4") && getenv("VSL_WGRAD4")[0] == '0');
     if (!f32_path && wg4 && k0 < 2) {        // fp32 operands: split once per workgroup through LDS (the bf16-feature jobs keep k_wgrad3)
-        if (k0 == 0) VSL_LAUNCH((k_wgrad4<false>), dim3(total), dim3(WG4_T), 0, s, wb);
-        else VSL_LAUNCH((k_wgrad4<true>), dim3(total), dim3(WG4_T), 0, s, wb);
+        static const size_t pad4 = getenv("VSL_WGRAD_LDS") ? (size_t)atol(getenv("VSL_WGRAD_LDS")) : (size_t)0;      // experiment knob: extra LDS = fewer co-residents
+        static size_t ok4[2] = {0, 0};
+        ensure_dynamic_lds(k0 == 0 ? (const void*)k_wgrad4<false> : (const void*)k_wgrad4<true>, pad4, ok4[k0], "k_wgrad4");
+        if (k0 == 0) VSL_LAUNCH((k_wgrad4<false>), dim3(total), dim3(WG4_T), pad4, s, wb);
+        else VSL_LAUNCH((k_wgrad4<true>), dim3(total), dim3(WG4_T), pad4, s, wb);
         return;
     }
     if (!f32_path) {
