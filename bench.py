@@ -96,8 +96,9 @@ def dtype_line(args):
         return 'bf16 features + bf16-MFMA VisualProjection, f32 elsewhere (throughput mode, not the parity path)'
     if os.environ.get('VSL_F32_GEMM') == '1' and os.environ.get('VSL_WGRAD_F32') == '1':
         return 'f32 (fp32-input MFMA everywhere: the round-2 kernels, A/B switch)'
-    return ('f32 in / out and f32 accumulate everywhere; VisualProjection, the conv-block GEMMs and every weight gradient as bf16x6 split '
-            'MFMA (exact 3-way operand split, 6 products: fp32 grade), attention / CQAttention / heads as fp32-input MFMA')
+    return ('f32 in / out and f32 accumulate everywhere; VisualProjection, the conv-block / q,k,v / embedding-linear GEMMs and every weight '
+            'gradient as bf16x6 split MFMA (exact 3-way operand split, 6 products: fp32 grade), attention / CQAttention / heads / char-CNN as '
+            'fp32-input MFMA')
 
 
 def host_cpu():

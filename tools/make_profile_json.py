@@ -10,7 +10,7 @@ import sys
 GROUP = {  # kernel function -> launcher group of vsl_profile_* (api.hip LAUNCH names); default = name without "k_"
     'k_attn_bwd_fused': 'attn_bwd', 'k_attn_bwd_long': 'attn_bwd',
     'k_cq_bwd_a': 'cq_bwd', 'k_cq_bwd_b': 'cq_bwd', 'k_cq_bwd_c': 'cq_bwd',
-    'k_loss_a': 'loss', 'k_loss_b': 'loss', 'k_loss_c': 'loss', 'k_loss_fused': 'loss', 'k_wgrad2': 'wgrad', 'k_wgrad3': 'wgrad', 'k_sqsum': 'adamw',
+    'k_loss_a': 'loss', 'k_loss_b': 'loss', 'k_loss_c': 'loss', 'k_loss_fused': 'loss', 'k_wgrad2': 'wgrad', 'k_wgrad3': 'wgrad', 'k_wgrad4': 'wgrad', 'k_sqsum': 'adamw',
     'k_vproj_fwd3': 'vproj_fwd', 'k_attn_block_fwd': 'attn_block_fwd',
 }
 
