@@ -363,9 +363,14 @@ def test_dropout_mask_statistics_and_scaling():
     dict(name='edge: engine limits Lq=128 = the reference max_pos_len bound, Lc=40', T=72, Dv=64, B=2, Lq=128, Lc=40),
     dict(name='edge: Lq=97 (first length on the lean layout), full word tiles absent', T=33, Dv=64, B=3, Lq=97, Lc=5),
     dict(name='edge: ActivityNet C3D width (500 = 4 * 125), one-word queries, ragged row count', T=50, Dv=500, B=3, Lq=1, Lc=4),
+    dict(name='embedding: char_dim 100, a 130-character alphabet (9 table tiles), trainable word table', T=40, Dv=64, B=3, Lq=11, Lc=17,
+         char_dim=100, char_size=130, word_table=True),
+    dict(name='embedding: char_dim 64 with 25-character tokens (two input-channel blocks in the long-token instantiation; found by tools/fuzz_parity.py)',
+         T=31, Dv=4, B=6, Lq=64, Lc=25, char_dim=64),
 ])
 def test_baseline_shapes_against_oracle(shape):
-    cfg = O.make_cfg(video_feature_dim=shape['Dv'], max_pos_len=max(shape['T'], shape['Lq']), word_size=102)
+    cfg = O.make_cfg(video_feature_dim=shape['Dv'], max_pos_len=max(shape['T'], shape['Lq']), word_size=102, char_dim=shape.get('char_dim', 50),
+                     char_size=shape.get('char_size', 40), word_table=shape.get('word_table', False))
     P = O.random_params(cfg, seed=11)
     b = O.synthetic_batch(cfg, shape['B'], shape['T'], shape['Lq'], shape['Lc'], seed=12, ragged=shape['B'] > 1)
     d = _dev(b)

@@ -17,7 +17,8 @@ def main(n=24, seed=0):
     for i in range(n):
         shape = dict(name='fuzz %d' % i, B=int(rs.randint(1, 7)), T=int(rs.choice([4, 7, 16, 31, 32, 33, 40, 50, 64, 97, 128, 160, 256])),
                      Lq=int(rs.choice([1, 2, 3, 8, 20, 31, 32, 33, 47, 64, 65, 82, 96, 97, 111, 128])), Lc=int(rs.choice([4, 5, 10, 17, 24, 25, 40])),
-                     Dv=int(rs.choice([4, 36, 64, 100, 500, 1024])))
+                     Dv=int(rs.choice([4, 36, 64, 100, 500, 1024])), char_dim=int(rs.choice([50, 50, 8, 64, 65, 100, 128])),
+                     char_size=int(rs.choice([40, 40, 17, 97, 200])), word_table=bool(rs.randint(0, 3) == 0))
         try:
             if i % 4 == 3:                      # every fourth shape goes through the rnn head (chunk-pipelined LSTMs, Dv = 64)
                 # (that test fixes max_pos_len = 128 and has no structural-zero gate for one-word queries)

@@ -449,8 +449,10 @@ void launch_embed_fwd(const int64_t* word_ids, const int64_t* char_ids, const fl
                       const float* glove, const float* char_tab, CharConvPtrs cc, const float* wimg, float* E, int8_t* argpos,
                       int Rq, int Lc, int word_dim, int char_dim, Drop dw, Drop dc, hipStream_t s) {
     const int lcm = Lc <= 24 ? 24 : MAX_LC;
-    // input-channel block: everything up to 64 channels in one block, beyond that equal blocks of at most 52 (multiples of 4)
-    const int nblk = char_dim <= 64 ? 1 : (char_dim + 51) / 52;
+    // input-channel block: as many channels as fit the 160 KB of LDS beside the word rows (64 with the short-token instantiation, 52 with the
+    // long one); wider character embeddings run in equal blocks (multiples of 4) with the accumulators carried across them
+    const int cb_max = lcm == 24 ? 64 : 52;
+    const int nblk = (char_dim + cb_max - 1) / cb_max;
     const int cb = nblk == 1 ? char_dim : (((char_dim + nblk - 1) / nblk) + 3) & ~3;
     const size_t shm = (size_t)(cb * 400 + EF_CHUNK * cb * (lcm + 4) + 32) * sizeof(float);   // + slack: invalid positions over-read
     static size_t ok24 = 0, ok40 = 0;
