@@ -1214,6 +1214,25 @@ int vsl_create(const vsl_config* cfg, vsl_handle* out) {
     h->cfg = *cfg;
     build_params(h);
     build_packs(h);
+    {
+        // Drop the pack jobs whose operand no kernel of this process reads: the fp32 packs of the GEMMs that run as split products (or the
+        // split packs under VSL_F32_GEMM=1), and the split packs of the attention output projection (it stays on the fp32-input MFMA).
+        // The regions stay in the pack buffer (offsets are fixed); k_pack just does a third less work every step.
+        const ModelPk& K = h->K;
+        const bool split = split_gemm_enabled();
+        std::vector<int> dead;
+        auto enc = [&](const EncPk& e) {
+            dead.push_back(e.o_f3); dead.push_back(e.o_t3);
+            for (int i = 0; i < 4; ++i) { dead.push_back(split ? e.pw_f[i] : e.pw_f3[i]); dead.push_back(split ? e.pw_t[i] : e.pw_t3[i]); }
+            dead.push_back(split ? e.qkv_f : e.qkv_f3); dead.push_back(split ? e.qkv_t : e.qkv_t3);
+        };
+        enc(K.fe);
+        if (cfg->predictor != 0) enc(K.pe);
+        if (split) { dead.push_back(K.va_f); dead.push_back(K.emb_t); if ((cfg->word_dim + 100) % 16 == 0) dead.push_back(K.emb_f); }
+        else { dead.push_back(K.va_f3); dead.push_back(K.emb_f3); dead.push_back(K.emb_t3); }
+        h->jobs.erase(std::remove_if(h->jobs.begin(), h->jobs.end(), [&](const PackJob& j) {
+                          return std::find(dead.begin(), dead.end(), j.dst) != dead.end(); }), h->jobs.end());
+    }
     if (hipMalloc(&h->loss_counter, sizeof(unsigned)) != hipSuccess || hipMemset(h->loss_counter, 0, sizeof(unsigned)) != hipSuccess) {
         delete h;
         return fail("hipMalloc of the loss counter failed");
