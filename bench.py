@@ -93,7 +93,8 @@ def workload_name(args):
 
 def dtype_line(args):
     if args.dtype != 'f32':
-        return 'bf16 features + bf16-MFMA VisualProjection, f32 elsewhere (throughput mode, not the parity path)'
+        return ('bf16 throughput mode (not the parity path): bf16 features in HBM; VisualProjection and every weight gradient as ONE bf16 product per '
+                'product (operands rounded to bf16, f32 accumulate); the other GEMMs bf16x6 / f32-input MFMA as in the f32 line; f32 activations')
     if os.environ.get('VSL_F32_GEMM') == '1' and os.environ.get('VSL_WGRAD_F32') == '1':
         return 'f32 (fp32-input MFMA everywhere: the round-2 kernels, A/B switch)'
     return ('f32 in / out and f32 accumulate everywhere; VisualProjection, the conv-block / q,k,v / embedding-linear GEMMs and every weight '
@@ -195,7 +196,7 @@ def main():
     ap.add_argument('--lc', type=int, default=10)
     ap.add_argument('--drop-rate', type=float, default=0.2)
     ap.add_argument('--predictor', default='transformer', help="'transformer' (headline, configs[1]) or 'rnn' (configs[0] shape)")
-    ap.add_argument('--dtype', default='f32', choices=('f32', 'bf16'), help="'bf16' = the separate throughput mode: bfloat16 features in HBM + bf16-MFMA VisualProjection (fp32 elsewhere); never the parity / headline line")
+    ap.add_argument('--dtype', default='f32', choices=('f32', 'bf16'), help="'bf16' = the separate throughput mode: bfloat16 features in HBM, VisualProjection and the weight gradients as single bf16 products (vsl_io.arithmetic = 1); never the parity / headline line")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-optimizer', action='store_true', help='time forward + losses + backward only (A/B runs)')
     ap.add_argument('--profile-all', action='store_true', help='also print the per-kernel HIP-event table to stderr')
@@ -250,7 +251,7 @@ def main():
 
     def step(i, skip_exchange=False):
         eng.forward(flat, pad_vec, glove_vec, batch['word_ids'], batch['char_ids'], batch['vfeats'], batch['v_mask'],
-                    batch['q_mask'], training=True, seed=i, sample_offset=rank * B)
+                    batch['q_mask'], training=True, seed=i, sample_offset=rank * B, arithmetic='bf16' if args.dtype == 'bf16' else 'f32')
         losses, d_h, d_sl, d_el = eng.loss(batch['s_labels'], batch['e_labels'], batch['h_labels'], 1.0,
                                            configs.highlight_lambda, inv_batch=inv_batch, mask_sum=mask_sum)
         skip_exchange = skip_exchange or os.environ.get('VSL_SKIP_ALLREDUCE') == '1'

@@ -1157,12 +1157,15 @@ int check_io(vsl_handle_s* h, const vsl_io* io) {
         return fail("vsl_io has a null device pointer");
     if (io->video_features_bf16 && (h->cfg.video_feature_dim % 8 != 0))
         return fail("bf16 features need video_feature_dim %% 8 == 0 (got %d)", h->cfg.video_feature_dim);
+    if (io->arithmetic != 0 && io->arithmetic != 1) return fail("vsl_io.arithmetic must be 0 (fp32 grade) or 1 (bf16 arithmetic), got %d", io->arithmetic);
+    vsl::g_one_product = io->arithmetic == 1;
     return 0;
 }
 
 }  // namespace
 
 namespace vsl {
+bool g_one_product = false;
 void vsl_launch_events(hipStream_t s, hipEvent_t* start, hipEvent_t* stop) {
     vsl_handle_s* h = g_cur;
     if (!h || !(h->stop_events || h->prof_name)) return;

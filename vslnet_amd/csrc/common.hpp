@@ -315,6 +315,13 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {       // {bf
     const f32x2_t v = {a, b};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
+// the same instruction as an opaque asm: for call sites where the vector form above makes clang assemble the operand pair through
+// scratch memory (the one-product instantiation of k_wgrad4: a masked row pair became a stack shuffle, 19 -> 47 us)
+__device__ __forceinline__ uint32_t cvt_pk_bf16_asm(float a, float b) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 // (x0, x1) -> packed pairs of the three terms: 11 vector instructions
 __device__ __forceinline__ void split3(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
     h = cvt_pk_bf16(x0, x1);

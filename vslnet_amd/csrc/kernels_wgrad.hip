@@ -314,7 +314,8 @@ constexpr int WG4_T = 512, WG4_NB = 4;
 // dword index of row pair rg (rows 2 rg, 2 rg + 1) of column c: the two 8-row halves of a column live in separate arrays, so the 16 lanes of a
 // ds_read_b128 phase (consecutive columns, one half) cover all 64 banks once
 __device__ __forceinline__ int wg4_idx(int buf, int o, int p, int c, int rg) { return (((((buf * 2 + o) * 3 + p) * 2 + (rg >> 2)) * 128 + c) << 2) + (rg & 3); }
-template <bool DROP>
+// ONE: vsl_io.arithmetic = 1 -- operands rounded to bfloat16 (the h term alone), one product per product
+template <bool DROP, bool ONE>
 __global__ __launch_bounds__(WG4_T, 1) void k_wgrad4(WgradBatch wb) {
     __shared__ __attribute__((aligned(16))) uint32_t Ps[2 * 2 * 3 * 128 * 8];
     int ji = 0;
@@ -344,24 +345,35 @@ __global__ __launch_bounds__(WG4_T, 1) void k_wgrad4(WgradBatch wb) {
     f32x16 acc[2];
     zero_acc(acc);
     float bs0 = 0.f, bs1 = 0.f;
-    float2 rawg[WG4_NB][2], rawa[WG4_NB][2];
-    auto ld = [&](int s, float2 (&g)[2], float2 (&a)[2]) {
+    // the ring of raw rows: four NAMED slots, not an array (in the one-product instantiation clang kept an array of float2 in scratch memory)
+    struct Slot { float2 g0, g1, a0, a1; };
+    Slot sl0, sl1, sl2, sl3;
+    static_assert(WG4_NB == 4, "four named ring slots");
+    // Loads are UNCONDITIONAL (row clamped into the chunk, column clamped into K) and masked by a multiplication: a load whose value is only
+    // selected is moved under the condition by the compiler, and the ring of raw rows then lives in scratch memory behind vmcnt(0) waits
+    // (seen in the one-product instantiation: 46.7 us instead of 19)
+    auto ld = [&](int s, Slot& x) {
         const int r0 = 16 * s + 2 * rg;                       // first row of the pair inside the chunk
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const bool ok = r0 + q < nrows;
-            g[q] = ok ? *reinterpret_cast<const float2*>(gsrc + (size_t)(16 * s + q) * ldg) : make_float2(0.f, 0.f);
-            a[q] = (ok && kin) ? *reinterpret_cast<const float2*>(asrc + (size_t)(16 * s + q) * lda) : make_float2(0.f, 0.f);
+        const int ra = min(r0, nrows - 1) - 2 * rg, rb = min(r0 + 1, nrows - 1) - 2 * rg;      // (gsrc / asrc already point at row 2 rg of the chunk)
+        const float m0 = r0 < nrows ? 1.f : 0.f, m1 = r0 + 1 < nrows ? 1.f : 0.f, k0m = kin ? 1.f : 0.f;
+        const float2 ga = *reinterpret_cast<const float2*>(gsrc + (ptrdiff_t)ra * ldg), gb2 = *reinterpret_cast<const float2*>(gsrc + (ptrdiff_t)rb * ldg);
+        const float2 aa = *reinterpret_cast<const float2*>(asrc + (ptrdiff_t)ra * lda), ab = *reinterpret_cast<const float2*>(asrc + (ptrdiff_t)rb * lda);
+        x.g0 = make_float2(ga.x * m0, ga.y * m0); x.g1 = make_float2(gb2.x * m1, gb2.y * m1);
+        x.a0 = make_float2(aa.x * m0 * k0m, aa.y * m0 * k0m); x.a1 = make_float2(ab.x * m1 * k0m, ab.y * m1 * k0m);
+    };
+    auto put = [&](int buf, int o, int c, float x0, float x1) {       // rows 2 rg, 2 rg + 1 of column c of operand o
+        if constexpr (ONE) Ps[wg4_idx(buf, o, 0, c, rg)] = cvt_pk_bf16_asm(x0, x1);
+        else {
+            uint32_t hh, mm, ll;
+            split3(x0, x1, hh, mm, ll);
+            Ps[wg4_idx(buf, o, 0, c, rg)] = hh; Ps[wg4_idx(buf, o, 1, c, rg)] = mm; Ps[wg4_idx(buf, o, 2, c, rg)] = ll;
         }
     };
-    auto stage = [&](int s, int buf, const float2 (&g)[2], const float2 (&a)[2]) {
-        uint32_t hh, mm, ll;
-        if (want_bias) { bs0 += g[0].x + g[1].x; bs1 += g[0].y + g[1].y; }
-        split3(g[0].x, g[1].x, hh, mm, ll);
-        Ps[wg4_idx(buf, 0, 0, 2 * cp, rg)] = hh; Ps[wg4_idx(buf, 0, 1, 2 * cp, rg)] = mm; Ps[wg4_idx(buf, 0, 2, 2 * cp, rg)] = ll;
-        split3(g[0].y, g[1].y, hh, mm, ll);
-        Ps[wg4_idx(buf, 0, 0, 2 * cp + 1, rg)] = hh; Ps[wg4_idx(buf, 0, 1, 2 * cp + 1, rg)] = mm; Ps[wg4_idx(buf, 0, 2, 2 * cp + 1, rg)] = ll;
-        float a00 = a[0].x, a01 = a[0].y, a10 = a[1].x, a11 = a[1].y;
+    auto stage = [&](int s, int buf, const Slot& x) {
+        if (want_bias) { bs0 += x.g0.x + x.g1.x; bs1 += x.g0.y + x.g1.y; }
+        put(buf, 0, 2 * cp, x.g0.x, x.g1.x);
+        put(buf, 0, 2 * cp + 1, x.g0.y, x.g1.y);
+        float a00 = x.a0.x, a01 = x.a0.y, a10 = x.a1.x, a11 = x.a1.y;
         if (DROP) {
             const uint32_t base = (uint32_t)(rbeg + 16 * s + 2 * rg) * (uint32_t)K + (uint32_t)kcol;
             a00 *= drop_hash(base, dseed, dkey) >= dthr ? dscale : 0.f;
@@ -369,15 +381,17 @@ __global__ __launch_bounds__(WG4_T, 1) void k_wgrad4(WgradBatch wb) {
             a10 *= drop_hash(base + (uint32_t)K, dseed, dkey) >= dthr ? dscale : 0.f;
             a11 *= drop_hash(base + (uint32_t)K + 1u, dseed, dkey) >= dthr ? dscale : 0.f;
         }
-        split3(a00, a10, hh, mm, ll);
-        Ps[wg4_idx(buf, 1, 0, 2 * cp, rg)] = hh; Ps[wg4_idx(buf, 1, 1, 2 * cp, rg)] = mm; Ps[wg4_idx(buf, 1, 2, 2 * cp, rg)] = ll;
-        split3(a01, a11, hh, mm, ll);
-        Ps[wg4_idx(buf, 1, 0, 2 * cp + 1, rg)] = hh; Ps[wg4_idx(buf, 1, 1, 2 * cp + 1, rg)] = mm; Ps[wg4_idx(buf, 1, 2, 2 * cp + 1, rg)] = ll;
+        put(buf, 1, 2 * cp, a00, a10);
+        put(buf, 1, 2 * cp + 1, a01, a11);
+    };
+    auto slot = [&](auto ic) -> Slot& {
+        constexpr int I = decltype(ic)::value & 3;
+        if constexpr (I == 0) return sl0; else if constexpr (I == 1) return sl1; else if constexpr (I == 2) return sl2; else return sl3;
     };
     struct Frag { u32x4_t g[2][3], a[3]; };
     auto frag_load = [&](int buf, Frag& f) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < (ONE ? 1 : 3); ++p) {
 #pragma unroll
             for (int a = 0; a < 2; ++a) f.g[a][p] = *reinterpret_cast<const u32x4_t*>(Ps + wg4_idx(buf, 0, p, 64 * nh + 32 * a + i, 4 * h));
             f.a[p] = *reinterpret_cast<const u32x4_t*>(Ps + wg4_idx(buf, 1, p, 32 * kq + i, 4 * h));
@@ -386,18 +400,18 @@ __global__ __launch_bounds__(WG4_T, 1) void k_wgrad4(WgradBatch wb) {
     auto mma = [&](const Frag& f) {
         constexpr int TG6[6] = {1, 0, 2, 0, 1, 0}, TA6[6] = {1, 2, 0, 1, 0, 0};      // (g term, a term): mm, hl, lh, hm, mh, hh (small terms first)
 #pragma unroll
-        for (int t = 0; t < 6; ++t)
+        for (int t = ONE ? 5 : 0; t < 6; ++t)
 #pragma unroll
             for (int a = 0; a < 2; ++a) acc[a] = mfma_bf16(f.g[a][TG6[t]], f.a[TA6[t]], acc[a]);
     };
     const int ns = ((nrows + 16 * WG4_NB - 1) / (16 * WG4_NB)) * WG4_NB;      // steps, a multiple of the ring (a step past the rows multiplies zeros)
-    static_for<0, WG4_NB - 1>([&](auto uc) { constexpr int u = decltype(uc)::value; ld(u, rawg[u], rawa[u]); });
-    stage(0, 0, rawg[0], rawa[0]);
+    ld(0, sl0); ld(1, sl1); ld(2, sl2);
+    stage(0, 0, sl0);
     for (int s0 = 0; s0 < ns; s0 += WG4_NB) {
         static_for<0, WG4_NB>([&](auto uc) {
             constexpr int u = decltype(uc)::value;
             const int s = s0 + u;
-            ld(s + WG4_NB - 1, rawg[(u + WG4_NB - 1) % WG4_NB], rawa[(u + WG4_NB - 1) % WG4_NB]);       // the slot step s - 1 was staged from
+            ld(s + WG4_NB - 1, slot(std::integral_constant<int, u + 3>()));       // the slot step s - 1 was staged from
             __syncthreads();
             // the operand reads of step s are issued BEFORE the staging of step s + 1 (the other buffer): their latency hides behind the
             // split arithmetic (21.3 -> 19.1 us).  Measured and dropped: MFMAs before the staging in half / all of the waves (19.3 / 19.3 us);
@@ -406,7 +420,7 @@ __global__ __launch_bounds__(WG4_T, 1) void k_wgrad4(WgradBatch wb) {
             Frag f;
             frag_load(u & 1, f);
             __builtin_amdgcn_sched_barrier(0);
-            stage(s + 1, (u + 1) & 1, rawg[(u + 1) % WG4_NB], rawa[(u + 1) % WG4_NB]);
+            stage(s + 1, (u + 1) & 1, slot(std::integral_constant<int, u + 1>()));
             mma(f);
         });
     }
@@ -471,9 +485,14 @@ void launch_wgrad2(const WgradBatch& wb0, hipStream_t s) {
     if (!f32_path && wg4 && k0 < 2) {        // fp32 operands: split once per workgroup through LDS (the bf16-feature jobs keep k_wgrad3)
         static const size_t pad4 = getenv("VSL_WGRAD_LDS") ? (size_t)atol(getenv("VSL_WGRAD_LDS")) : (size_t)0;      // experiment knob: extra LDS = fewer co-residents
         static size_t ok4[2] = {0, 0};
-        ensure_dynamic_lds(k0 == 0 ? (const void*)k_wgrad4<false> : (const void*)k_wgrad4<true>, pad4, ok4[k0], "k_wgrad4");
-        if (k0 == 0) VSL_LAUNCH((k_wgrad4<false>), dim3(total), dim3(WG4_T), pad4, s, wb);
-        else VSL_LAUNCH((k_wgrad4<true>), dim3(total), dim3(WG4_T), pad4, s, wb);
+        if (g_one_product) {               // vsl_io.arithmetic = 1
+            if (k0 == 0) VSL_LAUNCH((k_wgrad4<false, true>), dim3(total), dim3(WG4_T), 0, s, wb);
+            else VSL_LAUNCH((k_wgrad4<true, true>), dim3(total), dim3(WG4_T), 0, s, wb);
+            return;
+        }
+        ensure_dynamic_lds(k0 == 0 ? (const void*)k_wgrad4<false, false> : (const void*)k_wgrad4<true, false>, pad4, ok4[k0], "k_wgrad4");
+        if (k0 == 0) VSL_LAUNCH((k_wgrad4<false, false>), dim3(total), dim3(WG4_T), pad4, s, wb);
+        else VSL_LAUNCH((k_wgrad4<true, false>), dim3(total), dim3(WG4_T), pad4, s, wb);
         return;
     }
     if (!f32_path) {

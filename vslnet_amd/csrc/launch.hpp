@@ -277,6 +277,7 @@ constexpr int OPT_BLOCKS = 256;
 void launch_adamw(float* params, const float* grads, float* m, float* v, const uint8_t* decay_mask, float* partials /*[OPT_BLOCKS + 1]*/,
                   int64_t n, float lr, float b1, float b2, float eps, float wd, float clip, float bc1, float bc2_sqrt,
                   float* norm_out, hipStream_t s, int hf_order = 0);
+extern bool g_one_product;        // vsl_io.arithmetic == 1 for the call being enqueued (set by vsl_forward / vsl_backward, read by the launchers)
 constexpr int EMB_CHUNK_MAX = 8;  // most query words per workgroup in the embedding backward
 int embed_bwd_chunk(int Rq, int Lc, int char_dim);      // words per workgroup the launcher uses (the number of partial slabs follows from it)
 constexpr int EB_IMG_Q = 76;      // k-steps of the embedding backward's B-operand image ([channel tile][76][64 lanes], PackJob type 8)

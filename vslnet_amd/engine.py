@@ -31,7 +31,7 @@ class vsl_io(C.Structure):
                 ('workspace', C.c_void_p), ('training', C.c_int32), ('seed', C.c_uint64),
                 ('d_h_score', C.c_void_p), ('d_start_logits', C.c_void_p), ('d_end_logits', C.c_void_p),
                 ('grads', C.c_void_p), ('sample_offset', C.c_int32), ('video_features_bf16', C.c_void_p),
-                ('early_grads_event', C.c_void_p)]
+                ('early_grads_event', C.c_void_p), ('arithmetic', C.c_int32)]
 
 
 class vsl_loss_io(C.Structure):
@@ -54,7 +54,7 @@ ABI_SYMBOLS = ['vsl_last_error', 'vsl_create', 'vsl_destroy', 'vsl_param_count',
                'vsl_workspace_floats', 'vsl_forward', 'vsl_loss', 'vsl_backward', 'vsl_extract_index',
                'vsl_adamw_step', 'vsl_workspace_offset', 'vsl_profile_select', 'vsl_profile_read', 'vsl_abi_version',
                'vsl_early_grad_offset']
-ABI_VERSION = 4                                     # include/vslnet_hip.h: VSL_ABI_VERSION
+ABI_VERSION = 5                                     # include/vslnet_hip.h: VSL_ABI_VERSION
 
 
 def load_library():
@@ -205,10 +205,12 @@ class Engine:
 
     # ---- the three calls ------------------------------------------------------------------------------------
     def forward(self, flat, pad_vec, glove_vec, word_ids, char_ids, vfeats, v_mask, q_mask, training=False, seed=0,
-                sample_offset=0):
+                sample_offset=0, arithmetic='f32'):
         """`sample_offset`: index of this shard's first sample in the global batch (data parallel; vslnet_hip.h).
         `vfeats` in torch.bfloat16 selects the bf16 THROUGHPUT mode (vsl_io.video_features_bf16): bf16 features in HBM and a
-        bf16-MFMA VisualProjection; everything downstream stays fp32.  Not the parity path."""
+        bf16-MFMA VisualProjection; everything downstream stays fp32.  Not the parity path.
+        `arithmetic='bf16'` (vsl_io.arithmetic = 1): VisualProjection and every weight gradient round their operands to bfloat16 and issue
+        one product per product (fp32 accumulation); applies to the backward of this forward as well.  Not the parity path either."""
         B, T, Dv = vfeats.shape
         bf16 = vfeats.dtype == torch.bfloat16
         Lq, Lc = char_ids.shape[1], char_ids.shape[2]
@@ -234,6 +236,9 @@ class Engine:
         io.h_score, io.start_logits, io.end_logits = _ptr(out[0]), _ptr(out[1]), _ptr(out[2])
         io.workspace = _ptr(ws)
         io.training, io.seed, io.sample_offset = int(bool(training)), int(seed) & 0xFFFFFFFFFFFFFFFF, int(sample_offset)
+        if arithmetic not in ('f32', 'bf16'):
+            raise ValueError("arithmetic must be 'f32' or 'bf16', got %r" % (arithmetic,))
+        io.arithmetic = 1 if arithmetic == 'bf16' else 0
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         self._call(self.lib.vsl_forward(self.h, C.byref(io), stream))
         self._last, self._last_ws = io, ws
