@@ -3,7 +3,7 @@
 # bench.py quotes as the static half of its roofline object, then the final bench line and the HIP-event table.
 # usage (on the GPU box, from the repo root): bash tools/collect_evidence.sh r03_a
 set -u
-TAG=${1:-r03_a}
+TAG=${1:-r03_c}
 R=$PWD
 O=$R/gpurun_out/$TAG
 mkdir -p $O

@@ -345,23 +345,19 @@ __global__ __launch_bounds__(WG4_T, 1) void k_wgrad4(WgradBatch wb) {
     f32x16 acc[2];
     zero_acc(acc);
     float bs0 = 0.f, bs1 = 0.f;
-    // the ring of raw rows: four NAMED slots, not an array (in the one-product instantiation clang kept an array of float2 in scratch memory)
-    struct Slot { float2 g0, g1, a0, a1; };
-    Slot sl0, sl1, sl2, sl3;
-    static_assert(WG4_NB == 4, "four named ring slots");
-    // Loads are UNCONDITIONAL (row clamped into the chunk, column clamped into K) and masked by a multiplication: a load whose value is only
-    // selected is moved under the condition by the compiler, and the ring of raw rows then lives in scratch memory behind vmcnt(0) waits
-    // (seen in the one-product instantiation: 46.7 us instead of 19)
-    auto ld = [&](int s, Slot& x) {
+    float2 rawg[WG4_NB][2], rawa[WG4_NB][2];
+    auto ld = [&](int s, float2 (&g)[2], float2 (&a)[2]) {
         const int r0 = 16 * s + 2 * rg;                       // first row of the pair inside the chunk
-        const int ra = min(r0, nrows - 1) - 2 * rg, rb = min(r0 + 1, nrows - 1) - 2 * rg;      // (gsrc / asrc already point at row 2 rg of the chunk)
-        const float m0 = r0 < nrows ? 1.f : 0.f, m1 = r0 + 1 < nrows ? 1.f : 0.f, k0m = kin ? 1.f : 0.f;
-        const float2 ga = *reinterpret_cast<const float2*>(gsrc + (ptrdiff_t)ra * ldg), gb2 = *reinterpret_cast<const float2*>(gsrc + (ptrdiff_t)rb * ldg);
-        const float2 aa = *reinterpret_cast<const float2*>(asrc + (ptrdiff_t)ra * lda), ab = *reinterpret_cast<const float2*>(asrc + (ptrdiff_t)rb * lda);
-        x.g0 = make_float2(ga.x * m0, ga.y * m0); x.g1 = make_float2(gb2.x * m1, gb2.y * m1);
-        x.a0 = make_float2(aa.x * m0 * k0m, aa.y * m0 * k0m); x.a1 = make_float2(ab.x * m1 * k0m, ab.y * m1 * k0m);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const bool ok = r0 + q < nrows;
+            g[q] = ok ? *reinterpret_cast<const float2*>(gsrc + (size_t)(16 * s + q) * ldg) : make_float2(0.f, 0.f);
+            a[q] = (ok && kin) ? *reinterpret_cast<const float2*>(asrc + (size_t)(16 * s + q) * lda) : make_float2(0.f, 0.f);
+        }
     };
-    auto put = [&](int buf, int o, int c, float x0, float x1) {       // rows 2 rg, 2 rg + 1 of column c of operand o
+    // rows 2 rg, 2 rg + 1 of column c of operand o.  (The one-product form converts through an opaque asm: with the vector builtin clang
+    // assembled the operand pair in SCRATCH memory there -- a 128-byte private segment, scratch loads behind vmcnt(0) in the step loop: 47 us)
+    auto put = [&](int buf, int o, int c, float x0, float x1) {
         if constexpr (ONE) Ps[wg4_idx(buf, o, 0, c, rg)] = cvt_pk_bf16_asm(x0, x1);
         else {
             uint32_t hh, mm, ll;
@@ -369,11 +365,11 @@ __global__ __launch_bounds__(WG4_T, 1) void k_wgrad4(WgradBatch wb) {
             Ps[wg4_idx(buf, o, 0, c, rg)] = hh; Ps[wg4_idx(buf, o, 1, c, rg)] = mm; Ps[wg4_idx(buf, o, 2, c, rg)] = ll;
         }
     };
-    auto stage = [&](int s, int buf, const Slot& x) {
-        if (want_bias) { bs0 += x.g0.x + x.g1.x; bs1 += x.g0.y + x.g1.y; }
-        put(buf, 0, 2 * cp, x.g0.x, x.g1.x);
-        put(buf, 0, 2 * cp + 1, x.g0.y, x.g1.y);
-        float a00 = x.a0.x, a01 = x.a0.y, a10 = x.a1.x, a11 = x.a1.y;
+    auto stage = [&](int s, int buf, const float2 (&g)[2], const float2 (&a)[2]) {
+        if (want_bias) { bs0 += g[0].x + g[1].x; bs1 += g[0].y + g[1].y; }
+        put(buf, 0, 2 * cp, g[0].x, g[1].x);
+        put(buf, 0, 2 * cp + 1, g[0].y, g[1].y);
+        float a00 = a[0].x, a01 = a[0].y, a10 = a[1].x, a11 = a[1].y;
         if (DROP) {
             const uint32_t base = (uint32_t)(rbeg + 16 * s + 2 * rg) * (uint32_t)K + (uint32_t)kcol;
             a00 *= drop_hash(base, dseed, dkey) >= dthr ? dscale : 0.f;
@@ -383,10 +379,6 @@ __global__ __launch_bounds__(WG4_T, 1) void k_wgrad4(WgradBatch wb) {
         }
         put(buf, 1, 2 * cp, a00, a10);
         put(buf, 1, 2 * cp + 1, a01, a11);
-    };
-    auto slot = [&](auto ic) -> Slot& {
-        constexpr int I = decltype(ic)::value & 3;
-        if constexpr (I == 0) return sl0; else if constexpr (I == 1) return sl1; else if constexpr (I == 2) return sl2; else return sl3;
     };
     struct Frag { u32x4_t g[2][3], a[3]; };
     auto frag_load = [&](int buf, Frag& f) {
@@ -405,13 +397,13 @@ __global__ __launch_bounds__(WG4_T, 1) void k_wgrad4(WgradBatch wb) {
             for (int a = 0; a < 2; ++a) acc[a] = mfma_bf16(f.g[a][TG6[t]], f.a[TA6[t]], acc[a]);
     };
     const int ns = ((nrows + 16 * WG4_NB - 1) / (16 * WG4_NB)) * WG4_NB;      // steps, a multiple of the ring (a step past the rows multiplies zeros)
-    ld(0, sl0); ld(1, sl1); ld(2, sl2);
-    stage(0, 0, sl0);
+    static_for<0, WG4_NB - 1>([&](auto uc) { constexpr int u = decltype(uc)::value; ld(u, rawg[u], rawa[u]); });
+    stage(0, 0, rawg[0], rawa[0]);
     for (int s0 = 0; s0 < ns; s0 += WG4_NB) {
         static_for<0, WG4_NB>([&](auto uc) {
             constexpr int u = decltype(uc)::value;
             const int s = s0 + u;
-            ld(s + WG4_NB - 1, slot(std::integral_constant<int, u + 3>()));       // the slot step s - 1 was staged from
+            ld(s + WG4_NB - 1, rawg[(u + WG4_NB - 1) % WG4_NB], rawa[(u + WG4_NB - 1) % WG4_NB]);       // the slot step s - 1 was staged from
             __syncthreads();
             // the operand reads of step s are issued BEFORE the staging of step s + 1 (the other buffer): their latency hides behind the
             // split arithmetic (21.3 -> 19.1 us).  Measured and dropped: MFMAs before the staging in half / all of the waves (19.3 / 19.3 us);
@@ -420,7 +412,7 @@ __global__ __launch_bounds__(WG4_T, 1) void k_wgrad4(WgradBatch wb) {
             Frag f;
             frag_load(u & 1, f);
             __builtin_amdgcn_sched_barrier(0);
-            stage(s + 1, (u + 1) & 1, slot(std::integral_constant<int, u + 1>()));
+            stage(s + 1, (u + 1) & 1, rawg[(u + 1) % WG4_NB], rawa[(u + 1) % WG4_NB]);
             mma(f);
         });
     }
