@@ -1,3 +1,8 @@
-timeout 600 python -m pytest tests/test_bf16_mode.py tests/test_hip_parity.py tests/test_hip_training.py -x -q < /dev/null > gpurun_out/quick_tests.log 2>&1; tail -2 gpurun_out/quick_tests.log
-for rep in 1 2; do for n in base new; do if [ $n = new ]; then unset VSLNET_HIP_LIB; else export VSLNET_HIP_LIB=$PWD/vslnet_amd/lib/libvslnet_hip_base.so; fi; echo -n "$n cfg5: "; timeout 300 python bench.py --steps 40 --warmup 8 --no-cpu-baseline --batch 16 --T 1024 2>/dev/null < /dev/null | python -c "import json,sys;d=json.load(sys.stdin);print(d['value'],d['ms_per_step'])"; echo -n "$n cfg2: "; timeout 300 python bench.py --steps 100 --warmup 10 --no-cpu-baseline 2>/dev/null < /dev/null | python -c "import json,sys;d=json.load(sys.stdin);print(d['value'],d['ms_per_step'])"; done; done
-for dt in f32 bf16; do echo -n "dtype=$dt: "; timeout 200 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --dtype $dt 2>/dev/null < /dev/null | python -c "import json,sys;d=json.load(sys.stdin);print(d['value'],d['ms_per_step'])"; done
+run() { echo -n "$1: "; shift; env "$@" timeout 200 python bench.py --steps 100 --warmup 10 --no-cpu-baseline 2>/dev/null < /dev/null | python -c "import json,sys;d=json.load(sys.stdin);print(d['value'],d['ms_per_step'])"; }
+for rep in 1 2; do
+run default A=1
+run attn_waves8 VSL_ATTN_WAVES=8
+run lds_spread VSL_LDS_SPREAD=86016
+run queues4 GPU_MAX_HW_QUEUES=4
+run queues16 GPU_MAX_HW_QUEUES=16
+done
