@@ -1,3 +1,6 @@
-timeout 900 python -m pytest tests/test_hip_parity.py tests/test_hip_training.py tests/test_module_api.py -x -q < /dev/null > gpurun_out/quick_tests.log 2>&1; tail -4 gpurun_out/quick_tests.log
-timeout 500 bash tools/prof_serial.sh > gpurun_out/x_serial.log 2>&1 < /dev/null; grep "embed_fwd\|total kernel" gpurun_out/stats_serial.txt | cut -c1-140
-for rep in 1 2 3; do for n in 0 1; do echo -n "embed_fwd2=$n: "; VSL_EMBED_FWD2=$n timeout 200 python bench.py --steps 100 --warmup 10 --no-cpu-baseline 2>/dev/null < /dev/null | python -c "import json,sys;d=json.load(sys.stdin);print(d['value'],d['ms_per_step'])"; done; done
+run() { echo -n "$1: "; shift; env "$@" timeout 200 python bench.py --steps 100 --warmup 10 --no-cpu-baseline 2>/dev/null < /dev/null | python -c "import json,sys;d=json.load(sys.stdin);print(d['value'],d['ms_per_step'])"; }
+for rep in 1 2 3; do
+run "old embed, late " VSL_EMBED_FWD2=0 VSL_EARLY_QUERY=0
+run "new embed, early" VSL_EMBED_FWD2=1 VSL_EARLY_QUERY=1
+run "new embed, late " VSL_EMBED_FWD2=1 VSL_EARLY_QUERY=0
+done
