@@ -46,6 +46,14 @@ CASES = {
 }
 
 
+# TRAINING-mode cases (round 4): model.train(), drop_rate 0.2, every nn.Dropout call replaced by a mask drawn from a generator seeded
+# with MASK_SEED + call number (oracle.train_mask) -- the placement and ORDER of the 41 (transformer) / 23 (rnn) dropout sites
+# (layers_t7.py:45, 63-64, 113, 138, 168-169, 181, 185, 188-189, 227-228) is then pinned by the logits, losses and gradients.
+TRAIN_CASES = {
+    'train_tf':  (dict(video_feature_dim=64, max_pos_len=32, word_size=52, drop_rate=0.2), 3, 24, 7, 6, True),
+    'train_rnn': (dict(video_feature_dim=64, max_pos_len=32, word_size=52, drop_rate=0.2, predictor='rnn'), 3, 24, 7, 6, True),
+}
+
 PARAM_SEED = 12345
 
 
@@ -119,6 +127,64 @@ def run_case(VSLNet, name, spec):
     path = os.path.join(ROOT, 'tests', 'golden', name + '.npz')
     np.savez_compressed(path, **out)
     print(name, 'written', os.path.getsize(path) // 1024, 'KiB', 'loss', float(total))
+
+
+def run_train_case(VSLNet, name, spec):
+    """The reference in TRAINING mode under seeded per-call dropout masks.  The masks are defined in the layout the path's tensors
+    have outside the conv block, (B, L, C); the conv block's dropout (layers_t7.py:138) sees (B, C, L), so its masks are transposed."""
+    over, B, T, Lq, Lc, ragged = spec
+    cfg = O.make_cfg(**over)
+    torch.manual_seed(12345)
+    glove = np.zeros((cfg.word_size - 2, cfg.word_dim), np.float32)
+    model = VSLNet(configs=cfg, word_vectors=glove)
+    P = O.random_params(cfg, seed=PARAM_SEED)
+    model.load_state_dict(P, strict=True)
+    model.train()
+    batch = O.synthetic_batch(cfg, B, T, Lq, Lc, seed=4, ragged=ragged)
+    conv_drops = {id(model.feature_encoder.conv_block.dropout)}
+    if cfg.predictor != 'rnn':
+        conv_drops.add(id(model.predictor.encoder.conv_block.dropout))
+    calls = [0]
+    orig = torch.nn.Dropout.forward
+
+    def patched(self, x):
+        if not self.training or self.p == 0.0:
+            return x
+        n = calls[0]
+        calls[0] += 1
+        if id(self) in conv_drops:
+            return x * O.train_mask(n, tuple(x.transpose(1, 2).shape), self.p).transpose(1, 2)
+        return x * O.train_mask(n, tuple(x.shape), self.p)
+
+    torch.nn.Dropout.forward = patched
+    try:
+        h, sl, el = model(batch['word_ids'], batch['char_ids'], batch['vfeats'], batch['v_mask'], batch['q_mask'])
+        hl = model.compute_highlight_loss(h, batch['h_labels'], batch['v_mask'])
+        loc = model.compute_loss(sl, el, batch['s_labels'], batch['e_labels'])
+        total = loc + 5.0 * hl
+        model.zero_grad()
+        total.backward()
+    finally:
+        torch.nn.Dropout.forward = orig
+    out = {}
+    for k, v in batch.items():
+        out['in.' + k] = v.numpy()
+    out['param_seed'] = np.array(PARAM_SEED)
+    out['n_dropout_calls'] = np.array(calls[0])
+    for k, c in sd_checksums(model.state_dict()).items():
+        out['sdsum.' + k] = c
+    for n, p in model.named_parameters():
+        if p.requires_grad:
+            out['grad.' + n] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy()
+    out['out.h_score'] = h.detach().numpy()
+    out['out.start_logits'] = sl.detach().numpy()
+    out['out.end_logits'] = el.detach().numpy()
+    out['out.highlight_loss'] = hl.detach().numpy()
+    out['out.loc_loss'] = loc.detach().numpy()
+    out['cfg'] = np.array(repr(vars(cfg)))
+    path = os.path.join(ROOT, 'tests', 'golden', name + '.npz')
+    np.savez_compressed(path, **out)
+    print(name, 'written', os.path.getsize(path) // 1024, 'KiB', 'loss', float(total.detach()), 'dropout calls', calls[0])
 
 
 def run_host_helpers(ru, dl):
@@ -248,12 +314,17 @@ def main():
         return
     if len(sys.argv) > 2 and sys.argv[1] == 'case':          # one model fixture, the others untouched
         torch.set_num_threads(8)
-        run_case(VSLNet, sys.argv[2], CASES[sys.argv[2]])
+        if sys.argv[2] in TRAIN_CASES:
+            run_train_case(VSLNet, sys.argv[2], TRAIN_CASES[sys.argv[2]])
+        else:
+            run_case(VSLNet, sys.argv[2], CASES[sys.argv[2]])
         return
     os.makedirs(os.path.join(ROOT, 'tests', 'golden'), exist_ok=True)
     torch.set_num_threads(8)
     for name, spec in CASES.items():
         run_case(VSLNet, name, spec)
+    for name, spec in TRAIN_CASES.items():
+        run_train_case(VSLNet, name, spec)
     run_host_helpers(ru, dl)
     run_host_pipeline(ru, dl)
     run_init(VSLNet)

@@ -44,6 +44,16 @@ def force_dropout(fn):
     DROP_FORCED, DROP_CALLS = fn, 0
 
 
+TRAIN_MASK_SEED = 20260928
+
+
+def train_mask(call, shape, p, seed=TRAIN_MASK_SEED):
+    """Dropout multiplier of the seeded training-mode fixtures (oracle/make_golden.py TRAIN_CASES, tests/test_oracle_golden.py): call number
+    `call` of a forward draws its mask from its own generator, in the (B, L, C) layout of the call site."""
+    g = torch.Generator().manual_seed(seed + int(call))
+    return (torch.rand(shape, generator=g) >= p).to(torch.float32) / (1.0 - p)
+
+
 def _drop(x, p, training):
     """nn.Dropout(p) with inverted scaling (layers_t7.py: every nn.Dropout site)."""
     global DROP_CALLS

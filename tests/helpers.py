@@ -58,19 +58,22 @@ def relu_flips(eng, B, T, Lq, predictor='transformer'):
 #       |z_1 - z_2| / (u S)  <=  2 (K + 7 + 2 * 128 + K_in) * A,        K_in <= max(128, Dv) = 4096 at configs[2],
 # A = amplification of the inputs' relative error through LN (1 / sigma of a row, O(1) here).  That worst case (~1e4) is never approached:
 # rounding errors add like a random walk, sqrt instead of linear, so the expected scale is 2 sqrt(K + 7 + 256 + K_in) ~ 40 .. 130.  The
-# gate: a decision may be overridden only where |z| <= RELU_NOISE_KAPPA * u * S, KAPPA = 150 (the random-walk scale with Dv = 4096, rounded
-# up).  Measured over the whole GPU suite (tools/dbg/run_r3a.sh, `pytest -s` prints every value): at most 3.9 x (u * S) = |z| 2.0e-7 with
-# the split-bf16 kernels, 3.0 x (1.7e-7) with the fp32-input MFMA kernels of round 2 -- both far inside.  The absolute deviation is still
-# printed but no longer asserted: the old gate (2e-5, not tied to S) vetoed a legitimate re-ordering in round 2 (the 2-K-group
+# gate: a decision may be overridden only where |z| <= RELU_NOISE_KAPPA * u * S.  Round 3 set KAPPA = 150 (the random-walk scale with
+# Dv = 4096, rounded up); measured over the whole GPU suite (`pytest -s` prints every value) the largest override is 3.9 x (u * S) = |z| 2.0e-7
+# with the split-bf16 kernels, 3.0 x (1.7e-7) with the fp32-input MFMA kernels of round 2 -- so round 4 sets KAPPA = 16: four times the
+# largest value ever seen, and a kernel regression that moved pre-activations by 5 x today's noise now fails the gradient-parity tests
+# instead of being absorbed by forced branches (VERDICT r3 / ADVICE r3).  The margin is printed with every check.  The absolute deviation is
+# still printed but not asserted: the old gate (2e-5, not tied to S) vetoed a legitimate re-ordering in round 2 (the 2-K-group
 # VisualProjection: 3.3e-5 on a row with a large S) while being 100x looser than needed on ordinary rows.
 # ---------------------------------------------------------------------------------------------------------------------------
-RELU_NOISE_KAPPA = 150.0
+RELU_NOISE_KAPPA = 16.0
 
 
 def assert_forced_relu_inside_noise(O, context=None):
     """After a forward with forced ReLU branches: every overridden pre-activation must lie inside its own fp32 noise."""
     r = O.forced_relu_noise_ratio()
-    print('[relu-noise] %s: largest overridden pre-activation %.3e = %.1f x (u * S)' % (context if isinstance(context, str) else '', O.forced_relu_deviation(), r))
+    print('[relu-noise] %s: largest overridden pre-activation %.3e = %.1f x (u * S), gate %.0f (margin %.1f x)'
+          % (context if isinstance(context, str) else '', O.forced_relu_deviation(), r, RELU_NOISE_KAPPA, RELU_NOISE_KAPPA / max(r, 1e-9)))
     assert r <= RELU_NOISE_KAPPA, (context, 'forced ReLU branch at %.1f x (u * S), |z| up to %.3e' % (r, O.forced_relu_deviation()))
 
 

@@ -77,6 +77,50 @@ def test_backward_all_parameter_grads(name):
     assert n >= 40
 
 
+@pytest.mark.parametrize('name', ['train_tf', 'train_rnn'])
+def test_training_mode_matches_the_reference_under_seeded_masks(name):
+    """TRAINING mode (drop_rate 0.2, the benchmark's mode): the reference ran with every nn.Dropout call replaced by the seeded mask
+    O.train_mask(call number, shape, p) (oracle/make_golden.py: run_train_case); the oracle replays the same masks through
+    O.force_dropout.  Pins the placement AND the call order of the 41 / 23 dropout sites, on which every GPU training-mode parity
+    test (tests/test_hip_training.py) rests."""
+    cfg, P, b, z = load_golden(name)
+    assert cfg.drop_rate == 0.2
+    Pg = {k: (v.clone().requires_grad_(k not in O.FROZEN)) for k, v in P.items()}
+    O.force_dropout(O.train_mask)
+    try:
+        total, (h, sl, el, hl, loc) = O.total_loss(Pg, cfg, b, training=True)
+        n_calls = O.DROP_CALLS
+    finally:
+        O.force_dropout(None)
+    assert n_calls == int(z['n_dropout_calls']) == (23 if cfg.predictor == 'rnn' else 41)
+    _close(h, z['out.h_score'], atol=5e-6, what='h_score')
+    _close(sl, z['out.start_logits'], what='start_logits')
+    _close(el, z['out.end_logits'], what='end_logits')
+    _close(hl, z['out.highlight_loss'], atol=1e-5, what='hl loss')
+    _close(loc, z['out.loc_loss'], atol=2e-5, what='loc loss')
+    total.backward()
+    worst = 0.0
+    for k in z.files:
+        if not k.startswith('grad.'):
+            continue
+        g_ref = z[k]
+        g = Pg[k[5:]].grad
+        g = torch.zeros_like(Pg[k[5:]]) if g is None else g
+        err = float(np.abs(g.numpy() - g_ref).max())
+        assert err <= grad_tol(g_ref), '%s: grad err %.3e (tol %.3e)' % (k, err, grad_tol(g_ref))
+        worst = max(worst, err / grad_tol(g_ref))
+    print('%s: %d dropout calls, worst gradient at %.2f of its gate' % (name, n_calls, worst))
+    # the masks matter: with the call numbers shifted by one the logits must move far outside the gate
+    O.force_dropout(lambda call, shape, p: O.train_mask(call + 1, shape, p))
+    try:
+        with torch.no_grad():
+            _, (_, sl2, _, _, _) = O.total_loss(P, cfg, b, training=True)
+    finally:
+        O.force_dropout(None)
+    fin = np.abs(z['out.start_logits']) < 1e29
+    assert float(np.abs(sl2.numpy() - z['out.start_logits'])[fin].max()) > 1e-2
+
+
 def test_structural_zero_grads():
     """key bias and the final 1-channel logit biases get structurally zero gradient."""
     cfg, P, b, z = load_golden('tiny_tf')
