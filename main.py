@@ -129,6 +129,9 @@ def train(configs, dataset, features, device, world, rank, log=print):
                            warmup_proportion=configs.warmup_proportion, clip_norm=configs.clip_norm, engine=eng,
                            hf_order=configs.adamw == 'hf')
         pad_vec, glove_vec = model.embedding_net.word_emb.pad_vec.data, model.embedding_net.word_emb.glove_vec.data
+        # N > 1: backward + exchange as bench.py runs it -- the predictor block of the bucket goes out on a side stream behind the library's
+        # early-gradient event while the rest of the backward runs (dp.OverlappedExchange); VSL_ALLREDUCE=single: one call behind the backward
+        xchg = dp.OverlappedExchange(eng) if world > 1 and os.environ.get('VSL_ALLREDUCE', 'overlap') != 'single' else None
     else:
         optimizer, scheduler = build_optimizer_and_scheduler(model, configs)
     eval_period = max(1, n_batches // 2)
@@ -147,92 +150,102 @@ def train(configs, dataset, features, device, world, rank, log=print):
     else:
         clock = time.perf_counter
     epoch_end = []                                                         # wall clock at the end of every epoch (device idle)
-    for epoch in range(configs.epochs):
-        model.train()
-        it = iter(shards() if fused else train_loader)
-        while True:
-            t0 = clock()
-            try:
-                batch = next(it)
-            except StopIteration:
-                break
-            t1 = clock()
-            if trace is not None:
-                trace['batch'] += t1 - t0
-            global_step += 1
-            if fused:
-                # this rank's rows, padded to the GLOBAL batch widths; the losses are normalised with the global batch
-                inv_batch, mask_sum = dp.global_normalisers(batch['lens_global'])
-                if batch['vfeats'].shape[0] == 0:
-                    # the last batch of an epoch can hold fewer samples than there are ranks (TACoS: 10146 % 16 = 2): a rank
-                    # without rows contributes a zero bucket and still joins the exchange and the (replicated) update
-                    grads.zero_()
-                    losses = torch.zeros(4, device=device)
+    try:
+        for epoch in range(configs.epochs):
+            model.train()
+            it = iter(shards() if fused else train_loader)
+            while True:
+                t0 = clock()
+                try:
+                    batch = next(it)
+                except StopIteration:
+                    break
+                t1 = clock()
+                if trace is not None:
+                    trace['batch'] += t1 - t0
+                global_step += 1
+                if fused:
+                    # this rank's rows, padded to the GLOBAL batch widths; the losses are normalised with the global batch
+                    inv_batch, mask_sum = dp.global_normalisers(batch['lens_global'])
+                    if batch['vfeats'].shape[0] == 0:
+                        # the last batch of an epoch can hold fewer samples than there are ranks (TACoS: 10146 % 16 = 2): a rank
+                        # without rows contributes a zero bucket and still joins the exchange and the (replicated) update
+                        grads.zero_()
+                        losses = torch.zeros(4, device=device)
+                        if xchg is not None:
+                            xchg.exchange(grads)                        # the same two calls in the same order as the ranks that have rows
+                        else:
+                            dp.allreduce_flat_(grads)
+                    else:
+                        q_mask = (batch['word_ids'] != 0).float()
+                        eng.forward(flat, pad_vec, glove_vec, batch['word_ids'], batch['char_ids'], batch['vfeats'], batch['v_mask'], q_mask,
+                                    training=True, seed=(configs.seed << 20) + global_step, sample_offset=batch['row0'])
+                        losses, d_h, d_sl, d_el = eng.loss(batch['s_labels'], batch['e_labels'], batch['h_labels'], 1.0,
+                                                           configs.highlight_lambda, inv_batch=inv_batch, mask_sum=mask_sum)
+                        if xchg is not None:
+                            xchg.backward(d_h, d_sl, d_el, grads)
+                        else:
+                            eng.backward(d_h, d_sl, d_el, grads)
+                            dp.allreduce_flat_(grads)
+                    opt.step(grads)
+                    loss_t = losses[2]
                 else:
-                    q_mask = (batch['word_ids'] != 0).float()
-                    eng.forward(flat, pad_vec, glove_vec, batch['word_ids'], batch['char_ids'], batch['vfeats'], batch['v_mask'], q_mask,
-                                training=True, seed=(configs.seed << 20) + global_step, sample_offset=batch['row0'])
-                    losses, d_h, d_sl, d_el = eng.loss(batch['s_labels'], batch['e_labels'], batch['h_labels'], 1.0,
-                                                       configs.highlight_lambda, inv_batch=inv_batch, mask_sum=mask_sum)
-                    eng.backward(d_h, d_sl, d_el, grads)
-                dp.allreduce_flat_(grads)
-                opt.step(grads)
-                loss_t = losses[2]
-            else:
-                _, vfeats, vfeat_lens, word_ids, char_ids, s_labels, e_labels, h_labels = batch
-                vfeats, vfeat_lens, word_ids, char_ids, s_labels, e_labels, h_labels = _to_device(
-                    [vfeats, vfeat_lens, word_ids, char_ids, s_labels, e_labels, h_labels], device)
-                query_mask = (word_ids != 0).float()
-                video_mask = runner.convert_length_to_mask(vfeat_lens)
-                h_score, start_logits, end_logits = model(word_ids, char_ids, vfeats, video_mask, query_mask)
-                highlight_loss = model.compute_highlight_loss(h_score, h_labels, video_mask)
-                loc_loss = model.compute_loss(start_logits, end_logits, s_labels, e_labels)
-                loss_t = loc_loss + configs.highlight_lambda * highlight_loss
-                optimizer.zero_grad()
-                loss_t.backward()
-                torch.nn.utils.clip_grad_norm_(model.parameters(), configs.clip_norm)
-                optimizer.step()
-                scheduler.step()
-            t2 = clock()
-            if trace is not None:
-                trace['step_enqueue'] += t2 - t1
-            if global_step % configs.period == 0 or global_step == 1:
-                lv = float(loss_t.item())
-                if world > 1:                                   # local partial sums of the global loss
-                    t = torch.tensor([lv], device=device)
-                    torch.distributed.all_reduce(t)
-                    lv = float(t.item())
-                history.append((global_step, lv))
-                log('step %6d | loss %.4f' % (global_step, lv))
-            t3 = clock()
-            if trace is not None:
-                trace['log'] += t3 - t2
-            if global_step % eval_period == 0 or global_step % n_batches == 0:
-                if rank == 0:
-                    model.eval()
-                    r1i3, r1i5, r1i7, mi, score_str = runner.eval_test(model, test_loader, device, 'test', epoch + 1, global_step)
-                    t4 = clock()
-                    if trace is not None:
-                        trace['eval'] += t4 - t3
-                    log('Epoch: %2d | Step: %5d | r1i3: %.2f | r1i5: %.2f | r1i7: %.2f | mIoU: %.2f' % (epoch + 1, global_step, r1i3, r1i5, r1i7, mi))
-                    score_writer.write(score_str)
-                    score_writer.flush()
-                    history.append((global_step, {'r1i3': r1i3, 'r1i5': r1i5, 'r1i7': r1i7, 'mIoU': mi}))
-                    if r1i7 >= best_r1i7:
-                        best_r1i7 = r1i7
-                        ckpt.save_flat(model, os.path.join(model_dir, '{}_{}.t7'.format(configs.model_name, global_step)), model_dir,
-                                       suffix='t7', max_to_keep=3)
+                    _, vfeats, vfeat_lens, word_ids, char_ids, s_labels, e_labels, h_labels = batch
+                    vfeats, vfeat_lens, word_ids, char_ids, s_labels, e_labels, h_labels = _to_device(
+                        [vfeats, vfeat_lens, word_ids, char_ids, s_labels, e_labels, h_labels], device)
+                    query_mask = (word_ids != 0).float()
+                    video_mask = runner.convert_length_to_mask(vfeat_lens)
+                    h_score, start_logits, end_logits = model(word_ids, char_ids, vfeats, video_mask, query_mask)
+                    highlight_loss = model.compute_highlight_loss(h_score, h_labels, video_mask)
+                    loc_loss = model.compute_loss(start_logits, end_logits, s_labels, e_labels)
+                    loss_t = loc_loss + configs.highlight_lambda * highlight_loss
+                    optimizer.zero_grad()
+                    loss_t.backward()
+                    torch.nn.utils.clip_grad_norm_(model.parameters(), configs.clip_norm)
+                    optimizer.step()
+                    scheduler.step()
+                t2 = clock()
+                if trace is not None:
+                    trace['step_enqueue'] += t2 - t1
+                if global_step % configs.period == 0 or global_step == 1:
+                    lv = float(loss_t.item())
+                    if world > 1:                                   # local partial sums of the global loss
+                        t = torch.tensor([lv], device=device)
+                        torch.distributed.all_reduce(t)
+                        lv = float(t.item())
+                    history.append((global_step, lv))
+                    log('step %6d | loss %.4f' % (global_step, lv))
+                t3 = clock()
+                if trace is not None:
+                    trace['log'] += t3 - t2
+                if global_step % eval_period == 0 or global_step % n_batches == 0:
+                    if rank == 0:
+                        model.eval()
+                        r1i3, r1i5, r1i7, mi, score_str = runner.eval_test(model, test_loader, device, 'test', epoch + 1, global_step)
+                        t4 = clock()
                         if trace is not None:
-                            trace['checkpoint'] += clock() - t4
-                    model.train()
-                if world > 1:
-                    torch.distributed.barrier()
-        torch.cuda.synchronize(device)
-        epoch_end.append(time.perf_counter())
-    if score_writer:
-        score_writer.close()
-    if ckpt is not None:
-        ckpt.close()                                                       # every checkpoint is on disk when train() returns
+                            trace['eval'] += t4 - t3
+                        log('Epoch: %2d | Step: %5d | r1i3: %.2f | r1i5: %.2f | r1i7: %.2f | mIoU: %.2f' % (epoch + 1, global_step, r1i3, r1i5, r1i7, mi))
+                        score_writer.write(score_str)
+                        score_writer.flush()
+                        history.append((global_step, {'r1i3': r1i3, 'r1i5': r1i5, 'r1i7': r1i7, 'mIoU': mi}))
+                        if r1i7 >= best_r1i7:
+                            best_r1i7 = r1i7
+                            ckpt.save_flat(model, os.path.join(model_dir, '{}_{}.t7'.format(configs.model_name, global_step)), model_dir,
+                                           suffix='t7', max_to_keep=3)
+                            if trace is not None:
+                                trace['checkpoint'] += clock() - t4
+                        model.train()
+                    if world > 1:
+                        torch.distributed.barrier()
+            torch.cuda.synchronize(device)
+            epoch_end.append(time.perf_counter())
+    finally:
+        # an exception or Ctrl-C must not leave the writer thread mid-file: every queued checkpoint is written (atomically) first
+        if score_writer:
+            score_writer.close()
+        if ckpt is not None:
+            ckpt.close()                                                   # every checkpoint is on disk when train() returns
     return {'history': history, 'model_dir': model_dir, 'steps': global_step, 'trace': trace, 'epoch_end': epoch_end}
 
 

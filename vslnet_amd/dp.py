@@ -81,8 +81,15 @@ class OverlappedExchange:
             if self.split > 0:
                 dist.all_reduce(grads[:self.split], op=dist.ReduceOp.SUM, group=self.group)
             cur.wait_stream(self.side)
-        else:
+        else:                                             # rnn head: no early block -- [split:] is empty, ONE call (two_segment_allreduce_ does the same)
             dist.all_reduce(grads, op=dist.ReduceOp.SUM, group=self.group)
+        return grads
+
+
+    def exchange(self, grads):
+        """The exchange alone, for a rank whose shard of the batch is empty (it has no backward to overlap with): the same two calls in the
+        same order on the same communicator as `backward` issues on the other ranks."""
+        two_segment_allreduce_(grads, self.split, self.group)
         return grads
 
 

@@ -116,6 +116,25 @@ def _chk(t, dtype, shape, name):
                          (name, dtype, tuple(shape), t.dtype, tuple(t.shape), t.device))
 
 
+def check_hw_queues():
+    """A process group (RCCL) brings its own streams; with fewer than 8 hardware queues the library's two side streams then share a
+    queue with another stream and the fork / join overlap of the step is silently lost (measured: 1.25 -> 1.51 ms per step).  The
+    variable only counts if it was in the environment before the process initialised HIP -- the library cannot enforce that, so it
+    refuses to run in the state it can detect: a process group exists and GPU_MAX_HW_QUEUES is below 8 or was set too late."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    import vslnet_amd
+    try:
+        q = int(os.environ.get('GPU_MAX_HW_QUEUES', '0'))
+    except ValueError:
+        q = 0
+    if q < 8 or vslnet_amd.QUEUES_SET_LATE:
+        raise VslError('GPU_MAX_HW_QUEUES=%s%s while a torch.distributed process group exists: the step needs 8 hardware queues beside '
+                       "RCCL's streams.  Export GPU_MAX_HW_QUEUES=8 before the process starts (or import vslnet_amd before the first CUDA call)"
+                       % (os.environ.get('GPU_MAX_HW_QUEUES'), ' (set after HIP was initialised)' if vslnet_amd.QUEUES_SET_LATE else ''))
+
+
 class Engine:
     """One `vsl_handle` + caller-owned buffers.  Mirrors what VSLNet.__init__ / forward / backward need."""
 
@@ -124,6 +143,7 @@ class Engine:
         (layers_t7.py:36); forward() then takes pad_vec = glove_vec = None."""
         if not torch.cuda.is_available():
             raise VslError('vslnet_amd needs an MI355X (gfx950) visible to PyTorch-ROCm; there is no CPU fallback')
+        check_hw_queues()
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
         self.lib = load_library()
         pred = {'rnn': 0, 'transformer': 1}.get(configs.predictor)

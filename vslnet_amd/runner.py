@@ -37,11 +37,15 @@ def filter_checkpoints(model_dir, suffix='t7', max_to_keep=5):
 class _LazyState:
     """state_dict of a flat-bucket module from a host copy of the bucket (built on the worker thread)."""
 
-    def __init__(self, model, host_flat):
-        self.model, self.host = model, host_flat
+    def __init__(self, model, host_flat, free=None):
+        self.model, self.host, self.free = model, host_flat, free
 
     def build(self):
-        return self.model.state_dict_from_flat(self.host.clone())        # (a private copy: the pinned buffer is reused two saves later)
+        try:
+            return self.model.state_dict_from_flat(self.host.clone())    # a private copy ...
+        finally:
+            if self.free is not None:
+                self.free.set()                                          # ... after which the pinned buffer may be reused (save_flat waits for this)
 
 
 class CheckpointWriter:
@@ -71,12 +75,23 @@ class CheckpointWriter:
                     event.synchronize()
                 if isinstance(state, _LazyState):
                     state = state.build()
-                torch.save(state, path)
+                tmp = path + '.tmp'                      # a crash / Ctrl-C mid-write must not leave a truncated *.t7 for get_last_checkpoint
+                torch.save(state, tmp)
+                os.replace(tmp, path)
                 filter_checkpoints(model_dir, suffix=suffix, max_to_keep=keep)
-            except Exception as e:                       # surfaced by close()
+            except Exception as e:                       # raised by the next save() / save_flat() / close()
                 self.err = e
+                if isinstance(state, _LazyState) and state.free is not None:
+                    state.free.set()
+
+    def _raise_pending(self):
+        """A failed write stops the run at the next save, like the reference's synchronous torch.save would (main_t7.py:125)."""
+        if self.err is not None:
+            err, self.err = self.err, None
+            raise err
 
     def save(self, state_dict, path, model_dir, suffix='t7', max_to_keep=3):
+        self._raise_pending()
         if self.stream is None:
             self.q.put(({k: v.clone() for k, v in state_dict.items()}, None, path, model_dir, suffix, max_to_keep))
             return
@@ -98,27 +113,37 @@ class CheckpointWriter:
         bucket on the training stream (4.4 MB, microseconds; the optimizer may go on at once), ONE device-to-host copy of it on the side
         stream, and the worker thread rebuilds the reference's state_dict (same keys, shapes, order) from views of the host copy.  The
         per-tensor path above costs ~110 small copies the training stream has to wait for (3.4 ms per checkpoint)."""
+        import threading
+        self._raise_pending()
         flat, _ = model.flat_parameters
         snap = flat.clone()
         cur = torch.cuda.current_stream(self.device)
         self.stream.wait_stream(cur)
+        if getattr(self, '_pin', None) is None or self._pin[0].numel() != snap.numel():
+            self._pin = [torch.empty(snap.shape, dtype=snap.dtype, device='cpu', pin_memory=True) for _ in range(2)]
+            self._pin_free = [threading.Event(), threading.Event()]
+            for e in self._pin_free:
+                e.set()
+            self._pin_i = 0
+        self._pin_i ^= 1
+        # two buffers: the worker may still be writing the previous checkpoint.  Back-pressure: a buffer is reused only after the worker
+        # has taken its private copy of it (blocks only when the writer lags two saves behind -- a slow disk, tiny epochs)
+        free = self._pin_free[self._pin_i]
+        free.wait()
+        self._raise_pending()
+        free.clear()
         with torch.cuda.stream(self.stream):
-            if getattr(self, '_pin', None) is None or self._pin[0].numel() != snap.numel():
-                self._pin = [torch.empty(snap.shape, dtype=snap.dtype, device='cpu', pin_memory=True) for _ in range(2)]
-                self._pin_i = 0
-            self._pin_i ^= 1
-            host = self._pin[self._pin_i]                 # two buffers: the worker may still be writing the previous checkpoint
+            host = self._pin[self._pin_i]
             host.copy_(snap, non_blocking=True)
             snap.record_stream(self.stream)
             ev = torch.cuda.Event()
             ev.record(self.stream)
-        self.q.put((_LazyState(model, host), ev, path, model_dir, suffix, max_to_keep))
+        self.q.put((_LazyState(model, host, free), ev, path, model_dir, suffix, max_to_keep))
 
     def close(self):
         self.q.put(None)
         self.thread.join()
-        if self.err is not None:
-            raise self.err
+        self._raise_pending()
 
 
 def get_last_checkpoint(model_dir, suffix='t7'):
