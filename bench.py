@@ -31,7 +31,7 @@ PEAK_MFMA_F32 = 157.3e12       # MI355X_MICROARCH.md: fp32-in MFMA = fp32 vector
 PEAK_HBM = 8.0e12              # HBM3E spec
 PEAK_MFMA_BF16 = 2.5e15        # dense bf16 MFMA (the split kernels issue 6 bf16 products per fp32-grade product)
 CPU_THREADS = 16               # cpu_baseline's intra-op threads: the best of the sweep on the GPU boxes (tools/cpu_threads_sweep.py, profiles/r03_notes.md)
-PROFILE_JSON = 'r03_profile.json'   # tools/collect_evidence.sh -> tools/make_profile_json.py
+PROFILE_JSON = 'r04_profile.json'   # tools/collect_evidence.sh -> tools/make_profile_json.py
 
 
 def alg_flops_per_pair(T, Dv, Lq, Lc, d=128, NL=4, k=7, predictor='transformer'):
@@ -197,6 +197,10 @@ def main():
     ap.add_argument('--drop-rate', type=float, default=0.2)
     ap.add_argument('--predictor', default='transformer', help="'transformer' (headline, configs[1]) or 'rnn' (configs[0] shape)")
     ap.add_argument('--dtype', default='f32', choices=('f32', 'bf16'), help="'bf16' = the separate throughput mode: bfloat16 features in HBM, VisualProjection and the weight gradients as single bf16 products (vsl_io.arithmetic = 1); never the parity / headline line")
+    ap.add_argument('--resident-batches', type=int, default=10,
+                    help='distinct synthetic batches resident in HBM, rotated step by step: 10 x 32 MiB of features at the headline shape exceed the '
+                         '256 MiB Infinity Cache, so the feature stream of VisualProjection and of its weight gradient really comes from HBM '
+                         '(1 = one batch re-used every step, Infinity-Cache resident)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-optimizer', action='store_true', help='time forward + losses + backward only (A/B runs)')
     ap.add_argument('--profile-all', action='store_true', help='also print the per-kernel HIP-event table to stderr')
@@ -232,11 +236,14 @@ def main():
     flat, grads = model.flat_parameters
     eng = model._engine
     pad_vec, glove_vec = model.embedding_net.word_emb.pad_vec.data, model.embedding_net.word_emb.glove_vec.data
-    batch = synthetic_batch(configs, B, T, Lq, Lc, seed=100 + rank)
+    nres = max(1, args.resident_batches)
+    batches = [synthetic_batch(configs, B, T, Lq, Lc, seed=100 + rank + 1000 * k) for k in range(nres)]
     if args.dtype == 'bf16':
-        batch['vfeats'] = batch['vfeats'].to(torch.bfloat16).contiguous()
+        for bt in batches:
+            bt['vfeats'] = bt['vfeats'].to(torch.bfloat16).contiguous()
+    feat_mib = nres * batches[0]['vfeats'].numel() * batches[0]['vfeats'].element_size() / 2 ** 20
     inv_batch = 1.0 / (B * world)
-    mask_sum = float(batch['v_mask'].sum().item()) * world   # full-length synthetic clips: same on every rank
+    mask_sum = float(batches[0]['v_mask'].sum().item()) * world   # full-length synthetic clips: same for every batch and rank
 
     # the update of main_t7.py:111-113 (clip 1.0, AdamW, linear decay) as the library's fused two-kernel step; identical on
     # every rank because the reduced gradient is.  BASELINE's metric is "fwd+bwd": the update is extra work inside the
@@ -250,6 +257,7 @@ def main():
                     clip_norm=configs.clip_norm, engine=eng)
 
     def step(i, skip_exchange=False):
+        batch = batches[i % nres]
         eng.forward(flat, pad_vec, glove_vec, batch['word_ids'], batch['char_ids'], batch['vfeats'], batch['v_mask'],
                     batch['q_mask'], training=True, seed=i, sample_offset=rank * B, arithmetic='bf16' if args.dtype == 'bf16' else 'f32')
         losses, d_h, d_sl, d_el = eng.loss(batch['s_labels'], batch['e_labels'], batch['h_labels'], 1.0,
@@ -277,7 +285,8 @@ def main():
         tot = sum(v[0] for v in table.values())
         for k, (ms, n) in sorted(table.items(), key=lambda kv: -kv[1][0]):
             print('%-18s %8.1f us  %3d launches  %5.1f%%' % (k, ms * 1e3, n, 100 * ms / tot), file=sys.stderr)
-    eng.profile_select(dominant)                             # timed region: events around the dominant kernel only
+    # timed region: events around the dominant kernel group and the one HBM-streaming kernel (VisualProjection)
+    eng.profile_select(dominant if dominant == 'vproj_fwd' else dominant + ',vproj_fwd')
 
     def sync():
         torch.cuda.synchronize()
@@ -294,7 +303,9 @@ def main():
         tmax = torch.tensor([dt], device='cuda', dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    kt = eng.profile_read()[dominant]
+    ptab = eng.profile_read()
+    kt = ptab[dominant]
+    kvp = ptab.get('vproj_fwd')
     eng.profile_select(None)
     # the exchange's exposed cost: the same timed region once more without it (every rank runs it, so the barriers still pair up)
     dt_nox = None
@@ -352,6 +363,16 @@ def main():
         except Exception:
             pass
         roof['step_mfma_frac'] = round(fb * value / world / PEAK_MFMA_F32, 4)   # whole step vs the fp32 MFMA roof, per GPU
+        if kvp and kvp[1]:
+            # VisualProjection: the only kernel that streams the (B, T, Dv) feature tensor: algorithmic bytes (features in,
+            # projection out) over its live event time.  With --resident-batches >= 9 the features of a step were last touched > 256 MiB ago
+            vp_us = kvp[0] * 1e3 / kvp[1]
+            vp_bytes = (2 if args.dtype == 'bf16' else 4) * B * T * Dv + 4 * B * T * 128
+            roof['vproj_event_us'] = round(vp_us, 2)
+            roof['vproj_hbm_gbps'] = round(vp_bytes / (vp_us * 1e-6) / 1e9, 1)
+            roof['vproj_hbm_frac'] = round(vp_bytes / (vp_us * 1e-6) / PEAK_HBM, 4)
+            roof['vproj_features'] = ('%d resident batches = %.0f MiB of features, rotated: %s' %
+                                      (nres, feat_mib, 'streamed from HBM (> 256 MiB Infinity Cache)' if feat_mib > 256 else 'Infinity-Cache resident'))
         # the split kernels reach fp32 grade with 6 bf16 products per product: the same launch against the dense bf16 peak
         if work and dominant in ('wgrad', 'convblock_fwd', 'convblock_bwd', 'vproj_fwd') and os.environ.get('VSL_F32_GEMM') != '1':
             roof['bf16x6_frac_of_bf16_peak'] = round(6 * work[0] / k_s / PEAK_MFMA_BF16, 4)
@@ -361,8 +382,10 @@ def main():
                'dtype': dtype_line(args),
                'data': 'synthetic',
                'config': {'workload': '%s, --predictor %s, B=%d/GPU T=%d Dv=%d Lq=%d Lc=%d drop_rate=%.1f '
-                                      'train mode; step = forward + CE(start)+CE(end)+5*highlight + backward%s%s'
-                                      % (workload_name(args), args.predictor, B, T, Dv, Lq, Lc, args.drop_rate,
+                                      'train mode, %d distinct HBM-resident batches rotated (%.0f MiB of features%s); '
+                                      'step = forward + CE(start)+CE(end)+5*highlight + backward%s%s'
+                                      % (workload_name(args), args.predictor, B, T, Dv, Lq, Lc, args.drop_rate, nres, feat_mib,
+                                         '' if feat_mib > 256 else ': Infinity-Cache resident',
                                          ' + RCCL all-reduce of the flat grad bucket' if world > 1 else '',
                                          '' if args.no_optimizer else ' + clip_grad_norm(1.0) + AdamW update (fused HIP)'),
                           'global_batch': B * world, 'parallelism': 'dp%d' % world,
@@ -377,6 +400,10 @@ def main():
                                 'backward' % (xchg.split, xchg.split)) if xchg is not None else 'one call behind the backward'
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(configs, T, Lq, Lc)
+            try:        # port-vs-reference ratio measured in the build container (tools/calibrate_cpu_baseline.py): the reference cannot travel
+                out['cpu_baseline']['calibration'] = json.load(open(os.path.join(ROOT, 'profiles', 'r04_cpu_calibration.json')))
+            except Exception:
+                out['cpu_baseline']['calibration'] = None
         sys.stdout.flush()
         if saved_stdout is not None:
             os.dup2(saved_stdout, 1)

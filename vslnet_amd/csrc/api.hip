@@ -90,6 +90,7 @@ struct vsl_handle_s {
     int64_t pack_floats = 0;
     std::vector<PackJob> jobs;
     PackJob* jobs_dev = nullptr;
+    int jobs_first = 0, jobs_query = 0;  // jobs_dev = [first: the video branch's opening kernels | query: the embedding stack | everything else]
     unsigned* loss_counter = nullptr;    // arrival counter of k_loss_fused (zero between calls)
     uint8_t* decay_dev = nullptr;        // per-element weight-decay flag of the flat bucket (vsl_adamw_step)
     float* opt_scratch = nullptr;        // OPT_BLOCKS partial sums of grads^2
@@ -437,7 +438,20 @@ struct Ctx {
     hipStream_t side(int k) const { return (h->multi_stream && h->side[k]) ? h->side[k] : main; }
     hipStream_t main = nullptr;
     // built-in profiler: a selected LAUNCH hands its name to vsl_launch_events, which puts timing events on the kernel's own packet
-    void pb(const char* name) { h->prof_name = (h->prof_on && (h->prof_sel == "*" || h->prof_sel == name)) ? name : nullptr; }
+    void pb(const char* name) {          // prof_sel: "*", one launch name, or a comma-separated list of names
+        bool hit = false;
+        if (h->prof_on) {
+            const std::string& sel = h->prof_sel;
+            const size_t n = strlen(name);
+            for (size_t p = 0; !hit && p <= sel.size();) {
+                size_t q = sel.find(',', p);
+                if (q == std::string::npos) q = sel.size();
+                hit = (q - p == 1 && sel[p] == '*') || (q - p == n && sel.compare(p, n, name) == 0);
+                p = q + 1;
+            }
+        }
+        h->prof_name = hit ? name : nullptr;
+    }
     void pe(const char*) { h->prof_name = nullptr; }
     // elements one sample owns in the tensor dropped at `site` (the masks are keyed by the row-major element index)
     uint32_t site_elems(int site) const {
@@ -574,10 +588,23 @@ void run_forward(Ctx& c) {
     const Plan& p = *c.p;
     const vsl_io& io = *c.io;
     const int B = p.B, T = p.T, Lq = p.Lq, R = B * T, Rq = B * Lq;
-    LAUNCH("pack", launch_pack(io.params, c.W(p.pack), c.h->jobs_dev, (int)c.h->jobs.size(), c.s));
+    const int nj = (int)c.h->jobs.size(), nj0 = c.h->jobs_first, nj1 = c.h->jobs_query;
+    hipStream_t sq = c.side(0), sp = c.side(1);
+    static const bool pack_split = !(getenv("VSL_PACK_SPLIT") && getenv("VSL_PACK_SPLIT")[0] == '0');
+    const bool split3 = pack_split && sq != c.main && sp != c.main;
+    if (split3) {
+        LAUNCH("pack", launch_pack(io.params, c.W(p.pack), c.h->jobs_dev, nj0, c.s));
+        c.order2(c.main, sq, sp);          // both side streams start behind the first pack (its stop event: no marker packet), i.e. behind the caller's earlier work
+        c.s = sq;
+        LAUNCH("pack", launch_pack(io.params, c.W(p.pack), c.h->jobs_dev + nj0, nj1, c.s));
+        c.s = sp;
+        LAUNCH("pack", launch_pack(io.params, c.W(p.pack), c.h->jobs_dev + nj0 + nj1, nj - nj0 - nj1, c.s));
+        c.s = c.main;
+    } else {
+        LAUNCH("pack", launch_pack(io.params, c.W(p.pack), c.h->jobs_dev, nj, c.s));
+    }
     // fork: the query branch (embedding + query encoder pass) runs beside the video branch
-    hipStream_t sq = c.side(0);
-    c.order(c.main, sq);
+    if (!split3) c.order(c.main, sq);
     const bool qlong = query_chain_is_longer(p, true);  // the longer branch keeps the main stream (join wait already satisfied)
     c.s = qlong ? sq : c.main;
     if (io.video_features_bf16)      // bf16 throughput mode
@@ -602,6 +629,7 @@ void run_forward(Ctx& c) {
     enc_fwd(c, P.fe, K.fe, p.qe, c.W(p.qf), io.q_mask, B, 1);
     c.s = c.main;
     c.order(sq, c.main);                   // join
+    if (split3) c.order(sp, c.main);       // the remaining packs (long done)
     LAUNCH("cq_score", launch_cq_score(c.W(p.ve.out), c.W(p.qe.out), io.q_mask, c.P(P.w4C), c.P(P.w4Q), c.P(P.w4mlu), c.W(p.S), c.W(p.Srow), B, T,
                     Lq, 0, c.drop(SITE_CQ_C), c.drop(SITE_CQ_Q), c.s));
     // M = S_col^T C is produced as per-tile partials (the backward's cqP1 arena is free until then) and summed by cq_out
@@ -1239,6 +1267,22 @@ int vsl_create(const vsl_config* cfg, vsl_handle* out) {
     if (hipMalloc(&h->loss_counter, sizeof(unsigned)) != hipSuccess || hipMemset(h->loss_counter, 0, sizeof(unsigned)) != hipSuccess) {
         delete h;
         return fail("hipMalloc of the loss counter failed");
+    }
+    {   // Three pack launches per forward (run_forward): what VisualProjection and the shared feature encoder's forward read goes first on the
+        // main stream, the embedding stack's operands on the query stream, everything else (CQ fusion, heads, predictor encoder, every
+        // data-gradient pack) on the weight-gradient stream, which is idle in the forward -- the step no longer opens with ONE 11 us launch
+        // that packs 2.7 MB before its first kernel may start.
+        const ModelPk& K = h->K;
+        auto in = [](int dst, std::initializer_list<int> set) { return std::find(set.begin(), set.end(), dst) != set.end(); };
+        auto cls = [&](const PackJob& j) {
+            const EncPk& f = K.fe;
+            if (in(j.dst, {K.va_f, K.va_f16, K.va_f3, f.pw_f[0], f.pw_f[1], f.pw_f[2], f.pw_f[3], f.qkv_f, f.o_f, f.pw_f3[0], f.pw_f3[1], f.pw_f3[2], f.pw_f3[3],
+                           f.qkv_f3, f.o_f3})) return 0;
+            if (in(j.dst, {K.emb_f, K.emb_f3, K.ccw_img})) return 1;
+            return 2;
+        };
+        std::stable_sort(h->jobs.begin(), h->jobs.end(), [&](const PackJob& a, const PackJob& b) { return cls(a) < cls(b); });
+        for (const PackJob& j : h->jobs) { h->jobs_first += cls(j) == 0; h->jobs_query += cls(j) == 1; }
     }
     if (hipMalloc(&h->jobs_dev, h->jobs.size() * sizeof(PackJob)) != hipSuccess ||
         hipMemcpy(h->jobs_dev, h->jobs.data(), h->jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice) != hipSuccess) {
