@@ -95,8 +95,6 @@ def dtype_line(args):
     if args.dtype != 'f32':
         return ('bf16 throughput mode (not the parity path): bf16 features in HBM; VisualProjection and every weight gradient as ONE bf16 product per '
                 'product (operands rounded to bf16, f32 accumulate); the other GEMMs bf16x6 / f32-input MFMA as in the f32 line; f32 activations')
-    if os.environ.get('VSL_F32_GEMM') == '1' and os.environ.get('VSL_WGRAD_F32') == '1':
-        return 'f32 (fp32-input MFMA everywhere: the round-2 kernels, A/B switch)'
     return ('f32 in / out and f32 accumulate everywhere; VisualProjection, the conv-block / q,k,v / embedding-linear GEMMs and every weight '
             'gradient as bf16x6 split MFMA (exact 3-way operand split, 6 products: fp32 grade), attention / CQAttention / heads / char-CNN as '
             'fp32-input MFMA')
@@ -374,7 +372,7 @@ def main():
             roof['vproj_features'] = ('%d resident batches = %.0f MiB of features, rotated: %s' %
                                       (nres, feat_mib, 'streamed from HBM (> 256 MiB Infinity Cache)' if feat_mib > 256 else 'Infinity-Cache resident'))
         # the split kernels reach fp32 grade with 6 bf16 products per product: the same launch against the dense bf16 peak
-        if work and dominant in ('wgrad', 'convblock_fwd', 'convblock_bwd', 'vproj_fwd') and os.environ.get('VSL_F32_GEMM') != '1':
+        if work and dominant in ('wgrad', 'convblock_fwd', 'convblock_bwd', 'vproj_fwd'):
             roof['bf16x6_frac_of_bf16_peak'] = round(6 * work[0] / k_s / PEAK_MFMA_BF16, 4)
         out = {'metric': '(video,query) pairs/sec fwd+bwd, Charades I3D T=128 D=1024', 'value': round(value, 1),
                'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,

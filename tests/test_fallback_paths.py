@@ -1,8 +1,11 @@
-"""The library keeps an A/B switch for the split-bf16 kernels of round 3 (VSL_F32_GEMM / VSL_WGRAD_F32 = 1: the fp32-input MFMA kernels of
-round 2) and a few shape-selected variants that can be forced on (VSL_WGRAD4=0: the LDS-free split weight gradient, which still serves
-the bf16-feature jobs, for every job).  The switches are read once per process, so the parity suite is re-run
-in a child process per setting.  (The superseded kernels of rounds 1-2 -- per-layer conv kernels, LDS-staged weight gradient, 16-sample
-LSTM workgroups -- are gone; baselines for A/B runs come from git revisions: tools/build_base.py.)"""
+"""The library keeps two switches that force a variant the shapes of the suite would not select: VSL_MULTI_STREAM=0 (every kernel on the
+caller's stream: the isolated-kernel profiling mode of tools/prof_serial.sh) and VSL_LSTM1=0 (the 4-sample MFMA-group LSTM that serves B > 256,
+at the suite's small batches).  They are read once per process, so the parity suite is re-run once in a child process with both set.
+(Round 4 removed the A/B switches of earlier rounds -- the fp32-input GEMM / weight-gradient kernels, the 8-wave attention block override, the
+LDS-free weight gradient for fp32 jobs: baselines for A/B runs come from git revisions, tools/build_base.py.  The variants that remain are all
+selected by SHAPE and covered by the shapes of the suite: k_attn_fwd + k_attn_out_fwd and k_attn_bwd_long for L > 256, the 8-wave attention
+block for 128 < L <= 256, k_wgrad3 for bfloat16 features, k_linear_fwd for embedding widths that are not multiples of 16, k_loss_a / b / c
+when the caller leaves the mask sum to the device.)"""
 import os
 import subprocess
 import sys
@@ -12,13 +15,10 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-F32_PATHS = dict(VSL_F32_GEMM='1', VSL_WGRAD_F32='1', VSL_STOP_EVENTS='0')
 
 
-@pytest.mark.parametrize('env', [F32_PATHS, dict(VSL_MULTI_STREAM='0', VSL_LSTM1='0', VSL_ATTN_WAVES='8', VSL_WGRAD4='0')],
-                         ids=['fp32-input-mfma-kernels', 'single-stream-and-forced-variants'])
-def test_parity_suite_on_the_previous_kernels(env):
-    e = dict(os.environ, **env)
+def test_parity_suite_single_stream_and_forced_lstm_groups():
+    e = dict(os.environ, VSL_MULTI_STREAM='0', VSL_LSTM1='0')
     r = subprocess.run([sys.executable, '-m', 'pytest', '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider',
                         'tests/test_hip_parity.py', 'tests/test_hip_rnn.py', 'tests/test_bf16_mode.py'], cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

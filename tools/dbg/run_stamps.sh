@@ -5,4 +5,3 @@ grep "wgrad4" gpurun_out/stamps.log | head -5
 unset VSLNET_HIP_LIB VSL_DEBUG_TIMING
 timeout 600 bash tools/prof_serial.sh > gpurun_out/r3f_serial.log 2>&1; grep "wgrad\|total kernel" gpurun_out/stats_serial.txt
 unset VSL_MULTI_STREAM
-for rep in 1 2; do for n in 0 1; do export VSL_WGRAD4=$n; echo -n "wgrad4=$n: "; timeout 300 python bench.py --steps 100 --warmup 10 --no-cpu-baseline 2>/dev/null | python -c "import json,sys;d=json.load(sys.stdin);print(d['value'],d['ms_per_step'])"; done; done 2>&1 | tee gpurun_out/ab.log

@@ -7,7 +7,7 @@
 #include <vector>
 #include <math.h>
 #include <string.h>
-namespace vsl { bool g_one_product = false; void vsl_launch_events(hipStream_t, hipEvent_t* a, hipEvent_t* b) { *a = nullptr; *b = nullptr; } }
+namespace vsl { void vsl_launch_events(hipStream_t, hipEvent_t* a, hipEvent_t* b) { *a = nullptr; *b = nullptr; } }
 using namespace vsl;
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 static double urand() { return (rand() + 0.5) / ((double)RAND_MAX + 1.0); }

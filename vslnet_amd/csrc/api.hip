@@ -369,10 +369,9 @@ void plan_encoder(Bump& al, EncWs& w, int Bn, int L, int H) {
 static thread_local vsl_handle_s* g_cur = nullptr;
 struct CallScope {
     explicit CallScope(vsl_handle_s* h) {
-        static const bool off = getenv("VSL_STOP_EVENTS") && getenv("VSL_STOP_EVENTS")[0] == '0';
         h->sync_used = 0; h->stop_used = 0; h->ev_n = 0;
         for (bool& d : h->ev_dirty) d = false;
-        h->stop_events = h->multi_stream && !off;
+        h->stop_events = h->multi_stream;
         g_cur = h;
     }
     ~CallScope() { g_cur = nullptr; }
@@ -390,6 +389,7 @@ struct Ctx {
     std::vector<SlabRec>* recs = nullptr;
     std::vector<WgradBatch> pend;       // weight-gradient batches waiting for ONE ordering point (wgrad_async / wgrad_flush)
     bool defer_w = false;
+    bool one_product = false;           // vsl_io.arithmetic == 1 for this call: handed to the launchers that have a one-product form
     const float* P(int off) const { return io->params + off; }
     const float* PK(int off) const { return ws + p->pack + off; }
     float* W(int64_t off) const { return ws + off; }
@@ -494,7 +494,7 @@ void wgrad_async(Ctx& c, hipStream_t sw, const WgradBatch& wb) {
     hipStream_t keep = c.s;
     c.order(keep, sw);
     c.s = sw;
-    LAUNCH("wgrad", launch_wgrad(wb, c.s));
+    LAUNCH("wgrad", launch_wgrad(wb, c.s, c.one_product));
     c.s = keep;
 }
 void wgrad_flush(Ctx& c, hipStream_t sw) {
@@ -502,7 +502,7 @@ void wgrad_flush(Ctx& c, hipStream_t sw) {
     hipStream_t keep = c.s;
     c.order(keep, sw);
     c.s = sw;
-    for (const WgradBatch& wb : c.pend) LAUNCH("wgrad", launch_wgrad(wb, c.s));
+    for (const WgradBatch& wb : c.pend) LAUNCH("wgrad", launch_wgrad(wb, c.s, c.one_product));
     c.s = keep;
     c.pend.clear();
 }
@@ -513,11 +513,7 @@ bool query_chain_is_longer(const Plan& p, bool forward) {
     // conv block 25 + attention 11) are about even at the headline shape; the main stream keeps the video branch (swap: +0.6 %).
     // Backward: since the split-bf16 kernels of round 3 the QUERY side ends last (cq_bwd_d .. embed_bwd: 147 us of isolated kernels against
     // 133 for the video side), so it owns the main stream and the final join finds the video stream's event long signalled: 0.934-0.938 ->
-    // 0.930 ms with optimizer (profiles/r03_notes.md).  VSL_SWAP_FWD / VSL_SWAP_BWD = 0 / 1 override for A/B runs.
-    static const char* ef = getenv("VSL_SWAP_FWD");
-    static const char* eb = getenv("VSL_SWAP_BWD");
-    const char* e = forward ? ef : eb;
-    if (e) return e[0] == '1';
+    // 0.930 ms with optimizer (profiles/r03_notes.md).
     return !forward && p.T <= 128;          // longer videos: the video side's attention backward grows with T^2 and ends last again
 }
 
@@ -541,10 +537,8 @@ void enc_fwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float*
             }
             a.qf = QkvFuse{c.P(P.ln1g), c.P(P.ln1b), c.PK(K.qkv_f), c.P(P.qb), c.P(P.kb), c.P(P.vb), c.W(w.h1), c.W(w.q), c.W(w.k), c.W(w.v),
                            c.drop(app * 16 + 4)};
-            if (split_gemm_enabled()) {
-                for (int i = 0; i < 4; ++i) a.W3[i] = reinterpret_cast<const uint16_t*>(c.PK(K.pw_f3[i]));
-                a.Wqkv3 = reinterpret_cast<const uint16_t*>(c.PK(K.qkv_f3));
-            }
+            for (int i = 0; i < 4; ++i) a.W3[i] = reinterpret_cast<const uint16_t*>(c.PK(K.pw_f3[i]));
+            a.Wqkv3 = reinterpret_cast<const uint16_t*>(c.PK(K.qkv_f3));
             a.R = R; a.L = L;
         }
         LAUNCH("convblock_fwd", launch_convblock_fwd(a, c.s));
@@ -576,10 +570,7 @@ std::vector<int> lstm_chunks(int T, int chunk) {
     for (int i = 0; i < n; ++i) out.push_back((T * (i + 1)) / n - (T * i) / n);
     return out;
 }
-int lstm_chunk_len() {
-    static const int v = getenv("VSL_LSTM_CHUNK") ? atoi(getenv("VSL_LSTM_CHUNK")) : 32;
-    return v;
-}
+int lstm_chunk_len() { return 32; }
 
 void run_forward(Ctx& c) {
     const vsl_config& cf = c.h->cfg;
@@ -590,8 +581,7 @@ void run_forward(Ctx& c) {
     const int B = p.B, T = p.T, Lq = p.Lq, R = B * T, Rq = B * Lq;
     const int nj = (int)c.h->jobs.size(), nj0 = c.h->jobs_first, nj1 = c.h->jobs_query;
     hipStream_t sq = c.side(0), sp = c.side(1);
-    static const bool pack_split = !(getenv("VSL_PACK_SPLIT") && getenv("VSL_PACK_SPLIT")[0] == '0');
-    const bool split3 = pack_split && sq != c.main && sp != c.main;
+    const bool split3 = sq != c.main && sp != c.main;
     if (split3) {
         LAUNCH("pack", launch_pack(io.params, c.W(p.pack), c.h->jobs_dev, nj0, c.s));
         c.order2(c.main, sq, sp);          // both side streams start behind the first pack (its stop event: no marker packet), i.e. behind the caller's earlier work
@@ -611,21 +601,18 @@ void run_forward(Ctx& c) {
         LAUNCH("vproj_fwd", launch_vproj_fwd_bf16(io.video_features_bf16, reinterpret_cast<const uint16_t*>(c.PK(K.va_f16)), c.P(P.va_b), c.W(p.vf), R,
                                                   cf.video_feature_dim, c.drop(SITE_VIS), c.s));
     else
-        if (split_gemm_enabled())
         LAUNCH("vproj_fwd", launch_vproj_fwd3(io.video_features, reinterpret_cast<const uint16_t*>(c.PK(K.va_f3)), c.P(P.va_b), c.W(p.vf), R, cf.video_feature_dim,
-                                              c.drop(SITE_VIS), c.s));
-    else
-        LAUNCH("vproj_fwd", launch_vproj_fwd(io.video_features, c.PK(K.va_f), c.P(P.va_b), c.W(p.vf), R, cf.video_feature_dim, c.drop(SITE_VIS), c.s));
+                                              c.drop(SITE_VIS), c.s, c.one_product));
     enc_fwd(c, P.fe, K.fe, p.ve, c.W(p.vf), io.v_mask, B, 0);
     c.s = qlong ? c.main : sq;
     const bool wt = cf.word_table != 0;       // trainable word table: its rows 0, 1, 2.. are pad, unk, the vocabulary
     LAUNCH("embed_fwd", launch_embed_fwd(io.word_ids, io.char_ids, wt ? c.P(P.unk) : io.pad_vec, c.P(P.unk) + (wt ? cf.word_dim : 0), wt ? c.P(P.unk) + 2 * cf.word_dim : io.glove_vec, c.P(P.char_tab), char_ptrs(c), c.PK(K.ccw_img), c.W(p.E),
                      reinterpret_cast<int8_t*>(c.W(p.argpos)), Rq, p.Lc, cf.word_dim, cf.char_dim, c.drop(SITE_WORD),
                      c.drop(SITE_CHAR), c.s));
-    if (split_gemm_enabled() && (cf.word_dim + 100) % 16 == 0)
+    if ((cf.word_dim + 100) % 16 == 0)
         LAUNCH("linear_fwd", launch_linear_fwd3(c.W(p.E), reinterpret_cast<const uint16_t*>(c.PK(K.emb_f3)), c.P(P.emb_b), c.W(p.qf), Rq, cf.word_dim + 100, c.s));
-    else
-    LAUNCH("linear_fwd", launch_linear_fwd(c.W(p.E), c.PK(K.emb_f), c.P(P.emb_b), c.W(p.qf), Rq, cf.word_dim + 100, c.s));
+    else          // a width the 16-wide K steps of the split kernel do not tile: the fp32-input MFMA kernel (K streamed in chunks)
+        LAUNCH("linear_fwd", launch_linear_fwd(c.W(p.E), c.PK(K.emb_f), c.P(P.emb_b), c.W(p.qf), Rq, cf.word_dim + 100, c.s));
     enc_fwd(c, P.fe, K.fe, p.qe, c.W(p.qf), io.q_mask, B, 1);
     c.s = c.main;
     c.order(sq, c.main);                   // join
@@ -644,7 +631,7 @@ void run_forward(Ctx& c) {
         // The recurrence is latency bound (one 16-sample group per CU, 6.2 us per step), so the two LSTMs are pipelined in
         // TIME CHUNKS: while the start LSTM runs chunk k + 1 on the main stream, the side stream projects its chunk k
         // (x W_ih^T of the end LSTM, a row-mapped GEMM) and runs the end LSTM over it.  A chunk launch resumes from the state
-        // the previous one saved for the backward (h_{t-1}, c_{t-1}).  VSL_LSTM_CHUNK=<steps> (default 32), 0 = no pipelining.
+        // the previous one saved for the backward (h_{t-1}, c_{t-1}).  Chunks of 32 steps (lstm_chunk_len).
         const int chunk_env = lstm_chunk_len();
         auto lstm = [&](int l, int t0, int t1) {
             const LstmWs& w = p.lstm[l];
@@ -709,7 +696,7 @@ void enc_bwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float*
     float* p_ln1b = c.slab(P.ln1b, D, ntiles);
     LAUNCH("qkv_bwd", launch_qkv_bwd(c.W(t.dq), c.W(t.dk), c.W(t.dv), c.W(w.y[3]), c.W(t.dr), c.P(P.ln1g), c.PK(K.qkv_t),
                           c.W(t.ga), p_ln1g, p_ln1b, R, c.drop(app * 16 + 4), c.s, attn_bwd_dq_slabs(L),
-                          split_gemm_enabled() ? reinterpret_cast<const uint16_t*>(c.PK(K.qkv_t3)) : nullptr));
+                          reinterpret_cast<const uint16_t*>(c.PK(K.qkv_t3))));
     {   // out_layer + fused q/k/v weight gradients: every input exists now -> side stream, beside the conv chain
         WgradBatch wb;
         memset(&wb, 0, sizeof wb);
@@ -754,7 +741,7 @@ void enc_bwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float*
                 a.relu_mask[i] = reinterpret_cast<const uint32_t*>(c.W(w.mask[i])); a.WTpack[i] = c.PK(K.pw_t[i]);
                 a.ln_g[i] = c.P(P.lng[i]); a.ln_b[i] = c.P(P.lnb[i]); a.dw_w[i] = c.P(P.dw[i]);
                 a.dp[i] = c.drop(app * 16 + i); a.gz[i] = c.W(t.gz[i]);
-                if (split_gemm_enabled()) a.WT3[i] = reinterpret_cast<const uint16_t*>(c.PK(K.pw_t3[i]));
+                a.WT3[i] = reinterpret_cast<const uint16_t*>(c.PK(K.pw_t3[i]));
             }
         }
         LAUNCH("convblock_bwd", launch_convblock_bwd(a, c.s));
@@ -790,9 +777,7 @@ void run_backward(Ctx& c) {
     // reduction); sq = the query-side chain (query encoder pass + embedding stack) once CQAttention's backward is done
     hipStream_t sw = c.dry ? nullptr : c.side(1), sq = c.dry ? nullptr : c.side(0);
     auto on_stream = [&](hipStream_t st, auto&& fn) { hipStream_t keep = c.s; c.order(keep, st); c.s = st; fn(); c.s = keep; };
-    static const int batch_mode = getenv("VSL_WGRAD_BATCH") ? atoi(getenv("VSL_WGRAD_BATCH")) : 1;
-    const bool batch_w = batch_mode != 0;
-    c.defer_w = batch_w && !c.dry && cf.predictor == 1;
+    c.defer_w = !c.dry && cf.predictor == 1;
     // ---- span heads
     HeadBwdArgs hs, he;
     memset(&hs, 0, sizeof hs);
@@ -840,12 +825,9 @@ void run_backward(Ctx& c) {
         auto dx = [&](int l, int t0, int t1) {
             const LstmWs& w = p.lstm[l];
             const bool all = t0 == 0 && t1 == T;
-            if (split_gemm_enabled())
-                LAUNCH("lstm_dx", launch_vproj_fwd3(c.W(w.dG), reinterpret_cast<const uint16_t*>(c.PK(K.l_t3[l])), c.PK(K.zero128), c.W(l ? p.g_s1 : p.g_gated),
-                                                   all ? R : B * (t1 - t0), 4 * D, Drop{0u, 0u, 1.f}, c.s, all ? 0 : t1 - t0, T, t0));
-            else
-            LAUNCH("lstm_dx", launch_vproj_fwd(c.W(w.dG), c.PK(K.l_t[l]), c.PK(K.zero128), c.W(l ? p.g_s1 : p.g_gated), all ? R : B * (t1 - t0),
-                                              4 * D, Drop{0u, 0u, 1.f}, c.s, all ? 0 : t1 - t0, T, t0));
+            // (always the six-product form: vsl_io.arithmetic = 1 covers VisualProjection and the weight gradients only -- ADVICE r3)
+            LAUNCH("lstm_dx", launch_vproj_fwd3(c.W(w.dG), reinterpret_cast<const uint16_t*>(c.PK(K.l_t3[l])), c.PK(K.zero128), c.W(l ? p.g_s1 : p.g_gated),
+                                               all ? R : B * (t1 - t0), 4 * D, Drop{0u, 0u, 1.f}, c.s, false, all ? 0 : t1 - t0, T, t0));
         };
         const bool piped = !c.dry && chunk_env > 0 && chunk_env < T && sq != c.s;
         if (!c.dry) {
@@ -894,12 +876,12 @@ void run_backward(Ctx& c) {
                     wb.j[wb.n++] = j;
                 }
             }
-            on_stream(sw, [&] { LAUNCH("wgrad", launch_wgrad(wb, c.s)); });
+            on_stream(sw, [&] { LAUNCH("wgrad", launch_wgrad(wb, c.s, c.one_product)); });
         }
     } else {
     // ---- predictor encoder, second pass (input = output of the first pass), then first pass
     enc_bwd(c, P.pe, K.pe, p.p2, c.dry ? nullptr : c.W(p.dfeat_e), nullptr, p.g_s1, c.dry ? nullptr : io->v_mask, B, 3, sw);
-    if (batch_mode != 2) wgrad_flush(c, sw);   // span heads + pass-2 weight gradients: one ordering point
+    wgrad_flush(c, sw);   // span heads + pass-2 weight gradients: one ordering point
     // grad wrt the first pass' output = (input grad of the second pass) + (LayerNorm path of the start head)
     enc_bwd(c, P.pe, K.pe, p.p1, c.dry ? nullptr : c.W(p.g_s1), c.dry ? nullptr : c.W(p.dfeat_s), p.g_gated,
             c.dry ? nullptr : io->v_mask, B, 2, sw);
@@ -979,7 +961,7 @@ void run_backward(Ctx& c) {
         j.out = c.slab(P.va_w, D * cf.video_feature_dim, nchunk);
         j.out_bias[0] = c.slab(P.va_b, D, nchunk);
         wb.j[wb.n++] = j;
-        LAUNCH("wgrad", launch_wgrad(wb, c.s));
+        LAUNCH("wgrad", launch_wgrad(wb, c.s, c.one_product));
     }
     // ---- query pass, then the embedding stack (all on the other stream)
     c.s = qlong ? main_s : sq;
@@ -1002,14 +984,11 @@ void run_backward(Ctx& c) {
         hipStream_t qs = c.s, vs = qlong ? sq : main_s;
         c.order(qs, vs);
         c.s = vs;
-        LAUNCH("wgrad", launch_wgrad(wb_tail, c.s));
-        if (!fits) LAUNCH("wgrad", launch_wgrad(pw_query, c.s));
+        LAUNCH("wgrad", launch_wgrad(wb_tail, c.s, c.one_product));
+        if (!fits) LAUNCH("wgrad", launch_wgrad(pw_query, c.s, c.one_product));
         c.s = qs;
     }
-    if (split_gemm_enabled())
-        LAUNCH("linear_bwd_data", launch_linear_bwd_data3(c.W(p.dqf), reinterpret_cast<const uint16_t*>(c.PK(K.emb_t3)), c.W(p.dE), Rq, EW, K.emb_t3_cols, c.s));
-    else
-    LAUNCH("linear_bwd_data", launch_linear_bwd_data(c.W(p.dqf), c.PK(K.emb_t), c.W(p.dE), Rq, EW, c.s));
+    LAUNCH("linear_bwd_data", launch_linear_bwd_data3(c.W(p.dqf), reinterpret_cast<const uint16_t*>(c.PK(K.emb_t3)), c.W(p.dE), Rq, EW, K.emb_t3_cols, c.s));
     {
         const int ebc = embed_bwd_chunk(Rq, p.Lc, cf.char_dim), nce = (Rq + ebc - 1) / ebc;
         const int wtot = cf.char_dim * 300;
@@ -1186,14 +1165,12 @@ int check_io(vsl_handle_s* h, const vsl_io* io) {
     if (io->video_features_bf16 && (h->cfg.video_feature_dim % 8 != 0))
         return fail("bf16 features need video_feature_dim %% 8 == 0 (got %d)", h->cfg.video_feature_dim);
     if (io->arithmetic != 0 && io->arithmetic != 1) return fail("vsl_io.arithmetic must be 0 (fp32 grade) or 1 (bf16 arithmetic), got %d", io->arithmetic);
-    vsl::g_one_product = io->arithmetic == 1;
     return 0;
 }
 
 }  // namespace
 
 namespace vsl {
-bool g_one_product = false;
 void vsl_launch_events(hipStream_t s, hipEvent_t* start, hipEvent_t* stop) {
     vsl_handle_s* h = g_cur;
     if (!h || !(h->stop_events || h->prof_name)) return;
@@ -1246,21 +1223,21 @@ int vsl_create(const vsl_config* cfg, vsl_handle* out) {
     build_params(h);
     build_packs(h);
     {
-        // Drop the pack jobs whose operand no kernel of this process reads: the fp32 packs of the GEMMs that run as split products (or the
-        // split packs under VSL_F32_GEMM=1), and the split packs of the attention output projection (it stays on the fp32-input MFMA).
+        // Drop the pack jobs whose operand no kernel reads: the fp32 packs of the GEMMs that run as split products and the split packs of the
+        // attention output projection (it stays on the fp32-input MFMA).
         // The regions stay in the pack buffer (offsets are fixed); k_pack just does a third less work every step.
         const ModelPk& K = h->K;
-        const bool split = split_gemm_enabled();
         std::vector<int> dead;
         auto enc = [&](const EncPk& e) {
             dead.push_back(e.o_f3); dead.push_back(e.o_t3);
-            for (int i = 0; i < 4; ++i) { dead.push_back(split ? e.pw_f[i] : e.pw_f3[i]); dead.push_back(split ? e.pw_t[i] : e.pw_t3[i]); }
-            dead.push_back(split ? e.qkv_f : e.qkv_f3); dead.push_back(split ? e.qkv_t : e.qkv_t3);
+            for (int i = 0; i < 4; ++i) { dead.push_back(e.pw_f[i]); dead.push_back(e.pw_t[i]); }
+            dead.push_back(e.qkv_f); dead.push_back(e.qkv_t);
         };
         enc(K.fe);
         if (cfg->predictor != 0) enc(K.pe);
-        if (split) { dead.push_back(K.va_f); dead.push_back(K.emb_t); if ((cfg->word_dim + 100) % 16 == 0) dead.push_back(K.emb_f); }
-        else { dead.push_back(K.va_f3); dead.push_back(K.emb_f3); dead.push_back(K.emb_t3); }
+        dead.push_back(K.va_f); dead.push_back(K.emb_t);
+        if ((cfg->word_dim + 100) % 16 == 0) dead.push_back(K.emb_f);
+        if (cfg->predictor == 0) for (int l = 0; l < 2; ++l) dead.push_back(K.l_t[l]);        // the rnn head's dx GEMM reads the split pack l_t3
         h->jobs.erase(std::remove_if(h->jobs.begin(), h->jobs.end(), [&](const PackJob& j) {
                           return std::find(dead.begin(), dead.end(), j.dst) != dead.end(); }), h->jobs.end());
     }
@@ -1294,14 +1271,11 @@ int vsl_create(const vsl_config* cfg, vsl_handle* out) {
         h->multi_stream = !(e && e[0] == '0');
         if (h->multi_stream)
             for (int k = 0; k < 2; ++k) {
-                // side(1) carries the weight gradients: nothing waits for them until the final reduction, so it may run at the
-                // lowest priority the device offers (VSL_WGRAD_PRIO=0 keeps the default) and leave CUs to the dependent chain
+                // side(1) carries the weight gradients: nothing waits for them until the final reduction, so it runs at the
+                // lowest priority the device offers and leaves CUs to the dependent chain
                 int lo = 0, hi = 0;
                 (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-                static const bool low_prio = !(getenv("VSL_WGRAD_PRIO") && getenv("VSL_WGRAD_PRIO")[0] == '0');
-                static const bool hi_query = getenv("VSL_QUERY_PRIO") && getenv("VSL_QUERY_PRIO")[0] == '1';
-                static const bool lo_query = getenv("VSL_QUERY_PRIO") && getenv("VSL_QUERY_PRIO")[0] == '-';
-                const int prio = (k == 1 && low_prio) ? lo : (k == 0 && hi_query) ? hi : (k == 0 && lo_query) ? lo : 0;
+                const int prio = k == 1 ? lo : 0;       // (the query stream's priority makes no difference either way: profiles/r03_notes.md)
                 if (hipStreamCreateWithPriority(&h->side[k], hipStreamNonBlocking, prio) != hipSuccess) { h->side[k] = nullptr; (void)hipGetLastError(); }
             }
     }
@@ -1392,6 +1366,7 @@ int vsl_forward(vsl_handle h, const vsl_io* io, void* hip_stream) {
     if (int rc = get_plan(h, io->B, io->T, io->Lq, io->Lc, &p)) return rc;
     Ctx c{h, p, io, (hipStream_t)hip_stream, false, io->workspace};
     c.main = c.s;
+    c.one_product = io->arithmetic == 1;
     CallScope scope(h);
     run_forward(c);
     HIP_OK(hipGetLastError());
@@ -1419,6 +1394,7 @@ int vsl_backward(vsl_handle h, const vsl_io* io, void* hip_stream) {
     if (int rc = get_plan(h, io->B, io->T, io->Lq, io->Lc, &p)) return rc;
     Ctx c{h, p, io, (hipStream_t)hip_stream, false, io->workspace};
     c.main = c.s;
+    c.one_product = io->arithmetic == 1;
     CallScope scope(h);
     run_backward(c);
     HIP_OK(hipGetLastError());

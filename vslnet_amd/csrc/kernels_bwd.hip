@@ -332,15 +332,12 @@ __global__ __launch_bounds__(256) void k_head_bwd(HeadBwdArgs a0, HeadBwdArgs a1
 }
 void launch_head_bwd(const HeadBwdArgs& a0, const HeadBwdArgs& a1, int R, hipStream_t s) {
     {
-        static size_t lds_sp = 0;
-        const size_t shm_sp = spread_lds(0, 50816, (R + TILE_M - 1) / TILE_M);
-        ensure_dynamic_lds((const void*)k_head_bwd, shm_sp + 50816, lds_sp, "k_head_bwd");
+        const size_t shm_sp = 0;
         VSL_LAUNCH(k_head_bwd, dim3((R + TILE_M - 1) / TILE_M, 2), dim3(256), shm_sp, s, a0, a1, R);
     }
 }
 
-// Weight gradients: kernels_wgrad.hip (k_wgrad3 on the bf16 matrix cores; k_wgrad2, the fp32-input MFMA kernel of round 2, with VSL_WGRAD_F32=1)
-void launch_wgrad(const WgradBatch& wb, hipStream_t s) { launch_wgrad2(wb, s); }
+// Weight gradients: kernels_wgrad.hip
 
 // =========================================================================================================
 // MHA block backward (a8, :167-190)
@@ -409,9 +406,7 @@ __global__ __launch_bounds__(256) void k_attn_out_bwd(const float* __restrict__ 
 void launch_attn_out_bwd(const float* dy, const float* dy2, const float* r, const float* ln_g, const float* WTpack, float* g_o,
                          float* dr, float* p_lng, float* p_lnb, int R, Drop d4, Drop d5, hipStream_t s) {
     {
-        static size_t lds_sp = 0;
-        const size_t shm_sp = spread_lds(0, 33792, (R + TILE_M - 1) / TILE_M);
-        ensure_dynamic_lds((const void*)k_attn_out_bwd, shm_sp + 33792, lds_sp, "k_attn_out_bwd");
+        const size_t shm_sp = 0;
         VSL_LAUNCH(k_attn_out_bwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm_sp, s, dy, dy2, r, ln_g, WTpack, g_o, dr, p_lng,
                        p_lnb, R, d4, d5);
     }
@@ -760,9 +755,7 @@ void launch_attn_bwd(const float* Q, const float* K, const float* V, const float
                      const float* mask, float* dQ, float* dK, float* dV, int B, int L, int H, int b_off, Drop d2,
                      Drop d3, hipStream_t s) {
     const int Lp = (L + 15) & ~15;
-    static const bool fused_ok = !(getenv("VSL_ATTN_BWD_FUSED") && getenv("VSL_ATTN_BWD_FUSED")[0] == '0');
-    static const int fused_min = getenv("VSL_ATTN_FUSED_MIN") ? atoi(getenv("VSL_ATTN_FUSED_MIN")) : 0;
-    if (Lp <= 256 && Lp > fused_min && fused_ok) {
+    if (Lp <= 256) {
         static size_t ok128 = 0, ok256 = 0;
         if (Lp <= 128) {
             ensure_dynamic_lds((const void*)k_attn_bwd_fused<128>, ab_lds<128>(), ok128, "k_attn_bwd_fused<128>");
@@ -886,9 +879,7 @@ void launch_cqcat_bwd(const float* dg0, const float* dg1, const float* dg2, cons
                       const float* hscore, const float* wh, const float* W1Tpack, float* df2, float* df1, float* p_wh,
                       float* p_bh, int R, hipStream_t s) {
     {
-        static size_t lds_sp = 0;
-        const size_t shm_sp = spread_lds(0, 33920, (R + TILE_M - 1) / TILE_M);
-        ensure_dynamic_lds((const void*)k_cqcat_bwd, shm_sp + 33920, lds_sp, "k_cqcat_bwd");
+        const size_t shm_sp = 0;
         VSL_LAUNCH(k_cqcat_bwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm_sp, s, dg0, dg1, dg2, dh_loss, f2, hscore, wh,
                        W1Tpack, df2, df1, p_wh, p_bh, R);
     }

@@ -57,7 +57,6 @@ static void edbg_report2(const char* name, int i0, int i1, hipStream_t s, int& l
 
 constexpr int CB_T = 512;                       // threads per workgroup (8 waves, 2 per SIMD)
 constexpr int CB_HALO = 4 * HALO;               // 12 rows each side
-constexpr int CB_NW = TILE_M + 2 * CB_HALO;     // 56-row window
 
 // ---------------------------------------------------------------------------------------------------------
 // 16x16x4 fp32 MFMA GEMM on LDS row blocks.  Operand lane maps (lane = 16 g + i):
@@ -260,23 +259,20 @@ constexpr int CB_PS = 384;                      // per-layer small parameters in
 // FULL: R and L are multiples of the 32-row tile (every BASELINE shape): every tile is whole and lies inside one sample, so the boundary
 // flags below are compile-time constants and the per-row store / tap predicates disappear (12 % of the kernel's instructions were
 // v_cmp / v_cndmask / exec-mask branches).
-// SPLIT: the five GEMMs on the bf16 matrix cores at fp32 grade (gemm16s): the depthwise output / LN1 output is split into three bf16 planes
+// The five GEMMs run on the bf16 matrix cores at fp32 grade (gemm16s): the depthwise output / LN1 output is split into three bf16 planes
 // while it is stored (LDS +18 KB for the row tiles), the weight slices come from the split packs.
-template <int SH, bool FULL, bool SPLIT>
+template <int SH, bool FULL>
 __global__ __launch_bounds__(CB_T, 2) void k_convblock_fwd(CbFwdArgs a) {
     // sample tiles: 3 zero rows above and below the window in the LN / depthwise buffer stand for the taps that leave it
     constexpr int HL = 4 * SH, NW = TILE_M + 2 * HL, VOFF = SH ? 0 : HALO, VUR = SH ? NW + 12 : NW + 2 * HALO;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Xs = smem;                       // [56][LDP] residual stream
     float* VU = Xs + NW * LDP + VOFF * LDP; // (pointer to window row 0; sample tiles: rows -3 .. -1 and 32 .. 34 are the zero pad)           // [68][LDP] LN(x), then depthwise output = GEMM A operand (rows indexed by window row)
-    // depthwise output = GEMM A operand.  Row tiles: its own buffer, so no barrier between the window reads and these writes (104 KB; one
-    // workgroup per CU either way).  Sample tiles: in place in VU behind a barrier -- 45 KB, so a query-pass workgroup still fits beside a
-    // video-pass one (the two passes run concurrently on two streams).
-    float* Us = SH ? Xs + (NW + VUR) * LDP : VU;
-    // SPLIT: three bf16 planes [NW][CB_LDB] of the GEMM A operand (window rows) instead of the fp32 Us
+    // depthwise output = GEMM A operand: three bf16 planes [NW][CB_LDB] (window rows) in their own buffer, so no barrier between the window reads
+    // and these writes
     uint16_t* Ub = reinterpret_cast<uint16_t*>(Xs + (NW + VUR) * LDP);
     constexpr int UPS = NW * CB_LDB;                     // elements between planes
-    float* Ps = SPLIT ? Xs + (NW + VUR) * LDP + 3 * UPS / 2 : Xs + (NW + VUR + (SH ? NW : 0)) * LDP;   // [4][CB_PS] per-layer small parameters | ln1_g | ln1_b | bq | bk | bv
+    float* Ps = Xs + (NW + VUR) * LDP + 3 * UPS / 2;   // [4][CB_PS] per-layer small parameters | ln1_g | ln1_b | bq | bk | bv
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int R = a.R, L = a.L;
     const int r0 = SH ? blockIdx.x * TILE_M : blockIdx.x * L, rw0 = r0 - HL;      // global row of window row 0
@@ -322,10 +318,8 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_fwd(CbFwdArgs a) {
         *reinterpret_cast<float4*>(&VU[(pr < HALO ? pr - HALO : NW + pr - HALO) * LDP + c]) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     // first weight slice and depthwise taps: requested once the window registers are free (first used after LayerNorm 0)
-    BF16 bfA[1], bfB[1];
     B3 b3A, b3B;
-    if (SPLIT) b3_load(b3A, a.W3[0], D, D, 16 * w);
-    else bf16_load(bfA[0], a.Wpack[0], D, 16 * w);
+    b3_load(b3A, a.W3[0], D, D, 16 * w);
     float wkc[DWK];                                              // depthwise taps of this thread's channel, fetched a layer ahead
 #pragma unroll
     for (int k = 0; k < DWK; ++k) wkc[k] = a.dw_w[0][(tid & 127) * DWK + k];
@@ -383,17 +377,15 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_fwd(CbFwdArgs a) {
                     t = t + 1 == L ? 0 : t + 1;
                 }
             }
-            if (!SH && !SPLIT) __syncthreads();                  // every window is in registers: the buffer turns into the GEMM operand
             float* ug = a.u[l] + (ptrdiff_t)(rw0 + os) * D + c;
 #pragma unroll
             for (int i = 0; i < QS; ++i) {
                 if (os + i < o0 + n) {                           // wave-uniform
-                    if (!SPLIT) Us[(os + i) * LDP + c] = uo[i];
                     const int wr = os + i;
                     if (wr >= HL && wr < HL + TILE_M && row_ok(wr)) ug[(ptrdiff_t)i * D] = uo[i];   // saved: A operand of the weight gradient
                 }
             }
-            if (SPLIT) {                                         // GEMM operand: three bf16 planes, two channels of a row per dword
+            {                                                    // GEMM operand: three bf16 planes, two channels of a row per dword
 #pragma unroll
                 for (int i = 0; i < QS; i += 2)
                     split_store_pair(Ub, UPS, os + i, c, uo[i], i + 1 < QS ? uo[i + 1] : 0.f, os + i < o0 + n, i + 1 < QS && os + i + 1 < o0 + n);
@@ -405,8 +397,7 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_fwd(CbFwdArgs a) {
         f32x4 acc[1][NRB];
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) acc[0][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (SPLIT) gemm16s<NRB>(Ub + o0 * CB_LDB, UPS, cur, acc);
-        else gemm16<NRB, 1>(Us + o0 * LDP, LDP, cur, acc);
+        gemm16s<NRB>(Ub + o0 * CB_LDB, UPS, cur, acc);
         __builtin_amdgcn_sched_barrier(0);
         prefetch();                                              // weight slice of the next stage: most of a layer ahead of its use
         if (l < 3) {
@@ -466,23 +457,16 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_fwd(CbFwdArgs a) {
                 *reinterpret_cast<float4*>(a.y[l] + (size_t)(r0 + rr) * D + c) = *reinterpret_cast<const float4*>(&Xs[(HL + rr) * LDP + c]);
         }
     };
-    if constexpr (SPLIT) {
-        layer(std::integral_constant<int, 0>(), b3A, [&] { b3_load(b3B, a.W3[1], D, D, 16 * w); });
-        layer(std::integral_constant<int, 1>(), b3B, [&] { b3_load(b3A, a.W3[2], D, D, 16 * w); });
-        layer(std::integral_constant<int, 2>(), b3A, [&] { b3_load(b3B, a.W3[3], D, D, 16 * w); });
-        layer(std::integral_constant<int, 3>(), b3B, [&] { b3_load(b3A, a.Wqkv3, D, 3 * D, 16 * w); });
-    } else {
-    layer(std::integral_constant<int, 0>(), bfA, [&] { bf16_load(bfB[0], a.Wpack[1], D, 16 * w); });
+    layer(std::integral_constant<int, 0>(), b3A, [&] { b3_load(b3B, a.W3[1], D, D, 16 * w); });
     ESTAMP(2);
-    layer(std::integral_constant<int, 1>(), bfB, [&] { bf16_load(bfA[0], a.Wpack[2], D, 16 * w); });
+    layer(std::integral_constant<int, 1>(), b3B, [&] { b3_load(b3A, a.W3[2], D, D, 16 * w); });
     ESTAMP(3);
-    layer(std::integral_constant<int, 2>(), bfA, [&] { bf16_load(bfB[0], a.Wpack[3], D, 16 * w); });
+    layer(std::integral_constant<int, 2>(), b3A, [&] { b3_load(b3B, a.W3[3], D, D, 16 * w); });
     ESTAMP(4);
-    layer(std::integral_constant<int, 3>(), bfB, [&] { bf16_load(bfA[0], a.qf.Wpack, 3 * D, 16 * w); });
-    }
+    layer(std::integral_constant<int, 3>(), b3B, [&] { b3_load(b3A, a.Wqkv3, D, 3 * D, 16 * w); });
     ESTAMP(5);
     // ---- a8, first half (:168-173) on the owner rows: h1 = drop(LN1(y3)) ; [q | k | v] = h1 W^T + b  (wave w = head w)
-    if constexpr (SPLIT) {
+    {
         const float* Pq = Ps + 4 * CB_PS;
         // LN1 output: three bf16 planes in the (now free) GEMM operand buffer, rows 0..31 ; h1 goes to memory straight from the registers
         const int gn = FULL ? TILE_M : (SH ? min(TILE_M, R - r0) : L);
@@ -508,65 +492,26 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_fwd(CbFwdArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         proj(b3B, a.qf.k, 1);
         proj(b3A, a.qf.v, 2);
-    } else
-    {
-        const float* Pq = Ps + 4 * CB_PS;
-        ln_rows512(Xs + HL * LDP, VU, TILE_M, Pq, Pq + 128, a.qf.d1, r0);
-        bf16_load(bfB[0], a.qf.Wpack, 3 * D, D + 16 * w);
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-        if (a.qf.h1) {
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int e = tid + q * CB_T;
-                const int rr = e >> 5, c = (e & 31) * 4;
-                if (row_ok(HL + rr))
-                    *reinterpret_cast<float4*>(a.qf.h1 + (size_t)(r0 + rr) * D + c) = *reinterpret_cast<const float4*>(&VU[rr * LDP + c]);
-            }
-        }
-        auto proj = [&](BF16 (&cur)[1], float* __restrict__ outp, int t) {
-            f32x4 acc[1][2];
-            acc[0][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[0][1] = acc[0][0];
-            gemm16<2, 1>(VU, LDP, cur, acc);
-            const float bv = Pq[256 + t * D + col];
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const int gr = r0 + 16 * rb + g4 + rr;
-                    if (row_ok(HL + 16 * rb + g4 + rr)) outp[(size_t)gr * D + col] = acc[0][rb][rr] + bv;
-                }
-        };
-        proj(bfA, a.qf.q, 0);
-        bf16_load(bfA[0], a.qf.Wpack, 3 * D, 2 * D + 16 * w);
-        __builtin_amdgcn_sched_barrier(0);
-        proj(bfB, a.qf.k, 1);
-        proj(bfA, a.qf.v, 2);
     }
     ESTAMP(6);
 }
-constexpr size_t cb_fwd_lds(int sh) { return (size_t)(((sh ? 2 : 1) * (TILE_M + 8 * sh) + (sh ? TILE_M + 8 * sh + 12 : TILE_M + 2 * HALO)) * LDP + 4 * CB_PS + 640) * sizeof(float); }
 constexpr size_t cb_fwd_lds_split(int sh) {
     return (size_t)(((TILE_M + 8 * sh) + (sh ? TILE_M + 8 * sh + 12 : TILE_M + 2 * HALO)) * LDP + 3 * (TILE_M + 8 * sh) * CB_LDB / 2 + 4 * CB_PS + 640) * sizeof(float);
 }
-template <int SH, bool FULL, bool SPLIT>
+template <int SH, bool FULL>
 static void launch_cbf(const CbFwdArgs& a, int grid, hipStream_t s) {
     static size_t ok = 0;
-    const size_t lds = SPLIT ? cb_fwd_lds_split(SH) : cb_fwd_lds(SH);
-    ensure_dynamic_lds((const void*)k_convblock_fwd<SH, FULL, SPLIT>, lds, ok, "k_convblock_fwd");
-    VSL_LAUNCH((k_convblock_fwd<SH, FULL, SPLIT>), dim3(grid), dim3(CB_T), lds, s, a);
+    const size_t lds = cb_fwd_lds_split(SH);
+    ensure_dynamic_lds((const void*)k_convblock_fwd<SH, FULL>, lds, ok, "k_convblock_fwd");
+    VSL_LAUNCH((k_convblock_fwd<SH, FULL>), dim3(grid), dim3(CB_T), lds, s, a);
 }
 void launch_convblock_fwd(const CbFwdArgs& a, hipStream_t s) {
-    const bool split = a.W3[0] != nullptr;
     if (a.L <= TILE_M) {                    // sample tiles: one workgroup per sample
-        if (split) launch_cbf<0, false, true>(a, a.R / a.L, s); else launch_cbf<0, false, false>(a, a.R / a.L, s);
+        launch_cbf<0, false>(a, a.R / a.L, s);
         return;
     }
-    if (a.R % TILE_M == 0 && a.L % TILE_M == 0) {       // whole tiles inside one sample each: the predicate-free instantiation
-        if (split) launch_cbf<3, true, true>(a, a.R / TILE_M, s); else launch_cbf<3, true, false>(a, a.R / TILE_M, s);
-    } else {
-        if (split) launch_cbf<3, false, true>(a, (a.R + TILE_M - 1) / TILE_M, s); else launch_cbf<3, false, false>(a, (a.R + TILE_M - 1) / TILE_M, s);
-    }
+    if (a.R % TILE_M == 0 && a.L % TILE_M == 0) launch_cbf<3, true>(a, a.R / TILE_M, s);       // whole tiles inside one sample each: the predicate-free instantiation
+    else launch_cbf<3, false>(a, (a.R + TILE_M - 1) / TILE_M, s);
     static int left = 6;
     if (edbg_on() && a.R > 4096) { int l2 = left; edbg_report("convblock_fwd: load | L0 | L1 | L2 | L3 | qkv", 7, s, left); edbg_report2("  L0: LN | dw | gemm | epilogue | barrier", 8, 13, s, l2); }
 }
@@ -582,17 +527,17 @@ void launch_convblock_fwd(const CbFwdArgs& a, hipStream_t s) {
 // segment) with the 4 segments of a channel in 4 adjacent lanes, so the partial sums are combined with two quad shuffles.
 // LDS 91 KB: fits beside a weight-gradient workgroup (66 KB) of the side stream.
 // =========================================================================================================
-// SPLIT: du = dz Wp on the bf16 matrix cores at fp32 grade (gemm16s): phase A stores dz as three bf16 planes, which share their LDS with dv
+// du = dz Wp on the bf16 matrix cores at fp32 grade (gemm16s): phase A stores dz as three bf16 planes, which share their LDS with dv
 // (GU) -- dz is dead before phase C writes dv, but the next layer's phase A overwrites what phase D still reads: one more barrier per layer.
-template <int SH, bool FULL, bool SPLIT>        // SH 3: row tiles with a recomputed halo ; 0: sample tiles for L <= 32 ; FULL: see k_convblock_fwd
+template <int SH, bool FULL>        // SH 3: row tiles with a recomputed halo ; 0: sample tiles for L <= 32 ; FULL: see k_convblock_fwd
 __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
     constexpr int HL = 4 * SH, NW = TILE_M + 2 * HL, VUR = SH ? NW + 12 : NW, XR = NW - 2 * SH;
-    constexpr int ZPS = NW * CB_LDB;                     // SPLIT: elements between the dz planes
-    constexpr int GUF = SPLIT ? (3 * ZPS / 2 > VUR * LDP ? 3 * ZPS / 2 : VUR * LDP) : VUR * LDP;      // floats of the dz / dv region
+    constexpr int ZPS = NW * CB_LDB;                     // elements between the dz planes
+    constexpr int GUF = 3 * ZPS / 2 > VUR * LDP ? 3 * ZPS / 2 : VUR * LDP;      // floats of the dz / dv region
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* DY = smem;                       // [56][LDP] grad wrt the current layer's output (in place)
     float* GU = DY + NW * LDP;           // [68][LDP] dz (GEMM A operand), later dv
-    uint16_t* Pz = reinterpret_cast<uint16_t*>(GU);      // SPLIT: dz as three bf16 planes [NW][CB_LDB]
+    uint16_t* Pz = reinterpret_cast<uint16_t*>(GU);      // dz as three bf16 planes [NW][CB_LDB]
     float* DU = GU + GUF;                // [68][LDP] du: its own buffer, so neither the GEMM's reads nor the conv windows need a barrier of their own
     float* Xh = DU + VUR * LDP;              // [50][LDP] x_l, normalised in place; row = window row - SH
     float* RS = Xh + XR * LDP;           // [64] rstd per window row
@@ -642,10 +587,8 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
         for (int q = 0; q < 4; ++q)
             if (r8 < NW) *reinterpret_cast<float4*>(&DY[r8 * LDP + sub * 4 + 32 * q]) = dv[q];
     }
-    BF16 bfA[1], bfB[1];
     B3 b3A, b3B;
-    if (SPLIT) b3_load(b3A, a.WT3[3], D, D, 16 * w);
-    else bf16_load(bfA[0], a.WTpack[3], D, 16 * w);
+    b3_load(b3A, a.WT3[3], D, D, 16 * w);
     float wk[DWK], gc, bc, gnext = 0.f;
 #pragma unroll
     for (int k = 0; k < DWK; ++k) wk[k] = a.dw_w[3][cc * DWK + k];
@@ -682,7 +625,7 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
                 v.y = (bits & 2u) ? v.y * m[1] : 0.f;
                 v.z = (bits & 4u) ? v.z * m[2] : 0.f;
                 v.w = (bits & 8u) ? v.w * m[3] : 0.f;
-                if constexpr (SPLIT) {
+                {
                     uint32_t h0, m0, l0, h1, m1, l1;
                     split3(v.x, v.y, h0, m0, l0);
                     split3(v.z, v.w, h1, m1, l1);
@@ -690,7 +633,7 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
                     *reinterpret_cast<u32x2_t*>(d) = u32x2_t{h0, h1};
                     *reinterpret_cast<u32x2_t*>(d + ZPS) = u32x2_t{m0, m1};
                     *reinterpret_cast<u32x2_t*>(d + 2 * ZPS) = u32x2_t{l0, l1};
-                } else *reinterpret_cast<float4*>(&GU[wr * LDP + c4]) = v;
+                }
                 if (wr >= HL && wr < HL + TILE_M && row_ok(wr))
                     *reinterpret_cast<float4*>(a.gz[l] + (size_t)(rw0 + wr) * D + c4) = v;
             }
@@ -725,8 +668,7 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
         f32x4 acc[1][NRB];
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) acc[0][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (SPLIT) gemm16s<NRB>(Pz + ra * CB_LDB, ZPS, cur, acc);
-        else gemm16<NRB, 1>(GU + ra * LDP, LDP, cur, acc);
+        gemm16s<NRB>(Pz + ra * CB_LDB, ZPS, cur, acc);
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
@@ -829,8 +771,7 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
         if (l > 0) {
             constexpr int lm = l > 0 ? l - 1 : 0;
             fetch_layer(lm);
-            if constexpr (SPLIT) b3_load(nxt, a.WT3[lm], D, D, 16 * w);
-            else bf16_load(nxt[0], a.WTpack[lm], D, 16 * w);
+            b3_load(nxt, a.WT3[lm], D, D, 16 * w);
 #pragma unroll
             for (int k = 0; k < DWK; ++k) wk[k] = a.dw_w[lm][cc * DWK + k];
             gc = a.ln_g[lm][cc]; bc = a.ln_b[lm][cc];
@@ -872,48 +813,36 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
         }
         // no barrier: phase A of the next layer touches only what this thread itself read and wrote above -- except the dz planes of the
         // split path, which lie over the dv rows other threads are still reading
-        if (SPLIT && l > 0) __syncthreads();
+        if (l > 0) __syncthreads();
     };
     __syncthreads();
-    if constexpr (SPLIT) {
-        layer(std::integral_constant<int, 3>(), b3A, b3B);
-        layer(std::integral_constant<int, 2>(), b3B, b3A);
-        layer(std::integral_constant<int, 1>(), b3A, b3B);
-        layer(std::integral_constant<int, 0>(), b3B, b3A);
-    } else {
-    layer(std::integral_constant<int, 3>(), bfA, bfB);
+    layer(std::integral_constant<int, 3>(), b3A, b3B);
     ESTAMP(2);
-    layer(std::integral_constant<int, 2>(), bfB, bfA);
+    layer(std::integral_constant<int, 2>(), b3B, b3A);
     ESTAMP(3);
-    layer(std::integral_constant<int, 1>(), bfA, bfB);
+    layer(std::integral_constant<int, 1>(), b3A, b3B);
     ESTAMP(4);
-    layer(std::integral_constant<int, 0>(), bfB, bfA);
-    }
+    layer(std::integral_constant<int, 0>(), b3B, b3A);
     ESTAMP(5);
 }
-constexpr size_t cb_bwd_lds(int sh) { return (size_t)((TILE_M + 8 * sh + 2 * (sh ? TILE_M + 8 * sh + 12 : TILE_M) + TILE_M + 6 * sh) * LDP + 64 + 64 + 256) * sizeof(float); }
 constexpr size_t cb_bwd_lds_split(int sh) {
     const int nw = TILE_M + 8 * sh, vur = sh ? nw + 12 : nw, zf = 3 * nw * CB_LDB / 2, guf = zf > vur * LDP ? zf : vur * LDP;
     return (size_t)((nw + vur + TILE_M + 6 * sh) * LDP + guf + 64 + 64 + 256) * sizeof(float);
 }
-template <int SH, bool FULL, bool SPLIT>
+template <int SH, bool FULL>
 static void launch_cbb(const CbBwdArgs& a, int grid, hipStream_t s) {
     static size_t ok = 0;
-    const size_t lds = SPLIT ? cb_bwd_lds_split(SH) : cb_bwd_lds(SH);
-    ensure_dynamic_lds((const void*)k_convblock_bwd<SH, FULL, SPLIT>, lds, ok, "k_convblock_bwd");
-    VSL_LAUNCH((k_convblock_bwd<SH, FULL, SPLIT>), dim3(grid), dim3(CB_T), lds, s, a);
+    const size_t lds = cb_bwd_lds_split(SH);
+    ensure_dynamic_lds((const void*)k_convblock_bwd<SH, FULL>, lds, ok, "k_convblock_bwd");
+    VSL_LAUNCH((k_convblock_bwd<SH, FULL>), dim3(grid), dim3(CB_T), lds, s, a);
 }
 void launch_convblock_bwd(const CbBwdArgs& a, hipStream_t s) {
-    const bool split = a.WT3[3] != nullptr;
     if (a.L <= TILE_M) {                    // sample tiles: one workgroup per sample (partial slabs per SAMPLE: convblock_slabs())
-        if (split) launch_cbb<0, false, true>(a, a.R / a.L, s); else launch_cbb<0, false, false>(a, a.R / a.L, s);
+        launch_cbb<0, false>(a, a.R / a.L, s);
         return;
     }
-    if (a.R % TILE_M == 0 && a.L % TILE_M == 0) {
-        if (split) launch_cbb<3, true, true>(a, a.R / TILE_M, s); else launch_cbb<3, true, false>(a, a.R / TILE_M, s);
-    } else {
-        if (split) launch_cbb<3, false, true>(a, (a.R + TILE_M - 1) / TILE_M, s); else launch_cbb<3, false, false>(a, (a.R + TILE_M - 1) / TILE_M, s);
-    }
+    if (a.R % TILE_M == 0 && a.L % TILE_M == 0) launch_cbb<3, true>(a, a.R / TILE_M, s);
+    else launch_cbb<3, false>(a, (a.R + TILE_M - 1) / TILE_M, s);
     static int left = 6;
     if (edbg_on() && a.R > 4096) edbg_report("convblock_bwd: load | L3 | L2 | L1 | L0", 6, s, left);
 }
@@ -926,7 +855,7 @@ int convblock_slabs(int R, int L) { return L <= TILE_M ? R / L : (R + TILE_M - 1
 //   the online softmax is lane-local, as in k_attn_fwd).  K / V fragments come straight from L2 in MFMA operand shape (a key row of a
 //   head is 64 contiguous bytes), one key tile ahead -- no LDS staging, no barrier inside the key loop.  The eight 32 x 16 head outputs
 //   meet in one LDS tile, and the same workgroup finishes the block on it: r = drop(att) + x -> LN2 -> dropout -> Wo GEMM -> dropout -> + r.
-//   Saves att, LSE, r, h2 for the backward exactly like the two-kernel path (VSL_ATTN_BLOCK=0).
+//   Saves att, LSE, r, h2 for the backward exactly like the two-kernel path that serves L > 256.
 // =========================================================================================================
 template <int QB>     // 16-query blocks per wave: 2 = 8 waves (wave = head), 1 = 16 waves (wave = head x query block): twice the waves per SIMD
 __global__ __launch_bounds__(1024 / QB, QB) void k_attn_block_fwd(AttnBlockArgs a) {
@@ -1094,9 +1023,8 @@ __global__ __launch_bounds__(1024 / QB, QB) void k_attn_block_fwd(AttnBlockArgs 
 }
 void launch_attn_block_fwd(const AttnBlockArgs& a, int B, hipStream_t s) {
     // 16 waves (wave = head x 16-query block) up to L = 128, 8 waves (wave = head, two query blocks) beyond: measured ms/step 8 / 16 waves
-    // at cfg2 (L = 128) 1.030 / 1.023, at cfg4 (L = 256) 1.110 / 1.112.  VSL_ATTN_WAVES=8 / 16 forces one.
-    static const char* ew = getenv("VSL_ATTN_WAVES");
-    const bool w16 = ew ? ew[0] != '8' : a.L <= 128;
+    // at cfg2 (L = 128) 1.030 / 1.023, at cfg4 (L = 256) 1.110 / 1.112.
+    const bool w16 = a.L <= 128;
     const dim3 grid((a.L + TILE_M - 1) / TILE_M, B);
     const size_t shm = (size_t)((a.L + 15) & ~15) * sizeof(float);
     if (w16) VSL_LAUNCH(k_attn_block_fwd<1>, grid, dim3(1024), shm, s, a);

@@ -112,93 +112,15 @@ void launch_pack(const float* params, float* pack, const PackJob* jobs_dev, int 
 }
 
 // =========================================================================================================
-// a2  VisualProjection (:105-115):  Y = drop(X) W^T + b,  X (R, Dv) streamed from HBM once.
-//     32-row tile per workgroup, K streamed in 128-wide chunks through a double-buffered LDS tile
-//     (global -> regs -> LDS so the dropout mask is applied on the fly), B operand from the packed weight.
-// =========================================================================================================
-constexpr int VP_KC = 128;
-__global__ __launch_bounds__(256) void k_vproj_fwd(const float* __restrict__ X, const float* __restrict__ Wpack,
-                                                   const float* __restrict__ bias, float* __restrict__ Y, int R, int Dv,
-                                                   Drop dp, int seg, int stride, int off) {
-    __shared__ __attribute__((aligned(16))) float As[2][TILE_M * LDP];
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const int r0 = blockIdx.x * TILE_M;
-    // seg > 0 (GEMM use by the rnn head, no dropout): logical row r = physical row (r / seg) * stride + off + r % seg of X and Y
-    auto phys = [&](int r) { return seg > 0 ? (r / seg) * stride + off + r % seg : r; };
-    f32x16 acc[1];
-    zero_acc(acc);
-    const int nchunk = (Dv + VP_KC - 1) / VP_KC;
-    float4 stage[4];
-    auto gload = [&](int ch) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int e = tid + q * 256;                 // 1024 float4 per chunk: row = e >> 5, c4 = e & 31
-            const int rr = e >> 5, c = (e & 31) * 4 + ch * VP_KC;
-            const int r = r0 + rr;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < R && c < Dv) {
-                v = *reinterpret_cast<const float4*>(X + (size_t)phys(r) * Dv + c);
-                if (dp.thresh) {
-                    const uint32_t base = (uint32_t)((size_t)r * Dv + c);
-                    v.x *= drop_mul(dp, base); v.y *= drop_mul(dp, base + 1);
-                    v.z *= drop_mul(dp, base + 2); v.w *= drop_mul(dp, base + 3);
-                }
-            }
-            stage[q] = v;
-        }
-    };
-    auto sstore = [&](int buf) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int e = tid + q * 256;
-            *reinterpret_cast<float4*>(&As[buf][(e >> 5) * LDP + (e & 31) * 4]) = stage[q];
-        }
-    };
-    gload(0);
-    sstore(0);
-    __syncthreads();
-    for (int ch = 0; ch < nchunk; ++ch) {
-        const int buf = ch & 1;
-        if (ch + 1 < nchunk) gload(ch + 1);             // next chunk in flight while the MFMAs run
-        // Dv need only be a multiple of 4 (ActivityNet C3D: 500): the last 8-wide k block is zero in the LDS tile (gload) and
-        // in the packed weight (k_pack) beyond Dv
-        const int kc = (min(VP_KC, Dv - ch * VP_KC) + 7) & ~7;
-        {
-            const float* wp = Wpack + (size_t)ch * (VP_KC / 8) * D * 8;
-            BFrag<1, 8> bf;
-            bfrag_load(bf, wp, D, 32 * w, 0, 0, kc >> 3);
-            gemm32p<1, 8>(As[buf], LDP, kc, wp, D, 32 * w, 0, acc, bf);
-        }
-        if (ch + 1 < nchunk) sstore(buf ^ 1);
-        __syncthreads();
-    }
-    const int col = 32 * w + (lane & 31);
-    const float bv = bias[col];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int gr = r0 + acc_row(r, lane);
-        if (gr < R) Y[(size_t)phys(gr) * D + col] = acc[0][r] + bv;
-    }
-}
-void launch_vproj_fwd(const float* X, const float* Wpack, const float* bias, float* Y, int R, int Dv, Drop dp,
-                      hipStream_t s, int seg, int stride, int off) {
-    {
-        static size_t lds_sp = 0;
-        const size_t shm_sp = spread_lds(0, 33792, (R + TILE_M - 1) / TILE_M);
-        ensure_dynamic_lds((const void*)k_vproj_fwd, shm_sp + 33792, lds_sp, "k_vproj_fwd");
-        VSL_LAUNCH(k_vproj_fwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm_sp, s, X, Wpack, bias, Y, R, Dv, dp, seg, stride, off);
-    }
-}
-
-// =========================================================================================================
 // a2 in the bf16 THROUGHPUT mode (vsl_io.video_features_bf16): Y = (keep(X16) W16^T) / (1 - p) + b on the bf16 matrix cores
 // (v_mfma_f32_32x32x16_bf16: 16x the fp32 rate), X16 = bfloat16 features (half the HBM bytes), W16 = bf16-rounded weight
 // (PackJob type 5), products exact in fp32, fp32 accumulation.  The dropout keeps / zeroes the bf16 inputs exactly and the
-// scale 1 / (1 - p) multiplies the fp32 sum.  Same tiling as the fp32 kernel: 32 rows per workgroup, K streamed in 128-wide
+// scale 1 / (1 - p) multiplies the fp32 sum.  32 rows per workgroup, K streamed in 128-wide
 // chunks through a double-buffered LDS tile (8 KB each).  Lane maps of the MFMA: A lane (i = l & 31, h = l >> 5) = 8
 // consecutive k of row i starting at 8 h; B likewise for column i; C/D as for 32x32x2 (acc_row).
 // =========================================================================================================
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int VP_KC = 128;
 constexpr int VPB_LD = VP_KC + 8;       // bf16 elements per LDS row (272 B: 16-byte aligned rows, conflict-free b128 reads)
 __global__ __launch_bounds__(256) void k_vproj_fwd_bf16(const uint16_t* __restrict__ X, const uint16_t* __restrict__ Wp,
                                                         const float* __restrict__ bias, float* __restrict__ Y, int R, int Dv, Drop dp) {
@@ -506,9 +428,7 @@ __global__ __launch_bounds__(256) void k_linear_fwd(const float* __restrict__ A,
 }
 void launch_linear_fwd(const float* A, const float* Wpack, const float* bias, float* Y, int R, int K, hipStream_t s) {
     {
-        static size_t lds_sp = 0;
-        const size_t shm_sp = spread_lds(0, 16896, (R + TILE_M - 1) / TILE_M);
-        ensure_dynamic_lds((const void*)k_linear_fwd, shm_sp + 16896, lds_sp, "k_linear_fwd");
+        const size_t shm_sp = 0;
         VSL_LAUNCH(k_linear_fwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm_sp, s, A, Wpack, bias, Y, R, K);
     }
 }
@@ -687,9 +607,7 @@ void launch_attn_out_fwd(const float* att, const float* x, const float* ln_g, co
                          const float* bo, float* r_out, float* h2_out, float* y_out, int R, Drop d3, Drop d4, Drop d5,
                          hipStream_t s) {
     {
-        static size_t lds_sp = 0;
-        const size_t shm_sp = spread_lds(0, 33792, (R + TILE_M - 1) / TILE_M);
-        ensure_dynamic_lds((const void*)k_attn_out_fwd, shm_sp + 33792, lds_sp, "k_attn_out_fwd");
+        const size_t shm_sp = 0;
         VSL_LAUNCH(k_attn_out_fwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm_sp, s, att, x, ln_g, ln_b, Wpack, bo, r_out,
                        h2_out, y_out, R, d3, d4, d5);
     }
@@ -1268,9 +1186,7 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadArgs a0, HeadArgs a1, cons
 void launch_head_fwd(const HeadArgs& a0, const HeadArgs& a1, const float* x, const float* vmask, int R, hipStream_t s) {
     const size_t shm = (size_t)(TILE_M * HDP + TILE_M * LDP) * sizeof(float);
     {
-        static size_t lds_sp = 0;
-        const size_t shm_sp = spread_lds(shm, 0, (R + TILE_M - 1) / TILE_M);
-        ensure_dynamic_lds((const void*)k_head_fwd, shm_sp + 0, lds_sp, "k_head_fwd");
+        const size_t shm_sp = shm;
         VSL_LAUNCH(k_head_fwd, dim3((R + TILE_M - 1) / TILE_M, 2), dim3(256), shm_sp, s, a0, a1, x, vmask, R);
     }
 }

@@ -6,11 +6,6 @@
 
 namespace vsl {
 
-bool split_gemm_enabled() {
-    static const bool off = getenv("VSL_F32_GEMM") && getenv("VSL_F32_GEMM")[0] == '1';
-    return !off;
-}
-
 // =========================================================================================================
 // a2  VisualProjection (/root/reference/model/layers_t7.py:105-115):  Y = drop(X) W^T + b,  X (R, Dv) streamed from HBM once.
 // 32-row tile per workgroup, K streamed in 128-wide chunks through LDS: three planes (the bf16 terms h, m, l) of [32][128], double buffered.
@@ -189,12 +184,12 @@ __global__ __launch_bounds__(VP3_T, 2) void k_vproj_fwd3(const float* __restrict
         }
     }
 }
-void launch_vproj_fwd3(const float* X, const uint16_t* W3, const float* bias, float* Y, int R, int Dv, Drop dp, hipStream_t s, int seg, int stride, int off) {
+void launch_vproj_fwd3(const float* X, const uint16_t* W3, const float* bias, float* Y, int R, int Dv, Drop dp, hipStream_t s, bool one_product, int seg, int stride, int off) {
     const dim3 grid((R + TILE_M - 1) / TILE_M), block(VP3_T);
     const bool full = R % TILE_M == 0 && Dv % VP3_KC == 0 && seg == 0;
     const int sel = (full ? 2 : 0) | (dp.thresh ? 1 : 0);
 #define VP3_GO(F, DR, ON) VSL_LAUNCH((k_vproj_fwd3<F, DR, ON>), grid, block, 0, s, X, W3, bias, Y, R, Dv, dp, seg, stride, off)
-    if (g_one_product) {                   // vsl_io.arithmetic = 1
+    if (one_product) {                     // vsl_io.arithmetic = 1
         switch (sel) { case 3: VP3_GO(true, true, true); break; case 2: VP3_GO(true, false, true); break; case 1: VP3_GO(false, true, true); break; default: VP3_GO(false, false, true); }
     } else {
         switch (sel) { case 3: VP3_GO(true, true, false); break; case 2: VP3_GO(true, false, false); break; case 1: VP3_GO(false, true, false); break; default: VP3_GO(false, false, false); }

@@ -114,35 +114,16 @@ inline void ensure_dynamic_lds(const void* func, size_t bytes, size_t& granted, 
     }
 }
 
-// Workgroup spreading: the row-tile kernels launch about one 256-thread workgroup per CU (R / 32 = 256 at the headline
-// shape).  Several such workgroups fit one CU, and when the dispatcher co-locates them they serialise on that CU's four
-// matrix pipes while other CUs idle.  Requesting > 80 KiB of LDS per workgroup makes them mutually exclusive per CU.
-// Measured (profiles/r01_b_*): no gain alone and it blocks cross-stream co-residency, so it is OFF by default;
-// VSL_LDS_SPREAD=<bytes> (e.g. 86016) re-enables it for A/B runs.
-inline size_t lds_spread_bytes() {
-    static long v = -1;
-    if (v < 0) { const char* e = getenv("VSL_LDS_SPREAD"); v = e ? atol(e) : 0; }
-    return (size_t)v;
-}
-// dynamic-LDS size to launch with: at least `need`, padded so that static + dynamic >= the spread target
-inline size_t spread_lds(size_t need, size_t static_bytes, int nblocks) {
-    const size_t tgt = lds_spread_bytes();
-    if (tgt == 0 || nblocks > 2 * 256) return need;           // plenty of workgroups: let them share CUs
-    return (static_bytes + need >= tgt) ? need : tgt - static_bytes;
-}
-
 // ---------------------------------------------------------------- forward
 void launch_pack(const float* params, float* pack, const PackJob* jobs_dev, int njobs, hipStream_t s);
-void launch_vproj_fwd(const float* X, const float* Wpack, const float* bias, float* Y, int R, int Dv, Drop dp, hipStream_t s,
-                      int seg = 0, int stride = 0, int off = 0);   // seg > 0: rows of one time chunk (see launch_linear_bwd_data)
 // bf16 throughput mode: X bf16 (R, Dv), packed bf16 weight (PackJob type 5), fp32 accumulate / bias / output
 void launch_vproj_fwd_bf16(const uint16_t* X, const uint16_t* Wpack16, const float* bias, float* Y, int R, int Dv, Drop dp, hipStream_t s);
 // fp32-grade on the bf16 matrix cores (kernels_split.hip): W3 = split pack (PackJob type 6 / 7) of the (Dv, 128) operand
+// one_product: vsl_io.arithmetic == 1 for the call being enqueued (operands rounded to bfloat16, one product per product)
 void launch_vproj_fwd3(const float* X, const uint16_t* W3, const float* bias, float* Y, int R, int Dv, Drop dp, hipStream_t s,
-                       int seg = 0, int stride = 0, int off = 0);
+                       bool one_product = false, int seg = 0, int stride = 0, int off = 0);   // seg > 0: rows of one time chunk (see launch_linear_bwd_data)
 void launch_linear_fwd3(const float* A, const uint16_t* W3, const float* bias, float* Y, int R, int K, hipStream_t s);
 void launch_linear_bwd_data3(const float* G, const uint16_t* WT3, float* dA, int R, int K, int Kc, hipStream_t s);   // Kc: columns of the split pack
-bool split_gemm_enabled();       // false when VSL_F32_GEMM=1 selects the fp32-input MFMA kernels of round 2 (A/B runs)
 void launch_embed_fwd(const int64_t* word_ids, const int64_t* char_ids, const float* pad_vec, const float* unk_vec,
                       const float* glove, const float* char_tab, CharConvPtrs cc, const float* wimg, float* E, int8_t* argpos,
                       int Rq, int Lc, int word_dim, int char_dim, Drop dw, Drop dc, hipStream_t s);
@@ -227,8 +208,7 @@ void launch_lstm4_fwd(const float* gi, const float* Whh, const float* bih, const
                       float* cseq, float* hprev, float* out, int B, int T, hipStream_t s, int t0, int t1);
 void launch_lstm4_bwd(const float* dout, const float* dout2, const float* mask, const float* gates, const float* cseq,
                       const float* Whh, float* dG, int B, int T, hipStream_t s, float* carry, int t0, int t1);
-void launch_wgrad(const WgradBatch& wb, hipStream_t s);     // = launch_wgrad2 (kernels_wgrad.hip)
-void launch_wgrad2(const WgradBatch& wb, hipStream_t s);
+void launch_wgrad(const WgradBatch& wb, hipStream_t s, bool one_product = false);     // kernels_wgrad.hip
 void launch_attn_out_bwd(const float* dy, const float* dy2, const float* r, const float* ln_g, const float* WTpack, float* g_o,
                          float* dr, float* p_lng, float* p_lnb, int R, Drop d4, Drop d5, hipStream_t s);
 void launch_attn_bwd(const float* Q, const float* K, const float* V, const float* att, const float* dr, const float* lse,
@@ -277,7 +257,6 @@ constexpr int OPT_BLOCKS = 256;
 void launch_adamw(float* params, const float* grads, float* m, float* v, const uint8_t* decay_mask, float* partials /*[OPT_BLOCKS + 1]*/,
                   int64_t n, float lr, float b1, float b2, float eps, float wd, float clip, float bc1, float bc2_sqrt,
                   float* norm_out, hipStream_t s, int hf_order = 0);
-extern bool g_one_product;        // vsl_io.arithmetic == 1 for the call being enqueued (set by vsl_forward / vsl_backward, read by the launchers)
 constexpr int EMB_CHUNK_MAX = 8;  // most query words per workgroup in the embedding backward
 int embed_bwd_chunk(int Rq, int Lc, int char_dim);      // words per workgroup the launcher uses (the number of partial slabs follows from it)
 constexpr int EB_IMG_Q = 76;      // k-steps of the embedding backward's B-operand image ([channel tile][76][64 lanes], PackJob type 8)
