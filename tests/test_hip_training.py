@@ -367,10 +367,12 @@ def test_dropout_mask_statistics_and_scaling():
          char_dim=100, char_size=130, word_table=True),
     dict(name='embedding: char_dim 64 with 25-character tokens (two input-channel blocks in the long-token instantiation; found by tools/fuzz_parity.py)',
          T=31, Dv=4, B=6, Lq=64, Lc=25, char_dim=64),
+    dict(name='embedding: word_dim 52 (152 columns, not a multiple of 16: the fp32-input k_linear_fwd serves the embedding linear)', T=40, Dv=64, B=3, Lq=9, Lc=7,
+         word_dim=52),
 ])
 def test_baseline_shapes_against_oracle(shape):
     cfg = O.make_cfg(video_feature_dim=shape['Dv'], max_pos_len=max(shape['T'], shape['Lq']), word_size=102, char_dim=shape.get('char_dim', 50),
-                     char_size=shape.get('char_size', 40), word_table=shape.get('word_table', False))
+                     char_size=shape.get('char_size', 40), word_table=shape.get('word_table', False), word_dim=shape.get('word_dim', 300))
     P = O.random_params(cfg, seed=11)
     b = O.synthetic_batch(cfg, shape['B'], shape['T'], shape['Lq'], shape['Lc'], seed=12, ragged=shape['B'] > 1)
     d = _dev(b)

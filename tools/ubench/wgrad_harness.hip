@@ -2,6 +2,7 @@
 // operand-source combination (fp32 / bf16 planes, dropout, ragged rows, ragged K, three G blocks, the in-kernel fold of two partner jobs)
 // against fp64, and timings against k_wgrad4 at the headline shape.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize wgrad_harness.hip -o wgrad_harness.bin && ./wgrad_harness.bin
+#define WG4_STAMPS
 #include "../../vslnet_amd/csrc/kernels_wgrad.hip"
 #include "wgrad5_kernel.inc"
 #include <vector>
@@ -240,6 +241,27 @@ int main() {
             fill_starts(wb);
             const int total = wb.start[wb.n];
             printf("k_wgrad4, 4 jobs R=8192 (128 workgroups):              %.2f us\n", time_us([&] { hipLaunchKernelGGL((k_wgrad4<false, false>), dim3(total), dim3(WG4_T), 0, 0, wb); }));
+            long long st[8];
+            CHECK(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_wg4_stamps), sizeof st));
+            printf("  workgroup 0 (100 MHz wall clock ticks = 10 ns): job lookup %lld | address set-up + first loads + first stage %lld | 16-step loop %lld | slab stores issued %lld\n",
+                   st[1] - st[0], st[2] - st[1], st[3] - st[2], st[4] - st[3]);
+            {   // numerics of k_wgrad4 itself: job 0, slabs summed on the host, against fp64
+                const int nch = R / WG_ROWS;
+                std::vector<float> sl((size_t)nch * 128 * 128), bs((size_t)nch * 128);
+                CHECK(hipMemcpy(sl.data(), slab, sl.size() * 4, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(bs.data(), bsl, bs.size() * 4, hipMemcpyDeviceToHost));
+                double emax = 0, smax = 0, eb = 0;
+                for (int n = 0; n < 128; n += 5)
+                    for (int k = 0; k < 128; k += 3) {
+                        double sref = 0, sa = 0, got = 0;
+                        for (int r = 0; r < R; ++r) { const double g = Gm[0].h[(size_t)r * 128 + n], a = Am[0].h[(size_t)r * 128 + k]; sref += g * a; sa += fabs(g * a); }
+                        for (int c = 0; c < nch; ++c) got += sl[((size_t)c * 128 + n) * 128 + k];
+                        emax = fmax(emax, fabs(got - sref)); smax = fmax(smax, sa);
+                    }
+                for (int n = 0; n < 128; ++n) { double sref = 0, got = 0; for (int r = 0; r < R; ++r) sref += Gm[0].h[(size_t)r * 128 + n]; for (int c = 0; c < nch; ++c) got += bs[(size_t)c * 128 + n]; eb = fmax(eb, fabs(got - sref)); }
+                printf("  k_wgrad4 vs fp64 (R = 8192): err / max sum|g||a| = %.2e, bias err %.2e\n", emax / smax, eb);
+            }
+            // empty-kernel floor: same grid, same kernarg size
+            printf("  (hipEvent pair around 20 back-to-back launches: includes ~2 us of launch gap each)\n");
         }
         for (int rows : {256, 512, 1024})
             for (int kind = 0; kind < 4; ++kind)

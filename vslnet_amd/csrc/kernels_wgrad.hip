@@ -206,6 +206,12 @@ __global__ __launch_bounds__(WG2_T, 1) void k_wgrad3(WgradBatch wb) {
 // barrier s, the writes of step s + 1 follow it); raw rows travel three steps ahead in registers.  48 KB of LDS.
 // =====================================================================================================================
 constexpr int WG4_T = 512, WG4_NB = 4;
+#ifdef WG4_STAMPS      // harness builds (tools/ubench/wgrad_harness.hip): 100 MHz wall-clock stamps of workgroup 0, thread 0
+__device__ long long g_wg4_stamps[8];
+#define WG4STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_wg4_stamps[k] = wall_clock64(); } while (0)
+#else
+#define WG4STAMP(k) do { } while (0)
+#endif
 // dword index of row pair rg (rows 2 rg, 2 rg + 1) of column c: the two 8-row halves of a column live in separate arrays, so the 16 lanes of a
 // ds_read_b128 phase (consecutive columns, one half) cover all 64 banks once
 __device__ __forceinline__ int wg4_idx(int buf, int o, int p, int c, int rg) { return (((((buf * 2 + o) * 3 + p) * 2 + (rg >> 2)) * 128 + c) << 2) + (rg & 3); }
@@ -213,6 +219,7 @@ __device__ __forceinline__ int wg4_idx(int buf, int o, int p, int c, int rg) { r
 template <bool DROP, bool ONE>
 __global__ __launch_bounds__(WG4_T, 1) void k_wgrad4(WgradBatch wb) {
     __shared__ __attribute__((aligned(16))) uint32_t Ps[2 * 2 * 3 * 128 * 8];
+    WG4STAMP(0);
     int ji = 0;
     while (ji + 1 < wb.n && (int)blockIdx.x >= wb.start[ji + 1]) ++ji;
     const WgradJob& j = wb.j[ji];
@@ -227,6 +234,7 @@ __global__ __launch_bounds__(WG4_T, 1) void k_wgrad4(WgradBatch wb) {
     const int rbeg = ch * WG_ROWS, rend = min(R, rbeg + WG_ROWS), nrows = rend - rbeg;
     const uint32_t dseed = j.dp.seed, dthr = j.dp.thresh, dkey = j.dp.key;
     const float dscale = j.dp.scale;
+    WG4STAMP(1);
     // ---- staging role: row pair rg of the step (rows 2 rg, 2 rg + 1), column pair cp (columns 2 cp, 2 cp + 1) of both operands.
     //      lane = (rg, cp & 7): the 64 lanes of a wave write 32 distinct banks (all lanes on one row pair would hit 8)
     const int rg = lane >> 3, cp = 8 * wv + (lane & 7);
@@ -294,6 +302,7 @@ __global__ __launch_bounds__(WG4_T, 1) void k_wgrad4(WgradBatch wb) {
     const int ns = ((nrows + 16 * WG4_NB - 1) / (16 * WG4_NB)) * WG4_NB;      // steps, a multiple of the ring (a step past the rows multiplies zeros)
     static_for<0, WG4_NB - 1>([&](auto uc) { constexpr int u = decltype(uc)::value; ld(u, rawg[u], rawa[u]); });
     stage(0, 0, rawg[0], rawa[0]);
+    WG4STAMP(2);
     for (int s0 = 0; s0 < ns; s0 += WG4_NB) {
         static_for<0, WG4_NB>([&](auto uc) {
             constexpr int u = decltype(uc)::value;
@@ -302,8 +311,10 @@ __global__ __launch_bounds__(WG4_T, 1) void k_wgrad4(WgradBatch wb) {
             __syncthreads();
             // the operand reads of step s are issued BEFORE the staging of step s + 1 (the other buffer): their latency hides behind the
             // split arithmetic (21.3 -> 19.1 us).  Measured and dropped: MFMAs before the staging in half / all of the waves (19.3 / 19.3 us);
-            // producer / consumer wave roles with 64 x 64 consumer tiles (12 reads per 24 MFMAs: 20.1 us) -- the step is a mix of LDS
-            // bandwidth (96 KB per step), the barrier and the matrix pipe, none of them alone
+            // producer / consumer wave roles with 64 x 64 consumer tiles (12 reads per 24 MFMAs: 20.1 us); round 4: the staging woven between the
+            // MFMAs in four parts (loop of workgroup 0: 11.8 -> 12.4 us, harness stamps: job lookup 0.7, first loads + stage 1.7, 16-step loop
+            // 11.8, slab stores 0.6 us) -- the step is a mix of LDS bandwidth (96 KB per step, a quarter of it ds_write_b32 at half rate), the
+            // barrier and the matrix pipe, none of them alone
             Frag f;
             frag_load(u & 1, f);
             __builtin_amdgcn_sched_barrier(0);
@@ -311,6 +322,7 @@ __global__ __launch_bounds__(WG4_T, 1) void k_wgrad4(WgradBatch wb) {
             mma(f);
         });
     }
+    WG4STAMP(3);
     // ---- partial slab: register r of acc[a] = dW[n = 64 nh + 32 a + acc_row(r)][k = kt * 128 + 32 kq + i]
     const int N = 128 * j.nG;
     const int kglob = kt * 128 + 32 * kq + i;
@@ -321,6 +333,7 @@ __global__ __launch_bounds__(WG4_T, 1) void k_wgrad4(WgradBatch wb) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) out[(size_t)(32 * a + acc_row(r, lane)) * K] = acc[a][r];
     }
+    WG4STAMP(4);
     if (want_bias) {            // column sums of G: the 8 row pairs of a column pair sit in 8 lanes (lane >> 3) of one wave
         __syncthreads();
         float* red = reinterpret_cast<float*>(Ps);
