@@ -1,9 +1,9 @@
 #!/bin/bash
 # One gpurun call: kernel-trace stats, the PMC passes (each in its own run, as MI355X_MICROARCH.md prescribes), the profile json
 # bench.py quotes as the static half of its roofline object, then the final bench line and the HIP-event table.
-# usage (on the GPU box, from the repo root): bash tools/collect_evidence.sh r03_a
+# usage (on the GPU box, from the repo root): bash tools/collect_evidence.sh r04_a
 set -u
-TAG=${1:-r03_c}
+TAG=${1:-r04_a}
 R=$PWD
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -21,12 +21,22 @@ python tools/rocpd_pmc.py $FDB > $O/${TAG}_pmc_fetch_size.txt
 python tools/rocpd_pmc.py $WDB > $O/${TAG}_pmc_write_size.txt
 python tools/rocpd_mfma.py $(find $O/mfma -name "*.db" | head -1) > $O/${TAG}_pmc_mfma_busy.txt
 python tools/make_profile_json.py $SDB $FDB $WDB $O/${TAG}_profile.json $TAG
-cp $O/${TAG}_profile.json profiles/r03_profile.json
+cp $O/${TAG}_profile.json profiles/r04_profile.json
 python bench.py > $O/${TAG}_bench.json 2> $O/bench.err
 python bench.py --steps 30 --warmup 10 --no-cpu-baseline --profile-all 2> $O/${TAG}_hip_event_table.txt > /dev/null
 python bench.py --steps 30 --warmup 10 --no-cpu-baseline --dtype bf16 > $O/${TAG}_bench_bf16_mode.json 2>/dev/null
 python bench.py --steps 30 --warmup 10 --no-cpu-baseline --predictor rnn --batch 16 > $O/${TAG}_bench_rnn_b16_configs0.json 2>/dev/null
 python bench.py --steps 30 --warmup 10 --no-cpu-baseline --predictor rnn --batch 64 > $O/${TAG}_bench_rnn_b64.json 2>/dev/null
 bash tools/bench_shapes.sh > $O/${TAG}_bench_shapes.txt 2>/dev/null
+# per-kernel stats of the other BASELINE configs (configs[2..4]: per-GPU shapes)
+cd /tmp
+for cfg in "2 --batch 32 --T 256 --dv 4096" "3 --batch 32 --T 256" "4 --batch 16 --T 1024"; do
+  set -- $cfg; n=$1; shift
+  rm -rf $O/c$n
+  rocprofv3 --kernel-trace --stats -d $O/c$n -o s -- python $R/bench.py --steps 12 --warmup 4 --no-cpu-baseline "$@" > /dev/null 2> $O/c$n.err
+  python $R/tools/rocpd_stats.py $(find $O/c$n -name "*.db" | head -1) > $O/${TAG}_configs${n}_kernel_stats.txt
+  rm -rf $O/c$n
+done
+cd $R
 rm -rf $O/stats $O/fetch $O/write $O/mfma
 tail -c 2500 $O/${TAG}_bench.json

@@ -1,7 +1,7 @@
 """Build profiles/<tag>_profile.json -- what bench.py quotes as the STATIC half of its roofline object -- from the rocprofv3
 passes of one `tools/collect_evidence.sh` call: the kernel trace (average launch duration per kernel group) and the two PMC
 passes (FETCH_SIZE, WRITE_SIZE; separate runs, as MI355X_MICROARCH.md prescribes).  Launches per step are counted against
-the k_pack dispatches of the same database (one per step), so they cannot drift from the stats file.
+the k_adamw dispatches of the same database (one per step), so they cannot drift from the stats file.
 usage: make_profile_json.py <stats.db> <fetch.db> <write.db> <out.json> <tag>"""
 import json
 import sqlite3
@@ -43,7 +43,7 @@ def counters(db, counter):
 
 def main(stats_db, fetch_db, write_db, out_path, tag):
     d, f, w = durations(stats_db), counters(fetch_db, 'FETCH_SIZE'), counters(write_db, 'WRITE_SIZE')
-    nsteps = d['k_pack'][0]
+    nsteps = d['k_adamw'][0]                                    # one update per step (k_pack: three launches per step since round 4)
     groups = {}
     for k, (n, us) in d.items():
         if not k.startswith('k_'):

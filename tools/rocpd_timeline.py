@@ -1,5 +1,6 @@
-"""Print the per-stream kernel timeline of ONE benchmark step (between two k_pack launches) from a rocprofv3 rocpd
-database: start/end (us, relative to the step start), stream index, kernel, duration."""
+"""Print the per-stream kernel timeline of ONE benchmark step (the kernels between two k_adamw launches: a step ends with its update; since
+round 4 a step opens with three k_pack launches on three streams) from a rocprofv3 rocpd database: start/end (us, relative to the step
+start), stream index, kernel, duration."""
 import sqlite3
 import sys
 
@@ -7,8 +8,8 @@ import sys
 def main(db_path, step=12, out=sys.stdout):
     cur = sqlite3.connect(db_path).cursor()
     rows = list(cur.execute('select name, start, end, stream_id from kernels order by start'))
-    packs = [i for i, r in enumerate(rows) if 'k_pack' in r[0]]
-    i0, i1 = packs[step], packs[step + 1]
+    ends = [i for i, r in enumerate(rows) if 'k_adamw' in r[0]]
+    i0, i1 = ends[step] + 1, ends[step + 1] + 1
     t0 = rows[i0][1]
     st = rows[i0:i1]
     streams = sorted(set(r[3] for r in st))
