@@ -276,6 +276,39 @@ def run_host_pipeline(ru, dl):
     print('host_pipeline written', os.path.getsize(path) // 1024, 'KiB')
 
 
+REF_CKPT_ARGV = ['--task', 'synthetic', '--predictor', 'transformer', '--max_pos_len', '32', '--video_feature_dim', '64', '--batch_size', '16',
+                 '--synthetic_train', '8', '--synthetic_test', '48', '--drop_rate', '0.1']
+
+
+def run_ref_checkpoint(VSLNet, ru, dl):
+    """A checkpoint written BY THE REFERENCE (`torch.save(model.state_dict())`, main_t7.py:125) together with the `configs.json` it writes
+    (main_t7.py:81) and the metrics its own `eval_test` (runner_utils_t7.py:71-101) reports for it on the synthetic test split -- the file
+    `main.py --mode test` must load (main_t7.py:140-144) and reproduce.  The dataset is what `--task synthetic` builds from the same argv."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location('vsl_repo_main', os.path.join(ROOT, 'main.py'))      # (`import main` would find the reference's TF main.py)
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    from vslnet_amd import data
+    cfg = cli.build_parser().parse_args(REF_CKPT_ARGV)
+    dataset, feats = data.load_dataset(cfg)
+    cfg.char_size, cfg.word_size = dataset['n_chars'], dataset['n_words']
+    cfg.num_train_steps = 1
+    torch.manual_seed(4321)
+    model = VSLNet(configs=cfg, word_vectors=dataset['word_vector'])
+    model.eval()
+    out_dir = os.path.join(ROOT, 'tests', 'golden', 'ref_checkpoint')
+    os.makedirs(out_dir, exist_ok=True)
+    torch.save(model.state_dict(), os.path.join(out_dir, 'vslnet_5.t7'))
+    with open(os.path.join(out_dir, 'configs.json'), 'w', encoding='utf-8') as f:
+        f.write(json.dumps(vars(cfg), indent=4, sort_keys=True))
+    loader = dl.get_test_loader(dataset['test_set'], feats, cfg)
+    r1i3, r1i5, r1i7, mi, _ = ru.eval_test(model, loader, 'cpu', mode='test')
+    with open(os.path.join(out_dir, 'reference_metrics.json'), 'w') as f:
+        json.dump({'argv': REF_CKPT_ARGV, 'r1i3': r1i3, 'r1i5': r1i5, 'r1i7': r1i7, 'mIoU': mi, 'n_test': len(dataset['test_set'])}, f, indent=1)
+    print('ref_checkpoint written:', os.path.getsize(os.path.join(out_dir, 'vslnet_5.t7')) // 1024, 'KiB', r1i3, r1i5, r1i7, mi)
+
+
 INIT_SEED = 777
 
 
@@ -312,6 +345,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'init':
         run_init(VSLNet)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == 'ref_checkpoint':
+        run_ref_checkpoint(VSLNet, ru, dl)
+        return
     if len(sys.argv) > 2 and sys.argv[1] == 'case':          # one model fixture, the others untouched
         torch.set_num_threads(8)
         if sys.argv[2] in TRAIN_CASES:
@@ -328,6 +364,7 @@ def main():
     run_host_helpers(ru, dl)
     run_host_pipeline(ru, dl)
     run_init(VSLNet)
+    run_ref_checkpoint(VSLNet, ru, dl)
 
 
 if __name__ == '__main__':

@@ -61,6 +61,24 @@ def test_train_then_test_mode_on_synthetic_task(tmp_path, optimizer, predictor, 
     assert 'predictor.start_block.0.conv1d.weight' in sd and 'embedding_net.word_emb.glove_vec' in sd
 
 
+@pytest.mark.gpu
+def test_test_mode_loads_a_checkpoint_written_by_the_reference(tmp_path):
+    """tests/golden/ref_checkpoint/: `torch.save(model.state_dict())` done BY THE REFERENCE (main_t7.py:125) with the `configs.json` it writes
+    (main_t7.py:81) and the metrics its own `eval_test` reports on the synthetic test split (oracle/make_golden.py: run_ref_checkpoint).
+    `main.py --mode test` (main_t7.py:132-149) must load the file and reproduce the metrics."""
+    import shutil
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'ref_checkpoint')
+    want = json.load(open(os.path.join(src, 'reference_metrics.json')))
+    ns = cli.build_parser().parse_args(want['argv'] + ['--model_dir', str(tmp_path)])
+    home = cli.model_home(ns)
+    os.makedirs(home)
+    shutil.copy(os.path.join(src, 'vslnet_5.t7'), home)
+    shutil.copy(os.path.join(src, 'configs.json'), home)
+    res = cli.run(want['argv'] + ['--model_dir', str(tmp_path), '--mode', 'test'], log=lambda *a: None)
+    for k in ('r1i3', 'r1i5', 'r1i7', 'mIoU'):
+        assert abs(res[k] - want[k]) < 1e-3, (k, res[k], want[k])
+
+
 def test_rnn_predictor_has_the_reference_state_dict_entries():
     from vslnet_amd.model.VSLNet import VSLNet
     from vslnet_amd.synthetic import make_configs

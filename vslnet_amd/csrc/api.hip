@@ -531,11 +531,11 @@ void enc_fwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float*
         if (!c.dry) {
             a.xin = xin; a.pos = c.P(P.pos); a.x0_out = c.W(w.x0);
             for (int i = 0; i < 4; ++i) {
-                a.ln_g[i] = c.P(P.lng[i]); a.ln_b[i] = c.P(P.lnb[i]); a.dw_w[i] = c.P(P.dw[i]); a.Wpack[i] = c.PK(K.pw_f[i]);
+                a.ln_g[i] = c.P(P.lng[i]); a.ln_b[i] = c.P(P.lnb[i]); a.dw_w[i] = c.P(P.dw[i]);
                 a.pw_b[i] = c.P(P.pwb[i]); a.y[i] = c.W(w.y[i]); a.u[i] = c.W(w.u[i]);
                 a.relu_mask[i] = reinterpret_cast<uint32_t*>(c.W(w.mask[i])); a.dp[i] = c.drop(app * 16 + i);
             }
-            a.qf = QkvFuse{c.P(P.ln1g), c.P(P.ln1b), c.PK(K.qkv_f), c.P(P.qb), c.P(P.kb), c.P(P.vb), c.W(w.h1), c.W(w.q), c.W(w.k), c.W(w.v),
+            a.qf = QkvFuse{c.P(P.ln1g), c.P(P.ln1b), c.P(P.qb), c.P(P.kb), c.P(P.vb), c.W(w.h1), c.W(w.q), c.W(w.k), c.W(w.v),
                            c.drop(app * 16 + 4)};
             for (int i = 0; i < 4; ++i) a.W3[i] = reinterpret_cast<const uint16_t*>(c.PK(K.pw_f3[i]));
             a.Wqkv3 = reinterpret_cast<const uint16_t*>(c.PK(K.qkv_f3));
@@ -694,9 +694,8 @@ void enc_bwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float*
                            c.W(t.dv), Bn, L, H, 0, c.drop(app * 16 + 5), c.drop(app * 16 + 6), c.s));
     float* p_ln1g = c.slab(P.ln1g, D, ntiles);
     float* p_ln1b = c.slab(P.ln1b, D, ntiles);
-    LAUNCH("qkv_bwd", launch_qkv_bwd(c.W(t.dq), c.W(t.dk), c.W(t.dv), c.W(w.y[3]), c.W(t.dr), c.P(P.ln1g), c.PK(K.qkv_t),
-                          c.W(t.ga), p_ln1g, p_ln1b, R, c.drop(app * 16 + 4), c.s, attn_bwd_dq_slabs(L),
-                          reinterpret_cast<const uint16_t*>(c.PK(K.qkv_t3))));
+    LAUNCH("qkv_bwd", launch_qkv_bwd(c.W(t.dq), c.W(t.dk), c.W(t.dv), c.W(w.y[3]), c.W(t.dr), c.P(P.ln1g), reinterpret_cast<const uint16_t*>(c.PK(K.qkv_t3)),
+                          c.W(t.ga), p_ln1g, p_ln1b, R, c.drop(app * 16 + 4), c.s, attn_bwd_dq_slabs(L)));
     {   // out_layer + fused q/k/v weight gradients: every input exists now -> side stream, beside the conv chain
         WgradBatch wb;
         memset(&wb, 0, sizeof wb);
@@ -738,7 +737,7 @@ void enc_bwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float*
             a.dy = g; a.dx0 = dx0_out; a.R = R; a.L = L;
             for (int i = 0; i < 4; ++i) {
                 a.x[i] = i > 0 ? c.W(w.y[i - 1]) : c.W(w.x0);
-                a.relu_mask[i] = reinterpret_cast<const uint32_t*>(c.W(w.mask[i])); a.WTpack[i] = c.PK(K.pw_t[i]);
+                a.relu_mask[i] = reinterpret_cast<const uint32_t*>(c.W(w.mask[i]));
                 a.ln_g[i] = c.P(P.lng[i]); a.ln_b[i] = c.P(P.lnb[i]); a.dw_w[i] = c.P(P.dw[i]);
                 a.dp[i] = c.drop(app * 16 + i); a.gz[i] = c.W(t.gz[i]);
                 a.WT3[i] = reinterpret_cast<const uint16_t*>(c.PK(K.pw_t3[i]));

@@ -200,24 +200,21 @@ void launch_vproj_fwd3(const float* X, const uint16_t* W3, const float* bias, fl
 // =========================================================================================================
 // a8 backward, first half: dh1 = [dQ | dK | dV] [Wq; Wk; Wv] ; dx = dr + LN1^T(dh1 * m1)   (autograd of layers_t7.py:168-173)
 // =========================================================================================================
-constexpr int QKVP = 3 * D + 4;
 constexpr int QKV3_LD = 3 * D + 8;      // bf16 elements per plane row (784 B: 16 mod 128)
 __global__ __launch_bounds__(256) void k_qkv_bwd(const float* __restrict__ dQ, const float* __restrict__ dK,
                                                  const float* __restrict__ dV, const float* __restrict__ x,
                                                  const float* __restrict__ dr, const float* __restrict__ ln_g,
-                                                 const float* __restrict__ WTpack, float* __restrict__ dx,
+                                                 float* __restrict__ dx,
                                                  float* __restrict__ p_lng, float* __restrict__ p_lnb, int R, Drop d1, int dq_slabs,
                                                  size_t dq_slab, const uint16_t* __restrict__ WT3) {
-    // WT3 != nullptr: the K = 384 product on the bf16 matrix cores at fp32 grade (gemm32pl): the staged [dQ | dK | dV] tile is split into three
-    // bf16 planes on its way into LDS (75 KB instead of 50 KB of fp32)
+    // the K = 384 product on the bf16 matrix cores at fp32 grade (gemm32pl): the staged [dQ | dK | dV] tile is split into three bf16 planes on
+    // its way into LDS (75 KB)
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                         // [32][QKVP] = [dQ | dK | dV]   (fp32 path)
-    uint16_t* Ap = reinterpret_cast<uint16_t*>(smem);        // split path: 3 planes of [32][QKV3_LD]
-    float* Ts = WT3 ? smem + 3 * TILE_M * QKV3_LD / 2 : As + TILE_M * QKVP;           // [32][LDP]
+    uint16_t* Ap = reinterpret_cast<uint16_t*>(smem);        // 3 planes of [32][QKV3_LD] = [dQ | dK | dV]
+    float* Ts = smem + 3 * TILE_M * QKV3_LD / 2;             // [32][LDP]
     float* Xs = Ts + TILE_M * LDP;            // [32][LDP] raw LN1 input
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int r0 = blockIdx.x * TILE_M;
-    BFrag<1, 16> bf;
     {
         float4 a[4], bq[4], cv[4];
 #pragma unroll
@@ -239,20 +236,13 @@ __global__ __launch_bounds__(256) void k_qkv_bwd(const float* __restrict__ dQ, c
                 cv[q] = *reinterpret_cast<const float4*>(dV + (size_t)r * D + c);
             }
         }
-        if (!WT3) bfrag_load(bf, WTpack, D, 32 * w, 0, 0, 3 * D / 8);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int e = tid + q * 256;
             const int rr = e >> 5, c = (e & 31) * 4;
-            if (WT3) {
-                split_store4(Ap, QKV3_LD, TILE_M * QKV3_LD, rr, c, a[q]);
-                split_store4(Ap, QKV3_LD, TILE_M * QKV3_LD, rr, D + c, bq[q]);
-                split_store4(Ap, QKV3_LD, TILE_M * QKV3_LD, rr, 2 * D + c, cv[q]);
-            } else {
-                *reinterpret_cast<float4*>(&As[rr * QKVP + c]) = a[q];
-                *reinterpret_cast<float4*>(&As[rr * QKVP + D + c]) = bq[q];
-                *reinterpret_cast<float4*>(&As[rr * QKVP + 2 * D + c]) = cv[q];
-            }
+            split_store4(Ap, QKV3_LD, TILE_M * QKV3_LD, rr, c, a[q]);
+            split_store4(Ap, QKV3_LD, TILE_M * QKV3_LD, rr, D + c, bq[q]);
+            split_store4(Ap, QKV3_LD, TILE_M * QKV3_LD, rr, 2 * D + c, cv[q]);
         }
     }
     LnResid lres;
@@ -261,8 +251,7 @@ __global__ __launch_bounds__(256) void k_qkv_bwd(const float* __restrict__ dQ, c
     __syncthreads();
     f32x16 acc[1];
     zero_acc(acc);
-    if (WT3) gemm32pl<1>(Ap, QKV3_LD, TILE_M * QKV3_LD, 3 * D, WT3, D, 32 * w, 0, acc);
-    else gemm32p<1, 16>(As, QKVP, 3 * D, WTpack, D, 32 * w, 0, acc, bf);
+    gemm32pl<1>(Ap, QKV3_LD, TILE_M * QKV3_LD, 3 * D, WT3, D, 32 * w, 0, acc);
     const int col = 32 * w + (lane & 31);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -273,12 +262,12 @@ __global__ __launch_bounds__(256) void k_qkv_bwd(const float* __restrict__ dQ, c
     ln_bwd_tile(Ts, Xs, lres, ln_g, dx, p_lng, p_lnb, r0, R);
 }
 void launch_qkv_bwd(const float* dQ, const float* dK, const float* dV, const float* x, const float* dr,
-                    const float* ln_g, const float* WTpack, float* dx, float* p_lng, float* p_lnb, int R, Drop d1, hipStream_t s,
-                    int dq_slabs, const uint16_t* WT3) {
-    const size_t shm = (size_t)((WT3 ? 3 * TILE_M * QKV3_LD / 2 : TILE_M * QKVP) + 2 * TILE_M * LDP) * sizeof(float);
+                    const float* ln_g, const uint16_t* WT3, float* dx, float* p_lng, float* p_lnb, int R, Drop d1, hipStream_t s,
+                    int dq_slabs) {
+    const size_t shm = (size_t)(3 * TILE_M * QKV3_LD / 2 + 2 * TILE_M * LDP) * sizeof(float);
     static size_t lds_ok = 0;
     ensure_dynamic_lds((const void*)k_qkv_bwd, shm, lds_ok, "k_qkv_bwd");
-    VSL_LAUNCH(k_qkv_bwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm, s, dQ, dK, dV, x, dr, ln_g, WTpack, dx, p_lng,
+    VSL_LAUNCH(k_qkv_bwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm, s, dQ, dK, dV, x, dr, ln_g, dx, p_lng,
                        p_lnb, R, d1, dq_slabs, (size_t)R * D, WT3);
 }
 

@@ -130,17 +130,17 @@ void launch_embed_fwd(const int64_t* word_ids, const int64_t* char_ids, const fl
 void launch_linear_fwd(const float* A, const float* Wpack, const float* bias, float* Y, int R, int K, hipStream_t s);
 // LN1 + fused QKV projection at the end of the conv-block kernel (row-local on the owner rows)
 struct QkvFuse {
-    const float *ln_g, *ln_b, *Wpack, *bq, *bk, *bv;
+    const float *ln_g, *ln_b, *bq, *bk, *bv;
     float *h1, *q, *k, *v;
     Drop d1;
 };
 // fused conv block of one encoder application (kernels_enc.hip): 4 layers + LN1 / QKV in one launch, 12-row recomputed halo
 struct CbFwdArgs {
-    const uint16_t* W3[4];         // split packs (PackJob type 6) of the four pointwise weights ; nullptr = fp32-input MFMA path
+    const uint16_t* W3[4];         // split packs (PackJob type 6) of the four pointwise weights
     const uint16_t* Wqkv3;         // split pack of the fused (128, 384) QKV operand
     const float *xin, *pos;
     float* x0_out;
-    const float *ln_g[4], *ln_b[4], *dw_w[4], *Wpack[4], *pw_b[4];
+    const float *ln_g[4], *ln_b[4], *dw_w[4], *pw_b[4];
     float *y[4], *u[4];
     uint32_t* relu_mask[4];
     Drop dp[4];
@@ -149,11 +149,10 @@ struct CbFwdArgs {
 };
 void launch_convblock_fwd(const CbFwdArgs& a, hipStream_t s);
 struct CbBwdArgs {
-    const uint16_t* WT3[4];        // split packs (PackJob type 7) of the pointwise weights' data-gradient operand ; nullptr = fp32-input MFMA path
+    const uint16_t* WT3[4];        // split packs (PackJob type 7) of the pointwise weights' data-gradient operand
     const float* dy;               // (R,128) grad wrt the block output
     const float* x[4];             // LayerNorm inputs of layers 0..3 (x0, y0, y1, y2)
     const uint32_t* relu_mask[4];
-    const float* WTpack[4];        // transpose packs of the pointwise weights
     const float *ln_g[4], *ln_b[4], *dw_w[4];
     Drop dp[4];
     float* gz[4];                  // out (R,128): dz per layer, G operand of the pointwise weight gradients
@@ -216,8 +215,8 @@ void launch_attn_bwd(const float* Q, const float* K, const float* V, const float
                      Drop d3, hipStream_t s);
 int attn_bwd_dq_slabs(int L);             // L > 256: dQ is written as this many (R, 128) partial slabs (one per 256-key block); k_qkv_bwd adds them
 void launch_qkv_bwd(const float* dQ, const float* dK, const float* dV, const float* x, const float* dr,
-                    const float* ln_g, const float* WTpack, float* dx, float* p_lng, float* p_lnb, int R, Drop d1, hipStream_t s,
-                    int dq_slabs = 1, const uint16_t* WT3 = nullptr);      // WT3: split pack of the (384, 128) operand -> bf16 matrix cores
+                    const float* ln_g, const uint16_t* WT3 /* split pack of the (384, 128) operand */, float* dx, float* p_lng, float* p_lnb, int R,
+                    Drop d1, hipStream_t s, int dq_slabs = 1);
 void launch_cqcat_bwd(const float* dg0, const float* dg1, const float* dg2, const float* dh_loss, const float* f2,
                       const float* hscore, const float* wh, const float* W1Tpack, float* df2, float* df1, float* p_wh,
                       float* p_bh, int R, hipStream_t s);
