@@ -645,14 +645,20 @@ void run_forward(Ctx& c) {
             LAUNCH("lstm_gi", launch_linear_bwd_data(c.W(p.lstm[0].out), c.PK(K.l_f[1]), c.W(p.lstm[1].gi), R, 4 * D, c.s));
             lstm(1, 0, T);
         } else {
+            // Three streams (round 4): the end LSTM's input projection of chunk k (a 15 us GEMM) runs on the third stream behind the start
+            // LSTM's chunk k, BESIDE the end LSTM's chunk k - 1 -- on the end LSTM's own stream it made that chain 59 us per chunk against 39
+            // for the start LSTM, and the end LSTM finished 144 us after the start LSTM (profiles/r04_notes.md section 7).
+            hipStream_t sg = c.side(1) != main_s ? c.side(1) : sq;
             int t0 = 0;
             for (int len : lstm_chunks(T, chunk_env)) {
                 const int t1 = t0 + len;
                 lstm(0, t0, t1);
-                c.order(main_s, sq);
-                c.s = sq;
+                c.order(main_s, sg);
+                c.s = sg;
                 LAUNCH("lstm_gi", launch_linear_bwd_data(c.W(p.lstm[0].out), c.PK(K.l_f[1]), c.W(p.lstm[1].gi), B * (t1 - t0), 4 * D, c.s,
                                                          t1 - t0, T, t0));
+                c.order(sg, sq);
+                c.s = sq;
                 lstm(1, t0, t1);
                 c.s = main_s;
                 t0 = t1;
@@ -835,12 +841,15 @@ void run_backward(Ctx& c) {
             } else {
                 hipStream_t main_s = c.s;
                 int t1 = T;
+                hipStream_t sg = sw != main_s ? sw : sq;      // the dx GEMM of a chunk beside the start LSTM's previous chunk (see run_forward)
                 for (int len : lstm_chunks(T, chunk_env)) {
                     const int t0 = t1 - len;
                     bwd(1, t0, t1);
-                    c.order(main_s, sq);
-                    c.s = sq;
+                    c.order(main_s, sg);
+                    c.s = sg;
                     dx(1, t0, t1);
+                    c.order(sg, sq);
+                    c.s = sq;
                     bwd(0, t0, t1);
                     c.s = main_s;
                     t1 = t0;
