@@ -561,16 +561,18 @@ CharConvPtrs char_ptrs(const Ctx& c) {
     return cc;
 }
 
-// Time chunks of the pipelined rnn head (lengths in processing order): ceil(T / chunk) equal chunks.  Measured at T = 128:
-// 4 x 32 steps 3.18 ms/step, 8 x 16 3.26, 2 x 64 3.43, tapering tail (32, 32, 32, 16, 8, 8) 3.33 -- every chunk boundary is a
-// cross-stream wait, and a stream that is already blocked on it wakes up 30 - 40 us after the event fires.
-std::vector<int> lstm_chunks(int T, int chunk) {
-    const int n = (T + chunk - 1) / chunk;
+// Time chunks of the pipelined rnn head (lengths in processing order): n equal chunks.  The second LSTM lags the first by one chunk (T / n steps
+// of ~0.85 us) and every chunk boundary is a cross-stream hop (~15 us on the chain: a stream that is already blocked on an event wakes up late),
+// so n ~ sqrt(0.85 T / 15): 3 chunks at T = 128, 4 at T = 256.  Round 4, with the GEMMs on the third stream, ms per step at B = 16 | 64 for
+// 8 / 6 / 4 / 3 / 2 chunks: 1.072 | 1.255, 1.004 | 1.170, 0.949 | 1.119, 0.928 | 1.113, 0.931 | 1.111.  Measured and dropped (profiles/r04_notes.md
+// section 7): a shorter last chunk (0.950 against 0.938), the start LSTM's own input projection chunked (0.939: nothing), the start LSTM's dx GEMM
+// chunk by chunk on the third stream (1.051: every extra hop costs more than the 7 us GEMM it hides).
+std::vector<int> lstm_chunks(int T) {
+    const int n = std::max(1, (int)std::lround(std::sqrt(0.06 * T)));
     std::vector<int> out;
     for (int i = 0; i < n; ++i) out.push_back((T * (i + 1)) / n - (T * i) / n);
     return out;
 }
-int lstm_chunk_len() { return 32; }
 
 void run_forward(Ctx& c) {
     const vsl_config& cf = c.h->cfg;
@@ -631,8 +633,8 @@ void run_forward(Ctx& c) {
         // The recurrence is latency bound (one 16-sample group per CU, 6.2 us per step), so the two LSTMs are pipelined in
         // TIME CHUNKS: while the start LSTM runs chunk k + 1 on the main stream, the side stream projects its chunk k
         // (x W_ih^T of the end LSTM, a row-mapped GEMM) and runs the end LSTM over it.  A chunk launch resumes from the state
-        // the previous one saved for the backward (h_{t-1}, c_{t-1}).  Chunks of 32 steps (lstm_chunk_len).
-        const int chunk_env = lstm_chunk_len();
+        // the previous one saved for the backward (h_{t-1}, c_{t-1}).  Chunking: lstm_chunks().
+        const std::vector<int> chunks = lstm_chunks(T);
         auto lstm = [&](int l, int t0, int t1) {
             const LstmWs& w = p.lstm[l];
             LAUNCH("lstm_fwd", launch_lstm_fwd(c.W(w.gi), c.P(P.l_whh[l]), c.P(P.l_bih[l]), c.P(P.l_bhh[l]), io.v_mask, c.W(w.gates),
@@ -640,7 +642,7 @@ void run_forward(Ctx& c) {
         };
         LAUNCH("lstm_gi", launch_linear_bwd_data(c.W(p.gated), c.PK(K.l_f[0]), c.W(p.lstm[0].gi), R, 4 * D, c.s));   // (R,128) x (128,512), no bias
         hipStream_t main_s = c.s;
-        if (chunk_env <= 0 || chunk_env >= T || sq == main_s) {
+        if (chunks.size() < 2 || sq == main_s) {
             lstm(0, 0, T);
             LAUNCH("lstm_gi", launch_linear_bwd_data(c.W(p.lstm[0].out), c.PK(K.l_f[1]), c.W(p.lstm[1].gi), R, 4 * D, c.s));
             lstm(1, 0, T);
@@ -650,7 +652,7 @@ void run_forward(Ctx& c) {
             // for the start LSTM, and the end LSTM finished 144 us after the start LSTM (profiles/r04_notes.md section 7).
             hipStream_t sg = c.side(1) != main_s ? c.side(1) : sq;
             int t0 = 0;
-            for (int len : lstm_chunks(T, chunk_env)) {
+            for (int len : chunks) {
                 const int t1 = t0 + len;
                 lstm(0, t0, t1);
                 c.order(main_s, sg);
@@ -818,7 +820,7 @@ void run_backward(Ctx& c) {
         //      Pipelined in time chunks like the forward (run_forward): the end LSTM walks the chunks backwards on the main
         //      stream; behind it the side stream turns the chunk's gate gradients into the start LSTM's incoming gradient
         //      (dx = dG W_ih, row-mapped GEMM) and runs the start LSTM over the same chunk.
-        const int chunk_env = lstm_chunk_len();
+        const std::vector<int> chunks = lstm_chunks(T);
         auto bwd = [&](int l, int t0, int t1) {
             const LstmWs& w = p.lstm[l];
             const float* d1 = c.dry ? nullptr : c.W(l ? p.dfeat_e : p.dfeat_s);
@@ -834,7 +836,7 @@ void run_backward(Ctx& c) {
             LAUNCH("lstm_dx", launch_vproj_fwd3(c.W(w.dG), reinterpret_cast<const uint16_t*>(c.PK(K.l_t3[l])), c.PK(K.zero128), c.W(l ? p.g_s1 : p.g_gated),
                                                all ? R : B * (t1 - t0), 4 * D, Drop{0u, 0u, 1.f}, c.s, false, all ? 0 : t1 - t0, T, t0));
         };
-        const bool piped = !c.dry && chunk_env > 0 && chunk_env < T && sq != c.s;
+        const bool piped = !c.dry && chunks.size() >= 2 && sq != c.s;
         if (!c.dry) {
             if (!piped) {
                 bwd(1, 0, T); dx(1, 0, T); bwd(0, 0, T); dx(0, 0, T);
@@ -842,7 +844,7 @@ void run_backward(Ctx& c) {
                 hipStream_t main_s = c.s;
                 int t1 = T;
                 hipStream_t sg = sw != main_s ? sw : sq;      // the dx GEMM of a chunk beside the start LSTM's previous chunk (see run_forward)
-                for (int len : lstm_chunks(T, chunk_env)) {
+                for (int len : chunks) {
                     const int t0 = t1 - len;
                     bwd(1, t0, t1);
                     c.order(main_s, sg);
