@@ -48,7 +48,7 @@ struct ModelP {
     int l_wih[2], l_whh[2], l_bih[2], l_bhh[2];     // rnn predictor: start / end DynamicRNN (layers_t7.py:302-313)
 };
 struct ModelPk { int va_f, va_f16, va_f3, l_t3[2], emb_f, emb_t, emb_f3, emb_t3, emb_t3_cols; EncPk fe, pe; int cqa_f, cqa_t, cat1_f, cat1_t, s0_f, s0_t, e0_f, e0_t, ccw_img, ccw_imgb;
-                 int l_f[2], l_t[2], zero128; };
+                 int l_f3[2], l_t[2], zero128; };
 
 struct EncWs { int64_t x0, y[4], u[4], mask[4], h1, q, k, v, lse, att, r, h2, out; int R, L; };
 
@@ -309,7 +309,7 @@ void build_packs(vsl_handle_s* h) {
     build_encoder_packs(pk, h, P.fe, K.fe);
     if (c.predictor == 0) {
         for (int l = 0; l < 2; ++l) {
-            K.l_f[l] = pk.fwd(P.l_wih[l], 4 * D, D, D);      // gi = x W_ih^T  : (R,128) x (128,512)
+            K.l_f3[l] = pk.fwd3(P.l_wih[l], 4 * D, D, D);    // gi = x W_ih^T  : (R,128) x (128,512), split pack
             K.l_t[l] = pk.tr(P.l_wih[l], 4 * D, D, D);       // dx = dG W_ih   : (R,512) x (512,128)
             K.l_t3[l] = pk.tr3(P.l_wih[l], 4 * D, D, D, 128);
         }
@@ -640,11 +640,15 @@ void run_forward(Ctx& c) {
             LAUNCH("lstm_fwd", launch_lstm_fwd(c.W(w.gi), c.P(P.l_whh[l]), c.P(P.l_bih[l]), c.P(P.l_bhh[l]), io.v_mask, c.W(w.gates),
                                                c.W(w.cseq), c.W(w.hprev), c.W(w.out), B, T, c.s, t0, t1));
         };
-        LAUNCH("lstm_gi", launch_linear_bwd_data(c.W(p.gated), c.PK(K.l_f[0]), c.W(p.lstm[0].gi), R, 4 * D, c.s));   // (R,128) x (128,512), no bias
+        // gate projections gi = x W_ih^T: (rows,128) x (128,512), no bias, bf16x6 on the matrix cores
+        auto gi = [&](int l, const float* x, int rows, int seg = 0, int off = 0) {
+            LAUNCH("lstm_gi", launch_linear_fwd3(x, reinterpret_cast<const uint16_t*>(c.PK(K.l_f3[l])), nullptr, c.W(p.lstm[l].gi), rows, D, c.s, 4 * D, seg, T, off));
+        };
+        gi(0, c.W(p.gated), R);
         hipStream_t main_s = c.s;
         if (chunks.size() < 2 || sq == main_s) {
             lstm(0, 0, T);
-            LAUNCH("lstm_gi", launch_linear_bwd_data(c.W(p.lstm[0].out), c.PK(K.l_f[1]), c.W(p.lstm[1].gi), R, 4 * D, c.s));
+            gi(1, c.W(p.lstm[0].out), R);
             lstm(1, 0, T);
         } else {
             // Three streams (round 4): the end LSTM's input projection of chunk k (a 15 us GEMM) runs on the third stream behind the start
@@ -657,8 +661,7 @@ void run_forward(Ctx& c) {
                 lstm(0, t0, t1);
                 c.order(main_s, sg);
                 c.s = sg;
-                LAUNCH("lstm_gi", launch_linear_bwd_data(c.W(p.lstm[0].out), c.PK(K.l_f[1]), c.W(p.lstm[1].gi), B * (t1 - t0), 4 * D, c.s,
-                                                         t1 - t0, T, t0));
+                gi(1, c.W(p.lstm[0].out), B * (t1 - t0), t1 - t0, t0);
                 c.order(sg, sq);
                 c.s = sq;
                 lstm(1, t0, t1);

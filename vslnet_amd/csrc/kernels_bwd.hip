@@ -1462,54 +1462,6 @@ void launch_cq_bwd_query(const CqBwdArgs& a0, int B, hipStream_t s) {
 }
 
 // =========================================================================================================
-// generic data gradient  dA (R, K) = G (R, 128) W   (transpose pack, ncols = K) ; used for a5 (K = 400)
-// =========================================================================================================
-// Optional row map (seg > 0): logical row r of the launch is physical row (r / seg) * stride + off + r % seg of G and dA --
-// the rows of one TIME CHUNK of a (B, T, .) tensor (seg = chunk length, stride = T, off = first step), which lets the
-// recurrent kernels of the rnn head be pipelined chunk by chunk.
-__global__ __launch_bounds__(256) void k_linear_bwd_data(const float* __restrict__ G, const float* __restrict__ WTpack,
-                                                         float* __restrict__ dA, int R, int K, int seg, int stride, int off) {
-    __shared__ __attribute__((aligned(16))) float Gs[TILE_M * LDP];
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const int r0 = blockIdx.x * TILE_M;
-    auto phys = [&](int r) { return seg > 0 ? (r / seg) * stride + off + r % seg : r; };
-    if (seg > 0) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int e = tid + q * 256, rr = e >> 5, r = r0 + rr;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < R) v = *reinterpret_cast<const float4*>(G + (size_t)phys(r) * D + (e & 31) * 4);
-            *reinterpret_cast<float4*>(Gs + rr * LDP + (e & 31) * 4) = v;
-        }
-    } else load_tile128(Gs, G, r0, TILE_M, R);
-    __syncthreads();
-    for (int cb = 0; cb < K; cb += 512) {
-        f32x16 acc[4];
-        zero_acc(acc);
-        {
-            BFrag<4, 4> bf;
-            bfrag_load(bf, WTpack, K, cb + 32 * w, D, 0, D / 8);
-            gemm32p<4, 4>(Gs, LDP, D, WTpack, K, cb + 32 * w, D, acc, bf);
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int col = cb + 32 * w + t * D + (lane & 31);
-            if (col < K) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int gr = r0 + acc_row(r, lane);
-                    if (gr < R) dA[(size_t)phys(gr) * K + col] = acc[t][r];
-                }
-            }
-        }
-    }
-}
-void launch_linear_bwd_data(const float* G, const float* WTpack, float* dA, int R, int K, hipStream_t s, int seg, int stride,
-                            int off) {
-    VSL_LAUNCH(k_linear_bwd_data, dim3((R + TILE_M - 1) / TILE_M), dim3(256), 0, s, G, WTpack, dA, R, K, seg, stride, off);
-}
-
-// =========================================================================================================
 // a3 / a4 backward: unk_vec gradient, char-CNN weights / biases, char table (padding_idx = 0 gets none).
 //   One workgroup of 8 waves per `chunk` query words (embed_bwd_chunk: as many as keep the grid inside one round of the 256 CUs);
 //   the rows (word, position) of the chunk are packed densely.  Nothing here is sized by char_dim beyond an LDS row stride of 64

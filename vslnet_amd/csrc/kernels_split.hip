@@ -276,21 +276,26 @@ void launch_qkv_bwd(const float* dQ, const float* dK, const float* dV, const flo
 // dA = G W.  The query side is 40 row tiles at the headline shape -- pure latency -- and sits on the critical path of both directions
 // (forward: ahead of the query encoder pass; backward: the tail of the step), so both kernels stage their WHOLE tile once, split it into
 // bf16 planes on the way (one barrier) and run the product on the bf16 matrix cores.  fp32-input versions: k_linear_fwd (K streamed in four
-// chunks with two barriers each, 16.6 us) and k_linear_bwd_data (16.0 us), still used by the rnn head's gate projections.
+// chunks with two barriers each, 16.6 us), kept for widths that are not multiples of 16.  Round 4: the rnn head's gate projections
+// (128 -> 512, four column blocks per row tile) moved here from the fp32-input k_linear_bwd_data (15 us per launch whatever its size: 6.8 us of fp32 MFMA per wave).
 // =========================================================================================================
+// blockIdx.y = 128-column block of an operand with `ncols` columns (the rnn head's gate projection x W_ih^T: ncols = 512, no bias, output rows of
+// leading dimension ldy); seg > 0: logical row r is physical row (r / seg) * stride + off + r % seg of A and Y -- the rows of one TIME CHUNK of a
+// (B, T, .) tensor, which lets the recurrent kernels of the rnn head be pipelined chunk by chunk.
 __global__ __launch_bounds__(256) void k_linear_fwd3(const float* __restrict__ A, const uint16_t* __restrict__ W3, const float* __restrict__ bias,
-                                                     float* __restrict__ Y, int R, int K, int ldb) {
+                                                     float* __restrict__ Y, int R, int K, int ldb, int ncols, int ldy, int seg, int stride, int off) {
     extern __shared__ __attribute__((aligned(16))) uint16_t pl[];     // three planes [32][ldb]
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const int r0 = blockIdx.x * TILE_M, k4 = K >> 2;
+    const int r0 = blockIdx.x * TILE_M, k4 = K >> 2, cb = blockIdx.y * D;
+    auto phys = [&](int r) { return seg > 0 ? (r / seg) * stride + off + r % seg : r; };
     Ring3<1> ring;
-    ring3_prefetch<1>(ring, W3, K, D, 32 * w, 0);                    // weight fragments first: in flight during the staging
+    ring3_prefetch<1>(ring, W3, K, ncols, cb + 32 * w, 0);           // weight fragments first: in flight during the staging
     constexpr int MAXQ = 16;                                         // K <= 512: the whole tile in ONE round of loads (one memory latency)
     float4 v[MAXQ];
 #pragma unroll
     for (int q = 0; q < MAXQ; ++q) {
         const int e = tid + q * 256, rr = e / k4, c = (e - rr * k4) * 4;
-        v[q] = (e < TILE_M * k4 && r0 + rr < R) ? *reinterpret_cast<const float4*>(A + (size_t)(r0 + rr) * K + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[q] = (e < TILE_M * k4 && r0 + rr < R) ? *reinterpret_cast<const float4*>(A + (size_t)phys(r0 + rr) * K + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int q = 0; q < MAXQ; ++q) {
@@ -300,23 +305,24 @@ __global__ __launch_bounds__(256) void k_linear_fwd3(const float* __restrict__ A
     __syncthreads();
     f32x16 acc[1];
     zero_acc(acc);
-    gemm32pl<1>(pl, ldb, TILE_M * ldb, K, W3, D, 32 * w, 0, acc, ring);
-    const int col = 32 * w + (lane & 31);
-    const float bv = bias[col];
+    gemm32pl<1>(pl, ldb, TILE_M * ldb, K, W3, ncols, cb + 32 * w, 0, acc, ring);
+    const int col = cb + 32 * w + (lane & 31);
+    const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int gr = r0 + acc_row(r, lane);
-        if (gr < R) Y[(size_t)gr * D + col] = acc[0][r] + bv;
+        if (gr < R) Y[(size_t)phys(gr) * ldy + col] = acc[0][r] + bv;
     }
 }
 static int plane_ld(int K) { int l = K + 8; while (((l / 8) & 1) == 0) l += 8; return l; }      // row stride / 16 bytes odd: conflict-free b128 reads
-void launch_linear_fwd3(const float* A, const uint16_t* W3, const float* bias, float* Y, int R, int K, hipStream_t s) {
-    if (K > 512 || K % 16) { fprintf(stderr, "[vslnet_hip] launch_linear_fwd3: K=%d unsupported\n", K); return; }
+void launch_linear_fwd3(const float* A, const uint16_t* W3, const float* bias, float* Y, int R, int K, hipStream_t s, int ncols, int seg, int stride,
+                        int off) {
+    if (K > 512 || K % 16 || ncols % D) { fprintf(stderr, "[vslnet_hip] launch_linear_fwd3: K=%d ncols=%d unsupported\n", K, ncols); return; }
     const int ldb = plane_ld(K);
     const size_t shm = (size_t)3 * TILE_M * ldb * sizeof(uint16_t);
     static size_t ok = 0;
     ensure_dynamic_lds((const void*)k_linear_fwd3, shm, ok, "k_linear_fwd3");
-    VSL_LAUNCH(k_linear_fwd3, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm, s, A, W3, bias, Y, R, K, ldb);
+    VSL_LAUNCH(k_linear_fwd3, dim3((R + TILE_M - 1) / TILE_M, ncols / D), dim3(256), shm, s, A, W3, bias, Y, R, K, ldb, ncols, ncols, seg, stride, off);
 }
 // dA (R, K) = G (R, 128) Bm, Bm = split transpose pack with ncols = Kc >= K columns (Kc a multiple of 128: whole column tiles)
 __global__ __launch_bounds__(256) void k_linear_bwd_data3(const float* __restrict__ G, const uint16_t* __restrict__ WT3, float* __restrict__ dA,

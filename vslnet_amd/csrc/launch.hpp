@@ -121,8 +121,9 @@ void launch_vproj_fwd_bf16(const uint16_t* X, const uint16_t* Wpack16, const flo
 // fp32-grade on the bf16 matrix cores (kernels_split.hip): W3 = split pack (PackJob type 6 / 7) of the (Dv, 128) operand
 // one_product: vsl_io.arithmetic == 1 for the call being enqueued (operands rounded to bfloat16, one product per product)
 void launch_vproj_fwd3(const float* X, const uint16_t* W3, const float* bias, float* Y, int R, int Dv, Drop dp, hipStream_t s,
-                       bool one_product = false, int seg = 0, int stride = 0, int off = 0);   // seg > 0: rows of one time chunk (see launch_linear_bwd_data)
-void launch_linear_fwd3(const float* A, const uint16_t* W3, const float* bias, float* Y, int R, int K, hipStream_t s);
+                       bool one_product = false, int seg = 0, int stride = 0, int off = 0);   // seg > 0: rows of one time chunk (see launch_linear_fwd3)
+void launch_linear_fwd3(const float* A, const uint16_t* W3, const float* bias /* nullable */, float* Y, int R, int K, hipStream_t s, int ncols = 128,
+                        int seg = 0, int stride = 0, int off = 0);      // ncols: columns of the operand and of Y's rows; seg > 0: rows of one time chunk of a (B, T, .) tensor
 void launch_linear_bwd_data3(const float* G, const uint16_t* WT3, float* dA, int R, int K, int Kc, hipStream_t s);   // Kc: columns of the split pack
 void launch_embed_fwd(const int64_t* word_ids, const int64_t* char_ids, const float* pad_vec, const float* unk_vec,
                       const float* glove, const float* char_tab, CharConvPtrs cc, const float* wimg, float* E, int8_t* argpos,
@@ -239,8 +240,6 @@ struct CqBwdArgs {
 };
 void launch_cq_bwd(const CqBwdArgs& a, int B, hipStream_t s);          // kernels a, b, c: dC final, dQ partials
 void launch_cq_bwd_query(const CqBwdArgs& a, int B, hipStream_t s);    // kernel d: dQ + pooled-query parameters
-void launch_linear_bwd_data(const float* G, const float* WTpack, float* dA, int R, int K, hipStream_t s, int seg = 0, int stride = 0,
-                            int off = 0);      // seg > 0: rows of one time chunk of a (B, T, .) tensor
 void launch_embed_bwd(const float* dE, const int64_t* word_ids, const int64_t* char_ids, const float* E,
                       const int8_t* argpos, const float* char_tab, const float* wimg_b /* type-8 pack */,
                       float* p_cw /*[nchunk][300 char_dim]*/,
