@@ -48,11 +48,11 @@ struct ModelP {
     int l_wih[2], l_whh[2], l_bih[2], l_bhh[2];     // rnn predictor: start / end DynamicRNN (layers_t7.py:302-313)
 };
 struct ModelPk { int va_f, va_f16, va_f3, l_t3[2], emb_f, emb_t, emb_f3, emb_t3, emb_t3_cols; EncPk fe, pe; int cqa_f, cqa_t, cat1_f, cat1_t, s0_f, s0_t, e0_f, e0_t, ccw_img, ccw_imgb;
-                 int l_f3[2], l_t[2], zero128; };
+                 int l_f3[2], l_t[2], l_hf[2], l_hb[2], zero128; };
 
 struct EncWs { int64_t x0, y[4], u[4], mask[4], h1, q, k, v, lse, att, r, h2, out; int R, L; };
 
-struct LstmWs { int64_t gi, gates, cseq, hprev, out, dG, carry; };   // one DynamicRNN: x W_ih^T, activated gates, c_t, h_{t-1}, h * mask, gate grads, (B,2,128) dc/dh hand-over between time chunks
+struct LstmWs { int64_t gi, gates, cseq, tseq, hprev, out, dG, carry; };   // one DynamicRNN: x W_ih^T, activated gates, c_t, tanh(c_t), h_{t-1}, h * mask, gate grads, (B,2,128) dc/dh hand-over between time chunks
 
 struct EncTmp { int64_t dr, dq, dk, dv, go, gz[4], ga; };   // backward temporaries of one encoder application
 
@@ -312,6 +312,11 @@ void build_packs(vsl_handle_s* h) {
             K.l_f3[l] = pk.fwd3(P.l_wih[l], 4 * D, D, D);    // gi = x W_ih^T  : (R,128) x (128,512), split pack
             K.l_t[l] = pk.tr(P.l_wih[l], 4 * D, D, D);       // dx = dG W_ih   : (R,512) x (512,128)
             K.l_t3[l] = pk.tr3(P.l_wih[l], 4 * D, D, D, 128);
+            for (int bw = 0; bw < 2; ++bw) {                 // W_hh in the register order of k_lstm1_fwd / k_lstm1_bwd
+                (bw ? K.l_hb : K.l_hf)[l] = (int)h->pack_floats;
+                h->jobs.push_back(PackJob{P.l_whh[l], (int)h->pack_floats, LSTM_IMG_FLOATS, 1, 0, 9 + bw, 1, 0, 0});
+                h->pack_floats += LSTM_IMG_FLOATS;
+            }
         }
         K.zero128 = (int)h->pack_floats;                    // a zero bias vector for the bias-less GEMM above
         h->pack_floats += D;
@@ -637,8 +642,8 @@ void run_forward(Ctx& c) {
         const std::vector<int> chunks = lstm_chunks(T);
         auto lstm = [&](int l, int t0, int t1) {
             const LstmWs& w = p.lstm[l];
-            LAUNCH("lstm_fwd", launch_lstm_fwd(c.W(w.gi), c.P(P.l_whh[l]), c.P(P.l_bih[l]), c.P(P.l_bhh[l]), io.v_mask, c.W(w.gates),
-                                               c.W(w.cseq), c.W(w.hprev), c.W(w.out), B, T, c.s, t0, t1));
+            LAUNCH("lstm_fwd", launch_lstm_fwd(c.W(w.gi), c.P(P.l_whh[l]), c.PK(K.l_hf[l]), c.P(P.l_bih[l]), c.P(P.l_bhh[l]), io.v_mask, c.W(w.gates),
+                                               c.W(w.cseq), c.W(w.tseq), c.W(w.hprev), c.W(w.out), B, T, c.s, t0, t1));
         };
         // gate projections gi = x W_ih^T: (rows,128) x (128,512), no bias, bf16x6 on the matrix cores
         auto gi = [&](int l, const float* x, int rows, int seg = 0, int off = 0) {
@@ -828,8 +833,8 @@ void run_backward(Ctx& c) {
             const LstmWs& w = p.lstm[l];
             const float* d1 = c.dry ? nullptr : c.W(l ? p.dfeat_e : p.dfeat_s);
             const float* d2 = (c.dry || l) ? nullptr : c.W(p.g_s1);
-            LAUNCH("lstm_bwd", launch_lstm_bwd(d1, d2, io->v_mask, c.W(w.gates), c.W(w.cseq), c.P(P.l_whh[l]), c.W(w.dG), B, T, c.s,
-                                               c.W(w.carry), t0, t1));
+            LAUNCH("lstm_bwd", launch_lstm_bwd(d1, d2, io->v_mask, c.W(w.gates), c.W(w.cseq), c.W(w.tseq), c.P(P.l_whh[l]), c.PK(K.l_hb[l]), c.W(w.dG),
+                                               B, T, c.s, c.W(w.carry), t0, t1));
         };
         // dx = dG W_ih : (rows,512) x (512,128), K-streamed GEMM kernel of the visual projection, no dropout, zero bias
         auto dx = [&](int l, int t0, int t1) {
@@ -1052,7 +1057,7 @@ int build_plan(vsl_handle_s* h, int B, int T, int Lq, int Lc, Plan** out) {
         p->p1.R = p->p2.R = (int)R; p->p1.L = p->p2.L = T;
         for (int l = 0; l < 2; ++l) {
             LstmWs& w = p->lstm[l];
-            w.gi = al(R * 4 * D); w.gates = al(R * 4 * D); w.cseq = al(R * D); w.hprev = al(R * D); w.out = al(R * D); w.dG = al(R * 4 * D);
+            w.gi = al(R * 4 * D); w.gates = al(R * 4 * D); w.cseq = al(R * D); w.tseq = al(R * D); w.hprev = al(R * D); w.out = al(R * D); w.dG = al(R * 4 * D);
             w.carry = al((int64_t)B * 2 * D);
         }
         p->p1.out = p->lstm[0].out; p->p2.out = p->lstm[1].out;

@@ -1819,12 +1819,6 @@ void launch_reduce(const float* partial, float* grads, const ReduceSeg* segs_dev
     VSL_LAUNCH(k_reduce, dim3(nblocks), dim3(256), 0, s, partial, grads, segs_dev, blk2seg_dev);
 }
 
-void launch_lstm_bwd(const float* dout, const float* dout2, const float* mask, const float* gates, const float* cseq,
-                     const float* Whh, float* dG, int B, int T, hipStream_t s, float* carry, int t0, int t1) {
-    if (t1 < 0) t1 = T;
-    launch_lstm4_bwd(dout, dout2, mask, gates, cseq, Whh, dG, B, T, s, carry, t0, t1);
-}
-
 // =========================================================================================================
 // optimizer step on the flat buckets (main_t7.py:111-112, VSLNet_t7.py:8-17): HBM-bound, 5 streams of n floats.
 //   k_sqsum : OPT_BLOCKS partial sums of grads^2 (grid-stride, float4), fixed summation order

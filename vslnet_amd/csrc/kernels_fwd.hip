@@ -92,6 +92,15 @@ __global__ __launch_bounds__(256) void k_pack(const float* __restrict__ params, 
             if (ocl >= 0 && ocl < j.k_off) pack[j.dst + e] = (ci < cd && kk < kw) ? params[j.src + (ocl * cd + ci) * kw + kk] : 0.f;
             continue;
         }
+        if (j.transpose == 9 || j.transpose == 10) {     // W_hh (512, 128) in the register order of the one-sample LSTM kernels: [wave][float4 q][lane][x]
+            const int x = e & 3, ln = (e >> 2) & 63, q = (e >> 8) & 31, wv = e >> 13;
+            const int u = 16 * wv + (ln >> 2), jj = ln & 3;
+            // forward: gate (jj ^ x) of unit u at k = 32 jj + q ; backward: gate row 32 (ln & 15) + q, column of unit 16 wv + 4 (ln >> 4) + (quad ^ x)
+            const int src = j.transpose == 9 ? ((jj ^ x) * D + u) * D + 32 * jj + q
+                                             : (32 * (ln & 15) + q) * D + 16 * wv + 4 * (ln >> 4) + (((ln >> 2) & 3) ^ x);
+            pack[j.dst + e] = params[j.src + src];
+            continue;
+        }
         if (j.transpose == 4) {     // zero fill of kn * cn floats
             pack[j.dst + e] = 0.f;
             continue;
@@ -1189,13 +1198,6 @@ void launch_head_fwd(const HeadArgs& a0, const HeadArgs& a1, const float* x, con
         const size_t shm_sp = shm;
         VSL_LAUNCH(k_head_fwd, dim3((R + TILE_M - 1) / TILE_M, 2), dim3(256), shm_sp, s, a0, a1, x, vmask, R);
     }
-}
-
-// a15 DynamicRNN: the recurrence lives in kernels_lstm.hip (one-sample workgroups up to B = 256, 4-sample MFMA groups beyond)
-void launch_lstm_fwd(const float* gi, const float* Whh, const float* bih, const float* bhh, const float* mask, float* gates,
-                     float* cseq, float* hprev, float* out, int B, int T, hipStream_t s, int t0, int t1) {
-    if (t1 < 0) t1 = T;
-    launch_lstm4_fwd(gi, Whh, bih, bhh, mask, gates, cseq, hprev, out, B, T, s, t0, t1);
 }
 
 }  // namespace vsl

@@ -177,149 +177,241 @@ __global__ __launch_bounds__(512, 2) void k_lstm4_bwd(const float* __restrict__ 
 // =========================================================================================================
 // One-sample workgroups: the same recurrence on the VECTOR pipe.  A 4-sample group pays the full 128 x 512 product on one CU's matrix
 // cores every step (2.1 k cycles -- three quarters of the 4 x 4 tiles' rows are all a small batch has to offer anyway); one sample per
-// workgroup needs 128 packed FMAs per lane (v_pk_fma_f32, 512 cycles per SIMD per step) and spreads configs[0]'s B = 16 over 16 CUs.
-//   lane (u = 16 w + b, j): gate column j * 128 + u, W_hh row in 128 registers; h is read from LDS as wave-uniform broadcasts.
-//   the four gates of a unit sit in one quad: each lane activates ITS gate (tanh(x) = 2 sigmoid(2x) - 1, the same formula tanh_fast
-//   uses), DPP quad broadcasts hand all four to every lane, the cell update is computed redundantly by the quad -- no LDS transposition.
-//   backward: lane (u, j) contracts gate rows 128 j .. + 127 into column u and the quad adds its four slices with DPP: one LDS
-//   exchange (the step's 512 gate gradients) and one barrier per step; everything a step loads is fetched a step ahead.
-//   (Tried: h through DPP row_newbcast into v_fmac_f32_dpp -- 2 LDS reads per lane and step instead of 32 -- is no faster: 128 vs 118 us,
-//   the DPP FMAs issue at half rate; profiles/r02_notes.md.)
-// Used for B <= 256 (VSL_LSTM1=0 keeps the 4-sample kernels); saved tensors, chunk / carry interface identical.
+// workgroup needs 64 packed FMAs per lane (v_pk_fma_f32) and spreads configs[0]'s B = 16 over 16 CUs.
+//
+// A step is bound by VALU ISSUE: two waves per SIMD, every instruction of either costs the SIMD 4 cycles (16 for exp / rcp), and the
+// barrier keeps all eight waves in lockstep -- 2 x 64 FMAs = 512 cycles that cannot shrink, plus 8 cycles for every other instruction
+// of the step, plus the LDS exchange (write, barrier, read latency: ~300 cycles in which nothing issues).  tools/ubench/lstm_harness.hip
+// takes the step apart (profiles/r04_notes.md section 8).  So the step is built to need few instructions besides the FMAs:
+//   * a lane owns a QUARTER of the contraction for FOUR outputs (8 ds_read_b128 of the shared operand per step instead of 32 for one
+//     output over the whole contraction), accumulated as two packed pairs: {out a, out b} += {x_k, x_k} * {W_a[k], W_b[k]} (op_sel
+//     broadcasts x_k) -- no horizontal adds;
+//   * register r of a lane holds output (own ^ r): the partial that lane (own ^ d) needs is every lane's register d, so the
+//     transposing reductions are plain DPP adds, no selects;
+//   * the weights come from an image k_pack lays out in register order (PackJob types 9 / 10): 32 coalesced 16-byte loads per lane
+//     (1.7 us per launch instead of 6.4 for strided rows) straight into the register pairs;
+//   * sigmoid / tanh through v_exp_f32 + v_rcp_f32 (1 ulp) instead of an IEEE division; the forward saves tanh(c_t) for the backward
+//     in the store slot of the quad's fourth lane, the backward's per-step factors are computed while the LDS reads are in flight;
+//   * memory: inputs are prefetched a block of L1_NB steps ahead, the mask once per block (lane j of a quad holds step j's), a
+//     step's stores are issued during the next step's LDS reads.
+//   forward : quad (u = 16 w + b) = the four gates of unit u, lane j contracts k in [32 j, 32 j + 32); after the reduction lane j holds
+//             gate j and activates it (tanh(x) = 2 sigmoid(2x) - 1), quad broadcasts hand all four to every lane, the cell update is
+//             computed redundantly by the quad -- no LDS transposition.
+//   backward: a DPP row (16 lanes = 4 quads) owns the columns of its four units; lane m of the row contracts gate rows [32 m, 32 m + 32)
+//             into them; row_mirror / row_half_mirror reduce across the quads (quad i keeps column i), two quad adds finish it: every
+//             lane of unit u's quad holds dh_{t-1}[u].  One LDS exchange and one barrier per step.
+//   h and the gate gradients sit in LDS as 32-float segments on a 36-float stride (the quarter / sixteenth a lane reads).
+//   (Tried: h through DPP row_newbcast into v_fmac_f32_dpp -- no LDS reads at all -- is no faster: the DPP FMAs issue at half rate;
+//   profiles/r02_notes.md.)
+// Used for B <= 256 (VSL_LSTM1=0 keeps the 4-sample kernels, which read W_hh itself); saved tensors, chunk / carry interface identical,
+// plus tseq = tanh(c_t).
 // =========================================================================================================
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int L1_SEG = 36;              // LDS stride of a 32-float segment
+constexpr int L1_NB = 4;                // steps per block of prefetched inputs
 template <int I> __device__ __forceinline__ float quad_bcast(float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), I * 0x55, 0xF, 0xF, false));
 }
+template <int CTRL> __device__ __forceinline__ float dpp_get(float x) {      // 0xB1: lane ^ 1, 0x4E: lane ^ 2, 0x1B: lane ^ 3, 0x140: row mirror, 0x141: half-row mirror
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false));
+}
+constexpr float L1_LOG2E = 1.4426950408889634f;
+__device__ __forceinline__ float sigmoid_rcp(float x, float nk) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * nk)); }    // nk = -log2(e): sigmoid(x)
+__device__ __forceinline__ void lstm1_weights(const float* __restrict__ img, int w, int lane, f32x2 (&w01)[32], f32x2 (&w23)[32]) {
+    const float4* p = reinterpret_cast<const float4*>(img) + (size_t)(w * 32) * 64 + lane;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) { const float4 v = p[q * 64]; w01[q] = f32x2{v.x, v.y}; w23[q] = f32x2{v.z, v.w}; }
+}
+// {o0, o1} += x_k {W_0[k], W_1[k]} and {o2, o3} likewise over the lane's 32 contraction indices (8 float4 of the shared operand)
+__device__ __forceinline__ void lstm1_product(const float4 (&x)[8], const f32x2 (&w01)[32], const f32x2 (&w23)[32], f32x2& s01, f32x2& s23) {
+    f32x2 a01[2], a23[2];
+    a01[0] = a01[1] = a23[0] = a23[1] = f32x2{0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        a01[0] = __builtin_elementwise_fma(f32x2{x[q].x, x[q].x}, w01[4 * q], a01[0]);
+        a23[0] = __builtin_elementwise_fma(f32x2{x[q].x, x[q].x}, w23[4 * q], a23[0]);
+        a01[1] = __builtin_elementwise_fma(f32x2{x[q].y, x[q].y}, w01[4 * q + 1], a01[1]);
+        a23[1] = __builtin_elementwise_fma(f32x2{x[q].y, x[q].y}, w23[4 * q + 1], a23[1]);
+        a01[0] = __builtin_elementwise_fma(f32x2{x[q].z, x[q].z}, w01[4 * q + 2], a01[0]);
+        a23[0] = __builtin_elementwise_fma(f32x2{x[q].z, x[q].z}, w23[4 * q + 2], a23[0]);
+        a01[1] = __builtin_elementwise_fma(f32x2{x[q].w, x[q].w}, w01[4 * q + 3], a01[1]);
+        a23[1] = __builtin_elementwise_fma(f32x2{x[q].w, x[q].w}, w23[4 * q + 3], a23[1]);
+    }
+    s01 = a01[0] + a01[1];
+    s23 = a23[0] + a23[1];
+}
 
-__global__ __launch_bounds__(512, 2) void k_lstm1_fwd(const float* __restrict__ gi, const float* __restrict__ Whh,
+// Wimg: PackJob type 9 image of W_hh.  Lane (u, j), float4 q = W_hh[(j ^ x) * 128 + u][32 j + q] for x = 0 .. 3.
+__global__ __launch_bounds__(512, 2) void k_lstm1_fwd(const float* __restrict__ gi, const float* __restrict__ Wimg,
                                                       const float* __restrict__ bih, const float* __restrict__ bhh,
                                                       const float* __restrict__ mask, float* __restrict__ gates,
-                                                      float* __restrict__ cseq, float* __restrict__ hprev, float* __restrict__ out,
-                                                      int T, int t0, int t1) {
-    __shared__ __attribute__((aligned(16))) float hs[2][D];
+                                                      float* __restrict__ cseq, float* __restrict__ tseq, float* __restrict__ hprev,
+                                                      float* __restrict__ out, int T, int t0, int t1) {
+    __shared__ __attribute__((aligned(16))) float hs[2][4 * L1_SEG];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int b = lane >> 2, j = lane & 3;
     const int u = 16 * w + b;
     const int row = blockIdx.x * T;
-    f32x2 wr[D / 2];                                      // W_hh[j * 128 + u][0 .. 127]
-    {
-        const float4* p = reinterpret_cast<const float4*>(Whh + (size_t)(j * D + u) * D);
-#pragma unroll
-        for (int q = 0; q < D / 4; ++q) { const float4 v = p[q]; wr[2 * q] = f32x2{v.x, v.y}; wr[2 * q + 1] = f32x2{v.z, v.w}; }
-    }
+    const int hoff = (u >> 5) * L1_SEG + (u & 31);
+    f32x2 w01[32], w23[32];
+    lstm1_weights(Wimg, w, lane, w01, w23);
     const float bs = bih[j * D + u] + bhh[j * D + u];
-    const float sc = j == 2 ? 2.0f : 1.0f;               // gate 2 is the tanh gate
+    const float nk = j == 2 ? -2.0f * L1_LOG2E : -L1_LOG2E;                  // gate 2 is the tanh gate: 2 sigmoid(2 z) - 1
+    const float ma = j == 2 ? 2.0f : 1.0f, mb = j == 2 ? -1.0f : 0.0f;
     float cst = t0 > 0 ? cseq[(unsigned)((row + t0 - 1) * D + u)] : 0.f;
-    if (j == 0) hs[t0 & 1][u] = t0 > 0 ? hprev[(unsigned)((row + t0) * D + u)] : 0.f;
+    if (j == 0) hs[t0 & 1][hoff] = t0 > 0 ? hprev[(unsigned)((row + t0) * D + u)] : 0.f;     // (h_{-1} = 0: step 0's product is 0)
     if (j == 3 && t0 == 0) hprev[(unsigned)(row * D + u)] = 0.f;
-    // per-lane cursors, advanced by one time step per iteration: the loop holds no address arithmetic beyond the increments.
-    // One store per step carries the lane's activated gate; a second one the quad's cell results (lane j = 0: c_t, 1: masked h_t, 2: h_t as
-    // next step's hprev row).
-    const float* gip = gi + (size_t)(row + t0) * (4 * D) + j * D + u;
+    // per-lane cursors.  One store per step carries the lane's activated gate; a second one the quad's cell results (lane j = 0: c_t,
+    // 1: masked h_t, 2: h_t as next step's hprev row, 3: tanh(c_t)).  Step t's stores are issued during step t + 1's LDS reads; the last
+    // step's after the loop -- the only place where h_t of t = T - 1 (no hprev row) has to be held back.
     float* gtp = gates + (size_t)(row + t0) * (4 * D) + j * D + u;
-    float* qp = (j == 0 ? cseq : j == 1 ? out : hprev + D) + (size_t)(row + t0) * D + u;
-    const float* mkp = mask + row;
-    float Gc = *gip, Mk = mkp[t0];
-    __syncthreads();
-    for (int t = t0; t < t1; ++t) {
-        const int cur = t & 1;
-        f32x2 a0 = {0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
-        if (t > 0) {
-            const float4* hp = reinterpret_cast<const float4*>(hs[cur]);
+    float* qp = (j == 0 ? cseq : j == 1 ? out : j == 2 ? hprev + D : tseq) + (size_t)(row + t0) * D + u;
+    const float* gib = gi + (size_t)row * (4 * D) + j * D + u;
+    const float* mkb = mask + row;
+    float Gc[L1_NB], Gn[L1_NB], Mk[L1_NB], Mn;        // input projection + bias of the block's steps ; their masks (loaded: lane j holds step j's)
+    auto load_blk = [&](float (&G)[L1_NB], float& M, int tb) {
 #pragma unroll
-            for (int q = 0; q < D / 8; ++q) {
-                const float4 h0 = hp[2 * q], h1 = hp[2 * q + 1];
-                a0 = __builtin_elementwise_fma(f32x2{h0.x, h0.y}, wr[4 * q], a0);
-                a1 = __builtin_elementwise_fma(f32x2{h0.z, h0.w}, wr[4 * q + 1], a1);
-                a2 = __builtin_elementwise_fma(f32x2{h1.x, h1.y}, wr[4 * q + 2], a2);
-                a3 = __builtin_elementwise_fma(f32x2{h1.z, h1.w}, wr[4 * q + 3], a3);
+        for (int s = 0; s < L1_NB; ++s) G[s] = gib[(size_t)min(tb + s, T - 1) * (4 * D)] + bs;
+        M = mkb[min(tb + j, T - 1)];
+    };
+    load_blk(Gc, Mn, t0);
+    Mk[0] = quad_bcast<0>(Mn); Mk[1] = quad_bcast<1>(Mn); Mk[2] = quad_bcast<2>(Mn); Mk[3] = quad_bcast<3>(Mn);
+    float st_act = 0.f, st_q = 0.f;
+    __syncthreads();
+    for (int tb = t0; tb < t1; tb += L1_NB) {
+#pragma unroll
+        for (int s = 0; s < L1_NB; ++s) {
+            const int t = tb + s;
+            if (t >= t1) break;                           // uniform
+            const int cur = t & 1;
+            float4 hv[8];
+            {
+                const float4* hp = reinterpret_cast<const float4*>(hs[cur] + L1_SEG * j);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) hv[q] = hp[q];
             }
+            if (s != 0 || tb != t0) {                     // (uniform) the previous step's stores
+                *gtp = st_act; gtp += 4 * D;
+                *qp = st_q; qp += D;
+            }
+            if (s == 0) load_blk(Gn, Mn, tb + L1_NB);     // the next block's inputs
+            f32x2 s01, s23;
+            lstm1_product(hv, w01, w23, s01, s23);
+            // lane j's gate: its register 0 + register d of lane j ^ d
+            const float z = ((s01.x + Gc[s]) + dpp_get<0xB1>(s01.y)) + (dpp_get<0x4E>(s23.x) + dpp_get<0x1B>(s23.y));
+            const float act = sigmoid_rcp(z, nk) * ma + mb;
+            const float ig = quad_bcast<0>(act), fg = quad_bcast<1>(act), gg = quad_bcast<2>(act), og = quad_bcast<3>(act);
+            const float cn = fg * cst + ig * gg;
+            const float th = 2.0f * sigmoid_rcp(cn, -2.0f * L1_LOG2E) - 1.0f;
+            const float hn = og * th;
+            cst = cn;
+            if (j == 0) hs[cur ^ 1][hoff] = hn;
+            st_act = act;
+            st_q = j == 0 ? cn : j == 1 ? hn * Mk[s] : j == 2 ? hn : th;
+            __syncthreads();
         }
-        const f32x2 as = (a0 + a1) + (a2 + a3);
-        const float z = (as.x + as.y) + Gc + bs;
-        const float sg = sigmoid_fast(z * sc);
-        const float act = j == 2 ? 2.0f * sg - 1.0f : sg;
-        const float ig = quad_bcast<0>(act), fg = quad_bcast<1>(act), gg = quad_bcast<2>(act), og = quad_bcast<3>(act);
-        const float cn = fg * cst + ig * gg;
-        const float hn = og * tanh_fast(cn);
-        cst = cn;
-        if (j == 0) hs[cur ^ 1][u] = hn;
-        *gtp = act;
-        gtp += 4 * D;
-        const float qv = j == 0 ? cn : j == 1 ? hn * Mk : hn;
-        if (j < 2 || (j == 2 && t + 1 < T)) *qp = qv;
-        qp += D;
-        if (t + 1 < T) {                                  // uniform
-            gip += 4 * D;
-            Gc = *gip;
-            Mk = mkp[t + 1];
-        }
-        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < L1_NB; ++s) Gc[s] = Gn[s];
+        Mk[0] = quad_bcast<0>(Mn); Mk[1] = quad_bcast<1>(Mn); Mk[2] = quad_bcast<2>(Mn); Mk[3] = quad_bcast<3>(Mn);
+    }
+    if (t1 > t0) {
+        *gtp = st_act;
+        if (j != 2 || t1 < T) *qp = st_q;
     }
 }
 
+// Wimg: PackJob type 10 image of W_hh.  Lane m = lane & 15 of row r4 = lane >> 4, quad i = (lane >> 2) & 3, float4 q =
+// W_hh[32 m + q][16 w + 4 r4 + (i ^ x)] for x = 0 .. 3.
 __global__ __launch_bounds__(512, 2) void k_lstm1_bwd(const float* __restrict__ dout, const float* __restrict__ dout2,
                                                       const float* __restrict__ mask, const float* __restrict__ gates,
-                                                      const float* __restrict__ cseq, const float* __restrict__ Whh,
-                                                      float* __restrict__ dG, int T, float* __restrict__ carry, int t0, int t1) {
-    __shared__ __attribute__((aligned(16))) float dGs[2][4 * L4_HP];      // gate gradients of the step, one padded row per gate (double-buffered: one barrier per step)
+                                                      const float* __restrict__ cseq, const float* __restrict__ tseq,
+                                                      const float* __restrict__ Wimg, float* __restrict__ dG, int T,
+                                                      float* __restrict__ carry, int t0, int t1) {
+    __shared__ __attribute__((aligned(16))) float dGs[2][16 * L1_SEG];    // gate gradients of the step (row k = 128 gate + unit), double-buffered: one barrier per step
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int b = lane >> 2, j = lane & 3;
-    const int u = 16 * w + b;                             // cell u ; this lane's gate j ; product: rows 128 j .. + 127 into column u
+    const int u = 16 * w + b;                             // cell u ; this lane's gate j
+    const int m = lane & 15;                              // product: gate rows 32 m .. + 31 into the row's four columns ; quad i keeps column i (= u)
     const int bb = blockIdx.x;
-    f32x2 wr[D / 2];                                      // W_hh[128 j + 2 i .. + 1][u]
-#pragma unroll
-    for (int i = 0; i < D / 2; ++i) wr[i] = f32x2{Whh[(size_t)(128 * j + 2 * i) * D + u], Whh[(size_t)(128 * j + 2 * i + 1) * D + u]};
+    f32x2 w01[32], w23[32];
+    lstm1_weights(Wimg, w, lane, w01, w23);
+    const int goff = (4 * j + (u >> 5)) * L1_SEG + (u & 31);
+    const bool jodd = j & 1;
     float dcn = 0.f, dhr = 0.f;
     if (t1 < T) { dcn = carry[((size_t)bb * 2 + 0) * D + u]; dhr = carry[((size_t)bb * 2 + 1) * D + u]; }
-    // everything a step reads from memory is independent of the recurrence: fetched one step ahead
-    float n_do, n_mk, n_act, n_cp;
-    auto fetch = [&](int t) {
-        const int tt = max(t, 0);
-        const unsigned base = (unsigned)(bb * T + tt);
-        n_do = dout[base * D + u];
-        if (dout2) n_do += dout2[base * D + u];
-        n_mk = mask[base];
-        n_act = gates[base * (4 * D) + j * D + u];
-        n_cp = tt > 0 ? cseq[(base - 1) * D + u] : 0.f;
-    };
-    float ct = cseq[(unsigned)((bb * T + t1 - 1) * D + u)];
-    fetch(t1 - 1);
-    for (int t = t1 - 1; t >= t0; --t) {
-        const unsigned base = (unsigned)(bb * T + t);
-        const int cur = t & 1;
-        float dh = n_do * n_mk;
-        const float act = n_act, cp = n_cp;
-        fetch(t - 1);
-        if (t < T - 1) dh += dhr;
-        const float ig = quad_bcast<0>(act), fg = quad_bcast<1>(act), gg = quad_bcast<2>(act), og = quad_bcast<3>(act);
-        const float tc = tanh_fast(ct);
-        const float dc = dh * og * (1.f - tc * tc) + dcn;
-        const float dv = j == 0 ? dc * gg * ig * (1.f - ig) : j == 1 ? dc * cp * fg * (1.f - fg) : j == 2 ? dc * ig * (1.f - gg * gg)
-                                                                                                         : dh * tc * og * (1.f - og);
-        dcn = dc * fg;
-        ct = cp;
-        dGs[cur][j * L4_HP + u] = dv;
-        dG[base * (4 * D) + j * D + u] = dv;
-        if (t == 0) break;                               // dh_{-1} is not needed
-        __syncthreads();
-        f32x2 a0 = {0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
-        const float4* gp = reinterpret_cast<const float4*>(dGs[cur] + L4_HP * j);
+    // Everything a step reads from memory is independent of the recurrence: fetched in blocks of L1_NB steps, one block ahead.  Per step and
+    // lane: the incoming gradient, the lane's activated gate, and cx = c_{t-1} in lane 1 of the quad (the forget gate's factor),
+    // tanh(c_t) in the others; the mask once per block (lane j: step tb - j).
+    struct In { float d, act, cx; };
+    const float* cxp = j == 1 ? cseq - D : tseq;           // (lane 1 at t = 0 reads nothing: c_{-1} = 0)
+    auto load_blk = [&](In (&x)[L1_NB], float& M, int tb) { // steps tb, tb - 1, ...
 #pragma unroll
-        for (int q = 0; q < D / 8; ++q) {
-            const float4 g0 = gp[2 * q], g1 = gp[2 * q + 1];
-            a0 = __builtin_elementwise_fma(f32x2{g0.x, g0.y}, wr[4 * q], a0);
-            a1 = __builtin_elementwise_fma(f32x2{g0.z, g0.w}, wr[4 * q + 1], a1);
-            a2 = __builtin_elementwise_fma(f32x2{g1.x, g1.y}, wr[4 * q + 2], a2);
-            a3 = __builtin_elementwise_fma(f32x2{g1.z, g1.w}, wr[4 * q + 3], a3);
+        for (int s = 0; s < L1_NB; ++s) {
+            const int tt = max(tb - s, 0);
+            const unsigned base = (unsigned)(bb * T + tt);
+            x[s].d = dout[base * D + u];
+            if (dout2) x[s].d += dout2[base * D + u];
+            x[s].act = gates[base * (4 * D) + j * D + u];
+            x[s].cx = (j == 1 && tt == 0) ? 0.f : cxp[base * D + u];
         }
-        const f32x2 as = (a0 + a1) + (a2 + a3);
-        float pr = as.x + as.y;                                            // rows 128 j .. + 127 ; the quad holds the four slices
-        pr += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(pr), 0xB1, 0xF, 0xF, false));   // lanes (0,1) (2,3)
-        pr += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(pr), 0x4E, 0xF, 0xF, false));   // pairs: same value in all four lanes
-        dhr = pr;
+        M = mask[(unsigned)(bb * T + max(tb - j, 0))];
+    };
+    In xc[L1_NB], xn[L1_NB];
+    float Mk[L1_NB], Mn;
+    load_blk(xc, Mn, t1 - 1);
+    Mk[0] = quad_bcast<0>(Mn); Mk[1] = quad_bcast<1>(Mn); Mk[2] = quad_bcast<2>(Mn); Mk[3] = quad_bcast<3>(Mn);
+    float* dgp = dG + (size_t)(bb * T + t1 - 1) * (4 * D) + j * D + u;
+    float st_dv = 0.f;
+    for (int tb = t1 - 1; tb >= t0; tb -= L1_NB) {
+#pragma unroll
+        for (int s = 0; s < L1_NB; ++s) {
+            const int t = tb - s;
+            if (t < t0) break;                            // uniform
+            const int cur = t & 1;
+            // the step's factors: dc = dh k1 + dc_next ; dv = (gate 3: dh, else dc) kdv ; dc_next = dc f
+            const float act = xc[s].act, cx = xc[s].cx;
+            const float tc = quad_bcast<0>(cx), fg = quad_bcast<1>(act), og = quad_bcast<3>(act);
+            const float k1 = og * (1.f - tc * tc);
+            // kdv: gate 0 (i): g i (1 - i) ; 1 (f): c_{t-1} f (1 - f) ; 2 (g): i (1 - g^2) ; 3 (o): tanh(c_t) o (1 - o)
+            const float pf = jodd ? cx : dpp_get<0xC6>(act);                  // quad_perm [2,1,0,3]: lanes 0 and 2 swap
+            const float kdv = pf * (__builtin_fmaf(-act, act, j == 2 ? 1.f : act));
+            const float dm = xc[s].d * Mk[s];
+            // ---- the recurrence
+            const float dh = dm + dhr;                    // (dhr = 0 going into t = T - 1)
+            const float dc = __builtin_fmaf(dh, k1, dcn);
+            const float dv = (j == 3 ? dh : dc) * kdv;
+            dcn = dc * fg;
+            dGs[cur][goff] = dv;
+            if (t == 0) {                                 // dh_{-1} is not needed
+                if (s != 0 || tb != t1 - 1) { *dgp = st_dv; dgp -= 4 * D; }
+                st_dv = dv;
+                break;
+            }
+            __syncthreads();
+            float4 gv[8];
+            {
+                const float4* gp = reinterpret_cast<const float4*>(dGs[cur] + L1_SEG * m);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) gv[q] = gp[q];
+            }
+            if (s != 0 || tb != t1 - 1) { *dgp = st_dv; dgp -= 4 * D; }      // (uniform) the previous step's gate gradients
+            st_dv = dv;
+            if (s == 0) load_blk(xn, Mn, tb - L1_NB);
+            f32x2 s01, s23;
+            lstm1_product(gv, w01, w23, s01, s23);
+            // 16 lanes hold sixteenth sums of four columns, register r = column i ^ r: row mirror pairs quad i with i ^ 3, the half-row
+            // mirror with i ^ 1; the two passes reach every quad once, the quad adds the rest.
+            const float r0 = s01.x + dpp_get<0x140>(s23.y), r1 = s01.y + dpp_get<0x140>(s23.x);
+            float pr = r0 + dpp_get<0x141>(r1);
+            pr += dpp_get<0xB1>(pr);
+            pr += dpp_get<0x4E>(pr);                      // the same value in the quad's four lanes
+            dhr = pr;
+        }
+#pragma unroll
+        for (int s = 0; s < L1_NB; ++s) xc[s] = xn[s];
+        Mk[0] = quad_bcast<0>(Mn); Mk[1] = quad_bcast<1>(Mn); Mk[2] = quad_bcast<2>(Mn); Mk[3] = quad_bcast<3>(Mn);
     }
+    if (t1 > t0) *dgp = st_dv;
     if (t0 > 0 && j == 0) {
         carry[((size_t)bb * 2 + 0) * D + u] = dcn;
         carry[((size_t)bb * 2 + 1) * D + u] = dhr;
@@ -331,18 +423,20 @@ static bool lstm_one_sample(int B) {
     return on && B <= 256;
 }
 
-void launch_lstm4_fwd(const float* gi, const float* Whh, const float* bih, const float* bhh, const float* mask, float* gates,
-                      float* cseq, float* hprev, float* out, int B, int T, hipStream_t s, int t0, int t1) {
+void launch_lstm_fwd(const float* gi, const float* Whh, const float* Wimg, const float* bih, const float* bhh, const float* mask, float* gates,
+                      float* cseq, float* tseq, float* hprev, float* out, int B, int T, hipStream_t s, int t0, int t1) {
+    if (t1 < 0) t1 = T;
     if (lstm_one_sample(B)) {
-        VSL_LAUNCH(k_lstm1_fwd, dim3(B), dim3(512), 0, s, gi, Whh, bih, bhh, mask, gates, cseq, hprev, out, T, t0, t1);
+        VSL_LAUNCH(k_lstm1_fwd, dim3(B), dim3(512), 0, s, gi, Wimg, bih, bhh, mask, gates, cseq, tseq, hprev, out, T, t0, t1);
         return;
     }
     VSL_LAUNCH(k_lstm4_fwd, dim3((B + 3) / 4), dim3(512), 0, s, gi, Whh, bih, bhh, mask, gates, cseq, hprev, out, B, T, t0, t1);
 }
-void launch_lstm4_bwd(const float* dout, const float* dout2, const float* mask, const float* gates, const float* cseq,
-                      const float* Whh, float* dG, int B, int T, hipStream_t s, float* carry, int t0, int t1) {
+void launch_lstm_bwd(const float* dout, const float* dout2, const float* mask, const float* gates, const float* cseq, const float* tseq,
+                      const float* Whh, const float* Wimg, float* dG, int B, int T, hipStream_t s, float* carry, int t0, int t1) {
+    if (t1 < 0) t1 = T;
     if (lstm_one_sample(B)) {
-        VSL_LAUNCH(k_lstm1_bwd, dim3(B), dim3(512), 0, s, dout, dout2, mask, gates, cseq, Whh, dG, T, carry, t0, t1);
+        VSL_LAUNCH(k_lstm1_bwd, dim3(B), dim3(512), 0, s, dout, dout2, mask, gates, cseq, tseq, Wimg, dG, T, carry, t0, t1);
         return;
     }
     VSL_LAUNCH(k_lstm4_bwd, dim3((B + 3) / 4), dim3(512), 0, s, dout, dout2, mask, gates, cseq, Whh, dG, B, T, carry, t0, t1);

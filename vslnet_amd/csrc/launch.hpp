@@ -15,6 +15,7 @@ struct PackJob {          // one weight -> packed B-operand copy (see common.hpp
     int kn, cn;           // extent of the contraction index / of the output-column index covered by this job
     int ld;               // leading dimension of the source matrix
     int transpose;        // 0: Bm[k][c] = W[c][k] (forward pack)   1: Bm[k][c] = W[k][c] (data-gradient pack)  2: copy  3: char-conv image  4: zero fill  8: char-conv B-operand image of k_embed_bwd
+                          // 9 / 10: W_hh (512, 128) in the register order of k_lstm1_fwd / k_lstm1_bwd (kn = 65536 floats)
                           // 5: bf16 forward pack   6 / 7: SPLIT packs (three bf16 planes h, m, l; common.hpp pack3_index) of the forward / data-gradient operand
     int ncols;            // total columns of the packed operand
     int k_off, col_off;   // placement inside the packed operand
@@ -198,16 +199,14 @@ void launch_extract_index(const float* sl, const float* el, int64_t* si, int64_t
 // ---------------------------------------------------------------- backward
 void launch_head_bwd(const HeadBwdArgs& a0, const HeadBwdArgs& a1, int R, hipStream_t s);
 // a15 DynamicRNN (layers_t7.py:302-313): recurrent part of nn.LSTM(128, 128); the input projection x W_ih^T is a plain GEMM
-void launch_lstm_fwd(const float* gi, const float* Whh, const float* bih, const float* bhh, const float* mask, float* gates,
-                     float* cseq, float* hprev, float* out, int B, int T, hipStream_t s, int t0 = 0, int t1 = -1);   // steps [t0, t1)
-void launch_lstm_bwd(const float* dout, const float* dout2, const float* mask, const float* gates, const float* cseq,
-                     const float* Whh, float* dG, int B, int T, hipStream_t s, float* carry = nullptr, int t0 = 0, int t1 = -1);
+// (kernels_lstm.hip: one-sample workgroups for B <= 256, which read k_pack's register-order images of W_hh -- PackJob types 9 / 10 -- and
+// save tanh(c_t) in tseq; 4-sample MFMA groups beyond, which read W_hh itself)
+void launch_lstm_fwd(const float* gi, const float* Whh, const float* Wimg, const float* bih, const float* bhh, const float* mask, float* gates,
+                     float* cseq, float* tseq, float* hprev, float* out, int B, int T, hipStream_t s, int t0 = 0, int t1 = -1);   // steps [t0, t1)
+void launch_lstm_bwd(const float* dout, const float* dout2, const float* mask, const float* gates, const float* cseq, const float* tseq,
+                     const float* Whh, const float* Wimg, float* dG, int B, int T, hipStream_t s, float* carry = nullptr, int t0 = 0, int t1 = -1);
                      // steps [t0, t1) in reverse; carry (B, 2, 128): dc / dh handed from one time chunk to the next
-// kernels_lstm.hip: one-sample workgroups (B <= 256) or 4-sample MFMA groups; launch_lstm_fwd / launch_lstm_bwd forward to them
-void launch_lstm4_fwd(const float* gi, const float* Whh, const float* bih, const float* bhh, const float* mask, float* gates,
-                      float* cseq, float* hprev, float* out, int B, int T, hipStream_t s, int t0, int t1);
-void launch_lstm4_bwd(const float* dout, const float* dout2, const float* mask, const float* gates, const float* cseq,
-                      const float* Whh, float* dG, int B, int T, hipStream_t s, float* carry, int t0, int t1);
+constexpr int LSTM_IMG_FLOATS = 4 * D * D;      // one image = W_hh in the register order of k_lstm1_fwd (type 9) / k_lstm1_bwd (type 10)
 void launch_wgrad(const WgradBatch& wb, hipStream_t s, bool one_product = false);     // kernels_wgrad.hip
 void launch_attn_out_bwd(const float* dy, const float* dy2, const float* r, const float* ln_g, const float* WTpack, float* g_o,
                          float* dr, float* p_lng, float* p_lnb, int R, Drop d4, Drop d5, hipStream_t s);
