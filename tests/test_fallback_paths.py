@@ -5,7 +5,10 @@ at the suite's small batches).  They are read once per process, so the parity su
 LDS-free weight gradient for fp32 jobs: baselines for A/B runs come from git revisions, tools/build_base.py.  The variants that remain are all
 selected by SHAPE and covered by the shapes of the suite: k_attn_fwd + k_attn_out_fwd and k_attn_bwd_long for L > 256, the 8-wave attention
 block for 128 < L <= 256, k_wgrad3 for bfloat16 features, k_linear_fwd for embedding widths that are not multiples of 16, k_loss_a / b / c
-when the caller leaves the mask sum to the device.)"""
+when the caller leaves the mask sum to the device.)
+
+VSL_RNN_FUSED=0 is the third: the rnn head as chunked launches over three streams -- what batches of 81 .. 256 samples take -- instead of the
+one-launch dataflow pipeline (k_rnn_fwd / k_rnn_bwd) every shape of the suite selects."""
 import os
 import subprocess
 import sys
@@ -21,4 +24,11 @@ def test_parity_suite_single_stream_and_forced_lstm_groups():
     e = dict(os.environ, VSL_MULTI_STREAM='0', VSL_LSTM1='0')
     r = subprocess.run([sys.executable, '-m', 'pytest', '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider',
                         'tests/test_hip_parity.py', 'tests/test_hip_rnn.py', 'tests/test_bf16_mode.py'], cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_rnn_suite_with_the_chunked_launches():
+    e = dict(os.environ, VSL_RNN_FUSED='0')
+    r = subprocess.run([sys.executable, '-m', 'pytest', '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider', 'tests/test_hip_rnn.py'],
+                       cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -1,5 +1,6 @@
 // Stand-alone timing harness for the one-sample LSTM forward recurrence (k_lstm1_fwd of vslnet_amd/csrc/kernels_lstm.hip): the product
-// kernel beside copies with parts of the step knocked out, to see what a step's ~1 us is made of.  Not part of the product.
+// kernel beside its round-3 form (k_var: one gate column per lane over the whole contraction) and the intermediate candidates (k_opt,
+// k_opt2) with parts of the step knocked out, to see what a step is made of (profiles/r04_notes.md section 8).  Not part of the product.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 lstm_harness.hip -o lstm_harness.bin && ./lstm_harness.bin
 #include "../../vslnet_amd/csrc/kernels_lstm.hip"
 #include <vector>
@@ -8,6 +9,7 @@ namespace vsl { void vsl_launch_events(hipStream_t, hipEvent_t* a, hipEvent_t* b
 using namespace vsl;
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
+__device__ __forceinline__ int vzero() { int z; asm volatile("v_mov_b32 %0, 0" : "=v"(z)); return z; }      // a zero the compiler takes for lane-dependent
 enum { K_NOFMA = 1, K_NOLDS = 2, K_CHEAPACT = 4, K_NOSTORE = 8, K_NOLOAD = 16, K_NOBARRIER = 32, K_RCP = 64, K_NOXCHG = 128, K_STAMP = 256 };
 
 __device__ __forceinline__ float sig_rcp(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
@@ -428,26 +430,35 @@ int main() {
     CHECK(hipMemcpy(d[3], hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
     CHECK(hipMemcpy(d[4], hm.data(), hm.size() * 4, hipMemcpyHostToDevice));
     long long* dclk; CHECK(hipMalloc(&dclk, 256));
+    // the register-order image k_pack builds (PackJob type 9) and the tanh(c_t) tensor of the product kernel
+    std::vector<float> himg((size_t)4 * D * D);
+    for (int e = 0; e < 4 * D * D; ++e) {
+        const int x = e & 3, ln = (e >> 2) & 63, q = (e >> 8) & 31, wv = e >> 13, u = 16 * wv + (ln >> 2), jj = ln & 3;
+        himg[e] = hw[(size_t)((jj ^ x) * D + u) * D + 32 * jj + q];
+    }
+    float *dimg, *dts;
+    CHECK(hipMalloc(&dimg, himg.size() * 4)); CHECK(hipMemcpy(dimg, himg.data(), himg.size() * 4, hipMemcpyHostToDevice));
+    CHECK(hipMalloc(&dts, (size_t)B * T * D * 4));
     // the product kernel, whole sequence and one chunk
     {
         hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
         for (int pass = 0; pass < 2; ++pass) {
             const int t1 = pass ? 43 : T;
-            for (int i = 0; i < 3; ++i) launch_lstm4_fwd(d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], d[8], B, T, 0, 0, t1);
+            for (int i = 0; i < 3; ++i) launch_lstm_fwd(d[0], d[1], dimg, d[2], d[3], d[4], d[5], d[6], dts, d[7], d[8], B, T, 0, 0, t1);
             CHECK(hipDeviceSynchronize());
             CHECK(hipEventRecord(e0));
-            for (int i = 0; i < 20; ++i) launch_lstm4_fwd(d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], d[8], B, T, 0, 0, t1);
+            for (int i = 0; i < 20; ++i) launch_lstm_fwd(d[0], d[1], dimg, d[2], d[3], d[4], d[5], d[6], dts, d[7], d[8], B, T, 0, 0, t1);
             CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize());
             float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
             printf("product k_lstm1_fwd steps [0,%d): %.2f us/launch, %.3f us/step\n", t1, ms * 1e3 / 20, ms * 1e3 / 20 / t1);
         }
     }
-    run<0>("copy of the product kernel", d, B, T, 0, T, dclk);
+    run<0>("round-3 form (k_var)", d, B, T, 0, T, dclk);
     run<0>("  .. steps [0, 43)", d, B, T, 0, 43, dclk);
     {   // candidate against the product kernel: every saved tensor
         std::vector<float> ref[4], got[4];
         const int idx[4] = {5, 6, 7, 8};
-        launch_lstm4_fwd(d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], d[8], B, T, 0, 0, T);
+        launch_lstm_fwd(d[0], d[1], dimg, d[2], d[3], d[4], d[5], d[6], dts, d[7], d[8], B, T, 0, 0, T);
         CHECK(hipDeviceSynchronize());
         for (int i = 0; i < 4; ++i) { ref[i].resize(sz[idx[i]]); CHECK(hipMemcpy(ref[i].data(), d[idx[i]], sz[idx[i]] * 4, hipMemcpyDeviceToHost)); CHECK(hipMemset(d[idx[i]], 0xff, sz[idx[i]] * 4)); }
         const int cuts[4] = {0, 43, 86, T};

@@ -5,6 +5,7 @@
 #include "launch.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -48,7 +49,7 @@ struct ModelP {
     int l_wih[2], l_whh[2], l_bih[2], l_bhh[2];     // rnn predictor: start / end DynamicRNN (layers_t7.py:302-313)
 };
 struct ModelPk { int va_f, va_f16, va_f3, l_t3[2], emb_f, emb_t, emb_f3, emb_t3, emb_t3_cols; EncPk fe, pe; int cqa_f, cqa_t, cat1_f, cat1_t, s0_f, s0_t, e0_f, e0_t, ccw_img, ccw_imgb;
-                 int l_f3[2], l_t[2], l_hf[2], l_hb[2], zero128; };
+                 int l_f3[2], l_t[2], l_hf[2], l_hb[2], l_if, l_ib, zero128; };
 
 struct EncWs { int64_t x0, y[4], u[4], mask[4], h1, q, k, v, lse, att, r, h2, out; int R, L; };
 
@@ -65,6 +66,7 @@ struct Plan {
     int64_t pack, vf, E, argpos, qf;
     EncWs ve, qe, p1, p2;
     LstmWs lstm[2];
+    int64_t h_gran = -1, gi_gran = -1, dg_gran = -1, dx_gran = -1;     // granule buffers of the fused rnn head (8 bytes per value); -1: chunked launches
     int64_t S, Srow, Scol, M, alpha, pooled, pb, cat, f1, f2, gated, hid_s, hid_e, lnf_s, lnf_e;
     // backward temporaries
     int64_t loss_scratch, gz_s, gz_e, dfeat_s, dfeat_e, dxh_s, dxh_e, g_s1, g_gated;
@@ -315,6 +317,11 @@ void build_packs(vsl_handle_s* h) {
             for (int bw = 0; bw < 2; ++bw) {                 // W_hh in the register order of k_lstm1_fwd / k_lstm1_bwd
                 (bw ? K.l_hb : K.l_hf)[l] = (int)h->pack_floats;
                 h->jobs.push_back(PackJob{P.l_whh[l], (int)h->pack_floats, LSTM_IMG_FLOATS, 1, 0, 9 + bw, 1, 0, 0});
+                h->pack_floats += LSTM_IMG_FLOATS;
+            }
+            if (l == 1) for (int bw = 0; bw < 2; ++bw) {     // the end LSTM's W_ih likewise: the projection workgroups of k_rnn_fwd / k_rnn_bwd
+                (bw ? K.l_ib : K.l_if) = (int)h->pack_floats;
+                h->jobs.push_back(PackJob{P.l_wih[1], (int)h->pack_floats, LSTM_IMG_FLOATS, 1, 0, 9 + bw, 1, 0, 0});
                 h->pack_floats += LSTM_IMG_FLOATS;
             }
         }
@@ -573,10 +580,18 @@ CharConvPtrs char_ptrs(const Ctx& c) {
 // section 7): a shorter last chunk (0.950 against 0.938), the start LSTM's own input projection chunked (0.939: nothing), the start LSTM's dx GEMM
 // chunk by chunk on the third stream (1.051: every extra hop costs more than the 7 us GEMM it hides).
 std::vector<int> lstm_chunks(int T) {
-    const int n = std::max(1, (int)std::lround(std::sqrt(0.06 * T)));
+    int n = std::max(1, (int)std::lround(std::sqrt(0.06 * T)));
+    if (const char* e = getenv("VSL_DBG_CHUNKS")) n = atoi(e);
     std::vector<int> out;
     for (int i = 0; i < n; ++i) out.push_back((T * (i + 1)) / n - (T * i) / n);
     return out;
+}
+
+// Tag of one fused rnn launch's granules: unique per process and a NaN pattern (quiet NaN with a payload no arithmetic produces), so that
+// nothing the caller's workspace may hold from earlier use -- activations, indices, older granules -- reads as a valid tag.
+unsigned rnn_epoch() {
+    static std::atomic<unsigned> n{0};
+    return 0x7FE00000u | ((n.fetch_add(1) + 1) & 0x1FFFFFu);
 }
 
 void run_forward(Ctx& c) {
@@ -651,7 +666,20 @@ void run_forward(Ctx& c) {
         };
         gi(0, c.W(p.gated), R);
         hipStream_t main_s = c.s;
-        if (chunks.size() < 2 || sq == main_s) {
+        if (p.h_gran >= 0) {
+            // one launch, three workgroups per sample (kernels_lstm.hip: k_rnn_fwd)
+            RnnFwdArgs a;
+            memset(&a, 0, sizeof a);
+            a.gi0 = c.W(p.lstm[0].gi); a.Wih1 = c.PK(K.l_if); a.mask = io.v_mask;
+            for (int l = 0; l < 2; ++l) {
+                const LstmWs& w = p.lstm[l];
+                a.Whh[l] = c.PK(K.l_hf[l]); a.bih[l] = c.P(P.l_bih[l]); a.bhh[l] = c.P(P.l_bhh[l]);
+                a.gates[l] = c.W(w.gates); a.cseq[l] = c.W(w.cseq); a.tseq[l] = c.W(w.tseq); a.hprev[l] = c.W(w.hprev); a.out[l] = c.W(w.out);
+            }
+            a.h_gran = reinterpret_cast<unsigned long long*>(c.W(p.h_gran)); a.gi_gran = reinterpret_cast<unsigned long long*>(c.W(p.gi_gran));
+            a.epoch = rnn_epoch(); a.B = B; a.T = T;
+            LAUNCH("rnn_fwd", launch_rnn_fwd(a, c.s));
+        } else if (chunks.size() < 2 || sq == main_s) {
             lstm(0, 0, T);
             gi(1, c.W(p.lstm[0].out), R);
             lstm(1, 0, T);
@@ -846,7 +874,19 @@ void run_backward(Ctx& c) {
         };
         const bool piped = !c.dry && chunks.size() >= 2 && sq != c.s;
         if (!c.dry) {
-            if (!piped) {
+            if (p.h_gran >= 0) {
+                RnnBwdArgs a;
+                memset(&a, 0, sizeof a);
+                a.dout[0] = c.W(p.dfeat_s); a.dout[1] = c.W(p.dfeat_e); a.mask = io->v_mask; a.Wih1 = c.PK(K.l_ib);
+                for (int l = 0; l < 2; ++l) {
+                    const LstmWs& w = p.lstm[l];
+                    a.gates[l] = c.W(w.gates); a.cseq[l] = c.W(w.cseq); a.tseq[l] = c.W(w.tseq); a.Whh[l] = c.PK(K.l_hb[l]); a.dG[l] = c.W(w.dG);
+                }
+                a.dg_gran = reinterpret_cast<unsigned long long*>(c.W(p.dg_gran)); a.dx_gran = reinterpret_cast<unsigned long long*>(c.W(p.dx_gran));
+                a.epoch = rnn_epoch(); a.B = B; a.T = T;
+                LAUNCH("rnn_bwd", launch_rnn_bwd(a, c.s));
+                dx(0, 0, T);
+            } else if (!piped) {
                 bwd(1, 0, T); dx(1, 0, T); bwd(0, 0, T); dx(0, 0, T);
             } else {
                 hipStream_t main_s = c.s;
@@ -1061,6 +1101,7 @@ int build_plan(vsl_handle_s* h, int B, int T, int Lq, int Lc, Plan** out) {
             w.carry = al((int64_t)B * 2 * D);
         }
         p->p1.out = p->lstm[0].out; p->p2.out = p->lstm[1].out;
+        if (rnn_fused_ok(B)) { p->h_gran = al(R * 2 * D); p->gi_gran = al(R * 8 * D); p->dg_gran = al(R * 8 * D); p->dx_gran = al(R * 2 * D); }
     } else {
         plan_encoder(al, p->p1, B, T, H); plan_encoder(al, p->p2, B, T, H);
     }

@@ -241,17 +241,55 @@ __device__ __forceinline__ void lstm1_product(const float4 (&x)[8], const f32x2 
     s23 = a23[0] + a23[1];
 }
 
-// Wimg: PackJob type 9 image of W_hh.  Lane (u, j), float4 q = W_hh[(j ^ x) * 128 + u][32 j + q] for x = 0 .. 3.
-__global__ __launch_bounds__(512, 2) void k_lstm1_fwd(const float* __restrict__ gi, const float* __restrict__ Wimg,
-                                                      const float* __restrict__ bih, const float* __restrict__ bhh,
-                                                      const float* __restrict__ mask, float* __restrict__ gates,
-                                                      float* __restrict__ cseq, float* __restrict__ tseq, float* __restrict__ hprev,
-                                                      float* __restrict__ out, int T, int t0, int t1) {
-    __shared__ __attribute__((aligned(16))) float hs[2][4 * L1_SEG];
+// ---------------------------------------------------------------------------------------------------------
+// In-launch hand-offs between the workgroups of the fused rnn head (k_rnn_fwd / k_rnn_bwd below): 8-byte {tag, value} granules, each
+// written by ONE write-through (sc1) store and re-read with sc1 loads until its tag is the launch's epoch -- the data is the flag, no
+// fence on either side (MI355X_MICROARCH.md, handoff-1to1: ~1 us per hop; per-XCD L2s are not coherent, plain stores would not do).
+// A producer never waits for a consumer and is dispatched before it (lower block index), so the spins end whatever the residency; they
+// are bounded all the same: a lost producer ends in NaNs, not in a hung GPU.
+// ---------------------------------------------------------------------------------------------------------
+typedef unsigned long long u64;
+typedef __attribute__((address_space(1))) u64 gu64;
+__device__ __forceinline__ void granule_store(u64* g, unsigned epoch, float v) {
+    __hip_atomic_store((gu64*)g, ((u64)epoch << 32) | __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64 granule_load(const u64* g) { return __hip_atomic_load((gu64*)g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+constexpr unsigned L1_SPIN_LIMIT = 1u << 20;
+// every lane of the wave holds N granules: re-read until all tags carry the epoch (wave-uniform loop)
+template <int N, typename F> __device__ __forceinline__ void granule_wait(u64 (&r)[N], F&& ptr, unsigned epoch) {     // ptr(k): address of granule k
+    for (unsigned spins = 0;; ++spins) {
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < N; ++k) ok &= (unsigned)(r[k] >> 32) == epoch;
+        if (__all(ok)) return;
+        if (spins > L1_SPIN_LIMIT) {
+#pragma unroll
+            for (int k = 0; k < N; ++k) r[k] = 0x7fc00000ull;
+            return;
+        }
+        __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+        for (int k = 0; k < N; ++k) r[k] = granule_load(ptr(k));
+    }
+}
+
+enum { L1_PLAIN = 0, L1_PUBLISH = 1, L1_GRANULES = 2 };    // inputs from memory ; the same + the step's result published ; the step's input from granules
+
+// One sample's forward recurrence over the steps [t0, t1).  Wimg: PackJob type 9 image of W_hh -- lane (u, j), float4 q =
+// W_hh[(j ^ x) * 128 + u][32 j + q] for x = 0 .. 3.
+//   L1_PUBLISH : h_t * mask is also published to gout[(b T + t) 128 + u]
+//   L1_GRANULES: the input projection comes from gin[(b T + t) 512 + gate 128 + u] instead of gi
+template <int MODE>
+__device__ __forceinline__ void lstm1_fwd_body(float (&hs)[2][4 * L1_SEG], int bidx, const float* __restrict__ gi, const u64* gin,
+                                               const float* __restrict__ Wimg, const float* __restrict__ bih,
+                                               const float* __restrict__ bhh, const float* __restrict__ mask,
+                                               float* __restrict__ gates, float* __restrict__ cseq, float* __restrict__ tseq,
+                                               float* __restrict__ hprev, float* __restrict__ out, u64* gout, unsigned epoch, int T,
+                                               int t0, int t1) {
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int b = lane >> 2, j = lane & 3;
     const int u = 16 * w + b;
-    const int row = blockIdx.x * T;
+    const int row = bidx * T;
     const int hoff = (u >> 5) * L1_SEG + (u & 31);
     f32x2 w01[32], w23[32];
     lstm1_weights(Wimg, w, lane, w01, w23);
@@ -266,16 +304,37 @@ __global__ __launch_bounds__(512, 2) void k_lstm1_fwd(const float* __restrict__ 
     // step's after the loop -- the only place where h_t of t = T - 1 (no hprev row) has to be held back.
     float* gtp = gates + (size_t)(row + t0) * (4 * D) + j * D + u;
     float* qp = (j == 0 ? cseq : j == 1 ? out : j == 2 ? hprev + D : tseq) + (size_t)(row + t0) * D + u;
-    const float* gib = gi + (size_t)row * (4 * D) + j * D + u;
+    const float* gib = MODE == L1_GRANULES ? nullptr : gi + (size_t)row * (4 * D) + j * D + u;
+    const u64* ginb = MODE == L1_GRANULES ? gin + (size_t)row * (4 * D) + j * D + u : nullptr;
+    u64* goutp = MODE == L1_PUBLISH ? gout + (size_t)(row + t0) * D + u : nullptr;
     const float* mkb = mask + row;
     float Gc[L1_NB], Gn[L1_NB], Mk[L1_NB], Mn;        // input projection + bias of the block's steps ; their masks (loaded: lane j holds step j's)
-    auto load_blk = [&](float (&G)[L1_NB], float& M, int tb) {
+    u64 Rn[L1_NB];
+    int rtb = t0;                                     // block the granules in Rn belong to
+    auto load_blk = [&](int tb) {
 #pragma unroll
-        for (int s = 0; s < L1_NB; ++s) G[s] = gib[(size_t)min(tb + s, T - 1) * (4 * D)] + bs;
-        M = mkb[min(tb + j, T - 1)];
+        for (int s = 0; s < L1_NB; ++s) {
+            const size_t o = (size_t)min(tb + s, T - 1) * (4 * D);
+            if (MODE == L1_GRANULES) Rn[s] = granule_load(ginb + o);
+            else Gn[s] = gib[o];
+        }
+        rtb = tb;
+        Mn = mkb[min(tb + j, T - 1)];
     };
-    load_blk(Gc, Mn, t0);
-    Mk[0] = quad_bcast<0>(Mn); Mk[1] = quad_bcast<1>(Mn); Mk[2] = quad_bcast<2>(Mn); Mk[3] = quad_bcast<3>(Mn);
+    // (nothing is computed on a loaded value before the block is rotated in, four steps after its loads were issued)
+    auto rotate = [&] {
+        if (MODE == L1_GRANULES) {
+            granule_wait(Rn, [&](int k) { return ginb + (size_t)min(rtb + k, T - 1) * (4 * D); }, epoch);
+#pragma unroll
+            for (int s = 0; s < L1_NB; ++s) Gc[s] = __uint_as_float((unsigned)Rn[s]) + bs;
+        } else {
+#pragma unroll
+            for (int s = 0; s < L1_NB; ++s) Gc[s] = Gn[s] + bs;
+        }
+        Mk[0] = quad_bcast<0>(Mn); Mk[1] = quad_bcast<1>(Mn); Mk[2] = quad_bcast<2>(Mn); Mk[3] = quad_bcast<3>(Mn);
+    };
+    load_blk(t0);
+    rotate();
     float st_act = 0.f, st_q = 0.f;
     __syncthreads();
     for (int tb = t0; tb < t1; tb += L1_NB) {
@@ -294,7 +353,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm1_fwd(const float* __restrict__ 
                 *gtp = st_act; gtp += 4 * D;
                 *qp = st_q; qp += D;
             }
-            if (s == 0) load_blk(Gn, Mn, tb + L1_NB);     // the next block's inputs
+            if (s == 0) load_blk(tb + L1_NB);             // the next block's inputs
             f32x2 s01, s23;
             lstm1_product(hv, w01, w23, s01, s23);
             // lane j's gate: its register 0 + register d of lane j ^ d
@@ -306,13 +365,15 @@ __global__ __launch_bounds__(512, 2) void k_lstm1_fwd(const float* __restrict__ 
             const float hn = og * th;
             cst = cn;
             if (j == 0) hs[cur ^ 1][hoff] = hn;
+            if (MODE == L1_PUBLISH) {
+                if (j == 1) granule_store(goutp, epoch, hn * Mk[s]);
+                goutp += D;
+            }
             st_act = act;
             st_q = j == 0 ? cn : j == 1 ? hn * Mk[s] : j == 2 ? hn : th;
             __syncthreads();
         }
-#pragma unroll
-        for (int s = 0; s < L1_NB; ++s) Gc[s] = Gn[s];
-        Mk[0] = quad_bcast<0>(Mn); Mk[1] = quad_bcast<1>(Mn); Mk[2] = quad_bcast<2>(Mn); Mk[3] = quad_bcast<3>(Mn);
+        rotate();
     }
     if (t1 > t0) {
         *gtp = st_act;
@@ -320,19 +381,29 @@ __global__ __launch_bounds__(512, 2) void k_lstm1_fwd(const float* __restrict__ 
     }
 }
 
-// Wimg: PackJob type 10 image of W_hh.  Lane m = lane & 15 of row r4 = lane >> 4, quad i = (lane >> 2) & 3, float4 q =
-// W_hh[32 m + q][16 w + 4 r4 + (i ^ x)] for x = 0 .. 3.
-__global__ __launch_bounds__(512, 2) void k_lstm1_bwd(const float* __restrict__ dout, const float* __restrict__ dout2,
-                                                      const float* __restrict__ mask, const float* __restrict__ gates,
-                                                      const float* __restrict__ cseq, const float* __restrict__ tseq,
-                                                      const float* __restrict__ Wimg, float* __restrict__ dG, int T,
-                                                      float* __restrict__ carry, int t0, int t1) {
-    __shared__ __attribute__((aligned(16))) float dGs[2][16 * L1_SEG];    // gate gradients of the step (row k = 128 gate + unit), double-buffered: one barrier per step
+__global__ __launch_bounds__(512, 2) void k_lstm1_fwd(const float* __restrict__ gi, const float* __restrict__ Wimg,
+                                                      const float* __restrict__ bih, const float* __restrict__ bhh,
+                                                      const float* __restrict__ mask, float* __restrict__ gates,
+                                                      float* __restrict__ cseq, float* __restrict__ tseq, float* __restrict__ hprev,
+                                                      float* __restrict__ out, int T, int t0, int t1) {
+    __shared__ __attribute__((aligned(16))) float hs[2][4 * L1_SEG];
+    lstm1_fwd_body<L1_PLAIN>(hs, blockIdx.x, gi, nullptr, Wimg, bih, bhh, mask, gates, cseq, tseq, hprev, out, nullptr, 0u, T, t0, t1);
+}
+
+// One sample's backward recurrence over the steps [t0, t1) in reverse.  Wimg: PackJob type 10 image of W_hh -- lane m = lane & 15 of row
+// r4 = lane >> 4, quad i = (lane >> 2) & 3, float4 q = W_hh[32 m + q][16 w + 4 r4 + (i ^ x)] for x = 0 .. 3.
+//   L1_PUBLISH : the step's gate gradients are also published to gout[(b T + t) 512 + gate 128 + u]
+//   L1_GRANULES: the second incoming gradient comes from gin[(b T + t) 128 + u] instead of dout2
+template <int MODE>
+__device__ __forceinline__ void lstm1_bwd_body(float (&dGs)[2][16 * L1_SEG], int bb, const float* __restrict__ dout,
+                                               const float* __restrict__ dout2, const u64* gin, const float* __restrict__ mask,
+                                               const float* __restrict__ gates, const float* __restrict__ cseq,
+                                               const float* __restrict__ tseq, const float* __restrict__ Wimg, float* __restrict__ dG,
+                                               u64* gout, unsigned epoch, int T, float* __restrict__ carry, int t0, int t1) {
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int b = lane >> 2, j = lane & 3;
     const int u = 16 * w + b;                             // cell u ; this lane's gate j
     const int m = lane & 15;                              // product: gate rows 32 m .. + 31 into the row's four columns ; quad i keeps column i (= u)
-    const int bb = blockIdx.x;
     f32x2 w01[32], w23[32];
     lstm1_weights(Wimg, w, lane, w01, w23);
     const int goff = (4 * j + (u >> 5)) * L1_SEG + (u & 31);
@@ -340,27 +411,45 @@ __global__ __launch_bounds__(512, 2) void k_lstm1_bwd(const float* __restrict__ 
     float dcn = 0.f, dhr = 0.f;
     if (t1 < T) { dcn = carry[((size_t)bb * 2 + 0) * D + u]; dhr = carry[((size_t)bb * 2 + 1) * D + u]; }
     // Everything a step reads from memory is independent of the recurrence: fetched in blocks of L1_NB steps, one block ahead.  Per step and
-    // lane: the incoming gradient, the lane's activated gate, and cx = c_{t-1} in lane 1 of the quad (the forget gate's factor),
+    // lane: the incoming gradient(s), the lane's activated gate, and cx = c_{t-1} in lane 1 of the quad (the forget gate's factor),
     // tanh(c_t) in the others; the mask once per block (lane j: step tb - j).
     struct In { float d, act, cx; };
-    const float* cxp = j == 1 ? cseq - D : tseq;           // (lane 1 at t = 0 reads nothing: c_{-1} = 0)
-    auto load_blk = [&](In (&x)[L1_NB], float& M, int tb) { // steps tb, tb - 1, ...
+    struct Raw { float d, d2, act, cx; };
+    const float* cxp = j == 1 ? cseq - D : tseq;           // (lane 1 at t = 0 reads row 0 instead and drops it: c_{-1} = 0)
+    In xc[L1_NB];
+    Raw xn[L1_NB];
+    u64 Rn[L1_NB];
+    int rtb = t1 - 1;                                 // block the granules in Rn belong to
+    float Mk[L1_NB], Mn;
+    auto load_blk = [&](int tb) {                         // steps tb, tb - 1, ...
 #pragma unroll
         for (int s = 0; s < L1_NB; ++s) {
             const int tt = max(tb - s, 0);
             const unsigned base = (unsigned)(bb * T + tt);
-            x[s].d = dout[base * D + u];
-            if (dout2) x[s].d += dout2[base * D + u];
-            x[s].act = gates[base * (4 * D) + j * D + u];
-            x[s].cx = (j == 1 && tt == 0) ? 0.f : cxp[base * D + u];
+            xn[s].d = dout[base * D + u];
+            if (MODE == L1_GRANULES) Rn[s] = granule_load(gin + (size_t)base * D + u);
+            else xn[s].d2 = dout2 ? dout2[base * D + u] : 0.f;
+            xn[s].act = gates[base * (4 * D) + j * D + u];
+            xn[s].cx = cxp[(base + (j == 1 && tt == 0 ? 1u : 0u)) * D + u];
         }
-        M = mask[(unsigned)(bb * T + max(tb - j, 0))];
+        rtb = tb;
+        Mn = mask[(unsigned)(bb * T + max(tb - j, 0))];
     };
-    In xc[L1_NB], xn[L1_NB];
-    float Mk[L1_NB], Mn;
-    load_blk(xc, Mn, t1 - 1);
-    Mk[0] = quad_bcast<0>(Mn); Mk[1] = quad_bcast<1>(Mn); Mk[2] = quad_bcast<2>(Mn); Mk[3] = quad_bcast<3>(Mn);
+    // (nothing is computed on a loaded value before the block is rotated in, four steps after its loads were issued)
+    auto rotate = [&](int tb) {
+        if (MODE == L1_GRANULES) granule_wait(Rn, [&](int k) { return gin + (size_t)(bb * T + max(rtb - k, 0)) * D + u; }, epoch);
+#pragma unroll
+        for (int s = 0; s < L1_NB; ++s) {
+            xc[s].d = xn[s].d + (MODE == L1_GRANULES ? __uint_as_float((unsigned)Rn[s]) : xn[s].d2);
+            xc[s].act = xn[s].act;
+            xc[s].cx = (j == 1 && tb - s <= 0) ? 0.f : xn[s].cx;
+        }
+        Mk[0] = quad_bcast<0>(Mn); Mk[1] = quad_bcast<1>(Mn); Mk[2] = quad_bcast<2>(Mn); Mk[3] = quad_bcast<3>(Mn);
+    };
+    load_blk(t1 - 1);
+    rotate(t1 - 1);
     float* dgp = dG + (size_t)(bb * T + t1 - 1) * (4 * D) + j * D + u;
+    u64* goutp = MODE == L1_PUBLISH ? gout + (size_t)(bb * T + t1 - 1) * (4 * D) + j * D + u : nullptr;
     float st_dv = 0.f;
     for (int tb = t1 - 1; tb >= t0; tb -= L1_NB) {
 #pragma unroll
@@ -382,6 +471,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm1_bwd(const float* __restrict__ 
             const float dv = (j == 3 ? dh : dc) * kdv;
             dcn = dc * fg;
             dGs[cur][goff] = dv;
+            if (MODE == L1_PUBLISH) { granule_store(goutp, epoch, dv); goutp -= 4 * D; }
             if (t == 0) {                                 // dh_{-1} is not needed
                 if (s != 0 || tb != t1 - 1) { *dgp = st_dv; dgp -= 4 * D; }
                 st_dv = dv;
@@ -396,7 +486,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm1_bwd(const float* __restrict__ 
             }
             if (s != 0 || tb != t1 - 1) { *dgp = st_dv; dgp -= 4 * D; }      // (uniform) the previous step's gate gradients
             st_dv = dv;
-            if (s == 0) load_blk(xn, Mn, tb - L1_NB);
+            if (s == 0) load_blk(tb - L1_NB);
             f32x2 s01, s23;
             lstm1_product(gv, w01, w23, s01, s23);
             // 16 lanes hold sixteenth sums of four columns, register r = column i ^ r: row mirror pairs quad i with i ^ 3, the half-row
@@ -407,9 +497,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm1_bwd(const float* __restrict__ 
             pr += dpp_get<0x4E>(pr);                      // the same value in the quad's four lanes
             dhr = pr;
         }
-#pragma unroll
-        for (int s = 0; s < L1_NB; ++s) xc[s] = xn[s];
-        Mk[0] = quad_bcast<0>(Mn); Mk[1] = quad_bcast<1>(Mn); Mk[2] = quad_bcast<2>(Mn); Mk[3] = quad_bcast<3>(Mn);
+        rotate(tb - L1_NB);
     }
     if (t1 > t0) *dgp = st_dv;
     if (t0 > 0 && j == 0) {
@@ -418,11 +506,136 @@ __global__ __launch_bounds__(512, 2) void k_lstm1_bwd(const float* __restrict__ 
     }
 }
 
+__global__ __launch_bounds__(512, 2) void k_lstm1_bwd(const float* __restrict__ dout, const float* __restrict__ dout2,
+                                                      const float* __restrict__ mask, const float* __restrict__ gates,
+                                                      const float* __restrict__ cseq, const float* __restrict__ tseq,
+                                                      const float* __restrict__ Wimg, float* __restrict__ dG, int T,
+                                                      float* __restrict__ carry, int t0, int t1) {
+    __shared__ __attribute__((aligned(16))) float dGs[2][16 * L1_SEG];    // gate gradients of the step (row k = 128 gate + unit), double-buffered: one barrier per step
+    lstm1_bwd_body<L1_PLAIN>(dGs, blockIdx.x, dout, dout2, nullptr, mask, gates, cseq, tseq, Wimg, dG, nullptr, 0u, T, carry, t0, t1);
+}
+
+// =========================================================================================================
+// The rnn head as ONE launch per direction (B <= RNN_FUSED_MAX_B).  The end LSTM consumes the start LSTM's output through a GEMM
+// (x W_ih^T), step by step: as separate launches the two recurrences either run one after the other (2 x 80 us at T = 128) or are
+// pipelined in time chunks over three streams, where every cross-stream hop costs 10 us and eats what the overlap gains
+// (profiles/r04_notes.md section 8).  Here three workgroups per sample form a dataflow pipeline through granules:
+//   forward : [start LSTM, publishes h_t * mask] -> [projection: W_ih h_t, 512 outputs per step] -> [end LSTM]
+//   backward: [end LSTM backward, publishes its gate gradients] -> [projection: dG W_ih, 128 outputs] -> [start LSTM backward]
+// A projection workgroup holds W_ih in the same register images as the recurrences hold W_hh (PackJob types 9 / 10 of W_ih) and has
+// no recurrence of its own: it keeps up with its producer and adds ~2 us of lag.  Block order = pipeline order (see granule_wait).
+// The fp32 FMAs replace the bf16x6 GEMM of the chunked path: the same fp32-grade product.
+// =========================================================================================================
+__device__ __forceinline__ void lstm1_proj_fwd(float (&hs)[2][4 * L1_SEG], int bidx, const u64* gin, const float* __restrict__ Wimg, u64* gout,
+                                               unsigned epoch, int T) {
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int b = lane >> 2, j = lane & 3;
+    const int u = 16 * w + b;
+    f32x2 w01[32], w23[32];
+    lstm1_weights(Wimg, w, lane, w01, w23);
+    // waves 0, 1: lane tid waits for unit tid's granule of the step and puts it into the LDS vector
+    const int hoff = (tid >> 5) * L1_SEG + (tid & 31);
+    u64 r[1];
+    const u64* rp = gin + (size_t)bidx * T * D + (tid & (D - 1));
+    if (tid < D) r[0] = granule_load(rp);
+    u64* gp = gout + (size_t)bidx * T * (4 * D) + j * D + u;
+    for (int t = 0; t < T; ++t) {
+        const int cur = t & 1;
+        if (tid < D) {                                    // (wave-uniform)
+            granule_wait(r, [&](int) { return rp; }, epoch);
+            hs[cur][hoff] = __uint_as_float((unsigned)r[0]);
+            rp += D;
+            if (t + 1 < T) r[0] = granule_load(rp);
+        }
+        __syncthreads();
+        float4 hv[8];
+        {
+            const float4* hp = reinterpret_cast<const float4*>(hs[cur] + L1_SEG * j);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) hv[q] = hp[q];
+        }
+        f32x2 s01, s23;
+        lstm1_product(hv, w01, w23, s01, s23);
+        const float z = (s01.x + dpp_get<0xB1>(s01.y)) + (dpp_get<0x4E>(s23.x) + dpp_get<0x1B>(s23.y));
+        granule_store(gp, epoch, z);
+        gp += 4 * D;
+    }
+}
+
+__device__ __forceinline__ void lstm1_proj_bwd(float (&dGs)[2][16 * L1_SEG], int bb, const u64* gin, const float* __restrict__ Wimg, u64* gout,
+                                               unsigned epoch, int T) {
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int b = lane >> 2, j = lane & 3;
+    const int u = 16 * w + b;
+    const int m = lane & 15;
+    f32x2 w01[32], w23[32];
+    lstm1_weights(Wimg, w, lane, w01, w23);
+    const int goff = (4 * j + (u >> 5)) * L1_SEG + (u & 31);
+    u64 r[1];
+    const u64* rp = gin + (size_t)(bb * T + T - 1) * (4 * D) + j * D + u;
+    r[0] = granule_load(rp);
+    u64* gp = gout + (size_t)(bb * T + T - 1) * D + u;
+    for (int t = T - 1; t >= 0; --t) {
+        const int cur = t & 1;
+        granule_wait(r, [&](int) { return rp; }, epoch);
+        dGs[cur][goff] = __uint_as_float((unsigned)r[0]);
+        rp -= 4 * D;
+        if (t > 0) r[0] = granule_load(rp);
+        __syncthreads();
+        float4 gv[8];
+        {
+            const float4* gq = reinterpret_cast<const float4*>(dGs[cur] + L1_SEG * m);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) gv[q] = gq[q];
+        }
+        f32x2 s01, s23;
+        lstm1_product(gv, w01, w23, s01, s23);
+        const float r0 = s01.x + dpp_get<0x140>(s23.y), r1 = s01.y + dpp_get<0x140>(s23.x);
+        float pr = r0 + dpp_get<0x141>(r1);
+        pr += dpp_get<0xB1>(pr);
+        pr += dpp_get<0x4E>(pr);
+        if (j == 0) granule_store(gp, epoch, pr);
+        gp -= D;
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void k_rnn_fwd(RnnFwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float hs[2][4 * L1_SEG];
+    const int B = a.B;
+    if ((int)blockIdx.x < B)
+        lstm1_fwd_body<L1_PUBLISH>(hs, blockIdx.x, a.gi0, nullptr, a.Whh[0], a.bih[0], a.bhh[0], a.mask, a.gates[0], a.cseq[0], a.tseq[0], a.hprev[0],
+                                   a.out[0], a.h_gran, a.epoch, a.T, 0, a.T);
+    else if ((int)blockIdx.x < 2 * B)
+        lstm1_proj_fwd(hs, blockIdx.x - B, a.h_gran, a.Wih1, a.gi_gran, a.epoch, a.T);
+    else
+        lstm1_fwd_body<L1_GRANULES>(hs, blockIdx.x - 2 * B, nullptr, a.gi_gran, a.Whh[1], a.bih[1], a.bhh[1], a.mask, a.gates[1], a.cseq[1], a.tseq[1],
+                                    a.hprev[1], a.out[1], nullptr, a.epoch, a.T, 0, a.T);
+}
+
+__global__ __launch_bounds__(512, 2) void k_rnn_bwd(RnnBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float dGs[2][16 * L1_SEG];
+    const int B = a.B;
+    if ((int)blockIdx.x < B)
+        lstm1_bwd_body<L1_PUBLISH>(dGs, blockIdx.x, a.dout[1], nullptr, nullptr, a.mask, a.gates[1], a.cseq[1], a.tseq[1], a.Whh[1], a.dG[1], a.dg_gran,
+                                   a.epoch, a.T, nullptr, 0, a.T);
+    else if ((int)blockIdx.x < 2 * B)
+        lstm1_proj_bwd(dGs, blockIdx.x - B, a.dg_gran, a.Wih1, a.dx_gran, a.epoch, a.T);
+    else
+        lstm1_bwd_body<L1_GRANULES>(dGs, blockIdx.x - 2 * B, a.dout[0], nullptr, a.dx_gran, a.mask, a.gates[0], a.cseq[0], a.tseq[0], a.Whh[0], a.dG[0],
+                                    nullptr, a.epoch, a.T, nullptr, 0, a.T);
+}
+
 static bool lstm_one_sample(int B) {
     static const bool on = !(getenv("VSL_LSTM1") && getenv("VSL_LSTM1")[0] == '0');
     return on && B <= 256;
 }
 
+bool rnn_fused_ok(int B) {            // VSL_RNN_FUSED=0 keeps the chunked launches (the path of 80 < B <= 256) at every batch size
+    static const bool on = !(getenv("VSL_RNN_FUSED") && getenv("VSL_RNN_FUSED")[0] == '0');
+    return on && lstm_one_sample(B) && B <= RNN_FUSED_MAX_B;
+}
+void launch_rnn_fwd(const RnnFwdArgs& a, hipStream_t s) { VSL_LAUNCH(k_rnn_fwd, dim3(3 * a.B), dim3(512), 0, s, a); }
+void launch_rnn_bwd(const RnnBwdArgs& a, hipStream_t s) { VSL_LAUNCH(k_rnn_bwd, dim3(3 * a.B), dim3(512), 0, s, a); }
 void launch_lstm_fwd(const float* gi, const float* Whh, const float* Wimg, const float* bih, const float* bhh, const float* mask, float* gates,
                       float* cseq, float* tseq, float* hprev, float* out, int B, int T, hipStream_t s, int t0, int t1) {
     if (t1 < 0) t1 = T;

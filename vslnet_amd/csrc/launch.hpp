@@ -206,7 +206,38 @@ void launch_lstm_fwd(const float* gi, const float* Whh, const float* Wimg, const
 void launch_lstm_bwd(const float* dout, const float* dout2, const float* mask, const float* gates, const float* cseq, const float* tseq,
                      const float* Whh, const float* Wimg, float* dG, int B, int T, hipStream_t s, float* carry = nullptr, int t0 = 0, int t1 = -1);
                      // steps [t0, t1) in reverse; carry (B, 2, 128): dc / dh handed from one time chunk to the next
-constexpr int LSTM_IMG_FLOATS = 4 * D * D;      // one image = W_hh in the register order of k_lstm1_fwd (type 9) / k_lstm1_bwd (type 10)
+constexpr int LSTM_IMG_FLOATS = 4 * D * D;
+// The rnn head as one launch per direction: three workgroups per sample (start LSTM, W_ih projection, end LSTM) handing steps over through
+// {tag, value} granules.  B <= RNN_FUSED_MAX_B keeps all 3 B workgroups resident beside the side streams' kernels; beyond it the chunked
+// launches above.  The granule buffers are zeroed once (tags), `epoch` (> 0) is new for every launch.
+constexpr int RNN_FUSED_MAX_B = 80;
+struct RnnFwdArgs {
+    const float* gi0;                 // (R, 512) input projection of the start LSTM
+    const float* Whh[2];              // PackJob type 9 images of W_hh
+    const float* Wih1;                // PackJob type 9 image of the end LSTM's W_ih
+    const float* bih[2]; const float* bhh[2];
+    const float* mask;
+    float* gates[2]; float* cseq[2]; float* tseq[2]; float* hprev[2]; float* out[2];
+    unsigned long long* h_gran;       // (R, 128) start LSTM's h * mask
+    unsigned long long* gi_gran;      // (R, 512) W_ih1 (h * mask)
+    unsigned epoch;
+    int B, T;
+};
+struct RnnBwdArgs {
+    const float* dout[2];             // (R, 128) gradients wrt the LSTM outputs coming from the span heads
+    const float* mask;
+    const float* gates[2]; const float* cseq[2]; const float* tseq[2];
+    const float* Whh[2];              // PackJob type 10 images of W_hh
+    const float* Wih1;                // PackJob type 10 image of the end LSTM's W_ih
+    float* dG[2];
+    unsigned long long* dg_gran;      // (R, 512) end LSTM's gate gradients
+    unsigned long long* dx_gran;      // (R, 128) dG W_ih1: the start LSTM's second incoming gradient
+    unsigned epoch;
+    int B, T;
+};
+bool rnn_fused_ok(int B);
+void launch_rnn_fwd(const RnnFwdArgs& a, hipStream_t s);
+void launch_rnn_bwd(const RnnBwdArgs& a, hipStream_t s);      // one image = W_hh in the register order of k_lstm1_fwd (type 9) / k_lstm1_bwd (type 10)
 void launch_wgrad(const WgradBatch& wb, hipStream_t s, bool one_product = false);     // kernels_wgrad.hip
 void launch_attn_out_bwd(const float* dy, const float* dy2, const float* r, const float* ln_g, const float* WTpack, float* g_o,
                          float* dr, float* p_lng, float* p_lnb, int R, Drop d4, Drop d5, hipStream_t s);
