@@ -92,12 +92,13 @@ __global__ __launch_bounds__(256) void k_pack(const float* __restrict__ params, 
             if (ocl >= 0 && ocl < j.k_off) pack[j.dst + e] = (ci < cd && kk < kw) ? params[j.src + (ocl * cd + ci) * kw + kk] : 0.f;
             continue;
         }
-        if (j.transpose == 9 || j.transpose == 10) {     // W_hh (512, 128) in the register order of the one-sample LSTM kernels: [wave][float4 q][lane][x]
+        if (j.transpose == 9 || j.transpose == 10) {     // a (512, 128) LSTM weight in the register order of the one-sample kernels: [wave][float4 q][lane][x]
             const int x = e & 3, ln = (e >> 2) & 63, q = (e >> 8) & 31, wv = e >> 13;
+            const int r = q >> 3, kk = 4 * (q & 7) + x;                       // the lane's output r (named own ^ r), its contraction index kk of 32
             const int u = 16 * wv + (ln >> 2), jj = ln & 3;
-            // forward: gate (jj ^ x) of unit u at k = 32 jj + q ; backward: gate row 32 (ln & 15) + q, column of unit 16 wv + 4 (ln >> 4) + (quad ^ x)
-            const int src = j.transpose == 9 ? ((jj ^ x) * D + u) * D + 32 * jj + q
-                                             : (32 * (ln & 15) + q) * D + 16 * wv + 4 * (ln >> 4) + (((ln >> 2) & 3) ^ x);
+            // forward: gate (jj ^ r) of unit u at k = 32 jj + kk ; backward: gate row 32 (ln & 15) + kk, column of unit 16 wv + 4 (ln >> 4) + (quad ^ r)
+            const int src = j.transpose == 9 ? ((jj ^ r) * D + u) * D + 32 * jj + kk
+                                             : (32 * (ln & 15) + kk) * D + 16 * wv + 4 * (ln >> 4) + (((ln >> 2) & 3) ^ r);
             pack[j.dst + e] = params[j.src + src];
             continue;
         }

@@ -184,8 +184,8 @@ __global__ __launch_bounds__(512, 2) void k_lstm4_bwd(const float* __restrict__ 
 // of the step, plus the LDS exchange (write, barrier, read latency: ~300 cycles in which nothing issues).  tools/ubench/lstm_harness.hip
 // takes the step apart (profiles/r04_notes.md section 8).  So the step is built to need few instructions besides the FMAs:
 //   * a lane owns a QUARTER of the contraction for FOUR outputs (8 ds_read_b128 of the shared operand per step instead of 32 for one
-//     output over the whole contraction), accumulated as two packed pairs: {out a, out b} += {x_k, x_k} * {W_a[k], W_b[k]} (op_sel
-//     broadcasts x_k) -- no horizontal adds;
+//     output over the whole contraction), accumulated as packed {even k, odd k} pairs: both operands of the 64 v_pk_fma_f32 are natural
+//     register pairs, one add per output at the end;
 //   * register r of a lane holds output (own ^ r): the partial that lane (own ^ d) needs is every lane's register d, so the
 //     transposing reductions are plain DPP adds, no selects;
 //   * the weights come from an image k_pack lays out in register order (PackJob types 9 / 10): 32 coalesced 16-byte loads per lane
@@ -209,6 +209,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm4_bwd(const float* __restrict__ 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int L1_SEG = 36;              // LDS stride of a 32-float segment
 constexpr int L1_NB = 4;                // steps per block of prefetched inputs
+constexpr int L1_RING = 8;              // granules in flight per lane of a projection workgroup (granule_ring_arrived counts on 8)
 template <int I> __device__ __forceinline__ float quad_bcast(float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), I * 0x55, 0xF, 0xF, false));
 }
@@ -216,29 +217,32 @@ template <int CTRL> __device__ __forceinline__ float dpp_get(float x) {      // 
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false));
 }
 constexpr float L1_LOG2E = 1.4426950408889634f;
+// Ahead of a step loop: everything the prologue loaded (the 128 weight registers above all) has arrived.  Without it the compiler's waits for
+// those registers sit INSIDE the loop, the last of them as vmcnt(0): every step then also waits for the load or write-through store it issued
+// a moment ago -- a full memory round trip per step.
+__device__ __forceinline__ void lstm1_prologue_done() { __builtin_amdgcn_s_waitcnt(0x0F70); }      // vmcnt(0)
 __device__ __forceinline__ float sigmoid_rcp(float x, float nk) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * nk)); }    // nk = -log2(e): sigmoid(x)
-__device__ __forceinline__ void lstm1_weights(const float* __restrict__ img, int w, int lane, f32x2 (&w01)[32], f32x2 (&w23)[32]) {
+// float4 q of the lane's image = W_r[4 (q & 7) .. + 3] for output r = q >> 3: two {k, k + 1} pairs
+__device__ __forceinline__ void lstm1_weights(const float* __restrict__ img, int w, int lane, f32x2 (&wr)[4][16]) {
     const float4* p = reinterpret_cast<const float4*>(img) + (size_t)(w * 32) * 64 + lane;
 #pragma unroll
-    for (int q = 0; q < 32; ++q) { const float4 v = p[q * 64]; w01[q] = f32x2{v.x, v.y}; w23[q] = f32x2{v.z, v.w}; }
+    for (int q = 0; q < 32; ++q) { const float4 v = p[q * 64]; wr[q >> 3][2 * (q & 7)] = f32x2{v.x, v.y}; wr[q >> 3][2 * (q & 7) + 1] = f32x2{v.z, v.w}; }
 }
-// {o0, o1} += x_k {W_0[k], W_1[k]} and {o2, o3} likewise over the lane's 32 contraction indices (8 float4 of the shared operand)
-__device__ __forceinline__ void lstm1_product(const float4 (&x)[8], const f32x2 (&w01)[32], const f32x2 (&w23)[32], f32x2& s01, f32x2& s23) {
-    f32x2 a01[2], a23[2];
-    a01[0] = a01[1] = a23[0] = a23[1] = f32x2{0.f, 0.f};
+// o[r] = sum over the lane's 32 contraction indices of x_k W_r[k]: {even k, odd k} halves accumulated as packed pairs (both operands are
+// natural register pairs: no broadcasts, no moves), one add per output at the end
+__device__ __forceinline__ void lstm1_product(const float4 (&x)[8], const f32x2 (&wr)[4][16], float (&o)[4]) {
+    f32x2 a[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a[r] = f32x2{0.f, 0.f};
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-        a01[0] = __builtin_elementwise_fma(f32x2{x[q].x, x[q].x}, w01[4 * q], a01[0]);
-        a23[0] = __builtin_elementwise_fma(f32x2{x[q].x, x[q].x}, w23[4 * q], a23[0]);
-        a01[1] = __builtin_elementwise_fma(f32x2{x[q].y, x[q].y}, w01[4 * q + 1], a01[1]);
-        a23[1] = __builtin_elementwise_fma(f32x2{x[q].y, x[q].y}, w23[4 * q + 1], a23[1]);
-        a01[0] = __builtin_elementwise_fma(f32x2{x[q].z, x[q].z}, w01[4 * q + 2], a01[0]);
-        a23[0] = __builtin_elementwise_fma(f32x2{x[q].z, x[q].z}, w23[4 * q + 2], a23[0]);
-        a01[1] = __builtin_elementwise_fma(f32x2{x[q].w, x[q].w}, w01[4 * q + 3], a01[1]);
-        a23[1] = __builtin_elementwise_fma(f32x2{x[q].w, x[q].w}, w23[4 * q + 3], a23[1]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[r] = __builtin_elementwise_fma(f32x2{x[q].x, x[q].y}, wr[r][2 * q], a[r]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[r] = __builtin_elementwise_fma(f32x2{x[q].z, x[q].w}, wr[r][2 * q + 1], a[r]);
     }
-    s01 = a01[0] + a01[1];
-    s23 = a23[0] + a23[1];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = a[r].x + a[r].y;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -253,32 +257,66 @@ typedef __attribute__((address_space(1))) u64 gu64;
 __device__ __forceinline__ void granule_store(u64* g, unsigned epoch, float v) {
     __hip_atomic_store((gu64*)g, ((u64)epoch << 32) | __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// two neighbouring granules as ONE 16-byte write-through store (each half carries its own tag: readers keep reading 8 bytes).  An 8-byte sc1
+// store is one fabric write each -- 512 per step from a projection workgroup.  Through a buffer descriptor, not inline asm: the compiler
+// has to count the store, or every later wait for a polled granule also waits for write-through stores a few steps old (~2.4 us each).
+typedef __amdgpu_buffer_rsrc_t grsrc_t;      // (the descriptor type of the buffer builtins)
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ grsrc_t granule_rsrc(u64* base, unsigned bytes) {      // base, bytes: wave-uniform
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(base), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+__device__ __forceinline__ void granule_store2(grsrc_t rsrc, unsigned byte_off, unsigned epoch, float v0, float v1) {
+    const u32x4 d = {__float_as_uint(v0), epoch, __float_as_uint(v1), epoch};
+    __builtin_amdgcn_raw_buffer_store_b128(d, rsrc, byte_off, 0, /* sc1 */ 16);
+}
+// index of gate j, unit u in a (512)-granule row: gates 2 p, 2 p + 1 of a unit side by side
+__device__ __forceinline__ int granule_gate_index(int j, int u) { return ((j >> 1) * D + u) * 2 + (j & 1); }
 __device__ __forceinline__ u64 granule_load(const u64* g) { return __hip_atomic_load((gu64*)g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 constexpr unsigned L1_SPIN_LIMIT = 1u << 20;
-// every lane of the wave holds N granules: re-read until all tags carry the epoch (wave-uniform loop)
+// every lane of the wave holds N granules: re-read until all tags carry the epoch (wave-uniform loop).  The first check is straight-line
+// code: the compiler waits for exactly these loads there (the loop's wait is vmcnt(0), i.e. for every younger load and store as well).
+template <int N> __device__ __forceinline__ bool granule_ok(const u64 (&r)[N], unsigned epoch) {
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < N; ++k) ok &= (unsigned)(r[k] >> 32) == epoch;
+    return __all(ok);
+}
+// The re-poll is ONE inline-asm statement (load + wait): invisible to the compiler's wait-count bookkeeping, so the state it merges behind the
+// branch is the fast path's and the next first check still waits for exactly its own load -- with ordinary loads in the loop every later
+// check of the unrolled step loop got vmcnt(0).
+__device__ __forceinline__ u64 granule_load_sync(const u64* g) {
+    u64 r;
+    asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(g) : "memory");
+    return r;
+}
+// A projection workgroup's ring of polled granules is read with loads the compiler does not see, waited for by hand: behind the branches of
+// the unrolled step loop its own bookkeeping ends in vmcnt(0) ahead of every check, i.e. a wait for the ring load and the write-through store
+// issued one step ago -- a memory round trip per step, the projection slower than the recurrence it feeds.  Between a ring load and its check
+// eight steps later the wave issues 7 ring loads and 8 granule stores, nothing else: vmcnt(15) (memory operations retire in order).
+__device__ __forceinline__ u64 granule_load_ring(const u64* g) {
+    u64 r;
+    asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(r) : "v"(g) : "memory");
+    return r;
+}
+__device__ __forceinline__ void granule_ring_arrived(u64& r) { asm volatile("s_waitcnt vmcnt(15)" : "+v"(r)::"memory"); }
 template <int N, typename F> __device__ __forceinline__ void granule_wait(u64 (&r)[N], F&& ptr, unsigned epoch) {     // ptr(k): address of granule k
-    for (unsigned spins = 0;; ++spins) {
-        bool ok = true;
-#pragma unroll
-        for (int k = 0; k < N; ++k) ok &= (unsigned)(r[k] >> 32) == epoch;
-        if (__all(ok)) return;
-        if (spins > L1_SPIN_LIMIT) {
-#pragma unroll
-            for (int k = 0; k < N; ++k) r[k] = 0x7fc00000ull;
-            return;
-        }
+    if (__builtin_expect(granule_ok(r, epoch), 1)) return;
+    for (unsigned spins = 0; spins < L1_SPIN_LIMIT; ++spins) {
         __builtin_amdgcn_s_sleep(1);
 #pragma unroll
-        for (int k = 0; k < N; ++k) r[k] = granule_load(ptr(k));
+        for (int k = 0; k < N; ++k) r[k] = granule_load_sync(ptr(k));
+        if (granule_ok(r, epoch)) return;
     }
+#pragma unroll
+    for (int k = 0; k < N; ++k) r[k] = 0x7fc00000ull;      // a lost producer: NaNs
 }
 
 enum { L1_PLAIN = 0, L1_PUBLISH = 1, L1_GRANULES = 2 };    // inputs from memory ; the same + the step's result published ; the step's input from granules
 
 // One sample's forward recurrence over the steps [t0, t1).  Wimg: PackJob type 9 image of W_hh -- lane (u, j), float4 q =
-// W_hh[(j ^ x) * 128 + u][32 j + q] for x = 0 .. 3.
+// W_hh[(j ^ (q >> 3)) * 128 + u][32 j + 4 (q & 7) + x] for x = 0 .. 3.
 //   L1_PUBLISH : h_t * mask is also published to gout[(b T + t) 128 + u]
-//   L1_GRANULES: the input projection comes from gin[(b T + t) 512 + gate 128 + u] instead of gi
+//   L1_GRANULES: the input projection comes from gin[(b T + t) 512 + granule_gate_index(gate, u)] instead of gi
 template <int MODE>
 __device__ __forceinline__ void lstm1_fwd_body(float (&hs)[2][4 * L1_SEG], int bidx, const float* __restrict__ gi, const u64* gin,
                                                const float* __restrict__ Wimg, const float* __restrict__ bih,
@@ -291,8 +329,8 @@ __device__ __forceinline__ void lstm1_fwd_body(float (&hs)[2][4 * L1_SEG], int b
     const int u = 16 * w + b;
     const int row = bidx * T;
     const int hoff = (u >> 5) * L1_SEG + (u & 31);
-    f32x2 w01[32], w23[32];
-    lstm1_weights(Wimg, w, lane, w01, w23);
+    f32x2 wr[4][16];
+    lstm1_weights(Wimg, w, lane, wr);
     const float bs = bih[j * D + u] + bhh[j * D + u];
     const float nk = j == 2 ? -2.0f * L1_LOG2E : -L1_LOG2E;                  // gate 2 is the tanh gate: 2 sigmoid(2 z) - 1
     const float ma = j == 2 ? 2.0f : 1.0f, mb = j == 2 ? -1.0f : 0.0f;
@@ -305,11 +343,14 @@ __device__ __forceinline__ void lstm1_fwd_body(float (&hs)[2][4 * L1_SEG], int b
     float* gtp = gates + (size_t)(row + t0) * (4 * D) + j * D + u;
     float* qp = (j == 0 ? cseq : j == 1 ? out : j == 2 ? hprev + D : tseq) + (size_t)(row + t0) * D + u;
     const float* gib = MODE == L1_GRANULES ? nullptr : gi + (size_t)row * (4 * D) + j * D + u;
-    const u64* ginb = MODE == L1_GRANULES ? gin + (size_t)row * (4 * D) + j * D + u : nullptr;
+    const u64* ginb = MODE == L1_GRANULES ? gin + (size_t)row * (4 * D) + granule_gate_index(j, u) : nullptr;
     u64* goutp = MODE == L1_PUBLISH ? gout + (size_t)(row + t0) * D + u : nullptr;
     const float* mkb = mask + row;
-    float Gc[L1_NB], Gn[L1_NB], Mk[L1_NB], Mn;        // input projection + bias of the block's steps ; their masks (loaded: lane j holds step j's)
+    float Gc[L1_NB], Gn[L1_NB], Mq[L1_NB], Mn;        // input projection + bias of the block's steps ; their masks in lane 1 of the quad, 1 elsewhere (loaded: lane j holds step j's)
+    const bool j12 = j == 1 || j == 2;
     u64 Rn[L1_NB];
+#pragma unroll
+    for (int s = 0; s < L1_NB; ++s) Gn[s] = 0.f;
     int rtb = t0;                                     // block the granules in Rn belong to
     auto load_blk = [&](int tb) {
 #pragma unroll
@@ -323,6 +364,9 @@ __device__ __forceinline__ void lstm1_fwd_body(float (&hs)[2][4 * L1_SEG], int b
     };
     // (nothing is computed on a loaded value before the block is rotated in, four steps after its loads were issued)
     auto rotate = [&] {
+#pragma unroll
+        for (int s = 0; s < L1_NB; ++s) asm volatile("" : "+v"(Gn[s]));      // (keeps the compiler from waiting for the loads any earlier)
+        asm volatile("" : "+v"(Mn));
         if (MODE == L1_GRANULES) {
             granule_wait(Rn, [&](int k) { return ginb + (size_t)min(rtb + k, T - 1) * (4 * D); }, epoch);
 #pragma unroll
@@ -331,11 +375,13 @@ __device__ __forceinline__ void lstm1_fwd_body(float (&hs)[2][4 * L1_SEG], int b
 #pragma unroll
             for (int s = 0; s < L1_NB; ++s) Gc[s] = Gn[s] + bs;
         }
-        Mk[0] = quad_bcast<0>(Mn); Mk[1] = quad_bcast<1>(Mn); Mk[2] = quad_bcast<2>(Mn); Mk[3] = quad_bcast<3>(Mn);
+        const float m0 = quad_bcast<0>(Mn), m1 = quad_bcast<1>(Mn), m2 = quad_bcast<2>(Mn), m3 = quad_bcast<3>(Mn);      // (every lane runs the exchanges: a DPP read of a masked-off lane returns 0)
+        Mq[0] = j == 1 ? m0 : 1.f; Mq[1] = j == 1 ? m1 : 1.f; Mq[2] = j == 1 ? m2 : 1.f; Mq[3] = j == 1 ? m3 : 1.f;
     };
     load_blk(t0);
     rotate();
     float st_act = 0.f, st_q = 0.f;
+    lstm1_prologue_done();
     __syncthreads();
     for (int tb = t0; tb < t1; tb += L1_NB) {
 #pragma unroll
@@ -354,10 +400,10 @@ __device__ __forceinline__ void lstm1_fwd_body(float (&hs)[2][4 * L1_SEG], int b
                 *qp = st_q; qp += D;
             }
             if (s == 0) load_blk(tb + L1_NB);             // the next block's inputs
-            f32x2 s01, s23;
-            lstm1_product(hv, w01, w23, s01, s23);
+            float o[4];
+            lstm1_product(hv, wr, o);
             // lane j's gate: its register 0 + register d of lane j ^ d
-            const float z = ((s01.x + Gc[s]) + dpp_get<0xB1>(s01.y)) + (dpp_get<0x4E>(s23.x) + dpp_get<0x1B>(s23.y));
+            const float z = ((o[0] + Gc[s]) + dpp_get<0xB1>(o[1])) + (dpp_get<0x4E>(o[2]) + dpp_get<0x1B>(o[3]));
             const float act = sigmoid_rcp(z, nk) * ma + mb;
             const float ig = quad_bcast<0>(act), fg = quad_bcast<1>(act), gg = quad_bcast<2>(act), og = quad_bcast<3>(act);
             const float cn = fg * cst + ig * gg;
@@ -366,11 +412,11 @@ __device__ __forceinline__ void lstm1_fwd_body(float (&hs)[2][4 * L1_SEG], int b
             cst = cn;
             if (j == 0) hs[cur ^ 1][hoff] = hn;
             if (MODE == L1_PUBLISH) {
-                if (j == 1) granule_store(goutp, epoch, hn * Mk[s]);
+                if (j == 1) granule_store(goutp, epoch, hn * Mq[s]);
                 goutp += D;
             }
             st_act = act;
-            st_q = j == 0 ? cn : j == 1 ? hn * Mk[s] : j == 2 ? hn : th;
+            st_q = j12 ? hn * Mq[s] : (j == 0 ? cn : th);
             __syncthreads();
         }
         rotate();
@@ -391,8 +437,8 @@ __global__ __launch_bounds__(512, 2) void k_lstm1_fwd(const float* __restrict__ 
 }
 
 // One sample's backward recurrence over the steps [t0, t1) in reverse.  Wimg: PackJob type 10 image of W_hh -- lane m = lane & 15 of row
-// r4 = lane >> 4, quad i = (lane >> 2) & 3, float4 q = W_hh[32 m + q][16 w + 4 r4 + (i ^ x)] for x = 0 .. 3.
-//   L1_PUBLISH : the step's gate gradients are also published to gout[(b T + t) 512 + gate 128 + u]
+// r4 = lane >> 4, quad i = (lane >> 2) & 3, float4 q = W_hh[32 m + 4 (q & 7) + x][16 w + 4 r4 + (i ^ (q >> 3))] for x = 0 .. 3.
+//   L1_PUBLISH : the step's gate gradients are also published to gout[(b T + t) 512 + granule_gate_index(gate, u)]
 //   L1_GRANULES: the second incoming gradient comes from gin[(b T + t) 128 + u] instead of dout2
 template <int MODE>
 __device__ __forceinline__ void lstm1_bwd_body(float (&dGs)[2][16 * L1_SEG], int bb, const float* __restrict__ dout,
@@ -404,8 +450,8 @@ __device__ __forceinline__ void lstm1_bwd_body(float (&dGs)[2][16 * L1_SEG], int
     const int b = lane >> 2, j = lane & 3;
     const int u = 16 * w + b;                             // cell u ; this lane's gate j
     const int m = lane & 15;                              // product: gate rows 32 m .. + 31 into the row's four columns ; quad i keeps column i (= u)
-    f32x2 w01[32], w23[32];
-    lstm1_weights(Wimg, w, lane, w01, w23);
+    f32x2 wr[4][16];
+    lstm1_weights(Wimg, w, lane, wr);
     const int goff = (4 * j + (u >> 5)) * L1_SEG + (u & 31);
     const bool jodd = j & 1;
     float dcn = 0.f, dhr = 0.f;
@@ -418,6 +464,8 @@ __device__ __forceinline__ void lstm1_bwd_body(float (&dGs)[2][16 * L1_SEG], int
     const float* cxp = j == 1 ? cseq - D : tseq;           // (lane 1 at t = 0 reads row 0 instead and drops it: c_{-1} = 0)
     In xc[L1_NB];
     Raw xn[L1_NB];
+#pragma unroll
+    for (int s = 0; s < L1_NB; ++s) xn[s].d2 = 0.f;
     u64 Rn[L1_NB];
     int rtb = t1 - 1;                                 // block the granules in Rn belong to
     float Mk[L1_NB], Mn;
@@ -437,6 +485,9 @@ __device__ __forceinline__ void lstm1_bwd_body(float (&dGs)[2][16 * L1_SEG], int
     };
     // (nothing is computed on a loaded value before the block is rotated in, four steps after its loads were issued)
     auto rotate = [&](int tb) {
+#pragma unroll
+        for (int s = 0; s < L1_NB; ++s) asm volatile("" : "+v"(xn[s].d), "+v"(xn[s].d2), "+v"(xn[s].act), "+v"(xn[s].cx));      // (keeps the compiler from waiting for the loads any earlier)
+        asm volatile("" : "+v"(Mn));
         if (MODE == L1_GRANULES) granule_wait(Rn, [&](int k) { return gin + (size_t)(bb * T + max(rtb - k, 0)) * D + u; }, epoch);
 #pragma unroll
         for (int s = 0; s < L1_NB; ++s) {
@@ -448,8 +499,10 @@ __device__ __forceinline__ void lstm1_bwd_body(float (&dGs)[2][16 * L1_SEG], int
     };
     load_blk(t1 - 1);
     rotate(t1 - 1);
+    lstm1_prologue_done();
     float* dgp = dG + (size_t)(bb * T + t1 - 1) * (4 * D) + j * D + u;
-    u64* goutp = MODE == L1_PUBLISH ? gout + (size_t)(bb * T + t1 - 1) * (4 * D) + j * D + u : nullptr;
+    const grsrc_t grs = granule_rsrc(MODE == L1_PUBLISH ? gout + (size_t)bb * T * (4 * D) : nullptr, (unsigned)T * 4 * D * 8);
+    unsigned goff8 = ((unsigned)(t1 - 1) * 4 * D + granule_gate_index(j & 2, u)) * 8;
     float st_dv = 0.f;
     for (int tb = t1 - 1; tb >= t0; tb -= L1_NB) {
 #pragma unroll
@@ -462,7 +515,8 @@ __device__ __forceinline__ void lstm1_bwd_body(float (&dGs)[2][16 * L1_SEG], int
             const float tc = quad_bcast<0>(cx), fg = quad_bcast<1>(act), og = quad_bcast<3>(act);
             const float k1 = og * (1.f - tc * tc);
             // kdv: gate 0 (i): g i (1 - i) ; 1 (f): c_{t-1} f (1 - f) ; 2 (g): i (1 - g^2) ; 3 (o): tanh(c_t) o (1 - o)
-            const float pf = jodd ? cx : dpp_get<0xC6>(act);                  // quad_perm [2,1,0,3]: lanes 0 and 2 swap
+            const float sw = dpp_get<0xC6>(act);                              // quad_perm [2,1,0,3]: lanes 0 and 2 swap
+            const float pf = jodd ? cx : sw;
             const float kdv = pf * (__builtin_fmaf(-act, act, j == 2 ? 1.f : act));
             const float dm = xc[s].d * Mk[s];
             // ---- the recurrence
@@ -471,7 +525,11 @@ __device__ __forceinline__ void lstm1_bwd_body(float (&dGs)[2][16 * L1_SEG], int
             const float dv = (j == 3 ? dh : dc) * kdv;
             dcn = dc * fg;
             dGs[cur][goff] = dv;
-            if (MODE == L1_PUBLISH) { granule_store(goutp, epoch, dv); goutp -= 4 * D; }
+            if (MODE == L1_PUBLISH) {
+                const float dvn = dpp_get<0xB1>(dv);
+                if (!(j & 1)) granule_store2(grs, goff8, epoch, dv, dvn);
+                goff8 -= 4 * D * 8;
+            }
             if (t == 0) {                                 // dh_{-1} is not needed
                 if (s != 0 || tb != t1 - 1) { *dgp = st_dv; dgp -= 4 * D; }
                 st_dv = dv;
@@ -487,11 +545,11 @@ __device__ __forceinline__ void lstm1_bwd_body(float (&dGs)[2][16 * L1_SEG], int
             if (s != 0 || tb != t1 - 1) { *dgp = st_dv; dgp -= 4 * D; }      // (uniform) the previous step's gate gradients
             st_dv = dv;
             if (s == 0) load_blk(tb - L1_NB);
-            f32x2 s01, s23;
-            lstm1_product(gv, w01, w23, s01, s23);
+            float o[4];
+            lstm1_product(gv, wr, o);
             // 16 lanes hold sixteenth sums of four columns, register r = column i ^ r: row mirror pairs quad i with i ^ 3, the half-row
             // mirror with i ^ 1; the two passes reach every quad once, the quad adds the rest.
-            const float r0 = s01.x + dpp_get<0x140>(s23.y), r1 = s01.y + dpp_get<0x140>(s23.x);
+            const float r0 = o[0] + dpp_get<0x140>(o[3]), r1 = o[1] + dpp_get<0x140>(o[2]);
             float pr = r0 + dpp_get<0x141>(r1);
             pr += dpp_get<0xB1>(pr);
             pr += dpp_get<0x4E>(pr);                      // the same value in the quad's four lanes
@@ -531,34 +589,49 @@ __device__ __forceinline__ void lstm1_proj_fwd(float (&hs)[2][4 * L1_SEG], int b
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int b = lane >> 2, j = lane & 3;
     const int u = 16 * w + b;
-    f32x2 w01[32], w23[32];
-    lstm1_weights(Wimg, w, lane, w01, w23);
-    // waves 0, 1: lane tid waits for unit tid's granule of the step and puts it into the LDS vector
+    f32x2 wr[4][16];
+    lstm1_weights(Wimg, w, lane, wr);
+    // waves 0, 1: lane tid waits for unit tid's granule of the step and puts it into the LDS vector.  The granules of the next L1_RING steps
+    // are always in flight: a granule another XCD has just written through is ~2.4 us away, and the projection has to run faster than the
+    // recurrence it follows (0.4 against 0.57 us per step) to catch up whenever it lags -- one outstanding poll makes a step cost the whole
+    // round trip, four 0.6 us.
     const int hoff = (tid >> 5) * L1_SEG + (tid & 31);
-    u64 r[1];
     const u64* rp = gin + (size_t)bidx * T * D + (tid & (D - 1));
-    if (tid < D) r[0] = granule_load(rp);
-    u64* gp = gout + (size_t)bidx * T * (4 * D) + j * D + u;
-    for (int t = 0; t < T; ++t) {
-        const int cur = t & 1;
-        if (tid < D) {                                    // (wave-uniform)
-            granule_wait(r, [&](int) { return rp; }, epoch);
-            hs[cur][hoff] = __uint_as_float((unsigned)r[0]);
-            rp += D;
-            if (t + 1 < T) r[0] = granule_load(rp);
-        }
-        __syncthreads();
-        float4 hv[8];
-        {
-            const float4* hp = reinterpret_cast<const float4*>(hs[cur] + L1_SEG * j);
+    u64 ring[L1_RING];
+    if (tid < D) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) hv[q] = hp[q];
+        for (int k = 0; k < L1_RING; ++k) ring[k] = granule_load_ring(rp + (size_t)min(k, T - 1) * D);
+    }
+    const grsrc_t grs = granule_rsrc(gout + (size_t)bidx * T * (4 * D), (unsigned)T * 4 * D * 8);
+    unsigned goff8 = granule_gate_index(j & 2, u) * 8;
+    lstm1_prologue_done();
+    for (int tb = 0; tb < T; tb += L1_RING) {
+#pragma unroll
+        for (int k = 0; k < L1_RING; ++k) {
+            const int t = tb + k;
+            if (t >= T) break;                            // uniform
+            const int cur = t & 1;
+            if (tid < D) {                                // (wave-uniform)
+                granule_ring_arrived(ring[k]);
+                u64 r[1] = {ring[k]};
+                granule_wait(r, [&](int) { return rp + (size_t)t * D; }, epoch);
+                hs[cur][hoff] = __uint_as_float((unsigned)r[0]);
+                ring[k] = granule_load_ring(rp + (size_t)min(t + L1_RING, T - 1) * D);
+            }
+            __syncthreads();
+            float4 hv[8];
+            {
+                const float4* hp = reinterpret_cast<const float4*>(hs[cur] + L1_SEG * j);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) hv[q] = hp[q];
+            }
+            float o[4];
+            lstm1_product(hv, wr, o);
+            const float z = (o[0] + dpp_get<0xB1>(o[1])) + (dpp_get<0x4E>(o[2]) + dpp_get<0x1B>(o[3]));
+            const float zn = dpp_get<0xB1>(z);
+            if (!(j & 1)) granule_store2(grs, goff8, epoch, z, zn);
+            goff8 += 4 * D * 8;
         }
-        f32x2 s01, s23;
-        lstm1_product(hv, w01, w23, s01, s23);
-        const float z = (s01.x + dpp_get<0xB1>(s01.y)) + (dpp_get<0x4E>(s23.x) + dpp_get<0x1B>(s23.y));
-        granule_store(gp, epoch, z);
-        gp += 4 * D;
     }
 }
 
@@ -568,34 +641,42 @@ __device__ __forceinline__ void lstm1_proj_bwd(float (&dGs)[2][16 * L1_SEG], int
     const int b = lane >> 2, j = lane & 3;
     const int u = 16 * w + b;
     const int m = lane & 15;
-    f32x2 w01[32], w23[32];
-    lstm1_weights(Wimg, w, lane, w01, w23);
+    f32x2 wr[4][16];
+    lstm1_weights(Wimg, w, lane, wr);
     const int goff = (4 * j + (u >> 5)) * L1_SEG + (u & 31);
-    u64 r[1];
-    const u64* rp = gin + (size_t)(bb * T + T - 1) * (4 * D) + j * D + u;
-    r[0] = granule_load(rp);
-    u64* gp = gout + (size_t)(bb * T + T - 1) * D + u;
-    for (int t = T - 1; t >= 0; --t) {
-        const int cur = t & 1;
-        granule_wait(r, [&](int) { return rp; }, epoch);
-        dGs[cur][goff] = __uint_as_float((unsigned)r[0]);
-        rp -= 4 * D;
-        if (t > 0) r[0] = granule_load(rp);
-        __syncthreads();
-        float4 gv[8];
-        {
-            const float4* gq = reinterpret_cast<const float4*>(dGs[cur] + L1_SEG * m);
+    const u64* rp = gin + (size_t)bb * T * (4 * D) + granule_gate_index(j, u);
+    u64 ring[L1_RING];                                       // the granules of the next L1_RING steps are always in flight (see lstm1_proj_fwd)
 #pragma unroll
-            for (int q = 0; q < 8; ++q) gv[q] = gq[q];
+    for (int k = 0; k < L1_RING; ++k) ring[k] = granule_load_ring(rp + (size_t)max(T - 1 - k, 0) * (4 * D));
+    u64* gp = gout + (size_t)(bb * T + T - 1) * D + u;
+    lstm1_prologue_done();
+    for (int tb = T - 1; tb >= 0; tb -= L1_RING) {
+#pragma unroll
+        for (int k = 0; k < L1_RING; ++k) {
+            const int t = tb - k;
+            if (t < 0) break;                             // uniform
+            const int cur = t & 1;
+            granule_ring_arrived(ring[k]);
+            u64 r[1] = {ring[k]};
+            granule_wait(r, [&](int) { return rp + (size_t)t * (4 * D); }, epoch);
+            dGs[cur][goff] = __uint_as_float((unsigned)r[0]);
+            ring[k] = granule_load_ring(rp + (size_t)max(t - L1_RING, 0) * (4 * D));
+            __syncthreads();
+            float4 gv[8];
+            {
+                const float4* gq = reinterpret_cast<const float4*>(dGs[cur] + L1_SEG * m);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) gv[q] = gq[q];
+            }
+            float o[4];
+            lstm1_product(gv, wr, o);
+            const float r0 = o[0] + dpp_get<0x140>(o[3]), r1 = o[1] + dpp_get<0x140>(o[2]);
+            float pr = r0 + dpp_get<0x141>(r1);
+            pr += dpp_get<0xB1>(pr);
+            pr += dpp_get<0x4E>(pr);
+            if (j == 0) granule_store(gp, epoch, pr);
+            gp -= D;
         }
-        f32x2 s01, s23;
-        lstm1_product(gv, w01, w23, s01, s23);
-        const float r0 = s01.x + dpp_get<0x140>(s23.y), r1 = s01.y + dpp_get<0x140>(s23.x);
-        float pr = r0 + dpp_get<0x141>(r1);
-        pr += dpp_get<0xB1>(pr);
-        pr += dpp_get<0x4E>(pr);
-        if (j == 0) granule_store(gp, epoch, pr);
-        gp -= D;
     }
 }
 
