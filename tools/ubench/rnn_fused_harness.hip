@@ -13,14 +13,29 @@ __global__ __launch_bounds__(512, 2) void k_rnn_fwd_stamped(RnnFwdArgs a, long l
     const int B = a.B;
     const int role = (int)blockIdx.x / B, b = (int)blockIdx.x % B;
     const long long w0 = wall_clock64();
-    if (role < first) {}
+    if (role < first || role >= roles) {}
     else if (role == 0)
         lstm1_fwd_body<L1_PUBLISH>(hs, b, a.gi0, nullptr, a.Whh[0], a.bih[0], a.bhh[0], a.mask, a.gates[0], a.cseq[0], a.tseq[0], a.hprev[0],
                                    a.out[0], a.h_gran, a.epoch, a.T, 0, a.T);
-    else if (role == 1) { if (roles > 1) lstm1_proj_fwd(hs, b, a.h_gran, a.Wih1, a.gi_gran, a.epoch, a.T); }
-    else if (roles > 2)
+    else if (role == 1) lstm1_proj_fwd(hs, b, a.h_gran, a.Wih1, a.gi_gran, a.epoch, a.T);
+    else
         lstm1_fwd_body<L1_GRANULES>(hs, b, nullptr, a.gi_gran, a.Whh[1], a.bih[1], a.bhh[1], a.mask, a.gates[1], a.cseq[1], a.tseq[1],
                                     a.hprev[1], a.out[1], nullptr, a.epoch, a.T, 0, a.T);
+    const long long w1 = wall_clock64();
+    if (threadIdx.x == 0) { st[2 * blockIdx.x] = w0; st[2 * blockIdx.x + 1] = w1; }
+}
+
+__global__ __launch_bounds__(512, 2) void k_rnn_bwd_stamped(RnnBwdArgs a, long long* st, int roles, int first = 0) {
+    __shared__ __attribute__((aligned(16))) float dGs[2][16 * L1_SEG];
+    const int B = a.B;
+    const int role = (int)blockIdx.x / B, b = (int)blockIdx.x % B;
+    const long long w0 = wall_clock64();
+    if (role < first || role >= roles) {}
+    else if (role == 0)
+        lstm1_bwd_body<L1_PUBLISH>(dGs, b, a.dout[1], nullptr, nullptr, a.mask, a.gates[1], a.cseq[1], a.tseq[1], a.Whh[1], a.dG[1], a.dg_gran, a.epoch, a.T, nullptr, 0, a.T);
+    else if (role == 1) lstm1_proj_bwd(dGs, b, a.dg_gran, a.Wih1, a.dx_gran, a.epoch, a.T);
+    else
+        lstm1_bwd_body<L1_GRANULES>(dGs, b, a.dout[0], nullptr, a.dx_gran, a.mask, a.gates[0], a.cseq[0], a.tseq[0], a.Whh[0], a.dG[0], nullptr, a.epoch, a.T, nullptr, 0, a.T);
     const long long w1 = wall_clock64();
     if (threadIdx.x == 0) { st[2 * blockIdx.x] = w0; st[2 * blockIdx.x + 1] = w1; }
 }
@@ -84,6 +99,51 @@ int main(int argc, char** argv) {
         long long lo = 1ll << 62, hi = 0;
         for (int b = 0; b < B; ++b) { lo = std::min(lo, h[2 * (first * B + b) + 1] - h[2 * (first * B + b)]); hi = std::max(hi, h[2 * (first * B + b) + 1] - h[2 * (first * B + b)]); }
         printf("role %d alone, every granule ready: %.2f .. %.2f us for %d steps\n", first, lo * 0.01, hi * 0.01, T);
+    }
+    {   // ---- backward: the same three roles in reverse (end LSTM, dG W_ih projection, start LSTM), on what the forward saved
+        std::vector<float> himb((size_t)4 * D * D), hd(R * D);
+        for (int e = 0; e < 4 * D * D; ++e) {
+            const int x = e & 3, ln = (e >> 2) & 63, q = (e >> 8) & 31, wv = e >> 13, r = q >> 3, kk = 4 * (q & 7) + x;
+            himb[e] = hw[(size_t)(32 * (ln & 15) + kk) * D + 16 * wv + 4 * (ln >> 4) + (((ln >> 2) & 3) ^ r)];
+        }
+        for (auto& v : hd) v = (rand() / (float)RAND_MAX - 0.5f) * 0.01f;
+        RnnBwdArgs g;
+        memset(&g, 0, sizeof g);
+        float* imb = dev(himb.size(), himb.data());
+        float* dd = dev(hd.size(), hd.data());
+        g.mask = a.mask; g.Wih1 = imb;
+        for (int l = 0; l < 2; ++l) { g.dout[l] = dd; g.gates[l] = a.gates[l]; g.cseq[l] = a.cseq[l]; g.tseq[l] = a.tseq[l]; g.Whh[l] = imb; g.dG[l] = dev(R * 4 * D, nullptr); }
+        g.dg_gran = (unsigned long long*)dev(R * 8 * D, nullptr); g.dx_gran = (unsigned long long*)dev(R * 2 * D, nullptr);
+        g.B = B; g.T = T;
+        for (int roles = 1; roles <= 3; ++roles) {
+            float best = 1e9f;
+            std::vector<long long> h(6 * B);
+            for (int rep = 0; rep < 6; ++rep) {
+                g.epoch = ++epoch;
+                CHECK(hipEventRecord(e0));
+                hipLaunchKernelGGL(k_rnn_bwd_stamped, dim3(3 * B), dim3(512), 0, 0, g, st, roles, 0);
+                CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize());
+                float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+                if (ms < best) { best = ms; CHECK(hipMemcpy(h.data(), st, 6 * B * 8, hipMemcpyDeviceToHost)); }
+            }
+            long long base = h[0];
+            for (int i = 0; i < 3 * B; ++i) base = std::min(base, h[2 * i]);
+            printf("backward, roles 0 .. %d live: %.1f us per launch\n", roles - 1, best * 1e3);
+            for (int role = 0; role < roles; ++role) {
+                long long e0_ = 1ll << 62, e1_ = 0;
+                for (int b = 0; b < B; ++b) { const long long e = h[2 * (role * B + b) + 1] - base; e0_ = std::min(e0_, e); e1_ = std::max(e1_, e); }
+                printf("   role %d ends %.2f .. %.2f us\n", role, e0_ * 0.01, e1_ * 0.01);
+            }
+        }
+        for (int first = 1; first <= 2; ++first) {
+            std::vector<long long> h(6 * B);
+            hipLaunchKernelGGL(k_rnn_bwd_stamped, dim3(3 * B), dim3(512), 0, 0, g, st, first + 1, first);
+            CHECK(hipDeviceSynchronize());
+            CHECK(hipMemcpy(h.data(), st, 6 * B * 8, hipMemcpyDeviceToHost));
+            long long lo = 1ll << 62, hi = 0;
+            for (int b = 0; b < B; ++b) { lo = std::min(lo, h[2 * (first * B + b) + 1] - h[2 * (first * B + b)]); hi = std::max(hi, h[2 * (first * B + b) + 1] - h[2 * (first * B + b)]); }
+            printf("backward role %d alone, every granule ready: %.2f .. %.2f us for %d steps\n", first, lo * 0.01, hi * 0.01, T);
+        }
     }
     // product launch
     for (int rep = 0; rep < 3; ++rep) { a.epoch = ++epoch; launch_rnn_fwd(a, 0); }

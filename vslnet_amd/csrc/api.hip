@@ -573,15 +573,15 @@ CharConvPtrs char_ptrs(const Ctx& c) {
     return cc;
 }
 
-// Time chunks of the pipelined rnn head (lengths in processing order): n equal chunks.  The second LSTM lags the first by one chunk (T / n steps
-// of ~0.85 us) and every chunk boundary is a cross-stream hop (~15 us on the chain: a stream that is already blocked on an event wakes up late),
-// so n ~ sqrt(0.85 T / 15): 3 chunks at T = 128, 4 at T = 256.  Round 4, with the GEMMs on the third stream, ms per step at B = 16 | 64 for
-// 8 / 6 / 4 / 3 / 2 chunks: 1.072 | 1.255, 1.004 | 1.170, 0.949 | 1.119, 0.928 | 1.113, 0.931 | 1.111.  Measured and dropped (profiles/r04_notes.md
-// section 7): a shorter last chunk (0.950 against 0.938), the start LSTM's own input projection chunked (0.939: nothing), the start LSTM's dx GEMM
-// chunk by chunk on the third stream (1.051: every extra hop costs more than the 7 us GEMM it hides).
+// Time chunks of the rnn head's CHUNKED launches (batches the one-launch pipeline of kernels_lstm.hip does not take: 80 < B <= 256 and the
+// 4-sample groups beyond; lengths in processing order): n equal chunks.  The second LSTM lags the first by one chunk and every chunk boundary is a
+// cross-stream hop (~10-15 us on the chain: a stream that is already blocked on an event wakes up late), so n ~ sqrt(0.06 T): 3 chunks at
+// T = 128, 4 at T = 256.  With the round-4 step (0.6 us) the choice hardly matters any more -- ms per step at B = 16, T = 128 for 1 / 2 / 3 / 4 / 6
+// chunks: 0.823, 0.816, 0.817, 0.831, 0.869 (profiles/r04_rnn_chunk_sweep.txt): the hops eat what the overlap gains, which is why small batches
+// go through k_rnn_fwd / k_rnn_bwd instead.  Measured and dropped earlier (profiles/r04_notes.md section 7): a shorter last chunk, the start
+// LSTM's own input projection chunked, the start LSTM's dx GEMM chunk by chunk on the third stream.
 std::vector<int> lstm_chunks(int T) {
-    int n = std::max(1, (int)std::lround(std::sqrt(0.06 * T)));
-    if (const char* e = getenv("VSL_DBG_CHUNKS")) n = atoi(e);
+    const int n = std::max(1, (int)std::lround(std::sqrt(0.06 * T)));
     std::vector<int> out;
     for (int i = 0; i < n; ++i) out.push_back((T * (i + 1)) / n - (T * i) / n);
     return out;
@@ -650,10 +650,11 @@ void run_forward(Ctx& c) {
                   c.s));
     if (cf.predictor == 0) {
         // rnn head (:341-343): start = LSTM_s(x) * mask ; end = LSTM_e(start) * mask ; no LayerNorm in front of the span blocks
-        // The recurrence is latency bound (one 16-sample group per CU, 6.2 us per step), so the two LSTMs are pipelined in
-        // TIME CHUNKS: while the start LSTM runs chunk k + 1 on the main stream, the side stream projects its chunk k
-        // (x W_ih^T of the end LSTM, a row-mapped GEMM) and runs the end LSTM over it.  A chunk launch resumes from the state
-        // the previous one saved for the backward (h_{t-1}, c_{t-1}).  Chunking: lstm_chunks().
+        // The recurrence is latency bound (one sample per CU, 0.6 us per step).  Up to RNN_FUSED_MAX_B samples the whole head is ONE launch: start
+        // LSTM, input projection and end LSTM as three workgroups per sample that hand each step over in-launch (k_rnn_fwd).  Larger batches
+        // pipeline the two LSTMs in TIME CHUNKS over three streams: while the start LSTM runs chunk k + 1 on the main stream, a side stream
+        // projects its chunk k (x W_ih^T of the end LSTM, a row-mapped GEMM) and another runs the end LSTM over it.  A chunk launch resumes from
+        // the state the previous one saved for the backward (h_{t-1}, c_{t-1}).  Chunking: lstm_chunks().
         const std::vector<int> chunks = lstm_chunks(T);
         auto lstm = [&](int l, int t0, int t1) {
             const LstmWs& w = p.lstm[l];

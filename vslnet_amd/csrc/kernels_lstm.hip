@@ -342,6 +342,7 @@ __device__ __forceinline__ void lstm1_fwd_body(float (&hs)[2][4 * L1_SEG], int b
     // step's after the loop -- the only place where h_t of t = T - 1 (no hprev row) has to be held back.
     float* gtp = gates + (size_t)(row + t0) * (4 * D) + j * D + u;
     float* qp = (j == 0 ? cseq : j == 1 ? out : j == 2 ? hprev + D : tseq) + (size_t)(row + t0) * D + u;
+    float* qfirst = j == 2 ? tseq + (size_t)(row + t0) * D + u : qp;      // (placeholder target of lane 2: h_t's hprev row may not exist, t0 + 1 = T)
     const float* gib = MODE == L1_GRANULES ? nullptr : gi + (size_t)row * (4 * D) + j * D + u;
     const u64* ginb = MODE == L1_GRANULES ? gin + (size_t)row * (4 * D) + granule_gate_index(j, u) : nullptr;
     u64* goutp = MODE == L1_PUBLISH ? gout + (size_t)(row + t0) * D + u : nullptr;
@@ -395,7 +396,13 @@ __device__ __forceinline__ void lstm1_fwd_body(float (&hs)[2][4 * L1_SEG], int b
 #pragma unroll
                 for (int q = 0; q < 8; ++q) hv[q] = hp[q];
             }
-            if (s != 0 || tb != t0) {                     // (uniform) the previous step's stores
+            // the previous step's stores.  The launch's first step has none: it writes placeholders into its own rows, which the next
+            // step overwrites (same lanes, same addresses, in order) -- so that BOTH sides of the branch issue two stores: a memory
+            // instruction on one side only leaves the compiler's wait counts behind the join at their worst case, vmcnt(0)
+            if (s == 0 && tb == t0) {                     // (uniform)
+                *gtp = st_act;
+                *qfirst = st_q;
+            } else {
                 *gtp = st_act; gtp += 4 * D;
                 *qp = st_q; qp += D;
             }
@@ -497,6 +504,16 @@ __device__ __forceinline__ void lstm1_bwd_body(float (&dGs)[2][16 * L1_SEG], int
         }
         Mk[0] = quad_bcast<0>(Mn); Mk[1] = quad_bcast<1>(Mn); Mk[2] = quad_bcast<2>(Mn); Mk[3] = quad_bcast<3>(Mn);
     };
+    // step 0 ends the recurrence (dh_{-1} is not needed): it runs behind the loop, on inputs of its own
+    float z_d = 0.f, z_act = 0.f, z_cx = 0.f, z_mk = 0.f;
+    if (t0 == 0) {                                        // (uniform)
+        const unsigned base = (unsigned)(bb * T);
+        z_d = dout[base * D + u];
+        if (MODE != L1_GRANULES && dout2) z_d += dout2[base * D + u];
+        z_act = gates[base * (4 * D) + j * D + u];
+        z_cx = j == 1 ? 0.f : tseq[base * D + u];
+        z_mk = mask[base];
+    }
     load_blk(t1 - 1);
     rotate(t1 - 1);
     lstm1_prologue_done();
@@ -504,37 +521,35 @@ __device__ __forceinline__ void lstm1_bwd_body(float (&dGs)[2][16 * L1_SEG], int
     const grsrc_t grs = granule_rsrc(MODE == L1_PUBLISH ? gout + (size_t)bb * T * (4 * D) : nullptr, (unsigned)T * 4 * D * 8);
     unsigned goff8 = ((unsigned)(t1 - 1) * 4 * D + granule_gate_index(j & 2, u)) * 8;
     float st_dv = 0.f;
-    for (int tb = t1 - 1; tb >= t0; tb -= L1_NB) {
+    // one step up to the gate gradients: dc = dh k1 + dc_next ; dv = (gate 3: dh, else dc) kdv ; dc_next = dc f
+    auto gate_grads = [&](float d, float mk, float act, float cx) {
+        const float tc = quad_bcast<0>(cx), fg = quad_bcast<1>(act), og = quad_bcast<3>(act);
+        const float k1 = og * (1.f - tc * tc);
+        // kdv: gate 0 (i): g i (1 - i) ; 1 (f): c_{t-1} f (1 - f) ; 2 (g): i (1 - g^2) ; 3 (o): tanh(c_t) o (1 - o)
+        const float sw = dpp_get<0xC6>(act);                              // quad_perm [2,1,0,3]: lanes 0 and 2 swap
+        const float pf = jodd ? cx : sw;
+        const float kdv = pf * (__builtin_fmaf(-act, act, j == 2 ? 1.f : act));
+        // ---- the recurrence
+        const float dh = d * mk + dhr;                // (dhr = 0 going into t = T - 1)
+        const float dc = __builtin_fmaf(dh, k1, dcn);
+        const float dv = (j == 3 ? dh : dc) * kdv;
+        dcn = dc * fg;
+        if (MODE == L1_PUBLISH) {
+            const float dvn = dpp_get<0xB1>(dv);
+            if (!(j & 1)) granule_store2(grs, goff8, epoch, dv, dvn);
+            goff8 -= 4 * D * 8;
+        }
+        return dv;
+    };
+    const int tl = max(t0, 1);
+    for (int tb = t1 - 1; tb >= tl; tb -= L1_NB) {
 #pragma unroll
         for (int s = 0; s < L1_NB; ++s) {
             const int t = tb - s;
-            if (t < t0) break;                            // uniform
+            if (t < tl) break;                            // uniform
             const int cur = t & 1;
-            // the step's factors: dc = dh k1 + dc_next ; dv = (gate 3: dh, else dc) kdv ; dc_next = dc f
-            const float act = xc[s].act, cx = xc[s].cx;
-            const float tc = quad_bcast<0>(cx), fg = quad_bcast<1>(act), og = quad_bcast<3>(act);
-            const float k1 = og * (1.f - tc * tc);
-            // kdv: gate 0 (i): g i (1 - i) ; 1 (f): c_{t-1} f (1 - f) ; 2 (g): i (1 - g^2) ; 3 (o): tanh(c_t) o (1 - o)
-            const float sw = dpp_get<0xC6>(act);                              // quad_perm [2,1,0,3]: lanes 0 and 2 swap
-            const float pf = jodd ? cx : sw;
-            const float kdv = pf * (__builtin_fmaf(-act, act, j == 2 ? 1.f : act));
-            const float dm = xc[s].d * Mk[s];
-            // ---- the recurrence
-            const float dh = dm + dhr;                    // (dhr = 0 going into t = T - 1)
-            const float dc = __builtin_fmaf(dh, k1, dcn);
-            const float dv = (j == 3 ? dh : dc) * kdv;
-            dcn = dc * fg;
+            const float dv = gate_grads(xc[s].d, Mk[s], xc[s].act, xc[s].cx);
             dGs[cur][goff] = dv;
-            if (MODE == L1_PUBLISH) {
-                const float dvn = dpp_get<0xB1>(dv);
-                if (!(j & 1)) granule_store2(grs, goff8, epoch, dv, dvn);
-                goff8 -= 4 * D * 8;
-            }
-            if (t == 0) {                                 // dh_{-1} is not needed
-                if (s != 0 || tb != t1 - 1) { *dgp = st_dv; dgp -= 4 * D; }
-                st_dv = dv;
-                break;
-            }
             __syncthreads();
             float4 gv[8];
             {
@@ -542,7 +557,10 @@ __device__ __forceinline__ void lstm1_bwd_body(float (&dGs)[2][16 * L1_SEG], int
 #pragma unroll
                 for (int q = 0; q < 8; ++q) gv[q] = gp[q];
             }
-            if (s != 0 || tb != t1 - 1) { *dgp = st_dv; dgp -= 4 * D; }      // (uniform) the previous step's gate gradients
+            // the previous step's gate gradients (the launch's first step writes a placeholder into its own row instead: every step issues
+            // the same memory instructions, see lstm1_fwd_body)
+            *dgp = st_dv;
+            dgp -= (s == 0 && tb == t1 - 1) ? 0 : 4 * D;
             st_dv = dv;
             if (s == 0) load_blk(tb - L1_NB);
             float o[4];
@@ -556,6 +574,16 @@ __device__ __forceinline__ void lstm1_bwd_body(float (&dGs)[2][16 * L1_SEG], int
             dhr = pr;
         }
         rotate(tb - L1_NB);
+    }
+    if (t0 == 0) {                                        // (uniform)
+        if (MODE == L1_GRANULES) {
+            u64 r[1] = {granule_load_sync(gin + (size_t)(bb * T) * D + u)};
+            granule_wait(r, [&](int) { return gin + (size_t)(bb * T) * D + u; }, epoch);
+            z_d += __uint_as_float((unsigned)r[0]);
+        }
+        const float dv = gate_grads(z_d, z_mk, z_act, z_cx);
+        if (t1 - 1 >= tl) { *dgp = st_dv; dgp -= 4 * D; }
+        st_dv = dv;
     }
     if (t1 > t0) *dgp = st_dv;
     if (t0 > 0 && j == 0) {
