@@ -28,13 +28,14 @@ python bench.py --steps 30 --warmup 10 --no-cpu-baseline --dtype bf16 > $O/${TAG
 python bench.py --steps 30 --warmup 10 --no-cpu-baseline --predictor rnn --batch 16 > $O/${TAG}_bench_rnn_b16_configs0.json 2>/dev/null
 python bench.py --steps 30 --warmup 10 --no-cpu-baseline --predictor rnn --batch 64 > $O/${TAG}_bench_rnn_b64.json 2>/dev/null
 bash tools/bench_shapes.sh > $O/${TAG}_bench_shapes.txt 2>/dev/null
-# per-kernel stats of the other BASELINE configs (configs[2..4]: per-GPU shapes)
+# per-kernel stats of the other BASELINE configs (configs[0]: the rnn head, with a one-step timeline; configs[2..4]: per-GPU shapes)
 cd /tmp
-for cfg in "2 --batch 32 --T 256 --dv 4096" "3 --batch 32 --T 256" "4 --batch 16 --T 1024"; do
+for cfg in "0 --predictor rnn --batch 16" "2 --batch 32 --T 256 --dv 4096" "3 --batch 32 --T 256" "4 --batch 16 --T 1024"; do
   set -- $cfg; n=$1; shift
   rm -rf $O/c$n
   rocprofv3 --kernel-trace --stats -d $O/c$n -o s -- python $R/bench.py --steps 12 --warmup 4 --no-cpu-baseline "$@" > /dev/null 2> $O/c$n.err
   python $R/tools/rocpd_stats.py $(find $O/c$n -name "*.db" | head -1) > $O/${TAG}_configs${n}_kernel_stats.txt
+  if [ $n = 0 ]; then python $R/tools/rocpd_timeline.py $(find $O/c$n -name "*.db" | head -1) 8 > $O/${TAG}_configs0_timeline.txt; fi
   rm -rf $O/c$n
 done
 cd $R
