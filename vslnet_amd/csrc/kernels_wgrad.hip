@@ -238,10 +238,8 @@ __global__ __launch_bounds__(WG4_T, 1) void k_wgrad4(WgradBatch wb) {
     // ---- staging role: row pair rg of the step (rows 2 rg, 2 rg + 1), column pair cp (columns 2 cp, 2 cp + 1) of both operands.
     //      lane = (rg, cp & 7): the 64 lanes of a wave write 32 distinct banks (all lanes on one row pair would hit 8)
     const int rg = lane >> 3, cp = 8 * wv + (lane & 7);
-    const float* gsrc = j.G[gb] + (size_t)(rbeg + 2 * rg) * ldg + 2 * cp;
     const int kcol = kt * 128 + 2 * cp;                       // column of dW / of Afull
     const bool kin = kcol < K;                                // K is even
-    const float* asrc = (blocks ? j.A[kt] + 2 * cp : j.Afull + (kin ? kcol : 0)) + (size_t)(rbeg + 2 * rg) * lda;
     // ---- MFMA role: wave = rows 64 nh .. + 63 (two 32-row blocks) x columns 32 kq .. + 31 of the 128 x 128 block
     const int nh = wv & 1, kq = wv >> 1, i = lane & 31, h = lane >> 5;
     const bool want_bias = kt == 0 && j.out_bias[gb] != nullptr;
@@ -249,13 +247,17 @@ __global__ __launch_bounds__(WG4_T, 1) void k_wgrad4(WgradBatch wb) {
     zero_acc(acc);
     float bs0 = 0.f, bs1 = 0.f;
     float2 rawg[WG4_NB][2], rawa[WG4_NB][2];
+    // Loads are UNCONDITIONAL (a row past the chunk re-reads its last row, a column past K column 0) and the zeroing happens at staging time:
+    // a load under an exec-masked branch costs the compiler its count of what is in flight, and its one wait per ring turn became vmcnt(0) --
+    // for the four loads issued a few instructions earlier as well, a memory round trip every WG4_NB steps (round 4).
+    const float* gbase = j.G[gb] + 2 * cp;
+    const float* abase = blocks ? j.A[kt] + 2 * cp : j.Afull + (kin ? kcol : 0);
     auto ld = [&](int s, float2 (&g)[2], float2 (&a)[2]) {
-        const int r0 = 16 * s + 2 * rg;                       // first row of the pair inside the chunk
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const bool ok = r0 + q < nrows;
-            g[q] = ok ? *reinterpret_cast<const float2*>(gsrc + (size_t)(16 * s + q) * ldg) : make_float2(0.f, 0.f);
-            a[q] = (ok && kin) ? *reinterpret_cast<const float2*>(asrc + (size_t)(16 * s + q) * lda) : make_float2(0.f, 0.f);
+            const size_t row = (size_t)min(rbeg + 16 * s + 2 * rg + q, rend - 1);
+            g[q] = *reinterpret_cast<const float2*>(gbase + row * ldg);
+            a[q] = *reinterpret_cast<const float2*>(abase + row * lda);
         }
     };
     // rows 2 rg, 2 rg + 1 of column c of operand o.  (The one-product form converts through an opaque asm: with the vector builtin clang
@@ -268,7 +270,14 @@ __global__ __launch_bounds__(WG4_T, 1) void k_wgrad4(WgradBatch wb) {
             Ps[wg4_idx(buf, o, 0, c, rg)] = hh; Ps[wg4_idx(buf, o, 1, c, rg)] = mm; Ps[wg4_idx(buf, o, 2, c, rg)] = ll;
         }
     };
-    auto stage = [&](int s, int buf, const float2 (&g)[2], const float2 (&a)[2]) {
+    auto stage = [&](int s, int buf, const float2 (&gr)[2], const float2 (&ar)[2]) {
+        float2 g[2], a[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const bool ok = 16 * s + 2 * rg + q < nrows;
+            g[q] = ok ? gr[q] : make_float2(0.f, 0.f);
+            a[q] = (ok && kin) ? ar[q] : make_float2(0.f, 0.f);
+        }
         if (want_bias) { bs0 += g[0].x + g[1].x; bs1 += g[0].y + g[1].y; }
         put(buf, 0, 2 * cp, g[0].x, g[1].x);
         put(buf, 0, 2 * cp + 1, g[0].y, g[1].y);
