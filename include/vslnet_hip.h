@@ -59,7 +59,9 @@ typedef struct {
     float* h_score;                /* (B, T)  exactly 0 at padded clips                                            */
     float* start_logits;           /* (B, T)  exactly -1e30 at padded clips                                        */
     float* end_logits;             /* (B, T)                                                                       */
-    /* saved activations + backward temporaries; vsl_workspace_floats() floats, caller-owned                       */
+    /* saved activations + backward temporaries; vsl_workspace_floats() floats, caller-owned, 16-byte aligned.      */
+    /* Needs no initialisation, may be reused between shapes and handles (the rnn head's in-launch hand-off buffers */
+    /* live here: their tags are per-process NaN-patterned epochs, nothing older reads as valid).                   */
     float* workspace;
     /* dropout (nn.Dropout sites of layers_t7.py): counter-based masks, keyed by (seed, site, element)             */
     int32_t training;              /* 0: eval (no dropout)                                                         */
