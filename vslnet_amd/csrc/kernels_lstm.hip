@@ -12,7 +12,8 @@
 //   backward: the same lane computes the cell's four gate gradients -> LDS (4 x 512, A operand) and memory; dh_{t-1} = dG_t W_hh:
 //             wave w contracts gate rows 64 w .. 64 w + 63 into all 128 columns (B operand = W_hh[row][64 cg + 4 b + j], 128
 //             registers), the 8 partial tiles are added through LDS by the cell owners.
-// Same saved tensors, chunk / carry interface and launch signatures as the 16-sample kernels (VSL_LSTM4=0 selects those).
+// These 4-sample kernels serve B > 256 (and VSL_LSTM1=0); smaller batches run one sample per workgroup on the vector pipe (second half of this
+// file), up to 80 samples as ONE launch per direction for the whole rnn head (k_rnn_fwd / k_rnn_bwd at the end).
 #include "common.hpp"
 #include "launch.hpp"
 
