@@ -268,7 +268,7 @@ def main():
             if dist is not None and not skip_exchange:
                 dist.all_reduce(grads)
         if not args.no_optimizer:
-            opt.step(grads)
+            opt.step(grads, from_backward=xchg is None and dist is None)      # one process: the bucket is what the backward left
         return losses
 
     for i in range(args.warmup):

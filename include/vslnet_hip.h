@@ -96,7 +96,7 @@ typedef struct {
 } vsl_io;
 /* Every struct of this header must be zero-initialised by the caller before the fields are set: new optional fields are appended, and
  * zero means "off".  vsl_abi_version() changes whenever a struct layout or an entry point's meaning changes; a binding checks it once. */
-#define VSL_ABI_VERSION 5
+#define VSL_ABI_VERSION 6
 int vsl_abi_version(void);
 
 /* labels + weights for the fused loss (replaces compute_loss / compute_highlight_loss, VSLNet_t7.py:67-72, and the
@@ -146,7 +146,7 @@ int vsl_extract_index(vsl_handle h, const float* start_logits, const float* end_
 
 /* Optimizer step on the flat buckets: clip_grad_norm_(grads, clip_norm) (main_t7.py:111) followed by AdamW with decoupled
  * weight decay (build_optimizer_and_scheduler, VSLNet_t7.py:8-17: no decay for names containing "bias", "layer_norm" or
- * "LayerNorm" -- the library derives that mask from its own parameter names).  Two kernels, no host synchronisation: the
+ * "LayerNorm" -- the library derives that mask from its own parameter names).  Two kernels (one with norm_from_backward), no host synchronisation: the
  * global norm stays on the device.  Semantics are torch.optim.AdamW's (the reference's transformers.AdamW no longer
  * exists; SURVEY 8c "optimizer parity unpinned"):
  *     g   = grads * min(1, clip_norm / (||grads||_2 + 1e-6))            (clip_norm <= 0: no clipping)
@@ -162,6 +162,11 @@ typedef struct {
      * (VSLNet_t7.py:5,14; class removed from transformers 5.x, semantics from its published source):
      *     p -= lr * sqrt(1 - b2^t) / (1 - b1^t) * m / (sqrt(v) + eps) ;  then  p -= lr * weight_decay[param] * p          */
     int32_t hf_order;
+    /* 1: the caller vouches that `grads` is exactly what the last vsl_backward of this handle left (no all-reduce, no scaling in
+     * between: single-GPU training).  The global norm is then taken from the sums of squares the backward's final reduction
+     * recorded per block instead of another pass over the bucket (one kernel less on the step's tail); the un-clipped norm agrees
+     * with the two-kernel form to fp32 rounding (another summation order).  An error if `grads` is another buffer. */
+    int32_t norm_from_backward;
 } vsl_adamw;
 int vsl_adamw_step(vsl_handle h, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                    const vsl_adamw* hp, float* grad_norm_out, void* hip_stream);

@@ -187,7 +187,7 @@ def train(configs, dataset, features, device, world, rank, log=print):
                         else:
                             eng.backward(d_h, d_sl, d_el, grads)
                             dp.allreduce_flat_(grads)
-                    opt.step(grads)
+                    opt.step(grads, from_backward=world == 1)
                     loss_t = losses[2]
                 else:
                     _, vfeats, vfeat_lens, word_ids, char_ids, s_labels, e_labels, h_labels = batch

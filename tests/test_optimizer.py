@@ -97,6 +97,44 @@ def test_fused_adamw_kernels_match_torch_optim():
         eng.adamw_step(flat, grads_seq[0].cuda(), opt.m, opt.v, 1e-3, 0)               # step must be >= 1
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('predictor', ['transformer', 'rnn'])
+def test_norm_from_backward_matches_the_two_kernel_step(predictor):
+    """vsl_adamw.norm_from_backward (round 4): the clip's global norm out of the sums of squares the backward's final reduction records per
+    block, instead of a k_sqsum pass over the bucket.  Same norm to fp32 rounding, same update; NaNs in the bucket's alignment pads (which
+    no kernel writes) do not reach it; another bucket than the last backward's is refused."""
+    from oracle import vslnet_oracle as O
+    from vslnet_amd.engine import Engine, VslError, flat_from_state_dict
+    cfg = O.make_cfg(video_feature_dim=64, max_pos_len=64, word_size=52, predictor=predictor, drop_rate=0.2)
+    P = O.random_params(cfg, seed=2)
+    eng = Engine(cfg)
+    d = {k: v.cuda().contiguous() for k, v in O.synthetic_batch(cfg, B=5, T=40, Lq=7, Lc=6, seed=4, ragged=True).items()}
+    pad, glove = P['embedding_net.word_emb.pad_vec'].cuda(), P['embedding_net.word_emb.glove_vec'].cuda()
+    flat = flat_from_state_dict(eng, P)
+    eng.forward(flat, pad, glove, d['word_ids'], d['char_ids'], d['vfeats'], d['v_mask'], d['q_mask'], training=True, seed=3)
+    _, d_h, d_sl, d_el = eng.loss(d['s_labels'], d['e_labels'], d['h_labels'], 1.0, 5.0)
+    grads = torch.full((eng.param_floats,), float('nan'), device='cuda')       # pads stay NaN: the k_sqsum form could not take this bucket
+    eng.backward(d_h, d_sl, d_el, grads)
+    real = torch.zeros(eng.param_floats, dtype=torch.bool, device='cuda')
+    for _, off, numel, _ in eng.layout:
+        real[off:off + numel] = True
+    want = float(torch.linalg.vector_norm(grads[real].double()))
+    clean = torch.where(real, grads, torch.zeros_like(grads))
+    out = []
+    for fused in (False, True):
+        f, m, v, gn = flat.clone(), torch.zeros_like(flat), torch.zeros_like(flat), torch.zeros(1, device='cuda')
+        eng.adamw_step(f, grads if fused else clean, m, v, 1e-3, 1, clip_norm=0.05, grad_norm_out=gn, norm_from_backward=fused) if fused else \
+            eng.adamw_step(f, clean, m, v, 1e-3, 1, clip_norm=0.05, grad_norm_out=gn)
+        torch.cuda.synchronize()
+        out.append((f[real], m[real], v[real], float(gn)))
+    assert abs(out[0][3] - want) <= 2e-6 * want and abs(out[1][3] - want) <= 2e-6 * want, (out[0][3], out[1][3], want)
+    assert want > 0.05                                                          # the clip is active: the norm matters
+    for a, b, nm in zip(out[0][:3], out[1][:3], ('params', 'exp_avg', 'exp_avg_sq')):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-9), nm
+    with pytest.raises(VslError, match='norm_from_backward'):
+        eng.adamw_step(flat.clone(), clean, torch.zeros_like(flat), torch.zeros_like(flat), 1e-3, 1, norm_from_backward=True)
+
+
 def _hf_adamw_steps(P, layout, grads_seq, lr0, total, eps=1e-6, wd=0.01, clip=1.0):
     """The historical transformers.AdamW (the class VSLNet_t7.py:5 imports; removed from transformers 5.x), restated from its
     published source, per parameter, in float64: exp_avg / exp_avg_sq update, step_size = lr * sqrt(1 - b2^t) / (1 - b1^t),

@@ -77,6 +77,8 @@ struct Plan {
     std::vector<int64_t> part_offs;     // sequence of partial-arena allocations made by the backward
     ReduceSeg* segs_dev = nullptr;
     int* blk2seg_dev = nullptr;         // block table: [early blocks | late blocks]
+    float* sq_dev = nullptr;            // [nblocks] sum of squares of each reduction block's results (the clip's global norm, vsl_adamw.norm_from_backward)
+    bool sq_cover = false;              // the reduction blocks write every element of the gradient bucket exactly once
     int nblocks = 0, nblocks_early = 0;
     uint64_t last_use = 0;              // LRU stamp of the plan cache (get_plan)
 };
@@ -96,6 +98,9 @@ struct vsl_handle_s {
     unsigned* loss_counter = nullptr;    // arrival counter of k_loss_fused (zero between calls)
     uint8_t* decay_dev = nullptr;        // per-element weight-decay flag of the flat bucket (vsl_adamw_step)
     float* opt_scratch = nullptr;        // OPT_BLOCKS partial sums of grads^2
+    const float* sq_src = nullptr;       // the last vsl_backward's per-block sums of squares (Plan::sq_dev), their count, the bucket they describe
+    int sq_n = 0;
+    const float* sq_grads = nullptr;
     std::map<std::tuple<int, int, int, int>, Plan*> plans;
     uint64_t plan_clock = 0;
     // side streams for the independent chains (query branch, weight gradients) + fork/join events
@@ -998,7 +1003,7 @@ void run_backward(Ctx& c) {
     // (the pooled-query parameters of k_cq_bwd_d belong to the late reduction: that kernel opens the query chain below).
     // ONE event for both consumers: the early reduction on sw and the fork of the query side onto sq
     c.order2(c.s, sw, sq);
-    { hipStream_t keep = c.s; c.s = sw; LAUNCH("reduce", launch_reduce(c.ws, io->grads, p.segs_dev, p.blk2seg_dev, p.nblocks_early, c.s)); c.s = keep; }
+    { hipStream_t keep = c.s; c.s = sw; LAUNCH("reduce", launch_reduce(c.ws, io->grads, p.segs_dev, p.blk2seg_dev, p.nblocks_early, p.sq_dev, c.s)); c.s = keep; }
     // data parallel: the predictor block of the gradient bucket is final now -- the caller's all-reduce of it can start (vslnet_hip.h)
     if (!c.dry && io->early_grads_event && cf.predictor == 1) (void)hipEventRecord((hipEvent_t)io->early_grads_event, sw);
     // from here the video side and the query side are independent; the longer one keeps the main stream
@@ -1071,7 +1076,7 @@ void run_backward(Ctx& c) {
     c.s = main_s;
     c.order(sq, c.s);                      // join both side streams before the reduction
     c.order(sw, c.s);
-    LAUNCH("reduce", launch_reduce(c.ws, io->grads, p.segs_dev, p.blk2seg_dev + 2 * p.nblocks_early, p.nblocks - p.nblocks_early, c.s));
+    LAUNCH("reduce", launch_reduce(c.ws, io->grads, p.segs_dev, p.blk2seg_dev + 2 * p.nblocks_early, p.nblocks - p.nblocks_early, p.sq_dev + p.nblocks_early, c.s));
 }
 
 int build_plan(vsl_handle_s* h, int B, int T, int Lq, int Lc, Plan** out) {
@@ -1180,6 +1185,19 @@ int build_plan(vsl_handle_s* h, int B, int T, int Lq, int Lc, Plan** out) {
     HIP_OK(hipMalloc(&p->blk2seg_dev, blk.size() * sizeof(int)));
     HIP_OK(hipMemcpy(p->segs_dev, segs.data(), segs.size() * sizeof(ReduceSeg), hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(p->blk2seg_dev, blk.data(), blk.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIP_OK(hipMalloc(&p->sq_dev, (size_t)std::max(p->nblocks, 1) * sizeof(float)));
+    {   // do the reduction blocks write every parameter gradient exactly once?  (then their sums of squares ARE the bucket's)
+        std::vector<uint8_t> hit((size_t)h->param_floats, 0);
+        bool once = true;
+        for (const ReduceSeg& sg : segs)
+            for (int i = 0; i < sg.n; ++i) {
+                const int64_t d = (int64_t)sg.dst + (int64_t)(i / sg.rl) * sg.ds + (i % sg.rl);
+                if (d < 0 || d >= h->param_floats || hit[(size_t)d]++) once = false;
+            }
+        for (const ParamInfo& pi : h->params)
+            for (int64_t e = pi.off; e < pi.off + pi.numel; ++e) once = once && hit[(size_t)e] == 1;
+        p->sq_cover = once;
+    }
     *out = p;
     return 0;
 }
@@ -1188,6 +1206,7 @@ void free_plan(Plan* p) {
     if (!p) return;
     if (p->segs_dev) (void)hipFree(p->segs_dev);
     if (p->blk2seg_dev) (void)hipFree(p->blk2seg_dev);
+    if (p->sq_dev) (void)hipFree(p->sq_dev);
     delete p;
 }
 
@@ -1208,6 +1227,7 @@ int get_plan(vsl_handle_s* h, int B, int T, int Lq, int Lc, Plan** out) {
         for (auto jt = h->plans.begin(); jt != h->plans.end(); ++jt)
             if (jt->second->last_use < victim->second->last_use) victim = jt;
         (void)hipDeviceSynchronize();            // its tables may still be read by an enqueued reduction
+        if (h->sq_src == victim->second->sq_dev) { h->sq_src = nullptr; h->sq_grads = nullptr; }
         free_plan(victim->second);
         h->plans.erase(victim);
     }
@@ -1352,6 +1372,7 @@ int vsl_destroy(vsl_handle h) {
     for (auto& kv : h->plans) {
         if (kv.second->segs_dev) (void)hipFree(kv.second->segs_dev);
         if (kv.second->blk2seg_dev) (void)hipFree(kv.second->blk2seg_dev);
+        if (kv.second->sq_dev) (void)hipFree(kv.second->sq_dev);
         delete kv.second;
     }
     if (h->jobs_dev) (void)hipFree(h->jobs_dev);
@@ -1458,6 +1479,7 @@ int vsl_backward(vsl_handle h, const vsl_io* io, void* hip_stream) {
     CallScope scope(h);
     run_backward(c);
     HIP_OK(hipGetLastError());
+    h->sq_src = p->sq_cover ? p->sq_dev : nullptr; h->sq_n = p->nblocks; h->sq_grads = io->grads;
     return 0;
 }
 
@@ -1498,9 +1520,14 @@ int vsl_adamw_step(vsl_handle h, float* params, const float* grads, float* exp_a
             return fail("vsl_adamw_step: hipMemcpy failed");
     }
     const double bc1 = 1.0 - std::pow((double)hp->beta1, (double)hp->step), bc2 = 1.0 - std::pow((double)hp->beta2, (double)hp->step);
+    const float* sq = nullptr;
+    if (hp->norm_from_backward) {
+        if (h->sq_grads != grads) return fail("vsl_adamw_step: norm_from_backward is set but `grads` is not the bucket the last vsl_backward wrote");
+        sq = h->sq_src;             // (null when some gradient of this configuration does not leave k_reduce: the k_sqsum pass then)
+    }
     launch_adamw(params, grads, exp_avg, exp_avg_sq, h->decay_dev, h->opt_scratch, h->param_floats, hp->lr, hp->beta1, hp->beta2,
                  hp->eps, hp->weight_decay, hp->clip_norm, (float)bc1, (float)std::sqrt(bc2), grad_norm_out, (hipStream_t)hip_stream,
-                 hp->hf_order);
+                 hp->hf_order, sq, h->sq_n);
     if (hipGetLastError() != hipSuccess) return fail("vsl_adamw_step: launch failed");
     return 0;
 }

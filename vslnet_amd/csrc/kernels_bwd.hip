@@ -1743,9 +1743,12 @@ void launch_word_table_bwd(const float* dE, const int64_t* word_ids, float* gtab
 // final reduction of all partial slabs into the flat gradient bucket
 // =========================================================================================================
 __global__ __launch_bounds__(256) void k_reduce(const float* __restrict__ ws, float* __restrict__ grads,
-                                                const ReduceSeg* __restrict__ segs, const int* __restrict__ blk2seg) {
+                                                const ReduceSeg* __restrict__ segs, const int* __restrict__ blk2seg,
+                                                float* __restrict__ sq) {
     // block = 256 destination elements: 64 float4 lanes x 4 slab groups (group g sums slabs s = g, g + 4, ...), each
     // thread keeps 8 independent 16-byte loads in flight; the 4 group sums are combined through LDS.
+    // sq[block] = sum of squares of the block's 256 results: every gradient of the bucket leaves this kernel, so the clip's global norm
+    // needs no pass of its own over the bucket (vsl_adamw.norm_from_backward; k_adamw adds the partials in block order).
     __shared__ float4 part[4][64];
     const int si = blk2seg[2 * blockIdx.x], off = blk2seg[2 * blockIdx.x + 1];
     const ReduceSeg* __restrict__ sgp = segs + si;
@@ -1780,12 +1783,17 @@ __global__ __launch_bounds__(256) void k_reduce(const float* __restrict__ ws, fl
             const float4 b1 = part[1][l4], b2 = part[2][l4], b3 = part[3][l4];
             acc.x += (b1.x + b2.x) + b3.x; acc.y += (b1.y + b2.y) + b3.y; acc.z += (b1.z + b2.z) + b3.z; acc.w += (b1.w + b2.w) + b3.w;
             *reinterpret_cast<float4*>(grads + dst + (i / rl) * ds + (i % rl)) = acc;
+        } else acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (grp == 0) {                                  // (wave 0)
+            const float q = wave_sum((acc.x * acc.x + acc.y * acc.y) + (acc.z * acc.z + acc.w * acc.w));
+            if (l4 == 0) sq[blockIdx.x] = q;
         }
     } else {
         // ragged / unaligned segments (single biases, the 10- and 30-channel char-conv biases ...): same structure with
         // scalar loads -- 64 elements per pass, 4 slab groups, 8 loads in flight (a serial walk over up to 256 slabs is
         // 256 exposed memory latencies)
         float* sp = reinterpret_cast<float*>(&part[0][0]);
+        float q2 = 0.f;
         for (int base = 0; base < 256; base += 64) {
             const int e = off + base + l4;
             float a = 0.f;
@@ -1809,20 +1817,28 @@ __global__ __launch_bounds__(256) void k_reduce(const float* __restrict__ ws, fl
             __syncthreads();
             sp[grp * 64 + l4] = a;
             __syncthreads();
-            if (grp == 0 && e < n)
-                grads[dst + (e / rl) * ds + (e % rl)] = (sp[l4] + sp[64 + l4]) + (sp[128 + l4] + sp[192 + l4]);
+            if (grp == 0 && e < n) {
+                const float r = (sp[l4] + sp[64 + l4]) + (sp[128 + l4] + sp[192 + l4]);
+                grads[dst + (e / rl) * ds + (e % rl)] = r;
+                q2 += r * r;
+            }
+        }
+        if (grp == 0) {
+            q2 = wave_sum(q2);
+            if (l4 == 0) sq[blockIdx.x] = q2;
         }
     }
 }
 void launch_reduce(const float* partial, float* grads, const ReduceSeg* segs_dev, const int* blk2seg_dev, int nblocks,
-                   hipStream_t s) {
-    VSL_LAUNCH(k_reduce, dim3(nblocks), dim3(256), 0, s, partial, grads, segs_dev, blk2seg_dev);
+                   float* sq, hipStream_t s) {
+    VSL_LAUNCH(k_reduce, dim3(nblocks), dim3(256), 0, s, partial, grads, segs_dev, blk2seg_dev, sq);
 }
 
 // =========================================================================================================
 // optimizer step on the flat buckets (main_t7.py:111-112, VSLNet_t7.py:8-17): HBM-bound, 5 streams of n floats.
-//   k_sqsum : OPT_BLOCKS partial sums of grads^2 (grid-stride, float4), fixed summation order
-//   k_adamw : every block re-reduces the partials (256 floats, L2-resident) -> clip factor, then updates its elements
+//   k_sqsum : OPT_BLOCKS partial sums of grads^2 (grid-stride, float4), fixed summation order -- skipped when the caller vouches that
+//             `grads` is what vsl_backward left (vsl_adamw.norm_from_backward): k_reduce's per-block partials are used instead
+//   k_adamw : every block re-reduces the partials (L2-resident, fixed order) -> clip factor, then updates its elements
 // =========================================================================================================
 __global__ __launch_bounds__(256) void k_sqsum(const float* __restrict__ g, int64_t n4, float* __restrict__ partials) {
     __shared__ float red[4];
@@ -1839,10 +1855,11 @@ __global__ __launch_bounds__(256) void k_sqsum(const float* __restrict__ g, int6
 }
 __global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                float* __restrict__ v, const uint8_t* __restrict__ decay, const float* __restrict__ partials,
-                                               int64_t n4, float lr, float b1, float b2, float eps, float wd, float clip, float bc1,
+                                               int np, int64_t n4, float lr, float b1, float b2, float eps, float wd, float clip, float bc1,
                                                float bc2_sqrt, float* __restrict__ norm_out, int hf_order) {
     __shared__ float red[4];
-    float s = threadIdx.x < OPT_BLOCKS ? partials[threadIdx.x] : 0.f;
+    float s = 0.f;
+    for (int k = threadIdx.x; k < np; k += 256) s += partials[k];
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
@@ -1877,12 +1894,12 @@ __global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, const floa
 }
 void launch_adamw(float* params, const float* grads, float* m, float* v, const uint8_t* decay_mask, float* partials, int64_t n,
                   float lr, float b1, float b2, float eps, float wd, float clip, float bc1, float bc2_sqrt, float* norm_out,
-                  hipStream_t s, int hf_order) {
+                  hipStream_t s, int hf_order, const float* sq_from_backward, int nsq) {
     const int64_t n4 = n / 4;                    // the bucket is a multiple of 4 floats (every tensor is 16-byte aligned)
-    VSL_LAUNCH(k_sqsum, dim3(OPT_BLOCKS), dim3(256), 0, s, grads, n4, partials);
+    if (!sq_from_backward) VSL_LAUNCH(k_sqsum, dim3(OPT_BLOCKS), dim3(256), 0, s, grads, n4, partials);
     const int nb = (int)std::min<int64_t>(1024, (n4 + 255) / 256);
-    VSL_LAUNCH(k_adamw, dim3(nb), dim3(256), 0, s, params, grads, m, v, decay_mask, partials, n4, lr, b1, b2, eps, wd, clip,
-                       bc1, bc2_sqrt, norm_out, hf_order);
+    VSL_LAUNCH(k_adamw, dim3(nb), dim3(256), 0, s, params, grads, m, v, decay_mask, sq_from_backward ? sq_from_backward : partials,
+                       sq_from_backward ? nsq : OPT_BLOCKS, n4, lr, b1, b2, eps, wd, clip, bc1, bc2_sqrt, norm_out, hf_order);
 }
 
 }  // namespace vsl

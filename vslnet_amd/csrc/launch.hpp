@@ -278,13 +278,14 @@ void launch_embed_bwd(const float* dE, const int64_t* word_ids, const int64_t* c
                       Drop dc, hipStream_t s);
 void launch_word_table_bwd(const float* dE, const int64_t* word_ids, float* gtab /*(word_size, word_dim) inside the gradient bucket*/, int Rq,
                            int word_size, int word_dim, Drop dw, hipStream_t s);
-void launch_reduce(const float* ws, float* grads, const ReduceSeg* segs_dev, const int* blk2seg_dev, int nblocks,
-                   hipStream_t s);
+void launch_reduce(const float* partial, float* grads, const ReduceSeg* segs_dev, const int* blk2seg_dev, int nblocks,
+                   float* sq /* [nblocks]: sum of squares of each block's results */, hipStream_t s);
 // fused optimizer (vsl_adamw_step): sum of squares partials, then clip + AdamW
 constexpr int OPT_BLOCKS = 256;
 void launch_adamw(float* params, const float* grads, float* m, float* v, const uint8_t* decay_mask, float* partials /*[OPT_BLOCKS + 1]*/,
                   int64_t n, float lr, float b1, float b2, float eps, float wd, float clip, float bc1, float bc2_sqrt,
-                  float* norm_out, hipStream_t s, int hf_order = 0);
+                  float* norm_out, hipStream_t s, int hf_order = 0,
+                  const float* sq_from_backward = nullptr /* k_reduce's partials instead of a k_sqsum pass */, int nsq = 0);
 constexpr int EMB_CHUNK_MAX = 8;  // most query words per workgroup in the embedding backward
 int embed_bwd_chunk(int Rq, int Lc, int char_dim);      // words per workgroup the launcher uses (the number of partial slabs follows from it)
 constexpr int EB_IMG_Q = 76;      // k-steps of the embedding backward's B-operand image ([channel tile][76][64 lanes], PackJob type 8)

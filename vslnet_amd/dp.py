@@ -125,12 +125,14 @@ class FlatAdamW:
         return self.lr0 * max(0.0, (self.N - n) / max(1.0, self.N - self.warm))
 
     @torch.no_grad()
-    def step(self, grads):
+    def step(self, grads, from_backward=False):
+        """`from_backward=True`: `grads` is exactly what the engine's last backward() wrote (one process, no exchange, nothing applied to
+        it since): the clip's norm then comes out of the backward's own final reduction (Engine.adamw_step)."""
         lr = self.lr()
         self.t += 1
         if self.engine is not None:
             self.engine.adamw_step(self.flat, grads, self.m, self.v, lr, self.t, (self.b1, self.b2), self.eps, self.weight_decay,
-                                   self.clip, hf_order=self.hf_order)
+                                   self.clip, hf_order=self.hf_order, norm_from_backward=from_backward)
             return
         if self.clip:
             gn = torch.linalg.vector_norm(grads)

@@ -43,7 +43,7 @@ class vsl_loss_io(C.Structure):
 
 class vsl_adamw(C.Structure):
     _fields_ = [('lr', C.c_float), ('beta1', C.c_float), ('beta2', C.c_float), ('eps', C.c_float), ('weight_decay', C.c_float),
-                ('clip_norm', C.c_float), ('step', C.c_int32), ('hf_order', C.c_int32)]
+                ('clip_norm', C.c_float), ('step', C.c_int32), ('hf_order', C.c_int32), ('norm_from_backward', C.c_int32)]
 
 
 class VslError(RuntimeError):
@@ -54,7 +54,7 @@ ABI_SYMBOLS = ['vsl_last_error', 'vsl_create', 'vsl_destroy', 'vsl_param_count',
                'vsl_workspace_floats', 'vsl_forward', 'vsl_loss', 'vsl_backward', 'vsl_extract_index',
                'vsl_adamw_step', 'vsl_workspace_offset', 'vsl_profile_select', 'vsl_profile_read', 'vsl_abi_version',
                'vsl_early_grad_offset']
-ABI_VERSION = 5                                     # include/vslnet_hip.h: VSL_ABI_VERSION
+ABI_VERSION = 6                                     # include/vslnet_hip.h: VSL_ABI_VERSION
 
 
 def load_library():
@@ -340,14 +340,16 @@ class Engine:
         return out
 
     def adamw_step(self, flat, grads, exp_avg, exp_avg_sq, lr, step, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.01,
-                   clip_norm=1.0, grad_norm_out=None, hf_order=False):
+                   clip_norm=1.0, grad_norm_out=None, hf_order=False, norm_from_backward=False):
         """clip_grad_norm_ + AdamW on the flat buckets (main_t7.py:111-112), two kernels, no host synchronisation.
-        `step` is 1-based; `grad_norm_out` (optional 1-element device tensor) receives the un-clipped global norm."""
+        `step` is 1-based; `grad_norm_out` (optional 1-element device tensor) receives the un-clipped global norm.
+        `norm_from_backward=True`: `grads` is untouched since this engine's last backward() (single-GPU training, no exchange): the
+        norm comes from the sums of squares the backward's final reduction recorded -- one kernel less."""
         n = self.param_floats
         for t, nm in ((flat, 'flat'), (grads, 'grads'), (exp_avg, 'exp_avg'), (exp_avg_sq, 'exp_avg_sq')):
             _chk(t, torch.float32, (n,), nm)
         hp = vsl_adamw(float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), float(clip_norm or 0.0), int(step),
-                       int(bool(hf_order)))
+                       int(bool(hf_order)), int(bool(norm_from_backward)))
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         self._call(self.lib.vsl_adamw_step(self.h, _ptr(flat), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq), C.byref(hp),
                                            _ptr(grad_norm_out) if grad_norm_out is not None else None, stream))
