@@ -184,14 +184,16 @@ __global__ __launch_bounds__(256) void k_loss_fused(const float* __restrict__ sl
         d_h[i] = w_hl * wgt * m / (mask_sum + 1e-12f) * (p - y) / fmaxf(p * (1.f - p), 1e-12f);
     }
     if (tid == 0) {
-        scratch[2 * B + b] = (lses - s[sb]) + (lsee - e[eb]);
-        scratch[3 * B + b] = num;
-        __threadfence();                                                    // release the partials at agent scope
-        last = atomicAdd(counter, 1u) == (unsigned)(B - 1) ? 1u : 0u;
+        // the two partials go out WRITE-THROUGH (sc1 stores) and are drained before the arrival is counted; the last arriver reads them with
+        // sc1 loads.  No fence on either side: __threadfence() is an L2 write-back + invalidate on this part, ~3.5 us -- twice on the chain
+        // of a kernel that has 4 us of work (MI355X_MICROARCH.md, visibility; the protocol of the rnn head's granules)
+        __hip_atomic_store(scratch + 2 * B + b, (lses - s[sb]) + (lsee - e[eb]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(scratch + 3 * B + b, num, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(B - 1) ? 1u : 0u;
     }
     __syncthreads();
     if (!last) return;
-    __threadfence();                                                        // acquire
     float ce = 0.f, nm = 0.f;
     for (int bb = tid; bb < B; bb += 256) {                                 // L2 reads: another CU wrote these
         ce += __hip_atomic_load(scratch + 2 * B + bb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(256) void k_loss_fused(const float* __restrict__ sl
     if (tid == 0) {
         const float loc = ce * inv_batch, hl = nm / (mask_sum + 1e-12f);
         losses[0] = loc; losses[1] = hl; losses[2] = w_loc * loc + w_hl * hl; losses[3] = mask_sum;
-        *counter = 0u;                                                      // ready for the next call (stream order)
+        __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // ready for the next call (stream order)
     }
 }
 void launch_loss(const float* sl, const float* el, const float* h, const int64_t* s_lab, const int64_t* e_lab,
