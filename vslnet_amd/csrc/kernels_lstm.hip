@@ -212,10 +212,10 @@ constexpr int L1_SEG = 36;              // LDS stride of a 32-float segment
 constexpr int L1_NB = 4;                // steps per block of prefetched inputs
 constexpr int L1_RING = 8;              // granules in flight per lane of a projection workgroup (granule_ring_arrived counts on 8)
 template <int I> __device__ __forceinline__ float quad_bcast(float x) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), I * 0x55, 0xF, 0xF, false));
-}
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), I * 0x55, 0xF, 0xF, true));      // (bound_ctrl: no lane of these patterns is out of bounds, and the
+}                                                                                                         //  destination needs no zero ahead of the move)
 template <int CTRL> __device__ __forceinline__ float dpp_get(float x) {      // 0xB1: lane ^ 1, 0x4E: lane ^ 2, 0x1B: lane ^ 3, 0x140: row mirror, 0x141: half-row mirror
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
 }
 constexpr float L1_LOG2E = 1.4426950408889634f;
 // Ahead of a step loop: everything the prologue loaded (the 128 weight registers above all) has arrived.  Without it the compiler's waits for
