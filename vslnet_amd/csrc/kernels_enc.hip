@@ -498,6 +498,406 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_fwd(CbFwdArgs a) {
 constexpr size_t cb_fwd_lds_split(int sh) {
     return (size_t)(((TILE_M + 8 * sh) + (sh ? TILE_M + 8 * sh + 12 : TILE_M + 2 * HALO)) * LDP + 3 * (TILE_M + 8 * sh) * CB_LDB / 2 + 4 * CB_PS + 640) * sizeof(float);
 }
+
+// =========================================================================================================
+// k_convblock_fwd2: the forward conv block for WHOLE tiles (R and L multiples of 32, L > 32 -- every BASELINE shape), rebuilt around the
+// vector-instruction budget (round 5: a layer of the kernel above is ~57 % vector-ALU issue, ~20 % matrix pipe, the rest stalls --
+// tools/dbg/isa_count.py, profiles/r05_notes.md).  Same window, same saved tensors, same arithmetic per row; what changed:
+//   * LayerNorm in packed fp32 (v_pk_add / v_pk_mul / v_pk_fma_f32: two columns per instruction); the LayerNorm thread of an owner row also
+//     stores the row (= the previous layer's output y) to memory, so the separate store pass behind every layer's barrier is gone;
+//   * depthwise conv per (channel PAIR, row segment = wave): 8-byte LDS reads, 7 packed FMAs per output pair, the pair goes straight into
+//     split3 (no cross-lane exchange), u leaves as 8-byte stores (a wave writes whole 512-byte rows);
+//   * pointwise GEMM one 16-row block at a time, two accumulators, and the epilogue of block rb - 1 (bias, ReLU, dropout hash, residual
+//     update, ReLU bits) issued BETWEEN the MFMAs of block rb: the bf16 matrix pipe and the vector ALU overlap, also within a wave;
+//   * the epilogue is branch-free: the residual stream has spare rows for the last block's overhang, the ReLU bit words go to an LDS
+//     table and leave as one 16-byte store per owner row.
+// =========================================================================================================
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 pk2(float s) { return f32x2{s, s}; }
+constexpr int C2_XR = 68;                       // residual-stream rows: 56 window rows + the overhang of the last 16-row block (row 66 in layer 0)
+constexpr int C2_VUR = 68;                      // LayerNorm-output rows (window rows + the taps a last, partly idle row segment reaches)
+constexpr int C2_MBW = 8;                       // ReLU bit table: [68 rows][8 waves] uint16
+
+// Global traffic of the kernel: raw buffer instructions, every one of them executed by every wave -- a row that is not to be stored (or
+// loaded) gets an out-of-range offset (the hardware drops the store / returns zeros).  With loads or stores inside branches the compiler no
+// longer knows how many are outstanding, every wait for a weight fragment becomes vmcnt(0), and the wave sits out the acknowledgement of the
+// stores it issued a moment ago (a layer's GEMM phase opened with ~5 k cycles of that: profiles/r05_notes.md).
+typedef __amdgpu_buffer_rsrc_t brsrc_t;
+constexpr uint32_t BUF_OOB = 0x80000000u;
+__device__ __forceinline__ brsrc_t buf_rsrc(const void* p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+__device__ __forceinline__ void buf_store4(brsrc_t r, uint32_t off, const float4& v) {
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)}, r, off, 0, 0);
+}
+__device__ __forceinline__ float4 buf_load4(brsrc_t r, uint32_t off) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+}
+
+template <bool DROP>
+__global__ __launch_bounds__(CB_T, 2) void k_convblock_fwd2(CbFwdArgs a) {
+    constexpr int HL = 12, NW = TILE_M + 2 * HL, NT = CB_T;
+    constexpr int LPR = 8, NJ = 32 / LPR;                      // LayerNorm: lanes per row, float4 columns per lane (4 sub + 4 LPR j)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Xs = smem;                                          // [68][LDP] residual stream (window row index)
+    float* VU = Xs + C2_XR * LDP;                              // [68][LDP] LayerNorm output
+    uint16_t* Ub = reinterpret_cast<uint16_t*>(VU + C2_VUR * LDP);   // depthwise output: three bf16 planes [56][CB_LDB]
+    constexpr int UPS = NW * CB_LDB;
+    float* Ps = VU + C2_VUR * LDP + 3 * UPS / 2;               // [4][CB_PS] | ln1_g | ln1_b | bq | bk | bv
+    uint16_t* MB = reinterpret_cast<uint16_t*>(Ps + 4 * CB_PS + 640);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cb = w;                                          // GEMM role: column block (16 output columns = attention head w)
+    const int L = a.L;
+    const int r0 = blockIdx.x * TILE_M, rw0 = r0 - HL;
+    const uint32_t rbytes = (uint32_t)a.R * (D * 4);           // bytes of an (R, 128) fp32 tensor
+    ESTAMP(0);
+    constexpr int NQ = (NW * 32 + NT - 1) / NT;                // float4 items per thread of the window
+    float4 xv[NQ], pv[NQ];
+    const int s_own = r0 / L;
+    const int klo = max(0, s_own * L - rw0), khi = min(NW, (s_own + 1) * L - rw0);      // window rows of the owner sample
+    {
+        const brsrc_t rx = buf_rsrc(a.xin, rbytes), rp = buf_rsrc(a.pos, (uint32_t)L * (D * 4));
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int e = tid + q * NT;
+            const int wr = e >> 5, c = (e & 31) * 4;
+            const bool in = e < NW * 32 && wr >= klo && wr < khi;       // rows of other samples only ever act as zero padding
+            xv[q] = buf_load4(rx, in ? (uint32_t)(((rw0 + wr) * D + c) * 4) : BUF_OOB);
+            pv[q] = buf_load4(rp, in ? (uint32_t)(((rw0 + wr - s_own * L) * D + c) * 4) : BUF_OOB);
+        }
+    }
+    if (tid < 384) {
+        float pl[4], pq[2];
+#pragma unroll
+        for (int l = 0; l < 4; ++l) pl[l] = tid < 128 ? a.ln_g[l][tid] : tid < 256 ? a.ln_b[l][tid - 128] : a.pw_b[l][tid - 256];
+        pq[0] = tid < 128 ? a.qf.ln_g[tid] : tid < 256 ? a.qf.ln_b[tid - 128] : 0.f;
+        pq[1] = tid < 128 ? a.qf.bq[tid] : tid < 256 ? a.qf.bk[tid - 128] : a.qf.bv[tid - 256];
+#pragma unroll
+        for (int l = 0; l < 4; ++l) Ps[l * CB_PS + tid] = pl[l];
+        if (tid < 256) Ps[4 * CB_PS + tid] = pq[0];
+        Ps[4 * CB_PS + 256 + tid] = pq[1];
+    }
+    {
+        const brsrc_t r0o = buf_rsrc(a.x0_out, rbytes);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int e = tid + q * NT;
+            const int wr = e >> 5, c = (e & 31) * 4;
+            const float4 v = make_float4(xv[q].x + pv[q].x, xv[q].y + pv[q].y, xv[q].z + pv[q].z, xv[q].w + pv[q].w);
+            buf_store4(r0o, (e < NW * 32 && wr >= HL && wr < HL + TILE_M) ? (uint32_t)(((rw0 + wr) * D + c) * 4) : BUF_OOB, v);
+            if (e < NW * 32) *reinterpret_cast<float4*>(&Xs[wr * LDP + c]) = v;
+        }
+    }
+    B3 b3A, b3B;                                               // the wave's 128 x 16 weight slice of the current / next stage
+    b3_load(b3A, a.W3[0], D, D, 16 * cb);
+    f32x2 wk2[DWK];                                          // depthwise taps of the thread's channel pair (2 lane, 2 lane + 1), fetched a layer ahead
+#pragma unroll
+    for (int k = 0; k < DWK; ++k) wk2[k] = f32x2{a.dw_w[0][(2 * lane) * DWK + k], a.dw_w[0][(2 * lane + 1) * DWK + k]};
+    __syncthreads();
+    ESTAMP(1);
+    const int col = 16 * cb + (lane & 15), g4 = 4 * (lane >> 4);
+    auto grp_sum = [](float v) { return grp8_sum(v); };       // sum over the LPR lanes of a row
+    constexpr int TA[6] = {1, 0, 2, 0, 1, 0}, TB[6] = {1, 2, 0, 1, 0, 0};       // (a term, b term): mm, hl, lh, hm, mh, hh -- small terms first
+
+    auto layer = [&](auto LC, auto& cur, auto&& prefetch) {
+        constexpr int l = decltype(LC)::value;
+        constexpr int in0 = 3 * l, nin = NW - 6 * l;             // LayerNorm rows
+        constexpr int o0 = in0 + 3, n = nin - 6;                 // rows this layer produces
+        constexpr int NRB = (n + 15) / 16, QS = (n + 7) / 8;     // 16-row blocks ; rows per depthwise segment (one per wave)
+        const float* P = Ps + l * CB_PS;
+        const Drop dp = a.dp[l];
+        // ---- LayerNorm, LPR lanes per row (lane sub: columns 4 sub + 4 LPR j); owner rows of x_l = y[l - 1] leave for memory on the way
+        {
+            const int r = tid / LPR, sub = tid % LPR;
+            const bool act = r < nin;
+            const int wr = act ? in0 + r : in0;
+            const float* s = Xs + wr * LDP + sub * 4;
+            float4 v[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) v[j] = *reinterpret_cast<const float4*>(s + 4 * LPR * j);
+            if (l > 0) {
+                const brsrc_t ry = buf_rsrc(a.y[l > 0 ? l - 1 : 0], rbytes);
+                const uint32_t yo = (act && wr >= HL && wr < HL + TILE_M) ? (uint32_t)(((rw0 + wr) * D + sub * 4) * 4) : BUF_OOB;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) buf_store4(ry, yo + 16 * LPR * j, v[j]);
+            }
+            if (act) {
+                float* d = VU + wr * LDP + sub * 4;
+                if (wr < klo || wr >= khi) {
+                    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) *reinterpret_cast<float4*>(d + 4 * LPR * j) = z;
+                } else {
+                    f32x2 x[2 * NJ];
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) { x[2 * j] = f32x2{v[j].x, v[j].y}; x[2 * j + 1] = f32x2{v[j].z, v[j].w}; }
+                    f32x2 s2 = x[0] + x[1];
+#pragma unroll
+                    for (int i = 2; i < 2 * NJ; i += 2) s2 += x[i] + x[i + 1];
+                    const float mu = grp_sum(s2.x + s2.y) * (1.0f / D);
+                    const f32x2 nmu = pk2(-mu);
+#pragma unroll
+                    for (int i = 0; i < 2 * NJ; ++i) x[i] += nmu;
+                    f32x2 q2 = x[0] * x[0], q3 = x[1] * x[1];
+#pragma unroll
+                    for (int i = 2; i < 2 * NJ; i += 2) { q2 = pk_fma(x[i], x[i], q2); q3 = pk_fma(x[i + 1], x[i + 1], q3); }
+                    q2 += q3;
+                    const float rstd = rsqrtf(grp_sum(q2.x + q2.y) * (1.0f / D) + LN_EPS);
+                    const f32x2 rs2 = pk2(rstd);
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const float4 gv = *reinterpret_cast<const float4*>(P + sub * 4 + 4 * LPR * j);
+                        const float4 bb = *reinterpret_cast<const float4*>(P + 128 + sub * 4 + 4 * LPR * j);
+                        const f32x2 o0v = pk_fma(x[2 * j] * rs2, f32x2{gv.x, gv.y}, f32x2{bb.x, bb.y});
+                        const f32x2 o1v = pk_fma(x[2 * j + 1] * rs2, f32x2{gv.z, gv.w}, f32x2{bb.z, bb.w});
+                        *reinterpret_cast<float4*>(d + 4 * LPR * j) = make_float4(o0v.x, o0v.y, o1v.x, o1v.y);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (l == 0) ESTAMP(8);
+        // ---- depthwise conv k = 7: thread = (channel pair, row segment = wave); window of QS + 6 rows in registers.  A wave whose segment
+        // lies beyond the layer's rows recomputes segment 0 and discards it (the same instruction stream in every wave)
+        {
+            const bool sact = w * QS < n;
+            const int os = sact ? o0 + w * QS : o0;              // first produced window row of the segment (wave-uniform)
+            f32x2 win[QS + 2 * HALO];
+#pragma unroll
+            for (int i = 0; i < QS + 2 * HALO; ++i) win[i] = *reinterpret_cast<const f32x2*>(&VU[(os - HALO + i) * LDP + 2 * lane]);
+            uint32_t* ub = reinterpret_cast<uint32_t*>(Ub) + lane;
+            const brsrc_t ru = buf_rsrc(a.u[l], rbytes);
+#pragma unroll
+            for (int i = 0; i < QS; ++i) {
+                f32x2 u = wk2[0] * win[i];
+#pragma unroll
+                for (int k = 1; k < DWK; ++k) u = pk_fma(wk2[k], win[i + k], u);
+                const int row = os + i;
+                const bool rok = sact && row < o0 + n;           // wave-uniform
+                // saved: A operand of the weight gradient (owner rows; a wave stores whole 512-byte rows)
+                __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{__float_as_uint(u.x), __float_as_uint(u.y)}, ru,
+                                                      (rok && row >= HL && row < HL + TILE_M) ? (uint32_t)(((rw0 + row) * D + 2 * lane) * 4) : BUF_OOB, 0, 0);
+                if (rok) {
+                    uint32_t th, tm, tl;
+                    split3(u.x, u.y, th, tm, tl);
+                    uint32_t* dpl = ub + row * (CB_LDB / 2);
+                    dpl[0] = th; dpl[UPS / 2] = tm; dpl[UPS] = tl;
+                }
+            }
+        }
+        __syncthreads();
+        if (l == 0) ESTAMP(9);
+        // ---- pointwise GEMM: this wave = 16 output columns x every row block, one block at a time, the epilogue of the previous block between
+        // the MFMAs.  What the stamps and knock-out builds said on the way here (profiles/r05_notes.md): one accumulator chain per 16 x 16 tile
+        // already runs the matrix pipe at its full rate (tools/ubench/mfma_rate.hip), the two waves of a SIMD take turns on it (the older one
+        // first), and a request for A fragments per K step costs an LDS round trip per step -- a block's twelve fragments are requested one
+        // block ahead instead; the residual values the epilogue updates are read ahead as well.
+        if (l < 3) {
+#pragma unroll
+            for (int k = 0; k < DWK; ++k) wk2[k] = f32x2{a.dw_w[l < 3 ? l + 1 : 3][(2 * lane) * DWK + k], a.dw_w[l < 3 ? l + 1 : 3][(2 * lane + 1) * DWK + k]};
+        }
+        const float bv = P[256 + col];
+        const int row0 = o0 + g4;                                // window row of the lane's first element in block 0
+        const uint32_t hb = (uint32_t)((rw0 + row0) * D + col) * 0x9E3779B1u + dp.seed;    // hash input of that element
+        const int mybit = 1 << (lane & 15);
+        float* xb = Xs + row0 * LDP + col;
+        uint16_t* mb = MB + (row0 + (lane & 3)) * C2_MBW + cb;
+        const uint16_t* ar = Ub + (o0 + (lane & 15)) * CB_LDB + 8 * (lane >> 4);
+        Frag3 af[2][4];
+        auto areadblk = [&](int i, Frag3 (&f)[4]) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) f[ks].t[t] = *reinterpret_cast<const u32x4_t*>(ar + t * UPS + i * 16 * CB_LDB + ks * 32);
+        };
+        f32x4 accp = {0.f, 0.f, 0.f, 0.f};
+        float xold[4];
+        int pos01 = 0, pos23 = 0;
+        auto xread = [&](auto Ic) {                              // residual values of the lane's four rows of block i
+            constexpr int i = decltype(Ic)::value;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) xold[rr] = xb[(16 * i + rr) * LDP];
+        };
+        // one quarter (row rr of the lane's four) of the epilogue of block i
+        auto epi = [&](auto Ic, auto RRc) {
+            constexpr int i = decltype(Ic)::value, rr = decltype(RRc)::value;
+            const float z = accp[rr] + bv;
+            float av = fmaxf(z, 0.f);
+            if (DROP) {
+                uint32_t h = hb + (uint32_t)((16 * i + rr) * D) * 0x9E3779B1u;
+                h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= (h >> 13) ^ dp.key; h *= 0xC2B2AE35u; h ^= h >> 16;
+                av = h >= dp.thresh ? av * dp.scale : 0.f;
+            }
+            xb[(16 * i + rr) * LDP] = xold[rr] + av;
+            const int bit = z > 0.f ? (mybit << (16 * (rr & 1))) : 0;
+            if (rr == 0) pos01 = bit; else if (rr == 1) pos01 |= bit; else if (rr == 2) pos23 = bit; else pos23 |= bit;
+            if (rr == 3) {
+                auto row_or = [](int v) {
+                    v |= __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);       // quad_perm [1,0,3,2]
+                    v |= __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);       // quad_perm [2,3,0,1]
+                    v |= __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);      // row_half_mirror
+                    v |= __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);      // row_mirror
+                    return v;
+                };
+                const int p01 = row_or(pos01), p23 = row_or(pos23);
+                // lane q of the 16-lane row writes row (q & 3): four lanes write the same value to the same address (no exec masking)
+                const uint32_t wv = (uint32_t)((lane & 2) ? p23 : p01) >> (16 * (lane & 1));
+                mb[16 * i * C2_MBW] = (uint16_t)wv;
+            }
+        };
+        areadblk(0, af[0]);
+        static_for<0, NRB>([&](auto Ic) {
+            constexpr int i = decltype(Ic)::value;
+            if constexpr (i > 0) xread(std::integral_constant<int, (i > 0 ? i - 1 : 0)>());
+            if constexpr (i + 1 < NRB) areadblk(i + 1, af[(i + 1) & 1]);
+            f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
+            static_for<0, 4>([&](auto KSc) {
+                constexpr int ks = decltype(KSc)::value;
+                const Frag3& f = af[i & 1][ks];
+                c0 = mfma16_bf16(f.t[1], cur.b[1][ks], c0);      // mm
+                c1 = mfma16_bf16(f.t[0], cur.b[2][ks], c1);      // hl
+                c0 = mfma16_bf16(f.t[2], cur.b[0][ks], c0);      // lh
+                c1 = mfma16_bf16(f.t[0], cur.b[1][ks], c1);      // hm
+                c0 = mfma16_bf16(f.t[1], cur.b[0][ks], c0);      // mh
+                c1 = mfma16_bf16(f.t[0], cur.b[0][ks], c1);      // hh
+                if constexpr (i > 0) epi(std::integral_constant<int, (i > 0 ? i - 1 : 0)>(), KSc);
+            });
+            accp = c0 + c1;
+        });
+        xread(std::integral_constant<int, NRB - 1>());
+        __builtin_amdgcn_sched_barrier(0);
+        prefetch();                                              // weight slice of the next stage: most of a layer ahead of its use
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, 4>([&](auto RRc) { epi(std::integral_constant<int, NRB - 1>(), RRc); });
+        if (l == 0) ESTAMP(10);
+        __syncthreads();
+        if (l == 0) ESTAMP(11);
+        // ReLU decisions of the owner rows: one 16-byte store per row (the (R, 4) uint32 words)
+        {
+            const u32x4_t mv = *reinterpret_cast<const u32x4_t*>(MB + (HL + (tid & 31)) * C2_MBW);
+            __builtin_amdgcn_raw_buffer_store_b128(mv, buf_rsrc(a.relu_mask[l], (uint32_t)a.R * 16), tid < TILE_M ? (uint32_t)((r0 + tid) * 16) : BUF_OOB, 0, 0);
+        }
+    };
+    layer(std::integral_constant<int, 0>(), b3A, [&] { b3_load(b3B, a.W3[1], D, D, 16 * cb); });
+    ESTAMP(2);
+    layer(std::integral_constant<int, 1>(), b3B, [&] { b3_load(b3A, a.W3[2], D, D, 16 * cb); });
+    ESTAMP(3);
+    layer(std::integral_constant<int, 2>(), b3A, [&] { b3_load(b3B, a.W3[3], D, D, 16 * cb); });
+    ESTAMP(4);
+    layer(std::integral_constant<int, 3>(), b3B, [&] { b3_load(b3A, a.Wqkv3, D, 3 * D, 16 * cb); });
+    ESTAMP(5);
+    // ---- a8, first half (:168-173) on the owner rows: y3 -> memory ; h1 = drop(LN1(y3)) ; [q | k | v] = h1 W^T + b  (column block cb = head cb)
+    {
+        const float* Pq = Ps + 4 * CB_PS;
+        const Drop d1 = a.qf.d1;
+        // LayerNorm 1 in the row layout of the layers (LPR lanes per row, 32 rows): output to memory (h1) and, split, to the GEMM operand planes
+        {
+            const int r = tid / LPR, sub = tid % LPR;
+            const bool act = r < TILE_M;
+            const int wr = HL + (act ? r : 0);
+            const float* s = Xs + wr * LDP + sub * 4;
+            float4 v[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) v[j] = *reinterpret_cast<const float4*>(s + 4 * LPR * j);
+            const uint32_t go = act ? (uint32_t)(((rw0 + wr) * D + sub * 4) * 4) : BUF_OOB;
+            const brsrc_t ry = buf_rsrc(a.y[3], rbytes);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) buf_store4(ry, go + 16 * LPR * j, v[j]);
+            f32x2 x[2 * NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) { x[2 * j] = f32x2{v[j].x, v[j].y}; x[2 * j + 1] = f32x2{v[j].z, v[j].w}; }
+            f32x2 s2 = x[0] + x[1];
+#pragma unroll
+            for (int i = 2; i < 2 * NJ; i += 2) s2 += x[i] + x[i + 1];
+            const float mu = grp_sum(s2.x + s2.y) * (1.0f / D);
+            const f32x2 nmu = pk2(-mu);
+#pragma unroll
+            for (int i = 0; i < 2 * NJ; ++i) x[i] += nmu;
+            f32x2 q2 = x[0] * x[0], q3 = x[1] * x[1];
+#pragma unroll
+            for (int i = 2; i < 2 * NJ; i += 2) { q2 = pk_fma(x[i], x[i], q2); q3 = pk_fma(x[i + 1], x[i + 1], q3); }
+            q2 += q3;
+            const float rstd = rsqrtf(grp_sum(q2.x + q2.y) * (1.0f / D) + LN_EPS);
+            const f32x2 rs2 = pk2(rstd);
+            const brsrc_t rhb = buf_rsrc(a.qf.h1, a.qf.h1 ? rbytes : 0u);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const float4 gv = *reinterpret_cast<const float4*>(Pq + sub * 4 + 4 * LPR * j);
+                const float4 bb = *reinterpret_cast<const float4*>(Pq + 128 + sub * 4 + 4 * LPR * j);
+                f32x2 o0v = pk_fma(x[2 * j] * rs2, f32x2{gv.x, gv.y}, f32x2{bb.x, bb.y});
+                f32x2 o1v = pk_fma(x[2 * j + 1] * rs2, f32x2{gv.z, gv.w}, f32x2{bb.z, bb.w});
+                if (DROP) {
+                    const uint32_t base = (uint32_t)((rw0 + wr) * D + sub * 4 + 4 * LPR * j);
+                    o0v.x *= drop_keep_scale(d1, base); o0v.y *= drop_keep_scale(d1, base + 1);
+                    o1v.x *= drop_keep_scale(d1, base + 2); o1v.y *= drop_keep_scale(d1, base + 3);
+                }
+                buf_store4(rhb, go + 16 * LPR * j, make_float4(o0v.x, o0v.y, o1v.x, o1v.y));
+                if (act) {
+                    uint32_t h0, m0, l0, h1, m1, l1;
+                    split3(o0v.x, o0v.y, h0, m0, l0);
+                    split3(o1v.x, o1v.y, h1, m1, l1);
+                    uint16_t* d = Ub + (wr - HL) * CB_LDB + sub * 4 + 4 * LPR * j;
+                    *reinterpret_cast<u32x2_t*>(d) = u32x2_t{h0, h1};
+                    *reinterpret_cast<u32x2_t*>(d + UPS) = u32x2_t{m0, m1};
+                    *reinterpret_cast<u32x2_t*>(d + 2 * UPS) = u32x2_t{l0, l1};
+                }
+            }
+        }
+        b3_load(b3B, a.Wqkv3, D, 3 * D, D + 16 * cb);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        // the 32 rows of h1: the A fragments of both row blocks and all four K steps, read once for the three projections
+        Frag3 aq[2][4];
+        {
+            const uint16_t* ap = Ub + (lane & 15) * CB_LDB + 8 * (lane >> 4);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) aq[rb][ks].t[t] = *reinterpret_cast<const u32x4_t*>(ap + t * UPS + rb * 16 * CB_LDB + ks * 32);
+        }
+        auto proj = [&](const B3& cur, float* __restrict__ outp, int t) {
+            f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int p = 0; p < 6; ++p)
+#pragma unroll
+                    for (int rb = 0; rb < 2; ++rb) acc[rb] = mfma16_bf16(aq[rb][ks].t[TA[p]], cur.b[TB[p]][ks], acc[rb]);
+            const float bvv = Pq[256 + t * D + col];
+            const brsrc_t ro = buf_rsrc(outp, rbytes);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[rb][rr] + bvv), ro, (uint32_t)(((r0 + 16 * rb + g4 + rr) * D + col) * 4), 0, 0);
+        };
+        proj(b3A, a.qf.q, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        b3_load(b3A, a.Wqkv3, D, 3 * D, 2 * D + 16 * cb);
+        __builtin_amdgcn_sched_barrier(0);
+        proj(b3B, a.qf.k, 1);
+        proj(b3A, a.qf.v, 2);
+    }
+    ESTAMP(6);
+}
+constexpr size_t cb_fwd2_lds() {
+    return (size_t)((C2_XR + C2_VUR) * LDP + 3 * (TILE_M + 24) * CB_LDB / 2 + 4 * CB_PS + 640 + C2_XR * C2_MBW / 2) * sizeof(float);
+}
+template <bool DROP>
+static void launch_cbf2_t(const CbFwdArgs& a, int grid, hipStream_t s) {
+    static size_t ok = 0;
+    const size_t lds = cb_fwd2_lds();
+    ensure_dynamic_lds((const void*)k_convblock_fwd2<DROP>, lds, ok, "k_convblock_fwd2");
+    VSL_LAUNCH((k_convblock_fwd2<DROP>), dim3(grid), dim3(CB_T), lds, s, a);
+}
+static void launch_cbf2(const CbFwdArgs& a, int grid, hipStream_t s) {
+    if (a.dp[0].thresh) launch_cbf2_t<true>(a, grid, s); else launch_cbf2_t<false>(a, grid, s);
+}
 template <int SH, bool FULL>
 static void launch_cbf(const CbFwdArgs& a, int grid, hipStream_t s) {
     static size_t ok = 0;
@@ -510,10 +910,13 @@ void launch_convblock_fwd(const CbFwdArgs& a, hipStream_t s) {
         launch_cbf<0, false>(a, a.R / a.L, s);
         return;
     }
-    if (a.R % TILE_M == 0 && a.L % TILE_M == 0) launch_cbf<3, true>(a, a.R / TILE_M, s);       // whole tiles inside one sample each: the predicate-free instantiation
-    else launch_cbf<3, false>(a, (a.R + TILE_M - 1) / TILE_M, s);
+    static const bool cb2 = !(getenv("VSL_CB2") && atoi(getenv("VSL_CB2")) == 0);
+    if (a.R % TILE_M == 0 && a.L % TILE_M == 0) {              // whole tiles inside one sample each
+        if (cb2) launch_cbf2(a, a.R / TILE_M, s);
+        else launch_cbf<3, true>(a, a.R / TILE_M, s);
+    } else launch_cbf<3, false>(a, (a.R + TILE_M - 1) / TILE_M, s);
     static int left = 6;
-    if (edbg_on() && a.R > 4096) { int l2 = left; edbg_report("convblock_fwd: load | L0 | L1 | L2 | L3 | qkv", 7, s, left); edbg_report2("  L0: LN | dw | gemm | epilogue | barrier", 8, 13, s, l2); }
+    if (edbg_on() && a.R > 4096) { int l2 = left, l3 = left; edbg_report("convblock_fwd: load | L0 | L1 | L2 | L3 | qkv", 7, s, left); edbg_report2("  L0: LN | dw | gemm | epilogue | barrier", 8, 13, s, l2); edbg_report2("  L0 gemm: (stamp 14 = group 0 done) group 1", 14, 16, s, l3); }
 }
 
 // =========================================================================================================
