@@ -166,6 +166,79 @@ def cpu_baseline(configs, T, Lq, Lc, threads=None, budget_s=25.0):
                       % (nthr, T, configs.video_feature_dim, Lq, configs.drop_rate, n16, t16 * 1e3, n64, t64 * 1e3)}
 
 
+# The other BASELINE.json configs (per-GPU shapes) and the bf16 throughput mode, timed after the headline regions so that one driver run
+# observes them all: (tag, bench arguments, steps, warm-up, resident batches)
+OTHER_SHAPES = [
+    ('configs[0]', dict(predictor='rnn', batch=16, T=128, dv=1024), 30, 6, 4),
+    ('configs[2]', dict(predictor='transformer', batch=32, T=256, dv=4096), 20, 4, 3),
+    ('configs[3]/GPU', dict(predictor='transformer', batch=32, T=256, dv=1024), 20, 4, 4),
+    ('configs[4]/GPU', dict(predictor='transformer', batch=16, T=1024, dv=1024), 12, 3, 4),
+    ('configs[1] --dtype bf16', dict(predictor='transformer', batch=64, T=128, dv=1024, dtype='bf16'), 30, 6, 10),
+]
+
+
+def time_shape(predictor, batch, T, dv, lq, lc, drop_rate, dtype, steps, warmup, nres, regions=3):
+    """One single-process training step (forward + both losses + backward + clip + AdamW, as the headline) of another shape:
+    median of `regions` regions of `steps` steps.  Returns (ms per step, pairs/s, loss)."""
+    from vslnet_amd.dp import FlatAdamW
+    from vslnet_amd.model.VSLNet import VSLNet
+    from vslnet_amd.synthetic import make_configs, synthetic_batch
+    configs = make_configs(video_feature_dim=dv, max_pos_len=max(T, lq), drop_rate=drop_rate, predictor=predictor)
+    torch.manual_seed(configs.seed)
+    glove = torch.randn(configs.word_size - 2, configs.word_dim).numpy()
+    model = VSLNet(configs, glove).cuda().train()
+    flat, grads = model.flat_parameters
+    eng = model._engine
+    pad_vec, glove_vec = model.embedding_net.word_emb.pad_vec.data, model.embedding_net.word_emb.glove_vec.data
+    batches = [synthetic_batch(configs, batch, T, lq, lc, seed=100 + 1000 * k) for k in range(nres)]
+    if dtype == 'bf16':
+        for bt in batches:
+            bt['vfeats'] = bt['vfeats'].to(torch.bfloat16).contiguous()
+    mask_sum = float(batches[0]['v_mask'].sum().item())
+    opt = FlatAdamW(flat, eng.layout, lr=configs.init_lr, num_train_steps=10 * (regions * steps + warmup + 2), clip_norm=configs.clip_norm, engine=eng)
+
+    def step(i):
+        bt = batches[i % nres]
+        eng.forward(flat, pad_vec, glove_vec, bt['word_ids'], bt['char_ids'], bt['vfeats'], bt['v_mask'], bt['q_mask'], training=True, seed=i,
+                    sample_offset=0, arithmetic='bf16' if dtype == 'bf16' else 'f32')
+        losses, d_h, d_sl, d_el = eng.loss(bt['s_labels'], bt['e_labels'], bt['h_labels'], 1.0, configs.highlight_lambda, inv_batch=1.0 / batch, mask_sum=mask_sum)
+        eng.backward(d_h, d_sl, d_el, grads)
+        opt.step(grads, from_backward=True)
+        return losses
+    for i in range(warmup):
+        step(i)
+    dts = []
+    for rg in range(regions):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            losses = step(warmup + rg * steps + i)
+        torch.cuda.synchronize()
+        dts.append(time.perf_counter() - t0)
+    dt = sorted(dts)[(len(dts) - 1) // 2]
+    loss = float(losses[2].item())
+    if not (loss == loss) or abs(loss) > 1e6:
+        raise SystemExit('non-finite loss in a `shapes` region: %r' % loss)
+    return dt / steps * 1e3, batch * steps / dt, loss
+
+
+def other_shapes(args):
+    """`shapes`: [{workload, pairs_per_s, ms_per_step, step_mfma_frac, ...}] for OTHER_SHAPES -- same step as the headline (optimizer inside),
+    HBM-resident rotated batches, fewer steps; never part of `value`."""
+    out = []
+    for tag, kw, steps, warmup, nres in OTHER_SHAPES:
+        dtype = kw.get('dtype', 'f32')
+        ms, pps, loss = time_shape(kw['predictor'], kw['batch'], kw['T'], kw['dv'], args.lq, args.lc, args.drop_rate, dtype, steps, warmup, nres)
+        _, fb = alg_flops_per_pair(kw['T'], kw['dv'], args.lq, args.lc, predictor=kw['predictor'])
+        ns = argparse.Namespace(predictor=kw['predictor'], batch=kw['batch'], T=kw['T'], dv=kw['dv'])
+        out.append({'workload': '%s%s' % (workload_name(ns), ' -- bf16 throughput mode (own tolerance, not the parity path)' if dtype == 'bf16' else ''),
+                    'tag': tag, 'predictor': kw['predictor'], 'batch': kw['batch'], 'T': kw['T'], 'Dv': kw['dv'], 'dtype': dtype,
+                    'pairs_per_s': round(pps, 1), 'ms_per_step': round(ms, 4), 'steps': steps, 'warmup': warmup, 'regions': 3,
+                    'step_mfma_frac': round(fb * pps / PEAK_MFMA_F32, 4), 'alg_mflop_per_pair': round(fb / 1e6, 1), 'loss': round(loss, 5)})
+        torch.cuda.empty_cache()
+    return out
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without torchrun: re-exec under torch.distributed.run (one rank per GPU, RCCL); the
     child's rank 0 prints the one JSON line on our stdout."""
@@ -199,6 +272,11 @@ def main():
                     help='distinct synthetic batches resident in HBM, rotated step by step: 10 x 32 MiB of features at the headline shape exceed the '
                          '256 MiB Infinity Cache, so the feature stream of VisualProjection and of its weight gradient really comes from HBM '
                          '(1 = one batch re-used every step, Infinity-Cache resident)')
+    ap.add_argument('--regions', type=int, default=5,
+                    help='the timed region (exactly --steps steps between two barrier + synchronize pairs) is run this many times; `ms_per_step` / `value` '
+                         'are the MEDIAN region, every region is listed in `region_ms` (one driver run is then worth several: box noise exceeds 1 %%)')
+    ap.add_argument('--no-shapes', action='store_true',
+                    help='skip the `shapes` list (the other BASELINE configs and the bf16 mode at reduced step counts, after the headline regions; N = 1 only)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-optimizer', action='store_true', help='time forward + losses + backward only (A/B runs)')
     ap.add_argument('--profile-all', action='store_true', help='also print the per-kernel HIP-event table to stderr')
@@ -291,18 +369,24 @@ def main():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
-    sync()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        losses = step(args.warmup + 1 + i)
-    sync()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([dt], device='cuda', dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    # the timed region: EXACTLY --steps steps between barrier + synchronize pairs, max over ranks -- run --regions times, the median region is the line
+    region_dt = []
+    for rg in range(max(1, args.regions)):
+        sync()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            losses = step(args.warmup + 1 + rg * args.steps + i)
+        sync()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            tmax = torch.tensor([dt], device='cuda', dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        region_dt.append(dt)
+    dt = sorted(region_dt)[(len(region_dt) - 1) // 2]          # median (lower middle for an even count)
+    nreg = len(region_dt)
     ptab = eng.profile_read()
-    kt = ptab[dominant]
+    kt = (ptab[dominant][0] / nreg, ptab[dominant][1] // nreg)     # events accumulated over all regions -> per region
     kvp = ptab.get('vproj_fwd')
     eng.profile_select(None)
     # the exchange's exposed cost: the same timed region once more without it (every rank runs it, so the barriers still pair up)
@@ -311,7 +395,7 @@ def main():
         sync()
         t0 = time.perf_counter()
         for i in range(args.steps):
-            step(args.warmup + 1 + args.steps + i, skip_exchange=True)
+            step(args.warmup + 1 + nreg * args.steps + i, skip_exchange=True)
         sync()
         dt_nox = time.perf_counter() - t0
         tmax = torch.tensor([dt_nox], device='cuda', dtype=torch.float64)
@@ -376,7 +460,8 @@ def main():
             roof['bf16x6_frac_of_bf16_peak'] = round(6 * work[0] / k_s / PEAK_MFMA_BF16, 4)
         out = {'metric': '(video,query) pairs/sec fwd+bwd, Charades I3D T=128 D=1024', 'value': round(value, 1),
                'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-               'ms_per_step': round(ms_step, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+               'ms_per_step': round(ms_step, 4), 'regions': nreg, 'region_ms': [round(d / args.steps * 1e3, 4) for d in region_dt],
+               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
                'dtype': dtype_line(args),
                'data': 'synthetic',
                'config': {'workload': '%s, --predictor %s, B=%d/GPU T=%d Dv=%d Lq=%d Lc=%d drop_rate=%.1f '
@@ -402,6 +487,10 @@ def main():
                 out['cpu_baseline']['calibration'] = json.load(open(os.path.join(ROOT, 'profiles', 'r04_cpu_calibration.json')))
             except Exception:
                 out['cpu_baseline']['calibration'] = None
+        if world == 1 and dist is None and not args.no_shapes and workload_name(args).startswith('configs[1]') and args.dtype == 'f32':
+            del model, batches, opt, eng, flat, grads             # the headline's workspace goes back to the allocator first
+            torch.cuda.empty_cache()
+            out['shapes'] = other_shapes(args)
         sys.stdout.flush()
         if saved_stdout is not None:
             os.dup2(saved_stdout, 1)

@@ -39,3 +39,21 @@ def test_workload_names_follow_baseline_json():
     assert bench.workload_name(types.SimpleNamespace(predictor='transformer', batch=32, T=256, dv=4096)).startswith('configs[2]')
     assert bench.PEAK_MFMA_F32 == 157.3e12 and bench.PEAK_HBM == 8.0e12
     assert os.path.exists(os.path.join(ROOT, 'profiles', bench.PROFILE_JSON))
+
+
+def test_other_shapes_cover_the_remaining_baseline_configs_and_the_bf16_mode():
+    """The `shapes` list bench.py appends behind the headline regions (driver-observed numbers for every BASELINE config):
+    its entries are the per-GPU shapes of configs[0], [2], [3], [4] and the bf16 mode of configs[1]."""
+    tags = [t for t, *_ in bench.OTHER_SHAPES]
+    assert tags == ['configs[0]', 'configs[2]', 'configs[3]/GPU', 'configs[4]/GPU', 'configs[1] --dtype bf16']
+    for tag, kw, steps, warmup, nres in bench.OTHER_SHAPES:
+        ns = types.SimpleNamespace(predictor=kw['predictor'], batch=kw['batch'], T=kw['T'], dv=kw['dv'])
+        assert bench.workload_name(ns).startswith(tag.split('/')[0].split(' ')[0]), (tag, bench.workload_name(ns))
+        assert steps >= 10 and warmup >= 3 and nres >= 3
+        # rotated resident batches of every shape exceed the 256 MiB Infinity Cache only where that is cheap; they must at least differ step to step
+        assert kw.get('dtype', 'f32') in ('f32', 'bf16')
+    src = open(os.path.join(ROOT, 'bench.py')).read()
+    for key in ("'regions'", "'region_ms'", "'shapes'", "'pairs_per_s'", "'step_mfma_frac'"):
+        assert key in src, key
+    # the headline fields stay the median region's: value = B * world * steps / dt with dt the median of region_dt
+    assert 'dt = sorted(region_dt)[(len(region_dt) - 1) // 2]' in src
