@@ -71,10 +71,33 @@ def mask_logits(x, mask, value=MASK_VALUE):
     return x + (1.0 - mask.to(torch.float32)) * value
 
 
+# Sum of |terms| of every Conv1D bias gradient of the last backward (id(bias tensor) -> (C,) tensor): db[c] = sum_rows dY[row, c] cancels
+# structurally for some biases (the attention key bias: SURVEY 8a) and numerically on tiny batches; a test that wants an absolute gate
+# proportional to what was actually added asks for these (tests/test_fuzz_parity.py).  None = not recording.
+BIAS_TERMS = None
+
+
+def record_bias_terms(on=True):
+    global BIAS_TERMS
+    BIAS_TERMS = {} if on else None
+
+
+def bias_term_sums(P):
+    """{parameter name: max over its elements of sum |dY|} for the biases seen since record_bias_terms()."""
+    return {k: float(BIAS_TERMS[id(v)].max()) for k, v in P.items() if BIAS_TERMS is not None and id(v) in BIAS_TERMS}
+
+
 def pointwise(x, w, b=None):
     """Conv1D with kernel 1 (layers_t7.py:12-22): y[..., o] = sum_i x[..., i] * w[o, i, 0] + b[o]."""
     y = torch.matmul(x, w[:, :, 0].t())
-    return y if b is None else y + b
+    if b is None:
+        return y
+    out = y + b
+    if BIAS_TERMS is not None and out.requires_grad:
+        def hook(g, key=id(b)):
+            BIAS_TERMS[key] = BIAS_TERMS.get(key, 0) + g.detach().abs().reshape(-1, g.shape[-1]).sum(0)
+        out.register_hook(hook)
+    return out
 
 
 def layer_norm(x, g, b):
@@ -141,6 +164,7 @@ RELU_SIGNS = None
 RELU_FORCED = None
 RELU_FORCED_DEV = 0.0      # largest |pre-activation| on which a forced branch differed from the sign seen in that same forward (reported, not gated)
 RELU_FORCED_RATIO = 0.0    # the same in units of the pre-activation's own fp32 noise scale: |z| / (2^-24 * (sum_k |a_k w_k| + |b|))
+RELU_FORCED_COUNTS = []    # per ReLU site of the last forced forward: (overridden decisions, elements)
 
 
 def record_relu_signs(on=True):
@@ -151,11 +175,12 @@ def record_relu_signs(on=True):
 def force_relu_signs(masks):
     """Take the given branch (bool tensors, call order) at every ReLU of the next forward instead of sign(z): lets a test
     evaluate the oracle's gradient ON THE BRANCH THE GPU PATH TOOK when a pre-activation sits inside the forward noise."""
-    global RELU_FORCED, RELU_FORCED_DEV, RELU_FORCED_RATIO
+    global RELU_FORCED, RELU_FORCED_DEV, RELU_FORCED_RATIO, RELU_FORCED_COUNTS
     RELU_FORCED = list(masks) if masks is not None else None
     if masks is not None:
         RELU_FORCED_DEV = 0.0
         RELU_FORCED_RATIO = 0.0
+        RELU_FORCED_COUNTS = []
 
 
 def forced_relu_deviation():
@@ -163,6 +188,11 @@ def forced_relu_deviation():
     asserts it is inside the forward noise -- a forced branch is only legitimate where the pre-activation is ~0 (torch's own
     no_grad and autograd forwards already differ by ~1e-7 there: mkldnn picks different primitives)."""
     return RELU_FORCED_DEV
+
+
+def forced_relu_counts():
+    """After a forced forward: [(overridden decisions, elements)] per ReLU site, call order."""
+    return list(RELU_FORCED_COUNTS)
 
 
 def forced_relu_noise_ratio():
@@ -180,6 +210,7 @@ def _relu(z, site, operands=None):
     if RELU_FORCED is not None:
         m = RELU_FORCED.pop(0)
         bad = m != (z.detach() > 0)
+        RELU_FORCED_COUNTS.append((int(bad.sum()), bad.numel()))
         dis = z.detach().abs()[bad]
         if dis.numel():
             RELU_FORCED_DEV = max(RELU_FORCED_DEV, float(dis.max()))

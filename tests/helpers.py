@@ -67,6 +67,8 @@ def relu_flips(eng, B, T, Lq, predictor='transformer'):
 # VisualProjection: 3.3e-5 on a row with a large S) while being 100x looser than needed on ordinary rows.
 # ---------------------------------------------------------------------------------------------------------------------------
 RELU_NOISE_KAPPA = 16.0
+RELU_MAX_OVERRIDES_FRAC = 1e-4     # of a site's decisions
+RELU_MAX_OVERRIDES_ABS = 2         # ... but a tiny site may have one or two
 
 
 def assert_forced_relu_inside_noise(O, context=None):
@@ -75,6 +77,11 @@ def assert_forced_relu_inside_noise(O, context=None):
     print('[relu-noise] %s: largest overridden pre-activation %.3e = %.1f x (u * S), gate %.0f (margin %.1f x)'
           % (context if isinstance(context, str) else '', O.forced_relu_deviation(), r, RELU_NOISE_KAPPA, RELU_NOISE_KAPPA / max(r, 1e-9)))
     assert r <= RELU_NOISE_KAPPA, (context, 'forced ReLU branch at %.1f x (u * S), |z| up to %.3e' % (r, O.forced_relu_deviation()))
+    # ... and there must be FEW of them: a pre-activation lands inside its noise band with probability ~ KAPPA * u * S / spread(z) ~ 1e-6, so a
+    # site of n decisions may see max(RELU_MAX_OVERRIDES_ABS, RELU_MAX_OVERRIDES_FRAC * n) overrides -- a kernel that flipped thousands of
+    # near-zero decisions inside the band would pass the magnitude gate above
+    for site, (nbad, n) in enumerate(O.forced_relu_counts()):
+        assert nbad <= max(RELU_MAX_OVERRIDES_ABS, RELU_MAX_OVERRIDES_FRAC * n), (context, 'ReLU site %d: %d of %d decisions overridden' % (site, nbad, n))
 
 
 def hip_relu_masks(eng, B, T, Lq, predictor='transformer'):

@@ -63,9 +63,11 @@ def test_train_then_test_mode_on_synthetic_task(tmp_path, optimizer, predictor, 
 
 @pytest.mark.gpu
 def test_test_mode_loads_a_checkpoint_written_by_the_reference(tmp_path):
-    """tests/golden/ref_checkpoint/: `torch.save(model.state_dict())` done BY THE REFERENCE (main_t7.py:125) with the `configs.json` it writes
-    (main_t7.py:81) and the metrics its own `eval_test` reports on the synthetic test split (oracle/make_golden.py: run_ref_checkpoint).
-    `main.py --mode test` (main_t7.py:132-149) must load the file and reproduce the metrics."""
+    """tests/golden/ref_checkpoint/: `torch.save(model.state_dict())` done BY THE REFERENCE (main_t7.py:125) on a randomly initialised model, and the
+    metrics its own `eval_test` reports for it on the synthetic test split (oracle/make_golden.py: run_ref_checkpoint).  The `configs.json` beside it
+    is THIS repo's argument namespace for the same flags (the reference's main_t7.py cannot be imported here -- nltk -- so it is not the file
+    main_t7.py:81 would write); what the reference contributes is the `state_dict` and the metrics.  `main.py --mode test` (main_t7.py:132-149) must
+    load the file and reproduce the metrics: with untrained weights that pins the loader, the key schema and `extract_index`, not a trained model."""
     import shutil
     src = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'ref_checkpoint')
     want = json.load(open(os.path.join(src, 'reference_metrics.json')))

@@ -11,7 +11,7 @@ import pytest
 import torch
 
 from oracle import vslnet_oracle as O
-from tests.helpers import assert_forced_relu_inside_noise
+from tests.helpers import RELU_NOISE_KAPPA, assert_forced_relu_inside_noise
 
 pytestmark = pytest.mark.gpu
 
@@ -371,6 +371,13 @@ def test_dropout_mask_statistics_and_scaling():
          word_dim=52),
 ])
 def test_baseline_shapes_against_oracle(shape):
+    check_shape_against_oracle(shape)
+
+
+def check_shape_against_oracle(shape, scaled_bias_floor=False):
+    """Forward logits, losses, every gradient and extract_index of one shape against the oracle.  scaled_bias_floor (tests/test_fuzz_parity.py):
+    the absolute floor of a Conv1D bias gradient's gate is max(1e-6, KAPPA * 2^-24 * sum |dY|) -- what was actually added -- so that tiny shapes
+    with cancelling bias sums are judged by their summands (two T = 4 shapes of the round-4 sweep tripped the fixed 1e-6 on a structural zero)."""
     cfg = O.make_cfg(video_feature_dim=shape['Dv'], max_pos_len=max(shape['T'], shape['Lq']), word_size=102, char_dim=shape.get('char_dim', 50),
                      char_size=shape.get('char_size', 40), word_table=shape.get('word_table', False), word_dim=shape.get('word_dim', 300))
     P = O.random_params(cfg, seed=11)
@@ -394,10 +401,13 @@ def test_baseline_shapes_against_oracle(shape):
     # count above is not enough; the branch taken is legitimate iff the pre-activation it overrides is inside the noise)
     O.force_relu_signs(hip_masks)
     Pg = {k: v.clone().requires_grad_(k not in O.FROZEN) for k, v in P.items()}
+    O.record_bias_terms(scaled_bias_floor)
     total, (oh, osl, oel, _, _) = O.total_loss(Pg, cfg, b)
     O.force_relu_signs(None)
     assert_forced_relu_inside_noise(O, (shape['name'], flips))
     total.backward()
+    bias_S = O.bias_term_sums(Pg) if scaled_bias_floor else {}
+    O.record_bias_terms(False)
     fin = osl.detach().abs() < 1e29
     scale = max(1.0, float(osl.detach()[fin].abs().max()))
     assert float((sl.cpu() - osl.detach())[fin].abs().max()) <= 1e-4 * scale, shape['name']
@@ -408,7 +418,7 @@ def test_baseline_shapes_against_oracle(shape):
     for k, t in eng.views(g).items():
         ref = Pg[k].grad if Pg[k].grad is not None else torch.zeros_like(Pg[k])
         err = float((t.cpu() - ref).abs().max())
-        tol = 1e-4 * float(ref.abs().max()) + 1e-6
+        tol = 1e-4 * float(ref.abs().max()) + max(1e-6, RELU_NOISE_KAPPA * 2.0 ** -24 * bias_S.get(k, 0.0))
         if k == 'cq_attention.w4Q' and shape['Lq'] == 1:
             # one query word: the softmax over j is the constant 1, so dw4Q is structurally zero (w4Q only acts
             # through that softmax).  What both sides compute is the cancellation residue of sum_i S_col (dS - dot); the gate
