@@ -60,8 +60,11 @@ typedef struct {
     float* start_logits;           /* (B, T)  exactly -1e30 at padded clips                                        */
     float* end_logits;             /* (B, T)                                                                       */
     /* saved activations + backward temporaries; vsl_workspace_floats() floats, caller-owned, 16-byte aligned.      */
-    /* Needs no initialisation, may be reused between shapes and handles (the rnn head's in-launch hand-off buffers */
-    /* live here: their tags are per-process NaN-patterned epochs, nothing older reads as valid).                   */
+    /* Needs no initialisation, may be reused between shapes and handles.  The rnn head's in-launch hand-off buffers */
+    /* live here: their tags are per-process NaN-patterned epochs (a 21-bit counter); the library clears a plan's   */
+    /* hand-off range once per workspace pointer and again whenever the counter has wrapped.  A caller that writes  */
+    /* its own data into a workspace between two steps of the SAME shape must hand over a different pointer (or     */
+    /* re-create the handle): inside one generation a word of that range is assumed to be the library's own.        */
     float* workspace;
     /* dropout (nn.Dropout sites of layers_t7.py): counter-based masks, keyed by (seed, site, element)             */
     int32_t training;              /* 0: eval (no dropout)                                                         */

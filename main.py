@@ -168,26 +168,16 @@ def train(configs, dataset, features, device, world, rank, log=print):
                     # this rank's rows, padded to the GLOBAL batch widths; the losses are normalised with the global batch
                     inv_batch, mask_sum = dp.global_normalisers(batch['lens_global'])
                     if batch['vfeats'].shape[0] == 0:
-                        # the last batch of an epoch can hold fewer samples than there are ranks (TACoS: 10146 % 16 = 2): a rank
-                        # without rows contributes a zero bucket and still joins the exchange and the (replicated) update
-                        grads.zero_()
-                        losses = torch.zeros(4, device=device)
-                        if xchg is not None:
-                            xchg.exchange(grads)                        # the same two calls in the same order as the ranks that have rows
-                        else:
-                            dp.allreduce_flat_(grads)
+                        # a rank without rows in this batch: zero bucket, same exchange calls, same (replicated) update
+                        losses, seeds = torch.zeros(4, device=device), None
                     else:
                         q_mask = (batch['word_ids'] != 0).float()
                         eng.forward(flat, pad_vec, glove_vec, batch['word_ids'], batch['char_ids'], batch['vfeats'], batch['v_mask'], q_mask,
                                     training=True, seed=(configs.seed << 20) + global_step, sample_offset=batch['row0'])
-                        losses, d_h, d_sl, d_el = eng.loss(batch['s_labels'], batch['e_labels'], batch['h_labels'], 1.0,
-                                                           configs.highlight_lambda, inv_batch=inv_batch, mask_sum=mask_sum)
-                        if xchg is not None:
-                            xchg.backward(d_h, d_sl, d_el, grads)
-                        else:
-                            eng.backward(d_h, d_sl, d_el, grads)
-                            dp.allreduce_flat_(grads)
-                    opt.step(grads, from_backward=world == 1)
+                        losses, *seeds = eng.loss(batch['s_labels'], batch['e_labels'], batch['h_labels'], 1.0,
+                                                  configs.highlight_lambda, inv_batch=inv_batch, mask_sum=mask_sum)
+                    touched = dp.backward_and_exchange(eng, xchg, grads, seeds)       # (tests/test_dp_gloo.py drives this unit on 2 and 3 ranks)
+                    opt.step(grads, from_backward=not touched)                        # the backward's own norm only for an untouched bucket
                     loss_t = losses[2]
                 else:
                     _, vfeats, vfeat_lens, word_ids, char_ids, s_labels, e_labels, h_labels = batch
@@ -237,6 +227,14 @@ def train(configs, dataset, features, device, world, rank, log=print):
                                 trace['checkpoint'] += clock() - t4
                         model.train()
                     if world > 1:
+                        # rank 0 may have hit a checkpoint-write error (raised by the next save): agree on it BEFORE the barrier, or the
+                        # other ranks sit in the barrier / the next all-reduce until the communicator times out
+                        failed = torch.tensor([1 if (rank == 0 and ckpt is not None and ckpt.err is not None) else 0], device=device)
+                        torch.distributed.all_reduce(failed)
+                        if int(failed.item()):
+                            if rank == 0:
+                                ckpt._raise_pending()
+                            raise RuntimeError('rank 0 failed to write a checkpoint; stopping every rank')
                         torch.distributed.barrier()
             torch.cuda.synchronize(device)
             epoch_end.append(time.perf_counter())
@@ -245,7 +243,13 @@ def train(configs, dataset, features, device, world, rank, log=print):
         if score_writer:
             score_writer.close()
         if ckpt is not None:
-            ckpt.close()                                                   # every checkpoint is on disk when train() returns
+            in_flight = sys.exc_info()[1]
+            try:
+                ckpt.close()                                               # every checkpoint is on disk when train() returns
+            except Exception as e:                                         # noqa: BLE001
+                if in_flight is None:
+                    raise
+                log('checkpoint writer failed while another error was in flight: %r' % (e,))      # keep the original exception
     return {'history': history, 'model_dir': model_dir, 'steps': global_step, 'trace': trace, 'epoch_end': epoch_end}
 
 

@@ -113,7 +113,8 @@ def test_overlapped_exchange_equals_plain_backward_on_one_rank():
 def _bench(extra_env, *args):
     env = dict(os.environ)
     env.update(extra_env)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '6', '--warmup', '2', '--no-cpu-baseline', *args],
+    steps = [] if '--steps' in args else ['--steps', '6']
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), *steps, '--warmup', '2', '--regions', '1', '--no-shapes', '--no-cpu-baseline', *args],
                        capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     return json.loads(r.stdout.strip().splitlines()[-1])
@@ -134,11 +135,31 @@ def test_bench_under_a_one_rank_rccl_group_takes_the_overlapped_exchange():
     print('[one-rank exchange] plain %.4f ms/step, under RCCL %.4f ms/step (exposed %.1f us)' % (plain['ms_per_step'], over['ms_per_step'], over['allreduce_us']))
 
 
+@pytest.mark.gpu
+def test_fused_rnn_head_at_its_largest_batch_beside_a_communicator():
+    """The one-launch rnn head rests on workgroup dispatch order (producers are dispatched before their consumers; bounded spins turn a violation
+    into NaNs).  B = 80 is its largest batch: 240 workgroups per direction, here 50 steps in a row with an RCCL communicator's kernels and
+    streams in the same process (one rank: `VSL_FORCE_DIST=1`, overlapped two-call exchange path -- for the rnn head a single call).  The
+    loss must be finite and identical to the plain run's (same seeds, identity all-reduce)."""
+    args = ('--predictor', 'rnn', '--batch', '80', '--steps', '50')
+    plain = _bench({}, *args)
+    dist_env = {'VSL_FORCE_DIST': '1', 'VSL_ALLREDUCE': 'overlap', 'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': '29613', 'RANK': '0',
+                'WORLD_SIZE': '1', 'LOCAL_RANK': '0', 'HSA_ENABLE_IPC_MODE_LEGACY': '0'}
+    over = _bench(dist_env, *args)
+    assert over['rccl_ranks'] == 1 and over['steps'] == 50
+    assert over['config']['loss'] == plain['config']['loss'], (over['config']['loss'], plain['config']['loss'])
+
+
 def test_engine_refuses_a_process_group_with_too_few_hardware_queues(monkeypatch):
+    """Refused: a multi-rank RCCL ('nccl') group with fewer than 8 hardware queues (or the variable set after HIP came up).  A gloo group, one
+    rank, or VSL_ALLOW_FEW_HW_QUEUES=1 only get a warning (the condition is a performance one, embedders must be able to opt out)."""
     import torch.distributed as dist
     import vslnet_amd
     from vslnet_amd import engine
     monkeypatch.setattr(dist, 'is_initialized', lambda: True)
+    monkeypatch.setattr(dist, 'get_backend', lambda *a: 'nccl')
+    monkeypatch.setattr(dist, 'get_world_size', lambda *a: 2)
+    monkeypatch.delenv('VSL_ALLOW_FEW_HW_QUEUES', raising=False)
     monkeypatch.setenv('GPU_MAX_HW_QUEUES', '4')
     with pytest.raises(engine.VslError, match='GPU_MAX_HW_QUEUES'):
         engine.check_hw_queues()
@@ -148,5 +169,16 @@ def test_engine_refuses_a_process_group_with_too_few_hardware_queues(monkeypatch
     monkeypatch.setattr(vslnet_amd, 'QUEUES_SET_LATE', True)      # the default arrived after HIP was initialised
     with pytest.raises(engine.VslError, match='set after HIP was initialised'):
         engine.check_hw_queues()
+    # the same state, but nothing to lose: one rank / gloo / explicit opt-out -> a warning, once
+    for patch in (lambda: monkeypatch.setattr(dist, 'get_world_size', lambda *a: 1), lambda: monkeypatch.setattr(dist, 'get_backend', lambda *a: 'gloo'),
+                  lambda: monkeypatch.setenv('VSL_ALLOW_FEW_HW_QUEUES', '1')):
+        monkeypatch.setattr(dist, 'get_world_size', lambda *a: 2)
+        monkeypatch.setattr(dist, 'get_backend', lambda *a: 'nccl')
+        monkeypatch.delenv('VSL_ALLOW_FEW_HW_QUEUES', raising=False)
+        patch()
+        monkeypatch.setattr(engine, '_HW_QUEUE_WARNED', False)
+        with pytest.warns(UserWarning, match='GPU_MAX_HW_QUEUES'):
+            engine.check_hw_queues()
+        engine.check_hw_queues()                                  # second call: silent
     monkeypatch.setattr(dist, 'is_initialized', lambda: False)    # no process group: nothing to check
     engine.check_hw_queues()

@@ -67,6 +67,9 @@ struct Plan {
     EncWs ve, qe, p1, p2;
     LstmWs lstm[2];
     int64_t h_gran = -1, gi_gran = -1, dg_gran = -1, dx_gran = -1;     // granule buffers of the fused rnn head (8 bytes per value); -1: chunked launches
+    int64_t gran_floats = 0;                // their total extent (contiguous in the workspace, from h_gran)
+    long long gran_gen = -1;                // epoch generation and workspace these buffers were last cleared for (rnn_granules_fresh)
+    const void* gran_ws = nullptr;
     int64_t S, Srow, Scol, M, alpha, pooled, pb, cat, f1, f2, gated, hid_s, hid_e, lnf_s, lnf_e;
     // backward temporaries
     int64_t loss_scratch, gz_s, gz_e, dfeat_s, dfeat_e, dxh_s, dxh_e, g_s1, g_gated;
@@ -594,9 +597,23 @@ std::vector<int> lstm_chunks(int T) {
 
 // Tag of one fused rnn launch's granules: unique per process and a NaN pattern (quiet NaN with a payload no arithmetic produces), so that
 // nothing the caller's workspace may hold from earlier use -- activations, indices, older granules -- reads as a valid tag.
-unsigned rnn_epoch() {
-    static std::atomic<unsigned> n{0};
-    return 0x7FE00000u | ((n.fetch_add(1) + 1) & 0x1FFFFFu);
+// The counter has 21 bits: after 2^21 fused launches (two per training step) the tags repeat.  `gen` = how often it has wrapped; a plan's granule
+// buffers are cleared once per (workspace, generation) before a launch (rnn_granules_fresh), so a tag of generation g - 1 can never be read as
+// one of generation g.  What remains an assumption: inside one generation the caller does not write its own data into the workspace range the
+// plan uses for granules (include/vslnet_hip.h: the workspace belongs to the library between vsl_forward and vsl_backward of a step; across
+// steps only its granule ranges must be left alone or be re-zeroed by a plan change).
+static std::atomic<unsigned long long> g_rnn_launches{0};
+unsigned rnn_epoch(long long* gen = nullptr) {
+    const unsigned long long n = g_rnn_launches.fetch_add(1) + 1;
+    if (gen) *gen = (long long)(n >> 21);
+    return 0x7FE00000u | (unsigned)(n & 0x1FFFFFu) | ((n & 0x1FFFFFu) == 0 ? 1u : 0u);      // (counter value 0 is skipped: a cleared word must not look like a tag)
+}
+
+// first use of a plan's granule buffers in this workspace, or the epoch counter has wrapped since: one memset on the launch stream
+static void rnn_granules_fresh(Ctx& c, Plan& p, long long gen) {
+    if (p.gran_ws == (const void*)c.ws && p.gran_gen == gen) return;
+    (void)hipMemsetAsync(c.W(p.h_gran), 0, (size_t)p.gran_floats * sizeof(float), c.s);
+    p.gran_ws = c.ws; p.gran_gen = gen;
 }
 
 void run_forward(Ctx& c) {
@@ -683,7 +700,9 @@ void run_forward(Ctx& c) {
                 a.gates[l] = c.W(w.gates); a.cseq[l] = c.W(w.cseq); a.tseq[l] = c.W(w.tseq); a.hprev[l] = c.W(w.hprev); a.out[l] = c.W(w.out);
             }
             a.h_gran = reinterpret_cast<unsigned long long*>(c.W(p.h_gran)); a.gi_gran = reinterpret_cast<unsigned long long*>(c.W(p.gi_gran));
-            a.epoch = rnn_epoch(); a.B = B; a.T = T;
+            long long gen = 0;
+            a.epoch = rnn_epoch(&gen); a.B = B; a.T = T;
+            rnn_granules_fresh(c, *c.p, gen);
             LAUNCH("rnn_fwd", launch_rnn_fwd(a, c.s));
         } else if (chunks.size() < 2 || sq == main_s) {
             lstm(0, 0, T);
@@ -889,7 +908,9 @@ void run_backward(Ctx& c) {
                     a.gates[l] = c.W(w.gates); a.cseq[l] = c.W(w.cseq); a.tseq[l] = c.W(w.tseq); a.Whh[l] = c.PK(K.l_hb[l]); a.dG[l] = c.W(w.dG);
                 }
                 a.dg_gran = reinterpret_cast<unsigned long long*>(c.W(p.dg_gran)); a.dx_gran = reinterpret_cast<unsigned long long*>(c.W(p.dx_gran));
-                a.epoch = rnn_epoch(); a.B = B; a.T = T;
+                long long gen = 0;
+                a.epoch = rnn_epoch(&gen); a.B = B; a.T = T;
+                rnn_granules_fresh(c, *c.p, gen);
                 LAUNCH("rnn_bwd", launch_rnn_bwd(a, c.s));
                 dx(0, 0, T);
             } else if (!piped) {
@@ -1107,7 +1128,10 @@ int build_plan(vsl_handle_s* h, int B, int T, int Lq, int Lc, Plan** out) {
             w.carry = al((int64_t)B * 2 * D);
         }
         p->p1.out = p->lstm[0].out; p->p2.out = p->lstm[1].out;
-        if (rnn_fused_ok(B)) { p->h_gran = al(R * 2 * D); p->gi_gran = al(R * 8 * D); p->dg_gran = al(R * 8 * D); p->dx_gran = al(R * 2 * D); }
+        if (rnn_fused_ok(B)) {
+            p->h_gran = al(R * 2 * D); p->gi_gran = al(R * 8 * D); p->dg_gran = al(R * 8 * D); p->dx_gran = al(R * 2 * D);
+            p->gran_floats = (p->dx_gran + R * 2 * D) - p->h_gran;      // the four allocations are consecutive
+        }
     } else {
         plan_encoder(al, p->p1, B, T, H); plan_encoder(al, p->p2, B, T, H);
     }

@@ -209,7 +209,8 @@ void launch_lstm_bwd(const float* dout, const float* dout2, const float* mask, c
 constexpr int LSTM_IMG_FLOATS = 4 * D * D;
 // The rnn head as one launch per direction: three workgroups per sample (start LSTM, W_ih projection, end LSTM) handing steps over through
 // {tag, value} granules.  B <= RNN_FUSED_MAX_B keeps all 3 B workgroups resident beside the side streams' kernels; beyond it the chunked
-// launches above.  The granule buffers are zeroed once (tags), `epoch` (> 0) is new for every launch.
+// launches above.  `epoch` is new for every launch (a NaN-patterned 21-bit counter); api.hip clears a plan's granule buffers once per
+// workspace and once more whenever the counter has wrapped (rnn_granules_fresh), so a stale word never carries the live tag.
 constexpr int RNN_FUSED_MAX_B = 80;
 struct RnnFwdArgs {
     const float* gi0;                 // (R, 512) input projection of the start LSTM

@@ -64,11 +64,16 @@ class OverlappedExchange:
     def __init__(self, engine, group=None):
         self.engine, self.group = engine, group
         self.split = engine.early_grad_offset()
-        self.side = torch.cuda.Stream(device=engine.device)
-        self.event = torch.cuda.Event(enable_timing=False)
+        # (a CPU engine -- the gloo tests' stand-in -- has no streams: the same two calls, one after the other)
+        self.on_gpu = torch.device(engine.device).type == 'cuda'
+        self.side = torch.cuda.Stream(device=engine.device) if self.on_gpu else None
+        self.event = torch.cuda.Event(enable_timing=False) if self.on_gpu else None
 
     def backward(self, d_h, d_sl, d_el, grads, skip_exchange=False):
         import torch.distributed as dist
+        if not self.on_gpu:
+            self.engine.backward(d_h, d_sl, d_el, grads)
+            return grads if skip_exchange else two_segment_allreduce_(grads, self.split, self.group)
         cur = torch.cuda.current_stream(self.engine.device)
         overlapped = not skip_exchange and self.split < grads.numel()
         self.engine.backward(d_h, d_sl, d_el, grads, early_event=self.event if overlapped else None)
@@ -91,6 +96,31 @@ class OverlappedExchange:
         same order on the same communicator as `backward` issues on the other ranks."""
         two_segment_allreduce_(grads, self.split, self.group)
         return grads
+
+
+def backward_and_exchange(engine, xchg, grads, seeds):
+    """One training step's backward + gradient exchange, exactly as `main.train` runs it on every rank (the unit the multi-rank tests drive).
+      seeds = (d_h, d_sl, d_el) from `engine.loss`, or None for a rank whose shard of this batch is EMPTY (the last batch of an epoch can hold
+              fewer samples than there are ranks -- TACoS: 10146 % 16 = 2): such a rank contributes a zero bucket and joins the exchange with the
+              same calls, in the same order, on the same communicator as the ranks that have rows;
+      xchg  = an `OverlappedExchange` (two calls, the predictor block early) or None (ONE call behind the backward; VSL_ALLREDUCE=single).
+    Returns True when the bucket was MODIFIED after the backward wrote it (an exchange ran): the optimizer must then take its own norm of the
+    bucket (`FlatAdamW.step(from_backward=False)`) -- the backward's sum of squares belongs to the local gradient, not to the summed one."""
+    import torch.distributed as dist
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(xchg.group if xchg is not None else None) > 1
+    if seeds is None:
+        grads.zero_()
+        if xchg is not None:
+            xchg.exchange(grads)
+        else:
+            allreduce_flat_(grads)
+        return True
+    if xchg is not None:
+        xchg.backward(seeds[0], seeds[1], seeds[2], grads)
+        return True
+    engine.backward(seeds[0], seeds[1], seeds[2], grads)
+    allreduce_flat_(grads)
+    return multi
 
 
 class FlatAdamW:

@@ -116,11 +116,17 @@ def _chk(t, dtype, shape, name):
                          (name, dtype, tuple(shape), t.dtype, tuple(t.shape), t.device))
 
 
+_HW_QUEUE_WARNED = False
+
+
 def check_hw_queues():
-    """A process group (RCCL) brings its own streams; with fewer than 8 hardware queues the library's two side streams then share a
+    """A process group over RCCL brings its own streams; with fewer than 8 hardware queues the library's two side streams then share a
     queue with another stream and the fork / join overlap of the step is silently lost (measured: 1.25 -> 1.51 ms per step).  The
-    variable only counts if it was in the environment before the process initialised HIP -- the library cannot enforce that, so it
-    refuses to run in the state it can detect: a process group exists and GPU_MAX_HW_QUEUES is below 8 or was set too late."""
+    variable only counts if it was in the environment before the process initialised HIP -- the library cannot enforce that, so it refuses
+    to run in the state it can detect AND that costs: an nccl (= RCCL) group of more than one rank with GPU_MAX_HW_QUEUES below 8 or set too
+    late.  Anything else -- a gloo group, one rank, an embedding application that initialised HIP first -- is a performance note, printed once;
+    VSL_ALLOW_FEW_HW_QUEUES=1 turns the refusal into that note as well."""
+    global _HW_QUEUE_WARNED
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return
@@ -129,10 +135,18 @@ def check_hw_queues():
         q = int(os.environ.get('GPU_MAX_HW_QUEUES', '0'))
     except ValueError:
         q = 0
-    if q < 8 or vslnet_amd.QUEUES_SET_LATE:
-        raise VslError('GPU_MAX_HW_QUEUES=%s%s while a torch.distributed process group exists: the step needs 8 hardware queues beside '
-                       "RCCL's streams.  Export GPU_MAX_HW_QUEUES=8 before the process starts (or import vslnet_amd before the first CUDA call)"
-                       % (os.environ.get('GPU_MAX_HW_QUEUES'), ' (set after HIP was initialised)' if vslnet_amd.QUEUES_SET_LATE else ''))
+    if q >= 8 and not vslnet_amd.QUEUES_SET_LATE:
+        return
+    msg = ('GPU_MAX_HW_QUEUES=%s%s while a torch.distributed process group exists: the step needs 8 hardware queues beside '
+           "RCCL's streams.  Export GPU_MAX_HW_QUEUES=8 before the process starts (or import vslnet_amd before the first CUDA call)"
+           % (os.environ.get('GPU_MAX_HW_QUEUES'), ' (set after HIP was initialised)' if vslnet_amd.QUEUES_SET_LATE else ''))
+    rccl_multi = dist.get_backend() == 'nccl' and dist.get_world_size() > 1
+    if rccl_multi and os.environ.get('VSL_ALLOW_FEW_HW_QUEUES') != '1':
+        raise VslError(msg)
+    if not _HW_QUEUE_WARNED:
+        _HW_QUEUE_WARNED = True
+        import warnings
+        warnings.warn('vslnet_amd: ' + msg + ' -- continuing (%s)' % ('VSL_ALLOW_FEW_HW_QUEUES=1' if rccl_multi else 'no multi-rank RCCL group: nothing to lose'))
 
 
 class Engine:
