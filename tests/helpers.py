@@ -139,8 +139,7 @@ def _drop_hash(idx, seed, key):
     h = (h * np.uint64(0x85EBCA6B)) & _M32
     h ^= (h >> np.uint64(13)) ^ np.uint64(key)
     h = (h * np.uint64(0xC2B2AE35)) & _M32
-    h ^= h >> np.uint64(16)
-    return h
+    return h                                             # (no final xor-shift: the decision is a compare against p * 2^32)
 
 
 # site ids in the order the oracle reaches its dropout calls (api.hip: SITE_* = 64.., encoder pass `app` * 16 + 0..8)

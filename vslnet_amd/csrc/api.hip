@@ -746,8 +746,21 @@ void run_forward(Ctx& c) {
 WgradJob wjob() { WgradJob j; memset(&j, 0, sizeof j); return j; }
 
 // backward of one FeatureEncoder application: dy = grad wrt its output; writes grad wrt its input (dx0_out)
+// the attention-output backward of encoder application `app` (its LayerNorm-2 partial slabs are allocated here: call once per application)
+AttnOutBwdArgs attn_out_bwd_args(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float* dy, const float* dy2, int app) {
+    const Plan& p = *c.p;
+    const EncTmp& t = p.tmp[app];
+    const int ntiles = (w.R + TILE_M - 1) / TILE_M;
+    float* p_ln2g = c.slab(P.ln2g, D, ntiles);
+    float* p_ln2b = c.slab(P.ln2b, D, ntiles);
+    AttnOutBwdArgs a;
+    memset(&a, 0, sizeof a);
+    if (!c.dry) a = AttnOutBwdArgs{dy, dy2, c.W(w.r), c.P(P.ln2g), c.PK(K.o_t), c.W(t.go), c.W(t.dr), p_ln2g, p_ln2b, c.drop(app * 16 + 7), c.drop(app * 16 + 8)};
+    return a;
+}
+// attn_out_done: the attention-output backward of this application already ran (fused into the span heads' kernel: run_backward)
 void enc_bwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float* dy, const float* dy2, int64_t dx0_off,
-             const float* mask, int Bn, int app, hipStream_t sw, WgradBatch* defer_pw = nullptr) {
+             const float* mask, int Bn, int app, hipStream_t sw, WgradBatch* defer_pw = nullptr, bool attn_out_done = false) {
     // sw: stream of the early (out_layer / q,k,v) weight gradients.  The pointwise-conv batch goes to `sw` too unless the
     // caller asks for it back (defer_pw) to launch it on its own stream WITHOUT a cross-stream wait (each costs ~16 us).
     float* dx0_out = c.dry ? nullptr : c.W(dx0_off);
@@ -755,10 +768,10 @@ void enc_bwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float*
     const EncTmp& t = p.tmp[app];
     const int R = w.R, L = w.L, H = c.h->cfg.num_heads;
     const int ntiles = (R + TILE_M - 1) / TILE_M, nchunk = (R + WG_ROWS - 1) / WG_ROWS;
-    float* p_ln2g = c.slab(P.ln2g, D, ntiles);
-    float* p_ln2b = c.slab(P.ln2b, D, ntiles);
-    LAUNCH("attn_out_bwd", launch_attn_out_bwd(dy, dy2, c.W(w.r), c.P(P.ln2g), c.PK(K.o_t), c.W(t.go), c.W(t.dr), p_ln2g, p_ln2b, R,
-                               c.drop(app * 16 + 7), c.drop(app * 16 + 8), c.s));
+    if (!attn_out_done) {
+        const AttnOutBwdArgs ao = attn_out_bwd_args(c, P, K, w, dy, dy2, app);
+        LAUNCH("attn_out_bwd", launch_attn_out_bwd(ao.dy, ao.dy2, ao.r_in, ao.ln_g, ao.WTpack, ao.g_o, ao.dr, ao.p_lng, ao.p_lnb, R, ao.d4, ao.d5, c.s));
+    }
     LAUNCH("attn_bwd", launch_attn_bwd(c.W(w.q), c.W(w.k), c.W(w.v), c.W(w.att), c.W(t.dr), c.W(w.lse), mask, c.W(t.dq), c.W(t.dk),
                            c.W(t.dv), Bn, L, H, 0, c.drop(app * 16 + 5), c.drop(app * 16 + 6), c.s));
     float* p_ln1g = c.slab(P.ln1g, D, ntiles);
@@ -863,7 +876,10 @@ void run_backward(Ctx& c) {
         hs.p_lng = c.slab(P.sln_g, D, ntiles); hs.p_lnb = c.slab(P.sln_b, D, ntiles);
         he.p_lng = c.slab(P.eln_g, D, ntiles); he.p_lnb = c.slab(P.eln_b, D, ntiles);
     }
-    LAUNCH("head_bwd", launch_head_bwd(hs, he, R, c.s));
+    // transformer head: the end head's workgroups run the attention-output backward of the second predictor pass on their own tile of dfeat_e
+    AttnOutBwdArgs ao2;
+    if (!rnn) ao2 = attn_out_bwd_args(c, P.pe, K.pe, p.p2, nullptr, nullptr, 3);
+    LAUNCH("head_bwd", launch_head_bwd(hs, he, R, c.s, rnn ? nullptr : &ao2));
     {
         WgradBatch wb;
         memset(&wb, 0, sizeof wb);
@@ -965,7 +981,7 @@ void run_backward(Ctx& c) {
         }
     } else {
     // ---- predictor encoder, second pass (input = output of the first pass), then first pass
-    enc_bwd(c, P.pe, K.pe, p.p2, c.dry ? nullptr : c.W(p.dfeat_e), nullptr, p.g_s1, c.dry ? nullptr : io->v_mask, B, 3, sw);
+    enc_bwd(c, P.pe, K.pe, p.p2, c.dry ? nullptr : c.W(p.dfeat_e), nullptr, p.g_s1, c.dry ? nullptr : io->v_mask, B, 3, sw, nullptr, true);
     wgrad_flush(c, sw);   // span heads + pass-2 weight gradients: one ordering point
     // grad wrt the first pass' output = (input grad of the second pass) + (LayerNorm path of the start head)
     enc_bwd(c, P.pe, K.pe, p.p1, c.dry ? nullptr : c.W(p.g_s1), c.dry ? nullptr : c.W(p.dfeat_s), p.g_gated,

@@ -59,10 +59,12 @@ __host__ __device__ __forceinline__ uint16_t f32_to_bf16(float v) {
     return (uint16_t)(b >> 16);
 }
 // the keep decision's hash: murmur3's finaliser over (element * golden + seed) with the site key folded into the middle xor
-// (v_xor3_b32: no extra instruction)
+// (v_xor3_b32: no extra instruction) -- WITHOUT the finaliser's last xor-shift (round 5): the decision is `hash >= p * 2^32`, the
+// dropped step only touches the low 16 bits, i.e. it could change a decision for 2^-16 of the hashes; two instructions less at each of
+// the ~130 M elements a training step hashes (forward + recomputation in the backward; ~17 % of the step's vector instructions are this hash)
 __device__ __forceinline__ uint32_t drop_hash(uint32_t idx, uint32_t seed, uint32_t key) {
     uint32_t h = idx * 0x9E3779B1u + seed;
-    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= (h >> 13) ^ key; h *= 0xC2B2AE35u; h ^= h >> 16;
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= (h >> 13) ^ key; h *= 0xC2B2AE35u;
     return h;
 }
 // multiplier applied to element `idx` of the site: 0 or 1/(1-p)
@@ -615,7 +617,7 @@ __device__ __forceinline__ void ln_tile(float* tile, int nrows, int ld, const fl
 // LayerNorm backward on a 32-row tile.
 //   Ts : grad wrt the LN output (32 x 128, stride LDP) -- left in place (beta partial = its column sums)
 //   Xs : raw LN input rows (32 x 128, stride LDP)       -- overwritten with dy * xhat (gamma partial = column sums)
-//   out[r] = LN^T(Ts[r]) + resid[r] + extra[r]  for global rows r0 + rr < R ; partial slabs [blockIdx.x][128].
+//   out[r] = LN^T(Ts[r]) + resid[r] + extra[r]  for global rows r0 + rr < R (out nullable: the result then only goes to lds_out) ; partial slabs [blockIdx.x][128].
 //   lds_out (nullable): the result tile is also left in LDS (stride LDP; rows >= R zero) for a fused follow-up GEMM.
 // The residual rows (resid + resid2) a thread adds in ln_bwd_tile: requested at kernel entry so that their memory latency is
 // not paid in the middle of the kernel.  Rows >= R are clamped for the load and zeroed.
@@ -678,7 +680,7 @@ __device__ __forceinline__ void ln_bwd_tile(float* Ts, float* Xs, const LnResid&
             float4 o;
             o.x = rstd * (gd[j].x - m1 - x[j].x * m2) + rs[j].x; o.y = rstd * (gd[j].y - m1 - x[j].y * m2) + rs[j].y;
             o.z = rstd * (gd[j].z - m1 - x[j].z * m2) + rs[j].z; o.w = rstd * (gd[j].w - m1 - x[j].w * m2) + rs[j].w;
-            if (r < R) *reinterpret_cast<float4*>(out + (size_t)r * D + sub * 4 + 32 * j) = o;
+            if (out && r < R) *reinterpret_cast<float4*>(out + (size_t)r * D + sub * 4 + 32 * j) = o;
             const bool ok = r < R;
             if (lds_out) *reinterpret_cast<float4*>(lds_out + rr * LDP + sub * 4 + 32 * j) = ok ? o : make_float4(0.f, 0.f, 0.f, 0.f);
             *reinterpret_cast<float4*>(xr + 32 * j) = ok ? make_float4(dy[j].x * x[j].x, dy[j].y * x[j].y, dy[j].z * x[j].z, dy[j].w * x[j].w)

@@ -272,11 +272,95 @@ void launch_extract_index(const float* sl, const float* el, int64_t* si, int64_t
     VSL_LAUNCH(k_extract_index, dim3(B), dim3(256), (size_t)(2 * T + 8) * sizeof(float), s, sl, el, si, ei, T);
 }
 
+// Weight gradients: kernels_wgrad.hip
+
+// =========================================================================================================
+// MHA block backward (a8, :167-190)
+//  k_attn_out_bwd : do = dy * m5 ; dh2 = do Wo ; dr = dy + LN2^T(dh2 * m4)
+//  k_attn_bwd_dq / k_attn_bwd_dkv : attention core (recompute P from Q, K and the saved LSE)
+//  k_qkv_bwd      : dh1 = [dQ|dK|dV] [Wq;Wk;Wv] ; dx = dr + LN1^T(dh1 * m1)
+// =========================================================================================================
+// one 32-row tile.  lds_dy != nullptr: the incoming gradient tile is already in LDS (stride LDP, rows >= R zero; dy2 is then ignored) -- the
+// fused caller (k_head_bwd) hands over what it has just computed.  Gs / Xs: two [32][LDP] tiles, neither of them lds_dy.
+__device__ __forceinline__ void attn_out_bwd_tile(const AttnOutBwdArgs& a, const float* lds_dy, float* Gs, float* Xs, int r0, int R) {
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    BFrag<1, 16> bf;
+    LnResid lres;
+    {
+        float4 a1[4], a2[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + q * 256;
+            const int r = r0 + (e >> 5), c = (e & 31) * 4;
+            a1[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            a2[q] = a1[q];
+            if (lds_dy) a1[q] = *reinterpret_cast<const float4*>(lds_dy + (e >> 5) * LDP + c);
+            else if (r < R) {
+                a1[q] = *reinterpret_cast<const float4*>(a.dy + (size_t)r * D + c);
+                if (a.dy2) a2[q] = *reinterpret_cast<const float4*>(a.dy2 + (size_t)r * D + c);
+            }
+        }
+        bfrag_load(bf, a.WTpack, D, 32 * w, 0, 0, D / 8);     // after the tile (in-order return), before the LN input tile
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + q * 256;
+            const int rr = e >> 5, c = (e & 31) * 4;
+            const int r = r0 + rr;
+            float4 v = make_float4(a1[q].x + a2[q].x, a1[q].y + a2[q].y, a1[q].z + a2[q].z, a1[q].w + a2[q].w);
+            if (r < R) {
+                if (a.d5.thresh) {
+                    const uint32_t base = (uint32_t)(r * D + c);
+                    v.x *= drop_mul(a.d5, base); v.y *= drop_mul(a.d5, base + 1);
+                    v.z *= drop_mul(a.d5, base + 2); v.w *= drop_mul(a.d5, base + 3);
+                }
+                *reinterpret_cast<float4*>(a.g_o + (size_t)r * D + c) = v;       // G operand of the out_layer weight gradient
+            }
+            *reinterpret_cast<float4*>(&Gs[rr * LDP + c]) = v;
+        }
+    }
+    // residual path of LN2's backward: the same rows again (L2 hits, or the LDS tile), used last
+    if (lds_dy) {
+        const int sub = tid & 7, rr = tid >> 3;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lres.v[j] = *reinterpret_cast<const float4*>(lds_dy + rr * LDP + sub * 4 + 32 * j);
+    } else ln_resid_prefetch(lres, a.dy, a.dy2, r0, R);
+    load_tile128(Xs, a.r_in, r0, TILE_M, R);                  // only needed by the LayerNorm backward after the GEMM
+    __syncthreads();
+    f32x16 acc[1];
+    zero_acc(acc);
+    gemm32p<1, 16>(Gs, LDP, D, a.WTpack, D, 32 * w, 0, acc, bf);
+    __syncthreads();
+    const int col = 32 * w + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r, lane);
+        Gs[row * LDP + col] = acc[0][r] * drop_mul(a.d4, (uint32_t)((r0 + row) * D + col));
+    }
+    __syncthreads();
+    ln_bwd_tile(Gs, Xs, lres, a.ln_g, a.dr, a.p_lng, a.p_lnb, r0, R);
+}
+__global__ __launch_bounds__(256) void k_attn_out_bwd(AttnOutBwdArgs a, int R) {
+    __shared__ __attribute__((aligned(16))) float Gs[TILE_M * LDP];
+    __shared__ __attribute__((aligned(16))) float Xs[TILE_M * LDP];
+    attn_out_bwd_tile(a, nullptr, Gs, Xs, blockIdx.x * TILE_M, R);
+}
+void launch_attn_out_bwd(const float* dy, const float* dy2, const float* r, const float* ln_g, const float* WTpack, float* g_o,
+                         float* dr, float* p_lng, float* p_lnb, int R, Drop d4, Drop d5, hipStream_t s) {
+    {
+        const size_t shm_sp = 0;
+        const AttnOutBwdArgs a{dy, dy2, r, ln_g, WTpack, g_o, dr, p_lng, p_lnb, d4, d5};
+        VSL_LAUNCH(k_attn_out_bwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm_sp, s, a, R);
+    }
+}
+
 // =========================================================================================================
 // heads backward (a14, :349-352): dlogit -> dz = dlogit * w1 * (hid > 0) -> [dLN(feat) | dx] = dz W0 ;
 //   LN backward -> dfeat.  blockIdx.y selects start / end.
 // =========================================================================================================
-__global__ __launch_bounds__(256) void k_head_bwd(HeadBwdArgs a0, HeadBwdArgs a1, int R) {
+// `fuse` (transformer head): the END head's workgroups go on, on the tile of dfeat they have just produced, with the attention-output
+// backward of the predictor encoder's second pass (k_attn_out_bwd's body) -- that gradient has no other consumer, so it never leaves the chip,
+// and one kernel boundary of the dependent chain is gone (tile-local: no other workgroup's data is needed).
+__global__ __launch_bounds__(256) void k_head_bwd(HeadBwdArgs a0, HeadBwdArgs a1, int R, int fuse, AttnOutBwdArgs ao) {
     __shared__ __attribute__((aligned(16))) float Gs[TILE_M * LDP];
     __shared__ __attribute__((aligned(16))) float Hs[TILE_M * LDP];
     __shared__ __attribute__((aligned(16))) float Fs[TILE_M * LDP];
@@ -324,7 +408,12 @@ __global__ __launch_bounds__(256) void k_head_bwd(HeadBwdArgs a0, HeadBwdArgs a1
         LnResid nores;
 #pragma unroll
         for (int j = 0; j < 4; ++j) nores.v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        ln_bwd_tile(Hs, Fs, nores, a.ln_g, a.dfeat, a.p_lng, a.p_lnb, r0, R);
+        const bool go_on = fuse && blockIdx.y == 1;
+        ln_bwd_tile(Hs, Fs, nores, a.ln_g, go_on ? nullptr : a.dfeat, a.p_lng, a.p_lnb, r0, R, go_on ? Gs : nullptr);
+        if (go_on) {                       // (block-uniform)
+            __syncthreads();               // the column sums of ln_bwd_tile are done with Hs / Fs; Gs holds dfeat (rows >= R zero)
+            attn_out_bwd_tile(ao, Gs, Hs, Fs, r0, R);
+        }
     } else {
         for (int e = tid; e < TILE_M * D; e += 256) {
             const int rr = e >> 7, c = e & 127;
@@ -332,87 +421,16 @@ __global__ __launch_bounds__(256) void k_head_bwd(HeadBwdArgs a0, HeadBwdArgs a1
         }
     }
 }
-void launch_head_bwd(const HeadBwdArgs& a0, const HeadBwdArgs& a1, int R, hipStream_t s) {
+void launch_head_bwd(const HeadBwdArgs& a0, const HeadBwdArgs& a1, int R, hipStream_t s, const AttnOutBwdArgs* fuse) {
     {
         const size_t shm_sp = 0;
-        VSL_LAUNCH(k_head_bwd, dim3((R + TILE_M - 1) / TILE_M, 2), dim3(256), shm_sp, s, a0, a1, R);
+        AttnOutBwdArgs ao;
+        memset(&ao, 0, sizeof ao);
+        if (fuse) ao = *fuse;
+        VSL_LAUNCH(k_head_bwd, dim3((R + TILE_M - 1) / TILE_M, 2), dim3(256), shm_sp, s, a0, a1, R, fuse ? 1 : 0, ao);
     }
 }
 
-// Weight gradients: kernels_wgrad.hip
-
-// =========================================================================================================
-// MHA block backward (a8, :167-190)
-//  k_attn_out_bwd : do = dy * m5 ; dh2 = do Wo ; dr = dy + LN2^T(dh2 * m4)
-//  k_attn_bwd_dq / k_attn_bwd_dkv : attention core (recompute P from Q, K and the saved LSE)
-//  k_qkv_bwd      : dh1 = [dQ|dK|dV] [Wq;Wk;Wv] ; dx = dr + LN1^T(dh1 * m1)
-// =========================================================================================================
-__global__ __launch_bounds__(256) void k_attn_out_bwd(const float* __restrict__ dy, const float* __restrict__ dy2,
-                                                      const float* __restrict__ r_in, const float* __restrict__ ln_g,
-                                                      const float* __restrict__ WTpack, float* __restrict__ g_o,
-                                                      float* __restrict__ dr, float* __restrict__ p_lng,
-                                                      float* __restrict__ p_lnb, int R, Drop d4, Drop d5) {
-    __shared__ __attribute__((aligned(16))) float Gs[TILE_M * LDP];
-    __shared__ __attribute__((aligned(16))) float Xs[TILE_M * LDP];
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const int r0 = blockIdx.x * TILE_M;
-    BFrag<1, 16> bf;
-    {
-        float4 a1[4], a2[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int e = tid + q * 256;
-            const int r = r0 + (e >> 5), c = (e & 31) * 4;
-            a1[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            a2[q] = a1[q];
-            if (r < R) {
-                a1[q] = *reinterpret_cast<const float4*>(dy + (size_t)r * D + c);
-                if (dy2) a2[q] = *reinterpret_cast<const float4*>(dy2 + (size_t)r * D + c);
-            }
-        }
-        bfrag_load(bf, WTpack, D, 32 * w, 0, 0, D / 8);     // after the tile (in-order return), before the LN input tile
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int e = tid + q * 256;
-            const int rr = e >> 5, c = (e & 31) * 4;
-            const int r = r0 + rr;
-            float4 v = make_float4(a1[q].x + a2[q].x, a1[q].y + a2[q].y, a1[q].z + a2[q].z, a1[q].w + a2[q].w);
-            if (r < R) {
-                if (d5.thresh) {
-                    const uint32_t base = (uint32_t)(r * D + c);
-                    v.x *= drop_mul(d5, base); v.y *= drop_mul(d5, base + 1);
-                    v.z *= drop_mul(d5, base + 2); v.w *= drop_mul(d5, base + 3);
-                }
-                *reinterpret_cast<float4*>(g_o + (size_t)r * D + c) = v;       // G operand of the out_layer weight gradient
-            }
-            *reinterpret_cast<float4*>(&Gs[rr * LDP + c]) = v;
-        }
-    }
-    LnResid lres;
-    ln_resid_prefetch(lres, dy, dy2, r0, R);                // residual path of LN2's backward (same rows again, L2 hits), used last
-    load_tile128(Xs, r_in, r0, TILE_M, R);                  // only needed by the LayerNorm backward after the GEMM
-    __syncthreads();
-    f32x16 acc[1];
-    zero_acc(acc);
-    gemm32p<1, 16>(Gs, LDP, D, WTpack, D, 32 * w, 0, acc, bf);
-    __syncthreads();
-    const int col = 32 * w + (lane & 31);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = acc_row(r, lane);
-        Gs[row * LDP + col] = acc[0][r] * drop_mul(d4, (uint32_t)((r0 + row) * D + col));
-    }
-    __syncthreads();
-    ln_bwd_tile(Gs, Xs, lres, ln_g, dr, p_lng, p_lnb, r0, R);
-}
-void launch_attn_out_bwd(const float* dy, const float* dy2, const float* r, const float* ln_g, const float* WTpack, float* g_o,
-                         float* dr, float* p_lng, float* p_lnb, int R, Drop d4, Drop d5, hipStream_t s) {
-    {
-        const size_t shm_sp = 0;
-        VSL_LAUNCH(k_attn_out_bwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm_sp, s, dy, dy2, r, ln_g, WTpack, g_o, dr, p_lng,
-                       p_lnb, R, d4, d5);
-    }
-}
 
 // Fused attention backward for Lp <= 128: ONE workgroup (16 waves) per (sample, head) computes S, P, dP and dS once.
 // Queries are processed in passes of 64 so that dS[64][keys] fits beside the head slices in < 80 KB of LDS: two workgroups

@@ -728,7 +728,7 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_fwd2(CbFwdArgs a) {
             float av = fmaxf(z, 0.f);
             if (DROP) {
                 uint32_t h = hb + (uint32_t)((16 * i + rr) * D) * 0x9E3779B1u;
-                h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= (h >> 13) ^ dp.key; h *= 0xC2B2AE35u; h ^= h >> 16;
+                h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= (h >> 13) ^ dp.key; h *= 0xC2B2AE35u;       // = drop_hash() with its first multiply-add hoisted (hb)
                 av = h >= dp.thresh ? av * dp.scale : 0.f;
             }
             xb[(16 * i + rr) * LDP] = xold[rr] + av;

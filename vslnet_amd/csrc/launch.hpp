@@ -197,7 +197,14 @@ void launch_loss(const float* sl, const float* el, const float* h, const int64_t
 void launch_extract_index(const float* sl, const float* el, int64_t* si, int64_t* ei, int B, int T, hipStream_t s);
 
 // ---------------------------------------------------------------- backward
-void launch_head_bwd(const HeadBwdArgs& a0, const HeadBwdArgs& a1, int R, hipStream_t s);
+// the attention-output backward of one encoder application (a8 :183-190 backward; kernels_bwd.hip attn_out_bwd_tile)
+struct AttnOutBwdArgs {
+    const float *dy, *dy2, *r_in, *ln_g, *WTpack;
+    float *g_o, *dr, *p_lng, *p_lnb;
+    Drop d4, d5;
+};
+// fuse != nullptr: the end head's workgroups continue with that attention-output backward on their own tile of dfeat (which is then NOT stored)
+void launch_head_bwd(const HeadBwdArgs& a0, const HeadBwdArgs& a1, int R, hipStream_t s, const AttnOutBwdArgs* fuse = nullptr);
 // a15 DynamicRNN (layers_t7.py:302-313): recurrent part of nn.LSTM(128, 128); the input projection x W_ih^T is a plain GEMM
 // (kernels_lstm.hip: one-sample workgroups for B <= 256, which read k_pack's register-order images of W_hh -- PackJob types 9 / 10 -- and
 // save tanh(c_t) in tseq; 4-sample MFMA groups beyond, which read W_hh itself)
