@@ -759,8 +759,11 @@ AttnOutBwdArgs attn_out_bwd_args(Ctx& c, const EncP& P, const EncPk& K, const En
     return a;
 }
 // attn_out_done: the attention-output backward of this application already ran (fused into the span heads' kernel: run_backward)
+// tail_ao / tail_cq: what the conv block's backward workgroups go on with on their tile of dx0 (CbBwdArgs::tail; the caller has checked
+// convblock_bwd_hosts_tail and skips that launch)
 void enc_bwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float* dy, const float* dy2, int64_t dx0_off,
-             const float* mask, int Bn, int app, hipStream_t sw, WgradBatch* defer_pw = nullptr, bool attn_out_done = false) {
+             const float* mask, int Bn, int app, hipStream_t sw, WgradBatch* defer_pw = nullptr, bool attn_out_done = false,
+             const AttnOutBwdArgs* tail_ao = nullptr, const CqcatBwdArgs* tail_cq = nullptr) {
     // sw: stream of the early (out_layer / q,k,v) weight gradients.  The pointwise-conv batch goes to `sw` too unless the
     // caller asks for it back (defer_pw) to launch it on its own stream WITHOUT a cross-stream wait (each costs ~16 us).
     float* dx0_out = c.dry ? nullptr : c.W(dx0_off);
@@ -815,6 +818,8 @@ void enc_bwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float*
             a.p_lnb[i] = c.slab(P.lnb[i], D, nsl);
             a.p_dw[i] = c.slab(P.dw[i], D * DWK, nsl);
         }
+        if (tail_ao) { a.tail = 1; a.tail_ao = *tail_ao; }
+        if (tail_cq) { a.tail = 2; a.tail_cq = *tail_cq; }
         if (!c.dry) {
             a.dy = g; a.dx0 = dx0_out; a.R = R; a.L = L;
             for (int i = 0; i < 4; ++i) {
@@ -859,6 +864,9 @@ void run_backward(Ctx& c) {
     hipStream_t sw = c.dry ? nullptr : c.side(1), sq = c.dry ? nullptr : c.side(0);
     auto on_stream = [&](hipStream_t st, auto&& fn) { hipStream_t keep = c.s; c.order(keep, st); c.s = st; fn(); c.s = keep; };
     c.defer_w = !c.dry && cf.predictor == 1;
+    bool hosted = false;                    // transformer head on whole tiles: two launches ride inside the conv block's backward kernels (below)
+    float *p_hlw = nullptr, *p_hlb = nullptr;
+    CqcatBwdArgs cqa;
     // ---- span heads
     HeadBwdArgs hs, he;
     memset(&hs, 0, sizeof hs);
@@ -981,17 +989,31 @@ void run_backward(Ctx& c) {
         }
     } else {
     // ---- predictor encoder, second pass (input = output of the first pass), then first pass
-    enc_bwd(c, P.pe, K.pe, p.p2, c.dry ? nullptr : c.W(p.dfeat_e), nullptr, p.g_s1, c.dry ? nullptr : io->v_mask, B, 3, sw, nullptr, true);
+    // tile-local continuations inside the conv block's backward kernel (whole tiles): pass 2's conv block goes on with pass 1's attention-output
+    // backward (dy = its dx0 + the start head's LayerNorm path), pass 1's with the CQConcatenate backward (dg0 = its dx0)
+    hosted = convblock_bwd_hosts_tail(R, T);
+    AttnOutBwdArgs ao1;
+    if (hosted) ao1 = attn_out_bwd_args(c, P.pe, K.pe, p.p1, nullptr, c.dry ? nullptr : c.W(p.dfeat_s), 2);
+    enc_bwd(c, P.pe, K.pe, p.p2, c.dry ? nullptr : c.W(p.dfeat_e), nullptr, p.g_s1, c.dry ? nullptr : io->v_mask, B, 3, sw, nullptr, true,
+            hosted ? &ao1 : nullptr);
     wgrad_flush(c, sw);   // span heads + pass-2 weight gradients: one ordering point
     // grad wrt the first pass' output = (input grad of the second pass) + (LayerNorm path of the start head)
+    if (hosted) {
+        p_hlw = c.slab(P.hl_w, D, ntiles);
+        p_hlb = c.slab(P.hl_b, 1, ntiles);
+        memset(&cqa, 0, sizeof cqa);
+        if (!c.dry) cqa = CqcatBwdArgs{nullptr, c.W(p.dxh_s), c.W(p.dxh_e), io->d_h_score, c.W(p.f2), io->h_score, c.P(P.hl_w), c.PK(K.cat1_t), c.W(p.df2), c.W(p.df1), p_hlw, p_hlb};
+    }
     enc_bwd(c, P.pe, K.pe, p.p1, c.dry ? nullptr : c.W(p.g_s1), c.dry ? nullptr : c.W(p.dfeat_s), p.g_gated,
-            c.dry ? nullptr : io->v_mask, B, 2, sw);
+            c.dry ? nullptr : io->v_mask, B, 2, sw, nullptr, hosted, nullptr, hosted ? &cqa : nullptr);
     }
     // ---- gating + highlight + CQConcatenate
-    float* p_hlw = c.slab(P.hl_w, D, ntiles);
-    float* p_hlb = c.slab(P.hl_b, 1, ntiles);
-    LAUNCH("cqcat_bwd", launch_cqcat_bwd(c.W(p.g_gated), c.W(p.dxh_s), c.W(p.dxh_e), io->d_h_score, c.W(p.f2), io->h_score, c.P(P.hl_w),
-                            c.PK(K.cat1_t), c.W(p.df2), c.W(p.df1), p_hlw, p_hlb, R, c.s));
+    if (!hosted) {
+        p_hlw = c.slab(P.hl_w, D, ntiles);
+        p_hlb = c.slab(P.hl_b, 1, ntiles);
+        LAUNCH("cqcat_bwd", launch_cqcat_bwd(c.W(p.g_gated), c.W(p.dxh_s), c.W(p.dxh_e), io->d_h_score, c.W(p.f2), io->h_score, c.P(P.hl_w),
+                                c.PK(K.cat1_t), c.W(p.df2), c.W(p.df1), p_hlw, p_hlb, R, c.s));
+    }
     {
         WgradBatch wb;
         memset(&wb, 0, sizeof wb);

@@ -638,12 +638,13 @@ __device__ __forceinline__ void ln_resid_prefetch(LnResid& rs, const float* __re
         rs.v[j] = make_float4(a.x * keep, a.y * keep, a.z * keep, a.w * keep);
     }
 }
+// active = false: a thread of a wider workgroup that only joins the barrier (tile bodies hosted by a 512-thread kernel: tile_bodies.hpp)
 __device__ __forceinline__ void ln_bwd_tile(float* Ts, float* Xs, const LnResid& pre, const float* __restrict__ ln_g,
                                             float* __restrict__ out, float* __restrict__ p_lng, float* __restrict__ p_lnb,
-                                            int r0, int R, float* lds_out = nullptr) {
+                                            int r0, int R, float* lds_out = nullptr, bool active = true) {
     const int tid = threadIdx.x, sub = tid & 7, rr = tid >> 3;
     const int r = r0 + rr;
-    {
+    if (active) {
         float* xr = Xs + rr * LDP + sub * 4;
         const float* tr = Ts + rr * LDP + sub * 4;
         float4 x[4], dy[4], rs[4];
@@ -688,7 +689,7 @@ __device__ __forceinline__ void ln_bwd_tile(float* Ts, float* Xs, const LnResid&
         }
     }
     __syncthreads();
-    {
+    if (active) {
         const int c = tid & 127;
         const float* src = tid < 128 ? Xs : Ts;
         float acc = 0.f;

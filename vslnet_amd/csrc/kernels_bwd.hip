@@ -4,6 +4,7 @@
 // k_reduce into the flat gradient bucket (deterministic, no float atomics on global memory).
 #include "common.hpp"
 #include "launch.hpp"
+#include "tile_bodies.hpp"
 #include <type_traits>
 #include <algorithm>
 
@@ -280,65 +281,6 @@ void launch_extract_index(const float* sl, const float* el, int64_t* si, int64_t
 //  k_attn_bwd_dq / k_attn_bwd_dkv : attention core (recompute P from Q, K and the saved LSE)
 //  k_qkv_bwd      : dh1 = [dQ|dK|dV] [Wq;Wk;Wv] ; dx = dr + LN1^T(dh1 * m1)
 // =========================================================================================================
-// one 32-row tile.  lds_dy != nullptr: the incoming gradient tile is already in LDS (stride LDP, rows >= R zero; dy2 is then ignored) -- the
-// fused caller (k_head_bwd) hands over what it has just computed.  Gs / Xs: two [32][LDP] tiles, neither of them lds_dy.
-__device__ __forceinline__ void attn_out_bwd_tile(const AttnOutBwdArgs& a, const float* lds_dy, float* Gs, float* Xs, int r0, int R) {
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    BFrag<1, 16> bf;
-    LnResid lres;
-    {
-        float4 a1[4], a2[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int e = tid + q * 256;
-            const int r = r0 + (e >> 5), c = (e & 31) * 4;
-            a1[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            a2[q] = a1[q];
-            if (lds_dy) a1[q] = *reinterpret_cast<const float4*>(lds_dy + (e >> 5) * LDP + c);
-            else if (r < R) {
-                a1[q] = *reinterpret_cast<const float4*>(a.dy + (size_t)r * D + c);
-                if (a.dy2) a2[q] = *reinterpret_cast<const float4*>(a.dy2 + (size_t)r * D + c);
-            }
-        }
-        bfrag_load(bf, a.WTpack, D, 32 * w, 0, 0, D / 8);     // after the tile (in-order return), before the LN input tile
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int e = tid + q * 256;
-            const int rr = e >> 5, c = (e & 31) * 4;
-            const int r = r0 + rr;
-            float4 v = make_float4(a1[q].x + a2[q].x, a1[q].y + a2[q].y, a1[q].z + a2[q].z, a1[q].w + a2[q].w);
-            if (r < R) {
-                if (a.d5.thresh) {
-                    const uint32_t base = (uint32_t)(r * D + c);
-                    v.x *= drop_mul(a.d5, base); v.y *= drop_mul(a.d5, base + 1);
-                    v.z *= drop_mul(a.d5, base + 2); v.w *= drop_mul(a.d5, base + 3);
-                }
-                *reinterpret_cast<float4*>(a.g_o + (size_t)r * D + c) = v;       // G operand of the out_layer weight gradient
-            }
-            *reinterpret_cast<float4*>(&Gs[rr * LDP + c]) = v;
-        }
-    }
-    // residual path of LN2's backward: the same rows again (L2 hits, or the LDS tile), used last
-    if (lds_dy) {
-        const int sub = tid & 7, rr = tid >> 3;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) lres.v[j] = *reinterpret_cast<const float4*>(lds_dy + rr * LDP + sub * 4 + 32 * j);
-    } else ln_resid_prefetch(lres, a.dy, a.dy2, r0, R);
-    load_tile128(Xs, a.r_in, r0, TILE_M, R);                  // only needed by the LayerNorm backward after the GEMM
-    __syncthreads();
-    f32x16 acc[1];
-    zero_acc(acc);
-    gemm32p<1, 16>(Gs, LDP, D, a.WTpack, D, 32 * w, 0, acc, bf);
-    __syncthreads();
-    const int col = 32 * w + (lane & 31);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = acc_row(r, lane);
-        Gs[row * LDP + col] = acc[0][r] * drop_mul(a.d4, (uint32_t)((r0 + row) * D + col));
-    }
-    __syncthreads();
-    ln_bwd_tile(Gs, Xs, lres, a.ln_g, a.dr, a.p_lng, a.p_lnb, r0, R);
-}
 __global__ __launch_bounds__(256) void k_attn_out_bwd(AttnOutBwdArgs a, int R) {
     __shared__ __attribute__((aligned(16))) float Gs[TILE_M * LDP];
     __shared__ __attribute__((aligned(16))) float Xs[TILE_M * LDP];
@@ -803,105 +745,19 @@ void launch_attn_bwd(const float* Q, const float* K, const float* V, const float
 // a11 + a12 backward: gated = f2 * h ; h = sigmoid(mask_logits(f2 . wh + bh)) ; f2 = f1 W1^T + pb[b]
 //   dgated = dg0 + dg1 + dg2 (two heads + predictor encoder input) ; dh_loss from the highlight loss.
 // =========================================================================================================
-__global__ __launch_bounds__(256) void k_cqcat_bwd(const float* __restrict__ dg0, const float* __restrict__ dg1,
-                                                   const float* __restrict__ dg2, const float* __restrict__ dh_loss,
-                                                   const float* __restrict__ f2, const float* __restrict__ hscore,
-                                                   const float* __restrict__ wh, const float* __restrict__ W1Tpack,
-                                                   float* __restrict__ df2, float* __restrict__ df1,
-                                                   float* __restrict__ p_wh, float* __restrict__ p_bh, int R) {
+__global__ __launch_bounds__(256) void k_cqcat_bwd(CqcatBwdArgs a, int R) {
     __shared__ __attribute__((aligned(16))) float Gs[TILE_M * LDP];     // dgated -> df2
     __shared__ __attribute__((aligned(16))) float Fs[TILE_M * LDP];     // f2
     __shared__ float dlg[TILE_M];
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const int r0 = blockIdx.x * TILE_M;
-    {
-        float4 g0[4], g1[4], g2[4], fv[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int e = tid + q * 256;
-            const int r = r0 + (e >> 5), c = (e & 31) * 4;
-            g0[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            g1[q] = g0[q]; g2[q] = g0[q]; fv[q] = g0[q];
-            if (r < R) {
-                g0[q] = *reinterpret_cast<const float4*>(dg0 + (size_t)r * D + c);
-                if (dg1) g1[q] = *reinterpret_cast<const float4*>(dg1 + (size_t)r * D + c);
-                if (dg2) g2[q] = *reinterpret_cast<const float4*>(dg2 + (size_t)r * D + c);
-                fv[q] = *reinterpret_cast<const float4*>(f2 + (size_t)r * D + c);
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int e = tid + q * 256;
-            const int rr = e >> 5, c = (e & 31) * 4;
-            *reinterpret_cast<float4*>(&Gs[rr * LDP + c]) = make_float4(g0[q].x + g1[q].x + g2[q].x, g0[q].y + g1[q].y + g2[q].y,
-                                                                       g0[q].z + g1[q].z + g2[q].z, g0[q].w + g1[q].w + g2[q].w);
-            *reinterpret_cast<float4*>(&Fs[rr * LDP + c]) = fv[q];
-        }
-    }
-    __syncthreads();
-    {
-        const int rr = tid >> 3, sub = tid & 7;
-        const int r = r0 + rr;
-        float* grow = Gs + rr * LDP + sub * 4;
-        const float* frow = Fs + rr * LDP + sub * 4;
-        float4 g4[4];
-        float d = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            g4[j] = *reinterpret_cast<const float4*>(grow + 32 * j);
-            const float4 f4 = *reinterpret_cast<const float4*>(frow + 32 * j);
-            d += g4[j].x * f4.x + g4[j].y * f4.y + g4[j].z * f4.z + g4[j].w * f4.w;
-        }
-        d = grp8_sum(d);
-        float hv = 0.f, dl = 0.f;
-        if (r < R) {
-            hv = hscore[r];
-            dl = (d + (dh_loss ? dh_loss[r] : 0.f)) * hv * (1.f - hv);      // sigmoid backward; mask_logits is additive
-        }
-        // df2 = dgated * h + dlogit * wh
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float4 wv = *reinterpret_cast<const float4*>(wh + sub * 4 + 32 * j);
-            *reinterpret_cast<float4*>(grow + 32 * j) = make_float4(g4[j].x * hv + dl * wv.x, g4[j].y * hv + dl * wv.y,
-                                                                    g4[j].z * hv + dl * wv.z, g4[j].w * hv + dl * wv.w);
-        }
-        if (sub == 0) dlg[rr] = dl;
-    }
-    __syncthreads();
-    if (tid < 128) {
-        float acc = 0.f;
-        for (int rr = 0; rr < TILE_M; ++rr) acc += dlg[rr] * Fs[rr * LDP + tid];
-        p_wh[(size_t)blockIdx.x * D + tid] = acc;
-    } else if (tid == 128) {
-        float acc = 0.f;
-        for (int rr = 0; rr < TILE_M; ++rr) acc += dlg[rr];
-        p_bh[blockIdx.x] = acc;
-    }
-    for (int e = tid; e < TILE_M * 32; e += 256) {
-        const int rr = e >> 5, c = (e & 31) * 4;
-        if (r0 + rr < R) *reinterpret_cast<float4*>(df2 + (size_t)(r0 + rr) * D + c) = *reinterpret_cast<const float4*>(&Gs[rr * LDP + c]);
-    }
-    f32x16 acc[1];
-    zero_acc(acc);
-    {
-        BFrag<1, 16> bf;
-        bfrag_load(bf, W1Tpack, D, 32 * w, 0, 0, D / 8);
-        gemm32p<1, 16>(Gs, LDP, D, W1Tpack, D, 32 * w, 0, acc, bf);
-    }
-    const int col = 32 * w + (lane & 31);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int gr = r0 + acc_row(r, lane);
-        if (gr < R) df1[(size_t)gr * D + col] = acc[0][r];
-    }
+    cqcat_bwd_tile(a, nullptr, Gs, Fs, dlg, blockIdx.x * TILE_M, R);
 }
 void launch_cqcat_bwd(const float* dg0, const float* dg1, const float* dg2, const float* dh_loss, const float* f2,
                       const float* hscore, const float* wh, const float* W1Tpack, float* df2, float* df1, float* p_wh,
                       float* p_bh, int R, hipStream_t s) {
     {
         const size_t shm_sp = 0;
-        VSL_LAUNCH(k_cqcat_bwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm_sp, s, dg0, dg1, dg2, dh_loss, f2, hscore, wh,
-                       W1Tpack, df2, df1, p_wh, p_bh, R);
+        const CqcatBwdArgs a{dg0, dg1, dg2, dh_loss, f2, hscore, wh, W1Tpack, df2, df1, p_wh, p_bh};
+        VSL_LAUNCH(k_cqcat_bwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm_sp, s, a, R);
     }
 }
 

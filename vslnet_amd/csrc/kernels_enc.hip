@@ -15,6 +15,7 @@
 // registers per lane) is fetched by exactly one wave, straight from the packed layout of common.hpp, one layer ahead.
 #include "common.hpp"
 #include "launch.hpp"
+#include "tile_bodies.hpp"
 #include <type_traits>
 
 namespace vsl {
@@ -932,7 +933,9 @@ void launch_convblock_fwd(const CbFwdArgs& a, hipStream_t s) {
 // =========================================================================================================
 // du = dz Wp on the bf16 matrix cores at fp32 grade (gemm16s): phase A stores dz as three bf16 planes, which share their LDS with dv
 // (GU) -- dz is dead before phase C writes dv, but the next layer's phase A overwrites what phase D still reads: one more barrier per layer.
-template <int SH, bool FULL>        // SH 3: row tiles with a recomputed halo ; 0: sample tiles for L <= 32 ; FULL: see k_convblock_fwd
+// TAIL (whole tiles only): the workgroup goes on with a row-tile kernel's body on its 32 rows of dx0 (tile_bodies.hpp): 1 = attention-output
+// backward of the encoder pass below, 2 = CQConcatenate backward.  Waves 0-3 work, the others join the barriers.
+template <int SH, bool FULL, int TAIL = 0>        // SH 3: row tiles with a recomputed halo ; 0: sample tiles for L <= 32 ; FULL: see k_convblock_fwd
 __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
     constexpr int HL = 4 * SH, NW = TILE_M + 2 * HL, VUR = SH ? NW + 12 : NW, XR = NW - 2 * SH;
     constexpr int ZPS = NW * CB_LDB;                     // elements between the dz planes
@@ -1209,8 +1212,8 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
                     float4 o;
                     o.x = dy.x + rstd * (gd[j].x - m1 - xh[j].x * m2); o.y = dy.y + rstd * (gd[j].y - m1 - xh[j].y * m2);
                     o.z = dy.z + rstd * (gd[j].z - m1 - xh[j].z * m2); o.w = dy.w + rstd * (gd[j].w - m1 - xh[j].w * m2);
-                    if (l > 0) *reinterpret_cast<float4*>(dyr + 32 * j) = o;
-                    else if (row_ok(wr)) *reinterpret_cast<float4*>(a.dx0 + (size_t)(rw0 + wr) * D + sub * 4 + 32 * j) = o;
+                    if (l > 0 || TAIL) *reinterpret_cast<float4*>(dyr + 32 * j) = o;       // (TAIL: the owner rows of dx0 stay in LDS for the body that follows)
+                    if (l == 0 && row_ok(wr)) *reinterpret_cast<float4*>(a.dx0 + (size_t)(rw0 + wr) * D + sub * 4 + 32 * j) = o;
                 }
             }
         }
@@ -1227,25 +1230,36 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
     ESTAMP(4);
     layer(std::integral_constant<int, 0>(), b3B, b3A);
     ESTAMP(5);
+    if constexpr (TAIL != 0) {
+        static_assert(FULL && SH == 3, "tails ride on whole tiles");
+        __syncthreads();                                   // dx0's owner rows are in DY; every other LDS region is free
+        const bool active = tid < 256;
+        if constexpr (TAIL == 1) attn_out_bwd_tile(a.tail_ao, DY + HL * LDP, GU, DU, r0, R, active);
+        else cqcat_bwd_tile(a.tail_cq, DY + HL * LDP, GU, DU, RS, r0, R, active);
+    }
 }
 constexpr size_t cb_bwd_lds_split(int sh) {
     const int nw = TILE_M + 8 * sh, vur = sh ? nw + 12 : nw, zf = 3 * nw * CB_LDB / 2, guf = zf > vur * LDP ? zf : vur * LDP;
     return (size_t)((nw + vur + TILE_M + 6 * sh) * LDP + guf + 64 + 64 + 256) * sizeof(float);
 }
-template <int SH, bool FULL>
+template <int SH, bool FULL, int TAIL = 0>
 static void launch_cbb(const CbBwdArgs& a, int grid, hipStream_t s) {
     static size_t ok = 0;
     const size_t lds = cb_bwd_lds_split(SH);
-    ensure_dynamic_lds((const void*)k_convblock_bwd<SH, FULL>, lds, ok, "k_convblock_bwd");
-    VSL_LAUNCH((k_convblock_bwd<SH, FULL>), dim3(grid), dim3(CB_T), lds, s, a);
+    ensure_dynamic_lds((const void*)k_convblock_bwd<SH, FULL, TAIL>, lds, ok, "k_convblock_bwd");
+    VSL_LAUNCH((k_convblock_bwd<SH, FULL, TAIL>), dim3(grid), dim3(CB_T), lds, s, a);
 }
+bool convblock_bwd_hosts_tail(int R, int L) { return L > TILE_M && R % TILE_M == 0 && L % TILE_M == 0; }
 void launch_convblock_bwd(const CbBwdArgs& a, hipStream_t s) {
     if (a.L <= TILE_M) {                    // sample tiles: one workgroup per sample (partial slabs per SAMPLE: convblock_slabs())
         launch_cbb<0, false>(a, a.R / a.L, s);
         return;
     }
-    if (a.R % TILE_M == 0 && a.L % TILE_M == 0) launch_cbb<3, true>(a, a.R / TILE_M, s);
-    else launch_cbb<3, false>(a, (a.R + TILE_M - 1) / TILE_M, s);
+    if (a.R % TILE_M == 0 && a.L % TILE_M == 0) {
+        if (a.tail == 1) launch_cbb<3, true, 1>(a, a.R / TILE_M, s);
+        else if (a.tail == 2) launch_cbb<3, true, 2>(a, a.R / TILE_M, s);
+        else launch_cbb<3, true>(a, a.R / TILE_M, s);
+    } else launch_cbb<3, false>(a, (a.R + TILE_M - 1) / TILE_M, s);
     static int left = 6;
     if (edbg_on() && a.R > 4096) edbg_report("convblock_bwd: load | L3 | L2 | L1 | L0", 6, s, left);
 }

@@ -150,6 +150,17 @@ struct CbFwdArgs {
     int R, L;
 };
 void launch_convblock_fwd(const CbFwdArgs& a, hipStream_t s);
+// the attention-output backward of one encoder application (a8 :183-190 backward; kernels_bwd.hip attn_out_bwd_tile)
+struct AttnOutBwdArgs {
+    const float *dy, *dy2, *r_in, *ln_g, *WTpack;
+    float *g_o, *dr, *p_lng, *p_lnb;
+    Drop d4, d5;
+};
+// gating + HighLightLayer + CQConcatenate backward of one 32-row tile (kernels_bwd.hip k_cqcat_bwd / tile_bodies.hpp cqcat_bwd_tile)
+struct CqcatBwdArgs {
+    const float *dg0, *dg1, *dg2, *dh_loss, *f2, *hscore, *wh, *W1Tpack;
+    float *df2, *df1, *p_wh, *p_bh;
+};
 struct CbBwdArgs {
     const uint16_t* WT3[4];        // split packs (PackJob type 7) of the pointwise weights' data-gradient operand
     const float* dy;               // (R,128) grad wrt the block output
@@ -161,8 +172,14 @@ struct CbBwdArgs {
     float* dx0;                    // out (R,128): grad wrt the block input (x + pos)
     float *p_lng[4], *p_lnb[4], *p_dw[4];   // partial slabs [ntiles][128] / [ntiles][128 * 7]
     int R, L;
+    // what the workgroup goes on with, on its own 32 rows of dx0 (whole-tile instantiation only: convblock_bwd_hosts_tail):
+    // 0 nothing ; 1 the attention-output backward of the encoder pass below (tail_ao; its dy = dx0) ; 2 the CQConcatenate backward (tail_cq; its dg0 = dx0)
+    int tail;
+    AttnOutBwdArgs tail_ao;
+    CqcatBwdArgs tail_cq;
 };
 void launch_convblock_bwd(const CbBwdArgs& a, hipStream_t s);
+bool convblock_bwd_hosts_tail(int R, int L);      // does launch_convblock_bwd honour CbBwdArgs::tail for this shape?
 int convblock_slabs(int R, int L);        // partial slabs per parameter of launch_convblock_bwd (= its grid)
 void launch_attn_fwd(const float* Q, const float* K, const float* V, const float* mask, float* att, float* lse, int B,
                      int L, int H, int b_off, Drop d2, hipStream_t s);
@@ -197,12 +214,6 @@ void launch_loss(const float* sl, const float* el, const float* h, const int64_t
 void launch_extract_index(const float* sl, const float* el, int64_t* si, int64_t* ei, int B, int T, hipStream_t s);
 
 // ---------------------------------------------------------------- backward
-// the attention-output backward of one encoder application (a8 :183-190 backward; kernels_bwd.hip attn_out_bwd_tile)
-struct AttnOutBwdArgs {
-    const float *dy, *dy2, *r_in, *ln_g, *WTpack;
-    float *g_o, *dr, *p_lng, *p_lnb;
-    Drop d4, d5;
-};
 // fuse != nullptr: the end head's workgroups continue with that attention-output backward on their own tile of dfeat (which is then NOT stored)
 void launch_head_bwd(const HeadBwdArgs& a0, const HeadBwdArgs& a1, int R, hipStream_t s, const AttnOutBwdArgs* fuse = nullptr);
 // a15 DynamicRNN (layers_t7.py:302-313): recurrent part of nn.LSTM(128, 128); the input projection x W_ih^T is a plain GEMM
