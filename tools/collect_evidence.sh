@@ -1,9 +1,9 @@
 #!/bin/bash
 # One gpurun call: kernel-trace stats, the PMC passes (each in its own run, as MI355X_MICROARCH.md prescribes), the profile json
 # bench.py quotes as the static half of its roofline object, then the final bench line and the HIP-event table.
-# usage (on the GPU box, from the repo root): bash tools/collect_evidence.sh r04_a
+# usage (on the GPU box, from the repo root): bash tools/collect_evidence.sh r05_a
 set -u
-TAG=${1:-r04_a}
+TAG=${1:-r05_a}
 R=$PWD
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -21,7 +21,7 @@ python tools/rocpd_pmc.py $FDB > $O/${TAG}_pmc_fetch_size.txt
 python tools/rocpd_pmc.py $WDB > $O/${TAG}_pmc_write_size.txt
 python tools/rocpd_mfma.py $(find $O/mfma -name "*.db" | head -1) > $O/${TAG}_pmc_mfma_busy.txt
 python tools/make_profile_json.py $SDB $FDB $WDB $O/${TAG}_profile.json $TAG
-cp $O/${TAG}_profile.json profiles/r04_profile.json
+cp $O/${TAG}_profile.json profiles/r05_profile.json
 python bench.py > $O/${TAG}_bench.json 2> $O/bench.err
 python bench.py --steps 30 --warmup 10 --no-cpu-baseline --profile-all 2> $O/${TAG}_hip_event_table.txt > /dev/null
 python bench.py --steps 30 --warmup 10 --no-cpu-baseline --dtype bf16 > $O/${TAG}_bench_bf16_mode.json 2>/dev/null

@@ -124,6 +124,12 @@ __device__ __forceinline__ void b3_load(B3& f, const uint16_t* __restrict__ W3, 
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) f.b[t][ks] = *reinterpret_cast<const u32x4_t*>(p + t * plane + (size_t)(2 * ks) * ncols * 16);
 }
+// one 16-byte load of the slice: lets a caller spread a prefetch over a phase instead of issuing twelve loads at once
+__device__ __forceinline__ void b3_load_one(B3& f, const uint16_t* __restrict__ W3, int K, int ncols, int col0, int t, int ks) {
+    const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+    const uint16_t* p = W3 + ((size_t)(g >> 1) * ncols + col0 + j) * 16 + 8 * (g & 1);
+    f.b[t][ks] = *reinterpret_cast<const u32x4_t*>(p + t * pack3_plane(K, ncols) + (size_t)(2 * ks) * ncols * 16);
+}
 // acc[rb] (16 x 16) += A[16 rb + 0..15][0..127] * B ; Ah = plane h at the block range's first row, `ps` = elements between planes
 template <int NRB>
 __device__ __forceinline__ void gemm16s(const uint16_t* __restrict__ Ah, int ps, const B3& bf, f32x4 (&acc)[1][NRB]) {
@@ -969,25 +975,27 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
     ESTAMP(0);
     float4 xv[4];
     uint32_t mw[4];
+    // Global traffic as in k_convblock_fwd2: raw buffer instructions that EVERY wave executes, rows that do not exist / are not to be stored get
+    // an out-of-range offset (zeros / dropped).  With loads or stores inside divergent branches the compiler cannot count what is outstanding and
+    // every wait for a prefetched operand becomes vmcnt(0) -- i.e. a wait for the acknowledgement of the stores issued a moment ago.
+    const uint32_t rbytes = (uint32_t)R * (D * 4);
+    const bool rin = row_in(r8);
+    const uint32_t rowoff = rin ? (uint32_t)(((rw0 + r8) * D + sub * 4) * 4) : BUF_OOB;       // this thread's row in an (R, 128) tensor
+    auto fetch_part = [&](int l, int q) {   // one quarter of fetch_layer
+        const brsrc_t rx = buf_rsrc(a.x[l], rbytes), rm = buf_rsrc(a.relu_mask[l], (uint32_t)R * 16);
+        const uint32_t mo = rin ? (uint32_t)((rw0 + r8) * 16) : BUF_OOB;
+        xv[q] = buf_load4(rx, rowoff + 128 * q);
+        mw[q] = __builtin_amdgcn_raw_buffer_load_b32(rm, mo + 4 * q, 0, 0);
+    };
     auto fetch_layer = [&](int l) {         // x_l rows and ReLU words of the window, for phase A of layer l
-        const int r = rw0 + r8;
-        const bool ok = row_in(r8);
-        const size_t rc = (size_t)min(max(r, 0), R - 1);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 v = *reinterpret_cast<const float4*>(a.x[l] + rc * D + sub * 4 + 32 * q);
-            const uint32_t m = a.relu_mask[l][rc * 4 + q];
-            xv[q] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-            mw[q] = ok ? m : 0u;
-        }
+        for (int q = 0; q < 4; ++q) fetch_part(l, q);
     };
     {
         float4 dv[4];
+        const brsrc_t rdy = buf_rsrc(a.dy, rbytes);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            dv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row_in(r8)) dv[q] = *reinterpret_cast<const float4*>(a.dy + (size_t)(rw0 + r8) * D + sub * 4 + 32 * q);
-        }
+        for (int q = 0; q < 4; ++q) dv[q] = buf_load4(rdy, rowoff + 128 * q);
         fetch_layer(3);
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -999,7 +1007,7 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
 #pragma unroll
     for (int k = 0; k < DWK; ++k) wk[k] = a.dw_w[3][cc * DWK + k];
     gc = a.ln_g[3][cc]; bc = a.ln_b[3][cc];
-    if (tid < D) gnext = a.ln_g[3][tid];
+    gnext = a.ln_g[3][tid & (D - 1)];
     if (tid < 64) {
         VF[tid] = (one_owner ? (tid >= klo && tid < khi) : row_in(tid)) ? 1.f : 0.f;
     }
@@ -1014,12 +1022,36 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
         constexpr int nD = n - 2 * SH;                                // rows of phases C / D: [ra + SH, rb_ - SH)
         constexpr int NHL = SH * l, HQ = (NHL + 1) / 2;               // halo rows per side in phase C, per thread
         const Drop dp = a.dp[l];
+        // Prefetch of the layer below as 16 units (12 weight-slice loads, 4 x (x row quarter + ReLU word)) that are issued ONE AT A TIME between
+        // pieces of this layer's work: 128 KB per workgroup and layer arrive at ~26 bytes per cycle and CU (5 k cycles), and a wave that
+        // issues its twenty loads together sits at the full request queue for that long (profiles/r05_notes.md: without the prefetch a layer
+        // is 5 k cycles shorter wherever the block of loads is placed).
+        constexpr bool SPREAD = FULL && l > 0;        // (the other instantiations issue the prefetch in one piece at the end of phase C)
+        auto preB = [&](auto IC) {                    // weight-slice load IC of 12
+            constexpr int I = decltype(IC)::value;
+            if constexpr (SPREAD) {
+                __builtin_amdgcn_sched_barrier(0);
+                b3_load_one(nxt, a.WT3[l > 0 ? l - 1 : 0], D, D, 16 * w, I % 3, I / 3);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        auto preF = [&](auto IC) {                    // quarter IC of the x_(l-1) row + ReLU words (xv / mw are free once phase A is through)
+            if constexpr (SPREAD) {
+                __builtin_amdgcn_sched_barrier(0);
+                fetch_part(l > 0 ? l - 1 : 0, decltype(IC)::value);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
         // ---- A: dz = dy * relu-bit * dropout -> GU (+ gz on the owner rows) ; x_l -> Xh ; gamma -> GB
+        {
+            const bool inA = r8 >= ra && r8 < rb_;
+            const int wr = r8, wrc = inA ? r8 : ra;                    // (idle threads compute on row ra and discard)
+            const brsrc_t rgz = buf_rsrc(a.gz[l], rbytes);
+            const uint32_t gzo = (inA && wr >= HL && wr < HL + TILE_M && row_ok(wr)) ? rowoff : BUF_OOB;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int wr = r8, c4 = sub * 4 + 32 * q;
-            if (wr >= ra && wr < rb_) {
-                float4 v = *reinterpret_cast<const float4*>(&DY[wr * LDP + c4]);
+            for (int q = 0; q < 4; ++q) {
+                const int c4 = sub * 4 + 32 * q;
+                float4 v = *reinterpret_cast<const float4*>(&DY[wrc * LDP + c4]);
                 const uint32_t bits = mw[q] >> (c4 & 31);
                 float m[4] = {1.f, 1.f, 1.f, 1.f};
                 if (dp.thresh) {
@@ -1031,7 +1063,7 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
                 v.y = (bits & 2u) ? v.y * m[1] : 0.f;
                 v.z = (bits & 4u) ? v.z * m[2] : 0.f;
                 v.w = (bits & 8u) ? v.w * m[3] : 0.f;
-                {
+                if (inA) {
                     uint32_t h0, m0, l0, h1, m1, l1;
                     split3(v.x, v.y, h0, m0, l0);
                     split3(v.z, v.w, h1, m1, l1);
@@ -1040,14 +1072,18 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
                     *reinterpret_cast<u32x2_t*>(d + ZPS) = u32x2_t{m0, m1};
                     *reinterpret_cast<u32x2_t*>(d + 2 * ZPS) = u32x2_t{l0, l1};
                 }
-                if (wr >= HL && wr < HL + TILE_M && row_ok(wr))
-                    *reinterpret_cast<float4*>(a.gz[l] + (size_t)(rw0 + wr) * D + c4) = v;
+                buf_store4(rgz, gzo + 128 * q, v);                     // owner rows: G operand of the pointwise weight gradient
+                if (wr >= xlo && wr < NW - xlo) *reinterpret_cast<float4*>(&Xh[(wr - SH) * LDP + c4]) = xv[q];
+                if (q == 0) preB(std::integral_constant<int, 0>()); else if (q == 1) preB(std::integral_constant<int, 1>());
+                else if (q == 2) preB(std::integral_constant<int, 2>()); else preB(std::integral_constant<int, 3>());
             }
-            if (wr >= xlo && wr < NW - xlo) *reinterpret_cast<float4*>(&Xh[(wr - SH) * LDP + c4]) = xv[q];
         }
         float* GBl = GB + (l & 1) * D;
         if (tid < D) GBl[tid] = gnext;
+        if (l == 3) ESTAMP(8);
         __syncthreads();
+        if (l == 3) ESTAMP(9);
+        preB(std::integral_constant<int, 4>());
         // ---- x_l -> xhat in place, rstd per row (8 lanes per row)
         {
             if (r8 >= xlo && r8 < NW - xlo) {
@@ -1070,11 +1106,16 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
                 if (sub == 0) RS[r8] = rstd;
             }
         }
+        preF(std::integral_constant<int, 0>());
+        if (l == 3) ESTAMP(10);
+        preB(std::integral_constant<int, 5>());
         // ---- B: du = dz Wp
         f32x4 acc[1][NRB];
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) acc[0][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
         gemm16s<NRB>(Pz + ra * CB_LDB, ZPS, cur, acc);
+        if (l == 3) ESTAMP(11);
+        preF(std::integral_constant<int, 1>());
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
@@ -1082,7 +1123,10 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
                 const int row = ra + 16 * rb + g4 + rr;
                 DU[row * LDP + col] = acc[0][rb][rr] * VF[min(row, 63)];    // rows of another sample: zero padding of this one's conv
             }
+        preB(std::integral_constant<int, 6>());
+        if (l == 3) ESTAMP(12);
         __syncthreads();
+        if (l == 3) ESTAMP(13);
         // ---- C: dv = depthwise^T(du) ; partial sums over the owner rows
         float dvo[8], dvh[HQ > 0 ? HQ : 1];
         float gw[DWK], slb = 0.f, slg = 0.f;
@@ -1103,8 +1147,8 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
                 if (j >= 3 && j < 11) xc[j - 3] = xh;
             }
             if (plain) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
+                static_for<0, 8>([&](auto Ic) {
+                    constexpr int i = decltype(Ic)::value;
                     float dv = 0.f;
 #pragma unroll
                     for (int k = 0; k < DWK; ++k) { dv += wk[k] * dwin[i + 6 - k]; gw[k] += dwin[i + 3] * vv[i + k]; }
@@ -1112,7 +1156,12 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
                     // sample tiles: rows L .. 31 of the window lie outside the sample but receive dv from its last rows
                     slb += SH ? dv : dv * VF[t0 + i];
                     slg += dv * xc[i];
-                }
+                    if constexpr (i == 1) preF(std::integral_constant<int, 2>());
+                    else if constexpr (i == 3) preF(std::integral_constant<int, 3>());
+                    else if constexpr (i == 0) preB(std::integral_constant<int, 7>());
+                    else if constexpr (i == 2) preB(std::integral_constant<int, 8>());
+                    else if constexpr (i < 7) preB(std::integral_constant<int, (i < 7 ? i + 5 : 0)>());       // i = 4, 5, 6 -> loads 9, 10, 11
+                });
             } else {
                 int p = (r0 + 8 * seg) % L;                             // position of the row inside its sample
 #pragma unroll
@@ -1167,28 +1216,35 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
         for (int k = 0; k < DWK; ++k) { gw[k] += lane_xor1(gw[k]); gw[k] += lane_xor2(gw[k]); }
         slb += lane_xor1(slb); slb += lane_xor2(slb);
         slg += lane_xor1(slg); slg += lane_xor2(slg);
-        if (seg == 0) {
+        {
+            const uint32_t nsl = gridDim.x;
+            const brsrc_t rpd = buf_rsrc(a.p_dw[l], nsl * (D * DWK * 4)), rpb = buf_rsrc(a.p_lnb[l], nsl * (D * 4)), rpg = buf_rsrc(a.p_lng[l], nsl * (D * 4));
+            const uint32_t so = seg == 0 ? (uint32_t)((blockIdx.x * D + cc) * 4) : BUF_OOB;
+            const uint32_t sd = seg == 0 ? (uint32_t)((blockIdx.x * D + cc) * (DWK * 4)) : BUF_OOB;
 #pragma unroll
-            for (int k = 0; k < DWK; ++k) a.p_dw[l][(size_t)blockIdx.x * D * DWK + cc * DWK + k] = gw[k];
-            a.p_lnb[l][(size_t)blockIdx.x * D + cc] = slb;
-            a.p_lng[l][(size_t)blockIdx.x * D + cc] = slg;
+            for (int k = 0; k < DWK; ++k) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(gw[k]), rpd, sd + 4 * k, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(slb), rpb, so, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(slg), rpg, so, 0, 0);
         }
         // everything the layer below needs from memory: requested now, consumed after phase D
         if (l > 0) {
             constexpr int lm = l > 0 ? l - 1 : 0;
-            fetch_layer(lm);
-            b3_load(nxt, a.WT3[lm], D, D, 16 * w);
+            if constexpr (!SPREAD) { fetch_layer(lm); b3_load(nxt, a.WT3[lm], D, D, 16 * w); }
 #pragma unroll
             for (int k = 0; k < DWK; ++k) wk[k] = a.dw_w[lm][cc * DWK + k];
             gc = a.ln_g[lm][cc]; bc = a.ln_b[lm][cc];
-            if (tid < D) gnext = a.ln_g[lm][tid];
+            gnext = a.ln_g[lm][tid & (D - 1)];
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (l == 3) ESTAMP(14);
         __syncthreads();
+        if (l == 3) ESTAMP(15);
         // ---- D: dy <- dy + LN^T(dv)   (8 lanes per row)
         {
-            if (r8 >= ra + SH && r8 < ra + SH + nD) {
-                const int wr = r8;
+            const bool inD = r8 >= ra + SH && r8 < ra + SH + nD;
+            const brsrc_t rdx = buf_rsrc(a.dx0, rbytes);
+            if (l == 0 || inD) {                                       // (layer 0: every thread, idle ones on a valid row, so that the store is unconditional)
+                const int wr = inD ? r8 : ra + SH;
                 const float* dvr = GU + wr * LDP + sub * 4;
                 const float* xr = Xh + (wr - SH) * LDP + sub * 4;
                 float* dyr = DY + wr * LDP + sub * 4;
@@ -1212,14 +1268,16 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
                     float4 o;
                     o.x = dy.x + rstd * (gd[j].x - m1 - xh[j].x * m2); o.y = dy.y + rstd * (gd[j].y - m1 - xh[j].y * m2);
                     o.z = dy.z + rstd * (gd[j].z - m1 - xh[j].z * m2); o.w = dy.w + rstd * (gd[j].w - m1 - xh[j].w * m2);
-                    if (l > 0 || TAIL) *reinterpret_cast<float4*>(dyr + 32 * j) = o;       // (TAIL: the owner rows of dx0 stay in LDS for the body that follows)
-                    if (l == 0 && row_ok(wr)) *reinterpret_cast<float4*>(a.dx0 + (size_t)(rw0 + wr) * D + sub * 4 + 32 * j) = o;
+                    if ((l > 0 || TAIL) && inD) *reinterpret_cast<float4*>(dyr + 32 * j) = o;       // (TAIL: the owner rows of dx0 stay in LDS for the body that follows)
+                    if (l == 0) buf_store4(rdx, (inD && row_ok(wr)) ? rowoff + 128 * j : BUF_OOB, o);
                 }
             }
         }
         // no barrier: phase A of the next layer touches only what this thread itself read and wrote above -- except the dz planes of the
         // split path, which lie over the dv rows other threads are still reading
+        if (l == 3) ESTAMP(16);
         if (l > 0) __syncthreads();
+        if (l == 3) ESTAMP(17);
     };
     __syncthreads();
     layer(std::integral_constant<int, 3>(), b3A, b3B);
@@ -1261,7 +1319,7 @@ void launch_convblock_bwd(const CbBwdArgs& a, hipStream_t s) {
         else launch_cbb<3, true>(a, a.R / TILE_M, s);
     } else launch_cbb<3, false>(a, (a.R + TILE_M - 1) / TILE_M, s);
     static int left = 6;
-    if (edbg_on() && a.R > 4096) edbg_report("convblock_bwd: load | L3 | L2 | L1 | L0", 6, s, left);
+    if (edbg_on() && a.R > 4096) { int l2 = left; edbg_report("convblock_bwd: load | L3 | L2 | L1 | L0", 6, s, left); edbg_report2("  L3: (A) sync | xhat | gemm | DU | sync | C | sync | D | sync", 8, 18, s, l2); }
 }
 // partial slabs the backward writes per parameter: one per workgroup
 int convblock_slabs(int R, int L) { return L <= TILE_M ? R / L : (R + TILE_M - 1) / TILE_M; }
