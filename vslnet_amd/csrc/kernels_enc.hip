@@ -554,6 +554,7 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_fwd2(CbFwdArgs a) {
     constexpr int UPS = NW * CB_LDB;
     float* Ps = VU + C2_VUR * LDP + 3 * UPS / 2;               // [4][CB_PS] | ln1_g | ln1_b | bq | bk | bv
     uint16_t* MB = reinterpret_cast<uint16_t*>(Ps + 4 * CB_PS + 640);
+    float* TW = Ps + 4 * CB_PS + 640 + C2_XR * C2_MBW / 2;     // depthwise taps of the four layers, [layer][tap][channel]
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cb = w;                                          // GEMM role: column block (16 output columns = attention head w)
@@ -600,17 +601,41 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_fwd2(CbFwdArgs a) {
     }
     B3 b3A, b3B;                                               // the wave's 128 x 16 weight slice of the current / next stage
     b3_load(b3A, a.W3[0], D, D, 16 * cb);
-    f32x2 wk2[DWK];                                          // depthwise taps of the thread's channel pair (2 lane, 2 lane + 1), fetched a layer ahead
+    {   // depthwise taps of all four layers -> LDS, transposed to [tap][channel] (coalesced loads once per launch instead of 14 strided loads per layer and thread)
+        float tw[4][2];
 #pragma unroll
-    for (int k = 0; k < DWK; ++k) wk2[k] = f32x2{a.dw_w[0][(2 * lane) * DWK + k], a.dw_w[0][(2 * lane + 1) * DWK + k]};
+        for (int l = 0; l < 4; ++l) {
+            const brsrc_t rt = buf_rsrc(a.dw_w[l], D * DWK * 4);
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) tw[l][hh] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rt, tid < 448 ? (uint32_t)((tid + 448 * hh) * 4) : BUF_OOB, 0, 0));
+        }
+        if (tid < 448) {
+#pragma unroll
+            for (int l = 0; l < 4; ++l)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) { const int e = tid + 448 * hh; TW[l * (D * DWK) + (e % DWK) * D + e / DWK] = tw[l][hh]; }
+        }
+    }
+    f32x2 wk2[DWK];                                          // depthwise taps of the thread's channel pair (2 lane, 2 lane + 1)
     __syncthreads();
     ESTAMP(1);
     const int col = 16 * cb + (lane & 15), g4 = 4 * (lane >> 4);
     auto grp_sum = [](float v) { return grp8_sum(v); };       // sum over the LPR lanes of a row
     constexpr int TA[6] = {1, 0, 2, 0, 1, 0}, TB[6] = {1, 2, 0, 1, 0, 0};       // (a term, b term): mm, hl, lh, hm, mh, hh -- small terms first
 
-    auto layer = [&](auto LC, auto& cur, auto&& prefetch) {
+    // The next stage's weight slice (twelve 16-byte loads per lane) is requested ONE load at a time between pieces of this layer's work: a
+    // wave that issues the twelve together sits at the full request queue (k_convblock_bwd; without the prefetch a layer is 1.6 k cycles shorter).
+    auto layer = [&](auto LC, auto& cur, auto& nxt, const uint16_t* __restrict__ Wn, auto NCc) {
         constexpr int l = decltype(LC)::value;
+        constexpr int ncn = decltype(NCc)::value;
+        auto preB = [&](auto IC) {
+            constexpr int I = decltype(IC)::value;
+            __builtin_amdgcn_sched_barrier(0);
+            b3_load_one(nxt, Wn, D, ncn, 16 * cb, I % 3, I / 3);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+#pragma unroll
+        for (int k = 0; k < DWK; ++k) wk2[k] = *reinterpret_cast<const f32x2*>(&TW[l * (D * DWK) + k * D + 2 * lane]);
         constexpr int in0 = 3 * l, nin = NW - 6 * l;             // LayerNorm rows
         constexpr int o0 = in0 + 3, n = nin - 6;                 // rows this layer produces
         constexpr int NRB = (n + 15) / 16, QS = (n + 7) / 8;     // 16-row blocks ; rows per depthwise segment (one per wave)
@@ -631,6 +656,7 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_fwd2(CbFwdArgs a) {
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) buf_store4(ry, yo + 16 * LPR * j, v[j]);
             }
+            preB(std::integral_constant<int, 0>());
             if (act) {
                 float* d = VU + wr * LDP + sub * 4;
                 if (wr < klo || wr >= khi) {
@@ -664,6 +690,7 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_fwd2(CbFwdArgs a) {
                     }
                 }
             }
+            preB(std::integral_constant<int, 1>());
         }
         __syncthreads();
         if (l == 0) ESTAMP(8);
@@ -693,6 +720,8 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_fwd2(CbFwdArgs a) {
                     uint32_t* dpl = ub + row * (CB_LDB / 2);
                     dpl[0] = th; dpl[UPS / 2] = tm; dpl[UPS] = tl;
                 }
+                if (i == 0) preB(std::integral_constant<int, 2>()); else if (i == 1) preB(std::integral_constant<int, 3>());
+                else if (i == 2) preB(std::integral_constant<int, 4>()); else if (i == 3) preB(std::integral_constant<int, 5>());
             }
         }
         __syncthreads();
@@ -702,10 +731,6 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_fwd2(CbFwdArgs a) {
         // already runs the matrix pipe at its full rate (tools/ubench/mfma_rate.hip), the two waves of a SIMD take turns on it (the older one
         // first), and a request for A fragments per K step costs an LDS round trip per step -- a block's twelve fragments are requested one
         // block ahead instead; the residual values the epilogue updates are read ahead as well.
-        if (l < 3) {
-#pragma unroll
-            for (int k = 0; k < DWK; ++k) wk2[k] = f32x2{a.dw_w[l < 3 ? l + 1 : 3][(2 * lane) * DWK + k], a.dw_w[l < 3 ? l + 1 : 3][(2 * lane + 1) * DWK + k]};
-        }
         const float bv = P[256 + col];
         const int row0 = o0 + g4;                                // window row of the lane's first element in block 0
         const uint32_t hb = (uint32_t)((rw0 + row0) * D + col) * 0x9E3779B1u + dp.seed;    // hash input of that element
@@ -771,13 +796,13 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_fwd2(CbFwdArgs a) {
                 c0 = mfma16_bf16(f.t[1], cur.b[0][ks], c0);      // mh
                 c1 = mfma16_bf16(f.t[0], cur.b[0][ks], c1);      // hh
                 if constexpr (i > 0) epi(std::integral_constant<int, (i > 0 ? i - 1 : 0)>(), KSc);
+                if constexpr (i < 2 && (ks & 1)) preB(std::integral_constant<int, 6 + 2 * (i < 2 ? i : 0) + (ks >> 1)>());      // loads 6 .. 9
             });
             accp = c0 + c1;
         });
         xread(std::integral_constant<int, NRB - 1>());
-        __builtin_amdgcn_sched_barrier(0);
-        prefetch();                                              // weight slice of the next stage: most of a layer ahead of its use
-        __builtin_amdgcn_sched_barrier(0);
+        preB(std::integral_constant<int, 10>());
+        preB(std::integral_constant<int, 11>());
         static_for<0, 4>([&](auto RRc) { epi(std::integral_constant<int, NRB - 1>(), RRc); });
         if (l == 0) ESTAMP(10);
         __syncthreads();
@@ -788,13 +813,13 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_fwd2(CbFwdArgs a) {
             __builtin_amdgcn_raw_buffer_store_b128(mv, buf_rsrc(a.relu_mask[l], (uint32_t)a.R * 16), tid < TILE_M ? (uint32_t)((r0 + tid) * 16) : BUF_OOB, 0, 0);
         }
     };
-    layer(std::integral_constant<int, 0>(), b3A, [&] { b3_load(b3B, a.W3[1], D, D, 16 * cb); });
+    layer(std::integral_constant<int, 0>(), b3A, b3B, a.W3[1], std::integral_constant<int, D>());
     ESTAMP(2);
-    layer(std::integral_constant<int, 1>(), b3B, [&] { b3_load(b3A, a.W3[2], D, D, 16 * cb); });
+    layer(std::integral_constant<int, 1>(), b3B, b3A, a.W3[2], std::integral_constant<int, D>());
     ESTAMP(3);
-    layer(std::integral_constant<int, 2>(), b3A, [&] { b3_load(b3B, a.W3[3], D, D, 16 * cb); });
+    layer(std::integral_constant<int, 2>(), b3A, b3B, a.W3[3], std::integral_constant<int, D>());
     ESTAMP(4);
-    layer(std::integral_constant<int, 3>(), b3B, [&] { b3_load(b3A, a.Wqkv3, D, 3 * D, 16 * cb); });
+    layer(std::integral_constant<int, 3>(), b3B, b3A, a.Wqkv3, std::integral_constant<int, 3 * D>());
     ESTAMP(5);
     // ---- a8, first half (:168-173) on the owner rows: y3 -> memory ; h1 = drop(LN1(y3)) ; [q | k | v] = h1 W^T + b  (column block cb = head cb)
     {
@@ -893,7 +918,7 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_fwd2(CbFwdArgs a) {
     ESTAMP(6);
 }
 constexpr size_t cb_fwd2_lds() {
-    return (size_t)((C2_XR + C2_VUR) * LDP + 3 * (TILE_M + 24) * CB_LDB / 2 + 4 * CB_PS + 640 + C2_XR * C2_MBW / 2) * sizeof(float);
+    return (size_t)((C2_XR + C2_VUR) * LDP + 3 * (TILE_M + 24) * CB_LDB / 2 + 4 * CB_PS + 640 + C2_XR * C2_MBW / 2 + 4 * D * DWK) * sizeof(float);
 }
 template <bool DROP>
 static void launch_cbf2_t(const CbFwdArgs& a, int grid, hipStream_t s) {
