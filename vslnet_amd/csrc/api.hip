@@ -779,8 +779,12 @@ void enc_bwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float*
                            c.W(t.dv), Bn, L, H, 0, c.drop(app * 16 + 5), c.drop(app * 16 + 6), c.s));
     float* p_ln1g = c.slab(P.ln1g, D, ntiles);
     float* p_ln1b = c.slab(P.ln1b, D, ntiles);
-    LAUNCH("qkv_bwd", launch_qkv_bwd(c.W(t.dq), c.W(t.dk), c.W(t.dv), c.W(w.y[3]), c.W(t.dr), c.P(P.ln1g), reinterpret_cast<const uint16_t*>(c.PK(K.qkv_t3)),
-                          c.W(t.ga), p_ln1g, p_ln1b, R, c.drop(app * 16 + 4), c.s, attn_bwd_dq_slabs(L)));
+    // whole tiles (and one dQ slab): the conv block's backward kernel computes its own incoming gradient from dq / dk / dv (CbBwdArgs::qk)
+    static const bool fuse_on = !(getenv("VSL_QKV_FUSED") && getenv("VSL_QKV_FUSED")[0] == '0');
+    const bool fuse_qkv = fuse_on && convblock_bwd_hosts_tail(R, L) && attn_bwd_dq_slabs(L) == 1;
+    if (!fuse_qkv)
+        LAUNCH("qkv_bwd", launch_qkv_bwd(c.W(t.dq), c.W(t.dk), c.W(t.dv), c.W(w.y[3]), c.W(t.dr), c.P(P.ln1g), reinterpret_cast<const uint16_t*>(c.PK(K.qkv_t3)),
+                              c.W(t.ga), p_ln1g, p_ln1b, R, c.drop(app * 16 + 4), c.s, attn_bwd_dq_slabs(L)));
     {   // out_layer + fused q/k/v weight gradients: every input exists now -> side stream, beside the conv chain
         WgradBatch wb;
         memset(&wb, 0, sizeof wb);
@@ -820,6 +824,11 @@ void enc_bwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float*
         }
         if (tail_ao) { a.tail = 1; a.tail_ao = *tail_ao; }
         if (tail_cq) { a.tail = 2; a.tail_cq = *tail_cq; }
+        if (fuse_qkv) {
+            a.qkv = 1;
+            if (!c.dry) a.qk = QkvBwdFuse{c.W(t.dq), c.W(t.dk), c.W(t.dv), c.W(w.y[3]), c.W(t.dr), c.P(P.ln1g), reinterpret_cast<const uint16_t*>(c.PK(K.qkv_t3)),
+                                          p_ln1g, p_ln1b, c.drop(app * 16 + 4)};
+        }
         if (!c.dry) {
             a.dy = g; a.dx0 = dx0_out; a.R = R; a.L = L;
             for (int i = 0; i < 4; ++i) {

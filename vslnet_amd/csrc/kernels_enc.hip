@@ -966,7 +966,10 @@ void launch_convblock_fwd(const CbFwdArgs& a, hipStream_t s) {
 // (GU) -- dz is dead before phase C writes dv, but the next layer's phase A overwrites what phase D still reads: one more barrier per layer.
 // TAIL (whole tiles only): the workgroup goes on with a row-tile kernel's body on its 32 rows of dx0 (tile_bodies.hpp): 1 = attention-output
 // backward of the encoder pass below, 2 = CQConcatenate backward.  Waves 0-3 work, the others join the barriers.
-template <int SH, bool FULL, int TAIL = 0>        // SH 3: row tiles with a recomputed halo ; 0: sample tiles for L <= 32 ; FULL: see k_convblock_fwd
+// QKV (whole tiles only): the workgroup first does k_qkv_bwd's work on its whole 56-row window (CbBwdArgs::qk) -- dy is born in LDS.  The halo
+// rows are recomputed (1.75 x the K = 384 product), but the product's price is its 288 KB weight stream per workgroup, which a 32-row and a 56-row
+// tile pay alike; what goes away is a launch of the dependent chain with its own cold start, and dy's trip through memory.
+template <int SH, bool FULL, int TAIL = 0, bool QKV = false>        // SH 3: row tiles with a recomputed halo ; 0: sample tiles for L <= 32 ; FULL: see k_convblock_fwd
 __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
     constexpr int HL = 4 * SH, NW = TILE_M + 2 * HL, VUR = SH ? NW + 12 : NW, XR = NW - 2 * SH;
     constexpr int ZPS = NW * CB_LDB;                     // elements between the dz planes
@@ -1016,7 +1019,141 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) fetch_part(l, q);
     };
-    {
+    B3 b3A, b3B;
+    const int col = 16 * w + (lane & 15), g4 = 4 * (lane >> 4);
+    if constexpr (QKV) {
+        static_assert(FULL && SH == 3 && 3 * ZPS / 2 <= (VUR + XR) * LDP, "the q,k,v backward rides on whole tiles");
+        // dh1 = [dQ | dK | dV] [Wq; Wk; Wv] in three K = 128 chunks.  Plane buffers: Pz (the dz planes' place) and P2 (DU | Xh, unused before
+        // layer 3) alternate, so a chunk is split and stored while the previous one is multiplied: one barrier per chunk.
+        const QkvBwdFuse& qk = a.qk;
+        uint16_t* P2 = reinterpret_cast<uint16_t*>(DU);
+        const brsrc_t rq = buf_rsrc(qk.dq, rbytes), rk = buf_rsrc(qk.dk, rbytes), rv = buf_rsrc(qk.dv, rbytes);
+        const size_t wchunk = (size_t)(D / 16) * D * 16;          // bf16 elements of 128 contraction rows in a split plane
+        // two chunks of rows and weights are on their way at any time; a chunk's registers are reloaded as soon as its planes are stored / its
+        // product is done (more in flight starves the GEMM of fragment registers: it then reads its A operand one fragment at a time)
+        float4 g0[4], g1[4], xq[4], rs[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) g0[q] = buf_load4(rq, rowoff + 128 * q);
+        b3_load(b3B, qk.WT3, 3 * D, D, 16 * w);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) g1[q] = buf_load4(rk, rowoff + 128 * q);
+        b3_load(b3A, qk.WT3 + wchunk, 3 * D, D, 16 * w);
+        __builtin_amdgcn_sched_barrier(0);
+        auto put = [&](uint16_t* Pb, const float4 (&g)[4]) {
+            if (r8 < NW) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    uint32_t h0, m0, l0, h1, m1, l1;
+                    split3(g[q].x, g[q].y, h0, m0, l0);
+                    split3(g[q].z, g[q].w, h1, m1, l1);
+                    uint16_t* d = Pb + r8 * CB_LDB + sub * 4 + 32 * q;
+                    *reinterpret_cast<u32x2_t*>(d) = u32x2_t{h0, h1};
+                    *reinterpret_cast<u32x2_t*>(d + ZPS) = u32x2_t{m0, m1};
+                    *reinterpret_cast<u32x2_t*>(d + 2 * ZPS) = u32x2_t{l0, l1};
+                }
+            }
+        };
+        put(Pz, g0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) g0[q] = buf_load4(rv, rowoff + 128 * q);
+        ESTAMP(18);
+        __syncthreads();
+        ESTAMP(19);
+        f32x4 acc[1][4];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) acc[0][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        gemm16s<4>(Pz, ZPS, b3B, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        b3_load(b3B, qk.WT3 + 2 * wchunk, 3 * D, D, 16 * w);
+        __builtin_amdgcn_sched_barrier(0);
+        put(P2, g1);
+        ESTAMP(20);
+        __syncthreads();
+        ESTAMP(21);
+        gemm16s<4>(P2, ZPS, b3A, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        b3_load(b3A, a.WT3[3], D, D, 16 * w);                     // layer 3's weight slice
+        __builtin_amdgcn_sched_barrier(0);
+        put(Pz, g0);
+        {
+            const brsrc_t rx = buf_rsrc(qk.x, rbytes), rdr = buf_rsrc(qk.dr, rbytes);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { xq[q] = buf_load4(rx, rowoff + 128 * q); rs[q] = buf_load4(rdr, rowoff + 128 * q); }
+        }
+        ESTAMP(22);
+        __syncthreads();
+        ESTAMP(23);
+        gemm16s<4>(Pz, ZPS, b3B, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch_layer(3);
+        {   // Ts = dh1 * m1 -> DU (P2 is dead since the last barrier)
+            const Drop d1 = qk.d1;
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int row = 16 * rb + g4 + rr;
+                    DU[row * LDP + col] = acc[0][rb][rr] * drop_mul(d1, (uint32_t)((rw0 + row) * D + col));
+                }
+        }
+        ESTAMP(24);
+        __syncthreads();
+        ESTAMP(25);
+        {   // LayerNorm-1 backward per window row (8 lanes per row): dy = dr + rstd (g - mean(g) - xhat mean(g xhat)), g = Ts * gamma
+            const int rc = r8 < NW ? r8 : 0;
+            const float* tr = DU + rc * LDP + sub * 4;
+            float4 ts[4];
+            float sm = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { ts[j] = *reinterpret_cast<const float4*>(tr + 32 * j); sm += sum4(xq[j]); }
+            const float mu = grp8_sum(sm) * (1.0f / D);
+            float qv = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                xq[j].x -= mu; xq[j].y -= mu; xq[j].z -= mu; xq[j].w -= mu;
+                qv += xq[j].x * xq[j].x + xq[j].y * xq[j].y + xq[j].z * xq[j].z + xq[j].w * xq[j].w;
+            }
+            const float rstd = rsqrtf(grp8_sum(qv) * (1.0f / D) + LN_EPS);
+            float m1 = 0.f, m2 = 0.f;
+            float4 gd[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 gv = *reinterpret_cast<const float4*>(qk.ln_g + sub * 4 + 32 * j);
+                xq[j].x *= rstd; xq[j].y *= rstd; xq[j].z *= rstd; xq[j].w *= rstd;                       // xhat
+                gd[j] = make_float4(ts[j].x * gv.x, ts[j].y * gv.y, ts[j].z * gv.z, ts[j].w * gv.w);
+                m1 += sum4(gd[j]);
+                m2 += gd[j].x * xq[j].x + gd[j].y * xq[j].y + gd[j].z * xq[j].z + gd[j].w * xq[j].w;
+            }
+            m1 = grp8_sum(m1) * (1.0f / D);
+            m2 = grp8_sum(m2) * (1.0f / D);
+            const bool own = r8 >= HL && r8 < HL + TILE_M;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float4 o;
+                o.x = rstd * (gd[j].x - m1 - xq[j].x * m2) + rs[j].x; o.y = rstd * (gd[j].y - m1 - xq[j].y * m2) + rs[j].y;
+                o.z = rstd * (gd[j].z - m1 - xq[j].z * m2) + rs[j].z; o.w = rstd * (gd[j].w - m1 - xq[j].w * m2) + rs[j].w;
+                if (r8 < NW) *reinterpret_cast<float4*>(&DY[r8 * LDP + sub * 4 + 32 * j]) = o;
+                // gamma's gradient: Ts * xhat of the OWNER rows, summed per column below (Xh rows 0..31 are free until layer 3)
+                if (own) *reinterpret_cast<float4*>(&Xh[(r8 - HL) * LDP + sub * 4 + 32 * j]) =
+                    make_float4(ts[j].x * xq[j].x, ts[j].y * xq[j].y, ts[j].z * xq[j].z, ts[j].w * xq[j].w);
+            }
+        }
+        ESTAMP(26);
+        __syncthreads();
+        ESTAMP(27);
+        {   // column sums over the 32 owner rows -> this tile's partial slabs of LN1's gamma / beta
+            const int c = tid & 127;
+            const float* src = tid < 128 ? Xh + c : DU + HL * LDP + c;
+            float accs = 0.f;
+#pragma unroll 8
+            for (int i = 0; i < TILE_M; ++i) accs += src[i * LDP];
+            const brsrc_t rgg = buf_rsrc(qk.p_lng, gridDim.x * (D * 4)), rgb = buf_rsrc(qk.p_lnb, gridDim.x * (D * 4));
+            const uint32_t so = (uint32_t)((blockIdx.x * D + c) * 4);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(accs), rgg, tid < 128 ? so : BUF_OOB, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(accs), rgb, (tid >= 128 && tid < 256) ? so : BUF_OOB, 0, 0);
+        }
+    } else {
         float4 dv[4];
         const brsrc_t rdy = buf_rsrc(a.dy, rbytes);
 #pragma unroll
@@ -1025,9 +1162,8 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             if (r8 < NW) *reinterpret_cast<float4*>(&DY[r8 * LDP + sub * 4 + 32 * q]) = dv[q];
+        b3_load(b3A, a.WT3[3], D, D, 16 * w);
     }
-    B3 b3A, b3B;
-    b3_load(b3A, a.WT3[3], D, D, 16 * w);
     float wk[DWK], gc, bc, gnext = 0.f;
 #pragma unroll
     for (int k = 0; k < DWK; ++k) wk[k] = a.dw_w[3][cc * DWK + k];
@@ -1036,7 +1172,6 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
     if (tid < 64) {
         VF[tid] = (one_owner ? (tid >= klo && tid < khi) : row_in(tid)) ? 1.f : 0.f;
     }
-    const int col = 16 * w + (lane & 15), g4 = 4 * (lane >> 4);
     ESTAMP(1);
 
     auto layer = [&](auto LC, auto& cur, auto& nxt) {
@@ -1325,12 +1460,12 @@ constexpr size_t cb_bwd_lds_split(int sh) {
     const int nw = TILE_M + 8 * sh, vur = sh ? nw + 12 : nw, zf = 3 * nw * CB_LDB / 2, guf = zf > vur * LDP ? zf : vur * LDP;
     return (size_t)((nw + vur + TILE_M + 6 * sh) * LDP + guf + 64 + 64 + 256) * sizeof(float);
 }
-template <int SH, bool FULL, int TAIL = 0>
+template <int SH, bool FULL, int TAIL = 0, bool QKV = false>
 static void launch_cbb(const CbBwdArgs& a, int grid, hipStream_t s) {
     static size_t ok = 0;
     const size_t lds = cb_bwd_lds_split(SH);
-    ensure_dynamic_lds((const void*)k_convblock_bwd<SH, FULL, TAIL>, lds, ok, "k_convblock_bwd");
-    VSL_LAUNCH((k_convblock_bwd<SH, FULL, TAIL>), dim3(grid), dim3(CB_T), lds, s, a);
+    ensure_dynamic_lds((const void*)k_convblock_bwd<SH, FULL, TAIL, QKV>, lds, ok, "k_convblock_bwd");
+    VSL_LAUNCH((k_convblock_bwd<SH, FULL, TAIL, QKV>), dim3(grid), dim3(CB_T), lds, s, a);
 }
 bool convblock_bwd_hosts_tail(int R, int L) { return L > TILE_M && R % TILE_M == 0 && L % TILE_M == 0; }
 void launch_convblock_bwd(const CbBwdArgs& a, hipStream_t s) {
@@ -1339,12 +1474,16 @@ void launch_convblock_bwd(const CbBwdArgs& a, hipStream_t s) {
         return;
     }
     if (a.R % TILE_M == 0 && a.L % TILE_M == 0) {
-        if (a.tail == 1) launch_cbb<3, true, 1>(a, a.R / TILE_M, s);
+        if (a.qkv) {
+            if (a.tail == 1) launch_cbb<3, true, 1, true>(a, a.R / TILE_M, s);
+            else if (a.tail == 2) launch_cbb<3, true, 2, true>(a, a.R / TILE_M, s);
+            else launch_cbb<3, true, 0, true>(a, a.R / TILE_M, s);
+        } else if (a.tail == 1) launch_cbb<3, true, 1>(a, a.R / TILE_M, s);
         else if (a.tail == 2) launch_cbb<3, true, 2>(a, a.R / TILE_M, s);
         else launch_cbb<3, true>(a, a.R / TILE_M, s);
     } else launch_cbb<3, false>(a, (a.R + TILE_M - 1) / TILE_M, s);
     static int left = 6;
-    if (edbg_on() && a.R > 4096) { int l2 = left; edbg_report("convblock_bwd: load | L3 | L2 | L1 | L0", 6, s, left); edbg_report2("  L3: (A) sync | xhat | gemm | DU | sync | C | sync | D | sync", 8, 18, s, l2); }
+    if (edbg_on() && a.R > 4096) { int l2 = left; edbg_report("convblock_bwd: load | L3 | L2 | L1 | L0", 6, s, left); edbg_report2("  L3: (A) sync | xhat | gemm | DU | sync | C | sync | D | sync", 8, 18, s, l2); if (a.qkv) { int l3 = l2 + 1; edbg_report2("  qkv: (from 0: load+split c0) | sync | gemm c0 + split c1 | sync | gemm c1 + split c2 | sync | gemm c2 + Ts | sync | LN bwd | sync | (to stamp 1: sums + rest)", 18, 28, s, l3); } }
 }
 // partial slabs the backward writes per parameter: one per workgroup
 int convblock_slabs(int R, int L) { return L <= TILE_M ? R / L : (R + TILE_M - 1) / TILE_M; }

@@ -161,9 +161,20 @@ struct CqcatBwdArgs {
     const float *dg0, *dg1, *dg2, *dh_loss, *f2, *hscore, *wh, *W1Tpack;
     float *df2, *df1, *p_wh, *p_bh;
 };
+// a8 backward, first half (k_qkv_bwd's work), hosted by the conv block's backward kernel on its 56-row window:
+// dy = dr + LN1^T(([dQ | dK | dV] [Wq; Wk; Wv]) * m1) -- the conv block's incoming gradient never goes through memory
+struct QkvBwdFuse {
+    const float *dq, *dk, *dv;     // (R,128) each
+    const float* x;                // (R,128) LN1 input = the conv block's output y3
+    const float* dr;               // (R,128) gradient of the residual path (attention-output backward)
+    const float* ln_g;             // LN1 gamma
+    const uint16_t* WT3;           // split pack (type 7) of [Wq; Wk; Wv]: 384 contraction rows, 128 columns
+    float *p_lng, *p_lnb;          // partial slabs [ntiles][128]
+    Drop d1;
+};
 struct CbBwdArgs {
     const uint16_t* WT3[4];        // split packs (PackJob type 7) of the pointwise weights' data-gradient operand
-    const float* dy;               // (R,128) grad wrt the block output
+    const float* dy;               // (R,128) grad wrt the block output (unused when qkv is set)
     const float* x[4];             // LayerNorm inputs of layers 0..3 (x0, y0, y1, y2)
     const uint32_t* relu_mask[4];
     const float *ln_g[4], *ln_b[4], *dw_w[4];
@@ -177,6 +188,8 @@ struct CbBwdArgs {
     int tail;
     AttnOutBwdArgs tail_ao;
     CqcatBwdArgs tail_cq;
+    int qkv;                       // 1: the workgroup first computes dy from qk (whole-tile instantiation only: convblock_bwd_hosts_tail)
+    QkvBwdFuse qk;
 };
 void launch_convblock_bwd(const CbBwdArgs& a, hipStream_t s);
 bool convblock_bwd_hosts_tail(int R, int L);      // does launch_convblock_bwd honour CbBwdArgs::tail for this shape?
