@@ -777,11 +777,12 @@ void enc_bwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float*
     }
     LAUNCH("attn_bwd", launch_attn_bwd(c.W(w.q), c.W(w.k), c.W(w.v), c.W(w.att), c.W(t.dr), c.W(w.lse), mask, c.W(t.dq), c.W(t.dk),
                            c.W(t.dv), Bn, L, H, 0, c.drop(app * 16 + 5), c.drop(app * 16 + 6), c.s));
-    float* p_ln1g = c.slab(P.ln1g, D, ntiles);
-    float* p_ln1b = c.slab(P.ln1b, D, ntiles);
-    // whole tiles (and one dQ slab): the conv block's backward kernel computes its own incoming gradient from dq / dk / dv (CbBwdArgs::qk)
+    // whole tiles / sample tiles (and one dQ slab): the conv block's backward kernel computes its own incoming gradient from dq / dk / dv (CbBwdArgs::qk)
     static const bool fuse_on = !(getenv("VSL_QKV_FUSED") && getenv("VSL_QKV_FUSED")[0] == '0');
-    const bool fuse_qkv = fuse_on && convblock_bwd_hosts_tail(R, L) && attn_bwd_dq_slabs(L) == 1;
+    const bool fuse_qkv = fuse_on && convblock_bwd_hosts_qkv(R, L) && attn_bwd_dq_slabs(L) == 1;
+    const int nsl1 = fuse_qkv ? convblock_slabs(R, L) : ntiles;
+    float* p_ln1g = c.slab(P.ln1g, D, nsl1);
+    float* p_ln1b = c.slab(P.ln1b, D, nsl1);
     if (!fuse_qkv)
         LAUNCH("qkv_bwd", launch_qkv_bwd(c.W(t.dq), c.W(t.dk), c.W(t.dv), c.W(w.y[3]), c.W(t.dr), c.P(P.ln1g), reinterpret_cast<const uint16_t*>(c.PK(K.qkv_t3)),
                               c.W(t.ga), p_ln1g, p_ln1b, R, c.drop(app * 16 + 4), c.s, attn_bwd_dq_slabs(L)));

@@ -1022,7 +1022,8 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
     B3 b3A, b3B;
     const int col = 16 * w + (lane & 15), g4 = 4 * (lane >> 4);
     if constexpr (QKV) {
-        static_assert(FULL && SH == 3 && 3 * ZPS / 2 <= (VUR + XR) * LDP, "the q,k,v backward rides on whole tiles");
+        static_assert(((FULL && SH == 3) || SH == 0) && 3 * ZPS / 2 <= (VUR + XR) * LDP, "the q,k,v backward rides on whole tiles and on sample tiles");
+        constexpr int NRQ = (NW + 15) / 16;                       // 16-row blocks of the window
         // dh1 = [dQ | dK | dV] [Wq; Wk; Wv] in three K = 128 chunks.  Plane buffers: Pz (the dz planes' place) and P2 (DU | Xh, unused before
         // layer 3) alternate, so a chunk is split and stored while the previous one is multiplied: one barrier per chunk.
         const QkvBwdFuse& qk = a.qk;
@@ -1060,10 +1061,10 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
         ESTAMP(18);
         __syncthreads();
         ESTAMP(19);
-        f32x4 acc[1][4];
+        f32x4 acc[1][NRQ];
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb) acc[0][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
-        gemm16s<4>(Pz, ZPS, b3B, acc);
+        for (int rb = 0; rb < NRQ; ++rb) acc[0][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        gemm16s<NRQ>(Pz, ZPS, b3B, acc);
         __builtin_amdgcn_sched_barrier(0);
         b3_load(b3B, qk.WT3 + 2 * wchunk, 3 * D, D, 16 * w);
         __builtin_amdgcn_sched_barrier(0);
@@ -1071,7 +1072,7 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
         ESTAMP(20);
         __syncthreads();
         ESTAMP(21);
-        gemm16s<4>(P2, ZPS, b3A, acc);
+        gemm16s<NRQ>(P2, ZPS, b3A, acc);
         __builtin_amdgcn_sched_barrier(0);
         b3_load(b3A, a.WT3[3], D, D, 16 * w);                     // layer 3's weight slice
         __builtin_amdgcn_sched_barrier(0);
@@ -1084,13 +1085,13 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
         ESTAMP(22);
         __syncthreads();
         ESTAMP(23);
-        gemm16s<4>(Pz, ZPS, b3B, acc);
+        gemm16s<NRQ>(Pz, ZPS, b3B, acc);
         __builtin_amdgcn_sched_barrier(0);
         fetch_layer(3);
         {   // Ts = dh1 * m1 -> DU (P2 is dead since the last barrier)
             const Drop d1 = qk.d1;
 #pragma unroll
-            for (int rb = 0; rb < 4; ++rb)
+            for (int rb = 0; rb < NRQ; ++rb)
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) {
                     const int row = 16 * rb + g4 + rr;
@@ -1468,9 +1469,11 @@ static void launch_cbb(const CbBwdArgs& a, int grid, hipStream_t s) {
     VSL_LAUNCH((k_convblock_bwd<SH, FULL, TAIL, QKV>), dim3(grid), dim3(CB_T), lds, s, a);
 }
 bool convblock_bwd_hosts_tail(int R, int L) { return L > TILE_M && R % TILE_M == 0 && L % TILE_M == 0; }
+bool convblock_bwd_hosts_qkv(int R, int L) { return L <= TILE_M || convblock_bwd_hosts_tail(R, L); }
 void launch_convblock_bwd(const CbBwdArgs& a, hipStream_t s) {
     if (a.L <= TILE_M) {                    // sample tiles: one workgroup per sample (partial slabs per SAMPLE: convblock_slabs())
-        launch_cbb<0, false>(a, a.R / a.L, s);
+        if (a.qkv) launch_cbb<0, false, 0, true>(a, a.R / a.L, s);
+        else launch_cbb<0, false>(a, a.R / a.L, s);
         return;
     }
     if (a.R % TILE_M == 0 && a.L % TILE_M == 0) {

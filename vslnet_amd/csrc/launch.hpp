@@ -193,6 +193,7 @@ struct CbBwdArgs {
 };
 void launch_convblock_bwd(const CbBwdArgs& a, hipStream_t s);
 bool convblock_bwd_hosts_tail(int R, int L);      // does launch_convblock_bwd honour CbBwdArgs::tail for this shape?
+bool convblock_bwd_hosts_qkv(int R, int L);       // ... and CbBwdArgs::qkv?  (its LN1 partial slabs are then convblock_slabs(R, L) many)
 int convblock_slabs(int R, int L);        // partial slabs per parameter of launch_convblock_bwd (= its grid)
 void launch_attn_fwd(const float* Q, const float* K, const float* V, const float* mask, float* att, float* lse, int B,
                      int L, int H, int b_off, Drop d2, hipStream_t s);
