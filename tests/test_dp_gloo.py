@@ -259,7 +259,7 @@ def test_two_ranks_train_like_one_process_on_the_gpu():
     # A ReLU pre-activation within rounding noise of zero may land on the other side in a shard run (the summation order of
     # the per-tile partial sums depends on where the shard's tiles start); the gradient then changes discontinuously.  The
     # saved decisions tell: the parameters are compared strictly up to the first step whose forward moved a decision, and
-    # loosely (same order of magnitude as one flipped unit) afterwards.
+    # loosely (at most the optimizer's step per update) afterwards.
     first_moved = None
     for step in range(3):
         two_dec = [np.concatenate([got[0][2][step][s], got[1][2][step][s]], axis=0) for s in range(len(dec1[step]))]
@@ -270,7 +270,10 @@ def test_two_ranks_train_like_one_process_on_the_gpu():
         diff = (two[k] - one[k]).abs()
         assert float(diff[noise].max()) <= k * 1e-3                              # at most lr per step
         strict = first_moved is None or k <= first_moved
-        tol = 2e-3 * moved if strict else 0.1 * moved
+        # afterwards AdamW's own bound applies: this early an update is ~ lr * sign(g) per entry, so an entry whose (small) gradient is
+        # dominated by the unit that flipped moves by up to lr per step in opposite directions in the two runs (round 5: the per-sample
+        # LayerNorm-1 slabs of the fused q,k,v backward changed which pre-activations sit at zero; 0.1 * moved had held by luck)
+        tol = 2e-3 * moved if strict else k * 1e-3
         assert float(diff[~noise].max()) <= tol, (k, first_moved, float(diff[~noise].max()), moved)
 
 

@@ -8,7 +8,7 @@ R=$PWD
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline"
+BENCH="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-shapes --regions 1"
 rocprofv3 --kernel-trace --stats -d $O/stats -o s -- $BENCH > $O/stats_bench.json 2> $O/stats.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o f -- $BENCH > /dev/null 2> $O/fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o w -- $BENCH > /dev/null 2> $O/write.err

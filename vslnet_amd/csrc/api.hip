@@ -761,9 +761,10 @@ AttnOutBwdArgs attn_out_bwd_args(Ctx& c, const EncP& P, const EncPk& K, const En
 // attn_out_done: the attention-output backward of this application already ran (fused into the span heads' kernel: run_backward)
 // tail_ao / tail_cq: what the conv block's backward workgroups go on with on their tile of dx0 (CbBwdArgs::tail; the caller has checked
 // convblock_bwd_hosts_tail and skips that launch)
+struct LinTail { const uint16_t* WT3; float* dA; int K, Kc; };     // CbBwdArgs::tail == 3
 void enc_bwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float* dy, const float* dy2, int64_t dx0_off,
              const float* mask, int Bn, int app, hipStream_t sw, WgradBatch* defer_pw = nullptr, bool attn_out_done = false,
-             const AttnOutBwdArgs* tail_ao = nullptr, const CqcatBwdArgs* tail_cq = nullptr) {
+             const AttnOutBwdArgs* tail_ao = nullptr, const CqcatBwdArgs* tail_cq = nullptr, const LinTail* tail_lin = nullptr) {
     // sw: stream of the early (out_layer / q,k,v) weight gradients.  The pointwise-conv batch goes to `sw` too unless the
     // caller asks for it back (defer_pw) to launch it on its own stream WITHOUT a cross-stream wait (each costs ~16 us).
     float* dx0_out = c.dry ? nullptr : c.W(dx0_off);
@@ -825,6 +826,7 @@ void enc_bwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float*
         }
         if (tail_ao) { a.tail = 1; a.tail_ao = *tail_ao; }
         if (tail_cq) { a.tail = 2; a.tail_cq = *tail_cq; }
+        if (tail_lin) { a.tail = 3; a.tail_lin_WT3 = tail_lin->WT3; a.tail_lin_dA = tail_lin->dA; a.tail_lin_K = tail_lin->K; a.tail_lin_Kc = tail_lin->Kc; }
         if (fuse_qkv) {
             a.qkv = 1;
             if (!c.dry) a.qk = QkvBwdFuse{c.W(t.dq), c.W(t.dk), c.W(t.dv), c.W(w.y[3]), c.W(t.dr), c.P(P.ln1g), reinterpret_cast<const uint16_t*>(c.PK(K.qkv_t3)),
@@ -1101,8 +1103,13 @@ void run_backward(Ctx& c) {
     LAUNCH("cq_bwd_d", launch_cq_bwd_query(q, B, c.s));     // dQ: only the query side consumes it
     WgradBatch pw_query;
     memset(&pw_query, 0, sizeof pw_query);
-    enc_bwd(c, P.fe, K.fe, p.qe, c.dry ? nullptr : c.W(p.dQtot), nullptr, p.dqf, c.dry ? nullptr : io->q_mask, B, 1, sw, &pw_query);
     const int EW = cf.word_dim + 100;
+    // sample tiles (Lq <= 32): the query pass' conv-block backward goes on with the Embedding linear's data gradient on its rows of dx0
+    const bool lin_hosted = convblock_bwd_hosts_linear(Rq, Lq) && K.emb_t3_cols % 512 == 0;
+    LinTail lt{nullptr, nullptr, EW, K.emb_t3_cols};
+    if (lin_hosted && !c.dry) { lt.WT3 = reinterpret_cast<const uint16_t*>(c.PK(K.emb_t3)); lt.dA = c.W(p.dE); }
+    enc_bwd(c, P.fe, K.fe, p.qe, c.dry ? nullptr : c.W(p.dQtot), nullptr, p.dqf, c.dry ? nullptr : io->q_mask, B, 1, sw, &pw_query, false, nullptr, nullptr,
+            lin_hosted ? &lt : nullptr);
     {   // every remaining weight gradient (video + query pointwise convs, embedding linear) in ONE launch on the video
         // stream, beside the embedding backward that ends the query stream
         WgradBatch wb_tail = pw_video;
@@ -1121,7 +1128,8 @@ void run_backward(Ctx& c) {
         if (!fits) LAUNCH("wgrad", launch_wgrad(pw_query, c.s, c.one_product));
         c.s = qs;
     }
-    LAUNCH("linear_bwd_data", launch_linear_bwd_data3(c.W(p.dqf), reinterpret_cast<const uint16_t*>(c.PK(K.emb_t3)), c.W(p.dE), Rq, EW, K.emb_t3_cols, c.s));
+    if (!lin_hosted)
+        LAUNCH("linear_bwd_data", launch_linear_bwd_data3(c.W(p.dqf), reinterpret_cast<const uint16_t*>(c.PK(K.emb_t3)), c.W(p.dE), Rq, EW, K.emb_t3_cols, c.s));
     {
         const int ebc = embed_bwd_chunk(Rq, p.Lc, cf.char_dim), nce = (Rq + ebc - 1) / ebc;
         const int wtot = cf.char_dim * 300;

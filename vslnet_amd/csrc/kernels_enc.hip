@@ -1450,11 +1450,12 @@ __global__ __launch_bounds__(CB_T, 2) void k_convblock_bwd(CbBwdArgs a) {
     layer(std::integral_constant<int, 0>(), b3B, b3A);
     ESTAMP(5);
     if constexpr (TAIL != 0) {
-        static_assert(FULL && SH == 3, "tails ride on whole tiles");
+        static_assert(TAIL == 3 ? SH == 0 : (FULL && SH == 3), "tails 1, 2 ride on whole tiles, tail 3 on sample tiles");
         __syncthreads();                                   // dx0's owner rows are in DY; every other LDS region is free
         const bool active = tid < 256;
         if constexpr (TAIL == 1) attn_out_bwd_tile(a.tail_ao, DY + HL * LDP, GU, DU, r0, R, active);
-        else cqcat_bwd_tile(a.tail_cq, DY + HL * LDP, GU, DU, RS, r0, R, active);
+        else if constexpr (TAIL == 2) cqcat_bwd_tile(a.tail_cq, DY + HL * LDP, GU, DU, RS, r0, R, active);
+        else linear_bwd_data_tile(DY, Pz, a.tail_lin_WT3, a.tail_lin_dA, r0, L, a.tail_lin_K, a.tail_lin_Kc);
     }
 }
 constexpr size_t cb_bwd_lds_split(int sh) {
@@ -1469,10 +1470,12 @@ static void launch_cbb(const CbBwdArgs& a, int grid, hipStream_t s) {
     VSL_LAUNCH((k_convblock_bwd<SH, FULL, TAIL, QKV>), dim3(grid), dim3(CB_T), lds, s, a);
 }
 bool convblock_bwd_hosts_tail(int R, int L) { return L > TILE_M && R % TILE_M == 0 && L % TILE_M == 0; }
+bool convblock_bwd_hosts_linear(int R, int L) { return L <= TILE_M; }
 bool convblock_bwd_hosts_qkv(int R, int L) { return L <= TILE_M || convblock_bwd_hosts_tail(R, L); }
 void launch_convblock_bwd(const CbBwdArgs& a, hipStream_t s) {
     if (a.L <= TILE_M) {                    // sample tiles: one workgroup per sample (partial slabs per SAMPLE: convblock_slabs())
-        if (a.qkv) launch_cbb<0, false, 0, true>(a, a.R / a.L, s);
+        if (a.qkv) { if (a.tail == 3) launch_cbb<0, false, 3, true>(a, a.R / a.L, s); else launch_cbb<0, false, 0, true>(a, a.R / a.L, s); }
+        else if (a.tail == 3) launch_cbb<0, false, 3>(a, a.R / a.L, s);
         else launch_cbb<0, false>(a, a.R / a.L, s);
         return;
     }

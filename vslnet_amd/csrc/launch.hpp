@@ -183,16 +183,21 @@ struct CbBwdArgs {
     float* dx0;                    // out (R,128): grad wrt the block input (x + pos)
     float *p_lng[4], *p_lnb[4], *p_dw[4];   // partial slabs [ntiles][128] / [ntiles][128 * 7]
     int R, L;
-    // what the workgroup goes on with, on its own 32 rows of dx0 (whole-tile instantiation only: convblock_bwd_hosts_tail):
+    // what the workgroup goes on with, on its own 32 rows of dx0 (1, 2: whole-tile instantiation only: convblock_bwd_hosts_tail):
     // 0 nothing ; 1 the attention-output backward of the encoder pass below (tail_ao; its dy = dx0) ; 2 the CQConcatenate backward (tail_cq; its dg0 = dx0)
     int tail;
     AttnOutBwdArgs tail_ao;
     CqcatBwdArgs tail_cq;
+    // 3 (sample tiles only): the Embedding linear's data gradient dA (R, K) = dx0 WT3 -- the query pass' conv block goes on with k_linear_bwd_data3's work
+    const uint16_t* tail_lin_WT3;  // split transpose pack, Kc >= K columns (a multiple of 512)
+    float* tail_lin_dA;
+    int tail_lin_K, tail_lin_Kc;
     int qkv;                       // 1: the workgroup first computes dy from qk (whole-tile instantiation only: convblock_bwd_hosts_tail)
     QkvBwdFuse qk;
 };
 void launch_convblock_bwd(const CbBwdArgs& a, hipStream_t s);
 bool convblock_bwd_hosts_tail(int R, int L);      // does launch_convblock_bwd honour CbBwdArgs::tail for this shape?
+bool convblock_bwd_hosts_linear(int R, int L);    // ... and tail 3 (the Embedding linear's data gradient)?
 bool convblock_bwd_hosts_qkv(int R, int L);       // ... and CbBwdArgs::qkv?  (its LN1 partial slabs are then convblock_slabs(R, L) many)
 int convblock_slabs(int R, int L);        // partial slabs per parameter of launch_convblock_bwd (= its grid)
 void launch_attn_fwd(const float* Q, const float* K, const float* V, const float* mask, float* att, float* lse, int B,

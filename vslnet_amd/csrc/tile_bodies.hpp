@@ -167,4 +167,36 @@ __device__ __forceinline__ void cqcat_bwd_tile(const CqcatBwdArgs& a, const floa
     }
 }
 
+// Embedding linear, data gradient (layers_t7.py:81-87 backward): dA (rows r0 .. r0 + nrows - 1, K columns) = G WT3, G = a 32-row tile in LDS (stride LDP;
+// rows >= nrows are computed and dropped).  Called by ALL 8 waves of a 512-thread workgroup: the tile is split into bf16 planes `pl` (3 x [32][D + 8]),
+// wave w owns the 32-column blocks 32 (w & 3) + 256 (w >> 2) + {0, 128} of every 512-column pass.
+__device__ __forceinline__ void linear_bwd_data_tile(const float* lds_g, uint16_t* pl, const uint16_t* __restrict__ WT3, float* __restrict__ dA,
+                                                     int r0, int nrows, int K, int Kc) {
+    constexpr int LD = D + 8;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int e = tid + q * 512, rr = e >> 5, c = (e & 31) * 4;
+        split_store4(pl, LD, TILE_M * LD, rr, c, *reinterpret_cast<const float4*>(lds_g + rr * LDP + c));
+    }
+    __syncthreads();
+    for (int cb = 0; cb < Kc; cb += 512) {
+        f32x16 acc[2];
+        zero_acc(acc);
+        const int col0 = cb + 32 * (w & 3) + 256 * (w >> 2);
+        gemm32pl<2>(pl, LD, TILE_M * LD, D, WT3, Kc, col0, D, acc);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int col = col0 + t * D + (lane & 31);
+            if (col < K) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = acc_row(r, lane);
+                    if (row < nrows) dA[(size_t)(r0 + row) * K + col] = acc[t][r];
+                }
+            }
+        }
+    }
+}
+
 }  // namespace vsl
