@@ -542,7 +542,8 @@ bool query_chain_is_longer(const Plan& p, bool forward) {
 enum { SITE_VIS = 64, SITE_WORD = 65, SITE_CHAR = 66, SITE_CQ_C = 67, SITE_CQ_Q = 68 };
 
 // ------------------------------------------------------------------------------------------------ forward
-void enc_fwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float* xin, const float* mask, int Bn, int app) {
+struct HeadTail { HeadArgs hs, he; const float *x, *vmask; };     // AttnBlockArgs::head_tail
+void enc_fwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float* xin, const float* mask, int Bn, int app, const HeadTail* ht = nullptr) {
     const int R = w.R, L = w.L, H = c.h->cfg.num_heads;
     {
         // the whole conv block + LN1 / QKV in ONE launch (kernels_enc.hip: 12-row recomputed halo)
@@ -564,9 +565,14 @@ void enc_fwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float*
         LAUNCH("convblock_fwd", launch_convblock_fwd(a, c.s));
     }
     if (H == 8 && L <= 256) {      // longer sequences: K / V staged in LDS per 64 queries wins (T = 1024: 3.29 vs 3.33 ms)
-        AttnBlockArgs ab{c.W(w.q), c.W(w.k), c.W(w.v), mask, c.W(w.y[3]), c.P(P.ln2g), c.P(P.ln2b), c.PK(K.o_f), c.P(P.ob),
-                         c.W(w.att), c.W(w.lse), c.W(w.r), c.W(w.h2), c.W(w.out), L, 0,
-                         c.drop(app * 16 + 5), c.drop(app * 16 + 6), c.drop(app * 16 + 7), c.drop(app * 16 + 8)};
+        AttnBlockArgs ab;
+        memset(&ab, 0, sizeof ab);
+        if (!c.dry) {
+            ab = AttnBlockArgs{c.W(w.q), c.W(w.k), c.W(w.v), mask, c.W(w.y[3]), c.P(P.ln2g), c.P(P.ln2b), c.PK(K.o_f), c.P(P.ob),
+                               c.W(w.att), c.W(w.lse), c.W(w.r), c.W(w.h2), c.W(w.out), L, 0,
+                               c.drop(app * 16 + 5), c.drop(app * 16 + 6), c.drop(app * 16 + 7), c.drop(app * 16 + 8)};
+            if (ht) { ab.head_tail = 1; ab.hs = ht->hs; ab.he = ht->he; ab.head_x = ht->x; ab.head_vmask = ht->vmask; }
+        }
         LAUNCH("attn_block_fwd", launch_attn_block_fwd(ab, Bn, c.s));
         return;
     }
@@ -734,12 +740,16 @@ void run_forward(Ctx& c) {
         return;
     }
     enc_fwd(c, P.pe, K.pe, p.p1, c.W(p.gated), io.v_mask, B, 2);
-    enc_fwd(c, P.pe, K.pe, p.p2, c.W(p.p1.out), io.v_mask, B, 3);
     HeadArgs hs{c.W(p.p1.out), c.P(P.sln_g), c.P(P.sln_b), c.PK(K.s0_f), c.P(P.s0b), c.P(P.s1w), c.P(P.s1b), c.W(p.hid_s),
                 c.W(p.lnf_s), io.start_logits};
     HeadArgs he{c.W(p.p2.out), c.P(P.eln_g), c.P(P.eln_b), c.PK(K.e0_f), c.P(P.e0b), c.P(P.e1w), c.P(P.e1b), c.W(p.hid_e),
                 c.W(p.lnf_e), io.end_logits};
-    LAUNCH("head_fwd", launch_head_fwd(hs, he, c.W(p.gated), io.v_mask, R, c.s));
+    // T <= 128: the second pass' attention-block kernel goes on with both span heads on its tiles (one launch less on the dependent chain)
+    static const bool heads_on = !(getenv("VSL_HEADS_FUSED") && getenv("VSL_HEADS_FUSED")[0] == '0');
+    const bool heads_hosted = heads_on && cf.num_heads == 8 && attn_block_fwd_hosts_heads(T);
+    HeadTail ht{hs, he, c.W(p.gated), io.v_mask};
+    enc_fwd(c, P.pe, K.pe, p.p2, c.W(p.p1.out), io.v_mask, B, 3, heads_hosted ? &ht : nullptr);
+    if (!heads_hosted) LAUNCH("head_fwd", launch_head_fwd(hs, he, c.W(p.gated), io.v_mask, R, c.s));
 }
 
 // ------------------------------------------------------------------------------------------------ backward

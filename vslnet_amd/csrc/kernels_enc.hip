@@ -1502,7 +1502,9 @@ int convblock_slabs(int R, int L) { return L <= TILE_M ? R / L : (R + TILE_M - 1
 //   meet in one LDS tile, and the same workgroup finishes the block on it: r = drop(att) + x -> LN2 -> dropout -> Wo GEMM -> dropout -> + r.
 //   Saves att, LSE, r, h2 for the backward exactly like the two-kernel path that serves L > 256.
 // =========================================================================================================
-template <int QB>     // 16-query blocks per wave: 2 = 8 waves (wave = head), 1 = 16 waves (wave = head x query block): twice the waves per SIMD
+// HT (QB = 1 only): the workgroup goes on with both span heads on its tile (AttnBlockArgs::head_tail): threads 0-255 the start head, 256-511 the end
+// head, whose features are the y tile this kernel has just produced; the other waves only join the barriers.
+template <int QB, bool HT = false>     // 16-query blocks per wave: 2 = 8 waves (wave = head), 1 = 16 waves (wave = head x query block): twice the waves per SIMD
 __global__ __launch_bounds__(1024 / QB, QB) void k_attn_block_fwd(AttnBlockArgs a) {
     constexpr int NT = 1024 / QB, NQ = 1024 / NT;      // threads ; float4 items per thread of a 32 x 128 tile
     __shared__ __attribute__((aligned(16))) float Rs[TILE_M * LDP];          // att, then r = drop(att) + x
@@ -1654,17 +1656,31 @@ __global__ __launch_bounds__(1024 / QB, QB) void k_attn_block_fwd(AttnBlockArgs 
     gemm16<QB, 1>(Hs + qoff * LDP, LDP, bf, acc);
     const int col = 16 * h + qi;
     const float bv = Pn[256 + col];
+    float yv[QB][4];
 #pragma unroll
     for (int rb = 0; rb < QB; ++rb)
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const int row = qoff + 16 * rb + 4 * g + rr;
+            yv[rb][rr] = 0.f;
             if (q0 + row < L) {
                 const int r = (int)rowbase + q0 + row;
-                a.y_out[(size_t)r * D + col] = (acc[0][rb][rr] + bv) * drop_mul(a.d5, (uint32_t)(r * D + col)) + Rs[row * LDP + col];
+                yv[rb][rr] = (acc[0][rb][rr] + bv) * drop_mul(a.d5, (uint32_t)(r * D + col)) + Rs[row * LDP + col];
+                a.y_out[(size_t)r * D + col] = yv[rb][rr];
             }
         }
     ESTAMP(6);
+    if constexpr (HT) {
+        static_assert(QB == 1, "the span heads ride on the 16-wave instantiation");
+        __syncthreads();                                   // every wave is through with Hs (the GEMM's A operand)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) Hs[(qoff + 4 * g + rr) * LDP + col] = yv[0][rr];      // the y tile, rows >= L zero
+        __syncthreads();
+        const int grp = tid >> 8;
+        float* tl = Mb + Lp + (grp & 1) * (TILE_M * HEAD_LD + TILE_M * LDP);
+        head_fwd_tile<8>(grp == 0 ? a.hs : a.he, a.head_x, a.head_vmask, tl, tl + TILE_M * HEAD_LD, grp == 1 ? Hs : nullptr,
+                      rowbase + q0, min(TILE_M, L - q0), tid & 255, grp < 2);
+    }
 }
 void launch_attn_block_fwd(const AttnBlockArgs& a, int B, hipStream_t s) {
     // 16 waves (wave = head x 16-query block) up to L = 128, 8 waves (wave = head, two query blocks) beyond: measured ms/step 8 / 16 waves
@@ -1672,7 +1688,12 @@ void launch_attn_block_fwd(const AttnBlockArgs& a, int B, hipStream_t s) {
     const bool w16 = a.L <= 128;
     const dim3 grid((a.L + TILE_M - 1) / TILE_M, B);
     const size_t shm = (size_t)((a.L + 15) & ~15) * sizeof(float);
-    if (w16) VSL_LAUNCH(k_attn_block_fwd<1>, grid, dim3(1024), shm, s, a);
+    if (w16 && a.head_tail) {
+        const size_t shm_t = shm + (size_t)2 * (TILE_M * HEAD_LD + TILE_M * LDP) * sizeof(float);
+        static size_t ok = 0;
+        ensure_dynamic_lds((const void*)k_attn_block_fwd<1, true>, shm_t, ok, "k_attn_block_fwd");
+        VSL_LAUNCH((k_attn_block_fwd<1, true>), grid, dim3(1024), shm_t, s, a);
+    } else if (w16) VSL_LAUNCH(k_attn_block_fwd<1>, grid, dim3(1024), shm, s, a);
     else VSL_LAUNCH(k_attn_block_fwd<2>, grid, dim3(512), shm, s, a);
     static int left = 3;
     if (edbg_on() && B > 16) edbg_report("attn_block_fwd", 7, s, left);

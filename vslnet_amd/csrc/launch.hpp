@@ -212,8 +212,14 @@ struct AttnBlockArgs {
     float *att, *lse, *r_out, *h2_out, *y_out;     // saved: att (R,128), LSE (B,H,L), r, h2 ; y = block output
     int L, b_off;
     Drop d2, d3, d4, d5;
+    // head_tail (L <= 128 only: attn_block_fwd_hosts_heads): the workgroup goes on with both span heads on its 32 rows (tile_bodies.hpp
+    // head_fwd_tile) -- the second predictor pass: hs.feat = the first pass' output (memory), he's features = this kernel's y tile
+    int head_tail;
+    HeadArgs hs, he;
+    const float *head_x, *head_vmask;
 };
 void launch_attn_block_fwd(const AttnBlockArgs& a, int B, hipStream_t s);
+inline bool attn_block_fwd_hosts_heads(int L) { return L <= 128; }
 void launch_cq_score(const float* C, const float* Qf, const float* qmask, const float* w4C, const float* w4Q,
                      const float* w4mlu, float* S, float* Srow, int B, int T, int Lq, int b_off, Drop dc, Drop dq,
                      hipStream_t s);

@@ -167,6 +167,95 @@ __device__ __forceinline__ void cqcat_bwd_tile(const CqcatBwdArgs& a, const floa
     }
 }
 
+// One span head (a14, layers_t7.py:328-337, 347-352) on a 32-row tile: logits = mask_logits(Conv1D(d->1)(relu(Conv1D(2d->d)([LN(feat), x])))).
+// Run by ONE 256-thread group of a wider workgroup (lt = thread index inside the group; `active` = false: only the barriers), so that two groups do
+// the start and the end head side by side.  lds_feat != nullptr: the feature tile is in LDS (stride LDP) -- the end head's features are what the
+// hosting attention-block kernel has just produced.  grow0 = global row of tile row 0, nvalid = rows of the tile that exist.
+// As: [32][HEAD_LD] ; Hd: [32][LDP].
+// KB = weight fragments in flight per wave (k blocks of 8): the 16-wave host has 128 registers per lane.
+constexpr int HEAD_LD = 2 * D + 4;
+template <int KB>
+__device__ __forceinline__ void head_fwd_tile(const HeadArgs& a, const float* __restrict__ x, const float* __restrict__ vmask, float* As, float* Hd,
+                                              const float* lds_feat, size_t grow0, int nvalid, int lt, bool active) {
+    const int lw = lt >> 6, lane = lt & 63;
+    BFrag<1, KB> bf;
+    if (active) {
+        float4 fv[4], xv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = lt + q * 256, rr = e >> 5, c = (e & 31) * 4;
+            fv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            xv[q] = fv[q];
+            if (rr < nvalid) {
+                fv[q] = lds_feat ? *reinterpret_cast<const float4*>(lds_feat + rr * LDP + c) : *reinterpret_cast<const float4*>(a.feat + (grow0 + rr) * D + c);
+                xv[q] = *reinterpret_cast<const float4*>(x + (grow0 + rr) * D + c);
+            }
+        }
+        bfrag_load(bf, a.W0pack, D, 32 * lw, 0, 0, 2 * D / 8);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = lt + q * 256, rr = e >> 5, c = (e & 31) * 4;
+            *reinterpret_cast<float4*>(&As[rr * HEAD_LD + c]) = fv[q];
+            *reinterpret_cast<float4*>(&As[rr * HEAD_LD + D + c]) = xv[q];
+        }
+    }
+    __syncthreads();
+    if (active && a.ln_g) {                    // LayerNorm on the encoder features (:347-348), 8 lanes per row (as ln_tile)
+        const int sub = lt & 7, r = lt >> 3;
+        float* row = As + r * HEAD_LD + sub * 4;
+        float4 v[4];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = *reinterpret_cast<const float4*>(row + 32 * j); s += sum4(v[j]); }
+        const float mu = grp8_sum(s) * (1.0f / D);
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j].x -= mu; v[j].y -= mu; v[j].z -= mu; v[j].w -= mu;
+            q += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
+        }
+        const float rstd = rsqrtf(grp8_sum(q) * (1.0f / D) + LN_EPS);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 gv = *reinterpret_cast<const float4*>(a.ln_g + sub * 4 + 32 * j), bv = *reinterpret_cast<const float4*>(a.ln_b + sub * 4 + 32 * j);
+            float4 o;
+            o.x = v[j].x * rstd * gv.x + bv.x; o.y = v[j].y * rstd * gv.y + bv.y;
+            o.z = v[j].z * rstd * gv.z + bv.z; o.w = v[j].w * rstd * gv.w + bv.w;
+            *reinterpret_cast<float4*>(row + 32 * j) = o;
+            if (a.lnfeat && r < nvalid) *reinterpret_cast<float4*>(a.lnfeat + (grow0 + r) * D + sub * 4 + 32 * j) = o;
+        }
+    }
+    __syncthreads();
+    if (active) {
+        f32x16 acc[1];
+        zero_acc(acc);
+        gemm32p<1, KB>(As, HEAD_LD, 2 * D, a.W0pack, D, 32 * lw, 0, acc, bf);
+        const int col = 32 * lw + (lane & 31);
+        const float bv = a.b0[col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = acc_row(r, lane);
+            const float hv = fmaxf(acc[0][r] + bv, 0.f);
+            Hd[row * LDP + col] = hv;
+            if (row < nvalid) a.hid[(grow0 + row) * D + col] = hv;
+        }
+    }
+    __syncthreads();
+    if (active) {
+        const int rr = lt >> 3, sub = lt & 7;
+        const float* row = Hd + rr * LDP + sub * 4;
+        float d = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 fv = *reinterpret_cast<const float4*>(row + 32 * j);
+            const float4 wv = *reinterpret_cast<const float4*>(a.w1 + sub * 4 + 32 * j);
+            d += fv.x * wv.x + fv.y * wv.y + fv.z * wv.z + fv.w * wv.w;
+        }
+        d = grp8_sum(d);
+        if (sub == 0 && rr < nvalid) a.logits[grow0 + rr] = d + a.b1[0] + (1.f - vmask[grow0 + rr]) * MASK_VALUE;
+    }
+}
+
 // Embedding linear, data gradient (layers_t7.py:81-87 backward): dA (rows r0 .. r0 + nrows - 1, K columns) = G WT3, G = a 32-row tile in LDS (stride LDP;
 // rows >= nrows are computed and dropped).  Called by ALL 8 waves of a 512-thread workgroup: the tile is split into bf16 planes `pl` (3 x [32][D + 8]),
 // wave w owns the 32-column blocks 32 (w & 3) + 256 (w >> 2) + {0, 128} of every 512-column pass.
