@@ -8,7 +8,11 @@ block for 128 < L <= 256, k_wgrad3 for bfloat16 features, k_linear_fwd for embed
 when the caller leaves the mask sum to the device.)
 
 VSL_RNN_FUSED=0 is the third: the rnn head as chunked launches over three streams -- what batches of 81 .. 256 samples take -- instead of the
-one-launch dataflow pipeline (k_rnn_fwd / k_rnn_bwd) every shape of the suite selects."""
+one-launch dataflow pipeline (k_rnn_fwd / k_rnn_bwd) every shape of the suite selects.
+
+Round 5 added two of the same kind: VSL_QKV_FUSED=0 (k_qkv_bwd as its own launch instead of inside the conv block's backward kernel: what ragged row
+tiles and L > 256 take) and VSL_HEADS_FUSED=0 (k_head_fwd instead of the tail of the second predictor pass' attention-block kernel: what T > 128
+takes) -- the training suite's whole-tile shapes select the fused paths, so it is re-run once with both off."""
 import os
 import subprocess
 import sys
@@ -30,5 +34,12 @@ def test_parity_suite_single_stream_and_forced_lstm_groups():
 def test_rnn_suite_with_the_chunked_launches():
     e = dict(os.environ, VSL_RNN_FUSED='0')
     r = subprocess.run([sys.executable, '-m', 'pytest', '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider', 'tests/test_hip_rnn.py'],
+                       cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_training_suite_with_the_unfused_launches():
+    e = dict(os.environ, VSL_QKV_FUSED='0', VSL_HEADS_FUSED='0')
+    r = subprocess.run([sys.executable, '-m', 'pytest', '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider', 'tests/test_hip_training.py', 'tests/test_hip_parity.py'],
                        cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
