@@ -110,6 +110,14 @@ def test_overlapped_exchange_equals_plain_backward_on_one_rank():
     assert torch.equal(out[0], out[1])
 
 
+def _same_loss(over, plain):
+    """The two runs differ in ONE place: the plain run clips by the norm the backward's reduction left behind (`norm_from_backward`), the run under a
+    communicator by `k_sqsum` over the exchanged bucket -- the same sum of squares in another order, i.e. a clip factor that may differ in its last
+    bit, and parameters that then differ by an ulp per step.  The printed loss (5 decimals) is therefore compared to 1e-5 relative + its print
+    rounding, not for equality (equality had held until round 5 by rounding luck); a dispatch-order violation of the fused rnn head shows as NaN."""
+    assert over == over and abs(over - plain) <= 1e-5 * abs(plain) + 1.5e-5, (over, plain)
+
+
 def _bench(extra_env, *args):
     env = dict(os.environ)
     env.update(extra_env)
@@ -130,7 +138,7 @@ def test_bench_under_a_one_rank_rccl_group_takes_the_overlapped_exchange():
     over = _bench(dist_env)
     assert plain['rccl_ranks'] == 0 and over['rccl_ranks'] == 1
     assert 'allreduce_us' in over and 'step_without_allreduce_ms' in over and over['allreduce'].startswith('two calls')
-    assert over['config']['loss'] == plain['config']['loss'], (over['config']['loss'], plain['config']['loss'])
+    _same_loss(over['config']['loss'], plain['config']['loss'])
     assert over['ms_per_step'] < 3.0 * plain['ms_per_step']
     print('[one-rank exchange] plain %.4f ms/step, under RCCL %.4f ms/step (exposed %.1f us)' % (plain['ms_per_step'], over['ms_per_step'], over['allreduce_us']))
 
@@ -147,7 +155,7 @@ def test_fused_rnn_head_at_its_largest_batch_beside_a_communicator():
                 'WORLD_SIZE': '1', 'LOCAL_RANK': '0', 'HSA_ENABLE_IPC_MODE_LEGACY': '0'}
     over = _bench(dist_env, *args)
     assert over['rccl_ranks'] == 1 and over['steps'] == 50
-    assert over['config']['loss'] == plain['config']['loss'], (over['config']['loss'], plain['config']['loss'])
+    _same_loss(over['config']['loss'], plain['config']['loss'])
 
 
 def test_engine_refuses_a_process_group_with_too_few_hardware_queues(monkeypatch):
