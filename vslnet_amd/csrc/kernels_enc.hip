@@ -23,7 +23,7 @@ namespace vsl {
 __device__ long long g_stamps_e[32];
 __device__ int g_dbg_on_e = 0;
 #ifdef VSL_STAMPS       // see kernels_bwd.hip: stamps are a separate build
-#define ESTAMP(k) do { if (g_dbg_on_e && blockIdx.x == 0 && threadIdx.x == 0) g_stamps_e[k] = clock64(); } while (0)
+#define ESTAMP(k) do { if (g_dbg_on_e && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_stamps_e[k] = clock64(); } while (0)
 #else
 #define ESTAMP(k) do { } while (0)
 #endif
