@@ -45,3 +45,16 @@ def test_the_two_tolerance_edge_shapes_of_the_round_4_sweep():
     all100 = fuzz_shapes(100, 2026)
     for i in (17, 53):
         check_shape_against_oracle(all100[i], scaled_bias_floor=True)
+
+
+# Whole row tiles (T a multiple of 32) select the fused paths of round 5 -- the conv block's backward computing its own incoming gradient
+# (k_qkv_bwd's work) on the 56-row window, its tails, the span heads inside the second pass' attention block for T <= 128 and as their own
+# launch beyond -- at 1 to 8 tiles per sample, with sample borders inside and at the edge of a window.
+WHOLE_TILE_SHAPES = [dict(name='tiles T=%d B=%d' % (T, B), B=B, T=T, Lq=Lq, Lc=Lc, Dv=Dv, char_dim=50, char_size=40, word_table=False)
+                     for (B, T, Lq, Lc, Dv) in [(3, 64, 20, 10, 64), (2, 96, 7, 5, 100), (5, 128, 32, 10, 36), (1, 160, 1, 4, 64), (2, 224, 13, 17, 1024), (1, 256, 33, 10, 500)]]
+
+
+@pytest.mark.parametrize('shape', WHOLE_TILE_SHAPES, ids=lambda s: s['name'].replace(' ', '_'))
+def test_whole_tile_shapes_against_oracle(shape):
+    from tests.test_hip_training import check_shape_against_oracle
+    check_shape_against_oracle(shape, scaled_bias_floor=True)
