@@ -8,12 +8,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libvslnet_hip.so')
-SOURCES = ['kernels_fwd.hip', 'kernels_bwd.hip', 'kernels_enc.hip', 'kernels_wgrad.hip', 'kernels_split.hip', 'kernels_lstm.hip', 'api.hip']
+SOURCES = ['kernels_fwd.hip', 'kernels_bwd.hip', 'kernels_enc.hip', 'kernels_wgrad.hip', 'kernels_split.hip', 'kernels_lstm.hip', 'kernels_query.hip', 'api.hip']
 HEADERS = ['common.hpp', 'launch.hpp', os.path.join('..', '..', 'include', 'vslnet_hip.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value', '-Wno-pass-failed']
 # per-file flags.  kernels_wgrad.hip: the split-bf16 loop is hand-scheduled scalar fp32 code; SLP vectorisation turns its subtractions into
 # v_pk_add_f32 + v_mov packing, which is slower beside MFMAs (MI355X_MICROARCH.md, price of fillers)
-FILE_FLAGS = {'kernels_wgrad.hip': ['-fno-slp-vectorize'], 'kernels_split.hip': ['-fno-slp-vectorize'], 'kernels_enc.hip': ['-fno-slp-vectorize']}
+FILE_FLAGS = {'kernels_wgrad.hip': ['-fno-slp-vectorize'], 'kernels_split.hip': ['-fno-slp-vectorize'], 'kernels_enc.hip': ['-fno-slp-vectorize'], 'kernels_query.hip': ['-fno-slp-vectorize']}
 
 
 def _hipcc():

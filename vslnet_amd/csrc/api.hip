@@ -659,11 +659,36 @@ void run_forward(Ctx& c) {
     LAUNCH("embed_fwd", launch_embed_fwd(io.word_ids, io.char_ids, wt ? c.P(P.unk) : io.pad_vec, c.P(P.unk) + (wt ? cf.word_dim : 0), wt ? c.P(P.unk) + 2 * cf.word_dim : io.glove_vec, c.P(P.char_tab), char_ptrs(c), c.PK(K.ccw_img), c.W(p.E),
                      reinterpret_cast<int8_t*>(c.W(p.argpos)), Rq, p.Lc, cf.word_dim, cf.char_dim, c.drop(SITE_WORD),
                      c.drop(SITE_CHAR), c.s));
+    static const bool qfuse_on = !(getenv("VSL_QUERY_FUSED") && getenv("VSL_QUERY_FUSED")[0] == '0');
+    if (qfuse_on && query_fused_ok(Lq, cf.num_heads)) {
+        // the rest of the query branch in ONE sample-local launch (kernels_query.hip)
+        QueryFwdArgs qa;
+        memset(&qa, 0, sizeof qa);
+        if (!c.dry) {
+            const EncP& E = P.fe; const EncPk& EK = K.fe; const EncWs& w = p.qe;
+            qa.E = c.W(p.E); qa.Wemb3 = reinterpret_cast<const uint16_t*>(c.PK(K.emb_f3)); qa.b_emb = c.P(P.emb_b); qa.qf = c.W(p.qf);
+            qa.pos = c.P(E.pos); qa.x0 = c.W(w.x0);
+            for (int i = 0; i < 4; ++i) {
+                qa.W3[i] = reinterpret_cast<const uint16_t*>(c.PK(EK.pw_f3[i]));
+                qa.ln_g[i] = c.P(E.lng[i]); qa.ln_b[i] = c.P(E.lnb[i]); qa.dw_w[i] = c.P(E.dw[i]); qa.pw_b[i] = c.P(E.pwb[i]);
+                qa.y[i] = c.W(w.y[i]); qa.u[i] = c.W(w.u[i]); qa.relu_mask[i] = reinterpret_cast<uint32_t*>(c.W(w.mask[i])); qa.dp[i] = c.drop(16 + i);
+            }
+            qa.Wqkv3 = reinterpret_cast<const uint16_t*>(c.PK(EK.qkv_f3)); qa.Wo3 = reinterpret_cast<const uint16_t*>(c.PK(EK.o_f3));
+            qa.ln1_g = c.P(E.ln1g); qa.ln1_b = c.P(E.ln1b); qa.bq = c.P(E.qb); qa.bk = c.P(E.kb); qa.bv = c.P(E.vb);
+            qa.h1 = c.W(w.h1); qa.q = c.W(w.q); qa.k = c.W(w.k); qa.v = c.W(w.v); qa.d1 = c.drop(16 + 4);
+            qa.mask = io.q_mask; qa.ln2_g = c.P(E.ln2g); qa.ln2_b = c.P(E.ln2b); qa.bo = c.P(E.ob);
+            qa.att = c.W(w.att); qa.lse = c.W(w.lse); qa.r = c.W(w.r); qa.h2 = c.W(w.h2); qa.out = c.W(w.out);
+            qa.d2 = c.drop(16 + 5); qa.d3 = c.drop(16 + 6); qa.d4 = c.drop(16 + 7); qa.d5 = c.drop(16 + 8);
+            qa.EW = cf.word_dim + 100; qa.L = Lq; qa.b_off = 0;
+        }
+        LAUNCH("query_fwd", launch_query_fwd(qa, B, c.s));
+    } else {
     if ((cf.word_dim + 100) % 16 == 0)
         LAUNCH("linear_fwd", launch_linear_fwd3(c.W(p.E), reinterpret_cast<const uint16_t*>(c.PK(K.emb_f3)), c.P(P.emb_b), c.W(p.qf), Rq, cf.word_dim + 100, c.s));
     else          // a width the 16-wide K steps of the split kernel do not tile: the fp32-input MFMA kernel (K streamed in chunks)
         LAUNCH("linear_fwd", launch_linear_fwd(c.W(p.E), c.PK(K.emb_f), c.P(P.emb_b), c.W(p.qf), Rq, cf.word_dim + 100, c.s));
     enc_fwd(c, P.fe, K.fe, p.qe, c.W(p.qf), io.q_mask, B, 1);
+    }
     c.s = c.main;
     c.order(sq, c.main);                   // join
     if (split3) c.order(sp, c.main);       // the remaining packs (long done)
@@ -1399,7 +1424,7 @@ int vsl_create(const vsl_config* cfg, vsl_handle* out) {
         const ModelPk& K = h->K;
         std::vector<int> dead;
         auto enc = [&](const EncPk& e) {
-            dead.push_back(e.o_f3); dead.push_back(e.o_t3);
+            if (&e != &K.fe) { dead.push_back(e.o_f3); dead.push_back(e.o_t3); }      // (the feature encoder's: read by the sample-local query kernels, kernels_query.hip)
             for (int i = 0; i < 4; ++i) { dead.push_back(e.pw_f[i]); dead.push_back(e.pw_t[i]); }
             dead.push_back(e.qkv_f); dead.push_back(e.qkv_t);
         };

@@ -1,0 +1,386 @@
+// The QUERY branch of VSLNet as sample-local kernels (gfx950): one workgroup per sample, the whole 32-row window of a sample's words in
+// registers, ONE fp32 tile (17 KB) of LDS.
+//
+// Every kernel of the query branch is sample-local: Lq <= 32 words, and nothing on a word's path needs another sample -- Embedding.linear
+// (/root/reference/model/layers_t7.py:83-88), FeatureEncoder at L = Lq (:193-205: positional rows, the four conv layers :131-140, the
+// attention block :167-190), applied at /root/reference/model/VSLNet_t7.py:54,56.  As row-tile launches these were 3 (forward) / 4 (backward)
+// kernels of 64 - 160 workgroups with 36 - 125 KB of LDS each, which cannot sit beside the video chain's 142 - 144 KB workgroups (one per CU,
+// 256 of them): whichever chain reached a CU second waited a whole round of the other (profiles/r05_notes.md section 6).  Here a sample's
+// window lives in REGISTERS and the workgroup asks for 17 KB of LDS and 4 waves, so it fits in the shadow of a conv-block workgroup
+// (163 840 - 144 320 = 19 520 B free, two wave slots per SIMD free).
+//
+// "T layout".  All products are computed TRANSPOSED on the matrix cores:  Y^T[n][m] = sum_k W[n][k] X[m][k]  with the WEIGHT as the MFMA's
+// A operand (M dimension = 32 output channels of the wave) and the ACTIVATION as its B operand (N dimension = the sample's 32 rows):
+//   * wave w owns output channels [32 w, 32 w + 32); lane (m = lane & 31, h = lane >> 5) owns row m;
+//   * an accumulator register r of lane (m, h) is element [row m][channel 32 w + nl(r, h)], nl(r, h) = (r & 3) + 8 (r >> 2) + 4 h
+//     (the C/D map of v_mfma_f32_32x32x*): 16 channels of its row, i.e. the residual stream x of a sample is ONE f32x16 per lane;
+//   * the activation operand of the next product wants lane (m, h) to supply row m for a k that only has to match the weight operand's:
+//     the window passes through the LDS tile once per product ([row][channel], 16-byte writes from the accumulator layout, 32-byte
+//     reads of 8 consecutive k), and LayerNorm / the depthwise conv read the same tile by rows / by channel columns;
+//   * per-head attention never leaves the wave: head = 16 of the wave's 32 channels, S^T = K Q^T and the P V product take their operands
+//     straight from the accumulator registers (the lane's 16 channels / 16 keys ARE the contraction pairs (8 a + b, 8 a + 4 + b) of the two
+//     half-waves), only V passes through the wave's own 32 columns of the tile.
+// GEMMs run at fp32 grade on the bf16 matrix cores (common.hpp: 3-way split, six products) against the split packs the row-tile kernels
+// read (PackJob type 6 / 7): the weight fragment of lane (n, h) is one 16-byte load per plane, the activation fragment is split in
+// registers (44 vector instructions per K = 16 step).  The 20 x 20 attention products use the fp32-input v_mfma_f32_32x32x2_f32.
+#include "common.hpp"
+#include "launch.hpp"
+
+namespace vsl {
+
+constexpr int QT = 256;                         // threads per workgroup: 4 waves, one per SIMD
+constexpr int QROWS = 32;                       // rows of a sample window (L <= 32)
+
+__device__ __forceinline__ int nl(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// accumulator layout -> LDS tile [row][channel] (all 32 rows: rows >= L carry finite don't-care values)
+__device__ __forceinline__ void d2tile(const f32x16& x, float* __restrict__ T, int w, int m, int h) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+        *reinterpret_cast<float4*>(T + m * LDP + 32 * w + 8 * a + 4 * h) = make_float4(x[4 * a], x[4 * a + 1], x[4 * a + 2], x[4 * a + 3]);
+}
+// accumulator layout -> (rows, 128) row-major memory, rows < L ; g = row 0 of the sample
+__device__ __forceinline__ void d2global(const f32x16& x, float* __restrict__ g, int w, int m, int h, int L) {
+    if (m < L) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+            *reinterpret_cast<float4*>(g + (size_t)m * D + 32 * w + 8 * a + 4 * h) = make_float4(x[4 * a], x[4 * a + 1], x[4 * a + 2], x[4 * a + 3]);
+    }
+}
+// (rows, 128) row-major memory -> accumulator layout (rows >= L: zero)
+__device__ __forceinline__ void global2d(f32x16& x, const float* __restrict__ g, int w, int m, int h, int L) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const float4 v = m < L ? *reinterpret_cast<const float4*>(g + (size_t)m * D + 32 * w + 8 * a + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+        x[4 * a] = v.x; x[4 * a + 1] = v.y; x[4 * a + 2] = v.z; x[4 * a + 3] = v.w;
+    }
+}
+// a per-channel vector (bias, ...) in accumulator layout
+__device__ __forceinline__ void vec2d(f32x16& x, const float* __restrict__ v, int w, int h) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const float4 t = *reinterpret_cast<const float4*>(v + 32 * w + 8 * a + 4 * h);
+        x[4 * a] = t.x; x[4 * a + 1] = t.y; x[4 * a + 2] = t.z; x[4 * a + 3] = t.w;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// acc (32 channels x 32 rows, T layout) += sum over K = 16 steps s0 .. s0 + ns - 1 of the split pack:
+//   weight operand  : lane (n = lane & 31, h) reads column `col0 + n` of each plane, k = 16 s + 8 h .. + 7 (one 16-byte load per plane),
+//                     GS3_NB steps ahead in a register ring;
+//   activation      : lane (m, h) reads T[m][16 (s - s0) + 8 h .. + 7] (two ds_read_b128, one step ahead) and splits it in registers.
+// Two alternating accumulators: consecutive MFMAs never wait for each other's result.
+// ---------------------------------------------------------------------------------------------------------
+struct AF3 { u32x4_t t[3]; };
+__device__ __forceinline__ void split8(const float4& x, const float4& y, AF3& f) {
+    uint32_t h0, m0, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
+    split3(x.x, x.y, h0, m0, l0);
+    split3(x.z, x.w, h1, m1, l1);
+    split3(y.x, y.y, h2, m2, l2);
+    split3(y.z, y.w, h3, m3, l3);
+    f.t[0] = u32x4_t{h0, h1, h2, h3};
+    f.t[1] = u32x4_t{m0, m1, m2, m3};
+    f.t[2] = u32x4_t{l0, l1, l2, l3};
+}
+__device__ __forceinline__ void tgemm(const float* __restrict__ T, const uint16_t* __restrict__ W3, size_t plane, int ncols, int col0, int s0, int ns,
+                                      f32x16& acc) {
+    const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
+    const float* tr = T + m * LDP + 8 * h;
+    const uint16_t* wl = W3 + ((size_t)s0 * ncols + col0 + m) * 16 + 8 * h;
+    const size_t sstep = (size_t)ncols * 16;
+    Frag3 ring[GS3_NB];
+    auto wload = [&](int s, Frag3& f) {
+        const uint16_t* p = wl + (size_t)min(s, ns - 1) * sstep;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) f.t[q] = *reinterpret_cast<const u32x4_t*>(p + q * plane);
+    };
+    static_for<0, GS3_NB>([&](auto uc) { wload(decltype(uc)::value, ring[decltype(uc)::value]); });
+    float4 xa[2], xb[2];
+    auto aread = [&](int s, float4& p, float4& q) {
+        const float* t = tr + 16 * min(s, ns - 1);
+        p = *reinterpret_cast<const float4*>(t);
+        q = *reinterpret_cast<const float4*>(t + 4);
+    };
+    aread(0, xa[0], xb[0]);
+    f32x16 acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+    for (int sb = 0; sb < ns; sb += GS3_NB)
+        static_for<0, GS3_NB>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            const int s = sb + u;
+            if (s < ns) {
+                AF3 af;
+                split8(xa[u & 1], xb[u & 1], af);
+                aread(s + 1, xa[(u + 1) & 1], xb[(u + 1) & 1]);
+                constexpr int TW[6] = {1, 0, 2, 0, 1, 0}, TX[6] = {1, 2, 0, 1, 0, 0};      // (weight term, activation term): mm, hl, lh, hm, mh, hh
+#pragma unroll
+                for (int p = 0; p < 6; ++p) {
+                    if (p & 1) acc2 = mfma_bf16(ring[u].t[TW[p]], af.t[TX[p]], acc2);
+                    else acc = mfma_bf16(ring[u].t[TW[p]], af.t[TX[p]], acc);
+                }
+                wload(s + GS3_NB, ring[u]);
+            }
+        });
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// row phase: 8 lanes per row (lane sub owns float4 columns 4 sub + 32 j), 32 rows per pass of the 256 threads.
+// In place on the tile: T[row] <- LN(T[row]) * dropout for row < L, zeros for row >= L (the conv's zero padding / a defined GEMM
+// operand); the RAW row (the residual stream) goes to `raw_out`, the result to `ln_out` (both nullable, rows < L).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void row_ln(float* __restrict__ T, int L, const float* __restrict__ g, const float* __restrict__ b, const Drop& dp,
+                                       int grow0, float* __restrict__ raw_out, float* __restrict__ ln_out) {
+    const int sub = threadIdx.x & 7, r = threadIdx.x >> 3;
+    float* row = T + r * LDP + sub * 4;
+    if (r >= L) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(row + 32 * j) = z;
+        return;
+    }
+    float4 v[4];
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = *reinterpret_cast<const float4*>(row + 32 * j); sum += sum4(v[j]); }
+    if (raw_out) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(raw_out + (size_t)r * D + sub * 4 + 32 * j) = v[j];
+    }
+    const float mu = grp8_sum(sum) * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        v[j].x -= mu; v[j].y -= mu; v[j].z -= mu; v[j].w -= mu;
+        q += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
+    }
+    const float rstd = rsqrtf(grp8_sum(q) * (1.0f / D) + LN_EPS);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float4 gv = *reinterpret_cast<const float4*>(g + sub * 4 + 32 * j);
+        const float4 bv = *reinterpret_cast<const float4*>(b + sub * 4 + 32 * j);
+        float4 o;
+        o.x = v[j].x * rstd * gv.x + bv.x; o.y = v[j].y * rstd * gv.y + bv.y;
+        o.z = v[j].z * rstd * gv.z + bv.z; o.w = v[j].w * rstd * gv.w + bv.w;
+        if (dp.thresh) {
+            const uint32_t base = (uint32_t)((grow0 + r) * D + sub * 4 + 32 * j);
+            o.x *= drop_keep_scale(dp, base); o.y *= drop_keep_scale(dp, base + 1);
+            o.z *= drop_keep_scale(dp, base + 2); o.w *= drop_keep_scale(dp, base + 3);
+        }
+        if (ln_out) *reinterpret_cast<float4*>(ln_out + (size_t)r * D + sub * 4 + 32 * j) = o;
+        *reinterpret_cast<float4*>(row + 32 * j) = o;
+    }
+}
+
+// =========================================================================================================
+// k_query_fwd: Embedding.linear -> + positional rows -> 4 conv layers -> LN1 / q,k,v -> attention (8 heads, two per wave) -> output block.
+// Saves exactly what the row-tile kernels save (qf, x0, y0..3, u0..3, ReLU bits, h1, q, k, v, LSE, att, r, h2, out): the backward and the
+// weight-gradient launches do not care which forward produced them.
+// =========================================================================================================
+__global__ __launch_bounds__(QT, 2) void k_query_fwd(QueryFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* T = smem;                            // [32][LDP]
+    float* Mb = T + QROWS * LDP;                // key bias of the sample
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, m = lane & 31, h = lane >> 5;
+    const int L = a.L, b = blockIdx.x, row0 = b * L;
+    const size_t g0 = (size_t)row0 * D;
+    if (tid < QROWS) Mb[tid] = tid < L ? (1.0f - a.mask[row0 + tid]) * MASK_VALUE : MASK_VALUE;
+
+    // ---- Embedding.linear (:86-88): x = E W^T + b, E staged through the tile in 128-column chunks
+    f32x16 X;
+    {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const int EW = a.EW, Kp = (EW + 15) & ~15;
+        const size_t plane = pack3_plane(Kp, D);
+        const int sub = tid & 7, rr = tid >> 3;
+        for (int c0 = 0; c0 < EW; c0 += D) {
+            float4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = c0 + sub * 4 + 32 * j;
+                v[j] = (rr < L && c < EW) ? *reinterpret_cast<const float4*>(a.E + (size_t)(row0 + rr) * EW + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if (c0) __syncthreads();            // the previous chunk's readers are done
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(T + rr * LDP + sub * 4 + 32 * j) = v[j];
+            __syncthreads();
+            const int ns = (min(D, Kp - c0)) >> 4;
+            tgemm(T, a.Wemb3, plane, D, 32 * w, c0 >> 4, ns, acc);
+        }
+        f32x16 bv, pv;
+        vec2d(bv, a.b_emb, w, h);
+        global2d(pv, a.pos, w, m, h, L);        // positional rows 0 .. L - 1 (:202)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += bv[r];
+        if (a.qf) d2global(acc, a.qf + g0, w, m, h, L);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) X[r] = acc[r] + pv[r];
+    }
+    __syncthreads();
+
+    // ---- four conv layers (:133-139): x <- x + drop(relu(pointwise(depthwise7(LN(x)))))
+    const size_t plane_pw = pack3_plane(D, D);
+    static_for<0, 4>([&](auto LC) {
+        constexpr int l = decltype(LC)::value;
+        d2tile(X, T, w, m, h);
+        __syncthreads();
+        {
+            const Drop nodrop{0u, 0u, 1.f, 0u};
+            row_ln(T, L, a.ln_g[l], a.ln_b[l], nodrop, row0, (l == 0 ? a.x0 : a.y[l > 0 ? l - 1 : 0]) + g0, nullptr);
+        }
+        __syncthreads();
+        {   // depthwise conv k = 7 along the sequence: thread = (channel, half of the rows); rows outside [0, L) are zeros in the tile
+            const int c = tid & 127, os = 16 * (tid >> 7);
+            float wk[DWK], win[16 + 2 * HALO], uo[16];
+#pragma unroll
+            for (int k = 0; k < DWK; ++k) wk[k] = a.dw_w[l][c * DWK + k];
+#pragma unroll
+            for (int i = 0; i < 16 + 2 * HALO; ++i) {
+                const int r = os - HALO + i;
+                win[i] = (r >= 0 && r < QROWS) ? T[r * LDP + c] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float u = 0.f;
+#pragma unroll
+                for (int k = 0; k < DWK; ++k) u += wk[k] * win[i + k];
+                uo[i] = u;
+            }
+            __syncthreads();                    // every window is in registers
+            float* ug = a.u[l] + g0 + c;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                T[(os + i) * LDP + c] = uo[i];
+                if (os + i < L) ug[(size_t)(os + i) * D] = uo[i];       // saved: A operand of the weight gradient
+            }
+        }
+        __syncthreads();
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        tgemm(T, a.W3[l], plane_pw, D, 32 * w, 0, D / 16, acc);
+        f32x16 bv;
+        vec2d(bv, a.pw_b[l], w, h);
+        const Drop dp = a.dp[l];
+        uint32_t bits[2] = {0u, 0u};            // ReLU decisions of this lane's channels inside the two 16-channel groups of the wave
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float z = acc[r] + bv[r];
+            float av = fmaxf(z, 0.f);
+            if (dp.thresh) av *= drop_keep_scale(dp, (uint32_t)((row0 + m) * D + 32 * w + nl(r, h)));
+            X[r] += av;
+            if (z > 0.f) bits[r >> 3] |= 1u << (nl(r, h) & 15);
+        }
+        {   // (R, 4) uint32 words seen as uint16: [row][16-channel group]; the two half-waves hold disjoint bits of both groups
+            auto orr = [](uint32_t p, uint32_t q) { return p | q; };
+            const unsigned u0 = bits[0], u1 = bits[1];
+            auto r0 = __builtin_amdgcn_permlane32_swap(u0, u0, false, false);
+            auto r1 = __builtin_amdgcn_permlane32_swap(u1, u1, false, false);
+            const uint32_t g0b = orr(r0[0], r0[1]), g1b = orr(r1[0], r1[1]);
+            uint16_t* mk = reinterpret_cast<uint16_t*>(a.relu_mask[l]);
+            if (m < L) mk[(size_t)(row0 + m) * 8 + 2 * w + h] = (uint16_t)(h ? g1b : g0b);
+        }
+        __syncthreads();                        // every wave is through with the tile
+    });
+
+    // ---- a8 first half (:168-173): h1 = drop(LN1(y3)) ; q, k, v = h1 W^T + b
+    d2tile(X, T, w, m, h);
+    __syncthreads();
+    row_ln(T, L, a.ln1_g, a.ln1_b, a.d1, row0, a.y[3] + g0, a.h1 ? a.h1 + g0 : nullptr);
+    __syncthreads();
+    f32x16 Q, K, V;
+    {
+        const size_t plane_qkv = pack3_plane(D, 3 * D);
+        f32x16 bv;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Q[r] = 0.f;
+        tgemm(T, a.Wqkv3, plane_qkv, 3 * D, 32 * w, 0, D / 16, Q);
+        vec2d(bv, a.bq, w, h);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Q[r] += bv[r];
+        d2global(Q, a.q + g0, w, m, h, L);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) K[r] = 0.f;
+        tgemm(T, a.Wqkv3, plane_qkv, 3 * D, D + 32 * w, 0, D / 16, K);
+        vec2d(bv, a.bk, w, h);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) K[r] += bv[r];
+        d2global(K, a.k + g0, w, m, h, L);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) V[r] = 0.f;
+        tgemm(T, a.Wqkv3, plane_qkv, 3 * D, 2 * D + 32 * w, 0, D / 16, V);
+        vec2d(bv, a.bv, w, h);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) V[r] += bv[r];
+        d2global(V, a.v + g0, w, m, h, L);
+    }
+    __syncthreads();                            // the tile's readers are done
+    d2tile(V, T, w, m, h);                      // V[key][channel]: each wave reads back its own 32 columns only
+    __syncthreads();
+
+    // ---- attention core (:174-182), heads 2 w and 2 w + 1: S^T = K Q^T (lane = query, registers = keys), softmax in the lane, O^T = V^T P^T
+    f32x16 att;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        f32x16 S;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[r] = 0.f;
+#pragma unroll
+        for (int r = 8 * hh; r < 8 * hh + 8; ++r) S = __builtin_amdgcn_mfma_f32_32x32x2f32(K[r], Q[r], S, 0, 0, 0);
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { S[r] = S[r] * 0.25f + Mb[nl(r, h)]; mx = fmaxf(mx, S[r]); }      // scaled AFTER QK^T (:175), keys masked (:176-178)
+        mx = lane_pair32(mx, [](float p, float q) { return fmaxf(p, q); });
+        float ls = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { S[r] = __expf(S[r] - mx); ls += S[r]; }
+        ls = lane_pair32(ls, [](float p, float q) { return p + q; });
+        const int head = 2 * w + hh;
+        if (h == 0 && m < L) a.lse[((size_t)b * 8 + head) * L + m] = mx + __logf(ls);
+        if (a.d2.thresh) {
+            const uint32_t pbase = (uint32_t)(((size_t)(b + a.b_off) * 8 + head) * L + m) * (uint32_t)L;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) S[r] *= drop_keep_scale(a.d2, pbase + nl(r, h));
+        }
+        f32x16 O;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[r] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O = __builtin_amdgcn_mfma_f32_32x32x2f32(T[nl(r, h) * LDP + 32 * w + m], S[r], O, 0, 0, 0);
+        const float inv = 1.0f / ls;
+#pragma unroll
+        for (int r = 8 * hh; r < 8 * hh + 8; ++r) att[r] = O[r] * inv;
+    }
+    d2global(att, a.att + g0, w, m, h, L);
+    // ---- output block (:183-190): r = drop(att) + x ; h2 = drop(LN2(r)) ; y = drop(h2 Wo^T + b) + r
+#pragma unroll
+    for (int r = 0; r < 16; ++r) X[r] += att[r] * drop_mul(a.d3, (uint32_t)((row0 + m) * D + 32 * w + nl(r, h)));
+    __syncthreads();                            // V's readers are done
+    d2tile(X, T, w, m, h);
+    __syncthreads();
+    row_ln(T, L, a.ln2_g, a.ln2_b, a.d4, row0, a.r + g0, a.h2 ? a.h2 + g0 : nullptr);
+    __syncthreads();
+    {
+        f32x16 acc, bv;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        tgemm(T, a.Wo3, plane_pw, D, 32 * w, 0, D / 16, acc);
+        vec2d(bv, a.bo, w, h);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            X[r] += (acc[r] + bv[r]) * drop_mul(a.d5, (uint32_t)((row0 + m) * D + 32 * w + nl(r, h)));
+    }
+    d2global(X, a.out + g0, w, m, h, L);
+}
+
+bool query_fused_ok(int L, int H) { return L <= QROWS && H == 8; }
+size_t query_fwd_lds() { return (size_t)(QROWS * LDP + QROWS) * sizeof(float); }
+void launch_query_fwd(const QueryFwdArgs& a, int B, hipStream_t s) {
+    VSL_LAUNCH(k_query_fwd, dim3(B), dim3(QT), query_fwd_lds(), s, a);
+}
+
+}  // namespace vsl

@@ -220,6 +220,33 @@ struct AttnBlockArgs {
 };
 void launch_attn_block_fwd(const AttnBlockArgs& a, int B, hipStream_t s);
 inline bool attn_block_fwd_hosts_heads(int L) { return L <= 128; }
+// the query branch as ONE sample-local launch (kernels_query.hip): Embedding.linear + the whole FeatureEncoder application at L = Lq <= 32,
+// one workgroup per sample, 17 KB of LDS.  Saves the same tensors as linear_fwd + convblock_fwd + attn_block_fwd.
+struct QueryFwdArgs {
+    const float* E;                // (Rq, EW) concatenated word + char embedding rows
+    const uint16_t* Wemb3;         // split pack (type 6) of the (128, EW) Embedding.linear weight, K padded to 16
+    const float* b_emb;
+    float* qf;                     // (Rq,128) Embedding.linear output (nullable)
+    const float* pos;              // positional table
+    float* x0;
+    const uint16_t* W3[4];         // split packs of the pointwise weights
+    const uint16_t* Wqkv3;         // split pack of the fused (128, 384) q,k,v operand
+    const uint16_t* Wo3;           // split pack of the out_layer weight
+    const float *ln_g[4], *ln_b[4], *dw_w[4], *pw_b[4];
+    float *y[4], *u[4];
+    uint32_t* relu_mask[4];
+    Drop dp[4];
+    const float *ln1_g, *ln1_b, *bq, *bk, *bv;
+    float *h1, *q, *k, *v;
+    Drop d1;
+    const float* mask;             // (B, L) key mask
+    const float *ln2_g, *ln2_b, *bo;
+    float *att, *lse, *r, *h2, *out;
+    Drop d2, d3, d4, d5;
+    int EW, L, b_off;
+};
+bool query_fused_ok(int L, int H);                 // does the sample-local path take this query length?
+void launch_query_fwd(const QueryFwdArgs& a, int B, hipStream_t s);
 void launch_cq_score(const float* C, const float* Qf, const float* qmask, const float* w4C, const float* w4Q,
                      const float* w4mlu, float* S, float* Srow, int B, int T, int Lq, int b_off, Drop dc, Drop dq,
                      hipStream_t s);
