@@ -99,7 +99,7 @@ typedef struct {
 } vsl_io;
 /* Every struct of this header must be zero-initialised by the caller before the fields are set: new optional fields are appended, and
  * zero means "off".  vsl_abi_version() changes whenever a struct layout or an entry point's meaning changes; a binding checks it once. */
-#define VSL_ABI_VERSION 6
+#define VSL_ABI_VERSION 7
 int vsl_abi_version(void);
 
 /* labels + weights for the fused loss (replaces compute_loss / compute_highlight_loss, VSLNet_t7.py:67-72, and the
@@ -183,6 +183,12 @@ int64_t vsl_workspace_offset(vsl_handle h, int B, int T, int Lq, int Lc, const c
  * records; read: index-th aggregated record, returns 2 past the end. */
 int vsl_profile_select(vsl_handle h, const char* kernel);
 int vsl_profile_read(vsl_handle h, int index, char* name, int name_cap, double* total_ms, int32_t* count);
+/* the same records one launch at a time, in enqueue order (tools/critical_path.py: the step's critical-path ledger): stream = index of
+ * the launch's stream in order of first appearance, start / stop = the kernel's own dispatch-packet timestamps in us relative to the first
+ * record's start, host = when the host enqueued it (us since vsl_profile_select), deps = indices of the launches it was ordered behind
+ * (same-stream predecessor + every cross-stream ordering point in front of it).  Returns 2 past the end. */
+int vsl_profile_launch(vsl_handle h, int index, char* name, int name_cap, int32_t* stream, double* start_us, double* stop_us,
+                       double* host_us, int32_t* deps /* [6] */, int32_t* ndeps);
 
 #ifdef __cplusplus
 }

@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -97,7 +98,7 @@ struct vsl_handle_s {
     int64_t pack_floats = 0;
     std::vector<PackJob> jobs;
     PackJob* jobs_dev = nullptr;
-    int jobs_first = 0, jobs_query = 0;  // jobs_dev = [first: the video branch's opening kernels | query: the embedding stack | everything else]
+    int jobs_char = 0, jobs_first = 0, jobs_query = 0;  // jobs_dev = [char: the char-conv image embed_fwd reads | first: the video branch's opening kernels | query: the Embedding linear | everything else]
     unsigned* loss_counter = nullptr;    // arrival counter of k_loss_fused (zero between calls)
     uint8_t* decay_dev = nullptr;        // per-element weight-decay flag of the flat bucket (vsl_adamw_step)
     float* opt_scratch = nullptr;        // OPT_BLOCKS partial sums of grads^2
@@ -130,9 +131,17 @@ struct vsl_handle_s {
     std::string prof_sel;
     std::vector<hipEvent_t> prof_pool;
     size_t prof_used = 0;
-    struct ProfRec { const char* name; size_t e0, e1; };
+    struct ProfRec { const char* name; size_t e0, e1; hipStream_t s; double host_us; int deps[6]; int nd; };
     std::vector<ProfRec> prof_recs;
     const char* prof_name = nullptr;     // name of the LAUNCH being enqueued when it is profiled (vsl_launch_events)
+    // dependency bookkeeping of the critical-path ledger (vsl_profile_launch): last profiled launch per stream, and the cross-stream
+    // ordering points (Ctx::order) enqueued since -- they become `deps` of the consumer stream's next launch
+    std::vector<std::pair<hipStream_t, int>> prof_last, prof_pending;
+    std::chrono::steady_clock::time_point prof_t0;
+    void prof_wait(hipStream_t from, hipStream_t to) {
+        if (!prof_on || from == to) return;
+        for (auto& kv : prof_last) if (kv.first == from) { prof_pending.push_back({to, kv.second}); return; }
+    }
 };
 
 namespace {
@@ -397,6 +406,26 @@ struct CallScope {
     ~CallScope() { g_cur = nullptr; }
 };
 
+// vsl_loss / vsl_adamw_step: plain launches on the caller's stream; when the built-in profiler selects `name` they carry timing events too
+struct ProfScope {
+    vsl_handle_s* h;
+    ProfScope(vsl_handle_s* h_, const char* name) : h(h_) {
+        bool hit = false;
+        if (h->prof_on) {
+            const std::string& sel = h->prof_sel;
+            const size_t n = strlen(name);
+            for (size_t p = 0; !hit && p <= sel.size();) {
+                size_t q = sel.find(',', p);
+                if (q == std::string::npos) q = sel.size();
+                hit = (q - p == 1 && sel[p] == '*') || (q - p == n && sel.compare(p, n, name) == 0);
+                p = q + 1;
+            }
+        }
+        if (hit) { h->stop_events = false; h->prof_name = name; g_cur = h; }
+    }
+    ~ProfScope() { if (g_cur == h && h->prof_name) { h->prof_name = nullptr; g_cur = nullptr; } }
+};
+
 struct Ctx {
     vsl_handle_s* h;
     Plan* p;
@@ -433,6 +462,7 @@ struct Ctx {
     // make stream `to` wait for everything enqueued so far on stream `from`
     void order(hipStream_t from, hipStream_t to) {
         if (dry || from == to) return;
+        h->prof_wait(from, to);
         // rides on from's last kernel -- unless `from` itself was made to wait for something after that kernel (then a marker is recorded)
         if (hipEvent_t le = h->last_event(from)) { (void)hipStreamWaitEvent(to, le, 0); h->mark_waiting(to); return; }
         if (h->sync_used == h->sync_pool.size()) { hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); h->sync_pool.push_back(e); }
@@ -444,6 +474,8 @@ struct Ctx {
     // one event record on `from`, two waiters
     void order2(hipStream_t from, hipStream_t to1, hipStream_t to2) {
         if (dry) return;
+        h->prof_wait(from, to1);
+        if (to2 != to1) h->prof_wait(from, to2);
         if (hipEvent_t le = h->last_event(from)) {
             if (to1 != from) { (void)hipStreamWaitEvent(to1, le, 0); h->mark_waiting(to1); }
             if (to2 != from && to2 != to1) { (void)hipStreamWaitEvent(to2, le, 0); h->mark_waiting(to2); }
@@ -622,6 +654,12 @@ static void rnn_granules_fresh(Ctx& c, Plan& p, long long gen) {
     p.gran_ws = c.ws; p.gran_gen = gen;
 }
 
+// Lq <= 32: the query branch runs as sample-local launches (kernels_query.hip) in both directions
+static bool query_fused(const Ctx& c) {
+    static const bool on = !(getenv("VSL_QUERY_FUSED") && getenv("VSL_QUERY_FUSED")[0] == '0');
+    return on && query_fused_ok(c.p->Lq, c.h->cfg.num_heads);
+}
+
 void run_forward(Ctx& c) {
     const vsl_config& cf = c.h->cfg;
     const ModelP& P = c.h->P;
@@ -629,16 +667,26 @@ void run_forward(Ctx& c) {
     const Plan& p = *c.p;
     const vsl_io& io = *c.io;
     const int B = p.B, T = p.T, Lq = p.Lq, R = B * T, Rq = B * Lq;
-    const int nj = (int)c.h->jobs.size(), nj0 = c.h->jobs_first, nj1 = c.h->jobs_query;
+    const int nj = (int)c.h->jobs.size(), njc = c.h->jobs_char, nj0 = c.h->jobs_first, nj1 = c.h->jobs_query;
     hipStream_t sq = c.side(0), sp = c.side(1);
     const bool split3 = sq != c.main && sp != c.main;
+    hipEvent_t pack_first_ev = nullptr, pack_q_ev = nullptr;
+    int pack_first_rec = -1, pack_q_rec = -1;
     if (split3) {
-        LAUNCH("pack", launch_pack(io.params, c.W(p.pack), c.h->jobs_dev, nj0, c.s));
-        c.order2(c.main, sq, sp);          // both side streams start behind the first pack (its stop event: no marker packet), i.e. behind the caller's earlier work
-        c.s = sq;
-        LAUNCH("pack", launch_pack(io.params, c.W(p.pack), c.h->jobs_dev + nj0, nj1, c.s));
+        // The step opens with the smallest pack there is (the char-conv image, 4 jobs): both side streams start behind ITS stop event (no
+        // marker packet), i.e. behind the caller's earlier work, and the query stream's first kernel -- the word + char embedding, 160
+        // workgroups x 125 KB of LDS -- runs beside the packs and VisualProjection, not beside the video pass' 144 KB conv block (which it kept
+        // off 160 CUs: 49 us in the step against 25 alone, profiles/r05_notes.md section 9).
+        LAUNCH("pack", launch_pack(io.params, c.W(p.pack), c.h->jobs_dev, njc, c.s));
+        c.order2(c.main, sq, sp);
+        LAUNCH("pack", launch_pack(io.params, c.W(p.pack), c.h->jobs_dev + njc, nj0, c.s));
+        pack_first_ev = c.h->last_event(c.main);
+        pack_first_rec = c.h->prof_on ? (int)c.h->prof_recs.size() - 1 : -1;
         c.s = sp;
-        LAUNCH("pack", launch_pack(io.params, c.W(p.pack), c.h->jobs_dev + nj0 + nj1, nj - nj0 - nj1, c.s));
+        LAUNCH("pack", launch_pack(io.params, c.W(p.pack), c.h->jobs_dev + njc + nj0, nj1, c.s));      // the Embedding linear's operand: the query stream waits for it behind embed_fwd
+        pack_q_ev = c.h->last_event(sp);
+        pack_q_rec = c.h->prof_on ? (int)c.h->prof_recs.size() - 1 : -1;
+        LAUNCH("pack", launch_pack(io.params, c.W(p.pack), c.h->jobs_dev + njc + nj0 + nj1, nj - njc - nj0 - nj1, c.s));
         c.s = c.main;
     } else {
         LAUNCH("pack", launch_pack(io.params, c.W(p.pack), c.h->jobs_dev, nj, c.s));
@@ -659,8 +707,16 @@ void run_forward(Ctx& c) {
     LAUNCH("embed_fwd", launch_embed_fwd(io.word_ids, io.char_ids, wt ? c.P(P.unk) : io.pad_vec, c.P(P.unk) + (wt ? cf.word_dim : 0), wt ? c.P(P.unk) + 2 * cf.word_dim : io.glove_vec, c.P(P.char_tab), char_ptrs(c), c.PK(K.ccw_img), c.W(p.E),
                      reinterpret_cast<int8_t*>(c.W(p.argpos)), Rq, p.Lc, cf.word_dim, cf.char_dim, c.drop(SITE_WORD),
                      c.drop(SITE_CHAR), c.s));
-    static const bool qfuse_on = !(getenv("VSL_QUERY_FUSED") && getenv("VSL_QUERY_FUSED")[0] == '0');
-    if (qfuse_on && query_fused_ok(Lq, cf.num_heads)) {
+    if (split3 && !c.dry) {                // behind embed_fwd: the shared encoder's packs (main stream) and the Embedding linear's (third stream)
+        for (int k = 0; k < 2; ++k) {
+            hipEvent_t ev = k ? pack_q_ev : pack_first_ev;
+            const int rec = k ? pack_q_rec : pack_first_rec;
+            if (!ev) continue;
+            (void)hipStreamWaitEvent(c.s, ev, 0); c.h->mark_waiting(c.s);
+            if (rec >= 0) c.h->prof_pending.push_back({c.s, rec});
+        }
+    }   // the shared encoder's packs (main stream)
+    if (query_fused(c)) {
         // the rest of the query branch in ONE sample-local launch (kernels_query.hip)
         QueryFwdArgs qa;
         memset(&qa, 0, sizeof qa);
@@ -896,6 +952,76 @@ void enc_bwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float*
     }
     // positional table (:202): dpos[t] = sum_b dx0[b, t] -- the per-sample rows of dx0 ARE the partial slabs
     c.reg(P.pos, c.h->cfg.max_pos_len * D, dx0_off, Bn, L * D, 0, 0, L * D);
+}
+
+// the query pass' backward as ONE sample-local launch (kernels_query.hip: k_query_bwd) + the weight-gradient jobs that read what it leaves:
+// out_layer, fused q/k/v, the four pointwise convs (the Embedding linear's job is the caller's: it also owns dqf / E)
+void query_bwd(Ctx& c, const float* dy, int64_t dx0_off, WgradBatch& jobs) {
+    const vsl_config& cf = c.h->cfg;
+    const ModelPk& MK = c.h->K;
+    const EncP& P = c.h->P.fe;
+    const EncPk& K = c.h->K.fe;
+    const Plan& p = *c.p;
+    const EncWs& w = p.qe;
+    const EncTmp& t = p.tmp[1];
+    const int B = p.B, Lq = p.Lq, R = w.R, nchunk = (R + WG_ROWS - 1) / WG_ROWS, app = 1;
+    QueryBwdArgs a;
+    memset(&a, 0, sizeof a);
+    a.p_ln2g = c.slab(P.ln2g, D, B); a.p_ln2b = c.slab(P.ln2b, D, B);
+    a.p_ln1g = c.slab(P.ln1g, D, B); a.p_ln1b = c.slab(P.ln1b, D, B);
+    for (int i = 3; i >= 0; --i) {
+        a.p_lng[i] = c.slab(P.lng[i], D, B);
+        a.p_lnb[i] = c.slab(P.lnb[i], D, B);
+        a.p_dw[i] = c.slab(P.dw[i], D * DWK, B);
+    }
+    if (!c.dry) {
+        a.dout = dy; a.r = c.W(w.r); a.ln2_g = c.P(P.ln2g); a.WoT3 = reinterpret_cast<const uint16_t*>(c.PK(K.o_t3)); a.go = c.W(t.go);
+        a.d2 = c.drop(app * 16 + 5); a.d3 = c.drop(app * 16 + 6); a.d4 = c.drop(app * 16 + 7); a.d5 = c.drop(app * 16 + 8);
+        a.q = c.W(w.q); a.k = c.W(w.k); a.v = c.W(w.v); a.att = c.W(w.att); a.lse = c.W(w.lse); a.mask = c.io->q_mask;
+        a.dq = c.W(t.dq); a.dk = c.W(t.dk); a.dv = c.W(t.dv);
+        a.WqkvT3 = reinterpret_cast<const uint16_t*>(c.PK(K.qkv_t3)); a.y3 = c.W(w.y[3]); a.ln1_g = c.P(P.ln1g); a.d1 = c.drop(app * 16 + 4);
+        for (int i = 0; i < 4; ++i) {
+            a.WT3[i] = reinterpret_cast<const uint16_t*>(c.PK(K.pw_t3[i]));
+            a.x[i] = i > 0 ? c.W(w.y[i - 1]) : c.W(w.x0);
+            a.relu_mask[i] = reinterpret_cast<const uint32_t*>(c.W(w.mask[i]));
+            a.ln_g[i] = c.P(P.lng[i]); a.ln_b[i] = c.P(P.lnb[i]); a.dw_w[i] = c.P(P.dw[i]);
+            a.dp[i] = c.drop(app * 16 + i); a.gz[i] = c.W(t.gz[i]);
+        }
+        a.dx0 = c.W(dx0_off);
+        a.WembT3 = reinterpret_cast<const uint16_t*>(c.PK(MK.emb_t3)); a.dE = c.W(p.dE);
+        a.EW = cf.word_dim + 100; a.EWc = MK.emb_t3_cols; a.L = Lq; a.b_off = 0;
+    }
+    LAUNCH("query_bwd", launch_query_bwd(a, B, c.s));
+    {
+        WgradJob j = wjob();
+        j.G[0] = c.dry ? nullptr : c.W(t.go); j.nG = 1; j.A[0] = c.dry ? nullptr : c.W(w.h2); j.nA = 1; j.K = D; j.R = R;
+        j.out = c.slab(P.ow, D * D, nchunk);
+        j.out_bias[0] = c.slab(P.ob, D, nchunk);
+        jobs.j[jobs.n++] = j;
+    }
+    {
+        WgradJob j = wjob();
+        if (!c.dry) { j.G[0] = c.W(t.dq); j.G[1] = c.W(t.dk); j.G[2] = c.W(t.dv); j.A[0] = c.W(w.h1); }
+        j.nG = 3; j.nA = 1; j.K = D; j.R = R;
+        const int64_t o = c.part_alloc((int64_t)nchunk * 3 * D * D);
+        c.reg(P.qw, D * D, p.partial + o, nchunk, 3 * D * D);
+        c.reg(P.kw, D * D, p.partial + o + D * D, nchunk, 3 * D * D);
+        c.reg(P.vw, D * D, p.partial + o + 2 * D * D, nchunk, 3 * D * D);
+        j.out = c.part_ptr(o);
+        j.out_bias[0] = c.slab(P.qb, D, nchunk);
+        j.out_bias[1] = c.slab(P.kb, D, nchunk);
+        j.out_bias[2] = c.slab(P.vb, D, nchunk);
+        jobs.j[jobs.n++] = j;
+    }
+    for (int i = 0; i < 4; ++i) {
+        WgradJob j = wjob();
+        if (!c.dry) { j.G[0] = c.W(t.gz[i]); j.A[0] = c.W(w.u[i]); }
+        j.nG = 1; j.nA = 1; j.K = D; j.R = R;
+        j.out = c.slab(P.pw[i], D * D, nchunk);
+        j.out_bias[0] = c.slab(P.pwb[i], D, nchunk);
+        jobs.j[jobs.n++] = j;
+    }
+    c.reg(P.pos, cf.max_pos_len * D, dx0_off, B, Lq * D, 0, 0, Lq * D);     // positional table (:202): the per-sample rows of dx0 are the partial slabs
 }
 
 void run_backward(Ctx& c) {
@@ -1140,9 +1266,12 @@ void run_backward(Ctx& c) {
     memset(&pw_query, 0, sizeof pw_query);
     const int EW = cf.word_dim + 100;
     // sample tiles (Lq <= 32): the query pass' conv-block backward goes on with the Embedding linear's data gradient on its rows of dx0
-    const bool lin_hosted = convblock_bwd_hosts_linear(Rq, Lq) && K.emb_t3_cols % 512 == 0;
+    const bool qfused = query_fused(c);
+    const bool lin_hosted = qfused || (convblock_bwd_hosts_linear(Rq, Lq) && K.emb_t3_cols % 512 == 0);
     LinTail lt{nullptr, nullptr, EW, K.emb_t3_cols};
     if (lin_hosted && !c.dry) { lt.WT3 = reinterpret_cast<const uint16_t*>(c.PK(K.emb_t3)); lt.dA = c.W(p.dE); }
+    if (qfused) query_bwd(c, c.dry ? nullptr : c.W(p.dQtot), p.dqf, pw_query);
+    else
     enc_bwd(c, P.fe, K.fe, p.qe, c.dry ? nullptr : c.W(p.dQtot), nullptr, p.dqf, c.dry ? nullptr : io->q_mask, B, 1, sw, &pw_query, false, nullptr, nullptr,
             lin_hosted ? &lt : nullptr);
     {   // every remaining weight gradient (video + query pointwise convs, embedding linear) in ONE launch on the video
@@ -1372,7 +1501,19 @@ void vsl_launch_events(hipStream_t s, hipEvent_t* start, hipEvent_t* stop) {
     hipEvent_t e;
     if (h->prof_name) {                      // profiled launch: timing events, start + stop, one record per kernel
         while (h->prof_pool.size() < h->prof_used + 2) { hipEvent_t t; (void)hipEventCreate(&t); h->prof_pool.push_back(t); }
-        h->prof_recs.push_back({h->prof_name, h->prof_used, h->prof_used + 1});
+        {
+            vsl_handle_s::ProfRec rec{h->prof_name, h->prof_used, h->prof_used + 1, s,
+                                      std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h->prof_t0).count(), {0, 0, 0, 0, 0, 0}, 0};
+            const int me = (int)h->prof_recs.size();
+            bool seen = false;
+            for (auto& kv : h->prof_last) if (kv.first == s) { if (rec.nd < 6) rec.deps[rec.nd++] = kv.second; kv.second = me; seen = true; }
+            if (!seen) h->prof_last.push_back({s, me});
+            for (size_t i = 0; i < h->prof_pending.size();) {
+                if (h->prof_pending[i].first == s) { if (rec.nd < 6) rec.deps[rec.nd++] = h->prof_pending[i].second; h->prof_pending.erase(h->prof_pending.begin() + i); }
+                else ++i;
+            }
+            h->prof_recs.push_back(rec);
+        }
         *start = h->prof_pool[h->prof_used];
         e = h->prof_pool[h->prof_used + 1];
         h->prof_used += 2;
@@ -1448,13 +1589,14 @@ int vsl_create(const vsl_config* cfg, vsl_handle* out) {
         auto in = [](int dst, std::initializer_list<int> set) { return std::find(set.begin(), set.end(), dst) != set.end(); };
         auto cls = [&](const PackJob& j) {
             const EncPk& f = K.fe;
+            if (j.dst == K.ccw_img) return 0;
             if (in(j.dst, {K.va_f, K.va_f16, K.va_f3, f.pw_f[0], f.pw_f[1], f.pw_f[2], f.pw_f[3], f.qkv_f, f.o_f, f.pw_f3[0], f.pw_f3[1], f.pw_f3[2], f.pw_f3[3],
-                           f.qkv_f3, f.o_f3})) return 0;
-            if (in(j.dst, {K.emb_f, K.emb_f3, K.ccw_img})) return 1;
-            return 2;
+                           f.qkv_f3, f.o_f3})) return 1;
+            if (in(j.dst, {K.emb_f, K.emb_f3})) return 2;
+            return 3;
         };
         std::stable_sort(h->jobs.begin(), h->jobs.end(), [&](const PackJob& a, const PackJob& b) { return cls(a) < cls(b); });
-        for (const PackJob& j : h->jobs) { h->jobs_first += cls(j) == 0; h->jobs_query += cls(j) == 1; }
+        for (const PackJob& j : h->jobs) { h->jobs_char += cls(j) == 0; h->jobs_first += cls(j) == 1; h->jobs_query += cls(j) == 2; }
     }
     if (hipMalloc(&h->jobs_dev, h->jobs.size() * sizeof(PackJob)) != hipSuccess ||
         hipMemcpy(h->jobs_dev, h->jobs.data(), h->jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice) != hipSuccess) {
@@ -1576,6 +1718,7 @@ int vsl_loss(vsl_handle h, const vsl_io* io, const vsl_loss_io* l, void* hip_str
         return fail("gradient seed outputs must be all set or all null");
     Plan* p = nullptr;
     if (int rc = get_plan(h, io->B, io->T, io->Lq, io->Lc, &p)) return rc;
+    ProfScope ps(h, "loss");
     launch_loss(io->start_logits, io->end_logits, io->h_score, l->start_labels, l->end_labels, l->h_labels, io->v_mask, io->B,
                 io->T, l->inv_batch, l->mask_sum, l->w_loc, l->w_highlight, io->workspace + p->loss_scratch, l->losses,
                 l->d_start_logits, l->d_end_logits, l->d_h_score, (hipStream_t)hip_stream, h->loss_counter);
@@ -1640,6 +1783,7 @@ int vsl_adamw_step(vsl_handle h, float* params, const float* grads, float* exp_a
         if (h->sq_grads != grads) return fail("vsl_adamw_step: norm_from_backward is set but `grads` is not the bucket the last vsl_backward wrote");
         sq = h->sq_src;             // (null when some gradient of this configuration does not leave k_reduce: the k_sqsum pass then)
     }
+    ProfScope ps(h, "adamw");
     launch_adamw(params, grads, exp_avg, exp_avg_sq, h->decay_dev, h->opt_scratch, h->param_floats, hp->lr, hp->beta1, hp->beta2,
                  hp->eps, hp->weight_decay, hp->clip_norm, (float)bc1, (float)std::sqrt(bc2), grad_norm_out, (hipStream_t)hip_stream,
                  hp->hf_order, sq, h->sq_n);
@@ -1653,6 +1797,35 @@ int vsl_profile_select(vsl_handle h, const char* kernel) {
     h->prof_sel = kernel ? kernel : "";
     h->prof_recs.clear();
     h->prof_used = 0;
+    h->prof_last.clear(); h->prof_pending.clear();
+    h->prof_t0 = std::chrono::steady_clock::now();
+    return 0;
+}
+
+// one record of the ledger: the index-th profiled launch since vsl_profile_select, in enqueue order
+int vsl_profile_launch(vsl_handle h, int index, char* name, int name_cap, int32_t* stream, double* start_us, double* stop_us, double* host_us,
+                       int32_t* deps /* [6] */, int32_t* ndeps) {
+    if (!h) return fail("null handle");
+    if (index < 0 || index >= (int)h->prof_recs.size()) return 2;
+    const auto& r = h->prof_recs[index];
+    float t0 = 0.f, t1 = 0.f;
+    const hipEvent_t ref = h->prof_pool[h->prof_recs[0].e0];
+    if (hipEventSynchronize(h->prof_pool[r.e1]) != hipSuccess || hipEventElapsedTime(&t0, ref, h->prof_pool[r.e0]) != hipSuccess ||
+        hipEventElapsedTime(&t1, ref, h->prof_pool[r.e1]) != hipSuccess)
+        return fail("hipEventElapsedTime failed");
+    if (name && name_cap > 0) { strncpy(name, r.name, name_cap - 1); name[name_cap - 1] = 0; }
+    int si = 0;
+    {   // stream index in order of first appearance
+        std::vector<hipStream_t> seen;
+        for (const auto& q : h->prof_recs) { if (std::find(seen.begin(), seen.end(), q.s) == seen.end()) seen.push_back(q.s); if (&q == &r) break; }
+        si = (int)(std::find(seen.begin(), seen.end(), r.s) - seen.begin());
+    }
+    if (stream) *stream = si;
+    if (start_us) *start_us = 1e3 * t0;
+    if (stop_us) *stop_us = 1e3 * t1;
+    if (host_us) *host_us = r.host_us;
+    if (deps) for (int i = 0; i < 6; ++i) deps[i] = i < r.nd ? r.deps[i] : -1;
+    if (ndeps) *ndeps = r.nd;
     return 0;
 }
 

@@ -28,6 +28,30 @@
 
 namespace vsl {
 
+__device__ long long g_stamps_q[40];
+__device__ int g_dbg_on_q = 0;
+#ifdef VSL_STAMPS       // phase stamps of workgroup 0: a separate build (vslnet_amd/build.py --stamps), see kernels_bwd.hip
+#define QSTAMP(k) do { if (g_dbg_on_q && blockIdx.x == 0 && threadIdx.x == 0) g_stamps_q[k] = clock64(); } while (0)
+#else
+#define QSTAMP(k) do { } while (0)
+#endif
+static int qdbg_on() {
+#ifndef VSL_STAMPS
+    return 0;
+#endif
+    static int inited = 0, on = 0;
+    if (!inited) { inited = 1; on = getenv("VSL_DEBUG_TIMING") != nullptr; if (on) { int one = 1; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_on_q), &one, sizeof one); } }
+    return on;
+}
+static void qdbg_report(const char* name, int i0, int i1, hipStream_t s) {
+    long long h[40];
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamps_q), sizeof h);
+    fprintf(stderr, "[%s cycles]", name);
+    for (int i = i0 + 1; i < i1; ++i) fprintf(stderr, " %lld", h[i] - h[i - 1]);
+    fprintf(stderr, " | total %lld\n", h[i1 - 1] - h[i0]);
+}
+
 constexpr int QT = 256;                         // threads per workgroup: 4 waves, one per SIMD
 constexpr int QROWS = 32;                       // rows of a sample window (L <= 32)
 
@@ -186,6 +210,7 @@ __global__ __launch_bounds__(QT, 2) void k_query_fwd(QueryFwdArgs a) {
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, m = lane & 31, h = lane >> 5;
     const int L = a.L, b = blockIdx.x, row0 = b * L;
     const size_t g0 = (size_t)row0 * D;
+    QSTAMP(0);
     if (tid < QROWS) Mb[tid] = tid < L ? (1.0f - a.mask[row0 + tid]) * MASK_VALUE : MASK_VALUE;
 
     // ---- Embedding.linear (:86-88): x = E W^T + b, E staged through the tile in 128-column chunks
@@ -221,6 +246,7 @@ __global__ __launch_bounds__(QT, 2) void k_query_fwd(QueryFwdArgs a) {
         for (int r = 0; r < 16; ++r) X[r] = acc[r] + pv[r];
     }
     __syncthreads();
+    QSTAMP(1);
 
     // ---- four conv layers (:133-139): x <- x + drop(relu(pointwise(depthwise7(LN(x)))))
     const size_t plane_pw = pack3_plane(D, D);
@@ -228,11 +254,13 @@ __global__ __launch_bounds__(QT, 2) void k_query_fwd(QueryFwdArgs a) {
         constexpr int l = decltype(LC)::value;
         d2tile(X, T, w, m, h);
         __syncthreads();
+        if (l == 0) QSTAMP(10);
         {
             const Drop nodrop{0u, 0u, 1.f, 0u};
             row_ln(T, L, a.ln_g[l], a.ln_b[l], nodrop, row0, (l == 0 ? a.x0 : a.y[l > 0 ? l - 1 : 0]) + g0, nullptr);
         }
         __syncthreads();
+        if (l == 0) QSTAMP(11);
         {   // depthwise conv k = 7 along the sequence: thread = (channel, half of the rows); rows outside [0, L) are zeros in the tile
             const int c = tid & 127, os = 16 * (tid >> 7);
             float wk[DWK], win[16 + 2 * HALO], uo[16];
@@ -251,6 +279,7 @@ __global__ __launch_bounds__(QT, 2) void k_query_fwd(QueryFwdArgs a) {
                 uo[i] = u;
             }
             __syncthreads();                    // every window is in registers
+            if (l == 0) QSTAMP(12);
             float* ug = a.u[l] + g0 + c;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -259,10 +288,12 @@ __global__ __launch_bounds__(QT, 2) void k_query_fwd(QueryFwdArgs a) {
             }
         }
         __syncthreads();
+        if (l == 0) QSTAMP(13);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         tgemm(T, a.W3[l], plane_pw, D, 32 * w, 0, D / 16, acc);
+        if (l == 0) QSTAMP(14);
         f32x16 bv;
         vec2d(bv, a.pw_b[l], w, h);
         const Drop dp = a.dp[l];
@@ -284,7 +315,9 @@ __global__ __launch_bounds__(QT, 2) void k_query_fwd(QueryFwdArgs a) {
             uint16_t* mk = reinterpret_cast<uint16_t*>(a.relu_mask[l]);
             if (m < L) mk[(size_t)(row0 + m) * 8 + 2 * w + h] = (uint16_t)(h ? g1b : g0b);
         }
+        if (l == 0) QSTAMP(15);
         __syncthreads();                        // every wave is through with the tile
+        QSTAMP(2 + l);
     });
 
     // ---- a8 first half (:168-173): h1 = drop(LN1(y3)) ; q, k, v = h1 W^T + b
@@ -318,6 +351,7 @@ __global__ __launch_bounds__(QT, 2) void k_query_fwd(QueryFwdArgs a) {
         for (int r = 0; r < 16; ++r) V[r] += bv[r];
         d2global(V, a.v + g0, w, m, h, L);
     }
+    QSTAMP(6);
     __syncthreads();                            // the tile's readers are done
     d2tile(V, T, w, m, h);                      // V[key][channel]: each wave reads back its own 32 columns only
     __syncthreads();
@@ -356,6 +390,7 @@ __global__ __launch_bounds__(QT, 2) void k_query_fwd(QueryFwdArgs a) {
         for (int r = 8 * hh; r < 8 * hh + 8; ++r) att[r] = O[r] * inv;
     }
     d2global(att, a.att + g0, w, m, h, L);
+    QSTAMP(7);
     // ---- output block (:183-190): r = drop(att) + x ; h2 = drop(LN2(r)) ; y = drop(h2 Wo^T + b) + r
 #pragma unroll
     for (int r = 0; r < 16; ++r) X[r] += att[r] * drop_mul(a.d3, (uint32_t)((row0 + m) * D + 32 * w + nl(r, h)));
@@ -375,12 +410,433 @@ __global__ __launch_bounds__(QT, 2) void k_query_fwd(QueryFwdArgs a) {
             X[r] += (acc[r] + bv[r]) * drop_mul(a.d5, (uint32_t)((row0 + m) * D + 32 * w + nl(r, h)));
     }
     d2global(X, a.out + g0, w, m, h, L);
+    QSTAMP(8);
+}
+
+
+// =========================================================================================================
+// k_query_bwd: the backward of k_query_fwd's encoder application + the Embedding linear's data gradient, one workgroup per sample.
+//   dout (grad wrt the encoder output) -> output block backward (:183-190) -> attention backward (8 heads, two per wave, S / P / dP / dS
+//   recomputed once per operand orientation) -> q,k,v backward + LN1^T -> conv layers 3..0 -> dx0 (= grad wrt Embedding.linear's output)
+//   -> dE = dx0 W_emb.
+// Row-tile launches replaced: attn_out_bwd + attn_bwd + convblock_bwd<0> (with its q,k,v prologue and linear tail).  It writes what
+// they wrote: go, dq / dk / dv, gz[0..3] (G operands of the weight gradients), dx0, dE, and per-SAMPLE partial slabs of every
+// LayerNorm gamma / beta and of the depthwise taps.
+// Three thread layouts share the one LDS tile:  T layout (GEMM results / attention, see the file header);  ROW layout (8 lanes per row, lane
+// `sub` owns float4 columns 4 sub + 32 j): LayerNorm statistics and their backward -- a thread keeps ITS row of dy / xhat in registers from
+// phase to phase;  COLUMN layout (thread = channel c = tid >> 1, row half seg = tid & 1; the two halves of a channel in adjacent lanes):
+// depthwise^T, the tap gradients and every per-channel sum over the sample's rows.
+// =========================================================================================================
+struct Row4 { float4 v[4]; };
+__device__ __forceinline__ void row_load(Row4& x, const float* __restrict__ g, int rr, int sub, bool ok) {       // g = row 0 of the sample
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x.v[j] = ok ? *reinterpret_cast<const float4*>(g + (size_t)rr * D + sub * 4 + 32 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__device__ __forceinline__ void row_store(const Row4& x, float* __restrict__ g, int rr, int sub, bool ok) {
+    if (ok) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(g + (size_t)rr * D + sub * 4 + 32 * j) = x.v[j];
+    }
+}
+__device__ __forceinline__ void row_to_tile(const Row4& x, float* __restrict__ T, int rr, int sub) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(T + rr * LDP + sub * 4 + 32 * j) = x.v[j];
+}
+__device__ __forceinline__ void tile_to_row(Row4& x, const float* __restrict__ T, int rr, int sub) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x.v[j] = *reinterpret_cast<const float4*>(T + rr * LDP + sub * 4 + 32 * j);
+}
+__device__ __forceinline__ void tile2d(f32x16& x, const float* __restrict__ T, int w, int m, int h) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const float4 v = *reinterpret_cast<const float4*>(T + m * LDP + 32 * w + 8 * a + 4 * h);
+        x[4 * a] = v.x; x[4 * a + 1] = v.y; x[4 * a + 2] = v.z; x[4 * a + 3] = v.w;
+    }
+}
+// xhat / rstd of a row in ROW layout (rows that do not exist: zeros)
+__device__ __forceinline__ void row_xhat(Row4& x, float& rstd, bool ok) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s += sum4(x.v[j]);
+    const float mu = grp8_sum(s) * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        x.v[j].x -= mu; x.v[j].y -= mu; x.v[j].z -= mu; x.v[j].w -= mu;
+        q += x.v[j].x * x.v[j].x + x.v[j].y * x.v[j].y + x.v[j].z * x.v[j].z + x.v[j].w * x.v[j].w;
+    }
+    rstd = rsqrtf(grp8_sum(q) * (1.0f / D) + LN_EPS);
+    const float k = ok ? rstd : 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { x.v[j].x *= k; x.v[j].y *= k; x.v[j].z *= k; x.v[j].w *= k; }
+}
+// out = resid + rstd (gd - mean(gd) - xhat mean(gd xhat)), gd = dl * gamma  (ROW layout; rows that do not exist: zeros)
+__device__ __forceinline__ void row_ln_bwd(Row4& out, const Row4& dl, const Row4& xh, float rstd, const float* __restrict__ g, const Row4& resid, int sub, bool ok) {
+    Row4 gd;
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float4 gv = *reinterpret_cast<const float4*>(g + sub * 4 + 32 * j);
+        gd.v[j] = make_float4(dl.v[j].x * gv.x, dl.v[j].y * gv.y, dl.v[j].z * gv.z, dl.v[j].w * gv.w);
+        m1 += sum4(gd.v[j]);
+        m2 += gd.v[j].x * xh.v[j].x + gd.v[j].y * xh.v[j].y + gd.v[j].z * xh.v[j].z + gd.v[j].w * xh.v[j].w;
+    }
+    m1 = grp8_sum(m1) * (1.0f / D);
+    m2 = grp8_sum(m2) * (1.0f / D);
+    const float k = ok ? rstd : 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        out.v[j].x = resid.v[j].x + k * (gd.v[j].x - m1 - xh.v[j].x * m2); out.v[j].y = resid.v[j].y + k * (gd.v[j].y - m1 - xh.v[j].y * m2);
+        out.v[j].z = resid.v[j].z + k * (gd.v[j].z - m1 - xh.v[j].z * m2); out.v[j].w = resid.v[j].w + k * (gd.v[j].w - m1 - xh.v[j].w * m2);
+    }
+}
+
+__global__ __launch_bounds__(QT, 2) void k_query_bwd(QueryBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* T = smem;                            // [32][LDP]
+    float* Mb = T + QROWS * LDP;                // [32] key bias
+    float* Ls = Mb + QROWS;                     // [8 heads][32] LSE per query
+    float* Dqs = Ls + 8 * QROWS;                // [8 heads][32] D = dA . O per query
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, m = lane & 31, h = lane >> 5;
+    const int rr = tid >> 3, sub = tid & 7;     // ROW layout
+    const int cc = tid >> 1, seg = tid & 1;     // COLUMN layout: rows [16 seg, 16 seg + 16) of channel cc
+    const int L = a.L, b = blockIdx.x, row0 = b * L;
+    const size_t g0 = (size_t)row0 * D;
+    const bool rok = rr < L, mok = m < L;
+    QSTAMP(20);
+    if (tid < QROWS) Mb[tid] = tid < L ? (1.0f - a.mask[row0 + tid]) * MASK_VALUE : MASK_VALUE;
+    Ls[tid] = (tid & 31) < L ? a.lse[((size_t)b * 8 + (tid >> 5)) * L + (tid & 31)] : 0.f;
+    const size_t plane_pw = pack3_plane(D, D);
+
+    // one LayerNorm backward whose incoming gradient is in T layout (`dln`, rows >= L zero) and whose input row is in `x` (ROW layout):
+    // returns resid + LN^T(dln) in ROW layout, writes the per-sample gamma / beta slabs.  Leaves the tile with readers: barrier before the next write.
+    auto ln_bwd_t = [&](Row4& x, const f32x16& dln, const float* __restrict__ g, const Row4& resid, float* __restrict__ p_g, float* __restrict__ p_b, Row4& out) {
+        float rstd;
+        row_xhat(x, rstd, rok);
+        __syncthreads();                        // the tile is free
+        row_to_tile(x, T, rr, sub);
+        __syncthreads();
+        float xc[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) xc[i] = T[(16 * seg + i) * LDP + cc];
+        __syncthreads();
+        d2tile(dln, T, w, m, h);
+        __syncthreads();
+        float sb = 0.f, sg = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const float d = T[(16 * seg + i) * LDP + cc]; sb += d; sg += d * xc[i]; }
+        sb += lane_xor1(sb); sg += lane_xor1(sg);
+        if (seg == 0) { p_g[(size_t)b * D + cc] = sg; p_b[(size_t)b * D + cc] = sb; }
+        Row4 dl;
+        tile_to_row(dl, T, rr, sub);
+        row_ln_bwd(out, dl, x, rstd, g, resid, sub, rok);
+    };
+
+    // ---- output block backward (:183-190): go = dout * m5 ; dh2 = go Wo ; dr = dout + LN2^T(dh2 * m4)
+    Row4 DY, DR;
+    {
+        Row4 xr, go;
+        row_load(DY, a.dout + g0, rr, sub, rok);
+        row_load(xr, a.r + g0, rr, sub, rok);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t base = (uint32_t)((row0 + rr) * D + sub * 4 + 32 * j);
+            go.v[j] = make_float4(DY.v[j].x * drop_mul(a.d5, base), DY.v[j].y * drop_mul(a.d5, base + 1), DY.v[j].z * drop_mul(a.d5, base + 2),
+                                  DY.v[j].w * drop_mul(a.d5, base + 3));
+        }
+        row_store(go, a.go + g0, rr, sub, rok);         // G operand of the out_layer weight gradient
+        row_to_tile(go, T, rr, sub);
+        __syncthreads();
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        tgemm(T, a.WoT3, plane_pw, D, 32 * w, 0, D / 16, acc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = mok ? acc[r] * drop_mul(a.d4, (uint32_t)((row0 + m) * D + 32 * w + nl(r, h))) : 0.f;
+        ln_bwd_t(xr, acc, a.ln2_g, DY, a.p_ln2g, a.p_ln2b, DR);
+    }
+    QSTAMP(21);
+
+    // ---- attention backward (:174-182), heads 2 w and 2 w + 1
+    f32x16 dQd, dKd, dVd;
+    {
+        f32x16 Q, K, V, dA, O;
+        global2d(Q, a.q + g0, w, m, h, L);
+        global2d(K, a.k + g0, w, m, h, L);
+        global2d(V, a.v + g0, w, m, h, L);
+        global2d(O, a.att + g0, w, m, h, L);
+        __syncthreads();                        // ln_bwd_t's readers are done
+        row_to_tile(DR, T, rr, sub);
+        __syncthreads();
+        tile2d(dA, T, w, m, h);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dA[r] = mok ? dA[r] * drop_mul(a.d3, (uint32_t)((row0 + m) * D + 32 * w + nl(r, h))) : 0.f;      // r = drop3(att) + x (:183-184)
+        float DqA[2];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            float s = 0.f;
+#pragma unroll
+            for (int r = 8 * hh; r < 8 * hh + 8; ++r) s += dA[r] * O[r];
+            s = lane_pair32(s, [](float p, float q) { return p + q; });
+            DqA[hh] = s;
+            if (h == 0) Dqs[(2 * w + hh) * QROWS + m] = s;
+        }
+        // orientation A (lane = query, registers = keys): dS feeds dQ
+        f32x16 dSA[2];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int head = 2 * w + hh;
+            f32x16 S, dP;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { S[r] = 0.f; dP[r] = 0.f; }
+#pragma unroll
+            for (int r = 8 * hh; r < 8 * hh + 8; ++r) {
+                S = __builtin_amdgcn_mfma_f32_32x32x2f32(K[r], Q[r], S, 0, 0, 0);
+                dP = __builtin_amdgcn_mfma_f32_32x32x2f32(V[r], dA[r], dP, 0, 0, 0);
+            }
+            const float lq = Ls[head * QROWS + m];
+            const uint32_t pbase = (uint32_t)(((size_t)(b + a.b_off) * 8 + head) * L + m) * (uint32_t)L;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __expf(S[r] * 0.25f + Mb[nl(r, h)] - lq);
+                const float m2 = drop_mul(a.d2, pbase + nl(r, h));
+                dSA[hh][r] = p * (dP[r] * m2 - DqA[hh]) * 0.25f;
+            }
+        }
+        __syncthreads();                        // dA's readers are done (and Dqs is written)
+        d2tile(K, T, w, m, h);
+        __syncthreads();
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(T[nl(r, h) * LDP + 32 * w + m], dSA[hh][r], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 8 * hh; r < 8 * hh + 8; ++r) dQd[r] = mok ? acc[r] : 0.f;
+        }
+        // orientation B (lane = key, registers = queries): dS feeds dK, P * m2 feeds dV
+        f32x16 dSB[2], PdB[2];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int head = 2 * w + hh;
+            f32x16 S, dP;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { S[r] = 0.f; dP[r] = 0.f; }
+#pragma unroll
+            for (int r = 8 * hh; r < 8 * hh + 8; ++r) {
+                S = __builtin_amdgcn_mfma_f32_32x32x2f32(Q[r], K[r], S, 0, 0, 0);
+                dP = __builtin_amdgcn_mfma_f32_32x32x2f32(dA[r], V[r], dP, 0, 0, 0);
+            }
+            const float mbk = Mb[m];
+            const uint32_t hb = (uint32_t)(((size_t)(b + a.b_off) * 8 + head) * L);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int qq = nl(r, h);
+                const float p = __expf(S[r] * 0.25f + mbk - Ls[head * QROWS + qq]);
+                const float m2 = drop_mul(a.d2, (hb + (uint32_t)qq) * (uint32_t)L + (uint32_t)m);
+                PdB[hh][r] = p * m2;
+                dSB[hh][r] = p * (dP[r] * m2 - Dqs[head * QROWS + qq]) * 0.25f;
+            }
+        }
+        __syncthreads();
+        d2tile(Q, T, w, m, h);
+        __syncthreads();
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(T[nl(r, h) * LDP + 32 * w + m], dSB[hh][r], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 8 * hh; r < 8 * hh + 8; ++r) dKd[r] = mok ? acc[r] : 0.f;
+        }
+        __syncthreads();
+        d2tile(dA, T, w, m, h);
+        __syncthreads();
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(T[nl(r, h) * LDP + 32 * w + m], PdB[hh][r], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 8 * hh; r < 8 * hh + 8; ++r) dVd[r] = mok ? acc[r] : 0.f;
+        }
+        d2global(dQd, a.dq + g0, w, m, h, L);   // G operands of the q,k,v weight gradient
+        d2global(dKd, a.dk + g0, w, m, h, L);
+        d2global(dVd, a.dv + g0, w, m, h, L);
+    }
+    QSTAMP(22);
+
+    // ---- a8 first half backward (:168-173): dh1 = [dQ | dK | dV] [Wq; Wk; Wv] ; dy3 = dr + LN1^T(dh1 * m1)
+    {
+        Row4 x3;
+        row_load(x3, a.y3 + g0, rr, sub, rok);
+        const size_t plane_t = pack3_plane(3 * D, D);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            __syncthreads();
+            d2tile(t == 0 ? dQd : t == 1 ? dKd : dVd, T, w, m, h);
+            __syncthreads();
+            tgemm(T, a.WqkvT3, plane_t, D, 32 * w, 8 * t, D / 16, acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = mok ? acc[r] * drop_mul(a.d1, (uint32_t)((row0 + m) * D + 32 * w + nl(r, h))) : 0.f;
+        ln_bwd_t(x3, acc, a.ln1_g, DR, a.p_ln1g, a.p_ln1b, DY);
+    }
+    QSTAMP(23);
+
+    // ---- conv layers 3 .. 0 (autograd of :133-139)
+    static_for<0, 4>([&](auto LC) {
+        constexpr int l = 3 - decltype(LC)::value;
+        Row4 xh;
+        float rstd;
+        row_load(xh, a.x[l] + g0, rr, sub, rok);
+        const uint4 mw = rok ? *reinterpret_cast<const uint4*>(a.relu_mask[l] + (size_t)(row0 + rr) * 4) : make_uint4(0u, 0u, 0u, 0u);
+        float wk[DWK];
+#pragma unroll
+        for (int k = 0; k < DWK; ++k) wk[k] = a.dw_w[l][cc * DWK + k];
+        const float gc = a.ln_g[l][cc], bc = a.ln_b[l][cc];
+        row_xhat(xh, rstd, rok);
+        __syncthreads();                        // the tile is free
+        row_to_tile(xh, T, rr, sub);
+        __syncthreads();
+        float xw[16 + 2 * HALO];                // xhat of this channel, rows 16 seg - 3 .. 16 seg + 18 (zero outside the sample)
+#pragma unroll
+        for (int i = 0; i < 16 + 2 * HALO; ++i) {
+            const int r = 16 * seg - HALO + i;
+            xw[i] = (r >= 0 && r < QROWS) ? T[r * LDP + cc] : 0.f;
+        }
+        __syncthreads();
+        {   // dz = dy * relu bit * dropout: G operand of the pointwise weight gradient, B operand of du = dz Wp
+            const Drop dp = a.dp[l];
+            const uint32_t mwv[4] = {mw.x, mw.y, mw.z, mw.w};
+            Row4 dz;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t bits = mwv[j] >> (sub * 4);
+                float mm[4] = {1.f, 1.f, 1.f, 1.f};
+                if (dp.thresh) {
+                    const uint32_t base = (uint32_t)((row0 + rr) * D + sub * 4 + 32 * j);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) mm[i] = drop_keep_scale(dp, base + i);
+                }
+                dz.v[j].x = (bits & 1u) ? DY.v[j].x * mm[0] : 0.f;
+                dz.v[j].y = (bits & 2u) ? DY.v[j].y * mm[1] : 0.f;
+                dz.v[j].z = (bits & 4u) ? DY.v[j].z * mm[2] : 0.f;
+                dz.v[j].w = (bits & 8u) ? DY.v[j].w * mm[3] : 0.f;
+            }
+            row_store(dz, a.gz[l] + g0, rr, sub, rok);
+            row_to_tile(dz, T, rr, sub);
+        }
+        __syncthreads();
+        f32x16 du;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) du[r] = 0.f;
+        tgemm(T, a.WT3[l], plane_pw, D, 32 * w, 0, D / 16, du);
+        if (!mok) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) du[r] = 0.f;       // rows outside the sample: the conv's zero padding
+        }
+        __syncthreads();
+        d2tile(du, T, w, m, h);
+        __syncthreads();
+        {   // dv = depthwise^T(du) ; tap / gamma / beta partial sums over the sample's rows
+            float dw_[16 + 2 * HALO], dvo[16], gw[DWK], slb = 0.f, slg = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16 + 2 * HALO; ++i) {
+                const int r = 16 * seg - HALO + i;
+                dw_[i] = (r >= 0 && r < QROWS) ? T[r * LDP + cc] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < DWK; ++k) gw[k] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float dv = 0.f;
+#pragma unroll
+                for (int k = 0; k < DWK; ++k) {
+                    dv += wk[k] * dw_[i + 2 * HALO - k];
+                    const int rv = 16 * seg + i + k - HALO;                     // row of v this tap reads
+                    const float vv = (rv >= 0 && rv < L) ? xw[i + k] * gc + bc : 0.f;
+                    gw[k] += dw_[i + HALO] * vv;
+                }
+                dvo[i] = dv;
+                slb += (16 * seg + i < L) ? dv : 0.f;
+                slg += dv * xw[i + HALO];
+            }
+#pragma unroll
+            for (int k = 0; k < DWK; ++k) gw[k] += lane_xor1(gw[k]);
+            slb += lane_xor1(slb); slg += lane_xor1(slg);
+            if (seg == 0) {
+#pragma unroll
+                for (int k = 0; k < DWK; ++k) a.p_dw[l][((size_t)b * D + cc) * DWK + k] = gw[k];
+                a.p_lnb[l][(size_t)b * D + cc] = slb;
+                a.p_lng[l][(size_t)b * D + cc] = slg;
+            }
+            __syncthreads();                    // every du window is in registers
+#pragma unroll
+            for (int i = 0; i < 16; ++i) T[(16 * seg + i) * LDP + cc] = dvo[i];
+        }
+        __syncthreads();
+        {   // dy <- dy + LN^T(dv)
+            Row4 dvr, out;
+            tile_to_row(dvr, T, rr, sub);
+            row_ln_bwd(out, dvr, xh, rstd, a.ln_g[l], DY, sub, rok);
+            DY = out;
+        }
+        QSTAMP(24 + (3 - l));
+    });
+    row_store(DY, a.dx0 + g0, rr, sub, rok);            // grad wrt Embedding.linear's output (the positional table's partial slabs are these rows)
+
+    // ---- Embedding.linear, data gradient (:81-87 backward): dE = dx0 W
+    __syncthreads();
+    row_to_tile(DY, T, rr, sub);
+    __syncthreads();
+    {
+        const size_t plane_e = pack3_plane(D, a.EWc);
+        for (int blk = w; 32 * blk < a.EW; blk += 4) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            tgemm(T, a.WembT3, plane_e, a.EWc, 32 * blk, 0, D / 16, acc);
+            if (mok) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int col = 32 * blk + 8 * q + 4 * h;
+                    if (col < a.EW) *reinterpret_cast<float4*>(a.dE + (size_t)(row0 + m) * a.EW + col) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+                }
+            }
+        }
+    }
+    QSTAMP(28);
 }
 
 bool query_fused_ok(int L, int H) { return L <= QROWS && H == 8; }
 size_t query_fwd_lds() { return (size_t)(QROWS * LDP + QROWS) * sizeof(float); }
+size_t query_bwd_lds() { return (size_t)(QROWS * LDP + QROWS + 16 * QROWS) * sizeof(float); }
+void launch_query_bwd(const QueryBwdArgs& a, int B, hipStream_t s) {
+    VSL_LAUNCH(k_query_bwd, dim3(B), dim3(QT), query_bwd_lds(), s, a);
+    static int left = 2;
+    if (qdbg_on() && B > 16 && left > 0) {
+        --left;
+        qdbg_report("query_bwd: out block | attention | qkv + LN1 | L3 | L2 | L1 | L0 | linear", 20, 29, s);
+    }
+}
 void launch_query_fwd(const QueryFwdArgs& a, int B, hipStream_t s) {
     VSL_LAUNCH(k_query_fwd, dim3(B), dim3(QT), query_fwd_lds(), s, a);
+    static int left = 2;
+    if (qdbg_on() && B > 16 && left > 0) {
+        --left;
+        qdbg_report("query_fwd: linear | L0 | L1 | L2 | L3 | LN1+qkv | attention | out", 0, 9, s);
+        qdbg_report("  query_fwd L0 from d2tile: LN | dw | dw write | gemm | epilogue", 10, 16, s);
+    }
 }
 
 }  // namespace vsl

@@ -52,9 +52,9 @@ class VslError(RuntimeError):
 
 ABI_SYMBOLS = ['vsl_last_error', 'vsl_create', 'vsl_destroy', 'vsl_param_count', 'vsl_param_info', 'vsl_param_floats',
                'vsl_workspace_floats', 'vsl_forward', 'vsl_loss', 'vsl_backward', 'vsl_extract_index',
-               'vsl_adamw_step', 'vsl_workspace_offset', 'vsl_profile_select', 'vsl_profile_read', 'vsl_abi_version',
+               'vsl_adamw_step', 'vsl_workspace_offset', 'vsl_profile_select', 'vsl_profile_read', 'vsl_profile_launch', 'vsl_abi_version',
                'vsl_early_grad_offset']
-ABI_VERSION = 6                                     # include/vslnet_hip.h: VSL_ABI_VERSION
+ABI_VERSION = 7                                     # include/vslnet_hip.h: VSL_ABI_VERSION
 
 
 def load_library():
@@ -102,6 +102,8 @@ def load_library():
     lib.vsl_workspace_offset.restype = C.c_int64
     lib.vsl_profile_select.argtypes = [C.c_void_p, C.c_char_p]
     lib.vsl_profile_read.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+    lib.vsl_profile_launch.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                       C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     _LIB = lib
     return lib
 
@@ -350,6 +352,23 @@ class Engine:
                 break
             self._call(rc)
             out[name.value.decode()] = (ms.value, n.value)
+            i += 1
+        return out
+
+    def profile_launches(self):
+        """-> [dict(name, stream, start_us, stop_us, host_us, deps)] of every profiled launch since the last profile_select, in enqueue
+        order (tools/critical_path.py)."""
+        out, name = [], C.create_string_buffer(64)
+        st, t0, t1, th, nd = C.c_int32(), C.c_double(), C.c_double(), C.c_double(), C.c_int32()
+        deps = (C.c_int32 * 6)()
+        i = 0
+        while True:
+            rc = self.lib.vsl_profile_launch(self.h, i, name, 64, C.byref(st), C.byref(t0), C.byref(t1), C.byref(th), deps, C.byref(nd))
+            if rc == 2:
+                break
+            self._call(rc)
+            out.append(dict(name=name.value.decode(), stream=st.value, start_us=t0.value, stop_us=t1.value, host_us=th.value,
+                            deps=[deps[k] for k in range(nd.value)]))
             i += 1
         return out
 
