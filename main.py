@@ -209,32 +209,43 @@ def train(configs, dataset, features, device, world, rank, log=print):
                 if trace is not None:
                     trace['log'] += t3 - t2
                 if global_step % eval_period == 0 or global_step % n_batches == 0:
+                    rank0_error = None
                     if rank == 0:
-                        model.eval()
-                        r1i3, r1i5, r1i7, mi, score_str = runner.eval_test(model, test_loader, device, 'test', epoch + 1, global_step)
-                        t4 = clock()
-                        if trace is not None:
-                            trace['eval'] += t4 - t3
-                        log('Epoch: %2d | Step: %5d | r1i3: %.2f | r1i5: %.2f | r1i7: %.2f | mIoU: %.2f' % (epoch + 1, global_step, r1i3, r1i5, r1i7, mi))
-                        score_writer.write(score_str)
-                        score_writer.flush()
-                        history.append((global_step, {'r1i3': r1i3, 'r1i5': r1i5, 'r1i7': r1i7, 'mIoU': mi}))
-                        if r1i7 >= best_r1i7:
-                            best_r1i7 = r1i7
-                            ckpt.save_flat(model, os.path.join(model_dir, '{}_{}.t7'.format(configs.model_name, global_step)), model_dir,
-                                           suffix='t7', max_to_keep=3)
+                        # Whatever rank 0 raises here -- the evaluation, or a failed write of an EARLIER checkpoint that save_flat re-raises at its
+                        # entry -- is kept until every rank has agreed on it below: leaving the loop now would leave the other ranks in the
+                        # all-reduce until the communicator times out.
+                        try:
+                            model.eval()
+                            r1i3, r1i5, r1i7, mi, score_str = runner.eval_test(model, test_loader, device, 'test', epoch + 1, global_step)
+                            t4 = clock()
                             if trace is not None:
-                                trace['checkpoint'] += clock() - t4
-                        model.train()
+                                trace['eval'] += t4 - t3
+                            log('Epoch: %2d | Step: %5d | r1i3: %.2f | r1i5: %.2f | r1i7: %.2f | mIoU: %.2f' % (epoch + 1, global_step, r1i3, r1i5, r1i7, mi))
+                            score_writer.write(score_str)
+                            score_writer.flush()
+                            history.append((global_step, {'r1i3': r1i3, 'r1i5': r1i5, 'r1i7': r1i7, 'mIoU': mi}))
+                            if r1i7 >= best_r1i7:
+                                best_r1i7 = r1i7
+                                ckpt.save_flat(model, os.path.join(model_dir, '{}_{}.t7'.format(configs.model_name, global_step)), model_dir,
+                                               suffix='t7', max_to_keep=3)
+                                if trace is not None:
+                                    trace['checkpoint'] += clock() - t4
+                            model.train()
+                        except Exception as e:                                 # noqa: BLE001
+                            if world == 1:
+                                raise
+                            rank0_error = e
                     if world > 1:
-                        # rank 0 may have hit a checkpoint-write error (raised by the next save): agree on it BEFORE the barrier, or the
-                        # other ranks sit in the barrier / the next all-reduce until the communicator times out
-                        failed = torch.tensor([1 if (rank == 0 and ckpt is not None and ckpt.err is not None) else 0], device=device)
+                        # agree on rank 0's state BEFORE the barrier (run on every rank, unconditionally)
+                        bad = rank == 0 and (rank0_error is not None or (ckpt is not None and ckpt.err is not None))
+                        failed = torch.tensor([1 if bad else 0], device=device)
                         torch.distributed.all_reduce(failed)
                         if int(failed.item()):
                             if rank == 0:
+                                if rank0_error is not None:
+                                    raise rank0_error
                                 ckpt._raise_pending()
-                            raise RuntimeError('rank 0 failed to write a checkpoint; stopping every rank')
+                            raise RuntimeError('rank 0 failed during evaluation / checkpointing; stopping every rank')
                         torch.distributed.barrier()
             torch.cuda.synchronize(device)
             epoch_end.append(time.perf_counter())

@@ -575,7 +575,9 @@ enum { SITE_VIS = 64, SITE_WORD = 65, SITE_CHAR = 66, SITE_CQ_C = 67, SITE_CQ_Q 
 
 // ------------------------------------------------------------------------------------------------ forward
 struct HeadTail { HeadArgs hs, he; const float *x, *vmask; };     // AttnBlockArgs::head_tail
-void enc_fwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float* xin, const float* mask, int Bn, int app, const HeadTail* ht = nullptr) {
+struct CbMark { hipEvent_t ev = nullptr; int rec = -1; };        // stop event / ledger record of an application's conv-block launch
+void enc_fwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float* xin, const float* mask, int Bn, int app, const HeadTail* ht = nullptr,
+             CbMark* cb_mark = nullptr) {
     const int R = w.R, L = w.L, H = c.h->cfg.num_heads;
     {
         // the whole conv block + LN1 / QKV in ONE launch (kernels_enc.hip: 12-row recomputed halo)
@@ -595,6 +597,7 @@ void enc_fwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float*
             a.R = R; a.L = L;
         }
         LAUNCH("convblock_fwd", launch_convblock_fwd(a, c.s));
+        if (cb_mark && !c.dry) { cb_mark->ev = c.h->last_event(c.s); cb_mark->rec = c.h->prof_on ? (int)c.h->prof_recs.size() - 1 : -1; }
     }
     if (H == 8 && L <= 256) {      // longer sequences: K / V staged in LDS per 64 queries wins (T = 1024: 3.29 vs 3.33 ms)
         AttnBlockArgs ab;
@@ -642,9 +645,11 @@ std::vector<int> lstm_chunks(int T) {
 // steps only its granule ranges must be left alone or be re-zeroed by a plan change).
 static std::atomic<unsigned long long> g_rnn_launches{0};
 unsigned rnn_epoch(long long* gen = nullptr) {
+    // every tag carries the NaN pattern 0x7FE.....: counter value 0 gives 0x7FE00000, which is neither a cleared word (0) nor the tag of
+    // the launch before or after it -- no remap (mapping it onto ...01 made it collide with the next launch's tag)
     const unsigned long long n = g_rnn_launches.fetch_add(1) + 1;
     if (gen) *gen = (long long)(n >> 21);
-    return 0x7FE00000u | (unsigned)(n & 0x1FFFFFu) | ((n & 0x1FFFFFu) == 0 ? 1u : 0u);      // (counter value 0 is skipped: a cleared word must not look like a tag)
+    return 0x7FE00000u | (unsigned)(n & 0x1FFFFFu);
 }
 
 // first use of a plan's granule buffers in this workspace, or the epoch counter has wrapped since: one memset on the launch stream
@@ -655,9 +660,15 @@ static void rnn_granules_fresh(Ctx& c, Plan& p, long long gen) {
 }
 
 // Lq <= 32: the query branch runs as sample-local launches (kernels_query.hip) in both directions
-static bool query_fused(const Ctx& c) {
-    static const bool on = !(getenv("VSL_QUERY_FUSED") && getenv("VSL_QUERY_FUSED")[0] == '0');
-    return on && query_fused_ok(c.p->Lq, c.h->cfg.num_heads);
+// VSL_QUERY_FUSED: 0 = row-tile launches, 1 = both directions sample-local, 2 = forward only, 3 = backward only (A/B switch)
+static int query_fused_mode() {
+    static const int m = getenv("VSL_QUERY_FUSED") ? atoi(getenv("VSL_QUERY_FUSED")) : 1;
+    return m;
+}
+static bool query_fused(const Ctx& c, bool forward = true) {
+    const int m = query_fused_mode();
+    const bool on = m == 1 || (forward ? m == 2 : m == 3);
+    return on && query_fused_ok(c.p->Lq, c.h->cfg.num_heads, c.h->cfg.word_dim + 100);
 }
 
 void run_forward(Ctx& c) {
@@ -673,14 +684,13 @@ void run_forward(Ctx& c) {
     hipEvent_t pack_first_ev = nullptr, pack_q_ev = nullptr;
     int pack_first_rec = -1, pack_q_rec = -1;
     if (split3) {
-        // The step opens with the smallest pack there is (the char-conv image, 4 jobs): both side streams start behind ITS stop event (no
-        // marker packet), i.e. behind the caller's earlier work, and the query stream's first kernel -- the word + char embedding, 160
-        // workgroups x 125 KB of LDS -- runs beside the packs and VisualProjection, not beside the video pass' 144 KB conv block (which it kept
-        // off 160 CUs: 49 us in the step against 25 alone, profiles/r05_notes.md section 9).
-        LAUNCH("pack", launch_pack(io.params, c.W(p.pack), c.h->jobs_dev, njc, c.s));
+        // The main stream's pack carries the char-conv image as well, so the query stream's first kernel -- the word + char embedding, 160
+        // workgroups x 125 KB of LDS -- starts right behind it and runs beside the remaining packs and VisualProjection, not beside the video
+        // pass' conv block (which it kept off 160 CUs: 49 us in the step against 25 alone, profiles/r05_notes.md section 9); the Embedding
+        // linear's operand is packed on the third stream meanwhile.
+        LAUNCH("pack", launch_pack(io.params, c.W(p.pack), c.h->jobs_dev, njc + nj0, c.s));
         c.order2(c.main, sq, sp);
-        LAUNCH("pack", launch_pack(io.params, c.W(p.pack), c.h->jobs_dev + njc, nj0, c.s));
-        pack_first_ev = c.h->last_event(c.main);
+        pack_first_ev = nullptr;           // (the side streams already wait for this launch)
         pack_first_rec = c.h->prof_on ? (int)c.h->prof_recs.size() - 1 : -1;
         c.s = sp;
         LAUNCH("pack", launch_pack(io.params, c.W(p.pack), c.h->jobs_dev + njc + nj0, nj1, c.s));      // the Embedding linear's operand: the query stream waits for it behind embed_fwd
@@ -701,7 +711,8 @@ void run_forward(Ctx& c) {
     else
         LAUNCH("vproj_fwd", launch_vproj_fwd3(io.video_features, reinterpret_cast<const uint16_t*>(c.PK(K.va_f3)), c.P(P.va_b), c.W(p.vf), R, cf.video_feature_dim,
                                               c.drop(SITE_VIS), c.s, c.one_product));
-    enc_fwd(c, P.fe, K.fe, p.ve, c.W(p.vf), io.v_mask, B, 0);
+    CbMark vcb;
+    enc_fwd(c, P.fe, K.fe, p.ve, c.W(p.vf), io.v_mask, B, 0, nullptr, &vcb);
     c.s = qlong ? c.main : sq;
     const bool wt = cf.word_table != 0;       // trainable word table: its rows 0, 1, 2.. are pad, unk, the vocabulary
     LAUNCH("embed_fwd", launch_embed_fwd(io.word_ids, io.char_ids, wt ? c.P(P.unk) : io.pad_vec, c.P(P.unk) + (wt ? cf.word_dim : 0), wt ? c.P(P.unk) + 2 * cf.word_dim : io.glove_vec, c.P(P.char_tab), char_ptrs(c), c.PK(K.ccw_img), c.W(p.E),
@@ -718,6 +729,13 @@ void run_forward(Ctx& c) {
     }   // the shared encoder's packs (main stream)
     if (query_fused(c)) {
         // the rest of the query branch in ONE sample-local launch (kernels_query.hip)
+        // VSL_QORDER=1 (experiment): behind the video pass' conv block -- a conv-block workgroup fills its CU's register file, so a query
+        // workgroup that is resident when it launches costs it a second round of workgroups
+        static const bool qorder = getenv("VSL_QORDER") && getenv("VSL_QORDER")[0] == '1';
+        if (qorder && split3 && !c.dry && vcb.ev) {
+            (void)hipStreamWaitEvent(c.s, vcb.ev, 0); c.h->mark_waiting(c.s);
+            if (vcb.rec >= 0) c.h->prof_pending.push_back({c.s, vcb.rec});
+        }
         QueryFwdArgs qa;
         memset(&qa, 0, sizeof qa);
         if (!c.dry) {
@@ -1257,6 +1275,10 @@ void run_backward(Ctx& c) {
         j.out = c.slab(P.va_w, D * cf.video_feature_dim, nchunk);
         j.out_bias[0] = c.slab(P.va_b, D, nchunk);
         wb.j[wb.n++] = j;
+        // sample-local query backward (kernels_query.hip): nothing on the video stream waits for the query chain any more -- the video pass'
+        // pointwise weight gradients ride in THIS launch, the query side's own batch goes to the weight-gradient stream behind k_query_bwd.
+        // (Measured and dropped: the video pass' pointwise batch on the weight-gradient stream instead, +3.5 %: profiles/r06_notes.md)
+        if (query_fused(c, false)) { for (int i = 0; i < pw_video.n; ++i) wb.j[wb.n++] = pw_video.j[i]; }
         LAUNCH("wgrad", launch_wgrad(wb, c.s, c.one_product));
     }
     // ---- query pass, then the embedding stack (all on the other stream)
@@ -1266,7 +1288,7 @@ void run_backward(Ctx& c) {
     memset(&pw_query, 0, sizeof pw_query);
     const int EW = cf.word_dim + 100;
     // sample tiles (Lq <= 32): the query pass' conv-block backward goes on with the Embedding linear's data gradient on its rows of dx0
-    const bool qfused = query_fused(c);
+    const bool qfused = query_fused(c, false);
     const bool lin_hosted = qfused || (convblock_bwd_hosts_linear(Rq, Lq) && K.emb_t3_cols % 512 == 0);
     LinTail lt{nullptr, nullptr, EW, K.emb_t3_cols};
     if (lin_hosted && !c.dry) { lt.WT3 = reinterpret_cast<const uint16_t*>(c.PK(K.emb_t3)); lt.dA = c.W(p.dE); }
@@ -1277,6 +1299,7 @@ void run_backward(Ctx& c) {
     {   // every remaining weight gradient (video + query pointwise convs, embedding linear) in ONE launch on the video
         // stream, beside the embedding backward that ends the query stream
         WgradBatch wb_tail = pw_video;
+        if (qfused) wb_tail.n = 0;
         WgradJob j = wjob();
         if (!c.dry) { j.G[0] = c.W(p.dqf); j.Afull = c.W(p.E); }
         j.nG = 1; j.nA = 0; j.K = EW; j.R = Rq;
@@ -1285,7 +1308,7 @@ void run_backward(Ctx& c) {
         wb_tail.j[wb_tail.n++] = j;
         const bool fits = wb_tail.n + pw_query.n <= MAX_WJOBS;
         for (int i = 0; fits && i < pw_query.n; ++i) wb_tail.j[wb_tail.n++] = pw_query.j[i];
-        hipStream_t qs = c.s, vs = qlong ? sq : main_s;
+        hipStream_t qs = c.s, vs = qfused ? sw : (qlong ? sq : main_s);
         c.order(qs, vs);
         c.s = vs;
         LAUNCH("wgrad", launch_wgrad(wb_tail, c.s, c.one_product));
@@ -1327,6 +1350,8 @@ int build_plan(vsl_handle_s* h, int B, int T, int Lq, int Lc, Plan** out) {
         return fail("sequence length (T=%d, Lq=%d) exceeds max_pos_len=%d: the positional table has no such row "
                     "(layers_t7.py:196 -- IndexError in the reference)", T, Lq, cf.max_pos_len);
     if (T > MAX_L) return fail("T=%d > %d clips not supported by the LDS-resident attention kernels", T, MAX_L);
+    if ((int64_t)B * std::max(T, Lq) * D * 4 >= (int64_t(1) << 31))     // (the conv-block kernels address (R, 128) tensors with 32-bit byte offsets; 0x80000000 marks a dropped lane)
+        return fail("B*T = %lld rows: an (R, 128) fp32 activation must stay below 2 GiB for the 32-bit buffer offsets of the conv-block kernels", (long long)B * std::max(T, Lq));
     if (Lq > MAX_LQ) return fail("Lq=%d > %d query words: the CQAttention kernels keep the whole query of a sample in LDS "
                                  "(the reference truncates at max_pos_len words, data_gen.py:188)", Lq, MAX_LQ);
     if (Lc < 4 || Lc > MAX_LC) return fail("Lc=%d must be in [4, %d] (the widest char conv has kernel 4, layers_t7.py:52)", Lc, MAX_LC);

@@ -1,5 +1,5 @@
 // The QUERY branch of VSLNet as sample-local kernels (gfx950): one workgroup per sample, the whole 32-row window of a sample's words in
-// registers, ONE fp32 tile (17 KB) of LDS.
+// registers, 17 KB (one fp32 tile) + 2 x 26 KB (bf16 operand planes) of LDS.
 //
 // Every kernel of the query branch is sample-local: Lq <= 32 words, and nothing on a word's path needs another sample -- Embedding.linear
 // (/root/reference/model/layers_t7.py:83-88), FeatureEncoder at L = Lq (:193-205: positional rows, the four conv layers :131-140, the
@@ -21,8 +21,12 @@
 //     straight from the accumulator registers (the lane's 16 channels / 16 keys ARE the contraction pairs (8 a + b, 8 a + 4 + b) of the two
 //     half-waves), only V passes through the wave's own 32 columns of the tile.
 // GEMMs run at fp32 grade on the bf16 matrix cores (common.hpp: 3-way split, six products) against the split packs the row-tile kernels
-// read (PackJob type 6 / 7): the weight fragment of lane (n, h) is one 16-byte load per plane, the activation fragment is split in
-// registers (44 vector instructions per K = 16 step).  The 20 x 20 attention products use the fp32-input v_mfma_f32_32x32x2_f32.
+// read (PackJob type 6 / 7): the weight fragment of lane (n, h) is one 16-byte load per plane; the activation operand is split ONCE by the
+// phase that produces it, into three bf16 planes in LDS (a per-wave split in the GEMM loop made a K = 128 product 7.3 k cycles for 1.5 k
+// of matrix pipe: profiles/r06_notes.md), and the eight weight steps of the NEXT product stream into the fragment ring while the current one
+// runs.  The 20 x 20 attention products use the fp32-input v_mfma_f32_32x32x2_f32.
+// What round 6 measured about running beside the video chain: see profiles/r06_notes.md -- a conv-block workgroup of the video pass fills the
+// register file of its CU (215 / 255 VGPRs x 2 waves per SIMD), so NOTHING co-resides with it, whatever its LDS footprint.
 #include "common.hpp"
 #include "launch.hpp"
 
@@ -54,6 +58,7 @@ static void qdbg_report(const char* name, int i0, int i1, hipStream_t s) {
 
 constexpr int QT = 256;                         // threads per workgroup: 4 waves, one per SIMD
 constexpr int QROWS = 32;                       // rows of a sample window (L <= 32)
+constexpr int QMAXCH = 4;                       // 128-column chunks of an Embedding row the forward keeps in registers (word_dim + 100 <= 512)
 
 __device__ __forceinline__ int nl(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
@@ -89,112 +94,135 @@ __device__ __forceinline__ void vec2d(f32x16& x, const float* __restrict__ v, in
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// acc (32 channels x 32 rows, T layout) += sum over K = 16 steps s0 .. s0 + ns - 1 of the split pack:
-//   weight operand  : lane (n = lane & 31, h) reads column `col0 + n` of each plane, k = 16 s + 8 h .. + 7 (one 16-byte load per plane),
-//                     GS3_NB steps ahead in a register ring;
-//   activation      : lane (m, h) reads T[m][16 (s - s0) + 8 h .. + 7] (two ds_read_b128, one step ahead) and splits it in registers.
-// Two alternating accumulators: consecutive MFMAs never wait for each other's result.
+// Operand planes: three bf16 planes (terms h, m, l) [32 rows][QLB], QPS elements between planes; 272-byte rows: conflict-free ds_read_b128.
 // ---------------------------------------------------------------------------------------------------------
-struct AF3 { u32x4_t t[3]; };
-__device__ __forceinline__ void split8(const float4& x, const float4& y, AF3& f) {
-    uint32_t h0, m0, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
-    split3(x.x, x.y, h0, m0, l0);
-    split3(x.z, x.w, h1, m1, l1);
-    split3(y.x, y.y, h2, m2, l2);
-    split3(y.z, y.w, h3, m3, l3);
-    f.t[0] = u32x4_t{h0, h1, h2, h3};
-    f.t[1] = u32x4_t{m0, m1, m2, m3};
-    f.t[2] = u32x4_t{l0, l1, l2, l3};
+constexpr int QLB = D + 8;
+constexpr int QPS = QROWS * QLB;
+constexpr int QPLANES = 3 * QPS;                // bf16 elements of one operand buffer (26 112 B)
+// T layout registers -> planes (lane (m, h): 4 consecutive channels per a)
+__device__ __forceinline__ void d2planes(const f32x16& x, uint16_t* __restrict__ P, int w, int m, int h) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a) split_store4(P, QLB, QPS, m, 32 * w + 8 * a + 4 * h, make_float4(x[4 * a], x[4 * a + 1], x[4 * a + 2], x[4 * a + 3]));
 }
-__device__ __forceinline__ void tgemm(const float* __restrict__ T, const uint16_t* __restrict__ W3, size_t plane, int ncols, int col0, int s0, int ns,
-                                      f32x16& acc) {
-    const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
-    const float* tr = T + m * LDP + 8 * h;
-    const uint16_t* wl = W3 + ((size_t)s0 * ncols + col0 + m) * 16 + 8 * h;
-    const size_t sstep = (size_t)ncols * 16;
-    Frag3 ring[GS3_NB];
-    auto wload = [&](int s, Frag3& f) {
-        const uint16_t* p = wl + (size_t)min(s, ns - 1) * sstep;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) f.t[q] = *reinterpret_cast<const u32x4_t*>(p + q * plane);
-    };
-    static_for<0, GS3_NB>([&](auto uc) { wload(decltype(uc)::value, ring[decltype(uc)::value]); });
-    float4 xa[2], xb[2];
-    auto aread = [&](int s, float4& p, float4& q) {
-        const float* t = tr + 16 * min(s, ns - 1);
-        p = *reinterpret_cast<const float4*>(t);
-        q = *reinterpret_cast<const float4*>(t + 4);
-    };
-    aread(0, xa[0], xb[0]);
-    f32x16 acc2;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
-    for (int sb = 0; sb < ns; sb += GS3_NB)
-        static_for<0, GS3_NB>([&](auto uc) {
-            constexpr int u = decltype(uc)::value;
-            const int s = sb + u;
-            if (s < ns) {
-                AF3 af;
-                split8(xa[u & 1], xb[u & 1], af);
-                aread(s + 1, xa[(u + 1) & 1], xb[(u + 1) & 1]);
-                constexpr int TW[6] = {1, 0, 2, 0, 1, 0}, TX[6] = {1, 2, 0, 1, 0, 0};      // (weight term, activation term): mm, hl, lh, hm, mh, hh
-#pragma unroll
-                for (int p = 0; p < 6; ++p) {
-                    if (p & 1) acc2 = mfma_bf16(ring[u].t[TW[p]], af.t[TX[p]], acc2);
-                    else acc = mfma_bf16(ring[u].t[TW[p]], af.t[TX[p]], acc);
-                }
-                wload(s + GS3_NB, ring[u]);
-            }
-        });
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
+// COLUMN-phase producer (thread = channel c, two rows i0 / i0 + 1 of its segment): even lanes take row i0 of channels (c, c + 1), odd lanes
+// row i0 + 1 of channels (c - 1, c) -- one quad-permute exchange per row pair
+__device__ __forceinline__ void pair_split_store(uint16_t* __restrict__ P, int row0, int c, float v0, float v1) {
+    const bool odd = c & 1;
+    const float recv = lane_xor1(odd ? v0 : v1);
+    uint32_t th, tm, tl;
+    split3(odd ? recv : v0, odd ? v1 : recv, th, tm, tl);
+    uint32_t* d = reinterpret_cast<uint32_t*>(P + (row0 + (odd ? 1 : 0)) * QLB + (c & ~1));
+    d[0] = th; d[QPS / 2] = tm; d[QPS] = tl;
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// row phase: 8 lanes per row (lane sub owns float4 columns 4 sub + 32 j), 32 rows per pass of the 256 threads.
-// In place on the tile: T[row] <- LN(T[row]) * dropout for row < L, zeros for row >= L (the conv's zero padding / a defined GEMM
-// operand); the RAW row (the residual stream) goes to `raw_out`, the result to `ln_out` (both nullable, rows < L).
+// acc (32 channels x 32 rows, T layout) += sum over the ns <= 8 K = 16 steps held in the fragment ring:
+//   weight operand : ring slot s = lane (n = lane & 31, h)'s fragment of step s (column col0 + n, k = 16 s + 8 h .. + 7 of each plane);
+//   activation     : lane (m, h) reads planes[m][16 s + 8 h .. + 7] (three ds_read_b128, one step ahead).
+// While step s runs, slot s is reloaded with step s of the NEXT product (`nx`), so a product's weights are in registers long before its
+// operand planes are written.  Two alternating accumulators: consecutive MFMAs never wait for each other's result.
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void row_ln(float* __restrict__ T, int L, const float* __restrict__ g, const float* __restrict__ b, const Drop& dp,
-                                       int grow0, float* __restrict__ raw_out, float* __restrict__ ln_out) {
-    const int sub = threadIdx.x & 7, r = threadIdx.x >> 3;
-    float* row = T + r * LDP + sub * 4;
-    if (r >= L) {
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+struct AF3 { u32x4_t t[3]; };
+struct WRing { Frag3 f[8]; };
+// wl: this lane's address of step 0 ; ns = 0: nothing follows (wave-uniform) ; slim: last step that exists in the pack -- a product whose K is not a
+// multiple of 128 still runs eight steps, the steps past the end re-read the last one against zero activations
+struct WNext { const uint16_t* wl; size_t plane, sstep; int ns, slim; };
+__device__ __forceinline__ WNext wnext(const uint16_t* W3, size_t plane, int ncols, int col0, int s0, int ns, int slim = 7) {
+    const int lane = threadIdx.x & 63;
+    return WNext{W3 + ((size_t)s0 * ncols + col0 + (lane & 31)) * 16 + 8 * (lane >> 5), plane, (size_t)ncols * 16, W3 ? ns : 0, slim};
+}
+__device__ __forceinline__ void wload(Frag3& f, const WNext& n, int s) {
+    const uint16_t* p = n.wl + (size_t)min(s, n.slim) * n.sstep;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(row + 32 * j) = z;
-        return;
+    for (int q = 0; q < 3; ++q) f.t[q] = *reinterpret_cast<const u32x4_t*>(p + q * n.plane);
+}
+__device__ __forceinline__ void wprefetch(WRing& r, const WNext& n) {
+    static_for<0, 8>([&](auto sc) { constexpr int s = decltype(sc)::value; if (s < n.ns) wload(r.f[s], n, s); });
+}
+// NS = compile-time step count (8, or 1 for the tail chunk of a K that is not a multiple of 128)
+template <int NS>
+__device__ __forceinline__ void tgemm(const uint16_t* __restrict__ P, WRing& ring, f32x16& acc, const WNext& nx) {
+    const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
+    const uint16_t* pr = P + m * QLB + 8 * h;
+    // every operand fragment of the product is requested before its first MFMA (one wave per SIMD: registers are plentiful, and nothing
+    // else hides the LDS latency -- with the reads one step ahead the compiler left two MFMAs between a read and its use)
+    AF3 b[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) b[s].t[q] = *reinterpret_cast<const u32x4_t*>(pr + 16 * s + q * QPS);
+    // slots this product does not use: the next product's fragments can go there right away
+    static_for<NS, 8>([&](auto sc) { constexpr int s = decltype(sc)::value; if (s < nx.ns) wload(ring.f[s], nx, s); });
+    f32x16 acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+    static_for<0, NS>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        constexpr int TW[6] = {1, 0, 2, 0, 1, 0}, TX[6] = {1, 2, 0, 1, 0, 0};      // (weight term, activation term): mm, hl, lh, hm, mh, hh
+#pragma unroll
+        for (int p = 0; p < 6; ++p) {
+            if (p & 1) acc2 = mfma_bf16(ring.f[s].t[TW[p]], b[s].t[TX[p]], acc2);
+            else acc = mfma_bf16(ring.f[s].t[TW[p]], b[s].t[TX[p]], acc);
+        }
+        if (s < nx.ns) wload(ring.f[s], nx, s);
+    });
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
+}
+// ---------------------------------------------------------------------------------------------------------
+// ROW layout: 8 lanes per row (lane `sub` owns float4 columns 4 sub + 32 j), 32 rows per pass of the 256 threads.
+// ---------------------------------------------------------------------------------------------------------
+struct Row4 { float4 v[4]; };
+__device__ __forceinline__ void row_vec(Row4& x, const float* __restrict__ v, int sub) {        // a per-channel vector (gamma, beta)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x.v[j] = *reinterpret_cast<const float4*>(v + sub * 4 + 32 * j);
+}
+__device__ __forceinline__ void row_load(Row4& x, const float* __restrict__ g, int rr, int sub, bool ok) {       // g = row 0 of the sample
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x.v[j] = ok ? *reinterpret_cast<const float4*>(g + (size_t)rr * D + sub * 4 + 32 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__device__ __forceinline__ void row_store(const Row4& x, float* __restrict__ g, int rr, int sub, bool ok) {
+    if (ok) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(g + (size_t)rr * D + sub * 4 + 32 * j) = x.v[j];
     }
-    float4 v[4];
+}
+__device__ __forceinline__ void row_to_tile(const Row4& x, float* __restrict__ T, int rr, int sub) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(T + rr * LDP + sub * 4 + 32 * j) = x.v[j];
+}
+__device__ __forceinline__ void tile_to_row(Row4& x, const float* __restrict__ T, int rr, int sub) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x.v[j] = *reinterpret_cast<const float4*>(T + rr * LDP + sub * 4 + 32 * j);
+}
+__device__ __forceinline__ void row_to_planes(const Row4& x, uint16_t* __restrict__ P, int rr, int sub) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split_store4(P, QLB, QPS, rr, sub * 4 + 32 * j, x.v[j]);
+}
+// LayerNorm of the thread's row (+ dropout): x <- LN(x) * m for rows that exist, zeros otherwise (the conv's zero padding / a defined operand)
+__device__ __forceinline__ void row_ln(Row4& x, const Row4& g, const Row4& b, const Drop& dp, int grow, int sub, bool ok) {
     float sum = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { v[j] = *reinterpret_cast<const float4*>(row + 32 * j); sum += sum4(v[j]); }
-    if (raw_out) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(raw_out + (size_t)r * D + sub * 4 + 32 * j) = v[j];
-    }
+    for (int j = 0; j < 4; ++j) sum += sum4(x.v[j]);
     const float mu = grp8_sum(sum) * (1.0f / D);
     float q = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        v[j].x -= mu; v[j].y -= mu; v[j].z -= mu; v[j].w -= mu;
-        q += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
+        x.v[j].x -= mu; x.v[j].y -= mu; x.v[j].z -= mu; x.v[j].w -= mu;
+        q += x.v[j].x * x.v[j].x + x.v[j].y * x.v[j].y + x.v[j].z * x.v[j].z + x.v[j].w * x.v[j].w;
     }
     const float rstd = rsqrtf(grp8_sum(q) * (1.0f / D) + LN_EPS);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const float4 gv = *reinterpret_cast<const float4*>(g + sub * 4 + 32 * j);
-        const float4 bv = *reinterpret_cast<const float4*>(b + sub * 4 + 32 * j);
         float4 o;
-        o.x = v[j].x * rstd * gv.x + bv.x; o.y = v[j].y * rstd * gv.y + bv.y;
-        o.z = v[j].z * rstd * gv.z + bv.z; o.w = v[j].w * rstd * gv.w + bv.w;
+        o.x = x.v[j].x * rstd * g.v[j].x + b.v[j].x; o.y = x.v[j].y * rstd * g.v[j].y + b.v[j].y;
+        o.z = x.v[j].z * rstd * g.v[j].z + b.v[j].z; o.w = x.v[j].w * rstd * g.v[j].w + b.v[j].w;
         if (dp.thresh) {
-            const uint32_t base = (uint32_t)((grow0 + r) * D + sub * 4 + 32 * j);
+            const uint32_t base = (uint32_t)(grow * D + sub * 4 + 32 * j);
             o.x *= drop_keep_scale(dp, base); o.y *= drop_keep_scale(dp, base + 1);
             o.z *= drop_keep_scale(dp, base + 2); o.w *= drop_keep_scale(dp, base + 3);
         }
-        if (ln_out) *reinterpret_cast<float4*>(ln_out + (size_t)r * D + sub * 4 + 32 * j) = o;
-        *reinterpret_cast<float4*>(row + 32 * j) = o;
+        x.v[j] = ok ? o : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 
@@ -203,69 +231,95 @@ __device__ __forceinline__ void row_ln(float* __restrict__ T, int L, const float
 // Saves exactly what the row-tile kernels save (qf, x0, y0..3, u0..3, ReLU bits, h1, q, k, v, LSE, att, r, h2, out): the backward and the
 // weight-gradient launches do not care which forward produced them.
 // =========================================================================================================
-__global__ __launch_bounds__(QT, 2) void k_query_fwd(QueryFwdArgs a) {
+__global__ __launch_bounds__(QT) void k_query_fwd(QueryFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* T = smem;                            // [32][LDP]
+    float* T = smem;                            // [32][LDP] fp32 tile: residual stream by rows / by channel columns, V of the attention
     float* Mb = T + QROWS * LDP;                // key bias of the sample
+    uint16_t* P0 = reinterpret_cast<uint16_t*>(Mb + QROWS);     // two operand-plane buffers, used alternately
+    uint16_t* P1 = P0 + QPLANES;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, m = lane & 31, h = lane >> 5;
+    const int rr = tid >> 3, sub = tid & 7;
     const int L = a.L, b = blockIdx.x, row0 = b * L;
     const size_t g0 = (size_t)row0 * D;
+    const bool rok = rr < L;
     QSTAMP(0);
     if (tid < QROWS) Mb[tid] = tid < L ? (1.0f - a.mask[row0 + tid]) * MASK_VALUE : MASK_VALUE;
+    const size_t plane_pw = pack3_plane(D, D), plane_qkv = pack3_plane(D, 3 * D);
+    const Drop nodrop{0u, 0u, 1.f, 0u};
+    WRing ring;
 
-    // ---- Embedding.linear (:86-88): x = E W^T + b, E staged through the tile in 128-column chunks
+    // ---- Embedding.linear (:86-88): x = E W^T + b, E split into the operand planes in 128-column chunks (two buffers: one barrier per chunk)
     f32x16 X;
     {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const int EW = a.EW, Kp = (EW + 15) & ~15;
+        const int EW = a.EW, Kp = (EW + 15) & ~15, nch = (Kp + D - 1) / D;
         const size_t plane = pack3_plane(Kp, D);
-        const int sub = tid & 7, rr = tid >> 3;
-        for (int c0 = 0; c0 < EW; c0 += D) {
-            float4 v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int c = c0 + sub * 4 + 32 * j;
-                v[j] = (rr < L && c < EW) ? *reinterpret_cast<const float4*>(a.E + (size_t)(row0 + rr) * EW + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            if (c0) __syncthreads();            // the previous chunk's readers are done
-#pragma unroll
-            for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(T + rr * LDP + sub * 4 + 32 * j) = v[j];
-            __syncthreads();
-            const int ns = (min(D, Kp - c0)) >> 4;
-            tgemm(T, a.Wemb3, plane, D, 32 * w, c0 >> 4, ns, acc);
-        }
+        // every chunk runs eight K = 16 steps (columns past EW are zeros in the planes, steps past the pack's end re-read its last step)
+        const int nst = Kp >> 4;
+        auto chunk_w = [&](int ci) { return wnext(a.Wemb3, plane, D, 32 * w, 8 * ci, 8, nst - 1 - 8 * ci); };
+        wprefetch(ring, chunk_w(0));
         f32x16 bv, pv;
         vec2d(bv, a.b_emb, w, h);
         global2d(pv, a.pos, w, m, h, L);        // positional rows 0 .. L - 1 (:202)
+        auto erow = [&](Row4& e, int ci) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = D * ci + sub * 4 + 32 * j;
+                e.v[j] = (rok && c < EW) ? *reinterpret_cast<const float4*>(a.E + (size_t)(row0 + rr) * EW + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        Row4 e, en;
+        erow(e, 0);
+#pragma unroll 1
+        for (int ci = 0; ci < nch; ++ci) {
+            erow(en, ci + 1);                   // next chunk's row: in flight during this chunk's product (past the end: zeros)
+            uint16_t* P = (ci & 1) ? P1 : P0;
+            row_to_planes(e, P, rr, sub);
+            __syncthreads();
+            const WNext nx = ci + 1 < nch ? chunk_w(ci + 1) : wnext(a.W3[0], plane_pw, D, 32 * w, 0, 8);
+            tgemm<8>(P, ring, acc, nx);
+            e = en;
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] += bv[r];
         if (a.qf) d2global(acc, a.qf + g0, w, m, h, L);
 #pragma unroll
         for (int r = 0; r < 16; ++r) X[r] = acc[r] + pv[r];
     }
-    __syncthreads();
     QSTAMP(1);
 
     // ---- four conv layers (:133-139): x <- x + drop(relu(pointwise(depthwise7(LN(x)))))
-    const size_t plane_pw = pack3_plane(D, D);
-    static_for<0, 4>([&](auto LC) {
-        constexpr int l = decltype(LC)::value;
+    // (a real loop: the kernel executes every instruction ONCE per workgroup and one workgroup runs per CU, so unrolled it was 128 KB of
+    // straight-line code against a 64 KB instruction cache -- instruction fetch, not the matrix pipe, set its time)
+#pragma unroll 1
+    for (int l = 0; l < 4; ++l) {
+        // small operands of the layer: requested before the barriers they are needed behind
+        Row4 gl, bl;
+        row_vec(gl, a.ln_g[l], sub);
+        row_vec(bl, a.ln_b[l], sub);
+        const int c = tid & 127, os = 16 * (tid >> 7);
+        float wk[DWK];
+#pragma unroll
+        for (int k = 0; k < DWK; ++k) wk[k] = a.dw_w[l][c * DWK + k];
+        f32x16 bv;
+        vec2d(bv, a.pw_b[l], w, h);
         d2tile(X, T, w, m, h);
         __syncthreads();
         if (l == 0) QSTAMP(10);
         {
-            const Drop nodrop{0u, 0u, 1.f, 0u};
-            row_ln(T, L, a.ln_g[l], a.ln_b[l], nodrop, row0, (l == 0 ? a.x0 : a.y[l > 0 ? l - 1 : 0]) + g0, nullptr);
+            Row4 x;
+            tile_to_row(x, T, rr, sub);
+            row_store(x, (l == 0 ? a.x0 : a.y[max(l - 1, 0)]) + g0, rr, sub, rok);
+            row_ln(x, gl, bl, nodrop, 0, sub, rok);
+            row_to_tile(x, T, rr, sub);
         }
         __syncthreads();
         if (l == 0) QSTAMP(11);
+        uint16_t* P = (l & 1) ? P1 : P0;
         {   // depthwise conv k = 7 along the sequence: thread = (channel, half of the rows); rows outside [0, L) are zeros in the tile
-            const int c = tid & 127, os = 16 * (tid >> 7);
-            float wk[DWK], win[16 + 2 * HALO], uo[16];
-#pragma unroll
-            for (int k = 0; k < DWK; ++k) wk[k] = a.dw_w[l][c * DWK + k];
+            float win[16 + 2 * HALO], uo[16];
 #pragma unroll
             for (int i = 0; i < 16 + 2 * HALO; ++i) {
                 const int r = os - HALO + i;
@@ -278,24 +332,21 @@ __global__ __launch_bounds__(QT, 2) void k_query_fwd(QueryFwdArgs a) {
                 for (int k = 0; k < DWK; ++k) u += wk[k] * win[i + k];
                 uo[i] = u;
             }
-            __syncthreads();                    // every window is in registers
             if (l == 0) QSTAMP(12);
             float* ug = a.u[l] + g0 + c;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                T[(os + i) * LDP + c] = uo[i];
+            for (int i = 0; i < 16; i += 2) pair_split_store(P, os + i, c, uo[i], uo[i + 1]);     // GEMM operand: three bf16 planes
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
                 if (os + i < L) ug[(size_t)(os + i) * D] = uo[i];       // saved: A operand of the weight gradient
-            }
         }
         __syncthreads();
         if (l == 0) QSTAMP(13);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        tgemm(T, a.W3[l], plane_pw, D, 32 * w, 0, D / 16, acc);
+        tgemm<8>(P, ring, acc, l < 3 ? wnext(a.W3[min(l + 1, 3)], plane_pw, D, 32 * w, 0, 8) : wnext(a.Wqkv3, plane_qkv, 3 * D, 32 * w, 0, 8));
         if (l == 0) QSTAMP(14);
-        f32x16 bv;
-        vec2d(bv, a.pw_b[l], w, h);
         const Drop dp = a.dp[l];
         uint32_t bits[2] = {0u, 0u};            // ReLU decisions of this lane's channels inside the two 16-channel groups of the wave
 #pragma unroll
@@ -307,53 +358,48 @@ __global__ __launch_bounds__(QT, 2) void k_query_fwd(QueryFwdArgs a) {
             if (z > 0.f) bits[r >> 3] |= 1u << (nl(r, h) & 15);
         }
         {   // (R, 4) uint32 words seen as uint16: [row][16-channel group]; the two half-waves hold disjoint bits of both groups
-            auto orr = [](uint32_t p, uint32_t q) { return p | q; };
             const unsigned u0 = bits[0], u1 = bits[1];
             auto r0 = __builtin_amdgcn_permlane32_swap(u0, u0, false, false);
             auto r1 = __builtin_amdgcn_permlane32_swap(u1, u1, false, false);
-            const uint32_t g0b = orr(r0[0], r0[1]), g1b = orr(r1[0], r1[1]);
+            const uint32_t g0b = r0[0] | r0[1], g1b = r1[0] | r1[1];
             uint16_t* mk = reinterpret_cast<uint16_t*>(a.relu_mask[l]);
             if (m < L) mk[(size_t)(row0 + m) * 8 + 2 * w + h] = (uint16_t)(h ? g1b : g0b);
         }
         if (l == 0) QSTAMP(15);
-        __syncthreads();                        // every wave is through with the tile
         QSTAMP(2 + l);
-    });
+    }
 
     // ---- a8 first half (:168-173): h1 = drop(LN1(y3)) ; q, k, v = h1 W^T + b
-    d2tile(X, T, w, m, h);
-    __syncthreads();
-    row_ln(T, L, a.ln1_g, a.ln1_b, a.d1, row0, a.y[3] + g0, a.h1 ? a.h1 + g0 : nullptr);
-    __syncthreads();
     f32x16 Q, K, V;
     {
-        const size_t plane_qkv = pack3_plane(D, 3 * D);
-        f32x16 bv;
+        Row4 gl, bl, x;
+        row_vec(gl, a.ln1_g, sub);
+        row_vec(bl, a.ln1_b, sub);
+        f32x16 bq, bk, bvv;
+        vec2d(bq, a.bq, w, h);
+        vec2d(bk, a.bk, w, h);
+        vec2d(bvv, a.bv, w, h);
+        d2tile(X, T, w, m, h);
+        __syncthreads();
+        tile_to_row(x, T, rr, sub);
+        row_store(x, a.y[3] + g0, rr, sub, rok);
+        row_ln(x, gl, bl, a.d1, row0 + rr, sub, rok);
+        if (a.h1) row_store(x, a.h1 + g0, rr, sub, rok);
+        row_to_planes(x, P0, rr, sub);
+        __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 16; ++r) Q[r] = 0.f;
-        tgemm(T, a.Wqkv3, plane_qkv, 3 * D, 32 * w, 0, D / 16, Q);
-        vec2d(bv, a.bq, w, h);
+        for (int r = 0; r < 16; ++r) { Q[r] = 0.f; K[r] = 0.f; V[r] = 0.f; }
+        tgemm<8>(P0, ring, Q, wnext(a.Wqkv3, plane_qkv, 3 * D, D + 32 * w, 0, 8));
+        tgemm<8>(P0, ring, K, wnext(a.Wqkv3, plane_qkv, 3 * D, 2 * D + 32 * w, 0, 8));
+        tgemm<8>(P0, ring, V, wnext(a.Wo3, plane_pw, D, 32 * w, 0, 8));
 #pragma unroll
-        for (int r = 0; r < 16; ++r) Q[r] += bv[r];
+        for (int r = 0; r < 16; ++r) { Q[r] += bq[r]; K[r] += bk[r]; V[r] += bvv[r]; }
         d2global(Q, a.q + g0, w, m, h, L);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) K[r] = 0.f;
-        tgemm(T, a.Wqkv3, plane_qkv, 3 * D, D + 32 * w, 0, D / 16, K);
-        vec2d(bv, a.bk, w, h);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) K[r] += bv[r];
         d2global(K, a.k + g0, w, m, h, L);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) V[r] = 0.f;
-        tgemm(T, a.Wqkv3, plane_qkv, 3 * D, 2 * D + 32 * w, 0, D / 16, V);
-        vec2d(bv, a.bv, w, h);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) V[r] += bv[r];
         d2global(V, a.v + g0, w, m, h, L);
     }
     QSTAMP(6);
-    __syncthreads();                            // the tile's readers are done
-    d2tile(V, T, w, m, h);                      // V[key][channel]: each wave reads back its own 32 columns only
+    d2tile(V, T, w, m, h);                      // V[key][channel]: each wave reads back its own 32 columns only (the tile's row-phase readers are behind the barrier above)
     __syncthreads();
 
     // ---- attention core (:174-182), heads 2 w and 2 w + 1: S^T = K Q^T (lane = query, registers = keys), softmax in the lane, O^T = V^T P^T
@@ -392,27 +438,34 @@ __global__ __launch_bounds__(QT, 2) void k_query_fwd(QueryFwdArgs a) {
     d2global(att, a.att + g0, w, m, h, L);
     QSTAMP(7);
     // ---- output block (:183-190): r = drop(att) + x ; h2 = drop(LN2(r)) ; y = drop(h2 Wo^T + b) + r
-#pragma unroll
-    for (int r = 0; r < 16; ++r) X[r] += att[r] * drop_mul(a.d3, (uint32_t)((row0 + m) * D + 32 * w + nl(r, h)));
-    __syncthreads();                            // V's readers are done
-    d2tile(X, T, w, m, h);
-    __syncthreads();
-    row_ln(T, L, a.ln2_g, a.ln2_b, a.d4, row0, a.r + g0, a.h2 ? a.h2 + g0 : nullptr);
-    __syncthreads();
     {
-        f32x16 acc, bv;
+        Row4 gl, bl, x;
+        row_vec(gl, a.ln2_g, sub);
+        row_vec(bl, a.ln2_b, sub);
+        f32x16 bo;
+        vec2d(bo, a.bo, w, h);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) X[r] += att[r] * drop_mul(a.d3, (uint32_t)((row0 + m) * D + 32 * w + nl(r, h)));
+        __syncthreads();                        // V's readers are done
+        d2tile(X, T, w, m, h);
+        __syncthreads();
+        tile_to_row(x, T, rr, sub);
+        row_store(x, a.r + g0, rr, sub, rok);
+        row_ln(x, gl, bl, a.d4, row0 + rr, sub, rok);
+        if (a.h2) row_store(x, a.h2 + g0, rr, sub, rok);
+        row_to_planes(x, P1, rr, sub);
+        __syncthreads();
+        f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        tgemm(T, a.Wo3, plane_pw, D, 32 * w, 0, D / 16, acc);
-        vec2d(bv, a.bo, w, h);
+        tgemm<8>(P1, ring, acc, wnext(a.Wo3, plane_pw, D, 32 * w, 0, 0));
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            X[r] += (acc[r] + bv[r]) * drop_mul(a.d5, (uint32_t)((row0 + m) * D + 32 * w + nl(r, h)));
+            X[r] += (acc[r] + bo[r]) * drop_mul(a.d5, (uint32_t)((row0 + m) * D + 32 * w + nl(r, h)));
     }
     d2global(X, a.out + g0, w, m, h, L);
     QSTAMP(8);
 }
-
 
 // =========================================================================================================
 // k_query_bwd: the backward of k_query_fwd's encoder application + the Embedding linear's data gradient, one workgroup per sample.
@@ -427,25 +480,6 @@ __global__ __launch_bounds__(QT, 2) void k_query_fwd(QueryFwdArgs a) {
 // phase to phase;  COLUMN layout (thread = channel c = tid >> 1, row half seg = tid & 1; the two halves of a channel in adjacent lanes):
 // depthwise^T, the tap gradients and every per-channel sum over the sample's rows.
 // =========================================================================================================
-struct Row4 { float4 v[4]; };
-__device__ __forceinline__ void row_load(Row4& x, const float* __restrict__ g, int rr, int sub, bool ok) {       // g = row 0 of the sample
-#pragma unroll
-    for (int j = 0; j < 4; ++j) x.v[j] = ok ? *reinterpret_cast<const float4*>(g + (size_t)rr * D + sub * 4 + 32 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
-}
-__device__ __forceinline__ void row_store(const Row4& x, float* __restrict__ g, int rr, int sub, bool ok) {
-    if (ok) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(g + (size_t)rr * D + sub * 4 + 32 * j) = x.v[j];
-    }
-}
-__device__ __forceinline__ void row_to_tile(const Row4& x, float* __restrict__ T, int rr, int sub) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(T + rr * LDP + sub * 4 + 32 * j) = x.v[j];
-}
-__device__ __forceinline__ void tile_to_row(Row4& x, const float* __restrict__ T, int rr, int sub) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) x.v[j] = *reinterpret_cast<const float4*>(T + rr * LDP + sub * 4 + 32 * j);
-}
 __device__ __forceinline__ void tile2d(f32x16& x, const float* __restrict__ T, int w, int m, int h) {
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -491,12 +525,15 @@ __device__ __forceinline__ void row_ln_bwd(Row4& out, const Row4& dl, const Row4
     }
 }
 
-__global__ __launch_bounds__(QT, 2) void k_query_bwd(QueryBwdArgs a) {
+__global__ __launch_bounds__(QT) void k_query_bwd(QueryBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* T = smem;                            // [32][LDP]
     float* Mb = T + QROWS * LDP;                // [32] key bias
     float* Ls = Mb + QROWS;                     // [8 heads][32] LSE per query
     float* Dqs = Ls + 8 * QROWS;                // [8 heads][32] D = dA . O per query
+    uint16_t* P0 = reinterpret_cast<uint16_t*>(Dqs + 8 * QROWS);     // two operand-plane buffers, used alternately
+    uint16_t* P1 = P0 + QPLANES;
+    uint16_t* P2 = P1 + QPLANES;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, m = lane & 31, h = lane >> 5;
     const int rr = tid >> 3, sub = tid & 7;     // ROW layout
     const int cc = tid >> 1, seg = tid & 1;     // COLUMN layout: rows [16 seg, 16 seg + 16) of channel cc
@@ -506,7 +543,9 @@ __global__ __launch_bounds__(QT, 2) void k_query_bwd(QueryBwdArgs a) {
     QSTAMP(20);
     if (tid < QROWS) Mb[tid] = tid < L ? (1.0f - a.mask[row0 + tid]) * MASK_VALUE : MASK_VALUE;
     Ls[tid] = (tid & 31) < L ? a.lse[((size_t)b * 8 + (tid >> 5)) * L + (tid & 31)] : 0.f;
-    const size_t plane_pw = pack3_plane(D, D);
+    const size_t plane_pw = pack3_plane(D, D), plane_t = pack3_plane(3 * D, D), plane_e = pack3_plane(D, a.EWc);
+    WRing ring;
+    wprefetch(ring, wnext(a.WoT3, plane_pw, D, 32 * w, 0, 8));
 
     // one LayerNorm backward whose incoming gradient is in T layout (`dln`, rows >= L zero) and whose input row is in `x` (ROW layout):
     // returns resid + LN^T(dln) in ROW layout, writes the per-sample gamma / beta slabs.  Leaves the tile with readers: barrier before the next write.
@@ -545,12 +584,12 @@ __global__ __launch_bounds__(QT, 2) void k_query_bwd(QueryBwdArgs a) {
                                   DY.v[j].w * drop_mul(a.d5, base + 3));
         }
         row_store(go, a.go + g0, rr, sub, rok);         // G operand of the out_layer weight gradient
-        row_to_tile(go, T, rr, sub);
+        row_to_planes(go, P0, rr, sub);
         __syncthreads();
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        tgemm(T, a.WoT3, plane_pw, D, 32 * w, 0, D / 16, acc);
+        tgemm<8>(P0, ring, acc, wnext(a.WqkvT3, plane_t, D, 32 * w, 0, 8));
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = mok ? acc[r] * drop_mul(a.d4, (uint32_t)((row0 + m) * D + 32 * w + nl(r, h))) : 0.f;
         ln_bwd_t(xr, acc, a.ln2_g, DY, a.p_ln2g, a.p_ln2b, DR);
@@ -676,17 +715,16 @@ __global__ __launch_bounds__(QT, 2) void k_query_bwd(QueryBwdArgs a) {
     {
         Row4 x3;
         row_load(x3, a.y3 + g0, rr, sub, rok);
-        const size_t plane_t = pack3_plane(3 * D, D);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            __syncthreads();
-            d2tile(t == 0 ? dQd : t == 1 ? dKd : dVd, T, w, m, h);
-            __syncthreads();
-            tgemm(T, a.WqkvT3, plane_t, D, 32 * w, 8 * t, D / 16, acc);
-        }
+        d2planes(dQd, P0, w, m, h);             // three K = 128 chunks in three plane buffers: one barrier, one product body
+        d2planes(dKd, P1, w, m, h);
+        d2planes(dVd, P2, w, m, h);
+        __syncthreads();
+#pragma unroll 1
+        for (int t = 0; t < 3; ++t)
+            tgemm<8>(P0 + t * QPLANES, ring, acc, t < 2 ? wnext(a.WqkvT3, plane_t, D, 32 * w, 8 * (t + 1), 8) : wnext(a.WT3[3], plane_pw, D, 32 * w, 0, 8));
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = mok ? acc[r] * drop_mul(a.d1, (uint32_t)((row0 + m) * D + 32 * w + nl(r, h))) : 0.f;
         ln_bwd_t(x3, acc, a.ln1_g, DR, a.p_ln1g, a.p_ln1b, DY);
@@ -694,8 +732,8 @@ __global__ __launch_bounds__(QT, 2) void k_query_bwd(QueryBwdArgs a) {
     QSTAMP(23);
 
     // ---- conv layers 3 .. 0 (autograd of :133-139)
-    static_for<0, 4>([&](auto LC) {
-        constexpr int l = 3 - decltype(LC)::value;
+#pragma unroll 1
+    for (int l = 3; l >= 0; --l) {
         Row4 xh;
         float rstd;
         row_load(xh, a.x[l] + g0, rr, sub, rok);
@@ -714,7 +752,6 @@ __global__ __launch_bounds__(QT, 2) void k_query_bwd(QueryBwdArgs a) {
             const int r = 16 * seg - HALO + i;
             xw[i] = (r >= 0 && r < QROWS) ? T[r * LDP + cc] : 0.f;
         }
-        __syncthreads();
         {   // dz = dy * relu bit * dropout: G operand of the pointwise weight gradient, B operand of du = dz Wp
             const Drop dp = a.dp[l];
             const uint32_t mwv[4] = {mw.x, mw.y, mw.z, mw.w};
@@ -734,19 +771,19 @@ __global__ __launch_bounds__(QT, 2) void k_query_bwd(QueryBwdArgs a) {
                 dz.v[j].w = (bits & 8u) ? DY.v[j].w * mm[3] : 0.f;
             }
             row_store(dz, a.gz[l] + g0, rr, sub, rok);
-            row_to_tile(dz, T, rr, sub);
+            row_to_planes(dz, (l & 1) ? P1 : P0, rr, sub);
         }
         __syncthreads();
         f32x16 du;
 #pragma unroll
         for (int r = 0; r < 16; ++r) du[r] = 0.f;
-        tgemm(T, a.WT3[l], plane_pw, D, 32 * w, 0, D / 16, du);
+        tgemm<8>((l & 1) ? P1 : P0, ring, du,
+              l > 0 ? wnext(a.WT3[max(l - 1, 0)], plane_pw, D, 32 * w, 0, 8) : wnext(a.WembT3, plane_e, a.EWc, 32 * w, 0, 32 * w < a.EW ? 8 : 0));
         if (!mok) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) du[r] = 0.f;       // rows outside the sample: the conv's zero padding
         }
-        __syncthreads();
-        d2tile(du, T, w, m, h);
+        d2tile(du, T, w, m, h);                 // (the tile's last readers -- the xhat windows -- are behind the barrier above)
         __syncthreads();
         {   // dv = depthwise^T(du) ; tap / gamma / beta partial sums over the sample's rows
             float dw_[16 + 2 * HALO], dvo[16], gw[DWK], slb = 0.f, slg = 0.f;
@@ -792,20 +829,19 @@ __global__ __launch_bounds__(QT, 2) void k_query_bwd(QueryBwdArgs a) {
             DY = out;
         }
         QSTAMP(24 + (3 - l));
-    });
+    }
     row_store(DY, a.dx0 + g0, rr, sub, rok);            // grad wrt Embedding.linear's output (the positional table's partial slabs are these rows)
 
     // ---- Embedding.linear, data gradient (:81-87 backward): dE = dx0 W
-    __syncthreads();
-    row_to_tile(DY, T, rr, sub);
+    row_to_planes(DY, P1, rr, sub);             // (layer 0 read P0)
     __syncthreads();
     {
-        const size_t plane_e = pack3_plane(D, a.EWc);
+#pragma unroll 1
         for (int blk = w; 32 * blk < a.EW; blk += 4) {
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            tgemm(T, a.WembT3, plane_e, a.EWc, 32 * blk, 0, D / 16, acc);
+            tgemm<8>(P1, ring, acc, wnext(a.WembT3, plane_e, a.EWc, 32 * (blk + 4), 0, 32 * (blk + 4) < a.EW ? 8 : 0));
             if (mok) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -818,10 +854,12 @@ __global__ __launch_bounds__(QT, 2) void k_query_bwd(QueryBwdArgs a) {
     QSTAMP(28);
 }
 
-bool query_fused_ok(int L, int H) { return L <= QROWS && H == 8; }
-size_t query_fwd_lds() { return (size_t)(QROWS * LDP + QROWS) * sizeof(float); }
-size_t query_bwd_lds() { return (size_t)(QROWS * LDP + QROWS + 16 * QROWS) * sizeof(float); }
+bool query_fused_ok(int L, int H, int EW) { (void)EW; return L <= QROWS && H == 8; }
+size_t query_fwd_lds() { return (size_t)(QROWS * LDP + QROWS) * sizeof(float) + 2 * QPLANES * sizeof(uint16_t); }
+size_t query_bwd_lds() { return (size_t)(QROWS * LDP + QROWS + 16 * QROWS) * sizeof(float) + 3 * QPLANES * sizeof(uint16_t); }
 void launch_query_bwd(const QueryBwdArgs& a, int B, hipStream_t s) {
+    static size_t ok = 0;
+    ensure_dynamic_lds((const void*)k_query_bwd, query_bwd_lds(), ok, "k_query_bwd");
     VSL_LAUNCH(k_query_bwd, dim3(B), dim3(QT), query_bwd_lds(), s, a);
     static int left = 2;
     if (qdbg_on() && B > 16 && left > 0) {
@@ -830,6 +868,8 @@ void launch_query_bwd(const QueryBwdArgs& a, int B, hipStream_t s) {
     }
 }
 void launch_query_fwd(const QueryFwdArgs& a, int B, hipStream_t s) {
+    static size_t ok = 0;
+    ensure_dynamic_lds((const void*)k_query_fwd, query_fwd_lds(), ok, "k_query_fwd");
     VSL_LAUNCH(k_query_fwd, dim3(B), dim3(QT), query_fwd_lds(), s, a);
     static int left = 2;
     if (qdbg_on() && B > 16 && left > 0) {

@@ -271,7 +271,7 @@ struct QueryBwdArgs {
     int EW, EWc, L, b_off;
 };
 void launch_query_bwd(const QueryBwdArgs& a, int B, hipStream_t s);
-bool query_fused_ok(int L, int H);                 // does the sample-local path take this query length?
+bool query_fused_ok(int L, int H, int EW);         // does the sample-local path take this query length / embedding width?
 void launch_query_fwd(const QueryFwdArgs& a, int B, hipStream_t s);
 void launch_cq_score(const float* C, const float* Qf, const float* qmask, const float* w4C, const float* w4Q,
                      const float* w4mlu, float* S, float* Srow, int B, int T, int Lq, int b_off, Drop dc, Drop dq,
