@@ -174,6 +174,9 @@ OTHER_SHAPES = [
     ('configs[3]/GPU', dict(predictor='transformer', batch=32, T=256, dv=1024), 20, 4, 4),
     ('configs[4]/GPU', dict(predictor='transformer', batch=16, T=1024, dv=1024), 12, 3, 4),
     ('configs[1] --dtype bf16', dict(predictor='transformer', batch=64, T=128, dv=1024, dtype='bf16'), 30, 6, 10),
+    # a batch length that is not a multiple of the 32-row tile: what a real (collated) Charades batch looks like (data_util.py:145-159 pads to the
+    # batch's own maximum)
+    ('ragged T=117', dict(predictor='transformer', batch=64, T=117, dv=1024), 30, 6, 10),
 ]
 
 

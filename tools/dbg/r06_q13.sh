@@ -1,0 +1,8 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r06
+tag=${1:-q13}
+export VSL_JOIN1=0
+bash tools/dbg/r05_ab_env.sh 3 "VSL_QUERY_FUSED=0" "VSL_QUERY_FUSED=1" "VSL_QUERY_FUSED=1 VSL_QBWD_AFTER=1" "VSL_QUERY_FUSED=2" > gpurun_out/r06/${tag}_ab.txt 2>&1 < /dev/null
+cat gpurun_out/r06/${tag}_ab.txt
+VSL_QBWD_AFTER=1 python tools/critical_path.py --out gpurun_out/r06/${tag}_critical_path.txt > /dev/null 2> gpurun_out/r06/${tag}_err.txt; tail -1 gpurun_out/r06/${tag}_err.txt

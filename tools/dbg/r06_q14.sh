@@ -1,0 +1,10 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r06
+tag=${1:-q14}
+timeout 900 python -m pytest tests -m gpu -q -x -k "parity or training or module" > gpurun_out/r06/${tag}_tests.log 2>&1 < /dev/null
+tail -2 gpurun_out/r06/${tag}_tests.log
+bash tools/dbg/r05_stamps7.sh "query_" stamps > gpurun_out/r06/${tag}_stamps.txt 2>&1; cat gpurun_out/r06/${tag}_stamps.txt
+bash tools/dbg/r05_ab_env.sh 3 "VSL_QUERY_FUSED=0" "VSL_QUERY_FUSED=1 VSL_CQD_HOSTED=0" "VSL_QUERY_FUSED=1" > gpurun_out/r06/${tag}_ab.txt 2>&1 < /dev/null
+cat gpurun_out/r06/${tag}_ab.txt
+python tools/critical_path.py --out gpurun_out/r06/${tag}_critical_path.txt > /dev/null 2> gpurun_out/r06/${tag}_err.txt; tail -1 gpurun_out/r06/${tag}_err.txt

@@ -568,6 +568,9 @@ bool query_chain_is_longer(const Plan& p, bool forward) {
     // 0.930 ms with optimizer (profiles/r03_notes.md).
     return !forward && p.T <= 128;          // longer videos: the video side's attention backward grows with T^2 and ends last again
 }
+// (Round 6 measured, same box, and dropped -- profiles/r06_notes.md: one wait instead of two on the joining stream by folding the third stream into
+// the second, +0.5 %; the video chain on the main stream in the backward, +1 - 5 %; k_query_fwd held back behind the video pass' conv block, +2.5 %;
+// k_query_bwd held back behind the video pass' attention backward, +0.3 %; the video pass' pointwise weight gradients on the weight-gradient stream, +3.5 %.)
 
 // dropout site ids: encoder application `app` (0 video, 1 query, 2 predictor pass 1, 3 predictor pass 2) uses
 // app * 16 + {0..3 conv layers, 4 LN1 out, 5 attention probs, 6 attention out, 7 LN2 out, 8 out_layer}
@@ -575,9 +578,7 @@ enum { SITE_VIS = 64, SITE_WORD = 65, SITE_CHAR = 66, SITE_CQ_C = 67, SITE_CQ_Q 
 
 // ------------------------------------------------------------------------------------------------ forward
 struct HeadTail { HeadArgs hs, he; const float *x, *vmask; };     // AttnBlockArgs::head_tail
-struct CbMark { hipEvent_t ev = nullptr; int rec = -1; };        // stop event / ledger record of an application's conv-block launch
-void enc_fwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float* xin, const float* mask, int Bn, int app, const HeadTail* ht = nullptr,
-             CbMark* cb_mark = nullptr) {
+void enc_fwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float* xin, const float* mask, int Bn, int app, const HeadTail* ht = nullptr) {
     const int R = w.R, L = w.L, H = c.h->cfg.num_heads;
     {
         // the whole conv block + LN1 / QKV in ONE launch (kernels_enc.hip: 12-row recomputed halo)
@@ -597,7 +598,6 @@ void enc_fwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float*
             a.R = R; a.L = L;
         }
         LAUNCH("convblock_fwd", launch_convblock_fwd(a, c.s));
-        if (cb_mark && !c.dry) { cb_mark->ev = c.h->last_event(c.s); cb_mark->rec = c.h->prof_on ? (int)c.h->prof_recs.size() - 1 : -1; }
     }
     if (H == 8 && L <= 256) {      // longer sequences: K / V staged in LDS per 64 queries wins (T = 1024: 3.29 vs 3.33 ms)
         AttnBlockArgs ab;
@@ -711,8 +711,7 @@ void run_forward(Ctx& c) {
     else
         LAUNCH("vproj_fwd", launch_vproj_fwd3(io.video_features, reinterpret_cast<const uint16_t*>(c.PK(K.va_f3)), c.P(P.va_b), c.W(p.vf), R, cf.video_feature_dim,
                                               c.drop(SITE_VIS), c.s, c.one_product));
-    CbMark vcb;
-    enc_fwd(c, P.fe, K.fe, p.ve, c.W(p.vf), io.v_mask, B, 0, nullptr, &vcb);
+    enc_fwd(c, P.fe, K.fe, p.ve, c.W(p.vf), io.v_mask, B, 0);
     c.s = qlong ? c.main : sq;
     const bool wt = cf.word_table != 0;       // trainable word table: its rows 0, 1, 2.. are pad, unk, the vocabulary
     LAUNCH("embed_fwd", launch_embed_fwd(io.word_ids, io.char_ids, wt ? c.P(P.unk) : io.pad_vec, c.P(P.unk) + (wt ? cf.word_dim : 0), wt ? c.P(P.unk) + 2 * cf.word_dim : io.glove_vec, c.P(P.char_tab), char_ptrs(c), c.PK(K.ccw_img), c.W(p.E),
@@ -729,13 +728,6 @@ void run_forward(Ctx& c) {
     }   // the shared encoder's packs (main stream)
     if (query_fused(c)) {
         // the rest of the query branch in ONE sample-local launch (kernels_query.hip)
-        // VSL_QORDER=1 (experiment): behind the video pass' conv block -- a conv-block workgroup fills its CU's register file, so a query
-        // workgroup that is resident when it launches costs it a second round of workgroups
-        static const bool qorder = getenv("VSL_QORDER") && getenv("VSL_QORDER")[0] == '1';
-        if (qorder && split3 && !c.dry && vcb.ev) {
-            (void)hipStreamWaitEvent(c.s, vcb.ev, 0); c.h->mark_waiting(c.s);
-            if (vcb.rec >= 0) c.h->prof_pending.push_back({c.s, vcb.rec});
-        }
         QueryFwdArgs qa;
         memset(&qa, 0, sizeof qa);
         if (!c.dry) {

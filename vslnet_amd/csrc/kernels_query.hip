@@ -144,13 +144,15 @@ template <int NS>
 __device__ __forceinline__ void tgemm(const uint16_t* __restrict__ P, WRing& ring, f32x16& acc, const WNext& nx) {
     const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
     const uint16_t* pr = P + m * QLB + 8 * h;
-    // every operand fragment of the product is requested before its first MFMA (one wave per SIMD: registers are plentiful, and nothing
-    // else hides the LDS latency -- with the reads one step ahead the compiler left two MFMAs between a read and its use)
-    AF3 b[NS];
+    // operand fragments two steps ahead (three buffers): the whole operand up front measured the same and cost 96 registers -- with them the
+    // kernel no longer fits 256 VGPRs, i.e. no longer shares a CU with anything (profiles/r06_notes.md)
+    AF3 b[3];
+    auto bread = [&](int s, AF3& f) {
 #pragma unroll
-    for (int s = 0; s < NS; ++s)
-#pragma unroll
-        for (int q = 0; q < 3; ++q) b[s].t[q] = *reinterpret_cast<const u32x4_t*>(pr + 16 * s + q * QPS);
+        for (int q = 0; q < 3; ++q) f.t[q] = *reinterpret_cast<const u32x4_t*>(pr + 16 * (s < NS ? s : NS - 1) + q * QPS);
+    };
+    bread(0, b[0]);
+    if (NS > 1) bread(1, b[1]);
     // slots this product does not use: the next product's fragments can go there right away
     static_for<NS, 8>([&](auto sc) { constexpr int s = decltype(sc)::value; if (s < nx.ns) wload(ring.f[s], nx, s); });
     f32x16 acc2;
@@ -159,10 +161,11 @@ __device__ __forceinline__ void tgemm(const uint16_t* __restrict__ P, WRing& rin
     static_for<0, NS>([&](auto sc) {
         constexpr int s = decltype(sc)::value;
         constexpr int TW[6] = {1, 0, 2, 0, 1, 0}, TX[6] = {1, 2, 0, 1, 0, 0};      // (weight term, activation term): mm, hl, lh, hm, mh, hh
+        if (s + 2 < NS) bread(s + 2, b[(s + 2) % 3]);
 #pragma unroll
         for (int p = 0; p < 6; ++p) {
-            if (p & 1) acc2 = mfma_bf16(ring.f[s].t[TW[p]], b[s].t[TX[p]], acc2);
-            else acc = mfma_bf16(ring.f[s].t[TW[p]], b[s].t[TX[p]], acc);
+            if (p & 1) acc2 = mfma_bf16(ring.f[s].t[TW[p]], b[s % 3].t[TX[p]], acc2);
+            else acc = mfma_bf16(ring.f[s].t[TW[p]], b[s % 3].t[TX[p]], acc);
         }
         if (s < nx.ns) wload(ring.f[s], nx, s);
     });
@@ -575,8 +578,8 @@ __global__ __launch_bounds__(QT) void k_query_bwd(QueryBwdArgs a) {
     Row4 DY, DR;
     {
         Row4 xr, go;
-        row_load(DY, a.dout + g0, rr, sub, rok);
         row_load(xr, a.r + g0, rr, sub, rok);
+        row_load(DY, a.dout + g0, rr, sub, rok);         // (k_cq_bwd_d's work hosted here instead of a launch of its own: measured, 2.2 x slower inside this kernel)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint32_t base = (uint32_t)((row0 + rr) * D + sub * 4 + 32 * j);

@@ -245,32 +245,6 @@ struct QueryFwdArgs {
     Drop d2, d3, d4, d5;
     int EW, L, b_off;
 };
-// the backward of that launch (autograd of the same lines) + the Embedding linear's data gradient; per-SAMPLE partial slabs
-struct QueryBwdArgs {
-    const float* dout;             // (Rq,128) grad wrt the encoder output
-    const float *r, *ln2_g;        // output block
-    const uint16_t* WoT3;          // split pack (type 7) of the out_layer weight
-    float *go, *p_ln2g, *p_ln2b;
-    Drop d2, d3, d4, d5;
-    const float *q, *k, *v, *att, *lse, *mask;     // attention
-    float *dq, *dk, *dv;
-    const uint16_t* WqkvT3;        // split pack (type 7) of [Wq; Wk; Wv]: 384 contraction rows
-    const float *y3, *ln1_g;
-    float *p_ln1g, *p_ln1b;
-    Drop d1;
-    const uint16_t* WT3[4];        // conv layers
-    const float* x[4];
-    const uint32_t* relu_mask[4];
-    const float *ln_g[4], *ln_b[4], *dw_w[4];
-    Drop dp[4];
-    float* gz[4];
-    float *p_lng[4], *p_lnb[4], *p_dw[4];
-    float* dx0;
-    const uint16_t* WembT3;        // split pack (type 7) of the Embedding.linear weight, EWc >= EW columns
-    float* dE;
-    int EW, EWc, L, b_off;
-};
-void launch_query_bwd(const QueryBwdArgs& a, int B, hipStream_t s);
 bool query_fused_ok(int L, int H, int EW);         // does the sample-local path take this query length / embedding width?
 void launch_query_fwd(const QueryFwdArgs& a, int B, hipStream_t s);
 void launch_cq_score(const float* C, const float* Qf, const float* qmask, const float* w4C, const float* w4Q,
@@ -367,6 +341,32 @@ struct CqBwdArgs {
 };
 void launch_cq_bwd(const CqBwdArgs& a, int B, hipStream_t s);          // kernels a, b, c: dC final, dQ partials
 void launch_cq_bwd_query(const CqBwdArgs& a, int B, hipStream_t s);    // kernel d: dQ + pooled-query parameters
+// the backward of that launch (autograd of the same lines) + the Embedding linear's data gradient; per-SAMPLE partial slabs
+struct QueryBwdArgs {
+    const float* dout;             // (Rq,128) grad wrt the encoder output
+    const float *r, *ln2_g;        // output block
+    const uint16_t* WoT3;          // split pack (type 7) of the out_layer weight
+    float *go, *p_ln2g, *p_ln2b;
+    Drop d2, d3, d4, d5;
+    const float *q, *k, *v, *att, *lse, *mask;     // attention
+    float *dq, *dk, *dv;
+    const uint16_t* WqkvT3;        // split pack (type 7) of [Wq; Wk; Wv]: 384 contraction rows
+    const float *y3, *ln1_g;
+    float *p_ln1g, *p_ln1b;
+    Drop d1;
+    const uint16_t* WT3[4];        // conv layers
+    const float* x[4];
+    const uint32_t* relu_mask[4];
+    const float *ln_g[4], *ln_b[4], *dw_w[4];
+    Drop dp[4];
+    float* gz[4];
+    float *p_lng[4], *p_lnb[4], *p_dw[4];
+    float* dx0;
+    const uint16_t* WembT3;        // split pack (type 7) of the Embedding.linear weight, EWc >= EW columns
+    float* dE;
+    int EW, EWc, L, b_off;
+};
+void launch_query_bwd(const QueryBwdArgs& a, int B, hipStream_t s);
 void launch_embed_bwd(const float* dE, const int64_t* word_ids, const int64_t* char_ids, const float* E,
                       const int8_t* argpos, const float* char_tab, const float* wimg_b /* type-8 pack */,
                       float* p_cw /*[nchunk][300 char_dim]*/,
