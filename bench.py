@@ -93,8 +93,8 @@ def workload_name(args):
 
 def dtype_line(args):
     if args.dtype != 'f32':
-        return ('bf16 throughput mode (not the parity path): bf16 features in HBM; VisualProjection and every weight gradient as ONE bf16 product per '
-                'product (operands rounded to bf16, f32 accumulate); the other GEMMs bf16x6 / f32-input MFMA as in the f32 line; f32 activations')
+        return ('bf16 FEATURE STORAGE (not the parity path): bfloat16 features in HBM, VisualProjection as one bf16 product on them; every other GEMM '
+                'and every weight gradient bf16x6 / f32-input MFMA as in the f32 line; f32 activations')
     return ('f32 in / out and f32 accumulate everywhere; VisualProjection, the conv-block / q,k,v / embedding-linear GEMMs and every weight '
             'gradient as bf16x6 split MFMA (exact 3-way operand split, 6 products: fp32 grade), attention / CQAttention / heads / char-CNN as '
             'fp32-input MFMA')
@@ -203,7 +203,7 @@ def time_shape(predictor, batch, T, dv, lq, lc, drop_rate, dtype, steps, warmup,
     def step(i):
         bt = batches[i % nres]
         eng.forward(flat, pad_vec, glove_vec, bt['word_ids'], bt['char_ids'], bt['vfeats'], bt['v_mask'], bt['q_mask'], training=True, seed=i,
-                    sample_offset=0, arithmetic='bf16' if dtype == 'bf16' else 'f32')
+                    sample_offset=0)
         losses, d_h, d_sl, d_el = eng.loss(bt['s_labels'], bt['e_labels'], bt['h_labels'], 1.0, configs.highlight_lambda, inv_batch=1.0 / batch, mask_sum=mask_sum)
         eng.backward(d_h, d_sl, d_el, grads)
         opt.step(grads, from_backward=True)
@@ -270,7 +270,7 @@ def main():
     ap.add_argument('--lc', type=int, default=10)
     ap.add_argument('--drop-rate', type=float, default=0.2)
     ap.add_argument('--predictor', default='transformer', help="'transformer' (headline, configs[1]) or 'rnn' (configs[0] shape)")
-    ap.add_argument('--dtype', default='f32', choices=('f32', 'bf16'), help="'bf16' = the separate throughput mode: bfloat16 features in HBM, VisualProjection and the weight gradients as single bf16 products (vsl_io.arithmetic = 1); never the parity / headline line")
+    ap.add_argument('--dtype', default='f32', choices=('f32', 'bf16'), help="'bf16' = bfloat16 feature STORAGE in HBM (half the one large HBM / PCIe stream) and a bf16 VisualProjection on it; everything else as the f32 line; never the parity / headline line")
     ap.add_argument('--resident-batches', type=int, default=10,
                     help='distinct synthetic batches resident in HBM, rotated step by step: 10 x 32 MiB of features at the headline shape exceed the '
                          '256 MiB Infinity Cache, so the feature stream of VisualProjection and of its weight gradient really comes from HBM '
@@ -338,7 +338,7 @@ def main():
     def step(i, skip_exchange=False):
         batch = batches[i % nres]
         eng.forward(flat, pad_vec, glove_vec, batch['word_ids'], batch['char_ids'], batch['vfeats'], batch['v_mask'],
-                    batch['q_mask'], training=True, seed=i, sample_offset=rank * B, arithmetic='bf16' if args.dtype == 'bf16' else 'f32')
+                    batch['q_mask'], training=True, seed=i, sample_offset=rank * B)
         losses, d_h, d_sl, d_el = eng.loss(batch['s_labels'], batch['e_labels'], batch['h_labels'], 1.0,
                                            configs.highlight_lambda, inv_batch=inv_batch, mask_sum=mask_sum)
         skip_exchange = skip_exchange or os.environ.get('VSL_SKIP_ALLREDUCE') == '1'

@@ -90,12 +90,6 @@ typedef struct {
      * offsets are final when vsl_backward's work on the caller's stream completes.  No reference counterpart (main_t7.py has no
      * distributed code); it is what makes the ONE exchange of SURVEY 8(e) overlap with the backward. */
     void* early_grads_event;
-    /* 0 (default): fp32-grade arithmetic everywhere (the parity path).
-     * 1: "bf16 arithmetic" THROUGHPUT mode, with its own tolerance (tests/test_bf16_mode.py), never the parity path: the two heaviest GEMM
-     *    families -- VisualProjection (2.1 of the step's 16 GFLOP at the headline shape) and every Conv1D weight gradient (11.5) -- round their
-     *    operands to bfloat16 and issue ONE product per product instead of the six of the split scheme (fp32 accumulation; fp32 storage).
-     *    Set it on the forward AND the backward call of a step (one vsl_io serves both). */
-    int32_t arithmetic;
 } vsl_io;
 /* Every struct of this header must be zero-initialised by the caller before the fields are set: new optional fields are appended, and
  * zero means "off".  vsl_abi_version() changes whenever a struct layout or an entry point's meaning changes; a binding checks it once. */

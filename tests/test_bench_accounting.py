@@ -45,10 +45,13 @@ def test_other_shapes_cover_the_remaining_baseline_configs_and_the_bf16_mode():
     """The `shapes` list bench.py appends behind the headline regions (driver-observed numbers for every BASELINE config):
     its entries are the per-GPU shapes of configs[0], [2], [3], [4] and the bf16 mode of configs[1]."""
     tags = [t for t, *_ in bench.OTHER_SHAPES]
-    assert tags == ['configs[0]', 'configs[2]', 'configs[3]/GPU', 'configs[4]/GPU', 'configs[1] --dtype bf16']
+    assert tags == ['configs[0]', 'configs[2]', 'configs[3]/GPU', 'configs[4]/GPU', 'configs[1] --dtype bf16', 'ragged T=117']
     for tag, kw, steps, warmup, nres in bench.OTHER_SHAPES:
         ns = types.SimpleNamespace(predictor=kw['predictor'], batch=kw['batch'], T=kw['T'], dv=kw['dv'])
-        assert bench.workload_name(ns).startswith(tag.split('/')[0].split(' ')[0]), (tag, bench.workload_name(ns))
+        if tag.startswith('ragged'):          # round 6: a batch length off the 32-row tile (what a collated Charades batch looks like): no BASELINE config
+            assert kw['T'] % 32 != 0 and bench.workload_name(ns).startswith('custom shape')
+        else:
+            assert bench.workload_name(ns).startswith(tag.split('/')[0].split(' ')[0]), (tag, bench.workload_name(ns))
         assert steps >= 10 and warmup >= 3 and nres >= 3
         # rotated resident batches of every shape exceed the 256 MiB Infinity Cache only where that is cheap; they must at least differ step to step
         assert kw.get('dtype', 'f32') in ('f32', 'bf16')

@@ -12,7 +12,10 @@ one-launch dataflow pipeline (k_rnn_fwd / k_rnn_bwd) every shape of the suite se
 
 Round 5 added two of the same kind: VSL_QKV_FUSED=0 (k_qkv_bwd as its own launch instead of inside the conv block's backward kernel: what ragged row
 tiles and L > 256 take) and VSL_HEADS_FUSED=0 (k_head_fwd instead of the tail of the second predictor pass' attention-block kernel: what T > 128
-takes) -- the training suite's whole-tile shapes select the fused paths, so it is re-run once with both off."""
+takes) -- the training suite's whole-tile shapes select the fused paths, so it is re-run once with both off.
+
+Round 6: VSL_QUERY_FUSED=0 -- the query branch as row-tile launches (linear_fwd + convblock_fwd<0> + attn_block_fwd / attn_out_bwd + attn_bwd +
+convblock_bwd<0>) instead of the sample-local k_query_fwd / k_query_bwd that every Lq <= 32 shape now selects; what Lq > 32 takes.  Same re-run."""
 import os
 import subprocess
 import sys
@@ -39,7 +42,7 @@ def test_rnn_suite_with_the_chunked_launches():
 
 
 def test_training_suite_with_the_unfused_launches():
-    e = dict(os.environ, VSL_QKV_FUSED='0', VSL_HEADS_FUSED='0')
+    e = dict(os.environ, VSL_QKV_FUSED='0', VSL_HEADS_FUSED='0', VSL_QUERY_FUSED='0')
     r = subprocess.run([sys.executable, '-m', 'pytest', '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider', 'tests/test_hip_training.py', 'tests/test_hip_parity.py'],
                        cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -438,7 +438,6 @@ struct Ctx {
     std::vector<SlabRec>* recs = nullptr;
     std::vector<WgradBatch> pend;       // weight-gradient batches waiting for ONE ordering point (wgrad_async / wgrad_flush)
     bool defer_w = false;
-    bool one_product = false;           // vsl_io.arithmetic == 1 for this call: handed to the launchers that have a one-product form
     const float* P(int off) const { return io->params + off; }
     const float* PK(int off) const { return ws + p->pack + off; }
     float* W(int64_t off) const { return ws + off; }
@@ -546,7 +545,7 @@ void wgrad_async(Ctx& c, hipStream_t sw, const WgradBatch& wb) {
     hipStream_t keep = c.s;
     c.order(keep, sw);
     c.s = sw;
-    LAUNCH("wgrad", launch_wgrad(wb, c.s, c.one_product));
+    LAUNCH("wgrad", launch_wgrad(wb, c.s));
     c.s = keep;
 }
 void wgrad_flush(Ctx& c, hipStream_t sw) {
@@ -554,7 +553,7 @@ void wgrad_flush(Ctx& c, hipStream_t sw) {
     hipStream_t keep = c.s;
     c.order(keep, sw);
     c.s = sw;
-    for (const WgradBatch& wb : c.pend) LAUNCH("wgrad", launch_wgrad(wb, c.s, c.one_product));
+    for (const WgradBatch& wb : c.pend) LAUNCH("wgrad", launch_wgrad(wb, c.s));
     c.s = keep;
     c.pend.clear();
 }
@@ -710,7 +709,7 @@ void run_forward(Ctx& c) {
                                                   cf.video_feature_dim, c.drop(SITE_VIS), c.s));
     else
         LAUNCH("vproj_fwd", launch_vproj_fwd3(io.video_features, reinterpret_cast<const uint16_t*>(c.PK(K.va_f3)), c.P(P.va_b), c.W(p.vf), R, cf.video_feature_dim,
-                                              c.drop(SITE_VIS), c.s, c.one_product));
+                                              c.drop(SITE_VIS), c.s));
     enc_fwd(c, P.fe, K.fe, p.ve, c.W(p.vf), io.v_mask, B, 0);
     c.s = qlong ? c.main : sq;
     const bool wt = cf.word_table != 0;       // trainable word table: its rows 0, 1, 2.. are pad, unk, the vocabulary
@@ -1100,9 +1099,8 @@ void run_backward(Ctx& c) {
         auto dx = [&](int l, int t0, int t1) {
             const LstmWs& w = p.lstm[l];
             const bool all = t0 == 0 && t1 == T;
-            // (always the six-product form: vsl_io.arithmetic = 1 covers VisualProjection and the weight gradients only -- ADVICE r3)
             LAUNCH("lstm_dx", launch_vproj_fwd3(c.W(w.dG), reinterpret_cast<const uint16_t*>(c.PK(K.l_t3[l])), c.PK(K.zero128), c.W(l ? p.g_s1 : p.g_gated),
-                                               all ? R : B * (t1 - t0), 4 * D, Drop{0u, 0u, 1.f}, c.s, false, all ? 0 : t1 - t0, T, t0));
+                                               all ? R : B * (t1 - t0), 4 * D, Drop{0u, 0u, 1.f}, c.s, all ? 0 : t1 - t0, T, t0));
         };
         const bool piped = !c.dry && chunks.size() >= 2 && sq != c.s;
         if (!c.dry) {
@@ -1168,7 +1166,7 @@ void run_backward(Ctx& c) {
                     wb.j[wb.n++] = j;
                 }
             }
-            on_stream(sw, [&] { LAUNCH("wgrad", launch_wgrad(wb, c.s, c.one_product)); });
+            on_stream(sw, [&] { LAUNCH("wgrad", launch_wgrad(wb, c.s)); });
         }
     } else {
     // ---- predictor encoder, second pass (input = output of the first pass), then first pass
@@ -1271,7 +1269,7 @@ void run_backward(Ctx& c) {
         // pointwise weight gradients ride in THIS launch, the query side's own batch goes to the weight-gradient stream behind k_query_bwd.
         // (Measured and dropped: the video pass' pointwise batch on the weight-gradient stream instead, +3.5 %: profiles/r06_notes.md)
         if (query_fused(c, false)) { for (int i = 0; i < pw_video.n; ++i) wb.j[wb.n++] = pw_video.j[i]; }
-        LAUNCH("wgrad", launch_wgrad(wb, c.s, c.one_product));
+        LAUNCH("wgrad", launch_wgrad(wb, c.s));
     }
     // ---- query pass, then the embedding stack (all on the other stream)
     c.s = qlong ? main_s : sq;
@@ -1303,8 +1301,8 @@ void run_backward(Ctx& c) {
         hipStream_t qs = c.s, vs = qfused ? sw : (qlong ? sq : main_s);
         c.order(qs, vs);
         c.s = vs;
-        LAUNCH("wgrad", launch_wgrad(wb_tail, c.s, c.one_product));
-        if (!fits) LAUNCH("wgrad", launch_wgrad(pw_query, c.s, c.one_product));
+        LAUNCH("wgrad", launch_wgrad(wb_tail, c.s));
+        if (!fits) LAUNCH("wgrad", launch_wgrad(pw_query, c.s));
         c.s = qs;
     }
     if (!lin_hosted)
@@ -1505,7 +1503,6 @@ int check_io(vsl_handle_s* h, const vsl_io* io) {
         return fail("vsl_io has a null device pointer");
     if (io->video_features_bf16 && (h->cfg.video_feature_dim % 8 != 0))
         return fail("bf16 features need video_feature_dim %% 8 == 0 (got %d)", h->cfg.video_feature_dim);
-    if (io->arithmetic != 0 && io->arithmetic != 1) return fail("vsl_io.arithmetic must be 0 (fp32 grade) or 1 (bf16 arithmetic), got %d", io->arithmetic);
     return 0;
 }
 
@@ -1721,7 +1718,6 @@ int vsl_forward(vsl_handle h, const vsl_io* io, void* hip_stream) {
     if (int rc = get_plan(h, io->B, io->T, io->Lq, io->Lc, &p)) return rc;
     Ctx c{h, p, io, (hipStream_t)hip_stream, false, io->workspace};
     c.main = c.s;
-    c.one_product = io->arithmetic == 1;
     CallScope scope(h);
     run_forward(c);
     HIP_OK(hipGetLastError());
@@ -1750,7 +1746,6 @@ int vsl_backward(vsl_handle h, const vsl_io* io, void* hip_stream) {
     if (int rc = get_plan(h, io->B, io->T, io->Lq, io->Lc, &p)) return rc;
     Ctx c{h, p, io, (hipStream_t)hip_stream, false, io->workspace};
     c.main = c.s;
-    c.one_product = io->arithmetic == 1;
     CallScope scope(h);
     run_backward(c);
     HIP_OK(hipGetLastError());

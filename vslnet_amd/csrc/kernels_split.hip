@@ -35,8 +35,7 @@ constexpr int VP3_T = 512;
 #define VP3_NB 4         // weight fragments: K = 16 steps ahead (a divisor of 8)
 #endif
 // FULL: R % 32 == 0, Dv % 128 == 0, no row mapping -> no guards anywhere (every BASELINE shape) ; DROPON: dropout enabled (block-uniform)
-// ONE: vsl_io.arithmetic = 1 -- operands rounded to bfloat16 (the h term alone), one product per product
-template <bool FULL, bool DROPON, bool ONE>
+template <bool FULL, bool DROPON>
 __global__ __launch_bounds__(VP3_T, 2) void k_vproj_fwd3(const float* __restrict__ X, const uint16_t* __restrict__ W3, const float* __restrict__ bias,
                                                          float* __restrict__ Y, int R, int Dv, Drop dp, int seg, int stride, int off) {
     constexpr int NKS = VP3_KC / 16;
@@ -74,8 +73,7 @@ __global__ __launch_bounds__(VP3_T, 2) void k_vproj_fwd3(const float* __restrict
                     v.x *= drop_keep_scale(dp, base); v.y *= drop_keep_scale(dp, base + 1);
                     v.z *= drop_keep_scale(dp, base + 2); v.w *= drop_keep_scale(dp, base + 3);
                 }
-                if constexpr (ONE) *reinterpret_cast<u32x2_t*>(&As[buf][0][rr * VP3_LD + cl]) = u32x2_t{cvt_pk_bf16(v.x, v.y), cvt_pk_bf16(v.z, v.w)};
-                else {
+                {
                     uint32_t h0, m0, l0, h1, m1, l1;
                     split3(v.x, v.y, h0, m0, l0);
                     split3(v.z, v.w, h1, m1, l1);
@@ -129,12 +127,12 @@ __global__ __launch_bounds__(VP3_T, 2) void k_vproj_fwd3(const float* __restrict
         auto bload1 = [&](int ch, int j, BF& f) {         // weight fragments of step j of chunk ch (past the end: a harmless re-read of the last chunk)
             const uint16_t* p = wp + (size_t)(min(ch, nchunk - 1) * NKS + j) * D * 16;
 #pragma unroll
-            for (int t = 0; t < (ONE ? 1 : 3); ++t) f.t[t] = *reinterpret_cast<const u32x4_t*>(p + t * plane);
+            for (int t = 0; t < 3; ++t) f.t[t] = *reinterpret_cast<const u32x4_t*>(p + t * plane);
         };
         auto aread = [&](int buf, int j, BF& a) {
             const uint16_t* ap = &As[buf][0][i * VP3_LD + 8 * h + j * 16];
 #pragma unroll
-            for (int t = 0; t < (ONE ? 1 : 3); ++t) a.t[t] = *reinterpret_cast<const u32x4_t*>(ap + t * TILE_M * VP3_LD);
+            for (int t = 0; t < 3; ++t) a.t[t] = *reinterpret_cast<const u32x4_t*>(ap + t * TILE_M * VP3_LD);
         };
         // a chunk: the A fragments of step j + 1 are requested before the MFMAs of step j (one wave per role and SIMD: nothing else hides the
         // LDS latency -- measured 3.4 k cycles per chunk instead of 1.5 k when every step waited for its own reads); the weight fragments run
@@ -150,8 +148,7 @@ __global__ __launch_bounds__(VP3_T, 2) void k_vproj_fwd3(const float* __restrict
                 if (j + 1 < NKS) aread(buf, j + 1, an);
                 __builtin_amdgcn_sched_barrier(0);
                 BF& q = bq[j % VP3_NB];
-                if constexpr (ONE) acc[j & 1] = mfma_bf16(ac.t[0], q.t[0], acc[j & 1]);
-                else {
+                {
                     acc[0] = mfma_bf16(ac.t[1], q.t[1], acc[0]);          // two accumulators alternate ; small terms first
                     acc[1] = mfma_bf16(ac.t[0], q.t[2], acc[1]);
                     acc[0] = mfma_bf16(ac.t[2], q.t[0], acc[0]);
@@ -184,16 +181,12 @@ __global__ __launch_bounds__(VP3_T, 2) void k_vproj_fwd3(const float* __restrict
         }
     }
 }
-void launch_vproj_fwd3(const float* X, const uint16_t* W3, const float* bias, float* Y, int R, int Dv, Drop dp, hipStream_t s, bool one_product, int seg, int stride, int off) {
+void launch_vproj_fwd3(const float* X, const uint16_t* W3, const float* bias, float* Y, int R, int Dv, Drop dp, hipStream_t s, int seg, int stride, int off) {
     const dim3 grid((R + TILE_M - 1) / TILE_M), block(VP3_T);
     const bool full = R % TILE_M == 0 && Dv % VP3_KC == 0 && seg == 0;
     const int sel = (full ? 2 : 0) | (dp.thresh ? 1 : 0);
-#define VP3_GO(F, DR, ON) VSL_LAUNCH((k_vproj_fwd3<F, DR, ON>), grid, block, 0, s, X, W3, bias, Y, R, Dv, dp, seg, stride, off)
-    if (one_product) {                     // vsl_io.arithmetic = 1
-        switch (sel) { case 3: VP3_GO(true, true, true); break; case 2: VP3_GO(true, false, true); break; case 1: VP3_GO(false, true, true); break; default: VP3_GO(false, false, true); }
-    } else {
-        switch (sel) { case 3: VP3_GO(true, true, false); break; case 2: VP3_GO(true, false, false); break; case 1: VP3_GO(false, true, false); break; default: VP3_GO(false, false, false); }
-    }
+#define VP3_GO(F, DR) VSL_LAUNCH((k_vproj_fwd3<F, DR>), grid, block, 0, s, X, W3, bias, Y, R, Dv, dp, seg, stride, off)
+    switch (sel) { case 3: VP3_GO(true, true); break; case 2: VP3_GO(true, false); break; case 1: VP3_GO(false, true); break; default: VP3_GO(false, false); }
 #undef VP3_GO
 }
 

@@ -215,8 +215,7 @@ __device__ long long g_wg4_stamps[8];
 // dword index of row pair rg (rows 2 rg, 2 rg + 1) of column c: the two 8-row halves of a column live in separate arrays, so the 16 lanes of a
 // ds_read_b128 phase (consecutive columns, one half) cover all 64 banks once
 __device__ __forceinline__ int wg4_idx(int buf, int o, int p, int c, int rg) { return (((((buf * 2 + o) * 3 + p) * 2 + (rg >> 2)) * 128 + c) << 2) + (rg & 3); }
-// ONE: vsl_io.arithmetic = 1 -- operands rounded to bfloat16 (the h term alone), one product per product
-template <bool DROP, bool ONE>
+template <bool DROP>
 __global__ __launch_bounds__(WG4_T, 1) void k_wgrad4(WgradBatch wb) {
     __shared__ __attribute__((aligned(16))) uint32_t Ps[2 * 2 * 3 * 128 * 8];
     WG4STAMP(0);
@@ -260,15 +259,11 @@ __global__ __launch_bounds__(WG4_T, 1) void k_wgrad4(WgradBatch wb) {
             a[q] = *reinterpret_cast<const float2*>(abase + row * lda);
         }
     };
-    // rows 2 rg, 2 rg + 1 of column c of operand o.  (The one-product form converts through an opaque asm: with the vector builtin clang
-    // assembled the operand pair in SCRATCH memory there -- a 128-byte private segment, scratch loads behind vmcnt(0) in the step loop: 47 us)
+    // rows 2 rg, 2 rg + 1 of column c of operand o
     auto put = [&](int buf, int o, int c, float x0, float x1) {
-        if constexpr (ONE) Ps[wg4_idx(buf, o, 0, c, rg)] = cvt_pk_bf16_asm(x0, x1);
-        else {
-            uint32_t hh, mm, ll;
-            split3(x0, x1, hh, mm, ll);
-            Ps[wg4_idx(buf, o, 0, c, rg)] = hh; Ps[wg4_idx(buf, o, 1, c, rg)] = mm; Ps[wg4_idx(buf, o, 2, c, rg)] = ll;
-        }
+        uint32_t hh, mm, ll;
+        split3(x0, x1, hh, mm, ll);
+        Ps[wg4_idx(buf, o, 0, c, rg)] = hh; Ps[wg4_idx(buf, o, 1, c, rg)] = mm; Ps[wg4_idx(buf, o, 2, c, rg)] = ll;
     };
     auto stage = [&](int s, int buf, const float2 (&gr)[2], const float2 (&ar)[2]) {
         float2 g[2], a[2];
@@ -295,7 +290,7 @@ __global__ __launch_bounds__(WG4_T, 1) void k_wgrad4(WgradBatch wb) {
     struct Frag { u32x4_t g[2][3], a[3]; };
     auto frag_load = [&](int buf, Frag& f) {
 #pragma unroll
-        for (int p = 0; p < (ONE ? 1 : 3); ++p) {
+        for (int p = 0; p < 3; ++p) {
 #pragma unroll
             for (int a = 0; a < 2; ++a) f.g[a][p] = *reinterpret_cast<const u32x4_t*>(Ps + wg4_idx(buf, 0, p, 64 * nh + 32 * a + i, 4 * h));
             f.a[p] = *reinterpret_cast<const u32x4_t*>(Ps + wg4_idx(buf, 1, p, 32 * kq + i, 4 * h));
@@ -304,7 +299,7 @@ __global__ __launch_bounds__(WG4_T, 1) void k_wgrad4(WgradBatch wb) {
     auto mma = [&](const Frag& f) {
         constexpr int TG6[6] = {1, 0, 2, 0, 1, 0}, TA6[6] = {1, 2, 0, 1, 0, 0};      // (g term, a term): mm, hl, lh, hm, mh, hh (small terms first)
 #pragma unroll
-        for (int t = ONE ? 5 : 0; t < 6; ++t)
+        for (int t = 0; t < 6; ++t)
 #pragma unroll
             for (int a = 0; a < 2; ++a) acc[a] = mfma_bf16(f.g[a][TG6[t]], f.a[TA6[t]], acc[a]);
     };
@@ -360,7 +355,7 @@ __global__ __launch_bounds__(WG4_T, 1) void k_wgrad4(WgradBatch wb) {
 // One launch per batch of jobs.  fp32 operands: k_wgrad4 (every element split once per workgroup through LDS); bfloat16 features (the bf16
 // throughput mode's VisualProjection job): k_wgrad3, which widens them in registers.  The dropout hash (VisualProjection input) and the bf16
 // operand are separate instantiations: a batch that mixes kinds is launched kind by kind, in order.
-void launch_wgrad(const WgradBatch& wb0, hipStream_t s, bool one_product) {
+void launch_wgrad(const WgradBatch& wb0, hipStream_t s) {
     WgradBatch wb = wb0;
     int total = 0;
     for (int i = 0; i < wb.n; ++i) {
@@ -378,15 +373,13 @@ void launch_wgrad(const WgradBatch& wb0, hipStream_t s, bool one_product) {
             WgradBatch part;
             part.n = 0;
             for (int i = 0; i < wb.n; ++i) if (kind(wb.j[i]) == kd) part.j[part.n++] = wb.j[i];
-            if (part.n) launch_wgrad(part, s, one_product);
+            if (part.n) launch_wgrad(part, s);
         }
         return;
     }
-    switch (k0 | (one_product && k0 < 2 ? 4 : 0)) {
-        case 0: VSL_LAUNCH((k_wgrad4<false, false>), dim3(total), dim3(WG4_T), 0, s, wb); break;
-        case 1: VSL_LAUNCH((k_wgrad4<true, false>), dim3(total), dim3(WG4_T), 0, s, wb); break;
-        case 4: VSL_LAUNCH((k_wgrad4<false, true>), dim3(total), dim3(WG4_T), 0, s, wb); break;       // vsl_io.arithmetic = 1
-        case 5: VSL_LAUNCH((k_wgrad4<true, true>), dim3(total), dim3(WG4_T), 0, s, wb); break;
+    switch (k0) {
+        case 0: VSL_LAUNCH((k_wgrad4<false>), dim3(total), dim3(WG4_T), 0, s, wb); break;
+        case 1: VSL_LAUNCH((k_wgrad4<true>), dim3(total), dim3(WG4_T), 0, s, wb); break;
         case 2: VSL_LAUNCH((k_wgrad3<false, true>), dim3(total), dim3(WG2_T), 0, s, wb); break;       // bfloat16 features
         default: VSL_LAUNCH((k_wgrad3<true, true>), dim3(total), dim3(WG2_T), 0, s, wb); break;
     }

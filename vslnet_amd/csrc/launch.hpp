@@ -120,9 +120,8 @@ void launch_pack(const float* params, float* pack, const PackJob* jobs_dev, int 
 // bf16 throughput mode: X bf16 (R, Dv), packed bf16 weight (PackJob type 5), fp32 accumulate / bias / output
 void launch_vproj_fwd_bf16(const uint16_t* X, const uint16_t* Wpack16, const float* bias, float* Y, int R, int Dv, Drop dp, hipStream_t s);
 // fp32-grade on the bf16 matrix cores (kernels_split.hip): W3 = split pack (PackJob type 6 / 7) of the (Dv, 128) operand
-// one_product: vsl_io.arithmetic == 1 for the call being enqueued (operands rounded to bfloat16, one product per product)
 void launch_vproj_fwd3(const float* X, const uint16_t* W3, const float* bias, float* Y, int R, int Dv, Drop dp, hipStream_t s,
-                       bool one_product = false, int seg = 0, int stride = 0, int off = 0);   // seg > 0: rows of one time chunk (see launch_linear_fwd3)
+                       int seg = 0, int stride = 0, int off = 0);   // seg > 0: rows of one time chunk (see launch_linear_fwd3)
 void launch_linear_fwd3(const float* A, const uint16_t* W3, const float* bias /* nullable */, float* Y, int R, int K, hipStream_t s, int ncols = 128,
                         int seg = 0, int stride = 0, int off = 0);      // ncols: columns of the operand and of Y's rows; seg > 0: rows of one time chunk of a (B, T, .) tensor
 void launch_linear_bwd_data3(const float* G, const uint16_t* WT3, float* dA, int R, int K, int Kc, hipStream_t s);   // Kc: columns of the split pack
@@ -309,7 +308,7 @@ struct RnnBwdArgs {
 bool rnn_fused_ok(int B);
 void launch_rnn_fwd(const RnnFwdArgs& a, hipStream_t s);
 void launch_rnn_bwd(const RnnBwdArgs& a, hipStream_t s);      // one image = W_hh in the register order of k_lstm1_fwd (type 9) / k_lstm1_bwd (type 10)
-void launch_wgrad(const WgradBatch& wb, hipStream_t s, bool one_product = false);     // kernels_wgrad.hip
+void launch_wgrad(const WgradBatch& wb, hipStream_t s);     // kernels_wgrad.hip
 void launch_attn_out_bwd(const float* dy, const float* dy2, const float* r, const float* ln_g, const float* WTpack, float* g_o,
                          float* dr, float* p_lng, float* p_lnb, int R, Drop d4, Drop d5, hipStream_t s);
 void launch_attn_bwd(const float* Q, const float* K, const float* V, const float* att, const float* dr, const float* lse,

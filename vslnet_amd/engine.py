@@ -31,7 +31,7 @@ class vsl_io(C.Structure):
                 ('workspace', C.c_void_p), ('training', C.c_int32), ('seed', C.c_uint64),
                 ('d_h_score', C.c_void_p), ('d_start_logits', C.c_void_p), ('d_end_logits', C.c_void_p),
                 ('grads', C.c_void_p), ('sample_offset', C.c_int32), ('video_features_bf16', C.c_void_p),
-                ('early_grads_event', C.c_void_p), ('arithmetic', C.c_int32)]
+                ('early_grads_event', C.c_void_p)]
 
 
 class vsl_loss_io(C.Structure):
@@ -241,12 +241,12 @@ class Engine:
 
     # ---- the three calls ------------------------------------------------------------------------------------
     def forward(self, flat, pad_vec, glove_vec, word_ids, char_ids, vfeats, v_mask, q_mask, training=False, seed=0,
-                sample_offset=0, arithmetic='f32'):
+                sample_offset=0):
         """`sample_offset`: index of this shard's first sample in the global batch (data parallel; vslnet_hip.h).
         `vfeats` in torch.bfloat16 selects the bf16 THROUGHPUT mode (vsl_io.video_features_bf16): bf16 features in HBM and a
         bf16-MFMA VisualProjection; everything downstream stays fp32.  Not the parity path.
-        `arithmetic='bf16'` (vsl_io.arithmetic = 1): VisualProjection and every weight gradient round their operands to bfloat16 and issue
-        one product per product (fp32 accumulation); applies to the backward of this forward as well.  Not the parity path either."""
+        (Round 6 removed vsl_io.arithmetic, the one-product mode of VisualProjection and the weight gradients: it measured +0.5 % for a 5e-2
+        logit tolerance, and its measured ceiling -- every conv-block GEMM as one product too -- was 1.07 x; profiles/r05_notes.md section 9.)"""
         B, T, Dv = vfeats.shape
         bf16 = vfeats.dtype == torch.bfloat16
         Lq, Lc = char_ids.shape[1], char_ids.shape[2]
@@ -272,9 +272,6 @@ class Engine:
         io.h_score, io.start_logits, io.end_logits = _ptr(out[0]), _ptr(out[1]), _ptr(out[2])
         io.workspace = _ptr(ws)
         io.training, io.seed, io.sample_offset = int(bool(training)), int(seed) & 0xFFFFFFFFFFFFFFFF, int(sample_offset)
-        if arithmetic not in ('f32', 'bf16'):
-            raise ValueError("arithmetic must be 'f32' or 'bf16', got %r" % (arithmetic,))
-        io.arithmetic = 1 if arithmetic == 'bf16' else 0
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         self._call(self.lib.vsl_forward(self.h, C.byref(io), stream))
         self._last, self._last_ws = io, ws
