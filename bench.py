@@ -31,7 +31,7 @@ PEAK_MFMA_F32 = 157.3e12       # MI355X_MICROARCH.md: fp32-in MFMA = fp32 vector
 PEAK_HBM = 8.0e12              # HBM3E spec
 PEAK_MFMA_BF16 = 2.5e15        # dense bf16 MFMA (the split kernels issue 6 bf16 products per fp32-grade product)
 CPU_THREADS = 16               # cpu_baseline's intra-op threads: the best of the sweep on the GPU boxes (tools/cpu_threads_sweep.py, profiles/r03_notes.md)
-PROFILE_JSON = 'r05_profile.json'   # tools/collect_evidence.sh -> tools/make_profile_json.py
+PROFILE_JSON = 'r06_profile.json'   # tools/collect_evidence.sh -> tools/make_profile_json.py
 
 
 def alg_flops_per_pair(T, Dv, Lq, Lc, d=128, NL=4, k=7, predictor='transformer'):
