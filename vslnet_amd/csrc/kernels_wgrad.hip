@@ -365,6 +365,32 @@ void launch_wgrad(const WgradBatch& wb0, hipStream_t s) {
     wb.start[wb.n] = total;
     if (total == 0) return;
     auto kind = [](const WgradJob& j) { return (j.nA == 0 && j.drop_on_A && j.dp.thresh ? 1 : 0) | (j.nA == 0 && j.a_bf16 ? 2 : 0); };
+    // A batch that mixes the two fp32 kinds is ONE launch of the dropout instantiation: the jobs without dropout ride in it with a neutral mask
+    // (threshold 0, scale 1: every hash keeps, x 1.0 is exact) instead of a launch of their own -- one boundary less on the step's tail, where
+    // the video pass' pointwise gradients and the VisualProjection gradient are the last two launches in front of the final reduction
+    // (same box, four pairs: 0.8722 -> 0.8682 ms, profiles/r06_raw/q16_ab.txt).  VSL_WG_MERGE=0: kind by kind, as before.
+    static const bool merge = !(getenv("VSL_WG_MERGE") && getenv("VSL_WG_MERGE")[0] == '0');
+    if (merge) {
+        bool any1 = false, only01 = true;
+        for (int i = 0; i < wb.n; ++i) { any1 = any1 || kind(wb.j[i]) == 1; only01 = only01 && kind(wb.j[i]) < 2; }
+        if (any1 && only01) {
+            total = 0;
+            WgradBatch m;
+            m.n = 0;
+            for (int pass = 1; pass >= 0; --pass)                     // the dropout jobs (the long ones) first
+                for (int i = 0; i < wb.n; ++i)
+                    if (kind(wb.j[i]) == pass) {
+                        WgradJob j = wb.j[i];
+                        if (pass == 0) j.dp = Drop{0u, 0u, 1.0f, 0u};
+                        m.start[m.n] = total;
+                        total += j.nG * ((j.K + 127) / 128) * ((j.R + WG_ROWS - 1) / WG_ROWS);
+                        m.j[m.n++] = j;
+                    }
+            m.start[m.n] = total;
+            VSL_LAUNCH((k_wgrad4<true>), dim3(total), dim3(WG4_T), 0, s, m);
+            return;
+        }
+    }
     const int k0 = kind(wb.j[0]);
     bool mixed = false;
     for (int i = 1; i < wb.n; ++i) mixed = mixed || kind(wb.j[i]) != k0;
