@@ -1,9 +1,9 @@
 #!/bin/bash
 # One gpurun call: kernel-trace stats, the PMC passes (each in its own run, as MI355X_MICROARCH.md prescribes), the profile json
 # bench.py quotes as the static half of its roofline object, then the final bench line and the HIP-event table.
-# usage (on the GPU box, from the repo root): bash tools/collect_evidence.sh r06_a
+# usage (on the GPU box, from the repo root): bash tools/collect_evidence.sh r06_b
 set -u
-TAG=${1:-r06_a}
+TAG=${1:-r06_b}
 R=$PWD
 O=$R/gpurun_out/$TAG
 mkdir -p $O
