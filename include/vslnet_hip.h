@@ -137,6 +137,11 @@ int vsl_backward(vsl_handle h, const vsl_io* io, void* hip_stream);
 /* first float offset of the parameter block whose gradients are final when vsl_io.early_grads_event fires (== vsl_param_floats()
  * when the configuration has no such block: the rnn predictor) */
 int64_t vsl_early_grad_offset(vsl_handle h);
+
+/* test hook (tests/test_rnn_fused.py): sets the process-wide counter the fused rnn head derives its granule tags from -- 21 bits of it are the
+ * tag, the bits above the generation for which a plan's granule buffers were last cleared -- so that a test can step across the wrap without two
+ * million launches.  Returns the previous value.  No reference counterpart. */
+uint64_t vsl_debug_rnn_launches(uint64_t n);
 /* ConditionedPredictor.extract_index (layers_t7.py:355-363) */
 int vsl_extract_index(vsl_handle h, const float* start_logits, const float* end_logits, int B, int T,
                       int64_t* start_index, int64_t* end_index, void* hip_stream);

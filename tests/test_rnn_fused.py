@@ -95,3 +95,33 @@ def test_fused_launch_agrees_with_the_chunked_launches(tmp_path):
     err = float((a['g'] - b['g']).abs().max())
     print('[fused vs chunked] logits %.2e, gradients %.2e of max |g| %.2e' % (float((a['sl'] - b['sl'])[fin].abs().max()), err, scale))
     assert err <= 2e-5 * scale
+
+
+def test_granule_tags_stay_unique_across_the_21_bit_wrap():
+    """the launch whose counter value is 0 mod 2^21 used to be remapped onto the tag of the launch AFTER it; two forward-only launches
+    (eval / inference loops: no backward in between) then shared a tag and the second one's consumers could take the first one's granules as valid.
+    Forward-only launches on alternating inputs across the wrap must reproduce what the same inputs give far away from it, bit for bit."""
+    from vslnet_amd.engine import Engine, flat_from_state_dict
+    cfg = O.make_cfg(video_feature_dim=64, max_pos_len=32, word_size=52, predictor='rnn')
+    P = O.random_params(cfg, seed=7)
+    eng = Engine(cfg)
+    flat = flat_from_state_dict(eng, P)
+    pad, glove = P['embedding_net.word_emb.pad_vec'].cuda(), P['embedding_net.word_emb.glove_vec'].cuda()
+    batches = [{k: v.cuda().contiguous() for k, v in O.synthetic_batch(cfg, B=8, T=32, Lq=6, Lc=6, seed=s, ragged=True).items()} for s in (21, 22)]
+
+    def fwd(d):
+        h, sl, el = eng.forward(flat, pad, glove, d['word_ids'], d['char_ids'], d['vfeats'], d['v_mask'], d['q_mask'])
+        torch.cuda.synchronize()
+        return torch.stack([h, sl, el]).clone()
+
+    prev = eng.lib.vsl_debug_rnn_launches(1000)
+    try:
+        ref = [fwd(batches[0]), fwd(batches[1])]
+        assert not torch.equal(ref[0], ref[1])
+        eng.lib.vsl_debug_rnn_launches((1 << 21) - 3)
+        for i in range(8):                         # counter values 2^21 - 2 .. 2^21 + 5: the wrap sits in the middle
+            out = fwd(batches[i & 1])
+            assert torch.equal(out, ref[i & 1]), 'launch %d behind the wrap differs' % i
+        assert eng.lib.vsl_debug_rnn_launches(0) == (1 << 21) + 5
+    finally:
+        eng.lib.vsl_debug_rnn_launches(max(prev, 1 << 22))

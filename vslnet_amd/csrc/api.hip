@@ -1755,6 +1755,8 @@ int vsl_backward(vsl_handle h, const vsl_io* io, void* hip_stream) {
 
 int vsl_abi_version(void) { return VSL_ABI_VERSION; }
 
+uint64_t vsl_debug_rnn_launches(uint64_t n) { return (uint64_t)g_rnn_launches.exchange((unsigned long long)n); }
+
 int64_t vsl_early_grad_offset(vsl_handle h) {
     if (!h) return -1;
     if (h->cfg.predictor != 1) return h->param_floats;

@@ -53,7 +53,7 @@ class VslError(RuntimeError):
 ABI_SYMBOLS = ['vsl_last_error', 'vsl_create', 'vsl_destroy', 'vsl_param_count', 'vsl_param_info', 'vsl_param_floats',
                'vsl_workspace_floats', 'vsl_forward', 'vsl_loss', 'vsl_backward', 'vsl_extract_index',
                'vsl_adamw_step', 'vsl_workspace_offset', 'vsl_profile_select', 'vsl_profile_read', 'vsl_profile_launch', 'vsl_abi_version',
-               'vsl_early_grad_offset']
+               'vsl_early_grad_offset', 'vsl_debug_rnn_launches']
 ABI_VERSION = 7                                     # include/vslnet_hip.h: VSL_ABI_VERSION
 
 
@@ -81,6 +81,9 @@ def load_library():
     #                                                       new vsl_io fields are appended, so an older library simply does not read them
     if not explicit and (not hasattr(lib, 'vsl_abi_version') or lib.vsl_abi_version() != ABI_VERSION):
         raise VslError('%s implements another ABI version than this binding (%d): rebuild it (python -m vslnet_amd.build --force)' % (path, ABI_VERSION))
+    if hasattr(lib, 'vsl_debug_rnn_launches'):
+        lib.vsl_debug_rnn_launches.argtypes = [C.c_uint64]
+        lib.vsl_debug_rnn_launches.restype = C.c_uint64
     if hasattr(lib, 'vsl_early_grad_offset'):
         lib.vsl_early_grad_offset.argtypes = [C.c_void_p]
         lib.vsl_early_grad_offset.restype = C.c_int64
