@@ -1,13 +1,12 @@
-// The QUERY branch of VSLNet as sample-local kernels (gfx950): one workgroup per sample, the whole 32-row window of a sample's words in
-// registers, 17 KB (one fp32 tile) + 2 x 26 KB (bf16 operand planes) of LDS.
+// The QUERY branch of VSLNet as sample-local kernels (gfx950): one workgroup (four waves, one per SIMD) per sample, the residual stream of the
+// sample's 32-row window in registers, one fp32 tile (17 KB) + two or three bf16 operand-plane buffers (26 KB each) of LDS.
 //
 // Every kernel of the query branch is sample-local: Lq <= 32 words, and nothing on a word's path needs another sample -- Embedding.linear
 // (/root/reference/model/layers_t7.py:83-88), FeatureEncoder at L = Lq (:193-205: positional rows, the four conv layers :131-140, the
-// attention block :167-190), applied at /root/reference/model/VSLNet_t7.py:54,56.  As row-tile launches these were 3 (forward) / 4 (backward)
-// kernels of 64 - 160 workgroups with 36 - 125 KB of LDS each, which cannot sit beside the video chain's 142 - 144 KB workgroups (one per CU,
-// 256 of them): whichever chain reached a CU second waited a whole round of the other (profiles/r05_notes.md section 6).  Here a sample's
-// window lives in REGISTERS and the workgroup asks for 17 KB of LDS and 4 waves, so it fits in the shadow of a conv-block workgroup
-// (163 840 - 144 320 = 19 520 B free, two wave slots per SIMD free).
+// attention block :167-190), applied at /root/reference/model/VSLNet_t7.py:54,56.  As row-tile launches these are 3 (forward) / 3 (backward)
+// kernels of 40 - 64 workgroups each plus two launch boundaries per direction; here ONE launch per direction.  (The first version kept to
+// 17 KB of LDS and 228 registers so as to sit in the shadow of a video conv-block workgroup -- which turned out to own its CU's whole
+// register file: last paragraph.  This version uses what a workgroup that has its CU to itself can use.)
 //
 // "T layout".  All products are computed TRANSPOSED on the matrix cores:  Y^T[n][m] = sum_k W[n][k] X[m][k]  with the WEIGHT as the MFMA's
 // A operand (M dimension = 32 output channels of the wave) and the ACTIVATION as its B operand (N dimension = the sample's 32 rows):
@@ -58,7 +57,6 @@ static void qdbg_report(const char* name, int i0, int i1, hipStream_t s) {
 
 constexpr int QT = 256;                         // threads per workgroup: 4 waves, one per SIMD
 constexpr int QROWS = 32;                       // rows of a sample window (L <= 32)
-constexpr int QMAXCH = 4;                       // 128-column chunks of an Embedding row the forward keeps in registers (word_dim + 100 <= 512)
 
 __device__ __forceinline__ int nl(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
