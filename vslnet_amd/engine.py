@@ -31,7 +31,8 @@ class vsl_io(C.Structure):
                 ('workspace', C.c_void_p), ('training', C.c_int32), ('seed', C.c_uint64),
                 ('d_h_score', C.c_void_p), ('d_start_logits', C.c_void_p), ('d_end_logits', C.c_void_p),
                 ('grads', C.c_void_p), ('sample_offset', C.c_int32), ('video_features_bf16', C.c_void_p),
-                ('early_grads_event', C.c_void_p)]
+                ('early_grads_event', C.c_void_p),
+                ('_reserved', C.c_int64)]          # zero tail: an older build of the library (A/B runs, VSLNET_HIP_LIB) reads a field here
 
 
 class vsl_loss_io(C.Structure):
@@ -105,8 +106,9 @@ def load_library():
     lib.vsl_workspace_offset.restype = C.c_int64
     lib.vsl_profile_select.argtypes = [C.c_void_p, C.c_char_p]
     lib.vsl_profile_read.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
-    lib.vsl_profile_launch.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double),
-                                       C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    if hasattr(lib, 'vsl_profile_launch'):       # (absent from an older build loaded through VSLNET_HIP_LIB for an A/B run)
+        lib.vsl_profile_launch.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                           C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     _LIB = lib
     return lib
 
