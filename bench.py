@@ -183,7 +183,7 @@ OTHER_SHAPES = [
 def time_shape(predictor, batch, T, dv, lq, lc, drop_rate, dtype, steps, warmup, nres, regions=3):
     """One single-process training step (forward + both losses + backward + clip + AdamW, as the headline) of another shape:
     median of `regions` regions of `steps` steps.  Returns (ms per step, pairs/s, loss)."""
-    from vslnet_amd.dp import FlatAdamW
+    from vslnet_amd.dp import FlatAdamW, backward_exchange_step as dp_step
     from vslnet_amd.model.VSLNet import VSLNet
     from vslnet_amd.synthetic import make_configs, synthetic_batch
     configs = make_configs(video_feature_dim=dv, max_pos_len=max(T, lq), drop_rate=drop_rate, predictor=predictor)
@@ -205,8 +205,7 @@ def time_shape(predictor, batch, T, dv, lq, lc, drop_rate, dtype, steps, warmup,
         eng.forward(flat, pad_vec, glove_vec, bt['word_ids'], bt['char_ids'], bt['vfeats'], bt['v_mask'], bt['q_mask'], training=True, seed=i,
                     sample_offset=0)
         losses, d_h, d_sl, d_el = eng.loss(bt['s_labels'], bt['e_labels'], bt['h_labels'], 1.0, configs.highlight_lambda, inv_batch=1.0 / batch, mask_sum=mask_sum)
-        eng.backward(d_h, d_sl, d_el, grads)
-        opt.step(grads, from_backward=True)
+        dp_step(eng, None, grads, (d_h, d_sl, d_el), opt)       # one process: the update rides in the backward's last launch (as main.train does)
         return losses
     for i in range(warmup):
         step(i)
@@ -327,7 +326,7 @@ def main():
     # the update of main_t7.py:111-113 (clip 1.0, AdamW, linear decay) as the library's fused two-kernel step; identical on
     # every rank because the reduced gradient is.  BASELINE's metric is "fwd+bwd": the update is extra work inside the
     # timed region, so the reported number is a lower bound of that metric and a complete training step.
-    from vslnet_amd.dp import FlatAdamW, OverlappedExchange
+    from vslnet_amd.dp import FlatAdamW, OverlappedExchange, backward_exchange_step
     # N > 1 (or a single-rank torchrun launch): backward + exchange through OverlappedExchange -- the predictor block of the bucket is
     # all-reduced on a side stream while the rest of the backward runs (VSL_ALLREDUCE=single: one call behind the backward)
     # (one rank has nothing to hide a second call behind: measured 36.6 vs 28.8 us of exposed launch cost per step)
@@ -342,6 +341,9 @@ def main():
         losses, d_h, d_sl, d_el = eng.loss(batch['s_labels'], batch['e_labels'], batch['h_labels'], 1.0,
                                            configs.highlight_lambda, inv_batch=inv_batch, mask_sum=mask_sum)
         skip_exchange = skip_exchange or os.environ.get('VSL_SKIP_ALLREDUCE') == '1'
+        if xchg is None and dist is None and not args.no_optimizer:
+            backward_exchange_step(eng, None, grads, (d_h, d_sl, d_el), opt)      # one process, as main.train: the update rides in the backward's last launch
+            return losses
         if xchg is not None:
             xchg.backward(d_h, d_sl, d_el, grads, skip_exchange=skip_exchange)    # flat fp32 bucket, summed (losses carry 1/B_global)
         else:

@@ -90,10 +90,13 @@ typedef struct {
      * offsets are final when vsl_backward's work on the caller's stream completes.  No reference counterpart (main_t7.py has no
      * distributed code); it is what makes the ONE exchange of SURVEY 8(e) overlap with the backward. */
     void* early_grads_event;
+    /* single process, optional (NULL = off): the optimizer step of main_t7.py:111-113 applied by vsl_backward itself, behind its final
+     * reduction (see vsl_fused_step below).  Not for data-parallel callers: their gradients are exchanged between the backward and the update. */
+    const struct vsl_fused_step* fused_step;
 } vsl_io;
 /* Every struct of this header must be zero-initialised by the caller before the fields are set: new optional fields are appended, and
  * zero means "off".  vsl_abi_version() changes whenever a struct layout or an entry point's meaning changes; a binding checks it once. */
-#define VSL_ABI_VERSION 7
+#define VSL_ABI_VERSION 8
 int vsl_abi_version(void);
 
 /* labels + weights for the fused loss (replaces compute_loss / compute_highlight_loss, VSLNet_t7.py:67-72, and the
@@ -172,6 +175,19 @@ typedef struct {
 } vsl_adamw;
 int vsl_adamw_step(vsl_handle h, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                    const vsl_adamw* hp, float* grad_norm_out, void* hip_stream);
+/* vsl_io.fused_step: vsl_backward followed by vsl_adamw_step(params, io->grads, exp_avg, exp_avg_sq, &hp, grad_norm_out) with
+ * hp.norm_from_backward = 1, as ONE call (main_t7.py:110-113 without the host in between).  `params` is normally vsl_io.params itself: every
+ * kernel that reads the weights is ordered in front of the update.  io->grads still receives the (unclipped) gradients.  The library issues
+ * the final reduction and the update as two launches on the caller's stream; with VSL_FUSED_TAIL=1 in the environment they are ONE launch
+ * whose workgroups hand their sums of squares to each other (same arithmetic, the norm summed in another fixed order) -- measured level with
+ * the two launches, hence not the default; it needs every gradient to leave the final reduction (not word_table = 1). */
+typedef struct vsl_fused_step {
+    float* params;
+    float* exp_avg;
+    float* exp_avg_sq;
+    vsl_adamw hp;
+    float* grad_norm_out;      /* optional */
+} vsl_fused_step;
 
 /* workspace introspection for the parity tests: float offset of a named saved activation, -1 if unknown.
  * names: "video_affine", "embedding_net", "venc", "qenc", "cq_attention", "cq_concat", "gated", "pred_s", "pred_e" */

@@ -176,8 +176,7 @@ def train(configs, dataset, features, device, world, rank, log=print):
                                     training=True, seed=(configs.seed << 20) + global_step, sample_offset=batch['row0'])
                         losses, *seeds = eng.loss(batch['s_labels'], batch['e_labels'], batch['h_labels'], 1.0,
                                                   configs.highlight_lambda, inv_batch=inv_batch, mask_sum=mask_sum)
-                    touched = dp.backward_and_exchange(eng, xchg, grads, seeds)       # (tests/test_dp_gloo.py drives this unit on 2 and 3 ranks)
-                    opt.step(grads, from_backward=not touched)                        # the backward's own norm only for an untouched bucket
+                    dp.backward_exchange_step(eng, xchg, grads, seeds, opt)          # (tests/test_dp_gloo.py drives its multi-rank half on 2 and 3 ranks)
                     loss_t = losses[2]
                 else:
                     _, vfeats, vfeat_lens, word_ids, char_ids, s_labels, e_labels, h_labels = batch

@@ -135,6 +135,80 @@ def test_norm_from_backward_matches_the_two_kernel_step(predictor):
         eng.adamw_step(flat.clone(), clean, torch.zeros_like(flat), torch.zeros_like(flat), 1e-3, 1, norm_from_backward=True)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('variant', ['transformer', 'rnn', 'word_table', 'hf_order', 'two launches'])
+def test_fused_step_matches_backward_then_adamw(variant, monkeypatch):
+    """vsl_io.fused_step (round 6): the optimizer step applied by the backward's LAST launch (final reduction + global norm + AdamW in one
+    kernel whose workgroups hand their sums of squares to each other) against backward() followed by adamw_step(norm_from_backward=True).
+    Three consecutive training steps from the same state: identical gradients, the same norm to fp32 rounding (another summation order),
+    the same parameters and moments.  word_table = 1 (its table gradient does not leave the reduction) takes the library's two-launch form, and
+    so does every configuration unless VSL_FUSED_TAIL=1 asks for the one launch (the library's default: profiles/r06_notes.md section 7)."""
+    monkeypatch.setenv('VSL_FUSED_TAIL', '0' if variant == 'two launches' else '1')
+    from oracle import vslnet_oracle as O
+    from vslnet_amd.engine import Engine, flat_from_state_dict
+    from vslnet_amd.dp import FlatAdamW
+    kw = dict(video_feature_dim=64, max_pos_len=64, word_size=52, predictor='rnn' if variant == 'rnn' else 'transformer', drop_rate=0.2)
+    if variant == 'word_table':
+        kw['word_table'] = True
+    cfg = O.make_cfg(**kw)
+    P = O.random_params(cfg, seed=2)
+    eng = Engine(cfg)
+    batches = [{k: v.cuda().contiguous() for k, v in O.synthetic_batch(cfg, B=5, T=40, Lq=7, Lc=6, seed=4 + i, ragged=True).items()} for i in range(3)]
+    pad, glove = P.get('embedding_net.word_emb.pad_vec'), P.get('embedding_net.word_emb.glove_vec')       # (absent: trainable word table)
+    pad, glove = (None if pad is None else pad.cuda()), (None if glove is None else glove.cuda())
+    real = torch.zeros(eng.param_floats, dtype=torch.bool, device='cuda')
+    for _, off, numel, _ in eng.layout:
+        real[off:off + numel] = True
+    runs = []
+    for fused in (False, True):
+        flat = flat_from_state_dict(eng, P).clone()
+        opt = FlatAdamW(flat, eng.layout, lr=1e-3, num_train_steps=10, clip_norm=0.05, engine=eng, hf_order=variant == 'hf_order')
+        norms, gsnap = [], []
+        for i, d in enumerate(batches):
+            eng.forward(flat, pad, glove, d['word_ids'], d['char_ids'], d['vfeats'], d['v_mask'], d['q_mask'], training=True, seed=3 + i)
+            _, d_h, d_sl, d_el = eng.loss(d['s_labels'], d['e_labels'], d['h_labels'], 1.0, 5.0)
+            grads, gn = torch.zeros(eng.param_floats, device='cuda'), torch.zeros(1, device='cuda')
+            if fused:
+                eng.backward(d_h, d_sl, d_el, grads, fused_step=opt.fused_step(grad_norm_out=gn))
+            else:
+                eng.backward(d_h, d_sl, d_el, grads)
+                lr = opt.lr()
+                opt.t += 1
+                eng.adamw_step(flat, grads, opt.m, opt.v, lr, opt.t, clip_norm=0.05, grad_norm_out=gn, hf_order=opt.hf_order, norm_from_backward=True)
+            torch.cuda.synchronize()
+            norms.append(float(gn))
+            gsnap.append(grads[real].clone())
+        runs.append((flat[real].clone(), opt.m[real].clone(), opt.v[real].clone(), norms, gsnap, opt.t))
+    a, b = runs
+    assert a[5] == b[5] == 3
+    assert torch.equal(a[4][0], b[4][0])                                          # same weights, same batch, same seed: the same gradients
+    for na, nb in zip(a[3], b[3]):
+        assert na > 0.05 and abs(na - nb) <= 4e-6 * na, (a[3], b[3])               # (the clip is active)
+    for x, y, nm in zip(a[:3], b[:3], ('params', 'exp_avg', 'exp_avg_sq')):
+        assert torch.isfinite(y).all(), nm
+        assert torch.allclose(x, y, rtol=2e-5, atol=1e-8), (nm, float((x - y).abs().max()))
+
+
+@pytest.mark.gpu
+def test_fused_step_rejects_what_it_cannot_do():
+    from oracle import vslnet_oracle as O
+    from vslnet_amd.engine import Engine, VslError, flat_from_state_dict
+    cfg = O.make_cfg(video_feature_dim=64, max_pos_len=64, word_size=52, predictor='transformer', drop_rate=0.0)
+    P = O.random_params(cfg, seed=2)
+    eng = Engine(cfg)
+    d = {k: v.cuda().contiguous() for k, v in O.synthetic_batch(cfg, B=2, T=32, Lq=5, Lc=4, seed=4).items()}
+    flat = flat_from_state_dict(eng, P)
+    eng.forward(flat, P['embedding_net.word_emb.pad_vec'].cuda(), P['embedding_net.word_emb.glove_vec'].cuda(), d['word_ids'], d['char_ids'],
+                d['vfeats'], d['v_mask'], d['q_mask'], training=True, seed=1)
+    _, d_h, d_sl, d_el = eng.loss(d['s_labels'], d['e_labels'], d['h_labels'], 1.0, 5.0)
+    z = torch.zeros_like(flat)
+    fs = dict(flat=flat.clone(), exp_avg=z.clone(), exp_avg_sq=z.clone(), lr=1e-3, step=0)
+    with pytest.raises(VslError, match='step'):
+        eng.backward(d_h, d_sl, d_el, eng.new_flat(), fused_step=fs)
+    with pytest.raises(ValueError, match='early_event'):
+        eng.backward(d_h, d_sl, d_el, eng.new_flat(), fused_step=dict(fs, step=1), early_event=torch.cuda.Event())
+
+
 def _hf_adamw_steps(P, layout, grads_seq, lr0, total, eps=1e-6, wd=0.01, clip=1.0):
     """The historical transformers.AdamW (the class VSLNet_t7.py:5 imports; removed from transformers 5.x), restated from its
     published source, per parameter, in float64: exp_avg / exp_avg_sq update, step_size = lr * sqrt(1 - b2^t) / (1 - b1^t),

@@ -51,7 +51,7 @@ def test_sample_local_query_path_against_the_oracle(shape):
 
 @pytest.mark.gpu
 def test_which_launches_a_step_takes_and_what_the_ledger_records():
-    from vslnet_amd.dp import FlatAdamW
+    from vslnet_amd.dp import FlatAdamW, backward_exchange_step
     from vslnet_amd.model.VSLNet import VSLNet
     from vslnet_amd.synthetic import make_configs, synthetic_batch
 
@@ -69,8 +69,7 @@ def test_which_launches_a_step_takes_and_what_the_ledger_records():
         def step(i):
             eng.forward(flat, pad_vec, glove_vec, bt['word_ids'], bt['char_ids'], bt['vfeats'], bt['v_mask'], bt['q_mask'], training=True, seed=i)
             _, d_h, d_sl, d_el = eng.loss(bt['s_labels'], bt['e_labels'], bt['h_labels'], 1.0, 5.0, inv_batch=0.25, mask_sum=float(bt['v_mask'].sum()))
-            eng.backward(d_h, d_sl, d_el, grads)
-            opt.step(grads, from_backward=True)
+            backward_exchange_step(eng, None, grads, (d_h, d_sl, d_el), opt)        # (as main.train and bench.py)
         step(0)
         eng.profile_select('*')
         step(1)
@@ -92,5 +91,11 @@ def test_which_launches_a_step_takes_and_what_the_ledger_records():
         for d in r['deps']:
             assert recs[d]['stop_us'] <= r['start_us'] + 0.5, 'launch %d (%s) started before its dependency %d (%s) stopped' % (i, r['name'], d, recs[d]['name'])
     assert any(len(r['deps']) >= 2 for r in recs)                 # the joins
+    os.environ['VSL_FUSED_TAIL'] = '1'                          # the final reduction + clip + AdamW as one launch (off by default)
+    try:
+        fused = [r['name'] for r in launches(20)]
+    finally:
+        del os.environ['VSL_FUSED_TAIL']
+    assert fused[-1] == 'reduce_adamw' and 'adamw' not in fused and len(fused) == len(names) - 1
     names40 = [r['name'] for r in launches(40)]
     assert 'query_fwd' not in names40 and 'query_bwd' not in names40 and names40.count('convblock_fwd') == 4

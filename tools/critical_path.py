@@ -99,7 +99,7 @@ def main():
     import torch
     from vslnet_amd.model.VSLNet import VSLNet
     from vslnet_amd.synthetic import make_configs, synthetic_batch
-    from vslnet_amd.dp import FlatAdamW
+    from vslnet_amd.dp import FlatAdamW, backward_exchange_step
     B, T, Dv, Lq, Lc = args.batch, args.T, args.dv, args.lq, args.lc
     configs = make_configs(video_feature_dim=Dv, max_pos_len=max(T, Lq), drop_rate=0.2, predictor=args.predictor)
     torch.manual_seed(configs.seed)
@@ -116,8 +116,7 @@ def main():
         b = batches[i % len(batches)]
         eng.forward(flat, pad_vec, glove_vec, b['word_ids'], b['char_ids'], b['vfeats'], b['v_mask'], b['q_mask'], training=True, seed=i)
         _, d_h, d_sl, d_el = eng.loss(b['s_labels'], b['e_labels'], b['h_labels'], 1.0, configs.highlight_lambda, inv_batch=1.0 / B, mask_sum=mask_sum)
-        eng.backward(d_h, d_sl, d_el, grads)
-        opt.step(grads, from_backward=True)
+        backward_exchange_step(eng, None, grads, (d_h, d_sl, d_el), opt)
 
     for i in range(10):
         step(i)

@@ -102,6 +102,9 @@ struct vsl_handle_s {
     unsigned* loss_counter = nullptr;    // arrival counter of k_loss_fused (zero between calls)
     uint8_t* decay_dev = nullptr;        // per-element weight-decay flag of the flat bucket (vsl_adamw_step)
     float* opt_scratch = nullptr;        // OPT_BLOCKS partial sums of grads^2
+    unsigned long long* tail_gran = nullptr;   // vsl_io.fused_step: one {tag, sum of squares} granule per workgroup of the fused tail launch
+    int tail_cap = 0;                    // ... their number = the largest grid that launch may take (4 workgroups per CU)
+    unsigned tail_tag = 0;               // ... the tag of the last such launch
     const float* sq_src = nullptr;       // the last vsl_backward's per-block sums of squares (Plan::sq_dev), their count, the bucket they describe
     int sq_n = 0;
     const float* sq_grads = nullptr;
@@ -1330,7 +1333,32 @@ void run_backward(Ctx& c) {
     c.s = main_s;
     c.order(sq, c.s);                      // join both side streams before the reduction
     c.order(sw, c.s);
-    LAUNCH("reduce", launch_reduce(c.ws, io->grads, p.segs_dev, p.blk2seg_dev + 2 * p.nblocks_early, p.nblocks - p.nblocks_early, p.sq_dev + p.nblocks_early, c.s));
+    const int nlate = p.nblocks - p.nblocks_early;
+    const vsl_fused_step* fs = c.dry ? nullptr : io->fused_step;
+    if (!fs) {
+        LAUNCH("reduce", launch_reduce(c.ws, io->grads, p.segs_dev, p.blk2seg_dev + 2 * p.nblocks_early, nlate, p.sq_dev + p.nblocks_early, c.s));
+        return;
+    }
+    // the optimizer step inside the call (vsl_io.fused_step): one launch when every gradient leaves the reductions, the two launches otherwise
+    const vsl_adamw& hp = fs->hp;
+    const float bc1 = (float)(1.0 - std::pow((double)hp.beta1, (double)hp.step)), bc2s = (float)std::sqrt(1.0 - std::pow((double)hp.beta2, (double)hp.step));
+    // ONE launch only on request (VSL_FUSED_TAIL=1, read per call): same-box it is level with the two launches (profiles/r06_notes.md section 7), and a
+    // launch whose workgroups wait for each other is the wrong default for a process that may be given fewer CUs than the device reports
+    const char* ft = getenv("VSL_FUSED_TAIL");
+    const bool fuse = ft && atoi(ft) != 0;
+    const int grid = fuse && p.sq_cover ? reduce_adamw_grid(nlate, c.h->tail_cap) : 0;
+    if (grid > 0) {
+        if (++c.h->tail_tag == 0) ++c.h->tail_tag;
+        LAUNCH("reduce_adamw", launch_reduce_adamw(c.ws, io->grads, p.segs_dev, p.blk2seg_dev + 2 * p.nblocks_early, nlate, p.sq_dev + p.nblocks_early,
+                                                   p.sq_dev, p.blk2seg_dev, p.nblocks_early, grid, c.h->tail_gran, c.h->tail_tag, fs->params,
+                                                   fs->exp_avg, fs->exp_avg_sq, c.h->decay_dev, hp.lr, hp.beta1, hp.beta2, hp.eps,
+                                                   hp.weight_decay, hp.clip_norm, bc1, bc2s, fs->grad_norm_out, hp.hf_order, c.s));
+        return;
+    }
+    LAUNCH("reduce", launch_reduce(c.ws, io->grads, p.segs_dev, p.blk2seg_dev + 2 * p.nblocks_early, nlate, p.sq_dev + p.nblocks_early, c.s));
+    LAUNCH("adamw", launch_adamw(fs->params, io->grads, fs->exp_avg, fs->exp_avg_sq, c.h->decay_dev, c.h->opt_scratch, c.h->param_floats, hp.lr,
+                                 hp.beta1, hp.beta2, hp.eps, hp.weight_decay, hp.clip_norm, bc1, bc2s, fs->grad_norm_out, c.s, hp.hf_order,
+                                 p.sq_cover ? p.sq_dev : nullptr, p.nblocks));
 }
 
 int build_plan(vsl_handle_s* h, int B, int T, int Lq, int Lc, Plan** out) {
@@ -1423,6 +1451,16 @@ int build_plan(vsl_handle_s* h, int B, int T, int Lq, int Lc, Plan** out) {
     for (ReduceSeg& s : segs) {
         s.vec = (s.n % 4 == 0) && (s.rl % 4 == 0) && (s.ds % 4 == 0) && (s.dst % 4 == 0);
         for (int q = 0; q < s.nsrc; ++q) s.vec = s.vec && (s.src[q] % 4 == 0) && (s.ss[q] % 4 == 0) && (s.vn[q] % 4 == 0);
+    }
+    if (getenv("VSL_DEBUG_PLAN")) {
+        int64_t tot = 0;
+        for (const ReduceSeg& s : segs) {
+            int64_t fl = 0; int ns = 0;
+            for (int q = 0; q < s.nsrc; ++q) { fl += (int64_t)s.nslabs[q] * s.vn[q]; ns += s.nslabs[q]; }
+            tot += fl;
+            if (fl * 4 >= (256 << 10)) fprintf(stderr, "[plan] dst %8d n %7d nsrc %d slabs %5d  read %8.2f MiB\n", s.dst, s.n, s.nsrc, ns, fl * 4.0 / (1 << 20));
+        }
+        fprintf(stderr, "[plan] %zu segments, %.2f MiB of partial slabs read per step, partial arena %.2f MiB\n", segs.size(), tot * 4.0 / (1 << 20), p->partial_floats * 4.0 / (1 << 20));
     }
     // early / late split by destination: everything up to the end of the shared feature encoder's parameters is `late`
     // plus what k_cq_bwd_d produces on the query stream after the fork (w4Q, pooled-query weight, second half of / bias of
@@ -1650,6 +1688,7 @@ int vsl_destroy(vsl_handle h) {
     if (h->loss_counter) (void)hipFree(h->loss_counter);
     if (h->decay_dev) (void)hipFree(h->decay_dev);
     if (h->opt_scratch) (void)hipFree(h->opt_scratch);
+    if (h->tail_gran) (void)hipFree(h->tail_gran);
     delete h;
     return 0;
 }
@@ -1739,11 +1778,39 @@ int vsl_loss(vsl_handle h, const vsl_io* io, const vsl_loss_io* l, void* hip_str
     return 0;
 }
 
+// the optimizer's device-side constants (first use): decay flags, scratch of the two-kernel step, granules of the fused tail
+static int ensure_opt_state(vsl_handle_s* h) {
+    if (h->decay_dev) return 0;
+    std::vector<uint8_t> mask((size_t)h->param_floats, 0);          // VSLNet_t7.py:9-13: no decay for bias / layer_norm / LayerNorm parameters
+    for (const ParamInfo& p : h->params) {
+        const bool nd = p.name.find("bias") != std::string::npos || p.name.find("layer_norm") != std::string::npos ||
+                        p.name.find("LayerNorm") != std::string::npos;
+        if (!nd) std::fill(mask.begin() + p.off, mask.begin() + p.off + p.numel, (uint8_t)1);
+    }
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        return fail("optimizer state: cannot read the device's CU count");
+    h->tail_cap = reduce_adamw_resident(cus);
+    if (hipMalloc(&h->decay_dev, mask.size()) != hipSuccess || hipMalloc(&h->opt_scratch, (OPT_BLOCKS + 4) * sizeof(float)) != hipSuccess ||
+        hipMalloc(&h->tail_gran, (size_t)h->tail_cap * sizeof(unsigned long long)) != hipSuccess)
+        return fail("optimizer state: hipMalloc failed");
+    if (hipMemcpy(h->decay_dev, mask.data(), mask.size(), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemset(h->tail_gran, 0, (size_t)h->tail_cap * sizeof(unsigned long long)) != hipSuccess)      // tag 0 is never a launch's tag
+        return fail("optimizer state: hipMemcpy failed");
+    return 0;
+}
+
 int vsl_backward(vsl_handle h, const vsl_io* io, void* hip_stream) {
     if (int rc = check_io(h, io)) return rc;
     if (!io->d_start_logits || !io->d_end_logits || !io->grads) return fail("vsl_backward needs d_start_logits, d_end_logits and grads");
     Plan* p = nullptr;
     if (int rc = get_plan(h, io->B, io->T, io->Lq, io->Lc, &p)) return rc;
+    if (const vsl_fused_step* fs = io->fused_step) {
+        if (!fs->params || !fs->exp_avg || !fs->exp_avg_sq) return fail("vsl_backward: fused_step needs params, exp_avg and exp_avg_sq");
+        if (fs->hp.step < 1) return fail("vsl_backward: fused_step.hp.step must be >= 1 (got %d)", fs->hp.step);
+        if (io->early_grads_event) return fail("vsl_backward: fused_step (single process) and early_grads_event (data parallel) exclude each other");
+        if (int rc = ensure_opt_state(h)) return rc;
+    }
     Ctx c{h, p, io, (hipStream_t)hip_stream, false, io->workspace};
     c.main = c.s;
     CallScope scope(h);
@@ -1779,18 +1846,7 @@ int vsl_adamw_step(vsl_handle h, float* params, const float* grads, float* exp_a
                    float* grad_norm_out, void* hip_stream) {
     if (!h || !params || !grads || !exp_avg || !exp_avg_sq || !hp) return fail("vsl_adamw_step: null argument");
     if (hp->step < 1) return fail("vsl_adamw_step: step must be >= 1 (got %d)", hp->step);
-    if (!h->decay_dev) {          // VSLNet_t7.py:9-13: no decay for bias / layer_norm / LayerNorm parameters
-        std::vector<uint8_t> mask((size_t)h->param_floats, 0);
-        for (const ParamInfo& p : h->params) {
-            const bool nd = p.name.find("bias") != std::string::npos || p.name.find("layer_norm") != std::string::npos ||
-                            p.name.find("LayerNorm") != std::string::npos;
-            if (!nd) std::fill(mask.begin() + p.off, mask.begin() + p.off + p.numel, (uint8_t)1);
-        }
-        if (hipMalloc(&h->decay_dev, mask.size()) != hipSuccess || hipMalloc(&h->opt_scratch, (OPT_BLOCKS + 4) * sizeof(float)) != hipSuccess)
-            return fail("vsl_adamw_step: hipMalloc failed");
-        if (hipMemcpy(h->decay_dev, mask.data(), mask.size(), hipMemcpyHostToDevice) != hipSuccess)
-            return fail("vsl_adamw_step: hipMemcpy failed");
-    }
+    if (int rc = ensure_opt_state(h)) return rc;
     const double bc1 = 1.0 - std::pow((double)hp->beta1, (double)hp->step), bc2 = 1.0 - std::pow((double)hp->beta2, (double)hp->step);
     const float* sq = nullptr;
     if (hp->norm_from_backward) {

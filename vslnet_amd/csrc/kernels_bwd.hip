@@ -1618,15 +1618,14 @@ void launch_word_table_bwd(const float* dE, const int64_t* word_ids, float* gtab
 // =========================================================================================================
 // final reduction of all partial slabs into the flat gradient bucket
 // =========================================================================================================
-__global__ __launch_bounds__(256) void k_reduce(const float* __restrict__ ws, float* __restrict__ grads,
-                                                const ReduceSeg* __restrict__ segs, const int* __restrict__ blk2seg,
-                                                float* __restrict__ sq) {
-    // block = 256 destination elements: 64 float4 lanes x 4 slab groups (group g sums slabs s = g, g + 4, ...), each
-    // thread keeps 8 independent 16-byte loads in flight; the 4 group sums are combined through LDS.
-    // sq[block] = sum of squares of the block's 256 results: every gradient of the bucket leaves this kernel, so the clip's global norm
-    // needs no pass of its own over the bucket (vsl_adamw.norm_from_backward; k_adamw adds the partials in block order).
-    __shared__ float4 part[4][64];
-    const int si = blk2seg[2 * blockIdx.x], off = blk2seg[2 * blockIdx.x + 1];
+// unit = 256 destination elements: 64 float4 lanes x 4 slab groups (group g sums slabs s = g, g + 4, ...), each
+// thread keeps 8 independent 16-byte loads in flight; the 4 group sums are combined through LDS.
+// sq[unit] = sum of squares of the unit's 256 results (also returned, valid in thread 0): every gradient of the bucket leaves this code, so the
+// clip's global norm needs no pass of its own over the bucket (vsl_adamw.norm_from_backward; k_adamw adds the partials in unit order).
+__device__ __forceinline__ float reduce_unit(const float* __restrict__ ws, float* __restrict__ grads, const ReduceSeg* __restrict__ segs,
+                                             const int* __restrict__ blk2seg, float* __restrict__ sq, int unit, float4 (&part)[4][64],
+                                             float4* keep = nullptr /* wave 0: this lane's four results (ragged units: one per 64-element pass) */) {
+    const int si = blk2seg[2 * unit], off = blk2seg[2 * unit + 1];
     const ReduceSeg* __restrict__ sgp = segs + si;
     const int n = sgp->n, nsrc = sgp->nsrc, rl = sgp->rl, ds = sgp->ds, dst = sgp->dst;
     const int l4 = threadIdx.x & 63, grp = threadIdx.x >> 6;
@@ -1640,7 +1639,14 @@ __global__ __launch_bounds__(256) void k_reduce(const float* __restrict__ ws, fl
                 const size_t ss = (size_t)sgp->ss[q];
                 const int ns = sgp->nslabs[q];
                 int s = grp;
-                for (; s + 28 < ns; s += 32) {                       // 8 slabs of this group per iteration
+                for (; s + 60 < ns; s += 64) {                       // 16 slabs of this group per iteration (the 256-slab units of the embedding backward)
+                    float4 v[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const float4*>(p + (size_t)(s + 4 * u) * ss);
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+                }
+                for (; s + 28 < ns; s += 32) {                       // 8 slabs
                     float4 v[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(p + (size_t)(s + 4 * u) * ss);
@@ -1660,16 +1666,21 @@ __global__ __launch_bounds__(256) void k_reduce(const float* __restrict__ ws, fl
             acc.x += (b1.x + b2.x) + b3.x; acc.y += (b1.y + b2.y) + b3.y; acc.z += (b1.z + b2.z) + b3.z; acc.w += (b1.w + b2.w) + b3.w;
             *reinterpret_cast<float4*>(grads + dst + (i / rl) * ds + (i % rl)) = acc;
         } else acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        float q = 0.f;
         if (grp == 0) {                                  // (wave 0)
-            const float q = wave_sum((acc.x * acc.x + acc.y * acc.y) + (acc.z * acc.z + acc.w * acc.w));
-            if (l4 == 0) sq[blockIdx.x] = q;
+            if (keep) *keep = acc;
+            q = wave_sum((acc.x * acc.x + acc.y * acc.y) + (acc.z * acc.z + acc.w * acc.w));
+            if (l4 == 0) sq[unit] = q;
         }
+        return q;
     } else {
         // ragged / unaligned segments (single biases, the 10- and 30-channel char-conv biases ...): same structure with
         // scalar loads -- 64 elements per pass, 4 slab groups, 8 loads in flight (a serial walk over up to 256 slabs is
         // 256 exposed memory latencies)
         float* sp = reinterpret_cast<float*>(&part[0][0]);
         float q2 = 0.f;
+        float kp[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
         for (int base = 0; base < 256; base += 64) {
             const int e = off + base + l4;
             float a = 0.f;
@@ -1697,13 +1708,22 @@ __global__ __launch_bounds__(256) void k_reduce(const float* __restrict__ ws, fl
                 const float r = (sp[l4] + sp[64 + l4]) + (sp[128 + l4] + sp[192 + l4]);
                 grads[dst + (e / rl) * ds + (e % rl)] = r;
                 q2 += r * r;
+                kp[base >> 6] = r;
             }
         }
         if (grp == 0) {
+            if (keep) *keep = make_float4(kp[0], kp[1], kp[2], kp[3]);
             q2 = wave_sum(q2);
-            if (l4 == 0) sq[blockIdx.x] = q2;
+            if (l4 == 0) sq[unit] = q2;
         }
+        return q2;
     }
+}
+__global__ __launch_bounds__(256) void k_reduce(const float* __restrict__ ws, float* __restrict__ grads,
+                                                const ReduceSeg* __restrict__ segs, const int* __restrict__ blk2seg,
+                                                float* __restrict__ sq) {
+    __shared__ float4 part[4][64];
+    (void)reduce_unit(ws, grads, segs, blk2seg, sq, blockIdx.x, part);
 }
 void launch_reduce(const float* partial, float* grads, const ReduceSeg* segs_dev, const int* blk2seg_dev, int nblocks,
                    float* sq, hipStream_t s) {
@@ -1729,10 +1749,40 @@ __global__ __launch_bounds__(256) void k_sqsum(const float* __restrict__ g, int6
     __syncthreads();
     if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
+struct AdamHp { float lr, b1, b2, eps, wd, bc1, bc2_sqrt; int hf_order; };
+// clip + AdamW of one element (main_t7.py:111-112; eps 1e-6, decoupled decay)
+__device__ __forceinline__ void adamw_elem(float& pe, float& me, float& ve, float ge, unsigned char dke, float coef, const AdamHp& hp) {
+    const float lr = hp.lr, b1 = hp.b1, b2 = hp.b2, step_size = hp.lr / hp.bc1;
+    ge *= coef;
+    if (!hp.hf_order) pe *= 1.0f - lr * (dke ? hp.wd : 0.f);
+    me = b1 * me + (1.0f - b1) * ge;
+    ve = b2 * ve + (1.0f - b2) * ge * ge;
+    if (!hp.hf_order) pe -= step_size * me / (sqrtf(ve) / hp.bc2_sqrt + hp.eps);
+    else {                                   // transformers.AdamW: eps outside the bias correction, decay after the update
+        pe -= step_size * hp.bc2_sqrt * me / (sqrtf(ve) + hp.eps);
+        pe -= lr * (dke ? hp.wd : 0.f) * pe;
+    }
+}
+__device__ __forceinline__ void adamw_vec4(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, const uint8_t* __restrict__ decay,
+                                           int64_t i4, const float4 gv, float coef, const AdamHp& hp) {
+    float4* p4 = reinterpret_cast<float4*>(p);
+    float4* m4 = reinterpret_cast<float4*>(m);
+    float4* v4 = reinterpret_cast<float4*>(v);
+    float4 pv = p4[i4], mv = m4[i4], vv = v4[i4];
+    const uchar4 dk = reinterpret_cast<const uchar4*>(decay)[i4];
+    adamw_elem(pv.x, mv.x, vv.x, gv.x, dk.x, coef, hp); adamw_elem(pv.y, mv.y, vv.y, gv.y, dk.y, coef, hp);
+    adamw_elem(pv.z, mv.z, vv.z, gv.z, dk.z, coef, hp); adamw_elem(pv.w, mv.w, vv.w, gv.w, dk.w, coef, hp);
+    p4[i4] = pv; m4[i4] = mv; v4[i4] = vv;
+}
+// float4 elements [first, n4) with stride `stride`
+__device__ __forceinline__ void adamw_span(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                           const uint8_t* __restrict__ decay, int64_t first, int64_t stride, int64_t n4, float coef, const AdamHp& hp) {
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    for (int64_t i = first; i < n4; i += stride) adamw_vec4(p, m, v, decay, i, g4[i], coef, hp);
+}
 __global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                float* __restrict__ v, const uint8_t* __restrict__ decay, const float* __restrict__ partials,
-                                               int np, int64_t n4, float lr, float b1, float b2, float eps, float wd, float clip, float bc1,
-                                               float bc2_sqrt, float* __restrict__ norm_out, int hf_order) {
+                                               int np, int64_t n4, float clip, AdamHp hp, float* __restrict__ norm_out) {
     __shared__ float red[4];
     float s = 0.f;
     for (int k = threadIdx.x; k < np; k += 256) s += partials[k];
@@ -1742,31 +1792,148 @@ __global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, const floa
     const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
     if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out) *norm_out = norm;
     const float coef = clip > 0.f ? fminf(1.0f, clip / (norm + 1e-6f)) : 1.0f;       // clip_grad_norm_
-    const float step_size = lr / bc1;
-    float4* p4 = reinterpret_cast<float4*>(p);
-    const float4* g4 = reinterpret_cast<const float4*>(g);
-    float4* m4 = reinterpret_cast<float4*>(m);
-    float4* v4 = reinterpret_cast<float4*>(v);
-    const uchar4* d4 = reinterpret_cast<const uchar4*>(decay);
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        float4 pv = p4[i], mv = m4[i], vv = v4[i];
-        const float4 gv = g4[i];
-        const uchar4 dk = d4[i];
-        auto upd = [&](float& pe, float& me, float& ve, float ge, unsigned char dke) {
-            ge *= coef;
-            if (!hf_order) pe *= 1.0f - lr * (dke ? wd : 0.f);
-            me = b1 * me + (1.0f - b1) * ge;
-            ve = b2 * ve + (1.0f - b2) * ge * ge;
-            if (!hf_order) pe -= step_size * me / (sqrtf(ve) / bc2_sqrt + eps);
-            else {                                   // transformers.AdamW: eps outside the bias correction, decay after the update
-                pe -= step_size * bc2_sqrt * me / (sqrtf(ve) + eps);
-                pe -= lr * (dke ? wd : 0.f) * pe;
+    adamw_span(p, g, m, v, decay, (int64_t)blockIdx.x * 256 + threadIdx.x, (int64_t)gridDim.x * 256, n4, coef, hp);
+}
+
+// =========================================================================================================
+// The step's tail as ONE launch (single process, vsl_io.fused_step): the final reduction, the clip's global norm and the AdamW update.
+//   phase 1  the workgroup reduces its (at most TAIL_UNITS) units -- unit u = blockIdx.x + j gridDim.x, the code of k_reduce -- keeps their
+//            results in LDS and adds their sums of squares;
+//   hand-off thread 0 publishes that sum as an 8-byte {launch tag, value} granule (ONE agent-scope write-through store: the mechanism of the
+//            fused rnn head, kernels_lstm.hip); wave 0 of every workgroup polls all gridDim.x granules until they carry this launch's tag
+//            (~2.5 us across XCDs) while waves 1 - 3 add the partials of the EARLY reduction (an earlier launch);
+//   phase 2  clip factor from the norm (fixed summation order: deterministic for a given grid), then AdamW on the elements THIS workgroup
+//            reduced (from LDS) and on its share of the early reduction's units (their gradients are in `grads` since an earlier launch).
+// Nothing but the granules crosses workgroups inside the launch, so there is no L2 write-back / invalidate in it (a first version that
+// updated the bucket grid-stride behind release / acquire fences took 38 - 78 us for 256 - 1024 workgroups: profiles/r06_notes.md).
+// All gridDim.x workgroups must be resident at once (they wait for each other): the launcher keeps the grid <= 4 per CU (16 of a CU's 32
+// wave slots, 8 KB of LDS each) and nothing else is in flight on the caller's streams at this point of the step.
+// =========================================================================================================
+constexpr int TAIL_UNITS = 4;
+struct FusedTail {
+    float *p, *m, *v;
+    const uint8_t* decay;
+    const float* sq_early;      // the early reduction's per-unit sums of squares
+    const int* blk2seg_early;   // ... and its unit table
+    int n_early;
+    unsigned long long* gran;   // [gridDim.x] {tag, value}
+    unsigned tag;
+    int nunits;
+    float clip;
+    AdamHp hp;
+    float* norm_out;
+};
+// AdamW on the 256 elements of one reduction unit: lane l4 of the calling wave owns the unit's float4 l4 (ragged units: element l4 of each 64-element pass)
+__device__ __forceinline__ void adamw_unit(const FusedTail& f, const ReduceSeg* __restrict__ segs, const int* __restrict__ blk2seg, int unit, int l4,
+                                           const float4 g, float coef) {
+    const int si = blk2seg[2 * unit], off = blk2seg[2 * unit + 1];
+    const ReduceSeg* __restrict__ sgp = segs + si;
+    const int n = sgp->n, rl = sgp->rl, ds = sgp->ds, dst = sgp->dst;
+    if (sgp->vec) {
+        const int i = off + l4 * 4;
+        if (i < n) adamw_vec4(f.p, f.m, f.v, f.decay, (int64_t)((dst + (i / rl) * ds + (i % rl)) >> 2), g, coef, f.hp);
+    } else {
+        const float gs[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = off + 64 * k + l4;
+            if (e < n) {
+                const int d = dst + (e / rl) * ds + (e % rl);
+                float pe = f.p[d], me = f.m[d], ve = f.v[d];
+                adamw_elem(pe, me, ve, gs[k], f.decay[d], coef, f.hp);
+                f.p[d] = pe; f.m[d] = me; f.v[d] = ve;
             }
-        };
-        upd(pv.x, mv.x, vv.x, gv.x, dk.x); upd(pv.y, mv.y, vv.y, gv.y, dk.y);
-        upd(pv.z, mv.z, vv.z, gv.z, dk.z); upd(pv.w, mv.w, vv.w, gv.w, dk.w);
-        p4[i] = pv; m4[i] = mv; v4[i] = vv;
+        }
     }
+}
+// the gradients of one EARLY unit back from the bucket, in the layout adamw_unit takes
+__device__ __forceinline__ float4 unit_grads(const float* __restrict__ grads, const ReduceSeg* __restrict__ segs, const int* __restrict__ blk2seg,
+                                             int unit, int l4) {
+    const int si = blk2seg[2 * unit], off = blk2seg[2 * unit + 1];
+    const ReduceSeg* __restrict__ sgp = segs + si;
+    const int n = sgp->n, rl = sgp->rl, ds = sgp->ds, dst = sgp->dst;
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (sgp->vec) {
+        const int i = off + l4 * 4;
+        if (i < n) g = *reinterpret_cast<const float4*>(grads + dst + (i / rl) * ds + (i % rl));
+    } else {
+        float gs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = off + 64 * k + l4;
+            if (e < n) gs[k] = grads[dst + (e / rl) * ds + (e % rl)];
+        }
+        g = make_float4(gs[0], gs[1], gs[2], gs[3]);
+    }
+    return g;
+}
+__global__ __launch_bounds__(256) void k_reduce_adamw(const float* __restrict__ ws, float* __restrict__ grads,
+                                                      const ReduceSeg* __restrict__ segs, const int* __restrict__ blk2seg,
+                                                      float* __restrict__ sq, FusedTail f) {
+    __shared__ float4 part[4][64];
+    __shared__ float4 kept[TAIL_UNITS][64];
+    __shared__ float red[4];
+    const int l4 = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float mine = 0.f;                                    // (thread 0) sum of squares of this workgroup's units, in unit order
+#pragma unroll
+    for (int j = 0; j < TAIL_UNITS; ++j) {
+        const int u = blockIdx.x + j * gridDim.x;        // (block-uniform)
+        if (u < f.nunits) {
+            float4 k4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            mine += reduce_unit(ws, grads, segs, blk2seg, sq, u, part, &k4);
+            if (wv == 0) kept[j][l4] = k4;
+            __syncthreads();                             // `part` is free again
+        }
+    }
+    using gu64 = unsigned long long;
+    if (threadIdx.x == 0)
+        __hip_atomic_store(f.gran + blockIdx.x, ((gu64)f.tag << 32) | __float_as_uint(mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float s = 0.f;
+    if (threadIdx.x >= 64) {                             // waves 1 - 3: the early reduction's partials (an earlier launch: plain loads)
+        for (int k = threadIdx.x - 64; k < f.n_early; k += 192) s += f.sq_early[k];
+    } else {                                             // wave 0 polls (the other waves wait at the barrier below: no polling traffic of theirs)
+        for (int k = threadIdx.x; k < (int)gridDim.x; k += 64) {
+            gu64 g = __hip_atomic_load(f.gran + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while ((unsigned)(g >> 32) != f.tag) {
+                __builtin_amdgcn_s_sleep(4);
+                g = __hip_atomic_load(f.gran + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            s += __uint_as_float((unsigned)g);
+        }
+    }
+    s = wave_sum(s);
+    if (l4 == 0) red[wv] = s;
+    __syncthreads();
+    const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+    if (blockIdx.x == 0 && threadIdx.x == 0 && f.norm_out) *f.norm_out = norm;
+    const float coef = f.clip > 0.f ? fminf(1.0f, f.clip / (norm + 1e-6f)) : 1.0f;       // clip_grad_norm_
+    // phase 2: wave w takes the workgroup's unit w ...
+    {
+        const int u = blockIdx.x + wv * gridDim.x;
+        if (wv < TAIL_UNITS && u < f.nunits) adamw_unit(f, segs, blk2seg, u, l4, kept[wv][l4], coef);
+    }
+    // ... and one early unit per wave and round (the early table sits in front of the late one: blk2seg_early)
+    for (int e = 4 * blockIdx.x + wv; e < f.n_early; e += 4 * gridDim.x)
+        adamw_unit(f, segs, f.blk2seg_early, e, l4, unit_grads(grads, segs, f.blk2seg_early, e, l4), coef);
+}
+int reduce_adamw_resident(int cus) {       // workgroups of k_reduce_adamw that may wait for each other: half of what the occupancy calculator admits, at most 4 per CU
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_reduce_adamw, 256, 0) != hipSuccess) return 0;
+    return std::max(0, std::min(4, per_cu / 2)) * cus;
+}
+int reduce_adamw_grid(int nunits, int cap) {      // the grid launch_reduce_adamw takes for `nunits` late units with at most `cap` resident workgroups, 0 = does not fit
+    if (nunits <= 0 || cap <= 0 || (int64_t)nunits > (int64_t)TAIL_UNITS * cap) return 0;
+    return std::min(nunits, cap);
+}
+void launch_reduce_adamw(const float* partial, float* grads, const ReduceSeg* segs_dev, const int* blk2seg_dev, int nunits, float* sq,
+                         const float* sq_early, const int* blk2seg_early, int n_early, int grid, unsigned long long* gran, unsigned tag,
+                         float* params, float* m, float* v, const uint8_t* decay_mask, float lr, float b1, float b2, float eps, float wd,
+                         float clip, float bc1, float bc2_sqrt, float* norm_out, int hf_order, hipStream_t s) {
+    FusedTail f;
+    f.p = params; f.m = m; f.v = v; f.decay = decay_mask; f.sq_early = sq_early; f.blk2seg_early = blk2seg_early; f.n_early = n_early;
+    f.gran = gran; f.tag = tag; f.nunits = nunits; f.clip = clip; f.hp = AdamHp{lr, b1, b2, eps, wd, bc1, bc2_sqrt, hf_order};
+    f.norm_out = norm_out;
+    VSL_LAUNCH(k_reduce_adamw, dim3(grid), dim3(256), 0, s, partial, grads, segs_dev, blk2seg_dev, sq, f);
 }
 void launch_adamw(float* params, const float* grads, float* m, float* v, const uint8_t* decay_mask, float* partials, int64_t n,
                   float lr, float b1, float b2, float eps, float wd, float clip, float bc1, float bc2_sqrt, float* norm_out,
@@ -1775,7 +1942,7 @@ void launch_adamw(float* params, const float* grads, float* m, float* v, const u
     if (!sq_from_backward) VSL_LAUNCH(k_sqsum, dim3(OPT_BLOCKS), dim3(256), 0, s, grads, n4, partials);
     const int nb = (int)std::min<int64_t>(1024, (n4 + 255) / 256);
     VSL_LAUNCH(k_adamw, dim3(nb), dim3(256), 0, s, params, grads, m, v, decay_mask, sq_from_backward ? sq_from_backward : partials,
-                       sq_from_backward ? nsq : OPT_BLOCKS, n4, lr, b1, b2, eps, wd, clip, bc1, bc2_sqrt, norm_out, hf_order);
+                       sq_from_backward ? nsq : OPT_BLOCKS, n4, clip, AdamHp{lr, b1, b2, eps, wd, bc1, bc2_sqrt, hf_order}, norm_out);
 }
 
 }  // namespace vsl

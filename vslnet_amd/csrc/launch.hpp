@@ -376,6 +376,14 @@ void launch_word_table_bwd(const float* dE, const int64_t* word_ids, float* gtab
                            int word_size, int word_dim, Drop dw, hipStream_t s);
 void launch_reduce(const float* partial, float* grads, const ReduceSeg* segs_dev, const int* blk2seg_dev, int nblocks,
                    float* sq /* [nblocks]: sum of squares of each block's results */, hipStream_t s);
+// the final reduction + clip + AdamW as ONE launch (vsl_io.fused_step): `grid` = reduce_adamw_grid(nunits, cap) workgroups that wait for each other
+// (cap = reduce_adamw_resident(CUs): half of what the device holds at once, at most 4 per CU); 0 = the units do not fit, take the two launches
+int reduce_adamw_resident(int cus);
+int reduce_adamw_grid(int nunits, int cap);
+void launch_reduce_adamw(const float* partial, float* grads, const ReduceSeg* segs_dev, const int* blk2seg_dev, int nunits, float* sq,
+                         const float* sq_early, const int* blk2seg_early, int n_early, int grid, unsigned long long* gran /*[grid]*/, unsigned tag,
+                         float* params, float* m, float* v, const uint8_t* decay_mask, float lr, float b1, float b2, float eps, float wd,
+                         float clip, float bc1, float bc2_sqrt, float* norm_out, int hf_order, hipStream_t s);
 // fused optimizer (vsl_adamw_step): sum of squares partials, then clip + AdamW
 constexpr int OPT_BLOCKS = 256;
 void launch_adamw(float* params, const float* grads, float* m, float* v, const uint8_t* decay_mask, float* partials /*[OPT_BLOCKS + 1]*/,

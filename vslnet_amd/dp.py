@@ -123,6 +123,19 @@ def backward_and_exchange(engine, xchg, grads, seeds):
     return multi
 
 
+def backward_exchange_step(engine, xchg, grads, seeds, opt):
+    """One training step from the loss seeds on: backward, gradient exchange, clip + AdamW -- what `main.train` and `bench.py` run.
+    One process with rows in the batch: the update rides in the backward's last launch (`Engine.backward(fused_step=...)`: final reduction,
+    global norm and AdamW as one kernel).  More than one rank: `backward_and_exchange`, then the two-kernel step on the SUMMED bucket."""
+    import torch.distributed as dist
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(xchg.group if xchg is not None else None) > 1
+    if not multi and xchg is None and seeds is not None and opt.engine is not None and getattr(engine, 'fused_tail', False):
+        engine.backward(seeds[0], seeds[1], seeds[2], grads, fused_step=opt.fused_step())
+        return
+    touched = backward_and_exchange(engine, xchg, grads, seeds)
+    opt.step(grads, from_backward=not touched)                # the backward's own norm only for an untouched bucket
+
+
 class FlatAdamW:
     """clip_grad_norm_(1.0) + AdamW + linear decay (main_t7.py:111-113, VSLNet_t7.py:8-17) on the FLAT buckets.
     Weight decay 0.01 except for names containing bias / layer_norm / LayerNorm.  With an `engine` (GPU) the step is the
@@ -153,6 +166,16 @@ class FlatAdamW:
         if n < self.warm:
             return self.lr0 * n / max(1.0, self.warm)
         return self.lr0 * max(0.0, (self.N - n) / max(1.0, self.N - self.warm))
+
+    def fused_step(self, grad_norm_out=None):
+        """This optimizer step as the `fused_step` argument of `Engine.backward` (one process, no exchange): the update is applied by the
+        backward's last launch, so there is no `step()` call for it.  Advances the step count like `step()` does."""
+        if self.engine is None:
+            raise RuntimeError('fused_step needs the GPU engine')
+        lr = self.lr()
+        self.t += 1
+        return dict(flat=self.flat, exp_avg=self.m, exp_avg_sq=self.v, lr=lr, step=self.t, betas=(self.b1, self.b2), eps=self.eps,
+                    weight_decay=self.weight_decay, clip_norm=self.clip, hf_order=self.hf_order, grad_norm_out=grad_norm_out)
 
     @torch.no_grad()
     def step(self, grads, from_backward=False):

@@ -32,7 +32,7 @@ class vsl_io(C.Structure):
                 ('d_h_score', C.c_void_p), ('d_start_logits', C.c_void_p), ('d_end_logits', C.c_void_p),
                 ('grads', C.c_void_p), ('sample_offset', C.c_int32), ('video_features_bf16', C.c_void_p),
                 ('early_grads_event', C.c_void_p),
-                ('_reserved', C.c_int64)]          # zero tail: an older build of the library (A/B runs, VSLNET_HIP_LIB) reads a field here
+                ('fused_step', C.c_void_p)]        # (NULL unless Engine.backward(fused_step=...): an older build loaded for an A/B run reads zeros here)
 
 
 class vsl_loss_io(C.Structure):
@@ -47,6 +47,10 @@ class vsl_adamw(C.Structure):
                 ('clip_norm', C.c_float), ('step', C.c_int32), ('hf_order', C.c_int32), ('norm_from_backward', C.c_int32)]
 
 
+class vsl_fused_step(C.Structure):
+    _fields_ = [('params', C.c_void_p), ('exp_avg', C.c_void_p), ('exp_avg_sq', C.c_void_p), ('hp', vsl_adamw), ('grad_norm_out', C.c_void_p)]
+
+
 class VslError(RuntimeError):
     pass
 
@@ -55,7 +59,7 @@ ABI_SYMBOLS = ['vsl_last_error', 'vsl_create', 'vsl_destroy', 'vsl_param_count',
                'vsl_workspace_floats', 'vsl_forward', 'vsl_loss', 'vsl_backward', 'vsl_extract_index',
                'vsl_adamw_step', 'vsl_workspace_offset', 'vsl_profile_select', 'vsl_profile_read', 'vsl_profile_launch', 'vsl_abi_version',
                'vsl_early_grad_offset', 'vsl_debug_rnn_launches']
-ABI_VERSION = 7                                     # include/vslnet_hip.h: VSL_ABI_VERSION
+ABI_VERSION = 8                                     # include/vslnet_hip.h: VSL_ABI_VERSION
 
 
 def load_library():
@@ -167,6 +171,8 @@ class Engine:
         check_hw_queues()
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
         self.lib = load_library()
+        # vsl_io.fused_step (ABI 8): an older build loaded through VSLNET_HIP_LIB for an A/B run takes the two calls instead
+        self.fused_tail = hasattr(self.lib, 'vsl_abi_version') and self.lib.vsl_abi_version() >= 8
         pred = {'rnn': 0, 'transformer': 1}.get(configs.predictor)
         if pred is None:
             raise ValueError('unknown predictor %r' % (configs.predictor,))
@@ -321,9 +327,12 @@ class Engine:
         """First float offset of the block of `grads` that is final when `backward(..., early_event=)` fires its event."""
         return int(self.lib.vsl_early_grad_offset(self.h))
 
-    def backward(self, d_h, d_sl, d_el, grads, early_event=None):
+    def backward(self, d_h, d_sl, d_el, grads, early_event=None, fused_step=None):
         """Backward of the LAST forward; writes the flat gradient bucket `grads` (same layout as the params).
-        `early_event` (torch.cuda.Event, data parallel): recorded by the library as soon as grads[early_grad_offset():] is final."""
+        `early_event` (torch.cuda.Event, data parallel): recorded by the library as soon as grads[early_grad_offset():] is final.
+        `fused_step` (single process; `FlatAdamW.fused_step()`): dict(flat, exp_avg, exp_avg_sq, lr, step, betas, eps, weight_decay, clip_norm,
+        hf_order[, grad_norm_out]) -- this optimizer step is applied inside the backward's last launch (final reduction + clip + AdamW in one
+        kernel); equivalent to backward() followed by adamw_step(..., norm_from_backward=True)."""
         io = self._last
         B, T = io.B, io.T
         if d_h is not None:
@@ -336,8 +345,28 @@ class Engine:
         if early_event is not None:
             early_event.record(torch.cuda.current_stream(self.device))     # creates the handle lazily; harmless: recorded again by the library
             io.early_grads_event = C.c_void_p(early_event.cuda_event)
+        io.fused_step = None
+        fs = None
+        if fused_step is not None:
+            if early_event is not None:
+                raise ValueError('fused_step is the single-process step; early_event belongs to the data-parallel exchange')
+            n = self.param_floats
+            for nm in ('flat', 'exp_avg', 'exp_avg_sq'):
+                _chk(fused_step[nm], torch.float32, (n,), nm)
+            b = fused_step.get('betas', (0.9, 0.999))
+            fs = vsl_fused_step()
+            fs.params, fs.exp_avg, fs.exp_avg_sq = _ptr(fused_step['flat']), _ptr(fused_step['exp_avg']), _ptr(fused_step['exp_avg_sq'])
+            fs.hp = vsl_adamw(float(fused_step['lr']), float(b[0]), float(b[1]), float(fused_step.get('eps', 1e-6)),
+                              float(fused_step.get('weight_decay', 0.01)), float(fused_step.get('clip_norm', 1.0) or 0.0), int(fused_step['step']),
+                              int(bool(fused_step.get('hf_order', False))), 1)
+            gn = fused_step.get('grad_norm_out')
+            fs.grad_norm_out = _ptr(gn) if gn is not None else None
+            io.fused_step = C.cast(C.pointer(fs), C.c_void_p)
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        self._call(self.lib.vsl_backward(self.h, C.byref(io), stream))
+        try:
+            self._call(self.lib.vsl_backward(self.h, C.byref(io), stream))
+        finally:
+            io.fused_step = None                          # (`fs` lives until here; the library reads it during the call only)
         return grads
 
     def profile_select(self, kernel):
