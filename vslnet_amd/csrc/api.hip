@@ -103,6 +103,7 @@ struct vsl_handle_s {
     uint8_t* decay_dev = nullptr;        // per-element weight-decay flag of the flat bucket (vsl_adamw_step)
     float* opt_scratch = nullptr;        // OPT_BLOCKS partial sums of grads^2
     unsigned long long* tail_gran = nullptr;   // vsl_io.fused_step: one {tag, sum of squares} granule per workgroup of the fused tail launch
+    int cus = 0;                         // CUs of the device (vsl_create)
     int tail_cap = 0;                    // ... their number = the largest grid that launch may take (4 workgroups per CU)
     unsigned tail_tag = 0;               // ... the tag of the last such launch
     const float* sq_src = nullptr;       // the last vsl_backward's per-block sums of squares (Plan::sq_dev), their count, the bucket they describe
@@ -440,6 +441,7 @@ struct Ctx {
     int64_t part_cur = 0;
     std::vector<SlabRec>* recs = nullptr;
     std::vector<WgradBatch> pend;       // weight-gradient batches waiting for ONE ordering point (wgrad_async / wgrad_flush)
+    int pw_rows = 0;                    // rows per chunk of the NEXT enc_bwd's pointwise weight-gradient jobs (0 = WG_ROWS): the step's last batch, run_backward
     bool defer_w = false;
     const float* P(int off) const { return io->params + off; }
     const float* PK(int off) const { return ws + p->pack + off; }
@@ -955,8 +957,10 @@ void enc_bwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float*
             WgradJob j = wjob();
             if (!c.dry) { j.G[0] = c.W(t.gz[i]); j.A[0] = c.W(w.u[i]); }
             j.nG = 1; j.nA = 1; j.K = D; j.R = R;
-            j.out = c.slab(P.pw[i], D * D, nchunk);
-            j.out_bias[0] = c.slab(P.pwb[i], D, nchunk);
+            j.rows = c.pw_rows;
+            const int nch_pw = wgrad_chunks(R, wgrad_rows(j));
+            j.out = c.slab(P.pw[i], D * D, nch_pw);
+            j.out_bias[0] = c.slab(P.pwb[i], D, nch_pw);
             wb.j[wb.n++] = j;
         }
         if (defer_pw) *defer_pw = wb;
@@ -1255,11 +1259,20 @@ void run_backward(Ctx& c) {
     c.s = qlong ? sq : main_s;
     WgradBatch pw_video;
     memset(&pw_video, 0, sizeof pw_video);
+    // The step's LAST weight-gradient batch (VisualProjection + the video pass' four pointwise gradients, sample-local query path) starts into an
+    // empty chip: chunk rows that make it whole rounds of one-workgroup-per-CU chunks (Dv = 1024: 12 blocks x 32 chunks = 1.5 rounds -> 400 rows,
+    // 252 workgroups; profiles/r06_notes.md section 8).  VSL_TAIL_ROWS=0: 256 rows as everywhere else.
+    static const bool tail_rows_on = !(getenv("VSL_TAIL_ROWS") && getenv("VSL_TAIL_ROWS")[0] == '0');
+    const int tail_rows = query_fused(c, false) && tail_rows_on ? wgrad_rows_whole_rounds(R, (cf.video_feature_dim + 127) / 128 + 4, c.h->cus) : WG_ROWS;
+    c.pw_rows = tail_rows == WG_ROWS ? 0 : tail_rows;
     enc_bwd(c, P.fe, K.fe, p.ve, c.dry ? nullptr : c.W(p.dC), nullptr, p.dvf, c.dry ? nullptr : io->v_mask, B, 0, sw, &pw_video);
+    c.pw_rows = 0;
     {   // tail of the video stream: VisualProjection + the video pass' pointwise weight gradients, back to back, no waits
         WgradBatch wb;
         memset(&wb, 0, sizeof wb);
         WgradJob j = wjob();
+        j.rows = tail_rows == WG_ROWS ? 0 : tail_rows;
+        const int nchunk = wgrad_chunks(R, tail_rows);      // (shadows the 256-row count: this job's slabs)
         if (!c.dry) {
             j.G[0] = c.W(p.dvf); j.Afull = io->video_features;
             if (io->video_features_bf16) { j.Afull = reinterpret_cast<const float*>(io->video_features_bf16); j.a_bf16 = 1; }
@@ -1608,6 +1621,10 @@ int vsl_create(const vsl_config* cfg, vsl_handle* out) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("no HIP device available: libvslnet_hip needs an MI355X (gfx950)");
     vsl_handle_s* h = new vsl_handle_s();
     h->cfg = *cfg;
+    {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&h->cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) h->cus = 0;
+    }
     build_params(h);
     build_packs(h);
     {
@@ -1787,10 +1804,7 @@ static int ensure_opt_state(vsl_handle_s* h) {
                         p.name.find("LayerNorm") != std::string::npos;
         if (!nd) std::fill(mask.begin() + p.off, mask.begin() + p.off + p.numel, (uint8_t)1);
     }
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-        return fail("optimizer state: cannot read the device's CU count");
-    h->tail_cap = reduce_adamw_resident(cus);
+    h->tail_cap = reduce_adamw_resident(h->cus);
     if (hipMalloc(&h->decay_dev, mask.size()) != hipSuccess || hipMalloc(&h->opt_scratch, (OPT_BLOCKS + 4) * sizeof(float)) != hipSuccess ||
         hipMalloc(&h->tail_gran, (size_t)h->tail_cap * sizeof(unsigned long long)) != hipSuccess)
         return fail("optimizer state: hipMalloc failed");

@@ -50,7 +50,8 @@ __global__ __launch_bounds__(WG2_T, 1) void k_wgrad3(WgradBatch wb) {
     while (ji + 1 < wb.n && (int)blockIdx.x >= wb.start[ji + 1]) ++ji;
     const WgradJob& j = wb.j[ji];
     const int K = j.K, R = j.R;
-    const int nkt = (K + 127) >> 7, nch = (R + WG_ROWS - 1) / WG_ROWS;
+    const int crows = wgrad_rows(j);
+    const int nkt = (K + 127) >> 7, nch = wgrad_chunks(R, crows);
     const int local = blockIdx.x - wb.start[ji];
     const int kt = local % nkt, ch = (local / nkt) % nch, gb = local / (nkt * nch);
     const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, i = lane & 31, h = lane >> 5;
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(WG2_T, 1) void k_wgrad3(WgradBatch wb) {
     const int kloc = 64 * kh + 2 * i;                       // column inside the 128-wide k tile
     const int kglob = kt * 128 + kloc;                      // column of dW
     const bool kin = kglob < K;                             // K is even: both columns of the pair are in or out together
-    const int rbeg = ch * WG_ROWS, rend = min(R, rbeg + WG_ROWS), nrows = rend - rbeg;
+    const int rbeg = ch * crows, rend = min(R, rbeg + crows), nrows = rend - rbeg;
     const uint32_t dseed = j.dp.seed, dthr = j.dp.thresh, dkey = j.dp.key;
     const float dscale = j.dp.scale;
     constexpr int ASZ = ABF16 ? 2 : 4;                      // bytes per A element
@@ -223,14 +224,15 @@ __global__ __launch_bounds__(WG4_T, 1) void k_wgrad4(WgradBatch wb) {
     while (ji + 1 < wb.n && (int)blockIdx.x >= wb.start[ji + 1]) ++ji;
     const WgradJob& j = wb.j[ji];
     const int K = j.K, R = j.R;
-    const int nkt = (K + 127) >> 7, nch = (R + WG_ROWS - 1) / WG_ROWS;
+    const int crows = wgrad_rows(j);
+    const int nkt = (K + 127) >> 7, nch = wgrad_chunks(R, crows);
     const int local = blockIdx.x - wb.start[ji];
     const int kt = local % nkt, ch = (local / nkt) % nch, gb = local / (nkt * nch);
     const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int ldg = j.ldg ? j.ldg : D;
     const bool blocks = j.nA > 0;
     const int lda = blocks ? D : K;
-    const int rbeg = ch * WG_ROWS, rend = min(R, rbeg + WG_ROWS), nrows = rend - rbeg;
+    const int rbeg = ch * crows, rend = min(R, rbeg + crows), nrows = rend - rbeg;
     const uint32_t dseed = j.dp.seed, dthr = j.dp.thresh, dkey = j.dp.key;
     const float dscale = j.dp.scale;
     WG4STAMP(1);
@@ -360,7 +362,7 @@ void launch_wgrad(const WgradBatch& wb0, hipStream_t s) {
     int total = 0;
     for (int i = 0; i < wb.n; ++i) {
         wb.start[i] = total;
-        total += wb.j[i].nG * ((wb.j[i].K + 127) / 128) * ((wb.j[i].R + WG_ROWS - 1) / WG_ROWS);
+        total += wb.j[i].nG * ((wb.j[i].K + 127) / 128) * wgrad_chunks(wb.j[i].R, wgrad_rows(wb.j[i]));
     }
     wb.start[wb.n] = total;
     if (total == 0) return;
@@ -383,7 +385,7 @@ void launch_wgrad(const WgradBatch& wb0, hipStream_t s) {
                         WgradJob j = wb.j[i];
                         if (pass == 0) j.dp = Drop{0u, 0u, 1.0f, 0u};
                         m.start[m.n] = total;
-                        total += j.nG * ((j.K + 127) / 128) * ((j.R + WG_ROWS - 1) / WG_ROWS);
+                        total += j.nG * ((j.K + 127) / 128) * wgrad_chunks(j.R, wgrad_rows(j));
                         m.j[m.n++] = j;
                     }
             m.start[m.n] = total;

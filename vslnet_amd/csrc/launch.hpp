@@ -69,11 +69,25 @@ struct WgradJob {
     Drop dp;
     float* out;           // partial slabs [nchunk][N][K]
     float* out_bias[3];   // partial slabs [nchunk][128] per G block (nullable)
+    int rows;             // rows per chunk = workgroup of THIS job (0 = WG_ROWS; a multiple of 16): see wgrad_rows_one_round
 };
 #ifndef VSL_WG_ROWS
 #define VSL_WG_ROWS 256
 #endif
 constexpr int WG_ROWS = VSL_WG_ROWS;     // rows per weight-gradient chunk = workgroup (one partial slab each)
+__host__ __device__ inline int wgrad_rows(const WgradJob& j) { return j.rows > 0 ? j.rows : WG_ROWS; }
+__host__ __device__ inline int wgrad_chunks(int R, int rows) { return (R + rows - 1) / rows; }
+// A batch of `cols` 128 x 128 output blocks over R rows that is launched into an EMPTY chip (the step's last weight-gradient batch) takes
+// ceil(cols * chunks / CUs) rounds of one-workgroup-per-CU chunks: 384 workgroups of 256 rows are two rounds, the second half empty.  Longer chunks
+// that make it whole rounds cost rows / 256 each: -> the smallest multiple of 16 rows >= WG_ROWS with cols * chunks <= CUs * floor(rounds at WG_ROWS).
+inline int wgrad_rows_whole_rounds(int R, int cols, int cus) {
+    const int wgs = cols * wgrad_chunks(R, WG_ROWS);
+    if (cus <= 0 || cols <= 0 || wgs <= cus || wgs % cus == 0) return WG_ROWS;
+    const int target = cus * (wgs / cus);
+    for (int rows = WG_ROWS + 16; rows <= 4 * WG_ROWS; rows += 16)
+        if (cols * wgrad_chunks(R, rows) <= target) return rows;
+    return WG_ROWS;
+}
 constexpr int MAX_WJOBS = 12;
 struct WgradBatch { WgradJob j[MAX_WJOBS]; int n; int start[MAX_WJOBS + 1]; };   // start: first workgroup of each job (launch_wgrad fills it)
 
