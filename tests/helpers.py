@@ -153,7 +153,15 @@ def hip_dropout(seed):
         site = HIP_DROP_SITES[call_no]
         n = int(np.prod(shape))
         idx = np.arange(n, dtype=np.uint64)
-        h = _drop_hash(idx, hip_site_seed(seed, site), hip_site_key(seed, site))
+        if site < 64 and site % 16 == 5 and shape[-1] > 256:
+            # the attention probabilities of L > 256 (k_attn_fwd / k_attn_bwd_long, common.hpp drop_hash_odd): keys 2 j, 2 j + 1 of a (b, h, q) row
+            # share drop_hash(row * ceil(L / 2) + j); the odd key compares the hash rotated by 16 bits
+            L = np.uint64(shape[-1])
+            row, key = idx // L, idx % L
+            h = _drop_hash((row * ((L + np.uint64(1)) // np.uint64(2)) + key // np.uint64(2)) & _M32, hip_site_seed(seed, site), hip_site_key(seed, site))
+            h = np.where(key % np.uint64(2) == 1, ((h >> np.uint64(16)) | (h << np.uint64(16))) & _M32, h)
+        else:
+            h = _drop_hash(idx, hip_site_seed(seed, site), hip_site_key(seed, site))
         thresh = np.uint64(min(4294967295.0, float(np.float32(p)) * 4294967296.0))
         scale = np.float32(1.0) / (np.float32(1.0) - np.float32(p))
         return torch.from_numpy(np.where(h >= thresh, scale, np.float32(0.0)).astype(np.float32).reshape(shape))

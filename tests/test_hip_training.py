@@ -109,6 +109,7 @@ def test_dropout_forward_backward_consistency_by_finite_differences(dv, B, T, Lq
     (64, 3, 40, 7, 20, 'transformer', 100),     # main_t7.py:24's ActivityNet char_dim: two input-channel blocks x two position tiles forward, 7 channel tiles backward
     (64, 2, 30, 9, 40, 'transformer', 128),     # the engine's bounds: longest token, widest character embedding
     (64, 5, 24, 6, 8, 'transformer', 72),       # a width that is no multiple of 16
+    (64, 2, 301, 7, 6, 'transformer', 50),      # T > 256: k_attn_fwd / k_attn_bwd_long, two dropout decisions per hash over an odd row length
     (64, 6, 24, 9, 6, 'transformer', -50)])     # (negative: WordEmbedding(word_vectors=None), the trainable table; 54 words over 100 ids: repeats)
 def test_training_mode_matches_oracle_on_the_same_dropout_masks(dv, B, T, Lq, Lc, predictor, char_dim):
     """drop_rate 0.2 (the benchmark's mode), all 41 dropout sites: the oracle is handed the HIP path's masks -- recomputed on

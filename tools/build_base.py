@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 rev = sys.argv[1] if len(sys.argv) > 1 else 'HEAD'
 tmp = '/tmp/vsl_base_src'
 files = ['vslnet_amd/csrc/api.hip', 'vslnet_amd/csrc/kernels_fwd.hip', 'vslnet_amd/csrc/kernels_bwd.hip', 'vslnet_amd/csrc/kernels_enc.hip',
-         'vslnet_amd/csrc/kernels_wgrad.hip', 'vslnet_amd/csrc/kernels_split.hip', 'vslnet_amd/csrc/kernels_lstm.hip', 'vslnet_amd/csrc/common.hpp', 'vslnet_amd/csrc/launch.hpp', 'vslnet_amd/csrc/tile_bodies.hpp', 'include/vslnet_hip.h']
+         'vslnet_amd/csrc/kernels_wgrad.hip', 'vslnet_amd/csrc/kernels_split.hip', 'vslnet_amd/csrc/kernels_lstm.hip', 'vslnet_amd/csrc/kernels_query.hip', 'vslnet_amd/csrc/common.hpp', 'vslnet_amd/csrc/launch.hpp', 'vslnet_amd/csrc/tile_bodies.hpp', 'include/vslnet_hip.h']
 for f in files:
     os.makedirs(os.path.dirname(os.path.join(tmp, f)), exist_ok=True)
     try:

@@ -519,7 +519,9 @@ struct Ctx {
         if (site == 67) return T * D;                                 // SITE_CQ_C
         if (site == 68) return Lq * D;                                // SITE_CQ_Q
         const uint32_t L = (site >> 4) == 1 ? Lq : T;                 // encoder pass 1 = query
-        return (site & 15) == 5 ? cf.num_heads * L * L : L * D;       // 5 = attention probabilities (B, H, L, L)
+        if ((site & 15) != 5) return L * D;
+        // 5 = attention probabilities (B, H, L, L); the kernels of L > 256 key their masks by key PAIRS (common.hpp drop_hash_odd): ceil(L / 2) hashes per row
+        return L > 256 ? cf.num_heads * L * ((L + 1) / 2) : cf.num_heads * L * L;
     }
     Drop drop(int site) const {
         Drop d{0u, 0u, 1.0f, 0u};

@@ -73,6 +73,12 @@ __device__ __forceinline__ float drop_mul(const Drop& d, uint32_t idx) {
     return drop_hash(idx, d.seed, d.key) >= d.thresh ? d.scale : 0.0f;
 }
 
+// TWO decisions from one hash: elements 2 j and 2 j + 1 of a row share drop_hash(row * ceil(n / 2) + j); the odd one compares the hash rotated by
+// 16 bits (its upper half decides for the even element, its lower half for the odd one; p stays exact to 2^-32).  Used by the attention kernels
+// of L > 256 for the probability site -- L^2 decisions per head and sample, the hash was a third of their key loop's vector work
+// (profiles/r05_notes.md section 7) -- and restated in tests/helpers.py (hip_dropout).
+__device__ __forceinline__ uint32_t drop_hash_odd(uint32_t h) { return __builtin_amdgcn_alignbit(h, h, 16); }
+
 // same multiplier WITHOUT the "dropout enabled?" test: for call sites that have already branched on d.thresh (block-uniform)
 __device__ __forceinline__ float drop_keep_scale(const Drop& d, uint32_t idx) {
     return drop_hash(idx, d.seed, d.key) >= d.thresh ? d.scale : 0.0f;

@@ -660,11 +660,29 @@ __global__ __launch_bounds__(1024) void k_attn_bwd_long(const float* __restrict_
                 dp = __builtin_amdgcn_mfma_f32_16x16x4f32(aa.z, vf.z, dp, 0, 0, 0);
                 sc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa.w, kf.w, sc, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_16x16x4f32(aa.w, vf.w, dp, 0, 0, 0);
+                // dropout of the probabilities as the forward drew it (k_attn_fwd): keys 2 j, 2 j + 1 of a query row share one hash.  The lane
+                // and its neighbour (the other key of the pair, same four queries) hash two queries each and exchange the words.
+                float m2v[4] = {1.f, 1.f, 1.f, 1.f};
+                if (d2.thresh != 0u) {
+                    const uint32_t Lh = (uint32_t)((L + 1) >> 1), kp = (uint32_t)((k0 + keyl) >> 1);
+                    const int odd = ki & 1;
+                    uint32_t hm[2], hp[2];
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        hm[jj] = drop_hash((hb + (uint32_t)(qb + ql0 + 4 * g + 2 * odd + jj)) * Lh + kp, d2.seed, d2.key);
+                        hp[jj] = __float_as_uint(lane_xor1(__uint_as_float(hm[jj])));
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const uint32_t hr = (r >> 1) == odd ? hm[r & 1] : hp[r & 1];
+                        m2v[r] = (odd ? drop_hash_odd(hr) : hr) >= d2.thresh ? d2.scale : 0.f;
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int ql = ql0 + 4 * g + r;
                     const float p = __expf(sc[r] * scale + mb - Ls[ql]);
-                    const float m2 = drop_mul(d2, (hb + (uint32_t)(qb + ql)) * (uint32_t)L + (uint32_t)(k0 + keyl));
+                    const float m2 = m2v[r];
                     const float pd = p * m2;
                     const float ds = p * (dp[r] * m2 - Ds[ql]) * scale;
                     dSs[ql * AB_DSP + keyl] = ds;

@@ -444,24 +444,37 @@ void launch_linear_fwd(const float* A, const float* Wpack, const float* bias, fl
 }
 
 // =========================================================================================================
-// a8 (attention core)  S = Q K^T / sqrt(hd) + (1 - mask[key]) * -1e30 ; P = softmax ; O = drop(P) V   (:174-182)
+// a8 (attention core)  S = Q K^T / sqrt(hd) + (1 - mask[key]) * -1e30 ; P = softmax ; O = drop(P) V   (:174-182), sequences of L > 256
 //   head size 16, fp32 MFMA 16x16x4.  Workgroup = (64 queries, head, sample); wave = 16 queries.
 //   K/V head slices live in LDS; scores are computed transposed (S^T = K Q^T) so every lane owns one query column:
 //   online softmax is lane-local (+2 shuffles across the 4 key groups) and P feeds the PV MFMA from registers.
 //   Saves LSE = m + log(l) per (b, h, q) for the backward.
+// Round 6: the key loop was issue-bound (765 cycles per 16-key tile and wave, 256 of them matrix work): it now takes 64 keys per turn -- four
+// independent S tiles, ONE running-maximum update (2 shuffles, 1 rescale) per 64 keys instead of per 16 --, works in the log2 domain (x = S c +
+// bias with c = log2(e) / 4: v_exp_f32 directly, LSE converted back at the end), draws two dropout decisions from every hash (drop_hash_odd) and
+// feeds PV into two alternating accumulators.
 // =========================================================================================================
-constexpr int AF_KB = 256;          // keys staged per block: 42 KB of LDS whatever L is -> 3+ workgroups per CU at L = 1024
+#ifndef VSL_AF_KB
+#define VSL_AF_KB 256
+#endif
+constexpr int AF_KB = VSL_AF_KB;    // keys staged per block: 45 KB of LDS whatever L is -> 3 workgroups per CU at L = 1024
+constexpr int AF_NJ = AF_KB * 4 / 256;
+constexpr float AF_LOG2E = 1.4426950408889634f, AF_LN2 = 0.6931471805599453f;
+// element offset of dims [8 half, 8 half + 8) of key `key` inside a [keys][16] bf16 plane: the two 16-byte halves of a row swap places every 8 keys,
+// so the 16 lanes of a ds_read_b128 phase (16 consecutive keys, one half) cover all 64 banks once without padding
+__device__ __forceinline__ int af_kp(int key, int half) { return key * 16 + ((half ^ ((key >> 3) & 1)) << 3); }
 __global__ __launch_bounds__(256) void k_attn_fwd(const float* __restrict__ Q, const float* __restrict__ K,
                                                   const float* __restrict__ V, const float* __restrict__ mask,
                                                   float* __restrict__ att, float* __restrict__ lse, int L, int H,
                                                   int b_off, Drop d2) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int Lp = (L + 15) & ~15;
+    const int Lp = (L + 63) & ~63;                 // keys in turns of 64 (the pad keys carry the mask bias and zero K / V)
     const int KB = min(Lp, AF_KB);
     constexpr int kst = 20;
-    float* Ks = smem;                 // [KB][20]  K / V head slices of the current key block
-    float* Vs = Ks + KB * kst;        // [KB][20]
-    float* Mb = Vs + KB * kst;        // [KB] additive key bias
+    float* Vs = smem;                 // [KB][20]  V head slice of the current key block
+    float* Mb = Vs + KB * kst;        // [KB] additive key bias, log2 domain
+    uint16_t* Kp = reinterpret_cast<uint16_t*>(Mb + KB);      // [3 terms][KB][16] bf16: the K head slice, split once per block (af_kp)
+    const int KPL = KB * 16;          // elements per plane
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     int bxs, h, b;
     xcd_swizzle(bxs, h, b);                        // all heads of a sample on one XCD: its rows are fetched into one L2
@@ -469,61 +482,122 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const float* __restrict__ Q, c
     const int qi = lane & 15, g = lane >> 4;
     const int q = bxs * 64 + w * 16 + qi;
     const bool qok = q < L;
-    float4 qf = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (qok) qf = *reinterpret_cast<const float4*>(Q + (rowbase + q) * D + h * HD + 4 * g);
-    const float scale = 0.25f;                     // 1 / sqrt(16), applied AFTER QK^T like the reference (:175)
+    // S^T = K Q^T on the bf16 matrix cores at fp32 grade: v_mfma_f32_16x16x32_bf16 contracts over 32 = TWO products of the 16 head dims, so
+    // the six products of the 3-way split are three instructions (they overlap with the vector work of the SIMD's other waves; the fp32-input
+    // MFMA does not: tools/ubench/split_bf16.hip):  [kh | km] x [qh | qh] + [kh | kl] x [qm | qh] + [kh | km] x [ql | qm].
+    // lane (i, g): k group g < 2 = dims 8 g .. of the first term, g >= 2 = dims 8 (g - 2) .. of the second.
+    u32x4_t bq1, bq2, bq3;
+    {
+        float4 qa = make_float4(0.f, 0.f, 0.f, 0.f), qb = qa;
+        if (qok) {
+            const float* qp = Q + (rowbase + q) * D + h * HD + 8 * (g & 1);
+            qa = *reinterpret_cast<const float4*>(qp);
+            qb = *reinterpret_cast<const float4*>(qp + 4);
+        }
+        uint32_t th[4], tm[4], tl[4];
+        split3(qa.x, qa.y, th[0], tm[0], tl[0]); split3(qa.z, qa.w, th[1], tm[1], tl[1]);
+        split3(qb.x, qb.y, th[2], tm[2], tl[2]); split3(qb.z, qb.w, th[3], tm[3], tl[3]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { bq1[e] = th[e]; bq2[e] = g < 2 ? tm[e] : th[e]; bq3[e] = g < 2 ? tl[e] : tm[e]; }
+    }
+    // A operands of a key tile: planes (h | m) and (h | l) by k group
+    const int ka1 = (g < 2 ? 0 : 1) * KPL + af_kp(qi, g & 1), ka2 = (g < 2 ? 0 : 2) * KPL + af_kp(qi, g & 1);
+    const float c2 = 0.25f * AF_LOG2E;             // 1 / sqrt(16), applied AFTER QK^T like the reference (:175), times log2(e)
     float m = -3.0e38f, l = 0.f;
-    f32x4 o = {0.f, 0.f, 0.f, 0.f};
-    const uint32_t pbase = (uint32_t)(((size_t)(b + b_off) * H + h) * L + q) * (uint32_t)L;
+    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+    // dropout of the probabilities: decision of (row, key) = half (key & 1) of drop_hash(row * ceil(L / 2) + key / 2)
+    const uint32_t prow = (uint32_t)(((size_t)(b + b_off) * H + h) * L + q) * (uint32_t)((L + 1) >> 1);
+    const bool dropon = d2.thresh != 0u;
+    // the rows of the NEXT key block travel in registers while the current one is worked on (8 float4 per thread): a block's global-memory
+    // latency used to be exposed at every block boundary -- a third of the kernel's time with three workgroups per CU to hide it
+    float4 pk[AF_NJ], pv[AF_NJ];
+    float pm = 0.f;
+    auto fetch = [&](int kb0) {
+        const int nk = min(AF_KB, Lp - kb0);
+#pragma unroll
+        for (int j = 0; j < AF_NJ; ++j) {
+            const int e = tid + 256 * j, key = kb0 + (e >> 2), c4 = (e & 3) * 4;
+            pk[j] = make_float4(0.f, 0.f, 0.f, 0.f); pv[j] = pk[j];
+            if (e < nk * 4 && key < L) {
+                pk[j] = *reinterpret_cast<const float4*>(K + (rowbase + key) * D + h * HD + c4);
+                pv[j] = *reinterpret_cast<const float4*>(V + (rowbase + key) * D + h * HD + c4);
+            }
+        }
+        pm = kb0 + tid < L ? (1.0f - mask[rowbase + kb0 + tid]) * MASK_VALUE : MASK_VALUE;
+    };
+    fetch(0);
     for (int kb0 = 0; kb0 < Lp; kb0 += AF_KB) {
         const int nk = min(AF_KB, Lp - kb0);
         if (kb0) __syncthreads();                  // every wave is done with the previous block
-        for (int e = tid; e < nk * 4; e += 256) {
-            const int key = kb0 + (e >> 2), c4 = (e & 3) * 4;
-            float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-            if (key < L) {
-                kv = *reinterpret_cast<const float4*>(K + (rowbase + key) * D + h * HD + c4);
-                vv = *reinterpret_cast<const float4*>(V + (rowbase + key) * D + h * HD + c4);
+#pragma unroll
+        for (int j = 0; j < AF_NJ; ++j) {
+            const int e = tid + 256 * j, kl = e >> 2, c4 = (e & 3) * 4;
+            if (e < nk * 4) {
+                uint32_t h0, m0, l0, h1, m1, l1;
+                split3(pk[j].x, pk[j].y, h0, m0, l0);
+                split3(pk[j].z, pk[j].w, h1, m1, l1);
+                uint16_t* kd = Kp + af_kp(kl, c4 >> 3) + (c4 & 7);
+                *reinterpret_cast<u32x2_t*>(kd) = u32x2_t{h0, h1};
+                *reinterpret_cast<u32x2_t*>(kd + KPL) = u32x2_t{m0, m1};
+                *reinterpret_cast<u32x2_t*>(kd + 2 * KPL) = u32x2_t{l0, l1};
+                *reinterpret_cast<float4*>(&Vs[kl * kst + c4]) = pv[j];
             }
-            *reinterpret_cast<float4*>(&Ks[(e >> 2) * kst + c4]) = kv;
-            *reinterpret_cast<float4*>(&Vs[(e >> 2) * kst + c4]) = vv;
         }
-        for (int kk = tid; kk < nk; kk += 256) Mb[kk] = kb0 + kk < L ? (1.0f - mask[rowbase + kb0 + kk]) * MASK_VALUE : MASK_VALUE;
+        if (tid < nk) Mb[tid] = pm * AF_LOG2E;
         __syncthreads();
-        for (int kt = 0; kt < nk; kt += 16) {
-            // S^T tile: rows = keys kb0 + kt + 4g + reg, col = query qi
-            const float4 kf = *reinterpret_cast<const float4*>(&Ks[(kt + qi) * kst + 4 * g]);
-            f32x4 s = {0.f, 0.f, 0.f, 0.f};
-            s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf.x, s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf.y, s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf.z, s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf.w, s, 0, 0, 0);
-            float p[4];
+        if (kb0 + AF_KB < Lp) fetch(kb0 + AF_KB);
+        for (int kt = 0; kt < nk; kt += 64) {
+            // four S^T tiles: rows = keys kb0 + kt + 16 t + 4 g + reg, col = query qi
+            f32x4 s[4];
+            u32x4_t a1[4], a2[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                a1[t] = *reinterpret_cast<const u32x4_t*>(Kp + ka1 + (kt + 16 * t) * 16);
+                a2[t] = *reinterpret_cast<const u32x4_t*>(Kp + ka2 + (kt + 16 * t) * 16);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) s[t] = mfma16_bf16(a1[t], bq3, f32x4{0.f, 0.f, 0.f, 0.f});       // hl + mm (small terms first)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) s[t] = mfma16_bf16(a2[t], bq2, s[t]);                            // hm + lh
+#pragma unroll
+            for (int t = 0; t < 4; ++t) s[t] = mfma16_bf16(a1[t], bq1, s[t]);                            // hh + mh
+            float x[4][4];
             float tmax = -3.0e38f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                p[r] = s[r] * scale + Mb[kt + 4 * g + r];
-                tmax = fmaxf(tmax, p[r]);
+            for (int t = 0; t < 4; ++t) {
+                const float4 mb = *reinterpret_cast<const float4*>(&Mb[kt + 16 * t + 4 * g]);
+                x[t][0] = fmaf(s[t][0], c2, mb.x); x[t][1] = fmaf(s[t][1], c2, mb.y);
+                x[t][2] = fmaf(s[t][2], c2, mb.z); x[t][3] = fmaf(s[t][3], c2, mb.w);
+                tmax = fmaxf(fmaxf(tmax, fmaxf(x[t][0], x[t][1])), fmaxf(x[t][2], x[t][3]));
             }
             tmax = lane_pair16(tmax, [](float a, float b) { return fmaxf(a, b); });
             tmax = lane_pair32(tmax, [](float a, float b) { return fmaxf(a, b); });
             const float mn = fmaxf(m, tmax);
-            const float alpha = __expf(m - mn);
+            const float alpha = __builtin_amdgcn_exp2f(m - mn);
             m = mn;
             l *= alpha;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                p[r] = __expf(p[r] - mn);
-                l += p[r];
-                o[r] *= alpha;
-            }
-            // O^T += V^T P^T : A[i = dd][k = key] = V[key][dd], B[k = key][j = q] = P (in registers)
+            for (int r = 0; r < 4; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+            // O^T += V^T P^T : A[i = dd][k = key] = V[key][dd], B[k = key][j = q] = P (in registers); fp32-input MFMA (P would have to be split per tile)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kt + 4 * g + r;
-                const float pd = p[r] * drop_mul(d2, pbase + kb0 + key);
-                const float vv = Vs[key * kst + qi];
-                o = __builtin_amdgcn_mfma_f32_16x16x4f32(vv, pd, o, 0, 0, 0);
+            for (int t = 0; t < 4; ++t) {
+                float pr[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { pr[r] = __builtin_amdgcn_exp2f(x[t][r] - mn); l += pr[r]; }
+                if (dropon) {
+                    const uint32_t pi = prow + (uint32_t)((kb0 + kt + 16 * t + 4 * g) >> 1);
+                    const uint32_t h0 = drop_hash(pi, d2.seed, d2.key), h1 = drop_hash(pi + 1u, d2.seed, d2.key);
+                    pr[0] = h0 >= d2.thresh ? pr[0] * d2.scale : 0.f;
+                    pr[1] = drop_hash_odd(h0) >= d2.thresh ? pr[1] * d2.scale : 0.f;
+                    pr[2] = h1 >= d2.thresh ? pr[2] * d2.scale : 0.f;
+                    pr[3] = drop_hash_odd(h1) >= d2.thresh ? pr[3] * d2.scale : 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float vv = Vs[(kt + 16 * t + 4 * g + r) * kst + qi];
+                    if (r & 1) o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vv, pr[r], o1, 0, 0, 0);
+                    else o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(vv, pr[r], o0, 0, 0, 0);
+                }
             }
         }
     }
@@ -533,15 +607,15 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const float* __restrict__ Q, c
         const float inv = 1.0f / l;
         // lane (qi, g) holds O[q][dd = 4g + reg]
         *reinterpret_cast<float4*>(att + (rowbase + q) * D + h * HD + 4 * g) =
-            make_float4(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
-        if (g == 0) lse[((size_t)b * H + h) * L + q] = m + __logf(l);
+            make_float4((o0[0] + o1[0]) * inv, (o0[1] + o1[1]) * inv, (o0[2] + o1[2]) * inv, (o0[3] + o1[3]) * inv);
+        if (g == 0) lse[((size_t)b * H + h) * L + q] = m * AF_LN2 + __logf(l);
     }
 }
 void launch_attn_fwd(const float* Q, const float* K, const float* V, const float* mask, float* att, float* lse, int B,
                      int L, int H, int b_off, Drop d2, hipStream_t s) {
-    const int Lp = (L + 15) & ~15;
+    const int Lp = (L + 63) & ~63;
     const int KB = Lp < AF_KB ? Lp : AF_KB;
-    const size_t shm = (size_t)(2 * KB * 20 + KB) * sizeof(float);
+    const size_t shm = (size_t)(KB * 20 + KB) * sizeof(float) + (size_t)3 * KB * 16 * sizeof(uint16_t);
     static size_t lds_ok = 0;
     ensure_dynamic_lds((const void*)k_attn_fwd, shm, lds_ok, "k_attn_fwd");
     VSL_LAUNCH(k_attn_fwd, dim3((L + 63) / 64, H, B), dim3(256), shm, s, Q, K, V, mask, att, lse, L, H, b_off, d2);
