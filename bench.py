@@ -204,7 +204,7 @@ def time_shape(predictor, batch, T, dv, lq, lc, drop_rate, dtype, steps, warmup,
         bt = batches[i % nres]
         eng.forward(flat, pad_vec, glove_vec, bt['word_ids'], bt['char_ids'], bt['vfeats'], bt['v_mask'], bt['q_mask'], training=True, seed=i,
                     sample_offset=0)
-        losses, d_h, d_sl, d_el = eng.loss(bt['s_labels'], bt['e_labels'], bt['h_labels'], 1.0, configs.highlight_lambda, inv_batch=1.0 / batch, mask_sum=mask_sum)
+        losses, d_h, d_sl, d_el = eng.loss(bt['s_labels'], bt['e_labels'], bt['h_labels'], 1.0, configs.highlight_lambda, inv_batch=1.0 / batch, mask_sum=mask_sum, lazy=True)
         dp_step(eng, None, grads, (d_h, d_sl, d_el), opt)       # one process: the update rides in the backward's last launch (as main.train does)
         return losses
     for i in range(warmup):
@@ -339,7 +339,7 @@ def main():
         eng.forward(flat, pad_vec, glove_vec, batch['word_ids'], batch['char_ids'], batch['vfeats'], batch['v_mask'],
                     batch['q_mask'], training=True, seed=i, sample_offset=rank * B)
         losses, d_h, d_sl, d_el = eng.loss(batch['s_labels'], batch['e_labels'], batch['h_labels'], 1.0,
-                                           configs.highlight_lambda, inv_batch=inv_batch, mask_sum=mask_sum)
+                                           configs.highlight_lambda, inv_batch=inv_batch, mask_sum=mask_sum, lazy=True)
         skip_exchange = skip_exchange or os.environ.get('VSL_SKIP_ALLREDUCE') == '1'
         if xchg is None and dist is None and not args.no_optimizer:
             backward_exchange_step(eng, None, grads, (d_h, d_sl, d_el), opt)      # one process, as main.train: the update rides in the backward's last launch

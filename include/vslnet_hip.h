@@ -93,6 +93,12 @@ typedef struct {
     /* single process, optional (NULL = off): the optimizer step of main_t7.py:111-113 applied by vsl_backward itself, behind its final
      * reduction (see vsl_fused_step below).  Not for data-parallel callers: their gradients are exchanged between the backward and the update. */
     const struct vsl_fused_step* fused_step;
+    /* optional (NULL = off): vsl_loss folded into vsl_backward -- the call first does what vsl_loss(h, io, fused_loss) does (losses and the three
+     * seeds are written exactly as vsl_loss writes them; complete when vsl_backward's work on the caller's stream is), then runs the backward
+     * from those seeds; vsl_io.d_h_score / d_start_logits / d_end_logits are ignored.  For whole tiles (T % 32 == 0) with the caller's mask_sum
+     * the loss launch leaves the dependent chain: the span heads' and the highlight layer's backward compute their seeds from the logits
+     * themselves (VSLNet_t7.py:67-72 and main_t7.py:107-110 as one call). */
+    const struct vsl_loss_io* fused_loss;
 } vsl_io;
 /* Every struct of this header must be zero-initialised by the caller before the fields are set: new optional fields are appended, and
  * zero means "off".  vsl_abi_version() changes whenever a struct layout or an entry point's meaning changes; a binding checks it once. */
@@ -101,7 +107,7 @@ int vsl_abi_version(void);
 
 /* labels + weights for the fused loss (replaces compute_loss / compute_highlight_loss, VSLNet_t7.py:67-72, and the
  * combination `loc + highlight_lambda * hl` of main_t7.py:107).  Data-parallel callers pass the GLOBAL normalisers. */
-typedef struct {
+typedef struct vsl_loss_io {
     const int64_t* start_labels;   /* (B)    */
     const int64_t* end_labels;     /* (B)    */
     const int64_t* h_labels;       /* (B, T) */

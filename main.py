@@ -175,7 +175,7 @@ def train(configs, dataset, features, device, world, rank, log=print):
                         eng.forward(flat, pad_vec, glove_vec, batch['word_ids'], batch['char_ids'], batch['vfeats'], batch['v_mask'], q_mask,
                                     training=True, seed=(configs.seed << 20) + global_step, sample_offset=batch['row0'])
                         losses, *seeds = eng.loss(batch['s_labels'], batch['e_labels'], batch['h_labels'], 1.0,
-                                                  configs.highlight_lambda, inv_batch=inv_batch, mask_sum=mask_sum)
+                                                  configs.highlight_lambda, inv_batch=inv_batch, mask_sum=mask_sum, lazy=True)
                     dp.backward_exchange_step(eng, xchg, grads, seeds, opt)          # (tests/test_dp_gloo.py drives its multi-rank half on 2 and 3 ranks)
                     loss_t = losses[2]
                 else:

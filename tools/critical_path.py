@@ -115,7 +115,7 @@ def main():
     def step(i):
         b = batches[i % len(batches)]
         eng.forward(flat, pad_vec, glove_vec, b['word_ids'], b['char_ids'], b['vfeats'], b['v_mask'], b['q_mask'], training=True, seed=i)
-        _, d_h, d_sl, d_el = eng.loss(b['s_labels'], b['e_labels'], b['h_labels'], 1.0, configs.highlight_lambda, inv_batch=1.0 / B, mask_sum=mask_sum)
+        _, d_h, d_sl, d_el = eng.loss(b['s_labels'], b['e_labels'], b['h_labels'], 1.0, configs.highlight_lambda, inv_batch=1.0 / B, mask_sum=mask_sum, lazy=True)
         backward_exchange_step(eng, None, grads, (d_h, d_sl, d_el), opt)
 
     for i in range(10):

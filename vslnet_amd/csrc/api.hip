@@ -441,6 +441,7 @@ struct Ctx {
     int64_t part_cur = 0;
     std::vector<SlabRec>* recs = nullptr;
     std::vector<WgradBatch> pend;       // weight-gradient batches waiting for ONE ordering point (wgrad_async / wgrad_flush)
+    const vsl_loss_io* pend_loss = nullptr;   // vsl_io.fused_loss off the dependent chain: launched on the weight-gradient stream behind its first ordering point (loss_on_side)
     int pw_rows = 0;                    // rows per chunk of the NEXT enc_bwd's pointwise weight-gradient jobs (0 = WG_ROWS): the step's last batch, run_backward
     bool defer_w = false;
     const float* P(int off) const { return io->params + off; }
@@ -547,6 +548,17 @@ struct Ctx {
 // Every cross-stream ordering point (event record on the producer + wait on the consumer) leaves a ~6-7 us bubble in the
 // producer stream (rocprofv3 timeline), so weight-gradient batches -- nothing waits for them before the final reduction --
 // are collected while `defer_w` is set and go to the side stream behind ONE event.
+// the loss launch of vsl_io.fused_loss on the current stream (run_backward decides where: in front of the heads' backward when they read the seeds
+// from memory, at the end of the main stream's work when they compute them)
+void loss_on_side(Ctx& c) {
+    const vsl_loss_io* fl = c.pend_loss;
+    if (!fl || c.dry) return;
+    c.pend_loss = nullptr;
+    const vsl_io* io = c.io;
+    LAUNCH("loss", launch_loss(io->start_logits, io->end_logits, io->h_score, fl->start_labels, fl->end_labels, fl->h_labels, io->v_mask, io->B, io->T,
+                               fl->inv_batch, fl->mask_sum, fl->w_loc, fl->w_highlight, c.W(c.p->loss_scratch), fl->losses, fl->d_start_logits,
+                               fl->d_end_logits, fl->d_h_score, c.s, c.h->loss_counter));
+}
 void wgrad_async(Ctx& c, hipStream_t sw, const WgradBatch& wb) {
     if (c.defer_w) { c.pend.push_back(wb); return; }
     hipStream_t keep = c.s;
@@ -1063,11 +1075,30 @@ void run_backward(Ctx& c) {
     memset(&hs, 0, sizeof hs);
     memset(&he, 0, sizeof he);
     const bool rnn = cf.predictor == 0;
+    // vsl_io.fused_loss: the loss is part of this call.  Whole tiles + the caller's mask sum: k_loss_fused goes to the weight-gradient stream (nothing
+    // on the dependent chain reads what it writes) and the consumers of the seeds -- the span heads' backward, the highlight layer's -- compute
+    // them from the logits themselves.  Otherwise the loss launches first, on the caller's stream, and the seeds are read as they always were.
+    const vsl_loss_io* fl = c.dry ? nullptr : io->fused_loss;
+    const float *seed_s = nullptr, *seed_e = nullptr, *seed_h = nullptr;
+    bool seeds_inline = false;
+    HlSeed hlseed{nullptr, nullptr, 0.f, 0.f};
     if (!c.dry) {
-        hs = HeadBwdArgs{io->d_start_logits, c.W(p.hid_s), c.W(p.p1.out), rnn ? nullptr : c.P(P.sln_g), c.PK(K.s0_t), c.P(P.s1w), c.W(p.gz_s),
-                         c.W(p.dfeat_s), c.W(p.dxh_s), nullptr, nullptr, nullptr, nullptr, nullptr};
-        he = HeadBwdArgs{io->d_end_logits, c.W(p.hid_e), c.W(p.p2.out), rnn ? nullptr : c.P(P.eln_g), c.PK(K.e0_t), c.P(P.e1w), c.W(p.gz_e),
-                         c.W(p.dfeat_e), c.W(p.dxh_e), nullptr, nullptr, nullptr, nullptr, nullptr};
+        seed_s = fl ? fl->d_start_logits : io->d_start_logits; seed_e = fl ? fl->d_end_logits : io->d_end_logits; seed_h = fl ? fl->d_h_score : io->d_h_score;
+        if (fl) {
+            static const bool inline_on = !(getenv("VSL_LOSS_INLINE") && getenv("VSL_LOSS_INLINE")[0] == '0');
+            seeds_inline = inline_on && T % TILE_M == 0 && fl->mask_sum > 0.f && c.h->loss_counter != nullptr;
+            c.pend_loss = fl;
+            if (!seeds_inline) loss_on_side(c);            // (here and now, on the caller's stream: the seeds are read from memory)
+            else hlseed = HlSeed{fl->h_labels, io->v_mask, fl->w_highlight, fl->mask_sum};
+        }
+        hs = HeadBwdArgs{seed_s, c.W(p.hid_s), c.W(p.p1.out), rnn ? nullptr : c.P(P.sln_g), c.PK(K.s0_t), c.P(P.s1w), c.W(p.gz_s),
+                         c.W(p.dfeat_s), c.W(p.dxh_s), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0};
+        he = HeadBwdArgs{seed_e, c.W(p.hid_e), c.W(p.p2.out), rnn ? nullptr : c.P(P.eln_g), c.PK(K.e0_t), c.P(P.e1w), c.W(p.gz_e),
+                         c.W(p.dfeat_e), c.W(p.dxh_e), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0};
+        if (seeds_inline) {
+            hs.logits = io->start_logits; hs.label = fl->start_labels; hs.cs = fl->w_loc * fl->inv_batch; hs.T = T;
+            he.logits = io->end_logits; he.label = fl->end_labels; he.cs = fl->w_loc * fl->inv_batch; he.T = T;
+        }
     }
     hs.p_b0 = c.slab(P.s0b, D, ntiles); hs.p_w1 = c.slab(P.s1w, D, ntiles); hs.p_b1 = c.slab(P.s1b, 1, ntiles);
     he.p_b0 = c.slab(P.e0b, D, ntiles); he.p_w1 = c.slab(P.e1w, D, ntiles); he.p_b1 = c.slab(P.e1b, 1, ntiles);
@@ -1192,7 +1223,8 @@ void run_backward(Ctx& c) {
         p_hlw = c.slab(P.hl_w, D, ntiles);
         p_hlb = c.slab(P.hl_b, 1, ntiles);
         memset(&cqa, 0, sizeof cqa);
-        if (!c.dry) cqa = CqcatBwdArgs{nullptr, c.W(p.dxh_s), c.W(p.dxh_e), io->d_h_score, c.W(p.f2), io->h_score, c.P(P.hl_w), c.PK(K.cat1_t), c.W(p.df2), c.W(p.df1), p_hlw, p_hlb};
+        if (!c.dry) cqa = CqcatBwdArgs{nullptr, c.W(p.dxh_s), c.W(p.dxh_e), seed_h, c.W(p.f2), io->h_score, c.P(P.hl_w), c.PK(K.cat1_t), c.W(p.df2), c.W(p.df1), p_hlw, p_hlb,
+                                       hlseed.h_lab, hlseed.vmask, hlseed.w_hl, hlseed.mask_sum};
     }
     enc_bwd(c, P.pe, K.pe, p.p1, c.dry ? nullptr : c.W(p.g_s1), c.dry ? nullptr : c.W(p.dfeat_s), p.g_gated,
             c.dry ? nullptr : io->v_mask, B, 2, sw, nullptr, hosted, nullptr, hosted ? &cqa : nullptr);
@@ -1201,8 +1233,8 @@ void run_backward(Ctx& c) {
     if (!hosted) {
         p_hlw = c.slab(P.hl_w, D, ntiles);
         p_hlb = c.slab(P.hl_b, 1, ntiles);
-        LAUNCH("cqcat_bwd", launch_cqcat_bwd(c.W(p.g_gated), c.W(p.dxh_s), c.W(p.dxh_e), io->d_h_score, c.W(p.f2), io->h_score, c.P(P.hl_w),
-                                c.PK(K.cat1_t), c.W(p.df2), c.W(p.df1), p_hlw, p_hlb, R, c.s));
+        LAUNCH("cqcat_bwd", launch_cqcat_bwd(c.W(p.g_gated), c.W(p.dxh_s), c.W(p.dxh_e), seed_h, c.W(p.f2), io->h_score, c.P(P.hl_w),
+                                c.PK(K.cat1_t), c.W(p.df2), c.W(p.df1), p_hlw, p_hlb, R, c.s, hlseed.h_lab ? &hlseed : nullptr));
     }
     {
         WgradBatch wb;
@@ -1346,6 +1378,10 @@ void run_backward(Ctx& c) {
     if (cf.word_table && !c.dry)
         LAUNCH("word_table_bwd", launch_word_table_bwd(c.W(p.dE), io->word_ids, io->grads + P.unk, Rq, cf.word_size, cf.word_dim, c.drop(SITE_WORD), c.s));
     c.s = main_s;
+    // the loss of vsl_io.fused_loss whose seeds the kernels computed themselves: 64 small workgroups behind the main stream's last kernel, in the
+    // shadow of the join below (at the headline shape the main stream ends ~30 us before the video stream's last weight-gradient batch).  On the
+    // weight-gradient stream in front of its first batch it took CUs from the chain's 256-workgroup kernels and cost what it saved (r06 notes 10)
+    loss_on_side(c);
     c.order(sq, c.s);                      // join both side streams before the reduction
     c.order(sw, c.s);
     const int nlate = p.nblocks - p.nblocks_early;
@@ -1818,6 +1854,11 @@ static int ensure_opt_state(vsl_handle_s* h) {
 
 int vsl_backward(vsl_handle h, const vsl_io* io, void* hip_stream) {
     if (int rc = check_io(h, io)) return rc;
+    if (const vsl_loss_io* l = io->fused_loss) {
+        if (!l->start_labels || !l->end_labels || !l->h_labels || !l->losses) return fail("vsl_backward: fused_loss has a null pointer");
+        if (!l->d_start_logits || !l->d_end_logits || !l->d_h_score) return fail("vsl_backward: fused_loss needs the three gradient seed outputs");
+        if (!io->grads) return fail("vsl_backward needs grads");
+    } else
     if (!io->d_start_logits || !io->d_end_logits || !io->grads) return fail("vsl_backward needs d_start_logits, d_end_logits and grads");
     Plan* p = nullptr;
     if (int rc = get_plan(h, io->B, io->T, io->Lq, io->Lc, &p)) return rc;

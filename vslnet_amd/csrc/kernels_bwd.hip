@@ -140,6 +140,18 @@ __global__ __launch_bounds__(256) void k_loss_c(const float* __restrict__ sl, co
     // d BCE / dp = (p - y) / max(p (1 - p), 1e-12)   (torch's binary_cross_entropy_backward)
     d_h[i] = w_hl * wgt * m / (dsum + 1e-12f) * (p - y) / fmaxf(p * (1.f - p), 1e-12f);
 }
+// log-sum-exp of one sample's T logits by a 256-thread workgroup (every thread gets the result).  k_loss_fused and k_head_bwd's inline seeds
+// (vsl_io.fused_loss) both go through this function, so the seeds are the same bits whichever kernel computes them.
+__device__ __forceinline__ float loss_sample_lse(const float* __restrict__ x, int T, float* red) {
+    const int tid = threadIdx.x;
+    float mx = -3.0e38f;
+    for (int t = tid; t < T; t += 256) mx = fmaxf(mx, x[t]);
+    mx = block_reduce(mx, red, true);
+    float ss = 0.f;
+    for (int t = tid; t < T; t += 256) ss += expf(x[t] - mx);
+    ss = block_reduce(ss, red, false);
+    return mx + logf(ss);
+}
 // One launch when the caller supplies the global mask sum (the data-parallel path and bench.py do): the sample's workgroup writes its
 // gradient seeds itself -- they need nothing from other samples then -- and the LAST workgroup to arrive (agent-scope counter) adds the
 // per-sample partials in index order, so the loss values do not depend on which one that is.  Saves k_loss_c on the critical chain.
@@ -307,10 +319,16 @@ __global__ __launch_bounds__(256) void k_head_bwd(HeadBwdArgs a0, HeadBwdArgs a1
     __shared__ __attribute__((aligned(16))) float Hs[TILE_M * LDP];
     __shared__ __attribute__((aligned(16))) float Fs[TILE_M * LDP];
     __shared__ float dl[TILE_M];
+    __shared__ float red[8];
     const HeadBwdArgs a = blockIdx.y == 0 ? a0 : a1;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int r0 = blockIdx.x * TILE_M;
     BFrag<2, 8> bf;
+    if (a.logits) {                        // (block-uniform) vsl_io.fused_loss: the tile lies inside ONE sample (T % 32 == 0); its seeds from the sample's logits
+        const int b = r0 / a.T;
+        const float lse = loss_sample_lse(a.logits + (size_t)b * a.T, a.T, red);
+        if (tid < TILE_M) dl[tid] = r0 + tid < R ? loss_ce_seed(a.logits[r0 + tid], lse, r0 + tid - b * a.T, (int)a.label[b], a.cs) : 0.f;
+    } else
     if (tid < TILE_M) dl[tid] = r0 + tid < R ? a.dlogit[r0 + tid] : 0.f;
     load_tile128(Hs, a.hid, r0, TILE_M, R);
     load_tile128(Fs, a.feat, r0, TILE_M, R);
@@ -771,10 +789,11 @@ __global__ __launch_bounds__(256) void k_cqcat_bwd(CqcatBwdArgs a, int R) {
 }
 void launch_cqcat_bwd(const float* dg0, const float* dg1, const float* dg2, const float* dh_loss, const float* f2,
                       const float* hscore, const float* wh, const float* W1Tpack, float* df2, float* df1, float* p_wh,
-                      float* p_bh, int R, hipStream_t s) {
+                      float* p_bh, int R, hipStream_t s, const HlSeed* hl) {
     {
         const size_t shm_sp = 0;
-        const CqcatBwdArgs a{dg0, dg1, dg2, dh_loss, f2, hscore, wh, W1Tpack, df2, df1, p_wh, p_bh};
+        CqcatBwdArgs a{dg0, dg1, dg2, dh_loss, f2, hscore, wh, W1Tpack, df2, df1, p_wh, p_bh, nullptr, nullptr, 0.f, 0.f};
+        if (hl) { a.h_lab = hl->h_lab; a.vmask = hl->vmask; a.w_hl = hl->w_hl; a.mask_sum = hl->mask_sum; }
         VSL_LAUNCH(k_cqcat_bwd, dim3((R + TILE_M - 1) / TILE_M), dim3(256), shm_sp, s, a, R);
     }
 }

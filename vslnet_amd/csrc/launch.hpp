@@ -54,6 +54,12 @@ struct HeadBwdArgs {
     float* p_b1;          // [ntiles]
     float* p_lng;         // [ntiles][128]
     float* p_lnb;         // [ntiles][128]
+    // vsl_io.fused_loss, whole tiles (T % 32 == 0): the tile's seeds dlogit[r] = cs * (softmax(logits of r's sample)[t] - [t == label]) are computed HERE
+    // (the CrossEntropy gradient needs nothing but the sample's own T logits), so the loss launch is not on the dependent chain; logits == nullptr: read dlogit
+    const float* logits;  // (B, T)
+    const int64_t* label; // (B)
+    float cs;             // w_loc * inv_batch
+    int T;
 };
 
 // generic weight-gradient job: dW[n][k] = sum_r G[r][n] * A[r][k]  over row chunks -> partial slabs
@@ -173,6 +179,10 @@ struct AttnOutBwdArgs {
 struct CqcatBwdArgs {
     const float *dg0, *dg1, *dg2, *dh_loss, *f2, *hscore, *wh, *W1Tpack;
     float *df2, *df1, *p_wh, *p_bh;
+    // vsl_io.fused_loss: the highlight loss' seed (elementwise: k_loss_fused's expression) computed in place of the dh_loss read; h_lab == nullptr: read dh_loss
+    const int64_t* h_lab;
+    const float* vmask;
+    float w_hl, mask_sum;
 };
 // a8 backward, first half (k_qkv_bwd's work), hosted by the conv block's backward kernel on its 56-row window:
 // dy = dr + LN1^T(([dQ | dK | dV] [Wq; Wk; Wv]) * m1) -- the conv block's incoming gradient never goes through memory
@@ -332,9 +342,10 @@ int attn_bwd_dq_slabs(int L);             // L > 256: dQ is written as this many
 void launch_qkv_bwd(const float* dQ, const float* dK, const float* dV, const float* x, const float* dr,
                     const float* ln_g, const uint16_t* WT3 /* split pack of the (384, 128) operand */, float* dx, float* p_lng, float* p_lnb, int R,
                     Drop d1, hipStream_t s, int dq_slabs = 1);
+struct HlSeed { const int64_t* h_lab; const float* vmask; float w_hl, mask_sum; };     // (CqcatBwdArgs' inline highlight seed)
 void launch_cqcat_bwd(const float* dg0, const float* dg1, const float* dg2, const float* dh_loss, const float* f2,
                       const float* hscore, const float* wh, const float* W1Tpack, float* df2, float* df1, float* p_wh,
-                      float* p_bh, int R, hipStream_t s);
+                      float* p_bh, int R, hipStream_t s, const HlSeed* hl = nullptr);
 struct CqBwdArgs {
     const float *df1, *df2, *C, *Qf, *Srow, *Scol, *M, *alpha, *pooled;      // saved forward tensors / incoming grads
     const float *WcqaT;                                                        // transpose pack of cqa_linear (ncols 512)

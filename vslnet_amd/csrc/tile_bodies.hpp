@@ -77,6 +77,14 @@ __device__ __forceinline__ void attn_out_bwd_tile(const AttnOutBwdArgs& a, const
     ln_bwd_tile(Gs, Xs, lres, a.ln_g, a.dr, a.p_lng, a.p_lnb, r0, R, nullptr, active);
 }
 
+// CrossEntropy seed of logit x at position t (mean over the batch folded into cs = w_loc * inv_batch)
+__device__ __forceinline__ float loss_ce_seed(float x, float lse, int t, int label, float cs) { return cs * (expf(x - lse) - (t == label ? 1.f : 0.f)); }
+// highlight (weighted BCE, VSLNet_t7.py / layers_t7.py:291-299) seed of score p with label y under mask m
+__device__ __forceinline__ float loss_hl_seed(float p, float y, float m, float w_hl, float mask_sum) {
+    const float wgt = y == 0.f ? 1.f : 2.f * y;
+    // d BCE / dp = (p - y) / max(p (1 - p), 1e-12)   (torch's binary_cross_entropy_backward)
+    return w_hl * wgt * m / (mask_sum + 1e-12f) * (p - y) / fmaxf(p * (1.f - p), 1e-12f);
+}
 // gating + HighLightLayer + CQConcatenate backward (VSLNet_t7.py:60, layers_t7.py:262-289 backward):  dgated = dg0 + dg1 + dg2 ;
 // dlogit = (sum_c dgated * f2 + dh_loss) * h (1 - h) ; df2 = dgated * h + dlogit * wh ; df1 = df2 W1 ; partials of wh / bh.
 // lds_dg0 != nullptr: dg0's tile is in LDS (stride LDP; rows >= R zero).  Gs / Fs: two [32][LDP] tiles (neither of them lds_dg0), dlg: 32 floats.
@@ -125,7 +133,10 @@ __device__ __forceinline__ void cqcat_bwd_tile(const CqcatBwdArgs& a, const floa
         float hv = 0.f, dl = 0.f;
         if (r < R) {
             hv = a.hscore[r];
-            dl = (d + (a.dh_loss ? a.dh_loss[r] : 0.f)) * hv * (1.f - hv);      // sigmoid backward; mask_logits is additive
+            float dh = 0.f;                                                      // the highlight loss' seed: computed here (vsl_io.fused_loss) or read
+            if (a.h_lab) dh = loss_hl_seed(hv, (float)a.h_lab[r], a.vmask[r], a.w_hl, a.mask_sum);
+            else if (a.dh_loss) dh = a.dh_loss[r];
+            dl = (d + dh) * hv * (1.f - hv);                                     // sigmoid backward; mask_logits is additive
         }
         // df2 = dgated * h + dlogit * wh
 #pragma unroll

@@ -32,7 +32,8 @@ class vsl_io(C.Structure):
                 ('d_h_score', C.c_void_p), ('d_start_logits', C.c_void_p), ('d_end_logits', C.c_void_p),
                 ('grads', C.c_void_p), ('sample_offset', C.c_int32), ('video_features_bf16', C.c_void_p),
                 ('early_grads_event', C.c_void_p),
-                ('fused_step', C.c_void_p)]        # (NULL unless Engine.backward(fused_step=...): an older build loaded for an A/B run reads zeros here)
+                ('fused_step', C.c_void_p),        # (NULL unless Engine.backward(fused_step=...): an older build loaded for an A/B run reads zeros here)
+                ('fused_loss', C.c_void_p)]        # (NULL unless the last loss() was lazy=True)
 
 
 class vsl_loss_io(C.Structure):
@@ -201,6 +202,7 @@ class Engine:
             self.layout.append((name.value.decode(), off.value, num.value, tuple(dims[j] for j in range(nd.value))))
         self._ws, self._grown = None, False
         self._last = None
+        self._pending_loss = None
 
     def __del__(self):
         try:
@@ -283,6 +285,7 @@ class Engine:
         io.h_score, io.start_logits, io.end_logits = _ptr(out[0]), _ptr(out[1]), _ptr(out[2])
         io.workspace = _ptr(ws)
         io.training, io.seed, io.sample_offset = int(bool(training)), int(seed) & 0xFFFFFFFFFFFFFFFF, int(sample_offset)
+        self._flush_loss()
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         self._call(self.lib.vsl_forward(self.h, C.byref(io), stream))
         self._last, self._last_ws = io, ws
@@ -291,9 +294,13 @@ class Engine:
         return out[0], out[1], out[2]
 
     def loss(self, start_labels, end_labels, h_labels, w_loc=1.0, w_highlight=5.0, inv_batch=None, mask_sum=0.0,
-             want_grads=True, scores=None, start_logits=None, end_logits=None, v_mask=None):
+             want_grads=True, scores=None, start_logits=None, end_logits=None, v_mask=None, lazy=False):
         """Fused compute_loss + compute_highlight_loss.  By default on the outputs of the LAST forward; explicit
-        (B, T) tensors may be passed instead.  Returns (losses[4], d_h, d_sl, d_el)."""
+        (B, T) tensors may be passed instead.  Returns (losses[4], d_h, d_sl, d_el).
+        `lazy=True` (training steps: what `main.train` and `bench.py` do): nothing is launched here -- the loss becomes part of the next
+        `backward()` on the returned seeds (vsl_io.fused_loss: for whole tiles the loss kernel then leaves the dependent chain and the consumers of
+        the seeds compute them from the logits); `losses` and the seeds are valid once that backward's work is.  Any other use of the engine
+        in between (another forward / loss / a backward on other seeds) issues the pending loss first."""
         io = self._last
         if scores is not None:
             B, T = scores.shape
@@ -319,9 +326,21 @@ class Engine:
         l.losses = _ptr(losses)
         if want_grads:
             l.d_h_score, l.d_start_logits, l.d_end_logits = _ptr(d[0]), _ptr(d[1]), _ptr(d[2])
+        self._flush_loss()
+        if lazy and want_grads and scores is None and self.fused_tail:
+            self._pending_loss = (l, io, (start_labels, end_labels, h_labels, losses, d))
+            return losses, d[0], d[1], d[2]
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         self._call(self.lib.vsl_loss(self.h, C.byref(io), C.byref(l), stream))
         return (losses,) + ((d[0], d[1], d[2]) if want_grads else (None, None, None))
+
+    def _flush_loss(self):
+        """Issue a pending lazy loss() as its own launch (the caller did not go on to backward() on its seeds)."""
+        pend, self._pending_loss = getattr(self, '_pending_loss', None), None
+        if pend is not None:
+            l, io, _ = pend
+            stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            self._call(self.lib.vsl_loss(self.h, C.byref(io), C.byref(l), stream))
 
     def early_grad_offset(self):
         """First float offset of the block of `grads` that is final when `backward(..., early_event=)` fires its event."""
@@ -335,6 +354,14 @@ class Engine:
         kernel); equivalent to backward() followed by adamw_step(..., norm_from_backward=True)."""
         io = self._last
         B, T = io.B, io.T
+        pend = getattr(self, '_pending_loss', None)
+        fused_loss = None
+        if pend is not None:
+            d = pend[2][4]
+            if pend[1] is io and d_h is not None and d_h.data_ptr() == d[0].data_ptr() and d_sl.data_ptr() == d[1].data_ptr() and d_el.data_ptr() == d[2].data_ptr():
+                fused_loss, self._pending_loss = pend, None          # the lazy loss rides in this call
+            else:
+                self._flush_loss()
         if d_h is not None:
             _chk(d_h, torch.float32, (B, T), 'd_h_score')
         _chk(d_sl, torch.float32, (B, T), 'd_start_logits')
@@ -345,6 +372,7 @@ class Engine:
         if early_event is not None:
             early_event.record(torch.cuda.current_stream(self.device))     # creates the handle lazily; harmless: recorded again by the library
             io.early_grads_event = C.c_void_p(early_event.cuda_event)
+        io.fused_loss = C.cast(C.pointer(fused_loss[0]), C.c_void_p) if fused_loss is not None else None
         io.fused_step = None
         fs = None
         if fused_step is not None:
@@ -366,7 +394,7 @@ class Engine:
         try:
             self._call(self.lib.vsl_backward(self.h, C.byref(io), stream))
         finally:
-            io.fused_step = None                          # (`fs` lives until here; the library reads it during the call only)
+            io.fused_step = io.fused_loss = None          # (`fs` / the loss struct live until here; the library reads them during the call only)
         return grads
 
     def profile_select(self, kernel):
