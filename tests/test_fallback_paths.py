@@ -15,7 +15,10 @@ tiles and L > 256 take) and VSL_HEADS_FUSED=0 (k_head_fwd instead of the tail of
 takes) -- the training suite's whole-tile shapes select the fused paths, so it is re-run once with both off.
 
 Round 6: VSL_QUERY_FUSED=0 -- the query branch as row-tile launches (linear_fwd + convblock_fwd<0> + attn_block_fwd / attn_out_bwd + attn_bwd +
-convblock_bwd<0>) instead of the sample-local k_query_fwd / k_query_bwd that every Lq <= 32 shape now selects; what Lq > 32 takes.  Same re-run."""
+convblock_bwd<0>) instead of the sample-local k_query_fwd / k_query_bwd that every Lq <= 32 shape now selects; what Lq > 32 takes.  Same re-run.
+Later in round 6: VSL_CQ_FOLD=0 (k_cq_col as its own launch: what T > 128 or Lq > 32 takes), VSL_TAIL_ROWS=0 (256-row chunks for the step's last
+weight-gradient batch too) and VSL_LOSS_INLINE=0 / VSL_FUSED_TAIL=1 (the lazy loss in front of the heads' backward; the final reduction and AdamW as
+one launch), the last two through tests/test_fused_loss.py and tests/test_optimizer.py, which drive those paths."""
 import os
 import subprocess
 import sys
@@ -42,7 +45,8 @@ def test_rnn_suite_with_the_chunked_launches():
 
 
 def test_training_suite_with_the_unfused_launches():
-    e = dict(os.environ, VSL_QKV_FUSED='0', VSL_HEADS_FUSED='0', VSL_QUERY_FUSED='0')
-    r = subprocess.run([sys.executable, '-m', 'pytest', '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider', 'tests/test_hip_training.py', 'tests/test_hip_parity.py'],
+    e = dict(os.environ, VSL_QKV_FUSED='0', VSL_HEADS_FUSED='0', VSL_QUERY_FUSED='0', VSL_CQ_FOLD='0', VSL_TAIL_ROWS='0', VSL_LOSS_INLINE='0')
+    r = subprocess.run([sys.executable, '-m', 'pytest', '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider', 'tests/test_hip_training.py', 'tests/test_hip_parity.py',
+                        'tests/test_fused_loss.py'],
                        cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -82,8 +82,9 @@ def test_which_launches_a_step_takes_and_what_the_ledger_records():
     names = [r['name'] for r in recs]
     assert names.count('query_fwd') == 1 and names.count('query_bwd') == 1 and 'linear_fwd' not in names
     assert names.count('convblock_fwd') == 3 and names.count('convblock_bwd') == 3
-    assert 'loss' in names and names[-1] == 'adamw'
-    assert len(recs) <= 43, len(recs)
+    assert 'loss' in names and names[-1] == 'adamw' and 'cq_col' not in names       # (the column kernel is folded into its neighbours at T <= 128, Lq <= 32)
+    assert names.index('loss') > names.index('embed_bwd')                          # the lazy loss: behind the main stream's last kernel, not in front of head_bwd
+    assert len(recs) <= 42, len(recs)
     assert len(set(r['stream'] for r in recs)) == 3
     for i, r in enumerate(recs):
         assert r['stop_us'] > r['start_us'] >= 0.0

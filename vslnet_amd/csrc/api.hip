@@ -776,15 +776,21 @@ void run_forward(Ctx& c) {
     c.s = c.main;
     c.order(sq, c.main);                   // join
     if (split3) c.order(sp, c.main);       // the remaining packs (long done)
+    // short videos, short queries: the column kernel (column softmax over the clips, M = S_col^T C, WeightedPool) is folded into its neighbours --
+    // one launch and one boundary less on the dependent chain (VSL_CQ_FOLD=0: three launches)
+    static const bool fold_on = !(getenv("VSL_CQ_FOLD") && getenv("VSL_CQ_FOLD")[0] == '0');
+    const bool cq_fold = fold_on && cq_col_folds(T, Lq);
+    const CqPoolArgs pool{c.P(P.pool_w), c.P(P.cat_w), c.P(P.cat_b), c.W(p.alpha), c.W(p.pooled), c.W(p.pb)};
     LAUNCH("cq_score", launch_cq_score(c.W(p.ve.out), c.W(p.qe.out), io.q_mask, c.P(P.w4C), c.P(P.w4Q), c.P(P.w4mlu), c.W(p.S), c.W(p.Srow), B, T,
-                    Lq, 0, c.drop(SITE_CQ_C), c.drop(SITE_CQ_Q), c.s));
+                    Lq, 0, c.drop(SITE_CQ_C), c.drop(SITE_CQ_Q), c.s, cq_fold ? &pool : nullptr));
     // M = S_col^T C is produced as per-tile partials (the backward's cqP1 arena is free until then) and summed by cq_out
-    LAUNCH("cq_col", launch_cq_col(c.W(p.ve.out), c.W(p.qe.out), c.W(p.S), io.v_mask, io.q_mask, c.P(P.pool_w), c.P(P.cat_w), c.P(P.cat_b),
-                  c.W(p.Scol), c.W(p.cqP1), c.W(p.alpha), c.W(p.pooled), c.W(p.pb), B, T, Lq, c.s));
+    if (!cq_fold)
+        LAUNCH("cq_col", launch_cq_col(c.W(p.ve.out), c.W(p.qe.out), c.W(p.S), io.v_mask, io.q_mask, c.P(P.pool_w), c.P(P.cat_w), c.P(P.cat_b),
+                      c.W(p.Scol), c.W(p.cqP1), c.W(p.alpha), c.W(p.pooled), c.W(p.pb), B, T, Lq, c.s));
     // cq_out also carries CQConcatenate + HighLightLayer + gating (row-local on the tile it produces)
     LAUNCH("cq_out", launch_cq_out(c.W(p.ve.out), c.W(p.qe.out), c.W(p.Srow), c.W(p.cqP1), c.W(p.M), c.PK(K.cqa_f), c.P(P.cqa_b), c.W(p.cat),
                   c.W(p.f1), c.PK(K.cat1_f), c.W(p.pb), c.P(P.hl_w), c.P(P.hl_b), io.v_mask, c.W(p.f2), io.h_score, c.W(p.gated), B, T, Lq,
-                  c.s));
+                  c.s, cq_fold ? c.W(p.S) : nullptr, cq_fold ? c.W(p.Scol) : nullptr));
     if (cf.predictor == 0) {
         // rnn head (:341-343): start = LSTM_s(x) * mask ; end = LSTM_e(start) * mask ; no LayerNorm in front of the span blocks
         // The recurrence is latency bound (one sample per CU, 0.6 us per step).  Up to RNN_FUSED_MAX_B samples the whole head is ONE launch: start

@@ -706,12 +706,72 @@ void launch_attn_out_fwd(const float* att, const float* x, const float* ln_g, co
 //      plus a11's WeightedPool (:253-259) and the per-sample bias  pb = W2 pooled + b  of CQConcatenate (:268-274).
 //  (3) k_cq_out  : c2q = S_row Q, q2c = S_row M, concat [C, c2q, C*c2q, C*q2c] (:231) -> Conv1D 4d->d (:232).
 // =========================================================================================================
+// a11's WeightedPool (:253-259) and the pooled half of CQConcatenate's Conv1D (:268-274) for one sample: alpha, pooled, pb = W2 pooled + b.  Query-side only;
+// one 256-thread workgroup.  al: [128], pl: [128] floats of LDS.
+struct CqPool { const float *pool_w, *Wcat, *bcat; float *alpha, *pooled, *pb; };
+__device__ __forceinline__ void cq_pool_body(const float* __restrict__ Qf, const float* __restrict__ qmask, const CqPool& cp, int b, int Lq, float* al, float* pl) {
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const size_t qrow = (size_t)b * Lq;
+    const float* pool_w = cp.pool_w; const float* Wcat = cp.Wcat; const float* bcat = cp.bcat;
+    float* alpha = cp.alpha; float* pooled = cp.pooled; float* pb = cp.pb;
+    // ---- WeightedPool: alpha = softmax_j(Q[j].w + mask) ; pooled = sum_j alpha_j Q[j]
+    for (int jj = w; jj < Lq; jj += 4) {
+        const float* row = Qf + (qrow + jj) * D;
+        const float d = wave_sum(row[lane] * pool_w[lane] + row[lane + 64] * pool_w[lane + 64]);
+        if (lane == 0) al[jj] = d + (1.f - qmask[qrow + jj]) * MASK_VALUE;
+    }
+    __syncthreads();
+    if (w == 0) {                              // a lane owns words lane and lane + 64
+        const float v0 = lane < Lq ? al[lane] : -3.0e38f, v1 = lane + 64 < Lq ? al[lane + 64] : -3.0e38f;
+        const float mx = wave_max(fmaxf(v0, v1));
+        const float e0 = lane < Lq ? __expf(v0 - mx) : 0.f, e1 = lane + 64 < Lq ? __expf(v1 - mx) : 0.f;
+        const float inv = 1.0f / wave_sum(e0 + e1);
+        if (lane < Lq) { al[lane] = e0 * inv; alpha[qrow + lane] = e0 * inv; }
+        if (lane + 64 < Lq) { al[lane + 64] = e1 * inv; alpha[qrow + lane + 64] = e1 * inv; }
+    }
+    __syncthreads();
+    if (tid < D) {
+        float acc = 0.f;
+        for (int j0 = 0; j0 < Lq; j0 += 8) {        // eight rows in flight; same summation order as one row at a time
+            float qv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) qv[u] = Qf[(qrow + min(j0 + u, Lq - 1)) * D + tid];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (j0 + u < Lq) acc += al[j0 + u] * qv[u];
+        }
+        pl[tid] = acc;
+        pooled[(size_t)b * D + tid] = acc;
+    }
+    __syncthreads();
+    // ---- pb[o] = sum_c Wcat[o][128 + c] * pooled[c] + bcat[o]     (second half of the 2d -> d Conv1D); 8 lanes per row
+    for (int o = tid >> 3; o < D; o += 32) {
+        const int sub = tid & 7;
+        const float* wr = Wcat + (size_t)o * 2 * D + D + sub * 4;
+        float d = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 wv = *reinterpret_cast<const float4*>(wr + 32 * q);
+            const float4 pv = *reinterpret_cast<const float4*>(pl + sub * 4 + 32 * q);
+            d += wv.x * pv.x + wv.y * pv.y + wv.z * pv.z + wv.w * pv.w;
+        }
+        d = grp8_sum(d);
+        if (sub == 0) pb[(size_t)b * D + o] = d + bcat[o];
+    }
+}
+
 template <int NU>   // words per lane of the row softmax: 8 (Lq <= 64), 12 (<= 96) or 16 (<= MAX_LQ = 128)
 __global__ __launch_bounds__(256) void k_cq_score(const float* __restrict__ C, const float* __restrict__ Qf,
                                                   const float* __restrict__ qmask, const float* __restrict__ w4C,
                                                   const float* __restrict__ w4Q, const float* __restrict__ w4mlu,
                                                   float* __restrict__ S, float* __restrict__ Srow, int T, int Lq, int b_off,
-                                                  Drop dc, Drop dq) {
+                                                  Drop dc, Drop dq, CqPool cp) {
+    // cp.pool_w != nullptr: ONE extra workgroup per sample (blockIdx.x = number of tiles) runs the WeightedPool / pooled-bias path (the column kernel
+    // is folded into k_cq_out then: launch_cq_out)
+    if (cp.pool_w && blockIdx.x == gridDim.x - 1) {          // (block-uniform)
+        extern __shared__ __attribute__((aligned(16))) float psm[];
+        cq_pool_body(Qf, qmask, cp, blockIdx.y, Lq, psm, psm + 128);
+        return;
+    }
     // S[i][j] = Cd[i].w4C + Qd[j].w4Q + (Cd[i] * w4mlu).Qd[j]   (:233-243) on a 32-clip tile; Cd / Qd = dropped-out C / Q.
     // The trilinear term is a 32 x 32 MFMA tile per 32 query words with K = 128 split over the four waves (partial tiles
     // summed in wave order through LDS); the two rank-1 terms and the row softmax use 8 lanes per row.
@@ -870,20 +930,22 @@ __global__ __launch_bounds__(256) void k_cq_score(const float* __restrict__ C, c
 }
 void launch_cq_score(const float* C, const float* Qf, const float* qmask, const float* w4C, const float* w4Q,
                      const float* w4mlu, float* S, float* Srow, int B, int T, int Lq, int b_off, Drop dc, Drop dq,
-                     hipStream_t s) {
+                     hipStream_t s, const CqPoolArgs* pool) {
+    CqPool cp{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (pool) cp = CqPool{pool->pool_w, pool->Wcat, pool->bcat, pool->alpha, pool->pooled, pool->pb};
     const int NTJ = (Lq + 31) / 32;
     const size_t shm = (size_t)((TILE_M + 32 * NTJ) * LDP + TILE_M + 32 * NTJ + 4 * TILE_M * (32 * NTJ + 1)) * sizeof(float);
     static size_t ok8 = 0, ok12 = 0, ok16 = 0;
-    const dim3 grid((T + TILE_M - 1) / TILE_M, B);
+    const dim3 grid((T + TILE_M - 1) / TILE_M + (pool ? 1 : 0), B);
     if (Lq <= 64) {
         ensure_dynamic_lds((const void*)k_cq_score<8>, shm, ok8, "k_cq_score<8>");
-        VSL_LAUNCH(k_cq_score<8>, grid, dim3(256), shm, s, C, Qf, qmask, w4C, w4Q, w4mlu, S, Srow, T, Lq, b_off, dc, dq);
+        VSL_LAUNCH(k_cq_score<8>, grid, dim3(256), shm, s, C, Qf, qmask, w4C, w4Q, w4mlu, S, Srow, T, Lq, b_off, dc, dq, cp);
     } else if (Lq <= 96) {
         ensure_dynamic_lds((const void*)k_cq_score<12>, shm, ok12, "k_cq_score<12>");
-        VSL_LAUNCH(k_cq_score<12>, grid, dim3(256), shm, s, C, Qf, qmask, w4C, w4Q, w4mlu, S, Srow, T, Lq, b_off, dc, dq);
+        VSL_LAUNCH(k_cq_score<12>, grid, dim3(256), shm, s, C, Qf, qmask, w4C, w4Q, w4mlu, S, Srow, T, Lq, b_off, dc, dq, cp);
     } else {
         ensure_dynamic_lds((const void*)k_cq_score<16>, shm, ok16, "k_cq_score<16>");
-        VSL_LAUNCH(k_cq_score<16>, grid, dim3(256), shm, s, C, Qf, qmask, w4C, w4Q, w4mlu, S, Srow, T, Lq, b_off, dc, dq);
+        VSL_LAUNCH(k_cq_score<16>, grid, dim3(256), shm, s, C, Qf, qmask, w4C, w4Q, w4mlu, S, Srow, T, Lq, b_off, dc, dq, cp);
     }
 }
 
@@ -983,50 +1045,9 @@ __global__ __launch_bounds__(256) void k_cq_col(const float* __restrict__ C, con
     }
     return;
     }
-    // ---- WeightedPool: alpha = softmax_j(Q[j].w + mask) ; pooled = sum_j alpha_j Q[j]
-    for (int jj = w; jj < Lq; jj += 4) {
-        const float* row = Qf + (qrow + jj) * D;
-        const float d = wave_sum(row[lane] * pool_w[lane] + row[lane + 64] * pool_w[lane + 64]);
-        if (lane == 0) al[jj] = d + (1.f - qmask[qrow + jj]) * MASK_VALUE;
-    }
-    __syncthreads();
-    if (w == 0) {                              // a lane owns words lane and lane + 64
-        const float v0 = lane < Lq ? al[lane] : -3.0e38f, v1 = lane + 64 < Lq ? al[lane + 64] : -3.0e38f;
-        const float mx = wave_max(fmaxf(v0, v1));
-        const float e0 = lane < Lq ? __expf(v0 - mx) : 0.f, e1 = lane + 64 < Lq ? __expf(v1 - mx) : 0.f;
-        const float inv = 1.0f / wave_sum(e0 + e1);
-        if (lane < Lq) { al[lane] = e0 * inv; alpha[qrow + lane] = e0 * inv; }
-        if (lane + 64 < Lq) { al[lane + 64] = e1 * inv; alpha[qrow + lane + 64] = e1 * inv; }
-    }
-    __syncthreads();
-    if (tid < D) {
-        float acc = 0.f;
-        for (int j0 = 0; j0 < Lq; j0 += 8) {        // eight rows in flight; same summation order as one row at a time
-            float qv[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) qv[u] = Qf[(qrow + min(j0 + u, Lq - 1)) * D + tid];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) if (j0 + u < Lq) acc += al[j0 + u] * qv[u];
-        }
-        pl[tid] = acc;
-        pooled[(size_t)b * D + tid] = acc;
-    }
-    __syncthreads();
-    // ---- pb[o] = sum_c Wcat[o][128 + c] * pooled[c] + bcat[o]     (second half of the 2d -> d Conv1D); 8 lanes per row
-    for (int o = tid >> 3; o < D; o += 32) {
-        const int sub = tid & 7;
-        const float* wr = Wcat + (size_t)o * 2 * D + D + sub * 4;
-        float d = 0.f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 wv = *reinterpret_cast<const float4*>(wr + 32 * q);
-            const float4 pv = *reinterpret_cast<const float4*>(pl + sub * 4 + 32 * q);
-            d += wv.x * pv.x + wv.y * pv.y + wv.z * pv.z + wv.w * pv.w;
-        }
-        d = grp8_sum(d);
-        if (sub == 0) pb[(size_t)b * D + o] = d + bcat[o];
-    }
+    cq_pool_body(Qf, qmask, CqPool{pool_w, Wcat, bcat, alpha, pooled, pb}, b, Lq, al, pl);
 }
+bool cq_col_folds(int T, int Lq) { return T <= 4 * TILE_M && Lq <= 32; }      // (k_cq_out's fold: at most four tiles per sample, one 32-word tile of M)
 void launch_cq_col(const float* C, const float* Qf, const float* S, const float* cmask, const float* qmask,
                    const float* pool_w, const float* Wcat, const float* bcat, float* Scol, float* Mpart, float* alpha,
                    float* pooled, float* pb, int B, int T, int Lq, hipStream_t s) {
@@ -1039,6 +1060,11 @@ void launch_cq_col(const float* C, const float* Qf, const float* S, const float*
 struct CqCatFuse {
     const float *W1pack, *pb, *wh, *bh, *vmask;
     float *f2, *hscore, *gated;
+    // the column kernel folded in (T <= 128, Lq <= 32: launch_cq_out): every workgroup computes its SAMPLE's column-softmax statistics and
+    // M = S_col^T C over all (at most four) tiles itself instead of summing k_cq_col's per-tile partials -- 4 x 16 KB of L2 reads and four small
+    // MFMA products per workgroup against a launch + a kernel boundary on the dependent chain.  S == nullptr: off.
+    const float *S, *cmask;
+    float* Scol;
 };
 __global__ __launch_bounds__(256) void k_cq_out(const float* __restrict__ C, const float* __restrict__ Qf,
                                                 const float* __restrict__ Srow, const float* __restrict__ Mpart,
@@ -1059,6 +1085,84 @@ __global__ __launch_bounds__(256) void k_cq_out(const float* __restrict__ C, con
     const size_t crow = (size_t)b * T, qrow = (size_t)b * Lq;
     BFrag<1, 16> bf;
     load_tile128(Cs, C + crow * D, t0, TILE_M, T);
+    if (cf.S) {                                // (block-uniform) k_cq_col's work for the whole sample, in the concat tile's LDS (dead until the concat)
+        constexpr int JS = 128;
+        float* Ct = Cat;                       // [32][LDP]   C tile of the pass
+        float* Sc = Ct + TILE_M * LDP;         // [32][LQ1] + 72   S_col tile (+ slack for the 32-wide over-read of gemm_tn)
+        float* redm = Sc + TILE_M * LQ1 + 72;  // [8][JS]
+        float* reds = redm + 8 * JS;           // [8][JS]
+        float* cmax = reds + 8 * JS;           // [JS]
+        float* cinv = cmax + JS;               // [JS]
+        const float* S = cf.S;
+        const float* cmask = cf.cmask;
+        const int JW = 32, np = 256 / JW;      // (Lq <= 32 here)
+        const int j = tid & (JW - 1), part = tid / JW;
+        auto walk = [&](auto&& fold) {
+            if (j >= Lq) return;
+            for (int i0 = part; i0 < T; i0 += 8 * np) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = min(i0 + u * np, T - 1);
+                    v[u] = S[(crow + i) * Lq + j] + (1.f - cmask[crow + i]) * MASK_VALUE;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) if (i0 + u * np < T) fold(v[u]);
+            }
+        };
+        {
+            float mx = -3.0e38f;
+            walk([&](float v) { mx = fmaxf(mx, v); });
+            redm[part * JS + j] = mx;
+        }
+        __syncthreads();
+        float gm = -3.0e38f;
+        for (int q = 0; q < np; ++q) gm = fmaxf(gm, redm[q * JS + j]);
+        {
+            float sm = 0.f;
+            walk([&](float v) { sm += __expf(v - gm); });
+            reds[part * JS + j] = sm;
+        }
+        __syncthreads();
+        if (tid < JW) {
+            float sm = 0.f;
+            for (int q = 0; q < np; ++q) sm += reds[q * JS + j];
+            cmax[j] = gm;
+            cinv[j] = 1.0f / sm;
+        }
+        if (tid < 72) Sc[TILE_M * LQ1 + tid] = 0.f;          // finite values where gemm_tn over-reads
+        f32x16 macc[1];
+        zero_acc(macc);
+        for (int tl = 0; tl < ntile; ++tl) {                 // M[j][c] = sum over ALL clips of the sample, tile by tile (k_cq_col's order within a tile)
+            const int tt0 = tl * TILE_M;
+            __syncthreads();                                 // the previous pass' product is done with Ct / Sc ; cmax / cinv are written
+            load_tile128(Ct, C + crow * D, tt0, TILE_M, T);
+            for (int e = tid; e < TILE_M * LQ1; e += 256) {
+                const int i = e / LQ1, jj = e - i * LQ1;
+                float v = 0.f;
+                if (jj < Lq && tt0 + i < T) {
+                    const size_t o = (crow + tt0 + i) * Lq + jj;
+                    v = __expf(S[o] + (1.f - cmask[crow + tt0 + i]) * MASK_VALUE - cmax[jj]) * cinv[jj];
+                    if (tl == (int)blockIdx.x) cf.Scol[o] = v;       // this workgroup's own tile (saved for the backward)
+                }
+                Sc[e] = v;
+            }
+            __syncthreads();
+            gemm_tn_p<1, TILE_M>(Sc, LQ1, 0, Ct, LDP, 32 * w, macc);
+        }
+        {
+            const int colm = 32 * w + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int jj = acc_row(r, lane);
+                if (jj < Lq) {
+                    Ms[jj * LDP + colm] = macc[0][r];
+                    if (blockIdx.x == 0) M[(qrow + jj) * D + colm] = macc[0][r];     // saved for the backward
+                }
+            }
+        }
+        __syncthreads();                                     // Cat's region is free for the concat again ; Ms is complete
+    } else
     for (int e = tid; e < Lq * (D / 4); e += 256) {
         const int j = e >> 5, c4 = (e & 31) * 4;
         float4 sm = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1182,13 +1286,14 @@ __global__ __launch_bounds__(256) void k_cq_out(const float* __restrict__ C, con
 }
 void launch_cq_out(const float* C, const float* Qf, const float* Srow, const float* Mpart, float* M, const float* Wpack,
                    const float* bias, float* cat_out, float* out, const float* W1pack, const float* pb, const float* wh,
-                   const float* bh, const float* vmask, float* f2, float* hscore, float* gated, int B, int T, int Lq, hipStream_t s) {
+                   const float* bh, const float* vmask, float* f2, float* hscore, float* gated, int B, int T, int Lq, hipStream_t s,
+                   const float* S_fold, float* Scol_fold) {
     const size_t shm = (Lq > CQ_BIG_LQ ? (size_t)(std::max(TILE_M * CATP, Lq * LDP) + TILE_M * LDP + TILE_M * (Lq + 1) + 32)
                                        : (size_t)(TILE_M * CATP + TILE_M * LDP + Lq * LDP + TILE_M * (Lq + 1) + 32)) * sizeof(float);
     static size_t lds_ok = 0;
     ensure_dynamic_lds((const void*)k_cq_out, shm, lds_ok, "k_cq_out");
     VSL_LAUNCH(k_cq_out, dim3((T + TILE_M - 1) / TILE_M, B), dim3(256), shm, s, C, Qf, Srow, Mpart, M, Wpack, bias, cat_out, out,
-                       T, Lq, CqCatFuse{W1pack, pb, wh, bh, vmask, f2, hscore, gated});
+                       T, Lq, CqCatFuse{W1pack, pb, wh, bh, vmask, f2, hscore, gated, S_fold, S_fold ? vmask : nullptr, Scol_fold});
 }
 
 

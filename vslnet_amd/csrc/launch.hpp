@@ -270,15 +270,20 @@ struct QueryFwdArgs {
 };
 bool query_fused_ok(int L, int H, int EW);         // does the sample-local path take this query length / embedding width?
 void launch_query_fwd(const QueryFwdArgs& a, int B, hipStream_t s);
+// the column kernel folded away (cq_col_folds): k_cq_score gets one extra workgroup per sample for the WeightedPool / pooled-bias path (`pool`),
+// k_cq_out computes the sample's column softmax and M itself (S_fold / Scol_fold) and launch_cq_col is not called
+struct CqPoolArgs { const float *pool_w, *Wcat, *bcat; float *alpha, *pooled, *pb; };
+bool cq_col_folds(int T, int Lq);
 void launch_cq_score(const float* C, const float* Qf, const float* qmask, const float* w4C, const float* w4Q,
                      const float* w4mlu, float* S, float* Srow, int B, int T, int Lq, int b_off, Drop dc, Drop dq,
-                     hipStream_t s);
+                     hipStream_t s, const CqPoolArgs* pool = nullptr);
 void launch_cq_col(const float* C, const float* Qf, const float* S, const float* cmask, const float* qmask,
                    const float* pool_w, const float* Wcat, const float* bcat, float* Scol, float* Mpart /*[B][ntile][Lq][128]*/,
                    float* alpha, float* pooled, float* pb, int B, int T, int Lq, hipStream_t s);
 void launch_cq_out(const float* C, const float* Qf, const float* Srow, const float* Mpart, float* M, const float* Wpack,
                    const float* bias, float* cat_out, float* out, const float* W1pack, const float* pb, const float* wh,
-                   const float* bh, const float* vmask, float* f2, float* hscore, float* gated, int B, int T, int Lq, hipStream_t s);
+                   const float* bh, const float* vmask, float* f2, float* hscore, float* gated, int B, int T, int Lq, hipStream_t s,
+                   const float* S_fold = nullptr, float* Scol_fold = nullptr);
 void launch_head_fwd(const HeadArgs& a0, const HeadArgs& a1, const float* x, const float* vmask, int R, hipStream_t s);
 
 // ---------------------------------------------------------------- losses / eval
