@@ -68,7 +68,7 @@ def test_which_launches_a_step_takes_and_what_the_ledger_records():
 
         def step(i):
             eng.forward(flat, pad_vec, glove_vec, bt['word_ids'], bt['char_ids'], bt['vfeats'], bt['v_mask'], bt['q_mask'], training=True, seed=i)
-            _, d_h, d_sl, d_el = eng.loss(bt['s_labels'], bt['e_labels'], bt['h_labels'], 1.0, 5.0, inv_batch=0.25, mask_sum=float(bt['v_mask'].sum()))
+            _, d_h, d_sl, d_el = eng.loss(bt['s_labels'], bt['e_labels'], bt['h_labels'], 1.0, 5.0, inv_batch=0.25, mask_sum=float(bt['v_mask'].sum()), lazy=True)
             backward_exchange_step(eng, None, grads, (d_h, d_sl, d_el), opt)        # (as main.train and bench.py)
         step(0)
         eng.profile_select('*')
