@@ -95,7 +95,7 @@ typedef struct {
     const struct vsl_fused_step* fused_step;
     /* optional (NULL = off): vsl_loss folded into vsl_backward -- the call first does what vsl_loss(h, io, fused_loss) does (losses and the three
      * seeds are written exactly as vsl_loss writes them; complete when vsl_backward's work on the caller's stream is), then runs the backward
-     * from those seeds; vsl_io.d_h_score / d_start_logits / d_end_logits are ignored.  For whole tiles (T % 32 == 0) with the caller's mask_sum
+     * from those seeds; vsl_io.d_h_score / d_start_logits / d_end_logits are ignored.  For T >= 32 with the caller's mask_sum
      * the loss launch leaves the dependent chain: the span heads' and the highlight layer's backward compute their seeds from the logits
      * themselves (VSLNet_t7.py:67-72 and main_t7.py:107-110 as one call). */
     const struct vsl_loss_io* fused_loss;

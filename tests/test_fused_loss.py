@@ -1,6 +1,7 @@
 """vsl_io.fused_loss (round 6): the loss folded into vsl_backward (`Engine.loss(lazy=True)` + `backward()` on its seeds).
 
-For whole tiles (T % 32 == 0) with the caller's mask sum the loss kernel leaves the dependent chain -- it rides on the weight-gradient stream -- and the
+For T >= 32 (a row tile then touches at most two samples) with the caller's mask sum the loss kernel leaves the dependent chain -- it runs behind the
+main stream's last kernel -- and the
 span heads' backward and the highlight layer's backward compute their seeds from the logits themselves (the same expressions: tile_bodies.hpp
 loss_ce_seed / loss_hl_seed, kernels_bwd.hip loss_sample_lse).  Whatever the path: the same losses, the same seeds, the same gradients as
 loss() followed by backward()."""
@@ -13,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize('B,T,predictor,mask_sum_given', [(4, 64, 'transformer', True), (3, 128, 'transformer', True), (5, 40, 'transformer', True),
-                                                          (4, 64, 'transformer', False), (4, 64, 'rnn', True), (2, 320, 'transformer', True)])
+                                                          (4, 64, 'transformer', False), (4, 64, 'rnn', True), (2, 320, 'transformer', True), (6, 24, 'transformer', True), (3, 117, 'transformer', True)])
 def test_lazy_loss_rides_in_the_backward(B, T, predictor, mask_sum_given):
     from vslnet_amd.engine import Engine, flat_from_state_dict
     cfg = O.make_cfg(video_feature_dim=64, max_pos_len=max(T, 16), word_size=52, predictor=predictor, drop_rate=0.2)

@@ -1092,7 +1092,7 @@ void run_backward(Ctx& c) {
         seed_s = fl ? fl->d_start_logits : io->d_start_logits; seed_e = fl ? fl->d_end_logits : io->d_end_logits; seed_h = fl ? fl->d_h_score : io->d_h_score;
         if (fl) {
             static const bool inline_on = !(getenv("VSL_LOSS_INLINE") && getenv("VSL_LOSS_INLINE")[0] == '0');
-            seeds_inline = inline_on && T % TILE_M == 0 && fl->mask_sum > 0.f && c.h->loss_counter != nullptr;
+            seeds_inline = inline_on && T >= TILE_M && fl->mask_sum > 0.f && c.h->loss_counter != nullptr;       // (T >= 32: a row tile touches at most two samples)
             c.pend_loss = fl;
             if (!seeds_inline) loss_on_side(c);            // (here and now, on the caller's stream: the seeds are read from memory)
             else hlseed = HlSeed{fl->h_labels, io->v_mask, fl->w_highlight, fl->mask_sum};

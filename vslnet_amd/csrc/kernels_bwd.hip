@@ -324,10 +324,15 @@ __global__ __launch_bounds__(256) void k_head_bwd(HeadBwdArgs a0, HeadBwdArgs a1
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int r0 = blockIdx.x * TILE_M;
     BFrag<2, 8> bf;
-    if (a.logits) {                        // (block-uniform) vsl_io.fused_loss: the tile lies inside ONE sample (T % 32 == 0); its seeds from the sample's logits
-        const int b = r0 / a.T;
-        const float lse = loss_sample_lse(a.logits + (size_t)b * a.T, a.T, red);
-        if (tid < TILE_M) dl[tid] = r0 + tid < R ? loss_ce_seed(a.logits[r0 + tid], lse, r0 + tid - b * a.T, (int)a.label[b], a.cs) : 0.f;
+    if (a.logits) {                        // (block-uniform) vsl_io.fused_loss: the tile's seeds from its samples' logits.  T >= 32: a tile touches at most two samples
+        const int b0 = r0 / a.T, b1 = min(r0 + TILE_M - 1, R - 1) / a.T;
+        const float lse0 = loss_sample_lse(a.logits + (size_t)b0 * a.T, a.T, red);
+        float lse1 = lse0;
+        if (b1 != b0) { __syncthreads(); lse1 = loss_sample_lse(a.logits + (size_t)b1 * a.T, a.T, red); }      // (block-uniform)
+        if (tid < TILE_M) {
+            const int r = r0 + tid, b = r / a.T;
+            dl[tid] = r < R ? loss_ce_seed(a.logits[r], b == b0 ? lse0 : lse1, r - b * a.T, (int)a.label[b], a.cs) : 0.f;
+        }
     } else
     if (tid < TILE_M) dl[tid] = r0 + tid < R ? a.dlogit[r0 + tid] : 0.f;
     load_tile128(Hs, a.hid, r0, TILE_M, R);

@@ -298,7 +298,7 @@ class Engine:
         """Fused compute_loss + compute_highlight_loss.  By default on the outputs of the LAST forward; explicit
         (B, T) tensors may be passed instead.  Returns (losses[4], d_h, d_sl, d_el).
         `lazy=True` (training steps: what `main.train` and `bench.py` do): nothing is launched here -- the loss becomes part of the next
-        `backward()` on the returned seeds (vsl_io.fused_loss: for whole tiles the loss kernel then leaves the dependent chain and the consumers of
+        `backward()` on the returned seeds (vsl_io.fused_loss: for T >= 32 the loss kernel then leaves the dependent chain and the consumers of
         the seeds compute them from the logits); `losses` and the seeds are valid once that backward's work is.  Any other use of the engine
         in between (another forward / loss / a backward on other seeds) issues the pending loss first."""
         io = self._last
