@@ -69,8 +69,10 @@ struct Plan {
     LstmWs lstm[2];
     int64_t h_gran = -1, gi_gran = -1, dg_gran = -1, dx_gran = -1;     // granule buffers of the fused rnn head (8 bytes per value); -1: chunked launches
     int64_t gran_floats = 0;                // their total extent (contiguous in the workspace, from h_gran)
-    long long gran_gen = -1;                // epoch generation and workspace these buffers were last cleared for (rnn_granules_fresh)
-    const void* gran_ws = nullptr;
+    // epoch generation and workspace these buffers were last cleared for (rnn_granules_fresh): the last four workspaces, so that a caller who
+    // alternates two or three of them (double buffering) does not pay a memset of the granule range in every forward
+    struct GranSeen { const void* ws = nullptr; long long gen = -1; } gran_seen[4];
+    int gran_next = 0;
     int64_t S, Srow, Scol, M, alpha, pooled, pb, cat, f1, f2, gated, hid_s, hid_e, lnf_s, lnf_e;
     // backward temporaries
     int64_t loss_scratch, gz_s, gz_e, dfeat_s, dfeat_e, dxh_s, dxh_e, g_s1, g_gated;
@@ -672,9 +674,11 @@ unsigned rnn_epoch(long long* gen = nullptr) {
 
 // first use of a plan's granule buffers in this workspace, or the epoch counter has wrapped since: one memset on the launch stream
 static void rnn_granules_fresh(Ctx& c, Plan& p, long long gen) {
-    if (p.gran_ws == (const void*)c.ws && p.gran_gen == gen) return;
+    for (const Plan::GranSeen& g : p.gran_seen)
+        if (g.ws == (const void*)c.ws && g.gen == gen) return;
     (void)hipMemsetAsync(c.W(p.h_gran), 0, (size_t)p.gran_floats * sizeof(float), c.s);
-    p.gran_ws = c.ws; p.gran_gen = gen;
+    p.gran_seen[p.gran_next] = Plan::GranSeen{c.ws, gen};
+    p.gran_next = (p.gran_next + 1) & 3;
 }
 
 // Lq <= 32: the query branch runs as sample-local launches (kernels_query.hip) in both directions
