@@ -344,6 +344,9 @@ __device__ __forceinline__ f32x16 mfma_bf16(u32x4_t a, u32x4_t b, f32x16 c) {
 __device__ __forceinline__ f32x4 mfma16_bf16(u32x4_t a, u32x4_t b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
+// [rows][16] bf16 plane of a head slice (the attention kernels of L > 256): element offset of dims [8 half, 8 half + 8) of row `row`.  The two 16-byte
+// halves of a row swap places every 8 rows, so the 16 lanes of a ds_read_b128 phase (16 consecutive rows, one half) cover all 64 banks once without padding
+__device__ __forceinline__ int af_kp(int row, int half) { return row * 16 + ((half ^ ((row >> 3) & 1)) << 3); }
 // host-side / k_pack: the three terms of one value (bf16 bit patterns)
 __host__ __device__ __forceinline__ float bf16_to_f32(uint16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; }
 __host__ __device__ __forceinline__ void split3_scalar(float x, uint16_t& h, uint16_t& m, uint16_t& l) {

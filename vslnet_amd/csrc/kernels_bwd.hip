@@ -583,7 +583,7 @@ __global__ __launch_bounds__(1024) void k_attn_bwd_fused(const float* __restrict
 // dK / dV are complete; dQ is a partial over this key block and goes to slab `kb` of dQ (slab stride = the (R, 128) tensor): k_qkv_bwd adds
 // the slabs while it stages its tile (and leaves the sum in slab 0 for the weight gradient).  122 KB of LDS, one workgroup per CU.
 constexpr int ABL_KB = 256;
-constexpr size_t abl_lds() { return (size_t)(2 * ABL_KB * AB_KST + ABL_KB + AB_QP * (ABL_KB + 4) + 2 * AB_QP * AB_KST + 2 * AB_QP) * sizeof(float); }
+constexpr size_t abl_lds() { return (size_t)(2 * ABL_KB * AB_KST + ABL_KB + AB_QP * (ABL_KB + 4) + 2 * AB_QP * AB_KST + 2 * AB_QP) * sizeof(float) + (size_t)2 * 3 * AB_QP * 16 * sizeof(uint16_t); }
 __global__ __launch_bounds__(1024) void k_attn_bwd_long(const float* __restrict__ Q, const float* __restrict__ K,
                                                         const float* __restrict__ V, const float* __restrict__ att,
                                                         const float* __restrict__ dr, const float* __restrict__ lse,
@@ -600,6 +600,12 @@ __global__ __launch_bounds__(1024) void k_attn_bwd_long(const float* __restrict_
     float* As = Qs + AB_QP * AB_KST;            // [64][20] dA = dr * m3
     float* Ls = As + AB_QP * AB_KST;            // [64] LSE
     float* Ds = Ls + AB_QP;                     // [64] D = dA . O
+    // S = Q K^T and dP = dA V^T contract over the 16 head dims: on the bf16 matrix cores at fp32 grade like k_attn_fwd's K Q^T (three
+    // v_mfma_f32_16x16x32_bf16 per product: the six split products, two per instruction) -- 96 pipe cycles that overlap with the vector work instead
+    // of 256 of the fp32-input MFMA that do not.  Q and dA of the pass are split ONCE by the staging threads into three bf16 planes each.
+    uint16_t* Qp = reinterpret_cast<uint16_t*>(Ds + AB_QP);     // [3 terms][64][16] (af_kp)
+    uint16_t* Ap = Qp + 3 * AB_QP * 16;                         // [3 terms][64][16]
+    constexpr int QPL = AB_QP * 16;
     const int Lp = (L + 15) & ~15;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     int kb, h, b;
@@ -651,6 +657,18 @@ __global__ __launch_bounds__(1024) void k_attn_bwd_long(const float* __restrict_
             }
             *reinterpret_cast<float4*>(&Qs[rl * AB_KST + c4]) = nq;
             *reinterpret_cast<float4*>(&As[rl * AB_KST + c4]) = av;
+            {
+                uint32_t h0, m0, l0, h1, m1, l1;
+                const int po = af_kp(rl, c4 >> 3) + (c4 & 7);
+                split3(nq.x, nq.y, h0, m0, l0); split3(nq.z, nq.w, h1, m1, l1);
+                *reinterpret_cast<u32x2_t*>(Qp + po) = u32x2_t{h0, h1};
+                *reinterpret_cast<u32x2_t*>(Qp + QPL + po) = u32x2_t{m0, m1};
+                *reinterpret_cast<u32x2_t*>(Qp + 2 * QPL + po) = u32x2_t{l0, l1};
+                split3(av.x, av.y, h0, m0, l0); split3(av.z, av.w, h1, m1, l1);
+                *reinterpret_cast<u32x2_t*>(Ap + po) = u32x2_t{h0, h1};
+                *reinterpret_cast<u32x2_t*>(Ap + QPL + po) = u32x2_t{m0, m1};
+                *reinterpret_cast<u32x2_t*>(Ap + 2 * QPL + po) = u32x2_t{l0, l1};
+            }
             float dsum = av.x * no.x + av.y * no.y + av.z * no.z + av.w * no.w;     // D_q = dA . O (= sum_k dP_k P_k)
             dsum += lane_xor1(dsum);
             dsum += lane_xor2(dsum);
@@ -659,11 +677,25 @@ __global__ __launch_bounds__(1024) void k_attn_bwd_long(const float* __restrict_
     };
     fetch(0);
     __syncthreads();
+    // B operands of the wave's key tile (column = key ki; k group g < 2: dims 8 g .. of the first term of the pair, g >= 2: dims 8 (g - 2) .. of the
+    // second):  [Q_h | Q_m] x [K_h | K_h] + [Q_h | Q_l] x [K_m | K_h] + [Q_h | Q_m] x [K_l | K_m], the same with (dA, V)
+    u32x4_t bk1, bk2, bk3, bv1, bv2, bv3;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { bk1[e] = bk2[e] = bk3[e] = bv1[e] = bv2[e] = bv3[e] = 0u; }
     if (has_keys) {
-        kf = *reinterpret_cast<const float4*>(&Ks[keyl * AB_KST + 4 * g]);
-        vf = *reinterpret_cast<const float4*>(&Vs[keyl * AB_KST + 4 * g]);
         mb = Mb[keyl];
+        auto split8 = [&](const float* row, u32x4_t& b1, u32x4_t& b2, u32x4_t& b3) {
+            const float4 xa = *reinterpret_cast<const float4*>(row + 8 * (g & 1)), xb = *reinterpret_cast<const float4*>(row + 8 * (g & 1) + 4);
+            uint32_t th[4], tm[4], tl[4];
+            split3(xa.x, xa.y, th[0], tm[0], tl[0]); split3(xa.z, xa.w, th[1], tm[1], tl[1]);
+            split3(xb.x, xb.y, th[2], tm[2], tl[2]); split3(xb.z, xb.w, th[3], tm[3], tl[3]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { b1[e] = th[e]; b2[e] = g < 2 ? tm[e] : th[e]; b3[e] = g < 2 ? tl[e] : tm[e]; }
+        };
+        split8(&Ks[keyl * AB_KST], bk1, bk2, bk3);
+        split8(&Vs[keyl * AB_KST], bv1, bv2, bv3);
     }
+    const int pa1 = (g < 2 ? 0 : 1) * QPL, pa2 = (g < 2 ? 0 : 2) * QPL;        // A operands: planes (h | m) and (h | l) by k group
     for (int qb = 0; qb < Lp; qb += AB_QP) {
         const int qe = min(qb + AB_QP, Lp);
         stage(qb);
@@ -672,17 +704,16 @@ __global__ __launch_bounds__(1024) void k_attn_bwd_long(const float* __restrict_
         if (has_keys) {
             for (int qt = qb; qt < qe; qt += 16) {
                 const int ql0 = qt - qb;
-                const float4 qa = *reinterpret_cast<const float4*>(&Qs[(ql0 + ki) * AB_KST + 4 * g]);
-                const float4 aa = *reinterpret_cast<const float4*>(&As[(ql0 + ki) * AB_KST + 4 * g]);
+                const int ao = af_kp(ql0 + ki, g & 1);
+                const u32x4_t q1 = *reinterpret_cast<const u32x4_t*>(Qp + pa1 + ao), q2 = *reinterpret_cast<const u32x4_t*>(Qp + pa2 + ao);
+                const u32x4_t a1 = *reinterpret_cast<const u32x4_t*>(Ap + pa1 + ao), a2 = *reinterpret_cast<const u32x4_t*>(Ap + pa2 + ao);
                 f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-                sc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa.x, kf.x, sc, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x4f32(aa.x, vf.x, dp, 0, 0, 0);
-                sc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa.y, kf.y, sc, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x4f32(aa.y, vf.y, dp, 0, 0, 0);
-                sc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa.z, kf.z, sc, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x4f32(aa.z, vf.z, dp, 0, 0, 0);
-                sc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa.w, kf.w, sc, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x4f32(aa.w, vf.w, dp, 0, 0, 0);
+                sc = mfma16_bf16(q1, bk3, sc);          // hl + mm (small terms first)
+                dp = mfma16_bf16(a1, bv3, dp);
+                sc = mfma16_bf16(q2, bk2, sc);          // hm + lh
+                dp = mfma16_bf16(a2, bv2, dp);
+                sc = mfma16_bf16(q1, bk1, sc);          // hh + mh
+                dp = mfma16_bf16(a1, bv1, dp);
                 // dropout of the probabilities as the forward drew it (k_attn_fwd): keys 2 j, 2 j + 1 of a query row share one hash.  The lane
                 // and its neighbour (the other key of the pair, same four queries) hash two queries each and exchange the words.
                 float m2v[4] = {1.f, 1.f, 1.f, 1.f};

@@ -460,9 +460,6 @@ void launch_linear_fwd(const float* A, const float* Wpack, const float* bias, fl
 constexpr int AF_KB = VSL_AF_KB;    // keys staged per block: 45 KB of LDS whatever L is -> 3 workgroups per CU at L = 1024
 constexpr int AF_NJ = AF_KB * 4 / 256;
 constexpr float AF_LOG2E = 1.4426950408889634f, AF_LN2 = 0.6931471805599453f;
-// element offset of dims [8 half, 8 half + 8) of key `key` inside a [keys][16] bf16 plane: the two 16-byte halves of a row swap places every 8 keys,
-// so the 16 lanes of a ds_read_b128 phase (16 consecutive keys, one half) cover all 64 banks once without padding
-__device__ __forceinline__ int af_kp(int key, int half) { return key * 16 + ((half ^ ((key >> 3) & 1)) << 3); }
 __global__ __launch_bounds__(256) void k_attn_fwd(const float* __restrict__ Q, const float* __restrict__ K,
                                                   const float* __restrict__ V, const float* __restrict__ mask,
                                                   float* __restrict__ att, float* __restrict__ lse, int L, int H,
