@@ -1387,11 +1387,12 @@ void run_backward(Ctx& c) {
     }
     if (cf.word_table && !c.dry)
         LAUNCH("word_table_bwd", launch_word_table_bwd(c.W(p.dE), io->word_ids, io->grads + P.unk, Rq, cf.word_size, cf.word_dim, c.drop(SITE_WORD), c.s));
-    c.s = main_s;
-    // the loss of vsl_io.fused_loss whose seeds the kernels computed themselves: 64 small workgroups behind the main stream's last kernel, in the
-    // shadow of the join below (at the headline shape the main stream ends ~30 us before the video stream's last weight-gradient batch).  On the
-    // weight-gradient stream in front of its first batch it took CUs from the chain's 256-workgroup kernels and cost what it saved (r06 notes 10)
+    // the loss of vsl_io.fused_loss whose seeds the kernels computed themselves: 64 small workgroups behind the QUERY chain's last kernel (the main
+    // stream at T <= 128), in the shadow of the join below (at the headline shape that chain ends ~30 us before the video stream's last weight-gradient
+    // batch).  On the weight-gradient stream in front of its first batch it took CUs from the chain's 256-workgroup kernels and cost what it saved
+    // (r06 notes 10)
     loss_on_side(c);
+    c.s = main_s;
     c.order(sq, c.s);                      // join both side streams before the reduction
     c.order(sw, c.s);
     const int nlate = p.nblocks - p.nblocks_early;
