@@ -584,6 +584,9 @@ __global__ __launch_bounds__(1024) void k_attn_bwd_fused(const float* __restrict
 // the slabs while it stages its tile (and leaves the sum in slab 0 for the weight gradient).  122 KB of LDS, one workgroup per CU.
 constexpr int ABL_KB = 256;
 constexpr size_t abl_lds() { return (size_t)(2 * ABL_KB * AB_KST + ABL_KB + AB_QP * (ABL_KB + 4) + 2 * AB_QP * AB_KST + 2 * AB_QP) * sizeof(float) + (size_t)2 * 3 * AB_QP * 16 * sizeof(uint16_t); }
+// PAIR: the probability site's masks are keyed by key PAIRS (the forward of L > 256, k_attn_fwd) ; false: one hash per element (the forward of
+// L <= 256, k_attn_block_fwd) -- the kernel then serves 128 < L <= 256 as ONE key block (launch_attn_bwd)
+template <bool PAIR>
 __global__ __launch_bounds__(1024) void k_attn_bwd_long(const float* __restrict__ Q, const float* __restrict__ K,
                                                         const float* __restrict__ V, const float* __restrict__ att,
                                                         const float* __restrict__ dr, const float* __restrict__ lse,
@@ -717,6 +720,10 @@ __global__ __launch_bounds__(1024) void k_attn_bwd_long(const float* __restrict_
                 // dropout of the probabilities as the forward drew it (k_attn_fwd): keys 2 j, 2 j + 1 of a query row share one hash.  The lane
                 // and its neighbour (the other key of the pair, same four queries) hash two queries each and exchange the words.
                 float m2v[4] = {1.f, 1.f, 1.f, 1.f};
+                if (!PAIR) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) m2v[r] = drop_mul(d2, (hb + (uint32_t)(qb + ql0 + 4 * g + r)) * (uint32_t)L + (uint32_t)(k0 + keyl));
+                } else
                 if (d2.thresh != 0u) {
                     const uint32_t Lh = (uint32_t)((L + 1) >> 1), kp = (uint32_t)((k0 + keyl) >> 1);
                     const int odd = ki & 1;
@@ -784,6 +791,10 @@ __global__ __launch_bounds__(1024) void k_attn_bwd_long(const float* __restrict_
         *reinterpret_cast<float4*>(dV + off) = make_float4(dv[0], dv[1], dv[2], dv[3]);
     }
 }
+static bool attn_bwd_256_as_block() {
+    static const bool on = !(getenv("VSL_ATTN_BWD_256") && !strcmp(getenv("VSL_ATTN_BWD_256"), "fused"));
+    return on;
+}
 int attn_bwd_dq_slabs(int L) { const int Lp = (L + 15) & ~15; return Lp <= 256 ? 1 : (Lp + ABL_KB - 1) / ABL_KB; }
 void launch_attn_bwd(const float* Q, const float* K, const float* V, const float* att, const float* dr, const float* lse,
                      const float* mask, float* dQ, float* dK, float* dV, int B, int L, int H, int b_off, Drop d2,
@@ -795,6 +806,13 @@ void launch_attn_bwd(const float* Q, const float* K, const float* V, const float
             ensure_dynamic_lds((const void*)k_attn_bwd_fused<128>, ab_lds<128>(), ok128, "k_attn_bwd_fused<128>");
             VSL_LAUNCH(k_attn_bwd_fused<128>, dim3(H, B), dim3(1024), ab_lds<128>(), s, Q, K, V, att, dr, lse, mask, dQ, dK, dV, L, H,
                                b_off, d2, d3);
+        } else if (attn_bwd_256_as_block()) {
+            // 128 < L <= 256 as ONE 256-key block of the L > 256 kernel (S and dP on the bf16 pipe, Q / dA streamed in passes of 64), element hashes
+            static size_t okb = 0;
+            ensure_dynamic_lds((const void*)k_attn_bwd_long<false>, abl_lds(), okb, "k_attn_bwd_long<false>");
+            VSL_LAUNCH(k_attn_bwd_long<false>, dim3(1, H, B), dim3(1024), abl_lds(), s, Q, K, V, att, dr, lse, mask, dQ, dK, dV,
+                       L, H, b_off, (size_t)B * L * D, d2, d3);
+            return;
         } else {
             ensure_dynamic_lds((const void*)k_attn_bwd_fused<256>, ab_lds<256>(), ok256, "k_attn_bwd_fused<256>");
             VSL_LAUNCH(k_attn_bwd_fused<256>, dim3(H, B), dim3(1024), ab_lds<256>(), s, Q, K, V, att, dr, lse, mask, dQ, dK, dV, L, H,
@@ -806,8 +824,8 @@ void launch_attn_bwd(const float* Q, const float* K, const float* V, const float
     }
     // L > 256: one pass over S / dP per key block of 256; dQ arrives as attn_bwd_dq_slabs(L) partial slabs (k_qkv_bwd adds them)
     static size_t okl = 0;
-    ensure_dynamic_lds((const void*)k_attn_bwd_long, abl_lds(), okl, "k_attn_bwd_long");
-    VSL_LAUNCH(k_attn_bwd_long, dim3((Lp + ABL_KB - 1) / ABL_KB, H, B), dim3(1024), abl_lds(), s, Q, K, V, att, dr, lse, mask, dQ, dK, dV,
+    ensure_dynamic_lds((const void*)k_attn_bwd_long<true>, abl_lds(), okl, "k_attn_bwd_long");
+    VSL_LAUNCH(k_attn_bwd_long<true>, dim3((Lp + ABL_KB - 1) / ABL_KB, H, B), dim3(1024), abl_lds(), s, Q, K, V, att, dr, lse, mask, dQ, dK, dV,
                L, H, b_off, (size_t)B * L * D, d2, d3);
 }
 
