@@ -619,7 +619,8 @@ void enc_fwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float*
         }
         LAUNCH("convblock_fwd", launch_convblock_fwd(a, c.s));
     }
-    if (H == 8 && L <= 256) {      // longer sequences: K / V staged in LDS per 64 queries wins (T = 1024: 3.29 vs 3.33 ms)
+    static const bool fwd256_block = getenv("VSL_ATTN_FWD_256") && !strcmp(getenv("VSL_ATTN_FWD_256"), "block");
+    if (H == 8 && (L <= 128 || (L <= 256 && (fwd256_block || ht)))) {      // longer sequences: K / V staged in LDS per 64 queries (k_attn_fwd + k_attn_out_fwd)
         AttnBlockArgs ab;
         memset(&ab, 0, sizeof ab);
         if (!c.dry) {

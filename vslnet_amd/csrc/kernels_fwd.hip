@@ -460,6 +460,8 @@ void launch_linear_fwd(const float* A, const float* Wpack, const float* bias, fl
 constexpr int AF_KB = VSL_AF_KB;    // keys staged per block: 45 KB of LDS whatever L is -> 3 workgroups per CU at L = 1024
 constexpr int AF_NJ = AF_KB * 4 / 256;
 constexpr float AF_LOG2E = 1.4426950408889634f, AF_LN2 = 0.6931471805599453f;
+// PAIR: two dropout decisions per hash (L > 256) ; false: one hash per element, the masks of L <= 256 (the kernel then serves 128 < L <= 256 too)
+template <bool PAIR>
 __global__ __launch_bounds__(256) void k_attn_fwd(const float* __restrict__ Q, const float* __restrict__ K,
                                                   const float* __restrict__ V, const float* __restrict__ mask,
                                                   float* __restrict__ att, float* __restrict__ lse, int L, int H,
@@ -581,7 +583,11 @@ __global__ __launch_bounds__(256) void k_attn_fwd(const float* __restrict__ Q, c
                 float pr[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { pr[r] = __builtin_amdgcn_exp2f(x[t][r] - mn); l += pr[r]; }
-                if (dropon) {
+                if (dropon && !PAIR) {
+                    const uint32_t ei = (uint32_t)(((size_t)(b + b_off) * H + h) * L + q) * (uint32_t)L + (uint32_t)(kb0 + kt + 16 * t + 4 * g);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pr[r] = drop_hash(ei + r, d2.seed, d2.key) >= d2.thresh ? pr[r] * d2.scale : 0.f;
+                } else if (dropon) {
                     const uint32_t pi = prow + (uint32_t)((kb0 + kt + 16 * t + 4 * g) >> 1);
                     const uint32_t h0 = drop_hash(pi, d2.seed, d2.key), h1 = drop_hash(pi + 1u, d2.seed, d2.key);
                     pr[0] = h0 >= d2.thresh ? pr[0] * d2.scale : 0.f;
@@ -613,9 +619,14 @@ void launch_attn_fwd(const float* Q, const float* K, const float* V, const float
     const int Lp = (L + 63) & ~63;
     const int KB = Lp < AF_KB ? Lp : AF_KB;
     const size_t shm = (size_t)(KB * 20 + KB) * sizeof(float) + (size_t)3 * KB * 16 * sizeof(uint16_t);
-    static size_t lds_ok = 0;
-    ensure_dynamic_lds((const void*)k_attn_fwd, shm, lds_ok, "k_attn_fwd");
-    VSL_LAUNCH(k_attn_fwd, dim3((L + 63) / 64, H, B), dim3(256), shm, s, Q, K, V, mask, att, lse, L, H, b_off, d2);
+    static size_t lds_ok = 0, lds_ok_e = 0;
+    if (L > 256) {
+        ensure_dynamic_lds((const void*)k_attn_fwd<true>, shm, lds_ok, "k_attn_fwd");
+        VSL_LAUNCH(k_attn_fwd<true>, dim3((L + 63) / 64, H, B), dim3(256), shm, s, Q, K, V, mask, att, lse, L, H, b_off, d2);
+    } else {
+        ensure_dynamic_lds((const void*)k_attn_fwd<false>, shm, lds_ok_e, "k_attn_fwd<false>");
+        VSL_LAUNCH(k_attn_fwd<false>, dim3((L + 63) / 64, H, B), dim3(256), shm, s, Q, K, V, mask, att, lse, L, H, b_off, d2);
+    }
 }
 
 // =========================================================================================================
