@@ -16,10 +16,10 @@ takes) -- the training suite's whole-tile shapes select the fused paths, so it i
 
 Round 6: VSL_QUERY_FUSED=0 -- the query branch as row-tile launches (linear_fwd + convblock_fwd<0> + attn_block_fwd / attn_out_bwd + attn_bwd +
 convblock_bwd<0>) instead of the sample-local k_query_fwd / k_query_bwd that every Lq <= 32 shape now selects; what Lq > 32 takes.  Same re-run.
-Later in round 6: VSL_CQ_FOLD=0 (k_cq_col as its own launch: what T > 128 or Lq > 32 takes), VSL_TAIL_ROWS=0 (256-row chunks for the step's last
-weight-gradient batch too) and VSL_LOSS_INLINE=0 / VSL_FUSED_TAIL=1 (the lazy loss in front of the heads' backward; the final reduction and AdamW as
-one launch), the last two through tests/test_fused_loss.py and tests/test_optimizer.py, which drive those paths; VSL_ATTN_BWD_256=fused (k_attn_bwd_fused<256>
-for 128 < L <= 256 instead of one 256-key block of k_attn_bwd_long) and VSL_ATTN_FWD_256=block (k_attn_block_fwd<2> instead of k_attn_fwd + k_attn_out_fwd there)."""
+Later in round 6: VSL_CQ_FOLD=0 (k_cq_col as its own launch: what T > 128 or Lq > 32 takes) and VSL_LOSS_INLINE=0 / VSL_FUSED_TAIL=1 (the lazy loss in front
+of the heads' backward; the final reduction and AdamW as one launch), the last two also through tests/test_fused_loss.py and tests/test_optimizer.py, which drive
+those paths.  (The variants round 6 replaced outright left no switch: k_attn_block_fwd<2> and k_attn_bwd_fused<256> for 128 < L <= 256, 256-row chunks for the step's
+last weight-gradient batch, the unmerged tail batch -- their A/B numbers are in profiles/r06_notes.md.)"""
 import os
 import subprocess
 import sys
@@ -46,7 +46,7 @@ def test_rnn_suite_with_the_chunked_launches():
 
 
 def test_training_suite_with_the_unfused_launches():
-    e = dict(os.environ, VSL_QKV_FUSED='0', VSL_HEADS_FUSED='0', VSL_QUERY_FUSED='0', VSL_CQ_FOLD='0', VSL_TAIL_ROWS='0', VSL_LOSS_INLINE='0', VSL_ATTN_BWD_256='fused', VSL_ATTN_FWD_256='block')
+    e = dict(os.environ, VSL_QKV_FUSED='0', VSL_HEADS_FUSED='0', VSL_QUERY_FUSED='0', VSL_CQ_FOLD='0', VSL_LOSS_INLINE='0')
     r = subprocess.run([sys.executable, '-m', 'pytest', '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider', 'tests/test_hip_training.py', 'tests/test_hip_parity.py',
                         'tests/test_fused_loss.py'],
                        cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)

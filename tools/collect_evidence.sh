@@ -31,7 +31,7 @@ bash tools/bench_shapes.sh > $O/${TAG}_bench_shapes.txt 2>/dev/null
 # round 6: the step's critical-path ledger from HIP events (no profiler attached), batch lengths off the 32-row tile, the row-tile query launches as A/B
 python tools/critical_path.py --out $O/${TAG}_critical_path.txt > /dev/null 2> $O/critical_path.err
 python tools/dbg/r06_ragged.py 128 117 100 96 > $O/${TAG}_ragged.txt 2>/dev/null
-bash tools/dbg/r05_ab_env.sh 3 "VSL_QUERY_FUSED=0" "VSL_LOSS_INLINE=0" "VSL_TAIL_ROWS=0" "VSL_FUSED_TAIL=1" - > $O/${TAG}_ab_switches.txt 2>&1
+bash tools/dbg/r05_ab_env.sh 3 "VSL_QUERY_FUSED=0" "VSL_LOSS_INLINE=0" "VSL_CQ_FOLD=0" "VSL_FUSED_TAIL=1" - > $O/${TAG}_ab_switches.txt 2>&1
 VSL_MULTI_STREAM=0 python tools/critical_path.py --out $O/${TAG}_single_stream_ledger.txt > /dev/null 2>&1
 VSL_MULTI_STREAM=0 python tools/dbg/r06_attn_long.py 2>/dev/null | grep drop > $O/${TAG}_attn_long.txt
 # per-kernel stats of the other BASELINE configs (configs[0]: the rnn head, with a one-step timeline; configs[2..4]: per-GPU shapes)

@@ -619,8 +619,7 @@ void enc_fwd(Ctx& c, const EncP& P, const EncPk& K, const EncWs& w, const float*
         }
         LAUNCH("convblock_fwd", launch_convblock_fwd(a, c.s));
     }
-    static const bool fwd256_block = getenv("VSL_ATTN_FWD_256") && !strcmp(getenv("VSL_ATTN_FWD_256"), "block");
-    if (H == 8 && (L <= 128 || (L <= 256 && (fwd256_block || ht)))) {      // longer sequences: K / V staged in LDS per 64 queries (k_attn_fwd + k_attn_out_fwd)
+    if (H == 8 && L <= 128) {      // longer sequences: K / V staged in LDS per 64 queries (k_attn_fwd + k_attn_out_fwd)
         AttnBlockArgs ab;
         memset(&ab, 0, sizeof ab);
         if (!c.dry) {
@@ -1306,9 +1305,8 @@ void run_backward(Ctx& c) {
     memset(&pw_video, 0, sizeof pw_video);
     // The step's LAST weight-gradient batch (VisualProjection + the video pass' four pointwise gradients, sample-local query path) starts into an
     // empty chip: chunk rows that make it whole rounds of one-workgroup-per-CU chunks (Dv = 1024: 12 blocks x 32 chunks = 1.5 rounds -> 400 rows,
-    // 252 workgroups; profiles/r06_notes.md section 8).  VSL_TAIL_ROWS=0: 256 rows as everywhere else.
-    static const bool tail_rows_on = !(getenv("VSL_TAIL_ROWS") && getenv("VSL_TAIL_ROWS")[0] == '0');
-    const int tail_rows = query_fused(c, false) && tail_rows_on ? wgrad_rows_whole_rounds(R, (cf.video_feature_dim + 127) / 128 + 4, c.h->cus) : WG_ROWS;
+    // 252 workgroups; profiles/r06_notes.md section 8: -0.6 % against 256-row chunks).
+    const int tail_rows = query_fused(c, false) ? wgrad_rows_whole_rounds(R, (cf.video_feature_dim + 127) / 128 + 4, c.h->cus) : WG_ROWS;
     c.pw_rows = tail_rows == WG_ROWS ? 0 : tail_rows;
     enc_bwd(c, P.fe, K.fe, p.ve, c.dry ? nullptr : c.W(p.dC), nullptr, p.dvf, c.dry ? nullptr : io->v_mask, B, 0, sw, &pw_video);
     c.pw_rows = 0;

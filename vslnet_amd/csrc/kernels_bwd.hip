@@ -791,35 +791,26 @@ __global__ __launch_bounds__(1024) void k_attn_bwd_long(const float* __restrict_
         *reinterpret_cast<float4*>(dV + off) = make_float4(dv[0], dv[1], dv[2], dv[3]);
     }
 }
-static bool attn_bwd_256_as_block() {
-    static const bool on = !(getenv("VSL_ATTN_BWD_256") && !strcmp(getenv("VSL_ATTN_BWD_256"), "fused"));
-    return on;
-}
 int attn_bwd_dq_slabs(int L) { const int Lp = (L + 15) & ~15; return Lp <= 256 ? 1 : (Lp + ABL_KB - 1) / ABL_KB; }
 void launch_attn_bwd(const float* Q, const float* K, const float* V, const float* att, const float* dr, const float* lse,
                      const float* mask, float* dQ, float* dK, float* dV, int B, int L, int H, int b_off, Drop d2,
                      Drop d3, hipStream_t s) {
     const int Lp = (L + 15) & ~15;
-    if (Lp <= 256) {
-        static size_t ok128 = 0, ok256 = 0;
-        if (Lp <= 128) {
-            ensure_dynamic_lds((const void*)k_attn_bwd_fused<128>, ab_lds<128>(), ok128, "k_attn_bwd_fused<128>");
-            VSL_LAUNCH(k_attn_bwd_fused<128>, dim3(H, B), dim3(1024), ab_lds<128>(), s, Q, K, V, att, dr, lse, mask, dQ, dK, dV, L, H,
-                               b_off, d2, d3);
-        } else if (attn_bwd_256_as_block()) {
-            // 128 < L <= 256 as ONE 256-key block of the L > 256 kernel (S and dP on the bf16 pipe, Q / dA streamed in passes of 64), element hashes
-            static size_t okb = 0;
-            ensure_dynamic_lds((const void*)k_attn_bwd_long<false>, abl_lds(), okb, "k_attn_bwd_long<false>");
-            VSL_LAUNCH(k_attn_bwd_long<false>, dim3(1, H, B), dim3(1024), abl_lds(), s, Q, K, V, att, dr, lse, mask, dQ, dK, dV,
-                       L, H, b_off, (size_t)B * L * D, d2, d3);
-            return;
-        } else {
-            ensure_dynamic_lds((const void*)k_attn_bwd_fused<256>, ab_lds<256>(), ok256, "k_attn_bwd_fused<256>");
-            VSL_LAUNCH(k_attn_bwd_fused<256>, dim3(H, B), dim3(1024), ab_lds<256>(), s, Q, K, V, att, dr, lse, mask, dQ, dK, dV, L, H,
-                               b_off, d2, d3);
-        }
+    if (Lp <= 128) {
+        static size_t ok128 = 0;
+        ensure_dynamic_lds((const void*)k_attn_bwd_fused<128>, ab_lds<128>(), ok128, "k_attn_bwd_fused<128>");
+        VSL_LAUNCH(k_attn_bwd_fused<128>, dim3(H, B), dim3(1024), ab_lds<128>(), s, Q, K, V, att, dr, lse, mask, dQ, dK, dV, L, H, b_off, d2, d3);
         static int left = 3;
         if (dbg_budget("attn_bwd") && L > 64) dbg_report("attn_bwd_fused: stage-issue | landed+sync | pass-0 phase1 | sync | phase2 | sync | pass 1 + final", 8, s, left);
+        return;
+    }
+    if (Lp <= 256) {
+        // 128 < L <= 256 as ONE 256-key block of the L > 256 kernel (S and dP on the bf16 pipe, Q / dA streamed in passes of 64) with the element
+        // hashes of the L <= 256 forward.  (k_attn_bwd_fused<256>, 152 KB of LDS, served these lengths until round 6: +0.8 % on configs[2] / [3].)
+        static size_t okb = 0;
+        ensure_dynamic_lds((const void*)k_attn_bwd_long<false>, abl_lds(), okb, "k_attn_bwd_long<false>");
+        VSL_LAUNCH(k_attn_bwd_long<false>, dim3(1, H, B), dim3(1024), abl_lds(), s, Q, K, V, att, dr, lse, mask, dQ, dK, dV,
+                   L, H, b_off, (size_t)B * L * D, d2, d3);
         return;
     }
     // L > 256: one pass over S / dP per key block of 256; dQ arrives as attn_bwd_dq_slabs(L) partial slabs (k_qkv_bwd adds them)

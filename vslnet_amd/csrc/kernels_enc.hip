@@ -1683,18 +1683,16 @@ __global__ __launch_bounds__(1024 / QB, QB) void k_attn_block_fwd(AttnBlockArgs 
     }
 }
 void launch_attn_block_fwd(const AttnBlockArgs& a, int B, hipStream_t s) {
-    // 16 waves (wave = head x 16-query block) up to L = 128, 8 waves (wave = head, two query blocks) beyond: measured ms/step 8 / 16 waves
-    // at cfg2 (L = 128) 1.030 / 1.023, at cfg4 (L = 256) 1.110 / 1.112.
-    const bool w16 = a.L <= 128;
+    // L <= 128 only: 16 waves (wave = head x 16-query block).  Longer sequences take k_attn_fwd + k_attn_out_fwd (kernels_fwd.hip); the 8-wave
+    // instantiation that served 128 < L <= 256 until round 6 is gone (-0.6 % on configs[2] / [3] without it: profiles/r06_notes.md section 9).
     const dim3 grid((a.L + TILE_M - 1) / TILE_M, B);
     const size_t shm = (size_t)((a.L + 15) & ~15) * sizeof(float);
-    if (w16 && a.head_tail) {
+    if (a.head_tail) {
         const size_t shm_t = shm + (size_t)2 * (TILE_M * HEAD_LD + TILE_M * LDP) * sizeof(float);
         static size_t ok = 0;
         ensure_dynamic_lds((const void*)k_attn_block_fwd<1, true>, shm_t, ok, "k_attn_block_fwd");
         VSL_LAUNCH((k_attn_block_fwd<1, true>), grid, dim3(1024), shm_t, s, a);
-    } else if (w16) VSL_LAUNCH(k_attn_block_fwd<1>, grid, dim3(1024), shm, s, a);
-    else VSL_LAUNCH(k_attn_block_fwd<2>, grid, dim3(512), shm, s, a);
+    } else VSL_LAUNCH(k_attn_block_fwd<1>, grid, dim3(1024), shm, s, a);
     static int left = 3;
     if (edbg_on() && B > 16) edbg_report("attn_block_fwd", 7, s, left);
 }

@@ -370,9 +370,8 @@ void launch_wgrad(const WgradBatch& wb0, hipStream_t s) {
     // A batch that mixes the two fp32 kinds is ONE launch of the dropout instantiation: the jobs without dropout ride in it with a neutral mask
     // (threshold 0, scale 1: every hash keeps, x 1.0 is exact) instead of a launch of their own -- one boundary less on the step's tail, where
     // the video pass' pointwise gradients and the VisualProjection gradient are the last two launches in front of the final reduction
-    // (same box, four pairs: 0.8722 -> 0.8682 ms, profiles/r06_raw/q16_ab.txt).  VSL_WG_MERGE=0: kind by kind, as before.
-    static const bool merge = !(getenv("VSL_WG_MERGE") && getenv("VSL_WG_MERGE")[0] == '0');
-    if (merge) {
+    // (same box, four pairs: 0.8722 -> 0.8682 ms, profiles/r06_raw/q16_ab.txt; at the end of the round, with the batch in whole rounds: 0.8434 against 0.8712).
+    {
         bool any1 = false, only01 = true;
         for (int i = 0; i < wb.n; ++i) { any1 = any1 || kind(wb.j[i]) == 1; only01 = only01 && kind(wb.j[i]) < 2; }
         if (any1 && only01) {
